@@ -1,0 +1,125 @@
+"""Seeded synthetic checkpoints in the *source* parameter layout.
+
+No real checkpoints exist in the build or bench environment (no network), so
+benchmarks and parity fixtures use random weights of the exact architecture.
+The dict keys follow the source checkpoints the reference exporters read
+(FunASR `SenseVoiceSmall` state-dict names: SenseVoice/Export_SenseVoice.py:
+130-132,172-183,211-220; HF `WhisperForConditionalGeneration` names:
+Whisper/Export_Whisper.py:376-420,527-550), so the same converter
+(`arena.py`) would ingest a real state dict unchanged.
+
+Initialisation is fan-in scaled (std = 1/sqrt(fan_in)) so that activations are
+O(1) and the soft-max / LayerNorm paths are numerically exercised; LayerNorm
+affines are perturbed around (1, 0).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .config import SenseVoiceConfig, WhisperConfig
+
+
+def _lin(rng, out_f, in_f, bias=True, gain=1.0):
+    w = rng.standard_normal((out_f, in_f), dtype=np.float32) * np.float32(gain / np.sqrt(in_f))
+    b = rng.standard_normal((out_f,), dtype=np.float32) * np.float32(0.1) if bias else None
+    return w, b
+
+
+def _ln(rng, n):
+    g = (1.0 + 0.1 * rng.standard_normal((n,), dtype=np.float32)).astype(np.float32)
+    b = (0.1 * rng.standard_normal((n,), dtype=np.float32)).astype(np.float32)
+    return g, b
+
+
+def synth_sensevoice_checkpoint(cfg: SenseVoiceConfig, seed: int = 0) -> dict:
+    """Random SenseVoiceSmall-shaped checkpoint (raw, before any export-time fold)."""
+    rng = np.random.default_rng(seed)
+    ck: dict[str, np.ndarray] = {}
+    d, dff, feat = cfg.d_model, cfg.d_ffn, cfg.feat_dim
+
+    def block(prefix, in_size):
+        ck[prefix + "norm1.weight"], ck[prefix + "norm1.bias"] = _ln(rng, in_size)
+        w, b = _lin(rng, 3 * d, in_size)
+        ck[prefix + "self_attn.linear_q_k_v.weight"], ck[prefix + "self_attn.linear_q_k_v.bias"] = w, b
+        ck[prefix + "self_attn.fsmn_block.weight"] = (
+            rng.standard_normal((d, 1, cfg.fsmn_kernel), dtype=np.float32) * np.float32(0.2))
+        w, b = _lin(rng, d, d)
+        ck[prefix + "self_attn.linear_out.weight"], ck[prefix + "self_attn.linear_out.bias"] = w, b
+        ck[prefix + "norm2.weight"], ck[prefix + "norm2.bias"] = _ln(rng, d)
+        w, b = _lin(rng, dff, d, gain=1.4)
+        ck[prefix + "feed_forward.w_1.weight"], ck[prefix + "feed_forward.w_1.bias"] = w, b
+        w, b = _lin(rng, d, dff)
+        ck[prefix + "feed_forward.w_2.weight"], ck[prefix + "feed_forward.w_2.bias"] = w, b
+
+    for i in range(cfg.n_enc0):
+        block(f"encoder.encoders0.{i}.", feat)
+    for i in range(cfg.n_enc):
+        block(f"encoder.encoders.{i}.", d)
+    for i in range(cfg.n_tp):
+        block(f"encoder.tp_encoders.{i}.", d)
+    ck["encoder.after_norm.weight"], ck["encoder.after_norm.bias"] = _ln(rng, d)
+    ck["encoder.tp_norm.weight"], ck["encoder.tp_norm.bias"] = _ln(rng, d)
+    # prompt embedding table; the exporter multiplies it by sqrt(d_model) (Export_SenseVoice.py:361-362)
+    ck["embed.weight"] = rng.standard_normal((cfg.embed_rows, feat), dtype=np.float32) * np.float32(0.05)
+    w, b = _lin(rng, cfg.vocab, d)
+    ck["ctc.ctc_lo.weight"], ck["ctc.ctc_lo.bias"] = w, b
+    # Frontend CMVN (FunASR `WavFrontend.cmvn`): additive means, multiplicative inverse-std.
+    # Plausible magnitudes for int16-range Kaldi log-mel (ln power ~ 15..25).
+    ck["frontend.cmvn_means"] = (-18.0 + rng.standard_normal((feat,), dtype=np.float32)).astype(np.float32)
+    ck["frontend.cmvn_vars"] = (0.02 * (1.0 + 0.1 * rng.standard_normal((feat,), dtype=np.float32))).astype(np.float32)
+    return ck
+
+
+def synth_whisper_checkpoint(cfg: WhisperConfig, seed: int = 0) -> dict:
+    """Random Whisper-shaped checkpoint with HF `model.*` / `proj_out` key names."""
+    rng = np.random.default_rng(seed)
+    ck: dict[str, np.ndarray] = {}
+    d, dff = cfg.d_model, cfg.d_ffn
+
+    def attn(prefix):
+        for name, has_bias in (("q_proj", True), ("k_proj", False), ("v_proj", True), ("out_proj", True)):
+            w, b = _lin(rng, d, d, bias=has_bias)
+            ck[f"{prefix}{name}.weight"] = w
+            if has_bias:
+                ck[f"{prefix}{name}.bias"] = b
+
+    ck["model.encoder.conv1.weight"] = rng.standard_normal((d, cfg.n_mels, 3), dtype=np.float32) * np.float32(1.0 / np.sqrt(3 * cfg.n_mels))
+    ck["model.encoder.conv1.bias"] = rng.standard_normal((d,), dtype=np.float32) * np.float32(0.1)
+    ck["model.encoder.conv2.weight"] = rng.standard_normal((d, d, 3), dtype=np.float32) * np.float32(1.0 / np.sqrt(3 * d))
+    ck["model.encoder.conv2.bias"] = rng.standard_normal((d,), dtype=np.float32) * np.float32(0.1)
+    ck["model.encoder.embed_positions.weight"] = rng.standard_normal((cfg.max_source_positions, d), dtype=np.float32) * np.float32(0.1)
+    for i in range(cfg.n_enc_layers):
+        p = f"model.encoder.layers.{i}."
+        ck[p + "self_attn_layer_norm.weight"], ck[p + "self_attn_layer_norm.bias"] = _ln(rng, d)
+        attn(p + "self_attn.")
+        ck[p + "final_layer_norm.weight"], ck[p + "final_layer_norm.bias"] = _ln(rng, d)
+        ck[p + "fc1.weight"], ck[p + "fc1.bias"] = _lin(rng, dff, d, gain=1.4)
+        ck[p + "fc2.weight"], ck[p + "fc2.bias"] = _lin(rng, d, dff)
+    ck["model.encoder.layer_norm.weight"], ck["model.encoder.layer_norm.bias"] = _ln(rng, d)
+
+    ck["model.decoder.embed_tokens.weight"] = rng.standard_normal((cfg.vocab, d), dtype=np.float32) * np.float32(1.0 / np.sqrt(d))
+    ck["model.decoder.embed_positions.weight"] = rng.standard_normal((cfg.max_target_positions, d), dtype=np.float32) * np.float32(0.05)
+    for i in range(cfg.n_dec_layers):
+        p = f"model.decoder.layers.{i}."
+        ck[p + "self_attn_layer_norm.weight"], ck[p + "self_attn_layer_norm.bias"] = _ln(rng, d)
+        attn(p + "self_attn.")
+        ck[p + "encoder_attn_layer_norm.weight"], ck[p + "encoder_attn_layer_norm.bias"] = _ln(rng, d)
+        attn(p + "encoder_attn.")
+        ck[p + "final_layer_norm.weight"], ck[p + "final_layer_norm.bias"] = _ln(rng, d)
+        ck[p + "fc1.weight"], ck[p + "fc1.bias"] = _lin(rng, dff, d, gain=1.4)
+        ck[p + "fc2.weight"], ck[p + "fc2.bias"] = _lin(rng, d, dff)
+    ck["model.decoder.layer_norm.weight"], ck["model.decoder.layer_norm.bias"] = _ln(rng, d)
+    # proj_out is tied to embed_tokens in HF Whisper (no separate tensor).
+    return ck
+
+
+def synth_audio(kind: str, batch: int, n_samples: int, seed: int = 1234) -> np.ndarray:
+    """Synthetic chunks, SURVEY.md section 8(d): int16-range values for the Kaldi
+    front-ends ('kaldi'), [-1, 1] floats for Whisper/Qwen ('unit'). Shape (B, 1, L) f32."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((batch, 1, n_samples), dtype=np.float32)
+    if kind == "kaldi":
+        return np.round(np.clip(x * np.float32(3000.0), -32768, 32767)).astype(np.float32)
+    if kind == "unit":
+        return np.clip(x * np.float32(0.05), -1.0, 1.0).astype(np.float32)
+    raise ValueError(kind)

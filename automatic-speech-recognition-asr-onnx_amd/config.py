@@ -1,0 +1,121 @@
+"""Model geometry for the in-scope families.
+
+Every number here is read from a checkpoint by the reference exporters; the
+defaults are the public-checkpoint values quoted in SURVEY.md section 8
+(SenseVoiceSmall: SenseVoice/Export_SenseVoice.py:20-32,165,178-183;
+Whisper-large-v3: Whisper/Export_Whisper.py:678-683,721).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, asdict
+
+
+@dataclass(frozen=True)
+class SenseVoiceConfig:
+    sample_rate: int = 16000
+    n_mels: int = 80
+    nfft: int = 512              # Kaldi pads the 400-sample frame to 512 before the DFT
+    win_length: int = 400
+    hop_length: int = 160
+    pre_emphasis: float = 0.97
+    lfr_m: int = 7
+    lfr_n: int = 6
+    d_model: int = 512
+    n_heads: int = 4
+    d_head: int = 128
+    d_ffn: int = 2048
+    n_enc0: int = 1              # encoders0: first block, 560 -> 512, no residual
+    n_enc: int = 49              # encoders
+    n_tp: int = 20               # tp_encoders (after after_norm)
+    fsmn_kernel: int = 11
+    vocab: int = 25055
+    embed_rows: int = 16         # prompt embedding table rows (ids 0..15 used: 14 is the max)
+    blank_id: int = 0
+    use_emo: bool = True
+    max_audio_len: int = 480000
+    language_prompt_token_ids: tuple = (0, 3, 4, 7, 11, 12, 13)  # Export_SenseVoice.py:37-49
+
+    @property
+    def feat_dim(self) -> int:
+        return self.n_mels * self.lfr_m
+
+    @property
+    def n_blocks(self) -> int:
+        return self.n_enc0 + self.n_enc + self.n_tp
+
+    @property
+    def n_prompt(self) -> int:
+        return 1 + (3 if self.use_emo else 2)
+
+    def n_frames(self, audio_len: int) -> int:
+        """Kaldi snip_edges framing (Export_SenseVoice.py:53)."""
+        return (audio_len - self.win_length) // self.hop_length + 1
+
+    def n_lfr(self, audio_len: int) -> int:
+        return (self.n_frames(audio_len) + self.lfr_n - 1) // self.lfr_n
+
+    def seq_len(self, audio_len: int) -> int:
+        return self.n_lfr(audio_len) + self.n_prompt
+
+    def to_dict(self):
+        return asdict(self)
+
+
+def sensevoice_small() -> SenseVoiceConfig:
+    return SenseVoiceConfig()
+
+
+def sensevoice_tiny() -> SenseVoiceConfig:
+    """Reduced geometry for fast CPU goldens (same head_dim / feature width)."""
+    return SenseVoiceConfig(d_model=256, n_heads=2, d_head=128, d_ffn=512,
+                            n_enc0=1, n_enc=2, n_tp=1, vocab=1000)
+
+
+@dataclass(frozen=True)
+class WhisperConfig:
+    sample_rate: int = 16000
+    n_mels: int = 128
+    nfft: int = 400
+    hop_length: int = 160
+    d_model: int = 1280
+    n_heads: int = 20
+    d_head: int = 64
+    d_ffn: int = 5120
+    n_enc_layers: int = 32
+    n_dec_layers: int = 32
+    vocab: int = 51866
+    max_source_positions: int = 1500
+    max_target_positions: int = 448
+    max_audio_len: int = 480000
+    # special ids of large-v3 (generation_config.json); only used by the host loop
+    sot_id: int = 50258
+    eot_id: int = 50257
+    transcribe_id: int = 50360
+    translate_id: int = 50359
+    no_timestamps_id: int = 50364
+    no_speech_id: int = 50363
+    first_language_id: int = 50259
+    n_languages: int = 100
+
+    def n_frames(self, audio_len: int) -> int:
+        return audio_len // self.hop_length
+
+    def n_enc_pos(self, audio_len: int) -> int:
+        return (self.n_frames(audio_len) + 1) // 2
+
+    def to_dict(self):
+        return asdict(self)
+
+
+def whisper_large_v3() -> WhisperConfig:
+    return WhisperConfig()
+
+
+def whisper_tiny_test() -> WhisperConfig:
+    """Reduced geometry (same head_dim=64) for fast CPU goldens."""
+    return WhisperConfig(n_mels=80, d_model=128, n_heads=2, d_head=64, d_ffn=256,
+                         n_enc_layers=2, n_dec_layers=2, vocab=600,
+                         max_source_positions=1500, max_target_positions=64,
+                         sot_id=500, eot_id=499, transcribe_id=560, translate_id=559,
+                         no_timestamps_id=564, no_speech_id=563, first_language_id=501,
+                         n_languages=58)

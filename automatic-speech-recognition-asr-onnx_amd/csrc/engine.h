@@ -1,0 +1,108 @@
+// Session plumbing shared by the model families: weight arena, grow-only HBM workspace,
+// HIP-event profiler, debug taps.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+// ---- weight arena (layout written by arena.py) -----------------------------------------
+//   header  : "ASRARENA" | u32 version | u32 n_tensors | u64 data_offset | u64 total_bytes
+//   records : n_tensors x 128 B  { char name[80]; u32 dtype; u32 ndim; i64 shape[4]; u64 offset }
+//   data    : tensors, each 256-byte aligned, offsets relative to the start of the arena
+enum { ARENA_F32 = 0, ARENA_BF16 = 1, ARENA_I32 = 2, ARENA_F16 = 3 };
+
+struct TensorRef {
+  void* ptr = nullptr;
+  int dtype = 0;
+  int ndim = 0;
+  int64_t shape[4] = {0, 0, 0, 0};
+  int64_t numel() const {
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    return n;
+  }
+};
+
+struct Arena {
+  unsigned char* base = nullptr;   // device
+  size_t bytes = 0;
+  bool owned = false;
+  std::map<std::string, TensorRef> tensors;
+
+  void load(const void* src, size_t nbytes, int mem, hipStream_t s);
+  void release();
+  const TensorRef& get(const std::string& name) const;
+  const TensorRef& get(const std::string& name, int dtype, std::initializer_list<int64_t> shape) const;
+  bool has(const std::string& name) const { return tensors.count(name) != 0; }
+};
+
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  // grow-only; new memory is zero-filled so padded rows/columns are finite
+  void reserve(size_t bytes, hipStream_t s);
+  void release();
+  template <typename T> T* as() const { return reinterpret_cast<T*>(ptr); }
+};
+
+struct Profiler {
+  bool enabled = false;
+  std::vector<std::string> names;
+  std::vector<double> total_ms;
+  std::vector<int64_t> launches;
+  struct Pending { int cls; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> pool;
+
+  int cls(const char* name);
+  void begin(int c, hipStream_t s);
+  void end(hipStream_t s);
+  void collect();          // after the stream is synchronised
+  void reset();
+  void release();
+  hipEvent_t get_event();
+};
+
+struct ProfScope {
+  Profiler& p; hipStream_t s; bool on;
+  ProfScope(Profiler& p_, const char* name, hipStream_t s_) : p(p_), s(s_), on(p_.enabled) { if (on) p.begin(p.cls(name), s); }
+  ~ProfScope() { if (on) p.end(s); }
+};
+
+struct Tap {
+  DeviceBuffer buf;
+  int64_t rows = 0, cols = 0;
+  int elt = 4;
+};
+
+struct asr_session {
+  int kind = 0;               // 1 = sensevoice, 2 = whisper
+  int device = 0;
+  int precision = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  Arena arena;
+  Profiler prof;
+  bool taps_enabled = false;
+  std::map<std::string, Tap> taps;
+  virtual ~asr_session() {}
+  void save_tap(const char* name, const void* src, int64_t rows, int64_t cols, int64_t ld_src, int elt);
+};
+
+template <typename F>
+int asr_guard(F&& f) {
+  try {
+    f();
+    return ASR_OK;
+  } catch (const AsrError& e) {
+    asr_set_error(e.msg);
+    return e.code;
+  } catch (const std::exception& e) {
+    asr_set_error(std::string("internal error: ") + e.what());
+    return ASR_ERR_INVALID;
+  }
+}
+
+void asr_require_device(int device_id);

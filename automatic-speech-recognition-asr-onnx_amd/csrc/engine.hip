@@ -1,0 +1,191 @@
+// Session plumbing: error channel, arena parsing, workspace, profiler, taps.
+#include "engine.h"
+
+#include <cstring>
+
+static thread_local std::string g_last_error;
+void asr_set_error(const std::string& msg) { g_last_error = msg; }
+const std::string& asr_get_error() { return g_last_error; }
+
+void asr_require_device(int device_id) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    throw AsrError{ASR_ERR_NO_DEVICE, "no HIP device visible: the MI355X engine has no CPU fallback"};
+  if (device_id < 0 || device_id >= n)
+    throw AsrError{ASR_ERR_INVALID, "device_id " + std::to_string(device_id) + " out of range (" + std::to_string(n) + " devices)"};
+  HIP_CHECK(hipSetDevice(device_id));
+}
+
+// ---------------------------------------------------------------------------------------- Arena
+namespace {
+struct ArenaHeader {
+  char magic[8];
+  uint32_t version, n_tensors;
+  uint64_t data_offset, total_bytes;
+};
+struct ArenaRecord {
+  char name[80];
+  uint32_t dtype, ndim;
+  int64_t shape[4];
+  uint64_t offset;
+};
+static_assert(sizeof(ArenaHeader) == 32, "arena header layout");
+static_assert(sizeof(ArenaRecord) == 128, "arena record layout");
+}  // namespace
+
+void Arena::load(const void* src, size_t nbytes, int mem, hipStream_t s) {
+  ASR_REQUIRE(src && nbytes >= sizeof(ArenaHeader), "arena: empty");
+  ArenaHeader hdr;
+  if (mem == 0) {
+    memcpy(&hdr, src, sizeof(hdr));
+  } else {
+    HIP_CHECK(hipMemcpy(&hdr, src, sizeof(hdr), hipMemcpyDeviceToHost));
+  }
+  ASR_REQUIRE(memcmp(hdr.magic, "ASRARENA", 8) == 0, "arena: bad magic");
+  ASR_REQUIRE(hdr.version == 1, "arena: unsupported version %u", hdr.version);
+  ASR_REQUIRE(hdr.total_bytes == nbytes, "arena: size mismatch (header %llu, given %llu)",
+              (unsigned long long)hdr.total_bytes, (unsigned long long)nbytes);
+  const size_t table = (size_t)hdr.n_tensors * sizeof(ArenaRecord);
+  ASR_REQUIRE(sizeof(hdr) + table <= hdr.data_offset && hdr.data_offset <= nbytes, "arena: corrupt manifest");
+  std::vector<ArenaRecord> recs(hdr.n_tensors);
+  if (mem == 0) {
+    memcpy(recs.data(), (const unsigned char*)src + sizeof(hdr), table);
+    HIP_CHECK(hipMalloc((void**)&base, nbytes));
+    owned = true;
+    HIP_CHECK(hipMemcpyAsync(base, src, nbytes, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  } else {
+    HIP_CHECK(hipMemcpy(recs.data(), (const unsigned char*)src + sizeof(hdr), table, hipMemcpyDeviceToHost));
+    base = (unsigned char*)const_cast<void*>(src);
+    owned = false;
+  }
+  bytes = nbytes;
+  static const int elt[4] = {4, 2, 4, 2};
+  for (const auto& r : recs) {
+    ASR_REQUIRE(r.dtype < 4 && r.ndim <= 4, "arena: bad record");
+    TensorRef t;
+    t.dtype = (int)r.dtype;
+    t.ndim = (int)r.ndim;
+    for (int i = 0; i < 4; ++i) t.shape[i] = r.shape[i];
+    ASR_REQUIRE(r.offset % 256 == 0 && r.offset + (uint64_t)t.numel() * elt[r.dtype] <= nbytes, "arena: tensor out of range");
+    t.ptr = base + r.offset;
+    char nm[81];
+    memcpy(nm, r.name, 80);
+    nm[80] = 0;
+    tensors[nm] = t;
+  }
+}
+
+void Arena::release() {
+  if (owned && base) (void)hipFree(base);
+  base = nullptr;
+  tensors.clear();
+}
+
+const TensorRef& Arena::get(const std::string& name) const {
+  auto it = tensors.find(name);
+  if (it == tensors.end()) throw AsrError{ASR_ERR_NOT_FOUND, "arena: tensor '" + name + "' missing"};
+  return it->second;
+}
+
+const TensorRef& Arena::get(const std::string& name, int dtype, std::initializer_list<int64_t> shape) const {
+  const TensorRef& t = get(name);
+  bool ok = t.dtype == dtype && t.ndim == (int)shape.size();
+  int i = 0;
+  for (int64_t d : shape) { if (ok && t.shape[i] != d) ok = false; ++i; }
+  if (!ok) {
+    std::string want, got;
+    for (int64_t d : shape) want += std::to_string(d) + ",";
+    for (int j = 0; j < t.ndim; ++j) got += std::to_string(t.shape[j]) + ",";
+    throw AsrError{ASR_ERR_INVALID, "arena: tensor '" + name + "' has dtype " + std::to_string(t.dtype) + " shape (" + got +
+                                        "), expected dtype " + std::to_string(dtype) + " shape (" + want + ")"};
+  }
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------- DeviceBuffer
+void DeviceBuffer::reserve(size_t bytes, hipStream_t s) {
+  if (bytes <= cap) return;
+  if (ptr) {
+    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipFree(ptr));
+    ptr = nullptr;
+    cap = 0;
+  }
+  const size_t want = (bytes + 255) & ~(size_t)255;
+  HIP_CHECK(hipMalloc(&ptr, want));
+  HIP_CHECK(hipMemsetAsync(ptr, 0, want, s));
+  cap = want;
+}
+
+void DeviceBuffer::release() {
+  if (ptr) (void)hipFree(ptr);
+  ptr = nullptr;
+  cap = 0;
+}
+
+// ---------------------------------------------------------------------------------------- Profiler
+int Profiler::cls(const char* name) {
+  for (size_t i = 0; i < names.size(); ++i)
+    if (names[i] == name) return (int)i;
+  names.push_back(name);
+  total_ms.push_back(0.0);
+  launches.push_back(0);
+  return (int)names.size() - 1;
+}
+
+hipEvent_t Profiler::get_event() {
+  if (!pool.empty()) {
+    hipEvent_t e = pool.back();
+    pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  HIP_CHECK(hipEventCreate(&e));
+  return e;
+}
+
+void Profiler::begin(int c, hipStream_t s) {
+  Pending p{c, get_event(), get_event()};
+  HIP_CHECK(hipEventRecord(p.a, s));
+  pending.push_back(p);
+}
+
+void Profiler::end(hipStream_t s) { HIP_CHECK(hipEventRecord(pending.back().b, s)); }
+
+void Profiler::collect() {
+  for (auto& p : pending) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+    total_ms[p.cls] += ms;
+    launches[p.cls] += 1;
+    pool.push_back(p.a);
+    pool.push_back(p.b);
+  }
+  pending.clear();
+}
+
+void Profiler::reset() {
+  for (auto& v : total_ms) v = 0.0;
+  for (auto& v : launches) v = 0;
+}
+
+void Profiler::release() {
+  for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto e : pool) (void)hipEventDestroy(e);
+  pending.clear();
+  pool.clear();
+}
+
+// ---------------------------------------------------------------------------------------- taps
+void asr_session::save_tap(const char* name, const void* src, int64_t rows, int64_t cols, int64_t ld_src, int elt) {
+  if (!taps_enabled) return;
+  Tap& t = taps[name];
+  t.rows = rows;
+  t.cols = cols;
+  t.elt = elt;
+  t.buf.reserve((size_t)rows * cols * elt, stream);
+  HIP_CHECK(hipMemcpy2DAsync(t.buf.ptr, (size_t)cols * elt, src, (size_t)ld_src * elt, (size_t)cols * elt, (size_t)rows,
+                             hipMemcpyDeviceToDevice, stream));
+}

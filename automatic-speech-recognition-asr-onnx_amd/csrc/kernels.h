@@ -1,0 +1,86 @@
+// Non-GEMM kernels of the ASR hot path (gfx950).
+#pragma once
+#include "common.h"
+
+// Per-utterance geometry, built on the host for every run and uploaded with one copy.
+struct UttPlan {
+  int64_t audio_off;   // first sample in the packed audio buffer
+  int32_t n_samples;
+  int32_t n_frames;    // fbank / STFT frames
+  int32_t frame_off;   // first row in the packed mel buffer
+  int32_t n_lfr;       // low-frame-rate rows (SenseVoice/Paraformer) or encoder positions (Whisper)
+  int32_t T;           // encoder sequence length (n_lfr + prompts)
+  int32_t row_off;     // first row in the packed activation matrices (multiple of 16)
+  int32_t lang;        // language selector index
+  int32_t pad_;
+};
+
+// ---- Kaldi fbank: frames -> |DFT|^2 -> mel -> ln  (SenseVoice/Export_SenseVoice.py:139-160,275-278)
+// dft_packed / mel_packed are MFMA-fragment-ordered constant tables built by arena.py.
+struct FbankArgs {
+  const float* audio;          // packed samples
+  const UttPlan* plan;
+  const int32_t* blk_utt;      // per workgroup: utterance
+  const int32_t* blk_f0;       // per workgroup: first frame (multiple of 64)
+  const float* dft_packed;     // [n_bin_tiles][2][n_kchunks][64 lanes][4]
+  const float* mel_packed;     // [n_mel_tiles][n_bin_tiles][64 lanes][4]
+  float* mel_out;              // [total_frames][n_mels]
+  int n_bin_tiles;             // ceil((nfft/2+1)/16)
+  int n_kchunks;               // win_length / 16
+  int n_mel_tiles;             // n_mels / 16
+  int n_mels;
+  int win, hop;
+  float log_floor;             // FLT_EPSILON
+};
+void launch_fbank(const FbankArgs& a, int n_blocks, hipStream_t s);
+
+// ---- LFR stacking + CMVN + positions + prompt rows (Export_SenseVoice.py:280-287)
+struct LfrArgs {
+  const float* mel;            // [frames][n_mels]
+  const UttPlan* plan;
+  const int32_t* row_utt;      // per packed row: utterance (or -1)
+  const float* cmvn_means;     // [feat]
+  const float* cmvn_vars;      // [feat]
+  const float* speech_pos;     // [max_lfr][feat]
+  const float* language_embed; // [n_lang][feat]   (position-folded)
+  const float* system_embed;   // [n_prompt-1][feat]
+  float* out;                  // [rows][ld_out]
+  int ld_out, feat, n_mels, lfr_m, lfr_n, n_prompt, n_rows;
+};
+void launch_lfr_cmvn(const LfrArgs& a, hipStream_t s);
+
+// ---- LayerNorm over the last dim, one wave per row. gamma/beta may be null (affine folded away).
+// Output in operand dtype with zero fill of columns [D, ld_fill).
+template <typename OutT>
+void launch_layernorm(const float* x, int ld_x, int rows, int D, const float* gamma, const float* beta, float eps,
+                      OutT* out, int ld_out, int fill_to, hipStream_t s);
+
+// f32 -> f32 LayerNorm written to a separate f32 buffer (after_norm / tp_norm on the residual stream)
+void launch_layernorm_f32_inplace(float* x, int ld_x, int rows, int D, const float* gamma, const float* beta, float eps,
+                                  hipStream_t s);
+
+// ---- multi-head self-attention over packed ragged utterances (no mask inside an utterance).
+// q, k: [rows][ld] row-major; vt: [H*HD][ld_vt] (time-contiguous); ctx out: [rows][ld_ctx].
+// Scale is pre-folded into q and k (d^-1/4 each, Export_SenseVoice.py:210-216).
+struct AttnArgs {
+  const void* q; const void* k; int ld_qk;
+  const void* vt; int ld_vt;
+  void* ctx; int ld_ctx;
+  const UttPlan* plan;
+  const int32_t* qb_utt;       // per 64-row query block: utterance
+  const int32_t* qb_q0;        // per query block: first query row inside the utterance
+  int n_qblocks, n_heads;
+};
+void launch_attention_bf16_hd128(const AttnArgs& a, hipStream_t s);
+void launch_attention_bf16_hd64(const AttnArgs& a, hipStream_t s);
+void launch_attention_f32(const AttnArgs& a, int head_dim, hipStream_t s);
+
+// ---- FSMN memory: depth-wise conv (k taps, zero padded inside each utterance) over V + bias.
+// vt: [C][ld] time-contiguous, out_t: f32 [C][ld]  (Export_SenseVoice.py:217-220,240-244)
+template <typename InT>
+void launch_fsmn(const InT* vt, int ld, const float* w, const float* b, int C, int ktaps, const UttPlan* plan,
+                 const int32_t* row_utt, int n_rows, float* out_t, hipStream_t s);
+
+// ---- CTC greedy collapse, circular next-neighbour rule (Export_SenseVoice.py:290-296)
+void launch_ctc_collapse(const int32_t* frame_ids, const UttPlan* plan, int n_utts, int blank_id, int32_t* token_ids,
+                         int max_tokens, int32_t* num_id, hipStream_t s);

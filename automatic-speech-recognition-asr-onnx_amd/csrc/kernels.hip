@@ -1,0 +1,452 @@
+// Non-GEMM kernels of the ASR hot path for gfx950 (wave64, MFMA, LDS-staged tiles).
+#include "kernels.h"
+
+namespace {
+
+constexpr int HOP = 160, WIN = 400;          // 10 ms / 25 ms at 16 kHz: every in-scope front-end
+constexpr int FB_FRAMES = 64;                // frames per workgroup
+constexpr int FB_SPAN = (FB_FRAMES - 1) * HOP + WIN;           // 10480 samples
+constexpr int FB_AUDIO_LDS = FB_SPAN + FB_SPAN / HOP + 16;     // skewed: +1 float per hop => row stride 161
+constexpr int FB_PLD = 273;                  // power row stride (floats): 272 bins + 1 pad
+
+// ------------------------------------------------------------------------------------ fbank
+// One workgroup = 64 frames of one utterance. Stage the 10480-sample span in LDS once (frames
+// overlap 2.5x), then   spectrum = frames x foldedDFT^T   on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32),
+// power = re^2 + im^2 lane-locally (re / im fragments share the C layout), power tile -> LDS,
+// mel = power x melT on the same MFMA, then clamp + ln.  Frame m of the span starts at m*160, so the
+// A fragment (row = frame, k = sample) is a strided LDS read; the +1-per-hop skew makes the 16 rows
+// of a fragment hit 16 different banks.
+__global__ __launch_bounds__(256) void fbank_kernel(const FbankArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* aud = reinterpret_cast<float*>(smem);
+  float* pw = aud + FB_AUDIO_LDS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u = a.blk_utt[blockIdx.x], f0 = a.blk_f0[blockIdx.x];
+  const UttPlan up = a.plan[u];
+  const float* src = a.audio + up.audio_off;
+  const int s0 = f0 * HOP;
+  for (int i = tid; i < FB_SPAN; i += 256) {
+    const int s = s0 + i;
+    aud[i + i / HOP] = (s < up.n_samples) ? src[s] : 0.0f;
+  }
+  __syncthreads();
+
+  const int frow = lane & 15, fgrp = lane >> 4;
+  const float4* dft = reinterpret_cast<const float4*>(a.dft_packed);
+  for (int t = wave; t < a.n_bin_tiles; t += 4) {
+    f32x4_t re[4], im[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) { re[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; im[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    const float4* dre = dft + (size_t)(t * 2 + 0) * a.n_kchunks * 64 + lane;
+    const float4* dim = dft + (size_t)(t * 2 + 1) * a.n_kchunks * 64 + lane;
+    for (int kc = 0; kc < a.n_kchunks; ++kc) {
+      const float4 br = dre[kc * 64];
+      const float4 bi = dim[kc * 64];
+      const float brv[4] = {br.x, br.y, br.z, br.w};
+      const float biv[4] = {bi.x, bi.y, bi.z, bi.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = kc * 16 + j * 4 + fgrp;
+        const int koff = k + k / HOP;
+        float af[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) af[mt] = aud[(mt * 16 + frow) * (HOP + 1) + koff];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          re[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt], brv[j], re[mt], 0, 0, 0);
+          im[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt], biv[j], im[mt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        pw[(mt * 16 + fgrp * 4 + r) * FB_PLD + t * 16 + frow] = re[mt][r] * re[mt][r] + im[mt][r] * im[mt][r];
+  }
+  __syncthreads();
+
+  // mel: wave w owns frames [16w, 16w+16); all mel tiles
+  const float4* melp = reinterpret_cast<const float4*>(a.mel_packed);
+  for (int nt = 0; nt < a.n_mel_tiles; ++nt) {
+    f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < a.n_bin_tiles; ++kc) {
+      const float4 b4 = melp[(size_t)(nt * a.n_bin_tiles + kc) * 64 + lane];
+      const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float av = pw[(wave * 16 + frow) * FB_PLD + kc * 16 + j * 4 + fgrp];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = f0 + wave * 16 + fgrp * 4 + r;
+      if (f < up.n_frames)
+        a.mel_out[(size_t)(up.frame_off + f) * a.n_mels + nt * 16 + frow] = logf(fmaxf(acc[r], a.log_floor));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ LFR + CMVN
+__global__ void lfr_cmvn_kernel(const LfrArgs a) {
+  const int m = blockIdx.x;
+  float* o = a.out + (size_t)m * a.ld_out;
+  const int u = a.row_utt[m];
+  if (u < 0) {
+    for (int c = threadIdx.x; c < a.ld_out; c += blockDim.x) o[c] = 0.0f;
+    return;
+  }
+  const UttPlan up = a.plan[u];
+  const int t = m - up.row_off;
+  const int left = (a.lfr_m - 1) / 2;
+  for (int c = threadIdx.x; c < a.ld_out; c += blockDim.x) {
+    float v = 0.0f;
+    if (c < a.feat && t < up.T) {
+      if (t == 0) {
+        v = a.language_embed[(size_t)up.lang * a.feat + c];
+      } else if (t < a.n_prompt) {
+        v = a.system_embed[(size_t)(t - 1) * a.feat + c];
+      } else {
+        const int j = t - a.n_prompt;
+        int f = j * a.lfr_n + c / a.n_mels - left;
+        f = min(max(f, 0), up.n_frames - 1);
+        const float x = a.mel[(size_t)(up.frame_off + f) * a.n_mels + c % a.n_mels];
+        v = (x + a.cmvn_means[c]) * a.cmvn_vars[c];
+        v = v + a.speech_pos[(size_t)j * a.feat + c];
+      }
+    }
+    o[c] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------ LayerNorm
+template <typename OutT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ld_x, int rows, int D,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, OutT* out, int ld_out, int fill_to) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * ld_x;
+  float s = 0.0f;
+  for (int i = lane; i < D; i += 64) s += xr[i];
+  const float mean = wave_sum(s) / (float)D;
+  float v = 0.0f;
+  for (int i = lane; i < D; i += 64) { const float d = xr[i] - mean; v += d * d; }
+  const float var = wave_sum(v) / (float)D;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  OutT* o = out + (size_t)row * ld_out;
+  for (int i = lane; i < D; i += 64) {
+    float y = (xr[i] - mean) * rstd;
+    if (gamma) y = y * gamma[i] + beta[i];
+    Elem<OutT>::store(o + i, y);
+  }
+  for (int i = D + lane; i < fill_to; i += 64) Elem<OutT>::store(o + i, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------ attention (bf16, flash-style)
+// One workgroup = 64 query rows of one (utterance, head); wave w owns 16 of them. K and V^T chunks of
+// CHUNK keys are staged by LDS-DMA (global_load_lds_dwordx4) with the 16-byte-slot XOR swizzle on the
+// global source side. Scores are computed TRANSPOSED, S^T = K Q^T, so the C fragment puts one query per
+// lane column (lane & 15) and 4 consecutive keys per lane: the row soft-max is lane-local plus two
+// xor-shuffles across the four 16-lane groups, and the bf16-packed probabilities are directly the B
+// fragment of O^T = V^T P^T (no LDS round trip for P). O^T's C fragment again has one query per lane
+// column, so the online-softmax rescale is lane-local, and each lane ends with 4 consecutive d values
+// of its query row (one 8-byte store).
+template <int HD, int CHUNK>
+__global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a, int n_rows_alloc) {
+  constexpr int SLOTS = HD / 8;               // 16-byte slots per K row
+  constexpr int KROWB = HD * 2;               // bytes per K row
+  constexpr int K_RPI = 64 / SLOTS;           // K rows per LDS-DMA wave-instruction (1 KiB)
+  constexpr int K_NI = CHUNK / K_RPI;         // instructions per chunk
+  constexpr int VSLOTS = CHUNK / 8;           // 16-byte slots per V^T row
+  constexpr int VROWB = CHUNK * 2;
+  constexpr int V_RPI = 64 / VSLOTS;
+  constexpr int V_NI = HD / V_RPI;
+  static_assert(VSLOTS == 16, "V^T swizzle assumes 16 slots per row");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ks = smem;
+  unsigned char* Vs = smem + CHUNK * KROWB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fq = lane & 15, g = lane >> 4;
+  const int u = a.qb_utt[blockIdx.x], q0 = a.qb_q0[blockIdx.x], h = blockIdx.y;
+  const UttPlan up = a.plan[u];
+  const int T = up.T, row0 = up.row_off;
+  const bool active = (q0 + wave * 16) < T;   // wave-uniform
+  const int qrow = q0 + wave * 16 + fq;
+
+  bf16x8_t qf[HD / 32];
+  if (active) {
+    const bf16_t* qp = reinterpret_cast<const bf16_t*>(a.q) + (size_t)(row0 + qrow) * a.ld_qk + h * HD + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+  }
+  f32x4_t ot[HD / 16];
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; ++dt) ot[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.0f;
+
+  const bf16_t* kbase = reinterpret_cast<const bf16_t*>(a.k) + h * HD;
+  const bf16_t* vbase = reinterpret_cast<const bf16_t*>(a.vt) + (size_t)h * HD * a.ld_vt;
+
+  for (int kv0 = 0; kv0 < T; kv0 += CHUNK) {
+    __syncthreads();                          // all waves finished reading the previous chunk
+    for (int ii = wave; ii < K_NI; ii += 4) {
+      const int key = ii * K_RPI + lane / SLOTS;
+      const int sslot = (lane % SLOTS) ^ (key & (SLOTS - 1));
+      const int grow = min(row0 + kv0 + key, n_rows_alloc - 1);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(kbase + (size_t)grow * a.ld_qk + sslot * 8),
+          (__attribute__((address_space(3))) void*)(Ks + ii * 1024), 16, 0, 0);
+    }
+    for (int ii = wave; ii < V_NI; ii += 4) {
+      const int d = ii * V_RPI + lane / VSLOTS;
+      const int sslot = (lane % VSLOTS) ^ (d & 15);
+      const int gcol = min(row0 + kv0 + sslot * 8, a.ld_vt - 8);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(vbase + (size_t)d * a.ld_vt + gcol),
+          (__attribute__((address_space(3))) void*)(Vs + ii * 1024), 16, 0, 0);
+    }
+    __syncthreads();                          // chunk landed (the barrier drains the LDS-DMA queue)
+    if (!active) continue;
+    const int nsub = min(CHUNK, T - kv0);
+    for (int s = 0; s * 32 < nsub; ++s) {
+      f32x4_t st0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, st1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const int key0 = s * 32 + fq, key1 = key0 + 16;
+#pragma unroll
+      for (int ks = 0; ks < HD / 32; ++ks) {
+        const int c = ks * 4 + g;
+        const bf16x8_t kf0 = *reinterpret_cast<const bf16x8_t*>(Ks + key0 * KROWB + ((c ^ (key0 & (SLOTS - 1))) << 4));
+        const bf16x8_t kf1 = *reinterpret_cast<const bf16x8_t*>(Ks + key1 * KROWB + ((c ^ (key1 & (SLOTS - 1))) << 4));
+        st0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[ks], st0, 0, 0, 0);
+        st1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[ks], st1, 0, 0, 0);
+      }
+      float sv[8] = {st0[0], st0[1], st0[2], st0[3], st1[0], st1[1], st1[2], st1[3]};
+      const int kb = kv0 + s * 32 + g * 4;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int key = kb + (r & 3) + ((r >> 2) << 4);
+        if (key >= T) sv[r] = -INFINITY;
+        mx = fmaxf(mx, sv[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __expf(m_run - m_new);
+      float psum = 0.0f;
+      float p[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { p[r] = __expf(sv[r] - m_new); psum += p[r]; }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+      union { bf16x8_t v; uint32_t w[4]; } pf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pf.w[r] = pack_bf16x2(p[2 * r], p[2 * r + 1]);
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        const int d = dt * 16 + fq;
+        const unsigned char* vr = Vs + d * VROWB + (g & 1) * 8;
+        union { bf16x8_t v; uint2 h2[2]; } vf;
+        vf.h2[0] = *reinterpret_cast<const uint2*>(vr + (((s * 4 + (g >> 1)) ^ (d & 15)) << 4));
+        vf.h2[1] = *reinterpret_cast<const uint2*>(vr + (((s * 4 + 2 + (g >> 1)) ^ (d & 15)) << 4));
+        f32x4_t o = ot[dt];
+        o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o, 0, 0, 0);
+      }
+    }
+  }
+  if (!active) return;
+  float l = l_run + __shfl_xor(l_run, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  if (qrow < T) {
+    bf16_t* op = reinterpret_cast<bf16_t*>(a.ctx) + (size_t)(row0 + qrow) * a.ld_ctx + h * HD + g * 4;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      uint2 w;
+      w.x = pack_bf16x2(ot[dt][0] * inv, ot[dt][1] * inv);
+      w.y = pack_bf16x2(ot[dt][2] * inv, ot[dt][3] * inv);
+      *reinterpret_cast<uint2*>(op + dt * 16) = w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ attention (f32, verification mode)
+// One wave per query row; lanes over keys for the scores, lanes over d for the context. Plain f32 FMA.
+constexpr int ATT32_MAXT = 2048;
+__global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs a, int HD) {
+  __shared__ float sc[4][ATT32_MAXT];
+  __shared__ float qs[4][128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int u = a.qb_utt[blockIdx.x], q0 = a.qb_q0[blockIdx.x], h = blockIdx.y;
+  const UttPlan up = a.plan[u];
+  const int T = up.T, row0 = up.row_off;
+  const float* Q = reinterpret_cast<const float*>(a.q);
+  const float* K = reinterpret_cast<const float*>(a.k);
+  const float* Vt = reinterpret_cast<const float*>(a.vt);
+  float* C = reinterpret_cast<float*>(a.ctx);
+  for (int qi = wave; qi < 64; qi += 4) {
+    const int qrow = q0 + qi;
+    if (qrow >= T) break;                      // wave-uniform
+    const float* qp = Q + (size_t)(row0 + qrow) * a.ld_qk + h * HD;
+    for (int d = lane; d < HD; d += 64) qs[wave][d] = qp[d];
+    __builtin_amdgcn_wave_barrier();
+    float mx = -INFINITY;
+    for (int key = lane; key < T; key += 64) {
+      const float* kp = K + (size_t)(row0 + key) * a.ld_qk + h * HD;
+      float acc = 0.0f;
+      for (int d = 0; d < HD; d += 4) {
+        const float4 kv = *reinterpret_cast<const float4*>(kp + d);
+        acc = fmaf(qs[wave][d], kv.x, acc);
+        acc = fmaf(qs[wave][d + 1], kv.y, acc);
+        acc = fmaf(qs[wave][d + 2], kv.z, acc);
+        acc = fmaf(qs[wave][d + 3], kv.w, acc);
+      }
+      sc[wave][key] = acc;
+      mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.0f;
+    for (int key = lane; key < T; key += 64) {
+      const float e = expf(sc[wave][key] - mx);
+      sc[wave][key] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_wave_barrier();
+    const float inv = 1.0f / sum;
+    for (int d = lane; d < HD; d += 64) {
+      const float* vp = Vt + (size_t)(h * HD + d) * a.ld_vt + row0;
+      float acc = 0.0f;
+      for (int key = 0; key < T; ++key) acc = fmaf(sc[wave][key], vp[key], acc);
+      C[(size_t)(row0 + qrow) * a.ld_ctx + h * HD + d] = acc * inv;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------ FSMN
+template <typename InT>
+__global__ void fsmn_kernel(const InT* __restrict__ vt, int ld, const float* __restrict__ w, const float* __restrict__ b,
+                            int ktaps, const UttPlan* __restrict__ plan, const int32_t* __restrict__ row_utt, int n_rows,
+                            float* __restrict__ out_t) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  if (m >= n_rows) return;
+  const int u = row_utt[m];
+  float acc = 0.0f;
+  if (u >= 0) {
+    const int s = plan[u].row_off, e = s + plan[u].T;
+    if (m < e) {
+      acc = b[c];
+      const int pad = (ktaps - 1) / 2;
+      const InT* v = vt + (size_t)c * ld;
+      const float* wc = w + c * ktaps;
+      for (int j = 0; j < ktaps; ++j) {
+        const int mm = m + j - pad;
+        if (mm >= s && mm < e) acc = fmaf(wc[j], Elem<InT>::load(v + mm), acc);
+      }
+    }
+  }
+  out_t[(size_t)c * ld + m] = acc;
+}
+
+// ------------------------------------------------------------------------------------ CTC collapse
+__global__ __launch_bounds__(256) void ctc_collapse_kernel(const int32_t* __restrict__ ids, const UttPlan* __restrict__ plan,
+                                                           int blank_id, int32_t* __restrict__ token_ids, int max_tokens,
+                                                           int32_t* __restrict__ num_id) {
+  __shared__ int wave_cnt[4];
+  __shared__ int running;
+  const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = plan[u].T, base = plan[u].row_off;
+  if (tid == 0) running = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < T; t0 += 256) {
+    const int t = t0 + tid;
+    int id = 0;
+    bool keep = false;
+    if (t < T) {
+      id = ids[base + t];
+      const int nxt = ids[base + ((t + 1 == T) ? 0 : t + 1)];   // circular: last frame vs first
+      keep = (id != nxt) && (id != blank_id);
+    }
+    const unsigned long long bal = __ballot(keep);
+    const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = running + prefix;
+    for (int w2 = 0; w2 < wave; ++w2) off += wave_cnt[w2];
+    if (keep && off < max_tokens) token_ids[(size_t)u * max_tokens + off] = id;
+    __syncthreads();
+    if (tid == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (tid == 0) num_id[u] = running;
+}
+
+}  // namespace
+
+// ==================================================================================== launchers
+void launch_fbank(const FbankArgs& a, int n_blocks, hipStream_t s) {
+  ASR_REQUIRE(a.win == WIN && a.hop == HOP, "fbank: only win=400 hop=160 is built (got %d/%d)", a.win, a.hop);
+  ASR_REQUIRE(a.n_bin_tiles * 16 <= FB_PLD - 1, "fbank: too many frequency bins");
+  ASR_REQUIRE(a.n_kchunks * 16 == WIN, "fbank: k-chunks must cover the window");
+  const size_t lds = (size_t)(FB_AUDIO_LDS + FB_FRAMES * FB_PLD) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fbank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(fbank_kernel, dim3(n_blocks), dim3(256), lds, s, a);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_lfr_cmvn(const LfrArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(lfr_cmvn_kernel, dim3(a.n_rows), dim3(256), 0, s, a);
+  HIP_CHECK(hipGetLastError());
+}
+
+template <typename OutT>
+void launch_layernorm(const float* x, int ld_x, int rows, int D, const float* gamma, const float* beta, float eps,
+                      OutT* out, int ld_out, int fill_to, hipStream_t s) {
+  hipLaunchKernelGGL(layernorm_kernel<OutT>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld_x, rows, D, gamma, beta, eps, out,
+                     ld_out, fill_to);
+  HIP_CHECK(hipGetLastError());
+}
+template void launch_layernorm<float>(const float*, int, int, int, const float*, const float*, float, float*, int, int, hipStream_t);
+template void launch_layernorm<bf16_t>(const float*, int, int, int, const float*, const float*, float, bf16_t*, int, int, hipStream_t);
+
+template <int HD>
+static void launch_attn_bf16(const AttnArgs& a, hipStream_t s, int n_rows_alloc) {
+  constexpr int CHUNK = 128;
+  const size_t lds = (size_t)CHUNK * HD * 2 * 2;
+  hipLaunchKernelGGL((attn_bf16_kernel<HD, CHUNK>), dim3(a.n_qblocks, a.n_heads), dim3(256), lds, s, a, n_rows_alloc);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_attention_bf16_hd128(const AttnArgs& a, hipStream_t s) { launch_attn_bf16<128>(a, s, a.ld_vt); }
+void launch_attention_bf16_hd64(const AttnArgs& a, hipStream_t s) { launch_attn_bf16<64>(a, s, a.ld_vt); }
+
+void launch_attention_f32(const AttnArgs& a, int head_dim, hipStream_t s) {
+  ASR_REQUIRE(head_dim <= 128 && head_dim % 4 == 0, "attention_f32: head_dim %d unsupported", head_dim);
+  hipLaunchKernelGGL(attn_f32_kernel, dim3(a.n_qblocks, a.n_heads), dim3(256), 0, s, a, head_dim);
+  HIP_CHECK(hipGetLastError());
+}
+
+template <typename InT>
+void launch_fsmn(const InT* vt, int ld, const float* w, const float* b, int C, int ktaps, const UttPlan* plan,
+                 const int32_t* row_utt, int n_rows, float* out_t, hipStream_t s) {
+  hipLaunchKernelGGL(fsmn_kernel<InT>, dim3((n_rows + 255) / 256, C), dim3(256), 0, s, vt, ld, w, b, ktaps, plan, row_utt,
+                     n_rows, out_t);
+  HIP_CHECK(hipGetLastError());
+}
+template void launch_fsmn<float>(const float*, int, const float*, const float*, int, int, const UttPlan*, const int32_t*, int, float*, hipStream_t);
+template void launch_fsmn<bf16_t>(const bf16_t*, int, const float*, const float*, int, int, const UttPlan*, const int32_t*, int, float*, hipStream_t);
+
+void launch_ctc_collapse(const int32_t* frame_ids, const UttPlan* plan, int n_utts, int blank_id, int32_t* token_ids,
+                         int max_tokens, int32_t* num_id, hipStream_t s) {
+  hipLaunchKernelGGL(ctc_collapse_kernel, dim3(n_utts), dim3(256), 0, s, frame_ids, plan, blank_id, token_ids, max_tokens, num_id);
+  HIP_CHECK(hipGetLastError());
+}

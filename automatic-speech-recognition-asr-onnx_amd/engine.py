@@ -1,0 +1,198 @@
+"""Python handles over the C ABI: sessions, taps, profiling, operator hooks."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from . import _lib
+from .arena import PRECISION_BF16, PRECISION_F32, build_sensevoice_arena
+from .config import SenseVoiceConfig
+
+MEM_HOST, MEM_DEVICE = 0, 1
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def sensevoice_config_c(cfg: SenseVoiceConfig) -> _lib.SenseVoiceConfigC:
+    c = _lib.SenseVoiceConfigC()
+    c.sample_rate, c.n_mels, c.nfft, c.win_length, c.hop_length = cfg.sample_rate, cfg.n_mels, cfg.nfft, cfg.win_length, cfg.hop_length
+    c.lfr_m, c.lfr_n = cfg.lfr_m, cfg.lfr_n
+    c.d_model, c.n_heads, c.d_head, c.d_ffn = cfg.d_model, cfg.n_heads, cfg.d_head, cfg.d_ffn
+    c.n_blocks, c.n_main = cfg.n_blocks, cfg.n_enc0 + cfg.n_enc
+    c.fsmn_kernel, c.vocab, c.blank_id = cfg.fsmn_kernel, cfg.vocab, cfg.blank_id
+    c.n_prompt, c.n_languages, c.max_audio_len = cfg.n_prompt, len(cfg.language_prompt_token_ids), cfg.max_audio_len
+    return c
+
+
+class _Session:
+    """Common session utilities (stream, profiling, taps)."""
+
+    def __init__(self):
+        self._h = C.c_void_p(None)
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            _lib.check(_lib.load().asr_session_destroy(self._h))
+            self._h = C.c_void_p(None)
+        self._keep = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream: int):
+        _lib.check(_lib.load().asr_session_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def profile(self, enable: bool):
+        _lib.check(_lib.load().asr_session_profile_enable(self._h, int(enable)))
+
+    def profile_reset(self):
+        _lib.check(_lib.load().asr_session_profile_reset(self._h))
+
+    def profile_read(self) -> dict:
+        cap = 64
+        names = C.create_string_buffer(32 * cap)
+        ms = (C.c_double * cap)()
+        cnt = (C.c_int64 * cap)()
+        n = C.c_int(0)
+        _lib.check(_lib.load().asr_session_profile_read(self._h, cap, names, ms, cnt, C.byref(n)))
+        out = {}
+        for i in range(n.value):
+            nm = names.raw[i * 32:(i + 1) * 32].split(b"\0", 1)[0].decode()
+            out[nm] = {"total_ms": ms[i], "launches": int(cnt[i])}
+        return out
+
+    def taps(self, enable: bool):
+        _lib.check(_lib.load().asr_session_taps_enable(self._h, int(enable)))
+
+    def tap(self, name: str, dtype=np.float32) -> np.ndarray:
+        rows, cols = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.load().asr_session_tap_shape(self._h, name.encode(), C.byref(rows), C.byref(cols)))
+        out = np.empty((rows.value, cols.value), dtype=dtype)
+        _lib.check(_lib.load().asr_session_tap_read(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+
+class SenseVoiceSession(_Session):
+    """HIP replacement of `SenseVoiceSmall.onnx` (SENSE_VOICE.forward, Export_SenseVoice.py:271-296)."""
+
+    def __init__(self, cfg: SenseVoiceConfig, arena, precision: int = PRECISION_BF16, device_id: int = 0,
+                 arena_device_ptr: int | None = None, arena_bytes: int | None = None):
+        super().__init__()
+        self.cfg, self.precision, self.device_id = cfg, precision, device_id
+        self._cfg_c = sensevoice_config_c(cfg)
+        lib = _lib.load()
+        if arena_device_ptr is not None:
+            self._keep = arena          # whatever owns the device memory (e.g. a torch tensor)
+            _lib.check(lib.asr_sensevoice_create(C.byref(self._cfg_c), C.c_void_p(arena_device_ptr), arena_bytes, MEM_DEVICE,
+                                                 device_id, precision, C.byref(self._h)))
+        else:
+            blob = np.ascontiguousarray(arena, dtype=np.uint8)
+            _lib.check(lib.asr_sensevoice_create(C.byref(self._cfg_c), blob.ctypes.data_as(C.c_void_p), blob.nbytes, MEM_HOST,
+                                                 device_id, precision, C.byref(self._h)))
+
+    @classmethod
+    def from_checkpoint(cls, cfg, ck, precision=PRECISION_BF16, device_id=0):
+        return cls(cfg, build_sensevoice_arena(cfg, ck, precision), precision, device_id)
+
+    def seq_len(self, n_samples: int) -> int:
+        return self.cfg.seq_len(n_samples)
+
+    def run_packed(self, audio, offsets: np.ndarray, language_idx: np.ndarray, audio_device_ptr: int | None = None):
+        """audio: packed f32 samples (host ndarray) or None with `audio_device_ptr` (HBM-resident).
+        Returns (token_ids [B, max_T] int32, num_id [B] int32)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        lang = np.ascontiguousarray(language_idx, dtype=np.int32)
+        B = lang.shape[0]
+        assert offsets.shape[0] == B + 1
+        max_t = max(self.cfg.seq_len(int(n)) for n in np.diff(offsets)) if B else 1
+        tok = np.zeros((B, max_t), dtype=np.int32)
+        num = np.zeros((B,), dtype=np.int32)
+        lib = _lib.load()
+        if audio_device_ptr is not None:
+            ap, mem = C.c_void_p(audio_device_ptr), MEM_DEVICE
+        else:
+            audio = _f32(audio).reshape(-1)
+            ap, mem = audio.ctypes.data_as(C.c_void_p), MEM_HOST
+        _lib.check(lib.asr_sensevoice_run(self._h, ap, mem, offsets.ctypes.data_as(C.POINTER(C.c_int64)), B, _ip(lang),
+                                          _ip(tok), max_t, _ip(num)))
+        return tok, num
+
+    def run(self, audios: Sequence[np.ndarray], language_idx: Sequence[int]):
+        """List of 1-D utterances -> list of int32 token-id arrays (one per utterance)."""
+        flat = [_f32(a).reshape(-1) for a in audios]
+        offs = np.zeros(len(flat) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([a.size for a in flat])
+        tok, num = self.run_packed(np.concatenate(flat), offs, np.asarray(language_idx, dtype=np.int32))
+        return [tok[b, :num[b]].copy() for b in range(len(flat))]
+
+    def utterance_rows(self, lengths: Sequence[int]):
+        """(row_off, T) of each utterance inside the packed tap tensors (16-row aligned)."""
+        out, r = [], 0
+        for n in lengths:
+            t = self.cfg.seq_len(int(n))
+            out.append((r, t))
+            r += (t + 15) // 16 * 16
+        return out
+
+
+# ------------------------------------------------------------------------------- operator hooks
+def op_gemm(a, w, bias=None, act=0, precision=PRECISION_BF16):
+    a, w = _f32(a), _f32(w)
+    M, K = a.shape
+    N = w.shape[0]
+    out = np.empty((M, N), dtype=np.float32)
+    b = _f32(bias) if bias is not None else None
+    _lib.check(_lib.load().asr_op_gemm(precision, _fp(a), _fp(w), _fp(b), M, N, K, act, _fp(out)))
+    return out
+
+
+def op_layernorm(x, gamma=None, beta=None, eps=1e-5, precision=PRECISION_F32):
+    x = _f32(x)
+    rows, D = x.shape
+    out = np.empty_like(x)
+    g = _f32(gamma) if gamma is not None else None
+    b = _f32(beta) if beta is not None else None
+    _lib.check(_lib.load().asr_op_layernorm(precision, _fp(x), rows, D, _fp(g), _fp(b), eps, _fp(out)))
+    return out
+
+
+def op_attention(q, k, v, seq_lens, n_heads, d_head, precision=PRECISION_BF16):
+    q, k, v = _f32(q), _f32(k), _f32(v)
+    sl = np.ascontiguousarray(seq_lens, dtype=np.int32)
+    out = np.empty_like(q)
+    _lib.check(_lib.load().asr_op_attention(precision, _fp(q), _fp(k), _fp(v), _ip(sl), sl.size, n_heads, d_head, _fp(out)))
+    return out
+
+
+def op_fsmn(v, w, b, seq_lens, precision=PRECISION_F32):
+    v, w, b = _f32(v), _f32(w), _f32(b)
+    sl = np.ascontiguousarray(seq_lens, dtype=np.int32)
+    out = np.empty_like(v)
+    _lib.check(_lib.load().asr_op_fsmn(precision, _fp(v), _fp(w), _fp(b), _ip(sl), sl.size, v.shape[1], w.shape[1], _fp(out)))
+    return out
+
+
+def op_ctc_collapse(frame_ids, seq_lens, blank_id=0):
+    ids = np.ascontiguousarray(frame_ids, dtype=np.int32)
+    sl = np.ascontiguousarray(seq_lens, dtype=np.int32)
+    max_t = int(sl.max())
+    tok = np.zeros((sl.size, max_t), dtype=np.int32)
+    num = np.zeros((sl.size,), dtype=np.int32)
+    _lib.check(_lib.load().asr_op_ctc_collapse(_ip(ids), _ip(sl), sl.size, blank_id, _ip(tok), max_t, _ip(num)))
+    return [tok[b, :num[b]].copy() for b in range(sl.size)]

@@ -1,0 +1,129 @@
+/* asr_mi355x.h -- C ABI of the MI355X-native ASR hot path (libasr_mi355x.so).
+ *
+ * This library replaces what the reference executes behind
+ *   onnxruntime.InferenceSession.run_with_iobinding(binding, run_options)
+ * (process->native boundary: SenseVoice/Inference_SenseVoice_ONNX.py:303,
+ *  Whisper/Inference_Whisper_ONNX.py:247-248,640), i.e. the arithmetic that
+ * Export_*.py freezes into the .onnx graphs: in-graph STFT/FBank front-end,
+ * encoder, and CTC / autoregressive decoder. The reference has no native code of
+ * its own; its FFI for this path is the onnxruntime Python binding, so the
+ * reference-side stub that binds these symbols is a ctypes shim exposing the
+ * onnxruntime API subset the Inference_*_ONNX.py scripts use.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *  - every function returns ASR_OK (0) or an error code; asr_last_error() returns a
+ *    thread-local message (the Python shim raises it, mirroring ORT's exceptions;
+ *    nothing is swallowed);
+ *  - a session owns one HIP stream (or borrows the caller's, asr_session_set_stream)
+ *    and is re-entrant per session; runs are synchronous: outputs are complete when the
+ *    call returns (RunOptions "disable_synchronize_execution_providers"="0",
+ *    SenseVoice/Inference_SenseVoice_ONNX.py:142-147);
+ *  - there is NO CPU fallback: every entry point fails with ASR_ERR_NO_DEVICE when no
+ *    gfx950 device is visible.
+ */
+#ifndef ASR_MI355X_H
+#define ASR_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASR_ABI_VERSION 1
+
+enum asr_status {
+  ASR_STATUS_OK = 0,
+  ASR_STATUS_INVALID = 1,
+  ASR_STATUS_HIP = 2,
+  ASR_STATUS_NOT_FOUND = 3,
+  ASR_STATUS_UNSUPPORTED = 4,
+  ASR_STATUS_NO_DEVICE = 5
+};
+
+/* Arithmetic mode. BF16: bf16 MFMA operands, f32 accumulate, f32 residual stream / LayerNorm /
+ * soft-max / front-end. F32: exact-f32 MFMA everywhere (verification mode for the
+ * "logits within 1e-3" parity bar). The weight arena must be built for the same mode. */
+enum asr_precision { ASR_PRECISION_BF16 = 0, ASR_PRECISION_F32 = 1 };
+
+enum asr_mem { ASR_MEM_HOST = 0, ASR_MEM_DEVICE = 1 };
+
+typedef struct asr_session asr_session;
+
+int asr_abi_version(void);
+const char* asr_last_error(void);
+int asr_device_count(int* count);
+
+/* ------------------------------------------------------------------ SenseVoice (non-AR, CTC)
+ * Replaces SenseVoiceSmall.onnx == SENSE_VOICE.forward (SenseVoice/Export_SenseVoice.py:271-296).
+ * Graph I/O it mirrors (Export_SenseVoice.py:375-379): audio (1,1,audio_len) f32 int16-range,
+ * language_idx (1,) i32  ->  token_ids (num_token,) i32, num_id (1,) i32.
+ * Extension over the batch-1 reference: B independent utterances per call, ragged lengths. */
+typedef struct asr_sensevoice_config {
+  int32_t sample_rate, n_mels, nfft, win_length, hop_length;
+  int32_t lfr_m, lfr_n;
+  int32_t d_model, n_heads, d_head, d_ffn;
+  int32_t n_blocks;       /* total SANM blocks (encoders0 + encoders + tp_encoders) */
+  int32_t n_main;         /* blocks before after_norm (encoders0 + encoders)          */
+  int32_t fsmn_kernel;
+  int32_t vocab, blank_id;
+  int32_t n_prompt;       /* prompt rows prepended to the speech rows (1 language + 3 system) */
+  int32_t n_languages;    /* rows of the language embedding table */
+  int32_t max_audio_len;
+  int32_t reserved[8];
+} asr_sensevoice_config;
+
+/* `arena` is the flat weight arena built by arena.py (manifest + tensors). With
+ * ASR_MEM_HOST it is copied to HBM; with ASR_MEM_DEVICE the pointer is borrowed and must outlive
+ * the session (same ownership rule as SessionOptions.add_initializer,
+ * Whisper/Inference_Whisper_ONNX.py:242-243) -- used after the RCCL weight broadcast. */
+int asr_sensevoice_create(const asr_sensevoice_config* cfg, const void* arena, size_t arena_bytes, int arena_mem,
+                          int device_id, int precision, asr_session** out);
+
+/* audio: packed f32 samples; utterance b spans [audio_offsets[b], audio_offsets[b+1]).
+ * language_idx: B selector indices (host). token_ids_out: host [B][max_tokens] (row b holds num_id_out[b]
+ * ids, rest untouched); num_id_out: host [B]. Fails if any utterance is shorter than one frame. */
+int asr_sensevoice_run(asr_session* s, const float* audio, int audio_mem, const int64_t* audio_offsets, int batch,
+                       const int32_t* language_idx, int32_t* token_ids_out, int max_tokens, int32_t* num_id_out);
+
+/* sequence length (prompt + LFR rows) the graph produces for an utterance of n_samples */
+int asr_sensevoice_seq_len(const asr_sensevoice_config* cfg, int n_samples, int* seq_len);
+
+/* ------------------------------------------------------------------ session utilities */
+int asr_session_destroy(asr_session* s);
+int asr_session_set_stream(asr_session* s, void* hip_stream);       /* borrow a caller stream (e.g. torch's) */
+int asr_session_device(asr_session* s, int* device_id);
+
+/* Per-kernel-class timing with HIP events on the session stream (bench.py roofline leg).
+ * read: up to `cap` classes; names are NUL-terminated, 32 bytes apart in `names`. */
+int asr_session_profile_enable(asr_session* s, int enable);
+int asr_session_profile_reset(asr_session* s);
+int asr_session_profile_read(asr_session* s, int cap, char* names, double* total_ms, int64_t* launches, int* n_out);
+
+/* Debug taps (the reference's decode graphs expose no logits; the 1e-3 logit check needs one).
+ * enable before a run; read copies the named f32 tensor of the LAST run to host.
+ * names: "mel" "enc_in" "block0" "enc_out" "logits" "frame_ids"(i32) */
+int asr_session_taps_enable(asr_session* s, int enable);
+int asr_session_tap_shape(asr_session* s, const char* name, int64_t* rows, int64_t* cols);
+int asr_session_tap_read(asr_session* s, const char* name, void* host_out, size_t bytes);
+
+/* ------------------------------------------------------------------ operator-level entry points
+ * Single kernels on host arrays (device temporaries are internal). Used by the parity tests to pin
+ * each HIP kernel against the oracle separately; not part of the reference-facing surface. */
+int asr_op_gemm(int precision, const float* a, const float* w, const float* bias, int M, int N, int K, int act,
+                float* out);                                        /* out[M][N] = act(a[M][K] w[N][K]^T + bias) */
+int asr_op_layernorm(int precision, const float* x, int rows, int D, const float* gamma, const float* beta, float eps,
+                     float* out);
+int asr_op_attention(int precision, const float* q, const float* k, const float* v, const int32_t* seq_lens, int batch,
+                     int n_heads, int d_head, float* ctx);          /* packed rows, row-major [sum T][H*D] */
+int asr_op_fsmn(int precision, const float* v, const float* w, const float* b, const int32_t* seq_lens, int batch,
+                int channels, int ktaps, float* out);               /* v,out: [sum T][C] row-major */
+int asr_op_ctc_collapse(const int32_t* frame_ids, const int32_t* seq_lens, int batch, int blank_id, int32_t* token_ids,
+                        int max_tokens, int32_t* num_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASR_MI355X_H */

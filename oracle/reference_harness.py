@@ -1,0 +1,185 @@
+"""Run the REAL reference modules (build container only) to pin the oracle.
+
+TEST INFRASTRUCTURE -- never imported by the product package.
+
+`/root/reference` is a read-only mount that exists only in the build
+container. Its export scripts execute on import and need packages that are not
+installed (funasr, torchaudio, onnx), so -- as SURVEY.md Appendix A describes --
+only the class/function *definitions* are compiled from the reference file where
+it lies (nothing is copied into this repo) and run eagerly on CPU against a
+stand-in module tree carrying our seeded synthetic checkpoint.
+
+Used by `oracle/gen_golden.py` (writes tests/golden/*.npz) and by
+`tests/test_oracle_vs_reference.py` (skipped when /root/reference is absent).
+"""
+from __future__ import annotations
+
+import ast
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REFERENCE_ROOT = os.environ.get("ASR_REFERENCE_ROOT", "/root/reference")
+
+
+def reference_available() -> bool:
+    return os.path.isfile(os.path.join(REFERENCE_ROOT, "SenseVoice", "Export_SenseVoice.py"))
+
+
+def _compile_defs(path: str, ns: dict, replacements=()):
+    src = open(path, "r", encoding="utf-8").read()
+    for old, new in replacements:
+        src = src.replace(old, new)
+    defs = [n for n in ast.parse(src).body if isinstance(n, (ast.ClassDef, ast.FunctionDef))]
+    exec(compile(ast.Module(defs, []), os.path.basename(path) + ":defs", "exec"), ns)
+    return ns
+
+
+# --------------------------------------------------------------------------- SenseVoice
+class _Layer(torch.nn.Module):
+    def __init__(self, in_size, d, h, dk, dff, k):
+        super().__init__()
+        self.in_size, self.size = in_size, d
+        self.norm1 = torch.nn.LayerNorm(in_size)
+        self.norm2 = torch.nn.LayerNorm(d)
+        sa = torch.nn.Module()
+        sa.h, sa.d_k = h, dk
+        sa.linear_q_k_v = torch.nn.Linear(in_size, 3 * d)
+        sa.linear_out = torch.nn.Linear(d, d)
+        sa.fsmn_block = torch.nn.Conv1d(d, d, k, groups=d, bias=False)
+        self.self_attn = sa
+        ff = torch.nn.Module()
+        ff.w_1 = torch.nn.Linear(d, dff)
+        ff.w_2 = torch.nn.Linear(dff, d)
+        self.feed_forward = ff
+
+
+def build_sensevoice_standin(cfg, ck: dict) -> torch.nn.Module:
+    """FunASR-shaped module tree exposing exactly what SENSE_VOICE touches
+    (SenseVoice/Export_SenseVoice.py:130-132,172-183,211-220), loaded from `ck`."""
+    sv = torch.nn.Module()
+    enc = torch.nn.Module()
+    mk = lambda n, in_size: torch.nn.ModuleList(
+        [_Layer(in_size, cfg.d_model, cfg.n_heads, cfg.d_head, cfg.d_ffn, cfg.fsmn_kernel) for _ in range(n)])
+    enc.encoders0 = mk(cfg.n_enc0, cfg.feat_dim)
+    enc.encoders = mk(cfg.n_enc, cfg.d_model)
+    enc.tp_encoders = mk(cfg.n_tp, cfg.d_model)
+    enc.after_norm = torch.nn.LayerNorm(cfg.d_model)
+    enc.tp_norm = torch.nn.LayerNorm(cfg.d_model)
+    sv.encoder = enc
+    sv.embed = torch.nn.Embedding(cfg.embed_rows, cfg.feat_dim)
+    ctc = torch.nn.Module()
+    ctc.ctc_lo = torch.nn.Linear(cfg.d_model, cfg.vocab)
+    sv.ctc = ctc
+    sv.blank_id = cfg.blank_id
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in ck.items() if not k.startswith("frontend.")}
+    missing, unexpected = sv.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return sv.eval()
+
+
+def build_reference_sensevoice(cfg, ck: dict, kaldi_mel_banks_fn):
+    """Instantiate the reference's SENSE_VOICE class on the synthetic checkpoint.
+
+    Mirrors the script-level preparation at Export_SenseVoice.py:355-366:
+    embed.weight *= sqrt(d_model); cmvn_vars *= sqrt(d_model)."""
+    assert reference_available()
+    ns = dict(torch=torch, json=json,
+              kaldi=types.SimpleNamespace(get_mel_banks=kaldi_mel_banks_fn),
+              LANGUAGE_PROMPT_TOKEN_IDS=tuple(cfg.language_prompt_token_ids))
+    _compile_defs(os.path.join(REFERENCE_ROOT, "SenseVoice", "Export_SenseVoice.py"), ns)
+    sv = build_sensevoice_standin(cfg, ck)
+    factor = float(cfg.d_model) ** 0.5
+    with torch.no_grad():
+        sv.embed.weight.data *= factor
+    means = torch.from_numpy(ck["frontend.cmvn_means"]).reshape(1, 1, -1)
+    vars_ = (torch.from_numpy(ck["frontend.cmvn_vars"]) * factor).reshape(1, 1, -1)
+    stft_len = cfg.n_frames(cfg.max_audio_len)
+    lfr_len = (stft_len + cfg.lfr_n - 1) // cfg.lfr_n
+    with torch.inference_mode():
+        model = ns["SENSE_VOICE"](sv, cfg.d_model, cfg.nfft, cfg.win_length, cfg.hop_length, stft_len,
+                                  cfg.n_mels, cfg.sample_rate, cfg.pre_emphasis, cfg.lfr_m, cfg.lfr_n,
+                                  lfr_len, means, vars_, cfg.use_emo, False)
+    return model.eval()
+
+
+def reference_sensevoice_stages(model, audio: np.ndarray, language_idx: int) -> dict:
+    """Re-trace SENSE_VOICE.forward (Export_SenseVoice.py:271-296) calling the
+    reference's own sub-functions so intermediate tensors can be dumped."""
+    with torch.inference_mode():
+        a = torch.from_numpy(audio).reshape(1, 1, -1).float()
+        lang = torch.tensor([language_idx], dtype=torch.int32)
+        F = torch.nn.functional
+        spectrum = F.conv1d(a, model.fbank_kernel, stride=model.hop_length)
+        re, im = torch.split(spectrum * spectrum, model.fbank_freq, dim=1)
+        power = (re + im).transpose(1, 2)
+        mel = torch.matmul(power, model.mel_filters).clamp(min=model.log_eps).log()
+        n_frames = mel.shape[1]
+        _len = (n_frames + model.lfr_n - 1) // model.lfr_n
+        idx = torch.minimum(model.indices_mel[:_len], torch.tensor(n_frames - 1))
+        x = mel[:, idx].reshape(-1, model.feature_size)
+        x = (x + model.cmvn_means) * model.cmvn_vars
+        x = x + model.speech_position[:_len]
+        x = torch.cat([model.language_embed[lang], model.system_embed, x], dim=0)
+        enc_in = x.clone()
+        layers = list(model.encoder.encoders0) + list(model.encoder.encoders)
+        block0 = None
+        for i, layer in enumerate(layers):
+            x = model.sanm_block(x, layer)
+            if i == 0:
+                block0 = x.clone()
+        x = model.layer_norm(x, model.encoder.after_norm)
+        for layer in model.encoder.tp_encoders:
+            x = model.sanm_block(x, layer)
+        enc_out = model.layer_norm(x, model.encoder.tp_norm)
+        logits = model.ctc_lo(enc_out)
+        token_ids, num_id = model(a, lang)            # the reference's own end-to-end forward
+    return dict(mel=mel[0].numpy(), enc_in=enc_in.numpy(), block0=block0.numpy(), enc_out=enc_out.numpy(),
+                logits=logits.numpy(), token_ids=token_ids.numpy(), num_id=num_id.numpy())
+
+
+# --------------------------------------------------------------------------- Whisper
+def build_reference_whisper(cfg, ck: dict, use_fp16_kv=False):
+    """Reference WHISPER_ENCODER / WHISPER_DECODER (+ embed/position shells) on a
+    synthetic HF-layout checkpoint. Quantisation-only channel re-orderings are exact
+    permutations (Export_Whisper.py:568-612) and are disabled."""
+    assert reference_available()
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    from transformers.audio_utils import mel_filter_bank
+    sys.path.insert(0, os.path.join(REFERENCE_ROOT, "Whisper"))
+    try:
+        from STFT_Process import STFT_Process  # the real, unmodified reference module
+    finally:
+        sys.path.pop(0)
+    kv_dtype = torch.float16 if use_fp16_kv else torch.float32
+    ns = dict(torch=torch, json=json, STFT_Process=STFT_Process,
+              INPUT_AUDIO_DTYPE="F32", USE_FP16_KV=use_fp16_kv, COMPUTE_IN_F32=False, KV_DTYPE=kv_dtype,
+              REORDER_DOWNPROJ_FOR_QUANT=False, REORDER_OPROJ_FOR_QUANT=False, REORDER_KEY="absmean",
+              torchaudio=types.SimpleNamespace(functional=types.SimpleNamespace(
+                  melscale_fbanks=lambda nf, lo, hi, nm, sr, norm, scale: torch.from_numpy(
+                      mel_filter_bank(nf, nm, float(lo), float(hi), sr, norm=norm, mel_scale=scale)).float())))
+    _compile_defs(os.path.join(REFERENCE_ROOT, "Whisper", "Export_Whisper.py"), ns,
+                  replacements=[("hidden_states.shape[0].unsqueeze(0)", "hidden_states.shape[0]")])
+    hf_cfg = WhisperConfig(d_model=cfg.d_model, encoder_layers=cfg.n_enc_layers, decoder_layers=cfg.n_dec_layers,
+                           encoder_attention_heads=cfg.n_heads, decoder_attention_heads=cfg.n_heads,
+                           encoder_ffn_dim=cfg.d_ffn, decoder_ffn_dim=cfg.d_ffn, num_mel_bins=cfg.n_mels,
+                           vocab_size=cfg.vocab, max_source_positions=cfg.max_source_positions,
+                           max_target_positions=cfg.max_target_positions, pad_token_id=0, bos_token_id=1,
+                           eos_token_id=2, decoder_start_token_id=cfg.sot_id if cfg.sot_id < cfg.vocab else 1)
+    model = WhisperForConditionalGeneration(hf_cfg).float().eval()
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in ck.items()}
+    sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("embed_positions" in m or "proj_out" in m for m in missing), missing
+    stft = STFT_Process("stft_B_power", n_fft=cfg.nfft, win_length=cfg.nfft, hop_len=cfg.hop_length, max_frames=0,
+                        window_type="hann", pad_mode="reflect", center_pad=True, input_scale=1.0,
+                        drop_last_frame=True).eval()
+    with torch.inference_mode():
+        enc = ns["WHISPER_ENCODER"](model.model, stft, cfg.nfft, cfg.n_mels, cfg.sample_rate, cfg.n_dec_layers).eval()
+        dec = ns["WHISPER_DECODER"](model, None, cfg.n_dec_layers).eval()
+    return dict(ns=ns, model=model, encoder=enc, decoder=dec, stft=stft, kv_dtype=kv_dtype)

@@ -1,0 +1,101 @@
+"""CPU: the converter's arena layout, and that the C-ABI library loads and exports every symbol
+include/asr_mi355x.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, sub
+from helpers import sensevoice_setup
+
+
+def test_library_exports_every_declared_symbol():
+    _lib = sub("_lib")
+    if not os.path.isfile(_lib.LIB_PATH):
+        _lib.build()
+    hdr = open(os.path.join(ROOT, "include", "asr_mi355x.h")).read()
+    declared = set(re.findall(r"\b(asr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no prototypes found"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/asr_mi355x.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    loaded = _lib.load()
+    assert loaded.asr_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    _lib = sub("_lib")
+    if not os.path.isfile(_lib.LIB_PATH):
+        _lib.build()
+    if _lib.device_count() > 0:
+        pytest.skip("GPU present")
+    eng = sub("engine")
+    with pytest.raises(_lib.AsrError) as e:
+        eng.op_gemm(np.zeros((4, 64), np.float32), np.zeros((128, 64), np.float32))
+    assert e.value.code == 5 and "no CPU fallback" in str(e.value)
+
+
+def test_arena_layout_roundtrip():
+    arena = sub("arena")
+    cfg, ck = sensevoice_setup("sensevoice_tiny")
+    blob = arena.build_sensevoice_arena(cfg, ck, arena.PRECISION_BF16)
+    magic, ver, n, data_off, total = struct.unpack("<8sIIQQ", blob[:32].tobytes())
+    assert magic == b"ASRARENA" and ver == 1 and total == blob.nbytes
+    recs = {}
+    for i in range(n):
+        name, dt, nd, s0, s1, s2, s3, off = struct.unpack("<80sII4qQ", blob[32 + 128 * i: 160 + 128 * i].tobytes())
+        recs[name.rstrip(b"\0").decode()] = (dt, (s0, s1, s2, s3)[:nd], off)
+        assert off % 256 == 0 and off >= data_off
+    d = cfg.d_model
+    assert recs["blk0.wqkv"][0] == arena.DT_BF16 and recs["blk0.wqkv"][1] == (3 * d, 576)   # K padded 560 -> 576
+    assert recs["blk1.wqkv"][1] == (3 * d, d)
+    assert recs["ctc.w"][1] == (1024, d)
+    # folds (Export_SenseVoice.py:208-220): q,k rows scaled by d_k^-1/4, v rows untouched, FSMN centre tap + 1
+    dt, shape, off = recs["blk1.wqkv"]
+    w = blob[off: off + 2 * shape[0] * shape[1]].view(np.uint16).reshape(shape)
+    as_f32 = lambda u: (u.astype(np.uint32) << 16).view(np.float32)
+    raw = ck["encoder.encoders.0.self_attn.linear_q_k_v.weight"]
+    s = np.float32(cfg.d_head ** -0.25)
+    assert np.abs(as_f32(w[:2 * d]) - raw[:2 * d] * s).max() < 1e-2
+    assert np.abs(as_f32(w[2 * d:]) - raw[2 * d:]).max() < 1e-2
+    dt, shape, off = recs["blk1.wfsmn"]
+    wf = blob[off: off + 4 * shape[0] * shape[1]].view(np.float32).reshape(shape)
+    rawf = ck["encoder.encoders.0.self_attn.fsmn_block.weight"][:, 0, :]
+    assert np.allclose(wf[:, 5], rawf[:, 5] + 1.0) and np.array_equal(wf[:, :5], rawf[:, :5])
+
+
+def test_dft_fragment_packing_matches_dense_matrix():
+    arena = sub("arena")
+    cfg, _ = sensevoice_setup("sensevoice_tiny")
+    kmat = arena.kaldi_fbank_matrix(cfg).numpy()
+    packed = arena.pack_dft_for_mfma(kmat, 257, 400).reshape(17, 2, 25, 64, 4)
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        t, part, kc, lane, j = rng.integers(17), rng.integers(2), rng.integers(25), rng.integers(64), rng.integers(4)
+        b = t * 16 + (lane & 15)
+        k = kc * 16 + 4 * j + (lane >> 4)
+        want = kmat[part * 257 + b, k] if b < 257 else 0.0
+        assert packed[t, part, kc, lane, j] == want
+
+
+def test_kaldi_mel_banks_known_answers():
+    """The product's mel banks vs the oracle's restatement and analytic properties of Kaldi's MelBanks."""
+    import torch
+    arena = sub("arena")
+    from oracle.kaldi_mel import get_mel_banks
+    a = arena.kaldi_mel_banks(80, 512, 16000.0)
+    b, centers = get_mel_banks(80, 512, 16000.0, 20.0, 0.0, 100.0, -500.0, 1.0)
+    assert a.shape == (80, 256) and torch.equal(a, b)
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+    # triangles: centre frequencies increase, each filter is unimodal and non-empty, bin 0 (DC, below 20 Hz) is unused
+    assert torch.all(centers[1:] > centers[:-1])
+    assert float(a[:, 0].max()) == 0.0
+    peaks = a.argmax(dim=1)
+    assert torch.all(peaks[1:] >= peaks[:-1]) and torch.all(a.sum(dim=1) > 0)
+    # adjacent triangles partition unity between the first and last centre
+    inner = (torch.arange(256) * 31.25 > float(centers[0])) & (torch.arange(256) * 31.25 < float(centers[-1]))
+    assert torch.allclose(a.sum(dim=0)[inner], torch.ones(int(inner.sum())), atol=1e-4)

@@ -1,0 +1,140 @@
+"""Per-kernel parity: each HIP kernel, through the C ABI, against a plain torch fp32 statement of the op."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import sub
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = 0, 1
+
+
+def _bf16_round(a):
+    return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy()
+
+
+@pytest.mark.parametrize("M,N,K", [(137, 128, 64), (300, 384, 576), (1000, 1536, 512), (260, 512, 2048)])
+@pytest.mark.parametrize("prec", [BF16, F32])
+def test_gemm_matches_torch(M, N, K, prec):
+    eng = sub("engine")
+    rng = np.random.default_rng(M + N + K)
+    # asymmetric operands: catches transposed fragments / C-layout swaps
+    a = rng.standard_normal((M, K), dtype=np.float32) + np.linspace(-1, 1, K, dtype=np.float32)[None, :]
+    w = rng.standard_normal((N, K), dtype=np.float32) * 0.1 + np.linspace(0, 0.3, N, dtype=np.float32)[:, None]
+    bias = rng.standard_normal((N,), dtype=np.float32)
+    out = eng.op_gemm(a, w, bias, act=1, precision=prec)
+    if prec == BF16:
+        a, w = _bf16_round(a), _bf16_round(w)
+    ref = torch.relu(torch.from_numpy(a).double() @ torch.from_numpy(w).double().t() + torch.from_numpy(bias).double()).numpy()
+    tol = 2e-3 if prec == BF16 else 2e-4     # bf16: operands pre-rounded, only f32 accumulation order differs
+    assert np.abs(out - ref).max() <= tol * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("act", [0, 2, 3])
+def test_gemm_activations(act):
+    eng = sub("engine")
+    rng = np.random.default_rng(act)
+    a = rng.standard_normal((130, 128), dtype=np.float32)
+    w = rng.standard_normal((128, 128), dtype=np.float32) * 0.2
+    out = eng.op_gemm(a, w, None, act=act, precision=F32)
+    z = torch.from_numpy(a) @ torch.from_numpy(w).t()
+    ref = {0: z, 2: torch.nn.functional.gelu(z), 3: torch.nn.functional.gelu(z, approximate="tanh")}[act].numpy()
+    assert np.abs(out - ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("D", [512, 560, 1280])
+def test_layernorm(D):
+    eng = sub("engine")
+    rng = np.random.default_rng(D)
+    x = rng.standard_normal((77, D), dtype=np.float32) * 3 + 1
+    g = rng.standard_normal((D,), dtype=np.float32)
+    b = rng.standard_normal((D,), dtype=np.float32)
+    ref = torch.nn.functional.layer_norm(torch.from_numpy(x), (D,), torch.from_numpy(g), torch.from_numpy(b), 1e-5).numpy()
+    out = eng.op_layernorm(x, g, b, 1e-5, precision=F32)
+    assert np.abs(out - ref).max() < 2e-5
+    out16 = eng.op_layernorm(x, g, b, 1e-5, precision=BF16)
+    assert np.abs(out16 - ref).max() < 0.02 * np.abs(ref).max()
+    ref_na = torch.nn.functional.layer_norm(torch.from_numpy(x), (D,), None, None, 1e-5).numpy()
+    assert np.abs(eng.op_layernorm(x, None, None, 1e-5, precision=F32) - ref_na).max() < 2e-5
+
+
+def _attn_ref(q, k, v, lens, H, D):
+    out = np.zeros_like(q)
+    r = 0
+    for T in lens:
+        qq = torch.from_numpy(q[r:r + T]).double().reshape(T, H, D).transpose(0, 1)
+        kk = torch.from_numpy(k[r:r + T]).double().reshape(T, H, D).transpose(0, 1)
+        vv = torch.from_numpy(v[r:r + T]).double().reshape(T, H, D).transpose(0, 1)
+        p = torch.softmax(qq @ kk.transpose(1, 2), dim=-1)
+        out[r:r + T] = (p @ vv).transpose(0, 1).reshape(T, H * D).float().numpy()
+        r += T
+    return out
+
+
+@pytest.mark.parametrize("prec,H,D,lens", [
+    (BF16, 4, 128, [137, 45, 1, 64, 129, 300]),
+    (BF16, 2, 64, [400, 33, 128]),
+    (F32, 4, 128, [137, 45, 1, 64, 129]),
+    (F32, 2, 64, [200, 33]),
+])
+def test_attention_ragged(prec, H, D, lens):
+    eng = sub("engine")
+    rng = np.random.default_rng(sum(lens))
+    n = sum(lens)
+    scale = D ** -0.25
+    q = rng.standard_normal((n, H * D), dtype=np.float32) * scale
+    k = rng.standard_normal((n, H * D), dtype=np.float32) * scale
+    v = rng.standard_normal((n, H * D), dtype=np.float32)
+    # one spiked key per sequence: forces the online-softmax running-max rescale branch
+    r = 0
+    for T in lens:
+        k[r + T // 2] *= 6.0
+        r += T
+    if prec == BF16:
+        q, k, v = _bf16_round(q), _bf16_round(k), _bf16_round(v)
+    out = eng.op_attention(q, k, v, lens, H, D, precision=prec)
+    ref = _attn_ref(q, k, v, lens, H, D)
+    tol = 2e-2 if prec == BF16 else 2e-5
+    assert np.isfinite(out).all()
+    assert np.abs(out - ref).max() < tol
+
+
+@pytest.mark.parametrize("prec", [BF16, F32])
+def test_fsmn_zero_padding_inside_each_utterance(prec):
+    eng = sub("engine")
+    rng = np.random.default_rng(5)
+    lens = [137, 3, 20, 1]
+    C, K = 256, 11
+    v = rng.standard_normal((sum(lens), C), dtype=np.float32)
+    w = rng.standard_normal((C, K), dtype=np.float32)
+    b = rng.standard_normal((C,), dtype=np.float32)
+    if prec == BF16:
+        v = _bf16_round(v)
+    out = eng.op_fsmn(v, w, b, lens, precision=prec)
+    r = 0
+    for T in lens:
+        x = torch.from_numpy(v[r:r + T]).t().unsqueeze(0)
+        ref = torch.nn.functional.conv1d(x, torch.from_numpy(w).unsqueeze(1), torch.from_numpy(b), padding=5, groups=C)[0].t().numpy()
+        assert np.abs(out[r:r + T] - ref).max() < 1e-4
+        r += T
+
+
+def test_ctc_collapse_edge_cases():
+    """Circular next-neighbour rule (SenseVoice/Export_SenseVoice.py:291-292)."""
+    eng = sub("engine")
+    from oracle.sensevoice_oracle import SenseVoiceOracle
+    cases = [
+        [0, 0, 0, 0],                   # all blank
+        [5, 5, 5, 5],                   # one run touching both ends: circular compare drops everything
+        [7, 0, 3, 3, 0, 7],             # first == last: final token dropped by the wrap-around
+        [1, 2, 2, 0, 2, 3],
+        [4],                            # single frame: compared with itself
+        list(np.random.default_rng(0).integers(0, 4, size=700)),   # > 256 frames: multi-pass compaction
+    ]
+    lens = [len(c) for c in cases]
+    flat = np.concatenate([np.asarray(c, dtype=np.int32) for c in cases])
+    got = eng.op_ctc_collapse(flat, lens, blank_id=0)
+    for c, g in zip(cases, got):
+        want = SenseVoiceOracle.ctc_collapse(torch.tensor(c, dtype=torch.int64), 0).numpy()
+        assert np.array_equal(g, want), (c[:10], g, want)

@@ -1,0 +1,117 @@
+"""GPU parity: the HIP SenseVoice path (through the C ABI) vs the reference-minted goldens and the oracle."""
+import numpy as np
+import pytest
+
+from conftest import sub
+from helpers import golden_cases, kaldi_audio, load_golden, sensevoice_setup
+from oracle.sensevoice_oracle import SenseVoiceOracle
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = 0, 1
+LOGIT_TOL_F32 = 1e-3     # north-star: logits within 1e-3 in fp32 mode
+
+
+def _session(cfg_name, prec):
+    cfg, ck = sensevoice_setup(cfg_name)
+    return cfg, ck, sub("engine").SenseVoiceSession.from_checkpoint(cfg, ck, precision=prec)
+
+
+def _taps(sess, lengths):
+    rows = sess.utterance_rows(lengths)
+    t = {k: sess.tap(k) for k in ("enc_in", "block0", "enc_out", "logits")}
+    ids = sess.tap("frame_ids", dtype=np.int32)[:, 0]
+    mel = sess.tap("mel")
+    return rows, t, ids, mel
+
+
+@pytest.mark.parametrize("fixture,cfg_name", [("sensevoice_tiny", "sensevoice_tiny"), ("sensevoice_small", "sensevoice_small")])
+def test_f32_mode_matches_reference_goldens(fixture, cfg_name):
+    """fp32 mode: token-for-token and logits within 1e-3 against goldens minted from the reference modules.
+    All cases of a fixture go through ONE ragged batch."""
+    g = load_golden(fixture)
+    cfg, ck, sess = _session(cfg_name, F32)
+    cases = [c for _, c in golden_cases(g)]
+    audios = [kaldi_audio(c["audio_seed"], c["n_samples"]) for c in cases]
+    sess.taps(True)
+    toks = sess.run(audios, [int(c["lang"]) for c in cases])
+    rows, t, ids, mel = _taps(sess, [a.size for a in audios])
+    f_off = 0
+    for c, tok, (r0, T) in zip(cases, toks, rows):
+        nf = cfg.n_frames(int(c["n_samples"]))
+        assert T == c["frame_ids"].shape[0]
+        lg = t["logits"][r0:r0 + T]
+        if "logits" in c:
+            assert np.abs(mel[f_off:f_off + nf] - c["mel"]).max() < 2e-4
+            assert np.abs(t["enc_in"][r0:r0 + T] - c["enc_in"]).max() < 2e-4
+            assert np.abs(t["block0"][r0:r0 + T] - c["block0"]).max() < LOGIT_TOL_F32
+            assert np.abs(t["enc_out"][r0:r0 + T] - c["enc_out"]).max() < LOGIT_TOL_F32
+            assert np.abs(lg - c["logits"]).max() < LOGIT_TOL_F32
+        else:
+            assert np.abs(mel[f_off:f_off + nf][::8] - c["mel"]).max() < 2e-4
+            assert np.abs(t["enc_out"][r0:r0 + T][::8] - c["enc_out"]).max() < LOGIT_TOL_F32
+            assert np.abs(lg[:, ::97] - c["logits_cols"]).max() < LOGIT_TOL_F32
+        assert np.abs(np.sort(lg, axis=1)[:, -1] - c["top1"]).max() < LOGIT_TOL_F32
+        # arg-max must agree wherever the reference's own top-1/top-2 margin exceeds the logit tolerance
+        safe = c["margin"] > 2 * LOGIT_TOL_F32
+        assert np.array_equal(ids[r0:r0 + T][safe], c["frame_ids"][safe])
+        if safe.all():
+            assert np.array_equal(tok, c["token_ids"])
+        f_off += nf
+
+
+def test_bf16_mode_tiny_close_to_oracle():
+    """bf16 MFMA mode: per-stage error budget and arg-max agreement outside near-ties."""
+    g = load_golden("sensevoice_tiny")
+    cfg, ck, sess = _session("sensevoice_tiny", BF16)
+    cases = [c for _, c in golden_cases(g)]
+    audios = [kaldi_audio(c["audio_seed"], c["n_samples"]) for c in cases]
+    sess.taps(True)
+    toks = sess.run(audios, [int(c["lang"]) for c in cases])
+    rows, t, ids, mel = _taps(sess, [a.size for a in audios])
+    for c, tok, (r0, T) in zip(cases, toks, rows):
+        assert np.abs(t["enc_in"][r0:r0 + T] - c["enc_in"]).max() < 2e-4          # front-end stays f32
+        err = np.abs(t["logits"][r0:r0 + T] - c["logits"]).max()
+        assert err < 0.15, err
+        safe = c["margin"] > 2 * 0.15
+        assert np.array_equal(ids[r0:r0 + T][safe], c["frame_ids"][safe])
+
+
+def test_bf16_full_size_batch_vs_oracle():
+    """SenseVoiceSmall dims, ragged batch incl. duplicates: batching must not change per-utterance results."""
+    cfg, ck, sess = _session("sensevoice_small", BF16)
+    orc = SenseVoiceOracle(cfg, ck)
+    lens = [128000, 38880, 128000, 16000, 7777]
+    audios = [kaldi_audio(100 + i, n) for i, n in enumerate(lens)]
+    audios[2] = audios[0].copy()
+    sess.taps(True)
+    toks = sess.run(audios, [0, 1, 0, 3, 6])
+    rows, t, ids, _ = _taps(sess, lens)
+    assert np.array_equal(toks[0], toks[2])
+    r0a, Ta = rows[0]
+    r0c, _ = rows[2]
+    assert np.array_equal(t["logits"][r0a:r0a + Ta], t["logits"][r0c:r0c + Ta])
+    agree = total = 0
+    for a, lang, (r0, T) in zip(audios, [0, 1, 0, 3, 6], rows):
+        st = orc.stages(a, lang)
+        err = np.abs(t["logits"][r0:r0 + T] - st["logits"]).max()
+        assert err < 0.25, err
+        srt = np.sort(st["logits"], axis=1)
+        safe = (srt[:, -1] - srt[:, -2]) > 0.5
+        assert np.array_equal(ids[r0:r0 + T][safe], st["frame_ids"][safe])
+        agree += int((ids[r0:r0 + T] == st["frame_ids"]).sum())
+        total += T
+    assert agree / total > 0.85
+
+
+def test_run_is_deterministic_and_rejects_bad_input():
+    cfg, ck, sess = _session("sensevoice_tiny", BF16)
+    a = kaldi_audio(3, 30000)
+    t1 = sess.run([a], [2])[0]
+    t2 = sess.run([a], [2])[0]
+    assert np.array_equal(t1, t2)
+    _lib = sub("_lib")
+    with pytest.raises(_lib.AsrError):
+        sess.run([a[:399]], [2])                # shorter than one 25 ms frame
+    with pytest.raises(_lib.AsrError):
+        sess.run([a], [99])                     # language selector out of range

@@ -308,14 +308,12 @@ extern "C" int asr_op_fsmn(int precision, const float* v, const float* w, const 
     HIP_CHECK(hipMemcpy(dru, pp.row_utt.data(), (size_t)pp.Mpad * 4, hipMemcpyHostToDevice));
     float* dout = (float*)t.alloc((size_t)channels * pp.Mpad * 4);
     if (precision == ASR_PRECISION_F32)
-      launch_fsmn<float>((const float*)dvt, pp.Mpad, dw, db, channels, ktaps, dplan, dru, pp.rows, dout, nullptr);
+      launch_fsmn<float>((const float*)dvt, pp.Mpad, dw, db, channels, ktaps, dplan, dru, pp.Mpad, dout, channels, nullptr);
     else
-      launch_fsmn<bf16_t>((const bf16_t*)dvt, pp.Mpad, dw, db, channels, ktaps, dplan, dru, pp.rows, dout, nullptr);
+      launch_fsmn<bf16_t>((const bf16_t*)dvt, pp.Mpad, dw, db, channels, ktaps, dplan, dru, pp.Mpad, dout, channels, nullptr);
     HIP_CHECK(hipDeviceSynchronize());
-    std::vector<float> ot((size_t)channels * pp.Mpad), oa((size_t)pp.Mpad * channels);
-    HIP_CHECK(hipMemcpy(ot.data(), dout, ot.size() * 4, hipMemcpyDeviceToHost));
-    for (int r = 0; r < pp.Mpad; ++r)
-      for (int c = 0; c < channels; ++c) oa[(size_t)r * channels + c] = ot[(size_t)c * pp.Mpad + r];
+    std::vector<float> oa((size_t)pp.Mpad * channels);
+    HIP_CHECK(hipMemcpy(oa.data(), dout, oa.size() * 4, hipMemcpyDeviceToHost));
     from_aligned(pp, seq_lens, batch, channels, oa, out);
   });
 }
@@ -343,5 +341,57 @@ extern "C" int asr_op_ctc_collapse(const int32_t* frame_ids, const int32_t* seq_
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy(token_ids, dtok, (size_t)batch * max_tokens * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(num_id, dnum, (size_t)batch * 4, hipMemcpyDeviceToHost));
+  });
+}
+
+extern "C" int asr_op_gemm_bench(int variant, int M, int N, int K, int epilogue, int iters, float* avg_ms) {
+  return asr_guard([&] {
+    ASR_REQUIRE(avg_ms && iters > 0, "op_gemm_bench: bad argument");
+    asr_require_device(0);
+    Tmp t;
+    const int Mp = round_up(M, 128);
+    auto rnd = [](size_t n, uint32_t seed) {
+      std::vector<bf16_t> v(n);
+      uint32_t x = seed;
+      for (size_t i = 0; i < n; ++i) { x = x * 1664525u + 1013904223u; v[i] = f32_to_bf16(((int)(x >> 9) % 2001 - 1000) * 1e-3f); }
+      return v;
+    };
+    std::vector<bf16_t> ha = rnd((size_t)Mp * K, 1), hw = rnd((size_t)N * K, 2);
+    bf16_t* da = (bf16_t*)t.alloc(ha.size() * 2);
+    bf16_t* dw = (bf16_t*)t.alloc(hw.size() * 2);
+    HIP_CHECK(hipMemcpy(da, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    float* bias = (float*)t.alloc((size_t)N * 4);
+    float* addm = (float*)t.alloc((size_t)Mp * N * 4);
+    float* addt = (float*)t.alloc((size_t)Mp * N * 4);
+    float* of32 = (float*)t.alloc((size_t)Mp * N * 4);
+    bf16_t* olo = (bf16_t*)t.alloc((size_t)Mp * N * 2);
+    bf16_t* ot = (bf16_t*)t.alloc((size_t)Mp * N * 2);
+    GemmArgs g;
+    g.A = da; g.lda = K; g.W = dw; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = bias;
+    switch (epilogue) {
+      case 0: g.out_lo = olo; g.ld_out_lo = N; break;
+      case 1: g.out_lo = olo; g.ld_out_lo = N; g.act = ACT_RELU; break;
+      case 2: g.add = addm; g.ld_add = N; g.out_f32 = of32; g.ld_out_f32 = N; break;
+      case 3: g.bias = nullptr; g.add = addt; g.ld_add = N; g.add2 = addm; g.ld_add2 = N; g.out_f32 = of32; g.ld_out_f32 = N; break;
+      case 4: g.out_t = ot; g.ld_out_t = Mp; break;
+      default: ASR_THROW(ASR_ERR_INVALID, "op_gemm_bench: unknown epilogue %d", epilogue);
+    }
+    g.dbg = variant >> 8;
+    gemm_set_variant(variant & 0xff);
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch_gemm_bf16(g, nullptr);
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) launch_gemm_bf16(g, nullptr);
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    gemm_set_variant(-1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
   });
 }

@@ -11,20 +11,23 @@ struct GemmArgs {
   const void* W = nullptr; int ldw = 0;     // [N][K]
   int M = 0, N = 0, K = 0;                  // M = valid rows (stores are masked to m < M); N % 128 == 0; K % 64 == 0
   const float* bias = nullptr;              // [N] (nullable)
-  const float* add_t = nullptr; int ld_add_t = 0;   // + add_t[n * ld + m]  (transposed f32 matrix, nullable)
-  const float* add = nullptr; int ld_add = 0;       // + add[m * ld + n]    (row-major f32, nullable)
+  const float* add = nullptr; int ld_add = 0;       // + add[m * ld + n]   (row-major f32, nullable; readable to the tile edge)
+  const float* add2 = nullptr; int ld_add2 = 0;     // + add2[m * ld + n]  (second row-major f32 term, nullable)
   int act = ACT_NONE;
   float* out_f32 = nullptr; int ld_out_f32 = 0;     // row-major f32 out (nullable)
-  void* out_lo = nullptr; int ld_out_lo = 0;        // row-major out in the operand dtype, for n < n_split (nullable)
-  void* out_t = nullptr; int ld_out_t = 0;          // transposed out in the operand dtype for n >= n_split: out_t[(n-n_split)*ld + m]
-  int n_split = 1 << 30;
+  void* out_lo = nullptr; int ld_out_lo = 0;        // row-major out in the operand dtype (nullable)
+  // transposed out in the operand dtype: out_t[n * ld + m]. Exclusive with every row-major term above
+  // (the kernel then runs in the un-swapped MFMA orientation: 4 consecutive m per lane).
+  void* out_t = nullptr; int ld_out_t = 0;
   // fused row arg-max over n < n_valid (CTC / LM head): partial (max, idx) per 64-column slab
   float* amax_val = nullptr; int32_t* amax_idx = nullptr; int n_valid = 0;
+  int dbg = 0;   // tuning ablations (bench hook only): 1 = no refills, 2 = no MFMA, 4 = no epilogue
 };
 
 // operand dtype selects the kernel: bf16 MFMA (performance mode) or exact-f32 MFMA (verification mode)
 void launch_gemm_bf16(const GemmArgs& g, hipStream_t s);
 void launch_gemm_f32(const GemmArgs& g, hipStream_t s);
+void gemm_set_variant(int v);   // tuning hook: -1 = built-in heuristic
 
 // reduce the per-slab arg-max partials written by the GEMM epilogue: ids[m] = first index of the row max
 void launch_argmax_reduce(const float* val, const int32_t* idx, int M, int n_slabs, int32_t* ids, hipStream_t s);

@@ -1,30 +1,45 @@
-// MFMA GEMMs for gfx950 with fused epilogues (bias / activation / residual adds / transposed
-// stores / row arg-max). C[M][N] = A[M][K] * W[N][K]^T.
+// MFMA GEMMs for gfx950 with fused epilogues (bias / activation / residual adds / transposed store /
+// row arg-max). C[M][N] = A[M][K] * W[N][K]^T.
 //
-// bf16 kernel: 128x128x64 tile, 4 waves (2x2), each wave 64x64 = 4x4 fragments of
-// v_mfma_f32_16x16x32_bf16; operands staged by global_load_lds_dwordx4 (LDS-DMA, no VGPR round
-// trip) into a double-buffered LDS image. The LDS image is lane-linear, so the 16-byte-slot XOR
-// swizzle (slot ^= row & 7) is applied on the per-lane GLOBAL source address and again on the
-// ds_read_b128 address (cdna_hip_programming.md rule 21 / T2). Workgroup ids are remapped so each
-// XCD (private L2) walks a contiguous range of output tiles sharing A rows (T1).
+// bf16 kernel: 128 x BN x 64 tile (BN = 128 or 64), 4 waves (2 x 2), v_mfma_f32_16x16x32_bf16.
+//  * Operands are staged by global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip) into a STAGES-deep LDS
+//    ring. The LDS image of a DMA is lane-linear, so the 16-byte-slot XOR swizzle (slot ^= row & 7) that
+//    makes the ds_read_b128 fragment reads conflict-free is applied on the per-lane GLOBAL source address
+//    and again on the read address (cdna_hip_programming.md rule 21 / T2).
+//  * One raw s_barrier per K-step; the DMA queue is never drained in the loop: `s_waitcnt vmcnt(G*ahead)`
+//    retires only the tile about to be read (T3+T4; __syncthreads() would drain the queue).
+//  * Workgroup ids are remapped so each XCD (private L2) walks a contiguous range of tiles (T1).
+//  * Orientation. The product is computed as mfma(W-fragment, A-fragment): the C fragment then holds, per
+//    lane, FOUR CONSECUTIVE COLUMNS of one output row, so bias / residual loads and the row-major bf16 / f32
+//    stores are direct 8- / 16-byte accesses from registers -- no LDS transpose, no extra barrier. The
+//    un-swapped orientation (four consecutive ROWS per lane) is used only for the transposed store (V^T).
+//  * Epilogues are compile-time specialised (EPI / ACT) so they are straight-line code.
 //
-// f32 kernel: same tiling on v_mfma_f32_16x16x4_f32 (exact f32 FMA chains) for verification mode.
+// f32 kernel: same tile on v_mfma_f32_16x16x4_f32 (exact f32 FMA chains) for verification mode.
 #include "gemm.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
+constexpr int BM = 128;
 constexpr int BK16 = 64;                       // bf16 K-step
-constexpr int LDS_TILE_BYTES = BM * BK16 * 2;  // 16 KiB per operand tile
 
-__device__ __forceinline__ float apply_act(float v, int act) {
+enum { E_ADD = 1, E_ADD2 = 2, E_F32 = 4, E_LO = 8, E_AMAX = 32, E_BIAS = 64 };
+
+template <int ACT>
+__device__ __forceinline__ float apply_act_ct(float v) {
+  if constexpr (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+  else if constexpr (ACT == ACT_GELU_ERF) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  else if constexpr (ACT == ACT_GELU_TANH) {
+    const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+    return 0.5f * v * (1.0f + tanhf(u));
+  } else return v;
+}
+
+__device__ __forceinline__ float apply_act_rt(float v, int act) {
   switch (act) {
-    case ACT_RELU: return fmaxf(v, 0.0f);
-    case ACT_GELU_ERF: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    case ACT_GELU_TANH: {
-      const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
-      return 0.5f * v * (1.0f + tanhf(u));
-    }
+    case ACT_RELU: return apply_act_ct<ACT_RELU>(v);
+    case ACT_GELU_ERF: return apply_act_ct<ACT_GELU_ERF>(v);
+    case ACT_GELU_TANH: return apply_act_ct<ACT_GELU_TANH>(v);
     default: return v;
   }
 }
@@ -37,167 +52,220 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
-template <typename OutT>
-__device__ __forceinline__ void epilogue_tile(const GemmArgs& g, const f32x4_t& acc, int m0, int n) {
-  // this lane holds C[m0 + r][n], r = 0..3
-  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-  if (g.bias) {
-    const float b = g.bias[n];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] += b;
-  }
-  if (g.add_t) {
-    const float4 t = *reinterpret_cast<const float4*>(g.add_t + (size_t)n * g.ld_add_t + m0);
-    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-  }
-  if (g.add) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] += g.add[(size_t)(m0 + r) * g.ld_add + n];
-  }
-  if (g.act != ACT_NONE) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], g.act);
-  }
-  if (g.out_f32) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (m0 + r < g.M) g.out_f32[(size_t)(m0 + r) * g.ld_out_f32 + n] = v[r];
-  }
-  if (n < g.n_split) {
-    if (g.out_lo) {
-      OutT* o = reinterpret_cast<OutT*>(g.out_lo);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (m0 + r < g.M) Elem<OutT>::store(o + (size_t)(m0 + r) * g.ld_out_lo + n, v[r]);
-    }
-  } else if (g.out_t) {
-    OutT* o = reinterpret_cast<OutT*>(g.out_t) + (size_t)(n - g.n_split) * g.ld_out_t + m0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (m0 + r < g.M) Elem<OutT>::store(o + r, v[r]);
-  }
+template <int EPI, int F> __device__ __forceinline__ bool epi_has(const void* p) {
+  if constexpr (EPI < 0) return p != nullptr; else return (EPI & F) != 0;
 }
 
-// per-row arg-max over this wave's 64 columns; acc[i][j] fragments, lane holds col (lane&15)+16j
-__device__ __forceinline__ void epilogue_argmax(const GemmArgs& g, f32x4_t (&acc)[4][4], int m_wave, int n_wave, int lane) {
-  const int slab = n_wave >> 6;
-  const int n_slabs = g.N >> 6;
+template <typename OutT> __device__ __forceinline__ void store4(OutT* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  uint2 w;
+  w.x = pack_bf16x2(a, b);
+  w.y = pack_bf16x2(c, d);
+  *reinterpret_cast<uint2*>(p) = w;
+}
+
+// ---- swapped orientation: acc[i][j][r] = C[m_wave + 16 i + (lane & 15)][n_wave + 16 j + 4 (lane >> 4) + r]
+template <typename OutT, int ACT, int EPI, int NJ>
+__device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[4][NJ], int m_wave, int n_wave, int lane) {
+  const int frow = lane & 15, fgrp = lane >> 4;
+  const bool has_bias = epi_has<EPI, E_BIAS>(g.bias), has_add = epi_has<EPI, E_ADD>(g.add), has_add2 = epi_has<EPI, E_ADD2>(g.add2);
+  const bool want_f32 = epi_has<EPI, E_F32>(g.out_f32), want_lo = epi_has<EPI, E_LO>(g.out_lo);
+  if (epi_has<EPI, E_AMAX>(g.amax_val)) {
+    const int n_slabs = g.N / (NJ * 16), slab = n_wave / (NJ * 16);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int i = 0; i < 4; ++i) {
       float best = -INFINITY;
       int bidx = 0x7fffffff;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n_wave + j * 16 + (lane & 15);
-        float v = acc[i][j][r] + (g.bias ? g.bias[n] : 0.0f);
-        if (n >= g.n_valid) v = -INFINITY;
-        if (v > best) { best = v; bidx = n; }   // j ascending => lowest index kept on ties
+      for (int j = 0; j < NJ; ++j) {
+        const int n0 = n_wave + j * 16 + fgrp * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[i][j][r] + (has_bias ? g.bias[n0 + r] : 0.0f);
+          if (n0 + r >= g.n_valid) v = -INFINITY;
+          if (v > best) { best = v; bidx = n0 + r; }          // ascending n inside the lane: first max wins
+        }
       }
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
+      for (int o = 16; o < 64; o <<= 1) {
         const float ov = __shfl_xor(best, o, 64);
         const int oi = __shfl_xor(bidx, o, 64);
         if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
       }
-      const int m = m_wave + i * 16 + (lane >> 4) * 4 + r;
-      if ((lane & 15) == 0 && m < g.M) {
+      const int m = m_wave + i * 16 + frow;
+      if (fgrp == 0 && m < g.M) {
         g.amax_val[(size_t)m * n_slabs + slab] = best;
         g.amax_idx[(size_t)m * n_slabs + slab] = bidx;
       }
     }
   }
+  if (!(want_f32 || want_lo)) return;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = n_wave + j * 16 + fgrp * 4;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_bias) b4 = *reinterpret_cast<const float4*>(g.bias + n);
+    float4 t1[4], t2[4];
+    if (has_add) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)      // rows up to the 128-row tile edge are readable (padded buffers)
+        t1[i] = *reinterpret_cast<const float4*>(g.add + (size_t)(m_wave + i * 16 + frow) * g.ld_add + n);
+    }
+    if (has_add2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        t2[i] = *reinterpret_cast<const float4*>(g.add2 + (size_t)(m_wave + i * 16 + frow) * g.ld_add2 + n);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m_wave + i * 16 + frow;
+      float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+      if (has_add) { v0 += t1[i].x; v1 += t1[i].y; v2 += t1[i].z; v3 += t1[i].w; }
+      if (has_add2) { v0 += t2[i].x; v1 += t2[i].y; v2 += t2[i].z; v3 += t2[i].w; }
+      if constexpr (ACT >= 0) {
+        v0 = apply_act_ct<ACT>(v0); v1 = apply_act_ct<ACT>(v1); v2 = apply_act_ct<ACT>(v2); v3 = apply_act_ct<ACT>(v3);
+      } else {
+        v0 = apply_act_rt(v0, g.act); v1 = apply_act_rt(v1, g.act); v2 = apply_act_rt(v2, g.act); v3 = apply_act_rt(v3, g.act);
+      }
+      if (m < g.M) {
+        if (want_f32) store4<float>(g.out_f32 + (size_t)m * g.ld_out_f32 + n, v0, v1, v2, v3);
+        if (want_lo) store4<OutT>(reinterpret_cast<OutT*>(g.out_lo) + (size_t)m * g.ld_out_lo + n, v0, v1, v2, v3);
+      }
+    }
+  }
 }
 
-// ------------------------------------------------------------------------------------ bf16
-__global__ __launch_bounds__(256, 2) void gemm_bf16_128x128x64(const GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 buffers][A 16K | W 16K]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// ---- un-swapped orientation: acc[i][j][r] = C[m_wave + 16 i + 4 (lane >> 4) + r][n_wave + 16 j + (lane & 15)]
+template <typename OutT, int NJ>
+__device__ __forceinline__ void epilogue_transposed(const GemmArgs& g, f32x4_t (&acc)[4][NJ], int m_wave, int n_wave, int lane) {
+  const int frow = lane & 15, fgrp = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = n_wave + j * 16 + frow;
+    const float b = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m0 = m_wave + i * 16 + fgrp * 4;
+      OutT* o = reinterpret_cast<OutT*>(g.out_t) + (size_t)n * g.ld_out_t + m0;
+      if (m0 + 3 < g.M) {
+        store4<OutT>(o, acc[i][j][0] + b, acc[i][j][1] + b, acc[i][j][2] + b, acc[i][j][3] + b);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (m0 + r < g.M) Elem<OutT>::store(o + r, acc[i][j][r] + b);
+      }
+    }
+  }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ------------------------------------------------------------------------------------ bf16, ring-pipelined
+template <int BN_, int STAGES, int ACT, int EPI, bool SWAP>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_pipe(const GemmArgs g) {
+  constexpr int WN = BN_ / 2;                     // columns per wave
+  constexpr int NJ = WN / 16;                     // column fragments per wave
+  constexpr int STAGE_BYTES = BM * 128 + BN_ * 128;
+  constexpr int W_PASSES = BN_ / 32;              // LDS-DMA instructions per thread for the W tile
+  constexpr int G = 4 + W_PASSES;                 // LDS-DMA instructions per thread per stage
+  static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = g.N / BN;
+  const int tiles_n = g.N / BN_;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
 
-  // staging: each wave-instruction moves 8 rows x 128 B (8 slots of 16 B) = 1 KiB, lane-linear in LDS
-  const int srow = lane >> 3;                         // 0..7 within the 8-row group
-  const int sslot = (lane & 7) ^ srow;                // source slot: un-swizzle on the global side
+  // staging: one wave-instruction moves 8 rows x 128 B (8 slots of 16 B) = 1 KiB, lane-linear in LDS
+  const int srow = lane >> 3;
+  const int sslot = (lane & 7) ^ srow;            // un-swizzle on the global side
   const bf16_t* a_src = reinterpret_cast<const bf16_t*>(g.A) + (size_t)(tile_m * BM + wave * 8 + srow) * g.lda + sslot * 8;
-  const bf16_t* w_src = reinterpret_cast<const bf16_t*>(g.W) + (size_t)(tile_n * BN + wave * 8 + srow) * g.ldw + sslot * 8;
+  const bf16_t* w_src = reinterpret_cast<const bf16_t*>(g.W) + (size_t)(tile_n * BN_ + wave * 8 + srow) * g.ldw + sslot * 8;
   const size_t a_pass = (size_t)32 * g.lda, w_pass = (size_t)32 * g.ldw;
 
-  auto stage = [&](int buf, int k0) {
-    unsigned char* base = smem + buf * (2 * LDS_TILE_BYTES) + wave * 1024;
+  auto stage = [&](int slot, int k0) {
+    unsigned char* base = smem + slot * STAGE_BYTES + wave * 1024;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < 4; ++p)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src + p * a_pass + k0),
                                        (__attribute__((address_space(3))) void*)(base + p * 4096), 16, 0, 0);
-    }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < W_PASSES; ++p)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src + p * w_pass + k0),
-                                       (__attribute__((address_space(3))) void*)(base + LDS_TILE_BYTES + p * 4096), 16, 0, 0);
-    }
+                                       (__attribute__((address_space(3))) void*)(base + BM * 128 + p * 4096), 16, 0, 0);
   };
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int nk = g.K / BK16;
   const int frow = lane & 15, fgrp = lane >> 4;
-  stage(0, 0);
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) stage(s, s * BK16);
+
+  // per-lane fragment offsets inside a stage (swizzled), hoisted out of the K loop
+  int a_off[2][4], w_off[2][NJ];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int c = kk * 4 + fgrp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = wm * 64 + i * 16 + frow; a_off[kk][i] = r * 128 + ((c ^ (r & 7)) << 4); }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int r = wn * WN + j * 16 + frow; w_off[kk][j] = BM * 128 + r * 128 + ((c ^ (r & 7)) << 4); }
+  }
+
   for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();   // tile kt landed (vmcnt(0) is part of the barrier with LDS-DMA in flight); buf (kt+1)&1 is free
-    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK16);
-    const unsigned char* As = smem + (kt & 1) * (2 * LDS_TILE_BYTES);
-    const unsigned char* Ws = As + LDS_TILE_BYTES;
+    const int ahead = min(nk, kt + STAGES - 1) - (kt + 1);      // tiles allowed to stay in flight
+    if (STAGES >= 4 && ahead >= 2) wait_vmcnt<2 * G>();
+    else if (STAGES >= 3 && ahead >= 1) wait_vmcnt<G>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // tile kt landed for every wave; every wave is done reading slot (kt-1) % S
+    if (kt + STAGES - 1 < nk && !(g.dbg & 1)) stage((kt + STAGES - 1) % STAGES, (kt + STAGES - 1) * BK16);
+    if (g.dbg & 2) continue;
+    const unsigned char* St = smem + ((g.dbg & 1) ? 0 : (kt % STAGES)) * STAGE_BYTES;
+    bf16x8_t af[2][4], wf[2][NJ];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_t af[4], wf[4];
-      const int c = kk * 4 + fgrp;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = wm * 64 + i * 16 + frow;
-        af[i] = *reinterpret_cast<const bf16x8_t*>(As + r * 128 + ((c ^ (r & 7)) << 4));
-      }
+      for (int i = 0; i < 4; ++i) af[kk][i] = *reinterpret_cast<const bf16x8_t*>(St + a_off[kk][i]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = wn * 64 + j * 16 + frow;
-        wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + r * 128 + ((c ^ (r & 7)) << 4));
-      }
+      for (int j = 0; j < NJ; ++j) wf[kk][j] = *reinterpret_cast<const bf16x8_t*>(St + w_off[kk][j]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
-    }
+        for (int j = 0; j < NJ; ++j) {
+          if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], wf[kk][j], acc[i][j], 0, 0, 0);
+        }
   }
 
-  const int m_wave = tile_m * BM + wm * 64, n_wave = tile_n * BN + wn * 64;
-  if (g.amax_val) {
-    epilogue_argmax(g, acc, m_wave, n_wave, lane);
-    if (!g.out_f32) return;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      epilogue_tile<bf16_t>(g, acc[i][j], m_wave + i * 16 + fgrp * 4, n_wave + j * 16 + frow);
+  const int m_wave = tile_m * BM + wm * 64, n_wave = tile_n * BN_ + wn * WN;
+  if ((g.dbg & 4) && acc[0][0][0] != 12345.678f) return;
+  if constexpr (SWAP) epilogue_rows<bf16_t, ACT, EPI, NJ>(g, acc, m_wave, n_wave, lane);
+  else epilogue_transposed<bf16_t, NJ>(g, acc, m_wave, n_wave, lane);
 }
 
-// ------------------------------------------------------------------------------------ f32
+// ------------------------------------------------------------------------------------ f32 (verification mode)
 constexpr int BK32 = 16;
 constexpr int LDF = BK32 + 1;    // padded LDS row (floats): conflict-free fragment reads
 
+template <bool SWAP>
 __global__ __launch_bounds__(256, 2) void gemm_f32_128x128x16(const GemmArgs g) {
   __shared__ float As[BM * LDF];
-  __shared__ float Ws[BN * LDF];
+  __shared__ float Ws[128 * LDF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = g.N / BN;
+  const int tiles_n = g.N / 128;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
   const float* A = reinterpret_cast<const float*>(g.A);
@@ -213,10 +281,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_128x128x16(const GemmArgs g) 
   // 128 rows x 16 floats = 512 float4 per operand; thread t loads float4 #t and #t+256
   const int lrow = tid >> 2, lcol = (tid & 3) * 4;
   for (int k0 = 0; k0 < g.K; k0 += BK32) {
-    float4 a0 = *reinterpret_cast<const float4*>(A + (size_t)(tile_m * BM + lrow) * g.lda + k0 + lcol);
-    float4 a1 = *reinterpret_cast<const float4*>(A + (size_t)(tile_m * BM + lrow + 64) * g.lda + k0 + lcol);
-    float4 w0 = *reinterpret_cast<const float4*>(W + (size_t)(tile_n * BN + lrow) * g.ldw + k0 + lcol);
-    float4 w1 = *reinterpret_cast<const float4*>(W + (size_t)(tile_n * BN + lrow + 64) * g.ldw + k0 + lcol);
+    const float4 a0 = *reinterpret_cast<const float4*>(A + (size_t)(tile_m * BM + lrow) * g.lda + k0 + lcol);
+    const float4 a1 = *reinterpret_cast<const float4*>(A + (size_t)(tile_m * BM + lrow + 64) * g.lda + k0 + lcol);
+    const float4 w0 = *reinterpret_cast<const float4*>(W + (size_t)(tile_n * 128 + lrow) * g.ldw + k0 + lcol);
+    const float4 w1 = *reinterpret_cast<const float4*>(W + (size_t)(tile_n * 128 + lrow + 64) * g.ldw + k0 + lcol);
     __syncthreads();
     float* pa = As + lrow * LDF + lcol;
     pa[0] = a0.x; pa[1] = a0.y; pa[2] = a0.z; pa[3] = a0.w;
@@ -237,20 +305,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_128x128x16(const GemmArgs g) 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], wf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j], af[i], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], wf[j], acc[i][j], 0, 0, 0);
+        }
     }
   }
-  const int m_wave = tile_m * BM + wm * 64, n_wave = tile_n * BN + wn * 64;
-  if (g.amax_val) {
-    epilogue_argmax(g, acc, m_wave, n_wave, lane);
-    if (!g.out_f32) return;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      epilogue_tile<float>(g, acc[i][j], m_wave + i * 16 + fgrp * 4, n_wave + j * 16 + frow);
+  const int m_wave = tile_m * BM + wm * 64, n_wave = tile_n * 128 + wn * 64;
+  if constexpr (SWAP) epilogue_rows<float, -1, -1, 4>(g, acc, m_wave, n_wave, lane);
+  else epilogue_transposed<float, 4>(g, acc, m_wave, n_wave, lane);
 }
 
 __global__ void argmax_reduce_kernel(const float* __restrict__ val, const int32_t* __restrict__ idx, int M, int n_slabs,
@@ -277,31 +340,79 @@ __global__ void argmax_reduce_kernel(const float* __restrict__ val, const int32_
 void check_args(const GemmArgs& g, int kstep, int elt) {
   ASR_REQUIRE(g.A && g.W, "gemm: null operand");
   ASR_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
-  ASR_REQUIRE(g.N % BN == 0, "gemm: N=%d must be a multiple of %d", g.N, BN);
+  ASR_REQUIRE(g.N % 128 == 0, "gemm: N=%d must be a multiple of 128", g.N);
   ASR_REQUIRE(g.K % kstep == 0, "gemm: K=%d must be a multiple of %d", g.K, kstep);
   ASR_REQUIRE((g.lda * elt) % 16 == 0 && (g.ldw * elt) % 16 == 0, "gemm: leading dims must be 16-byte multiples");
-  if (g.add_t) ASR_REQUIRE(g.ld_add_t % 4 == 0, "gemm: ld_add_t must be a multiple of 4");
+  if (g.add) ASR_REQUIRE(g.ld_add % 4 == 0, "gemm: ld_add must be a multiple of 4");
+  if (g.add2) ASR_REQUIRE(g.ld_add2 % 4 == 0, "gemm: ld_add2 must be a multiple of 4");
+  if (g.out_f32) ASR_REQUIRE(g.ld_out_f32 % 4 == 0, "gemm: ld_out_f32 must be a multiple of 4");
+  if (g.out_lo) ASR_REQUIRE(g.ld_out_lo % 4 == 0, "gemm: ld_out_lo must be a multiple of 4");
+  if (g.out_t) {
+    ASR_REQUIRE(!(g.add || g.add2 || g.out_f32 || g.out_lo || g.amax_val || g.act != ACT_NONE),
+                "gemm: the transposed store excludes row-major epilogue terms");
+    ASR_REQUIRE(g.ld_out_t % 4 == 0, "gemm: ld_out_t must be a multiple of 4");
+  }
 }
+
+template <int BN_, int STAGES, int ACT, int EPI, bool SWAP>
+void launch_pipe_inst(const GemmArgs& g, hipStream_t s) {
+  constexpr int lds = STAGES * (BM * 128 + BN_ * 128);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pipe<BN_, STAGES, ACT, EPI, SWAP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int grid = ((g.M + BM - 1) / BM) * (g.N / BN_);
+  hipLaunchKernelGGL((gemm_bf16_pipe<BN_, STAGES, ACT, EPI, SWAP>), dim3(grid), dim3(256), lds, s, g);
+  HIP_CHECK(hipGetLastError());
+}
+
+// Specialised epilogues used on the hot path; anything else runs the generic (runtime-checked) instantiation.
+template <int BN_, int STAGES>
+void launch_pipe(const GemmArgs& g, hipStream_t s) {
+  if (g.out_t) { launch_pipe_inst<BN_, STAGES, ACT_NONE, 0, false>(g, s); return; }
+  const int epi = (g.add ? E_ADD : 0) | (g.add2 ? E_ADD2 : 0) | (g.out_f32 ? E_F32 : 0) | (g.out_lo ? E_LO : 0) |
+                  (g.amax_val ? E_AMAX : 0) | (g.bias ? E_BIAS : 0);
+#define ASR_GEMM_CASE(ACT_, EPI_) \
+  if (g.act == (ACT_) && epi == (EPI_)) { launch_pipe_inst<BN_, STAGES, ACT_, EPI_, true>(g, s); return; }
+  ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_LO)                    // q|k projection, cross-KV, plain projections
+  ASR_GEMM_CASE(ACT_RELU, E_BIAS | E_LO)                    // SANM FFN-1
+  ASR_GEMM_CASE(ACT_GELU_ERF, E_BIAS | E_LO)                // Whisper fc1
+  ASR_GEMM_CASE(ACT_GELU_TANH, E_BIAS | E_LO)
+  ASR_GEMM_CASE(ACT_NONE, E_ADD | E_ADD2 | E_F32)           // SANM out-proj: + FSMN memory + residual
+  ASR_GEMM_CASE(ACT_NONE, E_ADD | E_F32)                    // SANM out-proj of the first block (no residual)
+  ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_ADD | E_F32)           // FFN-2 / out-proj with bias + residual
+  ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_AMAX)                  // CTC / LM head arg-max
+#undef ASR_GEMM_CASE
+  launch_pipe_inst<BN_, STAGES, -1, -1, true>(g, s);
+}
+
+int g_gemm_variant = -1;   // -1 = heuristic
 
 }  // namespace
 
+void gemm_set_variant(int v) { g_gemm_variant = v; }
+
 void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
   check_args(g, BK16, 2);
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_128x128x64),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * LDS_TILE_BYTES));
-    attr_set = true;
+  int v = g_gemm_variant;
+  if (v < 0) v = 4;
+  if (g.amax_val && (v == 3 || v == 4)) v = 2;     // arg-max partials are per 64-column slab (BN = 128)
+  switch (v) {
+    case 1: launch_pipe<128, 3>(g, s); break;
+    case 2: launch_pipe<128, 2>(g, s); break;
+    case 3: launch_pipe<64, 3>(g, s); break;
+    case 4: launch_pipe<64, 2>(g, s); break;
+    default: ASR_THROW(ASR_ERR_INVALID, "gemm: unknown variant %d", v);
   }
-  const int grid = ((g.M + BM - 1) / BM) * (g.N / BN);
-  hipLaunchKernelGGL(gemm_bf16_128x128x64, dim3(grid), dim3(256), 4 * LDS_TILE_BYTES, s, g);
-  HIP_CHECK(hipGetLastError());
 }
 
 void launch_gemm_f32(const GemmArgs& g, hipStream_t s) {
   check_args(g, BK32, 4);
-  const int grid = ((g.M + BM - 1) / BM) * (g.N / BN);
-  hipLaunchKernelGGL(gemm_f32_128x128x16, dim3(grid), dim3(256), 0, s, g);
+  const int grid = ((g.M + BM - 1) / BM) * (g.N / 128);
+  if (g.out_t) hipLaunchKernelGGL(gemm_f32_128x128x16<false>, dim3(grid), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(gemm_f32_128x128x16<true>, dim3(grid), dim3(256), 0, s, g);
   HIP_CHECK(hipGetLastError());
 }
 

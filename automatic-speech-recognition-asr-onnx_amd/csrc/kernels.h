@@ -55,9 +55,6 @@ template <typename OutT>
 void launch_layernorm(const float* x, int ld_x, int rows, int D, const float* gamma, const float* beta, float eps,
                       OutT* out, int ld_out, int fill_to, hipStream_t s);
 
-// f32 -> f32 LayerNorm written to a separate f32 buffer (after_norm / tp_norm on the residual stream)
-void launch_layernorm_f32_inplace(float* x, int ld_x, int rows, int D, const float* gamma, const float* beta, float eps,
-                                  hipStream_t s);
 
 // ---- multi-head self-attention over packed ragged utterances (no mask inside an utterance).
 // q, k: [rows][ld] row-major; vt: [H*HD][ld_vt] (time-contiguous); ctx out: [rows][ld_ctx].
@@ -76,10 +73,11 @@ void launch_attention_bf16_hd64(const AttnArgs& a, hipStream_t s);
 void launch_attention_f32(const AttnArgs& a, int head_dim, hipStream_t s);
 
 // ---- FSMN memory: depth-wise conv (k taps, zero padded inside each utterance) over V + bias.
-// vt: [C][ld] time-contiguous, out_t: f32 [C][ld]  (Export_SenseVoice.py:217-220,240-244)
+// vt: [C][ld] time-contiguous (all rows of the padded packed layout); out: f32 row-major [n_rows_pad][ld_out]
+// (Export_SenseVoice.py:217-220,240-244). n_rows_pad is a multiple of 64 (pad rows are written as zeros).
 template <typename InT>
 void launch_fsmn(const InT* vt, int ld, const float* w, const float* b, int C, int ktaps, const UttPlan* plan,
-                 const int32_t* row_utt, int n_rows, float* out_t, hipStream_t s);
+                 const int32_t* row_utt, int n_rows_pad, float* out, int ld_out, hipStream_t s);
 
 // ---- CTC greedy collapse, circular next-neighbour rule (Export_SenseVoice.py:290-296)
 void launch_ctc_collapse(const int32_t* frame_ids, const UttPlan* plan, int n_utts, int blank_id, int32_t* token_ids,

@@ -121,6 +121,9 @@ __global__ void lfr_cmvn_kernel(const LfrArgs a) {
 }
 
 // ------------------------------------------------------------------------------------ LayerNorm
+// One wave per row; the row (D <= 1280) is read ONCE as float4 per lane and held in registers; two-pass
+// mean / variance on the registers (same arithmetic order class as torch's), wave-shuffle reductions.
+constexpr int LN_MAXV = 5;   // float4 per lane: 5 * 4 * 64 = 1280 columns
 template <typename OutT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ld_x, int rows, int D,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -129,18 +132,46 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* xr = x + (size_t)row * ld_x;
+  float4 v[LN_MAXV];
   float s = 0.0f;
-  for (int i = lane; i < D; i += 64) s += xr[i];
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    const int i = k * 256 + lane * 4;
+    v[k] = (i < D) ? *reinterpret_cast<const float4*>(xr + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  }
   const float mean = wave_sum(s) / (float)D;
-  float v = 0.0f;
-  for (int i = lane; i < D; i += 64) { const float d = xr[i] - mean; v += d * d; }
-  const float var = wave_sum(v) / (float)D;
+  float q = 0.0f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    const int i = k * 256 + lane * 4;
+    if (i < D) {
+      const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float var = wave_sum(q) / (float)D;
   const float rstd = 1.0f / sqrtf(var + eps);
   OutT* o = out + (size_t)row * ld_out;
-  for (int i = lane; i < D; i += 64) {
-    float y = (xr[i] - mean) * rstd;
-    if (gamma) y = y * gamma[i] + beta[i];
-    Elem<OutT>::store(o + i, y);
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    const int i = k * 256 + lane * 4;
+    if (i < D) {
+      float y0 = (v[k].x - mean) * rstd, y1 = (v[k].y - mean) * rstd, y2 = (v[k].z - mean) * rstd, y3 = (v[k].w - mean) * rstd;
+      if (gamma) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + i);
+        const float4 b = *reinterpret_cast<const float4*>(beta + i);
+        y0 = y0 * g.x + b.x; y1 = y1 * g.y + b.y; y2 = y2 * g.z + b.z; y3 = y3 * g.w + b.w;
+      }
+      if constexpr (sizeof(OutT) == 4) {
+        *reinterpret_cast<float4*>(o + i) = make_float4(y0, y1, y2, y3);
+      } else {
+        uint2 w;
+        w.x = pack_bf16x2(y0, y1);
+        w.y = pack_bf16x2(y2, y3);
+        *reinterpret_cast<uint2*>(o + i) = w;
+      }
+    }
   }
   for (int i = D + lane; i < fill_to; i += 64) Elem<OutT>::store(o + i, 0.0f);
 }
@@ -329,29 +360,89 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs a, int HD)
 }
 
 // ------------------------------------------------------------------------------------ FSMN
-template <typename InT>
-__global__ void fsmn_kernel(const InT* __restrict__ vt, int ld, const float* __restrict__ w, const float* __restrict__ b,
-                            int ktaps, const UttPlan* __restrict__ plan, const int32_t* __restrict__ row_utt, int n_rows,
-                            float* __restrict__ out_t) {
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  const int c = blockIdx.y;
-  if (m >= n_rows) return;
-  const int u = row_utt[m];
-  float acc = 0.0f;
-  if (u >= 0) {
-    const int s = plan[u].row_off, e = s + plan[u].T;
-    if (m < e) {
-      acc = b[c];
-      const int pad = (ktaps - 1) / 2;
-      const InT* v = vt + (size_t)c * ld;
-      const float* wc = w + c * ktaps;
-      for (int j = 0; j < ktaps; ++j) {
-        const int mm = m + j - pad;
-        if (mm >= s && mm < e) acc = fmaf(wc[j], Elem<InT>::load(v + mm), acc);
+// Depth-wise conv over time on the time-contiguous V^T: each thread produces 8 consecutive time steps of one
+// channel from three aligned 8-element loads (previous / current / next group), zeroing taps that fall
+// outside the utterance [s, e) (symmetric zero padding per utterance, Export_SenseVoice.py:220).
+template <typename InT> __device__ __forceinline__ void load8(const InT* p, float (&o)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&o)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&o)[8]) {
+  const uint4 a = *reinterpret_cast<const uint4*>(p);
+  const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(w[i] << 16); o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+
+// One workgroup = 64 time steps x 64 channels. Phase 1 (lanes along time, coalesced on V^T): each thread
+// computes 8 consecutive time steps of one channel in registers; phase 2: LDS transpose so the f32 memory is
+// written ROW-MAJOR [time][channel] with 16-byte stores (it is the out-projection GEMM's additive operand).
+template <typename InT, int KT>
+__global__ __launch_bounds__(256) void fsmn_kernel(const InT* __restrict__ vt, int ld, const float* __restrict__ w,
+                                                   const float* __restrict__ b, const UttPlan* __restrict__ plan,
+                                                   const int32_t* __restrict__ row_utt, int C, float* __restrict__ out,
+                                                   int ld_out) {
+  constexpr int PAD = (KT - 1) / 2;
+  constexpr int TLD = 65;
+  __shared__ float tile[64 * TLD];
+  const int tid = threadIdx.x;
+  const int m_base = blockIdx.x * 64, c_base = blockIdx.y * 64;
+  const int mg = tid & 7;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int cl = pass * 32 + (tid >> 3);
+    const int c = c_base + cl;
+    const int m = m_base + mg * 8;
+    const int u = row_utt[m];
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (u >= 0) {
+      const int s = plan[u].row_off, e = s + plan[u].T;
+      if (m < e) {
+        float x[24];
+        const InT* v = vt + (size_t)c * ld + m;
+        float t8[8];
+        if (m >= 8) { load8<InT>(v - 8, t8); } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) t8[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = t8[i];
+        load8<InT>(v, t8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[8 + i] = t8[i];
+        if (m + 8 < ld) { load8<InT>(v + 8, t8); } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) t8[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[16 + i] = t8[i];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) { const int mm = m - 8 + i; if (mm < s || mm >= e) x[i] = 0.f; }
+        float wc[KT];
+#pragma unroll
+        for (int j = 0; j < KT; ++j) wc[j] = w[c * KT + j];
+        const float bc = b[c];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float acc = bc;
+#pragma unroll
+          for (int j = 0; j < KT; ++j) acc = fmaf(wc[j], x[8 + i + j - PAD], acc);
+          o[i] = (m + i < e) ? acc : 0.f;
+        }
       }
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tile[(mg * 8 + i) * TLD + cl] = o[i];
   }
-  out_t[(size_t)c * ld + m] = acc;
+  __syncthreads();
+  const int q = (tid & 15) * 4;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int ml = pass * 16 + (tid >> 4);
+    const float* t = tile + ml * TLD + q;
+    *reinterpret_cast<float4*>(out + (size_t)(m_base + ml) * ld_out + c_base + q) = make_float4(t[0], t[1], t[2], t[3]);
+  }
 }
 
 // ------------------------------------------------------------------------------------ CTC collapse
@@ -412,6 +503,7 @@ void launch_lfr_cmvn(const LfrArgs& a, hipStream_t s) {
 template <typename OutT>
 void launch_layernorm(const float* x, int ld_x, int rows, int D, const float* gamma, const float* beta, float eps,
                       OutT* out, int ld_out, int fill_to, hipStream_t s) {
+  ASR_REQUIRE(D % 4 == 0 && D <= LN_MAXV * 256 && ld_x % 4 == 0 && ld_out % 4 == 0, "layernorm: D=%d ld=%d unsupported", D, ld_x);
   hipLaunchKernelGGL(layernorm_kernel<OutT>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld_x, rows, D, gamma, beta, eps, out,
                      ld_out, fill_to);
   HIP_CHECK(hipGetLastError());
@@ -437,13 +529,14 @@ void launch_attention_f32(const AttnArgs& a, int head_dim, hipStream_t s) {
 
 template <typename InT>
 void launch_fsmn(const InT* vt, int ld, const float* w, const float* b, int C, int ktaps, const UttPlan* plan,
-                 const int32_t* row_utt, int n_rows, float* out_t, hipStream_t s) {
-  hipLaunchKernelGGL(fsmn_kernel<InT>, dim3((n_rows + 255) / 256, C), dim3(256), 0, s, vt, ld, w, b, ktaps, plan, row_utt,
-                     n_rows, out_t);
+                 const int32_t* row_utt, int n_rows_pad, float* out, int ld_out, hipStream_t s) {
+  ASR_REQUIRE(ktaps == 11, "fsmn: built for 11 taps (got %d)", ktaps);
+  ASR_REQUIRE(ld % 8 == 0 && n_rows_pad % 64 == 0 && n_rows_pad <= ld && C % 64 == 0 && ld_out % 4 == 0, "fsmn: bad geometry");
+  hipLaunchKernelGGL((fsmn_kernel<InT, 11>), dim3(n_rows_pad / 64, C / 64), dim3(256), 0, s, vt, ld, w, b, plan, row_utt, C, out, ld_out);
   HIP_CHECK(hipGetLastError());
 }
-template void launch_fsmn<float>(const float*, int, const float*, const float*, int, int, const UttPlan*, const int32_t*, int, float*, hipStream_t);
-template void launch_fsmn<bf16_t>(const bf16_t*, int, const float*, const float*, int, int, const UttPlan*, const int32_t*, int, float*, hipStream_t);
+template void launch_fsmn<float>(const float*, int, const float*, const float*, int, int, const UttPlan*, const int32_t*, int, float*, int, hipStream_t);
+template void launch_fsmn<bf16_t>(const bf16_t*, int, const float*, const float*, int, int, const UttPlan*, const int32_t*, int, float*, int, hipStream_t);
 
 void launch_ctc_collapse(const int32_t* frame_ids, const UttPlan* plan, int n_utts, int blank_id, int32_t* token_ids,
                          int max_tokens, int32_t* num_id, hipStream_t s) {

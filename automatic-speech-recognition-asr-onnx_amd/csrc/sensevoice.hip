@@ -247,14 +247,18 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
     }
     {
       ProfScope ps(prof, "gemm_qkv", stream);
-      GemmArgs g;
-      g.A = h; g.lda = b.kpad; g.W = b.wqkv; g.ldw = b.kpad; g.M = rows; g.N = 3 * d; g.K = b.kpad; g.bias = b.bqkv;
-      g.out_lo = qk; g.ld_out_lo = 2 * d; g.out_t = vt; g.ld_out_t = Mpad; g.n_split = 2 * d;
+      GemmArgs g;                               // q | k, row-major
+      g.A = h; g.lda = b.kpad; g.W = b.wqkv; g.ldw = b.kpad; g.M = rows; g.N = 2 * d; g.K = b.kpad; g.bias = b.bqkv;
+      g.out_lo = qk; g.ld_out_lo = 2 * d;
       gemm(g);
+      GemmArgs gv;                              // v, stored transposed (time-contiguous) for the P.V operand and the FSMN
+      gv.A = h; gv.lda = b.kpad; gv.W = (const T*)b.wqkv + (size_t)2 * d * b.kpad; gv.ldw = b.kpad; gv.M = rows; gv.N = d;
+      gv.K = b.kpad; gv.bias = b.bqkv + 2 * d; gv.out_t = vt; gv.ld_out_t = Mpad;
+      gemm(gv);
     }
     {
       ProfScope ps(prof, "fsmn", stream);
-      launch_fsmn<T>(vt, Mpad, b.wfsmn, b.bfsmn, d, c.fsmn_kernel, dp, d_row_utt, rows, mem, stream);
+      launch_fsmn<T>(vt, Mpad, b.wfsmn, b.bfsmn, d, c.fsmn_kernel, dp, d_row_utt, Mpad, mem, d, stream);
     }
     {
       ProfScope ps(prof, "attention", stream);
@@ -268,8 +272,8 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
       ProfScope ps(prof, "gemm_out", stream);
       GemmArgs g;
       g.A = ctx; g.lda = d; g.W = b.wout; g.ldw = d; g.M = rows; g.N = d; g.K = d;
-      g.add_t = mem; g.ld_add_t = Mpad;
-      if (b.in_size == d) { g.add = x_in; g.ld_add = ld_in; }      // residual only when in/out sizes match (:246-256)
+      g.add = mem; g.ld_add = d;                                  // FSMN memory rides in as the GEMM's additive term (:244)
+      if (b.in_size == d) { g.add2 = x_in; g.ld_add2 = ld_in; }    // residual only when in/out sizes match (:246-256)
       g.out_f32 = xb; g.ld_out_f32 = d;
       gemm(g);
     }

@@ -1,0 +1,100 @@
+"""Utterance-level data parallelism: one process per GPU, full weight replica per GPU.
+
+Utterances (windows) are independent -- the reference has no cross-utterance state outside a
+streaming session -- so the path shards with no data-path collective. Two collectives remain
+(SURVEY.md section 8e), both through torch.distributed (backend "nccl" == RCCL over xGMI on ROCm,
+"gloo" in the CPU tests):
+  * start-up: broadcast of the weight arena built by rank 0 (0.47 GB SenseVoice / 3.1 GB Whisper),
+  * end of batch: gather of fixed-width hypothesis slabs (B_local, 1 + max_tokens) int32 to rank 0.
+"""
+from __future__ import annotations
+
+import os
+from typing import Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None):
+    """Returns (rank, local_rank, world_size). Initialises the process group when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_bounds(n_items: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous split; the first (n % world) ranks take one extra item."""
+    q, r = divmod(n_items, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def shard_by_length(lengths: Sequence[int], world: int) -> list[list[int]]:
+    """Length-balanced assignment (longest-first greedy) of utterance indices to ranks."""
+    order = sorted(range(len(lengths)), key=lambda i: -int(lengths[i]))
+    loads = [0] * world
+    out: list[list[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda j: (loads[j], j))
+        out[r].append(i)
+        loads[r] += int(lengths[i])
+    return [sorted(x) for x in out]
+
+
+def broadcast_arena(blob: np.ndarray | None, device: torch.device, src: int = 0) -> torch.Tensor:
+    """Rank `src` passes the host arena; every rank returns a device-resident uint8 tensor holding it."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return torch.from_numpy(blob).to(device)
+    rank = dist.get_rank()
+    n = torch.zeros(1, dtype=torch.int64, device=device)
+    if rank == src:
+        n[0] = blob.nbytes
+    dist.broadcast(n, src)
+    if rank == src:
+        t = torch.from_numpy(blob).to(device)
+    else:
+        t = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
+    dist.broadcast(t, src)
+    return t
+
+
+def pack_hypotheses(token_ids: np.ndarray, num_id: np.ndarray, width: int) -> np.ndarray:
+    """(B, 1 + width) int32 slab: column 0 = token count, then the ids (zero padded)."""
+    B = num_id.shape[0]
+    slab = np.zeros((B, 1 + width), dtype=np.int32)
+    slab[:, 0] = num_id
+    w = min(width, token_ids.shape[1])
+    slab[:, 1:1 + w] = token_ids[:, :w]
+    return slab
+
+
+def unpack_hypotheses(slab: np.ndarray) -> list[np.ndarray]:
+    return [row[1:1 + row[0]].copy() for row in slab]
+
+
+def gather_hypotheses(slab: np.ndarray, device: torch.device, dst: int = 0):
+    """All ranks pass equal-shaped slabs; rank `dst` gets the list of per-rank slabs (others None)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return [slab]
+    t = torch.from_numpy(slab).to(device)
+    bucket = [torch.empty_like(t) for _ in range(world)] if dist.get_rank() == dst else None
+    if dist.get_backend() == "nccl":
+        # RCCL gather is not universally available through c10d; all_gather of a <1 MB slab is latency-bound anyway
+        bucket = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(bucket, t)
+        return [b.cpu().numpy() for b in bucket] if dist.get_rank() == dst else None
+    dist.gather(t, bucket, dst=dst)
+    return [b.cpu().numpy() for b in bucket] if dist.get_rank() == dst else None

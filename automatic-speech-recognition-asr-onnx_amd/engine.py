@@ -196,3 +196,10 @@ def op_ctc_collapse(frame_ids, seq_lens, blank_id=0):
     num = np.zeros((sl.size,), dtype=np.int32)
     _lib.check(_lib.load().asr_op_ctc_collapse(_ip(ids), _ip(sl), sl.size, blank_id, _ip(tok), max_t, _ip(num)))
     return [tok[b, :num[b]].copy() for b in range(sl.size)]
+
+
+def op_gemm_bench(M, N, K, variant=-1, epilogue=0, iters=50) -> float:
+    """Average milliseconds per launch of the bf16 GEMM (device-resident operands)."""
+    ms = C.c_float(0.0)
+    _lib.check(_lib.load().asr_op_gemm_bench(variant, M, N, K, epilogue, iters, C.byref(ms)))
+    return ms.value

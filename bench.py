@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""Headline benchmark: SenseVoiceSmall, bf16 MFMA mode, batch = 64 x 8 s @ 16 kHz chunks per GPU
+(BASELINE.json configs[1]), data-parallel over utterances for --gpus N (weak scaling).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the whole hot path (fbank -> LFR/CMVN -> 70 SANM blocks -> CTC arg-max +
+collapse -> token ids on the host) over one batch of synthetic audio that is already resident in HBM.
+Rank 0 prints ONE JSON line. Random-init weights of the exact architecture, synthetic int16-range audio
+(no checkpoints / datasets exist offline).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "automatic-speech-recognition-asr-onnx_amd"
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md:42
+HBM_PEAK_GBS = 8000.0               # HBM3E spec, MI355X_MICROARCH.md:35
+
+
+def sensevoice_algorithmic_flops(cfg, lengths):
+    """Algorithmic FLOPs per kernel class for one batch (GEMM = 2MNK on un-padded rows, attention = 4 T^2 d
+    per layer, no recompute, no padding) -- SURVEY.md section 8(d)."""
+    d, dff, feat = cfg.d_model, cfg.d_ffn, cfg.feat_dim
+    nfreq = cfg.nfft // 2 + 1
+    out = dict.fromkeys(("gemm_qkv", "gemm_out", "gemm_ffn1", "gemm_ffn2", "gemm_ctc", "attention", "fsmn", "fbank"), 0.0)
+    for n in lengths:
+        T, frames = cfg.seq_len(n), cfg.n_frames(n)
+        nb = cfg.n_blocks
+        out["gemm_qkv"] += 2.0 * T * 3 * d * (feat * cfg.n_enc0 + d * (nb - cfg.n_enc0))
+        out["gemm_out"] += 2.0 * T * d * d * nb
+        out["gemm_ffn1"] += 2.0 * T * d * dff * nb
+        out["gemm_ffn2"] += 2.0 * T * d * dff * nb
+        out["gemm_ctc"] += 2.0 * T * d * cfg.vocab
+        out["attention"] += 4.0 * T * T * d * nb
+        out["fsmn"] += 2.0 * T * d * cfg.fsmn_kernel * nb
+        out["fbank"] += frames * (2.0 * cfg.win_length * 2 * nfreq + 2.0 * nfreq * cfg.n_mels)
+    return out
+
+
+def cpu_baseline(cfg, ck, audio_np, budget_s=15.0):
+    """The oracle (torch CPU f32 restatement of the reference graph, batch 1 like the reference) timed on this
+    host's cores on a bounded sample of the same workload. CHECKER ONLY -- never on the product path."""
+    import torch
+    from oracle.sensevoice_oracle import SenseVoiceOracle
+    orc = SenseVoiceOracle(cfg, ck)
+    orc(audio_np[0, 0], 0)                                  # warm-up
+    n_done, t0 = 0, time.perf_counter()
+    while True:
+        orc(audio_np[n_done % audio_np.shape[0], 0], 0)
+        n_done += 1
+        el = time.perf_counter() - t0
+        if (el >= budget_s and n_done >= 4) or n_done >= 64:
+            break
+    secs = audio_np.shape[2] / cfg.sample_rate
+    return {"value": round(n_done * secs / el, 2), "unit": "audio-s/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{n_done} x {secs:.0f} s utterances, batch 1, torch-CPU f32 oracle (oracle/sensevoice_oracle.py), "
+                      f"{el:.1f} s wall; RTF {el / (n_done * secs):.4f}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
+    ap.add_argument("--seconds", type=float, default=8.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    cfgm = importlib.import_module(PKG + ".config")
+    ckm = importlib.import_module(PKG + ".checkpoints")
+    arena = importlib.import_module(PKG + ".arena")
+    eng = importlib.import_module(PKG + ".engine")
+    dp = importlib.import_module(PKG + ".dist")
+
+    rank, local_rank, world = dp.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    cfg = cfgm.sensevoice_small()
+    n_samples = int(args.seconds * cfg.sample_rate)
+    B = args.batch
+
+    # ---- weights: rank 0 converts the checkpoint, RCCL broadcast of the bf16 arena, borrowed in place
+    ck = None
+    blob = None
+    if rank == 0:
+        ck = ckm.synth_sensevoice_checkpoint(cfg, seed=0)
+        blob = arena.build_sensevoice_arena(cfg, ck, arena.PRECISION_BF16)
+    t0 = time.perf_counter()
+    arena_dev = dp.broadcast_arena(blob, device)
+    torch.cuda.synchronize()
+    t_bcast = time.perf_counter() - t0
+    sess = eng.SenseVoiceSession(cfg, arena_dev, arena.PRECISION_BF16, local_rank, arena_device_ptr=arena_dev.data_ptr(),
+                                 arena_bytes=arena_dev.numel())
+
+    # ---- synthetic audio, resident in HBM before the timed region
+    audio_np = ckm.synth_audio("kaldi", B, n_samples, seed=1234 + rank)
+    audio_dev = torch.from_numpy(audio_np).to(device)
+    offsets = np.arange(B + 1, dtype=np.int64) * n_samples
+    lang = np.zeros(B, dtype=np.int32)
+    lengths = [n_samples] * B
+    max_t = cfg.seq_len(n_samples)
+
+    def step():
+        tok, num = sess.run_packed(None, offsets, lang, audio_device_ptr=audio_dev.data_ptr())
+        if world > 1:                                      # hypotheses to rank 0 (latency-bound, < 120 KB per rank)
+            dp.gather_hypotheses(dp.pack_hypotheses(tok, num, max_t), device)
+        return tok, num
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tok, num = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline leg: per-kernel-class HIP-event timing on the session stream (separate profiled steps)
+    sess.profile(True)
+    sess.profile_reset()
+    for _ in range(args.profile_steps):
+        sess.run_packed(None, offsets, lang, audio_device_ptr=audio_dev.data_ptr())
+    prof = sess.profile_read()
+    sess.profile(False)
+    # PCIe-inclusive rate (host audio in, ids out) -- reported in DESIGN.md, never as `value`
+    t1 = time.perf_counter()
+    for _ in range(3):
+        sess.run_packed(audio_np.reshape(-1), offsets, lang)
+    t_pcie = (time.perf_counter() - t1) / 3
+
+    if rank == 0:
+        audio_s_per_step = world * B * n_samples / cfg.sample_rate
+        ms_per_step = elapsed / args.steps * 1e3
+        value = audio_s_per_step * args.steps / elapsed
+        flops = sensevoice_algorithmic_flops(cfg, lengths)
+        kernels = {}
+        for name, p in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
+            ms = p["total_ms"] / args.profile_steps
+            k = {"ms_per_step": round(ms, 4), "launches_per_step": p["launches"] // args.profile_steps}
+            if name in flops and ms > 0:
+                k["tflops"] = round(flops[name] / (ms * 1e-3) / 1e12, 1)
+            kernels[name] = k
+        gemm_names = [n for n in kernels if n.startswith("gemm_") and n != "gemm_ctc"]
+        gemm_ms = sum(kernels[n]["ms_per_step"] for n in gemm_names)
+        gemm_flops = sum(flops[n] for n in gemm_names)
+        gemm_launches = sum(kernels[n]["launches_per_step"] for n in gemm_names)
+        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        total_flops = sum(flops.values())
+        out = {
+            "metric": "audio-sec/s, SenseVoiceSmall, 8 s @ 16 kHz chunks, batch 64 per GPU (RTF = 1/value per GPU-stream)",
+            "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"SenseVoiceSmall bf16 (234 M params, 70 SANM blocks), batch={B} x {args.seconds:g} s per GPU, "
+                                   "greedy CTC, audio resident in HBM, token ids returned to host",
+                       "global_batch": world * B, "audio_seconds_per_step": audio_s_per_step,
+                       "parallelism": f"dp{world} (utterance sharding, RCCL arena broadcast + hypothesis gather)"},
+            "rtf": round(elapsed / (audio_s_per_step * args.steps), 8),
+            "audio_s_per_s_per_gpu": round(value / world, 1),
+            "model_tflops_per_gpu": round(total_flops / (ms_per_step * 1e-3) / 1e12, 1),
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_128x128x64 (SANM qkv/out/ffn1/ffn2 launches)",
+                         "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": gemm_launches, "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),
+                         "algorithmic_gflop_per_step": round(gemm_flops / 1e9, 1)},
+            "kernels": kernels,
+            "pcie_inclusive_audio_s_per_s_per_gpu": round(B * n_samples / cfg.sample_rate / t_pcie, 1),
+            "arena_broadcast_s": round(t_bcast, 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, ck, audio_np)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,6 +120,10 @@ int asr_op_attention(int precision, const float* q, const float* k, const float*
                      int n_heads, int d_head, float* ctx);          /* packed rows, row-major [sum T][H*D] */
 int asr_op_fsmn(int precision, const float* v, const float* w, const float* b, const int32_t* seq_lens, int batch,
                 int channels, int ktaps, float* out);               /* v,out: [sum T][C] row-major */
+/* Tuning hook: time `iters` launches of the bf16 GEMM on device-resident pseudo-random operands.
+ * variant: -1 heuristic, 0..4 kernel variants (csrc/gemm.hip). epilogue: 0 bias->lo, 1 bias+relu->lo,
+ * 2 bias+residual->f32, 3 two residual terms->f32, 4 transposed store. */
+int asr_op_gemm_bench(int variant, int M, int N, int K, int epilogue, int iters, float* avg_ms);
 int asr_op_ctc_collapse(const int32_t* frame_ids, const int32_t* seq_lens, int batch, int blank_id, int32_t* token_ids,
                         int max_tokens, int32_t* num_id);
 

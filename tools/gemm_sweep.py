@@ -1,0 +1,13 @@
+"""GPU tuning sweep of the bf16 GEMM variants on the SenseVoice B=64 shapes (run via gpurun)."""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+eng = importlib.import_module("automatic-speech-recognition-asr-onnx_amd.engine")
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 9216
+shapes = [("qkv", 1536, 512, 4), ("out", 512, 512, 3), ("ffn1", 2048, 512, 1), ("ffn2", 512, 2048, 2)]
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3, 4]
+for name, N, K, epi in shapes:
+    row = []
+    for v in variants:
+        best = min(eng.op_gemm_bench(M, N, K, v, epi, 50) for _ in range(3))
+        row.append(f"v{v}: {best*1e3:7.1f} us {2*M*N*K/best/1e9:7.0f} TF")
+    print(f"{name:5s} M={M} N={N} K={K} | " + " | ".join(row), flush=True)

@@ -46,6 +46,9 @@ SIGNATURES = {
     "asr_sensevoice_create": (_i, [C.POINTER(SenseVoiceConfigC), _vp, _sz, _i, _i, _i, C.POINTER(_vp)]),
     "asr_sensevoice_run": (_i, [_vp, _vp, _i, _lp, _i, _ip, _ip, _i, _ip]),
     "asr_sensevoice_seq_len": (_i, [C.POINTER(SenseVoiceConfigC), _i, C.POINTER(C.c_int)]),
+    "asr_mem_alloc": (_i, [_i, _sz, C.POINTER(_vp)]),
+    "asr_mem_free": (_i, [_i, _vp]),
+    "asr_mem_copy": (_i, [_i, _vp, _vp, _sz, _i]),
     "asr_session_destroy": (_i, [_vp]),
     "asr_session_set_stream": (_i, [_vp, _vp]),
     "asr_session_device": (_i, [_vp, C.POINTER(C.c_int)]),

@@ -20,6 +20,32 @@ extern "C" int asr_device_count(int* count) {
   });
 }
 
+extern "C" int asr_mem_alloc(int device_id, size_t bytes, void** out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(out, "mem_alloc: null argument");
+    asr_require_device(device_id);
+    HIP_CHECK(hipMalloc(out, std::max<size_t>(bytes, 16)));
+  });
+}
+
+extern "C" int asr_mem_free(int device_id, void* ptr) {
+  return asr_guard([&] {
+    if (!ptr) return;
+    asr_require_device(device_id);
+    HIP_CHECK(hipFree(ptr));
+  });
+}
+
+extern "C" int asr_mem_copy(int device_id, void* dst, const void* src, size_t bytes, int kind) {
+  return asr_guard([&] {
+    ASR_REQUIRE(dst && src, "mem_copy: null argument");
+    ASR_REQUIRE(kind >= 0 && kind <= 2, "mem_copy: bad kind %d", kind);
+    asr_require_device(device_id);
+    static const hipMemcpyKind kinds[3] = {hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice};
+    HIP_CHECK(hipMemcpy(dst, src, bytes, kinds[kind]));
+  });
+}
+
 extern "C" int asr_session_destroy(asr_session* s) {
   return asr_guard([&] {
     if (!s) return;

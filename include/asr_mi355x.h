@@ -91,6 +91,14 @@ int asr_sensevoice_run(asr_session* s, const float* audio, int audio_mem, const 
 /* sequence length (prompt + LFR rows) the graph produces for an utterance of n_samples */
 int asr_sensevoice_seq_len(const asr_sensevoice_config* cfg, int n_samples, int* seq_len);
 
+/* ------------------------------------------------------------------ device buffers
+ * Backing store of the shim's OrtValue (OrtValue.ortvalue_from_numpy / update_inplace / numpy,
+ * SenseVoice/Inference_SenseVoice_ONNX.py:280-299): update_inplace is an H2D copy into the same
+ * allocation, numpy() a blocking D2H copy. kind: 0 = host->device, 1 = device->host, 2 = device->device. */
+int asr_mem_alloc(int device_id, size_t bytes, void** out);
+int asr_mem_free(int device_id, void* ptr);
+int asr_mem_copy(int device_id, void* dst, const void* src, size_t bytes, int kind);
+
 /* ------------------------------------------------------------------ session utilities */
 int asr_session_destroy(asr_session* s);
 int asr_session_set_stream(asr_session* s, void* hip_stream);       /* borrow a caller stream (e.g. torch's) */

@@ -1,0 +1,64 @@
+"""CPU, world_size 2 over gloo: utterance sharding, arena broadcast and hypothesis gather."""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG_NAME, ROOT, sub
+
+
+def test_sharding_helpers():
+    d = sub("dist")
+    assert [d.shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [d.shard_bounds(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    parts = d.shard_by_length([30, 8, 8, 8, 5, 1], 2)
+    assert sorted(sum(parts, [])) == list(range(6))
+    loads = [sum([30, 8, 8, 8, 5, 1][i] for i in p) for p in parts]
+    assert abs(loads[0] - loads[1]) <= 1
+    tok = np.array([[5, 6, 7, 0], [9, 0, 0, 0]], np.int32)
+    slab = d.pack_hypotheses(tok, np.array([3, 1], np.int32), 6)
+    assert slab.shape == (2, 7)
+    hyp = d.unpack_hypotheses(slab)
+    assert hyp[0].tolist() == [5, 6, 7] and hyp[1].tolist() == [9]
+
+
+def _worker(rank, world, port, out_dir):
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    d = importlib.import_module(PKG_NAME + ".dist")
+    r, lr, w = d.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    dev = torch.device("cpu")
+    blob = (np.arange(100003, dtype=np.int64) % 251).astype(np.uint8) if rank == 0 else None
+    t = d.broadcast_arena(blob, dev)
+    assert t.dtype == torch.uint8 and t.numel() == 100003 and int(t[100002]) == 100002 % 251
+    # each rank "transcribes" its shard of 5 utterances: utterance i -> tokens [i, i+1, ..., ] of length i+1
+    lo, hi = d.shard_bounds(5, rank, world)
+    width = 8
+    tok = np.zeros((3, width), np.int32)      # fixed slab height (max shard size) so all ranks send equal shapes
+    num = np.zeros((3,), np.int32)
+    for j, i in enumerate(range(lo, hi)):
+        num[j] = i + 1
+        tok[j, :i + 1] = np.arange(i, 2 * i + 1)
+    got = d.gather_hypotheses(d.pack_hypotheses(tok, num, width), dev)
+    if rank == 0:
+        hyps = []
+        for rk, slab in enumerate(got):
+            l, h = d.shard_bounds(5, rk, world)
+            hyps += d.unpack_hypotheses(slab)[: h - l]
+        assert [x.tolist() for x in hyps] == [list(range(i, 2 * i + 1)) for i in range(5)]
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_gather_world2(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").read_text() == "ok"

@@ -1,0 +1,133 @@
+"""CPU: the onnxruntime-API shim's host logic and the ORT_IO restatement (no compute calls)."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import sub
+from helpers import sensevoice_setup
+
+REF_ORT_IO = "/root/reference/ORT_IO.py"
+
+
+class _Meta:
+    def __init__(self, name, shape, type_):
+        self.name, self.shape, self.type = name, shape, type_
+
+
+def test_ort_io_contract():
+    io = sub("ort_io")
+    audio = _Meta("audio", [1, 1, "audio_len"], "tensor(float)")
+    a = io.array_for(audio, np.arange(6, dtype=np.int16), axes={0: 1, 1: 1, 2: 6})
+    assert a.shape == (1, 1, 6) and a.dtype == np.float32 and a.flags.c_contiguous
+    assert io.array_for(audio, np.zeros((1, 1, 9))).shape == (1, 1, 9)          # dynamic axis taken from the value
+    with pytest.raises(ValueError, match="provide axes"):
+        io.array_for(_Meta("kv", ["batch", 20, 64, "hist"], "tensor(float16)"), np.zeros((2, 20)))
+    lang = _Meta("language_idx", [1], "tensor(int32)")
+    assert io.filled_for(lang, 3, axes={0: 1}).tolist() == [3]
+    assert io.filled_for(_Meta("k", ["batch", 20, 64, 0], "tensor(float16)"), axes={0: 2}).shape == (2, 20, 64, 0)
+    assert io.scalar_for(_Meta("n", [], "tensor(int64)"), 7).shape == () and io.scalar_for(lang, 7).tolist() == [7]
+    assert io.resolve_shape(audio, symbols={"audio_len": 5}) == (1, 1, 5)
+    assert io.numpy_dtype("tensor(float16)") == np.float16 and io.is_dynamic_dim("x") and not io.is_dynamic_dim(np.int64(3))
+    with pytest.raises(KeyError):
+        io.numpy_dtype("tensor(string)")
+    meta = {"supported_languages": json.dumps({"en": {"name": "English", "aliases": ["English", "en-US"], "selector_index": 2},
+                                               "zh": {"aliases": ["Chinese", "中文"], "selector_index": 1}}),
+            "special_token_ids": json.dumps({"eos": [1, 2]}), "ids": "1,2,,3", "sample_rate": "16000"}
+    cat = io.load_supported_languages(meta)
+    assert io.resolve_supported_language(cat, " EN ")[0] == "en" and io.resolve_supported_language(cat, "中文")[0] == "zh"
+    assert cat["zh"]["name"] == "zh" and cat["zh"]["prompt_token_ids"] == []
+    with pytest.raises(ValueError, match="Unsupported language"):
+        io.resolve_supported_language(cat, "fr")
+    assert io.metadata_int_list(meta, "ids") == [1, 2, 3] and io.metadata_int(meta, "sample_rate") == 16000
+    assert io.load_special_token_ids(meta) == {"eos": [1, 2]}
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_ORT_IO), reason="reference only mounted in the build container")
+def test_ort_io_matches_reference_module():
+    spec = importlib.util.spec_from_file_location("ref_ort_io", REF_ORT_IO)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    io = sub("ort_io")
+    rng = np.random.default_rng(0)
+    metas = [_Meta("a", [1, 1, "L"], "tensor(float)"), _Meta("b", ["batch", 20, 64, "hist"], "tensor(float16)"),
+             _Meta("c", [1], "tensor(int64)"), _Meta("d", [], "tensor(int32)")]
+    for m in metas:
+        for axes in (None, {0: 2}, {0: 1, 1: 1, 2: 4, 3: 0}):
+            for val in (rng.standard_normal(4), np.zeros((2, 20, 64, 3)), 5):
+                got = want = None
+                try:
+                    want = ref.array_for(m, val, axes=axes)
+                except Exception as e:
+                    want = type(e)
+                try:
+                    got = io.array_for(m, val, axes=axes)
+                except Exception as e:
+                    got = type(e)
+                if isinstance(want, type):
+                    assert got is want, (m.name, axes, np.shape(val), got, want)
+                else:
+                    assert got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want)
+        assert np.array_equal(io.scalar_for(m, 3), ref.scalar_for(m, 3))
+
+
+def test_model_bundle_and_metadata_session(tmp_path):
+    shim, arena = sub("ort_shim"), sub("arena")
+    cfg, ck = sensevoice_setup("sensevoice_tiny")
+    meta = shim.sensevoice_metadata(cfg)
+    blob = arena.build_sensevoice_arena(cfg, ck, 0)
+    shim.save_model(str(tmp_path / "SenseVoiceSmall.asrmodel"), "sensevoice", cfg.to_dict(), blob, {}, 0)
+    shim.save_model(str(tmp_path / "ASR_Metadata.asrmodel"), "metadata", None, None, meta)
+    info, back = shim.load_model(str(tmp_path / "SenseVoiceSmall.onnx"))        # .onnx resolves to the sibling bundle
+    assert info["kind"] == "sensevoice" and np.array_equal(back, blob)
+    sess = shim.InferenceSession(str(tmp_path / "ASR_Metadata.onnx"), sess_options=shim.SessionOptions())
+    m = sess.get_modelmeta().custom_metadata_map
+    assert m["sample_rate"] == "16000" and m["audio_pcm_scale"] == "1"          # Kaldi front-end: int16-range floats
+    io = sub("ort_io")
+    cat = io.load_supported_languages(m)
+    assert [cat[c]["selector_index"] for c in ("auto", "zh", "en", "yue", "ja", "ko", "nospeech")] == list(range(7))
+    assert io.resolve_supported_language(cat, "Cantonese")[0] == "yue"
+    assert sess.get_providers() == ["MI355XExecutionProvider"]
+    with pytest.raises(ValueError, match="not an .asrmodel"):
+        (tmp_path / "x.onnx").write_bytes(b"\x08\x07onnx-protobuf")
+        shim.InferenceSession(str(tmp_path / "x.onnx"))
+
+
+def test_install_as_onnxruntime_exposes_the_names_the_scripts_import():
+    import sys
+    shim = sub("ort_shim")
+    saved = {k: sys.modules.get(k) for k in ("onnxruntime", "onnxruntime.capi", "onnxruntime.capi._pybind_state")}
+    try:
+        shim.install_as_onnxruntime()
+        import onnxruntime
+        from onnxruntime.capi import _pybind_state as C
+        for name in ("InferenceSession", "SessionOptions", "RunOptions", "OrtValue", "ExecutionMode", "GraphOptimizationLevel"):
+            assert hasattr(onnxruntime, name)
+        dev = C.OrtDevice(C.OrtDevice.cuda(), C.OrtDevice.default_memory(), 0)
+        assert dev.device_id == 0
+        o = onnxruntime.SessionOptions()
+        o.add_session_config_entry("session.set_denormal_as_zero", "1")
+        r = onnxruntime.RunOptions()
+        r.add_run_config_entry("disable_synchronize_execution_providers", "0")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_prepare_audio_and_window_plan():
+    sv = sub("sensevoice")
+    pcm = (np.arange(-5, 5, dtype=np.int16) * 1000).reshape(1, 1, -1)
+    a = sv.prepare_audio_input(pcm, "F32", audio_pcm_scale=1)
+    assert a.dtype == np.float32 and np.array_equal(a, pcm.astype(np.float32))          # no /32768 for the Kaldi front-end
+    n = sv.prepare_audio_input(pcm, "F32", audio_pcm_scale=1, normalise=True)
+    assert abs(float(np.sqrt(np.mean(n * n))) - 4096.0) < 1.0
+    assert sv.prepare_audio_input(pcm, "INT16", audio_pcm_scale=1).dtype == np.int16
+    x = np.ones((1, 1, 25), np.float32)
+    assert sv.plan_windows(x, 25, 10, 10).shape[-1] == 30      # ceil((25-10)/10)+1 = 3 windows
+    assert sv.plan_windows(x, 25, 40, 40).shape[-1] == 40
+    assert sv.plan_windows(x, 25, 25, 25).shape[-1] == 25

@@ -57,6 +57,19 @@ def cpu_baseline(cfg, ck, audio_np, budget_s=15.0):
     from oracle.sensevoice_oracle import SenseVoiceOracle
     orc = SenseVoiceOracle(cfg, ck)
     orc(audio_np[0, 0], 0)                                  # warm-up
+    # small GEMMs (T = 137 rows) scale poorly to every core of a big host: probe a few thread counts, keep the best
+    best_t, best_n = None, None
+    for n_thr in (8, 16, 32):
+        if n_thr > (os.cpu_count() or 8):
+            continue
+        torch.set_num_threads(n_thr)
+        orc(audio_np[0, 0], 0)
+        t0 = time.perf_counter()
+        orc(audio_np[0, 0], 0)
+        dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t:
+            best_t, best_n = dt, n_thr
+    torch.set_num_threads(best_n)
     n_done, t0 = 0, time.perf_counter()
     while True:
         orc(audio_np[n_done % audio_np.shape[0], 0], 0)
@@ -65,7 +78,7 @@ def cpu_baseline(cfg, ck, audio_np, budget_s=15.0):
         if (el >= budget_s and n_done >= 4) or n_done >= 64:
             break
     secs = audio_np.shape[2] / cfg.sample_rate
-    return {"value": round(n_done * secs / el, 2), "unit": "audio-s/s", "cores": int(torch.get_num_threads()), "kind": "port",
+    return {"value": round(n_done * secs / el, 2), "unit": "audio-s/s", "cores": int(torch.get_num_threads()), "host_cores": int(os.cpu_count() or 0), "kind": "port",
             "sample": f"{n_done} x {secs:.0f} s utterances, batch 1, torch-CPU f32 oracle (oracle/sensevoice_oracle.py), "
                       f"{el:.1f} s wall; RTF {el / (n_done * secs):.4f}"}
 

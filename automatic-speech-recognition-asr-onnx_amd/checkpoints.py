@@ -123,3 +123,21 @@ def synth_audio(kind: str, batch: int, n_samples: int, seed: int = 1234) -> np.n
     if kind == "unit":
         return np.clip(x * np.float32(0.05), -1.0, 1.0).astype(np.float32)
     raise ValueError(kind)
+
+
+def whisper_suppress_tokens(cfg: WhisperConfig) -> list:
+    """Synthetic stand-in for generation_config.suppress_tokens (permanent -128 penalty, Export_Whisper.py:517-520):
+    a fixed pseudo-random 1 % of the text vocabulary plus every special id except <|endoftext|> -- as in the real
+    list, <|nospeech|> is among them (which is why NO_SPEECH_DETECTION re-adds +128, :338-345)."""
+    rng = np.random.default_rng(77)
+    n_text = min(cfg.eot_id, cfg.vocab)
+    ids = set(int(i) for i in rng.choice(n_text, size=max(1, n_text // 100), replace=False))
+    for i in (cfg.sot_id, cfg.transcribe_id, cfg.translate_id, cfg.no_speech_id):
+        if 0 <= i < cfg.vocab:
+            ids.add(int(i))
+    return sorted(ids)
+
+
+def whisper_begin_suppress_tokens(cfg: WhisperConfig) -> list:
+    """generation_config.begin_suppress_tokens of Whisper = [" " token, <|endoftext|>]; synthetic: [220 % vocab, eot]."""
+    return sorted({220 % cfg.vocab, cfg.eot_id})

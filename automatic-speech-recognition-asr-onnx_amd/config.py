@@ -119,3 +119,11 @@ def whisper_tiny_test() -> WhisperConfig:
                          sot_id=500, eot_id=499, transcribe_id=560, translate_id=559,
                          no_timestamps_id=564, no_speech_id=563, first_language_id=501,
                          n_languages=58)
+
+
+def whisper_mid_test() -> WhisperConfig:
+    """Mid-size geometry: 128 mels like large-v3, 6 heads x 64, enough layers to exercise the fused cross-KV split."""
+    return WhisperConfig(n_mels=128, d_model=384, n_heads=6, d_head=64, d_ffn=1536, n_enc_layers=4, n_dec_layers=4, vocab=5000,
+                         max_source_positions=1500, max_target_positions=448,
+                         sot_id=4900, eot_id=4899, transcribe_id=4990, translate_id=4989, no_timestamps_id=4994,
+                         no_speech_id=4993, first_language_id=4901, n_languages=80)

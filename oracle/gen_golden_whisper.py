@@ -1,0 +1,89 @@
+"""Whisper goldens from the REAL reference classes (build container only); see oracle/gen_golden.py."""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "automatic-speech-recognition-asr-onnx_amd"
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+WHISPER_CASES = [
+    # (fixture, config factory, ckpt seed, n_new tokens, [(audio seed, n_samples)])
+    ("whisper_tiny", "whisper_tiny_test", 0, 6, [(2234, 16000), (2235, 48000), (2236, 7040)]),
+    ("whisper_mid", "whisper_mid_test", 0, 5, [(2237, 128000)]),
+]
+FULL_CASE = ("whisper_large_v3", "whisper_large_v3", 0, 4, [(2238, 128000)])
+
+
+def reference_greedy(ref, cfg, audio, prompt, n_new, suppress, begin_suppress):
+    """The reference's graphs driven like Inference_Whisper_ONNX.py: encoder once, prefill(prompt), decode steps."""
+    enc, dec, model = ref["encoder"], ref["decoder"], ref["model"]
+    L, H, hd, d = cfg.n_dec_layers, cfg.n_heads, cfg.d_head, cfg.d_model
+    embed = model.model.decoder.embed_tokens
+    pos_w = model.model.decoder.embed_positions.weight
+    with torch.inference_mode():
+        cross = enc(torch.from_numpy(audio).reshape(1, 1, -1))
+        sk = [torch.zeros(1, H, hd, 0) for _ in range(L)]
+        sv = [torch.zeros(1, H, 0, hd) for _ in range(L)]
+        begin_bias = torch.zeros(cfg.vocab)
+        if begin_suppress:
+            begin_bias[list(begin_suppress)] = float("-inf")
+        ids = torch.tensor([prompt], dtype=torch.long)
+        hist, toks, all_logits = 0, [], []
+        for step in range(n_new):
+            n = ids.shape[1]
+            mask = torch.triu(torch.full((1, n, hist + n), -128.0), diagonal=1)[:, :n, :hist + n] if step == 0 else torch.zeros(1, 1, hist + n)
+            out = dec(*sk, *sv, *cross, embed(ids), pos_w[hist:hist + n].unsqueeze(0), mask)
+            sk, sv, logits = list(out[:L]), list(out[L:2 * L]), out[-1]
+            all_logits.append(logits[0].clone())
+            tok = int(torch.argmax(logits[0] + (begin_bias if step == 0 else 0)))
+            toks.append(tok)
+            hist += n
+            ids = torch.tensor([[tok]], dtype=torch.long)
+    return dict(cross=cross, logits=torch.stack(all_logits).numpy(), token_ids=np.asarray(toks, np.int32))
+
+
+def gen_whisper(full=False):
+    from oracle import reference_harness as rh
+    cfgm = importlib.import_module(PKG + ".config")
+    ckm = importlib.import_module(PKG + ".checkpoints")
+    cases = list(WHISPER_CASES) + ([FULL_CASE] if full else [])
+    for fixture, cfg_name, ck_seed, n_new, clips in cases:
+        cfg = getattr(cfgm, cfg_name)()
+        ck = ckm.synth_whisper_checkpoint(cfg, ck_seed)
+        suppress = ckm.whisper_suppress_tokens(cfg)
+        begin = ckm.whisper_begin_suppress_tokens(cfg)
+        ref = rh.build_reference_whisper(cfg, ck, suppress_tokens=suppress)
+        small = cfg.d_model <= 128
+        out = {"ckpt_seed": np.int64(ck_seed), "n_cases": np.int64(len(clips)), "cfg_name": np.str_(cfg_name), "n_new": np.int64(n_new)}
+        for i, (seed, n) in enumerate(clips):
+            audio = ckm.synth_audio("unit", 1, n, seed=seed)[0, 0]
+            prompt = [cfg.sot_id, cfg.first_language_id, cfg.transcribe_id, cfg.no_timestamps_id]
+            r = reference_greedy(ref, cfg, audio, prompt, n_new, suppress, begin)
+            L = cfg.n_dec_layers
+            keys = torch.stack([k.permute(0, 2, 1) for k in r["cross"][:L]]).numpy()     # (L, H, T, hd)
+            vals = torch.stack(list(r["cross"][L:])).numpy()
+            p = f"c{i}_"
+            out[p + "audio_seed"], out[p + "n_samples"] = np.int64(seed), np.int64(n)
+            out[p + "prompt"] = np.asarray(prompt, np.int32)
+            out[p + "token_ids"] = r["token_ids"]
+            srt = np.sort(r["logits"], axis=1)
+            out[p + "margin"] = (srt[:, -1] - srt[:, -2]).astype(np.float32)
+            if small:
+                out[p + "cross_k"], out[p + "cross_v"], out[p + "logits"] = keys, vals, r["logits"]
+            else:
+                out[p + "cross_k"], out[p + "cross_v"] = keys[:, ::5, ::16].copy(), vals[:, ::5, ::16].copy()
+                out[p + "logits"] = r["logits"][:, ::53].copy()
+                out[p + "top1"] = srt[:, -1].astype(np.float32)
+            print(fixture, i, n, "tokens", r["token_ids"], "min margin", float(out[p + "margin"].min()))
+        np.savez_compressed(os.path.join(GOLDEN, fixture + ".npz"), **out)
+
+
+if __name__ == "__main__":
+    gen_whisper(full="--full" in sys.argv)

@@ -143,7 +143,7 @@ def reference_sensevoice_stages(model, audio: np.ndarray, language_idx: int) -> 
 
 
 # --------------------------------------------------------------------------- Whisper
-def build_reference_whisper(cfg, ck: dict, use_fp16_kv=False):
+def build_reference_whisper(cfg, ck: dict, use_fp16_kv=False, suppress_tokens=None):
     """Reference WHISPER_ENCODER / WHISPER_DECODER (+ embed/position shells) on a
     synthetic HF-layout checkpoint. Quantisation-only channel re-orderings are exact
     permutations (Export_Whisper.py:568-612) and are disabled."""
@@ -181,5 +181,5 @@ def build_reference_whisper(cfg, ck: dict, use_fp16_kv=False):
                         drop_last_frame=True).eval()
     with torch.inference_mode():
         enc = ns["WHISPER_ENCODER"](model.model, stft, cfg.nfft, cfg.n_mels, cfg.sample_rate, cfg.n_dec_layers).eval()
-        dec = ns["WHISPER_DECODER"](model, None, cfg.n_dec_layers).eval()
+        dec = ns["WHISPER_DECODER"](model, list(suppress_tokens) if suppress_tokens is not None else None, cfg.n_dec_layers).eval()
     return dict(ns=ns, model=model, encoder=enc, decoder=dec, stft=stft, kv_dtype=kv_dtype)

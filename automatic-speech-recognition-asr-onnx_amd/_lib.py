@@ -46,6 +46,11 @@ SIGNATURES = {
     "asr_sensevoice_create": (_i, [C.POINTER(SenseVoiceConfigC), _vp, _sz, _i, _i, _i, C.POINTER(_vp)]),
     "asr_sensevoice_run": (_i, [_vp, _vp, _i, _lp, _i, _ip, _ip, _i, _ip]),
     "asr_sensevoice_seq_len": (_i, [C.POINTER(SenseVoiceConfigC), _i, C.POINTER(C.c_int)]),
+    "asr_whisper_create": (_i, [C.POINTER(WhisperConfigC), _vp, _sz, _i, _i, _i, C.POINTER(_vp)]),
+    "asr_whisper_encode": (_i, [_vp, _vp, _i, _lp, _i, _ip]),
+    "asr_whisper_prefill": (_i, [_vp, _ip, _i, _ip, _fp]),
+    "asr_whisper_decode": (_i, [_vp, _ip, _ip, _fp]),
+    "asr_whisper_generate": (_i, [_vp, _i, _i, _ip, _ip]),
     "asr_mem_alloc": (_i, [_i, _sz, C.POINTER(_vp)]),
     "asr_mem_free": (_i, [_i, _vp]),
     "asr_mem_copy": (_i, [_i, _vp, _vp, _sz, _i]),

@@ -226,3 +226,115 @@ def build_sensevoice_arena(cfg: SenseVoiceConfig, ck: dict, precision: int = PRE
     w.weight("ctc.w", cw, precision)
     w.add("ctc.b", cb, DT_F32)
     return w.finish()
+
+
+# =========================================================================== Whisper
+def slaney_mel_filterbank(n_freqs: int, n_mels: int, sample_rate: int) -> np.ndarray:
+    """(n_mels, n_freqs) slaney-scale, slaney-normalised triangular filters over [0, sr/2].
+
+    Stands in for `torchaudio.functional.melscale_fbanks(n_freqs, 0, sr/2, n_mels, sr, "slaney", "slaney")`
+    (Whisper/Export_Whisper.py:359-361; third-party, not vendored): mel = f / (200/3) below 1 kHz, logarithmic
+    (step ln(6.4)/27) above; each triangle scaled by 2 / (f_right - f_left)."""
+    def to_mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-10) / 1000.0) * (27.0 / np.log(6.4)), f * 3.0 / 200.0)
+
+    def to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), m * 200.0 / 3.0)
+
+    freqs = np.linspace(0.0, sample_rate // 2, n_freqs)
+    edges = to_hz(np.linspace(to_mel(0.0), to_mel(sample_rate / 2.0), n_mels + 2))
+    width = np.diff(edges)
+    ramps = edges[None, :] - freqs[:, None]
+    tri = np.maximum(0.0, np.minimum(-ramps[:, :-2] / width[:-1], ramps[:, 2:] / width[1:]))
+    tri = tri * (2.0 / (edges[2:] - edges[:-2]))[None, :]
+    return np.ascontiguousarray(tri.T.astype(np.float32))
+
+
+def whisper_dft_matrix(nfft: int) -> np.ndarray:
+    """(2*(nfft/2+1), nfft): periodic-Hann-windowed cos rows then -sin rows (Whisper/STFT_Process.py:136-150)."""
+    bins = nfft // 2 + 1
+    t = torch.arange(nfft, dtype=torch.float32).unsqueeze(0)
+    f = torch.arange(bins, dtype=torch.float32).unsqueeze(1)
+    omega = (2.0 * torch.pi / nfft) * f * t
+    win = torch.hann_window(nfft, periodic=True).float().unsqueeze(0)
+    return torch.cat([torch.cos(omega) * win, -torch.sin(omega) * win], dim=0).numpy()
+
+
+def _absorb_ln(gamma, beta, w, b):
+    """Linear(gamma * xhat + beta) = (W * gamma) xhat + (W beta + b)   (Export_Whisper.py:215-225)."""
+    return w * gamma[None, :], b + w @ beta
+
+
+def build_whisper_arena(cfg, ck: dict, precision: int = PRECISION_BF16, suppress_tokens=None, begin_suppress_tokens=()) -> np.ndarray:
+    """Fold an HF-layout Whisper checkpoint into the engine arena (Export_Whisper.py:376-420,527-550)."""
+    w = ArenaWriter()
+    d, Ld = cfg.d_model, cfg.n_dec_layers
+    bins = cfg.nfft // 2 + 1
+    w.add("fe.dft", pack_dft_for_mfma(whisper_dft_matrix(cfg.nfft), bins, cfg.nfft), DT_F32)
+    w.add("fe.mel", pack_mel_for_mfma(slaney_mel_filterbank(bins, cfg.n_mels, cfg.sample_rate).T.copy(), cfg.n_mels), DT_F32)
+    # conv stem as GEMMs over time-major strided views: weight column index = tap * C_in + c_in
+    c1 = ck["model.encoder.conv1.weight"]                       # (d, n_mels, 3)
+    c2 = ck["model.encoder.conv2.weight"]                       # (d, d, 3)
+    w.weight("enc.conv1_w", np.ascontiguousarray(c1.transpose(0, 2, 1)).reshape(d, 3 * cfg.n_mels), precision)
+    w.add("enc.conv1_b", ck["model.encoder.conv1.bias"], DT_F32)
+    w.weight("enc.conv2_w", np.ascontiguousarray(c2.transpose(0, 2, 1)).reshape(d, 3 * d), precision)
+    w.add("enc.conv2_b", ck["model.encoder.conv2.bias"], DT_F32)
+    w.add("enc.pos", ck["model.encoder.embed_positions.weight"], DT_F32)
+    scale = np.float32(float(cfg.d_head ** -0.25))
+    zero = np.zeros(d, dtype=np.float32)
+
+    def fused_qkv(p, gamma, beta):
+        wq = np.concatenate([ck[p + "q_proj.weight"], ck[p + "k_proj.weight"], ck[p + "v_proj.weight"]], 0).copy()
+        bq = np.concatenate([ck[p + "q_proj.bias"], zero, ck[p + "v_proj.bias"]], 0).copy()
+        wq[:2 * d] *= scale                                      # d^-1/4 on q and k; k has no bias
+        bq[:d] *= scale
+        return _absorb_ln(gamma, beta, wq, bq)
+
+    for i in range(cfg.n_enc_layers):
+        p, q = f"model.encoder.layers.{i}.", f"enc{i}."
+        wq, bq = fused_qkv(p + "self_attn.", ck[p + "self_attn_layer_norm.weight"], ck[p + "self_attn_layer_norm.bias"])
+        w1, b1 = _absorb_ln(ck[p + "final_layer_norm.weight"], ck[p + "final_layer_norm.bias"], ck[p + "fc1.weight"], ck[p + "fc1.bias"])
+        w.weight(q + "wqkv", wq, precision); w.add(q + "bqkv", bq, DT_F32)
+        w.weight(q + "wo", ck[p + "self_attn.out_proj.weight"], precision); w.add(q + "bo", ck[p + "self_attn.out_proj.bias"], DT_F32)
+        w.weight(q + "w1", w1, precision); w.add(q + "b1", b1, DT_F32)
+        w.weight(q + "w2", ck[p + "fc2.weight"], precision); w.add(q + "b2", ck[p + "fc2.bias"], DT_F32)
+    w.add("enc.ln_g", ck["model.encoder.layer_norm.weight"], DT_F32)
+    w.add("enc.ln_b", ck["model.encoder.layer_norm.bias"], DT_F32)
+    # fused cross-KV: every layer's (scaled) K projection, then every layer's V projection (:393-417)
+    kw = [ck[f"model.decoder.layers.{i}.encoder_attn.k_proj.weight"] * scale for i in range(Ld)]
+    vw = [ck[f"model.decoder.layers.{i}.encoder_attn.v_proj.weight"] for i in range(Ld)]
+    vb = [ck[f"model.decoder.layers.{i}.encoder_attn.v_proj.bias"] for i in range(Ld)]
+    w.weight("ckv.w", np.concatenate(kw + vw, 0), precision)
+    w.add("ckv.b", np.concatenate([zero] * Ld + vb, 0), DT_F32)
+    # decoder
+    vpad = (cfg.vocab + 127) // 128 * 128
+    emb = np.zeros((vpad, d), dtype=np.float32)
+    emb[:cfg.vocab] = ck["model.decoder.embed_tokens.weight"]
+    w.weight("dec.embed", emb, precision)                        # token embedding == tied proj_out
+    w.add("dec.pos", ck["model.decoder.embed_positions.weight"], DT_F32)
+    sup = np.zeros(vpad, dtype=np.float32)
+    if suppress_tokens is not None:
+        sup[list(suppress_tokens)] = -128.0                      # -128, not -inf (:517-520)
+    beg = np.zeros(vpad, dtype=np.float32)
+    ids = [int(i) for i in begin_suppress_tokens if 0 <= int(i) < cfg.vocab]
+    if ids:
+        beg[ids] = -np.inf                                       # BEGIN_SUPPRESS (:228-240)
+    w.add("dec.suppress", sup, DT_F32)
+    w.add("dec.begin", beg, DT_F32)
+    for i in range(Ld):
+        p, q = f"model.decoder.layers.{i}.", f"dec{i}."
+        wq, bq = fused_qkv(p + "self_attn.", ck[p + "self_attn_layer_norm.weight"], ck[p + "self_attn_layer_norm.bias"])
+        wcq, bcq = _absorb_ln(ck[p + "encoder_attn_layer_norm.weight"], ck[p + "encoder_attn_layer_norm.bias"],
+                              ck[p + "encoder_attn.q_proj.weight"] * scale, ck[p + "encoder_attn.q_proj.bias"] * scale)
+        w1, b1 = _absorb_ln(ck[p + "final_layer_norm.weight"], ck[p + "final_layer_norm.bias"], ck[p + "fc1.weight"], ck[p + "fc1.bias"])
+        w.weight(q + "wqkv", wq, precision); w.add(q + "bqkv", bq, DT_F32)
+        w.weight(q + "wo", ck[p + "self_attn.out_proj.weight"], precision); w.add(q + "bo", ck[p + "self_attn.out_proj.bias"], DT_F32)
+        w.weight(q + "wcq", wcq, precision); w.add(q + "bcq", bcq, DT_F32)
+        w.weight(q + "wco", ck[p + "encoder_attn.out_proj.weight"], precision); w.add(q + "bco", ck[p + "encoder_attn.out_proj.bias"], DT_F32)
+        w.weight(q + "w1", w1, precision); w.add(q + "b1", b1, DT_F32)
+        w.weight(q + "w2", ck[p + "fc2.weight"], precision); w.add(q + "b2", ck[p + "fc2.bias"], DT_F32)
+    w.add("dec.ln_g", ck["model.decoder.layer_norm.weight"], DT_F32)
+    w.add("dec.ln_b", ck["model.decoder.layer_norm.bias"], DT_F32)
+    return w.finish()

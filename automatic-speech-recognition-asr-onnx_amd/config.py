@@ -113,7 +113,7 @@ def whisper_large_v3() -> WhisperConfig:
 
 def whisper_tiny_test() -> WhisperConfig:
     """Reduced geometry (same head_dim=64) for fast CPU goldens."""
-    return WhisperConfig(n_mels=80, d_model=128, n_heads=2, d_head=64, d_ffn=256,
+    return WhisperConfig(n_mels=128, d_model=128, n_heads=2, d_head=64, d_ffn=256,
                          n_enc_layers=2, n_dec_layers=2, vocab=600,
                          max_source_positions=1500, max_target_positions=64,
                          sot_id=500, eot_id=499, transcribe_id=560, translate_id=559,

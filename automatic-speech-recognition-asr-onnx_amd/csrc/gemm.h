@@ -12,10 +12,14 @@ struct GemmArgs {
   int M = 0, N = 0, K = 0;                  // M = valid rows (stores are masked to m < M); N % 128 == 0; K % 64 == 0
   const float* bias = nullptr;              // [N] (nullable)
   const float* add = nullptr; int ld_add = 0;       // + add[m * ld + n]   (row-major f32, nullable; readable to the tile edge)
-  const float* add2 = nullptr; int ld_add2 = 0;     // + add2[m * ld + n]  (second row-major f32 term, nullable)
+  // second row-major f32 term, added AFTER the activation: + add2[row(m) * ld + n], row(m) = add2_rows ? add2_rows[m] : m
+  const float* add2 = nullptr; int ld_add2 = 0; const int32_t* add2_rows = nullptr;
   int act = ACT_NONE;
   float* out_f32 = nullptr; int ld_out_f32 = 0;     // row-major f32 out (nullable)
   void* out_lo = nullptr; int ld_out_lo = 0;        // row-major out in the operand dtype (nullable)
+  // lo_group > 0: grouped layout instead -- out_lo[(n / lo_group) * ld_out_lo + m * lo_group + n % lo_group]
+  // (per-head K/V slabs [group][row][lo_group] for the decoder's cross-attention; ld_out_lo = slab stride)
+  int lo_group = 0;
   // transposed out in the operand dtype: out_t[n * ld + m]. Exclusive with every row-major term above
   // (the kernel then runs in the un-swapped MFMA orientation: 4 consecutive m per lane).
   void* out_t = nullptr; int ld_out_t = 0;

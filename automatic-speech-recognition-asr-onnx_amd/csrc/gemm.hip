@@ -116,23 +116,31 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[
     }
     if (has_add2) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        t2[i] = *reinterpret_cast<const float4*>(g.add2 + (size_t)(m_wave + i * 16 + frow) * g.ld_add2 + n);
+      for (int i = 0; i < 4; ++i) {
+        const int m = m_wave + i * 16 + frow;
+        const int row = g.add2_rows ? g.add2_rows[m] : m;
+        t2[i] = *reinterpret_cast<const float4*>(g.add2 + (size_t)row * g.ld_add2 + n);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m_wave + i * 16 + frow;
       float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
       if (has_add) { v0 += t1[i].x; v1 += t1[i].y; v2 += t1[i].z; v3 += t1[i].w; }
-      if (has_add2) { v0 += t2[i].x; v1 += t2[i].y; v2 += t2[i].z; v3 += t2[i].w; }
       if constexpr (ACT >= 0) {
         v0 = apply_act_ct<ACT>(v0); v1 = apply_act_ct<ACT>(v1); v2 = apply_act_ct<ACT>(v2); v3 = apply_act_ct<ACT>(v3);
       } else {
         v0 = apply_act_rt(v0, g.act); v1 = apply_act_rt(v1, g.act); v2 = apply_act_rt(v2, g.act); v3 = apply_act_rt(v3, g.act);
       }
+      if (has_add2) { v0 += t2[i].x; v1 += t2[i].y; v2 += t2[i].z; v3 += t2[i].w; }     // post-activation term
       if (m < g.M) {
         if (want_f32) store4<float>(g.out_f32 + (size_t)m * g.ld_out_f32 + n, v0, v1, v2, v3);
-        if (want_lo) store4<OutT>(reinterpret_cast<OutT*>(g.out_lo) + (size_t)m * g.ld_out_lo + n, v0, v1, v2, v3);
+        if (want_lo) {
+          OutT* o = reinterpret_cast<OutT*>(g.out_lo);
+          if (g.lo_group > 0) o += (size_t)(n / g.lo_group) * g.ld_out_lo + (size_t)m * g.lo_group + (n % g.lo_group);
+          else o += (size_t)m * g.ld_out_lo + n;
+          store4<OutT>(o, v0, v1, v2, v3);
+        }
       }
     }
   }
@@ -346,7 +354,7 @@ void check_args(const GemmArgs& g, int kstep, int elt) {
   if (g.add) ASR_REQUIRE(g.ld_add % 4 == 0, "gemm: ld_add must be a multiple of 4");
   if (g.add2) ASR_REQUIRE(g.ld_add2 % 4 == 0, "gemm: ld_add2 must be a multiple of 4");
   if (g.out_f32) ASR_REQUIRE(g.ld_out_f32 % 4 == 0, "gemm: ld_out_f32 must be a multiple of 4");
-  if (g.out_lo) ASR_REQUIRE(g.ld_out_lo % 4 == 0, "gemm: ld_out_lo must be a multiple of 4");
+  if (g.out_lo) ASR_REQUIRE(g.ld_out_lo % 4 == 0 && g.lo_group % 4 == 0, "gemm: ld_out_lo / lo_group must be multiples of 4");
   if (g.out_t) {
     ASR_REQUIRE(!(g.add || g.add2 || g.out_f32 || g.out_lo || g.amax_val || g.act != ACT_NONE),
                 "gemm: the transposed store excludes row-major epilogue terms");
@@ -384,6 +392,9 @@ void launch_pipe(const GemmArgs& g, hipStream_t s) {
   ASR_GEMM_CASE(ACT_NONE, E_ADD | E_F32)                    // SANM out-proj of the first block (no residual)
   ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_ADD | E_F32)           // FFN-2 / out-proj with bias + residual
   ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_AMAX)                  // CTC / LM head arg-max
+  ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_F32)                   // LM head logits
+  ASR_GEMM_CASE(ACT_GELU_ERF, E_BIAS | E_ADD2 | E_F32)      // Whisper conv2: gelu(conv) + positions
+  ASR_GEMM_CASE(ACT_GELU_TANH, E_BIAS | E_ADD2 | E_F32)
 #undef ASR_GEMM_CASE
   launch_pipe_inst<BN_, STAGES, -1, -1, true>(g, s);
 }

@@ -12,7 +12,7 @@ struct UttPlan {
   int32_t T;           // encoder sequence length (n_lfr + prompts)
   int32_t row_off;     // first row in the packed activation matrices (multiple of 16)
   int32_t lang;        // language selector index
-  int32_t pad_;
+  int32_t blk0;        // first front-end workgroup of this utterance
 };
 
 // ---- Kaldi fbank: frames -> |DFT|^2 -> mel -> ln  (SenseVoice/Export_SenseVoice.py:139-160,275-278)
@@ -30,9 +30,48 @@ struct FbankArgs {
   int n_mel_tiles;             // n_mels / 16
   int n_mels;
   int win, hop;
-  float log_floor;             // FLT_EPSILON
+  float log_floor;             // FLT_EPSILON (Kaldi) / 1e-10 (Whisper)
+  // Whisper variant (Whisper/STFT_Process.py:224-246): reflect pad nfft/2 left, nfft/2 - hop right (last frame dropped),
+  // log10 instead of ln, and the per-workgroup maximum written to blk_max for the per-utterance clamp
+  int whisper;
+  float* blk_max;
 };
 void launch_fbank(const FbankArgs& a, int n_blocks, hipStream_t s);
+
+// ---- Whisper log-mel finish (Export_Whisper.py:425-427): max(x, utterance_max - 8), (x + 4) / 4, written in the
+// GAPPED time-major layout the conv stem reads: utterance b owns rows [2*row_off_b, 2*row_off_b + 2*rows_b); row
+// 2*row_off_b is the conv's left zero pad, frame f sits at row 2*row_off_b + 1 + f, everything else is zero.
+template <typename T>
+void launch_whisper_mel_finish(const float* mel, const float* blk_max, const UttPlan* plan, const int32_t* grow_utt,
+                               int n_gapped_rows, int n_mels, T* out, hipStream_t s);
+// zero the rows of a gapped-layout matrix that are not frames (conv zero padding after conv1)
+template <typename T>
+void launch_zero_gap_rows(T* buf, int ld, int n_cols, const UttPlan* plan, const int32_t* grow_utt, int n_gapped_rows,
+                          hipStream_t s);
+
+// ---- decoder token + position embedding: x[b*n + i] = embed[ids[b*n + i]] + pos[hist + i]   (Export_Whisper.py:450-497)
+template <typename T>
+void launch_embed_pos(const int32_t* ids, int rows, int n, int hist, const T* embed, const float* pos, int d, float* x,
+                      hipStream_t s);
+
+// ---- decoder attention, head_dim 64, n <= 8 new queries per sequence. Keys/values are rows of 64:
+//   self : cache [b][h][S_max][64]; the n new rows are appended from `kv_new` (fused qkv GEMM output) and attended
+//          with the reference's additive -128 causal mask (Export_Whisper.py:468-480,640-647)
+//   cross: per-(layer, head) slabs [row][64] written by the encoder's cross-KV GEMM; no mask (:654-660)
+struct DecAttnArgs {
+  const void* q; int ld_q; int q_col0;
+  const void* kv_new; int ld_new; int k_col0, v_col0;          // null for cross
+  void* k_base; void* v_base;
+  int64_t stride_b, stride_h;                                  // element strides of (b, h) inside k_base / v_base
+  const UttPlan* plan;                                         // cross: row_off / n_lfr per sequence; null for self
+  int hist, n, n_heads, causal;
+  void* out; int ld_out;
+};
+template <typename T>
+void launch_decode_attention(const DecAttnArgs& a, int batch, hipStream_t s);
+
+// ids[r] = first arg-max over n < n_valid of logits[r][n] + (extra ? extra[n] : 0)
+void launch_argmax_rows(const float* logits, int ld, int rows, int n_valid, const float* extra, int32_t* ids, hipStream_t s);
 
 // ---- LFR stacking + CMVN + positions + prompt rows (Export_SenseVoice.py:280-287)
 struct LfrArgs {

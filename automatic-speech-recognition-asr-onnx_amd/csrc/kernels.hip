@@ -25,9 +25,22 @@ __global__ __launch_bounds__(256) void fbank_kernel(const FbankArgs a) {
   const UttPlan up = a.plan[u];
   const float* src = a.audio + up.audio_off;
   const int s0 = f0 * HOP;
-  for (int i = tid; i < FB_SPAN; i += 256) {
-    const int s = s0 + i;
-    aud[i + i / HOP] = (s < up.n_samples) ? src[s] : 0.0f;
+  if (!a.whisper) {
+    for (int i = tid; i < FB_SPAN; i += 256) {
+      const int s = s0 + i;
+      aud[i + i / HOP] = (s < up.n_samples) ? src[s] : 0.0f;
+    }
+  } else {
+    // padded signal = [x[200..1] | x | x[L-2 .. L-41]]  (reflect, right pad shortened by one hop)
+    const int L = up.n_samples, half = WIN / 2;
+    for (int i = tid; i < FB_SPAN; i += 256) {
+      const int p = s0 + i;
+      float v = 0.0f;
+      if (p < half) v = src[half - p];
+      else if (p < half + L) v = src[p - half];
+      else if (p < L + WIN - HOP) v = src[2 * L + half - 2 - p];
+      aud[i + i / HOP] = v;
+    }
   }
   __syncthreads();
 
@@ -67,6 +80,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(const FbankArgs a) {
   __syncthreads();
 
   // mel: wave w owns frames [16w, 16w+16); all mel tiles
+  float wmax = -INFINITY;
   const float4* melp = reinterpret_cast<const float4*>(a.mel_packed);
   for (int nt = 0; nt < a.n_mel_tiles; ++nt) {
     f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -82,9 +96,20 @@ __global__ __launch_bounds__(256) void fbank_kernel(const FbankArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = f0 + wave * 16 + fgrp * 4 + r;
-      if (f < up.n_frames)
-        a.mel_out[(size_t)(up.frame_off + f) * a.n_mels + nt * 16 + frow] = logf(fmaxf(acc[r], a.log_floor));
+      if (f < up.n_frames) {
+        const float c = fmaxf(acc[r], a.log_floor);
+        const float v = a.whisper ? log10f(c) : logf(c);
+        a.mel_out[(size_t)(up.frame_off + f) * a.n_mels + nt * 16 + frow] = v;
+        wmax = fmaxf(wmax, v);
+      }
     }
+  }
+  if (a.whisper) {
+    __shared__ float red[4];
+    wmax = wave_max(wmax);
+    if (lane == 0) red[wave] = wmax;
+    __syncthreads();
+    if (tid == 0) a.blk_max[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   }
 }
 
@@ -478,6 +503,195 @@ __global__ __launch_bounds__(256) void ctc_collapse_kernel(const int32_t* __rest
   if (tid == 0) num_id[u] = running;
 }
 
+
+// ------------------------------------------------------------------------------------ Whisper log-mel finish / conv padding
+__device__ __forceinline__ int gapped_frame(const UttPlan& up, int j) {   // frame index of gapped row j, or -1
+  const int f = j - 2 * up.row_off - 1;
+  return (f >= 0 && f < up.n_frames) ? f : -1;
+}
+
+template <typename T>
+__global__ void whisper_mel_finish_kernel(const float* __restrict__ mel, const float* __restrict__ blk_max,
+                                          const UttPlan* __restrict__ plan, const int32_t* __restrict__ grow_utt, int n_mels,
+                                          T* __restrict__ out) {
+  const int j = blockIdx.x;
+  T* o = out + (size_t)j * n_mels;
+  const int u = grow_utt[j];
+  int f = -1;
+  UttPlan up;
+  if (u >= 0) { up = plan[u]; f = gapped_frame(up, j); }
+  if (f < 0) {
+    for (int c = threadIdx.x; c < n_mels; c += blockDim.x) Elem<T>::store(o + c, 0.0f);
+    return;
+  }
+  float gmax = -INFINITY;                                   // global max over the clip (Export_Whisper.py:426)
+  const int nblk = (up.n_frames + FB_FRAMES - 1) / FB_FRAMES;
+  for (int k = 0; k < nblk; ++k) gmax = fmaxf(gmax, blk_max[up.blk0 + k]);
+  for (int c = threadIdx.x; c < n_mels; c += blockDim.x) {
+    float v = mel[(size_t)(up.frame_off + f) * n_mels + c];
+    v = fmaxf(v, gmax - 8.0f);
+    Elem<T>::store(o + c, (v + 4.0f) * 0.25f);
+  }
+}
+
+template <typename T>
+__global__ void zero_gap_rows_kernel(T* __restrict__ buf, int ld, int n_cols, const UttPlan* __restrict__ plan,
+                                     const int32_t* __restrict__ grow_utt) {
+  const int j = blockIdx.x;
+  const int u = grow_utt[j];
+  if (u >= 0 && gapped_frame(plan[u], j) >= 0) return;
+  T* o = buf + (size_t)j * ld;
+  for (int c = threadIdx.x; c < n_cols; c += blockDim.x) Elem<T>::store(o + c, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------ decoder embedding
+template <typename T>
+__global__ void embed_pos_kernel(const int32_t* __restrict__ ids, int n, int hist, const T* __restrict__ embed,
+                                 const float* __restrict__ pos, int d, float* __restrict__ x) {
+  const int r = blockIdx.x;
+  const T* e = embed + (size_t)ids[r] * d;
+  const float* p = pos + (size_t)(hist + r % n) * d;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) x[(size_t)r * d + c] = Elem<T>::load(e + c) + p[c];
+}
+
+// ------------------------------------------------------------------------------------ decoder attention (head_dim 64)
+// One workgroup per (sequence, head). Rows of 64 are read cooperatively: 8 lanes per row (8 dims each), 8 rows per
+// wave-instruction = 1 KiB contiguous (self cache / cross slab are [row][64]), so the K and V streams are fully
+// coalesced -- the cross-attention stream is the HBM-bound part of a decode step.
+constexpr int DA_MAXN = 8;
+constexpr int DA_MAXKEYS = 1536;
+
+template <typename T> __device__ __forceinline__ void load8dims(const T* p, float (&o)[8]) { load8<T>(p, o); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
+  __shared__ float sc[DA_MAXN * DA_MAXKEYS];
+  __shared__ float qs[DA_MAXN][64];
+  __shared__ float red[4][DA_MAXN][64];
+  __shared__ float stat[2][DA_MAXN];
+  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane & 7;                     // which 8 dims of the row
+  const int n = a.n;
+  int n_cached, row0 = 0;
+  if (a.plan) { n_cached = a.plan[b].n_lfr; row0 = a.plan[b].row_off; }
+  else n_cached = a.hist;
+  const int S = a.plan ? n_cached : a.hist + n;
+  const T* Kc = reinterpret_cast<const T*>(a.k_base) + (size_t)b * a.stride_b + (size_t)h * a.stride_h + (size_t)row0 * 64;
+  const T* Vc = reinterpret_cast<const T*>(a.v_base) + (size_t)b * a.stride_b + (size_t)h * a.stride_h + (size_t)row0 * 64;
+  const T* Q = reinterpret_cast<const T*>(a.q);
+  const T* NEW = reinterpret_cast<const T*>(a.kv_new);
+
+  for (int i = tid; i < n * 64; i += 256) qs[i >> 6][i & 63] = Elem<T>::load(Q + (size_t)(b * n + (i >> 6)) * a.ld_q + a.q_col0 + h * 64 + (i & 63));
+  if (NEW) {                                   // append the new rows to the cache (read back only by later steps)
+    T* Kw = const_cast<T*>(Kc);
+    T* Vw = const_cast<T*>(Vc);
+    for (int i = tid; i < n * 64; i += 256) {
+      const size_t src = (size_t)(b * n + (i >> 6)) * a.ld_new + h * 64 + (i & 63);
+      Kw[(size_t)(a.hist + (i >> 6)) * 64 + (i & 63)] = NEW[src + a.k_col0];
+      Vw[(size_t)(a.hist + (i >> 6)) * 64 + (i & 63)] = NEW[src + a.v_col0];
+    }
+  }
+  __syncthreads();
+  // ---- scores
+  for (int s0 = (tid >> 3); s0 < S; s0 += 32) {
+    float kv[8];
+    if (s0 < n_cached) load8dims<T>(Kc + (size_t)s0 * 64 + sub * 8, kv);
+    else load8dims<T>(NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.k_col0 + h * 64 + sub * 8, kv);
+    for (int i = 0; i < n; ++i) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc = fmaf(qs[i][sub * 8 + e], kv[e], acc);
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 4, 64);
+      if (sub == 0) sc[i * DA_MAXKEYS + s0] = acc + ((a.causal && s0 > a.hist + i) ? -128.0f : 0.0f);
+    }
+  }
+  __syncthreads();
+  // ---- soft-max statistics per query (wave w handles queries w, w+4)
+  for (int i = wave; i < n; i += 4) {
+    float mx = -INFINITY;
+    for (int s = lane; s < S; s += 64) mx = fmaxf(mx, sc[i * DA_MAXKEYS + s]);
+    mx = wave_max(mx);
+    float sum = 0.0f;
+    for (int s = lane; s < S; s += 64) {
+      const float e = expf(sc[i * DA_MAXKEYS + s] - mx);
+      sc[i * DA_MAXKEYS + s] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) stat[0][i] = 1.0f / sum;
+  }
+  __syncthreads();
+  // ---- context: each 8-lane group walks keys s = group, group + 32, ...
+  float acc[DA_MAXN][8];
+#pragma unroll
+  for (int i = 0; i < DA_MAXN; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[i][e] = 0.0f;
+  for (int s0 = (tid >> 3); s0 < S; s0 += 32) {
+    float vv[8];
+    if (s0 < n_cached) load8dims<T>(Vc + (size_t)s0 * 64 + sub * 8, vv);
+    else load8dims<T>(NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.v_col0 + h * 64 + sub * 8, vv);
+#pragma unroll
+    for (int i = 0; i < DA_MAXN; ++i) {
+      if (i < n) {
+        const float p = sc[i * DA_MAXKEYS + s0];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[i][e] = fmaf(p, vv[e], acc[i][e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DA_MAXN; ++i) {
+    if (i < n) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = acc[i][e];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 8) red[wave][i][sub * 8 + e] = v;
+      }
+    }
+  }
+  __syncthreads();
+  T* O = reinterpret_cast<T*>(a.out);
+  for (int i = tid; i < n * 64; i += 256) {
+    const int qi = i >> 6, dd = i & 63;
+    const float v = (red[0][qi][dd] + red[1][qi][dd]) + (red[2][qi][dd] + red[3][qi][dd]);
+    Elem<T>::store(O + (size_t)(b * n + qi) * a.ld_out + h * 64 + dd, v * stat[0][qi]);
+  }
+}
+
+// ------------------------------------------------------------------------------------ row arg-max
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ logits, int ld, int n_valid,
+                                                          const float* __restrict__ extra, int32_t* __restrict__ ids) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* x = logits + (size_t)r * ld;
+  float best = -INFINITY;
+  int bidx = 0x7fffffff;
+  for (int c = tid; c < n_valid; c += 256) {
+    const float v = x[c] + (extra ? extra[c] : 0.0f);
+    if (v > best) { best = v; bidx = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bidx, o, 64);
+    if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+  }
+  if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < bidx)) { best = bv[w]; bidx = bi[w]; }
+    ids[r] = bidx;
+  }
+}
+
 }  // namespace
 
 // ==================================================================================== launchers
@@ -541,5 +755,45 @@ template void launch_fsmn<bf16_t>(const bf16_t*, int, const float*, const float*
 void launch_ctc_collapse(const int32_t* frame_ids, const UttPlan* plan, int n_utts, int blank_id, int32_t* token_ids,
                          int max_tokens, int32_t* num_id, hipStream_t s) {
   hipLaunchKernelGGL(ctc_collapse_kernel, dim3(n_utts), dim3(256), 0, s, frame_ids, plan, blank_id, token_ids, max_tokens, num_id);
+  HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void launch_whisper_mel_finish(const float* mel, const float* blk_max, const UttPlan* plan, const int32_t* grow_utt,
+                               int n_gapped_rows, int n_mels, T* out, hipStream_t s) {
+  hipLaunchKernelGGL(whisper_mel_finish_kernel<T>, dim3(n_gapped_rows), dim3(128), 0, s, mel, blk_max, plan, grow_utt, n_mels, out);
+  HIP_CHECK(hipGetLastError());
+}
+template void launch_whisper_mel_finish<float>(const float*, const float*, const UttPlan*, const int32_t*, int, int, float*, hipStream_t);
+template void launch_whisper_mel_finish<bf16_t>(const float*, const float*, const UttPlan*, const int32_t*, int, int, bf16_t*, hipStream_t);
+
+template <typename T>
+void launch_zero_gap_rows(T* buf, int ld, int n_cols, const UttPlan* plan, const int32_t* grow_utt, int n_gapped_rows, hipStream_t s) {
+  hipLaunchKernelGGL(zero_gap_rows_kernel<T>, dim3(n_gapped_rows), dim3(256), 0, s, buf, ld, n_cols, plan, grow_utt);
+  HIP_CHECK(hipGetLastError());
+}
+template void launch_zero_gap_rows<float>(float*, int, int, const UttPlan*, const int32_t*, int, hipStream_t);
+template void launch_zero_gap_rows<bf16_t>(bf16_t*, int, int, const UttPlan*, const int32_t*, int, hipStream_t);
+
+template <typename T>
+void launch_embed_pos(const int32_t* ids, int rows, int n, int hist, const T* embed, const float* pos, int d, float* x, hipStream_t s) {
+  hipLaunchKernelGGL(embed_pos_kernel<T>, dim3(rows), dim3(256), 0, s, ids, n, hist, embed, pos, d, x);
+  HIP_CHECK(hipGetLastError());
+}
+template void launch_embed_pos<float>(const int32_t*, int, int, int, const float*, const float*, int, float*, hipStream_t);
+template void launch_embed_pos<bf16_t>(const int32_t*, int, int, int, const bf16_t*, const float*, int, float*, hipStream_t);
+
+template <typename T>
+void launch_decode_attention(const DecAttnArgs& a, int batch, hipStream_t s) {
+  ASR_REQUIRE(a.n >= 1 && a.n <= DA_MAXN, "decode attention: %d new positions per call (max %d)", a.n, DA_MAXN);
+  ASR_REQUIRE(a.plan || a.hist + a.n <= DA_MAXKEYS, "decode attention: %d keys exceed %d", a.hist + a.n, DA_MAXKEYS);
+  hipLaunchKernelGGL(decode_attn_kernel<T>, dim3(batch, a.n_heads), dim3(256), 0, s, a);
+  HIP_CHECK(hipGetLastError());
+}
+template void launch_decode_attention<float>(const DecAttnArgs&, int, hipStream_t);
+template void launch_decode_attention<bf16_t>(const DecAttnArgs&, int, hipStream_t);
+
+void launch_argmax_rows(const float* logits, int ld, int rows, int n_valid, const float* extra, int32_t* ids, hipStream_t s) {
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, s, logits, ld, n_valid, extra, ids);
   HIP_CHECK(hipGetLastError());
 }

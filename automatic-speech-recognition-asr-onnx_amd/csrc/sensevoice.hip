@@ -134,7 +134,7 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
     p.T = p.n_lfr + c.n_prompt;
     p.row_off = rows;
     p.lang = lang[b];
-    p.pad_ = 0;
+    p.blk0 = n_fb;
     frames += p.n_frames;
     rows += round_up(p.T, 16);
     n_fb += (p.n_frames + 63) / 64;
@@ -212,7 +212,7 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
     fa.audio = d_aud; fa.plan = dp; fa.blk_utt = d_blk_utt; fa.blk_f0 = d_blk_f0;
     fa.dft_packed = dft; fa.mel_packed = melp; fa.mel_out = d_mel.as<float>();
     fa.n_bin_tiles = n_bin_tiles; fa.n_kchunks = n_kchunks; fa.n_mel_tiles = c.n_mels / 16; fa.n_mels = c.n_mels;
-    fa.win = c.win_length; fa.hop = c.hop_length; fa.log_floor = 1.1920928955078125e-07f;
+    fa.win = c.win_length; fa.hop = c.hop_length; fa.log_floor = 1.1920928955078125e-07f; fa.whisper = 0; fa.blk_max = nullptr;
     launch_fbank(fa, n_fb, stream);
   }
   save_tap("mel", d_mel.ptr, frames, c.n_mels, c.n_mels, 4);

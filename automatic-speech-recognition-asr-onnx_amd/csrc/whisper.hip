@@ -1,0 +1,527 @@
+// Whisper hot path on one MI355X.
+//   encode : packed ragged batch -> STFT power / log-mel -> conv stem (two strided-view GEMMs, no im2col) ->
+//            N encoder layers -> fused cross-KV projection written straight into per-(layer, head) slabs.
+//            Follows WHISPER_ENCODER.forward (Whisper/Export_Whisper.py:422-447) + STFT_Process (:224-246).
+//   prefill / decode : token+position embedding -> M decoder layers (self-attention with an in-place KV cache,
+//            cross-attention over the slabs, FFN) -> tied proj_out + (-128) suppress penalty -> arg-max.
+//            Follows WHISPER_DECODER_EMBED / WHISPER_PREFILL / WHISPER_DECODE / WHISPER_DECODER.forward
+//            (:450-497,614-667) and the BEGIN_SUPPRESS / ARGMAX heads (:228-260).
+// The reference grows the self-KV by torch.cat every token (O(L^2) copies, :640-641) and shuttles 128 KV tensors
+// through Python per step; here the cache is appended in place and token ids stay on the device between steps.
+#include <cstring>
+
+#include "../../include/asr_mi355x.h"
+#include "engine.h"
+#include "gemm.h"
+#include "kernels.h"
+
+namespace {
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct EncLayer { const void *wqkv, *wo, *w1, *w2; const float *bqkv, *bo, *b1, *b2; };
+struct DecLayer { const void *wqkv, *wo, *wcq, *wco, *w1, *w2; const float *bqkv, *bo, *bcq, *bco, *b1, *b2; };
+
+struct WhSession : asr_session {
+  asr_whisper_config cfg;
+  int vpad = 0, n_bin_tiles = 0, n_kchunks = 0, act = ACT_GELU_ERF;
+  std::vector<EncLayer> enc;
+  std::vector<DecLayer> dec;
+  const float *dft = nullptr, *melp = nullptr, *conv1_b = nullptr, *conv2_b = nullptr, *enc_pos = nullptr, *enc_ln_g = nullptr,
+              *enc_ln_b = nullptr, *ckv_b = nullptr, *dec_pos = nullptr, *suppress = nullptr, *begin = nullptr, *dec_ln_g = nullptr,
+              *dec_ln_b = nullptr;
+  const void *conv1_w = nullptr, *conv2_w = nullptr, *ckv_w = nullptr, *embed = nullptr;
+
+  // encoder state of the current batch
+  int batch = 0, rows = 0, Mpad = 0, hist = 0;
+  std::vector<UttPlan> plan;
+  DeviceBuffer d_plan, d_audio, d_mel, d_blkmax, d_x0, d_h1, d_xa, d_xb, d_xc, d_h, d_qk, d_vt, d_ctx, d_ffn, d_cross;
+  // decoder state
+  DeviceBuffer d_kc, d_vc, d_ids, d_next, d_logits, d_dx, d_dqkv, d_dtok;
+  int dec_batch_cap = 0;
+  void* h_plan = nullptr; size_t h_plan_cap = 0;
+  void* h_io = nullptr; size_t h_io_cap = 0;
+
+  ~WhSession() override {
+    for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_x0, &d_h1, &d_xa, &d_xb, &d_xc, &d_h, &d_qk, &d_vt, &d_ctx,
+                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok})
+      b->release();
+    for (auto& kv : taps) kv.second.buf.release();
+    if (h_plan) (void)hipHostFree(h_plan);
+    if (h_io) (void)hipHostFree(h_io);
+    prof.release();
+    arena.release();
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
+  void init();
+  void gemm(const GemmArgs& g) { precision == ASR_PRECISION_BF16 ? launch_gemm_bf16(g, stream) : launch_gemm_f32(g, stream); }
+  void* pinned(size_t bytes) {
+    if (bytes > h_io_cap) {
+      if (h_io) HIP_CHECK(hipHostFree(h_io));
+      HIP_CHECK(hipHostMalloc(&h_io, bytes * 2, hipHostMallocDefault));
+      h_io_cap = bytes * 2;
+    }
+    return h_io;
+  }
+  template <typename T> void encode(const float* audio, int audio_mem, const int64_t* offs, int B, int32_t* n_pos_out);
+  template <typename T> void step(const int32_t* ids_host, int n, bool is_prefill, int32_t* next_out, float* logits_out);
+};
+
+void WhSession::init() {
+  const auto& c = cfg;
+  ASR_REQUIRE(c.d_model == c.n_heads * c.d_head && c.d_head == 64, "whisper: head_dim must be 64 and d_model = heads * 64");
+  ASR_REQUIRE(c.d_model % 128 == 0 && c.d_ffn % 128 == 0, "whisper: d_model and d_ffn must be multiples of 128");
+  ASR_REQUIRE(c.nfft == 400 && c.hop_length == 160, "whisper: front-end is built for n_fft 400 / hop 160");
+  ASR_REQUIRE(c.n_mels % 16 == 0 && (3 * c.n_mels) % 64 == 0, "whisper: n_mels must make 3*n_mels a multiple of 64");
+  ASR_REQUIRE(c.max_target_positions <= 1536, "whisper: decoder context too long for the attention kernel");
+  vpad = round_up(c.vocab, 128);
+  n_bin_tiles = (c.nfft / 2 + 1 + 15) / 16;
+  n_kchunks = c.nfft / 16;
+  act = c.gelu_tanh ? ACT_GELU_TANH : ACT_GELU_ERF;
+  const int wt = precision == ASR_PRECISION_BF16 ? ARENA_BF16 : ARENA_F32;
+  const int d = c.d_model, dff = c.d_ffn, Ld = c.n_dec_layers;
+  auto F = [&](const std::string& n, std::initializer_list<int64_t> sh) { return (const float*)arena.get(n, ARENA_F32, sh).ptr; };
+  auto W = [&](const std::string& n, std::initializer_list<int64_t> sh) { return arena.get(n, wt, sh).ptr; };
+  dft = F("fe.dft", {(int64_t)n_bin_tiles * 2 * n_kchunks * 64 * 4});
+  melp = F("fe.mel", {(int64_t)(c.n_mels / 16) * n_bin_tiles * 64 * 4});
+  conv1_w = W("enc.conv1_w", {d, 3 * c.n_mels});
+  conv1_b = F("enc.conv1_b", {d});
+  conv2_w = W("enc.conv2_w", {d, 3 * d});
+  conv2_b = F("enc.conv2_b", {d});
+  enc_pos = F("enc.pos", {c.max_source_positions, d});
+  enc_ln_g = F("enc.ln_g", {d});
+  enc_ln_b = F("enc.ln_b", {d});
+  ckv_w = W("ckv.w", {2 * Ld * d, d});
+  ckv_b = F("ckv.b", {2 * Ld * d});
+  embed = W("dec.embed", {vpad, d});
+  dec_pos = F("dec.pos", {c.max_target_positions, d});
+  suppress = F("dec.suppress", {vpad});
+  begin = F("dec.begin", {vpad});
+  dec_ln_g = F("dec.ln_g", {d});
+  dec_ln_b = F("dec.ln_b", {d});
+  enc.resize(c.n_enc_layers);
+  for (int i = 0; i < c.n_enc_layers; ++i) {
+    const std::string p = "enc" + std::to_string(i) + ".";
+    enc[i] = EncLayer{W(p + "wqkv", {3 * d, d}), W(p + "wo", {d, d}), W(p + "w1", {dff, d}), W(p + "w2", {d, dff}),
+                      F(p + "bqkv", {3 * d}), F(p + "bo", {d}), F(p + "b1", {dff}), F(p + "b2", {d})};
+  }
+  dec.resize(Ld);
+  for (int i = 0; i < Ld; ++i) {
+    const std::string p = "dec" + std::to_string(i) + ".";
+    dec[i] = DecLayer{W(p + "wqkv", {3 * d, d}), W(p + "wo", {d, d}), W(p + "wcq", {d, d}), W(p + "wco", {d, d}),
+                      W(p + "w1", {dff, d}), W(p + "w2", {d, dff}),
+                      F(p + "bqkv", {3 * d}), F(p + "bo", {d}), F(p + "bcq", {d}), F(p + "bco", {d}), F(p + "b1", {dff}), F(p + "b2", {d})};
+  }
+}
+
+// ======================================================================================== encoder
+template <typename T>
+void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, int B, int32_t* n_pos_out) {
+  const auto& c = cfg;
+  ASR_REQUIRE(B > 0 && audio && offs, "whisper_encode: bad argument");
+  HIP_CHECK(hipSetDevice(device));
+  const int d = c.d_model, dff = c.d_ffn, Ld = c.n_dec_layers, H = c.n_heads;
+  plan.assign(B, UttPlan{});
+  int r = 0, frames = 0, n_fb = 0, n_qb = 0;
+  const int64_t base0 = offs[0];
+  for (int b = 0; b < B; ++b) {
+    const int64_t n = offs[b + 1] - offs[b];
+    ASR_REQUIRE(n >= c.nfft, "whisper: utterance %d has %lld samples (< n_fft %d)", b, (long long)n, c.nfft);
+    ASR_REQUIRE(n <= c.max_audio_len, "whisper: utterance %d has %lld samples (> max_audio_len %d)", b, (long long)n, c.max_audio_len);
+    UttPlan& p = plan[b];
+    p.audio_off = offs[b] - base0;
+    p.n_samples = (int)n;
+    p.n_frames = (int)n / c.hop_length;                 // centred STFT with the last frame dropped (:96-103)
+    p.frame_off = frames;
+    p.T = (p.n_frames + 1) / 2;                          // conv2 stride 2, pad 1
+    p.n_lfr = p.T;
+    ASR_REQUIRE(p.T <= c.max_source_positions, "whisper: %d encoder positions exceed max_source_positions", p.T);
+    p.row_off = r;
+    p.lang = 0;
+    p.blk0 = n_fb;
+    frames += p.n_frames;
+    r += round_up(p.T + 1, 16);                          // +1: room for the conv stem's right zero-pad frame
+    n_fb += (p.n_frames + 63) / 64;
+    n_qb += (p.T + 63) / 64;
+    if (n_pos_out) n_pos_out[b] = p.T;
+  }
+  batch = B; rows = r; Mpad = round_up(r, 128); hist = 0;
+  const int R = 2 * Mpad;                                // gapped (frame-rate) rows
+  const int64_t total_samples = offs[B] - base0;
+
+  // plan blob: [UttPlan B][blk_utt][blk_f0][qb_utt][qb_q0][row_utt Mpad][pos_rows Mpad][grow_utt R]
+  const size_t plan_bytes = sizeof(UttPlan) * B + 4 * (2 * (size_t)n_fb + 2 * (size_t)n_qb + 2 * (size_t)Mpad + R);
+  if (plan_bytes > h_plan_cap) {
+    if (h_plan) HIP_CHECK(hipHostFree(h_plan));
+    HIP_CHECK(hipHostMalloc(&h_plan, plan_bytes * 2, hipHostMallocDefault));
+    h_plan_cap = plan_bytes * 2;
+  }
+  unsigned char* hp = (unsigned char*)h_plan;
+  memcpy(hp, plan.data(), sizeof(UttPlan) * B);
+  int32_t* blk_utt = (int32_t*)(hp + sizeof(UttPlan) * B);
+  int32_t* blk_f0 = blk_utt + n_fb;
+  int32_t* qb_utt = blk_f0 + n_fb;
+  int32_t* qb_q0 = qb_utt + n_qb;
+  int32_t* row_utt = qb_q0 + n_qb;
+  int32_t* pos_rows = row_utt + Mpad;
+  int32_t* grow_utt = pos_rows + Mpad;
+  for (int i = 0; i < Mpad; ++i) { row_utt[i] = -1; pos_rows[i] = 0; }
+  for (int i = 0; i < R; ++i) grow_utt[i] = -1;
+  {
+    int fi = 0, qi = 0;
+    for (int b = 0; b < B; ++b) {
+      for (int f0 = 0; f0 < plan[b].n_frames; f0 += 64) { blk_utt[fi] = b; blk_f0[fi++] = f0; }
+      for (int q0 = 0; q0 < plan[b].T; q0 += 64) { qb_utt[qi] = b; qb_q0[qi++] = q0; }
+      const int rb = round_up(plan[b].T + 1, 16);
+      for (int t = 0; t < rb; ++t) {
+        row_utt[plan[b].row_off + t] = b;
+        pos_rows[plan[b].row_off + t] = t < plan[b].T ? t : 0;
+        grow_utt[2 * (plan[b].row_off + t)] = b;
+        grow_utt[2 * (plan[b].row_off + t) + 1] = b;
+      }
+    }
+  }
+  d_plan.reserve(plan_bytes, stream);
+  HIP_CHECK(hipMemcpyAsync(d_plan.ptr, h_plan, plan_bytes, hipMemcpyHostToDevice, stream));
+  const UttPlan* dp = d_plan.as<UttPlan>();
+  const int32_t* d_blk_utt = (const int32_t*)((unsigned char*)d_plan.ptr + sizeof(UttPlan) * B);
+  const int32_t* d_blk_f0 = d_blk_utt + n_fb;
+  const int32_t* d_qb_utt = d_blk_f0 + n_fb;
+  const int32_t* d_qb_q0 = d_qb_utt + n_qb;
+  const int32_t* d_row_utt = d_qb_q0 + n_qb;
+  const int32_t* d_pos_rows = d_row_utt + Mpad;
+  const int32_t* d_grow_utt = d_pos_rows + Mpad;
+  (void)d_row_utt;
+
+  const size_t eT = sizeof(T);
+  const float* d_aud;
+  if (audio_mem == ASR_MEM_HOST) {
+    d_audio.reserve((size_t)total_samples * 4, stream);
+    HIP_CHECK(hipMemcpyAsync(d_audio.ptr, audio + base0, (size_t)total_samples * 4, hipMemcpyHostToDevice, stream));
+    d_aud = d_audio.as<float>();
+  } else {
+    d_aud = audio + base0;
+  }
+  const int Rpad = R + 256;                                        // tile-edge + halo rows of the strided conv views
+  d_mel.reserve((size_t)frames * c.n_mels * 4, stream);
+  d_blkmax.reserve((size_t)n_fb * 4, stream);
+  d_x0.reserve((size_t)(Rpad + 1) * c.n_mels * eT, stream);
+  d_h1.reserve((size_t)Rpad * d * eT, stream);
+  d_xa.reserve((size_t)Mpad * d * 4, stream);
+  d_xb.reserve((size_t)Mpad * d * 4, stream);
+  d_h.reserve((size_t)Mpad * d * eT, stream);
+  d_qk.reserve((size_t)Mpad * 2 * d * eT, stream);
+  d_vt.reserve((size_t)Mpad * d * eT, stream);
+  d_ctx.reserve((size_t)Mpad * d * eT, stream);
+  d_ffn.reserve((size_t)Mpad * dff * eT, stream);
+  d_cross.reserve((size_t)2 * Ld * H * Mpad * 64 * eT, stream);
+
+  // ---- STFT power -> mel -> log10 (STFT_Process.py:224-246, Export_Whisper.py:424-425)
+  {
+    ProfScope ps(prof, "logmel", stream);
+    FbankArgs fa;
+    fa.audio = d_aud; fa.plan = dp; fa.blk_utt = d_blk_utt; fa.blk_f0 = d_blk_f0; fa.dft_packed = dft; fa.mel_packed = melp;
+    fa.mel_out = d_mel.as<float>(); fa.n_bin_tiles = n_bin_tiles; fa.n_kchunks = n_kchunks; fa.n_mel_tiles = c.n_mels / 16;
+    fa.n_mels = c.n_mels; fa.win = c.nfft; fa.hop = c.hop_length; fa.log_floor = 1e-10f; fa.whisper = 1;
+    fa.blk_max = d_blkmax.as<float>();
+    launch_fbank(fa, n_fb, stream);
+    // per-utterance max clamp + (x+4)/4, written behind one leading zero row (the conv view of row j starts at j-1)
+    T* x0 = d_x0.as<T>();
+    HIP_CHECK(hipMemsetAsync(x0, 0, (size_t)c.n_mels * eT, stream));
+    launch_whisper_mel_finish<T>(d_mel.as<float>(), d_blkmax.as<float>(), dp, d_grow_utt, R, c.n_mels, x0 + c.n_mels, stream);
+  }
+  if (taps_enabled) save_tap("mel_gapped", d_x0.as<T>() + c.n_mels, R, c.n_mels, c.n_mels, (int)eT);
+  // ---- conv stem as two GEMMs over strided views (no im2col): conv1 row j = frames j-1..j+1, conv2 row m = rows 2m..2m+2
+  {
+    ProfScope ps(prof, "conv_stem", stream);
+    GemmArgs g1;
+    g1.A = d_x0.ptr; g1.lda = c.n_mels; g1.W = conv1_w; g1.ldw = 3 * c.n_mels; g1.M = R; g1.N = d; g1.K = 3 * c.n_mels;
+    g1.bias = conv1_b; g1.act = act; g1.out_lo = d_h1.ptr; g1.ld_out_lo = d;
+    gemm(g1);
+    launch_zero_gap_rows<T>(d_h1.as<T>(), d, d, dp, d_grow_utt, R, stream);      // conv2's zero padding
+    GemmArgs g2;
+    g2.A = d_h1.ptr; g2.lda = 2 * d; g2.W = conv2_w; g2.ldw = 3 * d; g2.M = rows; g2.N = d; g2.K = 3 * d; g2.bias = conv2_b;
+    g2.act = act; g2.add2 = enc_pos; g2.ld_add2 = d; g2.add2_rows = d_pos_rows; g2.out_f32 = d_xa.as<float>(); g2.ld_out_f32 = d;
+    gemm(g2);
+  }
+  if (taps_enabled) save_tap("stem", d_xa.ptr, rows, d, d, 4);
+  // ---- encoder layers (:430-437)
+  float* xa = d_xa.as<float>();
+  float* xb = d_xb.as<float>();
+  T* h = d_h.as<T>();
+  T* qk = d_qk.as<T>();
+  T* vt = d_vt.as<T>();
+  T* ctx = d_ctx.as<T>();
+  T* ffn = d_ffn.as<T>();
+  for (int i = 0; i < c.n_enc_layers; ++i) {
+    const EncLayer& L = enc[i];
+    { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(xa, d, rows, d, nullptr, nullptr, 1e-5f, h, d, d, stream); }
+    {
+      ProfScope ps(prof, "gemm_qkv", stream);
+      GemmArgs g;
+      g.A = h; g.lda = d; g.W = L.wqkv; g.ldw = d; g.M = rows; g.N = 2 * d; g.K = d; g.bias = L.bqkv; g.out_lo = qk; g.ld_out_lo = 2 * d;
+      gemm(g);
+      GemmArgs gv;
+      gv.A = h; gv.lda = d; gv.W = (const T*)L.wqkv + (size_t)2 * d * d; gv.ldw = d; gv.M = rows; gv.N = d; gv.K = d;
+      gv.bias = L.bqkv + 2 * d; gv.out_t = vt; gv.ld_out_t = Mpad;
+      gemm(gv);
+    }
+    {
+      ProfScope ps(prof, "attention", stream);
+      AttnArgs aa;
+      aa.q = qk; aa.k = qk + d; aa.ld_qk = 2 * d; aa.vt = vt; aa.ld_vt = Mpad; aa.ctx = ctx; aa.ld_ctx = d; aa.plan = dp;
+      aa.qb_utt = d_qb_utt; aa.qb_q0 = d_qb_q0; aa.n_qblocks = n_qb; aa.n_heads = H;
+      if (precision == ASR_PRECISION_BF16) launch_attention_bf16_hd64(aa, stream);
+      else launch_attention_f32(aa, c.d_head, stream);
+    }
+    {
+      ProfScope ps(prof, "gemm_out", stream);
+      GemmArgs g;
+      g.A = ctx; g.lda = d; g.W = L.wo; g.ldw = d; g.M = rows; g.N = d; g.K = d; g.bias = L.bo; g.add = xa; g.ld_add = d;
+      g.out_f32 = xb; g.ld_out_f32 = d;
+      gemm(g);
+    }
+    { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(xb, d, rows, d, nullptr, nullptr, 1e-5f, h, d, d, stream); }
+    {
+      ProfScope ps(prof, "gemm_ffn1", stream);
+      GemmArgs g;
+      g.A = h; g.lda = d; g.W = L.w1; g.ldw = d; g.M = rows; g.N = dff; g.K = d; g.bias = L.b1; g.act = act; g.out_lo = ffn; g.ld_out_lo = dff;
+      gemm(g);
+    }
+    {
+      ProfScope ps(prof, "gemm_ffn2", stream);
+      GemmArgs g;
+      g.A = ffn; g.lda = dff; g.W = L.w2; g.ldw = dff; g.M = rows; g.N = d; g.K = dff; g.bias = L.b2; g.add = xb; g.ld_add = d;
+      g.out_f32 = xa; g.ld_out_f32 = d;
+      gemm(g);
+    }
+  }
+  // ---- final LayerNorm + fused cross-KV projection into [kv][layer][head] slabs of [row][64] (:438-447)
+  if (taps_enabled) {
+    launch_layernorm<float>(xa, d, rows, d, enc_ln_g, enc_ln_b, 1e-5f, xb, d, d, stream);
+    save_tap("enc_out", xb, rows, d, d, 4);
+  }
+  { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(xa, d, rows, d, enc_ln_g, enc_ln_b, 1e-5f, h, d, d, stream); }
+  {
+    ProfScope ps(prof, "gemm_crosskv", stream);
+    GemmArgs g;
+    g.A = h; g.lda = d; g.W = ckv_w; g.ldw = d; g.M = rows; g.N = 2 * Ld * d; g.K = d; g.bias = ckv_b;
+    g.out_lo = d_cross.ptr; g.lo_group = 64; g.ld_out_lo = Mpad * 64;
+    gemm(g);
+  }
+  if (taps_enabled) save_tap("cross", d_cross.ptr, (int64_t)2 * Ld * H * Mpad, 64, 64, (int)eT);
+  HIP_CHECK(hipStreamSynchronize(stream));
+  if (prof.enabled) prof.collect();
+}
+
+// ======================================================================================== decoder step
+template <typename T>
+void WhSession::step(const int32_t* ids_host, int n, bool is_prefill, int32_t* next_out, float* logits_out) {
+  const auto& c = cfg;
+  ASR_REQUIRE(batch > 0, "whisper: encode a batch before prefill / decode");
+  ASR_REQUIRE(n >= 1 && n <= 8, "whisper: %d tokens per step (1..8)", n);
+  if (is_prefill) hist = 0;                      // the reference always prefills with an empty self-KV (:476-480)
+  ASR_REQUIRE(hist + n <= c.max_target_positions, "whisper: %d positions exceed max_target_positions %d", hist + n, c.max_target_positions);
+  HIP_CHECK(hipSetDevice(device));
+  const int B = batch, d = c.d_model, dff = c.d_ffn, Ld = c.n_dec_layers, H = c.n_heads;
+  const int R = B * n, Rp = round_up(R, 128), Bp = round_up(B, 128);
+  const size_t eT = sizeof(T);
+  const size_t cache_elems = (size_t)Ld * B * H * c.max_target_positions * 64;
+  d_kc.reserve(cache_elems * eT, stream);
+  d_vc.reserve(cache_elems * eT, stream);
+  d_ids.reserve((size_t)B * 8 * 4, stream);
+  d_next.reserve((size_t)B * 4, stream);
+  d_logits.reserve((size_t)Bp * vpad * 4, stream);
+  d_dx.reserve((size_t)3 * Rp * d * 4, stream);                 // three f32 residual-stream buffers
+  d_dqkv.reserve((size_t)Rp * (3 * d + d + d + dff + d) * eT + (size_t)Bp * d * eT, stream);
+  float* xa = d_dx.as<float>();
+  float* xb = xa + (size_t)Rp * d;
+  float* xc = xb + (size_t)Rp * d;
+  T* qkv = d_dqkv.as<T>();
+  T* hh = qkv + (size_t)Rp * 3 * d;
+  T* ctx = hh + (size_t)Rp * d;
+  T* ffn = ctx + (size_t)Rp * d;
+  T* cq = ffn + (size_t)Rp * dff;
+  T* hl = cq + (size_t)Rp * d;
+  const int32_t* ids_dev;
+  if (ids_host) {
+    int32_t* stage = (int32_t*)pinned((size_t)R * 4);
+    for (int i = 0; i < R; ++i) {
+      ASR_REQUIRE(ids_host[i] >= 0 && ids_host[i] < c.vocab, "whisper: token id %d out of range", ids_host[i]);
+      stage[i] = ids_host[i];
+    }
+    HIP_CHECK(hipMemcpyAsync(d_ids.ptr, stage, (size_t)R * 4, hipMemcpyHostToDevice, stream));
+    ids_dev = d_ids.as<int32_t>();
+  } else {
+    ASR_REQUIRE(n == 1, "whisper: device-resident ids feed single-token decode steps only");
+    ids_dev = d_next.as<int32_t>();
+  }
+  const UttPlan* dp = d_plan.as<UttPlan>();
+  { ProfScope ps(prof, "dec_embed", stream); launch_embed_pos<T>(ids_dev, R, n, hist, (const T*)embed, dec_pos, d, xa, stream); }
+  const size_t cache_l = (size_t)B * H * c.max_target_positions * 64;
+  for (int l = 0; l < Ld; ++l) {
+    const DecLayer& L = dec[l];
+    { ProfScope ps(prof, "dec_layernorm", stream); launch_layernorm<T>(xa, d, R, d, nullptr, nullptr, 1e-5f, hh, d, d, stream); }
+    {
+      ProfScope ps(prof, "dec_gemm", stream);
+      GemmArgs g;
+      g.A = hh; g.lda = d; g.W = L.wqkv; g.ldw = d; g.M = R; g.N = 3 * d; g.K = d; g.bias = L.bqkv; g.out_lo = qkv; g.ld_out_lo = 3 * d;
+      gemm(g);
+    }
+    {
+      ProfScope ps(prof, "dec_self_attn", stream);
+      DecAttnArgs a;
+      a.q = qkv; a.ld_q = 3 * d; a.q_col0 = 0; a.kv_new = qkv; a.ld_new = 3 * d; a.k_col0 = d; a.v_col0 = 2 * d;
+      a.k_base = d_kc.as<T>() + l * cache_l; a.v_base = d_vc.as<T>() + l * cache_l;
+      a.stride_b = (int64_t)H * c.max_target_positions * 64; a.stride_h = (int64_t)c.max_target_positions * 64;
+      a.plan = nullptr; a.hist = hist; a.n = n; a.n_heads = H; a.causal = 1; a.out = ctx; a.ld_out = d;
+      launch_decode_attention<T>(a, B, stream);
+    }
+    {
+      ProfScope ps(prof, "dec_gemm", stream);
+      GemmArgs g;
+      g.A = ctx; g.lda = d; g.W = L.wo; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bo; g.add = xa; g.ld_add = d; g.out_f32 = xb; g.ld_out_f32 = d;
+      gemm(g);
+    }
+    { ProfScope ps(prof, "dec_layernorm", stream); launch_layernorm<T>(xb, d, R, d, nullptr, nullptr, 1e-5f, hh, d, d, stream); }
+    {
+      ProfScope ps(prof, "dec_gemm", stream);
+      GemmArgs g;
+      g.A = hh; g.lda = d; g.W = L.wcq; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bcq; g.out_lo = cq; g.ld_out_lo = d;
+      gemm(g);
+    }
+    {
+      ProfScope ps(prof, "dec_cross_attn", stream);
+      DecAttnArgs a;
+      a.q = cq; a.ld_q = d; a.q_col0 = 0; a.kv_new = nullptr; a.ld_new = 0; a.k_col0 = a.v_col0 = 0;
+      a.k_base = d_cross.as<T>() + (size_t)(0 * Ld + l) * H * Mpad * 64;
+      a.v_base = d_cross.as<T>() + (size_t)(1 * Ld + l) * H * Mpad * 64;
+      a.stride_b = 0; a.stride_h = (int64_t)Mpad * 64; a.plan = dp; a.hist = 0; a.n = n; a.n_heads = H; a.causal = 0;
+      a.out = ctx; a.ld_out = d;
+      launch_decode_attention<T>(a, B, stream);
+    }
+    {
+      ProfScope ps(prof, "dec_gemm", stream);
+      GemmArgs g;
+      g.A = ctx; g.lda = d; g.W = L.wco; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bco; g.add = xb; g.ld_add = d; g.out_f32 = xc; g.ld_out_f32 = d;
+      gemm(g);
+    }
+    { ProfScope ps(prof, "dec_layernorm", stream); launch_layernorm<T>(xc, d, R, d, nullptr, nullptr, 1e-5f, hh, d, d, stream); }
+    {
+      ProfScope ps(prof, "dec_gemm", stream);
+      GemmArgs g;
+      g.A = hh; g.lda = d; g.W = L.w1; g.ldw = d; g.M = R; g.N = dff; g.K = d; g.bias = L.b1; g.act = act; g.out_lo = ffn; g.ld_out_lo = dff;
+      gemm(g);
+      GemmArgs g2;
+      g2.A = ffn; g2.lda = dff; g2.W = L.w2; g2.ldw = dff; g2.M = R; g2.N = d; g2.K = dff; g2.bias = L.b2; g2.add = xc; g2.ld_add = d;
+      g2.out_f32 = xa; g2.ld_out_f32 = d;
+      gemm(g2);
+    }
+  }
+  // final LayerNorm of the LAST position of every sequence, tied proj_out, -128 suppress penalty (:663-666)
+  { ProfScope ps(prof, "dec_layernorm", stream); launch_layernorm<T>(xa + (size_t)(n - 1) * d, n * d, B, d, dec_ln_g, dec_ln_b, 1e-5f, hl, d, d, stream); }
+  {
+    ProfScope ps(prof, "dec_logits", stream);
+    GemmArgs g;
+    g.A = hl; g.lda = d; g.W = embed; g.ldw = d; g.M = B; g.N = vpad; g.K = d; g.bias = suppress; g.out_f32 = d_logits.as<float>(); g.ld_out_f32 = vpad;
+    gemm(g);
+    // BEGIN_SUPPRESS (-inf on begin_suppress_tokens) applies to the head after a prefill only (:228-240)
+    launch_argmax_rows(d_logits.as<float>(), vpad, B, c.vocab, is_prefill ? begin : nullptr, d_next.as<int32_t>(), stream);
+  }
+  hist += n;
+  if (taps_enabled) save_tap("logits", d_logits.ptr, B, c.vocab, vpad, 4);
+  if (next_out || logits_out) {
+    unsigned char* st = (unsigned char*)pinned((size_t)B * 4 + (logits_out ? (size_t)B * c.vocab * 4 : 0));
+    if (next_out) HIP_CHECK(hipMemcpyAsync(st, d_next.ptr, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+    if (logits_out)
+      HIP_CHECK(hipMemcpy2DAsync(st + (size_t)B * 4, (size_t)c.vocab * 4, d_logits.ptr, (size_t)vpad * 4, (size_t)c.vocab * 4, B,
+                                 hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (next_out) memcpy(next_out, st, (size_t)B * 4);
+    if (logits_out) memcpy(logits_out, st + (size_t)B * 4, (size_t)B * c.vocab * 4);
+    if (prof.enabled) prof.collect();
+  }
+}
+
+}  // namespace
+
+extern "C" int asr_whisper_create(const asr_whisper_config* cfg, const void* arena, size_t arena_bytes, int arena_mem,
+                                  int device_id, int precision, asr_session** out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(cfg && arena && out, "whisper_create: null argument");
+    ASR_REQUIRE(precision == ASR_PRECISION_BF16 || precision == ASR_PRECISION_F32, "whisper_create: bad precision %d", precision);
+    asr_require_device(device_id);
+    WhSession* s = new WhSession();
+    try {
+      s->kind = 2;
+      s->device = device_id;
+      s->precision = precision;
+      s->cfg = *cfg;
+      HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+      s->own_stream = true;
+      s->arena.load(arena, arena_bytes, arena_mem, s->stream);
+      s->init();
+    } catch (...) {
+      delete s;
+      throw;
+    }
+    *out = s;
+  });
+}
+
+extern "C" int asr_whisper_encode(asr_session* s, const float* audio, int audio_mem, const int64_t* audio_offsets, int batch,
+                                  int32_t* n_positions_out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 2, "whisper_encode: not a Whisper session");
+    WhSession* w = static_cast<WhSession*>(s);
+    if (w->precision == ASR_PRECISION_BF16) w->encode<bf16_t>(audio, audio_mem, audio_offsets, batch, n_positions_out);
+    else w->encode<float>(audio, audio_mem, audio_offsets, batch, n_positions_out);
+  });
+}
+
+extern "C" int asr_whisper_prefill(asr_session* s, const int32_t* ids, int n, int32_t* next_ids_out, float* logits_out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 2 && ids, "whisper_prefill: bad argument");
+    WhSession* w = static_cast<WhSession*>(s);
+    if (w->precision == ASR_PRECISION_BF16) w->step<bf16_t>(ids, n, true, next_ids_out, logits_out);
+    else w->step<float>(ids, n, true, next_ids_out, logits_out);
+  });
+}
+
+extern "C" int asr_whisper_decode(asr_session* s, const int32_t* ids, int32_t* next_ids_out, float* logits_out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 2, "whisper_decode: not a Whisper session");
+    WhSession* w = static_cast<WhSession*>(s);
+    if (w->precision == ASR_PRECISION_BF16) w->step<bf16_t>(ids, 1, false, next_ids_out, logits_out);
+    else w->step<float>(ids, 1, false, next_ids_out, logits_out);
+  });
+}
+
+extern "C" int asr_whisper_generate(asr_session* s, int max_new, int eos_id, int32_t* tokens_out, int32_t* n_out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 2 && tokens_out && n_out && max_new >= 1, "whisper_generate: bad argument");
+    WhSession* w = static_cast<WhSession*>(s);
+    ASR_REQUIRE(w->hist > 0, "whisper_generate: prefill first");
+    const int B = w->batch;
+    std::vector<int32_t> cur(B);
+    HIP_CHECK(hipSetDevice(w->device));
+    HIP_CHECK(hipMemcpyAsync(cur.data(), w->d_next.ptr, (size_t)B * 4, hipMemcpyDeviceToHost, w->stream));
+    HIP_CHECK(hipStreamSynchronize(w->stream));
+    std::vector<char> done(B, 0);
+    for (int b = 0; b < B; ++b) n_out[b] = 0;
+    for (int t = 0; t < max_new; ++t) {
+      bool all_done = true;
+      for (int b = 0; b < B; ++b) {
+        if (!done[b]) {
+          if (cur[b] == eos_id) done[b] = 1;                         // the stop token itself is not emitted (:648)
+          else tokens_out[(size_t)b * max_new + n_out[b]++] = cur[b];
+        }
+        all_done = all_done && done[b];
+      }
+      if (all_done || t + 1 == max_new || w->hist + 1 > w->cfg.max_target_positions) break;
+      // token ids stay on the device between steps; one small D2H per step for the stop test
+      if (w->precision == ASR_PRECISION_BF16) w->step<bf16_t>(nullptr, 1, false, cur.data(), nullptr);
+      else w->step<float>(nullptr, 1, false, cur.data(), nullptr);
+    }
+  });
+}

@@ -203,3 +203,95 @@ def op_gemm_bench(M, N, K, variant=-1, epilogue=0, iters=50) -> float:
     ms = C.c_float(0.0)
     _lib.check(_lib.load().asr_op_gemm_bench(variant, M, N, K, epilogue, iters, C.byref(ms)))
     return ms.value
+
+
+# =============================================================================== Whisper
+def whisper_config_c(cfg, gelu_tanh: bool = False) -> _lib.WhisperConfigC:
+    c = _lib.WhisperConfigC()
+    c.sample_rate, c.n_mels, c.nfft, c.hop_length = cfg.sample_rate, cfg.n_mels, cfg.nfft, cfg.hop_length
+    c.d_model, c.n_heads, c.d_head, c.d_ffn = cfg.d_model, cfg.n_heads, cfg.d_head, cfg.d_ffn
+    c.n_enc_layers, c.n_dec_layers, c.vocab = cfg.n_enc_layers, cfg.n_dec_layers, cfg.vocab
+    c.max_source_positions, c.max_target_positions, c.max_audio_len = cfg.max_source_positions, cfg.max_target_positions, cfg.max_audio_len
+    c.gelu_tanh = int(gelu_tanh)
+    return c
+
+
+class WhisperSession(_Session):
+    """HIP replacement of the merged Whisper graphs (encoder + KV-cache decoder + greedy heads)."""
+
+    def __init__(self, cfg, arena, precision: int = PRECISION_BF16, device_id: int = 0, gelu_tanh: bool = False,
+                 arena_device_ptr: int | None = None, arena_bytes: int | None = None):
+        super().__init__()
+        self.cfg, self.precision, self.device_id = cfg, precision, device_id
+        self._cfg_c = whisper_config_c(cfg, gelu_tanh)
+        lib = _lib.load()
+        if arena_device_ptr is not None:
+            self._keep = arena
+            _lib.check(lib.asr_whisper_create(C.byref(self._cfg_c), C.c_void_p(arena_device_ptr), arena_bytes, MEM_DEVICE,
+                                              device_id, precision, C.byref(self._h)))
+        else:
+            blob = np.ascontiguousarray(arena, dtype=np.uint8)
+            _lib.check(lib.asr_whisper_create(C.byref(self._cfg_c), blob.ctypes.data_as(C.c_void_p), blob.nbytes, MEM_HOST,
+                                              device_id, precision, C.byref(self._h)))
+        self.batch = 0
+
+    @classmethod
+    def from_checkpoint(cls, cfg, ck, precision=PRECISION_BF16, device_id=0, suppress_tokens=None, begin_suppress_tokens=(),
+                        gelu_tanh=False):
+        from .arena import build_whisper_arena
+        return cls(cfg, build_whisper_arena(cfg, ck, precision, suppress_tokens, begin_suppress_tokens), precision, device_id, gelu_tanh)
+
+    def encode_packed(self, audio, offsets, audio_device_ptr: int | None = None) -> np.ndarray:
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        B = offsets.size - 1
+        npos = np.zeros(B, dtype=np.int32)
+        if audio_device_ptr is not None:
+            ap, mem = C.c_void_p(audio_device_ptr), MEM_DEVICE
+        else:
+            audio = _f32(audio).reshape(-1)
+            ap, mem = audio.ctypes.data_as(C.c_void_p), MEM_HOST
+        _lib.check(_lib.load().asr_whisper_encode(self._h, ap, mem, offsets.ctypes.data_as(C.POINTER(C.c_int64)), B, _ip(npos)))
+        self.batch = B
+        return npos
+
+    def encode(self, audios: Sequence[np.ndarray]) -> np.ndarray:
+        flat = [_f32(a).reshape(-1) for a in audios]
+        offs = np.zeros(len(flat) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([a.size for a in flat])
+        return self.encode_packed(np.concatenate(flat), offs)
+
+    def prefill(self, ids, want_logits: bool = True):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        assert ids.ndim == 2
+        if self.batch and ids.shape[0] != self.batch:
+            raise ValueError(f"prompt batch {ids.shape[0]} != encoded batch {self.batch}")
+        nxt = np.zeros(ids.shape[0], dtype=np.int32)
+        logits = np.empty((ids.shape[0], self.cfg.vocab), dtype=np.float32) if want_logits else None
+        _lib.check(_lib.load().asr_whisper_prefill(self._h, _ip(ids), ids.shape[1], _ip(nxt), _fp(logits)))
+        return nxt, logits
+
+    def decode(self, ids=None, want_logits: bool = False, sync: bool = True):
+        nxt = np.zeros(self.batch, dtype=np.int32) if sync else None
+        logits = np.empty((self.batch, self.cfg.vocab), dtype=np.float32) if want_logits else None
+        idp = _ip(np.ascontiguousarray(ids, dtype=np.int32)) if ids is not None else None
+        _lib.check(_lib.load().asr_whisper_decode(self._h, idp, _ip(nxt) if nxt is not None else None, _fp(logits)))
+        return nxt, logits
+
+    def generate(self, max_new: int, eos_id: int):
+        tok = np.zeros((self.batch, max_new), dtype=np.int32)
+        n = np.zeros(self.batch, dtype=np.int32)
+        _lib.check(_lib.load().asr_whisper_generate(self._h, max_new, eos_id, _ip(tok), _ip(n)))
+        return [tok[b, :n[b]].copy() for b in range(self.batch)]
+
+    def cross_kv(self, lengths_pos: Sequence[int]):
+        """Debug: (K, V) per utterance as (L, H, T, 64) arrays from the 'cross' tap (f32 mode)."""
+        cfg = self.cfg
+        raw = self.tap("cross", dtype=np.float32 if self.precision == PRECISION_F32 else np.uint16)
+        G = 2 * cfg.n_dec_layers * cfg.n_heads
+        mpad = raw.shape[0] // G
+        slabs = raw.reshape(2, cfg.n_dec_layers, cfg.n_heads, mpad, 64)
+        out, r = [], 0
+        for t in lengths_pos:
+            out.append((slabs[0, :, :, r:r + t], slabs[1, :, :, r:r + t]))
+            r += (t + 1 + 15) // 16 * 16
+        return out

@@ -91,6 +91,40 @@ int asr_sensevoice_run(asr_session* s, const float* audio, int audio_mem, const 
 /* sequence length (prompt + LFR rows) the graph produces for an utterance of n_samples */
 int asr_sensevoice_seq_len(const asr_sensevoice_config* cfg, int n_samples, int* seq_len);
 
+/* ------------------------------------------------------------------ Whisper (encoder + KV-cache decoder)
+ * Replaces the merged graphs Whisper_ProbePrefillGreedy / Whisper_PrefillGreedy / Whisper_DecodeGreedy
+ * (Whisper/Shared_Merged.py:864-888; I/O planner Whisper/Inference_Whisper_ONNX.py:323-392), i.e.
+ * STFT_Process + WHISPER_ENCODER.forward (Export_Whisper.py:422-447), WHISPER_DECODER_EMBED / _PREFILL / _DECODE /
+ * WHISPER_DECODER.forward (:450-497,614-667) and the BEGIN_SUPPRESS / ARGMAX heads (:228-260).
+ * The reference passes 2 x n_layers self-KV and 2 x n_layers cross-KV tensors through Python on every call; here
+ * they are session state: `encode` fills the cross-KV slabs, `prefill` resets and fills the self-KV cache, `decode`
+ * appends one position in place. Batch B = independent utterances (the reference is batch 1). */
+typedef struct asr_whisper_config {
+  int32_t sample_rate, n_mels, nfft, hop_length;
+  int32_t d_model, n_heads, d_head, d_ffn, n_enc_layers, n_dec_layers;
+  int32_t vocab, max_source_positions, max_target_positions, max_audio_len;
+  int32_t gelu_tanh;      /* 0 = erf GELU as exported (:428); 1 = tanh GELU, what ORT runs with
+                             optimization.enable_gelu_approximation=1 (Inference_Whisper_ONNX.py:166) */
+  int32_t reserved[9];
+} asr_whisper_config;
+
+int asr_whisper_create(const asr_whisper_config* cfg, const void* arena, size_t arena_bytes, int arena_mem, int device_id,
+                       int precision, asr_session** out);
+/* audio: packed f32 samples in [-1, 1] (audio_pcm_scale 32768, Export_Whisper.py:1068); n_positions_out (host, B,
+ * nullable) receives the encoder length (n_samples / 160 + 1) / 2 of each utterance. */
+int asr_whisper_encode(asr_session* s, const float* audio, int audio_mem, const int64_t* audio_offsets, int batch,
+                       int32_t* n_positions_out);
+/* ids: host [B][n] prompt tokens (n <= 8), history is reset to 0 like the reference's prefill. next_ids_out (host B,
+ * nullable): arg-max(logits + begin_suppress); logits_out (host [B][vocab], nullable): raw logits incl. the -128
+ * suppress penalty -- what language detection and NO_SPEECH_DETECTION read (Inference_Whisper_ONNX.py:780-805). */
+int asr_whisper_prefill(asr_session* s, const int32_t* ids, int n, int32_t* next_ids_out, float* logits_out);
+/* one position per sequence. ids: host [B], or NULL to feed the device-resident arg-max of the previous step (no
+ * host round trip); next_ids_out / logits_out nullable (NULL, NULL => fully asynchronous step). */
+int asr_whisper_decode(asr_session* s, const int32_t* ids, int32_t* next_ids_out, float* logits_out);
+/* greedy continuation after a prefill: tokens_out host [B][max_new], n_out host [B]; stops per sequence at eos_id
+ * (not emitted) -- the loop of _decode_tokens (Inference_Whisper_ONNX.py:584-663) with REPEAT_PENALTY = 1.0. */
+int asr_whisper_generate(asr_session* s, int max_new, int eos_id, int32_t* tokens_out, int32_t* n_out);
+
 /* ------------------------------------------------------------------ device buffers
  * Backing store of the shim's OrtValue (OrtValue.ortvalue_from_numpy / update_inplace / numpy,
  * SenseVoice/Inference_SenseVoice_ONNX.py:280-299): update_inplace is an H2D copy into the same

@@ -1,0 +1,108 @@
+"""GPU parity: the HIP Whisper path (encoder, cross-KV, KV-cache decoder, greedy heads) through the C ABI vs goldens
+minted from the reference's WHISPER_ENCODER / WHISPER_DECODER and vs the oracle."""
+import numpy as np
+import pytest
+
+from conftest import sub
+from helpers import golden_cases, load_golden
+from oracle.whisper_oracle import WhisperOracle
+from test_oracle_whisper import unit_audio, whisper_setup
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = 0, 1
+LOGIT_TOL_F32 = 1e-3
+
+
+def _session(cfg_name, prec):
+    cfg, ck, sup, beg = whisper_setup(cfg_name)
+    sess = sub("engine").WhisperSession.from_checkpoint(cfg, ck, precision=prec, suppress_tokens=sup, begin_suppress_tokens=beg)
+    return cfg, ck, sup, beg, sess
+
+
+@pytest.mark.parametrize("fixture", ["whisper_tiny", "whisper_mid"])
+def test_f32_mode_matches_reference_goldens(fixture):
+    """One ragged batch: encoder cross-KV, prefill logits, per-step decode logits and greedy ids."""
+    g = load_golden(fixture)
+    cfg, ck, sup, beg, sess = _session(str(g["cfg_name"]), F32)
+    cases = [c for _, c in golden_cases(g)]
+    n_new = int(g["n_new"])
+    audios = [unit_audio(c["audio_seed"], c["n_samples"]) for c in cases]
+    sess.taps(True)
+    npos = sess.encode(audios)
+    assert [int(t) for t in npos] == [cfg.n_enc_pos(int(c["n_samples"])) for c in cases]
+    sub_sampled = "top1" in cases[0]
+    for (k, v), c in zip(sess.cross_kv(npos), cases):
+        if sub_sampled:
+            k, v = k[:, ::5, ::16], v[:, ::5, ::16]
+        assert np.abs(k - c["cross_k"]).max() < LOGIT_TOL_F32 and np.abs(v - c["cross_v"]).max() < LOGIT_TOL_F32
+    prompts = np.stack([c["prompt"] for c in cases])
+    nxt, logits = sess.prefill(prompts)
+    steps_logits, steps_ids = [logits], [nxt]
+    for _ in range(n_new - 1):
+        nxt, logits = sess.decode(None, want_logits=True)          # ids fed back on the device
+        steps_logits.append(logits)
+        steps_ids.append(nxt)
+    got_logits = np.stack(steps_logits, 1)                         # (B, n_new, V)
+    got_ids = np.stack(steps_ids, 1)
+    for b, c in enumerate(cases):
+        lg = got_logits[b][:, ::53] if sub_sampled else got_logits[b]
+        assert np.abs(lg - c["logits"]).max() < LOGIT_TOL_F32, b
+        if sub_sampled:
+            assert np.abs(np.sort(got_logits[b], axis=1)[:, -1] - c["top1"]).max() < LOGIT_TOL_F32
+        if (c["margin"] > 2 * LOGIT_TOL_F32).all():
+            assert np.array_equal(got_ids[b], c["token_ids"]), b
+
+
+def test_generate_equals_stepwise_and_oracle_bf16():
+    """bf16 mode: generate() == explicit prefill/decode; logits stay within the bf16 budget of the oracle."""
+    cfg, ck, sup, beg, sess = _session("whisper_mid_test", BF16)
+    orc = WhisperOracle(cfg, ck, sup, beg)
+    audios = [unit_audio(31, 64000), unit_audio(32, 25600)]
+    prompt = [cfg.sot_id, cfg.first_language_id, cfg.transcribe_id, cfg.no_timestamps_id]
+    ref = orc.greedy(audios, [prompt, prompt], 6)
+    sess.encode(audios)
+    nxt, logits = sess.prefill(np.array([prompt, prompt], np.int32))
+    for b in range(2):
+        err = np.abs(logits[b] - ref["logits"][b][0]).max()
+        assert err < 0.15, err
+    ids = [nxt.copy()]
+    for _ in range(5):
+        nxt, _ = sess.decode(None)
+        ids.append(nxt.copy())
+    stepwise = np.stack(ids, 1)
+    sess.encode(audios)
+    sess.prefill(np.array([prompt, prompt], np.int32), want_logits=False)
+    gen = sess.generate(6, eos_id=-1)
+    for b in range(2):
+        assert np.array_equal(gen[b], stepwise[b])
+    # stop token: generation halts per sequence and the stop token is not emitted
+    sess.encode(audios)
+    sess.prefill(np.array([prompt, prompt], np.int32), want_logits=False)
+    stop = int(stepwise[0][2])
+    gen2 = sess.generate(6, eos_id=stop)
+    assert stop not in gen2[0].tolist() and len(gen2[0]) <= 2
+
+
+def test_erf_vs_tanh_gelu_and_errors():
+    cfg, ck, sup, beg = whisper_setup("whisper_tiny_test")
+    eng, _lib = sub("engine"), sub("_lib")
+    a = [unit_audio(40, 16000)]
+    prompt = np.array([[cfg.sot_id, cfg.first_language_id, cfg.transcribe_id, cfg.no_timestamps_id]], np.int32)
+    outs = {}
+    for kind in (False, True):
+        s = eng.WhisperSession.from_checkpoint(cfg, ck, precision=F32, suppress_tokens=sup, begin_suppress_tokens=beg, gelu_tanh=kind)
+        s.encode(a)
+        outs[kind] = s.prefill(prompt)[1]
+        orc = WhisperOracle(cfg, ck, sup, beg, gelu="tanh" if kind else "erf")
+        ref = orc.greedy(a, [prompt[0].tolist()], 1)["logits"][0][0]
+        assert np.abs(outs[kind][0] - ref).max() < LOGIT_TOL_F32
+    assert np.abs(outs[False] - outs[True]).max() > 1e-5          # the two GELUs are distinguishable (max gap 4.7e-4 per activation)
+    s = eng.WhisperSession.from_checkpoint(cfg, ck, precision=BF16, suppress_tokens=sup, begin_suppress_tokens=beg)
+    with pytest.raises(_lib.AsrError):
+        s.prefill(prompt)                                         # no encoded batch yet
+    with pytest.raises(_lib.AsrError):
+        s.encode([unit_audio(1, 399)])                            # shorter than n_fft
+    s.encode(a)
+    with pytest.raises(_lib.AsrError):
+        s.prefill(np.array([[cfg.vocab + 5]], np.int32))          # token id out of range

@@ -181,14 +181,14 @@ struct PackedPlan {
   std::vector<UttPlan> plan;
   std::vector<int32_t> qb_utt, qb_q0, row_utt;
   int rows = 0, Mpad = 0;
-  PackedPlan(const int32_t* seq_lens, int batch) {
+  PackedPlan(const int32_t* seq_lens, int batch, int q_rows = 64) {
     plan.resize(batch);
     for (int b = 0; b < batch; ++b) {
       ASR_REQUIRE(seq_lens[b] > 0, "op: empty sequence %d", b);
       memset(&plan[b], 0, sizeof(UttPlan));
       plan[b].T = seq_lens[b];
       plan[b].row_off = rows;
-      for (int q0 = 0; q0 < seq_lens[b]; q0 += 64) { qb_utt.push_back(b); qb_q0.push_back(q0); }
+      for (int q0 = 0; q0 < seq_lens[b]; q0 += q_rows) { qb_utt.push_back(b); qb_q0.push_back(q0); }
       rows += round_up(seq_lens[b], 16);
     }
     Mpad = round_up(rows, 128);
@@ -278,7 +278,10 @@ extern "C" int asr_op_attention(int precision, const float* q, const float* k, c
     ASR_REQUIRE(precision == ASR_PRECISION_F32 || d_head == 128 || d_head == 64, "op_attention: bf16 kernel is built for head_dim 64/128");
     asr_require_device(0);
     Tmp t;
-    PackedPlan pp(seq_lens, batch);
+    int max_T = 0, att_qt = 0, att_nw = 4, q_rows = 64;
+    for (int b = 0; b < batch; ++b) max_T = std::max(max_T, seq_lens[b]);
+    if (precision == ASR_PRECISION_BF16) { attention_geometry(max_T, d_head, &att_qt, &att_nw); q_rows = 16 * att_qt * att_nw; }
+    PackedPlan pp(seq_lens, batch, q_rows);
     const int d = n_heads * d_head;
     std::vector<float> qa, ka, va;
     to_aligned(pp, seq_lens, batch, d, q, qa);
@@ -301,6 +304,7 @@ extern "C" int asr_op_attention(int precision, const float* q, const float* k, c
     AttnArgs aa;
     aa.q = dq; aa.k = dk; aa.ld_qk = d; aa.vt = dvt; aa.ld_vt = pp.Mpad; aa.ctx = dctx; aa.ld_ctx = d;
     aa.plan = dplan; aa.qb_utt = dqu; aa.qb_q0 = dq0; aa.n_qblocks = (int)pp.qb_utt.size(); aa.n_heads = n_heads;
+    aa.qt = att_qt; aa.n_waves = att_nw; aa.max_T = max_T;
     if (precision == ASR_PRECISION_F32) launch_attention_f32(aa, d_head, nullptr);
     else if (d_head == 128) launch_attention_bf16_hd128(aa, nullptr);
     else launch_attention_bf16_hd64(aa, nullptr);

@@ -52,6 +52,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+// Column owned by fragment j, fragment-row index fr (0..15) inside a wave's column block. Fragments are paired
+// (2p, 2p+1) and the W rows they load are permuted so that the C fragment of the pair gives every lane EIGHT
+// consecutive output columns (8 * (fr / 4) + 4 * (j & 1) + fr % 4 inside the 32-column pair): one 16-byte bf16
+// store / two adjacent 16-byte f32 stores per lane, and the four lanes of a row cover 64 / 128 contiguous bytes.
+__device__ __forceinline__ int frag_col(int j, int fr) { return (j >> 1) * 32 + ((fr >> 2) << 3) + ((j & 1) << 2) + (fr & 3); }
+// LDS slot-swizzle key of a W-tile row. A fragment's 16 permuted rows are {8a + b (+4)}: within one row parity (the two
+// 128-byte halves of the 256-byte bank row) the 8 rows must get 8 different keys => key = 2 * ((r >> 3) & 3) + ((r >> 1) & 1).
+__device__ __forceinline__ int w_swz(int r) { return (((r >> 3) & 3) << 1) | ((r >> 1) & 1); }
+
 template <int EPI, int F> __device__ __forceinline__ bool epi_has(const void* p) {
   if constexpr (EPI < 0) return p != nullptr; else return (EPI & F) != 0;
 }
@@ -67,9 +76,21 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, f
   *reinterpret_cast<uint2*>(p) = w;
 }
 
-// ---- swapped orientation: acc[i][j][r] = C[m_wave + 16 i + (lane & 15)][n_wave + 16 j + 4 (lane >> 4) + r]
+// ---- swapped orientation: acc[i][j][r] = C[m_wave + 16 i + (lane & 15)][n_wave + frag_col(j, 4 (lane >> 4) + r)]
+template <typename OutT> __device__ __forceinline__ void store8(OutT* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+  uint4 w;
+  w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]); w.z = pack_bf16x2(v[4], v[5]); w.w = pack_bf16x2(v[6], v[7]);
+  *reinterpret_cast<uint4*>(p) = w;
+}
+
 template <typename OutT, int ACT, int EPI, int NJ>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[4][NJ], int m_wave, int n_wave, int lane) {
+  static_assert(NJ % 2 == 0, "fragments are paired");
   const int frow = lane & 15, fgrp = lane >> 4;
   const bool has_bias = epi_has<EPI, E_BIAS>(g.bias), has_add = epi_has<EPI, E_ADD>(g.add), has_add2 = epi_has<EPI, E_ADD2>(g.add2);
   const bool want_f32 = epi_has<EPI, E_F32>(g.out_f32), want_lo = epi_has<EPI, E_LO>(g.out_lo);
@@ -80,13 +101,13 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[
       float best = -INFINITY;
       int bidx = 0x7fffffff;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int n0 = n_wave + j * 16 + fgrp * 4;
+      for (int j = 0; j < NJ; ++j) {            // (pair, half, r) ascending == ascending column inside the lane
+        const int n0 = n_wave + frag_col(j, fgrp * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[i][j][r] + (has_bias ? g.bias[n0 + r] : 0.0f);
           if (n0 + r >= g.n_valid) v = -INFINITY;
-          if (v > best) { best = v; bidx = n0 + r; }          // ascending n inside the lane: first max wins
+          if (v > best) { best = v; bidx = n0 + r; }          // first max wins
         }
       }
 #pragma unroll
@@ -104,55 +125,69 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[
   }
   if (!(want_f32 || want_lo)) return;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int n = n_wave + j * 16 + fgrp * 4;
-    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (has_bias) b4 = *reinterpret_cast<const float4*>(g.bias + n);
-    float4 t1[4], t2[4];
+  for (int p = 0; p < NJ / 2; ++p) {
+    const int n = n_wave + p * 32 + fgrp * 8;              // this lane's 8 consecutive columns
+    float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (has_bias) {
+      const float4 lo = *reinterpret_cast<const float4*>(g.bias + n), hi = *reinterpret_cast<const float4*>(g.bias + n + 4);
+      b8[0] = lo.x; b8[1] = lo.y; b8[2] = lo.z; b8[3] = lo.w; b8[4] = hi.x; b8[5] = hi.y; b8[6] = hi.z; b8[7] = hi.w;
+    }
+    float4 t1[4][2], t2[4][2];
     if (has_add) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)      // rows up to the 128-row tile edge are readable (padded buffers)
-        t1[i] = *reinterpret_cast<const float4*>(g.add + (size_t)(m_wave + i * 16 + frow) * g.ld_add + n);
+      for (int i = 0; i < 4; ++i) {      // rows up to the 128-row tile edge are readable (padded buffers)
+        const float* q = g.add + (size_t)(m_wave + i * 16 + frow) * g.ld_add + n;
+        t1[i][0] = *reinterpret_cast<const float4*>(q);
+        t1[i][1] = *reinterpret_cast<const float4*>(q + 4);
+      }
     }
     if (has_add2) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = m_wave + i * 16 + frow;
-        const int row = g.add2_rows ? g.add2_rows[m] : m;
-        t2[i] = *reinterpret_cast<const float4*>(g.add2 + (size_t)row * g.ld_add2 + n);
+        const float* q = g.add2 + (size_t)(g.add2_rows ? g.add2_rows[m] : m) * g.ld_add2 + n;
+        t2[i][0] = *reinterpret_cast<const float4*>(q);
+        t2[i][1] = *reinterpret_cast<const float4*>(q + 4);
       }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m_wave + i * 16 + frow;
-      float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
-      if (has_add) { v0 += t1[i].x; v1 += t1[i].y; v2 += t1[i].z; v3 += t1[i].w; }
-      if constexpr (ACT >= 0) {
-        v0 = apply_act_ct<ACT>(v0); v1 = apply_act_ct<ACT>(v1); v2 = apply_act_ct<ACT>(v2); v3 = apply_act_ct<ACT>(v3);
-      } else {
-        v0 = apply_act_rt(v0, g.act); v1 = apply_act_rt(v1, g.act); v2 = apply_act_rt(v2, g.act); v3 = apply_act_rt(v3, g.act);
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * p][r] + b8[r]; v[4 + r] = acc[i][2 * p + 1][r] + b8[4 + r]; }
+      if (has_add) {
+        v[0] += t1[i][0].x; v[1] += t1[i][0].y; v[2] += t1[i][0].z; v[3] += t1[i][0].w;
+        v[4] += t1[i][1].x; v[5] += t1[i][1].y; v[6] += t1[i][1].z; v[7] += t1[i][1].w;
       }
-      if (has_add2) { v0 += t2[i].x; v1 += t2[i].y; v2 += t2[i].z; v3 += t2[i].w; }     // post-activation term
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if constexpr (ACT >= 0) v[e] = apply_act_ct<ACT>(v[e]); else v[e] = apply_act_rt(v[e], g.act);
+      }
+      if (has_add2) {                                         // post-activation term
+        v[0] += t2[i][0].x; v[1] += t2[i][0].y; v[2] += t2[i][0].z; v[3] += t2[i][0].w;
+        v[4] += t2[i][1].x; v[5] += t2[i][1].y; v[6] += t2[i][1].z; v[7] += t2[i][1].w;
+      }
       if (m < g.M) {
-        if (want_f32) store4<float>(g.out_f32 + (size_t)m * g.ld_out_f32 + n, v0, v1, v2, v3);
+        if (want_f32) store8<float>(g.out_f32 + (size_t)m * g.ld_out_f32 + n, v);
         if (want_lo) {
           OutT* o = reinterpret_cast<OutT*>(g.out_lo);
           if (g.lo_group > 0) o += (size_t)(n / g.lo_group) * g.ld_out_lo + (size_t)m * g.lo_group + (n % g.lo_group);
           else o += (size_t)m * g.ld_out_lo + n;
-          store4<OutT>(o, v0, v1, v2, v3);
+          store8<OutT>(o, v);
         }
       }
     }
   }
 }
 
-// ---- un-swapped orientation: acc[i][j][r] = C[m_wave + 16 i + 4 (lane >> 4) + r][n_wave + 16 j + (lane & 15)]
+// ---- un-swapped orientation: acc[i][j][r] = C[m_wave + 16 i + 4 (lane >> 4) + r][n_wave + frag_col(j, lane & 15)]
 template <typename OutT, int NJ>
 __device__ __forceinline__ void epilogue_transposed(const GemmArgs& g, f32x4_t (&acc)[4][NJ], int m_wave, int n_wave, int lane) {
   const int frow = lane & 15, fgrp = lane >> 4;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int n = n_wave + j * 16 + frow;
+    const int n = n_wave + frag_col(j, frow);
     const float b = g.bias ? g.bias[n] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -191,7 +226,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_pipe(const GemmArgs g) {
   const int srow = lane >> 3;
   const int sslot = (lane & 7) ^ srow;            // un-swizzle on the global side
   const bf16_t* a_src = reinterpret_cast<const bf16_t*>(g.A) + (size_t)(tile_m * BM + wave * 8 + srow) * g.lda + sslot * 8;
-  const bf16_t* w_src = reinterpret_cast<const bf16_t*>(g.W) + (size_t)(tile_n * BN_ + wave * 8 + srow) * g.ldw + sslot * 8;
+  const int wslot = (lane & 7) ^ w_swz(wave * 8 + srow);      // rows p*32 + wave*8 + srow: p*32 leaves the key bits alone
+  const bf16_t* w_src = reinterpret_cast<const bf16_t*>(g.W) + (size_t)(tile_n * BN_ + wave * 8 + srow) * g.ldw + wslot * 8;
   const size_t a_pass = (size_t)32 * g.lda, w_pass = (size_t)32 * g.ldw;
 
   auto stage = [&](int slot, int k0) {
@@ -226,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_pipe(const GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int r = wm * 64 + i * 16 + frow; a_off[kk][i] = r * 128 + ((c ^ (r & 7)) << 4); }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) { const int r = wn * WN + j * 16 + frow; w_off[kk][j] = BM * 128 + r * 128 + ((c ^ (r & 7)) << 4); }
+    for (int j = 0; j < NJ; ++j) { const int r = wn * WN + frag_col(j, frow); w_off[kk][j] = BM * 128 + r * 128 + ((c ^ w_swz(r)) << 4); }
   }
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -309,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_128x128x16(const GemmArgs g) 
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = As[(wm * 64 + i * 16 + frow) * LDF + kk * 4 + fgrp];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wf[j] = Ws[(wn * 64 + j * 16 + frow) * LDF + kk * 4 + fgrp];
+      for (int j = 0; j < 4; ++j) wf[j] = Ws[(wn * 64 + frag_col(j, frow)) * LDF + kk * 4 + fgrp];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -352,9 +388,10 @@ void check_args(const GemmArgs& g, int kstep, int elt) {
   ASR_REQUIRE(g.K % kstep == 0, "gemm: K=%d must be a multiple of %d", g.K, kstep);
   ASR_REQUIRE((g.lda * elt) % 16 == 0 && (g.ldw * elt) % 16 == 0, "gemm: leading dims must be 16-byte multiples");
   if (g.add) ASR_REQUIRE(g.ld_add % 4 == 0, "gemm: ld_add must be a multiple of 4");
+  ASR_REQUIRE(g.N % 32 == 0, "gemm: N must be a multiple of 32");
   if (g.add2) ASR_REQUIRE(g.ld_add2 % 4 == 0, "gemm: ld_add2 must be a multiple of 4");
   if (g.out_f32) ASR_REQUIRE(g.ld_out_f32 % 4 == 0, "gemm: ld_out_f32 must be a multiple of 4");
-  if (g.out_lo) ASR_REQUIRE(g.ld_out_lo % 4 == 0 && g.lo_group % 4 == 0, "gemm: ld_out_lo / lo_group must be multiples of 4");
+  if (g.out_lo) ASR_REQUIRE(g.ld_out_lo % 8 == 0 && g.lo_group % 8 == 0, "gemm: ld_out_lo / lo_group must be multiples of 8");
   if (g.out_t) {
     ASR_REQUIRE(!(g.add || g.add2 || g.out_f32 || g.out_lo || g.amax_val || g.act != ACT_NONE),
                 "gemm: the transposed store excludes row-major epilogue terms");

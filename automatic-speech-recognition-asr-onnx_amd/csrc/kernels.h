@@ -103,10 +103,15 @@ struct AttnArgs {
   const void* vt; int ld_vt;
   void* ctx; int ld_ctx;
   const UttPlan* plan;
-  const int32_t* qb_utt;       // per 64-row query block: utterance
+  const int32_t* qb_utt;       // per query block: utterance
   const int32_t* qb_q0;        // per query block: first query row inside the utterance
   int n_qblocks, n_heads;
+  // bf16 kernel geometry (attention_geometry): a query block = n_waves * qt tiles of 16 rows; max_T picks the chunk size.
+  // The f32 kernel uses fixed 64-row blocks (qt = 0).
+  int qt = 0, n_waves = 4, max_T = 0;
 };
+// query-block geometry for the longest utterance of a batch: rows per block = 16 * qt * n_waves
+void attention_geometry(int max_T, int head_dim, int* qt, int* n_waves);
 void launch_attention_bf16_hd128(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16_hd64(const AttnArgs& a, hipStream_t s);
 void launch_attention_f32(const AttnArgs& a, int head_dim, hipStream_t s);

@@ -1,6 +1,9 @@
 // Non-GEMM kernels of the ASR hot path for gfx950 (wave64, MFMA, LDS-staged tiles).
 #include "kernels.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace {
 
 constexpr int HOP = 160, WIN = 400;          // 10 ms / 25 ms at 16 kHz: every in-scope front-end
@@ -202,54 +205,60 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------ attention (bf16, flash-style)
-// One workgroup = 64 query rows of one (utterance, head); wave w owns 16 of them. K and V^T chunks of
-// CHUNK keys are staged by LDS-DMA (global_load_lds_dwordx4) with the 16-byte-slot XOR swizzle on the
-// global source side. Scores are computed TRANSPOSED, S^T = K Q^T, so the C fragment puts one query per
-// lane column (lane & 15) and 4 consecutive keys per lane: the row soft-max is lane-local plus two
-// xor-shuffles across the four 16-lane groups, and the bf16-packed probabilities are directly the B
-// fragment of O^T = V^T P^T (no LDS round trip for P). O^T's C fragment again has one query per lane
-// column, so the online-softmax rescale is lane-local, and each lane ends with 4 consecutive d values
-// of its query row (one 8-byte store).
-template <int HD, int CHUNK>
-__global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a, int n_rows_alloc) {
+// One workgroup = a block of NW*QT 16-row query tiles of one (utterance, head); wave w owns tiles w, w+NW, ...
+// (QT of them, all live in registers). K and V^T chunks of CHUNK keys are staged ONCE per workgroup by LDS-DMA
+// (global_load_lds_dwordx4) with the 16-byte-slot XOR swizzle on the global source side, and every K / V^T
+// fragment read from LDS is reused by the wave's QT query tiles. Scores are computed TRANSPOSED, S^T = K Q^T,
+// so the C fragment puts one query per lane column (lane & 15) and 4 consecutive keys per lane: the row soft-max
+// is lane-local plus two xor-shuffles across the four 16-lane groups, and the bf16-packed probabilities are
+// directly the B fragment of O^T = V^T P^T (no LDS round trip for P). O^T's C fragment again has one query per
+// lane column, so the online-softmax rescale is lane-local, and each lane ends with 4 consecutive d values of
+// its query row (one 8-byte store).
+template <int HD, int CHUNK, int QT>
+__global__ __launch_bounds__(512) void attn_bf16_kernel(const AttnArgs a, int n_rows_alloc) {
   constexpr int SLOTS = HD / 8;               // 16-byte slots per K row
   constexpr int KROWB = HD * 2;               // bytes per K row
   constexpr int K_RPI = 64 / SLOTS;           // K rows per LDS-DMA wave-instruction (1 KiB)
-  constexpr int K_NI = CHUNK / K_RPI;         // instructions per chunk
   constexpr int VSLOTS = CHUNK / 8;           // 16-byte slots per V^T row
   constexpr int VROWB = CHUNK * 2;
   constexpr int V_RPI = 64 / VSLOTS;
   constexpr int V_NI = HD / V_RPI;
-  static_assert(VSLOTS == 16, "V^T swizzle assumes 16 slots per row");
+  static_assert(VSLOTS == 16 || VSLOTS == 32, "V^T swizzle assumes 16 or 32 slots per row");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ks = smem;
   unsigned char* Vs = smem + CHUNK * KROWB;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = blockDim.x >> 6;
   const int fq = lane & 15, g = lane >> 4;
-  const int u = a.qb_utt[blockIdx.x], q0 = a.qb_q0[blockIdx.x], h = blockIdx.y;
+  const int u = a.qb_utt[blockIdx.x], q_base = a.qb_q0[blockIdx.x], h = blockIdx.y;
   const UttPlan up = a.plan[u];
   const int T = up.T, row0 = up.row_off;
-  const bool active = (q0 + wave * 16) < T;   // wave-uniform
-  const int qrow = q0 + wave * 16 + fq;
 
-  bf16x8_t qf[HD / 32];
-  if (active) {
-    const bf16_t* qp = reinterpret_cast<const bf16_t*>(a.q) + (size_t)(row0 + qrow) * a.ld_qk + h * HD + g * 8;
+  bf16x8_t qf[QT][HD / 32];
+  f32x4_t ot[QT][HD / 16];
+  float m_run[QT], l_run[QT];
+  bool act[QT];
 #pragma unroll
-    for (int ks = 0; ks < HD / 32; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+  for (int t = 0; t < QT; ++t) {
+    const int q0 = q_base + (t * NW + wave) * 16;
+    act[t] = q0 < T;                          // wave-uniform
+    m_run[t] = -INFINITY;
+    l_run[t] = 0.0f;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) ot[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* qp = reinterpret_cast<const bf16_t*>(a.q) + (size_t)(row0 + (act[t] ? q0 : 0) + fq) * a.ld_qk + h * HD + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
   }
-  f32x4_t ot[HD / 16];
-#pragma unroll
-  for (int dt = 0; dt < HD / 16; ++dt) ot[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.0f;
 
   const bf16_t* kbase = reinterpret_cast<const bf16_t*>(a.k) + h * HD;
   const bf16_t* vbase = reinterpret_cast<const bf16_t*>(a.vt) + (size_t)h * HD * a.ld_vt;
 
   for (int kv0 = 0; kv0 < T; kv0 += CHUNK) {
+    const int nkeys = min(CHUNK, (T - kv0 + 31) & ~31);       // keys of this chunk that are ever read (32-key sub-tiles)
     __syncthreads();                          // all waves finished reading the previous chunk
-    for (int ii = wave; ii < K_NI; ii += 4) {
+    for (int ii = wave; ii * K_RPI < nkeys; ii += NW) {
       const int key = ii * K_RPI + lane / SLOTS;
       const int sslot = (lane % SLOTS) ^ (key & (SLOTS - 1));
       const int grow = min(row0 + kv0 + key, n_rows_alloc - 1);
@@ -257,50 +266,63 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a, int n_
           (const __attribute__((address_space(1))) void*)(kbase + (size_t)grow * a.ld_qk + sslot * 8),
           (__attribute__((address_space(3))) void*)(Ks + ii * 1024), 16, 0, 0);
     }
-    for (int ii = wave; ii < V_NI; ii += 4) {
+    for (int ii = wave; ii < V_NI; ii += NW) {
       const int d = ii * V_RPI + lane / VSLOTS;
       const int sslot = (lane % VSLOTS) ^ (d & 15);
-      const int gcol = min(row0 + kv0 + sslot * 8, a.ld_vt - 8);
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(vbase + (size_t)d * a.ld_vt + gcol),
-          (__attribute__((address_space(3))) void*)(Vs + ii * 1024), 16, 0, 0);
+      if (sslot * 8 < nkeys) {                // slots beyond the last sub-tile are never read
+        const int gcol = min(row0 + kv0 + sslot * 8, a.ld_vt - 8);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(vbase + (size_t)d * a.ld_vt + gcol),
+            (__attribute__((address_space(3))) void*)(Vs + ii * 1024), 16, 0, 0);
+      }
     }
     __syncthreads();                          // chunk landed (the barrier drains the LDS-DMA queue)
-    if (!active) continue;
-    const int nsub = min(CHUNK, T - kv0);
-    for (int s = 0; s * 32 < nsub; ++s) {
-      f32x4_t st0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, st1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s * 32 < nkeys; ++s) {
+      f32x4_t st0[QT], st1[QT];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) { st0[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; st1[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
       const int key0 = s * 32 + fq, key1 = key0 + 16;
 #pragma unroll
       for (int ks = 0; ks < HD / 32; ++ks) {
         const int c = ks * 4 + g;
         const bf16x8_t kf0 = *reinterpret_cast<const bf16x8_t*>(Ks + key0 * KROWB + ((c ^ (key0 & (SLOTS - 1))) << 4));
         const bf16x8_t kf1 = *reinterpret_cast<const bf16x8_t*>(Ks + key1 * KROWB + ((c ^ (key1 & (SLOTS - 1))) << 4));
-        st0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[ks], st0, 0, 0, 0);
-        st1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[ks], st1, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          if (act[t]) {
+            st0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[t][ks], st0[t], 0, 0, 0);
+            st1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[t][ks], st1[t], 0, 0, 0);
+          }
+        }
       }
-      float sv[8] = {st0[0], st0[1], st0[2], st0[3], st1[0], st1[1], st1[2], st1[3]};
       const int kb = kv0 + s * 32 + g * 4;
-      float mx = -INFINITY;
+      bf16x8_t pfv[QT];
+      float alpha[QT];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int key = kb + (r & 3) + ((r >> 2) << 4);
-        if (key >= T) sv[r] = -INFINITY;
-        mx = fmaxf(mx, sv[r]);
+      for (int t = 0; t < QT; ++t) {
+        float sv[8] = {st0[t][0], st0[t][1], st0[t][2], st0[t][3], st1[t][0], st1[t][1], st1[t][2], st1[t][3]};
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int key = kb + (r & 3) + ((r >> 2) << 4);
+          if (key >= T) sv[r] = -INFINITY;
+          mx = fmaxf(mx, sv[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[t], mx);
+        alpha[t] = __expf(m_run[t] - m_new);
+        float psum = 0.0f;
+        float p[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { p[r] = __expf(sv[r] - m_new); psum += p[r]; }
+        l_run[t] = l_run[t] * alpha[t] + psum;
+        m_run[t] = m_new;
+        union { bf16x8_t v; uint32_t w[4]; } pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pf.w[r] = pack_bf16x2(p[2 * r], p[2 * r + 1]);
+        pfv[t] = pf.v;
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __expf(m_run - m_new);
-      float psum = 0.0f;
-      float p[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) { p[r] = __expf(sv[r] - m_new); psum += p[r]; }
-      l_run = l_run * alpha + psum;
-      m_run = m_new;
-      union { bf16x8_t v; uint32_t w[4]; } pf;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pf.w[r] = pack_bf16x2(p[2 * r], p[2 * r + 1]);
 #pragma unroll
       for (int dt = 0; dt < HD / 16; ++dt) {
         const int d = dt * 16 + fq;
@@ -308,24 +330,33 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a, int n_
         union { bf16x8_t v; uint2 h2[2]; } vf;
         vf.h2[0] = *reinterpret_cast<const uint2*>(vr + (((s * 4 + (g >> 1)) ^ (d & 15)) << 4));
         vf.h2[1] = *reinterpret_cast<const uint2*>(vr + (((s * 4 + 2 + (g >> 1)) ^ (d & 15)) << 4));
-        f32x4_t o = ot[dt];
-        o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
-        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          if (act[t]) {
+            f32x4_t o = ot[t][dt];
+            o[0] *= alpha[t]; o[1] *= alpha[t]; o[2] *= alpha[t]; o[3] *= alpha[t];
+            ot[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pfv[t], o, 0, 0, 0);
+          }
+        }
       }
     }
   }
-  if (!active) return;
-  float l = l_run + __shfl_xor(l_run, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  const float inv = 1.0f / l;
-  if (qrow < T) {
-    bf16_t* op = reinterpret_cast<bf16_t*>(a.ctx) + (size_t)(row0 + qrow) * a.ld_ctx + h * HD + g * 4;
 #pragma unroll
-    for (int dt = 0; dt < HD / 16; ++dt) {
-      uint2 w;
-      w.x = pack_bf16x2(ot[dt][0] * inv, ot[dt][1] * inv);
-      w.y = pack_bf16x2(ot[dt][2] * inv, ot[dt][3] * inv);
-      *reinterpret_cast<uint2*>(op + dt * 16) = w;
+  for (int t = 0; t < QT; ++t) {
+    const int qrow = q_base + (t * NW + wave) * 16 + fq;
+    if (!act[t]) continue;
+    float l = l_run[t] + __shfl_xor(l_run[t], 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (qrow < T) {
+      bf16_t* op = reinterpret_cast<bf16_t*>(a.ctx) + (size_t)(row0 + qrow) * a.ld_ctx + h * HD + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        uint2 w;
+        w.x = pack_bf16x2(ot[t][dt][0] * inv, ot[t][dt][1] * inv);
+        w.y = pack_bf16x2(ot[t][dt][2] * inv, ot[t][dt][3] * inv);
+        *reinterpret_cast<uint2*>(op + dt * 16) = w;
+      }
     }
   }
 }
@@ -725,15 +756,50 @@ void launch_layernorm(const float* x, int ld_x, int rows, int D, const float* ga
 template void launch_layernorm<float>(const float*, int, int, int, const float*, const float*, float, float*, int, int, hipStream_t);
 template void launch_layernorm<bf16_t>(const float*, int, int, int, const float*, const float*, float, bf16_t*, int, int, hipStream_t);
 
-template <int HD>
-static void launch_attn_bf16(const AttnArgs& a, hipStream_t s, int n_rows_alloc) {
-  constexpr int CHUNK = 128;
-  const size_t lds = (size_t)CHUNK * HD * 2 * 2;
-  hipLaunchKernelGGL((attn_bf16_kernel<HD, CHUNK>), dim3(a.n_qblocks, a.n_heads), dim3(256), lds, s, a, n_rows_alloc);
+template <int HD, int CHUNK, int QT>
+static void launch_attn_inst(const AttnArgs& a, hipStream_t s) {
+  constexpr int lds = CHUNK * HD * 2 * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel<HD, CHUNK, QT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_bf16_kernel<HD, CHUNK, QT>), dim3(a.n_qblocks, a.n_heads), dim3(64 * a.n_waves), lds, s, a, a.ld_vt);
   HIP_CHECK(hipGetLastError());
 }
-void launch_attention_bf16_hd128(const AttnArgs& a, hipStream_t s) { launch_attn_bf16<128>(a, s, a.ld_vt); }
-void launch_attention_bf16_hd64(const AttnArgs& a, hipStream_t s) { launch_attn_bf16<64>(a, s, a.ld_vt); }
+
+void attention_geometry(int max_T, int head_dim, int* qt, int* nw) {
+  // smallest number of query tiles per wave that lets one workgroup (<= 8 waves) cover the longest utterance
+  const int qt_max = head_dim == 128 ? 3 : 4;
+  const int n_tiles = (max_T + 15) / 16;
+  int q = 1;
+  while (q < qt_max && (n_tiles + q - 1) / q > 8) ++q;
+  if (const char* e = getenv("ASR_ATTN_QT")) q = std::max(1, std::min(qt_max, atoi(e)));
+  int w = std::min(8, (n_tiles + q - 1) / q);
+  if (const char* e = getenv("ASR_ATTN_NW")) w = std::max(1, std::min(8, atoi(e)));
+  *qt = q;
+  *nw = w;
+}
+
+void launch_attention_bf16_hd128(const AttnArgs& a, hipStream_t s) {
+  ASR_REQUIRE(a.qt >= 1 && a.qt <= 3 && a.n_waves >= 1 && a.n_waves <= 8, "attention: bad geometry qt=%d nw=%d", a.qt, a.n_waves);
+  const bool big = a.max_T <= 256;             // whole utterance in one 256-key chunk (128 KiB LDS)
+  switch (a.qt) {
+    case 1: big ? launch_attn_inst<128, 256, 1>(a, s) : launch_attn_inst<128, 128, 1>(a, s); break;
+    case 2: big ? launch_attn_inst<128, 256, 2>(a, s) : launch_attn_inst<128, 128, 2>(a, s); break;
+    default: big ? launch_attn_inst<128, 256, 3>(a, s) : launch_attn_inst<128, 128, 3>(a, s); break;
+  }
+}
+void launch_attention_bf16_hd64(const AttnArgs& a, hipStream_t s) {
+  ASR_REQUIRE(a.qt >= 1 && a.qt <= 4 && a.n_waves >= 1 && a.n_waves <= 8, "attention: bad geometry qt=%d nw=%d", a.qt, a.n_waves);
+  switch (a.qt) {
+    case 1: launch_attn_inst<64, 256, 1>(a, s); break;
+    case 2: launch_attn_inst<64, 256, 2>(a, s); break;
+    case 3: launch_attn_inst<64, 256, 3>(a, s); break;
+    default: launch_attn_inst<64, 256, 4>(a, s); break;
+  }
+}
 
 void launch_attention_f32(const AttnArgs& a, int head_dim, hipStream_t s) {
   ASR_REQUIRE(head_dim <= 128 && head_dim % 4 == 0, "attention_f32: head_dim %d unsupported", head_dim);

@@ -1,5 +1,6 @@
 // SenseVoiceSmall hot path on one MI355X: packed ragged batch -> fbank -> LFR/CMVN -> SANM blocks ->
 // CTC arg-max + collapse. Follows SENSE_VOICE.forward (SenseVoice/Export_SenseVoice.py:271-296).
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/asr_mi355x.h"
@@ -16,6 +17,8 @@ struct SvBlock {
 };
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct SvRunCtx;
 
 struct SvSession : asr_session {
   asr_sensevoice_config cfg;
@@ -40,6 +43,7 @@ struct SvSession : asr_session {
                             &d_amax_v, &d_amax_i, &d_ids, &d_tok, &d_num, &d_logits})
       b->release();
     for (auto& kv : taps) kv.second.buf.release();
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (h_plan) (void)hipHostFree(h_plan);
     if (h_out) (void)hipHostFree(h_out);
     prof.release();
@@ -47,7 +51,13 @@ struct SvSession : asr_session {
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
 
+  // hipGraph replay of the forward pass (one graph per batch geometry)
+  bool use_graph = true;
+  hipGraphExec_t graph_exec = nullptr;
+  uint64_t graph_key = 0, eager_key = 0, ws_epoch = 1;
+
   void init();
+  template <typename T> void enqueue(const struct SvRunCtx& r);
   template <typename T> void run(const float* audio, int audio_mem, const int64_t* offs, int batch, const int32_t* lang,
                                  int32_t* tok_out, int max_tokens, int32_t* num_out);
   void gemm(const GemmArgs& g) { precision == ASR_PRECISION_BF16 ? launch_gemm_bf16(g, stream) : launch_gemm_f32(g, stream); }
@@ -107,120 +117,35 @@ void SvSession::init() {
   }
 }
 
+// Everything a forward pass needs once the host plan is uploaded; captured into a hipGraph for replay.
+struct SvRunCtx {
+  int batch, rows, Mpad, frames, n_fb, n_qb, max_T, max_tokens, att_qt, att_nw;
+  const float* d_aud;
+  const UttPlan* dp;
+  const int32_t *d_blk_utt, *d_blk_f0, *d_qb_utt, *d_qb_q0, *d_row_utt;
+};
+
 template <typename T>
-void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int batch, const int32_t* lang, int32_t* tok_out,
-                    int max_tokens, int32_t* num_out) {
+void SvSession::enqueue(const SvRunCtx& r) {
   const auto& c = cfg;
-  ASR_REQUIRE(batch > 0, "sensevoice: empty batch");
-  ASR_REQUIRE(audio && offs && lang && tok_out && num_out, "sensevoice: null argument");
-  HIP_CHECK(hipSetDevice(device));
-  const int d = c.d_model, dff = c.d_ffn;
-
-  // ---- host plan -------------------------------------------------------------------------
-  std::vector<UttPlan> plan(batch);
-  int rows = 0, frames = 0, n_fb = 0, n_qb = 0, max_T = 0;
-  const int64_t base0 = offs[0];
-  for (int b = 0; b < batch; ++b) {
-    const int64_t n = offs[b + 1] - offs[b];
-    ASR_REQUIRE(n >= c.win_length, "sensevoice: utterance %d has %lld samples (< one %d-sample frame)", b, (long long)n, c.win_length);
-    ASR_REQUIRE(n <= c.max_audio_len, "sensevoice: utterance %d has %lld samples (> max_audio_len %d)", b, (long long)n, c.max_audio_len);
-    ASR_REQUIRE(lang[b] >= 0 && lang[b] < c.n_languages, "sensevoice: language_idx %d out of range", lang[b]);
-    UttPlan& p = plan[b];
-    p.audio_off = offs[b] - base0;
-    p.n_samples = (int)n;
-    p.n_frames = ((int)n - c.win_length) / c.hop_length + 1;
-    p.frame_off = frames;
-    p.n_lfr = (p.n_frames + c.lfr_n - 1) / c.lfr_n;
-    p.T = p.n_lfr + c.n_prompt;
-    p.row_off = rows;
-    p.lang = lang[b];
-    p.blk0 = n_fb;
-    frames += p.n_frames;
-    rows += round_up(p.T, 16);
-    n_fb += (p.n_frames + 63) / 64;
-    n_qb += (p.T + 63) / 64;
-    max_T = std::max(max_T, p.T);
-  }
-  ASR_REQUIRE(max_tokens >= 1, "sensevoice: max_tokens must be positive");
-  const int Mpad = round_up(rows, 128);
-  const int64_t total_samples = offs[batch] - base0;
-
-  // plan blob: [UttPlan x B][blk_utt n_fb][blk_f0 n_fb][qb_utt n_qb][qb_q0 n_qb][row_utt Mpad]
-  const size_t plan_bytes = sizeof(UttPlan) * batch + sizeof(int32_t) * (2 * (size_t)n_fb + 2 * (size_t)n_qb + Mpad);
-  if (plan_bytes > h_plan_cap) {
-    if (h_plan) HIP_CHECK(hipHostFree(h_plan));
-    HIP_CHECK(hipHostMalloc(&h_plan, plan_bytes * 2, hipHostMallocDefault));
-    h_plan_cap = plan_bytes * 2;
-  }
-  unsigned char* hp = (unsigned char*)h_plan;
-  memcpy(hp, plan.data(), sizeof(UttPlan) * batch);
-  int32_t* blk_utt = (int32_t*)(hp + sizeof(UttPlan) * batch);
-  int32_t* blk_f0 = blk_utt + n_fb;
-  int32_t* qb_utt = blk_f0 + n_fb;
-  int32_t* qb_q0 = qb_utt + n_qb;
-  int32_t* row_utt = qb_q0 + n_qb;
-  {
-    int fi = 0, qi = 0;
-    for (int b = 0; b < batch; ++b) {
-      for (int f0 = 0; f0 < plan[b].n_frames; f0 += 64) { blk_utt[fi] = b; blk_f0[fi++] = f0; }
-      for (int q0 = 0; q0 < plan[b].T; q0 += 64) { qb_utt[qi] = b; qb_q0[qi++] = q0; }
-      const int r16 = round_up(plan[b].T, 16);
-      for (int r = 0; r < r16; ++r) row_utt[plan[b].row_off + r] = b;
-    }
-    for (int r = rows; r < Mpad; ++r) row_utt[r] = -1;
-  }
-  d_plan.reserve(plan_bytes, stream);
-  HIP_CHECK(hipMemcpyAsync(d_plan.ptr, h_plan, plan_bytes, hipMemcpyHostToDevice, stream));
-  const UttPlan* dp = d_plan.as<UttPlan>();
-  const int32_t* d_blk_utt = (const int32_t*)((unsigned char*)d_plan.ptr + sizeof(UttPlan) * batch);
-  const int32_t* d_blk_f0 = d_blk_utt + n_fb;
-  const int32_t* d_qb_utt = d_blk_f0 + n_fb;
-  const int32_t* d_qb_q0 = d_qb_utt + n_qb;
-  const int32_t* d_row_utt = d_qb_q0 + n_qb;
-
-  // ---- workspace -------------------------------------------------------------------------
-  const size_t eT = sizeof(T);
-  const float* d_aud = nullptr;
-  if (audio_mem == ASR_MEM_HOST) {
-    d_audio.reserve((size_t)total_samples * 4, stream);
-    HIP_CHECK(hipMemcpyAsync(d_audio.ptr, audio + base0, (size_t)total_samples * 4, hipMemcpyHostToDevice, stream));
-    d_aud = d_audio.as<float>();
-  } else {
-    d_aud = audio + base0;
-  }
-  d_mel.reserve((size_t)frames * c.n_mels * 4, stream);
-  d_x0.reserve((size_t)Mpad * kpad0 * 4, stream);
-  d_xa.reserve((size_t)Mpad * d * 4, stream);
-  d_xb.reserve((size_t)Mpad * d * 4, stream);
-  d_h.reserve((size_t)Mpad * std::max(kpad0, d) * eT, stream);
-  d_qk.reserve((size_t)Mpad * 2 * d * eT, stream);
-  d_vt.reserve((size_t)Mpad * d * eT, stream);
-  d_ctx.reserve((size_t)Mpad * d * eT, stream);
-  d_mem.reserve((size_t)Mpad * d * 4, stream);
-  d_ffn.reserve((size_t)Mpad * dff * eT, stream);
+  const int d = c.d_model, dff = c.d_ffn, rows = r.rows, Mpad = r.Mpad;
   const int n_slabs = vpad / 64;
-  d_amax_v.reserve((size_t)Mpad * n_slabs * 4, stream);
-  d_amax_i.reserve((size_t)Mpad * n_slabs * 4, stream);
-  d_ids.reserve((size_t)Mpad * 4, stream);
-  d_tok.reserve((size_t)batch * max_tokens * 4, stream);
-  d_num.reserve((size_t)batch * 4, stream);
-
   // ---- 1. Kaldi fbank (Export_SenseVoice.py:275-278) ---------------------------------------
   {
     ProfScope ps(prof, "fbank", stream);
     FbankArgs fa;
-    fa.audio = d_aud; fa.plan = dp; fa.blk_utt = d_blk_utt; fa.blk_f0 = d_blk_f0;
+    fa.audio = r.d_aud; fa.plan = r.dp; fa.blk_utt = r.d_blk_utt; fa.blk_f0 = r.d_blk_f0;
     fa.dft_packed = dft; fa.mel_packed = melp; fa.mel_out = d_mel.as<float>();
     fa.n_bin_tiles = n_bin_tiles; fa.n_kchunks = n_kchunks; fa.n_mel_tiles = c.n_mels / 16; fa.n_mels = c.n_mels;
     fa.win = c.win_length; fa.hop = c.hop_length; fa.log_floor = 1.1920928955078125e-07f; fa.whisper = 0; fa.blk_max = nullptr;
-    launch_fbank(fa, n_fb, stream);
+    launch_fbank(fa, r.n_fb, stream);
   }
-  save_tap("mel", d_mel.ptr, frames, c.n_mels, c.n_mels, 4);
+  save_tap("mel", d_mel.ptr, r.frames, c.n_mels, c.n_mels, 4);
   // ---- 2./3. LFR + CMVN + positions + prompts (Export_SenseVoice.py:280-287) ---------------
   {
     ProfScope ps(prof, "lfr_cmvn", stream);
     LfrArgs la;
-    la.mel = d_mel.as<float>(); la.plan = dp; la.row_utt = d_row_utt; la.cmvn_means = cmvn_means; la.cmvn_vars = cmvn_vars;
+    la.mel = d_mel.as<float>(); la.plan = r.dp; la.row_utt = r.d_row_utt; la.cmvn_means = cmvn_means; la.cmvn_vars = cmvn_vars;
     la.speech_pos = speech_pos; la.language_embed = language_embed; la.system_embed = system_embed;
     la.out = d_x0.as<float>(); la.ld_out = kpad0; la.feat = feat; la.n_mels = c.n_mels; la.lfr_m = c.lfr_m; la.lfr_n = c.lfr_n;
     la.n_prompt = c.n_prompt; la.n_rows = Mpad;
@@ -258,13 +183,14 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
     }
     {
       ProfScope ps(prof, "fsmn", stream);
-      launch_fsmn<T>(vt, Mpad, b.wfsmn, b.bfsmn, d, c.fsmn_kernel, dp, d_row_utt, Mpad, mem, d, stream);
+      launch_fsmn<T>(vt, Mpad, b.wfsmn, b.bfsmn, d, c.fsmn_kernel, r.dp, r.d_row_utt, Mpad, mem, d, stream);
     }
     {
       ProfScope ps(prof, "attention", stream);
       AttnArgs aa;
       aa.q = qk; aa.k = qk + d; aa.ld_qk = 2 * d; aa.vt = vt; aa.ld_vt = Mpad; aa.ctx = ctx; aa.ld_ctx = d;
-      aa.plan = dp; aa.qb_utt = d_qb_utt; aa.qb_q0 = d_qb_q0; aa.n_qblocks = n_qb; aa.n_heads = c.n_heads;
+      aa.plan = r.dp; aa.qb_utt = r.d_qb_utt; aa.qb_q0 = r.d_qb_q0; aa.n_qblocks = r.n_qb; aa.n_heads = c.n_heads;
+      aa.qt = r.att_qt; aa.n_waves = r.att_nw; aa.max_T = r.max_T;
       if (precision == ASR_PRECISION_BF16) launch_attention_bf16_hd128(aa, stream);
       else launch_attention_f32(aa, c.d_head, stream);
     }
@@ -318,31 +244,165 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
     GemmArgs g;
     g.A = h; g.lda = d; g.W = ctc_w; g.ldw = d; g.M = rows; g.N = vpad; g.K = d; g.bias = ctc_b;
     g.amax_val = d_amax_v.as<float>(); g.amax_idx = d_amax_i.as<int32_t>(); g.n_valid = c.vocab;
-    if (taps_enabled) {
-      d_logits.reserve((size_t)Mpad * vpad * 4, stream);
-      g.out_f32 = d_logits.as<float>(); g.ld_out_f32 = vpad;
-    }
+    if (taps_enabled) { g.out_f32 = d_logits.as<float>(); g.ld_out_f32 = vpad; }
     gemm(g);
   }
   {
     ProfScope ps(prof, "ctc_tail", stream);
     launch_argmax_reduce(d_amax_v.as<float>(), d_amax_i.as<int32_t>(), rows, n_slabs, d_ids.as<int32_t>(), stream);
-    launch_ctc_collapse(d_ids.as<int32_t>(), dp, batch, c.blank_id, d_tok.as<int32_t>(), max_tokens, d_num.as<int32_t>(), stream);
+    launch_ctc_collapse(d_ids.as<int32_t>(), r.dp, r.batch, c.blank_id, d_tok.as<int32_t>(), r.max_tokens, d_num.as<int32_t>(), stream);
   }
   if (taps_enabled) {
     save_tap("logits", d_logits.ptr, rows, c.vocab, vpad, 4);
     save_tap("frame_ids", d_ids.ptr, rows, 1, 1, 4);
   }
-  // ---- outputs ---------------------------------------------------------------------------
+  // ---- outputs (pinned host staging) ---------------------------------------------------------
+  HIP_CHECK(hipMemcpyAsync(h_out, d_tok.ptr, (size_t)r.batch * r.max_tokens * 4, hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipMemcpyAsync((unsigned char*)h_out + (size_t)r.batch * r.max_tokens * 4, d_num.ptr, (size_t)r.batch * 4,
+                           hipMemcpyDeviceToHost, stream));
+}
+
+template <typename T>
+void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int batch, const int32_t* lang, int32_t* tok_out,
+                    int max_tokens, int32_t* num_out) {
+  const auto& c = cfg;
+  ASR_REQUIRE(batch > 0, "sensevoice: empty batch");
+  ASR_REQUIRE(audio && offs && lang && tok_out && num_out, "sensevoice: null argument");
+  HIP_CHECK(hipSetDevice(device));
+  const int d = c.d_model, dff = c.d_ffn;
+
+  // ---- host plan -------------------------------------------------------------------------
+  std::vector<UttPlan> plan(batch);
+  SvRunCtx r{};
+  int rows = 0, frames = 0, n_fb = 0, n_qb = 0, max_T = 0;
+  const int64_t base0 = offs[0];
+  uint64_t key = 1469598103934665603ull;                 // FNV-1a over everything that shapes the launch sequence
+  auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
+  for (int b = 0; b < batch; ++b) {
+    const int64_t n = offs[b + 1] - offs[b];
+    ASR_REQUIRE(n >= c.win_length, "sensevoice: utterance %d has %lld samples (< one %d-sample frame)", b, (long long)n, c.win_length);
+    ASR_REQUIRE(n <= c.max_audio_len, "sensevoice: utterance %d has %lld samples (> max_audio_len %d)", b, (long long)n, c.max_audio_len);
+    ASR_REQUIRE(lang[b] >= 0 && lang[b] < c.n_languages, "sensevoice: language_idx %d out of range", lang[b]);
+    UttPlan& p = plan[b];
+    p.audio_off = offs[b] - base0;
+    p.n_samples = (int)n;
+    p.n_frames = ((int)n - c.win_length) / c.hop_length + 1;
+    p.frame_off = frames;
+    p.n_lfr = (p.n_frames + c.lfr_n - 1) / c.lfr_n;
+    p.T = p.n_lfr + c.n_prompt;
+    p.row_off = rows;
+    p.lang = lang[b];
+    p.blk0 = n_fb;
+    frames += p.n_frames;
+    rows += round_up(p.T, 16);
+    n_fb += (p.n_frames + 63) / 64;
+    max_T = std::max(max_T, p.T);
+    mix((uint64_t)n);
+  }
+  ASR_REQUIRE(max_tokens >= 1, "sensevoice: max_tokens must be positive");
+  int att_qt = 0, att_nw = 4, q_rows = 64;             // f32 kernel: fixed 64-row query blocks
+  if (precision == ASR_PRECISION_BF16) { attention_geometry(max_T, c.d_head, &att_qt, &att_nw); q_rows = 16 * att_qt * att_nw; }
+  for (int b = 0; b < batch; ++b) n_qb += (plan[b].T + q_rows - 1) / q_rows;
+  const int Mpad = round_up(rows, 128);
+  const int64_t total_samples = offs[batch] - base0;
+
+  // plan blob: [UttPlan x B][blk_utt n_fb][blk_f0 n_fb][qb_utt n_qb][qb_q0 n_qb][row_utt Mpad]
+  const size_t plan_bytes = sizeof(UttPlan) * batch + sizeof(int32_t) * (2 * (size_t)n_fb + 2 * (size_t)n_qb + Mpad);
+  if (plan_bytes > h_plan_cap) {
+    if (h_plan) HIP_CHECK(hipHostFree(h_plan));
+    HIP_CHECK(hipHostMalloc(&h_plan, plan_bytes * 2, hipHostMallocDefault));
+    h_plan_cap = plan_bytes * 2;
+    ++ws_epoch;
+  }
+  unsigned char* hp = (unsigned char*)h_plan;
+  memcpy(hp, plan.data(), sizeof(UttPlan) * batch);
+  int32_t* blk_utt = (int32_t*)(hp + sizeof(UttPlan) * batch);
+  int32_t* blk_f0 = blk_utt + n_fb;
+  int32_t* qb_utt = blk_f0 + n_fb;
+  int32_t* qb_q0 = qb_utt + n_qb;
+  int32_t* row_utt = qb_q0 + n_qb;
+  {
+    int fi = 0, qi = 0;
+    for (int b = 0; b < batch; ++b) {
+      for (int f0 = 0; f0 < plan[b].n_frames; f0 += 64) { blk_utt[fi] = b; blk_f0[fi++] = f0; }
+      for (int q0 = 0; q0 < plan[b].T; q0 += q_rows) { qb_utt[qi] = b; qb_q0[qi++] = q0; }
+      const int r16 = round_up(plan[b].T, 16);
+      for (int t = 0; t < r16; ++t) row_utt[plan[b].row_off + t] = b;
+    }
+    for (int t = rows; t < Mpad; ++t) row_utt[t] = -1;
+  }
+  // ---- workspace (grow-only; any re-allocation invalidates the captured graph) -----------------
+  const size_t eT = sizeof(T);
+  auto grow = [&](DeviceBuffer& buf, size_t bytes) { void* before = buf.ptr; buf.reserve(bytes, stream); if (buf.ptr != before) ++ws_epoch; };
+  grow(d_plan, plan_bytes);
+  if (audio_mem == ASR_MEM_HOST) grow(d_audio, (size_t)total_samples * 4);
+  grow(d_mel, (size_t)frames * c.n_mels * 4);
+  grow(d_x0, (size_t)Mpad * kpad0 * 4);
+  grow(d_xa, (size_t)Mpad * d * 4);
+  grow(d_xb, (size_t)Mpad * d * 4);
+  grow(d_h, (size_t)Mpad * std::max(kpad0, d) * eT);
+  grow(d_qk, (size_t)Mpad * 2 * d * eT);
+  grow(d_vt, (size_t)Mpad * d * eT);
+  grow(d_ctx, (size_t)Mpad * d * eT);
+  grow(d_mem, (size_t)Mpad * d * 4);
+  grow(d_ffn, (size_t)Mpad * dff * eT);
+  const int n_slabs = vpad / 64;
+  grow(d_amax_v, (size_t)Mpad * n_slabs * 4);
+  grow(d_amax_i, (size_t)Mpad * n_slabs * 4);
+  grow(d_ids, (size_t)Mpad * 4);
+  grow(d_tok, (size_t)batch * max_tokens * 4);
+  grow(d_num, (size_t)batch * 4);
+  if (taps_enabled) grow(d_logits, (size_t)Mpad * vpad * 4);
   const size_t out_bytes = (size_t)batch * max_tokens * 4 + (size_t)batch * 4;
   if (out_bytes > h_out_cap) {
     if (h_out) HIP_CHECK(hipHostFree(h_out));
     HIP_CHECK(hipHostMalloc(&h_out, out_bytes * 2, hipHostMallocDefault));
     h_out_cap = out_bytes * 2;
+    ++ws_epoch;
   }
-  HIP_CHECK(hipMemcpyAsync(h_out, d_tok.ptr, (size_t)batch * max_tokens * 4, hipMemcpyDeviceToHost, stream));
-  HIP_CHECK(hipMemcpyAsync((unsigned char*)h_out + (size_t)batch * max_tokens * 4, d_num.ptr, (size_t)batch * 4,
-                           hipMemcpyDeviceToHost, stream));
+
+  HIP_CHECK(hipMemcpyAsync(d_plan.ptr, h_plan, plan_bytes, hipMemcpyHostToDevice, stream));
+  if (audio_mem == ASR_MEM_HOST) {
+    HIP_CHECK(hipMemcpyAsync(d_audio.ptr, audio + base0, (size_t)total_samples * 4, hipMemcpyHostToDevice, stream));
+    r.d_aud = d_audio.as<float>();
+  } else {
+    r.d_aud = audio + base0;
+  }
+  r.batch = batch; r.rows = rows; r.Mpad = Mpad; r.frames = frames; r.n_fb = n_fb; r.n_qb = n_qb; r.max_T = max_T;
+  r.max_tokens = max_tokens; r.att_qt = att_qt; r.att_nw = att_nw;
+  r.dp = d_plan.as<UttPlan>();
+  r.d_blk_utt = (const int32_t*)((unsigned char*)d_plan.ptr + sizeof(UttPlan) * batch);
+  r.d_blk_f0 = r.d_blk_utt + n_fb;
+  r.d_qb_utt = r.d_blk_f0 + n_fb;
+  r.d_qb_q0 = r.d_qb_utt + n_qb;
+  r.d_row_utt = r.d_qb_q0 + n_qb;
+  mix((uint64_t)batch); mix((uint64_t)max_tokens); mix((uint64_t)(uintptr_t)r.d_aud); mix(ws_epoch); mix((uint64_t)(uintptr_t)stream);
+
+  // ---- launch: eager the first time a geometry is seen (allocations settle), then capture once and replay ----
+  // 570 launches per forward are host-launch-bound when issued eagerly (~13 us each); replay costs ~1 us per node.
+  const bool graphable = use_graph && !taps_enabled && !prof.enabled;
+  if (graphable && graph_exec && key == graph_key) {
+    HIP_CHECK(hipGraphLaunch(graph_exec, stream));
+  } else if (graphable && key == eager_key) {
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    hipGraph_t graph = nullptr;
+    HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    try {
+      enqueue<T>(r);
+    } catch (...) {
+      (void)hipStreamEndCapture(stream, &graph);
+      if (graph) (void)hipGraphDestroy(graph);
+      throw;
+    }
+    HIP_CHECK(hipStreamEndCapture(stream, &graph));
+    HIP_CHECK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    graph_key = key;
+    HIP_CHECK(hipGraphLaunch(graph_exec, stream));
+  } else {
+    enqueue<T>(r);
+    eager_key = key;
+  }
   HIP_CHECK(hipStreamSynchronize(stream));
   if (prof.enabled) prof.collect();
   memcpy(num_out, (unsigned char*)h_out + (size_t)batch * max_tokens * 4, (size_t)batch * 4);
@@ -367,6 +427,7 @@ extern "C" int asr_sensevoice_create(const asr_sensevoice_config* cfg, const voi
       s->device = device_id;
       s->precision = precision;
       s->cfg = *cfg;
+      if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;
       s->arena.load(arena, arena_bytes, arena_mem, s->stream);

@@ -122,7 +122,7 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
   HIP_CHECK(hipSetDevice(device));
   const int d = c.d_model, dff = c.d_ffn, Ld = c.n_dec_layers, H = c.n_heads;
   plan.assign(B, UttPlan{});
-  int r = 0, frames = 0, n_fb = 0, n_qb = 0;
+  int r = 0, frames = 0, n_fb = 0, n_qb = 0, max_T = 0;
   const int64_t base0 = offs[0];
   for (int b = 0; b < B; ++b) {
     const int64_t n = offs[b + 1] - offs[b];
@@ -142,10 +142,13 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
     frames += p.n_frames;
     r += round_up(p.T + 1, 16);                          // +1: room for the conv stem's right zero-pad frame
     n_fb += (p.n_frames + 63) / 64;
-    n_qb += (p.T + 63) / 64;
+    max_T = std::max(max_T, p.T);
     if (n_pos_out) n_pos_out[b] = p.T;
   }
   batch = B; rows = r; Mpad = round_up(r, 128); hist = 0;
+  int att_qt = 0, att_nw = 4, q_rows = 64;
+  if (precision == ASR_PRECISION_BF16) { attention_geometry(max_T, c.d_head, &att_qt, &att_nw); q_rows = 16 * att_qt * att_nw; }
+  for (int b = 0; b < B; ++b) n_qb += (plan[b].T + q_rows - 1) / q_rows;
   const int R = 2 * Mpad;                                // gapped (frame-rate) rows
   const int64_t total_samples = offs[B] - base0;
 
@@ -171,7 +174,7 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
     int fi = 0, qi = 0;
     for (int b = 0; b < B; ++b) {
       for (int f0 = 0; f0 < plan[b].n_frames; f0 += 64) { blk_utt[fi] = b; blk_f0[fi++] = f0; }
-      for (int q0 = 0; q0 < plan[b].T; q0 += 64) { qb_utt[qi] = b; qb_q0[qi++] = q0; }
+      for (int q0 = 0; q0 < plan[b].T; q0 += q_rows) { qb_utt[qi] = b; qb_q0[qi++] = q0; }
       const int rb = round_up(plan[b].T + 1, 16);
       for (int t = 0; t < rb; ++t) {
         row_utt[plan[b].row_off + t] = b;
@@ -270,7 +273,7 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
       ProfScope ps(prof, "attention", stream);
       AttnArgs aa;
       aa.q = qk; aa.k = qk + d; aa.ld_qk = 2 * d; aa.vt = vt; aa.ld_vt = Mpad; aa.ctx = ctx; aa.ld_ctx = d; aa.plan = dp;
-      aa.qb_utt = d_qb_utt; aa.qb_q0 = d_qb_q0; aa.n_qblocks = n_qb; aa.n_heads = H;
+      aa.qb_utt = d_qb_utt; aa.qb_q0 = d_qb_q0; aa.n_qblocks = n_qb; aa.n_heads = H; aa.qt = att_qt; aa.n_waves = att_nw; aa.max_T = max_T;
       if (precision == ASR_PRECISION_BF16) launch_attention_bf16_hd64(aa, stream);
       else launch_attention_f32(aa, c.d_head, stream);
     }

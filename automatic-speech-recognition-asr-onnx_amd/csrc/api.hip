@@ -425,3 +425,29 @@ extern "C" int asr_op_gemm_bench(int variant, int M, int N, int K, int epilogue,
     (void)hipEventDestroy(e1);
   });
 }
+
+extern "C" int asr_op_gemm_ln(const float* x, const float* w, const float* bias, const float* gamma, const float* beta, int M, int N,
+                              int K, float* out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(x && w && out && M >= 1 && M <= 64 && N % 16 == 0 && K % 256 == 0, "op_gemm_ln: bad argument");
+    asr_require_device(0);
+    Tmp t;
+    float* dx = (float*)t.alloc((size_t)M * K * 4);
+    HIP_CHECK(hipMemcpy(dx, x, (size_t)M * K * 4, hipMemcpyHostToDevice));
+    void* dw = upload_operand(t, ASR_PRECISION_BF16, w, N, K, N, K);
+    float *db = nullptr, *dg = nullptr, *dbe = nullptr;
+    if (bias) { db = (float*)t.alloc((size_t)N * 4); HIP_CHECK(hipMemcpy(db, bias, (size_t)N * 4, hipMemcpyHostToDevice)); }
+    if (gamma) {
+      dg = (float*)t.alloc((size_t)K * 4); dbe = (float*)t.alloc((size_t)K * 4);
+      HIP_CHECK(hipMemcpy(dg, gamma, (size_t)K * 4, hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(dbe, beta, (size_t)K * 4, hipMemcpyHostToDevice));
+    }
+    float* dout = (float*)t.alloc((size_t)M * N * 4);
+    GemmArgs g;
+    g.W = dw; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = db; g.ln_x = dx; g.ld_ln_x = K; g.ln_gamma = dg; g.ln_beta = dbe;
+    g.out_f32 = dout; g.ld_out_f32 = N;
+    launch_gemm_bf16(g, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out, dout, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+  });
+}

@@ -299,6 +299,153 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_pipe(const GemmArgs g) {
   else epilogue_transposed<bf16_t, NJ>(g, acc, m_wave, n_wave, lane);
 }
 
+// ------------------------------------------------------------------------------------ bf16, skinny M (decode)
+// out[M <= 64][N] = A[M][K] W[N][K]^T: pure weight streaming. One workgroup = 16 output columns x all rows; its 8 waves
+// split K eight ways, each streaming its slice of the 16 weight rows straight from HBM into MFMA A-fragments
+// (16 bytes per lane, no LDS staging: the weights are read exactly once chip-wide), activations come from L2.
+// Partial sums are reduced across the waves through LDS; the swapped orientation leaves 4 consecutive columns per lane
+// for the bias / residual / store epilogue. With g.ln_x the A rows are LayerNorm(ln_x) computed in the prologue.
+constexpr int SK_WAVES = 8;
+
+template <int MT>
+__global__ __launch_bounds__(512) void gemm_bf16_skinny(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 15, fgrp = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int kslice = g.K / SK_WAVES;                       // multiple of 32 (host-checked)
+  const int k_begin = wave * kslice;
+  const bf16_t* wp = reinterpret_cast<const bf16_t*>(g.W) + (size_t)(n0 + frow) * g.ldw + k_begin + fgrp * 8;
+
+  constexpr int U = 8;                                  // K-steps per trip: 8 x 16-byte weight loads in flight per lane
+  // the weight stream does not depend on the activations: start it before the LayerNorm prologue
+  bf16x8_t wf0[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (u * 32 < kslice) wf0[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + u * 32));
+
+  // ---- A source: bf16 rows, or LayerNorm(ln_x) built here into LDS as bf16 [MT*16][K]
+  const bf16_t* A;
+  int lda;
+  if (g.ln_x) {
+    bf16_t* An = reinterpret_cast<bf16_t*>(smem + SK_WAVES * MT * 1024);
+    // wave w normalises rows w, w+8, ...: ALL of its rows are fetched in one batch of float4 loads (one L2 round trip),
+    // then mean / variance / output come from registers.
+    constexpr int RPW = MT * 16 / SK_WAVES;        // rows per wave
+    constexpr int KV = 5;                          // float4 per lane per row: K <= 1280
+    float4 v[RPW][KV];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int m = wave + rr * SK_WAVES;
+#pragma unroll
+      for (int q = 0; q < KV; ++q) {
+        const int k = q * 256 + lane * 4;
+        v[rr][q] = (m < g.M && k < g.K) ? *reinterpret_cast<const float4*>(g.ln_x + (size_t)m * g.ld_ln_x + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int m = wave + rr * SK_WAVES;
+      float s1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < KV; ++q) s1 += (v[rr][q].x + v[rr][q].y) + (v[rr][q].z + v[rr][q].w);
+      const float mean = wave_sum(s1) / (float)g.K;
+      float s2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < KV; ++q) {
+        if (q * 256 + lane * 4 < g.K) {
+          const float a = v[rr][q].x - mean, b = v[rr][q].y - mean, c = v[rr][q].z - mean, d = v[rr][q].w - mean;
+          s2 += (a * a + b * b) + (c * c + d * d);
+        }
+      }
+      const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)g.K + g.ln_eps);
+      bf16_t* o = An + (size_t)m * g.K;
+#pragma unroll
+      for (int q = 0; q < KV; ++q) {
+        const int k = q * 256 + lane * 4;
+        if (k < g.K) {
+          float y0 = (v[rr][q].x - mean) * rstd, y1 = (v[rr][q].y - mean) * rstd, y2 = (v[rr][q].z - mean) * rstd, y3 = (v[rr][q].w - mean) * rstd;
+          if (g.ln_gamma) {
+            const float4 ga = *reinterpret_cast<const float4*>(g.ln_gamma + k), be = *reinterpret_cast<const float4*>(g.ln_beta + k);
+            y0 = y0 * ga.x + be.x; y1 = y1 * ga.y + be.y; y2 = y2 * ga.z + be.z; y3 = y3 * ga.w + be.w;
+          }
+          if (m >= g.M) { y0 = y1 = y2 = y3 = 0.f; }
+          uint2 w2;
+          w2.x = pack_bf16x2(y0, y1);
+          w2.y = pack_bf16x2(y2, y3);
+          *reinterpret_cast<uint2*>(o + k) = w2;
+        }
+      }
+    }
+    __syncthreads();
+    A = An;
+    lda = g.K;
+  } else {
+    A = reinterpret_cast<const bf16_t*>(g.A);
+    lda = g.lda;
+  }
+  const bf16_t* ap = A + (size_t)frow * lda + k_begin + fgrp * 8;
+
+  f32x4_t acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < kslice; k += 32 * U) {
+    bf16x8_t wf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (k == 0) wf[u] = wf0[u];
+      else if (k + u * 32 < kslice) wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + k + u * 32));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (k + u * 32 < kslice) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(ap + (size_t)i * 16 * lda + k + u * 32);
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af, acc[i], 0, 0, 0);   // D[n = 4 fgrp + r][m = frow]
+        }
+      }
+    }
+  }
+  // ---- cross-wave reduction
+  float4* red = reinterpret_cast<float4*>(smem);                                     // [wave][MT][64]
+#pragma unroll
+  for (int i = 0; i < MT; ++i) red[(wave * MT + i) * 64 + lane] = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+  __syncthreads();
+  if (wave >= MT) return;
+  const int i = wave;                                                                // wave i finishes row tile i
+  float4 sum = red[i * 64 + lane];
+#pragma unroll
+  for (int w = 1; w < SK_WAVES; ++w) {
+    const float4 t = red[(w * MT + i) * 64 + lane];
+    sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+  }
+  const int m = i * 16 + frow, n = n0 + fgrp * 4;
+  if (m >= g.M) return;
+  if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + n); sum.x += b.x; sum.y += b.y; sum.z += b.z; sum.w += b.w; }
+  if (g.add) { const float4 t = *reinterpret_cast<const float4*>(g.add + (size_t)m * g.ld_add + n); sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w; }
+  if (g.act != ACT_NONE) { sum.x = apply_act_rt(sum.x, g.act); sum.y = apply_act_rt(sum.y, g.act); sum.z = apply_act_rt(sum.z, g.act); sum.w = apply_act_rt(sum.w, g.act); }
+  if (g.add2) {
+    const float4 t = *reinterpret_cast<const float4*>(g.add2 + (size_t)(g.add2_rows ? g.add2_rows[m] : m) * g.ld_add2 + n);
+    sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+  }
+  if (g.out_f32) store4<float>(g.out_f32 + (size_t)m * g.ld_out_f32 + n, sum.x, sum.y, sum.z, sum.w);
+  if (g.out_lo) store4<bf16_t>(reinterpret_cast<bf16_t*>(g.out_lo) + (size_t)m * g.ld_out_lo + n, sum.x, sum.y, sum.z, sum.w);
+}
+
+template <int MT>
+void launch_skinny(const GemmArgs& g, hipStream_t s) {
+  const size_t lds = (size_t)SK_WAVES * MT * 1024 + (g.ln_x ? (size_t)MT * 16 * g.K * 2 : 0);
+  ASR_REQUIRE(lds <= 160 * 1024, "gemm(skinny): LayerNorm prologue needs %zu bytes of LDS", lds);
+  static size_t attr = 0;
+  if (lds > attr) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+    attr = 160 * 1024;
+  }
+  hipLaunchKernelGGL(gemm_bf16_skinny<MT>, dim3(g.N / 16), dim3(64 * SK_WAVES), lds, s, g);
+  HIP_CHECK(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------ f32 (verification mode)
 constexpr int BK32 = 16;
 constexpr int LDF = BK32 + 1;    // padded LDS row (floats): conflict-free fragment reads
@@ -443,6 +590,16 @@ int g_gemm_variant = -1;   // -1 = heuristic
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 
 void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
+  if (g.ln_x) ASR_REQUIRE(g.M <= 64 && !g.A, "gemm: the fused LayerNorm prologue exists on the skinny (M <= 64) path only");
+  if (g.M <= 64 && !g.out_t && !g.amax_val && g.lo_group == 0 && g.K % (32 * SK_WAVES) == 0 && g_gemm_variant < 0) {
+    ASR_REQUIRE((g.A || g.ln_x) && g.W && g.N % 16 == 0, "gemm(skinny): bad operands");
+    ASR_REQUIRE(g.ln_x || (g.lda * 2) % 16 == 0, "gemm(skinny): lda must be a 16-byte multiple");
+    if (g.ln_x) ASR_REQUIRE(g.K % 4 == 0 && g.K <= 1280 && g.ld_ln_x % 4 == 0, "gemm(skinny): fused LayerNorm needs K <= 1280, float4-aligned rows");
+    if (g.M <= 16) launch_skinny<1>(g, s);
+    else if (g.M <= 32) launch_skinny<2>(g, s);
+    else launch_skinny<4>(g, s);
+    return;
+  }
   check_args(g, BK16, 2);
   int v = g_gemm_variant;
   if (v < 0) v = 4;

@@ -51,8 +51,9 @@ void launch_zero_gap_rows(T* buf, int ld, int n_cols, const UttPlan* plan, const
 
 // ---- decoder token + position embedding: x[b*n + i] = embed[ids[b*n + i]] + pos[hist + i]   (Export_Whisper.py:450-497)
 template <typename T>
-void launch_embed_pos(const int32_t* ids, int rows, int n, int hist, const T* embed, const float* pos, int d, float* x,
-                      hipStream_t s);
+void launch_embed_pos(const int32_t* ids, int rows, int n, int hist, const int32_t* hist_dev, const T* embed, const float* pos, int d,
+                      float* x, hipStream_t s);
+void launch_add_scalar(int32_t* p, int v, hipStream_t s);      // *p += v (device-side history counter)
 
 // ---- decoder attention, head_dim 64, n <= 8 new queries per sequence. Keys/values are rows of 64:
 //   self : cache [b][h][S_max][64]; the n new rows are appended from `kv_new` (fused qkv GEMM output) and attended
@@ -65,6 +66,9 @@ struct DecAttnArgs {
   int64_t stride_b, stride_h;                                  // element strides of (b, h) inside k_base / v_base
   const UttPlan* plan;                                         // cross: row_off / n_lfr per sequence; null for self
   int hist, n, n_heads, causal;
+  int max_keys = 0;                                            // upper bound of keys per sequence (sizes the LDS score buffer)
+  int sc_ld = 0;                                               // (set by the launcher)
+  const int32_t* hist_dev;                                     // when set, the history length is read from device memory (graph replay)
   void* out; int ld_out;
 };
 template <typename T>

@@ -577,9 +577,10 @@ __global__ void zero_gap_rows_kernel(T* __restrict__ buf, int ld, int n_cols, co
 
 // ------------------------------------------------------------------------------------ decoder embedding
 template <typename T>
-__global__ void embed_pos_kernel(const int32_t* __restrict__ ids, int n, int hist, const T* __restrict__ embed,
-                                 const float* __restrict__ pos, int d, float* __restrict__ x) {
+__global__ void embed_pos_kernel(const int32_t* __restrict__ ids, int n, int hist, const int32_t* __restrict__ hist_dev,
+                                 const T* __restrict__ embed, const float* __restrict__ pos, int d, float* __restrict__ x) {
   const int r = blockIdx.x;
+  if (hist_dev) hist = *hist_dev;
   const T* e = embed + (size_t)ids[r] * d;
   const float* p = pos + (size_t)(hist + r % n) * d;
   for (int c = threadIdx.x; c < d; c += blockDim.x) x[(size_t)r * d + c] = Elem<T>::load(e + c) + p[c];
@@ -596,17 +597,20 @@ template <typename T> __device__ __forceinline__ void load8dims(const T* p, floa
 
 template <typename T>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
-  __shared__ float sc[DA_MAXN * DA_MAXKEYS];
+  extern __shared__ __attribute__((aligned(16))) unsigned char da_smem[];
+  float* sc = reinterpret_cast<float*>(da_smem);          // [n][sc_ld]
+  const int sc_ld = a.sc_ld;
   __shared__ float qs[DA_MAXN][64];
   __shared__ float red[4][DA_MAXN][64];
   __shared__ float stat[2][DA_MAXN];
   const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane & 7;                     // which 8 dims of the row
   const int n = a.n;
+  const int hist = a.hist_dev ? *a.hist_dev : a.hist;
   int n_cached, row0 = 0;
   if (a.plan) { n_cached = a.plan[b].n_lfr; row0 = a.plan[b].row_off; }
-  else n_cached = a.hist;
-  const int S = a.plan ? n_cached : a.hist + n;
+  else n_cached = hist;
+  const int S = a.plan ? n_cached : hist + n;
   const T* Kc = reinterpret_cast<const T*>(a.k_base) + (size_t)b * a.stride_b + (size_t)h * a.stride_h + (size_t)row0 * 64;
   const T* Vc = reinterpret_cast<const T*>(a.v_base) + (size_t)b * a.stride_b + (size_t)h * a.stride_h + (size_t)row0 * 64;
   const T* Q = reinterpret_cast<const T*>(a.q);
@@ -618,36 +622,49 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
     T* Vw = const_cast<T*>(Vc);
     for (int i = tid; i < n * 64; i += 256) {
       const size_t src = (size_t)(b * n + (i >> 6)) * a.ld_new + h * 64 + (i & 63);
-      Kw[(size_t)(a.hist + (i >> 6)) * 64 + (i & 63)] = NEW[src + a.k_col0];
-      Vw[(size_t)(a.hist + (i >> 6)) * 64 + (i & 63)] = NEW[src + a.v_col0];
+      Kw[(size_t)(hist + (i >> 6)) * 64 + (i & 63)] = NEW[src + a.k_col0];
+      Vw[(size_t)(hist + (i >> 6)) * 64 + (i & 63)] = NEW[src + a.v_col0];
     }
   }
   __syncthreads();
   // ---- scores
-  for (int s0 = (tid >> 3); s0 < S; s0 += 32) {
-    float kv[8];
-    if (s0 < n_cached) load8dims<T>(Kc + (size_t)s0 * 64 + sub * 8, kv);
-    else load8dims<T>(NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.k_col0 + h * 64 + sub * 8, kv);
-    for (int i = 0; i < n; ++i) {
-      float acc = 0.0f;
+  constexpr int DU = 8;                          // rows in flight per 8-lane group
+  for (int sb = (tid >> 3); sb < S; sb += 32 * DU) {
+    float kv[DU][8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc = fmaf(qs[i][sub * 8 + e], kv[e], acc);
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      acc += __shfl_xor(acc, 4, 64);
-      if (sub == 0) sc[i * DA_MAXKEYS + s0] = acc + ((a.causal && s0 > a.hist + i) ? -128.0f : 0.0f);
+    for (int u = 0; u < DU; ++u) {
+      const int s0 = sb + u * 32;
+      if (s0 < S) {
+        if (s0 < n_cached) load8dims<T>(Kc + (size_t)s0 * 64 + sub * 8, kv[u]);
+        else load8dims<T>(NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.k_col0 + h * 64 + sub * 8, kv[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const int s0 = sb + u * 32;
+      if (s0 < S) {
+        for (int i = 0; i < n; ++i) {
+          float acc = 0.0f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc = fmaf(qs[i][sub * 8 + e], kv[u][e], acc);
+          acc += __shfl_xor(acc, 1, 64);
+          acc += __shfl_xor(acc, 2, 64);
+          acc += __shfl_xor(acc, 4, 64);
+          if (sub == 0) sc[i * sc_ld + s0] = acc + ((a.causal && s0 > hist + i) ? -128.0f : 0.0f);
+        }
+      }
     }
   }
   __syncthreads();
   // ---- soft-max statistics per query (wave w handles queries w, w+4)
   for (int i = wave; i < n; i += 4) {
     float mx = -INFINITY;
-    for (int s = lane; s < S; s += 64) mx = fmaxf(mx, sc[i * DA_MAXKEYS + s]);
+    for (int s = lane; s < S; s += 64) mx = fmaxf(mx, sc[i * sc_ld + s]);
     mx = wave_max(mx);
     float sum = 0.0f;
     for (int s = lane; s < S; s += 64) {
-      const float e = expf(sc[i * DA_MAXKEYS + s] - mx);
-      sc[i * DA_MAXKEYS + s] = e;
+      const float e = expf(sc[i * sc_ld + s] - mx);
+      sc[i * sc_ld + s] = e;
       sum += e;
     }
     sum = wave_sum(sum);
@@ -660,16 +677,28 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
   for (int i = 0; i < DA_MAXN; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[i][e] = 0.0f;
-  for (int s0 = (tid >> 3); s0 < S; s0 += 32) {
-    float vv[8];
-    if (s0 < n_cached) load8dims<T>(Vc + (size_t)s0 * 64 + sub * 8, vv);
-    else load8dims<T>(NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.v_col0 + h * 64 + sub * 8, vv);
+  for (int sb = (tid >> 3); sb < S; sb += 32 * DU) {
+    float vv[DU][8];
 #pragma unroll
-    for (int i = 0; i < DA_MAXN; ++i) {
-      if (i < n) {
-        const float p = sc[i * DA_MAXKEYS + s0];
+    for (int u = 0; u < DU; ++u) {
+      const int s0 = sb + u * 32;
+      if (s0 < S) {
+        if (s0 < n_cached) load8dims<T>(Vc + (size_t)s0 * 64 + sub * 8, vv[u]);
+        else load8dims<T>(NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.v_col0 + h * 64 + sub * 8, vv[u]);
+      }
+    }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[i][e] = fmaf(p, vv[e], acc[i][e]);
+    for (int u = 0; u < DU; ++u) {
+      const int s0 = sb + u * 32;
+      if (s0 < S) {
+#pragma unroll
+        for (int i = 0; i < DA_MAXN; ++i) {
+          if (i < n) {
+            const float p = sc[i * sc_ld + s0];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[i][e] = fmaf(p, vv[u][e], acc[i][e]);
+          }
+        }
       }
     }
   }
@@ -842,18 +871,28 @@ template void launch_zero_gap_rows<float>(float*, int, int, const UttPlan*, cons
 template void launch_zero_gap_rows<bf16_t>(bf16_t*, int, int, const UttPlan*, const int32_t*, int, hipStream_t);
 
 template <typename T>
-void launch_embed_pos(const int32_t* ids, int rows, int n, int hist, const T* embed, const float* pos, int d, float* x, hipStream_t s) {
-  hipLaunchKernelGGL(embed_pos_kernel<T>, dim3(rows), dim3(256), 0, s, ids, n, hist, embed, pos, d, x);
+void launch_embed_pos(const int32_t* ids, int rows, int n, int hist, const int32_t* hist_dev, const T* embed, const float* pos, int d,
+                      float* x, hipStream_t s) {
+  hipLaunchKernelGGL(embed_pos_kernel<T>, dim3(rows), dim3(256), 0, s, ids, n, hist, hist_dev, embed, pos, d, x);
   HIP_CHECK(hipGetLastError());
 }
-template void launch_embed_pos<float>(const int32_t*, int, int, int, const float*, const float*, int, float*, hipStream_t);
-template void launch_embed_pos<bf16_t>(const int32_t*, int, int, int, const bf16_t*, const float*, int, float*, hipStream_t);
+template void launch_embed_pos<float>(const int32_t*, int, int, int, const int32_t*, const float*, const float*, int, float*, hipStream_t);
+template void launch_embed_pos<bf16_t>(const int32_t*, int, int, int, const int32_t*, const bf16_t*, const float*, int, float*, hipStream_t);
+
+namespace { __global__ void add_scalar_kernel(int32_t* p, int v) { *p += v; } }
+void launch_add_scalar(int32_t* p, int v, hipStream_t s) {
+  hipLaunchKernelGGL(add_scalar_kernel, dim3(1), dim3(1), 0, s, p, v);
+  HIP_CHECK(hipGetLastError());
+}
 
 template <typename T>
 void launch_decode_attention(const DecAttnArgs& a, int batch, hipStream_t s) {
   ASR_REQUIRE(a.n >= 1 && a.n <= DA_MAXN, "decode attention: %d new positions per call (max %d)", a.n, DA_MAXN);
-  ASR_REQUIRE(a.plan || a.hist + a.n <= DA_MAXKEYS, "decode attention: %d keys exceed %d", a.hist + a.n, DA_MAXKEYS);
-  hipLaunchKernelGGL(decode_attn_kernel<T>, dim3(batch, a.n_heads), dim3(256), 0, s, a);
+  ASR_REQUIRE(a.plan || a.hist_dev || a.hist + a.n <= DA_MAXKEYS, "decode attention: %d keys exceed %d", a.hist + a.n, DA_MAXKEYS);
+  DecAttnArgs b = a;
+  b.sc_ld = (std::min(a.max_keys > 0 ? a.max_keys : DA_MAXKEYS, DA_MAXKEYS) + 63) & ~63;
+  const size_t lds = (size_t)a.n * b.sc_ld * 4;
+  hipLaunchKernelGGL(decode_attn_kernel<T>, dim3(batch, a.n_heads), dim3(256), lds, s, b);
   HIP_CHECK(hipGetLastError());
 }
 template void launch_decode_attention<float>(const DecAttnArgs&, int, hipStream_t);

@@ -8,6 +8,7 @@
 //            (:450-497,614-667) and the BEGIN_SUPPRESS / ARGMAX heads (:228-260).
 // The reference grows the self-KV by torch.cat every token (O(L^2) copies, :640-641) and shuttles 128 KV tensors
 // through Python per step; here the cache is appended in place and token ids stay on the device between steps.
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/asr_mi355x.h"
@@ -33,19 +34,22 @@ struct WhSession : asr_session {
   const void *conv1_w = nullptr, *conv2_w = nullptr, *ckv_w = nullptr, *embed = nullptr;
 
   // encoder state of the current batch
-  int batch = 0, rows = 0, Mpad = 0, hist = 0;
+  int batch = 0, rows = 0, Mpad = 0, hist = 0, max_T_enc = 0;
   std::vector<UttPlan> plan;
   DeviceBuffer d_plan, d_audio, d_mel, d_blkmax, d_x0, d_h1, d_xa, d_xb, d_xc, d_h, d_qk, d_vt, d_ctx, d_ffn, d_cross;
   // decoder state
-  DeviceBuffer d_kc, d_vc, d_ids, d_next, d_logits, d_dx, d_dqkv, d_dtok;
-  int dec_batch_cap = 0;
+  DeviceBuffer d_kc, d_vc, d_ids, d_next, d_logits, d_dx, d_dqkv, d_dtok, d_hist;
+  bool use_graph = true;
+  hipGraphExec_t dec_graph = nullptr;
+  uint64_t dec_key = 0, dec_eager_key = 0, ws_epoch = 1;
   void* h_plan = nullptr; size_t h_plan_cap = 0;
   void* h_io = nullptr; size_t h_io_cap = 0;
 
   ~WhSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_x0, &d_h1, &d_xa, &d_xb, &d_xc, &d_h, &d_qk, &d_vt, &d_ctx,
-                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok})
+                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist})
       b->release();
+    if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
     for (auto& kv : taps) kv.second.buf.release();
     if (h_plan) (void)hipHostFree(h_plan);
     if (h_io) (void)hipHostFree(h_io);
@@ -64,6 +68,7 @@ struct WhSession : asr_session {
     return h_io;
   }
   template <typename T> void encode(const float* audio, int audio_mem, const int64_t* offs, int B, int32_t* n_pos_out);
+  template <typename T> void enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, bool use_hist_dev);
   template <typename T> void step(const int32_t* ids_host, int n, bool is_prefill, int32_t* next_out, float* logits_out);
 };
 
@@ -145,7 +150,7 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
     max_T = std::max(max_T, p.T);
     if (n_pos_out) n_pos_out[b] = p.T;
   }
-  batch = B; rows = r; Mpad = round_up(r, 128); hist = 0;
+  batch = B; rows = r; Mpad = round_up(r, 128); hist = 0; max_T_enc = max_T;
   int att_qt = 0, att_nw = 4, q_rows = 64;
   if (precision == ASR_PRECISION_BF16) { attention_geometry(max_T, c.d_head, &att_qt, &att_nw); q_rows = 16 * att_qt * att_nw; }
   for (int b = 0; b < B; ++b) n_qb += (plan[b].T + q_rows - 1) / q_rows;
@@ -184,7 +189,7 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
       }
     }
   }
-  d_plan.reserve(plan_bytes, stream);
+  { void* before = d_plan.ptr; d_plan.reserve(plan_bytes, stream); if (d_plan.ptr != before) ++ws_epoch; }
   HIP_CHECK(hipMemcpyAsync(d_plan.ptr, h_plan, plan_bytes, hipMemcpyHostToDevice, stream));
   const UttPlan* dp = d_plan.as<UttPlan>();
   const int32_t* d_blk_utt = (const int32_t*)((unsigned char*)d_plan.ptr + sizeof(UttPlan) * B);
@@ -217,7 +222,7 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
   d_vt.reserve((size_t)Mpad * d * eT, stream);
   d_ctx.reserve((size_t)Mpad * d * eT, stream);
   d_ffn.reserve((size_t)Mpad * dff * eT, stream);
-  d_cross.reserve((size_t)2 * Ld * H * Mpad * 64 * eT, stream);
+  { void* before = d_cross.ptr; d_cross.reserve((size_t)2 * Ld * H * Mpad * 64 * eT, stream); if (d_cross.ptr != before) ++ws_epoch; }
 
   // ---- STFT power -> mel -> log10 (STFT_Process.py:224-246, Export_Whisper.py:424-425)
   {
@@ -318,6 +323,108 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
 }
 
 // ======================================================================================== decoder step
+// All launches of one step. `hist_dev` (device-resident history length) is what the kernels read, so the single-token
+// step is position independent and ONE captured hipGraph replays for every decode position.
+template <typename T>
+void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, bool use_hist_dev) {
+  const auto& c = cfg;
+  const int B = batch, d = c.d_model, dff = c.d_ffn, Ld = c.n_dec_layers, H = c.n_heads;
+  const int R = B * n, Rp = round_up(R, 128);
+  const int32_t* hd = use_hist_dev ? d_hist.as<int32_t>() : nullptr;
+  float* xa = d_dx.as<float>();
+  float* xb = xa + (size_t)Rp * d;
+  float* xc = xb + (size_t)Rp * d;
+  T* qkv = d_dqkv.as<T>();
+  T* hh = qkv + (size_t)Rp * 3 * d;
+  T* ctx = hh + (size_t)Rp * d;
+  T* ffn = ctx + (size_t)Rp * d;
+  T* cq = ffn + (size_t)Rp * dff;
+  T* hl = cq + (size_t)Rp * d;
+  const UttPlan* dp = d_plan.as<UttPlan>();
+  { ProfScope ps(prof, "dec_embed", stream); launch_embed_pos<T>(ids_dev, R, n, hist, hd, (const T*)embed, dec_pos, d, xa, stream); }
+  const size_t cache_l = (size_t)B * H * c.max_target_positions * 64;
+  // bf16 mode, M <= 64 rows: the (affine-less) LayerNorm runs inside the skinny GEMM's prologue
+  const bool fuse_ln = precision == ASR_PRECISION_BF16 && R <= 64 && d % 256 == 0;
+  auto ln_gemm = [&](const float* x, GemmArgs& g) {
+    if (fuse_ln) { g.A = nullptr; g.ln_x = x; g.ld_ln_x = d; }
+    else { ProfScope ps(prof, "dec_layernorm", stream); launch_layernorm<T>(x, d, R, d, nullptr, nullptr, 1e-5f, hh, d, d, stream); g.A = hh; g.lda = d; }
+    ProfScope ps(prof, "dec_gemm", stream);
+    gemm(g);
+  };
+  for (int l = 0; l < Ld; ++l) {
+    const DecLayer& L = dec[l];
+    {
+      GemmArgs g;
+      g.W = L.wqkv; g.ldw = d; g.M = R; g.N = 3 * d; g.K = d; g.bias = L.bqkv; g.out_lo = qkv; g.ld_out_lo = 3 * d;
+      ln_gemm(xa, g);
+    }
+    {
+      ProfScope ps(prof, "dec_self_attn", stream);
+      DecAttnArgs a;
+      a.q = qkv; a.ld_q = 3 * d; a.q_col0 = 0; a.kv_new = qkv; a.ld_new = 3 * d; a.k_col0 = d; a.v_col0 = 2 * d;
+      a.k_base = d_kc.as<T>() + l * cache_l; a.v_base = d_vc.as<T>() + l * cache_l;
+      a.stride_b = (int64_t)H * c.max_target_positions * 64; a.stride_h = (int64_t)c.max_target_positions * 64;
+      a.plan = nullptr; a.hist = hist; a.hist_dev = hd; a.n = n; a.n_heads = H; a.causal = 1; a.out = ctx; a.ld_out = d;
+      a.max_keys = c.max_target_positions;
+      launch_decode_attention<T>(a, B, stream);
+    }
+    {
+      ProfScope ps(prof, "dec_gemm", stream);
+      GemmArgs g;
+      g.A = ctx; g.lda = d; g.W = L.wo; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bo; g.add = xa; g.ld_add = d; g.out_f32 = xb; g.ld_out_f32 = d;
+      gemm(g);
+    }
+    {
+      GemmArgs g;
+      g.W = L.wcq; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bcq; g.out_lo = cq; g.ld_out_lo = d;
+      ln_gemm(xb, g);
+    }
+    {
+      ProfScope ps(prof, "dec_cross_attn", stream);
+      DecAttnArgs a;
+      a.q = cq; a.ld_q = d; a.q_col0 = 0; a.kv_new = nullptr; a.ld_new = 0; a.k_col0 = a.v_col0 = 0;
+      a.k_base = d_cross.as<T>() + (size_t)(0 * Ld + l) * H * Mpad * 64;
+      a.v_base = d_cross.as<T>() + (size_t)(1 * Ld + l) * H * Mpad * 64;
+      a.stride_b = 0; a.stride_h = (int64_t)Mpad * 64; a.plan = dp; a.hist = 0; a.hist_dev = nullptr; a.n = n; a.n_heads = H; a.causal = 0;
+      a.max_keys = max_T_enc;
+      a.out = ctx; a.ld_out = d;
+      launch_decode_attention<T>(a, B, stream);
+    }
+    {
+      ProfScope ps(prof, "dec_gemm", stream);
+      GemmArgs g;
+      g.A = ctx; g.lda = d; g.W = L.wco; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bco; g.add = xb; g.ld_add = d; g.out_f32 = xc; g.ld_out_f32 = d;
+      gemm(g);
+    }
+    {
+      GemmArgs g;
+      g.W = L.w1; g.ldw = d; g.M = R; g.N = dff; g.K = d; g.bias = L.b1; g.act = act; g.out_lo = ffn; g.ld_out_lo = dff;
+      ln_gemm(xc, g);
+      ProfScope ps(prof, "dec_gemm", stream);
+      GemmArgs g2;
+      g2.A = ffn; g2.lda = dff; g2.W = L.w2; g2.ldw = dff; g2.M = R; g2.N = d; g2.K = dff; g2.bias = L.b2; g2.add = xc; g2.ld_add = d;
+      g2.out_f32 = xa; g2.ld_out_f32 = d;
+      gemm(g2);
+    }
+  }
+  // final LayerNorm of the LAST position of every sequence, tied proj_out, -128 suppress penalty (:663-666)
+  {
+    ProfScope ps(prof, "dec_logits", stream);
+    GemmArgs g;
+    g.W = embed; g.ldw = d; g.M = B; g.N = vpad; g.K = d; g.bias = suppress; g.out_f32 = d_logits.as<float>(); g.ld_out_f32 = vpad;
+    if (precision == ASR_PRECISION_BF16 && B <= 64 && d % 256 == 0) {
+      g.ln_x = xa + (size_t)(n - 1) * d; g.ld_ln_x = n * d; g.ln_gamma = dec_ln_g; g.ln_beta = dec_ln_b;
+    } else {
+      launch_layernorm<T>(xa + (size_t)(n - 1) * d, n * d, B, d, dec_ln_g, dec_ln_b, 1e-5f, hl, d, d, stream);
+      g.A = hl; g.lda = d;
+    }
+    gemm(g);
+    // BEGIN_SUPPRESS (-inf on begin_suppress_tokens) applies to the head after a prefill only (:228-240)
+    launch_argmax_rows(d_logits.as<float>(), vpad, B, c.vocab, is_prefill ? begin : nullptr, d_next.as<int32_t>(), stream);
+    launch_add_scalar(d_hist.as<int32_t>(), n, stream);
+  }
+}
+
 template <typename T>
 void WhSession::step(const int32_t* ids_host, int n, bool is_prefill, int32_t* next_out, float* logits_out) {
   const auto& c = cfg;
@@ -330,25 +437,18 @@ void WhSession::step(const int32_t* ids_host, int n, bool is_prefill, int32_t* n
   const int R = B * n, Rp = round_up(R, 128), Bp = round_up(B, 128);
   const size_t eT = sizeof(T);
   const size_t cache_elems = (size_t)Ld * B * H * c.max_target_positions * 64;
-  d_kc.reserve(cache_elems * eT, stream);
-  d_vc.reserve(cache_elems * eT, stream);
-  d_ids.reserve((size_t)B * 8 * 4, stream);
-  d_next.reserve((size_t)B * 4, stream);
-  d_logits.reserve((size_t)Bp * vpad * 4, stream);
-  d_dx.reserve((size_t)3 * Rp * d * 4, stream);                 // three f32 residual-stream buffers
-  d_dqkv.reserve((size_t)Rp * (3 * d + d + d + dff + d) * eT + (size_t)Bp * d * eT, stream);
-  float* xa = d_dx.as<float>();
-  float* xb = xa + (size_t)Rp * d;
-  float* xc = xb + (size_t)Rp * d;
-  T* qkv = d_dqkv.as<T>();
-  T* hh = qkv + (size_t)Rp * 3 * d;
-  T* ctx = hh + (size_t)Rp * d;
-  T* ffn = ctx + (size_t)Rp * d;
-  T* cq = ffn + (size_t)Rp * dff;
-  T* hl = cq + (size_t)Rp * d;
+  auto grow = [&](DeviceBuffer& buf, size_t bytes) { void* before = buf.ptr; buf.reserve(bytes, stream); if (buf.ptr != before) ++ws_epoch; };
+  grow(d_kc, cache_elems * eT);
+  grow(d_vc, cache_elems * eT);
+  grow(d_ids, (size_t)B * 8 * 4);
+  grow(d_next, (size_t)B * 4);
+  grow(d_hist, 256);
+  grow(d_logits, (size_t)Bp * vpad * 4);
+  grow(d_dx, (size_t)3 * Rp * d * 4);                  // three f32 residual-stream buffers
+  grow(d_dqkv, (size_t)Rp * (3 * d + d + d + dff + d) * eT + (size_t)Bp * d * eT);
   const int32_t* ids_dev;
   if (ids_host) {
-    int32_t* stage = (int32_t*)pinned((size_t)R * 4);
+    int32_t* stage = (int32_t*)pinned((size_t)R * 4 + 64);
     for (int i = 0; i < R; ++i) {
       ASR_REQUIRE(ids_host[i] >= 0 && ids_host[i] < c.vocab, "whisper: token id %d out of range", ids_host[i]);
       stage[i] = ids_host[i];
@@ -359,77 +459,31 @@ void WhSession::step(const int32_t* ids_host, int n, bool is_prefill, int32_t* n
     ASR_REQUIRE(n == 1, "whisper: device-resident ids feed single-token decode steps only");
     ids_dev = d_next.as<int32_t>();
   }
-  const UttPlan* dp = d_plan.as<UttPlan>();
-  { ProfScope ps(prof, "dec_embed", stream); launch_embed_pos<T>(ids_dev, R, n, hist, (const T*)embed, dec_pos, d, xa, stream); }
-  const size_t cache_l = (size_t)B * H * c.max_target_positions * 64;
-  for (int l = 0; l < Ld; ++l) {
-    const DecLayer& L = dec[l];
-    { ProfScope ps(prof, "dec_layernorm", stream); launch_layernorm<T>(xa, d, R, d, nullptr, nullptr, 1e-5f, hh, d, d, stream); }
-    {
-      ProfScope ps(prof, "dec_gemm", stream);
-      GemmArgs g;
-      g.A = hh; g.lda = d; g.W = L.wqkv; g.ldw = d; g.M = R; g.N = 3 * d; g.K = d; g.bias = L.bqkv; g.out_lo = qkv; g.ld_out_lo = 3 * d;
-      gemm(g);
+  if (is_prefill) HIP_CHECK(hipMemsetAsync(d_hist.ptr, 0, 4, stream));
+  // single-token steps fed from the device are position independent => one graph for all of them
+  const bool graphable = use_graph && !ids_host && n == 1 && !taps_enabled && !prof.enabled;
+  const uint64_t key = ((uint64_t)B << 32) ^ (uint64_t)Mpad ^ (ws_epoch << 48) ^ (uint64_t)(uintptr_t)stream;
+  if (graphable && dec_graph && key == dec_key) {
+    HIP_CHECK(hipGraphLaunch(dec_graph, stream));
+  } else if (graphable && key == dec_eager_key) {
+    if (dec_graph) { (void)hipGraphExecDestroy(dec_graph); dec_graph = nullptr; }
+    hipGraph_t graph = nullptr;
+    HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    try {
+      enqueue_step<T>(ids_dev, 1, false, true);
+    } catch (...) {
+      (void)hipStreamEndCapture(stream, &graph);
+      if (graph) (void)hipGraphDestroy(graph);
+      throw;
     }
-    {
-      ProfScope ps(prof, "dec_self_attn", stream);
-      DecAttnArgs a;
-      a.q = qkv; a.ld_q = 3 * d; a.q_col0 = 0; a.kv_new = qkv; a.ld_new = 3 * d; a.k_col0 = d; a.v_col0 = 2 * d;
-      a.k_base = d_kc.as<T>() + l * cache_l; a.v_base = d_vc.as<T>() + l * cache_l;
-      a.stride_b = (int64_t)H * c.max_target_positions * 64; a.stride_h = (int64_t)c.max_target_positions * 64;
-      a.plan = nullptr; a.hist = hist; a.n = n; a.n_heads = H; a.causal = 1; a.out = ctx; a.ld_out = d;
-      launch_decode_attention<T>(a, B, stream);
-    }
-    {
-      ProfScope ps(prof, "dec_gemm", stream);
-      GemmArgs g;
-      g.A = ctx; g.lda = d; g.W = L.wo; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bo; g.add = xa; g.ld_add = d; g.out_f32 = xb; g.ld_out_f32 = d;
-      gemm(g);
-    }
-    { ProfScope ps(prof, "dec_layernorm", stream); launch_layernorm<T>(xb, d, R, d, nullptr, nullptr, 1e-5f, hh, d, d, stream); }
-    {
-      ProfScope ps(prof, "dec_gemm", stream);
-      GemmArgs g;
-      g.A = hh; g.lda = d; g.W = L.wcq; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bcq; g.out_lo = cq; g.ld_out_lo = d;
-      gemm(g);
-    }
-    {
-      ProfScope ps(prof, "dec_cross_attn", stream);
-      DecAttnArgs a;
-      a.q = cq; a.ld_q = d; a.q_col0 = 0; a.kv_new = nullptr; a.ld_new = 0; a.k_col0 = a.v_col0 = 0;
-      a.k_base = d_cross.as<T>() + (size_t)(0 * Ld + l) * H * Mpad * 64;
-      a.v_base = d_cross.as<T>() + (size_t)(1 * Ld + l) * H * Mpad * 64;
-      a.stride_b = 0; a.stride_h = (int64_t)Mpad * 64; a.plan = dp; a.hist = 0; a.n = n; a.n_heads = H; a.causal = 0;
-      a.out = ctx; a.ld_out = d;
-      launch_decode_attention<T>(a, B, stream);
-    }
-    {
-      ProfScope ps(prof, "dec_gemm", stream);
-      GemmArgs g;
-      g.A = ctx; g.lda = d; g.W = L.wco; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bco; g.add = xb; g.ld_add = d; g.out_f32 = xc; g.ld_out_f32 = d;
-      gemm(g);
-    }
-    { ProfScope ps(prof, "dec_layernorm", stream); launch_layernorm<T>(xc, d, R, d, nullptr, nullptr, 1e-5f, hh, d, d, stream); }
-    {
-      ProfScope ps(prof, "dec_gemm", stream);
-      GemmArgs g;
-      g.A = hh; g.lda = d; g.W = L.w1; g.ldw = d; g.M = R; g.N = dff; g.K = d; g.bias = L.b1; g.act = act; g.out_lo = ffn; g.ld_out_lo = dff;
-      gemm(g);
-      GemmArgs g2;
-      g2.A = ffn; g2.lda = dff; g2.W = L.w2; g2.ldw = dff; g2.M = R; g2.N = d; g2.K = dff; g2.bias = L.b2; g2.add = xc; g2.ld_add = d;
-      g2.out_f32 = xa; g2.ld_out_f32 = d;
-      gemm(g2);
-    }
-  }
-  // final LayerNorm of the LAST position of every sequence, tied proj_out, -128 suppress penalty (:663-666)
-  { ProfScope ps(prof, "dec_layernorm", stream); launch_layernorm<T>(xa + (size_t)(n - 1) * d, n * d, B, d, dec_ln_g, dec_ln_b, 1e-5f, hl, d, d, stream); }
-  {
-    ProfScope ps(prof, "dec_logits", stream);
-    GemmArgs g;
-    g.A = hl; g.lda = d; g.W = embed; g.ldw = d; g.M = B; g.N = vpad; g.K = d; g.bias = suppress; g.out_f32 = d_logits.as<float>(); g.ld_out_f32 = vpad;
-    gemm(g);
-    // BEGIN_SUPPRESS (-inf on begin_suppress_tokens) applies to the head after a prefill only (:228-240)
-    launch_argmax_rows(d_logits.as<float>(), vpad, B, c.vocab, is_prefill ? begin : nullptr, d_next.as<int32_t>(), stream);
+    HIP_CHECK(hipStreamEndCapture(stream, &graph));
+    HIP_CHECK(hipGraphInstantiate(&dec_graph, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    dec_key = key;
+    HIP_CHECK(hipGraphLaunch(dec_graph, stream));
+  } else {
+    enqueue_step<T>(ids_dev, n, is_prefill, true);
+    if (graphable) dec_eager_key = key;
   }
   hist += n;
   if (taps_enabled) save_tap("logits", d_logits.ptr, B, c.vocab, vpad, 4);
@@ -460,6 +514,7 @@ extern "C" int asr_whisper_create(const asr_whisper_config* cfg, const void* are
       s->device = device_id;
       s->precision = precision;
       s->cfg = *cfg;
+      if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;
       s->arena.load(arena, arena_bytes, arena_mem, s->stream);

@@ -162,6 +162,14 @@ def op_gemm(a, w, bias=None, act=0, precision=PRECISION_BF16):
     return out
 
 
+def op_gemm_ln(x, w, bias=None, gamma=None, beta=None):
+    x, w = _f32(x), _f32(w)
+    out = np.empty((x.shape[0], w.shape[0]), dtype=np.float32)
+    b, g, be = (_f32(a) if a is not None else None for a in (bias, gamma, beta))
+    _lib.check(_lib.load().asr_op_gemm_ln(_fp(x), _fp(w), _fp(b), _fp(g), _fp(be), x.shape[0], w.shape[0], x.shape[1], _fp(out)))
+    return out
+
+
 def op_layernorm(x, gamma=None, beta=None, eps=1e-5, precision=PRECISION_F32):
     x = _f32(x)
     rows, D = x.shape

@@ -92,7 +92,12 @@ def main():
     ap.add_argument("--seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--workload", choices=("sensevoice", "whisper"), default="sensevoice",
+                    help="sensevoice = BASELINE.json configs[1] (default, the headline line); whisper = large-v3 encoder + greedy decode")
+    ap.add_argument("--decode-tokens", type=int, default=0, help="whisper: generated tokens per utterance (default 4 per audio second)")
     args = ap.parse_args()
+    if args.workload == "whisper":
+        return main_whisper(args)
 
     import torch
     import torch.distributed as dist
@@ -211,6 +216,126 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ck, audio_np)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def whisper_algorithmic(cfg, n_samples, B, n_tokens, prompt_len):
+    """Algorithmic FLOPs / bytes: encoder GEMM 2MNK + attention 4 T^2 d per layer + conv stem + cross-KV
+    projection; decode: weights read once per step for the batch + cross-KV + self-KV streamed per utterance."""
+    d, dff, Le, Ld, T = cfg.d_model, cfg.d_ffn, cfg.n_enc_layers, cfg.n_dec_layers, cfg.n_enc_pos(n_samples)
+    F = cfg.n_frames(n_samples)
+    enc = Le * (2.0 * T * d * (4 * d + 2 * dff) + 4.0 * T * T * d) + 2.0 * F * d * 3 * cfg.n_mels + 2.0 * T * d * 3 * d \
+        + 2.0 * T * d * 2 * Ld * d + F * (2.0 * cfg.nfft * 2 * (cfg.nfft // 2 + 1) + 2.0 * (cfg.nfft // 2 + 1) * cfg.n_mels)
+    dec_w_params = Ld * (4 * d * d + 2 * d * d + 2 * d * dff) + cfg.vocab * d
+    dec_tok = 2.0 * dec_w_params + Ld * 4.0 * T * d
+    step_bytes = 2.0 * dec_w_params + B * Ld * 2 * T * d * 2.0          # bf16 weights once per step + bf16 cross-KV per utterance
+    return {"encoder_flops": B * enc, "decode_flops_per_step": B * dec_tok, "decode_bytes_per_step": step_bytes}
+
+
+def main_whisper(args):
+    """Whisper-large-v3 bf16: encoder + fused cross-KV once per batch, then prefill(4-token prompt) + greedy decode of a
+    FIXED number of tokens (random weights never emit EOS; SURVEY.md section 8d: 4 tokens per audio second)."""
+    import torch
+    import torch.distributed as dist
+    cfgm = importlib.import_module(PKG + ".config")
+    ckm = importlib.import_module(PKG + ".checkpoints")
+    arena = importlib.import_module(PKG + ".arena")
+    eng = importlib.import_module(PKG + ".engine")
+    dp = importlib.import_module(PKG + ".dist")
+    rank, local_rank, world = dp.init_from_env()
+    assert world == args.gpus
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    cfg = cfgm.whisper_large_v3()
+    B = args.batch if args.batch != 64 else 32
+    n_samples = int(args.seconds * cfg.sample_rate)
+    n_tok = args.decode_tokens or int(round(4 * args.seconds))
+    blob = ck = None
+    if rank == 0:
+        ck = ckm.synth_whisper_checkpoint(cfg, seed=0)
+        blob = arena.build_whisper_arena(cfg, ck, arena.PRECISION_BF16, ckm.whisper_suppress_tokens(cfg), ckm.whisper_begin_suppress_tokens(cfg))
+        ck = None
+    t0 = time.perf_counter()
+    arena_dev = dp.broadcast_arena(blob, device)
+    torch.cuda.synchronize()
+    t_bcast = time.perf_counter() - t0
+    blob = None
+    sess = eng.WhisperSession(cfg, arena_dev, arena.PRECISION_BF16, local_rank, arena_device_ptr=arena_dev.data_ptr(), arena_bytes=arena_dev.numel())
+    audio_np = ckm.synth_audio("unit", B, n_samples, seed=1234 + rank)
+    audio_dev = torch.from_numpy(audio_np).to(device)
+    offsets = np.arange(B + 1, dtype=np.int64) * n_samples
+    prompt = np.tile(np.array([[cfg.sot_id, cfg.first_language_id, cfg.transcribe_id, cfg.no_timestamps_id]], np.int32), (B, 1))
+    t_parts = {"encode": 0.0, "prefill": 0.0, "decode": 0.0}
+
+    def step(record=False):
+        t0 = time.perf_counter()
+        sess.encode_packed(None, offsets, audio_device_ptr=audio_dev.data_ptr())
+        t1 = time.perf_counter()
+        sess.prefill(prompt, want_logits=False)
+        t2 = time.perf_counter()
+        toks = sess.generate(n_tok, eos_id=-1)
+        t3 = time.perf_counter()
+        if record:
+            t_parts["encode"] += t1 - t0; t_parts["prefill"] += t2 - t1; t_parts["decode"] += t3 - t2
+        if world > 1:
+            tok = np.stack(toks)
+            dp.gather_hypotheses(dp.pack_hypotheses(tok, np.full(B, n_tok, np.int32), n_tok), device)
+        return toks
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(record=True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    sess.profile(True)
+    sess.profile_reset()
+    step()
+    prof = sess.profile_read()
+    sess.profile(False)
+    if rank == 0:
+        alg = whisper_algorithmic(cfg, n_samples, B, n_tok, 4)
+        audio_s = world * B * args.seconds
+        kernels = {k: {"ms_per_step": round(v["total_ms"], 3), "launches_per_step": v["launches"]}
+                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+        enc_gemm = [k for k in kernels if k.startswith("gemm_")]
+        enc_gemm_ms = sum(kernels[k]["ms_per_step"] for k in enc_gemm)
+        d, dff, Le, T = cfg.d_model, cfg.d_ffn, cfg.n_enc_layers, cfg.n_enc_pos(n_samples)
+        enc_gemm_flops = B * (Le * 2.0 * T * d * (4 * d + 2 * dff) + 2.0 * T * d * 2 * cfg.n_dec_layers * d)
+        achieved = enc_gemm_flops / (enc_gemm_ms * 1e-3) / 1e12 if enc_gemm_ms else 0.0
+        t_dec = t_parts["decode"] / args.steps
+        out = {
+            "metric": "audio-sec/s, Whisper-large-v3, %g s @ 16 kHz chunks, batch %d per GPU, greedy, %d tokens/utterance" % (args.seconds, B, n_tok),
+            "value": round(audio_s * args.steps / elapsed, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Whisper-large-v3 bf16 (1.54 B params), batch=%d x %g s per GPU, encoder + cross-KV + prefill(4) + %d greedy decode steps, audio resident in HBM" % (B, args.seconds, n_tok - 1),
+                       "global_batch": world * B, "parallelism": f"dp{world}"},
+            "rtf": round(elapsed / (audio_s * args.steps), 7),
+            "ms": {k: round(v / args.steps * 1e3, 2) for k, v in t_parts.items()},
+            "decode_ms_per_token": round(t_dec / max(n_tok - 1, 1) * 1e3, 3),
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pipe (encoder qkv/out/fc1/fc2/cross-KV launches)", "achieved": round(achieved, 1),
+                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None},
+            "roofline_decode": {"bound": "hbm", "kernel": "decode step (weights + cross-KV stream)",
+                                "achieved": round(alg["decode_bytes_per_step"] / (t_dec / max(n_tok - 1, 1)) / 1e9, 1),
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(alg["decode_bytes_per_step"] / (t_dec / max(n_tok - 1, 1)) / 1e9 / HBM_PEAK_GBS, 4)},
+            "kernels": kernels, "arena_broadcast_s": round(t_bcast, 3),
+        }
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

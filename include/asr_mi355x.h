@@ -162,6 +162,9 @@ int asr_op_attention(int precision, const float* q, const float* k, const float*
                      int n_heads, int d_head, float* ctx);          /* packed rows, row-major [sum T][H*D] */
 int asr_op_fsmn(int precision, const float* v, const float* w, const float* b, const int32_t* seq_lens, int batch,
                 int channels, int ktaps, float* out);               /* v,out: [sum T][C] row-major */
+/* out[M<=64][N] = LayerNorm(x[M][K]; gamma, beta) w[N][K]^T + bias  (bf16 skinny GEMM with the fused LayerNorm prologue) */
+int asr_op_gemm_ln(const float* x, const float* w, const float* bias, const float* gamma, const float* beta, int M, int N, int K,
+                   float* out);
 /* Tuning hook: time `iters` launches of the bf16 GEMM on device-resident pseudo-random operands.
  * variant: -1 heuristic, 0..4 kernel variants (csrc/gemm.hip). epilogue: 0 bias->lo, 1 bias+relu->lo,
  * 2 bias+residual->f32, 3 two residual terms->f32, 4 transposed store. */

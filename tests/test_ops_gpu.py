@@ -138,3 +138,32 @@ def test_ctc_collapse_edge_cases():
     for c, g in zip(cases, got):
         want = SenseVoiceOracle.ctc_collapse(torch.tensor(c, dtype=torch.int64), 0).numpy()
         assert np.array_equal(g, want), (c[:10], g, want)
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 384, 1280), (7, 128, 256), (64, 256, 5120), (1, 1280, 1280)])
+def test_skinny_gemm_decode_shapes(M, N, K):
+    """M <= 64 rows dispatches to the weight-streaming kernel (8-way K split, LDS reduction)."""
+    eng = sub("engine")
+    rng = np.random.default_rng(M * N + K)
+    a = _bf16_round(rng.standard_normal((M, K), dtype=np.float32) + np.linspace(-1, 1, K, dtype=np.float32)[None, :])
+    w = _bf16_round(rng.standard_normal((N, K), dtype=np.float32) * 0.05 + np.linspace(0, 0.1, N, dtype=np.float32)[:, None])
+    bias = rng.standard_normal((N,), dtype=np.float32)
+    out = eng.op_gemm(a, w, bias, act=2, precision=BF16)
+    ref = torch.nn.functional.gelu(torch.from_numpy(a).double() @ torch.from_numpy(w).double().t() + torch.from_numpy(bias).double()).numpy()
+    assert np.abs(out - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("affine", [False, True])
+def test_skinny_gemm_with_fused_layernorm(affine):
+    eng = sub("engine")
+    rng = np.random.default_rng(9)
+    M, N, K = 24, 256, 1280
+    x = rng.standard_normal((M, K), dtype=np.float32) * 2 + 0.5
+    w = _bf16_round(rng.standard_normal((N, K), dtype=np.float32) * 0.05)
+    bias = rng.standard_normal((N,), dtype=np.float32)
+    g = rng.standard_normal((K,), dtype=np.float32) if affine else None
+    b = rng.standard_normal((K,), dtype=np.float32) if affine else None
+    out = eng.op_gemm_ln(x, w, bias, g, b)
+    ln = torch.nn.functional.layer_norm(torch.from_numpy(x), (K,), torch.from_numpy(g) if affine else None, torch.from_numpy(b) if affine else None, 1e-5)
+    ref = (ln.to(torch.bfloat16).double() @ torch.from_numpy(w).double().t() + torch.from_numpy(bias).double()).numpy()
+    assert np.abs(out - ref).max() <= 3e-3 * max(1.0, np.abs(ref).max())

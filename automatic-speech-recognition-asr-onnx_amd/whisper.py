@@ -1,0 +1,108 @@
+"""Whisper host loop: audio in -> token ids out, RTF -- the call surface of `Whisper/Inference_Whisper_ONNX.py`
+(:721-842) on the native session (the three merged graphs collapse into `encode` / `prefill` / `generate`):
+
+  prepare_audio_input()   = :103-126  int16 PCM -> model dtype, PCM scale 32768 (floats in [-1, 1])
+  remove_repeated_parts() = :129-139  tail-repeat guard applied before detokenisation (:705-708)
+  probe                   = _probe_prefill (:493-550): encoder + cross-KV + prefill([SOT]); language = arg-max over the
+                            language-token logits (:793-798); no-speech gate: softmax(logits + 128 on suppressed
+                            ids)[<|nospeech|>] >= 0.6 => skip (:799-805, NO_SPEECH_DETECTION Export_Whisper.py:334-348)
+  prefill                 = _prefill (:437-490) with [SOT, language, task, <|notimestamps|>] (:807)
+  decode                  = _decode_tokens (:584-663), plain greedy (REPEAT_PENALTY = 1.0), limit MAX_SEQ_LEN - 4 (:821)
+Batch extension: a list of clips is one batch; language detection / no-speech are per clip.
+"""
+from __future__ import annotations
+
+import time
+from typing import Sequence
+
+import numpy as np
+
+from .config import WhisperConfig
+from .engine import WhisperSession
+
+
+def prepare_audio_input(audio_int16: np.ndarray, target_dtype=np.float32, *, audio_pcm_scale: int = 32768,
+                        normalise: bool = False, target_rms: float = 4096.0) -> np.ndarray:
+    target_dtype = np.dtype(target_dtype)
+    if not normalise and target_dtype == np.int16:
+        return np.ascontiguousarray(audio_int16, dtype=np.int16)
+    audio = np.asarray(audio_int16).astype(np.float32)
+    if normalise:
+        rms = np.sqrt(np.mean(audio * audio, dtype=np.float32), dtype=np.float32)
+        if rms > 0:
+            audio *= target_rms / (rms + 1e-7)
+            np.clip(audio, -float(audio_pcm_scale), float(audio_pcm_scale) - 1.0, out=audio)
+    if target_dtype == np.int16:
+        return np.ascontiguousarray(audio, dtype=np.int16)
+    audio *= np.float32(1.0 / audio_pcm_scale)
+    return np.ascontiguousarray(audio, dtype=target_dtype)
+
+
+def remove_repeated_parts(ids: Sequence[int], repeat_words_threshold: int, ids_len: int):
+    """Cut the sequence where a window of `threshold` ids re-occurs later (the reference's loop, :129-139)."""
+    if ids_len <= repeat_words_threshold:
+        return ids
+    left = repeat_words_threshold // 2
+    right = left + 1
+    end = ids_len - left
+    for i in range(left, end):
+        for j in range(i + repeat_words_threshold, end):
+            if all(ids[j + k] == ids[i + k] for k in range(-left, right)):
+                return ids[:j - left]
+    return ids
+
+
+def no_speech_probability(logits: np.ndarray, suppress_tokens: Sequence[int], no_speech_id: int) -> np.ndarray:
+    """softmax(logits + 128 on the permanently suppressed ids)[<|nospeech|>]  (Export_Whisper.py:334-348)."""
+    x = np.asarray(logits, dtype=np.float32).copy()
+    if suppress_tokens is not None:
+        x[:, list(suppress_tokens)] += np.float32(128.0)
+    x -= x.max(axis=1, keepdims=True)
+    e = np.exp(x)
+    return e[:, no_speech_id] / e.sum(axis=1)
+
+
+class WhisperTranscriber:
+    def __init__(self, cfg: WhisperConfig, session: WhisperSession, suppress_tokens=None, task: str = "transcribe",
+                 detect_language: bool = True, no_speech_detection: bool = True, no_speech_threshold: float = 0.6,
+                 remove_repeats: bool = True):
+        self.cfg, self.sess = cfg, session
+        self.suppress_tokens = list(suppress_tokens) if suppress_tokens is not None else None
+        self.task_token = cfg.transcribe_id if task == "transcribe" else cfg.translate_id
+        self.detect_language, self.no_speech_detection = detect_language, no_speech_detection
+        self.no_speech_threshold, self.remove_repeats = no_speech_threshold, remove_repeats
+        self.language_token_ids = np.arange(cfg.first_language_id, cfg.first_language_id + cfg.n_languages, dtype=np.int64)
+        self.stop_tokens = {cfg.eot_id}
+
+    def transcribe(self, clips_int16: Sequence[np.ndarray], language_ids: Sequence[int] | None = None, max_new: int | None = None):
+        """List of int16 mono 16 kHz clips (each <= 30 s) -> per clip dict(tokens, language_id, no_speech_prob, skipped)."""
+        cfg = self.cfg
+        audios = [prepare_audio_input(np.asarray(c, dtype=np.int16).reshape(-1)) for c in clips_int16]
+        B = len(audios)
+        lang = np.asarray(language_ids if language_ids is not None else [cfg.first_language_id] * B, dtype=np.int64)
+        t0 = time.time()
+        self.sess.encode(audios)                                         # STFT + encoder + cross-KV, once per window
+        probs = np.zeros(B, dtype=np.float32)
+        if self.detect_language or self.no_speech_detection:
+            _, logits = self.sess.prefill(np.full((B, 1), cfg.sot_id, dtype=np.int32))      # probe with [SOT]
+            if self.detect_language:
+                lang = self.language_token_ids[np.argmax(logits[:, self.language_token_ids], axis=1)]
+            if self.no_speech_detection:
+                probs = no_speech_probability(logits, self.suppress_tokens, cfg.no_speech_id)
+        skipped = probs >= self.no_speech_threshold if self.no_speech_detection else np.zeros(B, dtype=bool)
+        prompt = np.stack([[cfg.sot_id, int(l), self.task_token, cfg.no_timestamps_id] for l in lang]).astype(np.int32)
+        limit = max(0, cfg.max_target_positions - prompt.shape[1])
+        if max_new is not None:
+            limit = min(limit, max_new)
+        self.sess.prefill(prompt, want_logits=False)
+        toks = self.sess.generate(limit, eos_id=cfg.eot_id) if limit > 0 else [np.zeros(0, np.int32)] * B
+        wall = time.time() - t0
+        out = []
+        for b in range(B):
+            ids = [] if skipped[b] else toks[b].tolist()
+            if self.remove_repeats:
+                ids = list(remove_repeated_parts(ids, 3, len(ids)))
+            out.append({"tokens": np.asarray(ids, dtype=np.int32), "language_id": int(lang[b]), "no_speech_prob": float(probs[b]),
+                        "skipped": bool(skipped[b])})
+        total_s = sum(a.size for a in audios) / cfg.sample_rate
+        return out, {"rtf": wall / total_s, "wall_s": wall}

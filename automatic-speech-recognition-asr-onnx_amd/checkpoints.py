@@ -141,3 +141,48 @@ def whisper_suppress_tokens(cfg: WhisperConfig) -> list:
 def whisper_begin_suppress_tokens(cfg: WhisperConfig) -> list:
     """generation_config.begin_suppress_tokens of Whisper = [" " token, <|endoftext|>]; synthetic: [220 % vocab, eot]."""
     return sorted({220 % cfg.vocab, cfg.eot_id})
+
+
+def synth_paraformer_checkpoint(cfg, seed: int = 0) -> dict:
+    """Random Paraformer-shaped checkpoint with FunASR state-dict names (Export_Paraformer.py:389-457,474-563)."""
+    rng = np.random.default_rng(seed)
+    ck: dict[str, np.ndarray] = {}
+    d, dff, feat = cfg.d_model, cfg.d_ffn, cfg.feat_dim
+
+    def enc_block(prefix, in_size):
+        ck[prefix + "norm1.weight"], ck[prefix + "norm1.bias"] = _ln(rng, in_size)
+        ck[prefix + "self_attn.linear_q_k_v.weight"], ck[prefix + "self_attn.linear_q_k_v.bias"] = _lin(rng, 3 * d, in_size)
+        ck[prefix + "self_attn.fsmn_block.weight"] = rng.standard_normal((d, 1, cfg.fsmn_kernel), dtype=np.float32) * np.float32(0.2)
+        ck[prefix + "self_attn.linear_out.weight"], ck[prefix + "self_attn.linear_out.bias"] = _lin(rng, d, d)
+        ck[prefix + "norm2.weight"], ck[prefix + "norm2.bias"] = _ln(rng, d)
+        ck[prefix + "feed_forward.w_1.weight"], ck[prefix + "feed_forward.w_1.bias"] = _lin(rng, dff, d, gain=1.4)
+        ck[prefix + "feed_forward.w_2.weight"], ck[prefix + "feed_forward.w_2.bias"] = _lin(rng, d, dff)
+
+    for i in range(cfg.n_enc0):
+        enc_block(f"encoder.encoders0.{i}.", feat)
+    for i in range(cfg.n_enc):
+        enc_block(f"encoder.encoders.{i}.", d)
+    ck["encoder.after_norm.weight"], ck["encoder.after_norm.bias"] = _ln(rng, d)
+    ck["predictor.cif_conv1d.weight"] = rng.standard_normal((d, d, cfg.cif_kernel), dtype=np.float32) * np.float32(1.0 / np.sqrt(d * cfg.cif_kernel))
+    ck["predictor.cif_conv1d.bias"] = rng.standard_normal((d,), dtype=np.float32) * np.float32(0.1)
+    ck["predictor.cif_output.weight"] = rng.standard_normal((1, d), dtype=np.float32) * np.float32(2.0 / np.sqrt(d))
+    ck["predictor.cif_output.bias"] = np.asarray([-0.6], dtype=np.float32)          # mean alpha ~ 0.37: a token every ~3 rows
+    dd = cfg.d_dec_ffn
+    for i in range(cfg.n_dec + cfg.n_dec3):
+        p = f"decoder.decoders.{i}." if i < cfg.n_dec else f"decoder.decoders3.{i - cfg.n_dec}."
+        ck[p + "norm1.weight"], ck[p + "norm1.bias"] = _ln(rng, d)
+        ck[p + "feed_forward.w_1.weight"], ck[p + "feed_forward.w_1.bias"] = _lin(rng, dd, d, gain=1.4)
+        ck[p + "feed_forward.norm.weight"], ck[p + "feed_forward.norm.bias"] = _ln(rng, dd)
+        ck[p + "feed_forward.w_2.weight"] = _lin(rng, d, dd, bias=False)[0]
+        if i < cfg.n_dec:
+            ck[p + "norm2.weight"], ck[p + "norm2.bias"] = _ln(rng, d)
+            ck[p + "norm3.weight"], ck[p + "norm3.bias"] = _ln(rng, d)
+            ck[p + "self_attn.fsmn_block.weight"] = rng.standard_normal((d, 1, cfg.fsmn_kernel), dtype=np.float32) * np.float32(0.2)
+            ck[p + "src_attn.linear_q.weight"], ck[p + "src_attn.linear_q.bias"] = _lin(rng, d, d)
+            ck[p + "src_attn.linear_k_v.weight"], ck[p + "src_attn.linear_k_v.bias"] = _lin(rng, 2 * d, d)
+            ck[p + "src_attn.linear_out.weight"], ck[p + "src_attn.linear_out.bias"] = _lin(rng, d, d)
+    ck["decoder.after_norm.weight"], ck["decoder.after_norm.bias"] = _ln(rng, d)
+    ck["decoder.output_layer.weight"], ck["decoder.output_layer.bias"] = _lin(rng, cfg.vocab, d)
+    ck["frontend.cmvn_means"] = (-18.0 + rng.standard_normal((feat,), dtype=np.float32)).astype(np.float32)
+    ck["frontend.cmvn_vars"] = (0.02 * (1.0 + 0.1 * rng.standard_normal((feat,), dtype=np.float32))).astype(np.float32)
+    return ck

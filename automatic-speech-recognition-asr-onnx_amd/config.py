@@ -127,3 +127,51 @@ def whisper_mid_test() -> WhisperConfig:
                          max_source_positions=1500, max_target_positions=448,
                          sot_id=4900, eot_id=4899, transcribe_id=4990, translate_id=4989, no_timestamps_id=4994,
                          no_speech_id=4993, first_language_id=4901, n_languages=80)
+
+
+@dataclass(frozen=True)
+class ParaformerConfig:
+    """Paraformer-large (non-streaming): Paraformer/Non-Streaming/Export_Paraformer.py:73-96,389-431."""
+    sample_rate: int = 16000
+    n_mels: int = 80
+    nfft: int = 512
+    win_length: int = 400
+    hop_length: int = 160
+    pre_emphasis: float = 0.97
+    lfr_m: int = 7
+    lfr_n: int = 6
+    d_model: int = 512
+    n_heads: int = 4
+    d_head: int = 128
+    d_ffn: int = 2048
+    n_enc0: int = 1
+    n_enc: int = 49
+    fsmn_kernel: int = 11
+    n_dec: int = 16              # decoders: FFN -> FSMN self-attention -> cross-attention
+    n_dec3: int = 1              # decoders3: FFN only
+    d_dec_ffn: int = 2048
+    cif_kernel: int = 3
+    tail_threshold: float = 0.45
+    vocab: int = 8404
+    max_audio_len: int = 480000
+
+    @property
+    def feat_dim(self) -> int:
+        return self.n_mels * self.lfr_m
+
+    def n_frames(self, audio_len: int) -> int:
+        return (audio_len - self.win_length) // self.hop_length + 1
+
+    def seq_len(self, audio_len: int) -> int:
+        return (self.n_frames(audio_len) + self.lfr_n - 1) // self.lfr_n
+
+    def to_dict(self):
+        return asdict(self)
+
+
+def paraformer_large() -> ParaformerConfig:
+    return ParaformerConfig()
+
+
+def paraformer_tiny() -> ParaformerConfig:
+    return ParaformerConfig(d_model=256, n_heads=2, d_head=128, d_ffn=512, n_enc0=1, n_enc=2, n_dec=2, n_dec3=1, d_dec_ffn=512, vocab=500)

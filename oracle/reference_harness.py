@@ -183,3 +183,105 @@ def build_reference_whisper(cfg, ck: dict, use_fp16_kv=False, suppress_tokens=No
         enc = ns["WHISPER_ENCODER"](model.model, stft, cfg.nfft, cfg.n_mels, cfg.sample_rate, cfg.n_dec_layers).eval()
         dec = ns["WHISPER_DECODER"](model, list(suppress_tokens) if suppress_tokens is not None else None, cfg.n_dec_layers).eval()
     return dict(ns=ns, model=model, encoder=enc, decoder=dec, stft=stft, kv_dtype=kv_dtype)
+
+
+# --------------------------------------------------------------------------- Paraformer (non-streaming)
+def build_paraformer_standin(cfg, ck: dict) -> torch.nn.Module:
+    """FunASR-shaped module tree with exactly the attributes PARAFORMER touches
+    (Paraformer/Non-Streaming/Export_Paraformer.py:367-472)."""
+    d, k = cfg.d_model, cfg.fsmn_kernel
+
+    def enc_layer(in_size):
+        l = _Layer(in_size, d, cfg.n_heads, cfg.d_head, cfg.d_ffn, k)
+        l.self_attn.pad_fn = torch.nn.ConstantPad1d(((k - 1) // 2, (k - 1) // 2), 0.0)
+        l.feed_forward.activation = torch.nn.ReLU()
+        return l
+
+    def dec_ff():
+        ff = torch.nn.Module()
+        ff.w_1 = torch.nn.Linear(d, cfg.d_dec_ffn)
+        ff.norm = torch.nn.LayerNorm(cfg.d_dec_ffn)
+        ff.w_2 = torch.nn.Linear(cfg.d_dec_ffn, d, bias=False)
+        ff.activation = torch.nn.ReLU()
+        return ff
+
+    def dec_layer(full):
+        l = torch.nn.Module()
+        l.norm1 = torch.nn.LayerNorm(d)
+        l.feed_forward = dec_ff()
+        if full:
+            l.norm2, l.norm3 = torch.nn.LayerNorm(d), torch.nn.LayerNorm(d)
+            sa = torch.nn.Module()
+            sa.fsmn_block = torch.nn.Conv1d(d, d, k, groups=d, bias=False)
+            sa.pad_fn = torch.nn.ConstantPad1d(((k - 1) // 2, (k - 1) // 2), 0.0)
+            l.self_attn = sa
+            ca = torch.nn.Module()
+            ca.h, ca.d_k = cfg.n_heads, cfg.d_head
+            ca.linear_q, ca.linear_k_v, ca.linear_out = torch.nn.Linear(d, d), torch.nn.Linear(d, 2 * d), torch.nn.Linear(d, d)
+            l.src_attn = ca
+        return l
+
+    m = torch.nn.Module()
+    enc = torch.nn.Module()
+    enc.encoders0 = torch.nn.Sequential(*[enc_layer(cfg.feat_dim) for _ in range(cfg.n_enc0)])
+    enc.encoders = torch.nn.Sequential(*[enc_layer(d) for _ in range(cfg.n_enc)])
+    enc.after_norm = torch.nn.LayerNorm(d)
+    enc.embed = None
+    m.encoder = enc
+    pred = torch.nn.Module()
+    pred.pad = torch.nn.ConstantPad1d((cfg.cif_kernel // 2, cfg.cif_kernel // 2), 0.0)
+    pred.cif_conv1d = torch.nn.Conv1d(d, d, cfg.cif_kernel)
+    pred.cif_output = torch.nn.Linear(d, 1)
+    pred.tail_threshold = cfg.tail_threshold
+    m.predictor = pred
+    dec = torch.nn.Module()
+    dec.decoders = torch.nn.Sequential(*[dec_layer(True) for _ in range(cfg.n_dec)])
+    dec.decoders3 = torch.nn.Sequential(*[dec_layer(False) for _ in range(cfg.n_dec3)])
+    dec.after_norm = torch.nn.LayerNorm(d)
+    dec.output_layer = torch.nn.Linear(d, cfg.vocab)
+    dec.embed = None
+    m.decoder = dec
+    sd = {k_: torch.from_numpy(np.ascontiguousarray(v)) for k_, v in ck.items() if not k_.startswith("frontend.")}
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return m.eval()
+
+
+def build_reference_paraformer(cfg, ck: dict, kaldi_mel_banks_fn):
+    """The reference's PARAFORMER + KaldiFbank classes on a synthetic checkpoint (script-level prep :580-584:
+    cmvn_vars *= sqrt(d_model))."""
+    assert reference_available()
+    path = os.path.join(REFERENCE_ROOT, "Paraformer", "Non-Streaming", "Export_Paraformer.py")
+    ns = dict(torch=torch, json=json, F=torch.nn.functional, kaldi=types.SimpleNamespace(get_mel_banks=kaldi_mel_banks_fn),
+              DECODER_CROSS_KV_GROUP_SIZE=4)
+    _compile_defs(path, ns)
+    standin = build_paraformer_standin(cfg, ck)
+    factor = float(cfg.d_model) ** 0.5
+    means = torch.from_numpy(ck["frontend.cmvn_means"]).reshape(1, 1, -1)
+    vars_ = (torch.from_numpy(ck["frontend.cmvn_vars"]) * factor).reshape(1, 1, -1)
+    lfr_len = (cfg.n_frames(cfg.max_audio_len) + cfg.lfr_n - 1) // cfg.lfr_n
+    with torch.inference_mode():
+        fbank = ns["KaldiFbank"](cfg.nfft, cfg.win_length, cfg.hop_length, cfg.n_mels, cfg.sample_rate, "hamming", cfg.pre_emphasis).eval()
+        model = ns["PARAFORMER"](standin, fbank, cfg.n_mels, cfg.lfr_m, cfg.lfr_n, lfr_len, means, vars_, cfg.d_model)
+    return model.eval()
+
+
+def reference_paraformer_stages(model, audio: np.ndarray) -> dict:
+    """Run the reference's own forward; intermediates come from forward hooks (no re-statement)."""
+    taps = {}
+    hooks = [
+        model.fbank_model.register_forward_hook(lambda m, i, o: taps.__setitem__("mel", o[0].detach().clone())),
+        model.encoder.after_norm.register_forward_hook(lambda m, i, o: taps.__setitem__("enc_out", o[0].detach().clone())),
+        model.predictor.cif_output.register_forward_hook(lambda m, i, o: taps.__setitem__("alpha_logit", o[0, :, 0].detach().clone())),
+        model.decoder.output_layer.register_forward_hook(lambda m, i, o: taps.__setitem__("logits", o[0].detach().clone())),
+    ]
+    try:
+        with torch.inference_mode():
+            token_ids, num_id = model(torch.from_numpy(audio).reshape(1, 1, -1).float())
+    finally:
+        for h in hooks:
+            h.remove()
+    n = int(num_id[0])
+    return dict(mel=taps["mel"].numpy(), enc_out=taps["enc_out"].numpy(), alphas=torch.sigmoid(taps["alpha_logit"]).numpy(),
+                logits=taps["logits"].numpy()[:max(n, 1)], token_ids=token_ids[0].numpy().astype(np.int32),
+                num_id=num_id.numpy().astype(np.int32))

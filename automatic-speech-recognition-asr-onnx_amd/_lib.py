@@ -29,6 +29,13 @@ class SenseVoiceConfigC(C.Structure):
         ("reserved", C.c_int32 * 8)]
 
 
+class ParaformerConfigC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "sample_rate", "n_mels", "nfft", "win_length", "hop_length", "lfr_m", "lfr_n", "d_model", "n_heads", "d_head", "d_ffn",
+        "n_blocks", "fsmn_kernel", "n_dec", "n_dec3", "d_dec_ffn", "cif_kernel", "vocab", "max_audio_len")] + [
+        ("tail_threshold", C.c_float), ("reserved", C.c_int32 * 8)]
+
+
 class WhisperConfigC(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "sample_rate", "n_mels", "nfft", "hop_length", "d_model", "n_heads", "d_head", "d_ffn", "n_enc_layers",
@@ -46,6 +53,8 @@ SIGNATURES = {
     "asr_sensevoice_create": (_i, [C.POINTER(SenseVoiceConfigC), _vp, _sz, _i, _i, _i, C.POINTER(_vp)]),
     "asr_sensevoice_run": (_i, [_vp, _vp, _i, _lp, _i, _ip, _ip, _i, _ip]),
     "asr_sensevoice_seq_len": (_i, [C.POINTER(SenseVoiceConfigC), _i, C.POINTER(C.c_int)]),
+    "asr_paraformer_create": (_i, [C.POINTER(ParaformerConfigC), _vp, _sz, _i, _i, _i, C.POINTER(_vp)]),
+    "asr_paraformer_run": (_i, [_vp, _vp, _i, _lp, _i, _ip, _i, _ip]),
     "asr_whisper_create": (_i, [C.POINTER(WhisperConfigC), _vp, _sz, _i, _i, _i, C.POINTER(_vp)]),
     "asr_whisper_encode": (_i, [_vp, _vp, _i, _lp, _i, _ip]),
     "asr_whisper_prefill": (_i, [_vp, _ip, _i, _ip, _fp]),

@@ -338,3 +338,111 @@ def build_whisper_arena(cfg, ck: dict, precision: int = PRECISION_BF16, suppress
     w.add("dec.ln_g", ck["model.decoder.layer_norm.weight"], DT_F32)
     w.add("dec.ln_b", ck["model.decoder.layer_norm.bias"], DT_F32)
     return w.finish()
+
+
+# =========================================================================== Paraformer (non-streaming)
+def paraformer_fbank_matrix(cfg) -> np.ndarray:
+    """(2*(nfft/2+1), win): windowed DFT basis @ (pre-emphasis matrix @ DC-removal matrix) -- the Paraformer exporter's
+    formulation of the Kaldi front-end (Export_Paraformer.py:326-343; same operator as SenseVoice's fold, other rounding)."""
+    W = cfg.win_length
+    window = torch.hamming_window(W, periodic=False, alpha=0.54, beta=0.46)
+    k = torch.arange(cfg.nfft // 2 + 1, dtype=torch.float32).unsqueeze(1)
+    n = torch.arange(W, dtype=torch.float32).unsqueeze(0)
+    omega = (2.0 * torch.pi / cfg.nfft) * k * n
+    dc = torch.eye(W) - torch.full((W, W), 1.0 / W)
+    prev = torch.zeros(W, W)
+    prev[0, 0] = 1.0
+    prev[1:, :-1] = torch.eye(W - 1)
+    t = (torch.eye(W) - float(cfg.pre_emphasis) * prev) @ dc
+    return torch.cat([(torch.cos(omega) * window) @ t, (-torch.sin(omega) * window) @ t], 0).numpy()
+
+
+def _fold64(norm_w, norm_b, w, b, out_scale=1.0):
+    """absorb_layer_norm_affine / fold_linear_output_scale in float64, rounded once (Export_Paraformer.py:214-258)."""
+    w64 = np.asarray(w, dtype=np.float64)
+    b64 = np.asarray(b, dtype=np.float64) if b is not None else np.zeros(w64.shape[0])
+    s = np.asarray(out_scale, dtype=np.float64)
+    w64 = w64 * (s[:, None] if s.ndim else s)
+    b64 = b64 * s
+    if norm_w is not None:
+        b64 = b64 + w64 @ np.asarray(norm_b, dtype=np.float64)
+        w64 = w64 * np.asarray(norm_w, dtype=np.float64)[None, :]
+    return w64.astype(np.float32), b64.astype(np.float32)
+
+
+def build_paraformer_arena(cfg, ck: dict, precision: int = PRECISION_BF16) -> np.ndarray:
+    w = ArenaWriter()
+    d, feat, dd = cfg.d_model, cfg.feat_dim, cfg.d_dec_ffn
+    nfreq = cfg.nfft // 2 + 1
+    w.add("fe.dft", pack_dft_for_mfma(paraformer_fbank_matrix(cfg), nfreq, cfg.win_length), DT_F32)
+    banks = kaldi_mel_banks(cfg.n_mels, cfg.nfft, float(cfg.sample_rate))
+    w.add("fe.mel", pack_mel_for_mfma(torch.nn.functional.pad(banks, (0, 1), value=0.0).t().contiguous().numpy(), cfg.n_mels), DT_F32)
+    # encoder input: x * vars + (means * vars + positions), the bias built in float64 (:459-465, 580-584)
+    vars_ = torch.from_numpy(ck["frontend.cmvn_vars"]) * (float(d) ** 0.5)
+    lfr_len = cfg.seq_len(cfg.max_audio_len)
+    positions = torch.arange(1, lfr_len + 1, dtype=torch.float32)
+    log_inc = torch.log(torch.tensor([10000.0])) / (feat / 2 - 1)
+    inv_ts = torch.exp(torch.arange(feat / 2).float() * (-log_inc))
+    st = positions.reshape(-1, 1) * inv_ts.reshape(1, -1)
+    pos = torch.cat([torch.sin(st), torch.cos(st)], 1)
+    bias = (torch.from_numpy(ck["frontend.cmvn_means"]).double().reshape(1, feat) * vars_.double().reshape(1, feat) + pos.double()).float()
+    w.add("fe.cmvn_vars", vars_.numpy().reshape(feat), DT_F32)
+    w.add("fe.speech_pos", bias.numpy(), DT_F32)
+    factor = float(cfg.d_head ** -0.25)
+    pad = (cfg.fsmn_kernel - 1) // 2
+
+    def fsmn_w(p):
+        wf = ck[p + "self_attn.fsmn_block.weight"][:, 0, :].astype(np.float64)
+        wf[:, pad] += 1.0
+        return wf.astype(np.float32)
+
+    names = [f"encoder.encoders0.{i}." for i in range(cfg.n_enc0)] + [f"encoder.encoders.{i}." for i in range(cfg.n_enc)]
+    for i, p in enumerate(names):
+        q = f"blk{i}."
+        scale = np.ones(3 * d)
+        scale[:-d] = factor
+        wqkv, bqkv = _fold64(ck[p + "norm1.weight"], ck[p + "norm1.bias"], ck[p + "self_attn.linear_q_k_v.weight"], ck[p + "self_attn.linear_q_k_v.bias"], scale)
+        w1, b1 = _fold64(ck[p + "norm2.weight"], ck[p + "norm2.bias"], ck[p + "feed_forward.w_1.weight"], ck[p + "feed_forward.w_1.bias"])
+        kpad = (wqkv.shape[1] + 63) // 64 * 64
+        w.weight(q + "wqkv", _pad_cols(wqkv, kpad), precision)
+        w.add(q + "bqkv", bqkv, DT_F32)
+        w.add(q + "wfsmn", fsmn_w(p), DT_F32)
+        w.add(q + "bfsmn", ck[p + "self_attn.linear_out.bias"], DT_F32)       # linear_out.bias rides with the FSMN term of the out-projection
+        w.weight(q + "wout", ck[p + "self_attn.linear_out.weight"], precision)
+        w.weight(q + "w1", w1, precision)
+        w.add(q + "b1", b1, DT_F32)
+        w.weight(q + "w2", ck[p + "feed_forward.w_2.weight"], precision)
+        w.add(q + "b2", ck[p + "feed_forward.w_2.bias"], DT_F32)
+    w.add("after_norm_g", ck["encoder.after_norm.weight"], DT_F32)
+    w.add("after_norm_b", ck["encoder.after_norm.bias"], DT_F32)
+    # CIF predictor: conv k=3 as a GEMM over [x[t-1] | x[t] | x[t+1]] (column = tap * d + channel)
+    cw = ck["predictor.cif_conv1d.weight"]                                     # (d, d, 3)
+    w.weight("cif.conv_w", np.ascontiguousarray(cw.transpose(0, 2, 1)).reshape(d, 3 * d), precision)
+    w.add("cif.conv_b", ck["predictor.cif_conv1d.bias"], DT_F32)
+    w.add("cif.out_w", ck["predictor.cif_output.weight"].reshape(d), DT_F32)
+    w.add("cif.out_b", ck["predictor.cif_output.bias"].reshape(1), DT_F32)
+    for j in range(cfg.n_dec + cfg.n_dec3):
+        full = j < cfg.n_dec
+        p = f"decoder.decoders.{j}." if full else f"decoder.decoders3.{j - cfg.n_dec}."
+        q = f"dec{j}."
+        w1, b1 = _fold64(ck[p + "norm1.weight"], ck[p + "norm1.bias"], ck[p + "feed_forward.w_1.weight"], ck[p + "feed_forward.w_1.bias"])
+        w2, b2 = _fold64(ck[p + "feed_forward.norm.weight"], ck[p + "feed_forward.norm.bias"], ck[p + "feed_forward.w_2.weight"], None)
+        w.weight(q + "w1", w1, precision); w.add(q + "b1", b1, DT_F32)
+        w.weight(q + "w2", w2, precision); w.add(q + "b2", b2, DT_F32)
+        if full:
+            wq, bq = _fold64(ck[p + "norm3.weight"], ck[p + "norm3.bias"], ck[p + "src_attn.linear_q.weight"], ck[p + "src_attn.linear_q.bias"], factor)
+            kv_scale = np.ones(2 * d)
+            kv_scale[:d] = factor
+            wkv, bkv = _fold64(None, None, ck[p + "src_attn.linear_k_v.weight"], ck[p + "src_attn.linear_k_v.bias"], kv_scale)
+            w.add(q + "n2_g", ck[p + "norm2.weight"], DT_F32); w.add(q + "n2_b", ck[p + "norm2.bias"], DT_F32)
+            w.add(q + "wfsmn", fsmn_w(p), DT_F32)
+            w.weight(q + "wq", wq, precision); w.add(q + "bq", bq, DT_F32)
+            w.weight(q + "wkv", wkv, precision); w.add(q + "bkv", bkv, DT_F32)
+            w.weight(q + "wo", ck[p + "src_attn.linear_out.weight"], precision); w.add(q + "bo", ck[p + "src_attn.linear_out.bias"], DT_F32)
+    wo, bo = _fold64(ck["decoder.after_norm.weight"], ck["decoder.after_norm.bias"], ck["decoder.output_layer.weight"], ck["decoder.output_layer.bias"])
+    vpad = (cfg.vocab + 127) // 128 * 128
+    ow = np.zeros((vpad, d), np.float32); ow[:cfg.vocab] = wo
+    ob = np.zeros((vpad,), np.float32); ob[:cfg.vocab] = bo
+    w.weight("out.w", ow, precision)
+    w.add("out.b", ob, DT_F32)
+    return w.finish()

@@ -89,6 +89,8 @@ struct LfrArgs {
   const float* system_embed;   // [n_prompt-1][feat]
   float* out;                  // [rows][ld_out]
   int ld_out, feat, n_mels, lfr_m, lfr_n, n_prompt, n_rows;
+  // affine_mode 1 (Paraformer, Export_Paraformer.py:483): x * cmvn_vars + bias_table[j] (bias_table = speech_pos), no prompts
+  int affine_mode = 0;
 };
 void launch_lfr_cmvn(const LfrArgs& a, hipStream_t s);
 
@@ -103,7 +105,8 @@ void launch_layernorm(const float* x, int ld_x, int rows, int D, const float* ga
 // q, k: [rows][ld] row-major; vt: [H*HD][ld_vt] (time-contiguous); ctx out: [rows][ld_ctx].
 // Scale is pre-folded into q and k (d^-1/4 each, Export_SenseVoice.py:210-216).
 struct AttnArgs {
-  const void* q; const void* k; int ld_qk;
+  const void* q; const void* k; int ld_qk;   // ld_qk: row stride of k (and of q unless ld_q is set)
+  int ld_q = 0;
   const void* vt; int ld_vt;
   void* ctx; int ld_ctx;
   const UttPlan* plan;
@@ -113,6 +116,8 @@ struct AttnArgs {
   // bf16 kernel geometry (attention_geometry): a query block = n_waves * qt tiles of 16 rows; max_T picks the chunk size.
   // The f32 kernel uses fixed 64-row blocks (qt = 0).
   int qt = 0, n_waves = 4, max_T = 0;
+  // cross-attention: queries follow q_plan (row_off / T of the query rows), keys / values follow plan; null => self-attention
+  const UttPlan* q_plan = nullptr;
 };
 // query-block geometry for the longest utterance of a batch: rows per block = 16 * qt * n_waves
 void attention_geometry(int max_T, int head_dim, int* qt, int* n_waves);
@@ -130,3 +135,21 @@ void launch_fsmn(const InT* vt, int ld, const float* w, const float* b, int C, i
 // ---- CTC greedy collapse, circular next-neighbour rule (Export_SenseVoice.py:290-296)
 void launch_ctc_collapse(const int32_t* frame_ids, const UttPlan* plan, int n_utts, int blank_id, int32_t* token_ids,
                          int max_tokens, int32_t* num_id, hipStream_t s);
+
+// ---- Paraformer CIF predictor + decoder helpers (Paraformer/Non-Streaming/Export_Paraformer.py:499-563)
+// [x[t-1] | x[t] | x[t+1]] rows with zero padding at utterance edges: the k=3 conv as one GEMM (K = 3 d)
+template <typename T>
+void launch_shift3(const T* x, int d, const UttPlan* plan, const int32_t* row_utt, int n_rows, T* out, hipStream_t s);
+// alpha[m] = sigmoid(dot(h[m], w) + b)
+template <typename T>
+void launch_alpha(const T* h, int d, const float* w, const float* b, int rows, float* alpha, hipStream_t s);
+// continuous integrate-and-fire: float64 prefix sum of alpha (+ tail threshold), fire where floor() increments, acoustic
+// embedding = difference of completed prefix integrals. Writes the token rows in the utterance's own row range and a
+// DEVICE-side token plan (row_off, T = max(N,1), n_lfr = N) so the decoder needs no host round trip.
+void launch_cif_scan(const float* alpha, const float* enc_out, int d, const UttPlan* plan, int n_utts, float tail_threshold,
+                     float* acoustic, UttPlan* token_plan, int32_t* num_id, hipStream_t s);
+// out[t] = res[t] + depth-wise conv (k taps, zero padded inside the token sequence) of x, all row-major f32
+void launch_fsmn_rows(const float* x, const float* res, const float* w, int d, int ktaps, const UttPlan* token_plan,
+                      const int32_t* row_utt, int n_rows, float* out, hipStream_t s);
+// token_ids[b][i] = ids[row_off_b + i], i < N_b
+void launch_gather_tokens(const int32_t* ids, const UttPlan* token_plan, int n_utts, int32_t* token_ids, int max_tokens, hipStream_t s);

@@ -131,7 +131,7 @@ __global__ void lfr_cmvn_kernel(const LfrArgs a) {
   for (int c = threadIdx.x; c < a.ld_out; c += blockDim.x) {
     float v = 0.0f;
     if (c < a.feat && t < up.T) {
-      if (t == 0) {
+      if (a.n_prompt > 0 && t == 0) {
         v = a.language_embed[(size_t)up.lang * a.feat + c];
       } else if (t < a.n_prompt) {
         v = a.system_embed[(size_t)(t - 1) * a.feat + c];
@@ -140,8 +140,12 @@ __global__ void lfr_cmvn_kernel(const LfrArgs a) {
         int f = j * a.lfr_n + c / a.n_mels - left;
         f = min(max(f, 0), up.n_frames - 1);
         const float x = a.mel[(size_t)(up.frame_off + f) * a.n_mels + c % a.n_mels];
-        v = (x + a.cmvn_means[c]) * a.cmvn_vars[c];
-        v = v + a.speech_pos[(size_t)j * a.feat + c];
+        if (a.affine_mode == 1) {
+          v = x * a.cmvn_vars[c] + a.speech_pos[(size_t)j * a.feat + c];
+        } else {
+          v = (x + a.cmvn_means[c]) * a.cmvn_vars[c];
+          v = v + a.speech_pos[(size_t)j * a.feat + c];
+        }
       }
     }
     o[c] = v;
@@ -149,9 +153,9 @@ __global__ void lfr_cmvn_kernel(const LfrArgs a) {
 }
 
 // ------------------------------------------------------------------------------------ LayerNorm
-// One wave per row; the row (D <= 1280) is read ONCE as float4 per lane and held in registers; two-pass
+// One wave per row; the row (D <= 2048) is read ONCE as float4 per lane and held in registers; two-pass
 // mean / variance on the registers (same arithmetic order class as torch's), wave-shuffle reductions.
-constexpr int LN_MAXV = 5;   // float4 per lane: 5 * 4 * 64 = 1280 columns
+constexpr int LN_MAXV = 8;   // float4 per lane: 8 * 4 * 64 = 2048 columns
 template <typename OutT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ld_x, int rows, int D,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -233,7 +237,8 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(const AttnArgs a, int n_
   const int fq = lane & 15, g = lane >> 4;
   const int u = a.qb_utt[blockIdx.x], q_base = a.qb_q0[blockIdx.x], h = blockIdx.y;
   const UttPlan up = a.plan[u];
-  const int T = up.T, row0 = up.row_off;
+  const int T = up.T, row0 = up.row_off;                       // keys / values
+  const int Tq = a.q_plan ? a.q_plan[u].T : T, rowq0 = a.q_plan ? a.q_plan[u].row_off : row0;
 
   bf16x8_t qf[QT][HD / 32];
   f32x4_t ot[QT][HD / 16];
@@ -242,12 +247,12 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(const AttnArgs a, int n_
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     const int q0 = q_base + (t * NW + wave) * 16;
-    act[t] = q0 < T;                          // wave-uniform
+    act[t] = q0 < Tq;                         // wave-uniform
     m_run[t] = -INFINITY;
     l_run[t] = 0.0f;
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) ot[t][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const bf16_t* qp = reinterpret_cast<const bf16_t*>(a.q) + (size_t)(row0 + (act[t] ? q0 : 0) + fq) * a.ld_qk + h * HD + g * 8;
+    const bf16_t* qp = reinterpret_cast<const bf16_t*>(a.q) + (size_t)(rowq0 + (act[t] ? q0 : 0) + fq) * a.ld_q + h * HD + g * 8;
 #pragma unroll
     for (int ks = 0; ks < HD / 32; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
   }
@@ -348,8 +353,8 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(const AttnArgs a, int n_
     float l = l_run[t] + __shfl_xor(l_run[t], 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
-    if (qrow < T) {
-      bf16_t* op = reinterpret_cast<bf16_t*>(a.ctx) + (size_t)(row0 + qrow) * a.ld_ctx + h * HD + g * 4;
+    if (qrow < Tq) {
+      bf16_t* op = reinterpret_cast<bf16_t*>(a.ctx) + (size_t)(rowq0 + qrow) * a.ld_ctx + h * HD + g * 4;
 #pragma unroll
       for (int dt = 0; dt < HD / 16; ++dt) {
         uint2 w;
@@ -371,14 +376,15 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs a, int HD)
   const int u = a.qb_utt[blockIdx.x], q0 = a.qb_q0[blockIdx.x], h = blockIdx.y;
   const UttPlan up = a.plan[u];
   const int T = up.T, row0 = up.row_off;
+  const int Tq = a.q_plan ? a.q_plan[u].T : T, rowq0 = a.q_plan ? a.q_plan[u].row_off : row0;
   const float* Q = reinterpret_cast<const float*>(a.q);
   const float* K = reinterpret_cast<const float*>(a.k);
   const float* Vt = reinterpret_cast<const float*>(a.vt);
   float* C = reinterpret_cast<float*>(a.ctx);
   for (int qi = wave; qi < 64; qi += 4) {
     const int qrow = q0 + qi;
-    if (qrow >= T) break;                      // wave-uniform
-    const float* qp = Q + (size_t)(row0 + qrow) * a.ld_qk + h * HD;
+    if (qrow >= Tq) break;                     // wave-uniform
+    const float* qp = Q + (size_t)(rowq0 + qrow) * a.ld_q + h * HD;
     for (int d = lane; d < HD; d += 64) qs[wave][d] = qp[d];
     __builtin_amdgcn_wave_barrier();
     float mx = -INFINITY;
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs a, int HD)
       const float* vp = Vt + (size_t)(h * HD + d) * a.ld_vt + row0;
       float acc = 0.0f;
       for (int key = 0; key < T; ++key) acc = fmaf(sc[wave][key], vp[key], acc);
-      C[(size_t)(row0 + qrow) * a.ld_ctx + h * HD + d] = acc * inv;
+      C[(size_t)(rowq0 + qrow) * a.ld_ctx + h * HD + d] = acc * inv;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -752,6 +758,97 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
   }
 }
 
+
+// ------------------------------------------------------------------------------------ Paraformer predictor / decoder helpers
+template <typename T>
+__global__ void shift3_kernel(const T* __restrict__ x, int d, const UttPlan* __restrict__ plan, const int32_t* __restrict__ row_utt,
+                              T* __restrict__ out) {
+  const int m = blockIdx.x;
+  const int u = row_utt[m];
+  int s = 0, e = 0;
+  if (u >= 0) { s = plan[u].row_off; e = s + plan[u].T; }
+  for (int c = threadIdx.x; c < 3 * d; c += blockDim.x) {
+    const int tap = c / d, cc = c - tap * d;
+    const int mm = m + tap - 1;
+    const bool ok = (u >= 0) && (m < e) && (mm >= s) && (mm < e);
+    out[(size_t)m * 3 * d + c] = ok ? x[(size_t)mm * d + cc] : T(0);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void alpha_kernel(const T* __restrict__ h, int d, const float* __restrict__ w, const float* __restrict__ b,
+                                                    int rows, float* __restrict__ alpha) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= rows) return;
+  float acc = 0.f;
+  for (int c = lane; c < d; c += 64) acc = fmaf(Elem<T>::load(h + (size_t)m * d + c), w[c], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) alpha[m] = 1.0f / (1.0f + expf(-(acc + b[0])));
+}
+
+__global__ void cif_scan_kernel(const float* __restrict__ alpha, const float* __restrict__ enc, int d, const UttPlan* __restrict__ plan,
+                                float tail, float* __restrict__ acoustic, UttPlan* __restrict__ tplan, int32_t* __restrict__ num_id) {
+  const int u = blockIdx.x;
+  const UttPlan up = plan[u];
+  const int T = up.T, row0 = up.row_off;
+  const int rows16 = (T + 15) & ~15;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    double psum = 0.0;                        // FunASR accumulates alpha in float64 and rounds once (:505-507)
+    float hsum = 0.f, prev_floor = 0.f, prev_completed = 0.f;
+    int k = 0;
+    for (int t = 0; t <= T; ++t) {
+      const float a = (t < T) ? alpha[row0 + t] : tail;
+      const float hv = (t < T) ? enc[(size_t)(row0 + t) * d + c] : 0.f;
+      psum += (double)a;
+      const float p32 = (float)psum, fl = floorf(p32);
+      hsum = __fadd_rn(hsum, __fmul_rn(a, hv));              // f32 prefix sum of alpha * hidden (torch.cumsum order)
+      if (fl > prev_floor) {
+        const float completed = __fsub_rn(hsum, __fmul_rn(p32 - fl, hv));
+        if (k < rows16) acoustic[(size_t)(row0 + k) * d + c] = completed - prev_completed;
+        prev_completed = completed;
+        ++k;
+      }
+      prev_floor = fl;
+    }
+    for (int r = k; r < rows16; ++r) acoustic[(size_t)(row0 + r) * d + c] = 0.f;   // incl. the dummy row of a zero-fire clip
+    if (c == 0) {
+      UttPlan tp = up;
+      tp.n_lfr = k;
+      tp.T = k > 0 ? k : 1;                   // Conv1d cannot take an empty token axis: one zero row, dropped at the end (:525-530)
+      tplan[u] = tp;
+      num_id[u] = k;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void fsmn_rows_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ w,
+                                                        int d, int ktaps, const UttPlan* __restrict__ tplan,
+                                                        const int32_t* __restrict__ row_utt, float* __restrict__ out) {
+  const int m = blockIdx.x;
+  const int u = row_utt[m];
+  int s = 0, e = 0;
+  if (u >= 0) { s = tplan[u].row_off; e = s + tplan[u].T; }
+  const int pad = (ktaps - 1) / 2;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float acc = 0.f;
+    if (m >= s && m < e) {
+      acc = res[(size_t)m * d + c];
+      for (int j = 0; j < ktaps; ++j) {
+        const int mm = m + j - pad;
+        if (mm >= s && mm < e) acc = fmaf(w[c * ktaps + j], x[(size_t)mm * d + c], acc);
+      }
+    }
+    out[(size_t)m * d + c] = acc;
+  }
+}
+
+__global__ void gather_tokens_kernel(const int32_t* __restrict__ ids, const UttPlan* __restrict__ tplan, int32_t* __restrict__ token_ids,
+                                     int max_tokens) {
+  const int u = blockIdx.x;
+  const int n = min(tplan[u].n_lfr, max_tokens);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) token_ids[(size_t)u * max_tokens + i] = ids[tplan[u].row_off + i];
+}
+
 }  // namespace
 
 // ==================================================================================== launchers
@@ -794,7 +891,9 @@ static void launch_attn_inst(const AttnArgs& a, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_bf16_kernel<HD, CHUNK, QT>), dim3(a.n_qblocks, a.n_heads), dim3(64 * a.n_waves), lds, s, a, a.ld_vt);
+  AttnArgs b = a;
+  if (b.ld_q == 0) b.ld_q = b.ld_qk;
+  hipLaunchKernelGGL((attn_bf16_kernel<HD, CHUNK, QT>), dim3(a.n_qblocks, a.n_heads), dim3(64 * a.n_waves), lds, s, b, a.ld_vt);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -832,7 +931,9 @@ void launch_attention_bf16_hd64(const AttnArgs& a, hipStream_t s) {
 
 void launch_attention_f32(const AttnArgs& a, int head_dim, hipStream_t s) {
   ASR_REQUIRE(head_dim <= 128 && head_dim % 4 == 0, "attention_f32: head_dim %d unsupported", head_dim);
-  hipLaunchKernelGGL(attn_f32_kernel, dim3(a.n_qblocks, a.n_heads), dim3(256), 0, s, a, head_dim);
+  AttnArgs b = a;
+  if (b.ld_q == 0) b.ld_q = b.ld_qk;
+  hipLaunchKernelGGL(attn_f32_kernel, dim3(a.n_qblocks, a.n_heads), dim3(256), 0, s, b, head_dim);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -900,5 +1001,39 @@ template void launch_decode_attention<bf16_t>(const DecAttnArgs&, int, hipStream
 
 void launch_argmax_rows(const float* logits, int ld, int rows, int n_valid, const float* extra, int32_t* ids, hipStream_t s) {
   hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, s, logits, ld, n_valid, extra, ids);
+  HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void launch_shift3(const T* x, int d, const UttPlan* plan, const int32_t* row_utt, int n_rows, T* out, hipStream_t s) {
+  hipLaunchKernelGGL(shift3_kernel<T>, dim3(n_rows), dim3(256), 0, s, x, d, plan, row_utt, out);
+  HIP_CHECK(hipGetLastError());
+}
+template void launch_shift3<float>(const float*, int, const UttPlan*, const int32_t*, int, float*, hipStream_t);
+template void launch_shift3<bf16_t>(const bf16_t*, int, const UttPlan*, const int32_t*, int, bf16_t*, hipStream_t);
+
+template <typename T>
+void launch_alpha(const T* h, int d, const float* w, const float* b, int rows, float* alpha, hipStream_t s) {
+  hipLaunchKernelGGL(alpha_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, h, d, w, b, rows, alpha);
+  HIP_CHECK(hipGetLastError());
+}
+template void launch_alpha<float>(const float*, int, const float*, const float*, int, float*, hipStream_t);
+template void launch_alpha<bf16_t>(const bf16_t*, int, const float*, const float*, int, float*, hipStream_t);
+
+void launch_cif_scan(const float* alpha, const float* enc_out, int d, const UttPlan* plan, int n_utts, float tail_threshold,
+                     float* acoustic, UttPlan* token_plan, int32_t* num_id, hipStream_t s) {
+  hipLaunchKernelGGL(cif_scan_kernel, dim3(n_utts), dim3(std::min(1024, (d + 63) / 64 * 64)), 0, s, alpha, enc_out, d, plan, tail_threshold,
+                     acoustic, token_plan, num_id);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_fsmn_rows(const float* x, const float* res, const float* w, int d, int ktaps, const UttPlan* token_plan,
+                      const int32_t* row_utt, int n_rows, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(fsmn_rows_kernel, dim3(n_rows), dim3(256), 0, s, x, res, w, d, ktaps, token_plan, row_utt, out);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_gather_tokens(const int32_t* ids, const UttPlan* token_plan, int n_utts, int32_t* token_ids, int max_tokens, hipStream_t s) {
+  hipLaunchKernelGGL(gather_tokens_kernel, dim3(n_utts), dim3(256), 0, s, ids, token_plan, token_ids, max_tokens);
   HIP_CHECK(hipGetLastError());
 }

@@ -20,7 +20,22 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct SvRunCtx;
 
+// Paraformer decoder block (Export_Paraformer.py:536-552): FFN (norm folded) -> LayerNorm -> FSMN + residual -> cross-attention
+struct PfDecLayer {
+  const void *w1, *w2, *wq, *wkv, *wo;
+  const float *b1, *b2, *n2_g, *n2_b, *wfsmn, *bq, *bkv, *bo;
+  bool full;     // false: FFN-only block (decoders3)
+};
+
 struct SvSession : asr_session {
+  bool paraformer = false;
+  asr_paraformer_config pcfg{};
+  std::vector<PfDecLayer> pdec;
+  const void *cif_conv_w = nullptr, *pf_out_w = nullptr;
+  const float *cif_conv_b = nullptr, *cif_out_w = nullptr, *cif_out_b = nullptr, *pf_out_b = nullptr;
+  DeviceBuffer d_enc_lo, d_ck, d_cifa, d_alpha, d_dec, d_x2, d_sa, d_ffn32, d_tplan;
+  template <typename T> void enqueue_paraformer_tail(const struct SvRunCtx& r);
+
   asr_sensevoice_config cfg;
   int feat = 0, kpad0 = 0, vpad = 0, max_lfr = 0;
   int n_bin_tiles = 0, n_kchunks = 0;
@@ -40,7 +55,8 @@ struct SvSession : asr_session {
 
   ~SvSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_x0, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx, &d_mem, &d_ffn,
-                            &d_amax_v, &d_amax_i, &d_ids, &d_tok, &d_num, &d_logits})
+                            &d_amax_v, &d_amax_i, &d_ids, &d_tok, &d_num, &d_logits, &d_enc_lo, &d_ck, &d_cifa, &d_alpha, &d_dec, &d_x2,
+                            &d_sa, &d_ffn32, &d_tplan})
       b->release();
     for (auto& kv : taps) kv.second.buf.release();
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -71,6 +87,9 @@ void SvSession::init() {
   ASR_REQUIRE(c.win_length == 400 && c.hop_length == 160, "sensevoice: front-end is built for 25 ms / 10 ms frames");
   ASR_REQUIRE(c.n_mels % 16 == 0, "sensevoice: n_mels must be a multiple of 16");
   ASR_REQUIRE(c.n_blocks >= 1 && c.n_main >= 1 && c.n_main <= c.n_blocks, "sensevoice: bad block counts");
+  auto opt = [&](const std::string& n, std::initializer_list<int64_t> sh) -> const float* {
+    return arena.has(n) ? (const float*)arena.get(n, ARENA_F32, sh).ptr : nullptr;
+  };
   feat = c.n_mels * c.lfr_m;
   kpad0 = round_up(feat, 64);
   vpad = round_up(c.vocab, 128);
@@ -83,33 +102,65 @@ void SvSession::init() {
 
   dft = (const float*)arena.get("fe.dft", ARENA_F32, {(int64_t)n_bin_tiles * 2 * n_kchunks * 64 * 4}).ptr;
   melp = (const float*)arena.get("fe.mel", ARENA_F32, {(int64_t)(c.n_mels / 16) * n_bin_tiles * 64 * 4}).ptr;
-  cmvn_means = (const float*)arena.get("fe.cmvn_means", ARENA_F32, {feat}).ptr;
+  cmvn_means = opt("fe.cmvn_means", {feat});
   cmvn_vars = (const float*)arena.get("fe.cmvn_vars", ARENA_F32, {feat}).ptr;
   speech_pos = (const float*)arena.get("fe.speech_pos", ARENA_F32, {max_lfr, feat}).ptr;
-  language_embed = (const float*)arena.get("fe.language_embed", ARENA_F32, {c.n_languages, feat}).ptr;
-  system_embed = (const float*)arena.get("fe.system_embed", ARENA_F32, {c.n_prompt - 1, feat}).ptr;
+  language_embed = c.n_prompt > 0 ? (const float*)arena.get("fe.language_embed", ARENA_F32, {c.n_languages, feat}).ptr : nullptr;
+  system_embed = c.n_prompt > 1 ? (const float*)arena.get("fe.system_embed", ARENA_F32, {c.n_prompt - 1, feat}).ptr : nullptr;
   after_g = (const float*)arena.get("after_norm_g", ARENA_F32, {d}).ptr;
   after_b = (const float*)arena.get("after_norm_b", ARENA_F32, {d}).ptr;
-  tp_g = (const float*)arena.get("tp_norm_g", ARENA_F32, {d}).ptr;
-  tp_b = (const float*)arena.get("tp_norm_b", ARENA_F32, {d}).ptr;
-  ctc_w = arena.get("ctc.w", wt, {vpad, d}).ptr;
-  ctc_b = (const float*)arena.get("ctc.b", ARENA_F32, {vpad}).ptr;
+  if (!paraformer) {
+    tp_g = (const float*)arena.get("tp_norm_g", ARENA_F32, {d}).ptr;
+    tp_b = (const float*)arena.get("tp_norm_b", ARENA_F32, {d}).ptr;
+    ctc_w = arena.get("ctc.w", wt, {vpad, d}).ptr;
+    ctc_b = (const float*)arena.get("ctc.b", ARENA_F32, {vpad}).ptr;
+  } else {
+    const int dd = pcfg.d_dec_ffn;
+    ASR_REQUIRE(dd % 128 == 0 && dd <= 2048 && (3 * d) % 64 == 0 && pcfg.cif_kernel == 3, "paraformer: unsupported decoder geometry");
+    cif_conv_w = arena.get("cif.conv_w", wt, {d, 3 * d}).ptr;
+    cif_conv_b = (const float*)arena.get("cif.conv_b", ARENA_F32, {d}).ptr;
+    cif_out_w = (const float*)arena.get("cif.out_w", ARENA_F32, {d}).ptr;
+    cif_out_b = (const float*)arena.get("cif.out_b", ARENA_F32, {1}).ptr;
+    pf_out_w = arena.get("out.w", wt, {vpad, d}).ptr;
+    pf_out_b = (const float*)arena.get("out.b", ARENA_F32, {vpad}).ptr;
+    pdec.resize(pcfg.n_dec + pcfg.n_dec3);
+    for (int j = 0; j < (int)pdec.size(); ++j) {
+      PfDecLayer& L = pdec[j];
+      const std::string q = "dec" + std::to_string(j) + ".";
+      L.full = j < pcfg.n_dec;
+      L.w1 = arena.get(q + "w1", wt, {dd, d}).ptr;
+      L.b1 = (const float*)arena.get(q + "b1", ARENA_F32, {dd}).ptr;
+      L.w2 = arena.get(q + "w2", wt, {d, dd}).ptr;
+      L.b2 = (const float*)arena.get(q + "b2", ARENA_F32, {d}).ptr;
+      if (L.full) {
+        L.n2_g = (const float*)arena.get(q + "n2_g", ARENA_F32, {d}).ptr;
+        L.n2_b = (const float*)arena.get(q + "n2_b", ARENA_F32, {d}).ptr;
+        L.wfsmn = (const float*)arena.get(q + "wfsmn", ARENA_F32, {d, c.fsmn_kernel}).ptr;
+        L.wq = arena.get(q + "wq", wt, {d, d}).ptr;
+        L.bq = (const float*)arena.get(q + "bq", ARENA_F32, {d}).ptr;
+        L.wkv = arena.get(q + "wkv", wt, {2 * d, d}).ptr;
+        L.bkv = (const float*)arena.get(q + "bkv", ARENA_F32, {2 * d}).ptr;
+        L.wo = arena.get(q + "wo", wt, {d, d}).ptr;
+        L.bo = (const float*)arena.get(q + "bo", ARENA_F32, {d}).ptr;
+      }
+    }
+  }
   blocks.resize(c.n_blocks);
   for (int i = 0; i < c.n_blocks; ++i) {
     SvBlock& b = blocks[i];
     const std::string p = "blk" + std::to_string(i) + ".";
-    b.in_size = (int)arena.get(p + "ln1_g").shape[0];
-    ASR_REQUIRE(b.in_size == d || b.in_size == feat, "sensevoice: block %d has input size %d", i, b.in_size);
-    b.kpad = round_up(b.in_size, 64);
-    b.ln1_g = (const float*)arena.get(p + "ln1_g", ARENA_F32, {b.in_size}).ptr;
-    b.ln1_b = (const float*)arena.get(p + "ln1_b", ARENA_F32, {b.in_size}).ptr;
+    b.kpad = (int)arena.get(p + "wqkv").shape[1];
+    b.in_size = b.kpad == d ? d : feat;
+    ASR_REQUIRE(b.kpad == round_up(b.in_size, 64), "sensevoice: block %d has K = %d", i, b.kpad);
+    b.ln1_g = opt(p + "ln1_g", {b.in_size});             // absent when the affine is folded into the Linear (Paraformer)
+    b.ln1_b = opt(p + "ln1_b", {b.in_size});
     b.wqkv = arena.get(p + "wqkv", wt, {3 * d, b.kpad}).ptr;
     b.bqkv = (const float*)arena.get(p + "bqkv", ARENA_F32, {3 * d}).ptr;
     b.wfsmn = (const float*)arena.get(p + "wfsmn", ARENA_F32, {d, c.fsmn_kernel}).ptr;
     b.bfsmn = (const float*)arena.get(p + "bfsmn", ARENA_F32, {d}).ptr;
     b.wout = arena.get(p + "wout", wt, {d, d}).ptr;
-    b.ln2_g = (const float*)arena.get(p + "ln2_g", ARENA_F32, {d}).ptr;
-    b.ln2_b = (const float*)arena.get(p + "ln2_b", ARENA_F32, {d}).ptr;
+    b.ln2_g = opt(p + "ln2_g", {d});
+    b.ln2_b = opt(p + "ln2_b", {d});
     b.w1 = arena.get(p + "w1", wt, {dff, d}).ptr;
     b.b1 = (const float*)arena.get(p + "b1", ARENA_F32, {dff}).ptr;
     b.w2 = arena.get(p + "w2", wt, {d, dff}).ptr;
@@ -148,7 +199,7 @@ void SvSession::enqueue(const SvRunCtx& r) {
     la.mel = d_mel.as<float>(); la.plan = r.dp; la.row_utt = r.d_row_utt; la.cmvn_means = cmvn_means; la.cmvn_vars = cmvn_vars;
     la.speech_pos = speech_pos; la.language_embed = language_embed; la.system_embed = system_embed;
     la.out = d_x0.as<float>(); la.ld_out = kpad0; la.feat = feat; la.n_mels = c.n_mels; la.lfr_m = c.lfr_m; la.lfr_n = c.lfr_n;
-    la.n_prompt = c.n_prompt; la.n_rows = Mpad;
+    la.n_prompt = c.n_prompt; la.n_rows = Mpad; la.affine_mode = paraformer ? 1 : 0;
     launch_lfr_cmvn(la, stream);
   }
   save_tap("enc_in", d_x0.ptr, rows, feat, kpad0, 4);
@@ -224,11 +275,12 @@ void SvSession::enqueue(const SvRunCtx& r) {
     x_in = xa;
     ld_in = d;
     if (i == 0) save_tap("block0", xa, rows, d, d, 4);
-    if (i == c.n_main - 1) {
+    if (i == c.n_main - 1 && !paraformer) {
       ProfScope ps(prof, "layernorm", stream);
       launch_layernorm<float>(xa, d, rows, d, after_g, after_b, 1e-5f, xa, d, d, stream);
     }
   }
+  if (paraformer) { enqueue_paraformer_tail<T>(r); return; }
   // tp_norm -> operand dtype for the CTC GEMM (f32 copy kept only for the tap)
   if (taps_enabled) {
     launch_layernorm<float>(xa, d, rows, d, tp_g, tp_b, 1e-5f, xb, d, d, stream);
@@ -262,12 +314,120 @@ void SvSession::enqueue(const SvRunCtx& r) {
                            hipMemcpyDeviceToHost, stream));
 }
 
+
+// ---- Paraformer: CIF predictor + non-autoregressive decoder (Export_Paraformer.py:497-563) ----------------------
+template <typename T>
+void SvSession::enqueue_paraformer_tail(const SvRunCtx& r) {
+  const auto& c = cfg;
+  const int d = c.d_model, dd = pcfg.d_dec_ffn, rows = r.rows, Mpad = r.Mpad, n_slabs = vpad / 64;
+  float* xa = d_xa.as<float>();
+  float* enc32 = d_xb.as<float>();                 // after_norm output, f32: CIF integrals
+  T* enc_lo = d_enc_lo.as<T>();                    // same in the operand dtype: GEMM input (predictor conv, cross-KV)
+  T* h = d_h.as<T>();
+  T* q = d_qk.as<T>();
+  T* ck = d_ck.as<T>();
+  T* cvt = d_vt.as<T>();
+  T* ctx = d_ctx.as<T>();
+  T* ffn = d_ffn.as<T>();
+  float* ffn32 = d_ffn32.as<float>();
+  float* x1 = d_mem.as<float>();
+  float* dec = d_dec.as<float>();
+  float* x2 = d_x2.as<float>();
+  float* sa = d_sa.as<float>();
+  UttPlan* tplan = d_tplan.as<UttPlan>();
+  {
+    ProfScope ps(prof, "layernorm", stream);
+    launch_layernorm<float>(xa, d, rows, d, after_g, after_b, 1e-5f, enc32, d, d, stream);
+    launch_layernorm<T>(xa, d, rows, d, after_g, after_b, 1e-5f, enc_lo, d, d, stream);
+  }
+  save_tap("enc_out", enc32, rows, d, d, 4);
+  {
+    ProfScope ps(prof, "cif", stream);
+    launch_shift3<T>(enc_lo, d, r.dp, r.d_row_utt, Mpad, d_cifa.as<T>(), stream);     // conv k=3 (pad folded) as one GEMM
+    GemmArgs g;
+    g.A = d_cifa.ptr; g.lda = 3 * d; g.W = cif_conv_w; g.ldw = 3 * d; g.M = rows; g.N = d; g.K = 3 * d; g.bias = cif_conv_b; g.act = ACT_RELU;
+    g.out_lo = ctx; g.ld_out_lo = d;
+    gemm(g);
+    launch_alpha<T>(ctx, d, cif_out_w, cif_out_b, rows, d_alpha.as<float>(), stream);
+    launch_cif_scan(d_alpha.as<float>(), enc32, d, r.dp, r.batch, pcfg.tail_threshold, dec, tplan, d_num.as<int32_t>(), stream);
+  }
+  save_tap("alphas", d_alpha.ptr, rows, 1, 1, 4);
+  auto ffn_block = [&](const PfDecLayer& L, float* out, const float* res) {
+    { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(dec, d, rows, d, nullptr, nullptr, 1e-5f, h, d, d, stream); }
+    ProfScope ps(prof, "gemm_dec", stream);
+    GemmArgs g;
+    g.A = h; g.lda = d; g.W = L.w1; g.ldw = d; g.M = rows; g.N = dd; g.K = d; g.bias = L.b1; g.act = ACT_RELU; g.out_f32 = ffn32; g.ld_out_f32 = dd;
+    gemm(g);
+    launch_layernorm<T>(ffn32, dd, rows, dd, nullptr, nullptr, 1e-5f, ffn, dd, dd, stream);   // ff.norm, affine folded into w_2
+    GemmArgs g2;
+    g2.A = ffn; g2.lda = dd; g2.W = L.w2; g2.ldw = dd; g2.M = rows; g2.N = d; g2.K = dd; g2.bias = L.b2; g2.out_f32 = out; g2.ld_out_f32 = d;
+    if (res) { g2.add = res; g2.ld_add = d; }
+    gemm(g2);
+  };
+  for (const PfDecLayer& L : pdec) {
+    if (!L.full) { ffn_block(L, dec, nullptr); continue; }           // decoders3: dec = FFN(dec), no residual (:553-555)
+    {
+      ProfScope ps(prof, "gemm_dec", stream);                        // this layer's cross K (row-major) and V (transposed) from the memory
+      GemmArgs gk;
+      gk.A = enc_lo; gk.lda = d; gk.W = L.wkv; gk.ldw = d; gk.M = rows; gk.N = d; gk.K = d; gk.bias = L.bkv; gk.out_lo = ck; gk.ld_out_lo = d;
+      gemm(gk);
+      GemmArgs gv;
+      gv.A = enc_lo; gv.lda = d; gv.W = (const T*)L.wkv + (size_t)d * d; gv.ldw = d; gv.M = rows; gv.N = d; gv.K = d; gv.bias = L.bkv + d;
+      gv.out_t = cvt; gv.ld_out_t = Mpad;
+      gemm(gv);
+    }
+    ffn_block(L, x1, nullptr);                                       // x = w_2(norm(relu(w_1(norm1(dec)))))
+    {
+      ProfScope ps(prof, "fsmn", stream);
+      launch_layernorm<float>(x1, d, rows, d, L.n2_g, L.n2_b, 1e-5f, sa, d, d, stream);
+      launch_fsmn_rows(sa, dec, L.wfsmn, d, c.fsmn_kernel, tplan, r.d_row_utt, Mpad, x2, stream);   // x = dec + fsmn(norm2(x))
+    }
+    { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(x2, d, rows, d, nullptr, nullptr, 1e-5f, h, d, d, stream); }
+    {
+      ProfScope ps(prof, "gemm_dec", stream);
+      GemmArgs g;
+      g.A = h; g.lda = d; g.W = L.wq; g.ldw = d; g.M = rows; g.N = d; g.K = d; g.bias = L.bq; g.out_lo = q; g.ld_out_lo = d;
+      gemm(g);
+    }
+    {
+      ProfScope ps(prof, "attention", stream);
+      AttnArgs aa;
+      aa.q = q; aa.ld_q = d; aa.k = ck; aa.ld_qk = d; aa.vt = cvt; aa.ld_vt = Mpad; aa.ctx = ctx; aa.ld_ctx = d;
+      aa.plan = r.dp; aa.q_plan = tplan; aa.qb_utt = r.d_qb_utt; aa.qb_q0 = r.d_qb_q0; aa.n_qblocks = r.n_qb; aa.n_heads = c.n_heads;
+      aa.qt = r.att_qt; aa.n_waves = r.att_nw; aa.max_T = r.max_T;
+      if (precision == ASR_PRECISION_BF16) launch_attention_bf16_hd128(aa, stream);
+      else launch_attention_f32(aa, c.d_head, stream);
+    }
+    {
+      ProfScope ps(prof, "gemm_dec", stream);
+      GemmArgs g;
+      g.A = ctx; g.lda = d; g.W = L.wo; g.ldw = d; g.M = rows; g.N = d; g.K = d; g.bias = L.bo; g.add = x2; g.ld_add = d; g.out_f32 = dec; g.ld_out_f32 = d;
+      gemm(g);
+    }
+  }
+  { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(dec, d, rows, d, nullptr, nullptr, 1e-5f, h, d, d, stream); }
+  {
+    ProfScope ps(prof, "gemm_out", stream);
+    GemmArgs g;
+    g.A = h; g.lda = d; g.W = pf_out_w; g.ldw = d; g.M = rows; g.N = vpad; g.K = d; g.bias = pf_out_b;
+    g.amax_val = d_amax_v.as<float>(); g.amax_idx = d_amax_i.as<int32_t>(); g.n_valid = c.vocab;
+    if (taps_enabled) { g.out_f32 = d_logits.as<float>(); g.ld_out_f32 = vpad; }
+    gemm(g);
+    launch_argmax_reduce(d_amax_v.as<float>(), d_amax_i.as<int32_t>(), rows, n_slabs, d_ids.as<int32_t>(), stream);
+    launch_gather_tokens(d_ids.as<int32_t>(), tplan, r.batch, d_tok.as<int32_t>(), r.max_tokens, stream);
+  }
+  if (taps_enabled) save_tap("logits", d_logits.ptr, rows, c.vocab, vpad, 4);
+  HIP_CHECK(hipMemcpyAsync(h_out, d_tok.ptr, (size_t)r.batch * r.max_tokens * 4, hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipMemcpyAsync((unsigned char*)h_out + (size_t)r.batch * r.max_tokens * 4, d_num.ptr, (size_t)r.batch * 4,
+                           hipMemcpyDeviceToHost, stream));
+}
+
 template <typename T>
 void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int batch, const int32_t* lang, int32_t* tok_out,
                     int max_tokens, int32_t* num_out) {
   const auto& c = cfg;
   ASR_REQUIRE(batch > 0, "sensevoice: empty batch");
-  ASR_REQUIRE(audio && offs && lang && tok_out && num_out, "sensevoice: null argument");
+  ASR_REQUIRE(audio && offs && (lang || paraformer) && tok_out && num_out, "sensevoice: null argument");
   HIP_CHECK(hipSetDevice(device));
   const int d = c.d_model, dff = c.d_ffn;
 
@@ -282,7 +442,7 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
     const int64_t n = offs[b + 1] - offs[b];
     ASR_REQUIRE(n >= c.win_length, "sensevoice: utterance %d has %lld samples (< one %d-sample frame)", b, (long long)n, c.win_length);
     ASR_REQUIRE(n <= c.max_audio_len, "sensevoice: utterance %d has %lld samples (> max_audio_len %d)", b, (long long)n, c.max_audio_len);
-    ASR_REQUIRE(lang[b] >= 0 && lang[b] < c.n_languages, "sensevoice: language_idx %d out of range", lang[b]);
+    ASR_REQUIRE(paraformer || (lang[b] >= 0 && lang[b] < c.n_languages), "sensevoice: language_idx %d out of range", lang[b]);
     UttPlan& p = plan[b];
     p.audio_off = offs[b] - base0;
     p.n_samples = (int)n;
@@ -291,7 +451,7 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
     p.n_lfr = (p.n_frames + c.lfr_n - 1) / c.lfr_n;
     p.T = p.n_lfr + c.n_prompt;
     p.row_off = rows;
-    p.lang = lang[b];
+    p.lang = lang ? lang[b] : 0;
     p.blk0 = n_fb;
     frames += p.n_frames;
     rows += round_up(p.T, 16);
@@ -353,6 +513,19 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   grow(d_tok, (size_t)batch * max_tokens * 4);
   grow(d_num, (size_t)batch * 4);
   if (taps_enabled) grow(d_logits, (size_t)Mpad * vpad * 4);
+  if (paraformer) {
+    const int dd = pcfg.d_dec_ffn;
+    grow(d_enc_lo, (size_t)Mpad * d * eT);
+    grow(d_ck, (size_t)Mpad * d * eT);
+    grow(d_cifa, (size_t)Mpad * 3 * d * eT);
+    grow(d_alpha, (size_t)Mpad * 4);
+    grow(d_dec, (size_t)Mpad * d * 4);
+    grow(d_x2, (size_t)Mpad * d * 4);
+    grow(d_sa, (size_t)Mpad * d * 4);
+    grow(d_ffn32, (size_t)Mpad * dd * 4);
+    grow(d_ffn, (size_t)Mpad * std::max(dd, dff) * eT);
+    grow(d_tplan, sizeof(UttPlan) * batch);
+  }
   const size_t out_bytes = (size_t)batch * max_tokens * 4 + (size_t)batch * 4;
   if (out_bytes > h_out_cap) {
     if (h_out) HIP_CHECK(hipHostFree(h_out));
@@ -458,5 +631,49 @@ extern "C" int asr_sensevoice_seq_len(const asr_sensevoice_config* cfg, int n_sa
     ASR_REQUIRE(n_samples >= cfg->win_length, "seq_len: fewer samples than one frame");
     const int frames = (n_samples - cfg->win_length) / cfg->hop_length + 1;
     *seq_len = (frames + cfg->lfr_n - 1) / cfg->lfr_n + cfg->n_prompt;
+  });
+}
+
+extern "C" int asr_paraformer_create(const asr_paraformer_config* cfg, const void* arena, size_t arena_bytes, int arena_mem,
+                                     int device_id, int precision, asr_session** out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(cfg && arena && out, "paraformer_create: null argument");
+    ASR_REQUIRE(precision == ASR_PRECISION_BF16 || precision == ASR_PRECISION_F32, "paraformer_create: bad precision %d", precision);
+    asr_require_device(device_id);
+    SvSession* s = new SvSession();
+    try {
+      s->kind = 3;
+      s->device = device_id;
+      s->precision = precision;
+      s->paraformer = true;
+      s->pcfg = *cfg;
+      asr_sensevoice_config& c = s->cfg;
+      memset(&c, 0, sizeof(c));
+      c.sample_rate = cfg->sample_rate; c.n_mels = cfg->n_mels; c.nfft = cfg->nfft; c.win_length = cfg->win_length; c.hop_length = cfg->hop_length;
+      c.lfr_m = cfg->lfr_m; c.lfr_n = cfg->lfr_n; c.d_model = cfg->d_model; c.n_heads = cfg->n_heads; c.d_head = cfg->d_head; c.d_ffn = cfg->d_ffn;
+      c.n_blocks = cfg->n_blocks; c.n_main = cfg->n_blocks; c.fsmn_kernel = cfg->fsmn_kernel; c.vocab = cfg->vocab; c.blank_id = -1;
+      c.n_prompt = 0; c.n_languages = 0; c.max_audio_len = cfg->max_audio_len;
+      if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
+      HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+      s->own_stream = true;
+      s->arena.load(arena, arena_bytes, arena_mem, s->stream);
+      s->init();
+    } catch (...) {
+      delete s;
+      throw;
+    }
+    *out = s;
+  });
+}
+
+extern "C" int asr_paraformer_run(asr_session* s, const float* audio, int audio_mem, const int64_t* audio_offsets, int batch,
+                                  int32_t* token_ids_out, int max_tokens, int32_t* num_id_out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 3, "paraformer_run: not a Paraformer session");
+    SvSession* sv = static_cast<SvSession*>(s);
+    if (sv->precision == ASR_PRECISION_BF16)
+      sv->run<bf16_t>(audio, audio_mem, audio_offsets, batch, nullptr, token_ids_out, max_tokens, num_id_out);
+    else
+      sv->run<float>(audio, audio_mem, audio_offsets, batch, nullptr, token_ids_out, max_tokens, num_id_out);
   });
 }

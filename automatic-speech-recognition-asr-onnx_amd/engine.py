@@ -303,3 +303,63 @@ class WhisperSession(_Session):
             out.append((slabs[0, :, :, r:r + t], slabs[1, :, :, r:r + t]))
             r += (t + 1 + 15) // 16 * 16
         return out
+
+
+# =============================================================================== Paraformer
+class ParaformerSession(_Session):
+    """HIP replacement of `Paraformer.onnx` (PARAFORMER.forward, Export_Paraformer.py:474-563)."""
+
+    def __init__(self, cfg, arena, precision: int = PRECISION_BF16, device_id: int = 0, arena_device_ptr: int | None = None,
+                 arena_bytes: int | None = None):
+        super().__init__()
+        self.cfg, self.precision, self.device_id = cfg, precision, device_id
+        c = _lib.ParaformerConfigC()
+        for f in ("sample_rate", "n_mels", "nfft", "win_length", "hop_length", "lfr_m", "lfr_n", "d_model", "n_heads", "d_head", "d_ffn",
+                  "fsmn_kernel", "n_dec", "n_dec3", "d_dec_ffn", "cif_kernel", "vocab", "max_audio_len"):
+            setattr(c, f, getattr(cfg, f))
+        c.n_blocks = cfg.n_enc0 + cfg.n_enc
+        c.tail_threshold = cfg.tail_threshold
+        self._cfg_c = c
+        lib = _lib.load()
+        if arena_device_ptr is not None:
+            self._keep = arena
+            _lib.check(lib.asr_paraformer_create(C.byref(c), C.c_void_p(arena_device_ptr), arena_bytes, MEM_DEVICE, device_id, precision,
+                                                 C.byref(self._h)))
+        else:
+            blob = np.ascontiguousarray(arena, dtype=np.uint8)
+            _lib.check(lib.asr_paraformer_create(C.byref(c), blob.ctypes.data_as(C.c_void_p), blob.nbytes, MEM_HOST, device_id, precision,
+                                                 C.byref(self._h)))
+
+    @classmethod
+    def from_checkpoint(cls, cfg, ck, precision=PRECISION_BF16, device_id=0):
+        from .arena import build_paraformer_arena
+        return cls(cfg, build_paraformer_arena(cfg, ck, precision), precision, device_id)
+
+    def run_packed(self, audio, offsets, audio_device_ptr: int | None = None):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        B = offsets.size - 1
+        max_t = max(self.cfg.seq_len(int(n)) for n in np.diff(offsets)) if B else 1
+        tok = np.zeros((B, max_t), dtype=np.int32)
+        num = np.zeros((B,), dtype=np.int32)
+        if audio_device_ptr is not None:
+            ap, mem = C.c_void_p(audio_device_ptr), MEM_DEVICE
+        else:
+            audio = _f32(audio).reshape(-1)
+            ap, mem = audio.ctypes.data_as(C.c_void_p), MEM_HOST
+        _lib.check(_lib.load().asr_paraformer_run(self._h, ap, mem, offsets.ctypes.data_as(C.POINTER(C.c_int64)), B, _ip(tok), max_t, _ip(num)))
+        return tok, num
+
+    def run(self, audios: Sequence[np.ndarray]):
+        flat = [_f32(a).reshape(-1) for a in audios]
+        offs = np.zeros(len(flat) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([a.size for a in flat])
+        tok, num = self.run_packed(np.concatenate(flat), offs)
+        return [tok[b, :num[b]].copy() for b in range(len(flat))]
+
+    def utterance_rows(self, lengths: Sequence[int]):
+        out, r = [], 0
+        for n in lengths:
+            t = self.cfg.seq_len(int(n))
+            out.append((r, t))
+            r += (t + 15) // 16 * 16
+        return out

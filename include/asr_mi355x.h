@@ -91,6 +91,24 @@ int asr_sensevoice_run(asr_session* s, const float* audio, int audio_mem, const 
 /* sequence length (prompt + LFR rows) the graph produces for an utterance of n_samples */
 int asr_sensevoice_seq_len(const asr_sensevoice_config* cfg, int n_samples, int* seq_len);
 
+/* ------------------------------------------------------------------ Paraformer (non-streaming, CIF + NAR decoder)
+ * Replaces Paraformer.onnx == PARAFORMER.forward (Paraformer/Non-Streaming/Export_Paraformer.py:474-563).
+ * Graph I/O it mirrors (:600-606): audio (1,1,audio_len) f32 int16-range -> token_ids (1,num_token) i32, num_id (1,) i32. */
+typedef struct asr_paraformer_config {
+  int32_t sample_rate, n_mels, nfft, win_length, hop_length, lfr_m, lfr_n;
+  int32_t d_model, n_heads, d_head, d_ffn, n_blocks, fsmn_kernel;
+  int32_t n_dec, n_dec3, d_dec_ffn, cif_kernel, vocab, max_audio_len;
+  float tail_threshold;
+  int32_t reserved[8];
+} asr_paraformer_config;
+
+int asr_paraformer_create(const asr_paraformer_config* cfg, const void* arena, size_t arena_bytes, int arena_mem, int device_id,
+                          int precision, asr_session** out);
+/* same calling convention as asr_sensevoice_run (no language input): token_ids_out host [B][max_tokens], num_id_out host [B]
+ * (num_id is the CIF fire count; an utterance can legitimately yield zero tokens). */
+int asr_paraformer_run(asr_session* s, const float* audio, int audio_mem, const int64_t* audio_offsets, int batch,
+                       int32_t* token_ids_out, int max_tokens, int32_t* num_id_out);
+
 /* ------------------------------------------------------------------ Whisper (encoder + KV-cache decoder)
  * Replaces the merged graphs Whisper_ProbePrefillGreedy / Whisper_PrefillGreedy / Whisper_DecodeGreedy
  * (Whisper/Shared_Merged.py:864-888; I/O planner Whisper/Inference_Whisper_ONNX.py:323-392), i.e.

@@ -29,7 +29,7 @@ from typing import Any, Sequence
 import numpy as np
 
 from . import _lib
-from .config import SenseVoiceConfig
+from .config import ParaformerConfig, SenseVoiceConfig
 
 MAGIC = b"ASRMODEL"
 _ORT_TYPES = {np.dtype(np.float32): "tensor(float)", np.dtype(np.float16): "tensor(float16)", np.dtype(np.int16): "tensor(int16)",
@@ -263,6 +263,12 @@ class InferenceSession:
             self._native = SenseVoiceSession(self._cfg, blob, info["precision"], device_id)
             self._inputs = [NodeArg("audio", [1, 1, "audio_len"], np.float32), NodeArg("language_idx", [1], np.int32)]
             self._outputs = [NodeArg("token_ids", ["num_token"], np.int32), NodeArg("num_id", [1], np.int32)]
+        elif self._kind == "paraformer":
+            from .engine import ParaformerSession
+            self._cfg = ParaformerConfig(**info["config"])
+            self._native = ParaformerSession(self._cfg, blob, info["precision"], device_id)
+            self._inputs = [NodeArg("audio", [1, 1, "audio_len"], np.float32)]
+            self._outputs = [NodeArg("token_ids", [1, "num_token"], np.int32), NodeArg("num_id", [1], np.int32)]
         else:
             raise ValueError(f"unknown model kind {self._kind!r}")
         self._input_names = [a.name for a in self._inputs]
@@ -308,9 +314,30 @@ class InferenceSession:
             return {"token_ids": tok[0, :num[0]].copy(), "num_id": num.copy()}
         return {"token_ids": tok, "num_id": num}
 
+    def _run_paraformer(self, feeds: dict[str, OrtValue]) -> dict[str, np.ndarray]:
+        if "audio" not in feeds:
+            raise ValueError("input 'audio' is not bound")
+        audio = feeds["audio"]
+        shape = tuple(audio._shape)
+        if len(shape) != 3 or shape[1] != 1:
+            raise ValueError(f"audio must have shape (batch, 1, audio_len), got {shape}")
+        if np.dtype(audio._dtype) != np.float32:
+            raise ValueError(f"audio must be tensor(float) carrying int16-range values, got {audio._dtype}")
+        B, L = shape[0], shape[2]
+        offsets = np.arange(B + 1, dtype=np.int64) * L
+        if audio._host is not None:
+            tok, num = self._native.run_packed(audio._host.reshape(-1), offsets)
+        else:
+            tok, num = self._native.run_packed(None, offsets, audio_device_ptr=audio._dptr.value)
+        if B == 1:        # the reference graph's exact output shapes: token_ids (1, num_token), num_id (1,)
+            return {"token_ids": tok[:, :num[0]].copy(), "num_id": num.copy()}
+        return {"token_ids": tok, "num_id": num}
+
     def _execute(self, feeds: dict[str, OrtValue]) -> dict[str, np.ndarray]:
         if self._kind == "sensevoice":
             return self._run_sensevoice(feeds)
+        if self._kind == "paraformer":
+            return self._run_paraformer(feeds)
         if self._kind == "metadata":
             return {"metadata_marker_out": np.asarray(feeds["metadata_marker"].numpy())}
         raise ValueError(self._kind)

@@ -92,12 +92,14 @@ def main():
     ap.add_argument("--seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
-    ap.add_argument("--workload", choices=("sensevoice", "whisper"), default="sensevoice",
+    ap.add_argument("--workload", choices=("sensevoice", "whisper", "paraformer"), default="sensevoice",
                     help="sensevoice = BASELINE.json configs[1] (default, the headline line); whisper = large-v3 encoder + greedy decode")
     ap.add_argument("--decode-tokens", type=int, default=0, help="whisper: generated tokens per utterance (default 4 per audio second)")
     args = ap.parse_args()
     if args.workload == "whisper":
         return main_whisper(args)
+    if args.workload == "paraformer":
+        return main_paraformer(args)
 
     import torch
     import torch.distributed as dist
@@ -216,6 +218,120 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ck, audio_np)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def paraformer_algorithmic_flops(cfg, n_samples, n_tokens):
+    """GEMM = 2MNK on un-padded rows, attention = 4 T_q T_k d; encoder as SenseVoice, decoder over `n_tokens` fired tokens."""
+    d, dff, dd, feat = cfg.d_model, cfg.d_ffn, cfg.d_dec_ffn, cfg.feat_dim
+    T, nb = cfg.seq_len(n_samples), cfg.n_enc0 + cfg.n_enc
+    enc = 2.0 * T * (3 * d * (feat * cfg.n_enc0 + d * cfg.n_enc) + nb * (d * d + 2 * d * dff)) + 4.0 * T * T * d * nb
+    cif = 2.0 * T * d * 3 * d
+    N = n_tokens
+    dec = cfg.n_dec * (2.0 * T * d * 2 * d + 2.0 * N * (2 * d * dd + 2 * d * d) + 4.0 * N * T * d) + cfg.n_dec3 * 2.0 * N * 2 * d * dd
+    return enc + cif + dec + 2.0 * N * d * cfg.vocab
+
+
+def main_paraformer(args):
+    """Paraformer-large (non-streaming) bf16, batch x 8 s: fbank -> 50 SANM blocks -> CIF -> 16+1 decoder layers -> ids."""
+    import torch
+    import torch.distributed as dist
+    cfgm = importlib.import_module(PKG + ".config")
+    ckm = importlib.import_module(PKG + ".checkpoints")
+    arena = importlib.import_module(PKG + ".arena")
+    eng = importlib.import_module(PKG + ".engine")
+    dp = importlib.import_module(PKG + ".dist")
+    rank, local_rank, world = dp.init_from_env()
+    assert world == args.gpus and torch.cuda.is_available()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    cfg = cfgm.paraformer_large()
+    n_samples, B = int(args.seconds * cfg.sample_rate), args.batch
+    ck = blob = None
+    if rank == 0:
+        ck = ckm.synth_paraformer_checkpoint(cfg, seed=0)
+        blob = arena.build_paraformer_arena(cfg, ck, arena.PRECISION_BF16)
+    arena_dev = dp.broadcast_arena(blob, device)
+    sess = eng.ParaformerSession(cfg, arena_dev, arena.PRECISION_BF16, local_rank, arena_device_ptr=arena_dev.data_ptr(),
+                                 arena_bytes=arena_dev.numel())
+    audio_np = ckm.synth_audio("kaldi", B, n_samples, seed=1234 + rank)
+    audio_dev = torch.from_numpy(audio_np).to(device)
+    offsets = np.arange(B + 1, dtype=np.int64) * n_samples
+    max_t = cfg.seq_len(n_samples)
+
+    def step():
+        tok, num = sess.run_packed(None, offsets, audio_device_ptr=audio_dev.data_ptr())
+        if world > 1:
+            dp.gather_hypotheses(dp.pack_hypotheses(tok, num, max_t), device)
+        return tok, num
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tok, num = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    sess.profile(True)
+    sess.profile_reset()
+    for _ in range(args.profile_steps):
+        sess.run_packed(None, offsets, audio_device_ptr=audio_dev.data_ptr())
+    prof = sess.profile_read()
+    sess.profile(False)
+    if rank == 0:
+        audio_s = world * B * n_samples / cfg.sample_rate
+        ms = elapsed / args.steps * 1e3
+        flops = sum(paraformer_algorithmic_flops(cfg, n_samples, int(n)) for n in num)
+        kernels = {k: {"ms_per_step": round(v["total_ms"] / args.profile_steps, 4), "launches_per_step": v["launches"] // args.profile_steps}
+                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+        gemm_ms = sum(v["ms_per_step"] for k, v in kernels.items() if k.startswith("gemm_"))
+        T, nb, d = cfg.seq_len(n_samples), cfg.n_enc0 + cfg.n_enc, cfg.d_model
+        enc_gemm = B * 2.0 * T * (3 * d * (cfg.feat_dim * cfg.n_enc0 + d * cfg.n_enc) + nb * (d * d + 2 * d * cfg.d_ffn))
+        enc_ms = sum(kernels[k]["ms_per_step"] for k in ("gemm_qkv", "gemm_ffn1", "gemm_ffn2") if k in kernels)
+        enc_ms += kernels.get("gemm_out", {"ms_per_step": 0})["ms_per_step"]
+        ach = enc_gemm / (enc_ms * 1e-3) / 1e12 if enc_ms else 0.0
+        out = {"metric": "audio-sec/s, Paraformer-large (non-streaming), 8 s @ 16 kHz chunks, batch %d per GPU" % B,
+               "value": round(audio_s * args.steps / elapsed, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "Paraformer-large bf16 (50 SANM blocks, CIF predictor, 16+1 decoder layers, vocab 8404), batch=%d x %g s "
+                                      "per GPU, audio resident in HBM, token ids returned to host" % (B, args.seconds),
+                          "global_batch": world * B, "audio_seconds_per_step": audio_s, "tokens_per_step": int(np.sum(num)),
+                          "parallelism": f"dp{world}"},
+               "rtf": round(elapsed / (audio_s * args.steps), 8),
+               "model_tflops_per_gpu": round(flops / (ms * 1e-3) / 1e12, 1),
+               "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pipe (encoder qkv/out/ffn launches; the out class also holds the vocab GEMM)",
+                            "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "gemm_ms_per_step": round(gemm_ms, 3)},
+               "kernels": kernels}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.paraformer_oracle import ParaformerOracle
+            orc = ParaformerOracle(cfg, ck)
+            torch.set_num_threads(min(16, os.cpu_count() or 8))
+            orc(audio_np[0, 0])
+            n_done, t1 = 0, time.perf_counter()
+            while True:
+                orc(audio_np[n_done % B, 0])
+                n_done += 1
+                el = time.perf_counter() - t1
+                if (el >= 10.0 and n_done >= 4) or n_done >= 64:
+                    break
+            out["cpu_baseline"] = {"value": round(n_done * args.seconds / el, 2), "unit": "audio-s/s", "cores": int(torch.get_num_threads()),
+                                   "kind": "port", "sample": f"{n_done} x {args.seconds:g} s utterances, batch 1, torch-CPU f32 oracle "
+                                   f"(oracle/paraformer_oracle.py), {el:.1f} s wall"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

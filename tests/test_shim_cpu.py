@@ -131,3 +131,11 @@ def test_prepare_audio_and_window_plan():
     assert sv.plan_windows(x, 25, 10, 10).shape[-1] == 30      # ceil((25-10)/10)+1 = 3 windows
     assert sv.plan_windows(x, 25, 40, 40).shape[-1] == 40
     assert sv.plan_windows(x, 25, 25, 25).shape[-1] == 25
+
+
+def test_paraformer_decode_modes():
+    pf = sub("paraformer")
+    assert pf.decode_tokens(["hel@@", "lo", "wor@@", "ld"], "en") == "hello world"
+    assert pf.decode_tokens(["你", "好"], "zh") == "你好"
+    sp, langs = pf.build_tokenizer_metadata(["<blank>", "<s>", "</s>", "a", "<unk>"], "en", "en")
+    assert sp == {"blank": 0, "eos": 2, "stop": [2], "unknown": 4, "bos": 1} and langs["en"]["decode_mode"] == "en"

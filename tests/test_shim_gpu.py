@@ -59,3 +59,43 @@ def test_session_io_contract_and_batch_extension(model_folder):
     b._iobinding.bind_output("token_ids", None)
     with pytest.raises(ValueError, match="not bound"):
         sess.run_with_iobinding(b)
+
+
+# ------------------------------------------------------------------------------------------ Paraformer
+def _vocab(n):
+    toks = [f"t{i}" for i in range(n)]
+    toks[0], toks[1], toks[2], toks[n - 1] = "<blank>", "<s>", "</s>", "<unk>"
+    return toks
+
+
+@pytest.mark.parametrize("device_type", ["cpu", "cuda"])
+def test_paraformer_transcriber_matches_goldens(tmp_path, device_type):
+    from test_oracle_paraformer import paraformer_setup
+    g = load_golden("paraformer_tiny")
+    cfg, ck = paraformer_setup("paraformer_tiny")
+    pf = sub("paraformer")
+    vocab = _vocab(cfg.vocab)
+    pf.export_paraformer(str(tmp_path), cfg, ck, vocab, "zh", "zh", precision=1)
+    tr = pf.ParaformerTranscriber(str(tmp_path), device_type=device_type)
+    assert tr.stop_token_ids == [2] and tr.decode_mode == "zh" and tr.language == "zh"
+    sess = tr.session
+    assert [(a.name, a.type, a.shape) for a in sess.get_inputs()] == [("audio", "tensor(float)", [1, 1, "audio_len"])]
+    assert [(a.name, a.shape) for a in sess.get_outputs()] == [("token_ids", [1, "num_token"]), ("num_id", [1])]
+    checked = 0
+    for _, c in golden_cases(g):
+        pcm = kaldi_audio(c["audio_seed"], c["n_samples"]).astype(np.int16)
+        out = tr.transcribe(pcm)
+        assert out["windows"] == 1
+        if c["cif_slack"] > 2e-4 and int(c["num_id"][0]) and (c["margin"] > 2e-3).all():
+            ids = np.asarray(c["token_ids"]).reshape(-1)
+            keep = ids[~np.isin(ids, [2])]
+            assert np.array_equal(out["token_ids"][0], keep)
+            assert out["text"] == "".join(vocab[i] for i in keep)
+            checked += 1
+    assert checked >= 1
+    # raw graph contract: (1, num_token) ids and (1,) count; batch extension pads to the longest
+    a = kaldi_audio(5, 16000)
+    tok, num = sess.run(None, {"audio": a.reshape(1, 1, -1)})
+    assert tok.ndim == 2 and tok.shape == (1, int(num[0])) and tok.dtype == np.int32
+    tb, nb = sess.run(None, {"audio": np.stack([a, a])[:, None, :]})
+    assert np.array_equal(tb[0, :nb[0]], tok[0]) and np.array_equal(tb[1, :nb[1]], tok[0])

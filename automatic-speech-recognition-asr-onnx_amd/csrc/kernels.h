@@ -125,6 +125,22 @@ void launch_attention_bf16_hd128(const AttnArgs& a, hipStream_t s);
 void launch_attention_bf16_hd64(const AttnArgs& a, hipStream_t s);
 void launch_attention_f32(const AttnArgs& a, int head_dim, hipStream_t s);
 
+// ---- fused SANM attention half for windows of <= 144 rows (sanm_fused.hip): per (utterance, head) workgroup
+// q|k|v projection -> attention -> FSMN, intermediates in LDS. h: [rows][ld_h] operand-dtype LayerNorm output;
+// wqkv: [3 d][ldw] (q rows, k rows, v rows); ctx: bf16 [rows][ld_ctx]; mem: f32 [rows][ld_mem] (rows < T16 written).
+struct SanmFusedArgs {
+  const void* h; int ld_h; int K;
+  const void* wqkv; int ldw;
+  const float* bqkv;
+  const float* wfsmn; const float* bfsmn;
+  const UttPlan* plan; int n_utts, n_heads, d;
+  void* ctx; int ld_ctx;
+  float* mem; int ld_mem;
+  int n_rows_alloc;            // rows of h that may be read (rows past an utterance's end are read but never used)
+};
+bool sanm_fused_supported(int max_T, int d_head, int n_heads, int d, int fsmn_taps, int K);
+void launch_sanm_qkv_attn(const SanmFusedArgs& a, hipStream_t s);
+
 // ---- FSMN memory: depth-wise conv (k taps, zero padded inside each utterance) over V + bias.
 // vt: [C][ld] time-contiguous (all rows of the padded packed layout); out: f32 row-major [n_rows_pad][ld_out]
 // (Export_SenseVoice.py:217-220,240-244). n_rows_pad is a multiple of 64 (pad rows are written as zeros).

@@ -69,6 +69,7 @@ struct SvSession : asr_session {
 
   // hipGraph replay of the forward pass (one graph per batch geometry)
   bool use_graph = true;
+  bool use_fused = true;        // fused q|k|v + attention + FSMN kernel for windows of <= 144 rows (ASR_SANM_FUSED=0 disables)
   hipGraphExec_t graph_exec = nullptr;
   uint64_t graph_key = 0, eager_key = 0, ws_epoch = 1;
 
@@ -221,29 +222,40 @@ void SvSession::enqueue(const SvRunCtx& r) {
       ProfScope ps(prof, "layernorm", stream);
       launch_layernorm<T>(x_in, ld_in, rows, b.in_size, b.ln1_g, b.ln1_b, 1e-5f, h, b.kpad, b.kpad, stream);
     }
-    {
-      ProfScope ps(prof, "gemm_qkv", stream);
-      GemmArgs g;                               // q | k, row-major
-      g.A = h; g.lda = b.kpad; g.W = b.wqkv; g.ldw = b.kpad; g.M = rows; g.N = 2 * d; g.K = b.kpad; g.bias = b.bqkv;
-      g.out_lo = qk; g.ld_out_lo = 2 * d;
-      gemm(g);
-      GemmArgs gv;                              // v, stored transposed (time-contiguous) for the P.V operand and the FSMN
-      gv.A = h; gv.lda = b.kpad; gv.W = (const T*)b.wqkv + (size_t)2 * d * b.kpad; gv.ldw = b.kpad; gv.M = rows; gv.N = d;
-      gv.K = b.kpad; gv.bias = b.bqkv + 2 * d; gv.out_t = vt; gv.ld_out_t = Mpad;
-      gemm(gv);
-    }
-    {
-      ProfScope ps(prof, "fsmn", stream);
-      launch_fsmn<T>(vt, Mpad, b.wfsmn, b.bfsmn, d, c.fsmn_kernel, r.dp, r.d_row_utt, Mpad, mem, d, stream);
-    }
-    {
-      ProfScope ps(prof, "attention", stream);
-      AttnArgs aa;
-      aa.q = qk; aa.k = qk + d; aa.ld_qk = 2 * d; aa.vt = vt; aa.ld_vt = Mpad; aa.ctx = ctx; aa.ld_ctx = d;
-      aa.plan = r.dp; aa.qb_utt = r.d_qb_utt; aa.qb_q0 = r.d_qb_q0; aa.n_qblocks = r.n_qb; aa.n_heads = c.n_heads;
-      aa.qt = r.att_qt; aa.n_waves = r.att_nw; aa.max_T = r.max_T;
-      if (precision == ASR_PRECISION_BF16) launch_attention_bf16_hd128(aa, stream);
-      else launch_attention_f32(aa, c.d_head, stream);
+    const bool fused = use_fused && precision == ASR_PRECISION_BF16 &&
+                       sanm_fused_supported(r.max_T, c.d_head, c.n_heads, d, c.fsmn_kernel, b.kpad);
+    if (fused) {
+      ProfScope ps(prof, "sanm_fused", stream);
+      SanmFusedArgs fa;
+      fa.h = h; fa.ld_h = b.kpad; fa.K = b.kpad; fa.wqkv = b.wqkv; fa.ldw = b.kpad; fa.bqkv = b.bqkv;
+      fa.wfsmn = b.wfsmn; fa.bfsmn = b.bfsmn; fa.plan = r.dp; fa.n_utts = r.batch; fa.n_heads = c.n_heads; fa.d = d;
+      fa.ctx = ctx; fa.ld_ctx = d; fa.mem = mem; fa.ld_mem = d; fa.n_rows_alloc = Mpad;
+      launch_sanm_qkv_attn(fa, stream);
+    } else {
+      {
+        ProfScope ps(prof, "gemm_qkv", stream);
+        GemmArgs g;                               // q | k, row-major
+        g.A = h; g.lda = b.kpad; g.W = b.wqkv; g.ldw = b.kpad; g.M = rows; g.N = 2 * d; g.K = b.kpad; g.bias = b.bqkv;
+        g.out_lo = qk; g.ld_out_lo = 2 * d;
+        gemm(g);
+        GemmArgs gv;                              // v, stored transposed (time-contiguous) for the P.V operand and the FSMN
+        gv.A = h; gv.lda = b.kpad; gv.W = (const T*)b.wqkv + (size_t)2 * d * b.kpad; gv.ldw = b.kpad; gv.M = rows; gv.N = d;
+        gv.K = b.kpad; gv.bias = b.bqkv + 2 * d; gv.out_t = vt; gv.ld_out_t = Mpad;
+        gemm(gv);
+      }
+      {
+        ProfScope ps(prof, "fsmn", stream);
+        launch_fsmn<T>(vt, Mpad, b.wfsmn, b.bfsmn, d, c.fsmn_kernel, r.dp, r.d_row_utt, Mpad, mem, d, stream);
+      }
+      {
+        ProfScope ps(prof, "attention", stream);
+        AttnArgs aa;
+        aa.q = qk; aa.k = qk + d; aa.ld_qk = 2 * d; aa.vt = vt; aa.ld_vt = Mpad; aa.ctx = ctx; aa.ld_ctx = d;
+        aa.plan = r.dp; aa.qb_utt = r.d_qb_utt; aa.qb_q0 = r.d_qb_q0; aa.n_qblocks = r.n_qb; aa.n_heads = c.n_heads;
+        aa.qt = r.att_qt; aa.n_waves = r.att_nw; aa.max_T = r.max_T;
+        if (precision == ASR_PRECISION_BF16) launch_attention_bf16_hd128(aa, stream);
+        else launch_attention_f32(aa, c.d_head, stream);
+      }
     }
     {
       ProfScope ps(prof, "gemm_out", stream);
@@ -601,6 +613,7 @@ extern "C" int asr_sensevoice_create(const asr_sensevoice_config* cfg, const voi
       s->precision = precision;
       s->cfg = *cfg;
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
+      if (const char* e = getenv("ASR_SANM_FUSED")) s->use_fused = !(e[0] == '0');
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;
       s->arena.load(arena, arena_bytes, arena_mem, s->stream);
@@ -654,6 +667,7 @@ extern "C" int asr_paraformer_create(const asr_paraformer_config* cfg, const voi
       c.n_blocks = cfg->n_blocks; c.n_main = cfg->n_blocks; c.fsmn_kernel = cfg->fsmn_kernel; c.vocab = cfg->vocab; c.blank_id = -1;
       c.n_prompt = 0; c.n_languages = 0; c.max_audio_len = cfg->max_audio_len;
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
+      if (const char* e = getenv("ASR_SANM_FUSED")) s->use_fused = !(e[0] == '0');
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;
       s->arena.load(arena, arena_bytes, arena_mem, s->stream);

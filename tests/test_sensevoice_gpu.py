@@ -115,3 +115,32 @@ def test_run_is_deterministic_and_rejects_bad_input():
         sess.run([a[:399]], [2])                # shorter than one 25 ms frame
     with pytest.raises(_lib.AsrError):
         sess.run([a], [99])                     # language selector out of range
+
+
+def test_fused_attention_half_equals_unfused_kernels(monkeypatch):
+    """Windows of <= 144 rows run q|k|v projection + attention + FSMN as ONE kernel per (utterance, head); the arithmetic
+    order is that of the separate GEMM / attention / FSMN kernels, so both paths must give the same logits and ids."""
+    cfg, ck = sensevoice_setup("sensevoice_small")
+    eng = sub("engine")
+    lens = [128000, 38880, 127000, 16000, 7777, 128000]            # T = 137, 44, 136, 20, 12, 137 (ragged, incl. odd tails)
+    audios = [kaldi_audio(300 + i, n) for i, n in enumerate(lens)]
+    langs = [0, 1, 2, 3, 6, 0]
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ASR_SANM_FUSED", flag)
+        sess = eng.SenseVoiceSession.from_checkpoint(cfg, ck, precision=BF16)
+        sess.taps(True)
+        toks = sess.run(audios, langs)
+        b0, lg = sess.tap("block0"), sess.tap("logits")
+        sess.taps(False)
+        sess.profile(True)
+        sess.profile_reset()
+        sess.run(audios, langs)
+        out[flag] = (toks, b0, lg, set(sess.profile_read()))
+    assert "sanm_fused" in out["1"][3] and "sanm_fused" not in out["0"][3]
+    rows = sess.utterance_rows(lens)
+    for (r0, T) in rows:
+        assert np.array_equal(out["1"][1][r0:r0 + T], out["0"][1][r0:r0 + T])
+        assert np.array_equal(out["1"][2][r0:r0 + T], out["0"][2][r0:r0 + T])
+    for a, b in zip(out["1"][0], out["0"][0]):
+        assert np.array_equal(a, b)

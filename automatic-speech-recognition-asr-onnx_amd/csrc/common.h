@@ -25,8 +25,12 @@ __device__ __host__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return (bf16_t)(u >> 16);
 }
 
+// two f32 -> packed bf16 pair, round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  typedef __attribute__((ext_vector_type(2))) float f32x2_v;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_v;
+  const f32x2_v v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_v));
 }
 
 template <typename T> struct Elem;
@@ -36,7 +40,7 @@ template <> struct Elem<float> {
 };
 template <> struct Elem<bf16_t> {
   static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
-  static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+  static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = (bf16_t)(pack_bf16x2(v, 0.0f) & 0xffffu); }
 };
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -137,6 +137,7 @@ struct SanmFusedArgs {
   void* ctx; int ld_ctx;
   float* mem; int ld_mem;
   int n_rows_alloc;            // rows of h that may be read (rows past an utterance's end are read but never used)
+  int dbg = 0;
 };
 bool sanm_fused_supported(int max_T, int d_head, int n_heads, int d, int fsmn_taps, int K);
 void launch_sanm_qkv_attn(const SanmFusedArgs& a, hipStream_t s);

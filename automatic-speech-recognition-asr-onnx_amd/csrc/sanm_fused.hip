@@ -14,6 +14,7 @@
 //           over the V^T rows in LDS) with row-major coalesced f32 stores.
 // Arithmetic order equals the unfused kernels' (same K order, same 32-key online soft-max steps, same tap order),
 // so both paths produce the same bits.
+#include <type_traits>
 #include "kernels.h"
 
 namespace {
@@ -77,31 +78,44 @@ __global__ __launch_bounds__(768) void sanm_qkv_attn_kernel(const SanmFusedArgs 
   for (int i = 0; i < FMI; ++i) { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   const int nk = a.K / 64;
   const int a_lane = frow * 128, w_lane = FA_BYTES + (grp * FHD + sub * 32 + frow) * 128, key7 = frow & 7;
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    wait_all_dma();
-    __builtin_amdgcn_s_barrier();            // stage kt landed for every wave; every wave finished reading the other slot
-    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * 64);
-    const unsigned char* St = smem + (kt & 1) * FSTAGE;
+  auto k_loop = [&](auto full_tag, auto swap_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;      // FULL: all 9 row fragments, straight-line MFMA body
+    constexpr bool SWAP = decltype(swap_tag)::value;      // q / k waves: mfma(W, A); v waves: mfma(A, W)
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      wait_all_dma();
+      __builtin_amdgcn_s_barrier();          // stage kt landed for every wave; every wave finished reading the other slot
+      if (kt + 1 < nk && !(a.dbg & 1)) stage((kt + 1) & 1, (kt + 1) * 64);
+      if (a.dbg & 2) continue;
+      const unsigned char* St = smem + (kt & 1) * FSTAGE;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int sw = ((kk * 4 + fgrp) ^ key7) << 4;
-      const bf16x8_t w0 = *reinterpret_cast<const bf16x8_t*>(St + w_lane + sw);
-      const bf16x8_t w1 = *reinterpret_cast<const bf16x8_t*>(St + w_lane + 16 * 128 + sw);
+      for (int kk = 0; kk < 2; ++kk) {
+        const int sw = ((kk * 4 + fgrp) ^ key7) << 4;
+        const bf16x8_t w0 = *reinterpret_cast<const bf16x8_t*>(St + w_lane + sw);
+        const bf16x8_t w1 = *reinterpret_cast<const bf16x8_t*>(St + w_lane + 16 * 128 + sw);
+        bf16x8_t af[FMI];
 #pragma unroll
-      for (int i = 0; i < FMI; ++i) {
-        if (i < n_act) {
-          const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(St + a_lane + i * 2048 + sw);
-          if (grp < 2) {
-            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, af, acc[i][0], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, af, acc[i][1], 0, 0, 0);
-          } else {
-            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, w0, acc[i][0], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, w1, acc[i][1], 0, 0, 0);
+        for (int i = 0; i < FMI; ++i)
+          if (FULL || i < n_act) af[i] = *reinterpret_cast<const bf16x8_t*>(St + a_lane + i * 2048 + sw);
+#pragma unroll
+        for (int i = 0; i < FMI; ++i) {
+          if (FULL || i < n_act) {
+            if constexpr (SWAP) {
+              acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, af[i], acc[i][0], 0, 0, 0);
+              acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, af[i], acc[i][1], 0, 0, 0);
+            } else {
+              acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], w0, acc[i][0], 0, 0, 0);
+              acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], w1, acc[i][1], 0, 0, 0);
+            }
           }
         }
       }
     }
+  };
+  if (n_act == FMI) {
+    if (grp < 2) k_loop(std::true_type{}, std::true_type{}); else k_loop(std::true_type{}, std::false_type{});
+  } else {
+    if (grp < 2) k_loop(std::false_type{}, std::true_type{}); else k_loop(std::false_type{}, std::false_type{});
   }
   __syncthreads();                           // ring is dead: phase-2 images may overwrite it
 
@@ -148,7 +162,9 @@ __global__ __launch_bounds__(768) void sanm_qkv_attn_kernel(const SanmFusedArgs 
   __syncthreads();
 
   // ---------------------------------------------------------------- phase 2
+  if (a.dbg & 4) return;
   if (wave < FMI) {                          // attention, query tile `wave`
+    if (a.dbg & 8) return;
     const int q0 = wave * 16;
     if (q0 >= T) return;
     const unsigned char* Qs = smem + FQS;
@@ -222,6 +238,7 @@ __global__ __launch_bounds__(768) void sanm_qkv_attn_kernel(const SanmFusedArgs 
       }
     }
   } else if (wave < FMI + 2) {               // FSMN memory: lane = channel, sliding window along time
+    if (a.dbg & 16) return;
     constexpr int PAD = (FTAPS - 1) / 2;
     const int c = (wave - FMI) * 64 + lane, cg = h * FHD + c;
     const unsigned char* vrow = smem + FVS + c * 512;
@@ -279,6 +296,10 @@ void launch_sanm_qkv_attn(const SanmFusedArgs& a, hipStream_t s) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sanm_qkv_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FLDS));
     attr_set = true;
   }
-  hipLaunchKernelGGL(sanm_qkv_attn_kernel, dim3(a.n_utts * a.n_heads), dim3(FNW * 64), FLDS, s, a);
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("ASR_FUSED_DBG"); dbg = e ? atoi(e) : 0; }     // kernel ablation switches (timing only)
+  SanmFusedArgs b = a;
+  b.dbg = dbg;
+  hipLaunchKernelGGL(sanm_qkv_attn_kernel, dim3(a.n_utts * a.n_heads), dim3(FNW * 64), FLDS, s, b);
   HIP_CHECK(hipGetLastError());
 }

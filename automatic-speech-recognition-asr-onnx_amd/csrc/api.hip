@@ -407,8 +407,8 @@ extern "C" int asr_op_gemm_bench(int variant, int M, int N, int K, int epilogue,
       case 4: g.out_t = ot; g.ld_out_t = Mp; break;
       default: ASR_THROW(ASR_ERR_INVALID, "op_gemm_bench: unknown epilogue %d", epilogue);
     }
-    g.dbg = variant >> 8;
-    gemm_set_variant(variant & 0xff);
+    g.dbg = variant < 0 ? 0 : variant >> 8;
+    gemm_set_variant(variant < 0 ? -1 : (variant & 0xff));      // sticky: later asr_op_gemm calls use it too
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));

@@ -88,8 +88,8 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
   *reinterpret_cast<uint4*>(p) = w;
 }
 
-template <typename OutT, int ACT, int EPI, int NJ>
-__device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[4][NJ], int m_wave, int n_wave, int lane) {
+template <typename OutT, int ACT, int EPI, int NJ, int MI = 4>
+__device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[MI][NJ], int m_wave, int n_wave, int lane) {
   static_assert(NJ % 2 == 0, "fragments are paired");
   const int frow = lane & 15, fgrp = lane >> 4;
   const bool has_bias = epi_has<EPI, E_BIAS>(g.bias), has_add = epi_has<EPI, E_ADD>(g.add), has_add2 = epi_has<EPI, E_ADD2>(g.add2);
@@ -97,7 +97,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[
   if (epi_has<EPI, E_AMAX>(g.amax_val)) {
     const int n_slabs = g.N / (NJ * 16), slab = n_wave / (NJ * 16);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       float best = -INFINITY;
       int bidx = 0x7fffffff;
 #pragma unroll
@@ -132,26 +132,26 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[
       const float4 lo = *reinterpret_cast<const float4*>(g.bias + n), hi = *reinterpret_cast<const float4*>(g.bias + n + 4);
       b8[0] = lo.x; b8[1] = lo.y; b8[2] = lo.z; b8[3] = lo.w; b8[4] = hi.x; b8[5] = hi.y; b8[6] = hi.z; b8[7] = hi.w;
     }
-    float4 t1[4][2], t2[4][2];
+    float4 t1[MI][2], t2[MI][2];
     if (has_add) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {      // rows up to the 128-row tile edge are readable (padded buffers)
-        const float* q = g.add + (size_t)(m_wave + i * 16 + frow) * g.ld_add + n;
+      for (int i = 0; i < MI; ++i) {      // rows up to the 128-row tile edge are readable (padded buffers)
+        const float* q = g.add + (size_t)min(m_wave + i * 16 + frow, g.M - 1) * g.ld_add + n;
         t1[i][0] = *reinterpret_cast<const float4*>(q);
         t1[i][1] = *reinterpret_cast<const float4*>(q + 4);
       }
     }
     if (has_add2) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m_wave + i * 16 + frow;
+      for (int i = 0; i < MI; ++i) {
+        const int m = min(m_wave + i * 16 + frow, g.M - 1);
         const float* q = g.add2 + (size_t)(g.add2_rows ? g.add2_rows[m] : m) * g.ld_add2 + n;
         t2[i][0] = *reinterpret_cast<const float4*>(q);
         t2[i][1] = *reinterpret_cast<const float4*>(q + 4);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       const int m = m_wave + i * 16 + frow;
       float v[8];
 #pragma unroll
@@ -297,6 +297,136 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_pipe(const GemmArgs g) {
   if ((g.dbg & 4) && acc[0][0][0] != 12345.678f) return;
   if constexpr (SWAP) epilogue_rows<bf16_t, ACT, EPI, NJ>(g, acc, m_wave, n_wave, lane);
   else epilogue_transposed<bf16_t, NJ>(g, acc, m_wave, n_wave, lane);
+}
+
+// ------------------------------------------------------------------------------------ bf16, 144 x 128 tile, 8 waves
+// Row tiles of 144 = one 8 s window (137 rows padded to 144): M = 64 x 144 gives 64 row tiles, so an N = 512 GEMM is
+// exactly 256 workgroups (one per CU) and N = 2048 exactly 1024 (two rounds of two co-resident workgroups) -- the
+// 128-row tiling leaves 72 row tiles and a 12 % last round. 8 waves = 2 K-halves x 4 column groups of 32: a wave owns ALL
+// 9 row fragments of its 32 columns (the A fragment is shared by 2 W fragments: 11 LDS reads per 18 MFMA) for ONE
+// 32-wide half of every 64-wide K-step; the two halves are summed through LDS once per tile (the ring is dead by
+// then), after which the K-half-0 waves finish row fragments 0..4 and the K-half-1 waves 5..8 with the register
+// epilogue. STAGES = 4 (one workgroup per CU, counted vmcnt keeps two stages in flight) or 2 (two workgroups per CU).
+constexpr int TM = 144, TN = 128, TMI = TM / 16;
+constexpr int T_STAGE = (TM + TN) * 128;
+constexpr int T_AI = TM / 8, T_NI = (TM + TN) / 8;     // LDS-DMA wave-instructions per stage: A part / total
+constexpr int T_RED = TM * TN * 4;
+
+template <int STAGES, int ACT, int EPI>
+__global__ __launch_bounds__(512, (STAGES == 2 ? 2 : 1)) void gemm_bf16_t144(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = wave >> 2, cg = wave & 3;
+  const int frow = lane & 15, fgrp = lane >> 4;
+  const int tiles_n = g.N / TN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+  const int a_rows = (g.M + 127) & ~127;                  // rows of A that may be read (padded allocation)
+
+  const int srow = lane >> 3;
+  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A);
+  const bf16_t* Wb = reinterpret_cast<const bf16_t*>(g.W);
+  const bf16_t* src[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const int ii = min(wave + 8 * t, T_NI - 1);
+    if (ii < T_AI) {
+      const int r = min(tile_m * TM + ii * 8 + srow, a_rows - 1);
+      src[t] = Ab + (size_t)r * g.lda + (((lane & 7) ^ srow) << 3);
+    } else {
+      const int wr = (ii - T_AI) * 8 + srow;               // row inside the W tile
+      src[t] = Wb + (size_t)(tile_n * TN + wr) * g.ldw + (((lane & 7) ^ w_swz(wr)) << 3);
+    }
+  }
+  const bool five = wave + 32 < T_NI;                     // waves 0, 1 carry a fifth instruction per stage
+  auto stage = [&](int slot, int k0) {
+    unsigned char* base = smem + slot * T_STAGE + wave * 1024;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + t * 8192), 16, 0, 0);
+    if (five)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[4] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + 4 * 8192), 16, 0, 0);
+  };
+
+  f32x4_t acc[TMI][2];
+#pragma unroll
+  for (int i = 0; i < TMI; ++i) { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  const int nk = g.K / BK16;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) stage(s, s * BK16);
+
+  const int c = kg * 4 + fgrp;                            // this wave's 16-byte K-chunk inside the 128-byte stage row
+  const int a_off = frow * 128 + ((c ^ (frow & 7)) << 4);
+  int w_off[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int r = cg * 32 + frag_col(j, frow); w_off[j] = TM * 128 + r * 128 + ((c ^ w_swz(r)) << 4); }
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = min(nk, kt + STAGES - 1) - (kt + 1);
+    if (STAGES >= 4 && ahead >= 2) { if (five) wait_vmcnt<10>(); else wait_vmcnt<8>(); }
+    else if (STAGES >= 3 && ahead >= 1) { if (five) wait_vmcnt<5>(); else wait_vmcnt<4>(); }
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + STAGES - 1 < nk && !(g.dbg & 1)) stage((kt + STAGES - 1) % STAGES, (kt + STAGES - 1) * BK16);
+    if (g.dbg & 2) continue;
+    const unsigned char* St = smem + (kt % STAGES) * T_STAGE;
+    const bf16x8_t w0 = *reinterpret_cast<const bf16x8_t*>(St + w_off[0]);
+    const bf16x8_t w1 = *reinterpret_cast<const bf16x8_t*>(St + w_off[1]);
+    bf16x8_t af[TMI];
+#pragma unroll
+    for (int i = 0; i < TMI; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(St + a_off + i * 2048);
+#pragma unroll
+    for (int i = 0; i < TMI; ++i) {
+      acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, af[i], acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, af[i], acc[i][1], 0, 0, 0);
+    }
+  }
+  if ((g.dbg & 4) && acc[0][0][0] != 12345.678f) return;
+
+  // ---- sum the two K-halves: half 1 hands row fragments 0..4 to half 0, half 0 hands 5..8 to half 1
+  __syncthreads();                                        // ring dead
+  float4* red = reinterpret_cast<float4*>(smem);
+  constexpr int LO = 5, HI = TMI - LO;
+  if (kg == 1) {
+#pragma unroll
+    for (int i = 0; i < LO; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        red[((cg * LO + i) * 2 + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < HI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        red[4 * LO * 2 * 64 + ((cg * HI + i) * 2 + j) * 64 + lane] =
+            make_float4(acc[LO + i][j][0], acc[LO + i][j][1], acc[LO + i][j][2], acc[LO + i][j][3]);
+  }
+  __syncthreads();
+  const int n_wave = tile_n * TN + cg * 32;
+  if (kg == 0) {
+    f32x4_t fin[LO][2];
+#pragma unroll
+    for (int i = 0; i < LO; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float4 o = red[((cg * LO + i) * 2 + j) * 64 + lane];
+        fin[i][j] = f32x4_t{acc[i][j][0] + o.x, acc[i][j][1] + o.y, acc[i][j][2] + o.z, acc[i][j][3] + o.w};
+      }
+    epilogue_rows<bf16_t, ACT, EPI, 2, LO>(g, fin, tile_m * TM, n_wave, lane);
+  } else {
+    f32x4_t fin[HI][2];
+#pragma unroll
+    for (int i = 0; i < HI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float4 o = red[4 * LO * 2 * 64 + ((cg * HI + i) * 2 + j) * 64 + lane];
+        fin[i][j] = f32x4_t{o.x + acc[LO + i][j][0], o.y + acc[LO + i][j][1], o.z + acc[LO + i][j][2], o.w + acc[LO + i][j][3]};
+      }
+    epilogue_rows<bf16_t, ACT, EPI, 2, HI>(g, fin, tile_m * TM + LO * 16, n_wave, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------------ bf16, skinny M (decode)
@@ -583,7 +713,54 @@ void launch_pipe(const GemmArgs& g, hipStream_t s) {
   launch_pipe_inst<BN_, STAGES, -1, -1, true>(g, s);
 }
 
-int g_gemm_variant = -1;   // -1 = heuristic
+bool g_t144_generic = false;
+
+template <int STAGES, int ACT, int EPI>
+void launch_t144_inst(const GemmArgs& g, hipStream_t s) {
+  constexpr int ring = STAGES * T_STAGE;
+  constexpr int lds = ring > T_RED ? ring : T_RED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_t144<STAGES, ACT, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int grid = ((g.M + TM - 1) / TM) * (g.N / TN);
+  hipLaunchKernelGGL((gemm_bf16_t144<STAGES, ACT, EPI>), dim3(grid), dim3(512), lds, s, g);
+  HIP_CHECK(hipGetLastError());
+}
+
+template <int STAGES>
+bool launch_t144(const GemmArgs& g, hipStream_t s) {
+  const int epi = (g.add ? E_ADD : 0) | (g.add2 ? E_ADD2 : 0) | (g.out_f32 ? E_F32 : 0) | (g.out_lo ? E_LO : 0) | (g.bias ? E_BIAS : 0);
+#define ASR_T144_CASE(ACT_, EPI_) \
+  if (g.act == (ACT_) && epi == (EPI_)) { launch_t144_inst<STAGES, ACT_, EPI_>(g, s); return true; }
+  ASR_T144_CASE(ACT_NONE, E_BIAS | E_LO)
+  ASR_T144_CASE(ACT_RELU, E_BIAS | E_LO)
+  ASR_T144_CASE(ACT_NONE, E_ADD | E_ADD2 | E_F32)
+  ASR_T144_CASE(ACT_NONE, E_ADD | E_F32)
+  ASR_T144_CASE(ACT_NONE, E_BIAS | E_ADD | E_F32)
+#undef ASR_T144_CASE
+  if (g_t144_generic) { launch_t144_inst<STAGES, -1, -1>(g, s); return true; }   // runtime-checked epilogue (op hooks / tests)
+  return false;
+}
+
+// 144-row tiles pay off when the row count is (close to) a multiple of 144 and the tile count fills the chip evenly.
+bool t144_fits(const GemmArgs& g, int* stages) {
+  if (g.out_t || g.amax_val || g.lo_group || g.add2_rows || g.N % TN || g.K % BK16 || g.M < 8 * TM) return false;
+  const int tiles_m = (g.M + TM - 1) / TM, tiles = tiles_m * (g.N / TN);
+  if ((double)tiles_m * TM > 1.04 * g.M) return false;                 // padding waste
+  const int old_tiles = ((g.M + BM - 1) / BM) * (g.N / 64);
+  const double old_cost = (double)((old_tiles + 511) / 512) * BM * 64;   // rounds x tile area (two co-resident workgroups per CU)
+  if (tiles <= 256) {
+    *stages = 4;
+    return (double)TM * TN * 0.75 < old_cost;                            // one round, one workgroup per CU
+  }
+  *stages = 2;
+  return (double)((tiles + 511) / 512) * TM * TN * 0.85 < old_cost;
+}
+
+int g_gemm_variant = -1;   // -1 = heuristic; 5 / 6 = 144-row tiles with a 4- / 2-stage ring
 
 }  // namespace
 
@@ -602,7 +779,20 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
   }
   check_args(g, BK16, 2);
   int v = g_gemm_variant;
-  if (v < 0) v = 4;
+  if (v < 0) {
+    int st = 0;
+    static const bool t144_on = !(getenv("ASR_GEMM_T144") && getenv("ASR_GEMM_T144")[0] == '0');
+    if (t144_on && t144_fits(g, &st) && (st == 4 ? launch_t144<4>(g, s) : launch_t144<2>(g, s))) return;
+    v = 4;
+  }
+  if (v == 5 || v == 6) {
+    ASR_REQUIRE(!(g.out_t || g.amax_val || g.lo_group || g.add2_rows) && g.N % TN == 0, "gemm: variant %d (144-row tiles) does not support this epilogue", v);
+    g_t144_generic = true;
+    const bool ok = v == 5 ? launch_t144<4>(g, s) : launch_t144<2>(g, s);
+    g_t144_generic = false;
+    ASR_REQUIRE(ok, "gemm: variant %d has no instance for this epilogue", v);
+    return;
+  }
   if (g.amax_val && (v == 3 || v == 4)) v = 2;     // arg-max partials are per 64-column slab (BN = 128)
   switch (v) {
     case 1: launch_pipe<128, 3>(g, s); break;

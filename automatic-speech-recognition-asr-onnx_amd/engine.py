@@ -213,6 +213,11 @@ def op_gemm_bench(M, N, K, variant=-1, epilogue=0, iters=50) -> float:
     return ms.value
 
 
+def op_gemm_set_variant(variant: int = -1) -> None:
+    """Pin the bf16 GEMM kernel variant for the following op_gemm calls (-1 = heuristic); tuning / test hook."""
+    op_gemm_bench(1152, 128, 64, variant, 0, 1)
+
+
 # =============================================================================== Whisper
 def whisper_config_c(cfg, gelu_tanh: bool = False) -> _lib.WhisperConfigC:
     c = _lib.WhisperConfigC()

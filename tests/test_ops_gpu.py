@@ -167,3 +167,25 @@ def test_skinny_gemm_with_fused_layernorm(affine):
     ln = torch.nn.functional.layer_norm(torch.from_numpy(x), (K,), torch.from_numpy(g) if affine else None, torch.from_numpy(b) if affine else None, 1e-5)
     ref = (ln.to(torch.bfloat16).double() @ torch.from_numpy(w).double().t() + torch.from_numpy(bias).double()).numpy()
     assert np.abs(out - ref).max() <= 3e-3 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("variant", [5, 6])
+@pytest.mark.parametrize("M,N,K,act", [(1440, 512, 512, 0), (1447, 256, 576, 1), (2304, 128, 2048, 0)])
+def test_gemm_144_row_tiles(variant, M, N, K, act):
+    """144 x 128 tiles (8 waves, K-halves summed through LDS), 4-stage and 2-stage rings, ragged last tile."""
+    eng = sub("engine")
+    rng = np.random.default_rng(M + N + K)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    try:
+        eng.op_gemm_set_variant(variant)
+        got = eng.op_gemm(a, w, b, act=act, precision=0)
+    finally:
+        eng.op_gemm_set_variant(-1)
+    ref = _bf16_round(a).astype(np.float64) @ _bf16_round(w).astype(np.float64).T + b
+    if act == 1:
+        ref = np.maximum(ref, 0)
+    assert np.abs(got - ref).max() < 2e-3 * max(1.0, np.abs(ref).max())
+    base = eng.op_gemm(a, w, b, act=act, precision=0)              # default kernel: same products, other summation order
+    assert np.abs(got - base).max() < 2e-3 * max(1.0, np.abs(ref).max())

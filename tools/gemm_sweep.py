@@ -8,6 +8,9 @@ variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0
 for name, N, K, epi in shapes:
     row = []
     for v in variants:
-        best = min(eng.op_gemm_bench(M, N, K, v, epi, 50) for _ in range(3))
-        row.append(f"v{v}: {best*1e3:7.1f} us {2*M*N*K/best/1e9:7.0f} TF")
+        try:
+            best = min(eng.op_gemm_bench(M, N, K, v, epi, 50) for _ in range(3))
+            row.append(f"v{v}: {best*1e3:7.1f} us {2*M*N*K/best/1e9:7.0f} TF")
+        except Exception:
+            row.append(f"v{v}: n/a")
     print(f"{name:5s} M={M} N={N} K={K} | " + " | ".join(row), flush=True)

@@ -149,6 +149,15 @@ def pack_mel_for_mfma(mel_t: np.ndarray, n_mels: int) -> np.ndarray:
     return out.reshape(-1)
 
 
+def _operand_colsum(wmat: np.ndarray, precision: int) -> np.ndarray:
+    """c[n] = sum_k W[n][k] over the weights AS THE GEMM SEES THEM (bf16-rounded in bf16 mode), summed in float64.
+    With it the engine evaluates LayerNorm algebraically inside the GEMM: LN(x) W^T = rstd (x W^T - mean c)."""
+    wm = np.asarray(wmat, dtype=np.float32)
+    if precision == PRECISION_BF16:
+        wm = torch.from_numpy(wm).to(torch.bfloat16).float().numpy()
+    return wm.astype(np.float64).sum(axis=1).astype(np.float32)
+
+
 def _pad_cols(a: np.ndarray, cols: int) -> np.ndarray:
     if a.shape[1] == cols:
         return a
@@ -201,17 +210,26 @@ def build_sensevoice_arena(cfg: SenseVoiceConfig, ck: dict, precision: int = PRE
         kpad = (in_size + 63) // 64 * 64
         wf = ck[p + "self_attn.fsmn_block.weight"][:, 0, :].copy()
         wf[:, pad] += np.float32(1.0)
-        w.add(q + "ln1_g", ck[p + "norm1.weight"], DT_F32)
-        w.add(q + "ln1_b", ck[p + "norm1.bias"], DT_F32)
+        w1, b1 = ck[p + "feed_forward.w_1.weight"], ck[p + "feed_forward.w_1.bias"]
+        if precision == PRECISION_BF16:
+            # performance mode: LayerNorm affines are absorbed into the following Linear (float64, rounded once) so the
+            # normalisation itself can be evaluated inside the GEMM from row statistics (column sums below)
+            wqkv, bqkv = _fold64(ck[p + "norm1.weight"], ck[p + "norm1.bias"], wqkv, bqkv)
+            w1, b1 = _fold64(ck[p + "norm2.weight"], ck[p + "norm2.bias"], w1, b1)
+            w.add(q + "cqkv", _operand_colsum(wqkv, precision), DT_F32)
+            w.add(q + "c1", _operand_colsum(w1, precision), DT_F32)
+        else:
+            w.add(q + "ln1_g", ck[p + "norm1.weight"], DT_F32)
+            w.add(q + "ln1_b", ck[p + "norm1.bias"], DT_F32)
+            w.add(q + "ln2_g", ck[p + "norm2.weight"], DT_F32)
+            w.add(q + "ln2_b", ck[p + "norm2.bias"], DT_F32)
         w.weight(q + "wqkv", _pad_cols(wqkv, kpad), precision)
         w.add(q + "bqkv", bqkv, DT_F32)
         w.add(q + "wfsmn", wf, DT_F32)
         w.add(q + "bfsmn", ck[p + "self_attn.linear_out.bias"], DT_F32)
         w.weight(q + "wout", ck[p + "self_attn.linear_out.weight"], precision)
-        w.add(q + "ln2_g", ck[p + "norm2.weight"], DT_F32)
-        w.add(q + "ln2_b", ck[p + "norm2.bias"], DT_F32)
-        w.weight(q + "w1", ck[p + "feed_forward.w_1.weight"], precision)
-        w.add(q + "b1", ck[p + "feed_forward.w_1.bias"], DT_F32)
+        w.weight(q + "w1", w1, precision)
+        w.add(q + "b1", b1, DT_F32)
         w.weight(q + "w2", ck[p + "feed_forward.w_2.weight"], precision)
         w.add(q + "b2", ck[p + "feed_forward.w_2.bias"], DT_F32)
     w.add("after_norm_g", ck["encoder.after_norm.weight"], DT_F32)
@@ -404,6 +422,9 @@ def build_paraformer_arena(cfg, ck: dict, precision: int = PRECISION_BF16) -> np
         wqkv, bqkv = _fold64(ck[p + "norm1.weight"], ck[p + "norm1.bias"], ck[p + "self_attn.linear_q_k_v.weight"], ck[p + "self_attn.linear_q_k_v.bias"], scale)
         w1, b1 = _fold64(ck[p + "norm2.weight"], ck[p + "norm2.bias"], ck[p + "feed_forward.w_1.weight"], ck[p + "feed_forward.w_1.bias"])
         kpad = (wqkv.shape[1] + 63) // 64 * 64
+        if precision == PRECISION_BF16:
+            w.add(q + "cqkv", _operand_colsum(wqkv, precision), DT_F32)
+            w.add(q + "c1", _operand_colsum(w1, precision), DT_F32)
         w.weight(q + "wqkv", _pad_cols(wqkv, kpad), precision)
         w.add(q + "bqkv", bqkv, DT_F32)
         w.add(q + "wfsmn", fsmn_w(p), DT_F32)

@@ -405,6 +405,18 @@ extern "C" int asr_op_gemm_bench(int variant, int M, int N, int K, int epilogue,
       case 2: g.add = addm; g.ld_add = N; g.out_f32 = of32; g.ld_out_f32 = N; break;
       case 3: g.bias = nullptr; g.add = addt; g.ld_add = N; g.add2 = addm; g.ld_add2 = N; g.out_f32 = of32; g.ld_out_f32 = N; break;
       case 4: g.out_t = ot; g.ld_out_t = Mp; break;
+      case 5: {   // FFN-1 with the LayerNorm evaluated inside (statistics handed over by the producer)
+        float2* st = (float2*)t.alloc((size_t)Mp * (K / 32) * 8);
+        HIP_CHECK(hipMemset(st, 0, (size_t)Mp * (K / 32) * 8));
+        g.out_lo = olo; g.ld_out_lo = N; g.act = ACT_RELU; g.ln_colsum = bias; g.ln_dim = K; g.ln_stats_in = st; g.ln_slots = K / 32;
+        break;
+      }
+      case 6: {   // out-projection writing the residual stream in f32 + bf16 + row statistics
+        float2* st = (float2*)t.alloc((size_t)Mp * (N / 32) * 8);
+        g.bias = nullptr; g.add = addt; g.ld_add = N; g.add2 = addm; g.ld_add2 = N; g.out_f32 = of32; g.ld_out_f32 = N;
+        g.out_lo = olo; g.ld_out_lo = N; g.st_out = st;
+        break;
+      }
       default: ASR_THROW(ASR_ERR_INVALID, "op_gemm_bench: unknown epilogue %d", epilogue);
     }
     g.dbg = variant < 0 ? 0 : variant >> 8;

@@ -54,6 +54,21 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// sum of `n` (sum, sum-of-squares) partials of one row; the loads are issued in batches of 8 slots so that their latencies overlap
+__device__ __forceinline__ float2 sum_row_partials(const float2* sp, int n) {
+  float sx = 0.0f, sy = 0.0f;
+  int q = 0;
+  for (; q + 8 <= n; q += 8) {
+    float4 t[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = *reinterpret_cast<const float4*>(sp + q + 2 * e);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sx += t[e].x; sy += t[e].y; sx += t[e].z; sy += t[e].w; }
+  }
+  for (; q < n; ++q) { const float2 t = sp[q]; sx += t.x; sy += t.y; }
+  return make_float2(sx, sy);
+}
+
 // ---- host-side error plumbing (thread-local message, integer status) -------------------
 enum {
   ASR_OK = 0,

@@ -29,12 +29,23 @@ struct GemmArgs {
   // normalises the few activation rows itself (two-pass statistics in f32), so no separate LayerNorm launch and no bf16
   // round trip of the normalised rows through HBM. gamma/beta nullable (affine folded into W, Export_Whisper.py:215-225).
   const float* ln_x = nullptr; int ld_ln_x = 0; const float* ln_gamma = nullptr; const float* ln_beta = nullptr; float ln_eps = 1e-5f;
+  // LayerNorm evaluated inside the GEMM (144-row-tile kernel only; K must span the whole normalised row): A holds the RAW rows
+  // x in bf16, row statistics over the first ln_dim columns are accumulated from the LDS tiles during the MFMA loop and
+  // C = rstd (x W^T - mean ln_colsum) + bias. Needs the LayerNorm affine folded into W / bias; ln_colsum[n] = sum_k W[n][k].
+  const float* ln_colsum = nullptr; int ln_dim = 0;
+  // row statistics hand-over between GEMMs: a producer with st_out set writes, per row and per 32-column group, the
+  // (sum, sum of squares) of the bf16-ROUNDED values it stores to out_lo -- st_out[m * (N / 32) + n / 32]; a LayerNorm-fused
+  // consumer given ln_stats_in (ln_slots groups per row) sums them in a fixed order instead of re-deriving the statistics
+  // from its LDS tiles in every column tile.
+  float2* st_out = nullptr;
+  const float2* ln_stats_in = nullptr; int ln_slots = 0;
   int dbg = 0;   // tuning ablations (bench hook only): 1 = no refills, 2 = no MFMA, 4 = no epilogue
 };
 
 // operand dtype selects the kernel: bf16 MFMA (performance mode) or exact-f32 MFMA (verification mode)
 void launch_gemm_bf16(const GemmArgs& g, hipStream_t s);
 void launch_gemm_f32(const GemmArgs& g, hipStream_t s);
+bool gemm_ln_fusable(const GemmArgs& g);   // true when launch_gemm_bf16 would accept g with ln_colsum set
 void gemm_set_variant(int v);   // tuning hook: -1 = built-in heuristic
 
 // reduce the per-slab arg-max partials written by the GEMM epilogue: ids[m] = first index of the row max

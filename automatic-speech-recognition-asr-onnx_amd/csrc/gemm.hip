@@ -23,7 +23,7 @@ namespace {
 constexpr int BM = 128;
 constexpr int BK16 = 64;                       // bf16 K-step
 
-enum { E_ADD = 1, E_ADD2 = 2, E_F32 = 4, E_LO = 8, E_AMAX = 32, E_BIAS = 64 };
+enum { E_ADD = 1, E_ADD2 = 2, E_F32 = 4, E_LO = 8, E_AMAX = 32, E_BIAS = 64, E_LN = 128, E_ST = 256 };
 
 template <int ACT>
 __device__ __forceinline__ float apply_act_ct(float v) {
@@ -89,7 +89,8 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
 }
 
 template <typename OutT, int ACT, int EPI, int NJ, int MI = 4>
-__device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[MI][NJ], int m_wave, int n_wave, int lane) {
+__device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[MI][NJ], int m_wave, int n_wave, int lane,
+                                              const float2* ln_stats = nullptr) {   // (mean, rstd) of row m_wave + i, in LDS
   static_assert(NJ % 2 == 0, "fragments are paired");
   const int frow = lane & 15, fgrp = lane >> 4;
   const bool has_bias = epi_has<EPI, E_BIAS>(g.bias), has_add = epi_has<EPI, E_ADD>(g.add), has_add2 = epi_has<EPI, E_ADD2>(g.add2);
@@ -132,6 +133,11 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[
       const float4 lo = *reinterpret_cast<const float4*>(g.bias + n), hi = *reinterpret_cast<const float4*>(g.bias + n + 4);
       b8[0] = lo.x; b8[1] = lo.y; b8[2] = lo.z; b8[3] = lo.w; b8[4] = hi.x; b8[5] = hi.y; b8[6] = hi.z; b8[7] = hi.w;
     }
+    float c8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI >= 0 && (EPI & E_LN) != 0) {
+      const float4 lo = *reinterpret_cast<const float4*>(g.ln_colsum + n), hi = *reinterpret_cast<const float4*>(g.ln_colsum + n + 4);
+      c8[0] = lo.x; c8[1] = lo.y; c8[2] = lo.z; c8[3] = lo.w; c8[4] = hi.x; c8[5] = hi.y; c8[6] = hi.z; c8[7] = hi.w;
+    }
     float4 t1[MI][2], t2[MI][2];
     if (has_add) {
 #pragma unroll
@@ -155,7 +161,14 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[
       const int m = m_wave + i * 16 + frow;
       float v[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * p][r] + b8[r]; v[4 + r] = acc[i][2 * p + 1][r] + b8[4 + r]; }
+      for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * p][r]; v[4 + r] = acc[i][2 * p + 1][r]; }
+      if constexpr (EPI >= 0 && (EPI & E_LN) != 0) {
+        const float2 mr = ln_stats[i * 16 + frow];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] - mr.x * c8[e]) * mr.y;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += b8[e];
       if (has_add) {
         v[0] += t1[i][0].x; v[1] += t1[i][0].y; v[2] += t1[i][0].z; v[3] += t1[i][0].w;
         v[4] += t1[i][1].x; v[5] += t1[i][1].y; v[6] += t1[i][1].z; v[7] += t1[i][1].w;
@@ -167,6 +180,19 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[
       if (has_add2) {                                         // post-activation term
         v[0] += t2[i][0].x; v[1] += t2[i][0].y; v[2] += t2[i][0].z; v[3] += t2[i][0].w;
         v[4] += t2[i][1].x; v[5] += t2[i][1].y; v[6] += t2[i][1].z; v[7] += t2[i][1].w;
+      }
+      if constexpr (EPI >= 0 && (EPI & E_ST) != 0) {           // statistics of the bf16-rounded row segment (32 columns per wave pair)
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const uint32_t pk = pack_bf16x2(v[e], v[e + 1]);
+          const float lo = __uint_as_float(pk << 16), hi = __uint_as_float(pk & 0xffff0000u);
+          s1 += lo + hi;
+          s2 = fmaf(lo, lo, fmaf(hi, hi, s2));
+        }
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (fgrp == 0 && m < g.M) g.st_out[(size_t)m * (g.N >> 5) + ((n_wave >> 5) + p)] = make_float2(s1, s2);
       }
       if (m < g.M) {
         if (want_f32) store8<float>(g.out_f32 + (size_t)m * g.ld_out_f32 + n, v);
@@ -313,7 +339,7 @@ constexpr int T_AI = TM / 8, T_NI = (TM + TN) / 8;     // LDS-DMA wave-instructi
 constexpr int T_RED = TM * TN * 4;
 
 template <int STAGES, int ACT, int EPI>
-__global__ __launch_bounds__(512, (STAGES == 2 ? 2 : 1)) void gemm_bf16_t144(const GemmArgs g) {
+__global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void gemm_bf16_t144(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kg = wave >> 2, cg = wave & 3;
@@ -358,6 +384,23 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 2 : 1)) void gemm_bf16_t144(con
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) stage(s, s * BK16);
 
+  constexpr bool LN = EPI >= 0 && (EPI & E_LN) != 0;
+  constexpr int T_MAIN = (STAGES * T_STAGE > T_RED) ? STAGES * T_STAGE : T_RED;
+  float2* st_part = reinterpret_cast<float2*>(smem + T_MAIN);           // [2][144] partial (sum, sum of squares)
+  float2* st_fin = st_part + 2 * TM;                                     // [144] (mean, rstd)
+  const int st_row = tid % TM, st_half = tid / TM;                       // threads < 288 own (row, four 16-byte K slots)
+  float st_s = 0.0f, st_ss = 0.0f;
+
+  if constexpr (LN) {                                     // producer-side statistics: finalise (mean, rstd) while the first stages fly
+    if (g.ln_stats_in && tid < TM) {
+      const float2* sp = g.ln_stats_in + (size_t)min(tile_m * TM + tid, g.M - 1) * g.ln_slots;
+      const float2 ss = sum_row_partials(sp, g.ln_slots);
+      const float inv_d = 1.0f / (float)g.ln_dim;
+      const float mean = ss.x * inv_d;
+      const float var = fmaxf(ss.y * inv_d - mean * mean, 0.0f);
+      st_fin[tid] = make_float2(mean, rsqrtf(var + g.ln_eps));
+    }
+  }
   const int c = kg * 4 + fgrp;                            // this wave's 16-byte K-chunk inside the 128-byte stage row
   const int a_off = frow * 128 + ((c ^ (frow & 7)) << 4);
   int w_off[2];
@@ -373,6 +416,21 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 2 : 1)) void gemm_bf16_t144(con
     if (kt + STAGES - 1 < nk && !(g.dbg & 1)) stage((kt + STAGES - 1) % STAGES, (kt + STAGES - 1) * BK16);
     if (g.dbg & 2) continue;
     const unsigned char* St = smem + (kt % STAGES) * T_STAGE;
+    if constexpr (LN) {
+      if (!g.ln_stats_in && tid < 2 * TM) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint4 raw = *reinterpret_cast<const uint4*>(St + st_row * 128 + (((4 * st_half + q) ^ (st_row & 7)) << 4));
+          const uint32_t wds[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(wds[e] << 16), hi = __uint_as_float(wds[e] & 0xffff0000u);
+            st_s += lo + hi;
+            st_ss = fmaf(lo, lo, fmaf(hi, hi, st_ss));
+          }
+        }
+      }
+    }
     const bf16x8_t w0 = *reinterpret_cast<const bf16x8_t*>(St + w_off[0]);
     const bf16x8_t w1 = *reinterpret_cast<const bf16x8_t*>(St + w_off[1]);
     bf16x8_t af[TMI];
@@ -387,7 +445,17 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 2 : 1)) void gemm_bf16_t144(con
   if ((g.dbg & 4) && acc[0][0][0] != 12345.678f) return;
 
   // ---- sum the two K-halves: half 1 hands row fragments 0..4 to half 0, half 0 hands 5..8 to half 1
+  if constexpr (LN) { if (!g.ln_stats_in && tid < 2 * TM) st_part[st_half * TM + st_row] = make_float2(st_s, st_ss); }
   __syncthreads();                                        // ring dead
+  if constexpr (LN) {
+    if (!g.ln_stats_in && tid < TM) {
+      const float2 p0 = st_part[tid], p1 = st_part[TM + tid];
+      const float inv_d = 1.0f / (float)g.ln_dim;
+      const float mean = (p0.x + p1.x) * inv_d;
+      const float var = fmaxf((p0.y + p1.y) * inv_d - mean * mean, 0.0f);
+      st_fin[tid] = make_float2(mean, rsqrtf(var + g.ln_eps));
+    }
+  }
   float4* red = reinterpret_cast<float4*>(smem);
   constexpr int LO = 5, HI = TMI - LO;
   if (kg == 1) {
@@ -415,7 +483,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 2 : 1)) void gemm_bf16_t144(con
         const float4 o = red[((cg * LO + i) * 2 + j) * 64 + lane];
         fin[i][j] = f32x4_t{acc[i][j][0] + o.x, acc[i][j][1] + o.y, acc[i][j][2] + o.z, acc[i][j][3] + o.w};
       }
-    epilogue_rows<bf16_t, ACT, EPI, 2, LO>(g, fin, tile_m * TM, n_wave, lane);
+    epilogue_rows<bf16_t, ACT, EPI, 2, LO>(g, fin, tile_m * TM, n_wave, lane, st_fin);
   } else {
     f32x4_t fin[HI][2];
 #pragma unroll
@@ -425,7 +493,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 2 : 1)) void gemm_bf16_t144(con
         const float4 o = red[4 * LO * 2 * 64 + ((cg * HI + i) * 2 + j) * 64 + lane];
         fin[i][j] = f32x4_t{o.x + acc[LO + i][j][0], o.y + acc[LO + i][j][1], o.z + acc[LO + i][j][2], o.w + acc[LO + i][j][3]};
       }
-    epilogue_rows<bf16_t, ACT, EPI, 2, HI>(g, fin, tile_m * TM + LO * 16, n_wave, lane);
+    epilogue_rows<bf16_t, ACT, EPI, 2, HI>(g, fin, tile_m * TM + LO * 16, n_wave, lane, st_fin + LO * 16);
   }
 }
 
@@ -695,7 +763,7 @@ template <int BN_, int STAGES>
 void launch_pipe(const GemmArgs& g, hipStream_t s) {
   if (g.out_t) { launch_pipe_inst<BN_, STAGES, ACT_NONE, 0, false>(g, s); return; }
   const int epi = (g.add ? E_ADD : 0) | (g.add2 ? E_ADD2 : 0) | (g.out_f32 ? E_F32 : 0) | (g.out_lo ? E_LO : 0) |
-                  (g.amax_val ? E_AMAX : 0) | (g.bias ? E_BIAS : 0);
+                  (g.amax_val ? E_AMAX : 0) | (g.bias ? E_BIAS : 0) | (g.st_out ? E_ST : 0);
 #define ASR_GEMM_CASE(ACT_, EPI_) \
   if (g.act == (ACT_) && epi == (EPI_)) { launch_pipe_inst<BN_, STAGES, ACT_, EPI_, true>(g, s); return; }
   ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_LO)                    // q|k projection, cross-KV, plain projections
@@ -705,11 +773,18 @@ void launch_pipe(const GemmArgs& g, hipStream_t s) {
   ASR_GEMM_CASE(ACT_NONE, E_ADD | E_ADD2 | E_F32)           // SANM out-proj: + FSMN memory + residual
   ASR_GEMM_CASE(ACT_NONE, E_ADD | E_F32)                    // SANM out-proj of the first block (no residual)
   ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_ADD | E_F32)           // FFN-2 / out-proj with bias + residual
+  ASR_GEMM_CASE(ACT_NONE, E_ADD | E_ADD2 | E_F32 | E_LO)
+  ASR_GEMM_CASE(ACT_NONE, E_ADD | E_F32 | E_LO)
+  ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_ADD | E_F32 | E_LO)
+  ASR_GEMM_CASE(ACT_NONE, E_ADD | E_ADD2 | E_F32 | E_LO | E_ST)
+  ASR_GEMM_CASE(ACT_NONE, E_ADD | E_F32 | E_LO | E_ST)
+  ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_ADD | E_F32 | E_LO | E_ST)
   ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_AMAX)                  // CTC / LM head arg-max
   ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_F32)                   // LM head logits
   ASR_GEMM_CASE(ACT_GELU_ERF, E_BIAS | E_ADD2 | E_F32)      // Whisper conv2: gelu(conv) + positions
   ASR_GEMM_CASE(ACT_GELU_TANH, E_BIAS | E_ADD2 | E_F32)
 #undef ASR_GEMM_CASE
+  ASR_REQUIRE(!g.st_out, "gemm: no statistics-producing instance for this epilogue");
   launch_pipe_inst<BN_, STAGES, -1, -1, true>(g, s);
 }
 
@@ -718,7 +793,7 @@ bool g_t144_generic = false;
 template <int STAGES, int ACT, int EPI>
 void launch_t144_inst(const GemmArgs& g, hipStream_t s) {
   constexpr int ring = STAGES * T_STAGE;
-  constexpr int lds = ring > T_RED ? ring : T_RED;
+  constexpr int lds = (ring > T_RED ? ring : T_RED) + 3 * TM * 8;      // + LayerNorm statistics
   static bool attr_set = false;
   if (!attr_set) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_t144<STAGES, ACT, EPI>),
@@ -732,7 +807,8 @@ void launch_t144_inst(const GemmArgs& g, hipStream_t s) {
 
 template <int STAGES>
 bool launch_t144(const GemmArgs& g, hipStream_t s) {
-  const int epi = (g.add ? E_ADD : 0) | (g.add2 ? E_ADD2 : 0) | (g.out_f32 ? E_F32 : 0) | (g.out_lo ? E_LO : 0) | (g.bias ? E_BIAS : 0);
+  const int epi = (g.add ? E_ADD : 0) | (g.add2 ? E_ADD2 : 0) | (g.out_f32 ? E_F32 : 0) | (g.out_lo ? E_LO : 0) | (g.bias ? E_BIAS : 0) |
+                  (g.ln_colsum ? E_LN : 0) | (g.st_out ? E_ST : 0);
 #define ASR_T144_CASE(ACT_, EPI_) \
   if (g.act == (ACT_) && epi == (EPI_)) { launch_t144_inst<STAGES, ACT_, EPI_>(g, s); return true; }
   ASR_T144_CASE(ACT_NONE, E_BIAS | E_LO)
@@ -740,23 +816,34 @@ bool launch_t144(const GemmArgs& g, hipStream_t s) {
   ASR_T144_CASE(ACT_NONE, E_ADD | E_ADD2 | E_F32)
   ASR_T144_CASE(ACT_NONE, E_ADD | E_F32)
   ASR_T144_CASE(ACT_NONE, E_BIAS | E_ADD | E_F32)
+  ASR_T144_CASE(ACT_RELU, E_BIAS | E_LO | E_LN)              // FFN-1 on the raw residual rows, LayerNorm inside
+  ASR_T144_CASE(ACT_NONE, E_ADD | E_ADD2 | E_F32 | E_LO)     // residual stream written in f32 and as the next bf16 operand
+  ASR_T144_CASE(ACT_NONE, E_ADD | E_F32 | E_LO)
+  ASR_T144_CASE(ACT_NONE, E_BIAS | E_ADD | E_F32 | E_LO)
+  ASR_T144_CASE(ACT_NONE, E_ADD | E_ADD2 | E_F32 | E_LO | E_ST)
+  ASR_T144_CASE(ACT_NONE, E_ADD | E_F32 | E_LO | E_ST)
+  ASR_T144_CASE(ACT_NONE, E_BIAS | E_ADD | E_F32 | E_LO | E_ST)
 #undef ASR_T144_CASE
+  if (g.ln_colsum || g.st_out) return false;
   if (g_t144_generic) { launch_t144_inst<STAGES, -1, -1>(g, s); return true; }   // runtime-checked epilogue (op hooks / tests)
   return false;
 }
 
-// 144-row tiles pay off when the row count is (close to) a multiple of 144 and the tile count fills the chip evenly.
+// 144-row tiles: usable when the epilogue is one the kernel implements and the row count is close to a multiple of 144
+bool t144_geom_ok(const GemmArgs& g) {
+  if (g.out_t || g.amax_val || g.lo_group || g.add2_rows || g.N % TN || g.K % BK16 || g.M < TM) return false;
+  const int tiles_m = (g.M + TM - 1) / TM;
+  return (double)tiles_m * TM <= 1.04 * g.M;                              // padding waste
+}
+int t144_stages(const GemmArgs& g) { return ((g.M + TM - 1) / TM) * (g.N / TN) <= 256 ? 4 : 2; }
+// ... and pay off when the tile count fills the chip more evenly than the 128-row tiling does
 bool t144_fits(const GemmArgs& g, int* stages) {
-  if (g.out_t || g.amax_val || g.lo_group || g.add2_rows || g.N % TN || g.K % BK16 || g.M < 8 * TM) return false;
-  const int tiles_m = (g.M + TM - 1) / TM, tiles = tiles_m * (g.N / TN);
-  if ((double)tiles_m * TM > 1.04 * g.M) return false;                 // padding waste
+  if (!t144_geom_ok(g) || g.M < 8 * TM) return false;
+  const int tiles = ((g.M + TM - 1) / TM) * (g.N / TN);
   const int old_tiles = ((g.M + BM - 1) / BM) * (g.N / 64);
   const double old_cost = (double)((old_tiles + 511) / 512) * BM * 64;   // rounds x tile area (two co-resident workgroups per CU)
-  if (tiles <= 256) {
-    *stages = 4;
-    return (double)TM * TN * 0.75 < old_cost;                            // one round, one workgroup per CU
-  }
-  *stages = 2;
+  *stages = t144_stages(g);
+  if (tiles <= 256) return (double)TM * TN * 0.75 < old_cost;            // one round, one workgroup per CU
   return (double)((tiles + 511) / 512) * TM * TN * 0.85 < old_cost;
 }
 
@@ -765,6 +852,15 @@ int g_gemm_variant = -1;   // -1 = heuristic; 5 / 6 = 144-row tiles with a 4- / 
 }  // namespace
 
 void gemm_set_variant(int v) { g_gemm_variant = v; }
+
+static bool t144_enabled() {
+  static const bool on = !(getenv("ASR_GEMM_T144") && getenv("ASR_GEMM_T144")[0] == '0');
+  return on;
+}
+
+bool gemm_ln_fusable(const GemmArgs& g) {
+  return g_gemm_variant < 0 && t144_enabled() && g.M > 64 && g.ln_dim > 0 && g.K == (g.ln_dim + 63) / 64 * 64 && t144_geom_ok(g);
+}
 
 void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
   if (g.ln_x) ASR_REQUIRE(g.M <= 64 && !g.A, "gemm: the fused LayerNorm prologue exists on the skinny (M <= 64) path only");
@@ -781,8 +877,12 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
   int v = g_gemm_variant;
   if (v < 0) {
     int st = 0;
-    static const bool t144_on = !(getenv("ASR_GEMM_T144") && getenv("ASR_GEMM_T144")[0] == '0');
-    if (t144_on && t144_fits(g, &st) && (st == 4 ? launch_t144<4>(g, s) : launch_t144<2>(g, s))) return;
+    if (g.ln_colsum) {
+      ASR_REQUIRE(gemm_ln_fusable(g), "gemm: the fused LayerNorm needs the 144-row-tile kernel (check gemm_ln_fusable first)");
+      ASR_REQUIRE(t144_stages(g) == 4 ? launch_t144<4>(g, s) : launch_t144<2>(g, s), "gemm: no LayerNorm-fused instance for this epilogue");
+      return;
+    }
+    if (t144_enabled() && t144_fits(g, &st) && (st == 4 ? launch_t144<4>(g, s) : launch_t144<2>(g, s))) return;
     v = 4;
   }
   if (v == 5 || v == 6) {

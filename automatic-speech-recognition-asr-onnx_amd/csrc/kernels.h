@@ -91,6 +91,7 @@ struct LfrArgs {
   int ld_out, feat, n_mels, lfr_m, lfr_n, n_prompt, n_rows;
   // affine_mode 1 (Paraformer, Export_Paraformer.py:483): x * cmvn_vars + bias_table[j] (bias_table = speech_pos), no prompts
   int affine_mode = 0;
+  bf16_t* out_lo = nullptr;    // optional bf16 copy of `out` (same leading dimension): the operand of the LayerNorm-fused projection
 };
 void launch_lfr_cmvn(const LfrArgs& a, hipStream_t s);
 
@@ -137,6 +138,11 @@ struct SanmFusedArgs {
   void* ctx; int ld_ctx;
   float* mem; int ld_mem;
   int n_rows_alloc;            // rows of h that may be read (rows past an utterance's end are read but never used)
+  // LayerNorm evaluated inside the projection: h holds the RAW rows x (bf16), row statistics over the first ln_dim columns
+  // are accumulated from the LDS tiles while the MFMA loop runs and q|k|v = rstd (x W^T - mean colsum) + b. Needs the
+  // LayerNorm affine folded into wqkv / bqkv; ln_colsum[n] = sum_k wqkv[n][k]. Null => h is already normalised.
+  const float* ln_colsum = nullptr; int ln_dim = 0; float ln_eps = 1e-5f;
+  const float2* ln_stats_in = nullptr; int ln_slots = 0;   // producer-side row statistics (GemmArgs::st_out layout); null => computed here
   int dbg = 0;
 };
 bool sanm_fused_supported(int max_T, int d_head, int n_heads, int d, int fsmn_taps, int K);

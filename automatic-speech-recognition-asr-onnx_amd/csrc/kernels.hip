@@ -121,8 +121,9 @@ __global__ void lfr_cmvn_kernel(const LfrArgs a) {
   const int m = blockIdx.x;
   float* o = a.out + (size_t)m * a.ld_out;
   const int u = a.row_utt[m];
+  bf16_t* olo = a.out_lo ? a.out_lo + (size_t)m * a.ld_out : nullptr;
   if (u < 0) {
-    for (int c = threadIdx.x; c < a.ld_out; c += blockDim.x) o[c] = 0.0f;
+    for (int c = threadIdx.x; c < a.ld_out; c += blockDim.x) { o[c] = 0.0f; if (olo) olo[c] = 0; }
     return;
   }
   const UttPlan up = a.plan[u];
@@ -149,6 +150,7 @@ __global__ void lfr_cmvn_kernel(const LfrArgs a) {
       }
     }
     o[c] = v;
+    if (olo) olo[c] = f32_to_bf16(v);
   }
 }
 

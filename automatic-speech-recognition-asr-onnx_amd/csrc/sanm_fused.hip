@@ -33,7 +33,9 @@ constexpr int FQS = 0;                      // q  [144][256 B]
 constexpr int FKS = FQS + FR * 256;         // k  [160][256 B]
 constexpr int FVS = FKS + FKEYS * 256;      // v^T [128][512 B] (32 slots of 8 keys, 20 used)
 constexpr int FLDS2 = FVS + FHD * 512;
-constexpr int FLDS = (2 * FSTAGE > FLDS2) ? 2 * FSTAGE : FLDS2;
+constexpr int FST_P = (2 * FSTAGE > FLDS2) ? 2 * FSTAGE : FLDS2;   // LayerNorm statistics: partial sums [4][144] float2
+constexpr int FST_F = FST_P + 4 * FR * 8;                          // (mean, rstd) [144] float2
+constexpr int FLDS = FST_F + FR * 8;
 constexpr int FTAPS = 11;
 
 __device__ __forceinline__ void wait_all_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -78,6 +80,17 @@ __global__ __launch_bounds__(768) void sanm_qkv_attn_kernel(const SanmFusedArgs 
   for (int i = 0; i < FMI; ++i) { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   const int nk = a.K / 64;
   const int a_lane = frow * 128, w_lane = FA_BYTES + (grp * FHD + sub * 32 + frow) * 128, key7 = frow & 7;
+  const bool ln = a.ln_colsum != nullptr, ln_here = ln && !a.ln_stats_in;     // ln_here: statistics accumulated from the LDS tiles
+  const int st_row = tid % FR, st_sg = tid / FR;          // statistics: threads < 576 own (row, two 16-byte K slots)
+  float st_s = 0.0f, st_ss = 0.0f;
+  if (ln && !ln_here && tid < FR) {         // producer-side statistics: finalise (mean, rstd) while the first stage flies
+    const float2* sp = a.ln_stats_in + (size_t)min(row0 + tid, a.n_rows_alloc - 1) * a.ln_slots;
+    const float2 ss = sum_row_partials(sp, a.ln_slots);
+    const float inv_d = 1.0f / (float)a.ln_dim;
+    const float mean = ss.x * inv_d;
+    const float var = fmaxf(ss.y * inv_d - mean * mean, 0.0f);
+    reinterpret_cast<float2*>(smem + FST_F)[tid] = make_float2(mean, rsqrtf(var + a.ln_eps));
+  }
   auto k_loop = [&](auto full_tag, auto swap_tag) {
     constexpr bool FULL = decltype(full_tag)::value;      // FULL: all 9 row fragments, straight-line MFMA body
     constexpr bool SWAP = decltype(swap_tag)::value;      // q / k waves: mfma(W, A); v waves: mfma(A, W)
@@ -88,6 +101,19 @@ __global__ __launch_bounds__(768) void sanm_qkv_attn_kernel(const SanmFusedArgs 
       if (kt + 1 < nk && !(a.dbg & 1)) stage((kt + 1) & 1, (kt + 1) * 64);
       if (a.dbg & 2) continue;
       const unsigned char* St = smem + (kt & 1) * FSTAGE;
+      if (ln_here && wave < FMI) {                         // row sums of the raw operand tile (VALU, beside the MFMA waves)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const uint4 raw = *reinterpret_cast<const uint4*>(St + st_row * 128 + (((2 * st_sg + q) ^ (st_row & 7)) << 4));
+          const uint32_t wds[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(wds[e] << 16), hi = __uint_as_float(wds[e] & 0xffff0000u);
+            st_s += lo + hi;
+            st_ss = fmaf(lo, lo, fmaf(hi, hi, st_ss));
+          }
+        }
+      }
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int sw = ((kk * 4 + fgrp) ^ key7) << 4;
@@ -117,7 +143,20 @@ __global__ __launch_bounds__(768) void sanm_qkv_attn_kernel(const SanmFusedArgs 
   } else {
     if (grp < 2) k_loop(std::false_type{}, std::true_type{}); else k_loop(std::false_type{}, std::false_type{});
   }
+  float2* st_part = reinterpret_cast<float2*>(smem + FST_P);
+  float2* st_fin = reinterpret_cast<float2*>(smem + FST_F);
+  if (ln_here && wave < FMI) st_part[st_sg * FR + st_row] = make_float2(st_s, st_ss);
   __syncthreads();                           // ring is dead: phase-2 images may overwrite it
+  if (ln_here) {
+    if (tid < FR) {
+      const float2 p0 = st_part[tid], p1 = st_part[FR + tid], p2 = st_part[2 * FR + tid], p3 = st_part[3 * FR + tid];
+      const float inv_d = 1.0f / (float)a.ln_dim;
+      const float mean = ((p0.x + p1.x) + (p2.x + p3.x)) * inv_d;
+      const float var = fmaxf(((p0.y + p1.y) + (p2.y + p3.y)) * inv_d - mean * mean, 0.0f);
+      st_fin[tid] = make_float2(mean, rsqrtf(var + a.ln_eps));
+    }
+    __syncthreads();
+  }
 
   if (grp < 2) {            // acc[i][j][r] = C[16 i + frow][32 sub + 16 j + 4 fgrp + r] -> row-major, 8-byte writes
     unsigned char* dst = smem + (grp == 0 ? FQS : FKS);
@@ -126,12 +165,19 @@ __global__ __launch_bounds__(768) void sanm_qkv_attn_kernel(const SanmFusedArgs 
     for (int j = 0; j < 2; ++j) {
       const int col = sub * 32 + j * 16 + fgrp * 4;
       const float4 b4 = *reinterpret_cast<const float4*>(bias + col);
+      float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ln) c4 = *reinterpret_cast<const float4*>(a.ln_colsum + grp * a.d + h * FHD + col);
 #pragma unroll
       for (int i = 0; i < FMI; ++i) {
         const int row = i * 16 + frow;
+        float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+        if (ln) {
+          const float2 mr = st_fin[row];
+          v0 = (v0 - mr.x * c4.x) * mr.y; v1 = (v1 - mr.x * c4.y) * mr.y; v2 = (v2 - mr.x * c4.z) * mr.y; v3 = (v3 - mr.x * c4.w) * mr.y;
+        }
         uint2 w;
-        w.x = pack_bf16x2(acc[i][j][0] + b4.x, acc[i][j][1] + b4.y);
-        w.y = pack_bf16x2(acc[i][j][2] + b4.z, acc[i][j][3] + b4.w);
+        w.x = pack_bf16x2(v0 + b4.x, v1 + b4.y);
+        w.y = pack_bf16x2(v2 + b4.z, v3 + b4.w);
         *reinterpret_cast<uint2*>(dst + row * 256 + (((col >> 3) ^ (row & 15)) << 4) + ((col >> 2) & 1) * 8) = w;
       }
     }
@@ -142,11 +188,17 @@ __global__ __launch_bounds__(768) void sanm_qkv_attn_kernel(const SanmFusedArgs 
     for (int j = 0; j < 2; ++j) {
       const int dcol = sub * 32 + j * 16 + frow;
       const float b = bias[dcol];
+      const float cs = ln ? a.ln_colsum[2 * a.d + h * FHD + dcol] : 0.0f;
 #pragma unroll
       for (int i = 0; i < FMI; ++i) {
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (ln) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float2 mr = st_fin[i * 16 + fgrp * 4 + r]; v[r] = (v[r] - mr.x * cs) * mr.y; }
+        }
         uint2 w;
-        w.x = pack_bf16x2(acc[i][j][0] + b, acc[i][j][1] + b);
-        w.y = pack_bf16x2(acc[i][j][2] + b, acc[i][j][3] + b);
+        w.x = pack_bf16x2(v[0] + b, v[1] + b);
+        w.y = pack_bf16x2(v[2] + b, v[3] + b);
         *reinterpret_cast<uint2*>(dst + dcol * 512 + (((2 * i + (fgrp >> 1)) ^ (dcol & 15)) << 4) + (fgrp & 1) * 8) = w;
       }
     }

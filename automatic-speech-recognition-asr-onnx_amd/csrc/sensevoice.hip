@@ -12,6 +12,7 @@ namespace {
 
 struct SvBlock {
   const float *ln1_g, *ln1_b, *bqkv, *wfsmn, *bfsmn, *ln2_g, *ln2_b, *b1, *b2;
+  const float *cqkv, *c1;       // column sums of wqkv / w1 (bf16 arenas with folded LayerNorm affines): LayerNorm inside the GEMM
   const void *wqkv, *wout, *w1, *w2;
   int in_size, kpad;
 };
@@ -46,6 +47,8 @@ struct SvSession : asr_session {
   const void* ctc_w = nullptr;
 
   // workspace (grow-only)
+  DeviceBuffer d_sta, d_stb;               // per-row (sum, sum of squares) partials of those copies, 32-column groups
+  DeviceBuffer d_x0lo, d_xalo, d_xblo;     // bf16 copies of the residual stream (operands of the LayerNorm-fused projections)
   DeviceBuffer d_plan, d_audio, d_mel, d_x0, d_xa, d_xb, d_h, d_qk, d_vt, d_ctx, d_mem, d_ffn, d_amax_v, d_amax_i, d_ids,
       d_tok, d_num, d_logits;
   void* h_plan = nullptr;   // pinned staging
@@ -54,7 +57,7 @@ struct SvSession : asr_session {
   size_t h_out_cap = 0;
 
   ~SvSession() override {
-    for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_x0, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx, &d_mem, &d_ffn,
+    for (DeviceBuffer* b : {&d_sta, &d_stb, &d_x0lo, &d_xalo, &d_xblo, &d_plan, &d_audio, &d_mel, &d_x0, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx, &d_mem, &d_ffn,
                             &d_amax_v, &d_amax_i, &d_ids, &d_tok, &d_num, &d_logits, &d_enc_lo, &d_ck, &d_cifa, &d_alpha, &d_dec, &d_x2,
                             &d_sa, &d_ffn32, &d_tplan})
       b->release();
@@ -69,6 +72,7 @@ struct SvSession : asr_session {
 
   // hipGraph replay of the forward pass (one graph per batch geometry)
   bool use_graph = true;
+  bool use_ln_alg = true;       // LayerNorm evaluated inside the projections from row statistics (ASR_LN_FUSED=0 disables)
   bool use_fused = true;        // fused q|k|v + attention + FSMN kernel for windows of <= 144 rows (ASR_SANM_FUSED=0 disables)
   hipGraphExec_t graph_exec = nullptr;
   uint64_t graph_key = 0, eager_key = 0, ws_epoch = 1;
@@ -160,6 +164,8 @@ void SvSession::init() {
     b.wfsmn = (const float*)arena.get(p + "wfsmn", ARENA_F32, {d, c.fsmn_kernel}).ptr;
     b.bfsmn = (const float*)arena.get(p + "bfsmn", ARENA_F32, {d}).ptr;
     b.wout = arena.get(p + "wout", wt, {d, d}).ptr;
+    b.cqkv = opt(p + "cqkv", {3 * d});
+    b.c1 = opt(p + "c1", {dff});
     b.ln2_g = opt(p + "ln2_g", {d});
     b.ln2_b = opt(p + "ln2_b", {d});
     b.w1 = arena.get(p + "w1", wt, {dff, d}).ptr;
@@ -193,10 +199,26 @@ void SvSession::enqueue(const SvRunCtx& r) {
     launch_fbank(fa, r.n_fb, stream);
   }
   save_tap("mel", d_mel.ptr, r.frames, c.n_mels, c.n_mels, 4);
+  // LayerNorm inside the projections (bf16 mode, 8 s windows): the residual stream is kept in f32 AND as its bf16 rounding;
+  // the fused attention kernel and the FFN-1 GEMM read the raw bf16 rows, accumulate the row statistics from their LDS tiles
+  // and apply rstd (x W^T - mean colsum(W)) + b in the epilogue -- no LayerNorm launches, no normalised copy in memory.
+  bool alg = false;
+  if constexpr (sizeof(T) == 2) {
+    const SvBlock& b1 = blocks[c.n_blocks - 1];
+    GemmArgs probe;
+    probe.M = rows; probe.N = dff; probe.K = d; probe.ln_dim = d; probe.ln_colsum = b1.c1; probe.act = ACT_RELU; probe.bias = b1.b1;
+    probe.out_lo = d_ffn.ptr; probe.A = d_xblo.ptr; probe.W = b1.w1;
+    alg = use_ln_alg && use_fused && b1.cqkv && b1.c1 && blocks[0].cqkv &&
+          sanm_fused_supported(r.max_T, c.d_head, c.n_heads, d, c.fsmn_kernel, blocks[0].kpad) && gemm_ln_fusable(probe);
+  }
+  bf16_t* x0lo = d_x0lo.as<bf16_t>();
+  bf16_t* xalo = d_xalo.as<bf16_t>();
+  bf16_t* xblo = d_xblo.as<bf16_t>();
   // ---- 2./3. LFR + CMVN + positions + prompts (Export_SenseVoice.py:280-287) ---------------
   {
     ProfScope ps(prof, "lfr_cmvn", stream);
     LfrArgs la;
+    if (alg) la.out_lo = x0lo;
     la.mel = d_mel.as<float>(); la.plan = r.dp; la.row_utt = r.d_row_utt; la.cmvn_means = cmvn_means; la.cmvn_vars = cmvn_vars;
     la.speech_pos = speech_pos; la.language_embed = language_embed; la.system_embed = system_embed;
     la.out = d_x0.as<float>(); la.ld_out = kpad0; la.feat = feat; la.n_mels = c.n_mels; la.lfr_m = c.lfr_m; la.lfr_n = c.lfr_n;
@@ -207,6 +229,10 @@ void SvSession::enqueue(const SvRunCtx& r) {
 
   // ---- 4. SANM blocks (Export_SenseVoice.py:227-269) ---------------------------------------
   const float* x_in = d_x0.as<float>();
+  const bf16_t* x_in_lo = x0lo;
+  const float2* st_in = nullptr;            // statistics of x_in_lo's rows when its producer wrote them
+  float2* sta = d_sta.as<float2>();
+  float2* stb = d_stb.as<float2>();
   int ld_in = kpad0;
   float* xa = d_xa.as<float>();
   float* xb = d_xb.as<float>();
@@ -218,7 +244,7 @@ void SvSession::enqueue(const SvRunCtx& r) {
   T* ffn = d_ffn.as<T>();
   for (int i = 0; i < c.n_blocks; ++i) {
     const SvBlock& b = blocks[i];
-    {
+    if (!alg) {
       ProfScope ps(prof, "layernorm", stream);
       launch_layernorm<T>(x_in, ld_in, rows, b.in_size, b.ln1_g, b.ln1_b, 1e-5f, h, b.kpad, b.kpad, stream);
     }
@@ -227,7 +253,8 @@ void SvSession::enqueue(const SvRunCtx& r) {
     if (fused) {
       ProfScope ps(prof, "sanm_fused", stream);
       SanmFusedArgs fa;
-      fa.h = h; fa.ld_h = b.kpad; fa.K = b.kpad; fa.wqkv = b.wqkv; fa.ldw = b.kpad; fa.bqkv = b.bqkv;
+      fa.h = h; fa.ld_h = b.kpad; fa.K = b.kpad;
+      if (alg) { fa.h = x_in_lo; fa.ln_colsum = b.cqkv; fa.ln_dim = b.in_size; fa.ln_stats_in = st_in; fa.ln_slots = d / 32; } fa.wqkv = b.wqkv; fa.ldw = b.kpad; fa.bqkv = b.bqkv;
       fa.wfsmn = b.wfsmn; fa.bfsmn = b.bfsmn; fa.plan = r.dp; fa.n_utts = r.batch; fa.n_heads = c.n_heads; fa.d = d;
       fa.ctx = ctx; fa.ld_ctx = d; fa.mem = mem; fa.ld_mem = d; fa.n_rows_alloc = Mpad;
       launch_sanm_qkv_attn(fa, stream);
@@ -264,9 +291,10 @@ void SvSession::enqueue(const SvRunCtx& r) {
       g.add = mem; g.ld_add = d;                                  // FSMN memory rides in as the GEMM's additive term (:244)
       if (b.in_size == d) { g.add2 = x_in; g.ld_add2 = ld_in; }    // residual only when in/out sizes match (:246-256)
       g.out_f32 = xb; g.ld_out_f32 = d;
+      if (alg) { g.out_lo = xblo; g.ld_out_lo = d; g.st_out = stb; }
       gemm(g);
     }
-    {
+    if (!alg) {
       ProfScope ps(prof, "layernorm", stream);
       launch_layernorm<T>(xb, d, rows, d, b.ln2_g, b.ln2_b, 1e-5f, h, d, d, stream);
     }
@@ -275,6 +303,7 @@ void SvSession::enqueue(const SvRunCtx& r) {
       GemmArgs g;
       g.A = h; g.lda = d; g.W = b.w1; g.ldw = d; g.M = rows; g.N = dff; g.K = d; g.bias = b.b1; g.act = ACT_RELU;
       g.out_lo = ffn; g.ld_out_lo = dff;
+      if (alg) { g.A = xblo; g.ln_colsum = b.c1; g.ln_dim = d; g.ln_stats_in = stb; g.ln_slots = d / 32; }
       gemm(g);
     }
     {
@@ -282,13 +311,17 @@ void SvSession::enqueue(const SvRunCtx& r) {
       GemmArgs g;
       g.A = ffn; g.lda = dff; g.W = b.w2; g.ldw = dff; g.M = rows; g.N = d; g.K = dff; g.bias = b.b2;
       g.add = xb; g.ld_add = d; g.out_f32 = xa; g.ld_out_f32 = d;
+      if (alg) { g.out_lo = xalo; g.ld_out_lo = d; g.st_out = sta; }
       gemm(g);
     }
     x_in = xa;
+    x_in_lo = xalo;
+    st_in = sta;
     ld_in = d;
     if (i == 0) save_tap("block0", xa, rows, d, d, 4);
     if (i == c.n_main - 1 && !paraformer) {
       ProfScope ps(prof, "layernorm", stream);
+      if (alg) { launch_layernorm<bf16_t>(xa, d, rows, d, after_g, after_b, 1e-5f, xalo, d, d, stream); st_in = nullptr; }   // operand copy of the normed stream
       launch_layernorm<float>(xa, d, rows, d, after_g, after_b, 1e-5f, xa, d, d, stream);
     }
   }
@@ -513,6 +546,13 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   grow(d_xa, (size_t)Mpad * d * 4);
   grow(d_xb, (size_t)Mpad * d * 4);
   grow(d_h, (size_t)Mpad * std::max(kpad0, d) * eT);
+  if (precision == ASR_PRECISION_BF16) {
+    grow(d_x0lo, (size_t)Mpad * kpad0 * 2);
+    grow(d_xalo, (size_t)Mpad * d * 2);
+    grow(d_xblo, (size_t)Mpad * d * 2);
+    grow(d_sta, (size_t)Mpad * (d / 32) * 8);
+    grow(d_stb, (size_t)Mpad * (d / 32) * 8);
+  }
   grow(d_qk, (size_t)Mpad * 2 * d * eT);
   grow(d_vt, (size_t)Mpad * d * eT);
   grow(d_ctx, (size_t)Mpad * d * eT);
@@ -614,6 +654,7 @@ extern "C" int asr_sensevoice_create(const asr_sensevoice_config* cfg, const voi
       s->cfg = *cfg;
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       if (const char* e = getenv("ASR_SANM_FUSED")) s->use_fused = !(e[0] == '0');
+      if (const char* e = getenv("ASR_LN_FUSED")) s->use_ln_alg = !(e[0] == '0');
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;
       s->arena.load(arena, arena_bytes, arena_mem, s->stream);
@@ -668,6 +709,7 @@ extern "C" int asr_paraformer_create(const asr_paraformer_config* cfg, const voi
       c.n_prompt = 0; c.n_languages = 0; c.max_audio_len = cfg->max_audio_len;
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       if (const char* e = getenv("ASR_SANM_FUSED")) s->use_fused = !(e[0] == '0');
+      if (const char* e = getenv("ASR_LN_FUSED")) s->use_ln_alg = !(e[0] == '0');
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;
       s->arena.load(arena, arena_bytes, arena_mem, s->stream);

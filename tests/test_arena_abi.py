@@ -60,8 +60,24 @@ def test_arena_layout_roundtrip():
     as_f32 = lambda u: (u.astype(np.uint32) << 16).view(np.float32)
     raw = ck["encoder.encoders.0.self_attn.linear_q_k_v.weight"]
     s = np.float32(cfg.d_head ** -0.25)
-    assert np.abs(as_f32(w[:2 * d]) - raw[:2 * d] * s).max() < 1e-2
-    assert np.abs(as_f32(w[2 * d:]) - raw[2 * d:]).max() < 1e-2
+    # bf16 (performance) arenas also absorb the LayerNorm affine: W' = W diag(gamma), b' = b + W beta, plus the column sums the
+    # engine needs to evaluate the normalisation inside the GEMM; f32 (verification) arenas keep the reference's layout
+    gamma, beta = ck["encoder.encoders.0.norm1.weight"], ck["encoder.encoders.0.norm1.bias"]
+    assert np.abs(as_f32(w[:2 * d]) - raw[:2 * d] * s * gamma[None, :]).max() < 1e-2
+    assert np.abs(as_f32(w[2 * d:]) - raw[2 * d:] * gamma[None, :]).max() < 1e-2
+    assert "blk1.ln1_g" not in recs and recs["blk1.cqkv"][1] == (3 * d,) and recs["blk1.c1"][1] == (cfg.d_ffn,)
+    dt, shape, off = recs["blk1.cqkv"]
+    cq = blob[off: off + 4 * shape[0]].view(np.float32)
+    assert np.allclose(cq, as_f32(w).astype(np.float64).sum(1), rtol=1e-6, atol=1e-6)
+    dt, shape, off = recs["blk1.bqkv"]
+    bq = blob[off: off + 4 * shape[0]].view(np.float32)
+    braw = ck["encoder.encoders.0.self_attn.linear_q_k_v.bias"].astype(np.float64) + raw.astype(np.float64) @ beta.astype(np.float64)
+    braw[:2 * d] *= float(s)
+    assert np.allclose(bq, braw, rtol=1e-5, atol=1e-6)
+    blob32 = arena.build_sensevoice_arena(cfg, ck, arena.PRECISION_F32)
+    n32 = struct.unpack("<8sIIQQ", blob32[:32].tobytes())[2]
+    names32 = {struct.unpack("<80s", blob32[32 + 128 * i: 112 + 128 * i].tobytes())[0].rstrip(b"\0").decode() for i in range(n32)}
+    assert "blk1.ln1_g" in names32 and "blk1.cqkv" not in names32
     dt, shape, off = recs["blk1.wfsmn"]
     wf = blob[off: off + 4 * shape[0] * shape[1]].view(np.float32).reshape(shape)
     rawf = ck["encoder.encoders.0.self_attn.fsmn_block.weight"][:, 0, :]

@@ -144,3 +144,43 @@ def test_fused_attention_half_equals_unfused_kernels(monkeypatch):
         assert np.array_equal(out["1"][2][r0:r0 + T], out["0"][2][r0:r0 + T])
     for a, b in zip(out["1"][0], out["0"][0]):
         assert np.array_equal(a, b)
+
+
+def test_layernorm_inside_projections_matches_separate_layernorm(monkeypatch):
+    """Batches of full 8 s windows evaluate both LayerNorms inside the projections (statistics from the LDS tiles, applied
+    as rstd (x W^T - mean colsum) + b): same function up to bf16 operand rounding (x rounded before instead of after the
+    normalisation) -- checked against the separate-kernel path and against the f32 oracle's error budget."""
+    cfg, ck = sensevoice_setup("sensevoice_small")
+    eng = sub("engine")
+    lens = [128000] * 8 + [127400]
+    audios = [kaldi_audio(500 + i, n) for i, n in enumerate(lens)]
+    langs = [i % 7 for i in range(len(lens))]
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ASR_LN_FUSED", flag)
+        sess = eng.SenseVoiceSession.from_checkpoint(cfg, ck, precision=BF16)
+        sess.taps(True)
+        toks = sess.run(audios, langs)
+        lg, ids = sess.tap("logits"), sess.tap("frame_ids", dtype=np.int32)[:, 0]
+        sess.taps(False)
+        sess.profile(True)
+        sess.profile_reset()
+        sess.run(audios, langs)
+        out[flag] = (toks, lg, ids, sess.profile_read())
+    assert "layernorm" in out["0"][3] and out["0"][3]["layernorm"]["launches"] > 2 * cfg.n_blocks
+    assert out["1"][3]["layernorm"]["launches"] <= 4                     # after_norm (x2) + tp_norm only
+    rows = sess.utterance_rows(lens)
+    orc = SenseVoiceOracle(cfg, ck)
+    agree = total = 0
+    for a, lang, (r0, T) in zip(audios[:3], langs[:3], rows[:3]):
+        st = orc.stages(a, lang)
+        for flag in ("1", "0"):
+            assert np.abs(out[flag][1][r0:r0 + T] - st["logits"]).max() < 0.25
+        srt = np.sort(st["logits"], axis=1)
+        safe = (srt[:, -1] - srt[:, -2]) > 0.5
+        assert np.array_equal(out["1"][2][r0:r0 + T][safe], st["frame_ids"][safe])
+    for (r0, T) in rows:
+        assert np.abs(out["1"][1][r0:r0 + T] - out["0"][1][r0:r0 + T]).max() < 0.2
+        agree += int((out["1"][2][r0:r0 + T] == out["0"][2][r0:r0 + T]).sum())
+        total += T
+    assert agree / total > 0.95

@@ -3,7 +3,7 @@ import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 eng = importlib.import_module("automatic-speech-recognition-asr-onnx_amd.engine")
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 9216
-shapes = [("qkv", 1536, 512, 4), ("out", 512, 512, 3), ("ffn1", 2048, 512, 1), ("ffn2", 512, 2048, 2)]
+shapes = [("out", 512, 512, 3), ("out+lo+st", 512, 512, 6), ("ffn1", 2048, 512, 1), ("ffn1+ln", 2048, 512, 5), ("ffn2", 512, 2048, 2)]
 variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3, 4]
 for name, N, K, epi in shapes:
     row = []
@@ -13,4 +13,4 @@ for name, N, K, epi in shapes:
             row.append(f"v{v}: {best*1e3:7.1f} us {2*M*N*K/best/1e9:7.0f} TF")
         except Exception:
             row.append(f"v{v}: n/a")
-    print(f"{name:5s} M={M} N={N} K={K} | " + " | ".join(row), flush=True)
+    print(f"{name:10s} M={M} N={N} K={K} | " + " | ".join(row), flush=True)

@@ -9,11 +9,11 @@
 //           covers all 9 row fragments (A fragments are shared by its 2 column fragments: 11 LDS reads per 18 MFMA).
 //           q / k waves use the swapped operand order (4 consecutive columns per lane -> row-major LDS image), v waves
 //           the plain order (4 consecutive rows per lane -> V^T image, time contiguous).
-//  phase 2  waves 0..8: flash-style attention for query tile w (S^T = K Q^T so the soft-max is lane local, P is
-//           directly the B fragment of O^T = V^T P^T); waves 9..10: FSMN (one channel per lane, sliding 11-tap window
-//           over the V^T rows in LDS) with row-major coalesced f32 stores.
-// Arithmetic order equals the unfused kernels' (same K order, same 32-key online soft-max steps, same tap order),
-// so both paths produce the same bits.
+//  phase 2  all threads: FSMN (thread = channel x 24-step segment, 11 taps from the V^T image, row-major coalesced f32
+//           stores); waves 0..8: attention for query tile w -- S^T = K Q^T so the soft-max is lane local and P is directly
+//           the B fragment of O^T = V^T P^T; with <= 160 keys all scores stay in registers: one soft-max pass, no rescale.
+// The projection and the FSMN reproduce the separate kernels bit for bit; the attention differs from the chunked
+// online-softmax kernel only in summation order.
 #include <type_traits>
 #include "kernels.h"
 
@@ -215,7 +215,48 @@ __global__ __launch_bounds__(768) void sanm_qkv_attn_kernel(const SanmFusedArgs 
 
   // ---------------------------------------------------------------- phase 2
   if (a.dbg & 4) return;
-  if (wave < FMI) {                          // attention, query tile `wave`
+  // ---- FSMN memory on ALL threads: thread = (channel, 24-step time segment); 5 slots of 8 steps (own 3 + one halo slot
+  //      each side) come from the V^T image, 11 taps per output, row-major coalesced f32 stores (lanes = channels)
+  if (!(a.dbg & 16)) {
+    constexpr int PAD = (FTAPS - 1) / 2;
+    const int c = tid & (FHD - 1), seg = tid >> 7, cg = h * FHD + c;      // 6 segments x 24 steps = 144
+    const int t0 = seg * 24, T16 = n_act * 16;
+    if (t0 < T16) {
+      const unsigned char* vrow = smem + FVS + c * 512;
+      float wc[FTAPS];
+#pragma unroll
+      for (int j = 0; j < FTAPS; ++j) wc[j] = a.wfsmn[cg * FTAPS + j];
+      const float bc = a.bfsmn[cg];
+      float x[40];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const int sl = seg * 3 - 1 + q;                       // slot index, 8 steps each; -1 and >= 18 are outside the window
+        if (sl < 0 || sl * 8 >= T) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[q * 8 + e] = 0.0f;
+        } else {
+          const uint4 raw = *reinterpret_cast<const uint4*>(vrow + ((sl ^ (c & 15)) << 4));
+          const uint32_t wds[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            x[q * 8 + 2 * e] = (sl * 8 + 2 * e < T) ? __uint_as_float(wds[e] << 16) : 0.0f;
+            x[q * 8 + 2 * e + 1] = (sl * 8 + 2 * e + 1 < T) ? __uint_as_float(wds[e] & 0xffff0000u) : 0.0f;
+          }
+        }
+      }
+      float* out = a.mem + (size_t)(row0 + t0) * a.ld_mem + cg;
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        float accv = bc;
+#pragma unroll
+        for (int j = 0; j < FTAPS; ++j) accv = fmaf(wc[j], x[8 + i + j - PAD], accv);
+        if (t0 + i < T16) out[(size_t)i * a.ld_mem] = (t0 + i < T) ? accv : 0.0f;
+      }
+    }
+  }
+  // ---- attention, waves 0..8 = query tile. T <= 160 keys: all scores of a tile live in registers (10 independent MFMA
+  //      accumulators), so ONE soft-max pass (no running max / rescale) and then 8 independent P.V chains
+  if (wave < FMI) {
     if (a.dbg & 8) return;
     const int q0 = wave * 16;
     if (q0 >= T) return;
@@ -223,62 +264,74 @@ __global__ __launch_bounds__(768) void sanm_qkv_attn_kernel(const SanmFusedArgs 
     const unsigned char* Ks = smem + FKS;
     const unsigned char* Vs = smem + FVS;
     const int fq = frow, g = fgrp;
-    bf16x8_t qf[FHD / 32];
-    f32x4_t ot[FHD / 16];
     const int qrow = q0 + fq;
+    const int n_sub = (T + 31) >> 5;                          // 32-key sub-tiles in use (<= 5)
+    bf16x8_t qf[FHD / 32];
 #pragma unroll
     for (int ks = 0; ks < FHD / 32; ++ks)
       qf[ks] = *reinterpret_cast<const bf16x8_t*>(Qs + qrow * 256 + (((ks * 4 + g) ^ (qrow & 15)) << 4));
+    f32x4_t st[5][2];
 #pragma unroll
-    for (int dt = 0; dt < FHD / 16; ++dt) ot[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.0f;
-    for (int s = 0; s * 32 < T; ++s) {
-      f32x4_t st0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, st1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      const int key0 = s * 32 + fq, key1 = key0 + 16;
+    for (int s = 0; s < 5; ++s) { st[s][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; st[s][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-      for (int ks = 0; ks < FHD / 32; ++ks) {
-        const int c = ks * 4 + g;
-        const bf16x8_t kf0 = *reinterpret_cast<const bf16x8_t*>(Ks + key0 * 256 + ((c ^ (key0 & 15)) << 4));
-        const bf16x8_t kf1 = *reinterpret_cast<const bf16x8_t*>(Ks + key1 * 256 + ((c ^ (key1 & 15)) << 4));
-        st0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[ks], st0, 0, 0, 0);
-        st1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[ks], st1, 0, 0, 0);
-      }
-      const int kb = s * 32 + g * 4;
-      float sv[8] = {st0[0], st0[1], st0[2], st0[3], st1[0], st1[1], st1[2], st1[3]};
-      float mx = -INFINITY;
+    for (int s = 0; s < 5; ++s) {
+      if (s < n_sub) {
+        const int key0 = s * 32 + fq, key1 = key0 + 16;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int key = kb + (r & 3) + ((r >> 2) << 4);
-        if (key >= T) sv[r] = -INFINITY;
-        mx = fmaxf(mx, sv[r]);
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __expf(m_run - m_new);
-      float psum = 0.0f, p[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) { p[r] = __expf(sv[r] - m_new); psum += p[r]; }
-      l_run = l_run * alpha + psum;
-      m_run = m_new;
-      union { bf16x8_t v; uint32_t w[4]; } pf;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pf.w[r] = pack_bf16x2(p[2 * r], p[2 * r + 1]);
-#pragma unroll
-      for (int dt = 0; dt < FHD / 16; ++dt) {
-        const int d = dt * 16 + fq;
-        const unsigned char* vr = Vs + d * 512 + (g & 1) * 8;
-        union { bf16x8_t v; uint2 h2[2]; } vf;
-        vf.h2[0] = *reinterpret_cast<const uint2*>(vr + (((s * 4 + (g >> 1)) ^ (d & 15)) << 4));
-        vf.h2[1] = *reinterpret_cast<const uint2*>(vr + (((s * 4 + 2 + (g >> 1)) ^ (d & 15)) << 4));
-        f32x4_t o = ot[dt];
-        o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
-        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o, 0, 0, 0);
+        for (int ks = 0; ks < FHD / 32; ++ks) {
+          const int c = ks * 4 + g;
+          const bf16x8_t kf0 = *reinterpret_cast<const bf16x8_t*>(Ks + key0 * 256 + ((c ^ (key0 & 15)) << 4));
+          const bf16x8_t kf1 = *reinterpret_cast<const bf16x8_t*>(Ks + key1 * 256 + ((c ^ (key1 & 15)) << 4));
+          st[s][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[ks], st[s][0], 0, 0, 0);
+          st[s][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[ks], st[s][1], 0, 0, 0);
+        }
       }
     }
-    float l = l_run + __shfl_xor(l_run, 16, 64);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+      for (int hlf = 0; hlf < 2; ++hlf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = s * 32 + hlf * 16 + g * 4 + r;
+          if (key >= T) st[s][hlf][r] = -INFINITY;
+          mx = fmaxf(mx, st[s][hlf][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float l = 0.0f;
+    bf16x8_t pf[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      float p[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { p[r] = __expf(st[s][r >> 2][r & 3] - mx); l += p[r]; }
+      union { bf16x8_t v; uint32_t w[4]; } u8;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) u8.w[r] = pack_bf16x2(p[2 * r], p[2 * r + 1]);
+      pf[s] = u8.v;
+    }
+    l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
+    f32x4_t ot[FHD / 16];
+#pragma unroll
+    for (int dt = 0; dt < FHD / 16; ++dt) ot[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      if (s < n_sub) {
+#pragma unroll
+        for (int dt = 0; dt < FHD / 16; ++dt) {
+          const int d = dt * 16 + fq;
+          const unsigned char* vr = Vs + d * 512 + (g & 1) * 8;
+          union { bf16x8_t v; uint2 h2[2]; } vf;
+          vf.h2[0] = *reinterpret_cast<const uint2*>(vr + (((s * 4 + (g >> 1)) ^ (d & 15)) << 4));
+          vf.h2[1] = *reinterpret_cast<const uint2*>(vr + (((s * 4 + 2 + (g >> 1)) ^ (d & 15)) << 4));
+          ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[s], ot[dt], 0, 0, 0);
+        }
+      }
+    }
     if (qrow < T) {
       bf16_t* op = reinterpret_cast<bf16_t*>(a.ctx) + (size_t)(row0 + qrow) * a.ld_ctx + h * FHD + g * 4;
 #pragma unroll
@@ -288,48 +341,6 @@ __global__ __launch_bounds__(768) void sanm_qkv_attn_kernel(const SanmFusedArgs 
         w.y = pack_bf16x2(ot[dt][2] * inv, ot[dt][3] * inv);
         *reinterpret_cast<uint2*>(op + dt * 16) = w;
       }
-    }
-  } else if (wave < FMI + 2) {               // FSMN memory: lane = channel, sliding window along time
-    if (a.dbg & 16) return;
-    constexpr int PAD = (FTAPS - 1) / 2;
-    const int c = (wave - FMI) * 64 + lane, cg = h * FHD + c;
-    const unsigned char* vrow = smem + FVS + c * 512;
-    float wc[FTAPS];
-#pragma unroll
-    for (int j = 0; j < FTAPS; ++j) wc[j] = a.wfsmn[cg * FTAPS + j];
-    const float bc = a.bfsmn[cg];
-    float* out = a.mem + (size_t)row0 * a.ld_mem + cg;
-    const int T16 = n_act * 16;
-    float x[24];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = 0.0f;
-    auto load_slot = [&](int s, float* dstv) {          // 8 time steps t = 8 s .. 8 s + 7, zero outside [0, T)
-      if (s * 8 >= T) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dstv[i] = 0.0f;
-        return;
-      }
-      const uint4 raw = *reinterpret_cast<const uint4*>(vrow + ((s ^ (c & 15)) << 4));
-      const uint32_t wds[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        dstv[2 * i] = (s * 8 + 2 * i < T) ? __uint_as_float(wds[i] << 16) : 0.0f;
-        dstv[2 * i + 1] = (s * 8 + 2 * i + 1 < T) ? __uint_as_float(wds[i] & 0xffff0000u) : 0.0f;
-      }
-    };
-    load_slot(0, x + 8);
-    for (int s = 0; s * 8 < T16; ++s) {
-      load_slot(s + 1, x + 16);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float accv = bc;
-#pragma unroll
-        for (int j = 0; j < FTAPS; ++j) accv = fmaf(wc[j], x[8 + i + j - PAD], accv);
-        const int t = s * 8 + i;
-        out[(size_t)t * a.ld_mem] = (t < T) ? accv : 0.0f;
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) x[i] = x[i + 8];
     }
   }
 }

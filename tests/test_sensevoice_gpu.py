@@ -118,8 +118,9 @@ def test_run_is_deterministic_and_rejects_bad_input():
 
 
 def test_fused_attention_half_equals_unfused_kernels(monkeypatch):
-    """Windows of <= 144 rows run q|k|v projection + attention + FSMN as ONE kernel per (utterance, head); the arithmetic
-    order is that of the separate GEMM / attention / FSMN kernels, so both paths must give the same logits and ids."""
+    """Windows of <= 144 rows run q|k|v projection + attention + FSMN as ONE kernel per (utterance, head). Projection and
+    FSMN reproduce the separate kernels; the attention keeps all <= 160 scores in registers (one soft-max pass instead of the
+    chunked online soft-max), so results agree up to f32 summation order / bf16 re-rounding of the probabilities."""
     cfg, ck = sensevoice_setup("sensevoice_small")
     eng = sub("engine")
     lens = [128000, 38880, 127000, 16000, 7777, 128000]            # T = 137, 44, 136, 20, 12, 137 (ragged, incl. odd tails)
@@ -139,11 +140,13 @@ def test_fused_attention_half_equals_unfused_kernels(monkeypatch):
         out[flag] = (toks, b0, lg, set(sess.profile_read()))
     assert "sanm_fused" in out["1"][3] and "sanm_fused" not in out["0"][3]
     rows = sess.utterance_rows(lens)
+    same = total = 0
     for (r0, T) in rows:
-        assert np.array_equal(out["1"][1][r0:r0 + T], out["0"][1][r0:r0 + T])
-        assert np.array_equal(out["1"][2][r0:r0 + T], out["0"][2][r0:r0 + T])
-    for a, b in zip(out["1"][0], out["0"][0]):
-        assert np.array_equal(a, b)
+        assert np.abs(out["1"][1][r0:r0 + T] - out["0"][1][r0:r0 + T]).max() < 0.02          # after block 0
+        assert np.abs(out["1"][2][r0:r0 + T] - out["0"][2][r0:r0 + T]).max() < 0.1           # logits after 70 blocks
+        same += int((out["1"][2][r0:r0 + T].argmax(1) == out["0"][2][r0:r0 + T].argmax(1)).sum())
+        total += T
+    assert same / total > 0.97
 
 
 def test_layernorm_inside_projections_matches_separate_layernorm(monkeypatch):

@@ -39,6 +39,7 @@ struct GemmArgs {
   // from its LDS tiles in every column tile.
   float2* st_out = nullptr;
   const float2* ln_stats_in = nullptr; int ln_slots = 0;
+  int group_m = 0;   // (set by the launcher) row tiles walked per column tile before moving on: keeps wide weight matrices L2-resident
   int dbg = 0;   // tuning ablations (bench hook only): 1 = no refills, 2 = no MFMA, 4 = no epilogue
 };
 

@@ -246,7 +246,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_pipe(const GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = g.N / BN_;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+  int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+  if (g.group_m > 1) {       // wide N: consecutive workgroups share a W column tile over group_m row tiles (W is fetched once per group)
+    const int tiles_m = gridDim.x / tiles_n, gsz = g.group_m * tiles_n;
+    const int grp = tile / gsz, first = grp * g.group_m, local = tile - grp * gsz;
+    const int rows_in = min(g.group_m, tiles_m - first);
+    tile_m = first + local % rows_in;
+    tile_n = local / rows_in;
+  }
 
   // staging: one wave-instruction moves 8 rows x 128 B (8 slots of 16 B) = 1 KiB, lane-linear in LDS
   const int srow = lane >> 3;
@@ -754,7 +761,9 @@ void launch_pipe_inst(const GemmArgs& g, hipStream_t s) {
     attr_set = true;
   }
   const int grid = ((g.M + BM - 1) / BM) * (g.N / BN_);
-  hipLaunchKernelGGL((gemm_bf16_pipe<BN_, STAGES, ACT, EPI, SWAP>), dim3(grid), dim3(256), lds, s, g);
+  GemmArgs gg = g;
+  if ((size_t)g.N * g.K * 2 > ((size_t)3 << 20) && g.M > 2 * BM) gg.group_m = 8;     // weights beyond an XCD's L2: group the row tiles
+  hipLaunchKernelGGL((gemm_bf16_pipe<BN_, STAGES, ACT, EPI, SWAP>), dim3(grid), dim3(256), lds, s, gg);
   HIP_CHECK(hipGetLastError());
 }
 

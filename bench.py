@@ -50,6 +50,17 @@ def sensevoice_algorithmic_flops(cfg, lengths):
     return out
 
 
+def hbm_traffic(kernel):
+    """Memory-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_hbm_traffic.json: FETCH_SIZE
+    doubled per the gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE); None when no counter run is on file."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            rec = json.load(f)["kernels"].get(kernel)
+        return None if rec is None else {"bytes_per_launch": rec["bytes_per_launch"], "unit": "B", "source": "profiles/r01_hbm_traffic.json"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, ck, audio_np, budget_s=15.0):
     """The oracle (torch CPU f32 restatement of the reference graph, batch 1 like the reference) timed on this
     host's cores on a bounded sample of the same workload. CHECKER ONLY -- never on the product path."""
@@ -182,6 +193,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = audio_s_per_step * args.steps / elapsed
         flops = sensevoice_algorithmic_flops(cfg, lengths)
+        if "sanm_fused" in prof:      # q|k|v projection + attention + FSMN run as one kernel per (utterance, head)
+            flops["sanm_fused"] = flops["gemm_qkv"] + flops["attention"] + flops["fsmn"]
         kernels = {}
         for name, p in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
             ms = p["total_ms"] / args.profile_steps
@@ -207,9 +220,10 @@ def main():
             "rtf": round(elapsed / (audio_s_per_step * args.steps), 8),
             "audio_s_per_s_per_gpu": round(value / world, 1),
             "model_tflops_per_gpu": round(total_flops / (ms_per_step * 1e-3) / 1e12, 1),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_128x128x64 (SANM qkv/out/ffn1/ffn2 launches)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_t144 (SANM out-proj / ffn1 / ffn2 launches, 144 x 128 tiles; the q|k|v projection "
+                                                     "runs inside sanm_qkv_attn_kernel and is listed under kernels.sanm_fused)",
                          "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": hbm_traffic("gemm_bf16_t144"),
                          "launches_per_step": gemm_launches, "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),
                          "algorithmic_gflop_per_step": round(gemm_flops / 1e9, 1)},
             "kernels": kernels,

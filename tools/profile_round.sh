@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round profile: kernel-trace stats + two PMC passes (FETCH_SIZE, WRITE_SIZE) of the headline bench, plus the bench lines.
+set -x
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof
+mkdir -p $OUT
+cd $R
+python bench.py --steps 20 > $OUT/bench_sensevoice.json 2> $OUT/bench_sensevoice.err
+python bench.py --workload paraformer --steps 10 > $OUT/bench_paraformer.json 2> $OUT/bench_paraformer.err
+python bench.py --workload whisper --steps 3 --warmup 1 > $OUT/bench_whisper.json 2> $OUT/bench_whisper.err
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+find $OUT -name "*.csv" | head -30
+for f in $(find $OUT/pmc_fetch $OUT/pmc_write -name "*counter_collection.csv"); do echo $f; head -3 $f; wc -l $f; done
+find $OUT -name "*kernel_trace.csv" -size +20M -delete
+du -sh $OUT

@@ -77,6 +77,14 @@ void launch_decode_attention(const DecAttnArgs& a, int batch, hipStream_t s);
 // ids[r] = first arg-max over n < n_valid of logits[r][n] + (extra ? extra[n] : 0)
 void launch_argmax_rows(const float* logits, int ld, int rows, int n_valid, const float* extra, int32_t* ids, hipStream_t s);
 
+// ---- penalty-greedy head (Export_Whisper.py:312-325 APPLY_PENALTY + :243-251 GREEDY_SEARCH): logits of the last `range` saved
+// ids are multiplied by `value` once `range` ids are saved (the host's rule, Inference_Whisper_ONNX.py:630-632); gather first,
+// scatter second, so a repeated id is scaled once. In place on the f32 logits. n_saved lives on the device (graph replay).
+void launch_apply_penalty(float* logits, int ld, int rows, const int32_t* save_ids, int ld_save, const int32_t* n_saved,
+                          int range, float value, hipStream_t s);
+// save_ids[r][*n_saved] = next[r] (the counter itself is advanced by launch_add_scalar afterwards)
+void launch_append_ids(const int32_t* next, int rows, int32_t* save_ids, int ld_save, const int32_t* n_saved, hipStream_t s);
+
 // ---- LFR stacking + CMVN + positions + prompt rows (Export_SenseVoice.py:280-287)
 struct LfrArgs {
   const float* mel;            // [frames][n_mels]

@@ -761,6 +761,26 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
 }
 
 
+__global__ __launch_bounds__(64) void apply_penalty_kernel(float* __restrict__ logits, int ld, const int32_t* __restrict__ save_ids,
+                                                           int ld_save, const int32_t* __restrict__ n_saved, int range, float value) {
+  const int n = *n_saved;
+  if (n < range) return;                       // multiplier is 1.0 until the window is full
+  float* x = logits + (size_t)blockIdx.x * ld;
+  const int32_t* sv = save_ids + (size_t)blockIdx.x * ld_save + (n - range);
+  const int i = threadIdx.x;                   // range <= 64: every original value is gathered before the first write
+  const int id = i < range ? sv[i] : -1;
+  const float v = id >= 0 ? x[id] : 0.0f;
+  __syncthreads();
+  if (id >= 0) x[id] = v * value;
+}
+
+__global__ void append_ids_kernel(const int32_t* __restrict__ next, int rows, int32_t* __restrict__ save_ids, int ld_save,
+                                  const int32_t* __restrict__ n_saved) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = *n_saved;
+  if (r < rows && n < ld_save) save_ids[(size_t)r * ld_save + n] = next[r];
+}
+
 // ------------------------------------------------------------------------------------ Paraformer predictor / decoder helpers
 template <typename T>
 __global__ void shift3_kernel(const T* __restrict__ x, int d, const UttPlan* __restrict__ plan, const int32_t* __restrict__ row_utt,
@@ -1003,6 +1023,18 @@ template void launch_decode_attention<bf16_t>(const DecAttnArgs&, int, hipStream
 
 void launch_argmax_rows(const float* logits, int ld, int rows, int n_valid, const float* extra, int32_t* ids, hipStream_t s) {
   hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, s, logits, ld, n_valid, extra, ids);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_apply_penalty(float* logits, int ld, int rows, const int32_t* save_ids, int ld_save, const int32_t* n_saved,
+                          int range, float value, hipStream_t s) {
+  ASR_REQUIRE(range >= 1 && range <= 64 && range <= ld_save, "apply_penalty: range %d (1..64)", range);
+  hipLaunchKernelGGL(apply_penalty_kernel, dim3(rows), dim3(64), 0, s, logits, ld, save_ids, ld_save, n_saved, range, value);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_append_ids(const int32_t* next, int rows, int32_t* save_ids, int ld_save, const int32_t* n_saved, hipStream_t s) {
+  hipLaunchKernelGGL(append_ids_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, next, rows, save_ids, ld_save, n_saved);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -39,6 +39,9 @@ struct WhSession : asr_session {
   DeviceBuffer d_plan, d_audio, d_mel, d_blkmax, d_x0, d_h1, d_xa, d_xb, d_xc, d_h, d_qk, d_vt, d_ctx, d_ffn, d_cross;
   // decoder state
   DeviceBuffer d_kc, d_vc, d_ids, d_next, d_logits, d_dx, d_dqkv, d_dtok, d_hist;
+  DeviceBuffer d_save, d_nsaved;       // penalty-greedy: generated ids per sequence [B][max_target_positions] + their count
+  float penalty_value = 1.0f;          // 1.0 = plain greedy (REPEAT_PENALTY, Inference_Whisper_ONNX.py:78)
+  int penalty_range = 20;
   bool use_graph = true;
   hipGraphExec_t dec_graph = nullptr;
   uint64_t dec_key = 0, dec_eager_key = 0, ws_epoch = 1;
@@ -47,7 +50,7 @@ struct WhSession : asr_session {
 
   ~WhSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_x0, &d_h1, &d_xa, &d_xb, &d_xc, &d_h, &d_qk, &d_vt, &d_ctx,
-                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist})
+                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved})
       b->release();
     if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
     for (auto& kv : taps) kv.second.buf.release();
@@ -419,8 +422,16 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
       g.A = hl; g.lda = d;
     }
     gemm(g);
+    const bool penalised = penalty_value != 1.0f;
+    if (penalised && !is_prefill)          // APPLY_PENALTY over the saved ids; the history is empty at the prefill (:312-325)
+      launch_apply_penalty(d_logits.as<float>(), vpad, B, d_save.as<int32_t>(), c.max_target_positions, d_nsaved.as<int32_t>(),
+                           penalty_range, penalty_value, stream);
     // BEGIN_SUPPRESS (-inf on begin_suppress_tokens) applies to the head after a prefill only (:228-240)
     launch_argmax_rows(d_logits.as<float>(), vpad, B, c.vocab, is_prefill ? begin : nullptr, d_next.as<int32_t>(), stream);
+    if (penalised) {                       // GREEDY_SEARCH appends its pick to the history (:243-251)
+      launch_append_ids(d_next.as<int32_t>(), B, d_save.as<int32_t>(), c.max_target_positions, d_nsaved.as<int32_t>(), stream);
+      launch_add_scalar(d_nsaved.as<int32_t>(), 1, stream);
+    }
     launch_add_scalar(d_hist.as<int32_t>(), n, stream);
   }
 }
@@ -443,6 +454,8 @@ void WhSession::step(const int32_t* ids_host, int n, bool is_prefill, int32_t* n
   grow(d_ids, (size_t)B * 8 * 4);
   grow(d_next, (size_t)B * 4);
   grow(d_hist, 256);
+  grow(d_nsaved, 256);
+  grow(d_save, (size_t)B * c.max_target_positions * 4);
   grow(d_logits, (size_t)Bp * vpad * 4);
   grow(d_dx, (size_t)3 * Rp * d * 4);                  // three f32 residual-stream buffers
   grow(d_dqkv, (size_t)Rp * (3 * d + d + d + dff + d) * eT + (size_t)Bp * d * eT);
@@ -459,7 +472,10 @@ void WhSession::step(const int32_t* ids_host, int n, bool is_prefill, int32_t* n
     ASR_REQUIRE(n == 1, "whisper: device-resident ids feed single-token decode steps only");
     ids_dev = d_next.as<int32_t>();
   }
-  if (is_prefill) HIP_CHECK(hipMemsetAsync(d_hist.ptr, 0, 4, stream));
+  if (is_prefill) {
+    HIP_CHECK(hipMemsetAsync(d_hist.ptr, 0, 4, stream));
+    HIP_CHECK(hipMemsetAsync(d_nsaved.ptr, 0, 4, stream));
+  }
   // single-token steps fed from the device are position independent => one graph for all of them
   const bool graphable = use_graph && !ids_host && n == 1 && !taps_enabled && !prof.enabled;
   const uint64_t key = ((uint64_t)B << 32) ^ (uint64_t)Mpad ^ (ws_epoch << 48) ^ (uint64_t)(uintptr_t)stream;
@@ -552,6 +568,19 @@ extern "C" int asr_whisper_decode(asr_session* s, const int32_t* ids, int32_t* n
     WhSession* w = static_cast<WhSession*>(s);
     if (w->precision == ASR_PRECISION_BF16) w->step<bf16_t>(ids, 1, false, next_ids_out, logits_out);
     else w->step<float>(ids, 1, false, next_ids_out, logits_out);
+  });
+}
+
+extern "C" int asr_whisper_set_penalty(asr_session* s, float repeat_penalty, int penalty_range) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 2, "whisper_set_penalty: not a Whisper session");
+    ASR_REQUIRE(repeat_penalty > 0.0f && penalty_range >= 1 && penalty_range <= 64, "whisper_set_penalty: value %g range %d", repeat_penalty, penalty_range);
+    WhSession* w = static_cast<WhSession*>(s);
+    if (w->penalty_value != repeat_penalty || w->penalty_range != penalty_range) {
+      w->penalty_value = repeat_penalty;
+      w->penalty_range = penalty_range;
+      ++w->ws_epoch;                       // the captured decode graph bakes the head in: re-capture
+    }
   });
 }
 

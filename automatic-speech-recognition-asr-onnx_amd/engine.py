@@ -296,6 +296,10 @@ class WhisperSession(_Session):
         _lib.check(_lib.load().asr_whisper_generate(self._h, max_new, eos_id, _ip(tok), _ip(n)))
         return [tok[b, :n[b]].copy() for b in range(self.batch)]
 
+    def set_penalty(self, repeat_penalty: float = 1.0, penalty_range: int = 20):
+        """Decode head: 1.0 = plain arg-max; else penalty-greedy (APPLY_PENALTY + GREEDY_SEARCH, the reference host's default)."""
+        _lib.check(_lib.load().asr_whisper_set_penalty(self._h, C.c_float(repeat_penalty), int(penalty_range)))
+
     def cross_kv(self, lengths_pos: Sequence[int]):
         """Debug: (K, V) per utterance as (L, H, T, 64) arrays from the 'cross' tap (f32 mode)."""
         cfg = self.cfg

@@ -7,7 +7,8 @@
                             language-token logits (:793-798); no-speech gate: softmax(logits + 128 on suppressed
                             ids)[<|nospeech|>] >= 0.6 => skip (:799-805, NO_SPEECH_DETECTION Export_Whisper.py:334-348)
   prefill                 = _prefill (:437-490) with [SOT, language, task, <|notimestamps|>] (:807)
-  decode                  = _decode_tokens (:584-663), plain greedy (REPEAT_PENALTY = 1.0), limit MAX_SEQ_LEN - 4 (:821)
+  decode                  = _decode_tokens (:584-663): greedy (REPEAT_PENALTY = 1.0) or penalty-greedy (any other value; the
+                            multiplier applies once PENALTY_RANGE ids were generated, :630-632), limit MAX_SEQ_LEN - 4 (:821)
 Batch extension: a list of clips is one batch; language detection / no-speech are per clip.
 """
 from __future__ import annotations
@@ -65,7 +66,7 @@ def no_speech_probability(logits: np.ndarray, suppress_tokens: Sequence[int], no
 class WhisperTranscriber:
     def __init__(self, cfg: WhisperConfig, session: WhisperSession, suppress_tokens=None, task: str = "transcribe",
                  detect_language: bool = True, no_speech_detection: bool = True, no_speech_threshold: float = 0.6,
-                 remove_repeats: bool = True):
+                 remove_repeats: bool = True, repeat_penalty: float = 1.0, penalty_range: int = 20):
         self.cfg, self.sess = cfg, session
         self.suppress_tokens = list(suppress_tokens) if suppress_tokens is not None else None
         self.task_token = cfg.transcribe_id if task == "transcribe" else cfg.translate_id
@@ -73,6 +74,8 @@ class WhisperTranscriber:
         self.no_speech_threshold, self.remove_repeats = no_speech_threshold, remove_repeats
         self.language_token_ids = np.arange(cfg.first_language_id, cfg.first_language_id + cfg.n_languages, dtype=np.int64)
         self.stop_tokens = {cfg.eot_id}
+        # REPEAT_PENALTY / PENALTY_RANGE (:77-79): 1.0 selects greedy, any other value penalty-greedy (the reference default is 0.8)
+        self.repeat_penalty, self.penalty_range = float(repeat_penalty), int(penalty_range)
 
     def transcribe(self, clips_int16: Sequence[np.ndarray], language_ids: Sequence[int] | None = None, max_new: int | None = None):
         """List of int16 mono 16 kHz clips (each <= 30 s) -> per clip dict(tokens, language_id, no_speech_prob, skipped)."""
@@ -84,6 +87,7 @@ class WhisperTranscriber:
         self.sess.encode(audios)                                         # STFT + encoder + cross-KV, once per window
         probs = np.zeros(B, dtype=np.float32)
         if self.detect_language or self.no_speech_detection:
+            self.sess.set_penalty(1.0, self.penalty_range)
             _, logits = self.sess.prefill(np.full((B, 1), cfg.sot_id, dtype=np.int32))      # probe with [SOT]
             if self.detect_language:
                 lang = self.language_token_ids[np.argmax(logits[:, self.language_token_ids], axis=1)]
@@ -94,6 +98,7 @@ class WhisperTranscriber:
         limit = max(0, cfg.max_target_positions - prompt.shape[1])
         if max_new is not None:
             limit = min(limit, max_new)
+        self.sess.set_penalty(self.repeat_penalty, self.penalty_range)
         self.sess.prefill(prompt, want_logits=False)
         toks = self.sess.generate(limit, eos_id=cfg.eot_id) if limit > 0 else [np.zeros(0, np.int32)] * B
         wall = time.time() - t0

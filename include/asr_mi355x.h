@@ -140,8 +140,15 @@ int asr_whisper_prefill(asr_session* s, const int32_t* ids, int n, int32_t* next
  * host round trip); next_ids_out / logits_out nullable (NULL, NULL => fully asynchronous step). */
 int asr_whisper_decode(asr_session* s, const int32_t* ids, int32_t* next_ids_out, float* logits_out);
 /* greedy continuation after a prefill: tokens_out host [B][max_new], n_out host [B]; stops per sequence at eos_id
- * (not emitted) -- the loop of _decode_tokens (Inference_Whisper_ONNX.py:584-663) with REPEAT_PENALTY = 1.0. */
+ * (not emitted) -- the loop of _decode_tokens (Inference_Whisper_ONNX.py:584-663); the head is the one selected by
+ * asr_whisper_set_penalty (plain arg-max by default). */
 int asr_whisper_generate(asr_session* s, int max_new, int eos_id, int32_t* tokens_out, int32_t* n_out);
+/* decode head: repeat_penalty == 1 => ARGMAX (Export_Whisper.py:254-260); otherwise penalty-greedy = APPLY_PENALTY (:312-325)
+ * + GREEDY_SEARCH (:243-251): the logits of the last penalty_range generated ids (1..64) are multiplied by repeat_penalty
+ * once penalty_range ids exist (REPEAT_PENALTY / PENALTY_RANGE, Inference_Whisper_ONNX.py:78-79,630-632). The id history is kept
+ * on the device and restarts at every prefill. Applies to prefill / decode / generate; logits_out then holds the
+ * penalised logits. */
+int asr_whisper_set_penalty(asr_session* s, float repeat_penalty, int penalty_range);
 
 /* ------------------------------------------------------------------ device buffers
  * Backing store of the shim's OrtValue (OrtValue.ortvalue_from_numpy / update_inplace / numpy,

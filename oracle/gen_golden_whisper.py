@@ -21,8 +21,13 @@ WHISPER_CASES = [
 FULL_CASE = ("whisper_large_v3", "whisper_large_v3", 0, 4, [(2238, 128000)])
 
 
-def reference_greedy(ref, cfg, audio, prompt, n_new, suppress, begin_suppress):
-    """The reference's graphs driven like Inference_Whisper_ONNX.py: encoder once, prefill(prompt), decode steps."""
+PENALTY_VALUE, PENALTY_RANGE, PENALTY_STEPS = 0.8, 3, 12      # small range so the window fills inside a short golden
+
+
+def reference_greedy(ref, cfg, audio, prompt, n_new, suppress, begin_suppress, penalty=None):
+    """The reference's graphs driven like Inference_Whisper_ONNX.py: encoder once, prefill(prompt), decode steps.
+    penalty = (value, range): the reference's APPLY_PENALTY + GREEDY_SEARCH heads with the host's rule that the multiplier is
+    1.0 until `range` tokens were generated (Inference_Whisper_ONNX.py:606-632)."""
     enc, dec, model = ref["encoder"], ref["decoder"], ref["model"]
     L, H, hd, d = cfg.n_dec_layers, cfg.n_heads, cfg.d_head, cfg.d_model
     embed = model.model.decoder.embed_tokens
@@ -36,11 +41,25 @@ def reference_greedy(ref, cfg, audio, prompt, n_new, suppress, begin_suppress):
             begin_bias[list(begin_suppress)] = float("-inf")
         ids = torch.tensor([prompt], dtype=torch.long)
         hist, toks, all_logits = 0, [], []
+        apply_penalty, greedy_search = ref["ns"]["APPLY_PENALTY"](), ref["ns"]["GREEDY_SEARCH"]()
+        save_id = torch.zeros((1, 0), dtype=torch.int32)
         for step in range(n_new):
             n = ids.shape[1]
             mask = torch.triu(torch.full((1, n, hist + n), -128.0), diagonal=1)[:, :n, :hist + n] if step == 0 else torch.zeros(1, 1, hist + n)
             out = dec(*sk, *sv, *cross, embed(ids), pos_w[hist:hist + n].unsqueeze(0), mask)
             sk, sv, logits = list(out[:L]), list(out[L:2 * L]), out[-1]
+            if penalty is not None:
+                head = logits + (begin_bias if step == 0 else 0)
+                if step > 0:
+                    value = penalty[0] if save_id.shape[1] >= penalty[1] else 1.0
+                    head = apply_penalty(head, save_id, torch.tensor(value, dtype=torch.float32), penalty[1])
+                all_logits.append(head[0].clone())
+                max_idx, save_id = greedy_search(head, save_id)
+                tok = int(max_idx.reshape(-1)[0])
+                toks.append(tok)
+                hist += n
+                ids = torch.tensor([[tok]], dtype=torch.long)
+                continue
             all_logits.append(logits[0].clone())
             tok = int(torch.argmax(logits[0] + (begin_bias if step == 0 else 0)))
             toks.append(tok)
@@ -61,7 +80,8 @@ def gen_whisper(full=False):
         begin = ckm.whisper_begin_suppress_tokens(cfg)
         ref = rh.build_reference_whisper(cfg, ck, suppress_tokens=suppress)
         small = cfg.d_model <= 128
-        out = {"ckpt_seed": np.int64(ck_seed), "n_cases": np.int64(len(clips)), "cfg_name": np.str_(cfg_name), "n_new": np.int64(n_new)}
+        out = {"ckpt_seed": np.int64(ck_seed), "n_cases": np.int64(len(clips)), "cfg_name": np.str_(cfg_name), "n_new": np.int64(n_new),
+               "penalty_value": np.float32(PENALTY_VALUE), "penalty_range": np.int64(PENALTY_RANGE)}
         for i, (seed, n) in enumerate(clips):
             audio = ckm.synth_audio("unit", 1, n, seed=seed)[0, 0]
             prompt = [cfg.sot_id, cfg.first_language_id, cfg.transcribe_id, cfg.no_timestamps_id]
@@ -81,6 +101,15 @@ def gen_whisper(full=False):
                 out[p + "cross_k"], out[p + "cross_v"] = keys[:, ::5, ::16].copy(), vals[:, ::5, ::16].copy()
                 out[p + "logits"] = r["logits"][:, ::53].copy()
                 out[p + "top1"] = srt[:, -1].astype(np.float32)
+            if small:      # penalty-greedy (the reference host's default strategy) on the tiny config
+                rp = reference_greedy(ref, cfg, audio, prompt, PENALTY_STEPS, suppress, begin, penalty=(PENALTY_VALUE, PENALTY_RANGE))
+                out[p + "penalty_token_ids"] = rp["token_ids"]
+                lg = np.where(np.isfinite(rp["logits"]), rp["logits"], -1e30)
+                srt_p = np.sort(lg, axis=1)
+                out[p + "penalty_margin"] = (srt_p[:, -1] - srt_p[:, -2]).astype(np.float32)
+                plain = reference_greedy(ref, cfg, audio, prompt, PENALTY_STEPS, suppress, begin)["token_ids"]
+                out[p + "plain_token_ids"] = plain
+                print(fixture, i, "penalty tokens", rp["token_ids"], "plain", plain)
             print(fixture, i, n, "tokens", r["token_ids"], "min margin", float(out[p + "margin"].min()))
         np.savez_compressed(os.path.join(GOLDEN, fixture + ".npz"), **out)
 

@@ -225,9 +225,11 @@ class WhisperOracle:
         unsup = -self.suppress_penalty
         return torch.softmax(logits + self._c(unsup), dim=-1)[:, self.cfg.no_speech_id]
 
-    def greedy(self, audios, prompt_ids, n_new: int, eos_id=None):
+    def greedy(self, audios, prompt_ids, n_new: int, eos_id=None, repeat_penalty: float = 1.0, penalty_range: int = 20):
         """Batch of utterances (list of 1-D arrays) -> dict of per-step logits / ids, following the reference host
-        loop: prefill(prompt) -> arg-max(logits + begin_suppress) -> decode steps with plain arg-max."""
+        loop: prefill(prompt) -> arg-max(logits + begin_suppress) -> decode steps with plain arg-max, or -- repeat_penalty != 1,
+        the host's default -- penalty-greedy: APPLY_PENALTY (Export_Whisper.py:312-325) multiplies the logits of the last
+        `penalty_range` generated ids by the penalty once `penalty_range` tokens exist (Inference_Whisper_ONNX.py:606-632)."""
         with torch.inference_mode():
             enc = [self.encode(a) for a in audios]
             out_ids, out_logits = [], []
@@ -242,8 +244,12 @@ class WhisperOracle:
                 while len(toks) < n_new and (eos_id is None or tok != eos_id):
                     logits, sk, sv = self.decoder(torch.tensor([[tok]]), hist, sk, sv, ck_, cv_)
                     hist += 1
-                    steps_logits.append(logits[0])
-                    tok = int(torch.argmax(logits[0]))
+                    head = logits[0].clone()
+                    if repeat_penalty != 1.0 and len(toks) >= penalty_range:
+                        idx = torch.tensor(toks[-penalty_range:], dtype=torch.long)
+                        head[idx] = logits[0][idx] * repeat_penalty
+                    steps_logits.append(head)
+                    tok = int(torch.argmax(head))
                     toks.append(tok)
                 out_ids.append(np.asarray(toks, dtype=np.int32))
                 out_logits.append(torch.stack(steps_logits).float().numpy())

@@ -67,3 +67,24 @@ def test_no_speech_and_begin_suppress_heads():
     p = orc.no_speech_prob(logits)                       # uniform after the +128 un-suppress => 1/V
     assert abs(float(p) - 1.0 / cfg.vocab) < 1e-6
     assert torch.isinf(orc.begin_bias[beg]).all() and float(orc.suppress_penalty[sup].max()) == -128.0
+
+
+def test_penalty_greedy_matches_reference_heads():
+    """APPLY_PENALTY + GREEDY_SEARCH (the reference host's default strategy) vs goldens minted with the reference's own head
+    modules: the multiplier kicks in once `range` ids were generated and redirects the random-weight model's repeats."""
+    g = load_golden("whisper_tiny")
+    cfg, ck, sup, beg = whisper_setup(str(g["cfg_name"]), int(g["ckpt_seed"]))
+    orc = WhisperOracle(cfg, ck, sup, beg)
+    value, rng = float(g["penalty_value"]), int(g["penalty_range"])
+    differs = 0
+    for i, c in golden_cases(g):
+        want = c["penalty_token_ids"]
+        audio = [unit_audio(c["audio_seed"], c["n_samples"])]
+        r = orc.greedy(audio, [c["prompt"].tolist()], want.size, repeat_penalty=value, penalty_range=rng)
+        safe = c["penalty_margin"] > 1e-3
+        first_unsafe = int(np.argmin(safe)) if not safe.all() else want.size      # after a near-tie the histories may fork
+        assert np.array_equal(r["token_ids"][0][:first_unsafe], want[:first_unsafe]), i
+        plain = orc.greedy(audio, [c["prompt"].tolist()], want.size)["token_ids"][0]
+        assert np.array_equal(plain[:rng], want[:rng])                            # inactive until the window is full
+        differs += int(not np.array_equal(c["plain_token_ids"], want))
+    assert differs >= 2

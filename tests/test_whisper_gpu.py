@@ -106,3 +106,37 @@ def test_erf_vs_tanh_gelu_and_errors():
     s.encode(a)
     with pytest.raises(_lib.AsrError):
         s.prefill(np.array([[cfg.vocab + 5]], np.int32))          # token id out of range
+
+
+def test_penalty_greedy_head_matches_reference_goldens():
+    """set_penalty(): APPLY_PENALTY + GREEDY_SEARCH on the device (history and counter never leave HBM), f32 mode, ragged
+    batch, through generate() and through explicit decode steps; switching back to 1.0 restores plain greedy."""
+    g = load_golden("whisper_tiny")
+    cfg, ck, sup, beg, sess = _session(str(g["cfg_name"]), F32)
+    cases = [c for _, c in golden_cases(g)]
+    value, rng = float(g["penalty_value"]), int(g["penalty_range"])
+    audios = [unit_audio(c["audio_seed"], c["n_samples"]) for c in cases]
+    prompts = np.stack([c["prompt"] for c in cases])
+    n = cases[0]["penalty_token_ids"].size
+    sess.encode(audios)
+    sess.set_penalty(value, rng)
+    sess.prefill(prompts, want_logits=False)
+    gen = sess.generate(n, eos_id=-1)
+    first, _ = sess.prefill(prompts, want_logits=False)       # the id history restarts with every prefill
+    nxt = [first]
+    for _ in range(n - 1):
+        nxt.append(sess.decode(None)[0])
+    step = np.stack(nxt, 1)
+    sess.set_penalty(1.0, rng)
+    sess.prefill(prompts, want_logits=False)
+    plain = sess.generate(n, eos_id=-1)
+    for b, c in enumerate(cases):
+        safe = c["penalty_margin"] > 2e-3
+        k = int(np.argmin(safe)) if not safe.all() else n
+        assert k > rng + 1, "golden too fragile to exercise the penalty"
+        assert np.array_equal(gen[b][:k], c["penalty_token_ids"][:k]), b
+        assert np.array_equal(step[b][:k], c["penalty_token_ids"][:k]), b
+        m = int(np.argmin(c["margin"] > 2e-3)) if not (c["margin"] > 2e-3).all() else c["token_ids"].size
+        assert np.array_equal(plain[b][:m], c["plain_token_ids"][:m]), b
+    with pytest.raises(Exception, match="range"):
+        sess.set_penalty(0.8, 65)

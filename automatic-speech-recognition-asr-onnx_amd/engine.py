@@ -372,3 +372,19 @@ class ParaformerSession(_Session):
             out.append((r, t))
             r += (t + 15) // 16 * 16
         return out
+
+
+def load_session(path: str, device_id: int = 0):
+    """Open an `.asrmodel` bundle (tools/convert_checkpoint.py, export_*) as the matching native session."""
+    from . import config as cfgm
+    from .ort_shim import load_model
+    info, blob = load_model(path)
+    kind, conf, prec = info["kind"], dict(info["config"] or {}), int(info.get("precision", 0))
+    if kind == "sensevoice":
+        conf["language_prompt_token_ids"] = tuple(conf["language_prompt_token_ids"])
+        return SenseVoiceSession(cfgm.SenseVoiceConfig(**conf), blob, prec, device_id)
+    if kind == "paraformer":
+        return ParaformerSession(cfgm.ParaformerConfig(**conf), blob, prec, device_id)
+    if kind == "whisper":
+        return WhisperSession(cfgm.WhisperConfig(**conf), blob, prec, device_id)
+    raise ValueError(f"{path!r}: no native session for bundle kind {kind!r}")

@@ -1,0 +1,132 @@
+#!/usr/bin/env python
+"""Checkpoint converter: a source-layout checkpoint -> the engine's model folder.
+
+    python tools/convert_checkpoint.py --family sensevoice --checkpoint model.pt --cmvn am.mvn --out SenseVoice_MI355X
+    python tools/convert_checkpoint.py --family paraformer --checkpoint model.pt --cmvn am.mvn --tokens tokens.json --out Paraformer_MI355X
+    python tools/convert_checkpoint.py --family whisper    --checkpoint model.safetensors --out Whisper_MI355X
+
+It performs what the tail of the reference's Export_*.py does for ONNX (Export_SenseVoice.py:355-405, Export_Paraformer.py:575-640,
+Export_Whisper.py:1040-1130) for the arena format: load the FunASR / Hugging Face state dict (torch `.pt` or `.safetensors`), read
+the Kaldi CMVN statistics, infer the architecture from the tensor shapes, run the export-time folds (`arena.build_*_arena`) and
+write `<Model>.asrmodel` (+ `ASR_Metadata.asrmodel`, vocabulary file). No GPU needed. Real checkpoints are not available
+offline; `tests/test_convert_cpu.py` round-trips synthetic checkpoints through the file formats.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "automatic-speech-recognition-asr-onnx_amd"
+
+
+def load_state_dict(path: str) -> dict:
+    """{name: float32 ndarray}; accepts torch pickles (optionally wrapped in {'state_dict': ...} / {'model': ...}) and safetensors."""
+    if path.endswith(".safetensors"):
+        from safetensors.numpy import load_file
+        sd = load_file(path)
+    else:
+        import torch
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+        for key in ("state_dict", "model"):
+            if isinstance(obj, dict) and key in obj and isinstance(obj[key], dict):
+                obj = obj[key]
+        sd = {k: v.float().numpy() for k, v in obj.items() if hasattr(v, "numpy")}
+    return {k: np.ascontiguousarray(np.asarray(v, dtype=np.float32)) for k, v in sd.items()}
+
+
+def load_kaldi_cmvn(path: str):
+    """FunASR `am.mvn` (Kaldi nnet text): <AddShift> ... [ means ] then <Rescale> ... [ vars ]  (funasr WavFrontend.load_cmvn)."""
+    means = scales = None
+    with open(path, "r", encoding="utf-8") as f:
+        lines = f.readlines()
+    for i, line in enumerate(lines):
+        tag = line.split()[0] if line.split() else ""
+        if tag in ("<AddShift>", "<Rescale>"):
+            vals = re.findall(r"[-+]?\d*\.?\d+(?:[eE][-+]?\d+)?", lines[i + 1].split("[", 1)[1].rsplit("]", 1)[0])
+            arr = np.asarray([float(v) for v in vals], dtype=np.float32)
+            if tag == "<AddShift>":
+                means = arr
+            else:
+                scales = arr
+    if means is None or scales is None:
+        raise ValueError(f"{path}: no <AddShift>/<Rescale> blocks found")
+    return means, scales
+
+
+def _count(sd, pattern):
+    ids = {int(m.group(1)) for k in sd for m in [re.match(pattern, k)] if m}
+    return max(ids) + 1 if ids else 0
+
+
+def convert(family: str, sd: dict, out: str, precision: int, cmvn=None, tokens=None, language="zh", decode_mode="zh"):
+    cfgm = importlib.import_module(PKG + ".config")
+    if family in ("sensevoice", "paraformer"):
+        if cmvn is not None:
+            sd["frontend.cmvn_means"], sd["frontend.cmvn_vars"] = cmvn
+        if "frontend.cmvn_means" not in sd:
+            raise ValueError("SenseVoice / Paraformer need the CMVN statistics (--cmvn am.mvn)")
+    if family == "sensevoice":
+        d = sd["encoder.after_norm.weight"].shape[0]
+        cfg = cfgm.SenseVoiceConfig(d_model=d, d_ffn=sd["encoder.encoders.0.feed_forward.w_1.weight"].shape[0],
+                                    n_enc=_count(sd, r"encoder\.encoders\.(\d+)\."), n_tp=_count(sd, r"encoder\.tp_encoders\.(\d+)\."),
+                                    vocab=sd["ctc.ctc_lo.weight"].shape[0])
+        importlib.import_module(PKG + ".sensevoice").export_sensevoice(out, cfg, sd, precision)
+    elif family == "paraformer":
+        d = sd["encoder.after_norm.weight"].shape[0]
+        cfg = cfgm.ParaformerConfig(d_model=d, d_ffn=sd["encoder.encoders.0.feed_forward.w_1.weight"].shape[0],
+                                    n_enc=_count(sd, r"encoder\.encoders\.(\d+)\."), n_dec=_count(sd, r"decoder\.decoders\.(\d+)\."),
+                                    n_dec3=_count(sd, r"decoder\.decoders3\.(\d+)\."),
+                                    d_dec_ffn=sd["decoder.decoders.0.feed_forward.w_1.weight"].shape[0],
+                                    vocab=sd["decoder.output_layer.weight"].shape[0])
+        if tokens is None:
+            raise ValueError("Paraformer needs the token list (--tokens tokens.json or tokens.txt)")
+        importlib.import_module(PKG + ".paraformer").export_paraformer(out, cfg, sd, tokens, language, decode_mode, precision)
+    elif family == "whisper":
+        d = sd["model.encoder.layer_norm.weight"].shape[0]
+        cfg = cfgm.WhisperConfig(d_model=d, n_heads=d // 64, d_ffn=sd["model.encoder.layers.0.fc1.weight"].shape[0],
+                                 n_enc_layers=_count(sd, r"model\.encoder\.layers\.(\d+)\."),
+                                 n_dec_layers=_count(sd, r"model\.decoder\.layers\.(\d+)\."),
+                                 n_mels=sd["model.encoder.conv1.weight"].shape[1], vocab=sd["model.decoder.embed_tokens.weight"].shape[0],
+                                 max_source_positions=sd["model.encoder.embed_positions.weight"].shape[0],
+                                 max_target_positions=sd["model.decoder.embed_positions.weight"].shape[0])
+        arena = importlib.import_module(PKG + ".arena")
+        ckm = importlib.import_module(PKG + ".checkpoints")
+        shim = importlib.import_module(PKG + ".ort_shim")
+        os.makedirs(out, exist_ok=True)
+        blob = arena.build_whisper_arena(cfg, sd, precision, ckm.whisper_suppress_tokens(cfg), ckm.whisper_begin_suppress_tokens(cfg))
+        shim.save_model(os.path.join(out, "Whisper.asrmodel"), "whisper", cfg.to_dict(), blob, {}, precision)
+    else:
+        raise ValueError(family)
+    return cfg
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--family", required=True, choices=("sensevoice", "paraformer", "whisper"))
+    ap.add_argument("--checkpoint", required=True)
+    ap.add_argument("--cmvn", help="FunASR am.mvn (SenseVoice / Paraformer)")
+    ap.add_argument("--tokens", help="Paraformer token list: tokens.json (list) or one token per line")
+    ap.add_argument("--language", default="zh")
+    ap.add_argument("--decode-mode", default="zh", choices=("zh", "en"))
+    ap.add_argument("--precision", default="bf16", choices=("bf16", "f32"))
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    tokens = None
+    if a.tokens:
+        with open(a.tokens, "r", encoding="utf-8") as f:
+            tokens = json.load(f) if a.tokens.endswith(".json") else [ln.rstrip("\n") for ln in f]
+    cfg = convert(a.family, load_state_dict(a.checkpoint), a.out, 0 if a.precision == "bf16" else 1,
+                  load_kaldi_cmvn(a.cmvn) if a.cmvn else None, tokens, a.language, a.decode_mode)
+    print(f"wrote {a.out}: {cfg}")
+
+
+if __name__ == "__main__":
+    main()

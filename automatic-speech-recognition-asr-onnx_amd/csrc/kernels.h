@@ -85,6 +85,21 @@ void launch_apply_penalty(float* logits, int ld, int rows, const int32_t* save_i
 // save_ids[r][*n_saved] = next[r] (the counter itself is advanced by launch_add_scalar afterwards)
 void launch_append_ids(const int32_t* next, int rows, int32_t* save_ids, int ld_save, const int32_t* n_saved, hipStream_t s);
 
+// ---- TOPK_TOPP_SAMPLING head (Export_Whisper.py:263-308), one workgroup per sequence: repetition penalty on every saved id
+// (negative logits multiplied, others divided; gather before scatter), + `extra` bias (BEGIN_SUPPRESS), x 1/temperature, top-k
+// (k <= 64, ties to the lower index), soft-max + exclusive-cumsum top-p cut, Gumbel-max with clamped uniforms. The uniforms come
+// from `noise` ([rows][top_k], caller-supplied: parity tests) or, when null, from a counter-based generator keyed by
+// (seed, step = *n_saved, row, rank). Writes next[r]; the caller appends it to the history.
+struct SampleArgs {
+  float* logits; int ld; int rows; int n_valid;
+  const float* extra;
+  const int32_t* save_ids; int ld_save; const int32_t* n_saved;
+  float temperature, top_p, repetition_penalty; int top_k;
+  const float* noise; uint64_t seed;
+  int32_t* next;
+};
+void launch_sample_topk_topp(const SampleArgs& a, hipStream_t s);
+
 // ---- LFR stacking + CMVN + positions + prompt rows (Export_SenseVoice.py:280-287)
 struct LfrArgs {
   const float* mel;            // [frames][n_mels]

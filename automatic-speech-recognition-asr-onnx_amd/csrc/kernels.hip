@@ -774,6 +774,80 @@ __global__ __launch_bounds__(64) void apply_penalty_kernel(float* __restrict__ l
   if (id >= 0) x[id] = v * value;
 }
 
+__device__ __forceinline__ float uniform_from_counter(uint64_t seed, uint32_t step, uint32_t row, uint32_t j) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)step * 0x100000001B3ull + ((uint64_t)row << 8) + j + 1);   // splitmix64
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(256) void sample_topk_topp_kernel(const SampleArgs a) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  __shared__ float top_v[64];
+  __shared__ int top_i[64];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* x = a.logits + (size_t)r * a.ld;
+  const int n_prev = min(*a.n_saved, a.ld_save);
+  // 1. repetition penalty over the whole history (<= 512 ids: two per thread), every original gathered before the first write
+  const int32_t* sv = a.save_ids + (size_t)r * a.ld_save;
+  int id0 = tid < n_prev ? sv[tid] : -1, id1 = tid + 256 < n_prev ? sv[tid + 256] : -1;
+  const float v0 = id0 >= 0 ? x[id0] : 0.0f, v1 = id1 >= 0 ? x[id1] : 0.0f;
+  __syncthreads();
+  const float rp = a.repetition_penalty, irp = 1.0f / a.repetition_penalty;
+  if (id0 >= 0) x[id0] = v0 < 0.0f ? v0 * rp : v0 * irp;
+  if (id1 >= 0) x[id1] = v1 < 0.0f ? v1 * rp : v1 * irp;
+  __syncthreads();
+  // 2. top-k by k passes of (value desc, index asc) selection below the previous pick
+  const float inv_t = 1.0f / a.temperature;
+  float last_v = INFINITY;
+  int last_i = -1;
+  for (int k = 0; k < a.top_k; ++k) {
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int c = tid; c < a.n_valid; c += 256) {
+      const float v = (x[c] + (a.extra ? a.extra[c] : 0.0f)) * inv_t;
+      const bool below = v < last_v || (v == last_v && c > last_i);
+      if (below && (v > best || (v == best && c < bidx))) { best = v; bidx = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bidx, o, 64);
+      if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
+    __syncthreads();
+    best = bv[0]; bidx = bi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < bidx)) { best = bv[w]; bidx = bi[w]; }
+    if (tid == 0) { top_v[k] = best; top_i[k] = bidx; }
+    last_v = best; last_i = bidx;
+    __syncthreads();
+  }
+  // 3. soft-max over the k sorted scores, exclusive-cumsum top-p cut, Gumbel-max
+  if (tid == 0) {
+    const int K = a.top_k;
+    float sum = 0.0f;
+    for (int k = 0; k < K; ++k) sum += expf(top_v[k] - top_v[0]);
+    float cum = 0.0f, best = -INFINITY;
+    int win = 0;
+    const uint32_t step = (uint32_t)*a.n_saved;
+    for (int k = 0; k < K; ++k) {
+      const float p = expf(top_v[k] - top_v[0]) / sum;
+      const bool keep = cum <= a.top_p;              // (cumsum - p) <= top_p, cumsum taken before adding p
+      cum += p;
+      float u = a.noise ? a.noise[(size_t)r * K + k] : uniform_from_counter(a.seed, step, (uint32_t)r, (uint32_t)k);
+      u = fminf(fmaxf(u, 1.0e-7f), 1.0f - 1.0e-7f);
+      const float sc = keep ? top_v[k] - logf(-logf(u)) : -INFINITY;
+      if (sc > best) { best = sc; win = k; }
+    }
+    a.next[r] = top_i[win];
+  }
+}
+
 __global__ void append_ids_kernel(const int32_t* __restrict__ next, int rows, int32_t* __restrict__ save_ids, int ld_save,
                                   const int32_t* __restrict__ n_saved) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1030,6 +1104,13 @@ void launch_apply_penalty(float* logits, int ld, int rows, const int32_t* save_i
                           int range, float value, hipStream_t s) {
   ASR_REQUIRE(range >= 1 && range <= 64 && range <= ld_save, "apply_penalty: range %d (1..64)", range);
   hipLaunchKernelGGL(apply_penalty_kernel, dim3(rows), dim3(64), 0, s, logits, ld, save_ids, ld_save, n_saved, range, value);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_sample_topk_topp(const SampleArgs& a, hipStream_t s) {
+  ASR_REQUIRE(a.top_k >= 1 && a.top_k <= 64 && a.top_k <= a.n_valid, "sampling: top_k %d (1..64)", a.top_k);
+  ASR_REQUIRE(a.temperature > 0.0f && a.repetition_penalty > 0.0f && a.ld_save <= 512, "sampling: bad temperature / penalty / history capacity");
+  hipLaunchKernelGGL(sample_topk_topp_kernel, dim3(a.rows), dim3(256), 0, s, a);
   HIP_CHECK(hipGetLastError());
 }
 

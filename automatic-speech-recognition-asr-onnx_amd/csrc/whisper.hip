@@ -40,6 +40,12 @@ struct WhSession : asr_session {
   // decoder state
   DeviceBuffer d_kc, d_vc, d_ids, d_next, d_logits, d_dx, d_dqkv, d_dtok, d_hist;
   DeviceBuffer d_save, d_nsaved;       // penalty-greedy: generated ids per sequence [B][max_target_positions] + their count
+  bool sampling = false;               // TOPK_TOPP_SAMPLING head (USE_SAMPLING, Inference_Whisper_ONNX.py:71-75)
+  float temperature = 0.8f, top_p = 0.95f, samp_rep_penalty = 1.0f;
+  int top_k = 10;
+  uint64_t samp_seed = 0;
+  DeviceBuffer d_noise;                // caller-supplied uniforms [B][top_k] for the next step (parity tests); consumed once
+  bool noise_armed = false;
   float penalty_value = 1.0f;          // 1.0 = plain greedy (REPEAT_PENALTY, Inference_Whisper_ONNX.py:78)
   int penalty_range = 20;
   bool use_graph = true;
@@ -50,7 +56,7 @@ struct WhSession : asr_session {
 
   ~WhSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_x0, &d_h1, &d_xa, &d_xb, &d_xc, &d_h, &d_qk, &d_vt, &d_ctx,
-                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved})
+                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise})
       b->release();
     if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
     for (auto& kv : taps) kv.second.buf.release();
@@ -422,13 +428,22 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
       g.A = hl; g.lda = d;
     }
     gemm(g);
-    const bool penalised = penalty_value != 1.0f;
+    const bool penalised = penalty_value != 1.0f && !sampling;
     if (penalised && !is_prefill)          // APPLY_PENALTY over the saved ids; the history is empty at the prefill (:312-325)
       launch_apply_penalty(d_logits.as<float>(), vpad, B, d_save.as<int32_t>(), c.max_target_positions, d_nsaved.as<int32_t>(),
                            penalty_range, penalty_value, stream);
-    // BEGIN_SUPPRESS (-inf on begin_suppress_tokens) applies to the head after a prefill only (:228-240)
-    launch_argmax_rows(d_logits.as<float>(), vpad, B, c.vocab, is_prefill ? begin : nullptr, d_next.as<int32_t>(), stream);
-    if (penalised) {                       // GREEDY_SEARCH appends its pick to the history (:243-251)
+    if (sampling) {                        // TOPK_TOPP_SAMPLING (:263-308): BEGIN_SUPPRESS bias first, history = every sampled id
+      SampleArgs sa;
+      sa.logits = d_logits.as<float>(); sa.ld = vpad; sa.rows = B; sa.n_valid = c.vocab; sa.extra = is_prefill ? begin : nullptr;
+      sa.save_ids = d_save.as<int32_t>(); sa.ld_save = c.max_target_positions; sa.n_saved = d_nsaved.as<int32_t>();
+      sa.temperature = temperature; sa.top_p = top_p; sa.repetition_penalty = samp_rep_penalty; sa.top_k = top_k;
+      sa.noise = noise_armed ? d_noise.as<float>() : nullptr; sa.seed = samp_seed; sa.next = d_next.as<int32_t>();
+      launch_sample_topk_topp(sa, stream);
+    } else {
+      // BEGIN_SUPPRESS (-inf on begin_suppress_tokens) applies to the head after a prefill only (:228-240)
+      launch_argmax_rows(d_logits.as<float>(), vpad, B, c.vocab, is_prefill ? begin : nullptr, d_next.as<int32_t>(), stream);
+    }
+    if (penalised || sampling) {           // GREEDY_SEARCH / the sampling head append their pick to the history (:243-251,306)
       launch_append_ids(d_next.as<int32_t>(), B, d_save.as<int32_t>(), c.max_target_positions, d_nsaved.as<int32_t>(), stream);
       launch_add_scalar(d_nsaved.as<int32_t>(), 1, stream);
     }
@@ -477,7 +492,7 @@ void WhSession::step(const int32_t* ids_host, int n, bool is_prefill, int32_t* n
     HIP_CHECK(hipMemsetAsync(d_nsaved.ptr, 0, 4, stream));
   }
   // single-token steps fed from the device are position independent => one graph for all of them
-  const bool graphable = use_graph && !ids_host && n == 1 && !taps_enabled && !prof.enabled;
+  const bool graphable = use_graph && !ids_host && n == 1 && !taps_enabled && !prof.enabled && !noise_armed;
   const uint64_t key = ((uint64_t)B << 32) ^ (uint64_t)Mpad ^ (ws_epoch << 48) ^ (uint64_t)(uintptr_t)stream;
   if (graphable && dec_graph && key == dec_key) {
     HIP_CHECK(hipGraphLaunch(dec_graph, stream));
@@ -502,6 +517,7 @@ void WhSession::step(const int32_t* ids_host, int n, bool is_prefill, int32_t* n
     if (graphable) dec_eager_key = key;
   }
   hist += n;
+  noise_armed = false;                   // caller-supplied uniforms serve exactly one step
   if (taps_enabled) save_tap("logits", d_logits.ptr, B, c.vocab, vpad, 4);
   if (next_out || logits_out) {
     unsigned char* st = (unsigned char*)pinned((size_t)B * 4 + (logits_out ? (size_t)B * c.vocab * 4 : 0));
@@ -581,6 +597,36 @@ extern "C" int asr_whisper_set_penalty(asr_session* s, float repeat_penalty, int
       w->penalty_range = penalty_range;
       ++w->ws_epoch;                       // the captured decode graph bakes the head in: re-capture
     }
+  });
+}
+
+extern "C" int asr_whisper_set_sampling(asr_session* s, int enable, float temperature, int top_k, float top_p,
+                                        float repetition_penalty, uint64_t seed) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 2, "whisper_set_sampling: not a Whisper session");
+    WhSession* w = static_cast<WhSession*>(s);
+    if (enable) {
+      ASR_REQUIRE(temperature > 0.0f && top_k >= 1 && top_k <= 64 && top_p > 0.0f && repetition_penalty > 0.0f && w->cfg.max_target_positions <= 512,
+                  "whisper_set_sampling: temperature %g top_k %d top_p %g penalty %g", temperature, top_k, top_p, repetition_penalty);
+      w->temperature = temperature; w->top_k = top_k; w->top_p = top_p; w->samp_rep_penalty = repetition_penalty; w->samp_seed = seed;
+    }
+    w->sampling = enable != 0;
+    w->noise_armed = false;
+    ++w->ws_epoch;                         // the captured decode graph bakes the head in: re-capture
+  });
+}
+
+extern "C" int asr_whisper_set_sampling_noise(asr_session* s, const float* uniforms, int count) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 2 && uniforms, "whisper_set_sampling_noise: bad argument");
+    WhSession* w = static_cast<WhSession*>(s);
+    ASR_REQUIRE(w->sampling && w->batch > 0 && count == w->batch * w->top_k, "whisper_set_sampling_noise: expects batch x top_k = %d uniforms for the next step",
+                w->batch * w->top_k);
+    HIP_CHECK(hipSetDevice(w->device));
+    w->d_noise.reserve((size_t)count * 4, w->stream);
+    HIP_CHECK(hipMemcpyAsync(w->d_noise.ptr, uniforms, (size_t)count * 4, hipMemcpyHostToDevice, w->stream));
+    HIP_CHECK(hipStreamSynchronize(w->stream));
+    w->noise_armed = true;
   });
 }
 

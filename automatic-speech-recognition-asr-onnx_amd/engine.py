@@ -300,6 +300,17 @@ class WhisperSession(_Session):
         """Decode head: 1.0 = plain arg-max; else penalty-greedy (APPLY_PENALTY + GREEDY_SEARCH, the reference host's default)."""
         _lib.check(_lib.load().asr_whisper_set_penalty(self._h, C.c_float(repeat_penalty), int(penalty_range)))
 
+    def set_sampling(self, enable: bool, temperature: float = 0.8, top_k: int = 10, top_p: float = 0.95,
+                     repetition_penalty: float = 1.0, seed: int = 0):
+        """TOPK_TOPP_SAMPLING head (USE_SAMPLING in the reference host); enable=False restores arg-max / penalty-greedy."""
+        _lib.check(_lib.load().asr_whisper_set_sampling(self._h, int(enable), C.c_float(temperature), int(top_k), C.c_float(top_p),
+                                                        C.c_float(repetition_penalty), C.c_uint64(seed)))
+
+    def set_sampling_noise(self, uniforms):
+        """Parity hook: uniforms [batch, top_k] for the next prefill / decode step (otherwise the device generator is used)."""
+        u = _f32(uniforms).reshape(-1)
+        _lib.check(_lib.load().asr_whisper_set_sampling_noise(self._h, _fp(u), u.size))
+
     def cross_kv(self, lengths_pos: Sequence[int]):
         """Debug: (K, V) per utterance as (L, H, T, 64) arrays from the 'cross' tap (f32 mode)."""
         cfg = self.cfg

@@ -66,7 +66,9 @@ def no_speech_probability(logits: np.ndarray, suppress_tokens: Sequence[int], no
 class WhisperTranscriber:
     def __init__(self, cfg: WhisperConfig, session: WhisperSession, suppress_tokens=None, task: str = "transcribe",
                  detect_language: bool = True, no_speech_detection: bool = True, no_speech_threshold: float = 0.6,
-                 remove_repeats: bool = True, repeat_penalty: float = 1.0, penalty_range: int = 20):
+                 remove_repeats: bool = True, repeat_penalty: float = 1.0, penalty_range: int = 20,
+                 use_sampling: bool = False, temperature: float = 0.8, top_k: int = 10, top_p: float = 0.95,
+                 sampling_repetition_penalty: float = 1.0, seed: int = 0):
         self.cfg, self.sess = cfg, session
         self.suppress_tokens = list(suppress_tokens) if suppress_tokens is not None else None
         self.task_token = cfg.transcribe_id if task == "transcribe" else cfg.translate_id
@@ -76,6 +78,8 @@ class WhisperTranscriber:
         self.stop_tokens = {cfg.eot_id}
         # REPEAT_PENALTY / PENALTY_RANGE (:77-79): 1.0 selects greedy, any other value penalty-greedy (the reference default is 0.8)
         self.repeat_penalty, self.penalty_range = float(repeat_penalty), int(penalty_range)
+        # USE_SAMPLING / TEMPERATURE / TOP_K / TOP_P / SAMPLING_REPETITION_PENALTY (:71-75)
+        self.sampling = (bool(use_sampling), float(temperature), int(top_k), float(top_p), float(sampling_repetition_penalty), int(seed))
 
     def transcribe(self, clips_int16: Sequence[np.ndarray], language_ids: Sequence[int] | None = None, max_new: int | None = None):
         """List of int16 mono 16 kHz clips (each <= 30 s) -> per clip dict(tokens, language_id, no_speech_prob, skipped)."""
@@ -87,6 +91,7 @@ class WhisperTranscriber:
         self.sess.encode(audios)                                         # STFT + encoder + cross-KV, once per window
         probs = np.zeros(B, dtype=np.float32)
         if self.detect_language or self.no_speech_detection:
+            self.sess.set_sampling(False)
             self.sess.set_penalty(1.0, self.penalty_range)
             _, logits = self.sess.prefill(np.full((B, 1), cfg.sot_id, dtype=np.int32))      # probe with [SOT]
             if self.detect_language:
@@ -99,6 +104,7 @@ class WhisperTranscriber:
         if max_new is not None:
             limit = min(limit, max_new)
         self.sess.set_penalty(self.repeat_penalty, self.penalty_range)
+        self.sess.set_sampling(*self.sampling)
         self.sess.prefill(prompt, want_logits=False)
         toks = self.sess.generate(limit, eos_id=cfg.eot_id) if limit > 0 else [np.zeros(0, np.int32)] * B
         wall = time.time() - t0

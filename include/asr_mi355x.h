@@ -149,6 +149,15 @@ int asr_whisper_generate(asr_session* s, int max_new, int eos_id, int32_t* token
  * on the device and restarts at every prefill. Applies to prefill / decode / generate; logits_out then holds the
  * penalised logits. */
 int asr_whisper_set_penalty(asr_session* s, float repeat_penalty, int penalty_range);
+/* decode head TOPK_TOPP_SAMPLING (Export_Whisper.py:263-308; USE_SAMPLING / TEMPERATURE / TOP_K / TOP_P /
+ * SAMPLING_REPETITION_PENALTY, Inference_Whisper_ONNX.py:71-75): repetition penalty over every previously sampled id,
+ * temperature, top-k (1..64), top-p, Gumbel-max. enable = 0 returns to the arg-max / penalty-greedy head. The reference draws
+ * torch.rand_like inside the graph; here the uniforms come from a counter-based generator keyed by (seed, step, sequence, rank)
+ * -- reproducible run to run, but a different stream than torch's. */
+int asr_whisper_set_sampling(asr_session* s, int enable, float temperature, int top_k, float top_p, float repetition_penalty,
+                             uint64_t seed);
+/* parity hook: the uniforms of the NEXT prefill / decode step, host [batch][top_k] (count = batch * top_k); consumed once. */
+int asr_whisper_set_sampling_noise(asr_session* s, const float* uniforms, int count);
 
 /* ------------------------------------------------------------------ device buffers
  * Backing store of the shim's OrtValue (OrtValue.ortvalue_from_numpy / update_inplace / numpy,

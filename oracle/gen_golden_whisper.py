@@ -68,6 +68,47 @@ def reference_greedy(ref, cfg, audio, prompt, n_new, suppress, begin_suppress, p
     return dict(cross=cross, logits=torch.stack(all_logits).numpy(), token_ids=np.asarray(toks, np.int32))
 
 
+SAMPLING = dict(temperature=0.8, top_k=10, top_p=0.95, repetition_penalty=1.3, steps=10, seed=4242)
+
+
+def reference_sampling(ref, cfg, audio, prompt, begin_suppress):
+    """TOPK_TOPP_SAMPLING (Export_Whisper.py:263-308) driven like the host loop. The head draws torch.rand_like inside; the
+    same uniforms are captured by re-seeding the generator and drawing the same shape first, so they can be committed."""
+    enc, dec, model = ref["encoder"], ref["decoder"], ref["model"]
+    head = ref["ns"]["TOPK_TOPP_SAMPLING"]()
+    L, H, hd = cfg.n_dec_layers, cfg.n_heads, cfg.d_head
+    embed, pos_w = model.model.decoder.embed_tokens, model.model.decoder.embed_positions.weight
+    P = SAMPLING
+    with torch.inference_mode():
+        cross = enc(torch.from_numpy(audio).reshape(1, 1, -1))
+        sk = [torch.zeros(1, H, hd, 0) for _ in range(L)]
+        sv = [torch.zeros(1, H, 0, hd) for _ in range(L)]
+        begin_bias = torch.zeros(cfg.vocab)
+        if begin_suppress:
+            begin_bias[list(begin_suppress)] = float("-inf")
+        ids = torch.tensor([prompt], dtype=torch.long)
+        prev = torch.zeros((1, 0), dtype=torch.long)
+        hist, toks, noises, gaps = 0, [], [], []
+        for step in range(P["steps"]):
+            n = ids.shape[1]
+            mask = torch.triu(torch.full((1, n, hist + n), -128.0), diagonal=1)[:, :n, :hist + n] if step == 0 else torch.zeros(1, 1, hist + n)
+            out = dec(*sk, *sv, *cross, embed(ids), pos_w[hist:hist + n].unsqueeze(0), mask)
+            sk, sv, logits = list(out[:L]), list(out[L:2 * L]), out[-1]
+            logits = logits + (begin_bias if step == 0 else 0)
+            torch.manual_seed(P["seed"] + step)
+            noise = torch.rand((1, P["top_k"]))
+            torch.manual_seed(P["seed"] + step)
+            sampled, save = head(logits, torch.tensor(P["temperature"]), P["top_k"], torch.tensor(P["top_p"]),
+                                 torch.tensor(P["repetition_penalty"]), prev)
+            prev = save.long()
+            tok = int(sampled.reshape(-1)[0])
+            toks.append(tok)
+            noises.append(noise[0].numpy().copy())
+            hist += n
+            ids = torch.tensor([[tok]], dtype=torch.long)
+    return dict(token_ids=np.asarray(toks, np.int32), noise=np.stack(noises).astype(np.float32))
+
+
 def gen_whisper(full=False):
     from oracle import reference_harness as rh
     cfgm = importlib.import_module(PKG + ".config")
@@ -81,7 +122,8 @@ def gen_whisper(full=False):
         ref = rh.build_reference_whisper(cfg, ck, suppress_tokens=suppress)
         small = cfg.d_model <= 128
         out = {"ckpt_seed": np.int64(ck_seed), "n_cases": np.int64(len(clips)), "cfg_name": np.str_(cfg_name), "n_new": np.int64(n_new),
-               "penalty_value": np.float32(PENALTY_VALUE), "penalty_range": np.int64(PENALTY_RANGE)}
+               "penalty_value": np.float32(PENALTY_VALUE), "penalty_range": np.int64(PENALTY_RANGE),
+               "sampling_params": np.asarray([SAMPLING["temperature"], SAMPLING["top_k"], SAMPLING["top_p"], SAMPLING["repetition_penalty"]], np.float32)}
         for i, (seed, n) in enumerate(clips):
             audio = ckm.synth_audio("unit", 1, n, seed=seed)[0, 0]
             prompt = [cfg.sot_id, cfg.first_language_id, cfg.transcribe_id, cfg.no_timestamps_id]
@@ -110,6 +152,9 @@ def gen_whisper(full=False):
                 plain = reference_greedy(ref, cfg, audio, prompt, PENALTY_STEPS, suppress, begin)["token_ids"]
                 out[p + "plain_token_ids"] = plain
                 print(fixture, i, "penalty tokens", rp["token_ids"], "plain", plain)
+                rs = reference_sampling(ref, cfg, audio, prompt, begin)
+                out[p + "sampling_token_ids"], out[p + "sampling_noise"] = rs["token_ids"], rs["noise"]
+                print(fixture, i, "sampled", rs["token_ids"])
             print(fixture, i, n, "tokens", r["token_ids"], "min margin", float(out[p + "margin"].min()))
         np.savez_compressed(os.path.join(GOLDEN, fixture + ".npz"), **out)
 

@@ -225,6 +225,39 @@ class WhisperOracle:
         unsup = -self.suppress_penalty
         return torch.softmax(logits + self._c(unsup), dim=-1)[:, self.cfg.no_speech_id]
 
+    @staticmethod
+    def sample_head(logits, previous_ids, noise, temperature, top_k, top_p, repetition_penalty):
+        """TOPK_TOPP_SAMPLING (Export_Whisper.py:263-308) with the uniforms given: repetition penalty on every previous id
+        (negative logits multiplied, others divided), temperature, top-k, soft-max + exclusive-cumsum top-p cut, Gumbel-max."""
+        x = logits.clone()
+        if len(previous_ids):
+            idx = torch.tensor(list(previous_ids), dtype=torch.long)
+            pv = logits[idx]
+            x[idx] = torch.where(pv < 0, pv * repetition_penalty, pv / repetition_penalty)
+        x = x * (1.0 / temperature)
+        vals, inds = torch.topk(x, top_k)
+        probs = torch.softmax(vals, dim=-1)
+        keep = (torch.cumsum(probs, dim=-1) - probs) <= top_p
+        vals = torch.where(keep, vals, torch.tensor(float("-inf")))
+        u = torch.clamp(torch.as_tensor(noise, dtype=torch.float32), 1.0e-7, 1.0 - 1.0e-7)
+        return int(inds[int(torch.argmax(vals - torch.log(-torch.log(u))))])
+
+    def sample(self, audio, prompt, noise, temperature, top_k, top_p, repetition_penalty):
+        """One utterance, len(noise) sampled tokens; noise[step] holds the top_k uniforms of that step."""
+        with torch.inference_mode():
+            ck_, cv_ = (t.unsqueeze(0) for t in self.encode(audio))
+            ids = torch.tensor([list(prompt)], dtype=torch.long)
+            logits, sk, sv = self.decoder(ids, 0, None, None, ck_, cv_)
+            toks, hist = [], ids.shape[1]
+            head = logits[0] + self._c(self.begin_bias)
+            for step in range(len(noise)):
+                if step:
+                    logits, sk, sv = self.decoder(torch.tensor([[toks[-1]]]), hist, sk, sv, ck_, cv_)
+                    hist += 1
+                    head = logits[0]
+                toks.append(self.sample_head(head.float(), toks, noise[step], temperature, top_k, top_p, repetition_penalty))
+        return np.asarray(toks, dtype=np.int32)
+
     def greedy(self, audios, prompt_ids, n_new: int, eos_id=None, repeat_penalty: float = 1.0, penalty_range: int = 20):
         """Batch of utterances (list of 1-D arrays) -> dict of per-step logits / ids, following the reference host
         loop: prefill(prompt) -> arg-max(logits + begin_suppress) -> decode steps with plain arg-max, or -- repeat_penalty != 1,

@@ -88,3 +88,20 @@ def test_penalty_greedy_matches_reference_heads():
         assert np.array_equal(plain[:rng], want[:rng])                            # inactive until the window is full
         differs += int(not np.array_equal(c["plain_token_ids"], want))
     assert differs >= 2
+
+
+def test_sampling_head_matches_reference_module():
+    """TOPK_TOPP_SAMPLING restated with explicit uniforms vs goldens drawn from the reference module (its torch.rand_like stream
+    captured by re-seeding): repetition penalty, temperature, top-k, top-p cut, Gumbel-max."""
+    g = load_golden("whisper_tiny")
+    cfg, ck, sup, beg = whisper_setup(str(g["cfg_name"]), int(g["ckpt_seed"]))
+    orc = WhisperOracle(cfg, ck, sup, beg)
+    t, k, p, rp = (float(v) for v in g["sampling_params"])
+    for i, c in golden_cases(g):
+        got = orc.sample(unit_audio(c["audio_seed"], c["n_samples"]), c["prompt"].tolist(), c["sampling_noise"], t, int(k), p, rp)
+        assert np.array_equal(got, c["sampling_token_ids"]), i
+    # head-level properties: top_k = 1 is arg-max whatever the noise; a tiny top_p keeps only the best candidate
+    lg = torch.linspace(-3, 3, 50)
+    assert WhisperOracle.sample_head(lg, [], [0.3], 1.0, 1, 0.9, 1.0) == 49
+    assert WhisperOracle.sample_head(lg, [], [1e-6] + [0.999999] * 4, 1.0, 5, 1e-6, 1.0) == 49
+    assert WhisperOracle.sample_head(lg, [49], [0.5] * 2, 1.0, 2, 1.0, 100.0) == 48        # penalised id drops out of first place

@@ -140,3 +140,43 @@ def test_penalty_greedy_head_matches_reference_goldens():
         assert np.array_equal(plain[b][:m], c["plain_token_ids"][:m]), b
     with pytest.raises(Exception, match="range"):
         sess.set_penalty(0.8, 65)
+
+
+def test_sampling_head_matches_reference_goldens_and_is_reproducible():
+    """set_sampling(): with the reference's own uniforms the device head reproduces the reference module's picks (f32 mode, ragged
+    batch, one step at a time); with the built-in generator the same seed gives the same tokens and another seed differs."""
+    g = load_golden("whisper_tiny")
+    cfg, ck, sup, beg, sess = _session(str(g["cfg_name"]), F32)
+    cases = [c for _, c in golden_cases(g)]
+    t, k, p, rp = (float(v) for v in g["sampling_params"])
+    k = int(k)
+    audios = [unit_audio(c["audio_seed"], c["n_samples"]) for c in cases]
+    prompts = np.stack([c["prompt"] for c in cases])
+    steps = cases[0]["sampling_token_ids"].size
+    sess.encode(audios)
+    sess.set_sampling(True, t, k, p, rp, seed=1)
+    got = []
+    for s in range(steps):
+        sess.set_sampling_noise(np.stack([c["sampling_noise"][s] for c in cases]))
+        got.append(sess.prefill(prompts, want_logits=False)[0] if s == 0 else sess.decode(None)[0])
+    got = np.stack(got, 1)
+    for b, c in enumerate(cases):
+        assert np.array_equal(got[b], c["sampling_token_ids"]), b
+
+    def run(seed):
+        sess.set_sampling(True, t, k, p, rp, seed=seed)
+        sess.prefill(prompts, want_logits=False)
+        return np.stack(sess.generate(12, eos_id=-1))
+    a, b2, c2 = run(7), run(7), run(8)
+    assert np.array_equal(a, b2) and not np.array_equal(a, c2)
+    sess.set_sampling(True, t, 1, p, 1.0, seed=3)                  # top_k = 1 degenerates to greedy
+    sess.prefill(prompts, want_logits=False)
+    k1 = sess.generate(6, eos_id=-1)
+    sess.set_sampling(False)
+    sess.prefill(prompts, want_logits=False)
+    greedy = sess.generate(6, eos_id=-1)
+    for x, y, c in zip(k1, greedy, cases):
+        m = int(np.argmin(c["margin"] > 2e-3)) if not (c["margin"] > 2e-3).all() else 6
+        assert np.array_equal(x[:m], y[:m])
+    with pytest.raises(Exception, match="top_k"):
+        sess.set_sampling(True, t, 65, p, rp)

@@ -285,3 +285,82 @@ def reference_paraformer_stages(model, audio: np.ndarray) -> dict:
     return dict(mel=taps["mel"].numpy(), enc_out=taps["enc_out"].numpy(), alphas=torch.sigmoid(taps["alpha_logit"]).numpy(),
                 logits=taps["logits"].numpy()[:max(n, 1)], token_ids=token_ids[0].numpy().astype(np.int32),
                 num_id=num_id.numpy().astype(np.int32))
+
+
+# --------------------------------------------------------------------------- Paraformer (streaming)
+class _SinusoidalEmbed(torch.nn.Module):
+    """FunASR SinusoidalPositionEncoder.encode as the streaming exporter calls it (positions (1, n) -> (1, n, depth))."""
+
+    def encode(self, positions, depth, dtype=torch.float32):
+        positions = positions.to(torch.float32)
+        log_inc = torch.log(torch.tensor([10000.0])) / (depth / 2 - 1)
+        inv_ts = torch.exp(torch.arange(depth / 2).float() * (-log_inc)).reshape(1, -1)
+        st = positions.reshape(1, -1, 1) * inv_ts.reshape(1, 1, -1)
+        return torch.cat([torch.sin(st), torch.cos(st)], dim=2).to(dtype)
+
+
+def build_reference_paraformer_streaming(cfg, ck: dict, kaldi_mel_banks_fn, chunk=8000, look_back_encoder=4, look_back_decoder=1,
+                                         max_continue=502):
+    """The reference's PARAFORMER_ENCODER / PARAFORMER_DECODER (streaming) on a synthetic checkpoint, float32 caches
+    (USE_FP16_KV = False). Script-level prep :564-566: cmvn_vars *= sqrt(d_model)."""
+    assert reference_available()
+    from torch.onnx.operators import reshape_from_tensor_shape
+    path = os.path.join(REFERENCE_ROOT, "Paraformer", "Streaming", "Export_Paraformer_Streaming.py")
+    ns = dict(torch=torch, np=np, json=json, kaldi=types.SimpleNamespace(get_mel_banks=kaldi_mel_banks_fn),
+              reshape_from_tensor_shape=reshape_from_tensor_shape, CACHE_DTYPE=torch.float32, COMPUTE_IN_F32=False,
+              PREVENT_F16_OVERFLOW=False, USE_FP16_KV=False)
+    _compile_defs(path, ns)
+    standin = build_paraformer_standin(cfg, ck)
+    standin.encoder.embed = _SinusoidalEmbed()
+    for layer in standin.decoder.decoders:
+        layer.self_attn.kernel_size = cfg.fsmn_kernel
+    n_frames = (chunk - cfg.win_length) // cfg.hop_length + 1
+    B = ((cfg.lfr_m - 1) // 2 + n_frames) // cfg.lfr_n + 1
+    factor = float(cfg.d_model) ** 0.5
+    means = torch.from_numpy(ck["frontend.cmvn_means"]).reshape(1, 1, -1)
+    vars_ = (torch.from_numpy(ck["frontend.cmvn_vars"]) * factor).reshape(1, 1, -1)
+    with torch.inference_mode():
+        fbank = ns["KaldiFbank"](cfg.nfft, cfg.win_length, cfg.hop_length, cfg.n_mels, cfg.sample_rate, "hamming", cfg.pre_emphasis).eval()
+        enc = ns["PARAFORMER_ENCODER"](standin, fbank, n_frames, cfg.lfr_m, cfg.lfr_n, B, means, vars_, cfg.d_model, cfg.d_model, cfg.feat_dim,
+                                       0, B, B // 2, look_back_encoder, max_continue).eval()
+        dec = ns["PARAFORMER_DECODER"](standin, B, B // 2, look_back_decoder, cfg.d_model, cfg.n_dec).eval()
+    return dict(encoder=enc, decoder=dec, B=B, C=B // 2, chunk=chunk)
+
+
+def reference_paraformer_streaming_run(ref, cfg, audio: np.ndarray) -> list:
+    """Drive the two reference modules like Inference_Paraformer_Streaming_ONNX.py:401-449 (decoder state advances only when a
+    frame fired)."""
+    enc, dec = ref["encoder"], ref["decoder"]
+    H, hd, d = cfg.n_heads, cfg.d_head, cfg.d_model
+    n_en, n_de = cfg.n_enc0 + cfg.n_enc, cfg.n_dec
+    keys = [torch.zeros(H, hd, 0) for _ in range(n_en)]
+    vals = [torch.zeros(H, 0, hd) for _ in range(n_en)]
+    prev = torch.zeros(1, ref["C"], cfg.feat_dim)
+    cif_hidden, cif_alphas, start = torch.zeros(1, 1, d), torch.zeros(1), torch.zeros(1, dtype=torch.int64)
+    de_fsmn = [torch.zeros(1, d, cfg.fsmn_kernel - 1) for _ in range(n_de)]
+    de_k = [torch.zeros(H, hd, 0) for _ in range(n_de)]
+    de_v = [torch.zeros(H, 0, hd) for _ in range(n_de)]
+    out = []
+    with torch.inference_mode():
+        for s in range(0, audio.size - ref["chunk"] + 1, ref["chunk"]):
+            chunk = torch.from_numpy(audio[s:s + ref["chunk"]]).reshape(1, 1, -1).float()
+            res = enc(*[k.clone() for k in keys], *[v.clone() for v in vals], prev.clone(), cif_hidden.clone(), cif_alphas.clone(), start.clone(), chunk)
+            keys, vals = [t.clone() for t in res[:n_en]], [t.clone() for t in res[n_en:2 * n_en]]
+            prev, cif_hidden, cif_alphas, start, enc_out, list_frame, n = res[2 * n_en:]
+            prev, cif_hidden, cif_alphas, start = prev.clone(), cif_hidden.clone(), cif_alphas.clone(), start.clone()
+            n = int(n)
+            rec = dict(enc_out=enc_out[0].numpy().copy(), n=n, list_frame=list_frame[0].numpy().copy(), cif_alphas=float(cif_alphas.reshape(-1)[0]))
+            if n:
+                taps = {}
+                hook = dec.decoder.output_layer.register_forward_hook(lambda m, i, o: taps.__setitem__("logits", o[0].detach().clone()))
+                try:
+                    r2 = dec(*de_fsmn, *de_k, *de_v, enc_out, list_frame, torch.tensor(n))
+                finally:
+                    hook.remove()
+                de_fsmn, de_k, de_v = [t.clone() for t in r2[:n_de]], [t.clone() for t in r2[n_de:2 * n_de]], [t.clone() for t in r2[2 * n_de:3 * n_de]]
+                rec["token_ids"] = r2[-2].reshape(-1).numpy().astype(np.int32)
+                rec["logits"] = taps["logits"].numpy()
+            else:
+                rec["token_ids"] = np.zeros(0, np.int32)
+            out.append(rec)
+    return out

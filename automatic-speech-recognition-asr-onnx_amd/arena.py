@@ -388,7 +388,9 @@ def _fold64(norm_w, norm_b, w, b, out_scale=1.0):
     return w64.astype(np.float32), b64.astype(np.float32)
 
 
-def build_paraformer_arena(cfg, ck: dict, precision: int = PRECISION_BF16) -> np.ndarray:
+def build_paraformer_arena(cfg, ck: dict, precision: int = PRECISION_BF16, streaming: bool = False) -> np.ndarray:
+    """streaming=True (Export_Paraformer_Streaming.py): the decoder FSMN is a valid convolution over [10 history | tokens], so its
+    identity rides on the LAST tap; `cfg.max_audio_len` sizes the position table (MAX_CONTINUE_STREAMING - 1 rows for 30 s)."""
     w = ArenaWriter()
     d, feat, dd = cfg.d_model, cfg.feat_dim, cfg.d_dec_ffn
     nfreq = cfg.nfft // 2 + 1
@@ -409,9 +411,9 @@ def build_paraformer_arena(cfg, ck: dict, precision: int = PRECISION_BF16) -> np
     factor = float(cfg.d_head ** -0.25)
     pad = (cfg.fsmn_kernel - 1) // 2
 
-    def fsmn_w(p):
+    def fsmn_w(p, tap=pad):
         wf = ck[p + "self_attn.fsmn_block.weight"][:, 0, :].astype(np.float64)
-        wf[:, pad] += 1.0
+        wf[:, tap] += 1.0
         return wf.astype(np.float32)
 
     names = [f"encoder.encoders0.{i}." for i in range(cfg.n_enc0)] + [f"encoder.encoders.{i}." for i in range(cfg.n_enc)]
@@ -456,7 +458,7 @@ def build_paraformer_arena(cfg, ck: dict, precision: int = PRECISION_BF16) -> np
             kv_scale[:d] = factor
             wkv, bkv = _fold64(None, None, ck[p + "src_attn.linear_k_v.weight"], ck[p + "src_attn.linear_k_v.bias"], kv_scale)
             w.add(q + "n2_g", ck[p + "norm2.weight"], DT_F32); w.add(q + "n2_b", ck[p + "norm2.bias"], DT_F32)
-            w.add(q + "wfsmn", fsmn_w(p), DT_F32)
+            w.add(q + "wfsmn", fsmn_w(p, cfg.fsmn_kernel - 1 if streaming else pad), DT_F32)
             w.weight(q + "wq", wq, precision); w.add(q + "bq", bq, DT_F32)
             w.weight(q + "wkv", wkv, precision); w.add(q + "bkv", bkv, DT_F32)
             w.weight(q + "wo", ck[p + "src_attn.linear_out.weight"], precision); w.add(q + "bo", ck[p + "src_attn.linear_out.bias"], DT_F32)

@@ -199,3 +199,43 @@ void launch_fsmn_rows(const float* x, const float* res, const float* w, int d, i
                       const int32_t* row_utt, int n_rows, float* out, hipStream_t s);
 // token_ids[b][i] = ids[row_off_b + i], i < N_b
 void launch_gather_tokens(const int32_t* ids, const UttPlan* token_plan, int n_utts, int32_t* token_ids, int max_tokens, hipStream_t s);
+
+
+// ---- streaming Paraformer (Paraformer/Streaming/Export_Paraformer_Streaming.py:386-553). Every active stream owns a 16-row slot
+// (13 rows used: 4 carried + 9 new); UttPlan.lang carries the stream id that indexes the per-stream state.
+struct StreamLfrArgs {
+  const float* mel; const UttPlan* plan; const float* cmvn_vars; const float* pos_bias;   // pos_bias[p] = means * vars + position p + 1
+  const float* prev; const int32_t* start;      // state: carried rows [stream][n_prev][ld], absolute LFR position per stream
+  float* out; int ld; int feat, n_mels, lfr_m, lfr_n, n_prev, n_new, n_rows, n_frames, pos_rows;
+};
+void launch_stream_lfr(const StreamLfrArgs& a, hipStream_t s);
+// prev[stream] = rows [n_new .. n_new + n_prev) of the slot (the last n_prev of the n_prev + n_new rows); start[stream] += n_new
+void launch_stream_carry(const float* x, int ld, const UttPlan* plan, int n_active, int n_prev, int n_new, float* prev, int32_t* start,
+                         hipStream_t s);
+// soft-max attention of the slot's query rows over [cached keys of the stream | the slot's current rows], head_dim 128
+struct StreamAttnArgs {
+  const void* q; int ld_q, q_col0;
+  const void* k; int ld_k, k_col0; const void* v; int ld_v, v_col0; int n_cur;      // current rows (row-major, operand dtype)
+  const void* cache_k; const void* cache_v; const int32_t* cache_len; int cap;        // [stream][head][cap][128]
+  const UttPlan* q_plan;        // T = number of query rows (0 => nothing to do), row_off, lang = stream id
+  int n_heads;
+  void* ctx; int ld_ctx;
+};
+template <typename T> void launch_stream_attn(const StreamAttnArgs& a, int n_active, hipStream_t s);
+// cache = last `cap` of (cache ++ current rows [0, n_app)); skipped for streams whose cond_plan[i].T == 0 (when cond_plan is given)
+template <typename T>
+void launch_stream_cache_roll(void* cache_k, void* cache_v, const int32_t* cache_len, int cap, const void* k, int ld_k, int k_col0,
+                              const void* v, int ld_v, int v_col0, int n_app, const UttPlan* plan, const UttPlan* cond_plan, int n_active,
+                              int n_heads, hipStream_t s);
+// encoder FSMN over the slot's n_cur rows (zero padded at both ends), identity folded into the centre tap: mem = b + conv(v)
+template <typename T>
+void launch_stream_fsmn(const T* v, int ld_v, int v_col0, const float* w, const float* b, int d, int ktaps, int n_cur, int n_rows, float* mem,
+                        hipStream_t s);
+// unrolled integrate-and-fire over rows [0, n_int) of every slot with the carried (hidden, alphas) (:438-462)
+void launch_stream_cif(const float* alpha, const float* enc, int d, const UttPlan* plan, int n_active, int n_int, float* cif_hidden,
+                       float* cif_alphas, float* frames_out, UttPlan* token_plan, int32_t* num, hipStream_t s);
+// decoder FSMN over [hist | tokens] (valid conv, identity folded into the LAST tap) + residual; history advances when tokens exist
+void launch_stream_dec_fsmn(const float* x, const float* res, const float* w, int d, int ktaps, const UttPlan* token_plan, int n_active,
+                            float* hist, float* out, hipStream_t s);
+void launch_stream_advance(const UttPlan* plan, const UttPlan* token_plan, int n_active, int en_add, int en_cap, int de_add, int de_cap,
+                           int32_t* en_len, int32_t* de_len, hipStream_t s);

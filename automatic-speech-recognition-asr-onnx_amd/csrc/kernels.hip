@@ -1152,3 +1152,272 @@ void launch_gather_tokens(const int32_t* ids, const UttPlan* token_plan, int n_u
   hipLaunchKernelGGL(gather_tokens_kernel, dim3(n_utts), dim3(256), 0, s, ids, token_plan, token_ids, max_tokens);
   HIP_CHECK(hipGetLastError());
 }
+
+
+// ==================================================================================== streaming Paraformer
+namespace {
+
+__global__ __launch_bounds__(256) void stream_lfr_kernel(const StreamLfrArgs a) {
+  const int m = blockIdx.x, i = m >> 4, t = m & 15;
+  float* o = a.out + (size_t)m * a.ld;
+  const UttPlan up = a.plan[i];
+  const int sid = up.lang, left = (a.lfr_m - 1) / 2;
+  for (int c = threadIdx.x; c < a.ld; c += 256) {
+    float v = 0.0f;
+    if (c < a.feat && t < a.n_prev + a.n_new) {
+      if (t < a.n_prev) {
+        v = a.prev[((size_t)sid * a.n_prev + t) * a.ld + c];
+      } else {
+        const int j = t - a.n_prev;
+        int f = j * a.lfr_n + c / a.n_mels - left;
+        f = min(max(f, 0), a.n_frames - 1);
+        const int p = min(a.start[sid] + j, a.pos_rows - 1);
+        v = a.mel[(size_t)(up.frame_off + f) * a.n_mels + c % a.n_mels] * a.cmvn_vars[c] + a.pos_bias[(size_t)p * a.feat + c];
+      }
+    }
+    o[c] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void stream_carry_kernel(const float* __restrict__ x, int ld, const UttPlan* __restrict__ plan, int n_prev,
+                                                           int n_new, float* __restrict__ prev, int32_t* __restrict__ start) {
+  const int i = blockIdx.x, sid = plan[i].lang;
+  for (int e = threadIdx.x; e < n_prev * ld; e += 256) {
+    const int t = e / ld, c = e - t * ld;
+    prev[((size_t)sid * n_prev + t) * ld + c] = x[(size_t)(plan[i].row_off + n_new + t) * ld + c];
+  }
+  if (threadIdx.x == 0) start[sid] += n_new;
+}
+
+constexpr int SA_MAXK = 64, SA_HD = 128;
+
+template <typename T>
+__global__ __launch_bounds__(128) void stream_attn_kernel(const StreamAttnArgs a) {
+  __shared__ float Ks[SA_MAXK][SA_HD + 1];
+  __shared__ float Vs[SA_MAXK][SA_HD + 1];
+  __shared__ float qs[SA_HD];
+  __shared__ float pr[SA_MAXK];
+  const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  const UttPlan qp = a.q_plan[i];
+  const int nq = qp.T, sid = qp.lang, row0 = qp.row_off;
+  if (nq <= 0) return;
+  const int len = a.cache_len[sid], nk = len + a.n_cur;
+  const T* ck = reinterpret_cast<const T*>(a.cache_k) + ((size_t)sid * a.n_heads + h) * a.cap * SA_HD;
+  const T* cv = reinterpret_cast<const T*>(a.cache_v) + ((size_t)sid * a.n_heads + h) * a.cap * SA_HD;
+  const T* kk = reinterpret_cast<const T*>(a.k);
+  const T* vv = reinterpret_cast<const T*>(a.v);
+  for (int p = 0; p < nk; ++p) {
+    if (p < len) {
+      Ks[p][tid] = Elem<T>::load(ck + (size_t)p * SA_HD + tid);
+      Vs[p][tid] = Elem<T>::load(cv + (size_t)p * SA_HD + tid);
+    } else {
+      const size_t r = (size_t)(row0 + p - len);
+      Ks[p][tid] = Elem<T>::load(kk + r * a.ld_k + a.k_col0 + h * SA_HD + tid);
+      Vs[p][tid] = Elem<T>::load(vv + r * a.ld_v + a.v_col0 + h * SA_HD + tid);
+    }
+  }
+  const T* qq = reinterpret_cast<const T*>(a.q);
+  T* out = reinterpret_cast<T*>(a.ctx);
+  for (int qi = 0; qi < nq; ++qi) {
+    __syncthreads();
+    qs[tid] = Elem<T>::load(qq + (size_t)(row0 + qi) * a.ld_q + a.q_col0 + h * SA_HD + tid);
+    __syncthreads();
+    if (tid < 64) {                                   // one wave: scores, soft-max
+      float sc = -INFINITY;
+      if (tid < nk) {
+        sc = 0.0f;
+        for (int e = 0; e < SA_HD; ++e) sc = fmaf(qs[e], Ks[tid][e], sc);
+      }
+      const float mx = wave_max(sc);
+      const float ex = tid < nk ? expf(sc - mx) : 0.0f;
+      const float sum = wave_sum(ex);
+      pr[tid] = ex / sum;
+    }
+    __syncthreads();
+    float acc = 0.0f;
+    for (int p = 0; p < nk; ++p) acc = fmaf(pr[p], Vs[p][tid], acc);
+    Elem<T>::store(out + (size_t)(row0 + qi) * a.ld_ctx + h * SA_HD + tid, acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void stream_cache_roll_kernel(T* cache_k, T* cache_v, const int32_t* __restrict__ cache_len, int cap,
+                                                                const T* __restrict__ k, int ld_k, int k_col0, const T* __restrict__ v,
+                                                                int ld_v, int v_col0, int n_app, const UttPlan* __restrict__ plan,
+                                                                const UttPlan* __restrict__ cond_plan, int n_heads) {
+  const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  if (cond_plan && cond_plan[i].T <= 0) return;
+  const int sid = plan[i].lang, row0 = plan[i].row_off;
+  const int len = cache_len[sid], total = len + n_app, new_len = min(total, cap), drop = total - new_len;
+  T* ck = cache_k + ((size_t)sid * n_heads + h) * cap * SA_HD;
+  T* cv = cache_v + ((size_t)sid * n_heads + h) * cap * SA_HD;
+  for (int p = 0; p < new_len; ++p) {                // ascending: a thread only ever re-reads positions it has not overwritten yet
+    const int src = p + drop;
+    if (src < len) {
+      if (drop) { ck[(size_t)p * SA_HD + tid] = ck[(size_t)src * SA_HD + tid]; cv[(size_t)p * SA_HD + tid] = cv[(size_t)src * SA_HD + tid]; }
+    } else {
+      const size_t r = (size_t)(row0 + src - len);
+      ck[(size_t)p * SA_HD + tid] = k[r * ld_k + k_col0 + h * SA_HD + tid];
+      cv[(size_t)p * SA_HD + tid] = v[r * ld_v + v_col0 + h * SA_HD + tid];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stream_fsmn_kernel(const T* __restrict__ v, int ld_v, int v_col0, const float* __restrict__ w,
+                                                          const float* __restrict__ b, int d, int ktaps, int n_cur, float* __restrict__ mem) {
+  const int m = blockIdx.x, t = m & 15, base = m - t, pad = (ktaps - 1) / 2;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float acc = 0.0f;
+    if (t < n_cur) {
+      acc = b[c];
+      for (int j = 0; j < ktaps; ++j) {
+        const int tt = t + j - pad;
+        if (tt >= 0 && tt < n_cur) acc = fmaf(w[c * ktaps + j], Elem<T>::load(v + (size_t)(base + tt) * ld_v + v_col0 + c), acc);
+      }
+    }
+    mem[(size_t)m * d + c] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void stream_cif_kernel(const float* __restrict__ alpha, const float* __restrict__ enc, int d,
+                                                         const UttPlan* __restrict__ plan, int n_int, float* __restrict__ cif_hidden,
+                                                         float* __restrict__ cif_alphas, float* __restrict__ frames_out,
+                                                         UttPlan* __restrict__ token_plan, int32_t* __restrict__ num) {
+  const int i = blockIdx.x, sid = plan[i].lang, row0 = plan[i].row_off;
+  const float ca0 = cif_alphas[sid];
+  int n_fired = 0;
+  float ca_final = 0.0f;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float ca = ca0;
+    const float ch = cif_hidden[(size_t)sid * d + c];
+    int k = 0;
+    float cond_a = ca < 1.0f ? 1.0f : 0.0f, cond_b = 1.0f - cond_a;
+    float frames = ca * ch * cond_a + ch * cond_b;
+    float listed = frames;                                 // last entry of the reference's list_frame (fired or not)
+    if (cond_b != 0.0f) frames_out[(size_t)(row0 + k++) * d + c] = frames;
+    ca -= cond_b;
+    frames = frames * cond_a + ca * ch * cond_b;
+    for (int t = 0; t < n_int; ++t) {
+      const float al = alpha[row0 + t], hid = enc[(size_t)(row0 + t) * d + c];
+      const float thr = 1.0f - ca;
+      cond_a = al < thr ? 1.0f : 0.0f;
+      cond_b = 1.0f - cond_a;
+      frames = (frames + al * hid) * cond_a + (frames + thr * hid) * cond_b;
+      listed = frames;
+      if (cond_b != 0.0f) frames_out[(size_t)(row0 + k++) * d + c] = frames;
+      ca = ca + al;
+      ca -= cond_b;
+      frames = frames * cond_a + ca * hid * cond_b;
+    }
+    cif_hidden[(size_t)sid * d + c] = listed / ca;        // list_frame[:, -1] / cif_alphas, exactly as the reference carries it (:460)
+    n_fired = k;
+    ca_final = ca;
+  }
+  __syncthreads();                                         // every thread has read cif_alphas[sid] (before the loop) by now
+  if (threadIdx.x == 0) {
+    cif_alphas[sid] = ca_final;
+    UttPlan tp = plan[i];
+    tp.T = n_fired; tp.n_lfr = n_fired;
+    token_plan[i] = tp;
+    num[i] = n_fired;
+  }
+}
+
+__global__ __launch_bounds__(256) void stream_dec_fsmn_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                              const float* __restrict__ w, int d, int ktaps,
+                                                              const UttPlan* __restrict__ token_plan, float* __restrict__ hist,
+                                                              float* __restrict__ out) {
+  const int i = blockIdx.x;
+  const UttPlan tp = token_plan[i];
+  const int n = tp.T, sid = tp.lang, row0 = tp.row_off, nh = ktaps - 1;
+  if (n <= 0) return;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float cat[32];                                         // nh (10) history columns + up to 16 tokens
+    float* hc = hist + ((size_t)sid * nh) * d + c;
+    for (int j = 0; j < nh; ++j) cat[j] = hc[(size_t)j * d];
+    for (int t = 0; t < n; ++t) cat[nh + t] = x[(size_t)(row0 + t) * d + c];
+    for (int t = 0; t < n; ++t) {
+      float acc = res[(size_t)(row0 + t) * d + c];
+      for (int j = 0; j < ktaps; ++j) acc = fmaf(w[c * ktaps + j], cat[t + j], acc);
+      out[(size_t)(row0 + t) * d + c] = acc;
+    }
+    for (int j = 0; j < nh; ++j) hc[(size_t)j * d] = cat[n + j];
+  }
+}
+
+__global__ void stream_advance_kernel(const UttPlan* __restrict__ plan, const UttPlan* __restrict__ token_plan, int n_active, int en_add,
+                                      int en_cap, int de_add, int de_cap, int32_t* __restrict__ en_len, int32_t* __restrict__ de_len) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_active) return;
+  const int sid = plan[i].lang;
+  en_len[sid] = min(en_len[sid] + en_add, en_cap);
+  if (token_plan[i].T > 0) de_len[sid] = min(de_len[sid] + de_add, de_cap);
+}
+
+}  // namespace
+
+void launch_stream_lfr(const StreamLfrArgs& a, hipStream_t s) {
+  ASR_REQUIRE(a.n_prev + a.n_new <= 16 && a.n_rows % 16 == 0, "stream_lfr: %d + %d rows do not fit a 16-row slot", a.n_prev, a.n_new);
+  hipLaunchKernelGGL(stream_lfr_kernel, dim3(a.n_rows), dim3(256), 0, s, a);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_stream_carry(const float* x, int ld, const UttPlan* plan, int n_active, int n_prev, int n_new, float* prev, int32_t* start,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(stream_carry_kernel, dim3(n_active), dim3(256), 0, s, x, ld, plan, n_prev, n_new, prev, start);
+  HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void launch_stream_attn(const StreamAttnArgs& a, int n_active, hipStream_t s) {
+  ASR_REQUIRE(a.cap + a.n_cur <= SA_MAXK, "stream_attn: %d + %d keys exceed %d", a.cap, a.n_cur, SA_MAXK);
+  hipLaunchKernelGGL(stream_attn_kernel<T>, dim3(n_active, a.n_heads), dim3(128), 0, s, a);
+  HIP_CHECK(hipGetLastError());
+}
+template void launch_stream_attn<float>(const StreamAttnArgs&, int, hipStream_t);
+template void launch_stream_attn<bf16_t>(const StreamAttnArgs&, int, hipStream_t);
+
+template <typename T>
+void launch_stream_cache_roll(void* cache_k, void* cache_v, const int32_t* cache_len, int cap, const void* k, int ld_k, int k_col0,
+                              const void* v, int ld_v, int v_col0, int n_app, const UttPlan* plan, const UttPlan* cond_plan, int n_active,
+                              int n_heads, hipStream_t s) {
+  hipLaunchKernelGGL(stream_cache_roll_kernel<T>, dim3(n_active, n_heads), dim3(128), 0, s, (T*)cache_k, (T*)cache_v, cache_len, cap,
+                     (const T*)k, ld_k, k_col0, (const T*)v, ld_v, v_col0, n_app, plan, cond_plan, n_heads);
+  HIP_CHECK(hipGetLastError());
+}
+template void launch_stream_cache_roll<float>(void*, void*, const int32_t*, int, const void*, int, int, const void*, int, int, int,
+                                              const UttPlan*, const UttPlan*, int, int, hipStream_t);
+template void launch_stream_cache_roll<bf16_t>(void*, void*, const int32_t*, int, const void*, int, int, const void*, int, int, int,
+                                               const UttPlan*, const UttPlan*, int, int, hipStream_t);
+
+template <typename T>
+void launch_stream_fsmn(const T* v, int ld_v, int v_col0, const float* w, const float* b, int d, int ktaps, int n_cur, int n_rows, float* mem,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(stream_fsmn_kernel<T>, dim3(n_rows), dim3(256), 0, s, v, ld_v, v_col0, w, b, d, ktaps, n_cur, mem);
+  HIP_CHECK(hipGetLastError());
+}
+template void launch_stream_fsmn<float>(const float*, int, int, const float*, const float*, int, int, int, int, float*, hipStream_t);
+template void launch_stream_fsmn<bf16_t>(const bf16_t*, int, int, const float*, const float*, int, int, int, int, float*, hipStream_t);
+
+void launch_stream_cif(const float* alpha, const float* enc, int d, const UttPlan* plan, int n_active, int n_int, float* cif_hidden,
+                       float* cif_alphas, float* frames_out, UttPlan* token_plan, int32_t* num, hipStream_t s) {
+  ASR_REQUIRE(n_int + 1 <= 16, "stream_cif: %d frames per chunk exceed the 16-row slot", n_int + 1);
+  hipLaunchKernelGGL(stream_cif_kernel, dim3(n_active), dim3(256), 0, s, alpha, enc, d, plan, n_int, cif_hidden, cif_alphas, frames_out,
+                     token_plan, num);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_stream_dec_fsmn(const float* x, const float* res, const float* w, int d, int ktaps, const UttPlan* token_plan, int n_active,
+                            float* hist, float* out, hipStream_t s) {
+  ASR_REQUIRE(ktaps - 1 + 16 <= 32, "stream_dec_fsmn: %d taps", ktaps);
+  hipLaunchKernelGGL(stream_dec_fsmn_kernel, dim3(n_active), dim3(256), 0, s, x, res, w, d, ktaps, token_plan, hist, out);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_stream_advance(const UttPlan* plan, const UttPlan* token_plan, int n_active, int en_add, int en_cap, int de_add, int de_cap,
+                           int32_t* en_len, int32_t* de_len, hipStream_t s) {
+  hipLaunchKernelGGL(stream_advance_kernel, dim3((n_active + 63) / 64), dim3(64), 0, s, plan, token_plan, n_active, en_add, en_cap, de_add,
+                     de_cap, en_len, de_len);
+  HIP_CHECK(hipGetLastError());
+}

@@ -57,7 +57,8 @@ struct SvSession : asr_session {
   size_t h_out_cap = 0;
 
   ~SvSession() override {
-    for (DeviceBuffer* b : {&d_sta, &d_stb, &d_x0lo, &d_xalo, &d_xblo, &d_plan, &d_audio, &d_mel, &d_x0, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx, &d_mem, &d_ffn,
+    for (DeviceBuffer* b : {&d_sta, &d_stb, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
+                            &d_x0lo, &d_xalo, &d_xblo, &d_plan, &d_audio, &d_mel, &d_x0, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx, &d_mem, &d_ffn,
                             &d_amax_v, &d_amax_i, &d_ids, &d_tok, &d_num, &d_logits, &d_enc_lo, &d_ck, &d_cifa, &d_alpha, &d_dec, &d_x2,
                             &d_sa, &d_ffn32, &d_tplan})
       b->release();
@@ -71,6 +72,13 @@ struct SvSession : asr_session {
   }
 
   // hipGraph replay of the forward pass (one graph per batch geometry)
+  // ---- streaming Paraformer (kind 4): per-stream recurrent state in HBM, every step advances n streams by one chunk
+  int st_chunk = 0, st_B = 0, st_C = 0, st_en_cap = 0, st_de_cap = 0, st_max = 0, st_frames = 0;
+  DeviceBuffer st_enk, st_env, st_dek, st_dev, st_defsmn, st_prev, st_cifh, st_cifa, st_enlen, st_delen, st_start, d_sqkv, d_skv;
+  void stream_init(int chunk, int look_back_encoder, int look_back_decoder, int max_streams);
+  void stream_reset(int sid);
+  template <typename T> void stream_step(const float* audio, int audio_mem, const int32_t* stream_ids, int n, int32_t* tok_out, int max_tokens,
+                                         int32_t* num_out);
   bool use_graph = true;
   bool use_ln_alg = true;       // LayerNorm evaluated inside the projections from row statistics (ASR_LN_FUSED=0 disables)
   bool use_fused = true;        // fused q|k|v + attention + FSMN kernel for windows of <= 144 rows (ASR_SANM_FUSED=0 disables)
@@ -638,6 +646,308 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   }
 }
 
+// ---- streaming Paraformer (Paraformer/Streaming/Export_Paraformer_Streaming.py:386-553; host loop Inference_..._Streaming_ONNX.py:401-449)
+void SvSession::stream_init(int chunk, int look_back_encoder, int look_back_decoder, int max_streams) {
+  const auto& c = cfg;
+  ASR_REQUIRE(paraformer, "streaming: needs a Paraformer session");
+  ASR_REQUIRE(chunk >= c.win_length && max_streams >= 1 && look_back_encoder >= 1 && look_back_decoder >= 1, "streaming: bad geometry");
+  st_chunk = chunk;
+  st_frames = (chunk - c.win_length) / c.hop_length + 1;
+  st_B = ((c.lfr_m - 1) / 2 + st_frames) / c.lfr_n + 1;
+  st_C = st_B / 2;
+  st_en_cap = look_back_encoder * st_B;
+  st_de_cap = look_back_decoder * st_B;
+  st_max = max_streams;
+  ASR_REQUIRE(st_B + st_C <= 16 && st_frames <= 64 && st_en_cap + st_B + st_C <= 64 && st_de_cap + st_B + st_C <= 64 && c.d_head == 128,
+              "streaming: chunk of %d samples gives %d + %d rows per step (16-row slots, 64-key attention)", chunk, st_C, st_B);
+  const size_t T = precision == ASR_PRECISION_BF16 ? 2 : 4;
+  const size_t head_row = (size_t)c.n_heads * 128;
+  st_enk.reserve((size_t)c.n_blocks * max_streams * st_en_cap * head_row * T, stream);
+  st_env.reserve((size_t)c.n_blocks * max_streams * st_en_cap * head_row * T, stream);
+  st_dek.reserve((size_t)pcfg.n_dec * max_streams * st_de_cap * head_row * T, stream);
+  st_dev.reserve((size_t)pcfg.n_dec * max_streams * st_de_cap * head_row * T, stream);
+  st_defsmn.reserve((size_t)pcfg.n_dec * max_streams * (c.fsmn_kernel - 1) * c.d_model * 4, stream);
+  st_prev.reserve((size_t)max_streams * st_C * kpad0 * 4, stream);
+  st_cifh.reserve((size_t)max_streams * c.d_model * 4, stream);
+  st_cifa.reserve((size_t)max_streams * 4, stream);
+  st_enlen.reserve((size_t)max_streams * 4, stream);
+  st_delen.reserve((size_t)max_streams * 4, stream);
+  st_start.reserve((size_t)max_streams * 4, stream);
+  stream_reset(-1);
+}
+
+void SvSession::stream_reset(int sid) {
+  const auto& c = cfg;
+  ASR_REQUIRE(st_max > 0 && sid >= -1 && sid < st_max, "streaming: stream id %d out of range", sid);
+  HIP_CHECK(hipSetDevice(device));
+  const int lo = sid < 0 ? 0 : sid, cnt = sid < 0 ? st_max : 1;
+  // K/V histories are guarded by their length counters; the additive state must really be zero
+  HIP_CHECK(hipMemsetAsync(st_enlen.as<int32_t>() + lo, 0, (size_t)cnt * 4, stream));
+  HIP_CHECK(hipMemsetAsync(st_delen.as<int32_t>() + lo, 0, (size_t)cnt * 4, stream));
+  HIP_CHECK(hipMemsetAsync(st_start.as<int32_t>() + lo, 0, (size_t)cnt * 4, stream));
+  HIP_CHECK(hipMemsetAsync(st_cifa.as<float>() + lo, 0, (size_t)cnt * 4, stream));
+  HIP_CHECK(hipMemsetAsync(st_cifh.as<float>() + (size_t)lo * c.d_model, 0, (size_t)cnt * c.d_model * 4, stream));
+  HIP_CHECK(hipMemsetAsync(st_prev.as<float>() + (size_t)lo * st_C * kpad0, 0, (size_t)cnt * st_C * kpad0 * 4, stream));
+  const size_t hist = (size_t)(c.fsmn_kernel - 1) * c.d_model;
+  for (int l = 0; l < pcfg.n_dec; ++l)
+    HIP_CHECK(hipMemsetAsync(st_defsmn.as<float>() + ((size_t)l * st_max + lo) * hist, 0, (size_t)cnt * hist * 4, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+template <typename T>
+void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* stream_ids, int n, int32_t* tok_out, int max_tokens,
+                            int32_t* num_out) {
+  const auto& c = cfg;
+  ASR_REQUIRE(st_max > 0, "streaming: session was not created with asr_paraformer_stream_create");
+  ASR_REQUIRE(audio && stream_ids && tok_out && num_out && n >= 1 && n <= st_max && max_tokens >= st_B + 1, "streaming: bad argument (n = %d)", n);
+  HIP_CHECK(hipSetDevice(device));
+  const int d = c.d_model, dff = c.d_ffn, dd = pcfg.d_dec_ffn, H = c.n_heads, n_cur = st_B + st_C;
+  const int rows = n * 16, Mpad = round_up(rows, 128), frames = n * st_frames, n_slabs = vpad / 64;
+  std::vector<char> seen(st_max, 0);
+  // ---- plan: one 16-row slot / one fbank workgroup per active stream
+  const size_t plan_bytes = sizeof(UttPlan) * n + sizeof(int32_t) * (2 * (size_t)n + Mpad);
+  if (plan_bytes > h_plan_cap) {
+    if (h_plan) HIP_CHECK(hipHostFree(h_plan));
+    HIP_CHECK(hipHostMalloc(&h_plan, plan_bytes * 2, hipHostMallocDefault));
+    h_plan_cap = plan_bytes * 2;
+  }
+  UttPlan* hp = (UttPlan*)h_plan;
+  int32_t* blk_utt = (int32_t*)((unsigned char*)h_plan + sizeof(UttPlan) * n);
+  int32_t* blk_f0 = blk_utt + n;
+  int32_t* row_utt = blk_f0 + n;
+  for (int i = 0; i < n; ++i) {
+    ASR_REQUIRE(stream_ids[i] >= 0 && stream_ids[i] < st_max && !seen[stream_ids[i]], "streaming: stream id %d invalid or repeated", stream_ids[i]);
+    seen[stream_ids[i]] = 1;
+    UttPlan& p = hp[i];
+    p.audio_off = (int64_t)i * st_chunk; p.n_samples = st_chunk; p.n_frames = st_frames; p.frame_off = i * st_frames;
+    p.n_lfr = st_B; p.T = n_cur; p.row_off = i * 16; p.lang = stream_ids[i]; p.blk0 = i;
+    blk_utt[i] = i; blk_f0[i] = 0;
+    for (int t = 0; t < 16; ++t) row_utt[i * 16 + t] = i;
+  }
+  for (int t = rows; t < Mpad; ++t) row_utt[t] = -1;
+  const size_t eT = sizeof(T);
+  auto grow = [&](DeviceBuffer& buf, size_t bytes) { buf.reserve(bytes, stream); };
+  grow(d_plan, plan_bytes);
+  if (audio_mem == ASR_MEM_HOST) grow(d_audio, (size_t)n * st_chunk * 4);
+  grow(d_mel, (size_t)frames * c.n_mels * 4);
+  grow(d_x0, (size_t)Mpad * kpad0 * 4);
+  grow(d_xa, (size_t)Mpad * d * 4);
+  grow(d_xb, (size_t)Mpad * d * 4);
+  grow(d_h, (size_t)Mpad * std::max(kpad0, d) * eT);
+  grow(d_sqkv, (size_t)Mpad * 3 * d * eT);
+  grow(d_skv, (size_t)Mpad * 2 * d * eT);
+  grow(d_qk, (size_t)Mpad * 2 * d * eT);
+  grow(d_ctx, (size_t)Mpad * d * eT);
+  grow(d_mem, (size_t)Mpad * d * 4);
+  grow(d_ffn, (size_t)Mpad * std::max(dd, dff) * eT);
+  grow(d_amax_v, (size_t)Mpad * n_slabs * 4);
+  grow(d_amax_i, (size_t)Mpad * n_slabs * 4);
+  grow(d_ids, (size_t)Mpad * 4);
+  grow(d_tok, (size_t)n * max_tokens * 4);
+  grow(d_num, (size_t)n * 4);
+  grow(d_logits, (size_t)Mpad * vpad * 4);
+  grow(d_enc_lo, (size_t)Mpad * d * eT);
+  grow(d_cifa, (size_t)Mpad * 3 * d * eT);
+  grow(d_alpha, (size_t)Mpad * 4);
+  grow(d_dec, (size_t)Mpad * d * 4);
+  grow(d_x2, (size_t)Mpad * d * 4);
+  grow(d_sa, (size_t)Mpad * d * 4);
+  grow(d_ffn32, (size_t)Mpad * dd * 4);
+  grow(d_tplan, sizeof(UttPlan) * n);
+  const size_t out_bytes = (size_t)n * max_tokens * 4 + (size_t)n * 4;
+  if (out_bytes > h_out_cap) {
+    if (h_out) HIP_CHECK(hipHostFree(h_out));
+    HIP_CHECK(hipHostMalloc(&h_out, out_bytes * 2, hipHostMallocDefault));
+    h_out_cap = out_bytes * 2;
+  }
+  HIP_CHECK(hipMemcpyAsync(d_plan.ptr, h_plan, plan_bytes, hipMemcpyHostToDevice, stream));
+  const float* d_aud = audio;
+  if (audio_mem == ASR_MEM_HOST) {
+    HIP_CHECK(hipMemcpyAsync(d_audio.ptr, audio, (size_t)n * st_chunk * 4, hipMemcpyHostToDevice, stream));
+    d_aud = d_audio.as<float>();
+  }
+  const UttPlan* dp = d_plan.as<UttPlan>();
+  const int32_t* d_blk_utt = (const int32_t*)((unsigned char*)d_plan.ptr + sizeof(UttPlan) * n);
+  const int32_t* d_blk_f0 = d_blk_utt + n;
+  const int32_t* d_row_utt = d_blk_f0 + n;
+
+  // ---- front-end: fbank of the chunk, LFR rows, carried rows in front (:386-399)
+  {
+    ProfScope ps(prof, "fbank", stream);
+    FbankArgs fa;
+    fa.audio = d_aud; fa.plan = dp; fa.blk_utt = d_blk_utt; fa.blk_f0 = d_blk_f0;
+    fa.dft_packed = dft; fa.mel_packed = melp; fa.mel_out = d_mel.as<float>();
+    fa.n_bin_tiles = n_bin_tiles; fa.n_kchunks = n_kchunks; fa.n_mel_tiles = c.n_mels / 16; fa.n_mels = c.n_mels;
+    fa.win = c.win_length; fa.hop = c.hop_length; fa.log_floor = 1.1920928955078125e-07f; fa.whisper = 0; fa.blk_max = nullptr;
+    launch_fbank(fa, n, stream);
+  }
+  {
+    ProfScope ps(prof, "lfr_cmvn", stream);
+    StreamLfrArgs la;
+    la.mel = d_mel.as<float>(); la.plan = dp; la.cmvn_vars = cmvn_vars; la.pos_bias = speech_pos; la.prev = st_prev.as<float>();
+    la.start = st_start.as<int32_t>(); la.out = d_x0.as<float>(); la.ld = kpad0; la.feat = feat; la.n_mels = c.n_mels; la.lfr_m = c.lfr_m;
+    la.lfr_n = c.lfr_n; la.n_prev = st_C; la.n_new = st_B; la.n_rows = rows; la.n_frames = st_frames; la.pos_rows = max_lfr;
+    launch_stream_lfr(la, stream);
+    launch_stream_carry(d_x0.as<float>(), kpad0, dp, n, st_C, st_B, st_prev.as<float>(), st_start.as<int32_t>(), stream);
+  }
+  save_tap("enc_in", d_x0.ptr, rows, feat, kpad0, 4);
+  // ---- encoder layers with K/V history (:400-435)
+  const float* x_in = d_x0.as<float>();
+  int ld_in = kpad0;
+  float* xa = d_xa.as<float>();
+  float* xb = d_xb.as<float>();
+  T* h = d_h.as<T>();
+  T* qkv = d_sqkv.as<T>();
+  T* ctx = d_ctx.as<T>();
+  float* mem = d_mem.as<float>();
+  T* ffn = d_ffn.as<T>();
+  const size_t en_layer = (size_t)st_max * H * st_en_cap * 128;
+  for (int i = 0; i < c.n_blocks; ++i) {
+    const SvBlock& b = blocks[i];
+    { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(x_in, ld_in, rows, b.in_size, b.ln1_g, b.ln1_b, 1e-5f, h, b.kpad, b.kpad, stream); }
+    {
+      ProfScope ps(prof, "gemm_qkv", stream);
+      GemmArgs g;
+      g.A = h; g.lda = b.kpad; g.W = b.wqkv; g.ldw = b.kpad; g.M = rows; g.N = 3 * d; g.K = b.kpad; g.bias = b.bqkv; g.out_lo = qkv; g.ld_out_lo = 3 * d;
+      gemm(g);
+    }
+    {
+      ProfScope ps(prof, "attention", stream);
+      T* ck = st_enk.as<T>() + (size_t)i * en_layer;
+      T* cv = st_env.as<T>() + (size_t)i * en_layer;
+      StreamAttnArgs sa;
+      sa.q = qkv; sa.ld_q = 3 * d; sa.q_col0 = 0; sa.k = qkv; sa.ld_k = 3 * d; sa.k_col0 = d; sa.v = qkv; sa.ld_v = 3 * d; sa.v_col0 = 2 * d;
+      sa.n_cur = n_cur; sa.cache_k = ck; sa.cache_v = cv; sa.cache_len = st_enlen.as<int32_t>(); sa.cap = st_en_cap; sa.q_plan = dp; sa.n_heads = H;
+      sa.ctx = ctx; sa.ld_ctx = d;
+      launch_stream_attn<T>(sa, n, stream);
+      // history <- [-(cap + C) : -C] of (history ++ chunk): append the first B rows, keep the last cap (:421-422)
+      launch_stream_cache_roll<T>(ck, cv, st_enlen.as<int32_t>(), st_en_cap, qkv, 3 * d, d, qkv, 3 * d, 2 * d, st_B, dp, nullptr, n, H, stream);
+    }
+    { ProfScope ps(prof, "fsmn", stream); launch_stream_fsmn<T>(qkv, 3 * d, 2 * d, b.wfsmn, b.bfsmn, d, c.fsmn_kernel, n_cur, rows, mem, stream); }
+    {
+      ProfScope ps(prof, "gemm_out", stream);
+      GemmArgs g;
+      g.A = ctx; g.lda = d; g.W = b.wout; g.ldw = d; g.M = rows; g.N = d; g.K = d; g.add = mem; g.ld_add = d;
+      if (i > 0) { g.add2 = x_in; g.ld_add2 = ld_in; }             // residual from the second layer on (:402-403,431-432)
+      g.out_f32 = xb; g.ld_out_f32 = d;
+      gemm(g);
+    }
+    { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(xb, d, rows, d, b.ln2_g, b.ln2_b, 1e-5f, h, d, d, stream); }
+    {
+      ProfScope ps(prof, "gemm_ffn1", stream);
+      GemmArgs g;
+      g.A = h; g.lda = d; g.W = b.w1; g.ldw = d; g.M = rows; g.N = dff; g.K = d; g.bias = b.b1; g.act = ACT_RELU; g.out_lo = ffn; g.ld_out_lo = dff;
+      gemm(g);
+    }
+    {
+      ProfScope ps(prof, "gemm_ffn2", stream);
+      GemmArgs g;
+      g.A = ffn; g.lda = dff; g.W = b.w2; g.ldw = dff; g.M = rows; g.N = d; g.K = dff; g.bias = b.b2; g.add = xb; g.ld_add = d; g.out_f32 = xa; g.ld_out_f32 = d;
+      gemm(g);
+    }
+    x_in = xa;
+    ld_in = d;
+  }
+  // ---- after_norm, CIF conv + alphas, unrolled integrate-and-fire with the carried state (:436-462)
+  float* enc32 = d_xb.as<float>();
+  T* enc_lo = d_enc_lo.as<T>();
+  float* dec = d_dec.as<float>();
+  UttPlan* tplan = d_tplan.as<UttPlan>();
+  {
+    ProfScope ps(prof, "layernorm", stream);
+    launch_layernorm<float>(xa, d, rows, d, after_g, after_b, 1e-5f, enc32, d, d, stream);
+    launch_layernorm<T>(xa, d, rows, d, after_g, after_b, 1e-5f, enc_lo, d, d, stream);
+  }
+  save_tap("enc_out", enc32, rows, d, d, 4);
+  {
+    ProfScope ps(prof, "cif", stream);
+    launch_shift3<T>(enc_lo, d, dp, d_row_utt, Mpad, d_cifa.as<T>(), stream);
+    GemmArgs g;
+    g.A = d_cifa.ptr; g.lda = 3 * d; g.W = cif_conv_w; g.ldw = 3 * d; g.M = rows; g.N = d; g.K = 3 * d; g.bias = cif_conv_b; g.act = ACT_RELU;
+    g.out_lo = ctx; g.ld_out_lo = d;
+    gemm(g);
+    launch_alpha<T>(ctx, d, cif_out_w, cif_out_b, rows, d_alpha.as<float>(), stream);
+    launch_stream_cif(d_alpha.as<float>(), enc32, d, dp, n, st_B, st_cifh.as<float>(), st_cifa.as<float>(), dec, tplan, d_num.as<int32_t>(), stream);
+  }
+  save_tap("alphas", d_alpha.ptr, rows, 1, 1, 4);
+  save_tap("list_frame", dec, rows, d, d, 4);
+  // ---- decoder over the fired frames (:508-553); streams without a fired frame leave their decoder state untouched
+  T* q = d_qk.as<T>();
+  T* kv = d_skv.as<T>();
+  float* ffn32 = d_ffn32.as<float>();
+  float* x1 = d_mem.as<float>();
+  float* x2 = d_x2.as<float>();
+  float* sa32 = d_sa.as<float>();
+  const size_t de_layer = (size_t)st_max * H * st_de_cap * 128, fs_layer = (size_t)st_max * (c.fsmn_kernel - 1) * d;
+  auto ffn_block = [&](const PfDecLayer& L, float* out) {
+    { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(dec, d, rows, d, nullptr, nullptr, 1e-5f, h, d, d, stream); }
+    ProfScope ps(prof, "gemm_dec", stream);
+    GemmArgs g;
+    g.A = h; g.lda = d; g.W = L.w1; g.ldw = d; g.M = rows; g.N = dd; g.K = d; g.bias = L.b1; g.act = ACT_RELU; g.out_f32 = ffn32; g.ld_out_f32 = dd;
+    gemm(g);
+    launch_layernorm<T>(ffn32, dd, rows, dd, nullptr, nullptr, 1e-5f, ffn, dd, dd, stream);
+    GemmArgs g2;
+    g2.A = ffn; g2.lda = dd; g2.W = L.w2; g2.ldw = dd; g2.M = rows; g2.N = d; g2.K = dd; g2.bias = L.b2; g2.out_f32 = out; g2.ld_out_f32 = d;
+    gemm(g2);
+  };
+  int li = 0;
+  for (const PfDecLayer& L : pdec) {
+    if (!L.full) { ffn_block(L, dec); continue; }
+    ffn_block(L, x1);
+    {
+      ProfScope ps(prof, "fsmn", stream);
+      launch_layernorm<float>(x1, d, rows, d, L.n2_g, L.n2_b, 1e-5f, sa32, d, d, stream);
+      launch_stream_dec_fsmn(sa32, dec, L.wfsmn, d, c.fsmn_kernel, tplan, n, st_defsmn.as<float>() + (size_t)li * fs_layer, x2, stream);
+    }
+    { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(x2, d, rows, d, nullptr, nullptr, 1e-5f, h, d, d, stream); }
+    {
+      ProfScope ps(prof, "gemm_dec", stream);
+      GemmArgs g;
+      g.A = h; g.lda = d; g.W = L.wq; g.ldw = d; g.M = rows; g.N = d; g.K = d; g.bias = L.bq; g.out_lo = q; g.ld_out_lo = d;
+      gemm(g);
+      GemmArgs gk;
+      gk.A = enc_lo; gk.lda = d; gk.W = L.wkv; gk.ldw = d; gk.M = rows; gk.N = 2 * d; gk.K = d; gk.bias = L.bkv; gk.out_lo = kv; gk.ld_out_lo = 2 * d;
+      gemm(gk);
+    }
+    {
+      ProfScope ps(prof, "attention", stream);
+      T* ck = st_dek.as<T>() + (size_t)li * de_layer;
+      T* cv = st_dev.as<T>() + (size_t)li * de_layer;
+      StreamAttnArgs sa;
+      sa.q = q; sa.ld_q = d; sa.q_col0 = 0; sa.k = kv; sa.ld_k = 2 * d; sa.k_col0 = 0; sa.v = kv; sa.ld_v = 2 * d; sa.v_col0 = d; sa.n_cur = n_cur;
+      sa.cache_k = ck; sa.cache_v = cv; sa.cache_len = st_delen.as<int32_t>(); sa.cap = st_de_cap; sa.q_plan = tplan; sa.n_heads = H;
+      sa.ctx = ctx; sa.ld_ctx = d;
+      launch_stream_attn<T>(sa, n, stream);
+      launch_stream_cache_roll<T>(ck, cv, st_delen.as<int32_t>(), st_de_cap, kv, 2 * d, 0, kv, 2 * d, d, n_cur, dp, tplan, n, H, stream);
+    }
+    {
+      ProfScope ps(prof, "gemm_dec", stream);
+      GemmArgs g;
+      g.A = ctx; g.lda = d; g.W = L.wo; g.ldw = d; g.M = rows; g.N = d; g.K = d; g.bias = L.bo; g.add = x2; g.ld_add = d; g.out_f32 = dec; g.ld_out_f32 = d;
+      gemm(g);
+    }
+    ++li;
+  }
+  { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(dec, d, rows, d, nullptr, nullptr, 1e-5f, h, d, d, stream); }
+  {
+    ProfScope ps(prof, "gemm_out", stream);
+    GemmArgs g;
+    g.A = h; g.lda = d; g.W = pf_out_w; g.ldw = d; g.M = rows; g.N = vpad; g.K = d; g.bias = pf_out_b; g.out_f32 = d_logits.as<float>(); g.ld_out_f32 = vpad;
+    gemm(g);
+    launch_argmax_rows(d_logits.as<float>(), vpad, rows, c.vocab, nullptr, d_ids.as<int32_t>(), stream);
+    launch_gather_tokens(d_ids.as<int32_t>(), tplan, n, d_tok.as<int32_t>(), max_tokens, stream);
+  }
+  launch_stream_advance(dp, tplan, n, st_B, st_en_cap, n_cur, st_de_cap, st_enlen.as<int32_t>(), st_delen.as<int32_t>(), stream);
+  if (taps_enabled) save_tap("logits", d_logits.ptr, rows, c.vocab, vpad, 4);
+  HIP_CHECK(hipMemcpyAsync(h_out, d_tok.ptr, (size_t)n * max_tokens * 4, hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipMemcpyAsync((unsigned char*)h_out + (size_t)n * max_tokens * 4, d_num.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  if (prof.enabled) prof.collect();
+  memcpy(num_out, (unsigned char*)h_out + (size_t)n * max_tokens * 4, (size_t)n * 4);
+  const int32_t* ht = (const int32_t*)h_out;
+  for (int i = 0; i < n; ++i) memcpy(tok_out + (size_t)i * max_tokens, ht + (size_t)i * max_tokens, (size_t)std::min(num_out[i], max_tokens) * 4);
+}
+
 }  // namespace
 
 extern "C" int asr_sensevoice_create(const asr_sensevoice_config* cfg, const void* arena, size_t arena_bytes, int arena_mem,
@@ -719,6 +1029,39 @@ extern "C" int asr_paraformer_create(const asr_paraformer_config* cfg, const voi
       throw;
     }
     *out = s;
+  });
+}
+
+extern "C" int asr_paraformer_stream_create(const asr_paraformer_config* cfg, const void* arena, size_t arena_bytes, int arena_mem,
+                                            int device_id, int precision, int chunk_samples, int look_back_encoder, int look_back_decoder,
+                                            int max_streams, asr_session** out) {
+  asr_session* base = nullptr;
+  const int rc = asr_paraformer_create(cfg, arena, arena_bytes, arena_mem, device_id, precision, &base);
+  if (rc != ASR_OK) return rc;
+  const int rc2 = asr_guard([&] {
+    SvSession* sv = static_cast<SvSession*>(base);
+    sv->kind = 4;
+    sv->stream_init(chunk_samples, look_back_encoder, look_back_decoder, max_streams);
+    *out = base;
+  });
+  if (rc2 != ASR_OK) delete base;
+  return rc2;
+}
+
+extern "C" int asr_paraformer_stream_reset(asr_session* s, int stream_id) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 4, "paraformer_stream_reset: not a streaming Paraformer session");
+    static_cast<SvSession*>(s)->stream_reset(stream_id);
+  });
+}
+
+extern "C" int asr_paraformer_stream_step(asr_session* s, const float* audio, int audio_mem, const int32_t* stream_ids, int n_streams,
+                                          int32_t* token_ids_out, int max_tokens, int32_t* num_id_out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 4, "paraformer_stream_step: not a streaming Paraformer session");
+    SvSession* sv = static_cast<SvSession*>(s);
+    if (sv->precision == ASR_PRECISION_BF16) sv->stream_step<bf16_t>(audio, audio_mem, stream_ids, n_streams, token_ids_out, max_tokens, num_id_out);
+    else sv->stream_step<float>(audio, audio_mem, stream_ids, n_streams, token_ids_out, max_tokens, num_id_out);
   });
 }
 

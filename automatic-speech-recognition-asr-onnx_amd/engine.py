@@ -385,6 +385,46 @@ class ParaformerSession(_Session):
         return out
 
 
+class ParaformerStreamSession(_Session):
+    """Streaming Paraformer: per-stream recurrent state (encoder K/V histories, carried LFR rows, CIF state, decoder FSMN / cross
+    K/V histories) lives in the session; `step` advances a set of streams by one chunk (Export_Paraformer_Streaming.py:386-553)."""
+
+    def __init__(self, cfg, ck_or_arena, precision: int = PRECISION_BF16, device_id: int = 0, chunk: int = 8000, look_back_encoder: int = 4,
+                 look_back_decoder: int = 1, max_streams: int = 8, max_continue: int = 502):
+        super().__init__()
+        import dataclasses
+        from .arena import build_paraformer_arena
+        n_pos = max_continue - 1                                          # rows of the position table (positions 1 .. max_continue - 1)
+        cfg = dataclasses.replace(cfg, max_audio_len=cfg.win_length + cfg.hop_length * (n_pos * cfg.lfr_n - 1))
+        assert cfg.seq_len(cfg.max_audio_len) == n_pos
+        self.cfg, self.precision, self.chunk, self.max_streams = cfg, precision, int(chunk), int(max_streams)
+        n_frames = (chunk - cfg.win_length) // cfg.hop_length + 1
+        self.rows_per_chunk = ((cfg.lfr_m - 1) // 2 + n_frames) // cfg.lfr_n + 1
+        blob = build_paraformer_arena(cfg, ck_or_arena, precision, streaming=True) if isinstance(ck_or_arena, dict) else ck_or_arena
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        c = _lib.ParaformerConfigC()
+        for f in ("sample_rate", "n_mels", "nfft", "win_length", "hop_length", "lfr_m", "lfr_n", "d_model", "n_heads", "d_head", "d_ffn",
+                  "fsmn_kernel", "n_dec", "n_dec3", "d_dec_ffn", "cif_kernel", "vocab", "max_audio_len"):
+            setattr(c, f, getattr(cfg, f))
+        c.n_blocks = cfg.n_enc0 + cfg.n_enc
+        c.tail_threshold = cfg.tail_threshold
+        _lib.check(_lib.load().asr_paraformer_stream_create(C.byref(c), blob.ctypes.data_as(C.c_void_p), blob.nbytes, MEM_HOST, device_id, precision,
+                                                            int(chunk), look_back_encoder, look_back_decoder, int(max_streams), C.byref(self._h)))
+
+    def reset(self, stream_id: int = -1):
+        _lib.check(_lib.load().asr_paraformer_stream_reset(self._h, int(stream_id)))
+
+    def step(self, chunks, stream_ids):
+        """chunks: (n, chunk) int16-range float32; stream_ids: n distinct ids -> list of n int32 arrays (tokens fired by this chunk)."""
+        a = _f32(chunks).reshape(len(stream_ids), self.chunk)
+        sid = np.ascontiguousarray(stream_ids, dtype=np.int32)
+        cap = self.rows_per_chunk + 1
+        tok = np.zeros((sid.size, cap), dtype=np.int32)
+        num = np.zeros(sid.size, dtype=np.int32)
+        _lib.check(_lib.load().asr_paraformer_stream_step(self._h, a.ctypes.data_as(C.c_void_p), MEM_HOST, _ip(sid), sid.size, _ip(tok), cap, _ip(num)))
+        return [tok[i, :num[i]].copy() for i in range(sid.size)]
+
+
 def load_session(path: str, device_id: int = 0):
     """Open an `.asrmodel` bundle (tools/convert_checkpoint.py, export_*) as the matching native session."""
     from . import config as cfgm

@@ -109,6 +109,22 @@ int asr_paraformer_create(const asr_paraformer_config* cfg, const void* arena, s
 int asr_paraformer_run(asr_session* s, const float* audio, int audio_mem, const int64_t* audio_offsets, int batch,
                        int32_t* token_ids_out, int max_tokens, int32_t* num_id_out);
 
+/* Streaming Paraformer: replaces Paraformer_Streaming_Encoder.onnx + Paraformer_Streaming_Decoder.onnx (PARAFORMER_ENCODER /
+ * PARAFORMER_DECODER, Paraformer/Streaming/Export_Paraformer_Streaming.py:330-553) and the state shuttling of
+ * Inference_Paraformer_Streaming_ONNX.py:309-449. The 100 in_en_key/value tensors, in_previous_mel_features, in_cif_hidden,
+ * in_cif_alphas, start_idx, in_de_fsmn / in_de_key / in_de_value of a stream live in HBM inside the session, indexed by a
+ * stream id in [0, max_streams); one step advances n_streams DIFFERENT streams by one chunk_samples-sample chunk each
+ * (audio: [n_streams][chunk_samples], int16-range float) and runs the decoder for the streams whose CIF fired -- streams
+ * without a fired frame keep their decoder state, exactly like the host loop (:420-447). token_ids_out: host
+ * [n_streams][max_tokens] (max_tokens >= LFR rows per chunk + 1), num_id_out: host [n_streams]. The arena is the
+ * non-streaming Paraformer arena built for streaming (position table up to MAX_CONTINUE_STREAMING, causal decoder FSMN). */
+int asr_paraformer_stream_create(const asr_paraformer_config* cfg, const void* arena, size_t arena_bytes, int arena_mem, int device_id,
+                                 int precision, int chunk_samples, int look_back_encoder, int look_back_decoder, int max_streams,
+                                 asr_session** out);
+int asr_paraformer_stream_reset(asr_session* s, int stream_id);      /* -1 = every stream: empty histories, zero CIF state */
+int asr_paraformer_stream_step(asr_session* s, const float* audio, int audio_mem, const int32_t* stream_ids, int n_streams,
+                               int32_t* token_ids_out, int max_tokens, int32_t* num_id_out);
+
 /* ------------------------------------------------------------------ Whisper (encoder + KV-cache decoder)
  * Replaces the merged graphs Whisper_ProbePrefillGreedy / Whisper_PrefillGreedy / Whisper_DecodeGreedy
  * (Whisper/Shared_Merged.py:864-888; I/O planner Whisper/Inference_Whisper_ONNX.py:323-392), i.e.

@@ -1,0 +1,78 @@
+"""GPU parity: the HIP streaming-Paraformer path (per-stream state in HBM, chunk steps) through the C ABI vs goldens minted from
+the reference's PARAFORMER_ENCODER / PARAFORMER_DECODER and vs the streaming oracle."""
+import numpy as np
+import pytest
+
+from conftest import sub
+from helpers import kaldi_audio, load_golden
+from oracle.paraformer_streaming_oracle import ParaformerStreamingOracle
+from test_oracle_paraformer_streaming import streaming_cases, streaming_setup
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = 0, 1
+TOL_F32 = 1e-3
+
+
+@pytest.mark.parametrize("fixture", ["paraformer_streaming_tiny", "paraformer_streaming_sparse", "paraformer_streaming_large"])
+def test_f32_mode_matches_reference_goldens(fixture):
+    """All clips of a fixture run as concurrent streams of ONE session (shorter clips drop out when they end); per chunk the
+    encoder output, the fired-frame count, the logits and the token ids are compared."""
+    g = load_golden(fixture)
+    cfg, ck = streaming_setup(g)
+    chunk = int(g["chunk"])
+    cases = [c for _, c in streaming_cases(g)]
+    audios = [kaldi_audio(c["audio_seed"], int(c["n_chunks"]) * chunk) for c in cases]
+    sess = sub("engine").ParaformerStreamSession(cfg, ck, precision=F32, chunk=chunk, max_streams=4)
+    sess.taps(True)
+    small = cfg.d_model <= 128
+    toks = [[] for _ in cases]
+    for k in range(max(int(c["n_chunks"]) for c in cases)):
+        live = [i for i, c in enumerate(cases) if k < int(c["n_chunks"])]
+        sids = [i + 1 for i in live]                                  # stream ids need not be dense or start at 0
+        out = sess.step(np.stack([audios[i][k * chunk:(k + 1) * chunk] for i in live]), sids)
+        enc, logits = sess.tap("enc_out"), sess.tap("logits")
+        for slot, i in enumerate(live):
+            ref = cases[i]["chunks"][k]
+            e = enc[16 * slot:16 * slot + 13]
+            assert np.abs((e if small else e[:, ::8]) - ref["enc_out"]).max() < TOL_F32, (i, k)
+            n = int(cases[i]["n_fired"][k])
+            assert out[slot].size == n, (i, k)
+            if n:
+                lg = logits[16 * slot:16 * slot + n]
+                assert np.abs((lg if small else lg[:, ::37]) - ref["logits"]).max() < TOL_F32, (i, k)
+            toks[i].append(out[slot])
+    for i, c in enumerate(cases):
+        got = np.concatenate(toks[i]) if toks[i] else np.zeros(0, np.int32)
+        if (c["margin"] > 2 * TOL_F32).all():
+            assert np.array_equal(got, c["token_ids"]), i
+
+
+def test_bf16_streams_vs_oracle_reset_and_errors():
+    g = load_golden("paraformer_streaming_large")
+    cfg, ck = streaming_setup(g)
+    chunk = int(g["chunk"])
+    orc = ParaformerStreamingOracle(cfg, ck, chunk=chunk)
+    audio = [kaldi_audio(3400 + i, 5 * chunk) for i in range(3)]
+    want = [orc.run(a) for a in audio]
+    sess = sub("engine").ParaformerStreamSession(cfg, ck, precision=BF16, chunk=chunk, max_streams=3)
+    sess.taps(True)
+    fired_ok = total = 0
+    for k in range(5):
+        out = sess.step(np.stack([a[k * chunk:(k + 1) * chunk] for a in audio]), [2, 0, 1])
+        enc = sess.tap("enc_out")
+        for slot in range(3):
+            ref = want[slot][k]
+            assert np.abs(enc[16 * slot:16 * slot + 13] - ref["enc_out"]).max() < 0.15
+            fired_ok += int(out[slot].size == ref["n"])
+            total += 1
+    assert fired_ok / total >= 0.8                              # bf16 alphas may move a fire across a chunk boundary
+    # a reset stream restarts exactly like a fresh session; the others keep their state
+    sess.reset(2)
+    first = sess.step(audio[0][:chunk][None], [2])
+    fresh = sub("engine").ParaformerStreamSession(cfg, ck, precision=BF16, chunk=chunk, max_streams=1)
+    assert np.array_equal(first[0], fresh.step(audio[0][:chunk][None], [0])[0])
+    with pytest.raises(Exception, match="repeated"):
+        sess.step(np.stack([audio[0][:chunk]] * 2), [1, 1])
+    with pytest.raises(Exception, match="invalid"):
+        sess.step(audio[0][:chunk][None], [3])

@@ -414,14 +414,19 @@ class ParaformerStreamSession(_Session):
     def reset(self, stream_id: int = -1):
         _lib.check(_lib.load().asr_paraformer_stream_reset(self._h, int(stream_id)))
 
-    def step(self, chunks, stream_ids):
-        """chunks: (n, chunk) int16-range float32; stream_ids: n distinct ids -> list of n int32 arrays (tokens fired by this chunk)."""
-        a = _f32(chunks).reshape(len(stream_ids), self.chunk)
+    def step(self, chunks, stream_ids, audio_device_ptr: int | None = None):
+        """chunks: (n, chunk) int16-range float32 (or None with `audio_device_ptr`: HBM-resident [n][chunk] floats); stream_ids: n
+        distinct ids -> list of n int32 arrays (tokens fired by this chunk)."""
         sid = np.ascontiguousarray(stream_ids, dtype=np.int32)
+        if audio_device_ptr is not None:
+            ap, mem = C.c_void_p(audio_device_ptr), MEM_DEVICE
+        else:
+            a = _f32(chunks).reshape(sid.size, self.chunk)
+            ap, mem = a.ctypes.data_as(C.c_void_p), MEM_HOST
         cap = self.rows_per_chunk + 1
         tok = np.zeros((sid.size, cap), dtype=np.int32)
         num = np.zeros(sid.size, dtype=np.int32)
-        _lib.check(_lib.load().asr_paraformer_stream_step(self._h, a.ctypes.data_as(C.c_void_p), MEM_HOST, _ip(sid), sid.size, _ip(tok), cap, _ip(num)))
+        _lib.check(_lib.load().asr_paraformer_stream_step(self._h, ap, mem, _ip(sid), sid.size, _ip(tok), cap, _ip(num)))
         return [tok[i, :num[i]].copy() for i in range(sid.size)]
 
 

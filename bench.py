@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
-    ap.add_argument("--workload", choices=("sensevoice", "whisper", "paraformer"), default="sensevoice",
+    ap.add_argument("--workload", choices=("sensevoice", "whisper", "paraformer", "paraformer-streaming"), default="sensevoice",
                     help="sensevoice = BASELINE.json configs[1] (default, the headline line); whisper = large-v3 encoder + greedy decode")
     ap.add_argument("--decode-tokens", type=int, default=0, help="whisper: generated tokens per utterance (default 4 per audio second)")
     args = ap.parse_args()
@@ -111,6 +111,8 @@ def main():
         return main_whisper(args)
     if args.workload == "paraformer":
         return main_paraformer(args)
+    if args.workload == "paraformer-streaming":
+        return main_paraformer_streaming(args)
 
     import torch
     import torch.distributed as dist
@@ -346,6 +348,99 @@ def main_paraformer(args):
             out["cpu_baseline"] = {"value": round(n_done * args.seconds / el, 2), "unit": "audio-s/s", "cores": int(torch.get_num_threads()),
                                    "kind": "port", "sample": f"{n_done} x {args.seconds:g} s utterances, batch 1, torch-CPU f32 oracle "
                                    f"(oracle/paraformer_oracle.py), {el:.1f} s wall"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_paraformer_streaming(args):
+    """Paraformer-large streaming, chunk = 8000 samples (0.5 s): `--batch` concurrent streams advance one chunk per step."""
+    import torch
+    import torch.distributed as dist
+    cfgm = importlib.import_module(PKG + ".config")
+    ckm = importlib.import_module(PKG + ".checkpoints")
+    eng = importlib.import_module(PKG + ".engine")
+    dp = importlib.import_module(PKG + ".dist")
+    rank, local_rank, world = dp.init_from_env()
+    assert world == args.gpus and torch.cuda.is_available()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    cfg = cfgm.paraformer_large()
+    S, chunk = args.batch, 8000
+    ck = ckm.synth_paraformer_checkpoint(cfg, seed=0)                   # every rank builds the same arena (streams pin to their GPU)
+    sess = eng.ParaformerStreamSession(cfg, ck, precision=0, device_id=local_rank, chunk=chunk, max_streams=S)
+    n_chunks = 8
+    audio_np = ckm.synth_audio("kaldi", S, n_chunks * chunk, seed=1234 + rank)[:, 0].reshape(S, n_chunks, chunk)
+    audio_dev = torch.from_numpy(np.ascontiguousarray(audio_np.transpose(1, 0, 2))).to(device)      # [chunk index][stream][samples]
+    sids = list(range(S))
+    tokens = 0
+
+    def step(i):
+        nonlocal tokens
+        k = i % n_chunks
+        if k == 0:
+            sess.reset(-1)
+        out = sess.step(None, sids, audio_device_ptr=audio_dev[k].data_ptr())
+        tokens += sum(o.size for o in out)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    tokens = 0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    sess.profile(True)
+    sess.profile_reset()
+    for i in range(args.profile_steps):
+        step(i)
+    prof = sess.profile_read()
+    sess.profile(False)
+    if rank == 0:
+        audio_s = world * S * chunk / cfg.sample_rate
+        ms = elapsed / args.steps * 1e3
+        kernels = {k: {"ms_per_step": round(v["total_ms"] / args.profile_steps, 4), "launches_per_step": v["launches"] // args.profile_steps}
+                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+        wbytes = 2.0 * sum(v.size for k, v in ck.items() if not k.startswith("frontend."))
+        out = {"metric": "audio-sec/s, Paraformer-large streaming (chunk = 8000 samples), %d concurrent streams per GPU" % S,
+               "value": round(audio_s * args.steps / elapsed, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "Paraformer-large streaming bf16: %d streams x one 0.5 s chunk per step (13 encoder rows per stream, K/V histories "
+                                      "36 / 9 rows), decoder on fired frames, audio resident in HBM, token ids returned to host" % S,
+                          "global_batch": world * S, "audio_seconds_per_step": audio_s, "tokens_per_step": round(tokens / max(args.steps, 1), 1),
+                          "parallelism": f"dp{world} (streams pinned to their GPU)"},
+               "rtf": round(elapsed / (audio_s * args.steps), 8), "chunk_latency_ms": round(ms, 3),
+               "roofline": {"bound": "hbm", "kernel": "whole chunk step (weights streamed once per step; 13 x %d rows keep every GEMM weight-bound)" % S,
+                            "achieved": round(wbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(wbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},
+               "kernels": kernels}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.paraformer_streaming_oracle import ParaformerStreamingOracle
+            orc = ParaformerStreamingOracle(cfg, ck, chunk=chunk)
+            torch.set_num_threads(min(16, os.cpu_count() or 8))
+            orc.run(audio_np[0, :2].reshape(-1))
+            n_done, t1 = 0, time.perf_counter()
+            while True:
+                orc.run(audio_np[n_done % S].reshape(-1))
+                n_done += 1
+                el = time.perf_counter() - t1
+                if (el >= 10.0 and n_done >= 2) or n_done >= 16:
+                    break
+            out["cpu_baseline"] = {"value": round(n_done * n_chunks * chunk / cfg.sample_rate / el, 2), "unit": "audio-s/s", "cores": int(torch.get_num_threads()),
+                                   "kind": "port", "sample": f"{n_done} streams x {n_chunks} chunks, one stream at a time, torch-CPU f32 oracle "
+                                   f"(oracle/paraformer_streaming_oracle.py), {el:.1f} s wall"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -76,3 +76,29 @@ def test_bf16_streams_vs_oracle_reset_and_errors():
         sess.step(np.stack([audio[0][:chunk]] * 2), [1, 1])
     with pytest.raises(Exception, match="invalid"):
         sess.step(audio[0][:chunk][None], [3])
+
+
+def test_stream_transcriber_follows_the_reference_host_loop():
+    """Host loop: noise padding to whole chunks, decoder only on fired chunks, stop ids stripped, pieces joined; several clips
+    advance as concurrent streams and give what they give alone."""
+    g = load_golden("paraformer_streaming_tiny")
+    cfg, ck = streaming_setup(g)
+    chunk = int(g["chunk"])
+    ps = sub("paraformer_streaming")
+    vocab = [f"t{i}" for i in range(cfg.vocab)]
+    vocab[2] = "</s>"
+    sess = sub("engine").ParaformerStreamSession(cfg, ck, precision=F32, chunk=chunk, max_streams=2)
+    tr = ps.ParaformerStreamTranscriber(sess, vocab, stop_token_ids=[2], decode_mode="zh")
+    cases = [c for _, c in streaming_cases(g)]
+    clips = [kaldi_audio(c["audio_seed"], int(c["n_chunks"]) * chunk).astype(np.int16) for c in cases]
+    both, stats = tr.transcribe_many(clips)
+    assert stats["chunks"] == max(int(c["n_chunks"]) for c in cases) and all(r > 0 for r in stats["rtf_per_chunk"])
+    for o, c, clip in zip(both, cases, clips):
+        want = c["token_ids"][~np.isin(c["token_ids"], [2])]
+        if (c["margin"] > 2e-3).all():
+            assert np.array_equal(o["token_ids"], want) and o["text"] == "".join(vocab[i] for i in want)
+        alone, _ = tr.transcribe(clip)
+        assert np.array_equal(alone["token_ids"], o["token_ids"])
+    padded = ps.pad_to_chunks(np.ones((1, 1, chunk + 10), np.float32), chunk, np.random.default_rng(0))
+    assert padded.shape[-1] == 2 * chunk and np.all(padded[0, 0, :chunk + 10] == 1) and padded[0, 0, chunk + 10:].std() > 0.5
+    assert ps.pad_to_chunks(np.ones((1, 1, 2 * chunk), np.float32), chunk).shape[-1] == 2 * chunk

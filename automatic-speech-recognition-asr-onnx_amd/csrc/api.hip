@@ -463,3 +463,62 @@ extern "C" int asr_op_gemm_ln(const float* x, const float* w, const float* bias,
     HIP_CHECK(hipMemcpy(out, dout, (size_t)M * N * 4, hipMemcpyDeviceToHost));
   });
 }
+
+// ---- grid-barrier latency probe (tuning hook): a cooperative launch of one workgroup per CU crossing `iters` barriers.
+namespace {
+__device__ __forceinline__ bool grid_barrier_probe_step(unsigned int* counter, unsigned int target) {
+  __syncthreads();
+  bool ok = true;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(counter, 1u);
+    int spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 22)) { ok = false; break; }       // never hang the box: give up after ~1 s
+    }
+    __threadfence();
+  }
+  __syncthreads();
+  return ok;
+}
+__global__ __launch_bounds__(512) void grid_barrier_probe_kernel(unsigned int* counter, int iters, float* sink, int* failed) {
+  float acc = 0.0f;
+  for (int it = 0; it < iters; ++it) {
+    acc += sink[(blockIdx.x * 64 + (it & 63)) & 4095];          // a little cross-workgroup traffic between barriers
+    if (threadIdx.x == 0) sink[(blockIdx.x * 64 + ((it + 1) & 63)) & 4095] = acc * 0.5f;
+    if (!grid_barrier_probe_step(counter, (unsigned int)(it + 1) * gridDim.x)) { if (threadIdx.x == 0) *failed = 1; return; }
+  }
+  if (acc == 123.456f) sink[0] = acc;
+}
+}  // namespace
+
+extern "C" int asr_debug_grid_barrier(int n_workgroups, int iters, float* us_per_barrier) {
+  return asr_guard([&] {
+    ASR_REQUIRE(us_per_barrier && iters > 0 && n_workgroups > 0, "debug_grid_barrier: bad argument");
+    asr_require_device(0);
+    Tmp t;
+    unsigned int* counter = (unsigned int*)t.alloc(256);
+    float* sink = (float*)t.alloc(4096 * 4);
+    int* failed = (int*)t.alloc(256);
+    HIP_CHECK(hipMemset(counter, 0, 256));
+    HIP_CHECK(hipMemset(sink, 0, 4096 * 4));
+    HIP_CHECK(hipMemset(failed, 0, 256));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    void* args[] = {&counter, &iters, &sink, &failed};
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(grid_barrier_probe_kernel), dim3(n_workgroups), dim3(512), args, 0, nullptr));
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    int hf = 0;
+    HIP_CHECK(hipMemcpy(&hf, failed, 4, hipMemcpyDeviceToHost));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    ASR_REQUIRE(!hf, "debug_grid_barrier: a workgroup gave up waiting (grid not co-resident?)");
+    *us_per_barrier = ms * 1e3f / iters;
+  });
+}

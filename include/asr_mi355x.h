@@ -219,6 +219,8 @@ int asr_op_gemm_ln(const float* x, const float* w, const float* bias, const floa
  * variant: -1 heuristic, 0..4 kernel variants (csrc/gemm.hip). epilogue: 0 bias->lo, 1 bias+relu->lo,
  * 2 bias+residual->f32, 3 two residual terms->f32, 4 transposed store. */
 int asr_op_gemm_bench(int variant, int M, int N, int K, int epilogue, int iters, float* avg_ms);
+/* tuning hook: microseconds per grid-wide barrier of a cooperative launch with n_workgroups x 512 threads */
+int asr_debug_grid_barrier(int n_workgroups, int iters, float* us_per_barrier);
 int asr_op_ctc_collapse(const int32_t* frame_ids, const int32_t* seq_lens, int batch, int blank_id, int32_t* token_ids,
                         int max_tokens, int32_t* num_id);
 

@@ -39,6 +39,10 @@ struct GemmArgs {
   // from its LDS tiles in every column tile.
   float2* st_out = nullptr;
   const float2* ln_stats_in = nullptr; int ln_slots = 0;
+  // skinny path, split-K ACROSS workgroups (more workgroups stream the weights when N / 16 alone cannot fill the chip): partial
+  // sums go to sk_ws ([splits][rows16][N] f32), the last workgroup of a column granule (ticket in sk_cnt[N / 16], self-resetting)
+  // adds them in split order and runs the epilogue -- deterministic. Both buffers are per session; null => no split.
+  float* sk_ws = nullptr; size_t sk_ws_bytes = 0; int32_t* sk_cnt = nullptr; int sk_splits = 0;   // sk_splits: set by the launcher
   int group_m = 0;   // (set by the launcher) row tiles walked per column tile before moving on: keeps wide weight matrices L2-resident
   int dbg = 0;   // tuning ablations (bench hook only): 1 = no refills, 2 = no MFMA, 4 = no epilogue
 };

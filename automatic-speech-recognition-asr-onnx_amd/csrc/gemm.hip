@@ -518,8 +518,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny(const GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fgrp = lane >> 4;
   const int n0 = blockIdx.x * 16;
-  const int kslice = g.K / SK_WAVES;                       // multiple of 32 (host-checked)
-  const int k_begin = wave * kslice;
+  const int KS = g.sk_splits > 1 ? g.sk_splits : 1, ks = blockIdx.y;
+  const int kslice = g.K / (SK_WAVES * KS);               // multiple of 32 (host-checked)
+  const int k_begin = (ks * SK_WAVES + wave) * kslice;
   const bf16_t* wp = reinterpret_cast<const bf16_t*>(g.W) + (size_t)(n0 + frow) * g.ldw + k_begin + fgrp * 8;
 
   constexpr int U = 8;                                  // K-steps per trip: 8 x 16-byte weight loads in flight per lane
@@ -532,59 +533,64 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny(const GemmArgs g) {
   // ---- A source: bf16 rows, or LayerNorm(ln_x) built here into LDS as bf16 [MT*16][K]
   const bf16_t* A;
   int lda;
-  if (g.ln_x) {
-    bf16_t* An = reinterpret_cast<bf16_t*>(smem + SK_WAVES * MT * 1024);
-    // wave w normalises rows w, w+8, ...: ALL of its rows are fetched in one batch of float4 loads (one L2 round trip),
-    // then mean / variance / output come from registers.
-    constexpr int RPW = MT * 16 / SK_WAVES;        // rows per wave
-    constexpr int KV = 5;                          // float4 per lane per row: K <= 1280
-    float4 v[RPW][KV];
+  if constexpr (MT <= 4) {
+    if (g.ln_x) {
+      bf16_t* An = reinterpret_cast<bf16_t*>(smem + SK_WAVES * MT * 1024);
+      // wave w normalises rows w, w+8, ...: ALL of its rows are fetched in one batch of float4 loads (one L2 round trip),
+      // then mean / variance / output come from registers.
+      constexpr int RPW = MT * 16 / SK_WAVES;        // rows per wave
+      constexpr int KV = 5;                          // float4 per lane per row: K <= 1280
+      float4 v[RPW][KV];
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int m = wave + rr * SK_WAVES;
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int m = wave + rr * SK_WAVES;
 #pragma unroll
-      for (int q = 0; q < KV; ++q) {
-        const int k = q * 256 + lane * 4;
-        v[rr][q] = (m < g.M && k < g.K) ? *reinterpret_cast<const float4*>(g.ln_x + (size_t)m * g.ld_ln_x + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int m = wave + rr * SK_WAVES;
-      float s1 = 0.f;
-#pragma unroll
-      for (int q = 0; q < KV; ++q) s1 += (v[rr][q].x + v[rr][q].y) + (v[rr][q].z + v[rr][q].w);
-      const float mean = wave_sum(s1) / (float)g.K;
-      float s2 = 0.f;
-#pragma unroll
-      for (int q = 0; q < KV; ++q) {
-        if (q * 256 + lane * 4 < g.K) {
-          const float a = v[rr][q].x - mean, b = v[rr][q].y - mean, c = v[rr][q].z - mean, d = v[rr][q].w - mean;
-          s2 += (a * a + b * b) + (c * c + d * d);
+        for (int q = 0; q < KV; ++q) {
+          const int k = q * 256 + lane * 4;
+          v[rr][q] = (m < g.M && k < g.K) ? *reinterpret_cast<const float4*>(g.ln_x + (size_t)m * g.ld_ln_x + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
-      const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)g.K + g.ln_eps);
-      bf16_t* o = An + (size_t)m * g.K;
 #pragma unroll
-      for (int q = 0; q < KV; ++q) {
-        const int k = q * 256 + lane * 4;
-        if (k < g.K) {
-          float y0 = (v[rr][q].x - mean) * rstd, y1 = (v[rr][q].y - mean) * rstd, y2 = (v[rr][q].z - mean) * rstd, y3 = (v[rr][q].w - mean) * rstd;
-          if (g.ln_gamma) {
-            const float4 ga = *reinterpret_cast<const float4*>(g.ln_gamma + k), be = *reinterpret_cast<const float4*>(g.ln_beta + k);
-            y0 = y0 * ga.x + be.x; y1 = y1 * ga.y + be.y; y2 = y2 * ga.z + be.z; y3 = y3 * ga.w + be.w;
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int m = wave + rr * SK_WAVES;
+        float s1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < KV; ++q) s1 += (v[rr][q].x + v[rr][q].y) + (v[rr][q].z + v[rr][q].w);
+        const float mean = wave_sum(s1) / (float)g.K;
+        float s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < KV; ++q) {
+          if (q * 256 + lane * 4 < g.K) {
+            const float a = v[rr][q].x - mean, b = v[rr][q].y - mean, c = v[rr][q].z - mean, d = v[rr][q].w - mean;
+            s2 += (a * a + b * b) + (c * c + d * d);
           }
-          if (m >= g.M) { y0 = y1 = y2 = y3 = 0.f; }
-          uint2 w2;
-          w2.x = pack_bf16x2(y0, y1);
-          w2.y = pack_bf16x2(y2, y3);
-          *reinterpret_cast<uint2*>(o + k) = w2;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)g.K + g.ln_eps);
+        bf16_t* o = An + (size_t)m * g.K;
+#pragma unroll
+        for (int q = 0; q < KV; ++q) {
+          const int k = q * 256 + lane * 4;
+          if (k < g.K) {
+            float y0 = (v[rr][q].x - mean) * rstd, y1 = (v[rr][q].y - mean) * rstd, y2 = (v[rr][q].z - mean) * rstd, y3 = (v[rr][q].w - mean) * rstd;
+            if (g.ln_gamma) {
+              const float4 ga = *reinterpret_cast<const float4*>(g.ln_gamma + k), be = *reinterpret_cast<const float4*>(g.ln_beta + k);
+              y0 = y0 * ga.x + be.x; y1 = y1 * ga.y + be.y; y2 = y2 * ga.z + be.z; y3 = y3 * ga.w + be.w;
+            }
+            if (m >= g.M) { y0 = y1 = y2 = y3 = 0.f; }
+            uint2 w2;
+            w2.x = pack_bf16x2(y0, y1);
+            w2.y = pack_bf16x2(y2, y3);
+            *reinterpret_cast<uint2*>(o + k) = w2;
+          }
         }
       }
+      __syncthreads();
+      A = An;
+      lda = g.K;
+    } else {
+      A = reinterpret_cast<const bf16_t*>(g.A);
+      lda = g.lda;
     }
-    __syncthreads();
-    A = An;
-    lda = g.K;
   } else {
     A = reinterpret_cast<const bf16_t*>(g.A);
     lda = g.lda;
@@ -617,25 +623,97 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny(const GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < MT; ++i) red[(wave * MT + i) * 64 + lane] = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
   __syncthreads();
-  if (wave >= MT) return;
-  const int i = wave;                                                                // wave i finishes row tile i
-  float4 sum = red[i * 64 + lane];
+  const int rows16 = MT * 16;
+  float4 sums[(MT + SK_WAVES - 1) / SK_WAVES];
 #pragma unroll
-  for (int w = 1; w < SK_WAVES; ++w) {
-    const float4 t = red[(w * MT + i) * 64 + lane];
-    sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+  for (int t = 0; t < (MT + SK_WAVES - 1) / SK_WAVES; ++t) {                          // wave w finishes row tiles w, w + 8
+    const int i = wave + t * SK_WAVES;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < MT) {
+      sum = red[i * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < SK_WAVES; ++w) {
+        const float4 q = red[(w * MT + i) * 64 + lane];
+        sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
+      }
+    }
+    sums[t] = sum;
   }
-  const int m = i * 16 + frow, n = n0 + fgrp * 4;
-  if (m >= g.M) return;
-  if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + n); sum.x += b.x; sum.y += b.y; sum.z += b.z; sum.w += b.w; }
-  if (g.add) { const float4 t = *reinterpret_cast<const float4*>(g.add + (size_t)m * g.ld_add + n); sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w; }
-  if (g.act != ACT_NONE) { sum.x = apply_act_rt(sum.x, g.act); sum.y = apply_act_rt(sum.y, g.act); sum.z = apply_act_rt(sum.z, g.act); sum.w = apply_act_rt(sum.w, g.act); }
-  if (g.add2) {
-    const float4 t = *reinterpret_cast<const float4*>(g.add2 + (size_t)(g.add2_rows ? g.add2_rows[m] : m) * g.ld_add2 + n);
-    sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
+  if (KS > 1) {                      // hand the partial sums over; the last workgroup of this column granule finishes.
+    // Cross-XCD visibility without a release fence (on this part __threadfence() writes back / invalidates a whole L2): the
+    // partials and the ticket are relaxed AGENT-scope atomics (sc1: written through to / read from the memory side), and every
+    // thread waits for its own stores to complete before the workgroup takes its ticket.
+#pragma unroll
+    for (int t = 0; t < (MT + SK_WAVES - 1) / SK_WAVES; ++t) {
+      const int i = wave + t * SK_WAVES;
+      if (i < MT) {
+        float* dst = g.sk_ws + ((size_t)ks * rows16 + i * 16 + frow) * g.N + n0 + fgrp * 4;
+        __hip_atomic_store(dst + 0, sums[t].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, sums[t].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 2, sums[t].z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 3, sums[t].w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // every wave is done with `red`: its first word carries the verdict
+    int* sk_last = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      const int ticket = __hip_atomic_fetch_add(g.sk_cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *sk_last = ticket == KS - 1;
+      if (ticket == KS - 1) __hip_atomic_store(g.sk_cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    if (!*sk_last) return;
+#pragma unroll
+    for (int t = 0; t < (MT + SK_WAVES - 1) / SK_WAVES; ++t) {
+      const int i = wave + t * SK_WAVES;
+      if (i < MT) {
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s2 = 0; s2 < KS; ++s2) {              // fixed order => bit-reproducible
+          const float* src = g.sk_ws + ((size_t)s2 * rows16 + i * 16 + frow) * g.N + n0 + fgrp * 4;
+          sum.x += __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sum.y += __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sum.z += __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sum.w += __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        sums[t] = sum;
+      }
+    }
   }
-  if (g.out_f32) store4<float>(g.out_f32 + (size_t)m * g.ld_out_f32 + n, sum.x, sum.y, sum.z, sum.w);
-  if (g.out_lo) store4<bf16_t>(reinterpret_cast<bf16_t*>(g.out_lo) + (size_t)m * g.ld_out_lo + n, sum.x, sum.y, sum.z, sum.w);
+#pragma unroll
+  for (int t = 0; t < (MT + SK_WAVES - 1) / SK_WAVES; ++t) {
+    const int i = wave + t * SK_WAVES;
+    if (i >= MT) continue;
+    float4 sum = sums[t];
+    const int m = i * 16 + frow, n = n0 + fgrp * 4;
+    if (m >= g.M) continue;
+    if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + n); sum.x += b.x; sum.y += b.y; sum.z += b.z; sum.w += b.w; }
+    if (g.add) { const float4 q = *reinterpret_cast<const float4*>(g.add + (size_t)m * g.ld_add + n); sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w; }
+    if (g.act != ACT_NONE) { sum.x = apply_act_rt(sum.x, g.act); sum.y = apply_act_rt(sum.y, g.act); sum.z = apply_act_rt(sum.z, g.act); sum.w = apply_act_rt(sum.w, g.act); }
+    if (g.add2) {
+      const float4 q = *reinterpret_cast<const float4*>(g.add2 + (size_t)(g.add2_rows ? g.add2_rows[m] : m) * g.ld_add2 + n);
+      sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
+    }
+    if (g.out_f32) store4<float>(g.out_f32 + (size_t)m * g.ld_out_f32 + n, sum.x, sum.y, sum.z, sum.w);
+    if (g.out_lo) store4<bf16_t>(reinterpret_cast<bf16_t*>(g.out_lo) + (size_t)m * g.ld_out_lo + n, sum.x, sum.y, sum.z, sum.w);
+  }
+}
+
+// split-K across workgroups: enough splits that (N / 16) x splits workgroups cover about half the chip, K slices stay MFMA-sized
+static int skinny_splits(const GemmArgs& g, int rows16) {
+  // measured on MI355X (Whisper-large-v3 decode, SenseVoice single window): the hand-over costs more than the extra workgroups
+  // gain (3.84 -> 4.27 ms / token), so the split is opt-in (ASR_SKINNY_SPLITK=1) and kept for shapes where N / 16 is tiny
+  static const bool on = getenv("ASR_SKINNY_SPLITK") && getenv("ASR_SKINNY_SPLITK")[0] == '1';
+  if (!on || !g.sk_ws || !g.sk_cnt) return 1;
+  const int granules = g.N / 16;
+  int best = 1;
+  for (int s : {2, 3, 4, 5, 8}) {
+    if (g.K % (SK_WAVES * 32 * s) != 0) continue;
+    if ((size_t)s * rows16 * g.N * 4 > g.sk_ws_bytes) continue;
+    if (granules * best >= 160) break;
+    best = s;
+  }
+  return best;
 }
 
 template <int MT>
@@ -647,7 +725,9 @@ void launch_skinny(const GemmArgs& g, hipStream_t s) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
     attr = 160 * 1024;
   }
-  hipLaunchKernelGGL(gemm_bf16_skinny<MT>, dim3(g.N / 16), dim3(64 * SK_WAVES), lds, s, g);
+  GemmArgs gg = g;
+  gg.sk_splits = skinny_splits(g, MT * 16);
+  hipLaunchKernelGGL(gemm_bf16_skinny<MT>, dim3(g.N / 16, gg.sk_splits), dim3(64 * SK_WAVES), lds, s, gg);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -840,9 +920,9 @@ bool launch_t144(const GemmArgs& g, hipStream_t s) {
 
 // 144-row tiles: usable when the epilogue is one the kernel implements and the row count is close to a multiple of 144
 bool t144_geom_ok(const GemmArgs& g) {
-  if (g.out_t || g.amax_val || g.lo_group || g.add2_rows || g.N % TN || g.K % BK16 || g.M < TM) return false;
+  if (g.out_t || g.amax_val || g.lo_group || g.add2_rows || g.N % TN || g.K % BK16 || g.M < 128) return false;
   const int tiles_m = (g.M + TM - 1) / TM;
-  return (double)tiles_m * TM <= 1.04 * g.M;                              // padding waste
+  return (double)tiles_m * TM <= 1.06 * g.M;                              // padding waste (one 137-row window: 144 / 137)
 }
 int t144_stages(const GemmArgs& g) { return ((g.M + TM - 1) / TM) * (g.N / TN) <= 256 ? 4 : 2; }
 // ... and pay off when the tile count fills the chip more evenly than the 128-row tiling does
@@ -880,6 +960,13 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 16) launch_skinny<1>(g, s);
     else if (g.M <= 32) launch_skinny<2>(g, s);
     else launch_skinny<4>(g, s);
+    return;
+  }
+  // one 8 s window (<= 144 rows): a tiled GEMM would put 4..16 workgroups on the chip; stream the weights with the skinny kernel instead
+  static const bool skinny144 = getenv("ASR_SKINNY_M144") && getenv("ASR_SKINNY_M144")[0] == '1';
+  if (skinny144 && g.M <= 144 && g.sk_ws && !g.ln_x && !g.ln_colsum && !g.st_out && !g.out_t && !g.amax_val && g.lo_group == 0 && g.N % 16 == 0 &&
+      g.K % (32 * SK_WAVES) == 0 && (g.lda * 2) % 16 == 0 && g_gemm_variant < 0) {
+    launch_skinny<9>(g, s);
     return;
   }
   check_args(g, BK16, 2);

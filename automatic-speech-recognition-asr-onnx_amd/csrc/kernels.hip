@@ -1206,15 +1206,24 @@ __global__ __launch_bounds__(128) void stream_attn_kernel(const StreamAttnArgs a
   const T* cv = reinterpret_cast<const T*>(a.cache_v) + ((size_t)sid * a.n_heads + h) * a.cap * SA_HD;
   const T* kk = reinterpret_cast<const T*>(a.k);
   const T* vv = reinterpret_cast<const T*>(a.v);
-  for (int p = 0; p < nk; ++p) {
-    if (p < len) {
-      Ks[p][tid] = Elem<T>::load(ck + (size_t)p * SA_HD + tid);
-      Vs[p][tid] = Elem<T>::load(cv + (size_t)p * SA_HD + tid);
-    } else {
-      const size_t r = (size_t)(row0 + p - len);
-      Ks[p][tid] = Elem<T>::load(kk + r * a.ld_k + a.k_col0 + h * SA_HD + tid);
-      Vs[p][tid] = Elem<T>::load(vv + r * a.ld_v + a.v_col0 + h * SA_HD + tid);
+  for (int p0 = 0; p0 < nk; p0 += 8) {               // 8 key rows (K and V) in flight per thread
+    float kr[8], vr[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int p = p0 + u;
+      kr[u] = 0.0f; vr[u] = 0.0f;
+      if (p < len) {
+        kr[u] = Elem<T>::load(ck + (size_t)p * SA_HD + tid);
+        vr[u] = Elem<T>::load(cv + (size_t)p * SA_HD + tid);
+      } else if (p < nk) {
+        const size_t r = (size_t)(row0 + p - len);
+        kr[u] = Elem<T>::load(kk + r * a.ld_k + a.k_col0 + h * SA_HD + tid);
+        vr[u] = Elem<T>::load(vv + r * a.ld_v + a.v_col0 + h * SA_HD + tid);
+      }
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (p0 + u < nk) { Ks[p0 + u][tid] = kr[u]; Vs[p0 + u][tid] = vr[u]; }
   }
   const T* qq = reinterpret_cast<const T*>(a.q);
   T* out = reinterpret_cast<T*>(a.ctx);

@@ -57,7 +57,7 @@ struct SvSession : asr_session {
   size_t h_out_cap = 0;
 
   ~SvSession() override {
-    for (DeviceBuffer* b : {&d_sta, &d_stb, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
+    for (DeviceBuffer* b : {&d_skws, &d_skcnt, &d_sta, &d_stb, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
                             &d_x0lo, &d_xalo, &d_xblo, &d_plan, &d_audio, &d_mel, &d_x0, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx, &d_mem, &d_ffn,
                             &d_amax_v, &d_amax_i, &d_ids, &d_tok, &d_num, &d_logits, &d_enc_lo, &d_ck, &d_cifa, &d_alpha, &d_dec, &d_x2,
                             &d_sa, &d_ffn32, &d_tplan})
@@ -89,7 +89,14 @@ struct SvSession : asr_session {
   template <typename T> void enqueue(const struct SvRunCtx& r);
   template <typename T> void run(const float* audio, int audio_mem, const int64_t* offs, int batch, const int32_t* lang,
                                  int32_t* tok_out, int max_tokens, int32_t* num_out);
-  void gemm(const GemmArgs& g) { precision == ASR_PRECISION_BF16 ? launch_gemm_bf16(g, stream) : launch_gemm_f32(g, stream); }
+  DeviceBuffer d_skws, d_skcnt;        // split-K workspace + tickets of the skinny GEMM (per session: sessions may run concurrently)
+  void gemm(const GemmArgs& g0) {
+    if (precision != ASR_PRECISION_BF16) { launch_gemm_f32(g0, stream); return; }
+    if (!d_skws.ptr) { d_skws.reserve((size_t)16 << 20, stream); d_skcnt.reserve(4096 * 4, stream); }
+    GemmArgs g = g0;
+    g.sk_ws = d_skws.as<float>(); g.sk_ws_bytes = d_skws.cap; g.sk_cnt = d_skcnt.as<int32_t>();
+    launch_gemm_bf16(g, stream);
+  }
 };
 
 void SvSession::init() {
@@ -216,7 +223,9 @@ void SvSession::enqueue(const SvRunCtx& r) {
     GemmArgs probe;
     probe.M = rows; probe.N = dff; probe.K = d; probe.ln_dim = d; probe.ln_colsum = b1.c1; probe.act = ACT_RELU; probe.bias = b1.b1;
     probe.out_lo = d_ffn.ptr; probe.A = d_xblo.ptr; probe.W = b1.w1;
-    alg = use_ln_alg && use_fused && b1.cqkv && b1.c1 && blocks[0].cqkv &&
+    // a single window is weight-streaming bound: its GEMMs take the skinny split-K kernel, which wants separately normalised rows
+    static const bool skinny144 = getenv("ASR_SKINNY_M144") && getenv("ASR_SKINNY_M144")[0] == '1';
+    alg = (rows > 144 || !skinny144) && use_ln_alg && use_fused && b1.cqkv && b1.c1 && blocks[0].cqkv &&
           sanm_fused_supported(r.max_T, c.d_head, c.n_heads, d, c.fsmn_kernel, blocks[0].kpad) && gemm_ln_fusable(probe);
   }
   bf16_t* x0lo = d_x0lo.as<bf16_t>();

@@ -56,7 +56,7 @@ struct WhSession : asr_session {
 
   ~WhSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_x0, &d_h1, &d_xa, &d_xb, &d_xc, &d_h, &d_qk, &d_vt, &d_ctx,
-                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise})
+                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise, &d_skws, &d_skcnt})
       b->release();
     if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
     for (auto& kv : taps) kv.second.buf.release();
@@ -67,7 +67,14 @@ struct WhSession : asr_session {
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
   void init();
-  void gemm(const GemmArgs& g) { precision == ASR_PRECISION_BF16 ? launch_gemm_bf16(g, stream) : launch_gemm_f32(g, stream); }
+  DeviceBuffer d_skws, d_skcnt;        // split-K workspace + tickets of the skinny GEMM (per session: sessions may run concurrently)
+  void gemm(const GemmArgs& g0) {
+    if (precision != ASR_PRECISION_BF16) { launch_gemm_f32(g0, stream); return; }
+    if (!d_skws.ptr) { d_skws.reserve((size_t)16 << 20, stream); d_skcnt.reserve(4096 * 4, stream); }
+    GemmArgs g = g0;
+    g.sk_ws = d_skws.as<float>(); g.sk_ws_bytes = d_skws.cap; g.sk_cnt = d_skcnt.as<int32_t>();
+    launch_gemm_bf16(g, stream);
+  }
   void* pinned(size_t bytes) {
     if (bytes > h_io_cap) {
       if (h_io) HIP_CHECK(hipHostFree(h_io));

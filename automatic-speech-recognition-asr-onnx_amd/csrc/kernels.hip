@@ -601,16 +601,34 @@ __global__ void embed_pos_kernel(const int32_t* __restrict__ ids, int n, int his
 constexpr int DA_MAXN = 8;
 constexpr int DA_MAXKEYS = 1536;
 
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+  uint4 v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void get(float (&o)[8]) const {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[2 * e] = __uint_as_float(w[e] << 16); o[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+  }
+};
+template <> struct Raw8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+  __device__ __forceinline__ void get(float (&o)[8]) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
+};
+
 template <typename T> __device__ __forceinline__ void load8dims(const T* p, float (&o)[8]) { load8<T>(p, o); }
 
-template <typename T>
+// NQ = compile-time bound on the queries per sequence: 1 for single-token decode steps (lean registers: more loads in flight),
+// DA_MAXN for prefills.
+template <typename T, int NQ>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char da_smem[];
   float* sc = reinterpret_cast<float*>(da_smem);          // [n][sc_ld]
   const int sc_ld = a.sc_ld;
-  __shared__ float qs[DA_MAXN][64];
-  __shared__ float red[4][DA_MAXN][64];
-  __shared__ float stat[2][DA_MAXN];
+  __shared__ float qs[NQ][64];
+  __shared__ float red[4][NQ][64];
+  __shared__ float stat[2][NQ];
   const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane & 7;                     // which 8 dims of the row
   const int n = a.n;
@@ -635,30 +653,41 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
     }
   }
   __syncthreads();
-  // ---- scores
-  constexpr int DU = 8;                          // rows in flight per 8-lane group
-  for (int sb = (tid >> 3); sb < S; sb += 32 * DU) {
-    float kv[DU][8];
+  // ---- scores: the row segments of the NEXT trip are already in flight while this trip is reduced
+  constexpr int DU = 8;                          // rows in flight per 8-lane group and trip
+  auto k_ptr = [&](int s0) -> const T* {
+    return s0 < n_cached ? Kc + (size_t)s0 * 64 + sub * 8 : NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.k_col0 + h * 64 + sub * 8;
+  };
+  auto v_ptr = [&](int s0) -> const T* {
+    return s0 < n_cached ? Vc + (size_t)s0 * 64 + sub * 8 : NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.v_col0 + h * 64 + sub * 8;
+  };
+  {
+    Raw8<T> nxt[DU];
 #pragma unroll
-    for (int u = 0; u < DU; ++u) {
-      const int s0 = sb + u * 32;
-      if (s0 < S) {
-        if (s0 < n_cached) load8dims<T>(Kc + (size_t)s0 * 64 + sub * 8, kv[u]);
-        else load8dims<T>(NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.k_col0 + h * 64 + sub * 8, kv[u]);
-      }
-    }
+    for (int u = 0; u < DU; ++u) { const int s0 = (tid >> 3) + u * 32; if (s0 < S) nxt[u].load(k_ptr(s0)); }
+    for (int sb = (tid >> 3); sb < S; sb += 32 * DU) {
+      Raw8<T> cur[DU];
 #pragma unroll
-    for (int u = 0; u < DU; ++u) {
-      const int s0 = sb + u * 32;
-      if (s0 < S) {
-        for (int i = 0; i < n; ++i) {
-          float acc = 0.0f;
+      for (int u = 0; u < DU; ++u) cur[u] = nxt[u];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc = fmaf(qs[i][sub * 8 + e], kv[u][e], acc);
-          acc += __shfl_xor(acc, 1, 64);
-          acc += __shfl_xor(acc, 2, 64);
-          acc += __shfl_xor(acc, 4, 64);
-          if (sub == 0) sc[i * sc_ld + s0] = acc + ((a.causal && s0 > hist + i) ? -128.0f : 0.0f);
+      for (int u = 0; u < DU; ++u) { const int s1 = sb + 32 * DU + u * 32; if (s1 < S) nxt[u].load(k_ptr(s1)); }
+#pragma unroll
+      for (int u = 0; u < DU; ++u) {
+        const int s0 = sb + u * 32;
+        if (s0 < S) {
+          float kvf[8];
+          cur[u].get(kvf);
+#pragma unroll
+          for (int i = 0; i < NQ; ++i) {
+            if (i >= n) break;
+            float acc = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf(qs[i][sub * 8 + e], kvf[e], acc);
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            if (sub == 0) sc[i * sc_ld + s0] = acc + ((a.causal && s0 > hist + i) ? -128.0f : 0.0f);
+          }
         }
       }
     }
@@ -680,38 +709,41 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
   }
   __syncthreads();
   // ---- context: each 8-lane group walks keys s = group, group + 32, ...
-  float acc[DA_MAXN][8];
+  float acc[NQ][8];
 #pragma unroll
-  for (int i = 0; i < DA_MAXN; ++i)
+  for (int i = 0; i < NQ; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[i][e] = 0.0f;
-  for (int sb = (tid >> 3); sb < S; sb += 32 * DU) {
-    float vv[DU][8];
+  {
+    Raw8<T> nxt[DU];                               // the V stream starts before the soft-max statistics are needed
 #pragma unroll
-    for (int u = 0; u < DU; ++u) {
-      const int s0 = sb + u * 32;
-      if (s0 < S) {
-        if (s0 < n_cached) load8dims<T>(Vc + (size_t)s0 * 64 + sub * 8, vv[u]);
-        else load8dims<T>(NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.v_col0 + h * 64 + sub * 8, vv[u]);
-      }
-    }
+    for (int u = 0; u < DU; ++u) { const int s0 = (tid >> 3) + u * 32; if (s0 < S) nxt[u].load(v_ptr(s0)); }
+    for (int sb = (tid >> 3); sb < S; sb += 32 * DU) {
+      Raw8<T> cur[DU];
 #pragma unroll
-    for (int u = 0; u < DU; ++u) {
-      const int s0 = sb + u * 32;
-      if (s0 < S) {
+      for (int u = 0; u < DU; ++u) cur[u] = nxt[u];
 #pragma unroll
-        for (int i = 0; i < DA_MAXN; ++i) {
-          if (i < n) {
-            const float p = sc[i * sc_ld + s0];
+      for (int u = 0; u < DU; ++u) { const int s1 = sb + 32 * DU + u * 32; if (s1 < S) nxt[u].load(v_ptr(s1)); }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[i][e] = fmaf(p, vv[u][e], acc[i][e]);
+      for (int u = 0; u < DU; ++u) {
+        const int s0 = sb + u * 32;
+        if (s0 < S) {
+          float vf[8];
+          cur[u].get(vf);
+#pragma unroll
+          for (int i = 0; i < NQ; ++i) {
+            if (i < n) {
+              const float p = sc[i * sc_ld + s0];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[i][e] = fmaf(p, vf[e], acc[i][e]);
+            }
           }
         }
       }
     }
   }
 #pragma unroll
-  for (int i = 0; i < DA_MAXN; ++i) {
+  for (int i = 0; i < NQ; ++i) {
     if (i < n) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -1089,7 +1121,8 @@ void launch_decode_attention(const DecAttnArgs& a, int batch, hipStream_t s) {
   DecAttnArgs b = a;
   b.sc_ld = (std::min(a.max_keys > 0 ? a.max_keys : DA_MAXKEYS, DA_MAXKEYS) + 63) & ~63;
   const size_t lds = (size_t)a.n * b.sc_ld * 4;
-  hipLaunchKernelGGL(decode_attn_kernel<T>, dim3(batch, a.n_heads), dim3(256), lds, s, b);
+  if (a.n == 1) hipLaunchKernelGGL((decode_attn_kernel<T, 1>), dim3(batch, a.n_heads), dim3(256), lds, s, b);
+  else hipLaunchKernelGGL((decode_attn_kernel<T, DA_MAXN>), dim3(batch, a.n_heads), dim3(256), lds, s, b);
   HIP_CHECK(hipGetLastError());
 }
 template void launch_decode_attention<float>(const DecAttnArgs&, int, hipStream_t);

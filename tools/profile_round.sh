@@ -9,6 +9,8 @@ cd $R
 python bench.py --steps 20 > $OUT/bench_sensevoice.json 2> $OUT/bench_sensevoice.err
 python bench.py --workload paraformer --steps 10 > $OUT/bench_paraformer.json 2> $OUT/bench_paraformer.err
 python bench.py --workload whisper --steps 3 --warmup 1 > $OUT/bench_whisper.json 2> $OUT/bench_whisper.err
+python bench.py --workload whisper --seconds 30 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_whisper30.json 2> $OUT/bench_whisper30.err
+python bench.py --workload paraformer-streaming --steps 16 --warmup 8 > $OUT/bench_paraformer_streaming.json 2> $OUT/bench_paraformer_streaming.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1

@@ -187,3 +187,35 @@ def test_layernorm_inside_projections_matches_separate_layernorm(monkeypatch):
         agree += int((out["1"][2][r0:r0 + T] == out["0"][2][r0:r0 + T]).sum())
         total += T
     assert agree / total > 0.95
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+def test_long_and_maximum_windows_mixed_with_short_ones(prec):
+    """Windows beyond 144 rows (13.63 s, and the 30 s maximum) take the chunked attention / separate-kernel path; in a ragged batch
+    with 8 s and sub-second windows every utterance must match the batch-1 oracle (f32: logits <= 1e-3, tokens equal)."""
+    cfg, ck, sess = _session("sensevoice_small", prec)
+    orc = SenseVoiceOracle(cfg, ck)
+    lens = [218080, 128000, cfg.max_audio_len, 2400]
+    audios = [kaldi_audio(700 + i, n) for i, n in enumerate(lens)]
+    langs = [0, 3, 5, 1]
+    sess.taps(True)
+    toks = sess.run(audios, langs)
+    rows, t, ids, _ = _taps(sess, lens)
+    assert [T for _, T in rows] == [cfg.seq_len(n) for n in lens] and max(T for _, T in rows) > 500
+    for a, lang, (r0, T), tok in zip(audios, langs, rows, toks):
+        st = orc.stages(a, lang)
+        err = np.abs(t["logits"][r0:r0 + T] - st["logits"]).max()
+        srt = np.sort(st["logits"], axis=1)
+        margin = srt[:, -1] - srt[:, -2]
+        if prec == F32:
+            assert err < LOGIT_TOL_F32, err
+            if (margin > 2 * LOGIT_TOL_F32).all():
+                assert np.array_equal(tok, st["token_ids"])
+        else:
+            assert err < 0.3, err
+            safe = margin > 0.6
+            assert np.array_equal(ids[r0:r0 + T][safe], st["frame_ids"][safe])
+    with pytest.raises(Exception, match="max_audio_len"):
+        sess.run([kaldi_audio(1, cfg.max_audio_len + 160)], [0])
+    with pytest.raises(Exception, match="frame"):
+        sess.run([kaldi_audio(1, 399)], [0])

@@ -67,3 +67,30 @@ def test_bf16_batch_vs_oracle_and_determinism():
     t3 = sess.run(audios)
     for x, y, z in zip(t1, t2, t3):
         assert np.array_equal(x, y) and np.array_equal(y, z)
+
+
+def test_long_and_maximum_windows_f32():
+    """13.6 s and 30 s windows (beyond the 144-row fused kernels) beside short ones: every utterance vs the batch-1 oracle."""
+    cfg, ck = paraformer_setup("paraformer_tiny")
+    sess = sub("engine").ParaformerSession.from_checkpoint(cfg, ck, precision=F32)
+    orc = ParaformerOracle(cfg, ck)
+    lens = [218080, cfg.max_audio_len, 16000, 128000]
+    audios = [kaldi_audio(760 + i, n) for i, n in enumerate(lens)]
+    sess.taps(True)
+    toks = sess.run(audios)
+    rows = sess.utterance_rows(lens)
+    enc, alphas, logits = sess.tap("enc_out"), sess.tap("alphas")[:, 0], sess.tap("logits")
+    for a, (r0, T), tok in zip(audios, rows, toks):
+        st = orc.stages(a)
+        assert np.abs(enc[r0:r0 + T] - st["enc_out"]).max() < TOL_F32
+        assert np.abs(alphas[r0:r0 + T] - st["alphas"]).max() < TOL_F32
+        cs = np.cumsum(np.concatenate([st["alphas"].astype(np.float64), [cfg.tail_threshold]]))
+        if np.min(np.abs(cs - np.round(cs))) > 1e-3:                 # fire count defined away from an integer boundary
+            n = int(st["num_id"][0])
+            assert tok.size == n
+            assert np.abs(logits[r0:r0 + max(n, 1)] - st["logits"]).max() < TOL_F32
+            srt = np.sort(st["logits"][:max(n, 1)], axis=1)
+            if n and ((srt[:, -1] - srt[:, -2]) > 2 * TOL_F32).all():
+                assert np.array_equal(tok, st["token_ids"])
+    with pytest.raises(Exception, match="max_audio_len"):
+        sess.run([kaldi_audio(1, cfg.max_audio_len + 160)])

@@ -180,3 +180,30 @@ def test_sampling_head_matches_reference_goldens_and_is_reproducible():
         assert np.array_equal(x[:m], y[:m])
     with pytest.raises(Exception, match="top_k"):
         sess.set_sampling(True, t, 65, p, rp)
+
+
+def test_maximum_30s_window_with_a_short_one_f32():
+    """The 30 s maximum (1500 encoder positions, multi-chunk attention, 1500-key cross-attention) next to a 1 s clip: prefill and
+    greedy steps against the batch-1 oracle; clips beyond the maximum are refused."""
+    cfg, ck, sup, beg, sess = _session("whisper_tiny_test", F32)
+    orc = WhisperOracle(cfg, ck, sup, beg)
+    lens = [cfg.max_audio_len, 16000]
+    audios = [unit_audio(820 + i, n) for i, n in enumerate(lens)]
+    npos = sess.encode(audios)
+    assert [int(t) for t in npos] == [1500, 50]
+    prompt = [cfg.sot_id, cfg.first_language_id, cfg.transcribe_id, cfg.no_timestamps_id]
+    nxt, logits = sess.prefill(np.asarray([prompt, prompt], np.int32))
+    steps_l, steps_i = [logits], [nxt]
+    for _ in range(3):
+        nxt, logits = sess.decode(None, want_logits=True)
+        steps_l.append(logits)
+        steps_i.append(nxt)
+    got_l, got_i = np.stack(steps_l, 1), np.stack(steps_i, 1)
+    want = orc.greedy(audios, [prompt, prompt], 4)
+    for b in range(2):
+        assert np.abs(got_l[b] - want["logits"][b]).max() < LOGIT_TOL_F32, b
+        srt = np.sort(want["logits"][b], axis=1)
+        if ((srt[:, -1] - srt[:, -2]) > 2 * LOGIT_TOL_F32).all():
+            assert np.array_equal(got_i[b], want["token_ids"][b])
+    with pytest.raises(Exception, match="max_audio_len|samples"):
+        sess.encode([unit_audio(1, cfg.max_audio_len + 160)])

@@ -234,7 +234,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // ------------------------------------------------------------------------------------ bf16, ring-pipelined
 template <int BN_, int STAGES, int ACT, int EPI, bool SWAP>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_pipe(const GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16_pipe(const GemmArgs g0) {
+  GemmArgs g = g0;
+  if (g0.m_dev) g.M = min(g0.M, *g0.m_dev);
   constexpr int WN = BN_ / 2;                     // columns per wave
   constexpr int NJ = WN / 16;                     // column fragments per wave
   constexpr int STAGE_BYTES = BM * 128 + BN_ * 128;
@@ -245,7 +247,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_pipe(const GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = g.N / BN_;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  // with a device-side row count only the leading row tiles do work: keep them interleaved over the XCDs instead of contiguous
+  const int tile = g0.m_dev ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
   int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
   if (g.group_m > 1) {       // wide N: consecutive workgroups share a W column tile over group_m row tiles (W is fetched once per group)
     const int tiles_m = gridDim.x / tiles_n, gsz = g.group_m * tiles_n;
@@ -254,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_pipe(const GemmArgs g) {
     tile_m = first + local % rows_in;
     tile_n = local / rows_in;
   }
+  if (tile_m * BM >= g.M) return;                  // (device-side row count) nothing to do for this row tile
 
   // staging: one wave-instruction moves 8 rows x 128 B (8 slots of 16 B) = 1 KiB, lane-linear in LDS
   const int srow = lane >> 3;
@@ -346,15 +350,18 @@ constexpr int T_AI = TM / 8, T_NI = (TM + TN) / 8;     // LDS-DMA wave-instructi
 constexpr int T_RED = TM * TN * 4;
 
 template <int STAGES, int ACT, int EPI>
-__global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void gemm_bf16_t144(const GemmArgs g) {
+__global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void gemm_bf16_t144(const GemmArgs g0) {
+  GemmArgs g = g0;
+  if (g0.m_dev) g.M = min(g0.M, *g0.m_dev);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kg = wave >> 2, cg = wave & 3;
   const int frow = lane & 15, fgrp = lane >> 4;
   const int tiles_n = g.N / TN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = g0.m_dev ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
-  const int a_rows = (g.M + 127) & ~127;                  // rows of A that may be read (padded allocation)
+  if (tile_m * TM >= g.M) return;
+  const int a_rows = (g0.M + 127) & ~127;                 // rows of A that may be read (padded allocation)
 
   const int srow = lane >> 3;
   const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A);
@@ -870,6 +877,7 @@ void launch_pipe(const GemmArgs& g, hipStream_t s) {
   ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_ADD | E_F32 | E_LO | E_ST)
   ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_AMAX)                  // CTC / LM head arg-max
   ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_F32)                   // LM head logits
+  ASR_GEMM_CASE(ACT_RELU, E_BIAS | E_F32)                   // Paraformer decoder FFN-1 (f32 out feeds the inner LayerNorm)
   ASR_GEMM_CASE(ACT_GELU_ERF, E_BIAS | E_ADD2 | E_F32)      // Whisper conv2: gelu(conv) + positions
   ASR_GEMM_CASE(ACT_GELU_TANH, E_BIAS | E_ADD2 | E_F32)
 #undef ASR_GEMM_CASE

@@ -122,7 +122,7 @@ void launch_lfr_cmvn(const LfrArgs& a, hipStream_t s);
 // Output in operand dtype with zero fill of columns [D, ld_fill).
 template <typename OutT>
 void launch_layernorm(const float* x, int ld_x, int rows, int D, const float* gamma, const float* beta, float eps,
-                      OutT* out, int ld_out, int fill_to, hipStream_t s);
+                      OutT* out, int ld_out, int fill_to, hipStream_t s, const int32_t* rows_dev = nullptr);   // rows_dev: device-side row count
 
 
 // ---- multi-head self-attention over packed ragged utterances (no mask inside an utterance).
@@ -196,7 +196,13 @@ void launch_cif_scan(const float* alpha, const float* enc_out, int d, const UttP
                      float* acoustic, UttPlan* token_plan, int32_t* num_id, hipStream_t s);
 // out[t] = res[t] + depth-wise conv (k taps, zero padded inside the token sequence) of x, all row-major f32
 void launch_fsmn_rows(const float* x, const float* res, const float* w, int d, int ktaps, const UttPlan* token_plan,
-                      const int32_t* row_utt, int n_rows, float* out, hipStream_t s);
+                      const int32_t* row_utt, int n_rows, float* out, hipStream_t s, const int32_t* rows_dev = nullptr);
+// compact token layout: utterance b's max(N_b, 1) token rows move from its own row range to offset sum_{j<b} roundup16(max(N_j, 1));
+// writes the compact plan, the row -> utterance map of the compact rows (-1 past the end, n_rows_max entries) and the total row
+// count (device side: the decoder's GEMM / LayerNorm launches are sized for the worst case and stop at this count)
+void launch_token_compact(const UttPlan* own_plan, int n_utts, int n_rows_max, UttPlan* compact_plan, int32_t* row_utt, int32_t* total_rows,
+                          hipStream_t s);
+void launch_compact_rows(const float* src, const UttPlan* own_plan, const UttPlan* compact_plan, int n_utts, int d, float* dst, hipStream_t s);
 // token_ids[b][i] = ids[row_off_b + i], i < N_b
 void launch_gather_tokens(const int32_t* ids, const UttPlan* token_plan, int n_utts, int32_t* token_ids, int max_tokens, hipStream_t s);
 

@@ -161,10 +161,10 @@ constexpr int LN_MAXV = 8;   // float4 per lane: 8 * 4 * 64 = 2048 columns
 template <typename OutT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ld_x, int rows, int D,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float eps, OutT* out, int ld_out, int fill_to) {
+                                                        float eps, OutT* out, int ld_out, int fill_to, const int32_t* __restrict__ rows_dev) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (row >= rows) return;
+  if (row >= rows || (rows_dev && row >= *rows_dev)) return;
   const float* xr = x + (size_t)row * ld_x;
   float4 v[LN_MAXV];
   float s = 0.0f;
@@ -951,8 +951,10 @@ __global__ void cif_scan_kernel(const float* __restrict__ alpha, const float* __
 
 __global__ __launch_bounds__(256) void fsmn_rows_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ w,
                                                         int d, int ktaps, const UttPlan* __restrict__ tplan,
-                                                        const int32_t* __restrict__ row_utt, float* __restrict__ out) {
+                                                        const int32_t* __restrict__ row_utt, float* __restrict__ out,
+                                                        const int32_t* __restrict__ rows_dev) {
   const int m = blockIdx.x;
+  if (rows_dev && m >= *rows_dev) return;
   const int u = row_utt[m];
   int s = 0, e = 0;
   if (u >= 0) { s = tplan[u].row_off; e = s + tplan[u].T; }
@@ -968,6 +970,38 @@ __global__ __launch_bounds__(256) void fsmn_rows_kernel(const float* __restrict_
     }
     out[(size_t)m * d + c] = acc;
   }
+}
+
+__global__ __launch_bounds__(256) void token_compact_kernel(const UttPlan* __restrict__ own, int n_utts, int n_rows_max,
+                                                            UttPlan* __restrict__ compact, int32_t* __restrict__ row_utt,
+                                                            int32_t* __restrict__ total_rows) {
+  __shared__ int total_s;
+  if (threadIdx.x == 0) {                       // a few hundred utterances at most: a serial prefix sum is fine
+    int off = 0;
+    for (int u = 0; u < n_utts; ++u) {
+      UttPlan tp = own[u];
+      tp.row_off = off;
+      compact[u] = tp;
+      off += (tp.T + 15) & ~15;
+    }
+    total_s = off;
+    *total_rows = off;
+  }
+  __syncthreads();
+  const int total = total_s;
+  for (int r = threadIdx.x; r < n_rows_max; r += 256) row_utt[r] = -1;
+  __syncthreads();
+  for (int u = 0; u < n_utts; ++u) {
+    const int r0 = compact[u].row_off, n16 = (compact[u].T + 15) & ~15;
+    for (int r = threadIdx.x; r < n16; r += 256)
+      if (r0 + r < min(total, n_rows_max)) row_utt[r0 + r] = u;
+  }
+}
+
+__global__ __launch_bounds__(256) void compact_rows_kernel(const float* __restrict__ src, const UttPlan* __restrict__ own,
+                                                           const UttPlan* __restrict__ compact, int d, float* __restrict__ dst) {
+  const int u = blockIdx.x, s0 = own[u].row_off, d0 = compact[u].row_off, n16 = (compact[u].T + 15) & ~15;
+  for (int e = threadIdx.x; e < n16 * d; e += 256) dst[(size_t)d0 * d + e] = src[(size_t)s0 * d + e];
 }
 
 __global__ void gather_tokens_kernel(const int32_t* __restrict__ ids, const UttPlan* __restrict__ tplan, int32_t* __restrict__ token_ids,
@@ -1001,14 +1035,14 @@ void launch_lfr_cmvn(const LfrArgs& a, hipStream_t s) {
 
 template <typename OutT>
 void launch_layernorm(const float* x, int ld_x, int rows, int D, const float* gamma, const float* beta, float eps,
-                      OutT* out, int ld_out, int fill_to, hipStream_t s) {
+                      OutT* out, int ld_out, int fill_to, hipStream_t s, const int32_t* rows_dev) {
   ASR_REQUIRE(D % 4 == 0 && D <= LN_MAXV * 256 && ld_x % 4 == 0 && ld_out % 4 == 0, "layernorm: D=%d ld=%d unsupported", D, ld_x);
   hipLaunchKernelGGL(layernorm_kernel<OutT>, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld_x, rows, D, gamma, beta, eps, out,
-                     ld_out, fill_to);
+                     ld_out, fill_to, rows_dev);
   HIP_CHECK(hipGetLastError());
 }
-template void launch_layernorm<float>(const float*, int, int, int, const float*, const float*, float, float*, int, int, hipStream_t);
-template void launch_layernorm<bf16_t>(const float*, int, int, int, const float*, const float*, float, bf16_t*, int, int, hipStream_t);
+template void launch_layernorm<float>(const float*, int, int, int, const float*, const float*, float, float*, int, int, hipStream_t, const int32_t*);
+template void launch_layernorm<bf16_t>(const float*, int, int, int, const float*, const float*, float, bf16_t*, int, int, hipStream_t, const int32_t*);
 
 template <int HD, int CHUNK, int QT>
 static void launch_attn_inst(const AttnArgs& a, hipStream_t s) {
@@ -1176,8 +1210,19 @@ void launch_cif_scan(const float* alpha, const float* enc_out, int d, const UttP
 }
 
 void launch_fsmn_rows(const float* x, const float* res, const float* w, int d, int ktaps, const UttPlan* token_plan,
-                      const int32_t* row_utt, int n_rows, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(fsmn_rows_kernel, dim3(n_rows), dim3(256), 0, s, x, res, w, d, ktaps, token_plan, row_utt, out);
+                      const int32_t* row_utt, int n_rows, float* out, hipStream_t s, const int32_t* rows_dev) {
+  hipLaunchKernelGGL(fsmn_rows_kernel, dim3(n_rows), dim3(256), 0, s, x, res, w, d, ktaps, token_plan, row_utt, out, rows_dev);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_token_compact(const UttPlan* own_plan, int n_utts, int n_rows_max, UttPlan* compact_plan, int32_t* row_utt, int32_t* total_rows,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(token_compact_kernel, dim3(1), dim3(256), 0, s, own_plan, n_utts, n_rows_max, compact_plan, row_utt, total_rows);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_compact_rows(const float* src, const UttPlan* own_plan, const UttPlan* compact_plan, int n_utts, int d, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(n_utts), dim3(256), 0, s, src, own_plan, compact_plan, d, dst);
   HIP_CHECK(hipGetLastError());
 }
 

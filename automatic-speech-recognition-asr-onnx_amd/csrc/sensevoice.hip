@@ -47,6 +47,7 @@ struct SvSession : asr_session {
   const void* ctc_w = nullptr;
 
   // workspace (grow-only)
+  DeviceBuffer d_ctplan, d_mdev, d_trow;   // Paraformer: compact token plan, device-side token-row count, row -> utterance map of the token rows
   DeviceBuffer d_sta, d_stb;               // per-row (sum, sum of squares) partials of those copies, 32-column groups
   DeviceBuffer d_x0lo, d_xalo, d_xblo;     // bf16 copies of the residual stream (operands of the LayerNorm-fused projections)
   DeviceBuffer d_plan, d_audio, d_mel, d_x0, d_xa, d_xb, d_h, d_qk, d_vt, d_ctx, d_mem, d_ffn, d_amax_v, d_amax_i, d_ids,
@@ -57,7 +58,7 @@ struct SvSession : asr_session {
   size_t h_out_cap = 0;
 
   ~SvSession() override {
-    for (DeviceBuffer* b : {&d_skws, &d_skcnt, &d_sta, &d_stb, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
+    for (DeviceBuffer* b : {&d_ctplan, &d_mdev, &d_trow, &d_skws, &d_skcnt, &d_sta, &d_stb, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
                             &d_x0lo, &d_xalo, &d_xblo, &d_plan, &d_audio, &d_mel, &d_x0, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx, &d_mem, &d_ffn,
                             &d_amax_v, &d_amax_i, &d_ids, &d_tok, &d_num, &d_logits, &d_enc_lo, &d_ck, &d_cifa, &d_alpha, &d_dec, &d_x2,
                             &d_sa, &d_ffn32, &d_tplan})
@@ -395,8 +396,12 @@ void SvSession::enqueue_paraformer_tail(const SvRunCtx& r) {
   float* x1 = d_mem.as<float>();
   float* dec = d_dec.as<float>();
   float* x2 = d_x2.as<float>();
+  float* x2_own = d_sa.as<float>();                    // scratch for the un-packed CIF output (sa is not live yet)
   float* sa = d_sa.as<float>();
-  UttPlan* tplan = d_tplan.as<UttPlan>();
+  UttPlan* own_plan = d_tplan.as<UttPlan>();            // token rows inside each utterance's own row range (CIF scan output)
+  UttPlan* tplan = d_ctplan.as<UttPlan>();              // compact token rows: the decoder works on these
+  const int32_t* m_dev = d_mdev.as<int32_t>();          // their total count, device side
+  const int32_t* trow_utt = d_trow.as<int32_t>();
   {
     ProfScope ps(prof, "layernorm", stream);
     launch_layernorm<float>(xa, d, rows, d, after_g, after_b, 1e-5f, enc32, d, d, stream);
@@ -411,18 +416,22 @@ void SvSession::enqueue_paraformer_tail(const SvRunCtx& r) {
     g.out_lo = ctx; g.ld_out_lo = d;
     gemm(g);
     launch_alpha<T>(ctx, d, cif_out_w, cif_out_b, rows, d_alpha.as<float>(), stream);
-    launch_cif_scan(d_alpha.as<float>(), enc32, d, r.dp, r.batch, pcfg.tail_threshold, dec, tplan, d_num.as<int32_t>(), stream);
+    // fired frames land in the utterance's own rows first; then they are packed (16-row aligned per utterance) so that the decoder
+    // touches ~ the token count of the batch instead of every encoder row -- the count stays on the device (GemmArgs::m_dev)
+    launch_cif_scan(d_alpha.as<float>(), enc32, d, r.dp, r.batch, pcfg.tail_threshold, x2_own, own_plan, d_num.as<int32_t>(), stream);
+    launch_token_compact(own_plan, r.batch, Mpad, tplan, d_trow.as<int32_t>(), d_mdev.as<int32_t>(), stream);
+    launch_compact_rows(x2_own, own_plan, tplan, r.batch, d, dec, stream);
   }
   save_tap("alphas", d_alpha.ptr, rows, 1, 1, 4);
   auto ffn_block = [&](const PfDecLayer& L, float* out, const float* res) {
-    { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(dec, d, rows, d, nullptr, nullptr, 1e-5f, h, d, d, stream); }
+    { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(dec, d, rows, d, nullptr, nullptr, 1e-5f, h, d, d, stream, m_dev); }
     ProfScope ps(prof, "gemm_dec", stream);
     GemmArgs g;
-    g.A = h; g.lda = d; g.W = L.w1; g.ldw = d; g.M = rows; g.N = dd; g.K = d; g.bias = L.b1; g.act = ACT_RELU; g.out_f32 = ffn32; g.ld_out_f32 = dd;
+    g.A = h; g.lda = d; g.W = L.w1; g.ldw = d; g.M = rows; g.N = dd; g.K = d; g.bias = L.b1; g.act = ACT_RELU; g.out_f32 = ffn32; g.ld_out_f32 = dd; g.m_dev = m_dev;
     gemm(g);
-    launch_layernorm<T>(ffn32, dd, rows, dd, nullptr, nullptr, 1e-5f, ffn, dd, dd, stream);   // ff.norm, affine folded into w_2
+    launch_layernorm<T>(ffn32, dd, rows, dd, nullptr, nullptr, 1e-5f, ffn, dd, dd, stream, m_dev);   // ff.norm, affine folded into w_2
     GemmArgs g2;
-    g2.A = ffn; g2.lda = dd; g2.W = L.w2; g2.ldw = dd; g2.M = rows; g2.N = d; g2.K = dd; g2.bias = L.b2; g2.out_f32 = out; g2.ld_out_f32 = d;
+    g2.A = ffn; g2.lda = dd; g2.W = L.w2; g2.ldw = dd; g2.M = rows; g2.N = d; g2.K = dd; g2.bias = L.b2; g2.out_f32 = out; g2.ld_out_f32 = d; g2.m_dev = m_dev;
     if (res) { g2.add = res; g2.ld_add = d; }
     gemm(g2);
   };
@@ -441,14 +450,14 @@ void SvSession::enqueue_paraformer_tail(const SvRunCtx& r) {
     ffn_block(L, x1, nullptr);                                       // x = w_2(norm(relu(w_1(norm1(dec)))))
     {
       ProfScope ps(prof, "fsmn", stream);
-      launch_layernorm<float>(x1, d, rows, d, L.n2_g, L.n2_b, 1e-5f, sa, d, d, stream);
-      launch_fsmn_rows(sa, dec, L.wfsmn, d, c.fsmn_kernel, tplan, r.d_row_utt, Mpad, x2, stream);   // x = dec + fsmn(norm2(x))
+      launch_layernorm<float>(x1, d, rows, d, L.n2_g, L.n2_b, 1e-5f, sa, d, d, stream, m_dev);
+      launch_fsmn_rows(sa, dec, L.wfsmn, d, c.fsmn_kernel, tplan, trow_utt, Mpad, x2, stream, m_dev);   // x = dec + fsmn(norm2(x))
     }
-    { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(x2, d, rows, d, nullptr, nullptr, 1e-5f, h, d, d, stream); }
+    { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(x2, d, rows, d, nullptr, nullptr, 1e-5f, h, d, d, stream, m_dev); }
     {
       ProfScope ps(prof, "gemm_dec", stream);
       GemmArgs g;
-      g.A = h; g.lda = d; g.W = L.wq; g.ldw = d; g.M = rows; g.N = d; g.K = d; g.bias = L.bq; g.out_lo = q; g.ld_out_lo = d;
+      g.A = h; g.lda = d; g.W = L.wq; g.ldw = d; g.M = rows; g.N = d; g.K = d; g.bias = L.bq; g.out_lo = q; g.ld_out_lo = d; g.m_dev = m_dev;
       gemm(g);
     }
     {
@@ -463,16 +472,16 @@ void SvSession::enqueue_paraformer_tail(const SvRunCtx& r) {
     {
       ProfScope ps(prof, "gemm_dec", stream);
       GemmArgs g;
-      g.A = ctx; g.lda = d; g.W = L.wo; g.ldw = d; g.M = rows; g.N = d; g.K = d; g.bias = L.bo; g.add = x2; g.ld_add = d; g.out_f32 = dec; g.ld_out_f32 = d;
+      g.A = ctx; g.lda = d; g.W = L.wo; g.ldw = d; g.M = rows; g.N = d; g.K = d; g.bias = L.bo; g.add = x2; g.ld_add = d; g.out_f32 = dec; g.ld_out_f32 = d; g.m_dev = m_dev;
       gemm(g);
     }
   }
-  { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(dec, d, rows, d, nullptr, nullptr, 1e-5f, h, d, d, stream); }
+  { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(dec, d, rows, d, nullptr, nullptr, 1e-5f, h, d, d, stream, m_dev); }
   {
     ProfScope ps(prof, "gemm_out", stream);
     GemmArgs g;
     g.A = h; g.lda = d; g.W = pf_out_w; g.ldw = d; g.M = rows; g.N = vpad; g.K = d; g.bias = pf_out_b;
-    g.amax_val = d_amax_v.as<float>(); g.amax_idx = d_amax_i.as<int32_t>(); g.n_valid = c.vocab;
+    g.amax_val = d_amax_v.as<float>(); g.amax_idx = d_amax_i.as<int32_t>(); g.n_valid = c.vocab; g.m_dev = m_dev;
     if (taps_enabled) { g.out_f32 = d_logits.as<float>(); g.ld_out_f32 = vpad; }
     gemm(g);
     launch_argmax_reduce(d_amax_v.as<float>(), d_amax_i.as<int32_t>(), rows, n_slabs, d_ids.as<int32_t>(), stream);
@@ -594,6 +603,9 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
     grow(d_ffn32, (size_t)Mpad * dd * 4);
     grow(d_ffn, (size_t)Mpad * std::max(dd, dff) * eT);
     grow(d_tplan, sizeof(UttPlan) * batch);
+    grow(d_ctplan, sizeof(UttPlan) * batch);
+    grow(d_mdev, 256);
+    grow(d_trow, (size_t)Mpad * 4);
   }
   const size_t out_bytes = (size_t)batch * max_tokens * 4 + (size_t)batch * 4;
   if (out_bytes > h_out_cap) {

@@ -384,6 +384,16 @@ class ParaformerSession(_Session):
             r += (t + 15) // 16 * 16
         return out
 
+    @staticmethod
+    def token_rows(num_tokens: Sequence[int]):
+        """First row of each utterance's tokens in the decoder-side taps ('logits'): the fired frames are packed, 16-row aligned
+        per utterance (a zero-token utterance keeps one dummy row)."""
+        out, r = [], 0
+        for n in num_tokens:
+            out.append(r)
+            r += (max(int(n), 1) + 15) // 16 * 16
+        return out
+
 
 class ParaformerStreamSession(_Session):
     """Streaming Paraformer: per-stream recurrent state (encoder K/V histories, carried LFR rows, CIF state, decoder FSMN / cross

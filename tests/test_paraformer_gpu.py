@@ -25,7 +25,8 @@ def test_f32_mode_matches_reference_goldens(fixture):
     toks = sess.run(audios)                                   # one ragged batch, incl. the zero-token clip
     rows = sess.utterance_rows([a.size for a in audios])
     enc, alphas, logits = sess.tap("enc_out"), sess.tap("alphas")[:, 0], sess.tap("logits")
-    for c, tok, (r0, T) in zip(cases, toks, rows):
+    trow = sess.token_rows([t.size for t in toks])                 # decoder-side taps follow the packed token rows
+    for c, tok, (r0, T), t0 in zip(cases, toks, rows, trow):
         n = int(c["num_id"][0])
         assert np.abs(alphas[r0:r0 + T] - c["alphas"]).max() < TOL_F32
         if "logits" in c:
@@ -34,7 +35,7 @@ def test_f32_mode_matches_reference_goldens(fixture):
             assert np.abs(enc[r0:r0 + T][::8] - c["enc_out"]).max() < TOL_F32
         if c["cif_slack"] > 2e-4:                              # fire count is only defined away from an integer boundary
             assert tok.size == n, (tok.size, n)
-            lg = logits[r0:r0 + max(n, 1)]
+            lg = logits[t0:t0 + max(n, 1)]
             ref = c["logits"] if "logits" in c else None
             if ref is not None:
                 assert np.abs(lg - ref).max() < TOL_F32
@@ -80,7 +81,8 @@ def test_long_and_maximum_windows_f32():
     toks = sess.run(audios)
     rows = sess.utterance_rows(lens)
     enc, alphas, logits = sess.tap("enc_out"), sess.tap("alphas")[:, 0], sess.tap("logits")
-    for a, (r0, T), tok in zip(audios, rows, toks):
+    trow = sess.token_rows([t.size for t in toks])
+    for a, (r0, T), tok, t0 in zip(audios, rows, toks, trow):
         st = orc.stages(a)
         assert np.abs(enc[r0:r0 + T] - st["enc_out"]).max() < TOL_F32
         assert np.abs(alphas[r0:r0 + T] - st["alphas"]).max() < TOL_F32
@@ -88,7 +90,7 @@ def test_long_and_maximum_windows_f32():
         if np.min(np.abs(cs - np.round(cs))) > 1e-3:                 # fire count defined away from an integer boundary
             n = int(st["num_id"][0])
             assert tok.size == n
-            assert np.abs(logits[r0:r0 + max(n, 1)] - st["logits"]).max() < TOL_F32
+            assert np.abs(logits[t0:t0 + max(n, 1)] - st["logits"]).max() < TOL_F32
             srt = np.sort(st["logits"][:max(n, 1)], axis=1)
             if n and ((srt[:, -1] - srt[:, -2]) > 2 * TOL_F32).all():
                 assert np.array_equal(tok, st["token_ids"])

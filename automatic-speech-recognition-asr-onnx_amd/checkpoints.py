@@ -186,3 +186,46 @@ def synth_paraformer_checkpoint(cfg, seed: int = 0) -> dict:
     ck["frontend.cmvn_means"] = (-18.0 + rng.standard_normal((feat,), dtype=np.float32)).astype(np.float32)
     ck["frontend.cmvn_vars"] = (0.02 * (1.0 + 0.1 * rng.standard_normal((feat,), dtype=np.float32))).astype(np.float32)
     return ck
+
+
+def synth_qwen_asr_checkpoint(cfg, seed: int = 0) -> dict:
+    """Random Qwen3-ASR-shaped checkpoint with the Hugging Face state-dict names (Export_Qwen_ASR.py:311-516)."""
+    rng = np.random.default_rng(seed)
+    ck: dict[str, np.ndarray] = {}
+    a, C, d = "thinker.audio_tower.", cfg.conv_channels, cfg.enc_d
+    ck[a + "conv2d1.weight"] = (rng.standard_normal((C, 1, 3, 3), dtype=np.float32) * np.float32(1.0 / 3.0))
+    ck[a + "conv2d1.bias"] = rng.standard_normal((C,), dtype=np.float32) * np.float32(0.1)
+    for name in ("conv2d2", "conv2d3"):
+        ck[a + name + ".weight"] = rng.standard_normal((C, C, 3, 3), dtype=np.float32) * np.float32(1.4 / np.sqrt(9 * C))
+        ck[a + name + ".bias"] = rng.standard_normal((C,), dtype=np.float32) * np.float32(0.1)
+    freq = (((cfg.n_mels + 1) // 2 + 1) // 2 + 1) // 2
+    ck[a + "conv_out.weight"] = _lin(rng, d, C * freq, bias=False)[0]
+    for i in range(cfg.n_enc_layers):
+        p = f"{a}layers.{i}."
+        for proj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            ck[p + f"self_attn.{proj}.weight"], ck[p + f"self_attn.{proj}.bias"] = _lin(rng, d, d)
+        ck[p + "self_attn_layer_norm.weight"], ck[p + "self_attn_layer_norm.bias"] = _ln(rng, d)
+        ck[p + "fc1.weight"], ck[p + "fc1.bias"] = _lin(rng, cfg.enc_ffn, d, gain=1.4)
+        ck[p + "fc2.weight"], ck[p + "fc2.bias"] = _lin(rng, d, cfg.enc_ffn)
+        ck[p + "final_layer_norm.weight"], ck[p + "final_layer_norm.bias"] = _ln(rng, d)
+    ck[a + "ln_post.weight"], ck[a + "ln_post.bias"] = _ln(rng, d)
+    ck[a + "proj1.weight"], ck[a + "proj1.bias"] = _lin(rng, d, d, gain=1.4)
+    ck[a + "proj2.weight"], ck[a + "proj2.bias"] = _lin(rng, cfg.d_model, d)
+    t, h, hd = "thinker.model.", cfg.d_model, cfg.d_head
+    ck[t + "embed_tokens.weight"] = rng.standard_normal((cfg.vocab, h), dtype=np.float32) * np.float32(0.5)
+    for i in range(cfg.n_layers):
+        p = f"{t}layers.{i}."
+        ck[p + "self_attn.q_proj.weight"] = _lin(rng, cfg.n_heads * hd, h, bias=False)[0]
+        ck[p + "self_attn.k_proj.weight"] = _lin(rng, cfg.n_kv_heads * hd, h, bias=False)[0]
+        ck[p + "self_attn.v_proj.weight"] = _lin(rng, cfg.n_kv_heads * hd, h, bias=False)[0]
+        ck[p + "self_attn.o_proj.weight"] = _lin(rng, h, cfg.n_heads * hd, bias=False)[0]
+        ck[p + "self_attn.q_norm.weight"] = (1.0 + 0.1 * rng.standard_normal((hd,), dtype=np.float32)).astype(np.float32)
+        ck[p + "self_attn.k_norm.weight"] = (1.0 + 0.1 * rng.standard_normal((hd,), dtype=np.float32)).astype(np.float32)
+        ck[p + "mlp.gate_proj.weight"] = _lin(rng, cfg.d_ffn, h, bias=False, gain=1.4)[0]
+        ck[p + "mlp.up_proj.weight"] = _lin(rng, cfg.d_ffn, h, bias=False)[0]
+        ck[p + "mlp.down_proj.weight"] = _lin(rng, h, cfg.d_ffn, bias=False)[0]
+        ck[p + "input_layernorm.weight"] = (1.0 + 0.1 * rng.standard_normal((h,), dtype=np.float32)).astype(np.float32)
+        ck[p + "post_attention_layernorm.weight"] = (1.0 + 0.1 * rng.standard_normal((h,), dtype=np.float32)).astype(np.float32)
+    ck[t + "norm.weight"] = (1.0 + 0.1 * rng.standard_normal((h,), dtype=np.float32)).astype(np.float32)
+    ck["thinker.lm_head.weight"] = _lin(rng, cfg.vocab, h, bias=False)[0]
+    return ck

@@ -175,3 +175,58 @@ def paraformer_large() -> ParaformerConfig:
 
 def paraformer_tiny() -> ParaformerConfig:
     return ParaformerConfig(d_model=256, n_heads=2, d_head=128, d_ffn=512, n_enc0=1, n_enc=2, n_dec=2, n_dec3=1, d_dec_ffn=512, vocab=500)
+
+
+# =============================================================================== Qwen3-ASR
+@dataclass(frozen=True)
+class QwenAsrConfig:
+    """Qwen3-ASR (Qwen_ASR/Export_Qwen_ASR.py): Whisper-style log-mel -> 3 x Conv2d(s2) chunk stem -> windowed-attention audio encoder
+    -> Qwen3 decoder (RMSNorm, QK-norm, RoPE, GQA, SwiGLU). Defaults follow the 0.6B checkpoint's published geometry."""
+    sample_rate: int = 16000
+    n_mels: int = 128
+    nfft: int = 400
+    hop_length: int = 160
+    # audio encoder
+    enc_d: int = 896
+    enc_heads: int = 14
+    enc_ffn: int = 3584
+    n_enc_layers: int = 18
+    conv_channels: int = 480
+    n_window: int = 50                 # chunk = 2 * n_window mel frames -> 13 tokens
+    n_window_infer: int = 800          # attention window = n_window_infer / chunk chunks
+    max_source_positions: int = 1500
+    # text decoder
+    d_model: int = 1024
+    n_heads: int = 16
+    n_kv_heads: int = 8
+    d_head: int = 128
+    d_ffn: int = 3072
+    n_layers: int = 28
+    vocab: int = 151936
+    rms_eps: float = 1e-6
+    rope_theta: float = 1000000.0
+    max_seq_len: int = 1024
+    max_audio_len: int = 480000
+
+    @property
+    def chunk(self) -> int:
+        return 2 * self.n_window
+
+    @property
+    def chunks_per_window(self) -> int:
+        return self.n_window_infer // self.chunk
+
+    def n_frames(self, audio_len: int) -> int:
+        return audio_len // self.hop_length
+
+    def to_dict(self):
+        return asdict(self)
+
+
+def qwen_asr_0p6b() -> QwenAsrConfig:
+    return QwenAsrConfig()
+
+
+def qwen_asr_tiny() -> QwenAsrConfig:
+    return QwenAsrConfig(enc_d=128, enc_heads=2, enc_ffn=256, n_enc_layers=2, conv_channels=32, n_window_infer=400, d_model=128, n_heads=2,
+                         n_kv_heads=1, d_head=128, d_ffn=256, n_layers=2, vocab=600, max_seq_len=512)

@@ -1,0 +1,72 @@
+"""Qwen3-ASR goldens from the REAL reference classes (build container only); see oracle/gen_golden.py."""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "automatic-speech-recognition-asr-onnx_amd"
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+HEAD_IDS, TAIL_IDS, SUFFIX_IDS = [510, 511, 512], [520, 521, 512, 510, 522, 512, 530, 531], [521, 512, 510, 523, 512, 524]
+CASES = [  # (fixture, config, ckpt seed, n_new, [(audio seed, n_samples, query ids, language tail ids)])
+    ("qwen_asr_tiny", "qwen_asr_tiny", 0, 6, [(4401, 40000, [], []), (4402, 16000, [40, 41, 42], [77, 540]), (4403, 130000, [], [78, 540]),
+                                              (4404, 7000, [], [])]),
+]
+
+
+def reference_greedy(ref, cfg, audio, n_new, query_ids, tail_ids):
+    enc, embed, rp, rd, main = ref["encoder"], ref["embed"], ref["rotary_prefill"], ref["rotary_decode"], ref["main"]
+    L = cfg.n_layers
+    with torch.inference_mode():
+        q = embed(torch.tensor([query_ids], dtype=torch.int32).reshape(1, -1))
+        base, _ = enc(torch.from_numpy(audio).reshape(1, 1, -1), q)
+        tail = embed(torch.tensor([tail_ids], dtype=torch.int32).reshape(1, -1))
+        concat, ids_len = ref["ns"]["CONCAT_EMBED"]()(base, tail)
+        n_audio = base.shape[1] - len(HEAD_IDS) - len(query_ids) - len(SUFFIX_IDS) - len(TAIL_IDS)
+        a0 = len(HEAD_IDS) + len(query_ids) + len(SUFFIX_IDS)
+        audio_hidden = base[0, a0:a0 + n_audio].numpy().copy()
+        keys = [torch.zeros(1, cfg.n_kv_heads, 1, cfg.d_head, 0) for _ in range(L)]
+        vals = [torch.zeros(1, cfg.n_kv_heads, 1, 0, cfg.d_head) for _ in range(L)]
+        cos, sin, mask, kv_len = rp(ids_len, torch.zeros(1, dtype=torch.int64))
+        out = main(*keys, *vals, concat, cos, sin, mask)
+        steps, toks = [out[-1][0].clone()], [int(out[-1].argmax(-1))]
+        while len(toks) < n_new:
+            cos, sin, kv_next = rd(kv_len)
+            out = main(*out[:L], *out[L:2 * L], embed(torch.tensor([[toks[-1]]], dtype=torch.int32)), cos, sin, torch.zeros(1))
+            kv_len = kv_next
+            steps.append(out[-1][0].clone())
+            toks.append(int(out[-1].argmax(-1)))
+    return dict(audio_hidden=audio_hidden, ids_len=int(ids_len), logits=torch.stack(steps).numpy(), token_ids=np.asarray(toks, np.int32))
+
+
+def main():
+    from oracle import reference_harness as rh
+    cfgm = importlib.import_module(PKG + ".config")
+    ckm = importlib.import_module(PKG + ".checkpoints")
+    for fixture, cfg_name, ck_seed, n_new, clips in CASES:
+        cfg = getattr(cfgm, cfg_name)()
+        ck = ckm.synth_qwen_asr_checkpoint(cfg, ck_seed)
+        ref = rh.build_reference_qwen_asr(cfg, ck, HEAD_IDS, TAIL_IDS, SUFFIX_IDS, max_seq_len=cfg.max_seq_len)
+        out = {"ckpt_seed": np.int64(ck_seed), "n_cases": np.int64(len(clips)), "cfg_name": np.str_(cfg_name), "n_new": np.int64(n_new),
+               "head_ids": np.asarray(HEAD_IDS, np.int32), "tail_ids": np.asarray(TAIL_IDS, np.int32), "suffix_ids": np.asarray(SUFFIX_IDS, np.int32)}
+        for i, (seed, n, query, tail) in enumerate(clips):
+            audio = ckm.synth_audio("unit", 1, n, seed=seed)[0, 0]
+            r = reference_greedy(ref, cfg, audio, n_new, query, tail)
+            p = f"c{i}_"
+            out[p + "audio_seed"], out[p + "n_samples"] = np.int64(seed), np.int64(n)
+            out[p + "query_ids"], out[p + "language_tail_ids"] = np.asarray(query, np.int32), np.asarray(tail, np.int32)
+            out[p + "audio_hidden"], out[p + "ids_len"], out[p + "logits"], out[p + "token_ids"] = r["audio_hidden"], np.int64(r["ids_len"]), r["logits"], r["token_ids"]
+            srt = np.sort(r["logits"], axis=1)
+            out[p + "margin"] = (srt[:, -1] - srt[:, -2]).astype(np.float32)
+            print(fixture, i, n, "audio tokens", r["audio_hidden"].shape[0], "prompt", r["ids_len"], "tokens", r["token_ids"], "min margin", float(out[p + "margin"].min()))
+        np.savez_compressed(os.path.join(GOLDEN, fixture + ".npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

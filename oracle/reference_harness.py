@@ -364,3 +364,61 @@ def reference_paraformer_streaming_run(ref, cfg, audio: np.ndarray) -> list:
                 rec["token_ids"] = np.zeros(0, np.int32)
             out.append(rec)
     return out
+
+
+# --------------------------------------------------------------------------- Qwen3-ASR
+def build_reference_qwen_asr(cfg, ck: dict, head_ids, tail_ids, query_suffix_ids, max_seq_len=1024):
+    """The reference's QWEN3_ASR_ENCODER / ROTARY_MASK_PREFILL / ROTARY_MASK_DECODE / DECODER_EMBED / DECODER_MAIN on a synthetic
+    checkpoint (float32 KV cache, quantisation-only channel re-orderings disabled: they are exact permutations)."""
+    assert reference_available()
+    from typing import Dict, List, Sequence, Tuple
+    from transformers import AutoConfig, AutoModel, AutoTokenizer
+    from transformers.activations import ACT2FN
+    from transformers.audio_utils import mel_filter_bank
+    from transformers.configuration_utils import PretrainedConfig
+    from transformers.generation import GenerationMixin
+    from transformers.modeling_layers import GradientCheckpointingLayer
+    from transformers.modeling_rope_utils import ROPE_INIT_FUNCTIONS
+    from transformers.modeling_utils import PreTrainedModel
+    from torch.onnx import symbolic_helper
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("qwen_stft_process", os.path.join(REFERENCE_ROOT, "Qwen_ASR", "STFT_Process.py"))
+    stft_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(stft_mod)
+    ns = dict(torch=torch, np=np, json=json, F=torch.nn.functional, nn=torch.nn, Tensor=torch.Tensor, Dict=Dict, List=List, Sequence=Sequence,
+              Tuple=Tuple, AutoConfig=AutoConfig, AutoModel=AutoModel, AutoTokenizer=AutoTokenizer, ACT2FN=ACT2FN,
+              PretrainedConfig=PretrainedConfig, GenerationMixin=GenerationMixin, GradientCheckpointingLayer=GradientCheckpointingLayer,
+              ROPE_INIT_FUNCTIONS=ROPE_INIT_FUNCTIONS, PreTrainedModel=PreTrainedModel, symbolic_helper=symbolic_helper,
+              STFT_Process=stft_mod.STFT_Process, INPUT_AUDIO_DTYPE="F32", USE_FP16_KV=False, COMPUTE_IN_F32=False,
+              ROTARY_STORAGE_DTYPE=torch.float32, REORDER_DOWNPROJ_FOR_QUANT=False, REORDER_OPROJ_FOR_QUANT=False, REORDER_KEY="absmean",
+              MAX_INPUT_AUDIO_LENGTH=cfg.max_audio_len, _MODEL_SAMPLE_RATE=cfg.sample_rate, _MODEL_WINDOW_TYPE="hann", _MODEL_NUM_MELS=cfg.n_mels,
+              _MODEL_NFFT_STFT=cfg.nfft, _MODEL_WINDOW_LENGTH=cfg.nfft, _MODEL_HOP_LENGTH=cfg.hop_length, _MODEL_AUDIO_PCM_SCALE=32768,
+              torchaudio=types.SimpleNamespace(functional=types.SimpleNamespace(
+                  melscale_fbanks=lambda n_freqs, f_min, f_max, n_mels, sample_rate, norm, mel_scale: torch.from_numpy(
+                      mel_filter_bank(n_freqs, n_mels, float(f_min), float(f_max), sample_rate, norm=norm, mel_scale=mel_scale)).float())))
+    # transformers resolves the classes' string annotations through sys.modules[cls.__module__]: give the definitions a module
+    mod = types.ModuleType("qwen_asr_reference_defs")
+    mod.__dict__.update(ns)
+    sys.modules[mod.__name__] = mod
+    ns = mod.__dict__
+    _compile_defs(os.path.join(REFERENCE_ROOT, "Qwen_ASR", "Export_Qwen_ASR.py"), ns)
+    audio_cfg = dict(num_mel_bins=cfg.n_mels, encoder_layers=cfg.n_enc_layers, encoder_attention_heads=cfg.enc_heads, encoder_ffn_dim=cfg.enc_ffn,
+                     d_model=cfg.enc_d, max_source_positions=cfg.max_source_positions, n_window=cfg.n_window, output_dim=cfg.d_model,
+                     n_window_infer=cfg.n_window_infer, downsample_hidden_size=cfg.conv_channels, activation_function="gelu")
+    text_cfg = dict(vocab_size=cfg.vocab, hidden_size=cfg.d_model, intermediate_size=cfg.d_ffn, num_hidden_layers=cfg.n_layers,
+                    num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads, head_dim=cfg.d_head, rms_norm_eps=cfg.rms_eps,
+                    rope_theta=cfg.rope_theta, tie_word_embeddings=False, max_position_embeddings=4096)
+    config = ns["Qwen3ASRConfig"](thinker_config=dict(audio_config=audio_cfg, text_config=text_cfg))
+    with torch.inference_mode():
+        model = ns["Qwen3ASRForConditionalGeneration"](config).float().eval()
+        sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in ck.items()}
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not unexpected, unexpected
+        assert all("positional_embedding" in m or "inv_freq" in m for m in missing), missing
+        ns["refresh_non_persistent_buffers"](model, config.thinker_config.text_config)
+        enc = ns["QWEN3_ASR_ENCODER"](model.thinker.audio_tower, model.thinker.model.embed_tokens, head_ids, tail_ids, query_suffix_ids).eval()
+        embed = ns["QWEN3_ASR_DECODER_EMBED"](model).eval()
+        rot_p = ns["QWEN3_ASR_ROTARY_MASK_PREFILL"](model.thinker.model, max_seq_len).eval()
+        rot_d = ns["QWEN3_ASR_ROTARY_MASK_DECODE"](model.thinker.model, max_seq_len).eval()
+        main = ns["QWEN3_ASR_DECODER_MAIN"](model, cfg.n_heads, cfg.n_kv_heads, cfg.d_head, cfg.n_layers, cfg.d_model).eval()
+    return dict(ns=ns, encoder=enc, embed=embed, rotary_prefill=rot_p, rotary_decode=rot_d, main=main, model=model)

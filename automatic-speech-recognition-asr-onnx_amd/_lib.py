@@ -43,6 +43,13 @@ class WhisperConfigC(C.Structure):
         ("reserved", C.c_int32 * 9)]
 
 
+class QwenConfigC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "sample_rate", "n_mels", "nfft", "hop_length", "enc_d", "enc_heads", "enc_ffn", "n_enc_layers", "conv_channels", "n_window",
+        "n_window_infer", "max_source_positions", "d_model", "n_heads", "n_kv_heads", "d_head", "d_ffn", "n_layers", "vocab", "max_seq_len",
+        "max_audio_len")] + [("rms_eps", C.c_float), ("rope_theta", C.c_float), ("reserved", C.c_int32 * 9)]
+
+
 # name -> (restype, argtypes); every symbol include/asr_mi355x.h declares
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 _fp, _ip, _lp, _dp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double)
@@ -66,6 +73,10 @@ SIGNATURES = {
     "asr_whisper_set_penalty": (_i, [_vp, C.c_float, _i]),
     "asr_whisper_set_sampling": (_i, [_vp, _i, C.c_float, _i, C.c_float, C.c_float, C.c_uint64]),
     "asr_whisper_set_sampling_noise": (_i, [_vp, _fp, _i]),
+    "asr_qwen_create": (_i, [C.POINTER(QwenConfigC), _vp, _sz, _i, _i, _i, C.POINTER(_vp)]),
+    "asr_qwen_prefill": (_i, [_vp, _vp, _i, _lp, _i, _ip, _ip, _ip, _ip, _ip, _fp, _ip]),
+    "asr_qwen_decode": (_i, [_vp, _ip, _ip, _fp]),
+    "asr_qwen_generate": (_i, [_vp, _i, _ip, _i, _ip, _ip]),
     "asr_mem_alloc": (_i, [_i, _sz, C.POINTER(_vp)]),
     "asr_mem_free": (_i, [_i, _vp]),
     "asr_mem_copy": (_i, [_i, _vp, _vp, _sz, _i]),

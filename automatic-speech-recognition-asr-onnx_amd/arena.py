@@ -469,3 +469,87 @@ def build_paraformer_arena(cfg, ck: dict, precision: int = PRECISION_BF16, strea
     w.weight("out.w", ow, precision)
     w.add("out.b", ob, DT_F32)
     return w.finish()
+
+
+# =========================================================================== Qwen3-ASR
+def build_qwen_asr_arena(cfg, ck: dict, precision: int = PRECISION_BF16) -> np.ndarray:
+    """Fold an HF-layout Qwen3-ASR checkpoint (thinker.audio_tower.* / thinker.model.* / thinker.lm_head.weight) into the engine
+    arena. Folds follow the exporter: encoder LayerNorm affines into q|k|v / fc1 / proj1 and d^-1/4 on q and k
+    (Export_Qwen_ASR.py:381-398); decoder RMSNorm weights into q|k|v and gate|up, d^-1/4 into the q / k norm weights (:1141-1190).
+    The three stride-2 Conv2d become GEMMs over channel-last 3 x 3 patches: weight column = (kh * 3 + kw) * Cpad + c_in with
+    channels zero-padded to Cpad = 128-multiple; conv_out's columns are re-ordered from (c, f) to (f, c)."""
+    w = ArenaWriter()
+    a, t = "thinker.audio_tower.", "thinker.model."
+    bins = cfg.nfft // 2 + 1
+    w.add("fe.dft", pack_dft_for_mfma(whisper_dft_matrix(cfg.nfft), bins, cfg.nfft), DT_F32)
+    w.add("fe.mel", pack_mel_for_mfma(slaney_mel_filterbank(bins, cfg.n_mels, cfg.sample_rate).T.copy(), cfg.n_mels), DT_F32)
+    C, de, d = cfg.conv_channels, cfg.enc_d, cfg.d_model
+    cpad = (C + 127) // 128 * 128
+    f32 = lambda x: np.asarray(x, dtype=np.float32)
+
+    c1 = np.zeros((cpad, 64), dtype=np.float32)
+    c1[:C, :9] = f32(ck[a + "conv2d1.weight"]).reshape(C, 9)
+    w.weight("enc.conv1_w", c1, precision)
+    for name, key in (("enc.conv2_w", "conv2d2"), ("enc.conv3_w", "conv2d3")):
+        cw = np.zeros((cpad, 3, 3, cpad), dtype=np.float32)
+        cw[:C, :, :, :C] = f32(ck[a + key + ".weight"]).transpose(0, 2, 3, 1)
+        w.weight(name, cw.reshape(cpad, 9 * cpad), precision)
+    for name, key in (("enc.conv1_b", "conv2d1"), ("enc.conv2_b", "conv2d2"), ("enc.conv3_b", "conv2d3")):
+        b = np.zeros(cpad, dtype=np.float32)
+        b[:C] = f32(ck[a + key + ".bias"])
+        w.add(name, b, DT_F32)
+    n_f = f32(ck[a + "conv_out.weight"]).shape[1] // C                        # 16 frequency rows left after the stem
+    co = np.zeros((de, n_f, cpad), dtype=np.float32)
+    co[:, :, :C] = f32(ck[a + "conv_out.weight"]).reshape(de, C, n_f).transpose(0, 2, 1)
+    w.weight("enc.conv_out_w", co.reshape(de, n_f * cpad), precision)
+    half = de // 2
+    inv = np.exp(-(np.log(10000.0) / (half - 1)) * np.arange(half, dtype=np.float32)).astype(np.float32)
+    st = np.arange(13, dtype=np.float32)[:, None] * inv[None, :]               # SinusoidsPositionEmbedding rows 0..12 (:869-872)
+    w.add("enc.pos", np.concatenate([np.sin(st), np.cos(st)], 1).astype(np.float32), DT_F32)
+
+    s = np.float64((de // cfg.enc_heads) ** -0.25)
+    for i in range(cfg.n_enc_layers):
+        p, q = f"{a}layers.{i}.", f"enc{i}."
+        wq = np.concatenate([ck[p + "self_attn.q_proj.weight"], ck[p + "self_attn.k_proj.weight"], ck[p + "self_attn.v_proj.weight"]], 0).astype(np.float64)
+        bq = np.concatenate([ck[p + "self_attn.q_proj.bias"], ck[p + "self_attn.k_proj.bias"], ck[p + "self_attn.v_proj.bias"]], 0).astype(np.float64)
+        g, be = ck[p + "self_attn_layer_norm.weight"].astype(np.float64), ck[p + "self_attn_layer_norm.bias"].astype(np.float64)
+        bq = bq + wq @ be
+        wq = wq * g[None, :]
+        wq[:2 * de] *= s
+        bq[:2 * de] *= s
+        g2, be2 = ck[p + "final_layer_norm.weight"].astype(np.float64), ck[p + "final_layer_norm.bias"].astype(np.float64)
+        w1 = ck[p + "fc1.weight"].astype(np.float64)
+        b1 = ck[p + "fc1.bias"].astype(np.float64) + w1 @ be2
+        w1 = w1 * g2[None, :]
+        w.weight(q + "wqkv", f32(wq), precision); w.add(q + "bqkv", f32(bq), DT_F32)
+        w.weight(q + "wo", f32(ck[p + "self_attn.out_proj.weight"]), precision); w.add(q + "bo", f32(ck[p + "self_attn.out_proj.bias"]), DT_F32)
+        w.weight(q + "w1", f32(w1), precision); w.add(q + "b1", f32(b1), DT_F32)
+        w.weight(q + "w2", f32(ck[p + "fc2.weight"]), precision); w.add(q + "b2", f32(ck[p + "fc2.bias"]), DT_F32)
+    gp, bp = ck[a + "ln_post.weight"].astype(np.float64), ck[a + "ln_post.bias"].astype(np.float64)
+    wp = ck[a + "proj1.weight"].astype(np.float64)
+    w.weight("enc.proj1_w", f32(wp * gp[None, :]), precision)
+    w.add("enc.proj1_b", f32(ck[a + "proj1.bias"].astype(np.float64) + wp @ bp), DT_F32)
+    w.weight("enc.proj2_w", f32(ck[a + "proj2.weight"]), precision)
+    w.add("enc.proj2_b", f32(ck[a + "proj2.bias"]), DT_F32)
+
+    vpad = (cfg.vocab + 127) // 128 * 128
+    emb = np.zeros((vpad, d), dtype=np.float32)
+    emb[:cfg.vocab] = ck[t + "embed_tokens.weight"]
+    w.weight("dec.embed", emb, precision)
+    head = np.zeros((vpad, d), dtype=np.float32)
+    head[:cfg.vocab] = ck["thinker.lm_head.weight"]
+    w.weight("dec.lm_head", head, precision)
+    w.add("dec.inv_freq", (1.0 / (cfg.rope_theta ** (np.arange(0, cfg.d_head, 2, dtype=np.float32) / cfg.d_head))).astype(np.float32), DT_F32)
+    w.add("dec.final_norm", f32(ck[t + "norm.weight"]), DT_F32)
+    sc = np.float32(float(cfg.d_head ** -0.25))
+    for i in range(cfg.n_layers):
+        p, q = f"{t}layers.{i}.", f"dec{i}."
+        wqkv = np.concatenate([ck[p + "self_attn.q_proj.weight"], ck[p + "self_attn.k_proj.weight"], ck[p + "self_attn.v_proj.weight"]], 0)
+        w.weight(q + "wqkv", f32(wqkv * ck[p + "input_layernorm.weight"][None, :]), precision)
+        w.weight(q + "wo", f32(ck[p + "self_attn.o_proj.weight"]), precision)
+        gu = np.concatenate([ck[p + "mlp.gate_proj.weight"], ck[p + "mlp.up_proj.weight"]], 0)
+        w.weight(q + "gate_up", f32(gu * ck[p + "post_attention_layernorm.weight"][None, :]), precision)
+        w.weight(q + "down", f32(ck[p + "mlp.down_proj.weight"]), precision)
+        w.add(q + "qn", f32(ck[p + "self_attn.q_norm.weight"] * sc), DT_F32)
+        w.add(q + "kn", f32(ck[p + "self_attn.k_norm.weight"] * sc), DT_F32)
+    return w.finish()

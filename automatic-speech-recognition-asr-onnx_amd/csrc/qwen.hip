@@ -1,0 +1,785 @@
+// Qwen3-ASR hot path on one MI355X (Qwen_ASR/Export_Qwen_ASR.py).
+//   prefill : packed ragged batch -> Whisper-style log-mel (shared fbank kernel) -> 100-frame chunks -> 3 x Conv2d(k3, s2, p1) +
+//             tanh-GELU as GEMMs over gathered (channel-last) patches -> conv_out + positions -> windowed-attention encoder
+//             layers (windows of n_window_infer / 100 chunks are the attention units) -> proj1 / tanh-GELU / proj2 -> prompt rows
+//             [head | query | suffix | audio | tail | language tail] gathered into the decoder's residual stream -> Qwen3 decoder
+//             layers over the whole prompt (RMSNorm folded into q|k|v, per-head q/k RMSNorm, RoPE, causal GQA attention with an
+//             in-place KV cache, SwiGLU) -> final RMSNorm of each sequence's last row -> lm_head -> arg-max.
+//             Follows QWEN3_ASR_ENCODER.forward (:850-927), ROTARY_MASK_PREFILL (:933-1002), DECODER_MAIN.forward (:1265-1336).
+//   decode  : one token per sequence with per-sequence history lengths (ROTARY_MASK_DECODE :1005-1028).
+// The reference shuttles 2 x 28 KV tensors through Python per token and re-concatenates them (:1306-1309); here the cache is
+// appended in place and token ids / history lengths stay on the device between steps.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/asr_mi355x.h"
+#include "engine.h"
+#include "gemm.h"
+#include "kernels.h"
+
+namespace {
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// tokens after the three stride-2 convolutions of n mel frames (_get_feat_extract_output_lengths, :519-527)
+inline int feat_lengths(int n) {
+  const int leave = n % 100;
+  const int f1 = leave > 0 ? (std::max(leave - 1, 0) / 2 + 1) : 0;
+  const int f2 = f1 > 0 ? (std::max(f1 - 1, 0) / 2 + 1) : 0;
+  const int f3 = f2 > 0 ? (std::max(f2 - 1, 0) / 2 + 1) : 0;
+  return f3 + (n / 100) * 13;
+}
+
+// rows handed to the GEMMs must be readable up to the next row-tile edge (128- or 144-row tiles)
+inline size_t pad_rows(size_t r) { return (r + 127) / 128 * 128 + 144; }
+
+// ------------------------------------------------------------------------------------ kernels
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* o);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* o) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* o) {
+  const uint4 r = *reinterpret_cast<const uint4*>(p);
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[2 * e] = __uint_as_float(w[e] << 16); o[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+}
+// log-mel finish: clamp to (clip max - 8), x * 0.25 + 1, laid out per 100-frame chunk slot [slot][frame][mel]; frames past the clip
+// (and whole padding slots) are zero (:855-866)
+template <typename T>
+__global__ void qw_mel_finish_kernel(const float* __restrict__ mel, const float* __restrict__ blk_max, const UttPlan* __restrict__ plan,
+                                     const int32_t* __restrict__ slot_utt, const int32_t* __restrict__ slot_local, int n_mels, int chunk,
+                                     T* __restrict__ out) {
+  const int j = blockIdx.x, slot = j / chunk, t = j - slot * chunk, u = slot_utt[slot];
+  T* o = out + (size_t)j * n_mels;
+  int f = -1;
+  UttPlan up{};
+  if (u >= 0) { up = plan[u]; f = slot_local[slot] * chunk + t; if (f >= up.n_frames) f = -1; }
+  if (f < 0) {
+    for (int c = threadIdx.x; c < n_mels; c += blockDim.x) Elem<T>::store(o + c, 0.0f);
+    return;
+  }
+  float gmax = -INFINITY;
+  const int nblk = (up.n_frames + 63) / 64;
+  for (int k = 0; k < nblk; ++k) gmax = fmaxf(gmax, blk_max[up.blk0 + k]);
+  for (int c = threadIdx.x; c < n_mels; c += blockDim.x) {
+    const float v = fmaxf(mel[(size_t)(up.frame_off + f) * n_mels + c], gmax - 8.0f);
+    Elem<T>::store(o + c, v * 0.25f + 1.0f);
+  }
+}
+
+// conv1 patches: row (slot, t1, f1) <- the 3 x 3 neighbourhood of feat[slot][2 t1 + kw - 1][2 f1 + kh - 1]; K = 64 (9 used, k = kh*3+kw)
+template <typename T>
+__global__ void qw_im2col1_kernel(const T* __restrict__ feat, int n_mels, int chunk, int t_out, int f_out, T* __restrict__ out) {
+  const size_t r = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int k = threadIdx.x & 63;
+  const int per = t_out * f_out;
+  const int slot = (int)(r / per), rem = (int)(r % per), t1 = rem / f_out, f1 = rem % f_out;
+  float v = 0.0f;
+  if (k < 9) {
+    const int kh = k / 3, kw = k % 3, fi = 2 * f1 + kh - 1, ti = 2 * t1 + kw - 1;
+    if (fi >= 0 && fi < n_mels && ti >= 0 && ti < chunk) v = Elem<T>::load(feat + ((size_t)slot * chunk + ti) * n_mels + fi);
+  }
+  Elem<T>::store(out + r * 64 + k, v);
+}
+
+// channel-last patches of a stride-2 3 x 3 convolution: out row (unit, t_o, f_o), column (kh*3+kw) * C + c <- src row
+// (src_unit, 2 t_o + kw - 1, 2 f_o + kh - 1) (zero outside [0, t_in) x [0, f_in)). `slots` > 0 describes conv3's window layout: the
+// unit is a window of `slots` token rows; slot s maps to source unit unit * cpw + s / t_tok, t_o = s % t_tok (pad slots are zero).
+template <typename T>
+__global__ __launch_bounds__(256) void qw_im2col_cl_kernel(const T* __restrict__ src, int C, int t_in, int f_in, int t_o_n, int f_o_n, int slots,
+                                                           int cpw, int t_tok, T* __restrict__ out) {
+  const size_t r = blockIdx.x;
+  int unit, t_o, f_o, src_unit;
+  bool live = true;
+  if (slots > 0) {
+    const int per = slots * f_o_n;
+    unit = (int)(r / per);
+    const int rem = (int)(r % per), s = rem / f_o_n;
+    f_o = rem % f_o_n;
+    live = s < cpw * t_tok;
+    src_unit = unit * cpw + s / t_tok;
+    t_o = s % t_tok;
+  } else {
+    const int per = t_o_n * f_o_n;
+    unit = (int)(r / per);
+    const int rem = (int)(r % per);
+    t_o = rem / f_o_n; f_o = rem % f_o_n;
+    src_unit = unit;
+  }
+  constexpr int V = 16 / sizeof(T);                    // elements per 16-byte move
+  const int vec_per_tap = C / V;
+  for (int e = threadIdx.x; e < 9 * vec_per_tap; e += 256) {
+    const int tap = e / vec_per_tap, cv = e - tap * vec_per_tap, kh = tap / 3, kw = tap % 3;
+    const int ti = 2 * t_o + kw - 1, fi = 2 * f_o + kh - 1;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (live && ti >= 0 && ti < t_in && fi >= 0 && fi < f_in)
+      v = *reinterpret_cast<const uint4*>(src + (((size_t)src_unit * t_in + ti) * f_in + fi) * C + cv * V);
+    *reinterpret_cast<uint4*>(out + r * 9 * C + (size_t)tap * C + cv * V) = v;
+  }
+}
+
+// y = x * rsqrt(mean(x^2) + eps) [* weight]; one wave per row
+template <typename OutT>
+__global__ __launch_bounds__(256) void qw_rmsnorm_kernel(const float* __restrict__ x, int ld_x, int rows, int D, const float* __restrict__ w,
+                                                         float eps, OutT* __restrict__ out, int ld_out, const int32_t* __restrict__ src_rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)(src_rows ? src_rows[row] : row) * ld_x;
+  float ss = 0.0f;
+  for (int i = lane * 4; i < D; i += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + i);
+    ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  const float r = rsqrtf(wave_sum(ss) / (float)D + eps);
+  OutT* o = out + (size_t)row * ld_out;
+  for (int i = lane * 4; i < D; i += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + i);
+    float y[4] = {v.x * r, v.y * r, v.z * r, v.w * r};
+    if (w) { y[0] *= w[i]; y[1] *= w[i + 1]; y[2] *= w[i + 2]; y[3] *= w[i + 3]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Elem<OutT>::store(o + i + e, y[e]);
+  }
+}
+
+// per-head RMSNorm of q and k (weight * d^-1/4 folded), RoPE (half-split convention, position = hist + t), then q -> operand
+// buffer, k / v -> the KV cache [layer-local base][seq][kv head][S][128] at that position (:1283-1309). One wave per (row, head).
+template <typename T>
+__global__ __launch_bounds__(256) void qw_qk_rope_kernel(const float* __restrict__ qkv, int n_heads, int n_kv, const float* __restrict__ qn,
+                                                         const float* __restrict__ kn, const float* __restrict__ inv_freq, float eps,
+                                                         const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_t,
+                                                         const int32_t* __restrict__ hist, int rows, T* __restrict__ q_out, T* __restrict__ kc,
+                                                         T* __restrict__ vc, int S_max) {
+  constexpr int HD = 128;
+  const int heads = n_heads + 2 * n_kv;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int row = wid / heads, hh = wid - row * heads;
+  if (row >= rows) return;
+  const int b = row_seq[row];
+  if (b < 0) return;
+  const int pos = hist[b] + row_t[row];
+  const float* src = qkv + (size_t)row * heads * HD + hh * HD;
+  const float x0 = src[lane], x1 = src[lane + 64];              // the two rotary halves of this lane's pair
+  if (hh >= n_heads + n_kv) {                                  // v: cached as is
+    T* dst = vc + (((size_t)b * n_kv + (hh - n_heads - n_kv)) * S_max + pos) * HD;
+    Elem<T>::store(dst + lane, x0);
+    Elem<T>::store(dst + lane + 64, x1);
+    return;
+  }
+  const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / (float)HD + eps);
+  const float* w = hh < n_heads ? qn : kn;
+  const float a0 = x0 * r * w[lane], a1 = x1 * r * w[lane + 64];
+  const float th = (float)pos * inv_freq[lane];
+  const float cs = cosf(th), sn = sinf(th);
+  const float y0 = a0 * cs - a1 * sn, y1 = a1 * cs + a0 * sn;
+  T* dst = hh < n_heads ? q_out + (size_t)row * n_heads * HD + hh * HD
+                        : kc + (((size_t)b * n_kv + (hh - n_heads)) * S_max + pos) * HD;
+  Elem<T>::store(dst + lane, y0);
+  Elem<T>::store(dst + lane + 64, y1);
+}
+
+// causal GQA attention over the cache: workgroup = (sequence, q head), 128 threads; query t of the sequence sees keys [0, hist + t]
+template <typename T>
+__global__ __launch_bounds__(128) void qw_attn_kernel(const T* __restrict__ q, int n_heads, int n_kv, const T* __restrict__ kc,
+                                                      const T* __restrict__ vc, int S_max, const UttPlan* __restrict__ plan,
+                                                      const int32_t* __restrict__ hist, T* __restrict__ ctx) {
+  constexpr int HD = 128;
+  extern __shared__ float qw_sc[];                       // [S_max] scores / probabilities
+  __shared__ float qs[HD];
+  __shared__ float red[2];
+  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, kvh = h / (n_heads / n_kv);
+  const UttPlan p = plan[b];
+  const int nq = p.T, row0 = p.row_off, h0 = hist[b];
+  const T* K = kc + ((size_t)b * n_kv + kvh) * S_max * HD;
+  const T* V = vc + ((size_t)b * n_kv + kvh) * S_max * HD;
+  for (int t = 0; t < nq; ++t) {
+    const int nk = h0 + t + 1;
+    __syncthreads();
+    qs[tid] = Elem<T>::load(q + (size_t)(row0 + t) * n_heads * HD + h * HD + tid);
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int s = tid; s < nk; s += 128) {
+      const T* kr = K + (size_t)s * HD;
+      float acc = 0.0f;
+      for (int e = 0; e < HD; e += 8) {
+        float kv8[8];
+        load8<T>(kr + e, kv8);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(qs[e + u], kv8[u], acc);
+      }
+      qw_sc[s] = acc;
+      mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(red[0], red[1]);
+    __syncthreads();
+    float sum = 0.0f;
+    for (int s = tid; s < nk; s += 128) { const float e = expf(qw_sc[s] - mx); qw_sc[s] = e; sum += e; }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1]);
+    float acc = 0.0f;
+    for (int s = 0; s < nk; ++s) acc = fmaf(qw_sc[s], Elem<T>::load(V + (size_t)s * HD + tid), acc);
+    Elem<T>::store(ctx + (size_t)(row0 + t) * n_heads * HD + h * HD + tid, acc * inv);
+  }
+}
+
+template <typename T>
+__global__ void qw_silu_mul_kernel(const T* __restrict__ gu, int I, size_t n, T* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t row = i / I, c = i - row * I;
+  const float g = Elem<T>::load(gu + row * 2 * I + c), u = Elem<T>::load(gu + row * 2 * I + I + c);
+  Elem<T>::store(out + i, g / (1.0f + expf(-g)) * u);
+}
+
+// decoder input rows: src >= 0 -> embedding of token src; src < 0 -> audio embedding row -1 - src; pad rows are zero
+template <typename T>
+__global__ void qw_gather_prompt_kernel(const int32_t* __restrict__ src, const T* __restrict__ embed, const float* __restrict__ audio, int d,
+                                        int32_t pad_marker, float* __restrict__ x) {
+  const int row = blockIdx.x, s = src[row];
+  float* o = x + (size_t)row * d;
+  for (int c = threadIdx.x; c < d; c += blockDim.x)
+    o[c] = s == pad_marker ? 0.0f : (s >= 0 ? Elem<T>::load(embed + (size_t)s * d + c) : audio[(size_t)(-1 - s) * d + c]);
+}
+
+__global__ void qw_hist_add_kernel(int32_t* __restrict__ hist, const UttPlan* __restrict__ plan, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) hist[b] += plan[b].T;
+}
+
+// ------------------------------------------------------------------------------------ session
+struct QwEncLayer { const void *wqkv, *wo, *w1, *w2; const float *bqkv, *bo, *b1, *b2; };
+struct QwDecLayer { const void *wqkv, *wo, *gate_up, *down; const float *qn, *kn; };
+
+struct QwSession : asr_session {
+  asr_qwen_config cfg;
+  int vpad = 0, cpad = 0, n_bin_tiles = 0, n_kchunks = 0, chunk = 0, cpw = 0, rpw = 0, t_tok = 13;
+  std::vector<QwEncLayer> enc;
+  std::vector<QwDecLayer> dec;
+  const float *dft = nullptr, *melp = nullptr, *conv1_b = nullptr, *conv2_b = nullptr, *conv3_b = nullptr, *enc_pos = nullptr,
+              *proj1_b = nullptr, *proj2_b = nullptr, *inv_freq = nullptr, *final_norm = nullptr;
+  const void *conv1_w = nullptr, *conv2_w = nullptr, *conv3_w = nullptr, *conv_out_w = nullptr, *proj1_w = nullptr, *proj2_w = nullptr,
+             *embed = nullptr, *lm_head = nullptr;
+  int batch = 0;
+  std::vector<int> seq_len;                              // positions in the cache per sequence (host mirror)
+  DeviceBuffer d_plan, d_audio, d_mel, d_blkmax, d_feat, d_col, d_c1, d_c2, d_c3, d_xa, d_xb, d_h, d_qk, d_vt, d_ctx, d_ffn, d_aud_out;
+  DeviceBuffer d_dplan, d_x, d_x2, d_dh, d_qkv, d_q, d_dctx, d_gu, d_act, d_last, d_logits, d_next, d_kc, d_vc, d_hist, d_stepplan, d_skws, d_skcnt;
+  void* h_plan = nullptr; size_t h_plan_cap = 0;
+  void* h_io = nullptr; size_t h_io_cap = 0;
+  void* h_ids = nullptr; size_t h_ids_cap = 0;
+
+  ~QwSession() override {
+    for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_feat, &d_col, &d_c1, &d_c2, &d_c3, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx,
+                            &d_ffn, &d_aud_out, &d_dplan, &d_x, &d_x2, &d_dh, &d_qkv, &d_q, &d_dctx, &d_gu, &d_act, &d_last, &d_logits, &d_next,
+                            &d_kc, &d_vc, &d_hist, &d_stepplan, &d_skws, &d_skcnt})
+      b->release();
+    for (auto& kv : taps) kv.second.buf.release();
+    if (h_plan) (void)hipHostFree(h_plan);
+    if (h_io) (void)hipHostFree(h_io);
+    if (h_ids) (void)hipHostFree(h_ids);
+    prof.release();
+    arena.release();
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
+  void gemm(const GemmArgs& g0) {
+    if (precision != ASR_PRECISION_BF16) { launch_gemm_f32(g0, stream); return; }
+    if (!d_skws.ptr) { d_skws.reserve((size_t)16 << 20, stream); d_skcnt.reserve(4096 * 4, stream); }
+    GemmArgs g = g0;
+    g.sk_ws = d_skws.as<float>(); g.sk_ws_bytes = d_skws.cap; g.sk_cnt = d_skcnt.as<int32_t>();
+    launch_gemm_bf16(g, stream);
+  }
+  void* pinned(void*& p, size_t& cap, size_t bytes) {
+    if (bytes > cap) {
+      if (p) HIP_CHECK(hipHostFree(p));
+      HIP_CHECK(hipHostMalloc(&p, bytes * 2, hipHostMallocDefault));
+      cap = bytes * 2;
+    }
+    return p;
+  }
+  void init();
+  template <typename T> void prefill(const float* audio, int audio_mem, const int64_t* offs, int B, const int32_t* pre_ids, const int32_t* pre_off,
+                                     const int32_t* post_ids, const int32_t* post_off, int32_t* next_out, float* logits_out, int32_t* ids_len_out);
+  template <typename T> void decoder_pass(const UttPlan* dplan, const int32_t* row_seq, const int32_t* row_t, const int32_t* last_rows, int rows,
+                                          int B);
+  template <typename T> void step(const int32_t* ids_host, int32_t* next_out, float* logits_out);
+  template <typename T> void finish(int B, int32_t* next_out, float* logits_out, bool sync);
+};
+
+void QwSession::init() {
+  const auto& c = cfg;
+  ASR_REQUIRE(c.nfft == 400 && c.hop_length == 160 && c.n_mels == 128, "qwen: front-end is built for n_fft 400 / hop 160 / 128 mels");
+  ASR_REQUIRE(c.d_head == 128 && c.n_heads % c.n_kv_heads == 0, "qwen: decoder head_dim must be 128");
+  ASR_REQUIRE(c.enc_d % 128 == 0 && c.enc_d / c.enc_heads == 64 && c.enc_ffn % 128 == 0, "qwen: encoder needs 64-wide heads and widths that are multiples of 128");
+  ASR_REQUIRE(c.d_model % 128 == 0 && c.d_ffn % 64 == 0 && (2 * c.d_ffn) % 128 == 0, "qwen: decoder widths must be multiples of 128");
+  ASR_REQUIRE(c.n_window == 50, "qwen: the conv stem is built for 100-frame chunks (n_window 50)");
+  chunk = 2 * c.n_window;
+  cpw = c.n_window_infer / chunk;
+  rpw = round_up(cpw * t_tok, 16);
+  ASR_REQUIRE(cpw >= 1 && rpw <= 1024, "qwen: bad attention window");
+  vpad = round_up(c.vocab, 128);
+  cpad = round_up(c.conv_channels, 128);
+  n_bin_tiles = (c.nfft / 2 + 1 + 15) / 16;
+  n_kchunks = c.nfft / 16;
+  const int wt = precision == ASR_PRECISION_BF16 ? ARENA_BF16 : ARENA_F32;
+  const int de = c.enc_d, d = c.d_model, qkvn = (c.n_heads + 2 * c.n_kv_heads) * c.d_head;
+  auto F = [&](const std::string& n, std::initializer_list<int64_t> sh) { return (const float*)arena.get(n, ARENA_F32, sh).ptr; };
+  auto W = [&](const std::string& n, std::initializer_list<int64_t> sh) { return arena.get(n, wt, sh).ptr; };
+  dft = F("fe.dft", {(int64_t)n_bin_tiles * 2 * n_kchunks * 64 * 4});
+  melp = F("fe.mel", {(int64_t)(c.n_mels / 16) * n_bin_tiles * 64 * 4});
+  conv1_w = W("enc.conv1_w", {cpad, 64});          conv1_b = F("enc.conv1_b", {cpad});
+  conv2_w = W("enc.conv2_w", {cpad, 9 * cpad});    conv2_b = F("enc.conv2_b", {cpad});
+  conv3_w = W("enc.conv3_w", {cpad, 9 * cpad});    conv3_b = F("enc.conv3_b", {cpad});
+  conv_out_w = W("enc.conv_out_w", {de, 16 * cpad});
+  enc_pos = F("enc.pos", {t_tok, de});
+  enc.resize(c.n_enc_layers);
+  for (int i = 0; i < c.n_enc_layers; ++i) {
+    const std::string q = "enc" + std::to_string(i) + ".";
+    enc[i] = {W(q + "wqkv", {3 * de, de}), W(q + "wo", {de, de}), W(q + "w1", {c.enc_ffn, de}), W(q + "w2", {de, c.enc_ffn}),
+              F(q + "bqkv", {3 * de}), F(q + "bo", {de}), F(q + "b1", {c.enc_ffn}), F(q + "b2", {de})};
+  }
+  proj1_w = W("enc.proj1_w", {de, de});   proj1_b = F("enc.proj1_b", {de});
+  proj2_w = W("enc.proj2_w", {d, de});    proj2_b = F("enc.proj2_b", {d});
+  embed = W("dec.embed", {vpad, d});
+  lm_head = W("dec.lm_head", {vpad, d});
+  inv_freq = F("dec.inv_freq", {c.d_head / 2});
+  final_norm = F("dec.final_norm", {d});
+  dec.resize(c.n_layers);
+  for (int i = 0; i < c.n_layers; ++i) {
+    const std::string q = "dec" + std::to_string(i) + ".";
+    dec[i] = {W(q + "wqkv", {qkvn, d}), W(q + "wo", {d, c.n_heads * c.d_head}), W(q + "gate_up", {2 * c.d_ffn, d}), W(q + "down", {d, c.d_ffn}),
+              F(q + "qn", {c.d_head}), F(q + "kn", {c.d_head})};
+  }
+}
+
+// one pass of the decoder stack over `rows` packed rows described by `dplan` (T new positions per sequence, appended at hist[b])
+template <typename T>
+void QwSession::decoder_pass(const UttPlan* dplan, const int32_t* row_seq, const int32_t* row_t, const int32_t* last_rows, int rows, int B) {
+  const auto& c = cfg;
+  const int d = c.d_model, H = c.n_heads, KV = c.n_kv_heads, hd = c.d_head, I = c.d_ffn, qkvn = (H + 2 * KV) * hd, S = c.max_seq_len;
+  float* x = d_x.as<float>();
+  float* x2 = d_x2.as<float>();
+  T* h = d_dh.as<T>();
+  float* qkv = d_qkv.as<float>();
+  T* q = d_q.as<T>();
+  T* ctx = d_dctx.as<T>();
+  T* gu = d_gu.as<T>();
+  T* act = d_act.as<T>();
+  const size_t layer_kv = (size_t)B * KV * S * hd;
+  const int32_t* hist = d_hist.as<int32_t>();
+  for (int i = 0; i < c.n_layers; ++i) {
+    const QwDecLayer& L = dec[i];
+    T* kc = d_kc.as<T>() + (size_t)i * layer_kv;
+    T* vc = d_vc.as<T>() + (size_t)i * layer_kv;
+    { ProfScope ps(prof, "dec_norm", stream);
+      hipLaunchKernelGGL(qw_rmsnorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, d, rows, d, (const float*)nullptr, c.rms_eps, h, d, (const int32_t*)nullptr); }
+    { ProfScope ps(prof, "dec_gemm", stream);
+      GemmArgs g; g.A = h; g.lda = d; g.W = L.wqkv; g.ldw = d; g.M = rows; g.N = qkvn; g.K = d; g.out_f32 = qkv; g.ld_out_f32 = qkvn; gemm(g); }
+    { ProfScope ps(prof, "dec_rope", stream);
+      const int waves = rows * (H + 2 * KV);
+      hipLaunchKernelGGL(qw_qk_rope_kernel<T>, dim3((waves + 3) / 4), dim3(256), 0, stream, qkv, H, KV, L.qn, L.kn, inv_freq, c.rms_eps, row_seq, row_t,
+                         hist, rows, q, kc, vc, S); }
+    { ProfScope ps(prof, "dec_attn", stream);
+      hipLaunchKernelGGL(qw_attn_kernel<T>, dim3(B, H), dim3(128), (size_t)S * 4, stream, q, H, KV, kc, vc, S, dplan, hist, ctx); }
+    { ProfScope ps(prof, "dec_gemm", stream);
+      GemmArgs g; g.A = ctx; g.lda = H * hd; g.W = L.wo; g.ldw = H * hd; g.M = rows; g.N = d; g.K = H * hd; g.add = x; g.ld_add = d;
+      g.out_f32 = x2; g.ld_out_f32 = d; gemm(g); }
+    { ProfScope ps(prof, "dec_norm", stream);
+      hipLaunchKernelGGL(qw_rmsnorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, stream, x2, d, rows, d, (const float*)nullptr, c.rms_eps, h, d, (const int32_t*)nullptr); }
+    { ProfScope ps(prof, "dec_gemm", stream);
+      GemmArgs g; g.A = h; g.lda = d; g.W = L.gate_up; g.ldw = d; g.M = rows; g.N = 2 * I; g.K = d; g.out_lo = gu; g.ld_out_lo = 2 * I; gemm(g);
+      const size_t n = (size_t)rows * I;
+      hipLaunchKernelGGL(qw_silu_mul_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, gu, I, n, act);
+      GemmArgs g2; g2.A = act; g2.lda = I; g2.W = L.down; g2.ldw = I; g2.M = rows; g2.N = d; g2.K = I; g2.add = x2; g2.ld_add = d;
+      g2.out_f32 = x; g2.ld_out_f32 = d; gemm(g2); }
+  }
+  // final RMSNorm (learned weight) of every sequence's last row, lm_head (:1331-1335)
+  { ProfScope ps(prof, "dec_logits", stream);
+    T* last = d_last.as<T>();
+    hipLaunchKernelGGL(qw_rmsnorm_kernel<T>, dim3((B + 3) / 4), dim3(256), 0, stream, x, d, B, d, final_norm, c.rms_eps, last, d, last_rows);
+    GemmArgs g; g.A = last; g.lda = d; g.W = lm_head; g.ldw = d; g.M = B; g.N = vpad; g.K = d; g.out_f32 = d_logits.as<float>(); g.ld_out_f32 = vpad; gemm(g);
+    launch_argmax_rows(d_logits.as<float>(), vpad, B, c.vocab, nullptr, d_next.as<int32_t>(), stream); }
+  hipLaunchKernelGGL(qw_hist_add_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_hist.as<int32_t>(), dplan, B);
+  HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void QwSession::finish(int B, int32_t* next_out, float* logits_out, bool sync) {
+  const auto& c = cfg;
+  if (taps_enabled) save_tap("logits", d_logits.ptr, B, c.vocab, vpad, 4);
+  if (next_out || logits_out) {
+    unsigned char* st = (unsigned char*)pinned(h_io, h_io_cap, (size_t)B * 4 + (logits_out ? (size_t)B * c.vocab * 4 : 0));
+    if (next_out) HIP_CHECK(hipMemcpyAsync(st, d_next.ptr, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+    if (logits_out)
+      HIP_CHECK(hipMemcpy2DAsync(st + (size_t)B * 4, (size_t)c.vocab * 4, d_logits.ptr, (size_t)vpad * 4, (size_t)c.vocab * 4, B, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (next_out) memcpy(next_out, st, (size_t)B * 4);
+    if (logits_out) memcpy(logits_out, st + (size_t)B * 4, (size_t)B * c.vocab * 4);
+  } else if (sync || prof.enabled) {
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  if (prof.enabled) prof.collect();
+}
+
+template <typename T>
+void QwSession::prefill(const float* audio, int audio_mem, const int64_t* offs, int B, const int32_t* pre_ids, const int32_t* pre_off,
+                        const int32_t* post_ids, const int32_t* post_off, int32_t* next_out, float* logits_out, int32_t* ids_len_out) {
+  const auto& c = cfg;
+  ASR_REQUIRE(audio && offs && B >= 1 && pre_off && post_off, "qwen_prefill: bad argument");
+  HIP_CHECK(hipSetDevice(device));
+  const int de = c.enc_d, d = c.d_model, H = c.enc_heads, dff = c.enc_ffn;
+  const size_t eT = sizeof(T);
+  // ---- host plan: per utterance frames / chunk slots / windows; per window an attention unit
+  std::vector<UttPlan> up(B);
+  std::vector<int> n_chunks(B), n_win(B), slot0(B), win0(B), n_audio(B);
+  int frames = 0, n_fb = 0, slots = 0, wins = 0;
+  const int64_t base0 = offs[0];
+  for (int b = 0; b < B; ++b) {
+    const int64_t n = offs[b + 1] - offs[b];
+    ASR_REQUIRE(n >= c.nfft, "qwen: utterance %d has %lld samples (< n_fft %d)", b, (long long)n, c.nfft);
+    ASR_REQUIRE(n <= c.max_audio_len, "qwen: utterance %d has %lld samples (> max_audio_len %d)", b, (long long)n, c.max_audio_len);
+    UttPlan& p = up[b];
+    p.audio_off = offs[b] - base0; p.n_samples = (int)n; p.n_frames = (int)n / c.hop_length; p.frame_off = frames; p.blk0 = n_fb; p.lang = 0;
+    n_chunks[b] = (p.n_frames + chunk - 1) / chunk;
+    n_win[b] = (n_chunks[b] + cpw - 1) / cpw;
+    slot0[b] = slots; win0[b] = wins;
+    n_audio[b] = feat_lengths(p.n_frames);
+    p.n_lfr = n_audio[b]; p.T = n_audio[b]; p.row_off = wins * rpw;
+    frames += p.n_frames; n_fb += (p.n_frames + 63) / 64; slots += n_win[b] * cpw; wins += n_win[b];
+  }
+  const int rows_e = wins * rpw, Me = (int)pad_rows(rows_e);
+  int att_qt = 0, att_nw = 4, q_rows = 64, max_T = cpw * t_tok, n_qb = 0;
+  if (precision == ASR_PRECISION_BF16) { attention_geometry(max_T, 64, &att_qt, &att_nw); q_rows = 16 * att_qt * att_nw; }
+  // window plans (attention units) + tables
+  std::vector<UttPlan> wp(wins);
+  for (int b = 0; b < B; ++b) {
+    for (int w = 0; w < n_win[b]; ++w) {
+      int valid = 0;
+      for (int k = 0; k < cpw; ++k) {
+        const int ch = w * cpw + k;
+        if (ch < n_chunks[b]) valid += feat_lengths(std::min(std::max(up[b].n_frames - ch * chunk, 0), chunk));
+      }
+      UttPlan& p = wp[win0[b] + w];
+      p = up[b];
+      p.T = valid; p.n_lfr = valid; p.row_off = (win0[b] + w) * rpw;
+      n_qb += (valid + q_rows - 1) / q_rows;
+    }
+  }
+  // decoder prompt rows
+  std::vector<int> ids_len(B), drow0(B);
+  int rows_d = 0;
+  for (int b = 0; b < B; ++b) {
+    ids_len[b] = (pre_off[b + 1] - pre_off[b]) + n_audio[b] + (post_off[b + 1] - post_off[b]);
+    ASR_REQUIRE(ids_len[b] >= 1 && ids_len[b] <= c.max_seq_len, "qwen: prompt of %d positions exceeds max_seq_len %d", ids_len[b], c.max_seq_len);
+    drow0[b] = rows_d;
+    rows_d += round_up(ids_len[b], 16);
+    if (ids_len_out) ids_len_out[b] = ids_len[b];
+  }
+  const int Md = (int)pad_rows(rows_d);
+  // plan blob: [UttPlan B][win plans][dec plans B][blk_utt][blk_f0][qb_utt][qb_q0][slot_utt][slot_local][pos_rows Me][src Md][row_seq Md][row_t Md][last B]
+  const size_t plan_bytes = (sizeof(UttPlan) * (2 * (size_t)B + wins) + 4 * (2 * (size_t)n_fb + 2 * (size_t)n_qb + 2 * (size_t)slots + Me + 3 * (size_t)Md + B) + 15) / 16 * 16;
+  unsigned char* hp = (unsigned char*)pinned(h_plan, h_plan_cap, plan_bytes + sizeof(UttPlan) * B + 12 * (size_t)round_up(B, 128) + 64);
+  UttPlan* h_up = (UttPlan*)hp;
+  UttPlan* h_wp = h_up + B;
+  UttPlan* h_dp = h_wp + wins;
+  int32_t* blk_utt = (int32_t*)(h_dp + B);
+  int32_t* blk_f0 = blk_utt + n_fb;
+  int32_t* qb_utt = blk_f0 + n_fb;
+  int32_t* qb_q0 = qb_utt + n_qb;
+  int32_t* slot_utt = qb_q0 + n_qb;
+  int32_t* slot_local = slot_utt + slots;
+  int32_t* pos_rows = slot_local + slots;
+  int32_t* src = pos_rows + Me;
+  int32_t* row_seq = src + Md;
+  int32_t* row_t = row_seq + Md;
+  int32_t* last = row_t + Md;
+  memcpy(h_up, up.data(), sizeof(UttPlan) * B);
+  memcpy(h_wp, wp.data(), sizeof(UttPlan) * wins);
+  constexpr int32_t PAD = INT32_MIN;
+  {
+    int fi = 0, qi = 0;
+    for (int b = 0; b < B; ++b) {
+      for (int f0 = 0; f0 < up[b].n_frames; f0 += 64) { blk_utt[fi] = b; blk_f0[fi++] = f0; }
+      for (int k = 0; k < n_win[b] * cpw; ++k) { slot_utt[slot0[b] + k] = k < n_chunks[b] ? b : -1; slot_local[slot0[b] + k] = k; }
+    }
+    for (int w = 0; w < wins; ++w)
+      for (int q0 = 0; q0 < wp[w].T; q0 += q_rows) { qb_utt[qi] = w; qb_q0[qi++] = q0; }
+    for (int r = 0; r < Me; ++r) pos_rows[r] = (r < rows_e && (r % rpw) < cpw * t_tok) ? (r % rpw) % t_tok : 0;
+    for (int r = 0; r < Md; ++r) { src[r] = PAD; row_seq[r] = -1; row_t[r] = 0; }
+    for (int b = 0; b < B; ++b) {
+      int r = drow0[b];
+      for (int i = pre_off[b]; i < pre_off[b + 1]; ++i) {
+        ASR_REQUIRE(pre_ids[i] >= 0 && pre_ids[i] < c.vocab, "qwen: token id %d out of range", pre_ids[i]);
+        src[r++] = pre_ids[i];
+      }
+      // audio tokens: window w of the utterance holds tokens [w * cpw * 13, ...) at rows win * rpw + s
+      for (int j = 0; j < n_audio[b]; ++j) src[r++] = -1 - ((win0[b] + j / (cpw * t_tok)) * rpw + j % (cpw * t_tok));
+      for (int i = post_off[b]; i < post_off[b + 1]; ++i) {
+        ASR_REQUIRE(post_ids[i] >= 0 && post_ids[i] < c.vocab, "qwen: token id %d out of range", post_ids[i]);
+        src[r++] = post_ids[i];
+      }
+      for (int t = 0; t < ids_len[b]; ++t) { row_seq[drow0[b] + t] = b; row_t[drow0[b] + t] = t; }
+      last[b] = drow0[b] + ids_len[b] - 1;
+      UttPlan& p = h_dp[b];
+      p = up[b];
+      p.T = ids_len[b]; p.n_lfr = ids_len[b]; p.row_off = drow0[b];
+    }
+  }
+  d_plan.reserve(plan_bytes, stream);
+  HIP_CHECK(hipMemcpyAsync(d_plan.ptr, hp, plan_bytes, hipMemcpyHostToDevice, stream));
+  const UttPlan* dup = d_plan.as<UttPlan>();
+  const UttPlan* dwp = dup + B;
+  const UttPlan* ddp = dwp + wins;
+  const int32_t* d_blk_utt = (const int32_t*)(ddp + B);
+  const int32_t* d_blk_f0 = d_blk_utt + n_fb;
+  const int32_t* d_qb_utt = d_blk_f0 + n_fb;
+  const int32_t* d_qb_q0 = d_qb_utt + n_qb;
+  const int32_t* d_slot_utt = d_qb_q0 + n_qb;
+  const int32_t* d_slot_local = d_slot_utt + slots;
+  const int32_t* d_pos_rows = d_slot_local + slots;
+  const int32_t* d_src = d_pos_rows + Me;
+  const int32_t* d_row_seq = d_src + Md;
+  const int32_t* d_row_t = d_row_seq + Md;
+  const int32_t* d_last_rows = d_row_t + Md;
+
+  const float* d_aud;
+  const int64_t total_samples = offs[B] - base0;
+  if (audio_mem == ASR_MEM_HOST) {
+    d_audio.reserve((size_t)total_samples * 4, stream);
+    HIP_CHECK(hipMemcpyAsync(d_audio.ptr, audio + base0, (size_t)total_samples * 4, hipMemcpyHostToDevice, stream));
+    d_aud = d_audio.as<float>();
+  } else {
+    d_aud = audio + base0;
+  }
+  // ---- front-end + conv stem
+  const size_t r1 = (size_t)slots * 50 * 64, r2 = (size_t)slots * 25 * 32, r3 = (size_t)wins * rpw * 16;
+  d_mel.reserve((size_t)frames * c.n_mels * 4, stream);
+  d_blkmax.reserve((size_t)n_fb * 4, stream);
+  d_feat.reserve((size_t)slots * chunk * c.n_mels * eT, stream);
+  d_col.reserve(std::max(std::max(pad_rows(r1) * 64, pad_rows(r2) * 9 * cpad), pad_rows(r3) * 9 * cpad) * eT, stream);
+  d_c1.reserve(pad_rows(r1) * cpad * eT, stream);
+  d_c2.reserve(pad_rows(r2) * cpad * eT, stream);
+  d_c3.reserve((r3 + 16 * 288) * cpad * eT, stream);
+  d_xa.reserve((size_t)Me * de * 4, stream);
+  d_xb.reserve((size_t)Me * de * 4, stream);
+  d_h.reserve((size_t)Me * de * eT, stream);
+  d_qk.reserve((size_t)Me * 2 * de * eT, stream);
+  d_vt.reserve((size_t)Me * de * eT, stream);
+  d_ctx.reserve((size_t)Me * de * eT, stream);
+  d_ffn.reserve((size_t)Me * dff * eT, stream);
+  d_aud_out.reserve((size_t)Me * d * 4, stream);
+  {
+    ProfScope ps(prof, "logmel", stream);
+    FbankArgs fa;
+    fa.audio = d_aud; fa.plan = dup; fa.blk_utt = d_blk_utt; fa.blk_f0 = d_blk_f0; fa.dft_packed = dft; fa.mel_packed = melp;
+    fa.mel_out = d_mel.as<float>(); fa.n_bin_tiles = n_bin_tiles; fa.n_kchunks = n_kchunks; fa.n_mel_tiles = c.n_mels / 16; fa.n_mels = c.n_mels;
+    fa.win = c.nfft; fa.hop = c.hop_length; fa.log_floor = 1e-10f; fa.whisper = 1; fa.blk_max = d_blkmax.as<float>();
+    launch_fbank(fa, n_fb, stream);
+    hipLaunchKernelGGL(qw_mel_finish_kernel<T>, dim3(slots * chunk), dim3(128), 0, stream, d_mel.as<float>(), d_blkmax.as<float>(), dup, d_slot_utt,
+                       d_slot_local, c.n_mels, chunk, d_feat.as<T>());
+  }
+  {
+    ProfScope ps(prof, "conv_stem", stream);
+    T* col = d_col.as<T>();
+    hipLaunchKernelGGL(qw_im2col1_kernel<T>, dim3((unsigned)(r1 / 4)), dim3(256), 0, stream, d_feat.as<T>(), c.n_mels, chunk, 50, 64, col);
+    GemmArgs g1; g1.A = col; g1.lda = 64; g1.W = conv1_w; g1.ldw = 64; g1.M = (int)r1; g1.N = cpad; g1.K = 64; g1.bias = conv1_b; g1.act = ACT_GELU_TANH;
+    g1.out_lo = d_c1.ptr; g1.ld_out_lo = cpad; gemm(g1);
+    hipLaunchKernelGGL(qw_im2col_cl_kernel<T>, dim3((unsigned)r2), dim3(256), 0, stream, d_c1.as<T>(), cpad, 50, 64, 25, 32, 0, 0, 0, col);
+    GemmArgs g2; g2.A = col; g2.lda = 9 * cpad; g2.W = conv2_w; g2.ldw = 9 * cpad; g2.M = (int)r2; g2.N = cpad; g2.K = 9 * cpad; g2.bias = conv2_b;
+    g2.act = ACT_GELU_TANH; g2.out_lo = d_c2.ptr; g2.ld_out_lo = cpad; gemm(g2);
+    hipLaunchKernelGGL(qw_im2col_cl_kernel<T>, dim3((unsigned)r3), dim3(256), 0, stream, d_c2.as<T>(), cpad, 25, 32, 13, 16, rpw, cpw, t_tok, col);
+    GemmArgs g3; g3.A = col; g3.lda = 9 * cpad; g3.W = conv3_w; g3.ldw = 9 * cpad; g3.M = (int)r3; g3.N = cpad; g3.K = 9 * cpad; g3.bias = conv3_b;
+    g3.act = ACT_GELU_TANH; g3.out_lo = d_c3.ptr; g3.ld_out_lo = cpad; gemm(g3);
+    // conv_out over rows (window slot) x [f3][channel], + sinusoidal positions of the slot's token index (:867-872)
+    GemmArgs g4; g4.A = d_c3.ptr; g4.lda = 16 * cpad; g4.W = conv_out_w; g4.ldw = 16 * cpad; g4.M = rows_e; g4.N = de; g4.K = 16 * cpad;
+    g4.add2 = enc_pos; g4.ld_add2 = de; g4.add2_rows = d_pos_rows; g4.out_f32 = d_xa.as<float>(); g4.ld_out_f32 = de; gemm(g4);
+  }
+  if (taps_enabled) save_tap("stem", d_xa.ptr, rows_e, de, de, 4);
+  // ---- encoder layers over windows (:885-917)
+  float* xa = d_xa.as<float>();
+  float* xb = d_xb.as<float>();
+  T* h = d_h.as<T>();
+  T* qk = d_qk.as<T>();
+  T* vt = d_vt.as<T>();
+  T* ctx = d_ctx.as<T>();
+  T* ffn = d_ffn.as<T>();
+  for (int i = 0; i < c.n_enc_layers; ++i) {
+    const QwEncLayer& L = enc[i];
+    { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(xa, de, rows_e, de, nullptr, nullptr, 1e-5f, h, de, de, stream); }
+    { ProfScope ps(prof, "gemm_qkv", stream);
+      GemmArgs g; g.A = h; g.lda = de; g.W = L.wqkv; g.ldw = de; g.M = rows_e; g.N = 2 * de; g.K = de; g.bias = L.bqkv; g.out_lo = qk; g.ld_out_lo = 2 * de; gemm(g);
+      GemmArgs gv; gv.A = h; gv.lda = de; gv.W = (const T*)L.wqkv + (size_t)2 * de * de; gv.ldw = de; gv.M = rows_e; gv.N = de; gv.K = de;
+      gv.bias = L.bqkv + 2 * de; gv.out_t = vt; gv.ld_out_t = Me; gemm(gv); }
+    { ProfScope ps(prof, "attention", stream);
+      AttnArgs aa; aa.q = qk; aa.k = qk + de; aa.ld_qk = 2 * de; aa.vt = vt; aa.ld_vt = Me; aa.ctx = ctx; aa.ld_ctx = de; aa.plan = dwp;
+      aa.qb_utt = d_qb_utt; aa.qb_q0 = d_qb_q0; aa.n_qblocks = n_qb; aa.n_heads = H; aa.qt = att_qt; aa.n_waves = att_nw; aa.max_T = max_T;
+      if (precision == ASR_PRECISION_BF16) launch_attention_bf16_hd64(aa, stream); else launch_attention_f32(aa, 64, stream); }
+    { ProfScope ps(prof, "gemm_out", stream);
+      GemmArgs g; g.A = ctx; g.lda = de; g.W = L.wo; g.ldw = de; g.M = rows_e; g.N = de; g.K = de; g.bias = L.bo; g.add = xa; g.ld_add = de;
+      g.out_f32 = xb; g.ld_out_f32 = de; gemm(g); }
+    { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(xb, de, rows_e, de, nullptr, nullptr, 1e-5f, h, de, de, stream); }
+    { ProfScope ps(prof, "gemm_ffn1", stream);
+      GemmArgs g; g.A = h; g.lda = de; g.W = L.w1; g.ldw = de; g.M = rows_e; g.N = dff; g.K = de; g.bias = L.b1; g.act = ACT_GELU_TANH; g.out_lo = ffn;
+      g.ld_out_lo = dff; gemm(g); }
+    { ProfScope ps(prof, "gemm_ffn2", stream);
+      GemmArgs g; g.A = ffn; g.lda = dff; g.W = L.w2; g.ldw = dff; g.M = rows_e; g.N = de; g.K = dff; g.bias = L.b2; g.add = xb; g.ld_add = de;
+      g.out_f32 = xa; g.ld_out_f32 = de; gemm(g); }
+  }
+  { ProfScope ps(prof, "proj", stream);
+    launch_layernorm<T>(xa, de, rows_e, de, nullptr, nullptr, 1e-5f, h, de, de, stream);                  // ln_post, affine folded into proj1
+    GemmArgs g; g.A = h; g.lda = de; g.W = proj1_w; g.ldw = de; g.M = rows_e; g.N = de; g.K = de; g.bias = proj1_b; g.act = ACT_GELU_TANH; g.out_lo = ctx;
+    g.ld_out_lo = de; gemm(g);
+    GemmArgs g2; g2.A = ctx; g2.lda = de; g2.W = proj2_w; g2.ldw = de; g2.M = rows_e; g2.N = d; g2.K = de; g2.bias = proj2_b; g2.out_f32 = d_aud_out.as<float>();
+    g2.ld_out_f32 = d; gemm(g2); }
+  if (taps_enabled) save_tap("audio_hidden", d_aud_out.ptr, rows_e, d, d, 4);
+  // ---- decoder prefill over the assembled prompts
+  const int KV = c.n_kv_heads, hd = c.d_head, Hq = c.n_heads, I = c.d_ffn, qkvn = (Hq + 2 * KV) * hd, S = c.max_seq_len;
+  batch = B;
+  seq_len.assign(ids_len.begin(), ids_len.end());
+  d_kc.reserve((size_t)c.n_layers * B * KV * S * hd * eT, stream);
+  d_vc.reserve((size_t)c.n_layers * B * KV * S * hd * eT, stream);
+  d_hist.reserve((size_t)std::max(B, 64) * 4, stream);
+  HIP_CHECK(hipMemsetAsync(d_hist.ptr, 0, (size_t)B * 4, stream));
+  const int Mmax = std::max(Md, (int)pad_rows(B));
+  d_x.reserve((size_t)Mmax * d * 4, stream);
+  d_x2.reserve((size_t)Mmax * d * 4, stream);
+  d_dh.reserve((size_t)Mmax * d * eT, stream);
+  d_qkv.reserve((size_t)Mmax * qkvn * 4, stream);
+  d_q.reserve((size_t)Mmax * Hq * hd * eT, stream);
+  d_dctx.reserve((size_t)Mmax * Hq * hd * eT, stream);
+  d_gu.reserve((size_t)Mmax * 2 * I * eT, stream);
+  d_act.reserve((size_t)Mmax * I * eT, stream);
+  d_last.reserve(pad_rows(B) * d * eT, stream);
+  d_logits.reserve(pad_rows(B) * (size_t)vpad * 4, stream);
+  d_next.reserve((size_t)std::max(B, 64) * 4, stream);
+  { ProfScope ps(prof, "dec_embed", stream);
+    hipLaunchKernelGGL(qw_gather_prompt_kernel<T>, dim3(Md), dim3(256), 0, stream, d_src, (const T*)embed, d_aud_out.as<float>(), d, PAD, d_x.as<float>()); }
+  if (taps_enabled) save_tap("prompt", d_x.ptr, rows_d, d, d, 4);
+  decoder_pass<T>(ddp, d_row_seq, d_row_t, d_last_rows, rows_d, B);
+  // step plan for the decode calls that follow: one row per sequence
+  {
+    const int Mb = round_up(B, 128);
+    const size_t sbytes = sizeof(UttPlan) * B + 4 * 3 * (size_t)Mb;
+    unsigned char* sh = hp + plan_bytes;                 // tail of the pinned blob (reserved below)
+    UttPlan* sp = (UttPlan*)sh;
+    int32_t* s_seq = (int32_t*)(sp + B);
+    int32_t* s_t = s_seq + Mb;
+    int32_t* s_last = s_t + Mb;
+    for (int r = 0; r < Mb; ++r) { s_seq[r] = r < B ? r : -1; s_t[r] = 0; s_last[r] = r < B ? r : 0; }
+    for (int b = 0; b < B; ++b) { UttPlan p{}; p.T = 1; p.n_lfr = 1; p.row_off = b; sp[b] = p; }
+    d_stepplan.reserve(sbytes, stream);
+    HIP_CHECK(hipMemcpyAsync(d_stepplan.ptr, sh, sbytes, hipMemcpyHostToDevice, stream));
+  }
+  finish<T>(B, next_out, logits_out, true);
+}
+
+template <typename T>
+void QwSession::step(const int32_t* ids_host, int32_t* next_out, float* logits_out) {
+  const auto& c = cfg;
+  ASR_REQUIRE(batch > 0, "qwen_decode: prefill first");
+  HIP_CHECK(hipSetDevice(device));
+  const int B = batch, d = c.d_model, Mb = round_up(B, 128);
+  for (int b = 0; b < B; ++b) ASR_REQUIRE(seq_len[b] + 1 <= c.max_seq_len, "qwen_decode: sequence %d is at max_seq_len %d", b, c.max_seq_len);
+  if (ids_host) {
+    int32_t* st = (int32_t*)pinned(h_ids, h_ids_cap, (size_t)B * 4);
+    for (int b = 0; b < B; ++b) {
+      ASR_REQUIRE(ids_host[b] >= 0 && ids_host[b] < c.vocab, "qwen_decode: token id %d out of range", ids_host[b]);
+      st[b] = ids_host[b];
+    }
+    HIP_CHECK(hipMemcpyAsync(d_next.ptr, st, (size_t)B * 4, hipMemcpyHostToDevice, stream));
+  }
+  // the step plan (one row per sequence) was uploaded by prefill
+  const UttPlan* dsp = d_stepplan.as<UttPlan>();
+  const int32_t* d_row_seq = (const int32_t*)(dsp + B);
+  const int32_t* d_row_t = d_row_seq + Mb;
+  const int32_t* d_last = d_row_t + Mb;
+  { ProfScope ps(prof, "dec_embed", stream);
+    hipLaunchKernelGGL(qw_gather_prompt_kernel<T>, dim3(B), dim3(256), 0, stream, (const int32_t*)d_next.ptr, (const T*)embed, (const float*)nullptr, d,
+                       INT32_MIN, d_x.as<float>()); }
+  decoder_pass<T>(dsp, d_row_seq, d_row_t, d_last, B, B);
+  for (int b = 0; b < B; ++b) ++seq_len[b];
+  finish<T>(B, next_out, logits_out, ids_host != nullptr);
+}
+
+}  // namespace
+
+extern "C" int asr_qwen_create(const asr_qwen_config* cfg, const void* arena, size_t arena_bytes, int arena_mem, int device_id, int precision,
+                               asr_session** out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(cfg && arena && out, "qwen_create: null argument");
+    ASR_REQUIRE(precision == ASR_PRECISION_BF16 || precision == ASR_PRECISION_F32, "qwen_create: bad precision %d", precision);
+    asr_require_device(device_id);
+    QwSession* s = new QwSession();
+    try {
+      s->kind = 5;
+      s->device = device_id;
+      s->precision = precision;
+      s->cfg = *cfg;
+      HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+      s->own_stream = true;
+      s->arena.load(arena, arena_bytes, arena_mem, s->stream);
+      s->init();
+    } catch (...) {
+      delete s;
+      throw;
+    }
+    *out = s;
+  });
+}
+
+extern "C" int asr_qwen_prefill(asr_session* s, const float* audio, int audio_mem, const int64_t* audio_offsets, int batch, const int32_t* pre_ids,
+                                const int32_t* pre_offsets, const int32_t* post_ids, const int32_t* post_offsets, int32_t* next_ids_out,
+                                float* logits_out, int32_t* ids_len_out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 5, "qwen_prefill: not a Qwen3-ASR session");
+    QwSession* q = static_cast<QwSession*>(s);
+    if (q->precision == ASR_PRECISION_BF16)
+      q->prefill<bf16_t>(audio, audio_mem, audio_offsets, batch, pre_ids, pre_offsets, post_ids, post_offsets, next_ids_out, logits_out, ids_len_out);
+    else
+      q->prefill<float>(audio, audio_mem, audio_offsets, batch, pre_ids, pre_offsets, post_ids, post_offsets, next_ids_out, logits_out, ids_len_out);
+  });
+}
+
+extern "C" int asr_qwen_decode(asr_session* s, const int32_t* ids, int32_t* next_ids_out, float* logits_out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 5, "qwen_decode: not a Qwen3-ASR session");
+    QwSession* q = static_cast<QwSession*>(s);
+    if (q->precision == ASR_PRECISION_BF16) q->step<bf16_t>(ids, next_ids_out, logits_out);
+    else q->step<float>(ids, next_ids_out, logits_out);
+  });
+}
+
+extern "C" int asr_qwen_generate(asr_session* s, int max_new, const int32_t* stop_ids, int n_stop, int32_t* tokens_out, int32_t* n_out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 5 && tokens_out && n_out && max_new >= 1 && (n_stop == 0 || stop_ids), "qwen_generate: bad argument");
+    QwSession* q = static_cast<QwSession*>(s);
+    ASR_REQUIRE(q->batch > 0, "qwen_generate: prefill first");
+    const int B = q->batch;
+    std::vector<int32_t> cur(B);
+    HIP_CHECK(hipSetDevice(q->device));
+    HIP_CHECK(hipMemcpyAsync(cur.data(), q->d_next.ptr, (size_t)B * 4, hipMemcpyDeviceToHost, q->stream));
+    HIP_CHECK(hipStreamSynchronize(q->stream));
+    std::vector<char> done(B, 0);
+    for (int b = 0; b < B; ++b) n_out[b] = 0;
+    auto is_stop = [&](int32_t t) { for (int i = 0; i < n_stop; ++i) if (stop_ids[i] == t) return true; return false; };
+    for (int t = 0; t < max_new; ++t) {
+      bool all_done = true, room = true;
+      for (int b = 0; b < B; ++b) {
+        if (!done[b]) {
+          if (is_stop(cur[b])) done[b] = 1;                      // a stop token ends the sequence and is not emitted
+          else tokens_out[(size_t)b * max_new + n_out[b]++] = cur[b];
+        }
+        all_done = all_done && done[b];
+        room = room && q->seq_len[b] + 1 <= q->cfg.max_seq_len;
+      }
+      if (all_done || t + 1 == max_new || !room) break;
+      if (q->precision == ASR_PRECISION_BF16) q->step<bf16_t>(nullptr, cur.data(), nullptr);
+      else q->step<float>(nullptr, cur.data(), nullptr);
+    }
+  });
+}

@@ -440,6 +440,106 @@ class ParaformerStreamSession(_Session):
         return [tok[i, :num[i]].copy() for i in range(sid.size)]
 
 
+# =============================================================================== Qwen3-ASR
+class QwenAsrSession(_Session):
+    """HIP replacement of the merged Qwen3-ASR graphs (audio encoder + prompt assembly + Qwen3 decoder prefill / decode + arg-max;
+    Qwen_ASR/Inference_Qwen_ASR_ONNX.py:424-760 drives them)."""
+
+    def __init__(self, cfg, arena, precision: int = PRECISION_BF16, device_id: int = 0):
+        super().__init__()
+        self.cfg, self.precision, self.device_id = cfg, precision, device_id
+        c = _lib.QwenConfigC()
+        for f in ("sample_rate", "n_mels", "nfft", "hop_length", "enc_d", "enc_heads", "enc_ffn", "n_enc_layers", "conv_channels", "n_window",
+                  "n_window_infer", "max_source_positions", "d_model", "n_heads", "n_kv_heads", "d_head", "d_ffn", "n_layers", "vocab",
+                  "max_seq_len", "max_audio_len", "rms_eps", "rope_theta"):
+            setattr(c, f, getattr(cfg, f))
+        self._cfg_c = c
+        blob = np.ascontiguousarray(arena, dtype=np.uint8)
+        _lib.check(_lib.load().asr_qwen_create(C.byref(c), blob.ctypes.data_as(C.c_void_p), blob.nbytes, MEM_HOST, device_id, precision,
+                                               C.byref(self._h)))
+        self.batch = 0
+
+    @classmethod
+    def from_checkpoint(cls, cfg, ck, precision=PRECISION_BF16, device_id=0):
+        from .arena import build_qwen_asr_arena
+        return cls(cfg, build_qwen_asr_arena(cfg, ck, precision), precision, device_id)
+
+    @staticmethod
+    def _ragged(seqs, B):
+        seqs = [np.asarray(x, dtype=np.int32).reshape(-1) for x in seqs]
+        if len(seqs) == 1 and B > 1:
+            seqs = seqs * B
+        if len(seqs) != B:
+            raise ValueError(f"{len(seqs)} prompts for a batch of {B}")
+        offs = np.zeros(B + 1, dtype=np.int32)
+        offs[1:] = np.cumsum([x.size for x in seqs])
+        flat = np.concatenate(seqs) if offs[-1] else np.zeros(1, dtype=np.int32)
+        return np.ascontiguousarray(flat, dtype=np.int32), offs
+
+    def prefill_packed(self, audio, offsets, pre_ids, post_ids, want_logits: bool = True, audio_device_ptr: int | None = None):
+        """pre_ids / post_ids: one id list per utterance (or one shared list): the prompt is [pre | audio embeddings | post].
+        -> (next_ids (B,), logits (B, vocab) | None, ids_len (B,))"""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        B = offsets.size - 1
+        pre, pre_off = self._ragged(pre_ids, B)
+        post, post_off = self._ragged(post_ids, B)
+        nxt = np.zeros(B, dtype=np.int32)
+        ids_len = np.zeros(B, dtype=np.int32)
+        logits = np.empty((B, self.cfg.vocab), dtype=np.float32) if want_logits else None
+        if audio_device_ptr is not None:
+            ap, mem = C.c_void_p(audio_device_ptr), MEM_DEVICE
+        else:
+            audio = _f32(audio).reshape(-1)
+            ap, mem = audio.ctypes.data_as(C.c_void_p), MEM_HOST
+        _lib.check(_lib.load().asr_qwen_prefill(self._h, ap, mem, offsets.ctypes.data_as(C.POINTER(C.c_int64)), B, _ip(pre), _ip(pre_off),
+                                                _ip(post), _ip(post_off), _ip(nxt), _fp(logits), _ip(ids_len)))
+        self.batch = B
+        return nxt, logits, ids_len
+
+    def prefill(self, audios: Sequence[np.ndarray], pre_ids, post_ids, want_logits: bool = True):
+        flat = [_f32(a).reshape(-1) for a in audios]
+        offs = np.zeros(len(flat) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([a.size for a in flat])
+        return self.prefill_packed(np.concatenate(flat), offs, pre_ids, post_ids, want_logits)
+
+    def decode(self, ids=None, want_logits: bool = False, sync: bool = True):
+        nxt = np.zeros(self.batch, dtype=np.int32) if sync else None
+        logits = np.empty((self.batch, self.cfg.vocab), dtype=np.float32) if want_logits else None
+        idp = _ip(np.ascontiguousarray(ids, dtype=np.int32)) if ids is not None else None
+        _lib.check(_lib.load().asr_qwen_decode(self._h, idp, _ip(nxt) if nxt is not None else None, _fp(logits)))
+        return nxt, logits
+
+    def audio_tokens(self, n_samples: int) -> int:
+        """_get_feat_extract_output_lengths (Export_Qwen_ASR.py:519-527) of a clip's mel frames."""
+        n = int(n_samples) // self.cfg.hop_length
+        f = n % self.cfg.chunk
+        for _ in range(3):
+            f = (max(f - 1, 0) // 2 + 1) if f > 0 else 0
+        return f + (n // self.cfg.chunk) * 13
+
+    def audio_hidden(self, n_samples: Sequence[int]):
+        """Debug: per-utterance audio embeddings (tokens, d_model) from the 'audio_hidden' tap (rows live in window slots)."""
+        cfg = self.cfg
+        raw = self.tap("audio_hidden", dtype=np.float32)
+        cpw = cfg.chunks_per_window
+        rpw = (cpw * 13 + 15) // 16 * 16
+        out, win = [], 0
+        for n in n_samples:
+            frames = int(n) // cfg.hop_length
+            n_win = ((frames + cfg.chunk - 1) // cfg.chunk + cpw - 1) // cpw
+            rows = raw[win * rpw:(win + n_win) * rpw].reshape(n_win, rpw, -1)[:, :cpw * 13].reshape(n_win * cpw * 13, -1)
+            out.append(rows[:self.audio_tokens(n)].copy())
+            win += n_win
+        return out
+
+    def generate(self, max_new: int, stop_ids=()):
+        tok = np.zeros((self.batch, max_new), dtype=np.int32)
+        n = np.zeros(self.batch, dtype=np.int32)
+        stop = np.ascontiguousarray(list(stop_ids), dtype=np.int32)
+        _lib.check(_lib.load().asr_qwen_generate(self._h, max_new, _ip(stop) if stop.size else None, stop.size, _ip(tok), _ip(n)))
+        return [tok[b, :n[b]].copy() for b in range(self.batch)]
+
+
 def load_session(path: str, device_id: int = 0):
     """Open an `.asrmodel` bundle (tools/convert_checkpoint.py, export_*) as the matching native session."""
     from . import config as cfgm

@@ -175,6 +175,38 @@ int asr_whisper_set_sampling(asr_session* s, int enable, float temperature, int 
 /* parity hook: the uniforms of the NEXT prefill / decode step, host [batch][top_k] (count = batch * top_k); consumed once. */
 int asr_whisper_set_sampling_noise(asr_session* s, const float* uniforms, int count);
 
+/* ------------------------------------------------------------------ Qwen3-ASR (audio encoder + Qwen3 decoder with KV cache)
+ * Replaces the merged graphs Qwen_ASR prefill_greedy / decode_greedy and the Embed graph (Qwen_ASR/Shared_Merged.py; I/O planner
+ * Qwen_ASR/Inference_Qwen_ASR_ONNX.py:330-366), i.e. STFT_Process + QWEN3_ASR_ENCODER.forward (Export_Qwen_ASR.py:850-927),
+ * CONCAT_EMBED (:1428-1435), ROTARY_MASK_PREFILL / _DECODE (:933-1028), DECODER_MAIN.forward (:1265-1336) and the ARGMAX head.
+ * The reference hands 2 x n_layers KV tensors through Python per token (Inference_Qwen_ASR_ONNX.py:700-712); here the cache is
+ * session state appended in place, and the prompt embeddings (query_embed / language_tail_embed inputs) are gathered on the
+ * device from token ids. Batch B = independent utterances with their own prompts (the reference is batch 1). */
+typedef struct asr_qwen_config {
+  int32_t sample_rate, n_mels, nfft, hop_length;
+  int32_t enc_d, enc_heads, enc_ffn, n_enc_layers, conv_channels, n_window, n_window_infer, max_source_positions;
+  int32_t d_model, n_heads, n_kv_heads, d_head, d_ffn, n_layers, vocab, max_seq_len, max_audio_len;
+  float rms_eps, rope_theta;
+  int32_t reserved[9];
+} asr_qwen_config;
+
+int asr_qwen_create(const asr_qwen_config* cfg, const void* arena, size_t arena_bytes, int arena_mem, int device_id, int precision,
+                    asr_session** out);
+/* One call = the reference's prefill launch (:640-668): audio encoding, prompt assembly, rotary / causal mask, decoder prefill,
+ * first-token selection. Sequence b's prompt is [pre_ids[pre_offsets[b] : pre_offsets[b+1]] | audio embeddings of utterance b |
+ * post_ids[post_offsets[b] : post_offsets[b+1]]] -- pre = head + query + suffix ids, post = tail (+ language tail) ids
+ * (:923-927, CONCAT_EMBED). next_ids_out (host B, nullable) = arg-max of the last position; logits_out (host [B][vocab],
+ * nullable); ids_len_out (host B, nullable) = prompt length = the reference's kv_seq_len output (:672). Resets the KV cache. */
+int asr_qwen_prefill(asr_session* s, const float* audio, int audio_mem, const int64_t* audio_offsets, int batch, const int32_t* pre_ids,
+                     const int32_t* pre_offsets, const int32_t* post_ids, const int32_t* post_offsets, int32_t* next_ids_out, float* logits_out,
+                     int32_t* ids_len_out);
+/* one position per sequence (Embed + decode_greedy, :690-716). ids: host [B], or NULL to feed the device-resident arg-max of the
+ * previous call; next_ids_out / logits_out nullable (ids NULL and both outputs NULL => asynchronous step). */
+int asr_qwen_decode(asr_session* s, const int32_t* ids, int32_t* next_ids_out, float* logits_out);
+/* greedy continuation after a prefill (:687-728): tokens_out host [B][max_new], n_out host [B]; a sequence ends at the first id in
+ * stop_ids (not emitted) or when the cache is full. */
+int asr_qwen_generate(asr_session* s, int max_new, const int32_t* stop_ids, int n_stop, int32_t* tokens_out, int32_t* n_out);
+
 /* ------------------------------------------------------------------ device buffers
  * Backing store of the shim's OrtValue (OrtValue.ortvalue_from_numpy / update_inplace / numpy,
  * SenseVoice/Inference_SenseVoice_ONNX.py:280-299): update_inplace is an H2D copy into the same

@@ -1,0 +1,109 @@
+"""GPU parity: the HIP Qwen3-ASR path (log-mel, Conv2d chunk stem, windowed encoder, prompt assembly, Qwen3 decoder with an
+in-place KV cache, arg-max) through the C ABI vs goldens minted from the reference's classes and vs the oracle."""
+import numpy as np
+import pytest
+
+from conftest import sub
+from helpers import golden_cases, load_golden
+from oracle.qwen_asr_oracle import QwenAsrOracle
+from test_oracle_qwen_asr import qwen_setup, unit_audio
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = 0, 1
+TOL_F32 = 1e-3
+
+
+def _prompts(g, cases):
+    head, tail, suffix = g["head_ids"].tolist(), g["tail_ids"].tolist(), g["suffix_ids"].tolist()
+    pre = [head + c["query_ids"].tolist() + suffix for c in cases]
+    post = [tail + c["language_tail_ids"].tolist() for c in cases]
+    return pre, post
+
+
+def _stepwise(sess, audios, pre, post, n_new):
+    nxt, logits, ids_len = sess.prefill(audios, pre, post)
+    steps_logits, steps_ids = [logits], [nxt]
+    for _ in range(n_new - 1):
+        nxt, logits = sess.decode(None, want_logits=True)          # ids fed back on the device
+        steps_logits.append(logits)
+        steps_ids.append(nxt)
+    return np.stack(steps_logits, 1), np.stack(steps_ids, 1), ids_len
+
+
+@pytest.mark.parametrize("order", [(0, 1, 2, 3), (2, 3, 1), (3,)])
+def test_f32_mode_matches_reference_goldens(order):
+    """Ragged batches (different clip lengths, prompts and language tails per sequence) against the reference's own outputs."""
+    g = load_golden("qwen_asr_tiny")
+    cfg, ck = qwen_setup(g)
+    sess = sub("engine").QwenAsrSession.from_checkpoint(cfg, ck, precision=F32)
+    allc = [c for _, c in golden_cases(g)]
+    cases = [allc[i] for i in order]
+    audios = [unit_audio(c["audio_seed"], c["n_samples"]) for c in cases]
+    pre, post = _prompts(g, cases)
+    sess.taps(True)
+    got_logits, got_ids, ids_len = _stepwise(sess, audios, pre, post, int(g["n_new"]))
+    assert ids_len.tolist() == [int(c["ids_len"]) for c in cases]
+    sess.taps(True)
+    sess.prefill(audios, pre, post)
+    for b, (h, c) in enumerate(zip(sess.audio_hidden([int(c["n_samples"]) for c in cases]), cases)):
+        assert h.shape == c["audio_hidden"].shape, b
+        assert np.abs(h - c["audio_hidden"]).max() < TOL_F32, b
+    for b, c in enumerate(cases):
+        assert np.abs(got_logits[b] - c["logits"]).max() < TOL_F32, b
+        if (c["margin"] > 2 * TOL_F32).all():
+            assert np.array_equal(got_ids[b], c["token_ids"]), b
+
+
+def test_generate_equals_stepwise_and_oracle_bf16():
+    """bf16 mode: generate() == explicit prefill / decode; logits stay within the bf16 budget of the oracle; host-fed ids == device-fed."""
+    g = load_golden("qwen_asr_tiny")
+    cfg, ck = qwen_setup(g)
+    sess = sub("engine").QwenAsrSession.from_checkpoint(cfg, ck, precision=BF16)
+    cases = [c for _, c in golden_cases(g)]
+    audios = [unit_audio(c["audio_seed"], c["n_samples"]) for c in cases]
+    pre, post = _prompts(g, cases)
+    n_new = 8
+    # teacher-forced with the reference's ids (random weights have small margins; a flipped arg-max would change the later steps)
+    forced = np.stack([c["token_ids"] for c in cases])
+    _, lg, _ = sess.prefill(audios, pre, post)
+    steps = [lg]
+    for t in range(forced.shape[1] - 1):
+        steps.append(sess.decode(forced[:, t], want_logits=True)[1])
+    for b, c in enumerate(cases):
+        ref = c["logits"]
+        assert np.abs(np.stack(steps, 1)[b] - ref).max() < 0.06 * np.abs(ref).max() + 0.05, b
+    logits, ids, _ = _stepwise(sess, audios, pre, post, n_new)
+    sess.prefill(audios, pre, post, want_logits=False)
+    gen = sess.generate(n_new, stop_ids=())
+    for b in range(len(cases)):
+        assert np.array_equal(gen[b], ids[b]), b
+    # a stop id ends its own sequence only, and is not emitted
+    stop = int(ids[0, 2])
+    sess.prefill(audios, pre, post, want_logits=False)
+    gen = sess.generate(n_new, stop_ids=(stop,))
+    for b in range(len(cases)):
+        k = np.flatnonzero(ids[b] == stop)
+        want = ids[b, :k[0]] if k.size else ids[b]
+        assert np.array_equal(gen[b], want), b
+    # host-fed ids
+    nxt, _, _ = sess.prefill(audios, pre, post, want_logits=False)
+    for t in range(1, 4):
+        nxt, _ = sess.decode(nxt)
+        assert np.array_equal(nxt, ids[:, t])
+
+
+def test_bad_arguments_fail_loudly():
+    g = load_golden("qwen_asr_tiny")
+    cfg, ck = qwen_setup(g)
+    sess = sub("engine").QwenAsrSession.from_checkpoint(cfg, ck, precision=F32)
+    a = unit_audio(1, 16000)
+    with pytest.raises(Exception, match="prefill first"):
+        sess.batch = 1
+        sess.decode(None)
+    with pytest.raises(Exception, match="out of range"):
+        sess.prefill([a], [[cfg.vocab + 5]], [[1]])
+    with pytest.raises(Exception, match="n_fft"):
+        sess.prefill([a[:100]], [[1]], [[1]])
+    with pytest.raises(Exception, match="max_seq_len"):
+        sess.prefill([a], [[1] * cfg.max_seq_len], [[1]])

@@ -230,3 +230,10 @@ def qwen_asr_0p6b() -> QwenAsrConfig:
 def qwen_asr_tiny() -> QwenAsrConfig:
     return QwenAsrConfig(enc_d=128, enc_heads=2, enc_ffn=256, n_enc_layers=2, conv_channels=32, n_window_infer=400, d_model=128, n_heads=2,
                          n_kv_heads=1, d_head=128, d_ffn=256, n_layers=2, vocab=600, max_seq_len=512)
+
+
+def qwen_asr_mid() -> QwenAsrConfig:
+    """Geometry that reaches the production kernels' paths in tests: 8-chunk attention windows, two kv heads with a GQA group of 2,
+    widths the weight-streaming GEMM's fused RMSNorm accepts (d_model % 256 == 0)."""
+    return QwenAsrConfig(enc_d=256, enc_heads=4, enc_ffn=512, n_enc_layers=2, conv_channels=48, n_window_infer=800, d_model=256, n_heads=4,
+                         n_kv_heads=2, d_head=128, d_ffn=512, n_layers=3, vocab=1000, max_seq_len=512)

@@ -29,6 +29,7 @@ struct GemmArgs {
   // normalises the few activation rows itself (two-pass statistics in f32), so no separate LayerNorm launch and no bf16
   // round trip of the normalised rows through HBM. gamma/beta nullable (affine folded into W, Export_Whisper.py:215-225).
   const float* ln_x = nullptr; int ld_ln_x = 0; const float* ln_gamma = nullptr; const float* ln_beta = nullptr; float ln_eps = 1e-5f;
+  int ln_rms = 0;   // 1: RMSNorm instead (no mean subtraction; Qwen3 decoder, weight folded into W)
   // LayerNorm evaluated inside the GEMM (144-row-tile kernel only; K must span the whole normalised row): A holds the RAW rows
   // x in bf16, row statistics over the first ln_dim columns are accumulated from the LDS tiles during the MFMA loop and
   // C = rstd (x W^T - mean ln_colsum) + bias. Needs the LayerNorm affine folded into W / bias; ln_colsum[n] = sum_k W[n][k].

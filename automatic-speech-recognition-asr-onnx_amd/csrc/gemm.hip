@@ -563,7 +563,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny(const GemmArgs g) {
         float s1 = 0.f;
 #pragma unroll
         for (int q = 0; q < KV; ++q) s1 += (v[rr][q].x + v[rr][q].y) + (v[rr][q].z + v[rr][q].w);
-        const float mean = wave_sum(s1) / (float)g.K;
+        const float mean = g.ln_rms ? 0.f : wave_sum(s1) / (float)g.K;
         float s2 = 0.f;
 #pragma unroll
         for (int q = 0; q < KV; ++q) {

@@ -142,6 +142,9 @@ struct AttnArgs {
   int qt = 0, n_waves = 4, max_T = 0;
   // cross-attention: queries follow q_plan (row_off / T of the query rows), keys / values follow plan; null => self-attention
   const UttPlan* q_plan = nullptr;
+  // bf16 kernels: causal = 1 masks keys > the query's own index (decoder prefill); kv_group > 1 = grouped-query attention,
+  // q head h reads K / V head h / kv_group
+  int causal = 0, kv_group = 1;
 };
 // query-block geometry for the longest utterance of a batch: rows per block = 16 * qt * n_waves
 void attention_geometry(int max_T, int head_dim, int* qt, int* n_waves);

@@ -259,11 +259,14 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(const AttnArgs a, int n_
     for (int ks = 0; ks < HD / 32; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
   }
 
-  const bf16_t* kbase = reinterpret_cast<const bf16_t*>(a.k) + h * HD;
-  const bf16_t* vbase = reinterpret_cast<const bf16_t*>(a.vt) + (size_t)h * HD * a.ld_vt;
+  const int hk = h / a.kv_group;
+  const bf16_t* kbase = reinterpret_cast<const bf16_t*>(a.k) + hk * HD;
+  const bf16_t* vbase = reinterpret_cast<const bf16_t*>(a.vt) + (size_t)hk * HD * a.ld_vt;
+  // causal: no query of this block sees keys past the block's last row
+  const int Tk = a.causal ? min(T, q_base + 16 * QT * NW) : T;
 
-  for (int kv0 = 0; kv0 < T; kv0 += CHUNK) {
-    const int nkeys = min(CHUNK, (T - kv0 + 31) & ~31);       // keys of this chunk that are ever read (32-key sub-tiles)
+  for (int kv0 = 0; kv0 < Tk; kv0 += CHUNK) {
+    const int nkeys = min(CHUNK, (Tk - kv0 + 31) & ~31);       // keys of this chunk that are ever read (32-key sub-tiles)
     __syncthreads();                          // all waves finished reading the previous chunk
     for (int ii = wave; ii * K_RPI < nkeys; ii += NW) {
       const int key = ii * K_RPI + lane / SLOTS;
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(const AttnArgs a, int n_
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const int key = kb + (r & 3) + ((r >> 2) << 4);
-          if (key >= T) sv[r] = -INFINITY;
+          if (key >= T || (a.causal && key > q_base + (t * NW + wave) * 16 + fq)) sv[r] = -INFINITY;
           mx = fmaxf(mx, sv[r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void qw_qk_rope_kernel(const float* __restrict
                                                          const float* __restrict__ kn, const float* __restrict__ inv_freq, float eps,
                                                          const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_t,
                                                          const int32_t* __restrict__ hist, int rows, T* __restrict__ q_out, T* __restrict__ kc,
-                                                         T* __restrict__ vc, int S_max) {
+                                                         T* __restrict__ vc, int S_max, T* __restrict__ k_rows) {
   constexpr int HD = 128;
   const int heads = n_heads + 2 * n_kv;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -178,6 +178,11 @@ __global__ __launch_bounds__(256) void qw_qk_rope_kernel(const float* __restrict
                         : kc + (((size_t)b * n_kv + (hh - n_heads)) * S_max + pos) * HD;
   Elem<T>::store(dst + lane, y0);
   Elem<T>::store(dst + lane + 64, y1);
+  if (k_rows && hh >= n_heads) {                         // row-major copy of the new keys for the prefill attention kernel
+    T* kr = k_rows + (size_t)row * n_kv * HD + (hh - n_heads) * HD;
+    Elem<T>::store(kr + lane, y0);
+    Elem<T>::store(kr + lane + 64, y1);
+  }
 }
 
 // causal GQA attention over the cache: workgroup = (sequence, q head), 128 threads; query t of the sequence sees keys [0, hist + t]
@@ -229,6 +234,148 @@ __global__ __launch_bounds__(128) void qw_attn_kernel(const T* __restrict__ q, i
   }
 }
 
+// One decode position per sequence, everything between the q|k|v GEMM and the o_proj GEMM in one launch: workgroup = (sequence,
+// kv head), 4 waves. Waves first finish the new position -- per-head RMSNorm + RoPE of k (-> cache), v (-> cache) and of the
+// group's q heads (-> LDS) -- then run soft-max attention of those q heads over the cache: 16 lanes share a key (8 head-dim
+// elements each, one coalesced 256-byte row per 16 lanes), so K and V are read once per kv head and serve the whole GQA group.
+template <typename T, int G>
+__global__ __launch_bounds__(256) void qw_decode_attn_kernel(const float* __restrict__ qkv, int n_heads, int n_kv, const float* __restrict__ qn,
+                                                             const float* __restrict__ kn, const float* __restrict__ inv_freq, float eps,
+                                                             const int32_t* __restrict__ hist, T* __restrict__ kc, T* __restrict__ vc, int S_max,
+                                                             T* __restrict__ ctx) {
+  constexpr int HD = 128;
+  extern __shared__ float qw_dsc[];                      // [G][S_max] scores / probabilities
+  __shared__ float qsh[G][HD];
+  __shared__ float part[4][G][HD];
+  __shared__ float red[4][G];
+  const int b = blockIdx.x, kvh = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pos = hist[b], nk = pos + 1;
+  const int heads = n_heads + 2 * n_kv;
+  T* K = kc + ((size_t)b * n_kv + kvh) * S_max * HD;
+  T* V = vc + ((size_t)b * n_kv + kvh) * S_max * HD;
+  const float* row = qkv + (size_t)b * heads * HD;
+  // ---- the new position: task 0 = k, 1 = v, 2.. = the group's q heads
+  for (int task = wave; task < 2 + G; task += 4) {
+    const int hh = task == 0 ? n_heads + kvh : task == 1 ? n_heads + n_kv + kvh : kvh * G + (task - 2);
+    const float x0 = row[hh * HD + lane], x1 = row[hh * HD + lane + 64];
+    if (task == 1) {
+      Elem<T>::store(V + (size_t)pos * HD + lane, x0);
+      Elem<T>::store(V + (size_t)pos * HD + lane + 64, x1);
+      continue;
+    }
+    const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / (float)HD + eps);
+    const float* w = task == 0 ? kn : qn;
+    const float a0 = x0 * r * w[lane], a1 = x1 * r * w[lane + 64];
+    const float th = (float)pos * inv_freq[lane];
+    const float cs = cosf(th), sn = sinf(th);
+    const float y0 = a0 * cs - a1 * sn, y1 = a1 * cs + a0 * sn;
+    if (task == 0) {
+      Elem<T>::store(K + (size_t)pos * HD + lane, y0);
+      Elem<T>::store(K + (size_t)pos * HD + lane + 64, y1);
+    } else {                                             // through the operand dtype, like the unfused path
+      T t0, t1;
+      Elem<T>::store(&t0, y0);
+      Elem<T>::store(&t1, y1);
+      qsh[task - 2][lane] = Elem<T>::load(&t0);
+      qsh[task - 2][lane + 64] = Elem<T>::load(&t1);
+    }
+  }
+  __syncthreads();
+  // ---- scores: lane group (wave, lane >> 4) takes keys s = 16 i + 4 wave + (lane >> 4); 4 keys in flight per group
+  const int lg = lane >> 4, li = lane & 15, kslot = wave * 4 + lg;
+  float qr[G][8];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qr[g][e] = qsh[g][li * 8 + e];
+  float mx[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) mx[g] = -INFINITY;
+  for (int s0 = kslot; s0 < nk; s0 += 64) {
+    float kv8[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = s0 + 16 * u;
+      if (s < nk) load8<T>(K + (size_t)s * HD + li * 8, kv8[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = s0 + 16 * u;
+      if (s < nk) {                                      // uniform per 16-lane group
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          float acc = 0.0f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc = fmaf(qr[g][e], kv8[u][e], acc);
+          acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64); acc += __shfl_xor(acc, 8, 64);
+          if (li == 0) qw_dsc[g * S_max + s] = acc;
+          mx[g] = fmaxf(mx[g], acc);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float m = wave_max(mx[g]);
+    if (lane == 0) red[wave][g] = m;
+  }
+  __syncthreads();
+  float sum[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    mx[g] = fmaxf(fmaxf(red[0][g], red[1][g]), fmaxf(red[2][g], red[3][g]));
+    sum[g] = 0.0f;
+    for (int s = tid; s < nk; s += 256) { const float e = expf(qw_dsc[g * S_max + s] - mx[g]); qw_dsc[g * S_max + s] = e; sum[g] += e; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float t = wave_sum(sum[g]);
+    if (lane == 0) red[wave][g] = t;
+  }
+  // ---- P V: same key assignment, 8 head-dim columns per lane
+  float acc[G][8];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[g][e] = 0.0f;
+  for (int s0 = kslot; s0 < nk; s0 += 64) {
+    float v8[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = s0 + 16 * u;
+      if (s < nk) load8<T>(V + (size_t)s * HD + li * 8, v8[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = s0 + 16 * u;
+      if (s < nk) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float p = qw_dsc[g * S_max + s];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(p, v8[u][e], acc[g][e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = acc[g][e];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lg == 0) part[wave][g][li * 8 + e] = v;
+    }
+  __syncthreads();
+  for (int i = tid; i < G * HD; i += 256) {
+    const int g = i / HD, e = i - g * HD;
+    const float inv = 1.0f / (red[0][g] + red[1][g] + red[2][g] + red[3][g]);
+    Elem<T>::store(ctx + (size_t)b * n_heads * HD + (kvh * G + g) * HD + e, (part[0][g][e] + part[1][g][e] + part[2][g][e] + part[3][g][e]) * inv);
+  }
+}
+
 template <typename T>
 __global__ void qw_silu_mul_kernel(const T* __restrict__ gu, int I, size_t n, T* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -257,6 +404,13 @@ __global__ void qw_hist_add_kernel(int32_t* __restrict__ hist, const UttPlan* __
 struct QwEncLayer { const void *wqkv, *wo, *w1, *w2; const float *bqkv, *bo, *b1, *b2; };
 struct QwDecLayer { const void *wqkv, *wo, *gate_up, *down; const float *qn, *kn; };
 
+// one decoder pass: the packed rows (T new positions per sequence) and, for the bf16 prefill, the MFMA attention geometry
+struct DecPass {
+  const UttPlan* plan = nullptr; const int32_t *row_seq = nullptr, *row_t = nullptr, *last_rows = nullptr;
+  int rows = 0, B = 0; bool step = false;
+  const int32_t *qb_utt = nullptr, *qb_q0 = nullptr; int n_qb = 0, qt = 0, nw = 0, max_T = 0, ld_vt = 0;
+};
+
 struct QwSession : asr_session {
   asr_qwen_config cfg;
   int vpad = 0, cpad = 0, n_bin_tiles = 0, n_kchunks = 0, chunk = 0, cpw = 0, rpw = 0, t_tok = 13;
@@ -269,7 +423,9 @@ struct QwSession : asr_session {
   int batch = 0;
   std::vector<int> seq_len;                              // positions in the cache per sequence (host mirror)
   DeviceBuffer d_plan, d_audio, d_mel, d_blkmax, d_feat, d_col, d_c1, d_c2, d_c3, d_xa, d_xb, d_h, d_qk, d_vt, d_ctx, d_ffn, d_aud_out;
-  DeviceBuffer d_dplan, d_x, d_x2, d_dh, d_qkv, d_q, d_dctx, d_gu, d_act, d_last, d_logits, d_next, d_kc, d_vc, d_hist, d_stepplan, d_skws, d_skcnt;
+  DeviceBuffer d_dplan, d_x, d_x2, d_dh, d_qkv, d_q, d_dctx, d_gu, d_act, d_last, d_logits, d_next, d_kc, d_vc, d_hist, d_stepplan, d_skws, d_skcnt, d_vt2, d_krows;
+  bool no_fuse = false, use_graph = true;
+  hipGraphExec_t dec_graph = nullptr; uint64_t dec_key = 0, dec_eager_key = 0;
   void* h_plan = nullptr; size_t h_plan_cap = 0;
   void* h_io = nullptr; size_t h_io_cap = 0;
   void* h_ids = nullptr; size_t h_ids_cap = 0;
@@ -277,9 +433,10 @@ struct QwSession : asr_session {
   ~QwSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_feat, &d_col, &d_c1, &d_c2, &d_c3, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx,
                             &d_ffn, &d_aud_out, &d_dplan, &d_x, &d_x2, &d_dh, &d_qkv, &d_q, &d_dctx, &d_gu, &d_act, &d_last, &d_logits, &d_next,
-                            &d_kc, &d_vc, &d_hist, &d_stepplan, &d_skws, &d_skcnt})
+                            &d_kc, &d_vc, &d_hist, &d_stepplan, &d_skws, &d_skcnt, &d_vt2, &d_krows})
       b->release();
     for (auto& kv : taps) kv.second.buf.release();
+    if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
     if (h_plan) (void)hipHostFree(h_plan);
     if (h_io) (void)hipHostFree(h_io);
     if (h_ids) (void)hipHostFree(h_ids);
@@ -305,8 +462,7 @@ struct QwSession : asr_session {
   void init();
   template <typename T> void prefill(const float* audio, int audio_mem, const int64_t* offs, int B, const int32_t* pre_ids, const int32_t* pre_off,
                                      const int32_t* post_ids, const int32_t* post_off, int32_t* next_out, float* logits_out, int32_t* ids_len_out);
-  template <typename T> void decoder_pass(const UttPlan* dplan, const int32_t* row_seq, const int32_t* row_t, const int32_t* last_rows, int rows,
-                                          int B);
+  template <typename T> void decoder_pass(const DecPass& P);
   template <typename T> void step(const int32_t* ids_host, int32_t* next_out, float* logits_out);
   template <typename T> void finish(int B, int32_t* next_out, float* logits_out, bool sync);
 };
@@ -357,11 +513,13 @@ void QwSession::init() {
   }
 }
 
-// one pass of the decoder stack over `rows` packed rows described by `dplan` (T new positions per sequence, appended at hist[b])
+// one pass of the decoder stack over `rows` packed rows described by `plan` (T new positions per sequence, appended at hist[b])
 template <typename T>
-void QwSession::decoder_pass(const UttPlan* dplan, const int32_t* row_seq, const int32_t* row_t, const int32_t* last_rows, int rows, int B) {
+void QwSession::decoder_pass(const DecPass& P) {
   const auto& c = cfg;
   const int d = c.d_model, H = c.n_heads, KV = c.n_kv_heads, hd = c.d_head, I = c.d_ffn, qkvn = (H + 2 * KV) * hd, S = c.max_seq_len;
+  const int rows = P.rows, B = P.B;
+  const bool bf = precision == ASR_PRECISION_BF16;
   float* x = d_x.as<float>();
   float* x2 = d_x2.as<float>();
   T* h = d_dh.as<T>();
@@ -372,27 +530,57 @@ void QwSession::decoder_pass(const UttPlan* dplan, const int32_t* row_seq, const
   T* act = d_act.as<T>();
   const size_t layer_kv = (size_t)B * KV * S * hd;
   const int32_t* hist = d_hist.as<int32_t>();
+  const int G = H / KV;
+  // single-position steps of small batches: the RMSNorm runs inside the weight-streaming GEMM (no launch, no bf16 round trip)
+  const bool rms_in_gemm = P.step && bf && rows <= 64 && d <= 1280 && d % 256 == 0 && !no_fuse;
+  const bool fused_attn = P.step && (G == 1 || G == 2 || G == 4) && !no_fuse;
+  auto rmsnorm = [&](const float* src) {
+    ProfScope ps(prof, "dec_norm", stream);
+    hipLaunchKernelGGL(qw_rmsnorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, stream, src, d, rows, d, (const float*)nullptr, c.rms_eps, h, d, (const int32_t*)nullptr);
+  };
+  auto normed_gemm = [&](const float* src, GemmArgs& g) {          // g = RMSNorm(src) W^T
+    if (rms_in_gemm) { g.ln_x = src; g.ld_ln_x = d; g.ln_eps = c.rms_eps; g.ln_rms = 1; }
+    else { rmsnorm(src); g.A = h; g.lda = d; }
+    ProfScope ps(prof, "dec_gemm", stream);
+    gemm(g);
+  };
   for (int i = 0; i < c.n_layers; ++i) {
     const QwDecLayer& L = dec[i];
     T* kc = d_kc.as<T>() + (size_t)i * layer_kv;
     T* vc = d_vc.as<T>() + (size_t)i * layer_kv;
-    { ProfScope ps(prof, "dec_norm", stream);
-      hipLaunchKernelGGL(qw_rmsnorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, d, rows, d, (const float*)nullptr, c.rms_eps, h, d, (const int32_t*)nullptr); }
-    { ProfScope ps(prof, "dec_gemm", stream);
-      GemmArgs g; g.A = h; g.lda = d; g.W = L.wqkv; g.ldw = d; g.M = rows; g.N = qkvn; g.K = d; g.out_f32 = qkv; g.ld_out_f32 = qkvn; gemm(g); }
-    { ProfScope ps(prof, "dec_rope", stream);
-      const int waves = rows * (H + 2 * KV);
-      hipLaunchKernelGGL(qw_qk_rope_kernel<T>, dim3((waves + 3) / 4), dim3(256), 0, stream, qkv, H, KV, L.qn, L.kn, inv_freq, c.rms_eps, row_seq, row_t,
-                         hist, rows, q, kc, vc, S); }
-    { ProfScope ps(prof, "dec_attn", stream);
-      hipLaunchKernelGGL(qw_attn_kernel<T>, dim3(B, H), dim3(128), (size_t)S * 4, stream, q, H, KV, kc, vc, S, dplan, hist, ctx); }
+    { GemmArgs g; g.W = L.wqkv; g.ldw = d; g.M = rows; g.N = qkvn; g.K = d; g.out_f32 = qkv; g.ld_out_f32 = qkvn; normed_gemm(x, g); }
+    if (fused_attn) {
+      ProfScope ps(prof, "dec_attn", stream);
+      const size_t lds = (size_t)G * S * 4;
+      if (G == 1) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 1>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, inv_freq, c.rms_eps, hist, kc, vc, S, ctx);
+      else if (G == 2) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 2>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, inv_freq, c.rms_eps, hist, kc, vc, S, ctx);
+      else hipLaunchKernelGGL((qw_decode_attn_kernel<T, 4>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, inv_freq, c.rms_eps, hist, kc, vc, S, ctx);
+    } else {
+      const bool mfma_attn = bf && !P.step && P.n_qb > 0;
+      if (mfma_attn) {                                   // V^T for the MFMA attention kernel (the cache gets V from the q|k|v GEMM)
+        ProfScope ps(prof, "dec_gemm", stream);
+        GemmArgs gv; gv.A = h; gv.lda = d; gv.W = (const T*)L.wqkv + (size_t)(H + KV) * hd * d; gv.ldw = d; gv.M = rows; gv.N = KV * hd; gv.K = d;
+        gv.out_t = d_vt2.ptr; gv.ld_out_t = P.ld_vt; gemm(gv);
+      }
+      { ProfScope ps(prof, "dec_rope", stream);
+        const int waves = rows * (H + 2 * KV);
+        hipLaunchKernelGGL(qw_qk_rope_kernel<T>, dim3((waves + 3) / 4), dim3(256), 0, stream, qkv, H, KV, L.qn, L.kn, inv_freq, c.rms_eps, P.row_seq, P.row_t,
+                           hist, rows, q, kc, vc, S, mfma_attn ? d_krows.as<T>() : (T*)nullptr); }
+      ProfScope ps(prof, "dec_attn", stream);
+      if (mfma_attn) {
+        AttnArgs aa; aa.q = q; aa.ld_q = H * hd; aa.k = d_krows.ptr; aa.ld_qk = KV * hd; aa.vt = d_vt2.ptr; aa.ld_vt = P.ld_vt; aa.ctx = ctx; aa.ld_ctx = H * hd;
+        aa.plan = P.plan; aa.qb_utt = P.qb_utt; aa.qb_q0 = P.qb_q0; aa.n_qblocks = P.n_qb; aa.n_heads = H; aa.qt = P.qt; aa.n_waves = P.nw; aa.max_T = P.max_T;
+        aa.causal = 1; aa.kv_group = G;
+        launch_attention_bf16_hd128(aa, stream);
+      } else {
+        hipLaunchKernelGGL(qw_attn_kernel<T>, dim3(B, H), dim3(128), (size_t)S * 4, stream, q, H, KV, kc, vc, S, P.plan, hist, ctx);
+      }
+    }
     { ProfScope ps(prof, "dec_gemm", stream);
       GemmArgs g; g.A = ctx; g.lda = H * hd; g.W = L.wo; g.ldw = H * hd; g.M = rows; g.N = d; g.K = H * hd; g.add = x; g.ld_add = d;
       g.out_f32 = x2; g.ld_out_f32 = d; gemm(g); }
-    { ProfScope ps(prof, "dec_norm", stream);
-      hipLaunchKernelGGL(qw_rmsnorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, stream, x2, d, rows, d, (const float*)nullptr, c.rms_eps, h, d, (const int32_t*)nullptr); }
+    { GemmArgs g; g.W = L.gate_up; g.ldw = d; g.M = rows; g.N = 2 * I; g.K = d; g.out_lo = gu; g.ld_out_lo = 2 * I; normed_gemm(x2, g); }
     { ProfScope ps(prof, "dec_gemm", stream);
-      GemmArgs g; g.A = h; g.lda = d; g.W = L.gate_up; g.ldw = d; g.M = rows; g.N = 2 * I; g.K = d; g.out_lo = gu; g.ld_out_lo = 2 * I; gemm(g);
       const size_t n = (size_t)rows * I;
       hipLaunchKernelGGL(qw_silu_mul_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, gu, I, n, act);
       GemmArgs g2; g2.A = act; g2.lda = I; g2.W = L.down; g2.ldw = I; g2.M = rows; g2.N = d; g2.K = I; g2.add = x2; g2.ld_add = d;
@@ -401,10 +589,10 @@ void QwSession::decoder_pass(const UttPlan* dplan, const int32_t* row_seq, const
   // final RMSNorm (learned weight) of every sequence's last row, lm_head (:1331-1335)
   { ProfScope ps(prof, "dec_logits", stream);
     T* last = d_last.as<T>();
-    hipLaunchKernelGGL(qw_rmsnorm_kernel<T>, dim3((B + 3) / 4), dim3(256), 0, stream, x, d, B, d, final_norm, c.rms_eps, last, d, last_rows);
+    hipLaunchKernelGGL(qw_rmsnorm_kernel<T>, dim3((B + 3) / 4), dim3(256), 0, stream, x, d, B, d, final_norm, c.rms_eps, last, d, P.last_rows);
     GemmArgs g; g.A = last; g.lda = d; g.W = lm_head; g.ldw = d; g.M = B; g.N = vpad; g.K = d; g.out_f32 = d_logits.as<float>(); g.ld_out_f32 = vpad; gemm(g);
     launch_argmax_rows(d_logits.as<float>(), vpad, B, c.vocab, nullptr, d_next.as<int32_t>(), stream); }
-  hipLaunchKernelGGL(qw_hist_add_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_hist.as<int32_t>(), dplan, B);
+  hipLaunchKernelGGL(qw_hist_add_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_hist.as<int32_t>(), P.plan, B);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -481,8 +669,15 @@ void QwSession::prefill(const float* audio, int audio_mem, const int64_t* offs, 
     if (ids_len_out) ids_len_out[b] = ids_len[b];
   }
   const int Md = (int)pad_rows(rows_d);
+  int dqt = 0, dnw = 4, dq_rows = 0, n_dqb = 0, max_len = 0;
+  for (int b = 0; b < B; ++b) max_len = std::max(max_len, ids_len[b]);
+  if (precision == ASR_PRECISION_BF16) {
+    attention_geometry(max_len, 128, &dqt, &dnw);
+    dq_rows = 16 * dqt * dnw;
+    for (int b = 0; b < B; ++b) n_dqb += (ids_len[b] + dq_rows - 1) / dq_rows;
+  }
   // plan blob: [UttPlan B][win plans][dec plans B][blk_utt][blk_f0][qb_utt][qb_q0][slot_utt][slot_local][pos_rows Me][src Md][row_seq Md][row_t Md][last B]
-  const size_t plan_bytes = (sizeof(UttPlan) * (2 * (size_t)B + wins) + 4 * (2 * (size_t)n_fb + 2 * (size_t)n_qb + 2 * (size_t)slots + Me + 3 * (size_t)Md + B) + 15) / 16 * 16;
+  const size_t plan_bytes = (sizeof(UttPlan) * (2 * (size_t)B + wins) + 4 * (2 * (size_t)n_fb + 2 * (size_t)n_qb + 2 * (size_t)slots + Me + 3 * (size_t)Md + B + 2 * (size_t)n_dqb) + 15) / 16 * 16;
   unsigned char* hp = (unsigned char*)pinned(h_plan, h_plan_cap, plan_bytes + sizeof(UttPlan) * B + 12 * (size_t)round_up(B, 128) + 64);
   UttPlan* h_up = (UttPlan*)hp;
   UttPlan* h_wp = h_up + B;
@@ -498,6 +693,8 @@ void QwSession::prefill(const float* audio, int audio_mem, const int64_t* offs, 
   int32_t* row_seq = src + Md;
   int32_t* row_t = row_seq + Md;
   int32_t* last = row_t + Md;
+  int32_t* dqb_utt = last + B;
+  int32_t* dqb_q0 = dqb_utt + n_dqb;
   memcpy(h_up, up.data(), sizeof(UttPlan) * B);
   memcpy(h_wp, wp.data(), sizeof(UttPlan) * wins);
   constexpr int32_t PAD = INT32_MIN;
@@ -525,6 +722,8 @@ void QwSession::prefill(const float* audio, int audio_mem, const int64_t* offs, 
       }
       for (int t = 0; t < ids_len[b]; ++t) { row_seq[drow0[b] + t] = b; row_t[drow0[b] + t] = t; }
       last[b] = drow0[b] + ids_len[b] - 1;
+      if (dq_rows)
+        for (int q0 = 0; q0 < ids_len[b]; q0 += dq_rows) { *dqb_utt++ = b; *dqb_q0++ = q0; }
       UttPlan& p = h_dp[b];
       p = up[b];
       p.T = ids_len[b]; p.n_lfr = ids_len[b]; p.row_off = drow0[b];
@@ -546,6 +745,8 @@ void QwSession::prefill(const float* audio, int audio_mem, const int64_t* offs, 
   const int32_t* d_row_seq = d_src + Md;
   const int32_t* d_row_t = d_row_seq + Md;
   const int32_t* d_last_rows = d_row_t + Md;
+  const int32_t* d_dqb_utt = d_last_rows + B;
+  const int32_t* d_dqb_q0 = d_dqb_utt + n_dqb;
 
   const float* d_aud;
   const int64_t total_samples = offs[B] - base0;
@@ -660,7 +861,14 @@ void QwSession::prefill(const float* audio, int audio_mem, const int64_t* offs, 
   { ProfScope ps(prof, "dec_embed", stream);
     hipLaunchKernelGGL(qw_gather_prompt_kernel<T>, dim3(Md), dim3(256), 0, stream, d_src, (const T*)embed, d_aud_out.as<float>(), d, PAD, d_x.as<float>()); }
   if (taps_enabled) save_tap("prompt", d_x.ptr, rows_d, d, d, 4);
-  decoder_pass<T>(ddp, d_row_seq, d_row_t, d_last_rows, rows_d, B);
+  if (precision == ASR_PRECISION_BF16) {
+    d_vt2.reserve((size_t)KV * hd * Md * eT, stream);
+    d_krows.reserve((size_t)Md * KV * hd * eT, stream);
+  }
+  DecPass P;
+  P.plan = ddp; P.row_seq = d_row_seq; P.row_t = d_row_t; P.last_rows = d_last_rows; P.rows = rows_d; P.B = B; P.step = false;
+  P.qb_utt = d_dqb_utt; P.qb_q0 = d_dqb_q0; P.n_qb = no_fuse ? 0 : n_dqb; P.qt = dqt; P.nw = dnw; P.max_T = max_len; P.ld_vt = Md;
+  decoder_pass<T>(P);
   // step plan for the decode calls that follow: one row per sequence
   {
     const int Mb = round_up(B, 128);
@@ -697,11 +905,43 @@ void QwSession::step(const int32_t* ids_host, int32_t* next_out, float* logits_o
   const UttPlan* dsp = d_stepplan.as<UttPlan>();
   const int32_t* d_row_seq = (const int32_t*)(dsp + B);
   const int32_t* d_row_t = d_row_seq + Mb;
-  const int32_t* d_last = d_row_t + Mb;
-  { ProfScope ps(prof, "dec_embed", stream);
-    hipLaunchKernelGGL(qw_gather_prompt_kernel<T>, dim3(B), dim3(256), 0, stream, (const int32_t*)d_next.ptr, (const T*)embed, (const float*)nullptr, d,
-                       INT32_MIN, d_x.as<float>()); }
-  decoder_pass<T>(dsp, d_row_seq, d_row_t, d_last, B, B);
+  const int32_t* d_lastrows = d_row_t + Mb;
+  DecPass P;
+  P.plan = dsp; P.row_seq = d_row_seq; P.row_t = d_row_t; P.last_rows = d_lastrows; P.rows = B; P.B = B; P.step = true;
+  auto enqueue = [&] {
+    { ProfScope ps(prof, "dec_embed", stream);
+      hipLaunchKernelGGL(qw_gather_prompt_kernel<T>, dim3(B), dim3(256), 0, stream, (const int32_t*)d_next.ptr, (const T*)embed, (const float*)nullptr, d,
+                         INT32_MIN, d_x.as<float>()); }
+    decoder_pass<T>(P);
+  };
+  // every step reads its position from the device-side history counters => one captured graph replays for all of them
+  const bool graphable = use_graph && !taps_enabled && !prof.enabled;
+  uint64_t key = 1469598103934665603ull;
+  for (const void* q : {d_x.ptr, d_x2.ptr, d_dh.ptr, d_qkv.ptr, d_q.ptr, d_dctx.ptr, d_gu.ptr, d_act.ptr, d_last.ptr, d_logits.ptr, d_next.ptr, d_kc.ptr,
+                        d_vc.ptr, d_hist.ptr, d_stepplan.ptr, d_skws.ptr, (void*)stream, (void*)(uintptr_t)B})
+    key = (key ^ (uint64_t)(uintptr_t)q) * 1099511628211ull;
+  if (graphable && dec_graph && key == dec_key) {
+    HIP_CHECK(hipGraphLaunch(dec_graph, stream));
+  } else if (graphable && key == dec_eager_key) {
+    if (dec_graph) { (void)hipGraphExecDestroy(dec_graph); dec_graph = nullptr; }
+    hipGraph_t graph = nullptr;
+    HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    try {
+      enqueue();
+    } catch (...) {
+      (void)hipStreamEndCapture(stream, &graph);
+      if (graph) (void)hipGraphDestroy(graph);
+      throw;
+    }
+    HIP_CHECK(hipStreamEndCapture(stream, &graph));
+    HIP_CHECK(hipGraphInstantiate(&dec_graph, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    dec_key = key;
+    HIP_CHECK(hipGraphLaunch(dec_graph, stream));
+  } else {
+    enqueue();                                           // first step of a geometry runs eagerly (lazy kernel attributes, workspaces)
+    if (graphable) dec_eager_key = key;
+  }
   for (int b = 0; b < B; ++b) ++seq_len[b];
   finish<T>(B, next_out, logits_out, ids_host != nullptr);
 }
@@ -722,6 +962,8 @@ extern "C" int asr_qwen_create(const asr_qwen_config* cfg, const void* arena, si
       s->cfg = *cfg;
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;
+      if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
+      if (const char* e = getenv("ASR_QWEN_NO_FUSE")) s->no_fuse = e[0] == '1';
       s->arena.load(arena, arena_bytes, arena_mem, s->stream);
       s->init();
     } catch (...) {

@@ -445,7 +445,8 @@ class QwenAsrSession(_Session):
     """HIP replacement of the merged Qwen3-ASR graphs (audio encoder + prompt assembly + Qwen3 decoder prefill / decode + arg-max;
     Qwen_ASR/Inference_Qwen_ASR_ONNX.py:424-760 drives them)."""
 
-    def __init__(self, cfg, arena, precision: int = PRECISION_BF16, device_id: int = 0):
+    def __init__(self, cfg, arena, precision: int = PRECISION_BF16, device_id: int = 0, arena_device_ptr: int | None = None,
+                 arena_bytes: int | None = None):
         super().__init__()
         self.cfg, self.precision, self.device_id = cfg, precision, device_id
         c = _lib.QwenConfigC()
@@ -454,9 +455,14 @@ class QwenAsrSession(_Session):
                   "max_seq_len", "max_audio_len", "rms_eps", "rope_theta"):
             setattr(c, f, getattr(cfg, f))
         self._cfg_c = c
-        blob = np.ascontiguousarray(arena, dtype=np.uint8)
-        _lib.check(_lib.load().asr_qwen_create(C.byref(c), blob.ctypes.data_as(C.c_void_p), blob.nbytes, MEM_HOST, device_id, precision,
-                                               C.byref(self._h)))
+        if arena_device_ptr is not None:
+            self._keep = arena
+            _lib.check(_lib.load().asr_qwen_create(C.byref(c), C.c_void_p(arena_device_ptr), arena_bytes, MEM_DEVICE, device_id, precision,
+                                                   C.byref(self._h)))
+        else:
+            blob = np.ascontiguousarray(arena, dtype=np.uint8)
+            _lib.check(_lib.load().asr_qwen_create(C.byref(c), blob.ctypes.data_as(C.c_void_p), blob.nbytes, MEM_HOST, device_id, precision,
+                                                   C.byref(self._h)))
         self.batch = 0
 
     @classmethod

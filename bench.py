@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
-    ap.add_argument("--workload", choices=("sensevoice", "whisper", "paraformer", "paraformer-streaming"), default="sensevoice",
+    ap.add_argument("--workload", choices=("sensevoice", "whisper", "paraformer", "paraformer-streaming", "qwen"), default="sensevoice",
                     help="sensevoice = BASELINE.json configs[1] (default, the headline line); whisper = large-v3 encoder + greedy decode")
     ap.add_argument("--decode-tokens", type=int, default=0, help="whisper: generated tokens per utterance (default 4 per audio second)")
     args = ap.parse_args()
@@ -113,6 +113,8 @@ def main():
         return main_paraformer(args)
     if args.workload == "paraformer-streaming":
         return main_paraformer_streaming(args)
+    if args.workload == "qwen":
+        return main_qwen(args)
 
     import torch
     import torch.distributed as dist
@@ -559,6 +561,115 @@ def main_whisper(args):
                                 "achieved": round(alg["decode_bytes_per_step"] / (t_dec / max(n_tok - 1, 1)) / 1e9, 1),
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(alg["decode_bytes_per_step"] / (t_dec / max(n_tok - 1, 1)) / 1e9 / HBM_PEAK_GBS, 4)},
+            "kernels": kernels, "arena_broadcast_s": round(t_bcast, 3),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_qwen(args):
+    """Qwen3-ASR-0.6B bf16 greedy: one prefill launch (log-mel + conv stem + windowed encoder + prompt assembly + decoder prefill) and a
+    FIXED number of decode steps (random weights never emit a stop id; SURVEY.md section 8d: 4 tokens per audio second)."""
+    import torch
+    import torch.distributed as dist
+    cfgm = importlib.import_module(PKG + ".config")
+    ckm = importlib.import_module(PKG + ".checkpoints")
+    arena = importlib.import_module(PKG + ".arena")
+    eng = importlib.import_module(PKG + ".engine")
+    dp = importlib.import_module(PKG + ".dist")
+    rank, local_rank, world = dp.init_from_env()
+    assert world == args.gpus
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    cfg = cfgm.qwen_asr_0p6b()
+    B = args.batch
+    n_samples = int(args.seconds * cfg.sample_rate)
+    n_tok = args.decode_tokens or int(round(4 * args.seconds))
+    blob = None
+    if rank == 0:
+        blob = arena.build_qwen_asr_arena(cfg, ckm.synth_qwen_asr_checkpoint(cfg, seed=0), arena.PRECISION_BF16)
+    t0 = time.perf_counter()
+    arena_dev = dp.broadcast_arena(blob, device)
+    torch.cuda.synchronize()
+    t_bcast = time.perf_counter() - t0
+    blob = None
+    sess = eng.QwenAsrSession(cfg, arena_dev, arena.PRECISION_BF16, local_rank, arena_device_ptr=arena_dev.data_ptr(), arena_bytes=arena_dev.numel())
+    audio_dev = torch.from_numpy(ckm.synth_audio("unit", B, n_samples, seed=1234 + rank)).to(device)
+    offsets = np.arange(B + 1, dtype=np.int64) * n_samples
+    # prompt geometry of the reference host: head (3) + suffix (6) ids before the audio, tail (8) + language tail (2) after it
+    pre, post = [list(range(1000, 1009))], [list(range(2000, 2010))]
+    t_parts = {"prefill": 0.0, "decode": 0.0}
+
+    def step(record=False):
+        t0 = time.perf_counter()
+        sess.prefill_packed(None, offsets, pre, post, want_logits=False, audio_device_ptr=audio_dev.data_ptr())
+        t1 = time.perf_counter()
+        toks = sess.generate(n_tok, stop_ids=())
+        t2 = time.perf_counter()
+        if record:
+            t_parts["prefill"] += t1 - t0; t_parts["decode"] += t2 - t1
+        if world > 1:
+            dp.gather_hypotheses(dp.pack_hypotheses(np.stack(toks), np.full(B, n_tok, np.int32), n_tok), device)
+        return toks
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(record=True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    sess.profile(True)
+    sess.profile_reset()
+    step()
+    prof = sess.profile_read()
+    sess.profile(False)
+    if rank == 0:
+        audio_s = world * B * args.seconds
+        n_audio = sess.audio_tokens(n_samples)
+        L = len(pre[0]) + n_audio + len(post[0])
+        de, dff, d, I = cfg.enc_d, cfg.enc_ffn, cfg.d_model, cfg.d_ffn
+        qkvn = (cfg.n_heads + 2 * cfg.n_kv_heads) * cfg.d_head
+        dec_params = cfg.n_layers * (qkvn * d + cfg.n_heads * cfg.d_head * d + 3 * I * d)
+        # encoder + stem + decoder-prefill GEMM FLOPs per utterance (2MNK, unpadded channel counts)
+        C, chunks = cfg.conv_channels, (cfg.n_frames(n_samples) + cfg.chunk - 1) // cfg.chunk
+        stem = chunks * (2.0 * 3200 * C * 9 + 2.0 * 800 * C * 9 * C + 2.0 * 208 * C * 9 * C + 2.0 * 13 * de * 16 * C)
+        enc = n_audio * (cfg.n_enc_layers * 2.0 * de * (4 * de + 2 * dff) + 2.0 * de * de + 2.0 * de * d)
+        pre_dec = L * 2.0 * dec_params + 2.0 * d * cfg.vocab
+        kernels = {k: {"ms_per_step": round(v["total_ms"], 3), "launches_per_step": v["launches"]}
+                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+        t_pre, t_dec = t_parts["prefill"] / args.steps, t_parts["decode"] / args.steps
+        step_bytes = 2.0 * (dec_params + cfg.vocab * d) + B * cfg.n_layers * 2 * cfg.n_kv_heads * cfg.d_head * 2.0 * (L + n_tok / 2)
+        per_tok = t_dec / max(n_tok - 1, 1)
+        flops = B * (stem + enc + pre_dec)
+        out = {
+            "metric": "audio-sec/s, Qwen3-ASR-0.6B, %g s @ 16 kHz chunks, batch %d per GPU, greedy, %d tokens/utterance" % (args.seconds, B, n_tok),
+            "value": round(audio_s * args.steps / elapsed, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Qwen3-ASR-0.6B bf16 (18-layer windowed audio encoder + 28-layer Qwen3 decoder), batch=%d x %g s per GPU, prefill of "
+                                   "%d positions (%d audio tokens) + %d greedy decode steps, audio resident in HBM" % (B, args.seconds, L, n_audio, n_tok - 1),
+                       "global_batch": world * B, "parallelism": f"dp{world}"},
+            "rtf": round(elapsed / (audio_s * args.steps), 7),
+            "ms": {k: round(v / args.steps * 1e3, 2) for k, v in t_parts.items()},
+            "decode_ms_per_token": round(per_tok * 1e3, 3),
+            "roofline": {"bound": "mfma", "kernel": "prefill launch (stem + encoder + decoder-prefill GEMMs)", "achieved": round(flops / t_pre / 1e12, 1),
+                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / t_pre / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None},
+            "roofline_decode": {"bound": "hbm", "kernel": "decode step (decoder weights + lm_head + KV cache stream)",
+                                "achieved": round(step_bytes / per_tok / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(step_bytes / per_tok / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels": kernels, "arena_broadcast_s": round(t_bcast, 3),
         }
         print(json.dumps(out))

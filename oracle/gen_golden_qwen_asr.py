@@ -17,6 +17,7 @@ HEAD_IDS, TAIL_IDS, SUFFIX_IDS = [510, 511, 512], [520, 521, 512, 510, 522, 512,
 CASES = [  # (fixture, config, ckpt seed, n_new, [(audio seed, n_samples, query ids, language tail ids)])
     ("qwen_asr_tiny", "qwen_asr_tiny", 0, 6, [(4401, 40000, [], []), (4402, 16000, [40, 41, 42], [77, 540]), (4403, 130000, [], [78, 540]),
                                               (4404, 7000, [], [])]),
+    ("qwen_asr_mid", "qwen_asr_mid", 1, 6, [(4411, 128000, [], [77, 540]), (4412, 30000, [40, 41], []), (4413, 200000, [], [78, 540])]),
 ]
 
 

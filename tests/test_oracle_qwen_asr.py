@@ -20,8 +20,9 @@ def unit_audio(seed, n):
     return sub("checkpoints").synth_audio("unit", 1, int(n), seed=int(seed))[0, 0]
 
 
-def test_oracle_matches_reference_goldens():
-    g = load_golden("qwen_asr_tiny")
+@pytest.mark.parametrize("fixture", ["qwen_asr_tiny", "qwen_asr_mid"])
+def test_oracle_matches_reference_goldens(fixture):
+    g = load_golden(fixture)
     cfg, ck = qwen_setup(g)
     orc = QwenAsrOracle(cfg, ck, g["head_ids"].tolist(), g["tail_ids"].tolist(), g["suffix_ids"].tolist())
     for i, c in golden_cases(g):

@@ -31,10 +31,11 @@ def _stepwise(sess, audios, pre, post, n_new):
     return np.stack(steps_logits, 1), np.stack(steps_ids, 1), ids_len
 
 
-@pytest.mark.parametrize("order", [(0, 1, 2, 3), (2, 3, 1), (3,)])
-def test_f32_mode_matches_reference_goldens(order):
+@pytest.mark.parametrize("fixture,order", [("qwen_asr_tiny", (0, 1, 2, 3)), ("qwen_asr_tiny", (2, 3, 1)), ("qwen_asr_tiny", (3,)),
+                                           ("qwen_asr_mid", (0, 1, 2)), ("qwen_asr_mid", (2, 0))])
+def test_f32_mode_matches_reference_goldens(fixture, order):
     """Ragged batches (different clip lengths, prompts and language tails per sequence) against the reference's own outputs."""
-    g = load_golden("qwen_asr_tiny")
+    g = load_golden(fixture)
     cfg, ck = qwen_setup(g)
     sess = sub("engine").QwenAsrSession.from_checkpoint(cfg, ck, precision=F32)
     allc = [c for _, c in golden_cases(g)]
@@ -55,9 +56,13 @@ def test_f32_mode_matches_reference_goldens(order):
             assert np.array_equal(got_ids[b], c["token_ids"]), b
 
 
-def test_generate_equals_stepwise_and_oracle_bf16():
-    """bf16 mode: generate() == explicit prefill / decode; logits stay within the bf16 budget of the oracle; host-fed ids == device-fed."""
-    g = load_golden("qwen_asr_tiny")
+@pytest.mark.parametrize("fixture,no_fuse", [("qwen_asr_tiny", "0"), ("qwen_asr_mid", "0"), ("qwen_asr_mid", "1")])
+def test_generate_equals_stepwise_and_oracle_bf16(fixture, no_fuse, monkeypatch):
+    """bf16 mode: generate() == explicit prefill / decode; logits stay within the bf16 budget of the reference; host-fed ids == device-fed.
+    no_fuse = 1 runs the unfused kernels (separate RMSNorm / RoPE / per-head attention) instead of the fused decode step and the MFMA
+    prefill attention."""
+    monkeypatch.setenv("ASR_QWEN_NO_FUSE", no_fuse)
+    g = load_golden(fixture)
     cfg, ck = qwen_setup(g)
     sess = sub("engine").QwenAsrSession.from_checkpoint(cfg, ck, precision=BF16)
     cases = [c for _, c in golden_cases(g)]

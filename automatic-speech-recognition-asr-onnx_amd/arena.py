@@ -547,7 +547,8 @@ def build_qwen_asr_arena(cfg, ck: dict, precision: int = PRECISION_BF16) -> np.n
         wqkv = np.concatenate([ck[p + "self_attn.q_proj.weight"], ck[p + "self_attn.k_proj.weight"], ck[p + "self_attn.v_proj.weight"]], 0)
         w.weight(q + "wqkv", f32(wqkv * ck[p + "input_layernorm.weight"][None, :]), precision)
         w.weight(q + "wo", f32(ck[p + "self_attn.o_proj.weight"]), precision)
-        gu = np.concatenate([ck[p + "mlp.gate_proj.weight"], ck[p + "mlp.up_proj.weight"]], 0)
+        # rows interleaved (gate_0, up_0, gate_1, up_1, ...): the GEMM's SwiGLU epilogue finds each pair in one lane
+        gu = np.stack([ck[p + "mlp.gate_proj.weight"], ck[p + "mlp.up_proj.weight"]], 1).reshape(2 * cfg.d_ffn, d)
         w.weight(q + "gate_up", f32(gu * ck[p + "post_attention_layernorm.weight"][None, :]), precision)
         w.weight(q + "down", f32(ck[p + "mlp.down_proj.weight"]), precision)
         w.add(q + "qn", f32(ck[p + "self_attn.q_norm.weight"] * sc), DT_F32)

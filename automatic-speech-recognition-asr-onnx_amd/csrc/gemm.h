@@ -4,7 +4,9 @@
 #pragma once
 #include "common.h"
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU_ERF = 2, ACT_GELU_TANH = 3 };
+// ACT_SWIGLU: W rows interleave gate / up (row 2j = gate_j, row 2j + 1 = up_j); the epilogue stores silu(gate_j) * up_j to out_lo column j
+// (out_lo is [M][N / 2]); no other output term may be set.
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU_ERF = 2, ACT_GELU_TANH = 3, ACT_SWIGLU = 4 };
 
 struct GemmArgs {
   const void* A = nullptr; int lda = 0;     // [rows][K]; rows readable up to the 128-row tile edge
@@ -29,7 +31,10 @@ struct GemmArgs {
   // normalises the few activation rows itself (two-pass statistics in f32), so no separate LayerNorm launch and no bf16
   // round trip of the normalised rows through HBM. gamma/beta nullable (affine folded into W, Export_Whisper.py:215-225).
   const float* ln_x = nullptr; int ld_ln_x = 0; const float* ln_gamma = nullptr; const float* ln_beta = nullptr; float ln_eps = 1e-5f;
-  int ln_rms = 0;   // 1: RMSNorm instead (no mean subtraction; Qwen3 decoder, weight folded into W)
+  // Skinny path: RMSNorm of the A rows folded into the product -- RMSNorm(x) W^T = rstd(x) (x W^T) -- A holds the RAW rows in bf16,
+  // every workgroup accumulates sum(x^2) from the A fragments it streams anyway and scales its output rows by rsqrt(mean + a_rms_eps)
+  // before bias / residual terms. a_rms_eps > 0 enables it (the norm weight must be folded into W).
+  float a_rms_eps = 0.0f;
   // LayerNorm evaluated inside the GEMM (144-row-tile kernel only; K must span the whole normalised row): A holds the RAW rows
   // x in bf16, row statistics over the first ln_dim columns are accumulated from the LDS tiles during the MFMA loop and
   // C = rstd (x W^T - mean ln_colsum) + bias. Needs the LayerNorm affine folded into W / bias; ln_colsum[n] = sum_k W[n][k].

@@ -194,6 +194,15 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[
         s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
         if (fgrp == 0 && m < g.M) g.st_out[(size_t)m * (g.N >> 5) + ((n_wave >> 5) + p)] = make_float2(s1, s2);
       }
+      if ((ACT >= 0 ? ACT == ACT_SWIGLU : g.act == ACT_SWIGLU)) {      // interleaved (gate, up) columns -> N / 2 activations
+        if (m < g.M && want_lo) {
+          float y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = v[2 * e] / (1.0f + __expf(-v[2 * e])) * v[2 * e + 1];
+          store4<OutT>(reinterpret_cast<OutT*>(g.out_lo) + (size_t)m * g.ld_out_lo + (n >> 1), y[0], y[1], y[2], y[3]);
+        }
+        continue;
+      }
       if (m < g.M) {
         if (want_f32) store8<float>(g.out_f32 + (size_t)m * g.ld_out_f32 + n, v);
         if (want_lo) {
@@ -563,7 +572,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny(const GemmArgs g) {
         float s1 = 0.f;
 #pragma unroll
         for (int q = 0; q < KV; ++q) s1 += (v[rr][q].x + v[rr][q].y) + (v[rr][q].z + v[rr][q].w);
-        const float mean = g.ln_rms ? 0.f : wave_sum(s1) / (float)g.K;
+        const float mean = wave_sum(s1) / (float)g.K;
         float s2 = 0.f;
 #pragma unroll
         for (int q = 0; q < KV; ++q) {
@@ -605,8 +614,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny(const GemmArgs g) {
   const bf16_t* ap = A + (size_t)frow * lda + k_begin + fgrp * 8;
 
   f32x4_t acc[MT];
+  float ss[MT];                                          // a_rms: sum of squares of this lane's A fragments, row i * 16 + frow
 #pragma unroll
-  for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MT; ++i) { acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; ss[i] = 0.f; }
+  const bool a_rms = g.a_rms_eps > 0.0f;
   for (int k = 0; k < kslice; k += 32 * U) {
     bf16x8_t wf[U];
 #pragma unroll
@@ -621,14 +632,33 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny(const GemmArgs g) {
         for (int i = 0; i < MT; ++i) {
           const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(ap + (size_t)i * 16 * lda + k + u * 32);
           acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af, acc[i], 0, 0, 0);   // D[n = 4 fgrp + r][m = frow]
+          if (a_rms) {
+            union { bf16x8_t v; uint32_t w[4]; } q;
+            q.v = af;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float lo = __uint_as_float(q.w[e] << 16), hi = __uint_as_float(q.w[e] & 0xffff0000u);
+              ss[i] = fmaf(lo, lo, fmaf(hi, hi, ss[i]));
+            }
+          }
         }
       }
     }
   }
   // ---- cross-wave reduction
   float4* red = reinterpret_cast<float4*>(smem);                                     // [wave][MT][64]
+  float (*ss_red)[MT * 16] = reinterpret_cast<float (*)[MT * 16]>(smem + SK_WAVES * MT * 1024);    // a_rms only (excludes ln_x)
 #pragma unroll
   for (int i = 0; i < MT; ++i) red[(wave * MT + i) * 64 + lane] = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+  if (a_rms) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float t = ss[i];
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      if (fgrp == 0) ss_red[wave][i * 16 + frow] = t;
+    }
+  }
   __syncthreads();
   const int rows16 = MT * 16;
   float4 sums[(MT + SK_WAVES - 1) / SK_WAVES];
@@ -694,6 +724,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny(const GemmArgs g) {
     float4 sum = sums[t];
     const int m = i * 16 + frow, n = n0 + fgrp * 4;
     if (m >= g.M) continue;
+    if (a_rms) {                                          // fixed summation order over the waves
+      float t = ss_red[0][m];
+#pragma unroll
+      for (int w = 1; w < SK_WAVES; ++w) t += ss_red[w][m];
+      const float r = rsqrtf(t / (float)g.K + g.a_rms_eps);
+      sum.x *= r; sum.y *= r; sum.z *= r; sum.w *= r;
+    }
+    if (g.act == ACT_SWIGLU) {                            // columns (gate_j, up_j, gate_j+1, up_j+1)
+      const float y0 = sum.x / (1.0f + __expf(-sum.x)) * sum.y, y1 = sum.z / (1.0f + __expf(-sum.z)) * sum.w;
+      *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(g.out_lo) + (size_t)m * g.ld_out_lo + (n >> 1)) = pack_bf16x2(y0, y1);
+      continue;
+    }
     if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + n); sum.x += b.x; sum.y += b.y; sum.z += b.z; sum.w += b.w; }
     if (g.add) { const float4 q = *reinterpret_cast<const float4*>(g.add + (size_t)m * g.ld_add + n); sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w; }
     if (g.act != ACT_NONE) { sum.x = apply_act_rt(sum.x, g.act); sum.y = apply_act_rt(sum.y, g.act); sum.z = apply_act_rt(sum.z, g.act); sum.w = apply_act_rt(sum.w, g.act); }
@@ -710,8 +752,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny(const GemmArgs g) {
 static int skinny_splits(const GemmArgs& g, int rows16) {
   // measured on MI355X (Whisper-large-v3 decode, SenseVoice single window): the hand-over costs more than the extra workgroups
   // gain (3.84 -> 4.27 ms / token), so the split is opt-in (ASR_SKINNY_SPLITK=1) and kept for shapes where N / 16 is tiny
-  static const bool on = getenv("ASR_SKINNY_SPLITK") && getenv("ASR_SKINNY_SPLITK")[0] == '1';
-  if (!on || !g.sk_ws || !g.sk_cnt) return 1;
+  // ... except for 33..64 rows (Qwen3-ASR decode, batch 64: 2.68 -> 2.45 ms / token), where every workgroup also re-reads 4 row tiles
+  // of activations: there the split is on by default for the narrow outputs (o_proj / down_proj, N / 16 = 64 workgroups otherwise)
+  static const int on = getenv("ASR_SKINNY_SPLITK") ? atoi(getenv("ASR_SKINNY_SPLITK")) : -1;
+  if (on == 0 || (on < 0 && rows16 <= 32) || !g.sk_ws || !g.sk_cnt || g.a_rms_eps > 0.0f) return 1;
   const int granules = g.N / 16;
   int best = 1;
   for (int s : {2, 3, 4, 5, 8}) {
@@ -725,7 +769,8 @@ static int skinny_splits(const GemmArgs& g, int rows16) {
 
 template <int MT>
 void launch_skinny(const GemmArgs& g, hipStream_t s) {
-  const size_t lds = (size_t)SK_WAVES * MT * 1024 + (g.ln_x ? (size_t)MT * 16 * g.K * 2 : 0);
+  ASR_REQUIRE(!(g.ln_x && g.a_rms_eps > 0.0f), "gemm(skinny): ln_x and a_rms_eps are exclusive");
+  const size_t lds = (size_t)SK_WAVES * MT * 1024 + (g.ln_x ? (size_t)MT * 16 * g.K * 2 : 0) + (g.a_rms_eps > 0.0f ? (size_t)SK_WAVES * MT * 64 : 0);
   ASR_REQUIRE(lds <= 160 * 1024, "gemm(skinny): LayerNorm prologue needs %zu bytes of LDS", lds);
   static size_t attr = 0;
   if (lds > attr) {
@@ -831,6 +876,8 @@ void check_args(const GemmArgs& g, int kstep, int elt) {
   if (g.add2) ASR_REQUIRE(g.ld_add2 % 4 == 0, "gemm: ld_add2 must be a multiple of 4");
   if (g.out_f32) ASR_REQUIRE(g.ld_out_f32 % 4 == 0, "gemm: ld_out_f32 must be a multiple of 4");
   if (g.out_lo) ASR_REQUIRE(g.ld_out_lo % 8 == 0 && g.lo_group % 8 == 0, "gemm: ld_out_lo / lo_group must be multiples of 8");
+  if (g.act == ACT_SWIGLU)
+    ASR_REQUIRE(g.out_lo && !(g.add || g.add2 || g.out_f32 || g.amax_val || g.bias || g.lo_group || g.out_t), "gemm: SwiGLU stores to out_lo only");
   if (g.out_t) {
     ASR_REQUIRE(!(g.add || g.add2 || g.out_f32 || g.out_lo || g.amax_val || g.act != ACT_NONE),
                 "gemm: the transposed store excludes row-major epilogue terms");
@@ -877,6 +924,8 @@ void launch_pipe(const GemmArgs& g, hipStream_t s) {
   ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_ADD | E_F32 | E_LO | E_ST)
   ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_AMAX)                  // CTC / LM head arg-max
   ASR_GEMM_CASE(ACT_NONE, E_BIAS | E_F32)                   // LM head logits
+  ASR_GEMM_CASE(ACT_NONE, E_F32)
+  ASR_GEMM_CASE(ACT_SWIGLU, E_LO)
   ASR_GEMM_CASE(ACT_RELU, E_BIAS | E_F32)                   // Paraformer decoder FFN-1 (f32 out feeds the inner LayerNorm)
   ASR_GEMM_CASE(ACT_GELU_ERF, E_BIAS | E_ADD2 | E_F32)      // Whisper conv2: gelu(conv) + positions
   ASR_GEMM_CASE(ACT_GELU_TANH, E_BIAS | E_ADD2 | E_F32)
@@ -909,6 +958,9 @@ bool launch_t144(const GemmArgs& g, hipStream_t s) {
 #define ASR_T144_CASE(ACT_, EPI_) \
   if (g.act == (ACT_) && epi == (EPI_)) { launch_t144_inst<STAGES, ACT_, EPI_>(g, s); return true; }
   ASR_T144_CASE(ACT_NONE, E_BIAS | E_LO)
+  ASR_T144_CASE(ACT_NONE, E_F32)                             // decoder q|k|v (f32 for the per-head RMSNorm / RoPE)
+  ASR_T144_CASE(ACT_SWIGLU, E_LO)                            // decoder gate|up with the SwiGLU epilogue
+  ASR_T144_CASE(ACT_GELU_TANH, E_BIAS | E_LO)
   ASR_T144_CASE(ACT_RELU, E_BIAS | E_LO)
   ASR_T144_CASE(ACT_NONE, E_ADD | E_ADD2 | E_F32)
   ASR_T144_CASE(ACT_NONE, E_ADD | E_F32)
@@ -961,7 +1013,10 @@ bool gemm_ln_fusable(const GemmArgs& g) {
 
 void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
   if (g.ln_x) ASR_REQUIRE(g.M <= 64 && !g.A, "gemm: the fused LayerNorm prologue exists on the skinny (M <= 64) path only");
-  if (g.M <= 64 && !g.out_t && !g.amax_val && g.lo_group == 0 && g.K % (32 * SK_WAVES) == 0 && g_gemm_variant < 0) {
+  // 33..64 rows against a vocabulary-sized N: the 128 x 128 tiles re-read the activations 8 x less often than 16-column granules do
+  // (lm_head 64 x 151936 x 1024: 76 us vs 240 us)
+  const bool tall = g.M > 32 && g.N >= 16384 && !g.ln_x && g.a_rms_eps == 0.0f && g.act != ACT_SWIGLU;
+  if (g.M <= 64 && !tall && !g.out_t && !g.amax_val && g.lo_group == 0 && g.K % (32 * SK_WAVES) == 0 && g_gemm_variant < 0) {
     ASR_REQUIRE((g.A || g.ln_x) && g.W && g.N % 16 == 0, "gemm(skinny): bad operands");
     ASR_REQUIRE(g.ln_x || (g.lda * 2) % 16 == 0, "gemm(skinny): lda must be a 16-byte multiple");
     if (g.ln_x) ASR_REQUIRE(g.K % 4 == 0 && g.K <= 1280 && g.ld_ln_x % 4 == 0, "gemm(skinny): fused LayerNorm needs K <= 1280, float4-aligned rows");
@@ -987,7 +1042,7 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
       return;
     }
     if (t144_enabled() && t144_fits(g, &st) && (st == 4 ? launch_t144<4>(g, s) : launch_t144<2>(g, s))) return;
-    v = 4;
+    v = tall ? 2 : 4;
   }
   if (v == 5 || v == 6) {
     ASR_REQUIRE(!(g.out_t || g.amax_val || g.lo_group || g.add2_rows) && g.N % TN == 0, "gemm: variant %d (144-row tiles) does not support this epilogue", v);

@@ -768,18 +768,33 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------ row arg-max
-__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ logits, int ld, int n_valid,
-                                                          const float* __restrict__ extra, int32_t* __restrict__ ids) {
-  __shared__ float bv[4];
-  __shared__ int bi[4];
+// one workgroup of 1024 threads per row, 16-byte loads, two independent loads in flight per thread (a 150 k-column row is ~19 trips)
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* __restrict__ logits, int ld, int n_valid,
+                                                           const float* __restrict__ extra, int32_t* __restrict__ ids) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* x = logits + (size_t)r * ld;
   float best = -INFINITY;
   int bidx = 0x7fffffff;
-  for (int c = tid; c < n_valid; c += 256) {
-    const float v = x[c] + (extra ? extra[c] : 0.0f);
-    if (v > best) { best = v; bidx = c; }
+  auto take = [&](const float4 v, int c) {                    // ascending columns: strict > keeps the first maximum
+    if (c + 0 < n_valid && v.x > best) { best = v.x; bidx = c; }
+    if (c + 1 < n_valid && v.y > best) { best = v.y; bidx = c + 1; }
+    if (c + 2 < n_valid && v.z > best) { best = v.z; bidx = c + 2; }
+    if (c + 3 < n_valid && v.w > best) { best = v.w; bidx = c + 3; }
+  };
+  auto load = [&](int c) {
+    float4 v = *reinterpret_cast<const float4*>(x + c);       // rows are padded to a multiple of 128 columns
+    if (extra) { const float4 e = *reinterpret_cast<const float4*>(extra + c); v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w; }
+    return v;
+  };
+  int c = tid * 4;
+  for (; c + 4096 < n_valid; c += 8192) {
+    const float4 a = load(c), b = load(c + 4096);
+    take(a, c);
+    take(b, c + 4096);
   }
+  if (c < n_valid) take(load(c), c);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float ov = __shfl_xor(best, o, 64);
@@ -789,7 +804,7 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
   if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < 16; ++w)
       if (bv[w] > best || (bv[w] == best && bi[w] < bidx)) { best = bv[w]; bidx = bi[w]; }
     ids[r] = bidx;
   }
@@ -1166,7 +1181,8 @@ template void launch_decode_attention<float>(const DecAttnArgs&, int, hipStream_
 template void launch_decode_attention<bf16_t>(const DecAttnArgs&, int, hipStream_t);
 
 void launch_argmax_rows(const float* logits, int ld, int rows, int n_valid, const float* extra, int32_t* ids, hipStream_t s) {
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, s, logits, ld, n_valid, extra, ids);
+  ASR_REQUIRE(ld % 4 == 0 && n_valid <= ld, "argmax_rows: rows must be padded to a multiple of 4 columns");
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(1024), 0, s, logits, ld, n_valid, extra, ids);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -376,23 +376,17 @@ __global__ __launch_bounds__(256) void qw_decode_attn_kernel(const float* __rest
   }
 }
 
-template <typename T>
-__global__ void qw_silu_mul_kernel(const T* __restrict__ gu, int I, size_t n, T* __restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const size_t row = i / I, c = i - row * I;
-  const float g = Elem<T>::load(gu + row * 2 * I + c), u = Elem<T>::load(gu + row * 2 * I + I + c);
-  Elem<T>::store(out + i, g / (1.0f + expf(-g)) * u);
-}
-
 // decoder input rows: src >= 0 -> embedding of token src; src < 0 -> audio embedding row -1 - src; pad rows are zero
 template <typename T>
 __global__ void qw_gather_prompt_kernel(const int32_t* __restrict__ src, const T* __restrict__ embed, const float* __restrict__ audio, int d,
-                                        int32_t pad_marker, float* __restrict__ x) {
+                                        int32_t pad_marker, float* __restrict__ x, T* __restrict__ x_lo) {
   const int row = blockIdx.x, s = src[row];
   float* o = x + (size_t)row * d;
-  for (int c = threadIdx.x; c < d; c += blockDim.x)
-    o[c] = s == pad_marker ? 0.0f : (s >= 0 ? Elem<T>::load(embed + (size_t)s * d + c) : audio[(size_t)(-1 - s) * d + c]);
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    const float v = s == pad_marker ? 0.0f : (s >= 0 ? Elem<T>::load(embed + (size_t)s * d + c) : audio[(size_t)(-1 - s) * d + c]);
+    o[c] = v;
+    if (x_lo) Elem<T>::store(x_lo + (size_t)row * d + c, v);
+  }
 }
 
 __global__ void qw_hist_add_kernel(int32_t* __restrict__ hist, const UttPlan* __restrict__ plan, int B) {
@@ -423,7 +417,7 @@ struct QwSession : asr_session {
   int batch = 0;
   std::vector<int> seq_len;                              // positions in the cache per sequence (host mirror)
   DeviceBuffer d_plan, d_audio, d_mel, d_blkmax, d_feat, d_col, d_c1, d_c2, d_c3, d_xa, d_xb, d_h, d_qk, d_vt, d_ctx, d_ffn, d_aud_out;
-  DeviceBuffer d_dplan, d_x, d_x2, d_dh, d_qkv, d_q, d_dctx, d_gu, d_act, d_last, d_logits, d_next, d_kc, d_vc, d_hist, d_stepplan, d_skws, d_skcnt, d_vt2, d_krows;
+  DeviceBuffer d_dplan, d_x, d_x2, d_dh, d_qkv, d_q, d_dctx, d_act, d_last, d_logits, d_next, d_kc, d_vc, d_hist, d_stepplan, d_skws, d_skcnt, d_vt2, d_krows, d_xlo, d_x2lo;
   bool no_fuse = false, use_graph = true;
   hipGraphExec_t dec_graph = nullptr; uint64_t dec_key = 0, dec_eager_key = 0;
   void* h_plan = nullptr; size_t h_plan_cap = 0;
@@ -432,8 +426,8 @@ struct QwSession : asr_session {
 
   ~QwSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_feat, &d_col, &d_c1, &d_c2, &d_c3, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx,
-                            &d_ffn, &d_aud_out, &d_dplan, &d_x, &d_x2, &d_dh, &d_qkv, &d_q, &d_dctx, &d_gu, &d_act, &d_last, &d_logits, &d_next,
-                            &d_kc, &d_vc, &d_hist, &d_stepplan, &d_skws, &d_skcnt, &d_vt2, &d_krows})
+                            &d_ffn, &d_aud_out, &d_dplan, &d_x, &d_x2, &d_dh, &d_qkv, &d_q, &d_dctx, &d_act, &d_last, &d_logits, &d_next,
+                            &d_kc, &d_vc, &d_hist, &d_stepplan, &d_skws, &d_skcnt, &d_vt2, &d_krows, &d_xlo, &d_x2lo})
       b->release();
     for (auto& kv : taps) kv.second.buf.release();
     if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
@@ -526,21 +520,23 @@ void QwSession::decoder_pass(const DecPass& P) {
   float* qkv = d_qkv.as<float>();
   T* q = d_q.as<T>();
   T* ctx = d_dctx.as<T>();
-  T* gu = d_gu.as<T>();
   T* act = d_act.as<T>();
   const size_t layer_kv = (size_t)B * KV * S * hd;
   const int32_t* hist = d_hist.as<int32_t>();
   const int G = H / KV;
-  // single-position steps of small batches: the RMSNorm runs inside the weight-streaming GEMM (no launch, no bf16 round trip)
-  const bool rms_in_gemm = P.step && bf && rows <= 64 && d <= 1280 && d % 256 == 0 && !no_fuse;
+  // single-position steps of small batches (bf16): RMSNorm(x) W^T = rstd(x) (x W^T) -- the weight-streaming GEMM reads the raw residual
+  // rows (bf16 copy written by the producing GEMM), sums x^2 from the fragments it streams anyway and scales its output rows
+  const bool rms_in_gemm = P.step && bf && rows <= 64 && d % 256 == 0 && !no_fuse;
   const bool fused_attn = P.step && (G == 1 || G == 2 || G == 4) && !no_fuse;
-  auto rmsnorm = [&](const float* src) {
-    ProfScope ps(prof, "dec_norm", stream);
-    hipLaunchKernelGGL(qw_rmsnorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, stream, src, d, rows, d, (const float*)nullptr, c.rms_eps, h, d, (const int32_t*)nullptr);
-  };
-  auto normed_gemm = [&](const float* src, GemmArgs& g) {          // g = RMSNorm(src) W^T
-    if (rms_in_gemm) { g.ln_x = src; g.ld_ln_x = d; g.ln_eps = c.rms_eps; g.ln_rms = 1; }
-    else { rmsnorm(src); g.A = h; g.lda = d; }
+  T* xlo = d_xlo.as<T>();
+  T* x2lo = d_x2lo.as<T>();
+  auto normed_gemm = [&](const float* src, const T* src_lo, GemmArgs& g) {          // g = RMSNorm(src) W^T
+    if (rms_in_gemm) { g.A = src_lo; g.lda = d; g.a_rms_eps = c.rms_eps; }
+    else {
+      ProfScope ps(prof, "dec_norm", stream);
+      hipLaunchKernelGGL(qw_rmsnorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, stream, src, d, rows, d, (const float*)nullptr, c.rms_eps, h, d, (const int32_t*)nullptr);
+      g.A = h; g.lda = d;
+    }
     ProfScope ps(prof, "dec_gemm", stream);
     gemm(g);
   };
@@ -548,7 +544,7 @@ void QwSession::decoder_pass(const DecPass& P) {
     const QwDecLayer& L = dec[i];
     T* kc = d_kc.as<T>() + (size_t)i * layer_kv;
     T* vc = d_vc.as<T>() + (size_t)i * layer_kv;
-    { GemmArgs g; g.W = L.wqkv; g.ldw = d; g.M = rows; g.N = qkvn; g.K = d; g.out_f32 = qkv; g.ld_out_f32 = qkvn; normed_gemm(x, g); }
+    { GemmArgs g; g.W = L.wqkv; g.ldw = d; g.M = rows; g.N = qkvn; g.K = d; g.out_f32 = qkv; g.ld_out_f32 = qkvn; normed_gemm(x, xlo, g); }
     if (fused_attn) {
       ProfScope ps(prof, "dec_attn", stream);
       const size_t lds = (size_t)G * S * 4;
@@ -578,13 +574,16 @@ void QwSession::decoder_pass(const DecPass& P) {
     }
     { ProfScope ps(prof, "dec_gemm", stream);
       GemmArgs g; g.A = ctx; g.lda = H * hd; g.W = L.wo; g.ldw = H * hd; g.M = rows; g.N = d; g.K = H * hd; g.add = x; g.ld_add = d;
-      g.out_f32 = x2; g.ld_out_f32 = d; gemm(g); }
-    { GemmArgs g; g.W = L.gate_up; g.ldw = d; g.M = rows; g.N = 2 * I; g.K = d; g.out_lo = gu; g.ld_out_lo = 2 * I; normed_gemm(x2, g); }
+      g.out_f32 = x2; g.ld_out_f32 = d;
+      if (rms_in_gemm) { g.out_lo = x2lo; g.ld_out_lo = d; }
+      gemm(g); }
+    // gate|up rows are interleaved in the arena: the epilogue stores silu(gate) * up directly (:1322-1325)
+    { GemmArgs g; g.W = L.gate_up; g.ldw = d; g.M = rows; g.N = 2 * I; g.K = d; g.act = ACT_SWIGLU; g.out_lo = act; g.ld_out_lo = I; normed_gemm(x2, x2lo, g); }
     { ProfScope ps(prof, "dec_gemm", stream);
-      const size_t n = (size_t)rows * I;
-      hipLaunchKernelGGL(qw_silu_mul_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, gu, I, n, act);
       GemmArgs g2; g2.A = act; g2.lda = I; g2.W = L.down; g2.ldw = I; g2.M = rows; g2.N = d; g2.K = I; g2.add = x2; g2.ld_add = d;
-      g2.out_f32 = x; g2.ld_out_f32 = d; gemm(g2); }
+      g2.out_f32 = x; g2.ld_out_f32 = d;
+      if (rms_in_gemm) { g2.out_lo = xlo; g2.ld_out_lo = d; }
+      gemm(g2); }
   }
   // final RMSNorm (learned weight) of every sequence's last row, lm_head (:1331-1335)
   { ProfScope ps(prof, "dec_logits", stream);
@@ -853,13 +852,14 @@ void QwSession::prefill(const float* audio, int audio_mem, const int64_t* offs, 
   d_qkv.reserve((size_t)Mmax * qkvn * 4, stream);
   d_q.reserve((size_t)Mmax * Hq * hd * eT, stream);
   d_dctx.reserve((size_t)Mmax * Hq * hd * eT, stream);
-  d_gu.reserve((size_t)Mmax * 2 * I * eT, stream);
+  d_xlo.reserve(pad_rows(B) * d * eT, stream);
+  d_x2lo.reserve(pad_rows(B) * d * eT, stream);
   d_act.reserve((size_t)Mmax * I * eT, stream);
   d_last.reserve(pad_rows(B) * d * eT, stream);
   d_logits.reserve(pad_rows(B) * (size_t)vpad * 4, stream);
   d_next.reserve((size_t)std::max(B, 64) * 4, stream);
   { ProfScope ps(prof, "dec_embed", stream);
-    hipLaunchKernelGGL(qw_gather_prompt_kernel<T>, dim3(Md), dim3(256), 0, stream, d_src, (const T*)embed, d_aud_out.as<float>(), d, PAD, d_x.as<float>()); }
+    hipLaunchKernelGGL(qw_gather_prompt_kernel<T>, dim3(Md), dim3(256), 0, stream, d_src, (const T*)embed, d_aud_out.as<float>(), d, PAD, d_x.as<float>(), (T*)nullptr); }
   if (taps_enabled) save_tap("prompt", d_x.ptr, rows_d, d, d, 4);
   if (precision == ASR_PRECISION_BF16) {
     d_vt2.reserve((size_t)KV * hd * Md * eT, stream);
@@ -911,13 +911,13 @@ void QwSession::step(const int32_t* ids_host, int32_t* next_out, float* logits_o
   auto enqueue = [&] {
     { ProfScope ps(prof, "dec_embed", stream);
       hipLaunchKernelGGL(qw_gather_prompt_kernel<T>, dim3(B), dim3(256), 0, stream, (const int32_t*)d_next.ptr, (const T*)embed, (const float*)nullptr, d,
-                         INT32_MIN, d_x.as<float>()); }
+                         INT32_MIN, d_x.as<float>(), precision == ASR_PRECISION_BF16 ? d_xlo.as<T>() : (T*)nullptr); }
     decoder_pass<T>(P);
   };
   // every step reads its position from the device-side history counters => one captured graph replays for all of them
   const bool graphable = use_graph && !taps_enabled && !prof.enabled;
   uint64_t key = 1469598103934665603ull;
-  for (const void* q : {d_x.ptr, d_x2.ptr, d_dh.ptr, d_qkv.ptr, d_q.ptr, d_dctx.ptr, d_gu.ptr, d_act.ptr, d_last.ptr, d_logits.ptr, d_next.ptr, d_kc.ptr,
+  for (const void* q : {d_x.ptr, d_x2.ptr, d_dh.ptr, d_qkv.ptr, d_q.ptr, d_dctx.ptr, d_xlo.ptr, d_x2lo.ptr, d_act.ptr, d_last.ptr, d_logits.ptr, d_next.ptr, d_kc.ptr,
                         d_vc.ptr, d_hist.ptr, d_stepplan.ptr, d_skws.ptr, (void*)stream, (void*)(uintptr_t)B})
     key = (key ^ (uint64_t)(uintptr_t)q) * 1099511628211ull;
   if (graphable && dec_graph && key == dec_key) {

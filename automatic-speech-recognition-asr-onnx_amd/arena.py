@@ -539,7 +539,10 @@ def build_qwen_asr_arena(cfg, ck: dict, precision: int = PRECISION_BF16) -> np.n
     head = np.zeros((vpad, d), dtype=np.float32)
     head[:cfg.vocab] = ck["thinker.lm_head.weight"]
     w.weight("dec.lm_head", head, precision)
-    w.add("dec.inv_freq", (1.0 / (cfg.rope_theta ** (np.arange(0, cfg.d_head, 2, dtype=np.float32) / cfg.d_head))).astype(np.float32), DT_F32)
+    # rotary table [position][cos | sin] in f32, like the exporter's precomputed cos / sin buffers (:933-960)
+    inv_freq = (1.0 / (cfg.rope_theta ** (np.arange(0, cfg.d_head, 2, dtype=np.float32) / cfg.d_head))).astype(np.float32)
+    theta = np.arange(cfg.max_seq_len, dtype=np.float32)[:, None] * inv_freq[None, :]
+    w.add("dec.rope", np.concatenate([np.cos(theta), np.sin(theta)], 1).astype(np.float32), DT_F32)
     w.add("dec.final_norm", f32(ck[t + "norm.weight"]), DT_F32)
     sc = np.float32(float(cfg.d_head ** -0.25))
     for i in range(cfg.n_layers):

@@ -27,7 +27,7 @@ struct GemmArgs {
   void* out_t = nullptr; int ld_out_t = 0;
   // fused row arg-max over n < n_valid (CTC / LM head): partial (max, idx) per 64-column slab
   float* amax_val = nullptr; int32_t* amax_idx = nullptr; int n_valid = 0;
-  // Skinny path (M <= 64, decode): when ln_x is set, A is produced on the fly as LayerNorm(ln_x) -- every workgroup
+  // Skinny path (decode), M <= 32: when ln_x is set, A is produced on the fly as LayerNorm(ln_x) -- every workgroup
   // normalises the few activation rows itself (two-pass statistics in f32), so no separate LayerNorm launch and no bf16
   // round trip of the normalised rows through HBM. gamma/beta nullable (affine folded into W, Export_Whisper.py:215-225).
   const float* ln_x = nullptr; int ld_ln_x = 0; const float* ln_gamma = nullptr; const float* ln_beta = nullptr; float ln_eps = 1e-5f;

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void gemm_bf16_t144(con
 constexpr int SK_WAVES = 8;
 
 template <int MT>
-__global__ __launch_bounds__(512) void gemm_bf16_skinny(const GemmArgs g) {
+__global__ __launch_bounds__(512, MT == 4 ? 4 : 2) void gemm_bf16_skinny(const GemmArgs g) {   // 4 row tiles: <= 128 VGPRs so two workgroups share a CU
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fgrp = lane >> 4;
@@ -539,17 +539,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny(const GemmArgs g) {
   const int k_begin = (ks * SK_WAVES + wave) * kslice;
   const bf16_t* wp = reinterpret_cast<const bf16_t*>(g.W) + (size_t)(n0 + frow) * g.ldw + k_begin + fgrp * 8;
 
-  constexpr int U = 8;                                  // K-steps per trip: 8 x 16-byte weight loads in flight per lane
+  constexpr int U = MT >= 4 ? 4 : 8;                    // K-steps per trip: U x 16-byte weight loads in flight per lane (4 row tiles: fewer, to stay under 128 VGPRs => two workgroups per CU)
   // the weight stream does not depend on the activations: start it before the LayerNorm prologue
   bf16x8_t wf0[U];
 #pragma unroll
   for (int u = 0; u < U; ++u)
     if (u * 32 < kslice) wf0[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + u * 32));
 
+  // the residual term of the epilogue (wave w finishes row tiles w, w + 8) is requested now: its L2 round trip hides behind the stream
+  float4 addv[(MT + SK_WAVES - 1) / SK_WAVES];
+#pragma unroll
+  for (int t = 0; t < (MT + SK_WAVES - 1) / SK_WAVES; ++t) {
+    const int m = (wave + t * SK_WAVES) * 16 + frow;
+    addv[t] = (g.add && wave + t * SK_WAVES < MT && m < g.M) ? *reinterpret_cast<const float4*>(g.add + (size_t)m * g.ld_add + n0 + fgrp * 4)
+                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
   // ---- A source: bf16 rows, or LayerNorm(ln_x) built here into LDS as bf16 [MT*16][K]
   const bf16_t* A;
   int lda;
-  if constexpr (MT <= 4) {
+  if constexpr (MT <= 2) {                               // (<= 32 rows: beyond that every workgroup redoing all rows costs more than a launch)
     if (g.ln_x) {
       bf16_t* An = reinterpret_cast<bf16_t*>(smem + SK_WAVES * MT * 1024);
       // wave w normalises rows w, w+8, ...: ALL of its rows are fetched in one batch of float4 loads (one L2 round trip),
@@ -614,9 +623,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny(const GemmArgs g) {
   const bf16_t* ap = A + (size_t)frow * lda + k_begin + fgrp * 8;
 
   f32x4_t acc[MT];
-  float ss[MT];                                          // a_rms: sum of squares of this lane's A fragments, row i * 16 + frow
+  f32x4_t gram[MT];                                      // a_rms: A A^T of the row tile on the (idle) MFMA pipe; its diagonal is sum(x^2)
 #pragma unroll
-  for (int i = 0; i < MT; ++i) { acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; ss[i] = 0.f; }
+  for (int i = 0; i < MT; ++i) { acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; gram[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   const bool a_rms = g.a_rms_eps > 0.0f;
   for (int k = 0; k < kslice; k += 32 * U) {
     bf16x8_t wf[U];
@@ -632,15 +641,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny(const GemmArgs g) {
         for (int i = 0; i < MT; ++i) {
           const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(ap + (size_t)i * 16 * lda + k + u * 32);
           acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af, acc[i], 0, 0, 0);   // D[n = 4 fgrp + r][m = frow]
-          if (a_rms) {
-            union { bf16x8_t v; uint32_t w[4]; } q;
-            q.v = af;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float lo = __uint_as_float(q.w[e] << 16), hi = __uint_as_float(q.w[e] & 0xffff0000u);
-              ss[i] = fmaf(lo, lo, fmaf(hi, hi, ss[i]));
-            }
-          }
+          if (a_rms) gram[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, af, gram[i], 0, 0, 0);
         }
       }
     }
@@ -652,12 +653,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny(const GemmArgs g) {
   for (int i = 0; i < MT; ++i) red[(wave * MT + i) * 64 + lane] = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
   if (a_rms) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      float t = ss[i];
-      t += __shfl_xor(t, 16, 64);
-      t += __shfl_xor(t, 32, 64);
-      if (fgrp == 0) ss_red[wave][i * 16 + frow] = t;
-    }
+    for (int i = 0; i < MT; ++i)                          // D[4 fgrp + r][frow]: the diagonal entry of row frow sits in lane group frow / 4
+      if (fgrp == (frow >> 2)) ss_red[wave][i * 16 + frow] = gram[i][frow & 3];
   }
   __syncthreads();
   const int rows16 = MT * 16;
@@ -737,7 +734,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny(const GemmArgs g) {
       continue;
     }
     if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + n); sum.x += b.x; sum.y += b.y; sum.z += b.z; sum.w += b.w; }
-    if (g.add) { const float4 q = *reinterpret_cast<const float4*>(g.add + (size_t)m * g.ld_add + n); sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w; }
+    if (g.add) { const float4 q = addv[t]; sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w; }
     if (g.act != ACT_NONE) { sum.x = apply_act_rt(sum.x, g.act); sum.y = apply_act_rt(sum.y, g.act); sum.z = apply_act_rt(sum.z, g.act); sum.w = apply_act_rt(sum.w, g.act); }
     if (g.add2) {
       const float4 q = *reinterpret_cast<const float4*>(g.add2 + (size_t)(g.add2_rows ? g.add2_rows[m] : m) * g.ld_add2 + n);
@@ -1012,7 +1009,7 @@ bool gemm_ln_fusable(const GemmArgs& g) {
 }
 
 void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
-  if (g.ln_x) ASR_REQUIRE(g.M <= 64 && !g.A, "gemm: the fused LayerNorm prologue exists on the skinny (M <= 64) path only");
+  if (g.ln_x) ASR_REQUIRE(g.M <= 32 && !g.A, "gemm: the fused LayerNorm prologue exists on the skinny path for M <= 32 only");
   // 33..64 rows against a vocabulary-sized N: the 128 x 128 tiles re-read the activations 8 x less often than 16-column granules do
   // (lm_head 64 x 151936 x 1024: 76 us vs 240 us)
   const bool tall = g.M > 32 && g.N >= 16384 && !g.ln_x && g.a_rms_eps == 0.0f && g.act != ACT_SWIGLU;

@@ -11,6 +11,7 @@
 // appended in place and token ids / history lengths stay on the device between steps.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/asr_mi355x.h"
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void qw_rmsnorm_kernel(const float* __restrict
 // buffer, k / v -> the KV cache [layer-local base][seq][kv head][S][128] at that position (:1283-1309). One wave per (row, head).
 template <typename T>
 __global__ __launch_bounds__(256) void qw_qk_rope_kernel(const float* __restrict__ qkv, int n_heads, int n_kv, const float* __restrict__ qn,
-                                                         const float* __restrict__ kn, const float* __restrict__ inv_freq, float eps,
+                                                         const float* __restrict__ kn, const float* __restrict__ rope, float eps,
                                                          const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_t,
                                                          const int32_t* __restrict__ hist, int rows, T* __restrict__ q_out, T* __restrict__ kc,
                                                          T* __restrict__ vc, int S_max, T* __restrict__ k_rows) {
@@ -171,8 +172,7 @@ __global__ __launch_bounds__(256) void qw_qk_rope_kernel(const float* __restrict
   const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / (float)HD + eps);
   const float* w = hh < n_heads ? qn : kn;
   const float a0 = x0 * r * w[lane], a1 = x1 * r * w[lane + 64];
-  const float th = (float)pos * inv_freq[lane];
-  const float cs = cosf(th), sn = sinf(th);
+  const float cs = rope[(size_t)pos * HD + lane], sn = rope[(size_t)pos * HD + 64 + lane];
   const float y0 = a0 * cs - a1 * sn, y1 = a1 * cs + a0 * sn;
   T* dst = hh < n_heads ? q_out + (size_t)row * n_heads * HD + hh * HD
                         : kc + (((size_t)b * n_kv + (hh - n_heads)) * S_max + pos) * HD;
@@ -234,145 +234,189 @@ __global__ __launch_bounds__(128) void qw_attn_kernel(const T* __restrict__ q, i
   }
 }
 
+// sum over the 16 lanes of a DPP row in four VALU moves (xor 1, xor 2, mirror within 8, mirror within 16): no LDS-crossbar shuffles
+__device__ __forceinline__ float dpp_sum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+  return v;
+}
+
+// 8 consecutive elements of a cache row, kept raw in registers while the load is in flight
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+  uint4 r;
+  __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void unpack(float* o) const {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[2 * e] = __uint_as_float(w[e] << 16); o[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+  }
+};
+template <> struct Raw8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+  __device__ __forceinline__ void unpack(float* o) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
+};
+
 // One decode position per sequence, everything between the q|k|v GEMM and the o_proj GEMM in one launch: workgroup = (sequence,
-// kv head), 4 waves. Waves first finish the new position -- per-head RMSNorm + RoPE of k (-> cache), v (-> cache) and of the
-// group's q heads (-> LDS) -- then run soft-max attention of those q heads over the cache: 16 lanes share a key (8 head-dim
-// elements each, one coalesced 256-byte row per 16 lanes), so K and V are read once per kv head and serve the whole GQA group.
+// kv head), 4 waves. The cache rows of the first key block are requested before anything else, so the HBM round trip overlaps
+// the new position's work -- per-head RMSNorm + RoPE of k (-> cache, LDS), v (-> cache, LDS) and of the group's q heads (-> LDS).
+// Attention: 16 lanes share a key (8 head-dim elements each: one coalesced 256-byte row per 16 lanes), every 16-lane group keeps
+// its own online soft-max state over keys s = 16 j + group, blocks of KPI keys per group are double-buffered in registers, and
+// the 16 partial states merge through LDS. K and V are read once per kv head and serve the whole GQA group.
 template <typename T, int G>
 __global__ __launch_bounds__(256) void qw_decode_attn_kernel(const float* __restrict__ qkv, int n_heads, int n_kv, const float* __restrict__ qn,
-                                                             const float* __restrict__ kn, const float* __restrict__ inv_freq, float eps,
+                                                             const float* __restrict__ kn, const float* __restrict__ rope, float eps,
                                                              const int32_t* __restrict__ hist, T* __restrict__ kc, T* __restrict__ vc, int S_max,
                                                              T* __restrict__ ctx) {
-  constexpr int HD = 128;
-  extern __shared__ float qw_dsc[];                      // [G][S_max] scores / probabilities
+  constexpr int HD = 128, KPI = 4, NTASK = (2 + G + 3) / 4;
   __shared__ float qsh[G][HD];
-  __shared__ float part[4][G][HD];
-  __shared__ float red[4][G];
+  __shared__ float knew[HD], vnew[HD];
+  __shared__ float pm[16][G], pl[16][G];
+  __shared__ float pacc[16][G][HD];
   const int b = blockIdx.x, kvh = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pos = hist[b], nk = pos + 1;
+  const int pos = hist[b];                               // keys [0, pos) are in the cache; key pos is made here
   const int heads = n_heads + 2 * n_kv;
   T* K = kc + ((size_t)b * n_kv + kvh) * S_max * HD;
   T* V = vc + ((size_t)b * n_kv + kvh) * S_max * HD;
   const float* row = qkv + (size_t)b * heads * HD;
-  // ---- the new position: task 0 = k, 1 = v, 2.. = the group's q heads
-  for (int task = wave; task < 2 + G; task += 4) {
+  const int lg = lane >> 4, li = lane & 15, gid = wave * 4 + lg;
+  // ---- requests: the new position's inputs first (L2), then the first block of cache rows (HBM)
+  float x0[NTASK], x1[NTASK];
+#pragma unroll
+  for (int t = 0; t < NTASK; ++t) {
+    const int task = wave + 4 * t;
     const int hh = task == 0 ? n_heads + kvh : task == 1 ? n_heads + n_kv + kvh : kvh * G + (task - 2);
-    const float x0 = row[hh * HD + lane], x1 = row[hh * HD + lane + 64];
+    if (task < 2 + G) { x0[t] = row[hh * HD + lane]; x1[t] = row[hh * HD + lane + 64]; }
+  }
+  Raw8<T> kb[KPI], vb[KPI];
+#pragma unroll
+  for (int u = 0; u < KPI; ++u) {
+    const int s = u * 16 + gid;
+    if (s < pos) { kb[u].load(K + (size_t)s * HD + li * 8); vb[u].load(V + (size_t)s * HD + li * 8); }
+  }
+  // ---- the new position: task 0 = k, 1 = v, 2.. = the group's q heads
+  const float cs = rope[(size_t)pos * HD + lane], sn = rope[(size_t)pos * HD + 64 + lane];
+#pragma unroll
+  for (int t = 0; t < NTASK; ++t) {
+    const int task = wave + 4 * t;
+    if (task >= 2 + G) continue;
+    T t0, t1;
     if (task == 1) {
-      Elem<T>::store(V + (size_t)pos * HD + lane, x0);
-      Elem<T>::store(V + (size_t)pos * HD + lane + 64, x1);
+      Elem<T>::store(&t0, x0[t]);
+      Elem<T>::store(&t1, x1[t]);
+      V[(size_t)pos * HD + lane] = t0;
+      V[(size_t)pos * HD + lane + 64] = t1;
+      vnew[lane] = Elem<T>::load(&t0);
+      vnew[lane + 64] = Elem<T>::load(&t1);
       continue;
     }
-    const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / (float)HD + eps);
+    const float r = rsqrtf(wave_sum(x0[t] * x0[t] + x1[t] * x1[t]) / (float)HD + eps);
     const float* w = task == 0 ? kn : qn;
-    const float a0 = x0 * r * w[lane], a1 = x1 * r * w[lane + 64];
-    const float th = (float)pos * inv_freq[lane];
-    const float cs = cosf(th), sn = sinf(th);
-    const float y0 = a0 * cs - a1 * sn, y1 = a1 * cs + a0 * sn;
-    if (task == 0) {
-      Elem<T>::store(K + (size_t)pos * HD + lane, y0);
-      Elem<T>::store(K + (size_t)pos * HD + lane + 64, y1);
-    } else {                                             // through the operand dtype, like the unfused path
-      T t0, t1;
-      Elem<T>::store(&t0, y0);
-      Elem<T>::store(&t1, y1);
-      qsh[task - 2][lane] = Elem<T>::load(&t0);
-      qsh[task - 2][lane + 64] = Elem<T>::load(&t1);
-    }
+    const float a0 = x0[t] * r * w[lane], a1 = x1[t] * r * w[lane + 64];
+    Elem<T>::store(&t0, a0 * cs - a1 * sn);              // through the operand dtype, like the unfused path
+    Elem<T>::store(&t1, a1 * cs + a0 * sn);
+    float* dst = task == 0 ? knew : qsh[task - 2];
+    dst[lane] = Elem<T>::load(&t0);
+    dst[lane + 64] = Elem<T>::load(&t1);
+    if (task == 0) { K[(size_t)pos * HD + lane] = t0; K[(size_t)pos * HD + lane + 64] = t1; }
   }
   __syncthreads();
-  // ---- scores: lane group (wave, lane >> 4) takes keys s = 16 i + 4 wave + (lane >> 4); 4 keys in flight per group
-  const int lg = lane >> 4, li = lane & 15, kslot = wave * 4 + lg;
-  float qr[G][8];
+  float qr[G][8], m[G], l[G], acc[G][8];
 #pragma unroll
-  for (int g = 0; g < G; ++g)
+  for (int g = 0; g < G; ++g) {
+    m[g] = -INFINITY; l[g] = 0.0f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qr[g][e] = qsh[g][li * 8 + e];
-  float mx[G];
+    for (int e = 0; e < 8; ++e) { qr[g][e] = qsh[g][li * 8 + e]; acc[g][e] = 0.0f; }
+  }
+  // one block of NB keys of this 16-lane group: all the dot products first (independent chains), one soft-max rescale per block
+  auto block = [&](const float (*k8)[8], const float (*v8)[8], const bool* valid, auto nb_tag) {
+    constexpr int NB = decltype(nb_tag)::value;
+    float sc[NB][G];
 #pragma unroll
-  for (int g = 0; g < G; ++g) mx[g] = -INFINITY;
-  for (int s0 = kslot; s0 < nk; s0 += 64) {
-    float kv8[4][8];
+    for (int u = 0; u < NB; ++u)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int s = s0 + 16 * u;
-      if (s < nk) load8<T>(K + (size_t)s * HD + li * 8, kv8[u]);
-    }
+      for (int g = 0; g < G; ++g) {
+        float t = 0.0f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int s = s0 + 16 * u;
-      if (s < nk) {                                      // uniform per 16-lane group
+        for (int e = 0; e < 8; ++e) t = fmaf(qr[g][e], k8[u][e], t);
+        sc[u][g] = t;
+      }
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          float acc = 0.0f;
+    for (int u = 0; u < NB; ++u)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc = fmaf(qr[g][e], kv8[u][e], acc);
-          acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64); acc += __shfl_xor(acc, 8, 64);
-          if (li == 0) qw_dsc[g * S_max + s] = acc;
-          mx[g] = fmaxf(mx[g], acc);
-        }
+      for (int g = 0; g < G; ++g) sc[u][g] = dpp_sum16(sc[u][g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float mn = m[g];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) if (valid[u]) mn = fmaxf(mn, sc[u][g]);
+      const float scale = m[g] == -INFINITY ? 0.0f : __expf(m[g] - mn);
+      m[g] = mn;
+      l[g] *= scale;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[g][e] *= scale;
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const float p = valid[u] ? __expf(sc[u][g] - mn) : 0.0f;
+        l[g] += p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(p, v8[u][e], acc[g][e]);
       }
     }
-  }
+  };
+  for (int s0 = 0; s0 < pos; s0 += 16 * KPI) {
+    Raw8<T> kn2[KPI], vn2[KPI];
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const float m = wave_max(mx[g]);
-    if (lane == 0) red[wave][g] = m;
-  }
-  __syncthreads();
-  float sum[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    mx[g] = fmaxf(fmaxf(red[0][g], red[1][g]), fmaxf(red[2][g], red[3][g]));
-    sum[g] = 0.0f;
-    for (int s = tid; s < nk; s += 256) { const float e = expf(qw_dsc[g * S_max + s] - mx[g]); qw_dsc[g * S_max + s] = e; sum[g] += e; }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const float t = wave_sum(sum[g]);
-    if (lane == 0) red[wave][g] = t;
-  }
-  // ---- P V: same key assignment, 8 head-dim columns per lane
-  float acc[G][8];
-#pragma unroll
-  for (int g = 0; g < G; ++g)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[g][e] = 0.0f;
-  for (int s0 = kslot; s0 < nk; s0 += 64) {
-    float v8[4][8];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int s = s0 + 16 * u;
-      if (s < nk) load8<T>(V + (size_t)s * HD + li * 8, v8[u]);
+    for (int u = 0; u < KPI; ++u) {                      // next block's rows while this one is consumed
+      const int s = s0 + (KPI + u) * 16 + gid;
+      if (s < pos) { kn2[u].load(K + (size_t)s * HD + li * 8); vn2[u].load(V + (size_t)s * HD + li * 8); }
     }
+    float k8[KPI][8], v8[KPI][8];
+    bool valid[KPI];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int s = s0 + 16 * u;
-      if (s < nk) {
+    for (int u = 0; u < KPI; ++u) {
+      valid[u] = s0 + u * 16 + gid < pos;                // uniform per 16-lane group
+      if (valid[u]) { kb[u].unpack(k8[u]); vb[u].unpack(v8[u]); }
+      else {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const float p = qw_dsc[g * S_max + s];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(p, v8[u][e], acc[g][e]);
-        }
+        for (int e = 0; e < 8; ++e) { k8[u][e] = 0.0f; v8[u][e] = 0.0f; }
       }
     }
+    block(k8, v8, valid, std::integral_constant<int, KPI>{});
+#pragma unroll
+    for (int u = 0; u < KPI; ++u) { kb[u] = kn2[u]; vb[u] = vn2[u]; }
   }
+  {                                                      // the new key / value, from LDS (group 0 only)
+    float k8[1][8], v8[1][8];
+    const bool valid[1] = {gid == 0};
 #pragma unroll
-  for (int g = 0; g < G; ++g)
+    for (int e = 0; e < 8; ++e) { k8[0][e] = knew[li * 8 + e]; v8[0][e] = vnew[li * 8 + e]; }
+    block(k8, v8, valid, std::integral_constant<int, 1>{});
+  }
+  // ---- merge the 16 partial soft-max states
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = acc[g][e];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (lg == 0) part[wave][g][li * 8 + e] = v;
-    }
+  for (int g = 0; g < G; ++g) {
+    if (li == 0) { pm[gid][g] = m[g]; pl[gid][g] = l[g]; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pacc[gid][g][li * 8 + e] = acc[g][e];
+  }
   __syncthreads();
   for (int i = tid; i < G * HD; i += 256) {
     const int g = i / HD, e = i - g * HD;
-    const float inv = 1.0f / (red[0][g] + red[1][g] + red[2][g] + red[3][g]);
-    Elem<T>::store(ctx + (size_t)b * n_heads * HD + (kvh * G + g) * HD + e, (part[0][g][e] + part[1][g][e] + part[2][g][e] + part[3][g][e]) * inv);
+    float mx = pm[0][g];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) mx = fmaxf(mx, pm[q][g]);
+    float num = 0.0f, den = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float w = __expf(pm[q][g] - mx);
+      num = fmaf(pacc[q][g][e], w, num);
+      den = fmaf(pl[q][g], w, den);
+    }
+    Elem<T>::store(ctx + (size_t)b * n_heads * HD + (kvh * G + g) * HD + e, num / den);
   }
 }
 
@@ -411,7 +455,7 @@ struct QwSession : asr_session {
   std::vector<QwEncLayer> enc;
   std::vector<QwDecLayer> dec;
   const float *dft = nullptr, *melp = nullptr, *conv1_b = nullptr, *conv2_b = nullptr, *conv3_b = nullptr, *enc_pos = nullptr,
-              *proj1_b = nullptr, *proj2_b = nullptr, *inv_freq = nullptr, *final_norm = nullptr;
+              *proj1_b = nullptr, *proj2_b = nullptr, *rope = nullptr, *final_norm = nullptr;
   const void *conv1_w = nullptr, *conv2_w = nullptr, *conv3_w = nullptr, *conv_out_w = nullptr, *proj1_w = nullptr, *proj2_w = nullptr,
              *embed = nullptr, *lm_head = nullptr;
   int batch = 0;
@@ -497,7 +541,7 @@ void QwSession::init() {
   proj2_w = W("enc.proj2_w", {d, de});    proj2_b = F("enc.proj2_b", {d});
   embed = W("dec.embed", {vpad, d});
   lm_head = W("dec.lm_head", {vpad, d});
-  inv_freq = F("dec.inv_freq", {c.d_head / 2});
+  rope = F("dec.rope", {c.max_seq_len, c.d_head});             // [position][cos(64) | sin(64)] (ROTARY_MASK_PREFILL tables, :933-1002)
   final_norm = F("dec.final_norm", {d});
   dec.resize(c.n_layers);
   for (int i = 0; i < c.n_layers; ++i) {
@@ -547,10 +591,10 @@ void QwSession::decoder_pass(const DecPass& P) {
     { GemmArgs g; g.W = L.wqkv; g.ldw = d; g.M = rows; g.N = qkvn; g.K = d; g.out_f32 = qkv; g.ld_out_f32 = qkvn; normed_gemm(x, xlo, g); }
     if (fused_attn) {
       ProfScope ps(prof, "dec_attn", stream);
-      const size_t lds = (size_t)G * S * 4;
-      if (G == 1) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 1>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, inv_freq, c.rms_eps, hist, kc, vc, S, ctx);
-      else if (G == 2) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 2>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, inv_freq, c.rms_eps, hist, kc, vc, S, ctx);
-      else hipLaunchKernelGGL((qw_decode_attn_kernel<T, 4>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, inv_freq, c.rms_eps, hist, kc, vc, S, ctx);
+      const size_t lds = 0;
+      if (G == 1) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 1>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx);
+      else if (G == 2) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 2>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx);
+      else hipLaunchKernelGGL((qw_decode_attn_kernel<T, 4>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx);
     } else {
       const bool mfma_attn = bf && !P.step && P.n_qb > 0;
       if (mfma_attn) {                                   // V^T for the MFMA attention kernel (the cache gets V from the q|k|v GEMM)
@@ -560,7 +604,7 @@ void QwSession::decoder_pass(const DecPass& P) {
       }
       { ProfScope ps(prof, "dec_rope", stream);
         const int waves = rows * (H + 2 * KV);
-        hipLaunchKernelGGL(qw_qk_rope_kernel<T>, dim3((waves + 3) / 4), dim3(256), 0, stream, qkv, H, KV, L.qn, L.kn, inv_freq, c.rms_eps, P.row_seq, P.row_t,
+        hipLaunchKernelGGL(qw_qk_rope_kernel<T>, dim3((waves + 3) / 4), dim3(256), 0, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, P.row_seq, P.row_t,
                            hist, rows, q, kc, vc, S, mfma_attn ? d_krows.as<T>() : (T*)nullptr); }
       ProfScope ps(prof, "dec_attn", stream);
       if (mfma_attn) {

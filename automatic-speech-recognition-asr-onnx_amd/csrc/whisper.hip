@@ -360,7 +360,7 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
   { ProfScope ps(prof, "dec_embed", stream); launch_embed_pos<T>(ids_dev, R, n, hist, hd, (const T*)embed, dec_pos, d, xa, stream); }
   const size_t cache_l = (size_t)B * H * c.max_target_positions * 64;
   // bf16 mode, M <= 64 rows: the (affine-less) LayerNorm runs inside the skinny GEMM's prologue
-  const bool fuse_ln = precision == ASR_PRECISION_BF16 && R <= 64 && d % 256 == 0;
+  const bool fuse_ln = precision == ASR_PRECISION_BF16 && R <= 32 && d % 256 == 0;   // above 32 rows a separate LayerNorm launch is cheaper
   auto ln_gemm = [&](const float* x, GemmArgs& g) {
     if (fuse_ln) { g.A = nullptr; g.ln_x = x; g.ld_ln_x = d; }
     else { ProfScope ps(prof, "dec_layernorm", stream); launch_layernorm<T>(x, d, R, d, nullptr, nullptr, 1e-5f, hh, d, d, stream); g.A = hh; g.lda = d; }
@@ -428,7 +428,7 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
     ProfScope ps(prof, "dec_logits", stream);
     GemmArgs g;
     g.W = embed; g.ldw = d; g.M = B; g.N = vpad; g.K = d; g.bias = suppress; g.out_f32 = d_logits.as<float>(); g.ld_out_f32 = vpad;
-    if (precision == ASR_PRECISION_BF16 && B <= 64 && d % 256 == 0) {
+    if (precision == ASR_PRECISION_BF16 && B <= 32 && d % 256 == 0) {
       g.ln_x = xa + (size_t)(n - 1) * d; g.ld_ln_x = n * d; g.ln_gamma = dec_ln_g; g.ln_beta = dec_ln_b;
     } else {
       launch_layernorm<T>(xa + (size_t)(n - 1) * d, n * d, B, d, dec_ln_g, dec_ln_b, 1e-5f, hl, d, d, stream);

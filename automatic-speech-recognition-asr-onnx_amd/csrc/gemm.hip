@@ -528,8 +528,8 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void gemm_bf16_t144(con
 // for the bias / residual / store epilogue. With g.ln_x the A rows are LayerNorm(ln_x) computed in the prologue.
 constexpr int SK_WAVES = 8;
 
-template <int MT>
-__global__ __launch_bounds__(512, MT == 4 ? 4 : 2) void gemm_bf16_skinny(const GemmArgs g) {   // 4 row tiles: <= 128 VGPRs so two workgroups share a CU
+template <int MT, bool LN>     // LN: the LayerNorm prologue (own instance: its registers / LDS allow one workgroup per CU only)
+__global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_bf16_skinny(const GemmArgs g) {   // <= 128 VGPRs: two workgroups share a CU
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fgrp = lane >> 4;
@@ -558,8 +558,8 @@ __global__ __launch_bounds__(512, MT == 4 ? 4 : 2) void gemm_bf16_skinny(const G
   // ---- A source: bf16 rows, or LayerNorm(ln_x) built here into LDS as bf16 [MT*16][K]
   const bf16_t* A;
   int lda;
-  if constexpr (MT <= 2) {                               // (<= 32 rows: beyond that every workgroup redoing all rows costs more than a launch)
-    if (g.ln_x) {
+  if constexpr (LN) {                                    // (<= 32 rows: beyond that every workgroup redoing all rows costs more than a launch)
+    {
       bf16_t* An = reinterpret_cast<bf16_t*>(smem + SK_WAVES * MT * 1024);
       // wave w normalises rows w, w+8, ...: ALL of its rows are fetched in one batch of float4 loads (one L2 round trip),
       // then mean / variance / output come from registers.
@@ -612,9 +612,6 @@ __global__ __launch_bounds__(512, MT == 4 ? 4 : 2) void gemm_bf16_skinny(const G
       __syncthreads();
       A = An;
       lda = g.K;
-    } else {
-      A = reinterpret_cast<const bf16_t*>(g.A);
-      lda = g.lda;
     }
   } else {
     A = reinterpret_cast<const bf16_t*>(g.A);
@@ -771,12 +768,21 @@ void launch_skinny(const GemmArgs& g, hipStream_t s) {
   ASR_REQUIRE(lds <= 160 * 1024, "gemm(skinny): LayerNorm prologue needs %zu bytes of LDS", lds);
   static size_t attr = 0;
   if (lds > attr) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny<MT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+    if constexpr (MT <= 2)
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny<MT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
     attr = 160 * 1024;
   }
   GemmArgs gg = g;
   gg.sk_splits = skinny_splits(g, MT * 16);
-  hipLaunchKernelGGL(gemm_bf16_skinny<MT>, dim3(g.N / 16, gg.sk_splits), dim3(64 * SK_WAVES), lds, s, gg);
+  if constexpr (MT <= 2) {
+    if (g.ln_x) {
+      hipLaunchKernelGGL((gemm_bf16_skinny<MT, true>), dim3(g.N / 16, gg.sk_splits), dim3(64 * SK_WAVES), lds, s, gg);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
+  }
+  hipLaunchKernelGGL((gemm_bf16_skinny<MT, false>), dim3(g.N / 16, gg.sk_splits), dim3(64 * SK_WAVES), lds, s, gg);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -362,7 +362,9 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
   // bf16 mode, M <= 64 rows: the (affine-less) LayerNorm runs inside the skinny GEMM's prologue
   const bool fuse_ln = precision == ASR_PRECISION_BF16 && R <= 32 && d % 256 == 0;   // above 32 rows a separate LayerNorm launch is cheaper
   auto ln_gemm = [&](const float* x, GemmArgs& g) {
-    if (fuse_ln) { g.A = nullptr; g.ln_x = x; g.ld_ln_x = d; }
+    // the prologue's registers / LDS hold one workgroup per CU: outputs wider than the chip (N / 16 > 256 workgroups, fc1) are faster
+    // behind a separate LayerNorm launch, with two plain workgroups sharing a CU
+    if (fuse_ln && (R <= 16 || g.N / 16 <= 256)) { g.A = nullptr; g.ln_x = x; g.ld_ln_x = d; }
     else { ProfScope ps(prof, "dec_layernorm", stream); launch_layernorm<T>(x, d, R, d, nullptr, nullptr, 1e-5f, hh, d, d, stream); g.A = hh; g.lda = d; }
     ProfScope ps(prof, "dec_gemm", stream);
     gemm(g);

@@ -3,7 +3,7 @@ import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 g = collections.defaultdict(list)
 for r in rows:
-    g[(r["Kernel_Name"].split("(")[0][-60:], r["Grid_Size_X"], r["Grid_Size_Y"], r["Workgroup_Size_X"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    g[(r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0][:60], r["Grid_Size_X"], r["Grid_Size_Y"], r["Workgroup_Size_X"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 tot = sum(sum(v) for v in g.values())
 for k, v in sorted(g.items(), key=lambda kv: -sum(kv[1])):
     v.sort()

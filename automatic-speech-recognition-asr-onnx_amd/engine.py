@@ -559,4 +559,6 @@ def load_session(path: str, device_id: int = 0):
         return ParaformerSession(cfgm.ParaformerConfig(**conf), blob, prec, device_id)
     if kind == "whisper":
         return WhisperSession(cfgm.WhisperConfig(**conf), blob, prec, device_id)
+    if kind == "qwen_asr":
+        return QwenAsrSession(cfgm.QwenAsrConfig(**conf), blob, prec, device_id)
     raise ValueError(f"{path!r}: no native session for bundle kind {kind!r}")

@@ -587,16 +587,20 @@ def main_qwen(args):
     B = args.batch
     n_samples = int(args.seconds * cfg.sample_rate)
     n_tok = args.decode_tokens or int(round(4 * args.seconds))
-    blob = None
+    blob = ck = None
     if rank == 0:
-        blob = arena.build_qwen_asr_arena(cfg, ckm.synth_qwen_asr_checkpoint(cfg, seed=0), arena.PRECISION_BF16)
+        ck = ckm.synth_qwen_asr_checkpoint(cfg, seed=0)
+        blob = arena.build_qwen_asr_arena(cfg, ck, arena.PRECISION_BF16)
+        if world > 1 or args.no_cpu_baseline:
+            ck = None
     t0 = time.perf_counter()
     arena_dev = dp.broadcast_arena(blob, device)
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t0
     blob = None
     sess = eng.QwenAsrSession(cfg, arena_dev, arena.PRECISION_BF16, local_rank, arena_device_ptr=arena_dev.data_ptr(), arena_bytes=arena_dev.numel())
-    audio_dev = torch.from_numpy(ckm.synth_audio("unit", B, n_samples, seed=1234 + rank)).to(device)
+    audio_np = ckm.synth_audio("unit", B, n_samples, seed=1234 + rank)
+    audio_dev = torch.from_numpy(audio_np).to(device)
     offsets = np.arange(B + 1, dtype=np.int64) * n_samples
     # prompt geometry of the reference host: head (3) + suffix (6) ids before the audio, tail (8) + language tail (2) after it
     pre, post = [list(range(1000, 1009))], [list(range(2000, 2010))]
@@ -672,6 +676,21 @@ def main_qwen(args):
                                 "frac": round(step_bytes / per_tok / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels": kernels, "arena_broadcast_s": round(t_bcast, 3),
         }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.qwen_asr_oracle import QwenAsrOracle
+            orc = QwenAsrOracle(cfg, ck, pre[0][:3], post[0], pre[0][3:])          # CHECKER ONLY: the CPU restatement, batch 1 like the reference
+            torch.set_num_threads(min(32, os.cpu_count() or 8))
+            n_done, t1 = 0, time.perf_counter()
+            while True:
+                orc.greedy(audio_np[n_done % B, 0], n_tok)
+                n_done += 1
+                el = time.perf_counter() - t1
+                if el >= 15.0 or n_done >= 16:
+                    break
+            out["cpu_baseline"] = {"value": round(n_done * args.seconds / el, 2), "unit": "audio-s/s", "cores": int(torch.get_num_threads()),
+                                   "host_cores": int(os.cpu_count() or 0), "kind": "port",
+                                   "sample": f"{n_done} x {args.seconds:g} s utterances, batch 1, prefill + {n_tok - 1} decode steps, torch-CPU f32 oracle "
+                                             f"(oracle/qwen_asr_oracle.py), {el:.1f} s wall"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

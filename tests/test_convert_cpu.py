@@ -62,3 +62,22 @@ def test_paraformer_needs_tokens_and_cmvn(tmp_path):
     got = cc.convert("paraformer", dict(ck), str(tmp_path / "o3"), 0, tokens=toks)
     assert (got.n_enc, got.n_dec, got.n_dec3, got.vocab) == (cfg.n_enc, cfg.n_dec, cfg.n_dec3, cfg.vocab)
     assert open(tmp_path / "o3" / "Vocab_Paraformer.txt", encoding="utf-8").read().splitlines()[:3] == ["<blank>", "<s>", "</s>"]
+
+
+def test_qwen_asr_safetensors_roundtrip(tmp_path):
+    import pytest
+    from safetensors.numpy import save_file
+    cfgm, ckm = sub("config"), sub("checkpoints")
+    cfg = cfgm.qwen_asr_mid()
+    ck = ckm.synth_qwen_asr_checkpoint(cfg, 0)
+    save_file({k: np.ascontiguousarray(v) for k, v in ck.items()}, str(tmp_path / "model.safetensors"))
+    sd = cc.load_state_dict(str(tmp_path / "model.safetensors"))
+    with pytest.raises(ValueError, match="metadata"):
+        cc.convert("qwen_asr", dict(sd), str(tmp_path / "o1"), 0)
+    meta = {"audio_pcm_scale": "32768", "max_seq_len": "1024", "sample_rate": "16000", "special_token_ids": "{}", "supported_languages": "{}"}
+    got = cc.convert("qwen_asr", sd, str(tmp_path / "out"), 0, tokens=meta)
+    for f in ("enc_d", "enc_heads", "enc_ffn", "n_enc_layers", "conv_channels", "d_model", "n_heads", "n_kv_heads", "d_head", "d_ffn", "n_layers", "vocab"):
+        assert getattr(got, f) == getattr(cfg, f), f
+    info, blob = sub("ort_shim").load_model(str(tmp_path / "out" / "Qwen_ASR.asrmodel"))
+    assert info["kind"] == "qwen_asr" and info["metadata"]["max_seq_len"] == "1024"
+    assert np.array_equal(blob, sub("arena").build_qwen_asr_arena(got, ck, 0))

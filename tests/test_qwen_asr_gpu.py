@@ -112,3 +112,38 @@ def test_bad_arguments_fail_loudly():
         sess.prefill([a[:100]], [[1]], [[1]])
     with pytest.raises(Exception, match="max_seq_len"):
         sess.prefill([a], [[1] * cfg.max_seq_len], [[1]])
+
+
+def test_transcriber_matches_reference_goldens():
+    """The host mirror (prompt assembly from the metadata map, language tail, generation limit, stop handling) drives the same
+    prompts the goldens were minted with: [head | system-prompt ids | suffix | audio | tail + "language " | language tail]."""
+    g = load_golden("qwen_asr_tiny")
+    cfg, ck = qwen_setup(g)
+    sess = sub("engine").QwenAsrSession.from_checkpoint(cfg, ck, precision=F32)
+    special = {"stop": [1, 521], "asr_text": [540], "audio_start": 524, "audio_end": 520, "audio_pad": 525, "im_start": 510, "im_end": 521,
+               "system": 511, "user": 523, "assistant": 522, "newline": 512, "language_prefix": [530, 531]}
+    langs = {"en": {"name": "English", "aliases": ["english"], "prompt_token_ids": [77, 540]},
+             "zh": {"name": "Chinese", "aliases": ["chinese"], "prompt_token_ids": [78, 540]}}
+    meta = {"audio_pcm_scale": "32768", "max_seq_len": str(cfg.max_seq_len), "sample_rate": "16000", "special_token_ids": special,
+            "supported_languages": langs}
+    q = sub("qwen_asr")
+    tr = q.QwenAsrTranscriber(cfg, sess, meta)
+    assert (tr.head_ids, tr.suffix_ids, tr.tail_ids) == (g["head_ids"].tolist(), g["suffix_ids"].tolist(), g["tail_ids"].tolist())
+    cases = [c for _, c in golden_cases(g)]
+    lang_of = {(): "", (77, 540): "English", (78, 540): "zh"}
+    clips = [np.round(unit_audio(c["audio_seed"], c["n_samples"]) * 32768.0).astype(np.int16) for c in cases]
+    out, stats = tr.transcribe([c for c in clips], task_prompts=[c["query_ids"].tolist() for c in cases],
+                               language_prompts=[lang_of[tuple(c["language_tail_ids"].tolist())] for c in cases], max_new=int(g["n_new"]))
+    assert stats["rtf"] > 0
+    for b, c in enumerate(cases):
+        assert out[b]["prompt_tokens"] == int(c["ids_len"]), b
+    # exact-float run for the token comparison
+    pre = [tr.head_ids + c["query_ids"].tolist() + tr.suffix_ids for c in cases]
+    post = [tr.tail_ids + c["language_tail_ids"].tolist() for c in cases]
+    sess.prefill([unit_audio(c["audio_seed"], c["n_samples"]) for c in cases], pre, post, want_logits=False)
+    toks = sess.generate(int(g["n_new"]), stop_ids=tr.stop)
+    for b, c in enumerate(cases):
+        if (c["margin"] > 2 * TOL_F32).all():
+            want = c["token_ids"].tolist()
+            cut = next((i for i, t in enumerate(want) if t in tr.stop), len(want))
+            assert toks[b].tolist() == want[:cut], b

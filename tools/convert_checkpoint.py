@@ -103,6 +103,22 @@ def convert(family: str, sd: dict, out: str, precision: int, cmvn=None, tokens=N
         os.makedirs(out, exist_ok=True)
         blob = arena.build_whisper_arena(cfg, sd, precision, ckm.whisper_suppress_tokens(cfg), ckm.whisper_begin_suppress_tokens(cfg))
         shim.save_model(os.path.join(out, "Whisper.asrmodel"), "whisper", cfg.to_dict(), blob, {}, precision)
+    elif family == "qwen_asr":
+        a, t = "thinker.audio_tower.", "thinker.model."
+        de, d = sd[a + "ln_post.weight"].shape[0], sd[t + "norm.weight"].shape[0]
+        hd = sd[t + "layers.0.self_attn.q_norm.weight"].shape[0]
+        cfg = cfgm.QwenAsrConfig(enc_d=de, enc_heads=de // 64, enc_ffn=sd[a + "layers.0.fc1.weight"].shape[0],
+                                 n_enc_layers=_count(sd, r"thinker\.audio_tower\.layers\.(\d+)\."), conv_channels=sd[a + "conv2d1.weight"].shape[0],
+                                 d_model=d, d_head=hd, n_heads=sd[t + "layers.0.self_attn.q_proj.weight"].shape[0] // hd,
+                                 n_kv_heads=sd[t + "layers.0.self_attn.k_proj.weight"].shape[0] // hd,
+                                 d_ffn=sd[t + "layers.0.mlp.gate_proj.weight"].shape[0], n_layers=_count(sd, r"thinker\.model\.layers\.(\d+)\."),
+                                 vocab=sd[t + "embed_tokens.weight"].shape[0])
+        if "thinker.lm_head.weight" not in sd:                       # tied embeddings
+            sd["thinker.lm_head.weight"] = sd[t + "embed_tokens.weight"]
+        if tokens is None:
+            raise ValueError("Qwen3-ASR needs the exporter's metadata map (--tokens metadata.json: special_token_ids, supported_languages, ...)")
+        os.makedirs(out, exist_ok=True)
+        importlib.import_module(PKG + ".qwen_asr").export_qwen_asr(cfg, sd, os.path.join(out, "Qwen_ASR.asrmodel"), tokens, precision)
     else:
         raise ValueError(family)
     return cfg
@@ -110,10 +126,10 @@ def convert(family: str, sd: dict, out: str, precision: int, cmvn=None, tokens=N
 
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--family", required=True, choices=("sensevoice", "paraformer", "whisper"))
+    ap.add_argument("--family", required=True, choices=("sensevoice", "paraformer", "whisper", "qwen_asr"))
     ap.add_argument("--checkpoint", required=True)
     ap.add_argument("--cmvn", help="FunASR am.mvn (SenseVoice / Paraformer)")
-    ap.add_argument("--tokens", help="Paraformer token list: tokens.json (list) or one token per line")
+    ap.add_argument("--tokens", help="Paraformer token list: tokens.json (list) or one token per line; Qwen3-ASR: metadata.json (dict)")
     ap.add_argument("--language", default="zh")
     ap.add_argument("--decode-mode", default="zh", choices=("zh", "en"))
     ap.add_argument("--precision", default="bf16", choices=("bf16", "f32"))

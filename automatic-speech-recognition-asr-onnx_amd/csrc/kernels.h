@@ -80,8 +80,9 @@ void launch_argmax_rows(const float* logits, int ld, int rows, int n_valid, cons
 // ---- penalty-greedy head (Export_Whisper.py:312-325 APPLY_PENALTY + :243-251 GREEDY_SEARCH): logits of the last `range` saved
 // ids are multiplied by `value` once `range` ids are saved (the host's rule, Inference_Whisper_ONNX.py:630-632); gather first,
 // scatter second, so a repeated id is scaled once. In place on the f32 logits. n_saved lives on the device (graph replay).
+// partial = 1 (Qwen3-ASR, Export_Qwen_ASR.py:1403-1415): the window is save_id[:, -range:] of whatever exists -- fewer ids are penalised too.
 void launch_apply_penalty(float* logits, int ld, int rows, const int32_t* save_ids, int ld_save, const int32_t* n_saved,
-                          int range, float value, hipStream_t s);
+                          int range, float value, hipStream_t s, int partial = 0);
 // save_ids[r][*n_saved] = next[r] (the counter itself is advanced by launch_add_scalar afterwards)
 void launch_append_ids(const int32_t* next, int rows, int32_t* save_ids, int ld_save, const int32_t* n_saved, hipStream_t s);
 

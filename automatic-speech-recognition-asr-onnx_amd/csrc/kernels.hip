@@ -812,9 +812,12 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* __restri
 
 
 __global__ __launch_bounds__(64) void apply_penalty_kernel(float* __restrict__ logits, int ld, const int32_t* __restrict__ save_ids,
-                                                           int ld_save, const int32_t* __restrict__ n_saved, int range, float value) {
+                                                           int ld_save, const int32_t* __restrict__ n_saved, int range, float value, int partial) {
   const int n = *n_saved;
-  if (n < range) return;                       // multiplier is 1.0 until the window is full
+  if (n < range) {
+    if (!partial || n == 0) return;            // Whisper's host: multiplier 1.0 until the window is full; Qwen3-ASR: save_id[:, -range:] of what exists
+    range = n;
+  }
   float* x = logits + (size_t)blockIdx.x * ld;
   const int32_t* sv = save_ids + (size_t)blockIdx.x * ld_save + (n - range);
   const int i = threadIdx.x;                   // range <= 64: every original value is gathered before the first write
@@ -840,14 +843,20 @@ __global__ __launch_bounds__(256) void sample_topk_topp_kernel(const SampleArgs 
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* x = a.logits + (size_t)r * a.ld;
   const int n_prev = min(*a.n_saved, a.ld_save);
-  // 1. repetition penalty over the whole history (<= 512 ids: two per thread), every original gathered before the first write
+  // 1. repetition penalty over the whole history (<= 1024 ids: four per thread), every original gathered before the first write
   const int32_t* sv = a.save_ids + (size_t)r * a.ld_save;
-  int id0 = tid < n_prev ? sv[tid] : -1, id1 = tid + 256 < n_prev ? sv[tid + 256] : -1;
-  const float v0 = id0 >= 0 ? x[id0] : 0.0f, v1 = id1 >= 0 ? x[id1] : 0.0f;
+  int idh[4];
+  float vh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    idh[j] = tid + 256 * j < n_prev ? sv[tid + 256 * j] : -1;
+    vh[j] = idh[j] >= 0 ? x[idh[j]] : 0.0f;
+  }
   __syncthreads();
   const float rp = a.repetition_penalty, irp = 1.0f / a.repetition_penalty;
-  if (id0 >= 0) x[id0] = v0 < 0.0f ? v0 * rp : v0 * irp;
-  if (id1 >= 0) x[id1] = v1 < 0.0f ? v1 * rp : v1 * irp;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (idh[j] >= 0) x[idh[j]] = vh[j] < 0.0f ? vh[j] * rp : vh[j] * irp;
   __syncthreads();
   // 2. top-k by k passes of (value desc, index asc) selection below the previous pick
   const float inv_t = 1.0f / a.temperature;
@@ -1187,15 +1196,15 @@ void launch_argmax_rows(const float* logits, int ld, int rows, int n_valid, cons
 }
 
 void launch_apply_penalty(float* logits, int ld, int rows, const int32_t* save_ids, int ld_save, const int32_t* n_saved,
-                          int range, float value, hipStream_t s) {
+                          int range, float value, hipStream_t s, int partial) {
   ASR_REQUIRE(range >= 1 && range <= 64 && range <= ld_save, "apply_penalty: range %d (1..64)", range);
-  hipLaunchKernelGGL(apply_penalty_kernel, dim3(rows), dim3(64), 0, s, logits, ld, save_ids, ld_save, n_saved, range, value);
+  hipLaunchKernelGGL(apply_penalty_kernel, dim3(rows), dim3(64), 0, s, logits, ld, save_ids, ld_save, n_saved, range, value, partial);
   HIP_CHECK(hipGetLastError());
 }
 
 void launch_sample_topk_topp(const SampleArgs& a, hipStream_t s) {
   ASR_REQUIRE(a.top_k >= 1 && a.top_k <= 64 && a.top_k <= a.n_valid, "sampling: top_k %d (1..64)", a.top_k);
-  ASR_REQUIRE(a.temperature > 0.0f && a.repetition_penalty > 0.0f && a.ld_save <= 512, "sampling: bad temperature / penalty / history capacity");
+  ASR_REQUIRE(a.temperature > 0.0f && a.repetition_penalty > 0.0f && a.ld_save <= 1024, "sampling: bad temperature / penalty / history capacity");
   hipLaunchKernelGGL(sample_topk_topp_kernel, dim3(a.rows), dim3(256), 0, s, a);
   HIP_CHECK(hipGetLastError());
 }

@@ -463,6 +463,11 @@ struct QwSession : asr_session {
   DeviceBuffer d_plan, d_audio, d_mel, d_blkmax, d_feat, d_col, d_c1, d_c2, d_c3, d_xa, d_xb, d_h, d_qk, d_vt, d_ctx, d_ffn, d_aud_out;
   DeviceBuffer d_dplan, d_x, d_x2, d_dh, d_qkv, d_q, d_dctx, d_act, d_last, d_logits, d_next, d_kc, d_vc, d_hist, d_stepplan, d_skws, d_skcnt, d_vt2, d_krows, d_xlo, d_x2lo;
   bool no_fuse = false, use_graph = true;
+  // decode head (Inference_Qwen_ASR_ONNX.py:369-376): arg-max, penalty-greedy (APPLY_PENALTY + GREEDY_SEARCH) or top-k / top-p sampling
+  float penalty_value = 1.0f; int penalty_range = 10;
+  bool sampling = false, noise_armed = false; float temperature = 0.8f, top_p = 0.95f, samp_rep_penalty = 1.0f; int top_k = 10; uint64_t samp_seed = 0;
+  uint64_t head_epoch = 0;
+  DeviceBuffer d_save, d_nsaved, d_noise;
   hipGraphExec_t dec_graph = nullptr; uint64_t dec_key = 0, dec_eager_key = 0;
   void* h_plan = nullptr; size_t h_plan_cap = 0;
   void* h_io = nullptr; size_t h_io_cap = 0;
@@ -471,7 +476,7 @@ struct QwSession : asr_session {
   ~QwSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_feat, &d_col, &d_c1, &d_c2, &d_c3, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx,
                             &d_ffn, &d_aud_out, &d_dplan, &d_x, &d_x2, &d_dh, &d_qkv, &d_q, &d_dctx, &d_act, &d_last, &d_logits, &d_next,
-                            &d_kc, &d_vc, &d_hist, &d_stepplan, &d_skws, &d_skcnt, &d_vt2, &d_krows, &d_xlo, &d_x2lo})
+                            &d_kc, &d_vc, &d_hist, &d_stepplan, &d_skws, &d_skcnt, &d_vt2, &d_krows, &d_xlo, &d_x2lo, &d_save, &d_nsaved, &d_noise})
       b->release();
     for (auto& kv : taps) kv.second.buf.release();
     if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
@@ -634,7 +639,25 @@ void QwSession::decoder_pass(const DecPass& P) {
     T* last = d_last.as<T>();
     hipLaunchKernelGGL(qw_rmsnorm_kernel<T>, dim3((B + 3) / 4), dim3(256), 0, stream, x, d, B, d, final_norm, c.rms_eps, last, d, P.last_rows);
     GemmArgs g; g.A = last; g.lda = d; g.W = lm_head; g.ldw = d; g.M = B; g.N = vpad; g.K = d; g.out_f32 = d_logits.as<float>(); g.ld_out_f32 = vpad; gemm(g);
-    launch_argmax_rows(d_logits.as<float>(), vpad, B, c.vocab, nullptr, d_next.as<int32_t>(), stream); }
+    // heads: the prefill graphs select from the raw logits with an empty history; the decode graphs apply the penalty first
+    // (Shared_Merged.py merge_prefill_* / merge_decode_*)
+    const bool penalised = penalty_value != 1.0f && !sampling;
+    if (penalised && P.step)
+      launch_apply_penalty(d_logits.as<float>(), vpad, B, d_save.as<int32_t>(), c.max_seq_len, d_nsaved.as<int32_t>(), penalty_range, penalty_value, stream, 1);
+    if (sampling) {
+      SampleArgs sa;
+      sa.logits = d_logits.as<float>(); sa.ld = vpad; sa.rows = B; sa.n_valid = c.vocab; sa.extra = nullptr;
+      sa.save_ids = d_save.as<int32_t>(); sa.ld_save = c.max_seq_len; sa.n_saved = d_nsaved.as<int32_t>();
+      sa.temperature = temperature; sa.top_p = top_p; sa.repetition_penalty = samp_rep_penalty; sa.top_k = top_k;
+      sa.noise = noise_armed ? d_noise.as<float>() : nullptr; sa.seed = samp_seed; sa.next = d_next.as<int32_t>();
+      launch_sample_topk_topp(sa, stream);
+    } else {
+      launch_argmax_rows(d_logits.as<float>(), vpad, B, c.vocab, nullptr, d_next.as<int32_t>(), stream);
+    }
+    if (penalised || sampling) {                         // GREEDY_SEARCH / the sampling head append their pick to save_id
+      launch_append_ids(d_next.as<int32_t>(), B, d_save.as<int32_t>(), c.max_seq_len, d_nsaved.as<int32_t>(), stream);
+      launch_add_scalar(d_nsaved.as<int32_t>(), 1, stream);
+    } }
   hipLaunchKernelGGL(qw_hist_add_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_hist.as<int32_t>(), P.plan, B);
   HIP_CHECK(hipGetLastError());
 }
@@ -902,6 +925,9 @@ void QwSession::prefill(const float* audio, int audio_mem, const int64_t* offs, 
   d_last.reserve(pad_rows(B) * d * eT, stream);
   d_logits.reserve(pad_rows(B) * (size_t)vpad * 4, stream);
   d_next.reserve((size_t)std::max(B, 64) * 4, stream);
+  d_save.reserve((size_t)B * c.max_seq_len * 4, stream);
+  d_nsaved.reserve(64, stream);
+  HIP_CHECK(hipMemsetAsync(d_nsaved.ptr, 0, 4, stream));
   { ProfScope ps(prof, "dec_embed", stream);
     hipLaunchKernelGGL(qw_gather_prompt_kernel<T>, dim3(Md), dim3(256), 0, stream, d_src, (const T*)embed, d_aud_out.as<float>(), d, PAD, d_x.as<float>(), (T*)nullptr); }
   if (taps_enabled) save_tap("prompt", d_x.ptr, rows_d, d, d, 4);
@@ -927,6 +953,7 @@ void QwSession::prefill(const float* audio, int audio_mem, const int64_t* offs, 
     d_stepplan.reserve(sbytes, stream);
     HIP_CHECK(hipMemcpyAsync(d_stepplan.ptr, sh, sbytes, hipMemcpyHostToDevice, stream));
   }
+  noise_armed = false;
   finish<T>(B, next_out, logits_out, true);
 }
 
@@ -959,10 +986,10 @@ void QwSession::step(const int32_t* ids_host, int32_t* next_out, float* logits_o
     decoder_pass<T>(P);
   };
   // every step reads its position from the device-side history counters => one captured graph replays for all of them
-  const bool graphable = use_graph && !taps_enabled && !prof.enabled;
+  const bool graphable = use_graph && !taps_enabled && !prof.enabled && !noise_armed;
   uint64_t key = 1469598103934665603ull;
   for (const void* q : {d_x.ptr, d_x2.ptr, d_dh.ptr, d_qkv.ptr, d_q.ptr, d_dctx.ptr, d_xlo.ptr, d_x2lo.ptr, d_act.ptr, d_last.ptr, d_logits.ptr, d_next.ptr, d_kc.ptr,
-                        d_vc.ptr, d_hist.ptr, d_stepplan.ptr, d_skws.ptr, (void*)stream, (void*)(uintptr_t)B})
+                        d_vc.ptr, d_hist.ptr, d_stepplan.ptr, d_skws.ptr, d_save.ptr, (void*)stream, (void*)(uintptr_t)B, (void*)(uintptr_t)head_epoch})
     key = (key ^ (uint64_t)(uintptr_t)q) * 1099511628211ull;
   if (graphable && dec_graph && key == dec_key) {
     HIP_CHECK(hipGraphLaunch(dec_graph, stream));
@@ -986,6 +1013,7 @@ void QwSession::step(const int32_t* ids_host, int32_t* next_out, float* logits_o
     enqueue();                                           // first step of a geometry runs eagerly (lazy kernel attributes, workspaces)
     if (graphable) dec_eager_key = key;
   }
+  noise_armed = false;                                   // caller-supplied uniforms serve exactly one step
   for (int b = 0; b < B; ++b) ++seq_len[b];
   finish<T>(B, next_out, logits_out, ids_host != nullptr);
 }
@@ -1037,6 +1065,47 @@ extern "C" int asr_qwen_decode(asr_session* s, const int32_t* ids, int32_t* next
     QwSession* q = static_cast<QwSession*>(s);
     if (q->precision == ASR_PRECISION_BF16) q->step<bf16_t>(ids, next_ids_out, logits_out);
     else q->step<float>(ids, next_ids_out, logits_out);
+  });
+}
+
+extern "C" int asr_qwen_set_penalty(asr_session* s, float repeat_penalty, int penalty_range) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 5, "qwen_set_penalty: not a Qwen3-ASR session");
+    ASR_REQUIRE(repeat_penalty > 0.0f && penalty_range >= 1 && penalty_range <= 64, "qwen_set_penalty: value %g range %d", repeat_penalty, penalty_range);
+    QwSession* q = static_cast<QwSession*>(s);
+    if (q->penalty_value != repeat_penalty || q->penalty_range != penalty_range) {
+      q->penalty_value = repeat_penalty;
+      q->penalty_range = penalty_range;
+      ++q->head_epoch;                     // the captured decode graph bakes the head in: re-capture
+    }
+  });
+}
+
+extern "C" int asr_qwen_set_sampling(asr_session* s, int enable, float temperature, int top_k, float top_p, float repetition_penalty, uint64_t seed) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 5, "qwen_set_sampling: not a Qwen3-ASR session");
+    QwSession* q = static_cast<QwSession*>(s);
+    if (enable) {
+      ASR_REQUIRE(temperature > 0.0f && top_k >= 1 && top_k <= 64 && top_p > 0.0f && repetition_penalty > 0.0f && q->cfg.max_seq_len <= 1024,
+                  "qwen_set_sampling: temperature %g top_k %d top_p %g penalty %g", temperature, top_k, top_p, repetition_penalty);
+      q->temperature = temperature; q->top_k = top_k; q->top_p = top_p; q->samp_rep_penalty = repetition_penalty; q->samp_seed = seed;
+    }
+    q->sampling = enable != 0;
+    q->noise_armed = false;
+    ++q->head_epoch;
+  });
+}
+
+extern "C" int asr_qwen_set_sampling_noise(asr_session* s, const float* uniforms, int count) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 5 && uniforms && count > 0, "qwen_set_sampling_noise: bad argument");
+    QwSession* q = static_cast<QwSession*>(s);
+    ASR_REQUIRE(q->sampling && count % q->top_k == 0, "qwen_set_sampling_noise: expects batch x top_k uniforms for the next step");
+    HIP_CHECK(hipSetDevice(q->device));
+    q->d_noise.reserve((size_t)count * 4, q->stream);
+    HIP_CHECK(hipMemcpyAsync(q->d_noise.ptr, uniforms, (size_t)count * 4, hipMemcpyHostToDevice, q->stream));
+    HIP_CHECK(hipStreamSynchronize(q->stream));
+    q->noise_armed = true;
   });
 }
 

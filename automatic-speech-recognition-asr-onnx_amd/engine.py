@@ -515,6 +515,19 @@ class QwenAsrSession(_Session):
         _lib.check(_lib.load().asr_qwen_decode(self._h, idp, _ip(nxt) if nxt is not None else None, _fp(logits)))
         return nxt, logits
 
+    def set_penalty(self, repeat_penalty: float = 1.0, penalty_range: int = 10):
+        """Decode head: 1.0 = plain arg-max; else penalty-greedy (the reference host's default is 0.8 over the last 10 ids)."""
+        _lib.check(_lib.load().asr_qwen_set_penalty(self._h, C.c_float(repeat_penalty), int(penalty_range)))
+
+    def set_sampling(self, enable: bool, temperature: float = 0.8, top_k: int = 10, top_p: float = 0.95, repetition_penalty: float = 1.0, seed: int = 0):
+        _lib.check(_lib.load().asr_qwen_set_sampling(self._h, int(enable), C.c_float(temperature), int(top_k), C.c_float(top_p),
+                                                     C.c_float(repetition_penalty), C.c_uint64(seed)))
+
+    def set_sampling_noise(self, uniforms):
+        """Parity hook: uniforms [batch, top_k] for the next prefill / decode step (otherwise the device generator is used)."""
+        u = _f32(uniforms).reshape(-1)
+        _lib.check(_lib.load().asr_qwen_set_sampling_noise(self._h, _fp(u), u.size))
+
     def audio_tokens(self, n_samples: int) -> int:
         """_get_feat_extract_output_lengths (Export_Qwen_ASR.py:519-527) of a clip's mel frames."""
         n = int(n_samples) // self.cfg.hop_length

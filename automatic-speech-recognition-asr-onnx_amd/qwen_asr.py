@@ -121,8 +121,14 @@ def export_qwen_asr(cfg: QwenAsrConfig, ck: dict, path: str, metadata: dict, pre
 
 
 class QwenAsrTranscriber:
-    def __init__(self, cfg: QwenAsrConfig, session: QwenAsrSession, metadata: dict, tokenizer=None, normalise_audio: bool = False):
+    def __init__(self, cfg: QwenAsrConfig, session: QwenAsrSession, metadata: dict, tokenizer=None, normalise_audio: bool = False,
+                 repeat_penalty: float = 1.0, penalty_range: int = 10, use_sampling: bool = False, temperature: float = 0.8, top_k: int = 10,
+                 top_p: float = 0.95, sampling_repetition_penalty: float = 1.0, seed: int = 0):
         self.cfg, self.sess, self.tokenizer = cfg, session, tokenizer
+        # _resolve_strategy (:369-376): sampling wins; REPEAT_PENALTY == 1.0 selects greedy, any other value penalty-greedy (the
+        # reference's defaults are 0.8 over PENALTY_RANGE = 10 ids)
+        self.repeat_penalty, self.penalty_range = float(repeat_penalty), int(penalty_range)
+        self.sampling = (bool(use_sampling), float(temperature), int(top_k), float(top_p), float(sampling_repetition_penalty), int(seed))
         self.audio_pcm_scale = int(metadata["audio_pcm_scale"])
         self.max_seq_len = int(metadata["max_seq_len"])
         special = metadata["special_token_ids"]
@@ -156,6 +162,8 @@ class QwenAsrTranscriber:
         pre = [self.head_ids + self._query_ids(t) + self.suffix_ids for t in tasks]
         post = [self.tail_ids + (list(resolve_language(self.languages, l)[1]["prompt_token_ids"]) if l else []) for l in langs]
         t0 = time.time()
+        self.sess.set_penalty(self.repeat_penalty, self.penalty_range)
+        self.sess.set_sampling(*self.sampling)
         first, _, ids_len = self.sess.prefill(audios, pre, post, want_logits=False)
         limits = np.maximum(self.max_seq_len - 10 - ids_len, 0)
         if max_new is not None:

@@ -203,8 +203,17 @@ int asr_qwen_prefill(asr_session* s, const float* audio, int audio_mem, const in
 /* one position per sequence (Embed + decode_greedy, :690-716). ids: host [B], or NULL to feed the device-resident arg-max of the
  * previous call; next_ids_out / logits_out nullable (ids NULL and both outputs NULL => asynchronous step). */
 int asr_qwen_decode(asr_session* s, const int32_t* ids, int32_t* next_ids_out, float* logits_out);
-/* greedy continuation after a prefill (:687-728): tokens_out host [B][max_new], n_out host [B]; a sequence ends at the first id in
- * stop_ids (not emitted) or when the cache is full. */
+/* decode heads (strategy selection Inference_Qwen_ASR_ONNX.py:369-376; graphs Shared_Merged.py merge_prefill_* / merge_decode_*):
+ * repeat_penalty == 1 => ARGMAX (Export_Qwen_ASR.py:1418-1420); otherwise penalty-greedy = APPLY_PENALTY (:1403-1415, the logits of
+ * save_id[:, -penalty_range:] -- fewer ids while the history is shorter -- multiplied by repeat_penalty, decode steps only) +
+ * GREEDY_SEARCH (:1342-1345). set_sampling selects TOPK_TOPP_SAMPLING (:1348-1400) for prefill and decode, with the counter-based
+ * uniforms of asr_whisper_set_sampling; set_sampling_noise supplies the next step's uniforms [batch][top_k] (parity hook). The id
+ * history lives on the device and restarts at every prefill. */
+int asr_qwen_set_penalty(asr_session* s, float repeat_penalty, int penalty_range);
+int asr_qwen_set_sampling(asr_session* s, int enable, float temperature, int top_k, float top_p, float repetition_penalty, uint64_t seed);
+int asr_qwen_set_sampling_noise(asr_session* s, const float* uniforms, int count);
+/* continuation after a prefill with the selected head (:687-745): tokens_out host [B][max_new], n_out host [B]; a sequence ends at
+ * the first id in stop_ids (not emitted) or when the cache is full. */
 int asr_qwen_generate(asr_session* s, int max_new, const int32_t* stop_ids, int n_stop, int32_t* tokens_out, int32_t* n_out);
 
 /* ------------------------------------------------------------------ device buffers

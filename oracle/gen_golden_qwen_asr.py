@@ -46,6 +46,56 @@ def reference_greedy(ref, cfg, audio, n_new, query_ids, tail_ids):
     return dict(audio_hidden=audio_hidden, ids_len=int(ids_len), logits=torch.stack(steps).numpy(), token_ids=np.asarray(toks, np.int32))
 
 
+PENALTY = dict(value=0.8, range=3, steps=10)          # the host's REPEAT_PENALTY with a short window so that it bites within 10 steps
+SAMPLING = dict(temperature=0.8, top_k=10, top_p=0.95, repetition_penalty=1.3, steps=8, seed=777)
+
+
+def reference_heads(ref, cfg, audio, query_ids, tail_ids, mode):
+    """The reference's head classes driven like its merged graphs (Shared_Merged.py): prefill = GREEDY_SEARCH / TOPK_TOPP_SAMPLING on the
+    raw logits with an empty save_id; decode = APPLY_PENALTY (value, range passed straight through, Inference :563-575) + GREEDY_SEARCH, or
+    the sampling head over every previous id. The sampling head draws torch.rand_like inside: the uniforms are captured by re-seeding."""
+    enc, embed, rp, rd, main = ref["encoder"], ref["embed"], ref["rotary_prefill"], ref["rotary_decode"], ref["main"]
+    ns, L = ref["ns"], cfg.n_layers
+    apply_penalty, greedy_search, sampler = ns["APPLY_PENALTY"](), ns["GREEDY_SEARCH"](), ns["TOPK_TOPP_SAMPLING"]()
+    steps = PENALTY["steps"] if mode == "penalty" else SAMPLING["steps"]
+    with torch.inference_mode():
+        q = embed(torch.tensor([query_ids], dtype=torch.int32).reshape(1, -1))
+        base, _ = enc(torch.from_numpy(audio).reshape(1, 1, -1), q)
+        concat, ids_len = ns["CONCAT_EMBED"]()(base, embed(torch.tensor([tail_ids], dtype=torch.int32).reshape(1, -1)))
+        keys = [torch.zeros(1, cfg.n_kv_heads, 1, cfg.d_head, 0) for _ in range(L)]
+        vals = [torch.zeros(1, cfg.n_kv_heads, 1, 0, cfg.d_head) for _ in range(L)]
+        cos, sin, mask, kv_len = rp(ids_len, torch.zeros(1, dtype=torch.int64))
+        out = main(*keys, *vals, concat, cos, sin, mask)
+        save_id = torch.zeros((1, 0), dtype=torch.int32)
+        toks, heads, noises = [], [], []
+        for step in range(steps):
+            if step:
+                cos, sin, kv_next = rd(kv_len)
+                out = main(*out[:L], *out[L:2 * L], embed(torch.tensor([[toks[-1]]], dtype=torch.int32)), cos, sin, torch.zeros(1))
+                kv_len = kv_next
+            logits = out[-1]
+            if mode == "penalty":
+                if step:
+                    logits = apply_penalty(logits, save_id, torch.tensor(PENALTY["value"], dtype=torch.float32), PENALTY["range"])
+                heads.append(logits[0].clone())
+                tok, save_id = greedy_search(logits, save_id)
+            else:
+                P = SAMPLING
+                torch.manual_seed(P["seed"] + step)
+                noises.append(torch.rand((1, P["top_k"]))[0].numpy().copy())
+                torch.manual_seed(P["seed"] + step)
+                tok, save_id = sampler(logits, torch.tensor(P["temperature"]), P["top_k"], torch.tensor(P["top_p"]), torch.tensor(P["repetition_penalty"]),
+                                       save_id.long())
+                save_id = save_id.int()
+            toks.append(int(tok.reshape(-1)[0]))
+    r = dict(token_ids=np.asarray(toks, np.int32))
+    if mode == "penalty":
+        r["logits"] = torch.stack(heads).numpy()
+    else:
+        r["noise"] = np.stack(noises).astype(np.float32)
+    return r
+
+
 def main():
     from oracle import reference_harness as rh
     cfgm = importlib.import_module(PKG + ".config")
@@ -55,6 +105,8 @@ def main():
         ck = ckm.synth_qwen_asr_checkpoint(cfg, ck_seed)
         ref = rh.build_reference_qwen_asr(cfg, ck, HEAD_IDS, TAIL_IDS, SUFFIX_IDS, max_seq_len=cfg.max_seq_len)
         out = {"ckpt_seed": np.int64(ck_seed), "n_cases": np.int64(len(clips)), "cfg_name": np.str_(cfg_name), "n_new": np.int64(n_new),
+               "penalty": np.asarray([PENALTY["value"], PENALTY["range"]], np.float32),
+               "sampling_params": np.asarray([SAMPLING["temperature"], SAMPLING["top_k"], SAMPLING["top_p"], SAMPLING["repetition_penalty"]], np.float32),
                "head_ids": np.asarray(HEAD_IDS, np.int32), "tail_ids": np.asarray(TAIL_IDS, np.int32), "suffix_ids": np.asarray(SUFFIX_IDS, np.int32)}
         for i, (seed, n, query, tail) in enumerate(clips):
             audio = ckm.synth_audio("unit", 1, n, seed=seed)[0, 0]
@@ -66,6 +118,14 @@ def main():
             srt = np.sort(r["logits"], axis=1)
             out[p + "margin"] = (srt[:, -1] - srt[:, -2]).astype(np.float32)
             print(fixture, i, n, "audio tokens", r["audio_hidden"].shape[0], "prompt", r["ids_len"], "tokens", r["token_ids"], "min margin", float(out[p + "margin"].min()))
+            if i < 2:                                     # the other decode heads on two clips per fixture
+                rp_ = reference_heads(ref, cfg, audio, query, tail, "penalty")
+                srt = np.sort(rp_["logits"], axis=1)
+                out[p + "penalty_token_ids"], out[p + "penalty_logits"] = rp_["token_ids"], rp_["logits"][:, ::7].copy()
+                out[p + "penalty_margin"] = (srt[:, -1] - srt[:, -2]).astype(np.float32)
+                rs_ = reference_heads(ref, cfg, audio, query, tail, "sampling")
+                out[p + "sampling_token_ids"], out[p + "sampling_noise"] = rs_["token_ids"], rs_["noise"]
+                print(fixture, i, "penalty", rp_["token_ids"], "sampling", rs_["token_ids"])
         np.savez_compressed(os.path.join(GOLDEN, fixture + ".npz"), **out)
 
 

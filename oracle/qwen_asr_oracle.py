@@ -180,6 +180,31 @@ class QwenAsrOracle:
         last = self._rms(x[-1], c.rms_eps) * self.ck["thinker.model.norm.weight"]
         return last @ self.ck["thinker.lm_head.weight"].t(), new_k, new_v
 
+    def heads(self, audio_1d, n_new: int, query_ids=(), language_tail_ids=(), penalty=None, sampling=None, noise=None):
+        """The other decode strategies (Inference_Qwen_ASR_ONNX.py:369-376). penalty = (value, range): prefill picks arg-max of the raw
+        logits; every decode step multiplies the logits of save_id[-range:] (whatever exists, APPLY_PENALTY :1403-1415) by value, then
+        arg-max (GREEDY_SEARCH). sampling = (temperature, top_k, top_p, repetition_penalty) with noise[step] = the top_k uniforms:
+        TOPK_TOPP_SAMPLING (:1348-1400) at the prefill too, history = every sampled id. -> dict(token_ids, logits (penalised heads))"""
+        from .whisper_oracle import WhisperOracle
+        with torch.inference_mode():
+            x = self.prompt(self.encode(audio_1d), query_ids, language_tail_ids)
+            logits, ks, vs = self.decoder(x, 0, None, None)
+            hist, toks, heads = x.shape[0], [], []
+            for step in range(n_new):
+                if step:
+                    logits, ks, vs = self.decoder(self.embed([toks[-1]]), hist, ks, vs)
+                    hist += 1
+                head = logits.clone()
+                if sampling is not None:
+                    toks.append(WhisperOracle.sample_head(head.float(), toks, noise[step], *sampling))
+                    continue
+                if penalty is not None and step and toks:
+                    idx = torch.tensor(toks[-int(penalty[1]):], dtype=torch.long)
+                    head[idx] = logits[idx] * float(penalty[0])
+                heads.append(head)
+                toks.append(int(head.argmax()))
+        return dict(token_ids=np.asarray(toks, np.int32), logits=torch.stack(heads).numpy() if heads else None)
+
     def greedy(self, audio_1d, n_new: int, query_ids=(), language_tail_ids=(), stop_ids=()):
         """-> dict(audio_hidden, ids_len, logits (steps, vocab), token_ids)"""
         with torch.inference_mode():

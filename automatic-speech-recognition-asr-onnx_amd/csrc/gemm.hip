@@ -964,6 +964,7 @@ bool launch_t144(const GemmArgs& g, hipStream_t s) {
   ASR_T144_CASE(ACT_NONE, E_F32)                             // decoder q|k|v (f32 for the per-head RMSNorm / RoPE)
   ASR_T144_CASE(ACT_SWIGLU, E_LO)                            // decoder gate|up with the SwiGLU epilogue
   ASR_T144_CASE(ACT_GELU_TANH, E_BIAS | E_LO)
+  ASR_T144_CASE(ACT_GELU_ERF, E_BIAS | E_LO)                 // Whisper fc1
   ASR_T144_CASE(ACT_RELU, E_BIAS | E_LO)
   ASR_T144_CASE(ACT_NONE, E_ADD | E_ADD2 | E_F32)
   ASR_T144_CASE(ACT_NONE, E_ADD | E_F32)

@@ -196,3 +196,33 @@ def test_penalty_and_sampling_heads_match_reference_goldens(fixture):
     for b, c in enumerate(cases):
         if (c["margin"] > 2 * TOL_F32).all():
             assert np.array_equal(ids_plain[b], c["token_ids"][:4]), b
+
+
+def test_edge_lengths_vs_oracle():
+    """f32 mode against the oracle on the lengths the goldens do not hold: the shortest clip the front-end accepts (one token), exact
+    chunk / window multiples, and max_audio_len (30 s: 30 chunks, 8 windows of 4 at the tiny geometry, 390 audio tokens)."""
+    g = load_golden("qwen_asr_tiny")
+    cfg, ck = qwen_setup(g)
+    head, tail, suffix = g["head_ids"].tolist(), g["tail_ids"].tolist(), g["suffix_ids"].tolist()
+    orc = QwenAsrOracle(cfg, ck, head, tail, suffix)
+    sess = sub("engine").QwenAsrSession.from_checkpoint(cfg, ck, precision=F32)
+    lens = [cfg.nfft, 16000, 64000, cfg.max_audio_len, 64160]
+    audios = [unit_audio(9000 + i, n) for i, n in enumerate(lens)]
+    pre, post = [head + suffix], [tail]
+    sess.taps(True)
+    nxt, logits, ids_len = sess.prefill(audios, pre, post)
+    hidden = sess.audio_hidden(lens)
+    steps = [logits]
+    for _ in range(2):
+        steps.append(sess.decode(None, want_logits=True)[1])
+    for b, a in enumerate(audios):
+        r = orc.greedy(a, 3)
+        assert r["ids_len"] == int(ids_len[b]) and hidden[b].shape == r["audio_hidden"].shape == (sess.audio_tokens(lens[b]), cfg.d_model), b
+        assert np.abs(hidden[b] - r["audio_hidden"]).max() < TOL_F32, b
+        srt = np.sort(r["logits"], axis=1)
+        ok = True
+        for t in range(3):
+            if not ok:
+                break                                               # a flipped near-tie changes the later steps
+            assert np.abs(steps[t][b] - r["logits"][t]).max() < TOL_F32, (b, t)
+            ok = srt[t, -1] - srt[t, -2] > 2 * TOL_F32

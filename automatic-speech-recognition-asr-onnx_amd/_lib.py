@@ -99,6 +99,7 @@ SIGNATURES = {
     "asr_op_gemm_ln": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp]),
     "asr_op_gemm_bench": (_i, [_i, _i, _i, _i, _i, _i, _fp]),
     "asr_debug_grid_barrier": (_i, [_i, _i, _fp]),
+    "asr_debug_grid_barrier2": (_i, [_i, _i, _i, _fp]),
     "asr_op_ctc_collapse": (_i, [_ip, _ip, _i, _i, _ip, _i, _ip]),
 }
 

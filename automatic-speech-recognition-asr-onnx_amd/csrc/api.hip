@@ -493,6 +493,97 @@ __global__ __launch_bounds__(512) void grid_barrier_probe_kernel(unsigned int* c
 }
 }  // namespace
 
+namespace {
+// hierarchical barrier probe: arrivals are counted per XCD (workgroup b runs on XCD b % 8), the last arrival of an XCD counts
+// itself on the chip counter, the last XCD publishes the generation. Relaxed agent-scope atomics only -- no fence, i.e. no L2
+// write-back / invalidate; payload that must cross XCDs would travel through sc1 accesses.
+struct HBar { unsigned int* xcd; unsigned int* chip; unsigned int* flag; };   // xcd[8 * 32], flag[8 * 32] (128-byte spacing)
+__device__ __forceinline__ bool hbar_step(const HBar& hb, unsigned int gen, int mode) {
+  __syncthreads();
+  bool ok = true;
+  if (threadIdx.x == 0) {
+    const int x = blockIdx.x & 7;
+    const unsigned int in_xcd = (gridDim.x + 7 - x) >> 3;
+    const unsigned int old = __hip_atomic_fetch_add(hb.xcd + x * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == gen * in_xcd) {
+      const unsigned int n_xcd = gridDim.x < 8 ? gridDim.x : 8;
+      const unsigned int o2 = __hip_atomic_fetch_add(hb.chip, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (o2 + 1 == gen * n_xcd) {
+        if (mode == 2) { for (int q = 0; q < 8; ++q) __hip_atomic_store(hb.flag + q * 32, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else __hip_atomic_store(hb.flag, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    const unsigned int* f = mode == 2 ? hb.flag + x * 32 : hb.flag;
+    int spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 22)) { ok = false; break; }
+    }
+  }
+  __syncthreads();
+  return ok;
+}
+__global__ __launch_bounds__(512) void hbar_probe_kernel(HBar hb, int iters, int mode, float* sink, int* failed, const unsigned long long* bulk,
+                                                         int bulk_words, int bulk_sc1) {
+  float acc = 0.0f;
+  for (int it = 0; it < iters; ++it) {
+    // bulk activation read every workgroup does per phase: `bulk_words` 8-byte words of ONE shared buffer, through sc1 (relaxed
+    // agent-scope atomic loads: what a persistent kernel must use for data produced by other XCDs) or through plain cached loads
+    unsigned long long bsum = 0;
+    if (bulk_sc1) { for (int w = threadIdx.x; w < bulk_words; w += 512) bsum += __hip_atomic_load(bulk + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    else { for (int w = threadIdx.x; w < bulk_words; w += 512) bsum += bulk[w]; }
+    if (bsum == 0x123456789abcdefull) acc += 1.0f;
+    // payload through sc1 accesses: one value written by this workgroup, one read from the neighbour's slot of the previous round
+    const float v = __hip_atomic_load(sink + ((blockIdx.x + 1) % gridDim.x) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (it > 0 && v != (float)it) { if (threadIdx.x == 0) *failed = 2; }      // stale payload => visibility bug
+    acc += v;
+    if (!hbar_step(hb, 2u * it + 1u, mode)) { if (threadIdx.x == 0) *failed = 1; return; }
+    if (threadIdx.x == 0) __hip_atomic_store(sink + blockIdx.x * 32, (float)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!hbar_step(hb, 2u * it + 2u, mode)) { if (threadIdx.x == 0) *failed = 1; return; }
+  }
+  if (acc == 123.456f) sink[0] = acc;
+}
+}  // namespace
+
+extern "C" int asr_debug_grid_barrier2(int n_workgroups, int iters, int mode, float* us_per_barrier) {
+  return asr_guard([&] {
+    // mode = (1 | 2) + 16 * bulk KiB read per workgroup per round + 8 if that read goes through plain cached loads instead of sc1
+    int bulk_kib = mode >> 4, bulk_sc1 = (mode & 8) ? 0 : 1;
+    mode &= 7;
+    ASR_REQUIRE(us_per_barrier && iters > 0 && n_workgroups > 0 && n_workgroups <= 1024 && (mode == 1 || mode == 2) && bulk_kib <= 1024, "debug_grid_barrier2: bad argument");
+    asr_require_device(0);
+    Tmp t;
+    unsigned int* ctr = (unsigned int*)t.alloc(3 * 8 * 32 * 4);
+    float* sink = (float*)t.alloc(1024 * 32 * 4);
+    int* failed = (int*)t.alloc(256);
+    HIP_CHECK(hipMemset(ctr, 0, 3 * 8 * 32 * 4));
+    HIP_CHECK(hipMemset(sink, 0, 1024 * 32 * 4));
+    HIP_CHECK(hipMemset(failed, 0, 256));
+    HBar hb{ctr, ctr + 8 * 32, ctr + 2 * 8 * 32};
+    const unsigned long long* bulk = (const unsigned long long*)t.alloc((size_t)std::max(bulk_kib, 1) * 1024);
+    HIP_CHECK(hipMemset((void*)bulk, 1, (size_t)std::max(bulk_kib, 1) * 1024));
+    int bulk_words = bulk_kib * 128;
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    void* args[] = {&hb, &iters, &mode, &sink, &failed, &bulk, &bulk_words, &bulk_sc1};
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(hbar_probe_kernel), dim3(n_workgroups), dim3(512), args, 0, nullptr));
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    int hf = 0;
+    HIP_CHECK(hipMemcpy(&hf, failed, 4, hipMemcpyDeviceToHost));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    ASR_REQUIRE(hf != 1, "debug_grid_barrier2: a workgroup gave up waiting (grid not co-resident?)");
+    ASR_REQUIRE(hf != 2, "debug_grid_barrier2: a payload written before the barrier was not visible after it");
+    *us_per_barrier = ms * 1e3f / (2.0f * iters);
+  });
+}
+
 extern "C" int asr_debug_grid_barrier(int n_workgroups, int iters, float* us_per_barrier) {
   return asr_guard([&] {
     ASR_REQUIRE(us_per_barrier && iters > 0 && n_workgroups > 0, "debug_grid_barrier: bad argument");

@@ -249,3 +249,25 @@ void launch_stream_dec_fsmn(const float* x, const float* res, const float* w, in
                             float* hist, float* out, hipStream_t s);
 void launch_stream_advance(const UttPlan* plan, const UttPlan* token_plan, int n_active, int en_add, int en_cap, int de_add, int de_cap,
                            int32_t* en_len, int32_t* de_len, hipStream_t s);
+
+// ---- Qwen3-ASR decode step as one persistent kernel (qwen_mega.hip): token embedding + every decoder layer, phases separated by a
+// chip-wide barrier; bf16 mode, <= 64 sequences. The final norm / lm_head / head kernels follow as ordinary launches.
+struct QwMegaLayer { const bf16_t *wqkv, *wo, *gate_up, *down; const float *qn, *kn; };
+struct QwMegaArgs {
+  int B, n_layers, d, d_ffn, n_heads, n_kv, S_max; float eps;
+  const QwMegaLayer* layers;                 // device array [n_layers]
+  const bf16_t* embed; const int32_t* ids;   // token embedding table, this step's ids [B]
+  const float* rope;                         // [S_max][cos(64) | sin(64)]
+  const int32_t* hist; int32_t* hist_rw;     // positions already in the cache per sequence (advanced by the kernel)
+  float *x, *x2, *qkv;                       // inter-phase activations read once per element: sc1 traffic
+  // broadcast operands (every workgroup reads all of them): ONE buffer PER LAYER, each written exactly once per launch (sc1 store) before
+  // anyone reads it, so consumers may use ordinary cached loads -- no XCD L2 can hold a stale line of an address nobody has read yet
+  bf16_t *xlo, *x2lo, *ctx, *act; size_t xlo_stride, ctx_stride, act_stride;     // element strides between layers
+  bf16_t *kc, *vc; size_t layer_kv;          // KV cache [layer][b][kv head][S_max][128]
+  unsigned int *bar_xcd, *bar_chip, *bar_flag; unsigned int gen_base;     // barrier state (zeroed once) and this launch's first generation - 1
+  int* failed;                               // set to 1 when a workgroup gave up waiting at a barrier
+  unsigned long long* dbg_clock;             // tuning: workgroup 0 stamps wall_clock64() after every barrier (nullable)
+};
+bool qw_decode_mega_supported(const QwMegaArgs& a);
+int qw_decode_mega_barriers(const QwMegaArgs& a);          // generations one launch consumes
+void launch_qw_decode_mega(const QwMegaArgs& a, hipStream_t s);

@@ -1030,7 +1030,8 @@ bool QwSession::mega_step(int B) {
     for (int l = 0; l < 2 && l < c.n_layers; ++l)
       fprintf(stderr, " L%d: qkv %.1f attn %.1f wo %.1f gate_up %.1f down %.1f;", l, (h[2 + 5 * l] - h[1 + 5 * l]) * 0.01, (h[3 + 5 * l] - h[2 + 5 * l]) * 0.01,
               (h[4 + 5 * l] - h[3 + 5 * l]) * 0.01, (h[5 + 5 * l] - h[4 + 5 * l]) * 0.01, (h[6 + 5 * l] - h[5 + 5 * l]) * 0.01);
-    fprintf(stderr, " total %.1f us\n", (h[5 * c.n_layers] - h[0]) * 0.01);
+    fprintf(stderr, " total %.1f us; L1 qkv inside workgroup 0: operands+mfma %.1f reduce %.1f stores acked %.1f barrier %.1f\n", (h[5 * c.n_layers] - h[0]) * 0.01,
+            (h[512] - h[516]) * 0.01, (h[513] - h[512]) * 0.01, (h[514] - h[513]) * 0.01, (h[7] - h[514]) * 0.01);
   }
   mega_gen += (unsigned int)qw_decode_mega_barriers(a);
   mega_used = true;

@@ -92,7 +92,7 @@ __device__ __forceinline__ bool mega_barrier(const QwMegaArgs& a, unsigned int g
 // n0 + 4 fgrp ..+3); with RMS also rstd of that row. A is a write-once-per-launch buffer: cached loads.
 template <int MT, bool RMS>
 __device__ __forceinline__ void mega_granule(const bf16_t* __restrict__ W, int ldw, int K, int n0, const bf16_t* A, int lda, float eps,
-                                             unsigned char* smem, float4& sum, float& rstd) {
+                                             unsigned char* smem, float4& sum, float& rstd, unsigned long long* dbg = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fgrp = lane >> 4;
   const int kslice = K / MG_WAVES, k_begin = wave * kslice;
@@ -124,6 +124,7 @@ __device__ __forceinline__ void mega_granule(const bf16_t* __restrict__ W, int l
         }
       }
   }
+  if (dbg && blockIdx.x == 0 && tid == 0) dbg[0] = wall_clock64();                                   // operands arrived, MFMAs issued
   float4* red = reinterpret_cast<float4*>(smem);                                                     // [wave][MT][64]
   float (*ss_red)[MT * 16] = reinterpret_cast<float (*)[MT * 16]>(smem + MG_WAVES * MT * 1024);
   __syncthreads();                                       // the previous granule's readers are done with `red`
@@ -354,11 +355,18 @@ __global__ __launch_bounds__(512) void qw_decode_mega_kernel(const QwMegaArgs a)
     // ---- P1: q|k|v (f32)
     for (int gr = wg; gr < qkvn / 16; gr += nwg) {
       float4 s; float r;
-      mega_granule<MT, true>(L.wqkv, d, d, gr * 16, xlo, d, a.eps, smem, s, r);
+      unsigned long long* dbg = (a.dbg_clock && layer == 1) ? a.dbg_clock + 512 : nullptr;
+      if (dbg && wg == 0 && tid == 0) dbg[4] = wall_clock64();
+      mega_granule<MT, true>(L.wqkv, d, d, gr * 16, xlo, d, a.eps, smem, s, r, dbg);
+      if (dbg && wg == 0 && tid == 0) dbg[1] = wall_clock64();
       const int m = wave * 16 + frow, n = gr * 16 + fgrp * 4;
       if (wave < MT && m < B) {
         st_sc1_u64(a.qkv + (size_t)m * qkvn + n, pack_f32x2(s.x * r, s.y * r));
         st_sc1_u64(a.qkv + (size_t)m * qkvn + n + 2, pack_f32x2(s.z * r, s.w * r));
+      }
+      if (dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wg == 0 && tid == 0) dbg[2] = wall_clock64();
       }
     }
     if (!mega_barrier(a, ++gen)) return;

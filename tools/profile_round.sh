@@ -11,10 +11,13 @@ python bench.py --workload paraformer --steps 10 > $OUT/bench_paraformer.json 2>
 python bench.py --workload whisper --steps 3 --warmup 1 > $OUT/bench_whisper.json 2> $OUT/bench_whisper.err
 python bench.py --workload whisper --seconds 30 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_whisper30.json 2> $OUT/bench_whisper30.err
 python bench.py --workload paraformer-streaming --steps 16 --warmup 8 > $OUT/bench_paraformer_streaming.json 2> $OUT/bench_paraformer_streaming.err
+python bench.py --workload qwen --steps 5 --warmup 2 > $OUT/bench_qwen.json 2> $OUT/bench_qwen.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_qwen -- python $R/bench.py --workload qwen --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats_qwen.log 2>&1
+for f in $(find $OUT/stats_qwen -name "*kernel_trace.csv"); do python $R/tools/trace_summary.py $f > $OUT/qwen_trace_summary.txt; done
 find $OUT -name "*.csv" | head -30
 for f in $(find $OUT/pmc_fetch $OUT/pmc_write -name "*counter_collection.csv"); do echo $f; head -3 $f; wc -l $f; done
 find $OUT -name "*kernel_trace.csv" -size +20M -delete

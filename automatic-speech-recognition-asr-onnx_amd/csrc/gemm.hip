@@ -345,6 +345,89 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_pipe(const GemmArgs g0) {
   else epilogue_transposed<bf16_t, NJ>(g, acc, m_wave, n_wave, lane);
 }
 
+// ------------------------------------------------------------------------------------ bf16, 256 x 256 tile, 8 waves (large M)
+// For the shapes of the Whisper / Qwen3-ASR stacks (M >= 8 k rows, N and K >= 1 k) the 128 x 64 tiles are bound by the L2 -> LDS
+// operand stream: every workgroup re-reads (128 + 64) x K operands for 128 x 64 outputs = 43 flop / byte, i.e. 3.9 GB through the
+// LDS-DMA paths for Whisper's fc1 (231 us at the ~17 TB/s the stream saturates at; measured 226 us). A 256 x 256 tile moves
+// (256 + 256) x K for 256 x 256 outputs = 128 flop / byte. 8 waves as 4 x 2, each owning 64 x 128 outputs (32 C fragments = 128
+// accumulator registers; per K step 24 fragment reads feed 64 MFMAs: 96 B / clk / CU of LDS reads at full MFMA rate); two 64 KiB
+// stages (the whole 160 KiB LDS is one workgroup's: one workgroup per CU, two waves per SIMD), same LDS-DMA staging, slot swizzle
+// and swapped orientation as the ring kernel above. Row indices are clamped to M - 1 on the global side, so the A operand needs
+// no padding rows beyond M.
+constexpr int BIG = 256;
+
+template <int ACT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_big(const GemmArgs g) {
+  constexpr int NJ = 8;                           // 128 columns per wave
+  constexpr int STAGE_BYTES = 2 * BIG * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = g.N / BIG;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+
+  const int srow = lane >> 3;
+  const int sslot = (lane & 7) ^ srow;
+  const bf16_t* a_src[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    a_src[p] = reinterpret_cast<const bf16_t*>(g.A) + (size_t)min(tile_m * BIG + p * 64 + wave * 8 + srow, g.M - 1) * g.lda + sslot * 8;
+  const int wslot = (lane & 7) ^ w_swz(wave * 8 + srow);      // rows p*64 + wave*8 + srow: p*64 leaves the key bits alone
+  const bf16_t* w_src = reinterpret_cast<const bf16_t*>(g.W) + (size_t)(tile_n * BIG + wave * 8 + srow) * g.ldw + wslot * 8;
+  const size_t w_pass = (size_t)64 * g.ldw;
+
+  auto stage = [&](int slot, int k0) {
+    unsigned char* base = smem + slot * STAGE_BYTES + wave * 1024;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[p] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + p * 8192), 16, 0, 0);
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src + p * w_pass + k0),
+                                       (__attribute__((address_space(3))) void*)(base + BIG * 128 + p * 8192), 16, 0, 0);
+  };
+
+  f32x4_t acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK16;
+  const int frow = lane & 15, fgrp = lane >> 4;
+  stage(0, 0);
+  int a_off[2][4], w_off[2][NJ];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int c = kk * 4 + fgrp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = wm * 64 + i * 16 + frow; a_off[kk][i] = r * 128 + ((c ^ (r & 7)) << 4); }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int r = wn * 128 + frag_col(j, frow); w_off[kk][j] = BIG * 128 + r * 128 + ((c ^ w_swz(r)) << 4); }
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // tile kt landed for every wave; every wave is done reading the other slot
+    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK16);
+    const unsigned char* St = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t af[4], wf[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(St + a_off[kk][i]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(St + w_off[kk][j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  epilogue_rows<bf16_t, ACT, EPI, NJ>(g, acc, tile_m * BIG + wm * 64, tile_n * BIG + wn * 128, lane);
+}
+
 // ------------------------------------------------------------------------------------ bf16, 144 x 128 tile, 8 waves
 // Row tiles of 144 = one 8 s window (137 rows padded to 144): M = 64 x 144 gives 64 row tiles, so an N = 512 GEMM is
 // exactly 256 workgroups (one per CU) and N = 2048 exactly 1024 (two rounds of two co-resident workgroups) -- the
@@ -904,6 +987,45 @@ void launch_pipe_inst(const GemmArgs& g, hipStream_t s) {
   HIP_CHECK(hipGetLastError());
 }
 
+template <int ACT, int EPI>
+void launch_big_inst(const GemmArgs& g, hipStream_t s) {
+  constexpr int lds = 2 * 2 * BIG * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big<ACT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int grid = ((g.M + BIG - 1) / BIG) * (g.N / BIG);
+  hipLaunchKernelGGL((gemm_bf16_big<ACT, EPI>), dim3(grid), dim3(512), lds, s, g);
+  HIP_CHECK(hipGetLastError());
+}
+
+// the 256 x 256 tiling pays when it fills whole rounds of the chip (one workgroup per CU) with little padding
+bool big_fits(const GemmArgs& g) {
+  static const bool off = getenv("ASR_GEMM_BIG") && getenv("ASR_GEMM_BIG")[0] == '0';
+  if (off || g.out_t || g.amax_val || g.lo_group || g.add2_rows || g.ln_colsum || g.st_out || g.m_dev || g.N % BIG || g.K % BK16 || g.M < 2048 || g.K < 512) return false;
+  const int tiles_m = (g.M + BIG - 1) / BIG, tiles = tiles_m * (g.N / BIG);
+  const int rounds = (tiles + 255) / 256;
+  return (double)tiles / (rounds * 256.0) >= 0.85 && (double)g.M / (tiles_m * BIG) >= 0.9;
+}
+
+bool launch_big(const GemmArgs& g, hipStream_t s) {
+  const int epi = (g.add ? E_ADD : 0) | (g.add2 ? E_ADD2 : 0) | (g.out_f32 ? E_F32 : 0) | (g.out_lo ? E_LO : 0) | (g.bias ? E_BIAS : 0);
+#define ASR_BIG_CASE(ACT_, EPI_) \
+  if (g.act == (ACT_) && epi == (EPI_)) { launch_big_inst<ACT_, EPI_>(g, s); return true; }
+  ASR_BIG_CASE(ACT_NONE, E_BIAS | E_LO)                      // q|k projections
+  ASR_BIG_CASE(ACT_GELU_ERF, E_BIAS | E_LO)                  // Whisper fc1
+  ASR_BIG_CASE(ACT_GELU_TANH, E_BIAS | E_LO)                 // Qwen3-ASR encoder fc1 / conv stem
+  ASR_BIG_CASE(ACT_NONE, E_BIAS | E_ADD | E_F32)             // out-proj / fc2 + residual
+  ASR_BIG_CASE(ACT_NONE, E_F32)                              // Qwen3 decoder q|k|v
+  ASR_BIG_CASE(ACT_SWIGLU, E_LO)                             // Qwen3 decoder gate|up
+  ASR_BIG_CASE(ACT_NONE, E_ADD | E_F32)                      // Qwen3 decoder o_proj / down_proj
+  ASR_BIG_CASE(ACT_NONE, E_BIAS | E_F32)                     // logits
+  ASR_BIG_CASE(ACT_RELU, E_BIAS | E_F32)
+#undef ASR_BIG_CASE
+  return false;
+}
+
 // Specialised epilogues used on the hot path; anything else runs the generic (runtime-checked) instantiation.
 template <int BN_, int STAGES>
 void launch_pipe(const GemmArgs& g, hipStream_t s) {
@@ -1045,8 +1167,13 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
       ASR_REQUIRE(t144_stages(g) == 4 ? launch_t144<4>(g, s) : launch_t144<2>(g, s), "gemm: no LayerNorm-fused instance for this epilogue");
       return;
     }
+    if (big_fits(g) && launch_big(g, s)) return;
     if (t144_enabled() && t144_fits(g, &st) && (st == 4 ? launch_t144<4>(g, s) : launch_t144<2>(g, s))) return;
     v = tall ? 2 : 4;
+  }
+  if (v == 7) {
+    ASR_REQUIRE(g.N % BIG == 0 && launch_big(g, s), "gemm: variant 7 (256 x 256 tiles) has no instance for this shape / epilogue");
+    return;
   }
   if (v == 5 || v == 6) {
     ASR_REQUIRE(!(g.out_t || g.amax_val || g.lo_group || g.add2_rows) && g.N % TN == 0, "gemm: variant %d (144-row tiles) does not support this epilogue", v);

@@ -215,7 +215,7 @@ def op_gemm_bench(M, N, K, variant=-1, epilogue=0, iters=50) -> float:
 
 def op_gemm_set_variant(variant: int = -1) -> None:
     """Pin the bf16 GEMM kernel variant for the following op_gemm calls (-1 = heuristic); tuning / test hook."""
-    op_gemm_bench(1152, 128, 64, variant, 0, 1)
+    op_gemm_bench(1152, 256, 64, variant, 0, 1)
 
 
 # =============================================================================== Whisper

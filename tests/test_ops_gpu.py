@@ -191,6 +191,25 @@ def test_gemm_144_row_tiles(variant, M, N, K, act):
     assert np.abs(got - base).max() < 2e-3 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("M,N,K,act", [(300, 256, 128, 0), (2500, 512, 576, 1), (4096, 1024, 64, 0)])
+def test_gemm_256_tiles(M, N, K, act):
+    """256 x 256 tiles (8 waves of 64 x 128, two 64 KiB stages), ragged last row tile with clamped operand rows."""
+    eng = sub("engine")
+    rng = np.random.default_rng(M + N + K)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    try:
+        eng.op_gemm_set_variant(7)
+        got = eng.op_gemm(a, w, b, act=act, precision=0)
+    finally:
+        eng.op_gemm_set_variant(-1)
+    ref = _bf16_round(a).astype(np.float64) @ _bf16_round(w).astype(np.float64).T + b
+    if act == 1:
+        ref = np.maximum(ref, 0)
+    assert np.abs(got - ref).max() < 2e-3 * max(1.0, np.abs(ref).max())
+
+
 def test_skinny_split_k_hand_over_is_exact(monkeypatch):
     """Opt-in split-K across workgroups of the skinny (weight-streaming) GEMM: partial sums handed over through agent-scope
     atomics, last-arriver reduction in split order => bit-reproducible, and a single 137-row window through the 9-row-tile

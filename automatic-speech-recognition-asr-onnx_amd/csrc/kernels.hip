@@ -1297,61 +1297,80 @@ __global__ __launch_bounds__(256) void stream_carry_kernel(const float* __restri
 
 constexpr int SA_MAXK = 64, SA_HD = 128;
 
+// One workgroup per (stream, head), 256 threads, every query row of the chunk at once: K / V (history + current rows) and up to 16
+// query rows are staged in LDS, the nq x nk scores are spread over the threads (one 128-long dot product each), a wave per
+// query row does the soft-max, and the nq x 128 outputs are spread over the threads again.
+constexpr int SA_MAXQ = 16;
+
 template <typename T>
-__global__ __launch_bounds__(128) void stream_attn_kernel(const StreamAttnArgs a) {
+__global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a) {
   __shared__ float Ks[SA_MAXK][SA_HD + 1];
   __shared__ float Vs[SA_MAXK][SA_HD + 1];
-  __shared__ float qs[SA_HD];
-  __shared__ float pr[SA_MAXK];
-  const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  __shared__ float Qs[SA_MAXQ][SA_HD + 1];
+  __shared__ float Ps[SA_MAXQ][SA_MAXK + 1];
+  const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const UttPlan qp = a.q_plan[i];
-  const int nq = qp.T, sid = qp.lang, row0 = qp.row_off;
-  if (nq <= 0) return;
+  const int nq_all = qp.T, sid = qp.lang, row0 = qp.row_off;
+  if (nq_all <= 0) return;
   const int len = a.cache_len[sid], nk = len + a.n_cur;
   const T* ck = reinterpret_cast<const T*>(a.cache_k) + ((size_t)sid * a.n_heads + h) * a.cap * SA_HD;
   const T* cv = reinterpret_cast<const T*>(a.cache_v) + ((size_t)sid * a.n_heads + h) * a.cap * SA_HD;
   const T* kk = reinterpret_cast<const T*>(a.k);
   const T* vv = reinterpret_cast<const T*>(a.v);
-  for (int p0 = 0; p0 < nk; p0 += 8) {               // 8 key rows (K and V) in flight per thread
-    float kr[8], vr[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int p = p0 + u;
-      kr[u] = 0.0f; vr[u] = 0.0f;
-      if (p < len) {
-        kr[u] = Elem<T>::load(ck + (size_t)p * SA_HD + tid);
-        vr[u] = Elem<T>::load(cv + (size_t)p * SA_HD + tid);
-      } else if (p < nk) {
-        const size_t r = (size_t)(row0 + p - len);
-        kr[u] = Elem<T>::load(kk + r * a.ld_k + a.k_col0 + h * SA_HD + tid);
-        vr[u] = Elem<T>::load(vv + r * a.ld_v + a.v_col0 + h * SA_HD + tid);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (p0 + u < nk) { Ks[p0 + u][tid] = kr[u]; Vs[p0 + u][tid] = vr[u]; }
-  }
   const T* qq = reinterpret_cast<const T*>(a.q);
   T* out = reinterpret_cast<T*>(a.ctx);
-  for (int qi = 0; qi < nq; ++qi) {
-    __syncthreads();
-    qs[tid] = Elem<T>::load(qq + (size_t)(row0 + qi) * a.ld_q + a.q_col0 + h * SA_HD + tid);
-    __syncthreads();
-    if (tid < 64) {                                   // one wave: scores, soft-max
-      float sc = -INFINITY;
-      if (tid < nk) {
-        sc = 0.0f;
-        for (int e = 0; e < SA_HD; ++e) sc = fmaf(qs[e], Ks[tid][e], sc);
+  {                                                      // stage K and V: thread = (row parity, column), 8 rows in flight
+    const int c = tid & 127, half = tid >> 7;
+    for (int p0 = half; p0 < nk; p0 += 16) {
+      float kr[8], vr[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + 2 * u;
+        kr[u] = 0.0f; vr[u] = 0.0f;
+        if (p < len) {
+          kr[u] = Elem<T>::load(ck + (size_t)p * SA_HD + c);
+          vr[u] = Elem<T>::load(cv + (size_t)p * SA_HD + c);
+        } else if (p < nk) {
+          const size_t r = (size_t)(row0 + p - len);
+          kr[u] = Elem<T>::load(kk + r * a.ld_k + a.k_col0 + h * SA_HD + c);
+          vr[u] = Elem<T>::load(vv + r * a.ld_v + a.v_col0 + h * SA_HD + c);
+        }
       }
-      const float mx = wave_max(sc);
-      const float ex = tid < nk ? expf(sc - mx) : 0.0f;
-      const float sum = wave_sum(ex);
-      pr[tid] = ex / sum;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (p0 + 2 * u < nk) { Ks[p0 + 2 * u][c] = kr[u]; Vs[p0 + 2 * u][c] = vr[u]; }
+    }
+  }
+  for (int q0 = 0; q0 < nq_all; q0 += SA_MAXQ) {
+    const int nq = min(SA_MAXQ, nq_all - q0);
+    __syncthreads();                                     // K / V staged; the previous block's readers are done with Qs / Ps
+    for (int e = tid; e < nq * SA_HD; e += 256) {
+      const int q = e >> 7, c = e & 127;
+      Qs[q][c] = Elem<T>::load(qq + (size_t)(row0 + q0 + q) * a.ld_q + a.q_col0 + h * SA_HD + c);
     }
     __syncthreads();
-    float acc = 0.0f;
-    for (int p = 0; p < nk; ++p) acc = fmaf(pr[p], Vs[p][tid], acc);
-    Elem<T>::store(out + (size_t)(row0 + qi) * a.ld_ctx + h * SA_HD + tid, acc);
+    for (int e = tid; e < nq * nk; e += 256) {
+      const int q = e / nk, k = e - q * nk;
+      float sc = 0.0f;
+#pragma unroll 8
+      for (int c = 0; c < SA_HD; ++c) sc = fmaf(Qs[q][c], Ks[k][c], sc);
+      Ps[q][k] = sc;
+    }
+    __syncthreads();
+    for (int q = wave; q < nq; q += 4) {                 // nk <= 64: one lane per key
+      const float sc = lane < nk ? Ps[q][lane] : -INFINITY;
+      const float mx = wave_max(sc);
+      const float ex = lane < nk ? expf(sc - mx) : 0.0f;
+      const float sum = wave_sum(ex);
+      if (lane < nk) Ps[q][lane] = ex / sum;
+    }
+    __syncthreads();
+    for (int e = tid; e < nq * SA_HD; e += 256) {
+      const int q = e >> 7, c = e & 127;
+      float acc = 0.0f;
+      for (int p = 0; p < nk; ++p) acc = fmaf(Ps[q][p], Vs[p][c], acc);
+      Elem<T>::store(out + (size_t)(row0 + q0 + q) * a.ld_ctx + h * SA_HD + c, acc);
+    }
   }
 }
 
@@ -1487,7 +1506,7 @@ void launch_stream_carry(const float* x, int ld, const UttPlan* plan, int n_acti
 template <typename T>
 void launch_stream_attn(const StreamAttnArgs& a, int n_active, hipStream_t s) {
   ASR_REQUIRE(a.cap + a.n_cur <= SA_MAXK, "stream_attn: %d + %d keys exceed %d", a.cap, a.n_cur, SA_MAXK);
-  hipLaunchKernelGGL(stream_attn_kernel<T>, dim3(n_active, a.n_heads), dim3(128), 0, s, a);
+  hipLaunchKernelGGL(stream_attn_kernel<T>, dim3(n_active, a.n_heads), dim3(256), 0, s, a);
   HIP_CHECK(hipGetLastError());
 }
 template void launch_stream_attn<float>(const StreamAttnArgs&, int, hipStream_t);

@@ -65,6 +65,7 @@ struct SvSession : asr_session {
       b->release();
     for (auto& kv : taps) kv.second.buf.release();
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (st_graph) (void)hipGraphExecDestroy(st_graph);
     if (h_plan) (void)hipHostFree(h_plan);
     if (h_out) (void)hipHostFree(h_out);
     prof.release();
@@ -85,6 +86,7 @@ struct SvSession : asr_session {
   bool use_fused = true;        // fused q|k|v + attention + FSMN kernel for windows of <= 144 rows (ASR_SANM_FUSED=0 disables)
   hipGraphExec_t graph_exec = nullptr;
   uint64_t graph_key = 0, eager_key = 0, ws_epoch = 1;
+  hipGraphExec_t st_graph = nullptr; uint64_t st_graph_key = 0, st_eager_key = 0;     // streaming chunk step
 
   void init();
   template <typename T> void enqueue(const struct SvRunCtx& r);
@@ -792,6 +794,9 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
   const int32_t* d_blk_f0 = d_blk_utt + n;
   const int32_t* d_row_utt = d_blk_f0 + n;
 
+  // Everything below reads its geometry from the uploaded plan and the device-side state (history lengths, fired-token counts), so
+  // the launch sequence depends on n only: one captured hipGraph replays every chunk step of a given set size.
+  auto enqueue = [&]() {
   // ---- front-end: fbank of the chunk, LFR rows, carried rows in front (:386-399)
   {
     ProfScope ps(prof, "fbank", stream);
@@ -959,6 +964,40 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
     launch_gather_tokens(d_ids.as<int32_t>(), tplan, n, d_tok.as<int32_t>(), max_tokens, stream);
   }
   launch_stream_advance(dp, tplan, n, st_B, st_en_cap, n_cur, st_de_cap, st_enlen.as<int32_t>(), st_delen.as<int32_t>(), stream);
+  };
+  {
+    const bool graphable = use_graph && !taps_enabled && !prof.enabled;
+    uint64_t key = 1469598103934665603ull;
+    for (const void* q : {(const void*)d_aud, (const void*)d_plan.ptr, (const void*)d_mel.ptr, (const void*)d_x0.ptr, (const void*)d_xa.ptr, (const void*)d_xb.ptr,
+                          (const void*)d_h.ptr, (const void*)d_sqkv.ptr, (const void*)d_skv.ptr, (const void*)d_qk.ptr, (const void*)d_ctx.ptr, (const void*)d_mem.ptr,
+                          (const void*)d_ffn.ptr, (const void*)d_amax_v.ptr, (const void*)d_amax_i.ptr, (const void*)d_ids.ptr, (const void*)d_tok.ptr, (const void*)d_num.ptr,
+                          (const void*)d_logits.ptr, (const void*)d_enc_lo.ptr, (const void*)d_cifa.ptr, (const void*)d_alpha.ptr, (const void*)d_dec.ptr, (const void*)d_x2.ptr,
+                          (const void*)d_sa.ptr, (const void*)d_ffn32.ptr, (const void*)d_tplan.ptr, (const void*)stream, (const void*)(uintptr_t)n,
+                          (const void*)(uintptr_t)max_tokens})
+      key = (key ^ (uint64_t)(uintptr_t)q) * 1099511628211ull;
+    if (graphable && st_graph && key == st_graph_key) {
+      HIP_CHECK(hipGraphLaunch(st_graph, stream));
+    } else if (graphable && key == st_eager_key) {
+      if (st_graph) { (void)hipGraphExecDestroy(st_graph); st_graph = nullptr; }
+      hipGraph_t graph = nullptr;
+      HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+      try {
+        enqueue();
+      } catch (...) {
+        (void)hipStreamEndCapture(stream, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        throw;
+      }
+      HIP_CHECK(hipStreamEndCapture(stream, &graph));
+      HIP_CHECK(hipGraphInstantiate(&st_graph, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      st_graph_key = key;
+      HIP_CHECK(hipGraphLaunch(st_graph, stream));
+    } else {
+      enqueue();                                         // first step of a geometry runs eagerly (lazy kernel attributes, workspaces)
+      if (graphable) st_eager_key = key;
+    }
+  }
   if (taps_enabled) save_tap("logits", d_logits.ptr, rows, c.vocab, vpad, 4);
   HIP_CHECK(hipMemcpyAsync(h_out, d_tok.ptr, (size_t)n * max_tokens * 4, hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipMemcpyAsync((unsigned char*)h_out + (size_t)n * max_tokens * 4, d_num.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, stream));

@@ -619,7 +619,11 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
   const int n0 = blockIdx.x * 16;
   const int KS = g.sk_splits > 1 ? g.sk_splits : 1, ks = blockIdx.y;
   const int kslice = g.K / (SK_WAVES * KS);               // multiple of 32 (host-checked)
-  const int k_begin = (ks * SK_WAVES + wave) * kslice;
+  // Every workgroup reads the SAME activation rows: if all of them walked K in the same order, each L2 channel would be hit by all
+  // CUs of its XCD at the same moment while the others idle. Rotating the wave -> K-slice assignment by the workgroup index spreads
+  // the simultaneous requests over the slices (the cross-wave sum below is order-stable per workgroup, so results stay reproducible).
+  const int kw = (wave + (int)blockIdx.x) & (SK_WAVES - 1);
+  const int k_begin = (ks * SK_WAVES + kw) * kslice;
   const bf16_t* wp = reinterpret_cast<const bf16_t*>(g.W) + (size_t)(n0 + frow) * g.ldw + k_begin + fgrp * 8;
 
   constexpr int U = MT >= 4 ? 4 : 8;                    // K-steps per trip: U x 16-byte weight loads in flight per lane (4 row tiles: fewer, to stay under 128 VGPRs => two workgroups per CU)

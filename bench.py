@@ -103,8 +103,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
-    ap.add_argument("--workload", choices=("sensevoice", "whisper", "paraformer", "paraformer-streaming", "qwen"), default="sensevoice",
+    ap.add_argument("--workload", choices=("sensevoice", "whisper", "paraformer", "paraformer-streaming", "qwen", "mixed"), default="sensevoice",
                     help="sensevoice = BASELINE.json configs[1] (default, the headline line); whisper = large-v3 encoder + greedy decode")
+    ap.add_argument("--streams", type=int, default=256, help="mixed: concurrent Paraformer streams per GPU")
     ap.add_argument("--decode-tokens", type=int, default=0, help="whisper: generated tokens per utterance (default 4 per audio second)")
     args = ap.parse_args()
     if args.workload == "whisper":
@@ -115,6 +116,8 @@ def main():
         return main_paraformer_streaming(args)
     if args.workload == "qwen":
         return main_qwen(args)
+    if args.workload == "mixed":
+        return main_mixed(args)
 
     import torch
     import torch.distributed as dist
@@ -691,6 +694,130 @@ def main_qwen(args):
                                    "host_cores": int(os.cpu_count() or 0), "kind": "port",
                                    "sample": f"{n_done} x {args.seconds:g} s utterances, batch 1, prefill + {n_tok - 1} decode steps, torch-CPU f32 oracle "
                                              f"(oracle/qwen_asr_oracle.py), {el:.1f} s wall"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_mixed(args):
+    """BASELINE.json configs[4], the single-GPU part: Qwen3-ASR-0.6B (greedy -- the reference has no beam decoder) over batches of 8 s
+    utterances AND Paraformer-large streaming chunk steps, CONCURRENTLY on one GPU: two native sessions, each on its own HIP stream,
+    driven by two host threads (ctypes releases the GIL inside the C ABI). Both paths are chains of small dependent launches that
+    leave most CUs idle, so they overlap. A step = one Qwen batch (prefill + decode); the streaming thread advances chunk steps for as
+    long as the K Qwen steps take. value = audio seconds both paths processed / wall time; the solo rates are measured first."""
+    import threading
+    import torch
+    import torch.distributed as dist
+    cfgm = importlib.import_module(PKG + ".config")
+    ckm = importlib.import_module(PKG + ".checkpoints")
+    arena = importlib.import_module(PKG + ".arena")
+    eng = importlib.import_module(PKG + ".engine")
+    dp = importlib.import_module(PKG + ".dist")
+    rank, local_rank, world = dp.init_from_env()
+    assert world == args.gpus and torch.cuda.is_available()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    # ---- Qwen3-ASR batch path
+    qcfg = cfgm.qwen_asr_0p6b()
+    B, n_samples = args.batch, int(args.seconds * qcfg.sample_rate)
+    n_tok = args.decode_tokens or int(round(4 * args.seconds))
+    blob = None
+    if rank == 0:
+        blob = arena.build_qwen_asr_arena(qcfg, ckm.synth_qwen_asr_checkpoint(qcfg, seed=0), arena.PRECISION_BF16)
+    arena_dev = dp.broadcast_arena(blob, device)
+    blob = None
+    qsess = eng.QwenAsrSession(qcfg, arena_dev, arena.PRECISION_BF16, local_rank, arena_device_ptr=arena_dev.data_ptr(), arena_bytes=arena_dev.numel())
+    q_audio = torch.from_numpy(ckm.synth_audio("unit", B, n_samples, seed=1234 + rank)).to(device)
+    q_offs = np.arange(B + 1, dtype=np.int64) * n_samples
+    pre, post = [list(range(1000, 1009))], [list(range(2000, 2010))]
+    # ---- Paraformer streaming path
+    pcfg = cfgm.paraformer_large()
+    S, chunk, n_chunks = args.streams, 8000, 8
+    psess = eng.ParaformerStreamSession(pcfg, ckm.synth_paraformer_checkpoint(pcfg, seed=0), precision=0, device_id=local_rank, chunk=chunk, max_streams=S)
+    p_np = ckm.synth_audio("kaldi", S, n_chunks * chunk, seed=4321 + rank)[:, 0].reshape(S, n_chunks, chunk)
+    p_audio = torch.from_numpy(np.ascontiguousarray(p_np.transpose(1, 0, 2))).to(device)
+    sids = list(range(S))
+
+    def qwen_step():
+        qsess.prefill_packed(None, q_offs, pre, post, want_logits=False, audio_device_ptr=q_audio.data_ptr())
+        return qsess.generate(n_tok, stop_ids=())
+
+    def stream_step(i):
+        k = i % n_chunks
+        if k == 0:
+            psess.reset(-1)
+        psess.step(None, sids, audio_device_ptr=p_audio[k].data_ptr())
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(max(args.warmup, 1)):
+        qwen_step()
+    for i in range(2 * n_chunks):
+        stream_step(i)
+    # solo rates
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        qwen_step()
+    fence()
+    q_solo = (time.perf_counter() - t0) / args.steps
+    t0 = time.perf_counter()
+    for i in range(4 * n_chunks):
+        stream_step(i)
+    fence()
+    p_solo = (time.perf_counter() - t0) / (4 * n_chunks)
+    # concurrent
+    stop = threading.Event()
+    chunks_done = [0]
+
+    def stream_loop():
+        torch.cuda.set_device(local_rank)
+        i = 0
+        while not stop.is_set():
+            stream_step(i)
+            i += 1
+        chunks_done[0] = i
+
+    fence()
+    th = threading.Thread(target=stream_loop)
+    t0 = time.perf_counter()
+    th.start()
+    for _ in range(args.steps):
+        qwen_step()
+    stop.set()
+    th.join()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([chunks_done[0]], dtype=torch.float64, device=device)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total_chunks = float(c.item())
+    else:
+        total_chunks = float(chunks_done[0])
+    if rank == 0:
+        q_audio_s = world * args.steps * B * args.seconds
+        p_audio_s = total_chunks * S * chunk / pcfg.sample_rate
+        solo_q, solo_p = B * args.seconds / q_solo, S * chunk / pcfg.sample_rate / p_solo
+        out = {"metric": "audio-sec/s, Qwen3-ASR-0.6B greedy (batch %d x %g s) + Paraformer-large streaming (%d streams, chunk 8000) concurrently on each GPU" % (B, args.seconds, S),
+               "value": round((q_audio_s + p_audio_s) / elapsed, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+               "data": "synthetic",
+               "config": {"workload": "mixed: Qwen3-ASR-0.6B bf16 batches (prefill + %d greedy steps) and Paraformer-large streaming chunk steps, two sessions on "
+                                      "two HIP streams driven by two host threads" % (n_tok - 1),
+                          "global_batch": world * B, "streams": world * S, "parallelism": f"dp{world}"},
+               "concurrent": {"qwen_audio_s_per_s": round(q_audio_s / elapsed, 1), "streaming_audio_s_per_s": round(p_audio_s / elapsed, 1),
+                              "streaming_chunk_steps": int(total_chunks), "streaming_ms_per_chunk_step": round(elapsed / max(total_chunks / world, 1) * 1e3, 2)},
+               "solo_per_gpu": {"qwen_audio_s_per_s": round(solo_q, 1), "qwen_ms_per_step": round(q_solo * 1e3, 2), "streaming_audio_s_per_s": round(solo_p, 1),
+                                "streaming_ms_per_chunk_step": round(p_solo * 1e3, 2)},
+               "roofline": {"bound": "hbm", "kernel": "both launch chains are latency-bound; see the qwen and paraformer-streaming workloads", "achieved": None,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

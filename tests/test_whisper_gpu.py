@@ -207,3 +207,32 @@ def test_maximum_30s_window_with_a_short_one_f32():
             assert np.array_equal(got_i[b], want["token_ids"][b])
     with pytest.raises(Exception, match="max_audio_len|samples"):
         sess.encode([unit_audio(1, cfg.max_audio_len + 160)])
+
+
+def test_concurrent_sessions_on_separate_streams_match_sequential_runs():
+    """Serving mode: independent sessions driven by separate host threads (own HIP stream and state, ctypes releases the GIL) -- each must
+    produce exactly what it produces alone."""
+    import threading
+    cfg, ck, sup, beg, _ = _session("whisper_mid_test", BF16)
+    eng = sub("engine")
+    prompt = np.tile(np.array([[cfg.sot_id, cfg.first_language_id, cfg.transcribe_id, cfg.no_timestamps_id]], np.int32), (3, 1))
+    jobs = [[unit_audio(700 + 10 * j + i, 48000 + 16000 * i) for i in range(3)] for j in range(3)]
+
+    def run(sess, audios, out, k, reps):
+        for _ in range(reps):
+            sess.encode(audios)
+            sess.prefill(prompt, want_logits=False)
+            out[k] = sess.generate(12, eos_id=-1)
+
+    sessions = [eng.WhisperSession.from_checkpoint(cfg, ck, precision=BF16, suppress_tokens=sup, begin_suppress_tokens=beg) for _ in jobs]
+    alone, together = [None] * 3, [None] * 3
+    for k, (s, a) in enumerate(zip(sessions, jobs)):
+        run(s, a, alone, k, 1)
+    ths = [threading.Thread(target=run, args=(s, a, together, k, 4)) for k, (s, a) in enumerate(zip(sessions, jobs))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for k in range(3):
+        for b in range(3):
+            assert np.array_equal(alone[k][b], together[k][b]), (k, b)

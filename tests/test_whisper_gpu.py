@@ -236,3 +236,18 @@ def test_concurrent_sessions_on_separate_streams_match_sequential_runs():
     for k in range(3):
         for b in range(3):
             assert np.array_equal(alone[k][b], together[k][b]), (k, b)
+    # the same through the pool: batches go to whichever session is free, results come back in submission order
+    def transcribe(sess, audios):
+        sess.encode(audios)
+        sess.prefill(prompt, want_logits=False)
+        return sess.generate(12, eos_id=-1)
+
+    it = iter(sessions)
+    with sub("pool").SessionPool(lambda i: next(it), n=3) as pool:
+        got = pool.map(transcribe, [(jobs[k % 3],) for k in range(7)])
+        bad = pool.submit(lambda sess: sess.prefill(np.zeros((5, 1), np.int32)))
+        with pytest.raises(Exception):
+            bad.result()
+    for k in range(7):
+        for b in range(3):
+            assert np.array_equal(got[k][b], alone[k % 3][b]), (k, b)

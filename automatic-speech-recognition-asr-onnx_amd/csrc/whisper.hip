@@ -47,6 +47,7 @@ struct WhSession : asr_session {
   DeviceBuffer d_noise;                // caller-supplied uniforms [B][top_k] for the next step (parity tests); consumed once
   bool noise_armed = false;
   float penalty_value = 1.0f;          // 1.0 = plain greedy (REPEAT_PENALTY, Inference_Whisper_ONNX.py:78)
+  bool track_history = false;          // GREEDY_SEARCH graphs append every pick to save_id even while the penalty value is 1.0
   int penalty_range = 20;
   bool use_graph = true;
   hipGraphExec_t dec_graph = nullptr;
@@ -452,7 +453,7 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
       // BEGIN_SUPPRESS (-inf on begin_suppress_tokens) applies to the head after a prefill only (:228-240)
       launch_argmax_rows(d_logits.as<float>(), vpad, B, c.vocab, is_prefill ? begin : nullptr, d_next.as<int32_t>(), stream);
     }
-    if (penalised || sampling) {           // GREEDY_SEARCH / the sampling head append their pick to the history (:243-251,306)
+    if (penalised || sampling || track_history) {   // GREEDY_SEARCH / the sampling head append their pick to the history (:243-251,306)
       launch_append_ids(d_next.as<int32_t>(), B, d_save.as<int32_t>(), c.max_target_positions, d_nsaved.as<int32_t>(), stream);
       launch_add_scalar(d_nsaved.as<int32_t>(), 1, stream);
     }
@@ -604,6 +605,17 @@ extern "C" int asr_whisper_set_penalty(asr_session* s, float repeat_penalty, int
     if (w->penalty_value != repeat_penalty || w->penalty_range != penalty_range) {
       w->penalty_value = repeat_penalty;
       w->penalty_range = penalty_range;
+      ++w->ws_epoch;                       // the captured decode graph bakes the head in: re-capture
+    }
+  });
+}
+
+extern "C" int asr_whisper_track_history(asr_session* s, int enable) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 2, "whisper_track_history: not a Whisper session");
+    WhSession* w = static_cast<WhSession*>(s);
+    if (w->track_history != (enable != 0)) {
+      w->track_history = enable != 0;
       ++w->ws_epoch;                       // the captured decode graph bakes the head in: re-capture
     }
   });

@@ -300,6 +300,10 @@ class WhisperSession(_Session):
         """Decode head: 1.0 = plain arg-max; else penalty-greedy (APPLY_PENALTY + GREEDY_SEARCH, the reference host's default)."""
         _lib.check(_lib.load().asr_whisper_set_penalty(self._h, C.c_float(repeat_penalty), int(penalty_range)))
 
+    def track_history(self, enable: bool):
+        """Append every pick to the device-side id history even while the penalty value is 1.0 (what the *PenaltyGreedy graphs do)."""
+        _lib.check(_lib.load().asr_whisper_track_history(self._h, int(enable)))
+
     def set_sampling(self, enable: bool, temperature: float = 0.8, top_k: int = 10, top_p: float = 0.95,
                      repetition_penalty: float = 1.0, seed: int = 0):
         """TOPK_TOPP_SAMPLING head (USE_SAMPLING in the reference host); enable=False restores arg-max / penalty-greedy."""

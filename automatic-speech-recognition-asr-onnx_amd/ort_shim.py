@@ -269,6 +269,15 @@ class InferenceSession:
             self._native = ParaformerSession(self._cfg, blob, info["precision"], device_id)
             self._inputs = [NodeArg("audio", [1, 1, "audio_len"], np.float32)]
             self._outputs = [NodeArg("token_ids", [1, "num_token"], np.int32), NodeArg("num_id", [1], np.int32)]
+        elif self._kind == "whisper_graph":          # one of Whisper's merged graphs: state lives in the folder's shared native session
+            from .ort_shim_whisper import WhisperGraph
+            path = str(path_or_bytes)
+            if not os.path.isfile(path) and path.endswith(".onnx"):
+                path = path[:-5] + ".asrmodel"
+            self._graph = WhisperGraph(path, info, device_id, load_model)
+            self._native = self._graph.sh.native
+            self._inputs = [NodeArg(n, sh, dt) for n, sh, dt in self._graph.inputs]
+            self._outputs = [NodeArg(n, sh, dt) for n, sh, dt in self._graph.outputs]
         else:
             raise ValueError(f"unknown model kind {self._kind!r}")
         self._input_names = [a.name for a in self._inputs]
@@ -340,6 +349,8 @@ class InferenceSession:
             return self._run_paraformer(feeds)
         if self._kind == "metadata":
             return {"metadata_marker_out": np.asarray(feeds["metadata_marker"].numpy())}
+        if self._kind == "whisper_graph":
+            return self._graph.execute(feeds, OrtValue)
         raise ValueError(self._kind)
 
     def run_with_iobinding(self, binding: IOBinding, run_options: RunOptions | None = None):
@@ -349,7 +360,9 @@ class InferenceSession:
             if name not in binding._out_requests:
                 continue
             target = binding._out_requests[name]
-            if target is None:
+            if isinstance(results[name], OrtValue):                # state handles / values the engine keeps a reference to
+                outs.append(results[name])
+            elif target is None:
                 outs.append(OrtValue(results[name], "cpu", 0))     # ownership passes to the returned value
             else:
                 target.update_inplace(results[name])
@@ -360,7 +373,7 @@ class InferenceSession:
         feeds = {k: OrtValue(np.asarray(v, dtype=self._dtype_of(k)), "cpu", 0) for k, v in input_feed.items()}
         results = self._execute(feeds)
         names = list(output_names) if output_names else self._output_names
-        return [results[n] for n in names]
+        return [results[n].numpy() if isinstance(results[n], OrtValue) else results[n] for n in names]
 
     def _dtype_of(self, name):
         from .ort_io import numpy_dtype

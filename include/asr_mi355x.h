@@ -165,6 +165,10 @@ int asr_whisper_generate(asr_session* s, int max_new, int eos_id, int32_t* token
  * on the device and restarts at every prefill. Applies to prefill / decode / generate; logits_out then holds the
  * penalised logits. */
 int asr_whisper_set_penalty(asr_session* s, float repeat_penalty, int penalty_range);
+/* The *PenaltyGreedy graphs run GREEDY_SEARCH (:243-251) on every step, so save_id grows even while the host still feeds
+ * penalty_penalty_value = 1.0 (before PENALTY_RANGE ids exist, Inference_Whisper_ONNX.py:630-632): enable = 1 keeps appending the
+ * picks to the device-side history whatever the penalty value is (the onnxruntime shim drives the value per step). */
+int asr_whisper_track_history(asr_session* s, int enable);
 /* decode head TOPK_TOPP_SAMPLING (Export_Whisper.py:263-308; USE_SAMPLING / TEMPERATURE / TOP_K / TOP_P /
  * SAMPLING_REPETITION_PENALTY, Inference_Whisper_ONNX.py:71-75): repetition penalty over every previously sampled id,
  * temperature, top-k (1..64), top-p, Gumbel-max. enable = 0 returns to the arg-max / penalty-greedy head. The reference draws

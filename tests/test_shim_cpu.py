@@ -139,3 +139,32 @@ def test_paraformer_decode_modes():
     assert pf.decode_tokens(["你", "好"], "zh") == "你好"
     sp, langs = pf.build_tokenizer_metadata(["<blank>", "<s>", "</s>", "a", "<unk>"], "en", "en")
     assert sp == {"blank": 0, "eos": 2, "stop": [2], "unknown": 4, "bos": 1} and langs["en"]["decode_mode"] == "en"
+
+
+def test_whisper_graph_io_names_follow_the_merged_graphs():
+    """The reference host derives its binding plan from the NAMES and ORDER of the merged graphs' inputs / outputs
+    (Whisper/Inference_Whisper_ONNX.py:323-392); `graph_io` must keep them for every role x strategy."""
+    wg, cfg = sub("ort_shim_whisper"), sub("config").whisper_tiny_test()
+    L = cfg.n_dec_layers
+    for strategy in wg.STRATEGIES:
+        for role in ("probe_prefill", "prefill", "decode"):
+            ins, outs = wg.graph_io(cfg, role, strategy)
+            names_in, names_out = [n for n, _, _ in ins], [n for n, _, _ in outs]
+            assert names_in[:2 * L] == [f"in_de_key_layer_{i}" for i in range(L)] + [f"in_de_value_layer_{i}" for i in range(L)]
+            assert not names_in[2 * L].startswith("in_de_")                       # the state block ends where the planner's loop breaks
+            assert names_out[:2 * L] == [f"out_de_key_layer_{i}" for i in range(L)] + [f"out_de_value_layer_{i}" for i in range(L)]
+            assert ("audio" in names_in) == (role == "probe_prefill")
+            assert any(n.startswith("en_key_") for n in names_in) == (role != "probe_prefill")
+            assert any(n.startswith("encoder_en_key_") for n in names_out) == (role == "probe_prefill")
+            assert ("logits" in names_out) == (role != "decode")
+            assert ("decode_kv_seq_len" in names_in) == (role == "decode") and ("prefill_history_len" in names_in) == (role != "decode")
+            assert names_out[-1] == ("decode_kv_seq_len_next" if role == "decode" else "prefill_kv_seq_len")
+            assert wg.MAX_OUT[strategy] in names_out
+            if strategy == "penalty_greedy":
+                assert "greedy_save_id_in" in names_in and "greedy_save_id_out" in names_out
+                assert ("penalty_penalty_value" in names_in) == (role == "decode") == ("penalty_save_id_in" in names_in)
+            if strategy == "sampling":
+                assert all(n in names_in for n in wg.SAMPLING_INPUTS) and "sampling_previous_ids" in names_in and "sampling_save_id_out" in names_out
+            if strategy == "greedy":
+                assert not any(n.startswith(("greedy_", "penalty_", "sampling_")) for n in names_in + names_out)
+    assert wg.graph_io(cfg, "no_speech", "greedy") == ([("logits", ["batch", cfg.vocab], np.float32)], [("no_speech_prob", ["batch"], np.float32)])

@@ -79,6 +79,7 @@ SIGNATURES = {
     "asr_qwen_decode": (_i, [_vp, _ip, _ip, _fp]),
     "asr_qwen_generate": (_i, [_vp, _i, _ip, _i, _ip, _ip]),
     "asr_qwen_set_penalty": (_i, [_vp, C.c_float, _i]),
+    "asr_qwen_track_history": (_i, [_vp, _i]),
     "asr_qwen_set_sampling": (_i, [_vp, _i, C.c_float, _i, C.c_float, C.c_float, C.c_uint64]),
     "asr_qwen_set_sampling_noise": (_i, [_vp, _fp, _i]),
     "asr_mem_alloc": (_i, [_i, _sz, C.POINTER(_vp)]),

@@ -465,6 +465,7 @@ struct QwSession : asr_session {
   bool no_fuse = false, use_graph = true;
   // decode head (Inference_Qwen_ASR_ONNX.py:369-376): arg-max, penalty-greedy (APPLY_PENALTY + GREEDY_SEARCH) or top-k / top-p sampling
   float penalty_value = 1.0f; int penalty_range = 10;
+  bool track_history = false;          // GREEDY_SEARCH graphs append every pick to save_id whatever the penalty value is
   bool sampling = false, noise_armed = false; float temperature = 0.8f, top_p = 0.95f, samp_rep_penalty = 1.0f; int top_k = 10; uint64_t samp_seed = 0;
   uint64_t head_epoch = 0;
   // persistent decode-step kernel (qwen_mega.hip): barrier state, per-layer pointer table, generation counter
@@ -667,7 +668,7 @@ void QwSession::logits_head(const DecPass& P) {
     } else {
       launch_argmax_rows(d_logits.as<float>(), vpad, B, c.vocab, nullptr, d_next.as<int32_t>(), stream);
     }
-    if (penalised || sampling) {                         // GREEDY_SEARCH / the sampling head append their pick to save_id
+    if (penalised || sampling || track_history) {        // GREEDY_SEARCH / the sampling head append their pick to save_id
       launch_append_ids(d_next.as<int32_t>(), B, d_save.as<int32_t>(), c.max_seq_len, d_nsaved.as<int32_t>(), stream);
       launch_add_scalar(d_nsaved.as<int32_t>(), 1, stream);
     } }
@@ -1167,6 +1168,17 @@ extern "C" int asr_qwen_set_penalty(asr_session* s, float repeat_penalty, int pe
       q->penalty_value = repeat_penalty;
       q->penalty_range = penalty_range;
       ++q->head_epoch;                     // the captured decode graph bakes the head in: re-capture
+    }
+  });
+}
+
+extern "C" int asr_qwen_track_history(asr_session* s, int enable) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 5, "qwen_track_history: not a Qwen3-ASR session");
+    QwSession* q = static_cast<QwSession*>(s);
+    if (q->track_history != (enable != 0)) {
+      q->track_history = enable != 0;
+      ++q->head_epoch;
     }
   });
 }

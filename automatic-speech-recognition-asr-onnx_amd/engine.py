@@ -523,6 +523,10 @@ class QwenAsrSession(_Session):
         """Decode head: 1.0 = plain arg-max; else penalty-greedy (the reference host's default is 0.8 over the last 10 ids)."""
         _lib.check(_lib.load().asr_qwen_set_penalty(self._h, C.c_float(repeat_penalty), int(penalty_range)))
 
+    def track_history(self, enable: bool):
+        """Append every pick to the device-side id history whatever the penalty value is (what the *_Penalty_Greedy graphs do)."""
+        _lib.check(_lib.load().asr_qwen_track_history(self._h, int(enable)))
+
     def set_sampling(self, enable: bool, temperature: float = 0.8, top_k: int = 10, top_p: float = 0.95, repetition_penalty: float = 1.0, seed: int = 0):
         _lib.check(_lib.load().asr_qwen_set_sampling(self._h, int(enable), C.c_float(temperature), int(top_k), C.c_float(top_p),
                                                      C.c_float(repetition_penalty), C.c_uint64(seed)))

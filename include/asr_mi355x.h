@@ -214,6 +214,7 @@ int asr_qwen_decode(asr_session* s, const int32_t* ids, int32_t* next_ids_out, f
  * uniforms of asr_whisper_set_sampling; set_sampling_noise supplies the next step's uniforms [batch][top_k] (parity hook). The id
  * history lives on the device and restarts at every prefill. */
 int asr_qwen_set_penalty(asr_session* s, float repeat_penalty, int penalty_range);
+int asr_qwen_track_history(asr_session* s, int enable);   /* like asr_whisper_track_history: the *_Penalty_Greedy graphs append every pick */
 int asr_qwen_set_sampling(asr_session* s, int enable, float temperature, int top_k, float top_p, float repetition_penalty, uint64_t seed);
 int asr_qwen_set_sampling_noise(asr_session* s, const float* uniforms, int count);
 /* continuation after a prefill with the selected head (:687-745): tokens_out host [B][max_new], n_out host [B]; a sequence ends at

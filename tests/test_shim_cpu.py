@@ -168,3 +168,26 @@ def test_whisper_graph_io_names_follow_the_merged_graphs():
             if strategy == "greedy":
                 assert not any(n.startswith(("greedy_", "penalty_", "sampling_")) for n in names_in + names_out)
     assert wg.graph_io(cfg, "no_speech", "greedy") == ([("logits", ["batch", cfg.vocab], np.float32)], [("no_speech_prob", ["batch"], np.float32)])
+
+
+def test_qwen_graph_io_names_and_embedding_handles():
+    """Qwen3-ASR host plans positionally after a leading `past_*` block (Inference_Qwen_ASR_ONNX.py:315-366); the Embed graph's output is
+    an id-carrying tensor that survives the host's `array_for` conversions."""
+    wq, cfg, io = sub("ort_shim_qwen"), sub("config").qwen_asr_tiny(), sub("ort_io")
+    L = cfg.n_layers
+    for strategy in wq.STRATEGIES:
+        for role in ("prefill", "decode"):
+            ins, outs = wq.graph_io(cfg, role, strategy)
+            ni, no = [n for n, _, _ in ins], [n for n, _, _ in outs]
+            assert ni[:2 * L] == [f"past_key_{i}" for i in range(L)] + [f"past_value_{i}" for i in range(L)] and not ni[2 * L].startswith("past_")
+            assert no[:2 * L] == [f"present_key_{i}" for i in range(L)] + [f"present_value_{i}" for i in range(L)]
+            assert len(no) - 2 * L == (2 if strategy == "greedy" else 3)             # max id, (save ids), kv_seq_len -- taken positionally
+            assert ("hidden_states" in ni) == (role == "decode") and ("audio" in ni) == (role == "prefill")
+            if strategy == "penalty_greedy":
+                assert "penalty_greedy_save_id_in" in ni and ("penalty_save_id_in" in ni) == (role == "decode")
+            if strategy == "sampling":
+                assert "sampling_previous_ids" in ni and all(n in ni for n in wq.SAMPLING_INPUTS)
+    e = wq.ids_as_embedding([3, 151935, 0], cfg.d_model)
+    meta = sub("ort_shim").NodeArg("query_embed", [1, "query_len", cfg.d_model], np.float32)
+    assert wq.embedding_as_ids(io.array_for(meta, e, axes={0: 1, 1: 3}), "query_embed") == [3, 151935, 0]
+    assert wq.embedding_as_ids(np.zeros((1, 0, cfg.d_model), np.float32), "query_embed") == []

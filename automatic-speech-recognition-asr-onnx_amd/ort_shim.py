@@ -269,16 +269,19 @@ class InferenceSession:
             self._native = ParaformerSession(self._cfg, blob, info["precision"], device_id)
             self._inputs = [NodeArg("audio", [1, 1, "audio_len"], np.float32)]
             self._outputs = [NodeArg("token_ids", [1, "num_token"], np.int32), NodeArg("num_id", [1], np.int32)]
-        elif self._kind in ("whisper_graph", "qwen_graph"):    # a merged graph: state lives in the folder's shared native session
+        elif self._kind in ("whisper_graph", "qwen_graph", "paraformer_stream_graph"):    # state lives in the folder's shared native session
             path = str(path_or_bytes)
             if not os.path.isfile(path) and path.endswith(".onnx"):
                 path = path[:-5] + ".asrmodel"
             if self._kind == "whisper_graph":
                 from .ort_shim_whisper import WhisperGraph
                 self._graph = WhisperGraph(path, info, device_id, load_model)
-            else:
+            elif self._kind == "qwen_graph":
                 from .ort_shim_qwen import QwenGraph
                 self._graph = QwenGraph(path, info, device_id, load_model)
+            else:
+                from .ort_shim_paraformer_streaming import ParaformerStreamGraph
+                self._graph = ParaformerStreamGraph(path, info, device_id, load_model)
             self._native = self._graph.sh.native
             self._inputs = [NodeArg(n, sh, dt) for n, sh, dt in self._graph.inputs]
             self._outputs = [NodeArg(n, sh, dt) for n, sh, dt in self._graph.outputs]
@@ -353,7 +356,7 @@ class InferenceSession:
             return self._run_paraformer(feeds)
         if self._kind == "metadata":
             return {"metadata_marker_out": np.asarray(feeds["metadata_marker"].numpy())}
-        if self._kind in ("whisper_graph", "qwen_graph"):
+        if self._kind in ("whisper_graph", "qwen_graph", "paraformer_stream_graph"):
             return self._graph.execute(feeds, OrtValue)
         raise ValueError(self._kind)
 

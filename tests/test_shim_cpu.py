@@ -191,3 +191,25 @@ def test_qwen_graph_io_names_and_embedding_handles():
     meta = sub("ort_shim").NodeArg("query_embed", [1, "query_len", cfg.d_model], np.float32)
     assert wq.embedding_as_ids(io.array_for(meta, e, axes={0: 1, 1: 3}), "query_embed") == [3, 151935, 0]
     assert wq.embedding_as_ids(np.zeros((1, 0, cfg.d_model), np.float32), "query_embed") == []
+
+
+def test_paraformer_streaming_graph_io_names():
+    """The streaming host wires the two graphs by NAME (encoder_feedback / decoder_feedback / encoder_decoder_bridge,
+    Inference_Paraformer_Streaming_ONNX.py:296-338) and reads static sizes from the metadata (audio length, FSMN pad)."""
+    ws, cfg = sub("ort_shim_paraformer_streaming"), sub("config").paraformer_large()
+    ins, outs = ws.graph_io(cfg, "encoder", 8000, 9, 4)
+    ni, no = {n: (s, d) for n, s, d in ins}, {n: (s, d) for n, s, d in outs}
+    n_en = cfg.n_enc0 + cfg.n_enc
+    for i in (0, n_en - 1):
+        assert ni[f"in_en_key_{i}"][0][:2] == [4, 128] and isinstance(ni[f"in_en_key_{i}"][0][2], str)
+        assert isinstance(ni[f"in_en_value_{i}"][0][1], str) and f"out_en_value_{i}" in no
+    assert f"in_en_key_{n_en}" not in ni and ni["audio"][0] == [1, 1, 8000] and ni["in_previous_mel_features"][0] == [1, 4, 560]
+    for a, b in (("in_previous_mel_features", "out_previous_mel_features"), ("in_cif_hidden", "out_cif_hidden"), ("in_cif_alphas", "out_cif_alphas"), ("start_idx", "end_idx")):
+        assert ni[a] == no[b]
+    assert no["encoder_out"][0] == [1, 13, 512] and no["list_frame_len"] == ([], np.int64)
+    dins, douts = ws.graph_io(cfg, "decoder", 8000, 9, 4)
+    di, do = {n: (s, d) for n, s, d in dins}, {n: (s, d) for n, s, d in douts}
+    assert di["in_de_fsmn_0"][0] == [1, 512, 10] and f"in_de_fsmn_{cfg.n_dec - 1}" in di and f"in_de_fsmn_{cfg.n_dec}" not in di
+    for n in ("encoder_out", "list_frame", "list_frame_len"):
+        assert di[n] == no[n]
+    assert do["max_logit_ids"][1] == np.int32 and do["num_id"] == ([1], np.int32)

@@ -8,10 +8,11 @@ mkdir -p $OUT
 cd $R
 python bench.py --steps 20 > $OUT/bench_sensevoice.json 2> $OUT/bench_sensevoice.err
 python bench.py --workload paraformer --steps 10 > $OUT/bench_paraformer.json 2> $OUT/bench_paraformer.err
-python bench.py --workload whisper --steps 3 --warmup 1 > $OUT/bench_whisper.json 2> $OUT/bench_whisper.err
-python bench.py --workload whisper --seconds 30 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_whisper30.json 2> $OUT/bench_whisper30.err
+python bench.py --workload whisper --steps 6 --warmup 1 --inflight 3 > $OUT/bench_whisper.json 2> $OUT/bench_whisper.err
+python bench.py --workload whisper --seconds 30 --steps 3 --warmup 1 --inflight 3 --no-cpu-baseline > $OUT/bench_whisper30.json 2> $OUT/bench_whisper30.err
 python bench.py --workload paraformer-streaming --steps 16 --warmup 8 > $OUT/bench_paraformer_streaming.json 2> $OUT/bench_paraformer_streaming.err
-python bench.py --workload qwen --steps 5 --warmup 2 > $OUT/bench_qwen.json 2> $OUT/bench_qwen.err
+python bench.py --workload qwen --steps 6 --warmup 2 --inflight 3 > $OUT/bench_qwen.json 2> $OUT/bench_qwen.err
+python bench.py --workload mixed --steps 6 --warmup 1 > $OUT/bench_mixed.json 2> $OUT/bench_mixed.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1

@@ -511,7 +511,8 @@ def main_whisper(args):
     if rank == 0:
         ck = ckm.synth_whisper_checkpoint(cfg, seed=0)
         blob = arena.build_whisper_arena(cfg, ck, arena.PRECISION_BF16, ckm.whisper_suppress_tokens(cfg), ckm.whisper_begin_suppress_tokens(cfg))
-        ck = None
+        if world > 1 or args.no_cpu_baseline:
+            ck = None
     t0 = time.perf_counter()
     arena_dev = dp.broadcast_arena(blob, device)
     torch.cuda.synchronize()
@@ -623,6 +624,21 @@ def main_whisper(args):
         }
         if inflight:
             out["inflight"] = inflight
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.whisper_oracle import WhisperOracle                # CHECKER ONLY: the CPU restatement, batch 1 like the reference
+            orc = WhisperOracle(cfg, ck, ckm.whisper_suppress_tokens(cfg), ckm.whisper_begin_suppress_tokens(cfg))
+            torch.set_num_threads(min(32, os.cpu_count() or 8))
+            n_done, t1 = 0, time.perf_counter()
+            while True:
+                orc.greedy([audio_np[n_done % B, 0]], [prompt[0].tolist()], n_tok)
+                n_done += 1
+                el = time.perf_counter() - t1
+                if el >= 15.0 or n_done >= 8:
+                    break
+            out["cpu_baseline"] = {"value": round(n_done * args.seconds / el, 2), "unit": "audio-s/s", "cores": int(torch.get_num_threads()),
+                                   "host_cores": int(os.cpu_count() or 0), "kind": "port",
+                                   "sample": f"{n_done} x {args.seconds:g} s utterances, batch 1, encoder + prefill(4) + {n_tok - 1} decode steps, torch-CPU f32 "
+                                             f"oracle (oracle/whisper_oracle.py), {el:.1f} s wall"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -686,9 +686,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
             float acc = 0.0f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc = fmaf(qs[i][sub * 8 + e], kvf[e], acc);
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 4, 64);
+            // sum over the 8 lanes of a row in three DPP moves (xor 1, xor 2, mirror within 8) instead of LDS-crossbar shuffles
+            acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0xB1, 0xf, 0xf, true));
+            acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x4E, 0xf, 0xf, true));
+            acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x141, 0xf, 0xf, true));
             if (sub == 0) sc[i * sc_ld + s0] = acc + ((a.causal && s0 > hist + i) ? -128.0f : 0.0f);
           }
         }
@@ -696,6 +697,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
     }
   }
   __syncthreads();
+  // the V stream does not depend on the scores: its first trip is requested before the soft-max statistics are computed
+  Raw8<T> vnxt[DU];
+#pragma unroll
+  for (int u = 0; u < DU; ++u) { const int s0 = (tid >> 3) + u * 32; if (s0 < S) vnxt[u].load(v_ptr(s0)); }
   // ---- soft-max statistics per query (wave w handles queries w, w+4)
   for (int i = wave; i < n; i += 4) {
     float mx = -INFINITY;
@@ -718,15 +723,12 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[i][e] = 0.0f;
   {
-    Raw8<T> nxt[DU];                               // the V stream starts before the soft-max statistics are needed
-#pragma unroll
-    for (int u = 0; u < DU; ++u) { const int s0 = (tid >> 3) + u * 32; if (s0 < S) nxt[u].load(v_ptr(s0)); }
     for (int sb = (tid >> 3); sb < S; sb += 32 * DU) {
       Raw8<T> cur[DU];
 #pragma unroll
-      for (int u = 0; u < DU; ++u) cur[u] = nxt[u];
+      for (int u = 0; u < DU; ++u) cur[u] = vnxt[u];
 #pragma unroll
-      for (int u = 0; u < DU; ++u) { const int s1 = sb + 32 * DU + u * 32; if (s1 < S) nxt[u].load(v_ptr(s1)); }
+      for (int u = 0; u < DU; ++u) { const int s1 = sb + 32 * DU + u * 32; if (s1 < S) vnxt[u].load(v_ptr(s1)); }
 #pragma unroll
       for (int u = 0; u < DU; ++u) {
         const int s0 = sb + u * 32;

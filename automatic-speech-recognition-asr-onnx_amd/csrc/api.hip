@@ -235,6 +235,7 @@ extern "C" int asr_op_gemm(int precision, const float* a, const float* w, const 
     GemmArgs g;
     g.A = da; g.lda = Kp; g.W = dw; g.ldw = Kp; g.M = M; g.N = Np; g.K = Kp; g.bias = db; g.act = act;
     g.out_f32 = dout; g.ld_out_f32 = Np;
+    g.sk_ws = (float*)t.alloc((size_t)8 << 20); g.sk_ws_bytes = (size_t)8 << 20;     // lets the launcher pick the split-K tiled path for small grids
     if (precision == ASR_PRECISION_BF16) launch_gemm_bf16(g, nullptr); else launch_gemm_f32(g, nullptr);
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy2D(out, (size_t)N * 4, dout, (size_t)Np * 4, (size_t)N * 4, M, hipMemcpyDeviceToHost));

@@ -51,6 +51,9 @@ struct GemmArgs {
   float* sk_ws = nullptr; size_t sk_ws_bytes = 0; int32_t* sk_cnt = nullptr; int sk_splits = 0;   // sk_splits: set by the launcher
   // device-side row count (bf16 kernels): rows >= min(M, *m_dev) are neither computed nor stored -- row tiles past it exit at once.
   // Lets a graph-captured launch sized for the worst case follow a data-dependent row count (Paraformer token rows) without a host sync.
+  // tiled path, split-K across workgroups (set by the launcher for small grids with long K): grid.y = k_splits, every split writes its f32
+  // partial product to sk_ws[split][M][N]; a second launch sums the partials in split order and runs the epilogue -- deterministic
+  int k_splits = 0;
   const int32_t* m_dev = nullptr;
   int group_m = 0;   // (set by the launcher) row tiles walked per column tile before moving on: keeps wide weight matrices L2-resident
   int dbg = 0;   // tuning ablations (bench hook only): 1 = no refills, 2 = no MFMA, 4 = no epilogue

@@ -246,6 +246,13 @@ template <int BN_, int STAGES, int ACT, int EPI, bool SWAP>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_pipe(const GemmArgs g0) {
   GemmArgs g = g0;
   if (g0.m_dev) g.M = min(g0.M, *g0.m_dev);
+  if (g0.k_splits > 1) {                          // this workgroup's K range; partial products land in its slab of the workspace
+    const int kc = g0.K / g0.k_splits, ks = blockIdx.y;
+    g.A = reinterpret_cast<const bf16_t*>(g0.A) + (size_t)ks * kc;
+    g.W = reinterpret_cast<const bf16_t*>(g0.W) + (size_t)ks * kc;
+    g.K = kc;
+    g.out_f32 = g0.out_f32 + (size_t)ks * g0.M * g0.ld_out_f32;
+  }
   constexpr int WN = BN_ / 2;                     // columns per wave
   constexpr int NJ = WN / 16;                     // column fragments per wave
   constexpr int STAGE_BYTES = BM * 128 + BN_ * 128;
@@ -975,6 +982,50 @@ void check_args(const GemmArgs& g, int kstep, int elt) {
   }
 }
 
+// second launch of a split-K GEMM: out = epilogue(sum over splits, in split order); 4 columns per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g, const float* __restrict__ ws, int splits) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = g.N >> 2;
+  if (idx >= (size_t)g.M * n4) return;
+  const int m = (int)(idx / n4), n = (int)(idx - (size_t)m * n4) * 4;
+  float4 v = *reinterpret_cast<const float4*>(ws + (size_t)m * g.N + n);
+  for (int sp = 1; sp < splits; ++sp) {
+    const float4 q = *reinterpret_cast<const float4*>(ws + ((size_t)sp * g.M + m) * g.N + n);
+    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+  }
+  if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+  if (g.add) { const float4 q = *reinterpret_cast<const float4*>(g.add + (size_t)m * g.ld_add + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+  if (g.act != ACT_NONE) { v.x = apply_act_rt(v.x, g.act); v.y = apply_act_rt(v.y, g.act); v.z = apply_act_rt(v.z, g.act); v.w = apply_act_rt(v.w, g.act); }
+  if (g.add2) { const float4 q = *reinterpret_cast<const float4*>(g.add2 + (size_t)m * g.ld_add2 + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+  if (g.out_f32) store4<float>(g.out_f32 + (size_t)m * g.ld_out_f32 + n, v.x, v.y, v.z, v.w);
+  if (g.out_lo) store4<bf16_t>(reinterpret_cast<bf16_t*>(g.out_lo) + (size_t)m * g.ld_out_lo + n, v.x, v.y, v.z, v.w);
+  if (g.st_out) {                                // (sum, sum of squares) of the bf16-rounded values per 32-column group = 8 consecutive threads
+    const uint32_t p0 = pack_bf16x2(v.x, v.y), p1 = pack_bf16x2(v.z, v.w);
+    const float a = __uint_as_float(p0 << 16), b = __uint_as_float(p0 & 0xffff0000u), c = __uint_as_float(p1 << 16), d = __uint_as_float(p1 & 0xffff0000u);
+    float s1 = (a + b) + (c + d), s2 = fmaf(a, a, fmaf(b, b, fmaf(c, c, d * d)));
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if ((threadIdx.x & 7) == 0) g.st_out[(size_t)m * (g.N >> 5) + (n >> 5)] = make_float2(s1, s2);
+  }
+}
+
+// split-K for the tiled kernel: a grid of at most a few dozen tiles walking a long K is one latency-bound loop per workgroup
+// (M = 144, N = 512, K = 2048: 16 workgroups x 32 K-steps = 30 us); S-way split => S x the workgroups, 1 / S the steps
+static int tiled_splits(const GemmArgs& g) {
+  static const bool off = getenv("ASR_GEMM_SPLITK") && getenv("ASR_GEMM_SPLITK")[0] == '0';
+  if (off || !g.sk_ws || g.out_t || g.amax_val || g.lo_group || g.add2_rows || g.ln_colsum || g.m_dev || g.act == ACT_SWIGLU || g.N % 32) return 1;
+  const int tiles = ((g.M + BM - 1) / BM) * (g.N / 64);
+  if (tiles > 64 || g.K < 1024) return 1;
+  int best = 1;
+  for (int sp : {2, 4, 8}) {
+    if (g.K % (sp * BK16) != 0 || g.K / sp < 256) break;
+    if ((size_t)sp * g.M * g.N * 4 > g.sk_ws_bytes) break;
+    best = sp;
+    if (tiles * sp >= 128) break;
+  }
+  return best;
+}
+
 template <int BN_, int STAGES, int ACT, int EPI, bool SWAP>
 void launch_pipe_inst(const GemmArgs& g, hipStream_t s) {
   constexpr int lds = STAGES * (BM * 128 + BN_ * 128);
@@ -987,7 +1038,7 @@ void launch_pipe_inst(const GemmArgs& g, hipStream_t s) {
   const int grid = ((g.M + BM - 1) / BM) * (g.N / BN_);
   GemmArgs gg = g;
   if ((size_t)g.N * g.K * 2 > ((size_t)3 << 20) && g.M > 2 * BM) gg.group_m = 8;     // weights beyond an XCD's L2: group the row tiles
-  hipLaunchKernelGGL((gemm_bf16_pipe<BN_, STAGES, ACT, EPI, SWAP>), dim3(grid), dim3(256), lds, s, gg);
+  hipLaunchKernelGGL((gemm_bf16_pipe<BN_, STAGES, ACT, EPI, SWAP>), dim3(grid, g.k_splits > 1 ? g.k_splits : 1), dim3(256), lds, s, gg);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1173,6 +1224,16 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
     }
     if (big_fits(g) && launch_big(g, s)) return;
     if (t144_enabled() && t144_fits(g, &st) && (st == 4 ? launch_t144<4>(g, s) : launch_t144<2>(g, s))) return;
+    if (const int sp = tiled_splits(g); sp > 1) {
+      GemmArgs p = g;                                    // pass 1: raw f32 partials, no epilogue terms
+      p.bias = nullptr; p.add = nullptr; p.add2 = nullptr; p.act = ACT_NONE; p.out_lo = nullptr;
+      p.out_f32 = g.sk_ws; p.ld_out_f32 = g.N; p.k_splits = sp; p.st_out = nullptr;
+      launch_pipe<64, 2>(p, s);
+      const size_t n = (size_t)g.M * (g.N / 4);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, (const float*)g.sk_ws, sp);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     v = tall ? 2 : 4;
   }
   if (v == 7) {

@@ -210,6 +210,23 @@ def test_gemm_256_tiles(M, N, K, act):
     assert np.abs(got - ref).max() < 2e-3 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("M,N,K,act", [(137, 512, 2048, 0), (1024, 512, 2048, 1), (144, 128, 4096, 0)])
+def test_tiled_split_k_for_small_grids(M, N, K, act):
+    """A few tiles walking a long K: the launcher splits K across workgroups (f32 partials + an ordered reduce / epilogue launch)."""
+    eng = sub("engine")
+    rng = np.random.default_rng(M + N + K)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    got = eng.op_gemm(a, w, b, act=act, precision=0)
+    again = eng.op_gemm(a, w, b, act=act, precision=0)
+    ref = _bf16_round(a).astype(np.float64) @ _bf16_round(w).astype(np.float64).T + b
+    if act == 1:
+        ref = np.maximum(ref, 0)
+    assert np.abs(got - ref).max() < 2e-3 * max(1.0, np.abs(ref).max())
+    assert np.array_equal(got, again)                             # fixed summation order
+
+
 def test_skinny_split_k_hand_over_is_exact(monkeypatch):
     """Opt-in split-K across workgroups of the skinny (weight-streaming) GEMM: partial sums handed over through agent-scope
     atomics, last-arriver reduction in split order => bit-reproducible, and a single 137-row window through the 9-row-tile

@@ -614,7 +614,7 @@ def main_whisper(args):
             "rtf": round(elapsed / (audio_s * args.steps), 7),
             "ms": {k: round(v / args.steps * 1e3, 2) for k, v in t_parts.items()},
             "decode_ms_per_token": round(t_dec / max(n_tok - 1, 1) * 1e3, 3),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pipe (encoder qkv/out/fc1/fc2/cross-KV launches)", "achieved": round(achieved, 1),
+            "roofline": {"bound": "mfma", "kernel": "encoder GEMM launches: qkv / out / fc1 / fc2 / cross-KV (gemm_bf16_big 256x256 tiles where they fill whole rounds, else gemm_bf16_t144 / gemm_bf16_pipe)", "achieved": round(achieved, 1),
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None},
             "roofline_decode": {"bound": "hbm", "kernel": "decode step (weights + cross-KV stream)",
                                 "achieved": round(alg["decode_bytes_per_step"] / (t_dec / max(n_tok - 1, 1)) / 1e9, 1),

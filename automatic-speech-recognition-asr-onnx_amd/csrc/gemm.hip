@@ -1015,7 +1015,7 @@ static int tiled_splits(const GemmArgs& g) {
   static const bool off = getenv("ASR_GEMM_SPLITK") && getenv("ASR_GEMM_SPLITK")[0] == '0';
   if (off || !g.sk_ws || g.out_t || g.amax_val || g.lo_group || g.add2_rows || g.ln_colsum || g.m_dev || g.act == ACT_SWIGLU || g.N % 32) return 1;
   const int tiles = ((g.M + BM - 1) / BM) * (g.N / 64);
-  if (tiles > 64 || g.K < 1024) return 1;
+  if (tiles > 128 || g.K < 1024) return 1;
   int best = 1;
   for (int sp : {2, 4, 8}) {
     if (g.K % (sp * BK16) != 0 || g.K / sp < 256) break;

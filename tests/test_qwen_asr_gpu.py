@@ -228,3 +228,42 @@ def test_edge_lengths_vs_oracle():
                 break                                               # a flipped near-tie changes the later steps
             assert np.abs(steps[t][b] - r["logits"][t]).max() < TOL_F32, (b, t)
             ok = srt[t, -1] - srt[t, -2] > 2 * TOL_F32
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+def test_large_batch_equals_small_batches(prec):
+    """70 sequences (more than the 64 the weight-streaming decode kernels take: the tiled kernels run instead) against the same
+    clips decoded three at a time. f32: identical ids (every row is computed independently of the batch); bf16: logits within
+    the operand-rounding budget."""
+    g = load_golden("qwen_asr_mid")
+    cfg, ck = qwen_setup(g)
+    sess = sub("engine").QwenAsrSession.from_checkpoint(cfg, ck, precision=prec)
+    head, tail, suffix = g["head_ids"].tolist(), g["tail_ids"].tolist(), g["suffix_ids"].tolist()
+    lens = [8000 + 1600 * (i % 17) for i in range(70)]
+    audios = [unit_audio(5000 + i, n) for i, n in enumerate(lens)]
+    pre = [head + ([40, 41] if i % 3 == 0 else []) + suffix for i in range(70)]
+    post = [tail + ([77, 540] if i % 2 else []) for i in range(70)]
+    nxt, logits, ids_len = sess.prefill(audios, pre, post)
+    big = [nxt.copy()]
+    big_logits = [logits]
+    for _ in range(3):
+        n, lg = sess.decode(None, want_logits=True)
+        big.append(n.copy())
+        big_logits.append(lg)
+    big = np.stack(big, 1)
+    for lo in (0, 33, 67):
+        sel = list(range(lo, lo + 3))
+        n0, lg0, il = sess.prefill([audios[i] for i in sel], [pre[i] for i in sel], [post[i] for i in sel])
+        assert il.tolist() == ids_len[sel].tolist()
+        small, small_logits = [n0.copy()], [lg0]
+        for _ in range(3):
+            n, lg = sess.decode(None, want_logits=True)
+            small.append(n.copy())
+            small_logits.append(lg)
+        small = np.stack(small, 1)
+        if prec == F32:
+            assert np.array_equal(small, big[sel])
+            assert np.abs(small_logits[0] - big_logits[0][sel]).max() < 1e-4
+        else:
+            ref = small_logits[0]
+            assert np.abs(ref - big_logits[0][sel]).max() < 0.06 * np.abs(ref).max() + 0.05

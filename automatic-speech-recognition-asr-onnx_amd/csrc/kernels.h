@@ -230,6 +230,11 @@ struct StreamAttnArgs {
   const UttPlan* q_plan;        // T = number of query rows (0 => nothing to do), row_off, lang = stream id
   int n_heads;
   void* ctx; int ld_ctx;
+  // encoder layers: the same workgroup also (a) rolls its (stream, head) K / V history -- keep the last `cap` of (history ++ the first
+  // roll_rows current rows) -- and (b) computes the FSMN memory term of the chunk rows (depth-wise conv over the CURRENT rows of V, taps
+  // outside them are zero) for its 128 channels; both null / 0 for the decoder's cross-attention
+  int roll_rows = 0;
+  const float* fsmn_w = nullptr; const float* fsmn_b = nullptr; int ktaps = 0; float* mem = nullptr; int d = 0;
 };
 template <typename T> void launch_stream_attn(const StreamAttnArgs& a, int n_active, hipStream_t s);
 // cache = last `cap` of (cache ++ current rows [0, n_app)); skipped for streams whose cond_plan[i].T == 0 (when cond_plan is given)

@@ -1374,6 +1374,35 @@ __global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a
       Elem<T>::store(out + (size_t)(row0 + q0 + q) * a.ld_ctx + h * SA_HD + c, acc);
     }
   }
+  if (a.mem) {                                           // FSMN memory term of the 16-row slot (rows >= n_cur are zero), channels of this head
+    const int pad = (a.ktaps - 1) / 2;
+    for (int e = tid; e < 16 * SA_HD; e += 256) {
+      const int t = e >> 7, c = e & 127, hc = h * SA_HD + c;
+      float acc = 0.0f;
+      if (t < a.n_cur) {
+        acc = a.fsmn_b[hc];
+        for (int j = 0; j < a.ktaps; ++j) {
+          const int tt = t + j - pad;
+          if (tt >= 0 && tt < a.n_cur) acc = fmaf(a.fsmn_w[hc * a.ktaps + j], Vs[len + tt][c], acc);
+        }
+      }
+      a.mem[(size_t)(row0 + t) * a.d + hc] = acc;
+    }
+  }
+  if (a.roll_rows > 0) {                                 // history <- last cap of (history ++ current[:roll_rows]); every old row is in LDS already
+    const int total = len + a.roll_rows, new_len = min(total, a.cap), drop = total - new_len;
+    T* wk = const_cast<T*>(ck);
+    T* wv = const_cast<T*>(cv);
+    if (drop > 0 || a.roll_rows > 0) {
+      for (int e = tid; e < new_len * SA_HD; e += 256) {
+        const int p = e >> 7, c = e & 127, src = p + drop;
+        if (src >= len || drop > 0) {                    // rows that move or are new (values round-trip exactly: they came from T)
+          Elem<T>::store(wk + (size_t)p * SA_HD + c, Ks[src][c]);
+          Elem<T>::store(wv + (size_t)p * SA_HD + c, Vs[src][c]);
+        }
+      }
+    }
+  }
 }
 
 template <typename T>

@@ -845,11 +845,12 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
       sa.q = qkv; sa.ld_q = 3 * d; sa.q_col0 = 0; sa.k = qkv; sa.ld_k = 3 * d; sa.k_col0 = d; sa.v = qkv; sa.ld_v = 3 * d; sa.v_col0 = 2 * d;
       sa.n_cur = n_cur; sa.cache_k = ck; sa.cache_v = cv; sa.cache_len = st_enlen.as<int32_t>(); sa.cap = st_en_cap; sa.q_plan = dp; sa.n_heads = H;
       sa.ctx = ctx; sa.ld_ctx = d;
+      // the same launch rolls the history -- [-(cap + C) : -C] of (history ++ chunk): append the first B rows, keep the last cap (:421-422) --
+      // and computes the FSMN memory term of the chunk rows
+      sa.roll_rows = st_B;
+      sa.fsmn_w = b.wfsmn; sa.fsmn_b = b.bfsmn; sa.ktaps = c.fsmn_kernel; sa.mem = mem; sa.d = d;
       launch_stream_attn<T>(sa, n, stream);
-      // history <- [-(cap + C) : -C] of (history ++ chunk): append the first B rows, keep the last cap (:421-422)
-      launch_stream_cache_roll<T>(ck, cv, st_enlen.as<int32_t>(), st_en_cap, qkv, 3 * d, d, qkv, 3 * d, 2 * d, st_B, dp, nullptr, n, H, stream);
     }
-    { ProfScope ps(prof, "fsmn", stream); launch_stream_fsmn<T>(qkv, 3 * d, 2 * d, b.wfsmn, b.bfsmn, d, c.fsmn_kernel, n_cur, rows, mem, stream); }
     {
       ProfScope ps(prof, "gemm_out", stream);
       GemmArgs g;

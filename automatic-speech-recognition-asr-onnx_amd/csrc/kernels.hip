@@ -1321,26 +1321,31 @@ __global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a
   const T* vv = reinterpret_cast<const T*>(a.v);
   const T* qq = reinterpret_cast<const T*>(a.q);
   T* out = reinterpret_cast<T*>(a.ctx);
-  {                                                      // stage K and V: thread = (row parity, column), 8 rows in flight
-    const int c = tid & 127, half = tid >> 7;
-    for (int p0 = half; p0 < nk; p0 += 16) {
-      float kr[8], vr[8];
+  {                                                      // stage K and V: 16 threads per row (8 elements = 16 bytes each), all loads of a thread in flight
+    constexpr int NIT = SA_MAXK * 16 / 256;              // 4 row segments per thread cover 64 rows
+    Raw8<T> rk[NIT], rv[NIT];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int p = p0 + 2 * u;
-        kr[u] = 0.0f; vr[u] = 0.0f;
-        if (p < len) {
-          kr[u] = Elem<T>::load(ck + (size_t)p * SA_HD + c);
-          vr[u] = Elem<T>::load(cv + (size_t)p * SA_HD + c);
-        } else if (p < nk) {
-          const size_t r = (size_t)(row0 + p - len);
-          kr[u] = Elem<T>::load(kk + r * a.ld_k + a.k_col0 + h * SA_HD + c);
-          vr[u] = Elem<T>::load(vv + r * a.ld_v + a.v_col0 + h * SA_HD + c);
-        }
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * 256, p = idx >> 4, c0 = (idx & 15) * 8;
+      if (p < len) {
+        rk[it].load(ck + (size_t)p * SA_HD + c0);
+        rv[it].load(cv + (size_t)p * SA_HD + c0);
+      } else if (p < nk) {
+        const size_t r = (size_t)(row0 + p - len);
+        rk[it].load(kk + r * a.ld_k + a.k_col0 + h * SA_HD + c0);
+        rv[it].load(vv + r * a.ld_v + a.v_col0 + h * SA_HD + c0);
       }
+    }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (p0 + 2 * u < nk) { Ks[p0 + 2 * u][c] = kr[u]; Vs[p0 + 2 * u][c] = vr[u]; }
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * 256, p = idx >> 4, c0 = (idx & 15) * 8;
+      if (p < nk) {
+        float k8[8], v8[8];
+        rk[it].get(k8);
+        rv[it].get(v8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { Ks[p][c0 + e] = k8[e]; Vs[p][c0 + e] = v8[e]; }
+      }
     }
   }
   for (int q0 = 0; q0 < nq_all; q0 += SA_MAXQ) {

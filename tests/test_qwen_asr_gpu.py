@@ -267,3 +267,34 @@ def test_large_batch_equals_small_batches(prec):
         else:
             ref = small_logits[0]
             assert np.abs(ref - big_logits[0][sel]).max() < 0.06 * np.abs(ref).max() + 0.05
+
+
+def test_long_prompt_bf16_vs_f32_mode():
+    """30 s clips: ~400-position prompts, i.e. the MFMA causal attention walks several key chunks and the decode attention several key
+    blocks. The bf16 path must stay within the operand-rounding budget of the f32 verification mode (itself pinned to the oracle)."""
+    g = load_golden("qwen_asr_mid")
+    cfg, ck = qwen_setup(g)
+    eng = sub("engine")
+    head, tail, suffix = g["head_ids"].tolist(), g["tail_ids"].tolist(), g["suffix_ids"].tolist()
+    audios = [unit_audio(8800 + i, n) for i, n in enumerate((cfg.max_audio_len, 300000, 47000))]
+    pre, post = [head + suffix], [tail + [77, 540]]
+    out = {}
+    for prec in (F32, BF16):
+        s = eng.QwenAsrSession.from_checkpoint(cfg, ck, precision=prec)
+        nxt, logits, ids_len = s.prefill(audios, pre, post)
+        steps = [logits]
+        forced = nxt.copy() if prec == F32 else out[F32][2]                # teacher-force the bf16 run with the f32 run's ids
+        for t in range(3):
+            ids = forced if prec == F32 else out[F32][3][t]
+            nx, lg = s.decode(ids, want_logits=True)
+            steps.append(lg)
+            if prec == F32:
+                out.setdefault("ids", []).append(nx.copy())
+                forced = nx
+        if prec == F32:
+            out[F32] = (np.stack(steps), ids_len, nxt.copy(), [nxt.copy()] + out["ids"][:2])
+        else:
+            out[BF16] = (np.stack(steps), ids_len)
+    assert out[F32][1].tolist() == out[BF16][1].tolist() and int(out[F32][1].max()) > 380
+    ref, got = out[F32][0], out[BF16][0]
+    assert np.abs(got - ref).max() < 0.06 * np.abs(ref).max() + 0.05

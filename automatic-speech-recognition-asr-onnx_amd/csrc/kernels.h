@@ -76,6 +76,9 @@ void launch_decode_attention(const DecAttnArgs& a, int batch, hipStream_t s);
 
 // ids[r] = first arg-max over n < n_valid of logits[r][n] + (extra ? extra[n] : 0)
 void launch_argmax_rows(const float* logits, int ld, int rows, int n_valid, const float* extra, int32_t* ids, hipStream_t s);
+// NO_SPEECH_DETECTION (Export_Whisper.py:334-348): prob[r] = softmax(logits[r] - penalty)[no_speech_id] over the first n_valid columns, where
+// `penalty` is the permanent suppress bias the logits carry (-128 on the suppressed ids: subtracting it re-adds the +128 the reference adds back)
+void launch_no_speech_prob(const float* logits, int ld, int rows, int n_valid, const float* penalty, int no_speech_id, float* prob, hipStream_t s);
 
 // ---- penalty-greedy head (Export_Whisper.py:312-325 APPLY_PENALTY + :243-251 GREEDY_SEARCH): logits of the last `range` saved
 // ids are multiplied by `value` once `range` ids are saved (the host's rule, Inference_Whisper_ONNX.py:630-632); gather first,

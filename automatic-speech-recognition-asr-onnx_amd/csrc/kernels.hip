@@ -813,6 +813,31 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* __restri
 }
 
 
+__global__ __launch_bounds__(1024) void no_speech_prob_kernel(const float* __restrict__ logits, int ld, int n_valid, const float* __restrict__ penalty,
+                                                              int no_speech_id, float* __restrict__ prob) {
+  __shared__ float red[16];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* x = logits + (size_t)r * ld;
+  float mx = -INFINITY;
+  for (int c = tid; c < n_valid; c += 1024) mx = fmaxf(mx, x[c] - penalty[c]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = red[0];
+  for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
+  __syncthreads();
+  float sum = 0.0f;
+  for (int c = tid; c < n_valid; c += 1024) sum += expf(x[c] - penalty[c] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.0f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    prob[r] = expf(x[no_speech_id] - penalty[no_speech_id] - mx) / t;
+  }
+}
+
 __global__ __launch_bounds__(64) void apply_penalty_kernel(float* __restrict__ logits, int ld, const int32_t* __restrict__ save_ids,
                                                            int ld_save, const int32_t* __restrict__ n_saved, int range, float value, int partial) {
   const int n = *n_saved;
@@ -1194,6 +1219,12 @@ template void launch_decode_attention<bf16_t>(const DecAttnArgs&, int, hipStream
 void launch_argmax_rows(const float* logits, int ld, int rows, int n_valid, const float* extra, int32_t* ids, hipStream_t s) {
   ASR_REQUIRE(ld % 4 == 0 && n_valid <= ld, "argmax_rows: rows must be padded to a multiple of 4 columns");
   hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(1024), 0, s, logits, ld, n_valid, extra, ids);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_no_speech_prob(const float* logits, int ld, int rows, int n_valid, const float* penalty, int no_speech_id, float* prob, hipStream_t s) {
+  ASR_REQUIRE(no_speech_id >= 0 && no_speech_id < n_valid, "no_speech_prob: id %d outside the vocabulary", no_speech_id);
+  hipLaunchKernelGGL(no_speech_prob_kernel, dim3(rows), dim3(1024), 0, s, logits, ld, n_valid, penalty, no_speech_id, prob);
   HIP_CHECK(hipGetLastError());
 }
 

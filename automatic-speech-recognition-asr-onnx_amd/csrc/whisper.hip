@@ -44,6 +44,7 @@ struct WhSession : asr_session {
   float temperature = 0.8f, top_p = 0.95f, samp_rep_penalty = 1.0f;
   int top_k = 10;
   uint64_t samp_seed = 0;
+  DeviceBuffer d_nsp;                  // no-speech probabilities of the last prefill
   DeviceBuffer d_noise;                // caller-supplied uniforms [B][top_k] for the next step (parity tests); consumed once
   bool noise_armed = false;
   float penalty_value = 1.0f;          // 1.0 = plain greedy (REPEAT_PENALTY, Inference_Whisper_ONNX.py:78)
@@ -57,7 +58,7 @@ struct WhSession : asr_session {
 
   ~WhSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_x0, &d_h1, &d_xa, &d_xb, &d_xc, &d_h, &d_qk, &d_vt, &d_ctx,
-                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise, &d_skws, &d_skcnt})
+                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise, &d_nsp, &d_skws, &d_skcnt})
       b->release();
     if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
     for (auto& kv : taps) kv.second.buf.release();
@@ -607,6 +608,20 @@ extern "C" int asr_whisper_set_penalty(asr_session* s, float repeat_penalty, int
       w->penalty_range = penalty_range;
       ++w->ws_epoch;                       // the captured decode graph bakes the head in: re-capture
     }
+  });
+}
+
+extern "C" int asr_whisper_no_speech_prob(asr_session* s, int no_speech_id, float* prob_out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 2 && prob_out, "whisper_no_speech_prob: bad argument");
+    WhSession* w = static_cast<WhSession*>(s);
+    ASR_REQUIRE(w->batch > 0 && w->hist > 0 && w->d_logits.ptr, "whisper_no_speech_prob: run a prefill first (the probe's logits are the input)");
+    HIP_CHECK(hipSetDevice(w->device));
+    const int B = w->batch;
+    w->d_nsp.reserve((size_t)std::max(B, 64) * 4, w->stream);
+    launch_no_speech_prob(w->d_logits.as<float>(), w->vpad, B, w->cfg.vocab, w->suppress, no_speech_id, w->d_nsp.as<float>(), w->stream);
+    HIP_CHECK(hipMemcpyAsync(prob_out, w->d_nsp.ptr, (size_t)B * 4, hipMemcpyDeviceToHost, w->stream));
+    HIP_CHECK(hipStreamSynchronize(w->stream));
   });
 }
 

@@ -300,6 +300,12 @@ class WhisperSession(_Session):
         """Decode head: 1.0 = plain arg-max; else penalty-greedy (APPLY_PENALTY + GREEDY_SEARCH, the reference host's default)."""
         _lib.check(_lib.load().asr_whisper_set_penalty(self._h, C.c_float(repeat_penalty), int(penalty_range)))
 
+    def no_speech_prob(self, no_speech_id: int | None = None) -> np.ndarray:
+        """NO_SPEECH_DETECTION on the device-resident logits of the last prefill (the probe): (B,) probabilities."""
+        out = np.zeros(self.batch, dtype=np.float32)
+        _lib.check(_lib.load().asr_whisper_no_speech_prob(self._h, int(self.cfg.no_speech_id if no_speech_id is None else no_speech_id), _fp(out)))
+        return out
+
     def track_history(self, enable: bool):
         """Append every pick to the device-side id history even while the penalty value is 1.0 (what the *PenaltyGreedy graphs do)."""
         _lib.check(_lib.load().asr_whisper_track_history(self._h, int(enable)))

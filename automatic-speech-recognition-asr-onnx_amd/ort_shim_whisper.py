@@ -170,9 +170,12 @@ class WhisperGraph:
     # ------------------------------------------------------------------ execution
     def execute(self, feeds: dict, OrtValue) -> dict:
         if self.role == "no_speech":
-            from .whisper import no_speech_probability
-            logits = np.asarray(feeds["logits"].numpy(), dtype=np.float32)
-            return {"no_speech_prob": no_speech_probability(logits.reshape(-1, self.cfg.vocab), self.sh.suppress, self.cfg.no_speech_id).astype(np.float32)}
+            # the host feeds the probe's `logits` output straight back (:799-805): the device head runs on the resident copy of those logits
+            if "logits" not in feeds:
+                raise ValueError("input 'logits' is not bound")
+            if tuple(feeds["logits"]._shape) != (self.sh.batch, self.cfg.vocab):
+                raise ValueError(f"logits must be the (batch, vocab) output of the probe-prefill graph, got {tuple(feeds['logits']._shape)}")
+            return {"no_speech_prob": self.sh.native.no_speech_prob(self.cfg.no_speech_id)}
         for name, _, _ in self.inputs:
             if name not in feeds:
                 raise ValueError(f"input {name!r} is not bound")

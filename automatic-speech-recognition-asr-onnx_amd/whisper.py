@@ -97,7 +97,7 @@ class WhisperTranscriber:
             if self.detect_language:
                 lang = self.language_token_ids[np.argmax(logits[:, self.language_token_ids], axis=1)]
             if self.no_speech_detection:
-                probs = no_speech_probability(logits, self.suppress_tokens, cfg.no_speech_id)
+                probs = self.sess.no_speech_prob(cfg.no_speech_id)          # device head over the probe's logits
         skipped = probs >= self.no_speech_threshold if self.no_speech_detection else np.zeros(B, dtype=bool)
         prompt = np.stack([[cfg.sot_id, int(l), self.task_token, cfg.no_timestamps_id] for l in lang]).astype(np.int32)
         limit = max(0, cfg.max_target_positions - prompt.shape[1])

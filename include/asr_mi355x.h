@@ -169,6 +169,9 @@ int asr_whisper_set_penalty(asr_session* s, float repeat_penalty, int penalty_ra
  * penalty_penalty_value = 1.0 (before PENALTY_RANGE ids exist, Inference_Whisper_ONNX.py:630-632): enable = 1 keeps appending the
  * picks to the device-side history whatever the penalty value is (the onnxruntime shim drives the value per step). */
 int asr_whisper_track_history(asr_session* s, int enable);
+/* NO_SPEECH_DETECTION head (Export_Whisper.py:334-348; graph Whisper_No_Speech_Detection.onnx, host :799-805) on the logits of the last
+ * prefill (the probe with [SOT]): prob_out host [B] = softmax(logits + 128 on the permanently suppressed ids)[no_speech_id]. */
+int asr_whisper_no_speech_prob(asr_session* s, int no_speech_id, float* prob_out);
 /* decode head TOPK_TOPP_SAMPLING (Export_Whisper.py:263-308; USE_SAMPLING / TEMPERATURE / TOP_K / TOP_P /
  * SAMPLING_REPETITION_PENALTY, Inference_Whisper_ONNX.py:71-75): repetition penalty over every previously sampled id,
  * temperature, top-k (1..64), top-p, Gumbel-max. enable = 0 returns to the arg-max / penalty-greedy head. The reference draws

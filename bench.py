@@ -628,9 +628,10 @@ def main_whisper(args):
             from oracle.whisper_oracle import WhisperOracle                # CHECKER ONLY: the CPU restatement, batch 1 like the reference
             orc = WhisperOracle(cfg, ck, ckm.whisper_suppress_tokens(cfg), ckm.whisper_begin_suppress_tokens(cfg))
             torch.set_num_threads(min(32, os.cpu_count() or 8))
-            n_done, t1 = 0, time.perf_counter()
+            n_done, t1, first = 0, time.perf_counter(), None
             while True:
-                orc.greedy([audio_np[n_done % B, 0]], [prompt[0].tolist()], n_tok)
+                r = orc.greedy([audio_np[n_done % B, 0]], [prompt[0].tolist()], n_tok)
+                first = first or r
                 n_done += 1
                 el = time.perf_counter() - t1
                 if el >= 15.0 or n_done >= 8:
@@ -639,6 +640,12 @@ def main_whisper(args):
                                    "host_cores": int(os.cpu_count() or 0), "kind": "port",
                                    "sample": f"{n_done} x {args.seconds:g} s utterances, batch 1, encoder + prefill(4) + {n_tok - 1} decode steps, torch-CPU f32 "
                                              f"oracle (oracle/whisper_oracle.py), {el:.1f} s wall"}
+            # spot check at full size (random weights: margins are tiny, so logits are compared, not ids): utterance 0's prefill logits, bf16 path vs oracle
+            sess.encode_packed(None, offsets, audio_device_ptr=audio_dev.data_ptr())
+            _, lg = sess.prefill(prompt)
+            ref0 = first["logits"][0][0]
+            out["parity_spotcheck"] = {"what": "prefill logits of utterance 0, bf16 engine vs f32 oracle", "max_abs_diff": round(float(np.abs(lg[0] - ref0).max()), 4),
+                                       "logit_abs_max": round(float(np.abs(ref0).max()), 3)}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -784,13 +791,17 @@ def main_qwen(args):
             from oracle.qwen_asr_oracle import QwenAsrOracle
             orc = QwenAsrOracle(cfg, ck, pre[0][:3], post[0], pre[0][3:])          # CHECKER ONLY: the CPU restatement, batch 1 like the reference
             torch.set_num_threads(min(32, os.cpu_count() or 8))
-            n_done, t1 = 0, time.perf_counter()
+            n_done, t1, first = 0, time.perf_counter(), None
             while True:
-                orc.greedy(audio_np[n_done % B, 0], n_tok)
+                r = orc.greedy(audio_np[n_done % B, 0], n_tok)
+                first = first or r
                 n_done += 1
                 el = time.perf_counter() - t1
                 if el >= 15.0 or n_done >= 16:
                     break
+            _, lg, _ = sess.prefill_packed(None, offsets, pre, post, want_logits=True, audio_device_ptr=audio_dev.data_ptr())
+            out["parity_spotcheck"] = {"what": "prefill logits of utterance 0, bf16 engine vs f32 oracle", "max_abs_diff": round(float(np.abs(lg[0] - first["logits"][0]).max()), 4),
+                                       "logit_abs_max": round(float(np.abs(first["logits"][0]).max()), 3)}
             out["cpu_baseline"] = {"value": round(n_done * args.seconds / el, 2), "unit": "audio-s/s", "cores": int(torch.get_num_threads()),
                                    "host_cores": int(os.cpu_count() or 0), "kind": "port",
                                    "sample": f"{n_done} x {args.seconds:g} s utterances, batch 1, prefill + {n_tok - 1} decode steps, torch-CPU f32 oracle "

@@ -263,6 +263,20 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ck, audio_np)
+            # spot check at full size: CTC logits and frame arg-max of utterance 0, bf16 engine vs f32 oracle (CHECKER ONLY)
+            from oracle.sensevoice_oracle import SenseVoiceOracle
+            st = SenseVoiceOracle(cfg, ck).stages(audio_np[0, 0], 0)
+            sess.taps(True)
+            sess.run_packed(None, offsets[:2], lang[:1], audio_device_ptr=audio_dev.data_ptr())
+            lg = sess.tap("logits")[:st["logits"].shape[0]]
+            sess.taps(False)
+            srt = np.sort(st["logits"], axis=1)
+            diff = float(np.abs(lg - st["logits"]).max())
+            safe = (srt[:, -1] - srt[:, -2]) > 2.0 * diff               # frames whose top-1 / top-2 margin exceeds twice the measured error
+            out["parity_spotcheck"] = {"what": "CTC logits of utterance 0, bf16 engine vs f32 oracle", "max_abs_diff": round(diff, 4),
+                                       "logit_abs_max": round(float(np.abs(st["logits"]).max()), 3), "frames": int(safe.size),
+                                       "frames_with_safe_margin": int(safe.sum()),
+                                       "argmax_equal_on_those": bool(np.array_equal(lg.argmax(1)[safe], st["frame_ids"][safe]))}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -55,9 +55,10 @@ __global__ __launch_bounds__(256) void fbank_kernel(const FbankArgs a) {
     for (int mt = 0; mt < 4; ++mt) { re[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; im[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
     const float4* dre = dft + (size_t)(t * 2 + 0) * a.n_kchunks * 64 + lane;
     const float4* dim = dft + (size_t)(t * 2 + 1) * a.n_kchunks * 64 + lane;
+    float4 br = dre[0], bi = dim[0];
     for (int kc = 0; kc < a.n_kchunks; ++kc) {
-      const float4 br = dre[kc * 64];
-      const float4 bi = dim[kc * 64];
+      float4 brn = br, bin = bi;                 // the next chunk's basis columns are requested before this chunk's MFMAs
+      if (kc + 1 < a.n_kchunks) { brn = dre[(kc + 1) * 64]; bin = dim[(kc + 1) * 64]; }
       const float brv[4] = {br.x, br.y, br.z, br.w};
       const float biv[4] = {bi.x, bi.y, bi.z, bi.w};
 #pragma unroll
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(const FbankArgs a) {
           im[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt], biv[j], im[mt], 0, 0, 0);
         }
       }
+      br = brn; bi = bin;
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -87,14 +89,17 @@ __global__ __launch_bounds__(256) void fbank_kernel(const FbankArgs a) {
   const float4* melp = reinterpret_cast<const float4*>(a.mel_packed);
   for (int nt = 0; nt < a.n_mel_tiles; ++nt) {
     f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float4 b4 = melp[(size_t)(nt * a.n_bin_tiles) * 64 + lane];
     for (int kc = 0; kc < a.n_bin_tiles; ++kc) {
-      const float4 b4 = melp[(size_t)(nt * a.n_bin_tiles + kc) * 64 + lane];
+      float4 b4n = b4;
+      if (kc + 1 < a.n_bin_tiles) b4n = melp[(size_t)(nt * a.n_bin_tiles + kc + 1) * 64 + lane];
       const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float av = pw[(wave * 16 + frow) * FB_PLD + kc * 16 + j * 4 + fgrp];
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc, 0, 0, 0);
       }
+      b4 = b4n;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

@@ -266,23 +266,51 @@ template <> struct Raw8<float> {
 // Attention: 16 lanes share a key (8 head-dim elements each: one coalesced 256-byte row per 16 lanes), every 16-lane group keeps
 // its own online soft-max state over keys s = 16 j + group, blocks of KPI keys per group are double-buffered in registers, and
 // the 16 partial states merge through LDS. K and V are read once per kv head and serve the whole GQA group.
-template <typename T, int G>
+// BEAM: the sequences are beam-search hypotheses, `beam` rows per utterance. Positions below p0[b] (the prompt) are read from the
+// utterance's prefill cache (kc_p / vc_p, shared by its rows: one HBM read serves the whole beam when the rows sit on one XCD -- see
+// the workgroup order below); generated position p0[b] + j lives in slot j of the hypothesis cache kc / vc (S_max slots per row), in
+// the row that wrote it on the hypothesis' ancestry, src[b][j] -- nothing is re-ordered between steps.
+template <typename T, int G, bool BEAM = false>
 __global__ __launch_bounds__(256) void qw_decode_attn_kernel(const float* __restrict__ qkv, int n_heads, int n_kv, const float* __restrict__ qn,
                                                              const float* __restrict__ kn, const float* __restrict__ rope, float eps,
                                                              const int32_t* __restrict__ hist, T* __restrict__ kc, T* __restrict__ vc, int S_max,
-                                                             T* __restrict__ ctx) {
+                                                             T* __restrict__ ctx, const int32_t* __restrict__ src = nullptr, int ld_src = 0,
+                                                             const int32_t* __restrict__ p0 = nullptr, const T* __restrict__ kc_p = nullptr,
+                                                             const T* __restrict__ vc_p = nullptr, int S_p = 0, int beam = 1) {
   constexpr int HD = 128, KPI = 4, NTASK = (2 + G + 3) / 4;
   __shared__ float qsh[G][HD];
   __shared__ float knew[HD], vnew[HD];
   __shared__ float pm[16][G], pl[16][G];
   __shared__ float pacc[16][G][HD];
-  const int b = blockIdx.x, kvh = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int b = blockIdx.x, kvh = blockIdx.y;
+  if constexpr (BEAM) {
+    // 1-D grid. Consecutive workgroup ids go to consecutive XCDs: the `beam` rows of one (utterance, kv head) unit take ids that are
+    // 8 apart, so they share an L2 and the prompt keys come from HBM once per unit. (Needs units % 8 == 0; plain order otherwise.)
+    const int w = blockIdx.x, units = (gridDim.x / beam);
+    int u, r;
+    if (units % 8 == 0) { const int x = w & 7, q = w >> 3; u = (q / beam) * 8 + x; r = q % beam; }
+    else { u = w / beam; r = w % beam; }
+    b = (u / n_kv) * beam + r; kvh = u % n_kv;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pos = hist[b];                               // keys [0, pos) are in the cache; key pos is made here
   const int heads = n_heads + 2 * n_kv;
-  T* K = kc + ((size_t)b * n_kv + kvh) * S_max * HD;
-  T* V = vc + ((size_t)b * n_kv + kvh) * S_max * HD;
+  const int base = BEAM ? p0[b] : 0;
+  T* K = kc + ((size_t)b * n_kv + kvh) * S_max * HD - (size_t)base * HD;   // BEAM: indexed by position, slot = position - base
+  T* V = vc + ((size_t)b * n_kv + kvh) * S_max * HD - (size_t)base * HD;
+  const T* Kp = BEAM ? kc_p + ((size_t)(b / beam) * n_kv + kvh) * S_p * HD : nullptr;
+  const T* Vp = BEAM ? vc_p + ((size_t)(b / beam) * n_kv + kvh) * S_p * HD : nullptr;
   const float* row = qkv + (size_t)b * heads * HD;
   const int lg = lane >> 4, li = lane & 15, gid = wave * 4 + lg;
+  auto row_ptrs = [&](int s, const T*& kp, const T*& vp) {   // where position s of this sequence lives
+    if constexpr (BEAM) {
+      if (s < base) { kp = Kp + (size_t)s * HD; vp = Vp + (size_t)s * HD; return; }
+      const ptrdiff_t o = (ptrdiff_t)(src[(size_t)b * ld_src + (s - base)] - b) * n_kv * S_max * HD + (ptrdiff_t)s * HD;
+      kp = K + o; vp = V + o;
+      return;
+    }
+    kp = K + (size_t)s * HD; vp = V + (size_t)s * HD;
+  };
   // ---- requests: the new position's inputs first (L2), then the first block of cache rows (HBM)
   float x0[NTASK], x1[NTASK];
 #pragma unroll
@@ -295,7 +323,7 @@ __global__ __launch_bounds__(256) void qw_decode_attn_kernel(const float* __rest
 #pragma unroll
   for (int u = 0; u < KPI; ++u) {
     const int s = u * 16 + gid;
-    if (s < pos) { kb[u].load(K + (size_t)s * HD + li * 8); vb[u].load(V + (size_t)s * HD + li * 8); }
+    if (s < pos) { const T *kp, *vp; row_ptrs(s, kp, vp); kb[u].load(kp + li * 8); vb[u].load(vp + li * 8); }
   }
   // ---- the new position: task 0 = k, 1 = v, 2.. = the group's q heads
   const float cs = rope[(size_t)pos * HD + lane], sn = rope[(size_t)pos * HD + 64 + lane];
@@ -372,7 +400,7 @@ __global__ __launch_bounds__(256) void qw_decode_attn_kernel(const float* __rest
 #pragma unroll
     for (int u = 0; u < KPI; ++u) {                      // next block's rows while this one is consumed
       const int s = s0 + (KPI + u) * 16 + gid;
-      if (s < pos) { kn2[u].load(K + (size_t)s * HD + li * 8); vn2[u].load(V + (size_t)s * HD + li * 8); }
+      if (s < pos) { const T *kp, *vp; row_ptrs(s, kp, vp); kn2[u].load(kp + li * 8); vn2[u].load(vp + li * 8); }
     }
     float k8[KPI][8], v8[KPI][8];
     bool valid[KPI];
@@ -438,6 +466,147 @@ __global__ void qw_hist_add_kernel(int32_t* __restrict__ hist, const UttPlan* __
   if (b < B) hist[b] += plan[b].T;
 }
 
+// ------------------------------------------------------------------------------------ beam search
+// Width-`beam` search over summed log-probabilities (README.md:38 names a beam mode for Qwen3-ASR; the reference ships no code for it, the
+// semantics are those of oracle/qwen_asr_oracle.py:beam_search_core). Hypotheses of utterance b are the decoder rows b * beam + r.
+constexpr int BEAM_MAX = 8;
+
+// per row: log-soft-max statistics and the K best (log-prob, id) pairs, ties -> lower id. One pass: every thread keeps a running
+// (max, sum) pair and its own sorted best-8 list; the lists merge in K rounds of a block-wide arg-max.
+__global__ __launch_bounds__(1024) void qw_beam_topk_kernel(const float* __restrict__ logits, int ld, int n_valid, int K, float* __restrict__ topv,
+                                                            int32_t* __restrict__ topi) {
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* p = logits + (size_t)row * ld;
+  float tv[BEAM_MAX]; int ti[BEAM_MAX];
+#pragma unroll
+  for (int j = 0; j < BEAM_MAX; ++j) { tv[j] = -INFINITY; ti[j] = INT32_MAX; }
+  float m = -INFINITY, sum = 0.0f;
+  for (int v0 = tid * 4; v0 < n_valid; v0 += 4096) {
+    const float4 q = *reinterpret_cast<const float4*>(p + v0);
+    const float xs[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = xs[e];
+      if (v0 + e >= n_valid) continue;
+      if (x > m) { sum = sum * __expf(m - x) + 1.0f; m = x; } else { sum += __expf(x - m); }
+      if (x > tv[BEAM_MAX - 1]) {
+        tv[BEAM_MAX - 1] = x; ti[BEAM_MAX - 1] = v0 + e;
+#pragma unroll
+        for (int j = BEAM_MAX - 1; j > 0; --j)
+          if (tv[j] > tv[j - 1]) { const float a = tv[j]; tv[j] = tv[j - 1]; tv[j - 1] = a; const int c = ti[j]; ti[j] = ti[j - 1]; ti[j - 1] = c; }
+      }
+    }
+  }
+  __shared__ float sm[16], ss[16], sv[16];
+  __shared__ int si[16];
+  __shared__ float lse_sh;
+  __shared__ int win_sh;
+  auto merge = [](float& m1, float& s1, float m2, float s2) {
+    const float M = fmaxf(m1, m2);
+    const float a = m1 == -INFINITY ? 0.0f : s1 * __expf(m1 - M), b = m2 == -INFINITY ? 0.0f : s2 * __expf(m2 - M);
+    m1 = M; s1 = a + b;
+  };
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) merge(m, sum, __shfl_xor(m, o, 64), __shfl_xor(sum, o, 64));
+  if (lane == 0) { sm[wave] = m; ss[wave] = sum; }
+  __syncthreads();
+  if (tid == 0) {
+    float M = sm[0], S = ss[0];
+    for (int w = 1; w < 16; ++w) merge(M, S, sm[w], ss[w]);
+    lse_sh = M + logf(S);
+  }
+  for (int k = 0; k < K; ++k) {
+    float bv = tv[0]; int bi = ti[0];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float v = sv[0]; int i = si[0];
+      for (int w = 1; w < 16; ++w) if (sv[w] > v || (sv[w] == v && si[w] < i)) { v = sv[w]; i = si[w]; }
+      win_sh = i;
+      topv[(size_t)row * K + k] = v - lse_sh;
+      topi[(size_t)row * K + k] = i;
+    }
+    __syncthreads();
+    if (ti[0] == win_sh) {                               // the owner pops its head
+#pragma unroll
+      for (int j = 0; j < BEAM_MAX - 1; ++j) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
+      tv[BEAM_MAX - 1] = -INFINITY; ti[BEAM_MAX - 1] = INT32_MAX;
+    }
+  }
+}
+
+struct QwBeamArgs {
+  int beam, K, ld, first, n_slots;       // ld: row stride of the ancestry / token tables; n_slots: generated cache slots after this pass
+  const float* topv; const int32_t* topi;
+  float* cum; int32_t* fin; int32_t* len; int32_t* next; int32_t* done;
+  const int32_t* stop; int n_stop;
+  const int32_t *src_in, *tok_in; int32_t *src_out, *tok_out;
+};
+
+// one wave per utterance: rank the <= beam * K extensions (finished hypotheses stand as themselves), keep the best `beam` in order
+// (score descending, then hypothesis, then rank inside the hypothesis), and rebuild the rows' ancestry / token tables from their parents'.
+__global__ __launch_bounds__(64) void qw_beam_select_kernel(QwBeamArgs a) {
+  const int b = blockIdx.x, lane = threadIdx.x, beam = a.beam, K = a.K, base = b * beam;
+  __shared__ int par[BEAM_MAX], ntok[BEAM_MAX], nfin[BEAM_MAX], nlen[BEAM_MAX], nnext[BEAM_MAX];
+  __shared__ float ncum[BEAM_MAX];
+  const bool frozen_utt = !a.first && a.done[b] != 0;
+  const int r = lane / K, k = lane - r * K;
+  bool valid = r < beam && (!a.first || r == 0);
+  float score = -INFINITY; int tokv = -1, pf = 0, pl = 0, pn = 0;
+  if (valid) {
+    const int row = base + r;
+    if (a.first) { score = a.topv[(size_t)b * K + k]; tokv = a.topi[(size_t)b * K + k]; }
+    else {
+      pf = a.fin[row]; pl = a.len[row]; pn = a.next[row];
+      if (frozen_utt) { valid = k == 0; score = a.cum[row]; }
+      else if (pf) { valid = k == 0; score = a.cum[row]; }
+      else { score = a.cum[row] + a.topv[(size_t)row * K + k]; tokv = a.topi[(size_t)row * K + k]; }
+    }
+  }
+  const float sc = valid ? score : -INFINITY;
+  int rank = 0;
+  for (int j = 0; j < 64; ++j) {
+    const float sj = __shfl(sc, j, 64);
+    rank += (sj > sc || (sj == sc && j < lane)) ? 1 : 0;
+  }
+  if (frozen_utt) rank = r;                               // a finished utterance keeps its n-best list as it stands
+  if (valid && rank < beam) {
+    const bool frozen = frozen_utt || (!a.first && pf);
+    bool is_stop = false;
+    if (!frozen) for (int i = 0; i < a.n_stop; ++i) is_stop = is_stop || a.stop[i] == tokv;
+    par[rank] = r; ncum[rank] = score;
+    ntok[rank] = (frozen || is_stop) ? -1 : tokv;        // the id appended to the hypothesis (stop ids are not emitted)
+    nfin[rank] = (frozen ? pf : (is_stop ? 1 : 0));
+    nlen[rank] = pl + ((frozen || is_stop) ? 0 : 1);
+    nnext[rank] = frozen ? pn : tokv;
+  }
+  __syncthreads();
+  // tables: row r' = parent's generated-slot ancestry + the parent itself for the slot written by this pass; parent's tokens + the new id
+  for (int q = 0; q < beam; ++q) {
+    const int prow = base + par[q], orow = base + q;
+    const int ncopy = a.n_slots - (frozen_utt ? 0 : 1);
+    for (int j = lane; j < ncopy; j += 64) a.src_out[(size_t)orow * a.ld + j] = a.src_in[(size_t)prow * a.ld + j];
+    if (!frozen_utt && a.n_slots > 0 && lane == 0) a.src_out[(size_t)orow * a.ld + a.n_slots - 1] = prow;
+    const int keep = nlen[q] - (ntok[q] >= 0 ? 1 : 0);
+    for (int j = lane; j < keep; j += 64) a.tok_out[(size_t)orow * a.ld + j] = a.tok_in[(size_t)prow * a.ld + j];
+    if (ntok[q] >= 0 && lane == 0) a.tok_out[(size_t)orow * a.ld + keep] = ntok[q];
+  }
+  if (lane < beam) {
+    a.cum[base + lane] = ncum[lane]; a.fin[base + lane] = nfin[lane]; a.len[base + lane] = nlen[lane]; a.next[base + lane] = nnext[lane];
+  }
+  if (lane == 0) a.done[b] = nfin[0];
+}
+
+__global__ void qw_beam_init_kernel(const int32_t* __restrict__ hist_in, int B, int beam, int32_t* __restrict__ hist_out, int32_t* __restrict__ p0) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < B * beam) { hist_out[n] = hist_in[n / beam]; p0[n] = hist_in[n / beam]; }
+}
+
 // ------------------------------------------------------------------------------------ session
 struct QwEncLayer { const void *wqkv, *wo, *w1, *w2; const float *bqkv, *bo, *b1, *b2; };
 struct QwDecLayer { const void *wqkv, *wo, *gate_up, *down; const float *qn, *kn; };
@@ -447,6 +616,8 @@ struct DecPass {
   const UttPlan* plan = nullptr; const int32_t *row_seq = nullptr, *row_t = nullptr, *last_rows = nullptr;
   int rows = 0, B = 0; bool step = false, hist_done = false;   // hist_done: the history counters were advanced already
   const int32_t *qb_utt = nullptr, *qb_q0 = nullptr; int n_qb = 0, qt = 0, nw = 0, max_T = 0, ld_vt = 0;
+  // beam search: the rows are hypotheses with their own cache (slot stride S), history counters and generated-slot ancestry table
+  void *kc = nullptr, *vc = nullptr; int S = 0; int32_t* hist = nullptr; const int32_t *beam_src = nullptr, *beam_p0 = nullptr; int ld_src = 0, beam = 1;
 };
 
 struct QwSession : asr_session {
@@ -472,6 +643,7 @@ struct QwSession : asr_session {
   // opt-in (ASR_QWEN_MEGA=1): measured 2.0 ms / token vs 1.72 for per-phase launches
   bool use_mega = false, mega_used = false; unsigned int mega_gen = 0; DeviceBuffer d_megabar, d_megalayers, d_megadbg, d_mlo, d_mctx, d_mact;
   DeviceBuffer d_save, d_nsaved, d_noise;
+  DeviceBuffer d_bkc, d_bvc, d_bhist, d_bp0, d_bplan, d_bsrc[2], d_btok[2], d_bcum, d_bfin, d_blen, d_bdone, d_btopv, d_btopi, d_bstop, d_bnext;   // beam search state
   hipGraphExec_t dec_graph = nullptr; uint64_t dec_key = 0, dec_eager_key = 0;
   void* h_plan = nullptr; size_t h_plan_cap = 0;
   void* h_io = nullptr; size_t h_io_cap = 0;
@@ -480,7 +652,7 @@ struct QwSession : asr_session {
   ~QwSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_feat, &d_col, &d_c1, &d_c2, &d_c3, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx,
                             &d_ffn, &d_aud_out, &d_dplan, &d_x, &d_x2, &d_dh, &d_qkv, &d_q, &d_dctx, &d_act, &d_last, &d_logits, &d_next,
-                            &d_kc, &d_vc, &d_hist, &d_stepplan, &d_skws, &d_skcnt, &d_vt2, &d_krows, &d_xlo, &d_x2lo, &d_save, &d_nsaved, &d_noise, &d_megabar, &d_megalayers, &d_megadbg, &d_mlo, &d_mctx, &d_mact})
+                            &d_kc, &d_vc, &d_hist, &d_stepplan, &d_skws, &d_skcnt, &d_vt2, &d_krows, &d_xlo, &d_x2lo, &d_save, &d_nsaved, &d_noise, &d_bkc, &d_bvc, &d_bhist, &d_bp0, &d_bplan, &d_bsrc[0], &d_bsrc[1], &d_btok[0], &d_btok[1], &d_bcum, &d_bfin, &d_blen, &d_bdone, &d_btopv, &d_btopi, &d_bstop, &d_bnext, &d_megabar, &d_megalayers, &d_megadbg, &d_mlo, &d_mctx, &d_mact})
       b->release();
     for (auto& kv : taps) kv.second.buf.release();
     if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
@@ -514,6 +686,7 @@ struct QwSession : asr_session {
   bool mega_step(int B);
   template <typename T> void step(const int32_t* ids_host, int32_t* next_out, float* logits_out);
   template <typename T> void finish(int B, int32_t* next_out, float* logits_out, bool sync);
+  template <typename T> void beam_search(int beam, int max_new, const int32_t* stop_ids, int n_stop, int32_t* tokens_out, int32_t* n_out, float* scores_out);
 };
 
 void QwSession::init() {
@@ -566,7 +739,7 @@ void QwSession::init() {
 template <typename T>
 void QwSession::decoder_pass(const DecPass& P) {
   const auto& c = cfg;
-  const int d = c.d_model, H = c.n_heads, KV = c.n_kv_heads, hd = c.d_head, I = c.d_ffn, qkvn = (H + 2 * KV) * hd, S = c.max_seq_len;
+  const int d = c.d_model, H = c.n_heads, KV = c.n_kv_heads, hd = c.d_head, I = c.d_ffn, qkvn = (H + 2 * KV) * hd, S = P.S ? P.S : c.max_seq_len;
   const int rows = P.rows, B = P.B;
   const bool bf = precision == ASR_PRECISION_BF16;
   float* x = d_x.as<float>();
@@ -577,7 +750,7 @@ void QwSession::decoder_pass(const DecPass& P) {
   T* ctx = d_dctx.as<T>();
   T* act = d_act.as<T>();
   const size_t layer_kv = (size_t)B * KV * S * hd;
-  const int32_t* hist = d_hist.as<int32_t>();
+  const int32_t* hist = P.hist ? P.hist : d_hist.as<int32_t>();
   const int G = H / KV;
   // single-position steps of small batches (bf16): RMSNorm(x) W^T = rstd(x) (x W^T) -- the weight-streaming GEMM reads the raw residual
   // rows (bf16 copy written by the producing GEMM), sums x^2 from the fragments it streams anyway and scales its output rows
@@ -597,15 +770,24 @@ void QwSession::decoder_pass(const DecPass& P) {
   };
   for (int i = 0; i < c.n_layers; ++i) {
     const QwDecLayer& L = dec[i];
-    T* kc = d_kc.as<T>() + (size_t)i * layer_kv;
-    T* vc = d_vc.as<T>() + (size_t)i * layer_kv;
+    T* kc = (P.kc ? (T*)P.kc : d_kc.as<T>()) + (size_t)i * layer_kv;
+    T* vc = (P.vc ? (T*)P.vc : d_vc.as<T>()) + (size_t)i * layer_kv;
     { GemmArgs g; g.W = L.wqkv; g.ldw = d; g.M = rows; g.N = qkvn; g.K = d; g.out_f32 = qkv; g.ld_out_f32 = qkvn; normed_gemm(x, xlo, g); }
     if (fused_attn) {
       ProfScope ps(prof, "dec_attn", stream);
       const size_t lds = 0;
-      if (G == 1) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 1>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx);
-      else if (G == 2) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 2>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx);
-      else hipLaunchKernelGGL((qw_decode_attn_kernel<T, 4>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx);
+      if (P.beam_src) {
+        ASR_REQUIRE(fused_attn, "qwen beam search needs the fused decode attention kernel");
+        const size_t prompt_kv = (size_t)(B / P.beam) * KV * c.max_seq_len * hd;    // the utterances' prefill cache, one layer
+        const T* kc_p = d_kc.as<T>() + (size_t)i * prompt_kv;
+        const T* vc_p = d_vc.as<T>() + (size_t)i * prompt_kv;
+        if (G == 1) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 1, true>), dim3(B * KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx, P.beam_src, P.ld_src, P.beam_p0, kc_p, vc_p, c.max_seq_len, P.beam);
+        else if (G == 2) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 2, true>), dim3(B * KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx, P.beam_src, P.ld_src, P.beam_p0, kc_p, vc_p, c.max_seq_len, P.beam);
+        else hipLaunchKernelGGL((qw_decode_attn_kernel<T, 4, true>), dim3(B * KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx, P.beam_src, P.ld_src, P.beam_p0, kc_p, vc_p, c.max_seq_len, P.beam);
+      } else
+      if (G == 1) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 1, false>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx, (const int32_t*)nullptr, 0, (const int32_t*)nullptr, (const T*)nullptr, (const T*)nullptr, 0, 1);
+      else if (G == 2) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 2, false>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx, (const int32_t*)nullptr, 0, (const int32_t*)nullptr, (const T*)nullptr, (const T*)nullptr, 0, 1);
+      else hipLaunchKernelGGL((qw_decode_attn_kernel<T, 4, false>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx, (const int32_t*)nullptr, 0, (const int32_t*)nullptr, (const T*)nullptr, (const T*)nullptr, 0, 1);
     } else {
       const bool mfma_attn = bf && !P.step && P.n_qb > 0;
       if (mfma_attn) {                                   // V^T for the MFMA attention kernel (the cache gets V from the q|k|v GEMM)
@@ -656,9 +838,12 @@ void QwSession::logits_head(const DecPass& P) {
     // heads: the prefill graphs select from the raw logits with an empty history; the decode graphs apply the penalty first
     // (Shared_Merged.py merge_prefill_* / merge_decode_*)
     const bool penalised = penalty_value != 1.0f && !sampling;
+    if (P.beam_src) {                                    // beam search ranks the rows' extensions itself
+    } else
     if (penalised && P.step)
       launch_apply_penalty(d_logits.as<float>(), vpad, B, d_save.as<int32_t>(), c.max_seq_len, d_nsaved.as<int32_t>(), penalty_range, penalty_value, stream, 1);
-    if (sampling) {
+    if (P.beam_src) {
+    } else if (sampling) {
       SampleArgs sa;
       sa.logits = d_logits.as<float>(); sa.ld = vpad; sa.rows = B; sa.n_valid = c.vocab; sa.extra = nullptr;
       sa.save_ids = d_save.as<int32_t>(); sa.ld_save = c.max_seq_len; sa.n_saved = d_nsaved.as<int32_t>();
@@ -668,11 +853,11 @@ void QwSession::logits_head(const DecPass& P) {
     } else {
       launch_argmax_rows(d_logits.as<float>(), vpad, B, c.vocab, nullptr, d_next.as<int32_t>(), stream);
     }
-    if (penalised || sampling || track_history) {        // GREEDY_SEARCH / the sampling head append their pick to save_id
+    if (!P.beam_src && (penalised || sampling || track_history)) {        // GREEDY_SEARCH / the sampling head append their pick to save_id
       launch_append_ids(d_next.as<int32_t>(), B, d_save.as<int32_t>(), c.max_seq_len, d_nsaved.as<int32_t>(), stream);
       launch_add_scalar(d_nsaved.as<int32_t>(), 1, stream);
     } }
-  if (!P.hist_done) hipLaunchKernelGGL(qw_hist_add_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, d_hist.as<int32_t>(), P.plan, B);
+  if (!P.hist_done) hipLaunchKernelGGL(qw_hist_add_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, P.hist ? P.hist : d_hist.as<int32_t>(), P.plan, B);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1108,6 +1293,108 @@ void QwSession::step(const int32_t* ids_host, int32_t* next_out, float* logits_o
   finish<T>(B, next_out, logits_out, ids_host != nullptr);
 }
 
+// Beam search after a prefill: every step runs the decoder over all B * beam hypothesis rows. The prompts stay where the prefill wrote
+// them (one copy per utterance, shared by its rows); generated positions go to a small per-row cache and the attention kernel follows
+// each row's ancestry through it, so nothing is copied or re-ordered between steps. The extensions are ranked on the device; the host
+// reads back only the per-utterance "best hypothesis has ended" flags.
+// Output: per utterance its `beam` hypotheses best-first -- tokens_out [B][beam][max_new], n_out [B][beam], scores_out [B][beam].
+template <typename T>
+void QwSession::beam_search(int beam, int max_new, const int32_t* stop_ids, int n_stop, int32_t* tokens_out, int32_t* n_out, float* scores_out) {
+  const auto& c = cfg;
+  ASR_REQUIRE(batch > 0, "qwen_beam_search: prefill first");
+  ASR_REQUIRE(beam >= 1 && beam <= BEAM_MAX, "qwen_beam_search: beam width %d outside 1..%d", beam, BEAM_MAX);
+  ASR_REQUIRE(!no_fuse && (c.n_heads / c.n_kv_heads == 1 || c.n_heads / c.n_kv_heads == 2 || c.n_heads / c.n_kv_heads == 4),
+              "qwen_beam_search: needs the fused decode attention kernel");
+  ASR_REQUIRE(!sampling && penalty_value == 1.0f, "qwen_beam_search: the penalty / sampling heads do not combine with beam search");
+  HIP_CHECK(hipSetDevice(device));
+  const int B = batch, N = B * beam, KV = c.n_kv_heads, hd = c.d_head, d = c.d_model, H = c.n_heads, I = c.d_ffn, qkvn = (H + 2 * KV) * hd;
+  const size_t eT = sizeof(T);
+  int max_len = 0;
+  for (int b = 0; b < B; ++b) max_len = std::max(max_len, seq_len[b]);
+  ASR_REQUIRE(max_len + 1 <= c.max_seq_len, "qwen_beam_search: no room after the prompt (max_seq_len %d)", c.max_seq_len);
+  const int out_stride = max_new;
+  max_new = std::min(max_new, c.max_seq_len - max_len);  // positions (RoPE rows) end at max_seq_len
+  const int Sb = round_up(max_new, 16), ld = Sb;         // generated slots per hypothesis row; the prompts stay in the prefill cache
+  // ---- the first ranking reads the prefill logits; do it before any buffer grows
+  d_btopv.reserve((size_t)std::max(N, 64) * BEAM_MAX * 4, stream);
+  d_btopi.reserve((size_t)std::max(N, 64) * BEAM_MAX * 4, stream);
+  for (DeviceBuffer* q : {&d_bcum, &d_bfin, &d_blen, &d_bdone, &d_bhist, &d_bp0}) q->reserve((size_t)std::max(N, 64) * 4, stream);
+  for (int i = 0; i < 2; ++i) { d_bsrc[i].reserve((size_t)N * ld * 4, stream); d_btok[i].reserve((size_t)N * ld * 4, stream); }
+  d_bstop.reserve((size_t)std::max(n_stop, 16) * 4, stream);
+  if (n_stop) HIP_CHECK(hipMemcpyAsync(d_bstop.ptr, stop_ids, (size_t)n_stop * 4, hipMemcpyHostToDevice, stream));
+  HIP_CHECK(hipMemsetAsync(d_bdone.ptr, 0, (size_t)B * 4, stream));
+  HIP_CHECK(hipMemsetAsync(d_blen.ptr, 0, (size_t)N * 4, stream));
+  hipLaunchKernelGGL(qw_beam_topk_kernel, dim3(B), dim3(1024), 0, stream, d_logits.as<float>(), vpad, c.vocab, beam, d_btopv.as<float>(), d_btopi.as<int32_t>());
+  DeviceBuffer& nxt = d_bnext;
+  nxt.reserve((size_t)std::max(N, 64) * 4, stream);
+  QwBeamArgs ba{};
+  ba.beam = beam; ba.K = beam; ba.ld = ld; ba.topv = d_btopv.as<float>(); ba.topi = d_btopi.as<int32_t>();
+  ba.cum = d_bcum.as<float>(); ba.fin = d_bfin.as<int32_t>(); ba.len = d_blen.as<int32_t>(); ba.done = d_bdone.as<int32_t>(); ba.next = nxt.as<int32_t>();
+  ba.stop = d_bstop.as<int32_t>(); ba.n_stop = n_stop;
+  int cur = 0;
+  auto select = [&](int first, int n_slots) {
+    ba.first = first; ba.n_slots = n_slots;
+    ba.src_in = d_bsrc[cur].as<int32_t>(); ba.tok_in = d_btok[cur].as<int32_t>();
+    ba.src_out = d_bsrc[cur ^ 1].as<int32_t>(); ba.tok_out = d_btok[cur ^ 1].as<int32_t>();
+    hipLaunchKernelGGL(qw_beam_select_kernel, dim3(B), dim3(64), 0, stream, ba);
+    cur ^= 1;
+  };
+  select(1, 0);
+  // ---- hypothesis rows: caches, counters, row buffers, the one-row-per-hypothesis plan
+  d_bkc.reserve((size_t)c.n_layers * N * KV * Sb * hd * eT, stream);
+  d_bvc.reserve((size_t)c.n_layers * N * KV * Sb * hd * eT, stream);
+  hipLaunchKernelGGL(qw_beam_init_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, d_hist.as<int32_t>(), B, beam, d_bhist.as<int32_t>(), d_bp0.as<int32_t>());
+  const size_t Mn = pad_rows(N);
+  d_x.reserve(Mn * d * 4, stream); d_x2.reserve(Mn * d * 4, stream); d_dh.reserve(Mn * d * eT, stream); d_qkv.reserve(Mn * qkvn * 4, stream);
+  d_dctx.reserve(Mn * H * hd * eT, stream); d_xlo.reserve(Mn * d * eT, stream); d_x2lo.reserve(Mn * d * eT, stream); d_act.reserve(Mn * I * eT, stream);
+  d_last.reserve(Mn * d * eT, stream); d_logits.reserve(Mn * (size_t)vpad * 4, stream);
+  const int Mb = round_up(N, 128);
+  const size_t sbytes = sizeof(UttPlan) * N + 4 * 3 * (size_t)Mb;
+  {
+    std::vector<unsigned char> blob(sbytes);
+    UttPlan* sp = (UttPlan*)blob.data();
+    int32_t* s_seq = (int32_t*)(sp + N); int32_t* s_t = s_seq + Mb; int32_t* s_last = s_t + Mb;
+    for (int r = 0; r < Mb; ++r) { s_seq[r] = r < N ? r : -1; s_t[r] = 0; s_last[r] = r < N ? r : 0; }
+    for (int n = 0; n < N; ++n) { UttPlan p{}; p.T = 1; p.n_lfr = 1; p.row_off = n; sp[n] = p; }
+    d_bplan.reserve(sbytes, stream);
+    HIP_CHECK(hipMemcpyAsync(d_bplan.ptr, blob.data(), sbytes, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));             // `blob` is a stack object
+  }
+  const UttPlan* dsp = d_bplan.as<UttPlan>();
+  DecPass P;
+  P.plan = dsp; P.row_seq = (const int32_t*)(dsp + N); P.row_t = P.row_seq + Mb; P.last_rows = P.row_t + Mb; P.rows = N; P.B = N; P.step = true;
+  P.kc = d_bkc.ptr; P.vc = d_bvc.ptr; P.S = Sb; P.hist = d_bhist.as<int32_t>(); P.beam_p0 = d_bp0.as<int32_t>(); P.ld_src = ld; P.beam = beam;
+  int32_t* h_done = (int32_t*)pinned(h_ids, h_ids_cap, (size_t)std::max(B, 64) * 4);
+  for (int t = 0; t + 1 < max_new; ++t) {
+    HIP_CHECK(hipMemcpyAsync(h_done, d_bdone.ptr, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    bool all = true;
+    for (int b = 0; b < B; ++b) all = all && h_done[b] != 0;
+    if (all) break;
+    { ProfScope ps(prof, "dec_embed", stream);
+      hipLaunchKernelGGL(qw_gather_prompt_kernel<T>, dim3(N), dim3(256), 0, stream, (const int32_t*)nxt.ptr, (const T*)embed, (const float*)nullptr, d,
+                         INT32_MIN, d_x.as<float>(), precision == ASR_PRECISION_BF16 ? d_xlo.as<T>() : (T*)nullptr); }
+    P.beam_src = d_bsrc[cur].as<int32_t>();
+    decoder_pass<T>(P);
+    { ProfScope ps(prof, "beam_rank", stream);
+      hipLaunchKernelGGL(qw_beam_topk_kernel, dim3(N), dim3(1024), 0, stream, d_logits.as<float>(), vpad, c.vocab, beam, d_btopv.as<float>(), d_btopi.as<int32_t>());
+      select(0, t + 1); }
+  }
+  HIP_CHECK(hipGetLastError());
+  std::vector<int32_t> h_tok((size_t)N * ld), h_len(N);
+  std::vector<float> h_cum(N);
+  HIP_CHECK(hipMemcpyAsync(h_tok.data(), d_btok[cur].ptr, (size_t)N * ld * 4, hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipMemcpyAsync(h_len.data(), d_blen.ptr, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipMemcpyAsync(h_cum.data(), d_bcum.ptr, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  if (prof.enabled) prof.collect();
+  for (int n = 0; n < N; ++n) {
+    n_out[n] = h_len[n];
+    if (scores_out) scores_out[n] = h_cum[n];
+    for (int j = 0; j < h_len[n] && j < out_stride; ++j) tokens_out[(size_t)n * out_stride + j] = h_tok[(size_t)n * ld + j];
+  }
+}
+
 }  // namespace
 
 extern "C" int asr_qwen_create(const asr_qwen_config* cfg, const void* arena, size_t arena_bytes, int arena_mem, int device_id, int precision,
@@ -1208,6 +1495,16 @@ extern "C" int asr_qwen_set_sampling_noise(asr_session* s, const float* uniforms
     HIP_CHECK(hipMemcpyAsync(q->d_noise.ptr, uniforms, (size_t)count * 4, hipMemcpyHostToDevice, q->stream));
     HIP_CHECK(hipStreamSynchronize(q->stream));
     q->noise_armed = true;
+  });
+}
+
+extern "C" int asr_qwen_beam_search(asr_session* s, int beam, int max_new, const int32_t* stop_ids, int n_stop, int32_t* tokens_out, int32_t* n_out,
+                                    float* scores_out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 5 && tokens_out && n_out && max_new >= 1 && n_stop >= 0 && (n_stop == 0 || stop_ids), "qwen_beam_search: bad argument");
+    QwSession* q = static_cast<QwSession*>(s);
+    if (q->precision == ASR_PRECISION_BF16) q->beam_search<bf16_t>(beam, max_new, stop_ids, n_stop, tokens_out, n_out, scores_out);
+    else q->beam_search<float>(beam, max_new, stop_ids, n_stop, tokens_out, n_out, scores_out);
   });
 }
 

@@ -572,6 +572,16 @@ class QwenAsrSession(_Session):
         _lib.check(_lib.load().asr_qwen_generate(self._h, max_new, _ip(stop) if stop.size else None, stop.size, _ip(tok), _ip(n)))
         return [tok[b, :n[b]].copy() for b in range(self.batch)]
 
+    def beam_search(self, beam: int, max_new: int, stop_ids=()):
+        """Width-`beam` search after a prefill -> per utterance a best-first list of (token ids, summed log-probability)."""
+        tok = np.zeros((self.batch, beam, max_new), dtype=np.int32)
+        n = np.zeros((self.batch, beam), dtype=np.int32)
+        score = np.zeros((self.batch, beam), dtype=np.float32)
+        stop = np.ascontiguousarray(list(stop_ids), dtype=np.int32)
+        _lib.check(_lib.load().asr_qwen_beam_search(self._h, int(beam), int(max_new), _ip(stop) if stop.size else None, stop.size, _ip(tok), _ip(n),
+                                                    _fp(score)))
+        return [[(tok[b, r, :n[b, r]].copy(), float(score[b, r])) for r in range(beam)] for b in range(self.batch)]
+
 
 def load_session(path: str, device_id: int = 0):
     """Open an `.asrmodel` bundle (tools/convert_checkpoint.py, export_*) as the matching native session."""

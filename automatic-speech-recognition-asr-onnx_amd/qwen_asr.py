@@ -123,12 +123,17 @@ def export_qwen_asr(cfg: QwenAsrConfig, ck: dict, path: str, metadata: dict, pre
 class QwenAsrTranscriber:
     def __init__(self, cfg: QwenAsrConfig, session: QwenAsrSession, metadata: dict, tokenizer=None, normalise_audio: bool = False,
                  repeat_penalty: float = 1.0, penalty_range: int = 10, use_sampling: bool = False, temperature: float = 0.8, top_k: int = 10,
-                 top_p: float = 0.95, sampling_repetition_penalty: float = 1.0, seed: int = 0):
+                 top_p: float = 0.95, sampling_repetition_penalty: float = 1.0, seed: int = 0, beam_size: int = 1):
         self.cfg, self.sess, self.tokenizer = cfg, session, tokenizer
         # _resolve_strategy (:369-376): sampling wins; REPEAT_PENALTY == 1.0 selects greedy, any other value penalty-greedy (the
         # reference's defaults are 0.8 over PENALTY_RANGE = 10 ids)
         self.repeat_penalty, self.penalty_range = float(repeat_penalty), int(penalty_range)
         self.sampling = (bool(use_sampling), float(temperature), int(top_k), float(top_p), float(sampling_repetition_penalty), int(seed))
+        # beam_size > 1: the README's "beam search" mode (README.md:38; no reference code -- include/asr_mi355x.h asr_qwen_beam_search);
+        # it replaces the per-step head, so it excludes sampling and the repeat penalty
+        self.beam_size = int(beam_size)
+        if self.beam_size > 1 and (use_sampling or self.repeat_penalty != 1.0):
+            raise ValueError("beam_size > 1 needs REPEAT_PENALTY = 1.0 and no sampling")
         self.audio_pcm_scale = int(metadata["audio_pcm_scale"])
         self.max_seq_len = int(metadata["max_seq_len"])
         special = metadata["special_token_ids"]
@@ -168,7 +173,12 @@ class QwenAsrTranscriber:
         limits = np.maximum(self.max_seq_len - 10 - ids_len, 0)
         if max_new is not None:
             limits = np.minimum(limits, max_new)
-        toks = self.sess.generate(int(limits.max()), stop_ids=self.stop) if limits.max() > 0 else [np.zeros(0, np.int32)] * B
+        if limits.max() <= 0:
+            toks = [np.zeros(0, np.int32)] * B
+        elif self.beam_size > 1:
+            toks = [h[0][0] for h in self.sess.beam_search(self.beam_size, int(limits.max()), stop_ids=self.stop)]
+        else:
+            toks = self.sess.generate(int(limits.max()), stop_ids=self.stop)
         wall = time.time() - t0
         out = []
         for b in range(B):

@@ -107,6 +107,7 @@ def main():
                     help="sensevoice = BASELINE.json configs[1] (default, the headline line); whisper = large-v3 encoder + greedy decode")
     ap.add_argument("--inflight", type=int, default=1, help="whisper / qwen: also measure N batches in flight on N sessions / HIP streams")
     ap.add_argument("--streams", type=int, default=256, help="mixed: concurrent Paraformer streams per GPU")
+    ap.add_argument("--beam", type=int, default=1, help="qwen / mixed: beam width (1 = greedy; BASELINE.json configs[4] names beam 5)")
     ap.add_argument("--decode-tokens", type=int, default=0, help="whisper: generated tokens per utterance (default 4 per audio second)")
     args = ap.parse_args()
     if args.workload == "whisper":
@@ -707,7 +708,7 @@ def main_qwen(args):
         t0 = time.perf_counter()
         sess.prefill_packed(None, offsets, pre, post, want_logits=False, audio_device_ptr=audio_dev.data_ptr())
         t1 = time.perf_counter()
-        toks = sess.generate(n_tok, stop_ids=())
+        toks = sess.generate(n_tok, stop_ids=()) if args.beam <= 1 else [h[0][0] for h in sess.beam_search(args.beam, n_tok)]
         t2 = time.perf_counter()
         if record:
             t_parts["prefill"] += t1 - t0; t_parts["decode"] += t2 - t1
@@ -742,7 +743,7 @@ def main_qwen(args):
             torch.cuda.set_device(local_rank)
             for _ in range(n_):
                 s_.prefill_packed(None, offsets, pre, post, want_logits=False, audio_device_ptr=audio_dev.data_ptr())
-                s_.generate(n_tok, stop_ids=())
+                s_.generate(n_tok, stop_ids=()) if args.beam <= 1 else s_.beam_search(args.beam, n_tok)
 
         for s_ in others:
             worker(s_, 1)
@@ -778,16 +779,17 @@ def main_qwen(args):
         kernels = {k: {"ms_per_step": round(v["total_ms"], 3), "launches_per_step": v["launches"]}
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
         t_pre, t_dec = t_parts["prefill"] / args.steps, t_parts["decode"] / args.steps
-        step_bytes = 2.0 * (dec_params + cfg.vocab * d) + B * cfg.n_layers * 2 * cfg.n_kv_heads * cfg.d_head * 2.0 * (L + n_tok / 2)
+        step_bytes = 2.0 * (dec_params + cfg.vocab * d) + B * max(args.beam, 1) * cfg.n_layers * 2 * cfg.n_kv_heads * cfg.d_head * 2.0 * (L + n_tok / 2)
         per_tok = t_dec / max(n_tok - 1, 1)
+        mode = "greedy" if args.beam <= 1 else "beam %d (%d hypothesis rows per step)" % (args.beam, B * args.beam)
         flops = B * (stem + enc + pre_dec)
         out = {
-            "metric": "audio-sec/s, Qwen3-ASR-0.6B, %g s @ 16 kHz chunks, batch %d per GPU, greedy, %d tokens/utterance" % (args.seconds, B, n_tok),
+            "metric": "audio-sec/s, Qwen3-ASR-0.6B, %g s @ 16 kHz chunks, batch %d per GPU, %s, %d tokens/utterance" % (args.seconds, B, mode, n_tok),
             "value": round(audio_s * args.steps / elapsed, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "Qwen3-ASR-0.6B bf16 (18-layer windowed audio encoder + 28-layer Qwen3 decoder), batch=%d x %g s per GPU, prefill of "
-                                   "%d positions (%d audio tokens) + %d greedy decode steps, audio resident in HBM" % (B, args.seconds, L, n_audio, n_tok - 1),
+                                   "%d positions (%d audio tokens) + %d %s decode steps, audio resident in HBM" % (B, args.seconds, L, n_audio, n_tok - 1, mode),
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "rtf": round(elapsed / (audio_s * args.steps), 7),
             "ms": {k: round(v / args.steps * 1e3, 2) for k, v in t_parts.items()},
@@ -867,7 +869,7 @@ def main_mixed(args):
 
     def qwen_step():
         qsess.prefill_packed(None, q_offs, pre, post, want_logits=False, audio_device_ptr=q_audio.data_ptr())
-        return qsess.generate(n_tok, stop_ids=())
+        return qsess.generate(n_tok, stop_ids=()) if args.beam <= 1 else qsess.beam_search(args.beam, n_tok)
 
     def stream_step(i):
         k = i % n_chunks
@@ -931,12 +933,13 @@ def main_mixed(args):
         q_audio_s = world * args.steps * B * args.seconds
         p_audio_s = total_chunks * S * chunk / pcfg.sample_rate
         solo_q, solo_p = B * args.seconds / q_solo, S * chunk / pcfg.sample_rate / p_solo
-        out = {"metric": "audio-sec/s, Qwen3-ASR-0.6B greedy (batch %d x %g s) + Paraformer-large streaming (%d streams, chunk 8000) concurrently on each GPU" % (B, args.seconds, S),
+        mode = "greedy" if args.beam <= 1 else "beam=%d" % args.beam
+        out = {"metric": "audio-sec/s, Qwen3-ASR-0.6B %s (batch %d x %g s) + Paraformer-large streaming (%d streams, chunk 8000) concurrently on each GPU" % (mode, B, args.seconds, S),
                "value": round((q_audio_s + p_audio_s) / elapsed, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                "data": "synthetic",
-               "config": {"workload": "mixed: Qwen3-ASR-0.6B bf16 batches (prefill + %d greedy steps) and Paraformer-large streaming chunk steps, two sessions on "
-                                      "two HIP streams driven by two host threads" % (n_tok - 1),
+               "config": {"workload": "mixed: Qwen3-ASR-0.6B bf16 batches (prefill + %d %s steps) and Paraformer-large streaming chunk steps, two sessions on "
+                                      "two HIP streams driven by two host threads" % (n_tok - 1, mode),
                           "global_batch": world * B, "streams": world * S, "parallelism": f"dp{world}"},
                "concurrent": {"qwen_audio_s_per_s": round(q_audio_s / elapsed, 1), "streaming_audio_s_per_s": round(p_audio_s / elapsed, 1),
                               "streaming_chunk_steps": int(total_chunks), "streaming_ms_per_chunk_step": round(elapsed / max(total_chunks / world, 1) * 1e3, 2)},

@@ -223,6 +223,15 @@ int asr_qwen_set_sampling_noise(asr_session* s, const float* uniforms, int count
 /* continuation after a prefill with the selected head (:687-745): tokens_out host [B][max_new], n_out host [B]; a sequence ends at
  * the first id in stop_ids (not emitted) or when the cache is full. */
 int asr_qwen_generate(asr_session* s, int max_new, const int32_t* stop_ids, int n_stop, int32_t* tokens_out, int32_t* n_out);
+/* beam search after a prefill (the README's "greedy / beam search" for Qwen3-ASR, README.md:38; the reference ships no code for it, the
+ * semantics are written down in oracle/qwen_asr_oracle.py:beam_search_core): width-`beam` (1..8) search over summed log-soft-max scores,
+ * no length normalisation. A hypothesis ends at the first id in stop_ids (not emitted) and then stands with its score; an utterance is
+ * finished when its best hypothesis has ended (no live one can overtake it: log-probabilities are <= 0) or after max_new ids. Every
+ * step is one decoder pass over all B * beam rows; the KV cache is never re-ordered (the attention kernel follows each row's
+ * ancestry). Host outputs, hypotheses best-first: tokens_out [B][beam][max_new], n_out [B][beam], scores_out [B][beam] (nullable).
+ * Plain arg-max head only (no penalty / sampling). The session's greedy state (asr_qwen_decode / _generate) is left untouched. */
+int asr_qwen_beam_search(asr_session* s, int beam, int max_new, const int32_t* stop_ids, int n_stop, int32_t* tokens_out, int32_t* n_out,
+                         float* scores_out);
 
 /* ------------------------------------------------------------------ device buffers
  * Backing store of the shim's OrtValue (OrtValue.ortvalue_from_numpy / update_inplace / numpy,

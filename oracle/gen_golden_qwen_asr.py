@@ -96,6 +96,38 @@ def reference_heads(ref, cfg, audio, query_ids, tail_ids, mode):
     return r
 
 
+BEAM = dict(width=3, max_new=6)
+
+
+def reference_beam(ref, cfg, audio, query_ids, tail_ids, stop_ids):
+    """The build's beam search (oracle.qwen_asr_oracle.beam_search_core -- the reference has no beam code) over logits computed by the
+    REFERENCE's encoder / decoder classes, one hypothesis per decoder call with its own KV tensors."""
+    from oracle.qwen_asr_oracle import beam_search_core
+    enc, embed, rp, rd, main_ = ref["encoder"], ref["embed"], ref["rotary_prefill"], ref["rotary_decode"], ref["main"]
+    ns, L = ref["ns"], cfg.n_layers
+    with torch.inference_mode():
+        q = embed(torch.tensor([query_ids], dtype=torch.int32).reshape(1, -1))
+        base, _ = enc(torch.from_numpy(audio).reshape(1, 1, -1), q)
+        concat, ids_len = ns["CONCAT_EMBED"]()(base, embed(torch.tensor([tail_ids], dtype=torch.int32).reshape(1, -1)))
+        keys = [torch.zeros(1, cfg.n_kv_heads, 1, cfg.d_head, 0) for _ in range(L)]
+        vals = [torch.zeros(1, cfg.n_kv_heads, 1, 0, cfg.d_head) for _ in range(L)]
+        cos, sin, mask, kv_len = rp(ids_len, torch.zeros(1, dtype=torch.int64))
+        out = main_(*keys, *vals, concat, cos, sin, mask)
+
+        def step(state, token):
+            kv, kv_len_ = state
+            cos_, sin_, kv_next = rd(kv_len_)
+            o = main_(*kv, embed(torch.tensor([[token]], dtype=torch.int32)), cos_, sin_, torch.zeros(1))
+            return o[-1][0].numpy(), (tuple(o[:2 * L]), kv_next)
+        margins = []
+        hyps = beam_search_core(out[-1][0].numpy(), (tuple(out[:2 * L]), kv_len), step, BEAM["width"], BEAM["max_new"], stop_ids, margins)
+    toks = np.full((BEAM["width"], BEAM["max_new"]), -1, np.int32)
+    for r, (t, _) in enumerate(hyps):
+        toks[r, :t.size] = t
+    return dict(tokens=toks, lens=np.asarray([t.size for t, _ in hyps], np.int32), scores=np.asarray([s for _, s in hyps], np.float32),
+                margin=np.float32(min(margins)))
+
+
 def main():
     from oracle import reference_harness as rh
     cfgm = importlib.import_module(PKG + ".config")
@@ -105,6 +137,7 @@ def main():
         ck = ckm.synth_qwen_asr_checkpoint(cfg, ck_seed)
         ref = rh.build_reference_qwen_asr(cfg, ck, HEAD_IDS, TAIL_IDS, SUFFIX_IDS, max_seq_len=cfg.max_seq_len)
         out = {"ckpt_seed": np.int64(ck_seed), "n_cases": np.int64(len(clips)), "cfg_name": np.str_(cfg_name), "n_new": np.int64(n_new),
+               "beam": np.asarray([BEAM["width"], BEAM["max_new"]], np.int64),
                "penalty": np.asarray([PENALTY["value"], PENALTY["range"]], np.float32),
                "sampling_params": np.asarray([SAMPLING["temperature"], SAMPLING["top_k"], SAMPLING["top_p"], SAMPLING["repetition_penalty"]], np.float32),
                "head_ids": np.asarray(HEAD_IDS, np.int32), "tail_ids": np.asarray(TAIL_IDS, np.int32), "suffix_ids": np.asarray(SUFFIX_IDS, np.int32)}
@@ -126,6 +159,14 @@ def main():
                 rs_ = reference_heads(ref, cfg, audio, query, tail, "sampling")
                 out[p + "sampling_token_ids"], out[p + "sampling_noise"] = rs_["token_ids"], rs_["noise"]
                 print(fixture, i, "penalty", rp_["token_ids"], "sampling", rs_["token_ids"])
+                best = None
+                for tag in ("beam", "beamstop"):              # second run: the third id of the best hypothesis becomes a stop id
+                    stop = [] if best is None else [int(best[2])]
+                    rb = reference_beam(ref, cfg, audio, query, tail, stop)
+                    best = rb["tokens"][0] if best is None else best
+                    out[p + tag + "_tokens"], out[p + tag + "_lens"], out[p + tag + "_scores"], out[p + tag + "_margin"] = rb["tokens"], rb["lens"], rb["scores"], rb["margin"]
+                    out[p + tag + "_stop"] = np.asarray(stop, np.int32)
+                    print(fixture, i, tag, rb["tokens"].tolist(), rb["lens"], rb["scores"], "min ranking gap", float(rb["margin"]))
         np.savez_compressed(os.path.join(GOLDEN, fixture + ".npz"), **out)
 
 

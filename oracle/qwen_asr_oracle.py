@@ -38,6 +38,63 @@ def feat_lengths(n: int) -> int:
     return f3 + (n // 100) * 13
 
 
+def log_softmax_f32(logits) -> np.ndarray:
+    x = np.asarray(logits, dtype=np.float32)
+    m = x.max()
+    return (x - (m + np.log(np.exp(x - m, dtype=np.float32).sum(dtype=np.float32), dtype=np.float32))).astype(np.float32)
+
+
+def beam_search_core(first_logits, state0, step, beam: int, max_new: int, stop_ids=(), margins=None):
+    """Beam search as the build defines it (the reference repo names a beam mode for Qwen3-ASR in README.md:38 but ships no code for it,
+    so there is NO reference behaviour to pin this against -- parity for this entry point is build-vs-this-restatement only).
+
+    Width-`beam` search over summed log-soft-max scores, no length normalisation:
+      * first ranking: the `beam` best ids of the prompt's logits (ties -> lower id) open the hypotheses;
+      * every step, each live hypothesis offers its `beam` best extensions (score + log-prob); a hypothesis that has ended on a stop id
+        (not emitted) offers itself unchanged; the best `beam` candidates are kept, ordered by score descending, then by parent
+        hypothesis index, then by rank inside the parent;
+      * the utterance is finished when the best hypothesis has ended (extensions only lower a score, so no live one can overtake it), or
+        when max_new ids have been produced; the list then stands as it is.
+    step(state, token) -> (logits, new_state) advances ONE hypothesis. -> best-first list of (token ids, score). `margins` (a list)
+    collects the smallest score gap between neighbours of each ranking's first beam + 1 entries (how close the search came to a flip)."""
+    stop = set(int(t) for t in stop_ids)
+    lp = log_softmax_f32(first_logits)
+    order = np.lexsort((np.arange(lp.size), -lp))[:beam + 1]
+    if margins is not None:
+        margins.append(float(np.min(-np.diff(lp[order]))))
+    order = order[:beam]
+    hyps = []
+    for v in order:
+        v = int(v)
+        hyps.append(dict(tokens=[] if v in stop else [v], last=v, score=np.float32(lp[v]), fin=v in stop, state=state0))
+    for _ in range(max_new - 1):
+        if hyps[0]["fin"]:
+            break
+        cands = []
+        for r, h in enumerate(hyps):
+            if h["fin"]:
+                cands.append((h["score"], r, 0, None, None))
+                continue
+            logits, st = step(h["state"], h["last"])
+            lp = log_softmax_f32(logits)
+            top = np.lexsort((np.arange(lp.size), -lp))[:beam]
+            for k, v in enumerate(top):
+                cands.append((np.float32(h["score"] + lp[v]), r, k, int(v), st))
+        cands.sort(key=lambda q: (-float(q[0]), q[1], q[2]))
+        if margins is not None and len(cands) > 1:
+            sc = np.asarray([float(q[0]) for q in cands[:beam + 1]])
+            margins.append(float(np.min(-np.diff(sc))))
+        new = []
+        for score, r, _, v, st in cands[:beam]:
+            h = hyps[r]
+            if v is None:
+                new.append(h)
+            else:
+                new.append(dict(tokens=h["tokens"] + ([] if v in stop else [v]), last=v, score=score, fin=v in stop, state=st))
+        hyps = new
+    return [(np.asarray(h["tokens"], np.int32), float(h["score"])) for h in hyps]
+
+
 class QwenAsrOracle:
     def __init__(self, cfg, ck: dict, head_ids, tail_ids, query_suffix_ids):
         self.cfg = cfg
@@ -204,6 +261,18 @@ class QwenAsrOracle:
                 heads.append(head)
                 toks.append(int(head.argmax()))
         return dict(token_ids=np.asarray(toks, np.int32), logits=torch.stack(heads).numpy() if heads else None)
+
+    def beam(self, audio_1d, beam: int, max_new: int, query_ids=(), language_tail_ids=(), stop_ids=()):
+        """beam_search_core over this restatement's decoder -> best-first [(token ids, score)]"""
+        with torch.inference_mode():
+            x = self.prompt(self.encode(audio_1d), query_ids, language_tail_ids)
+            logits, ks, vs = self.decoder(x, 0, None, None)
+
+            def step(state, token):
+                hist, k, v = state
+                lg, k2, v2 = self.decoder(self.embed([token]), hist, k, v)
+                return lg.numpy(), (hist + 1, k2, v2)
+            return beam_search_core(logits.numpy(), (x.shape[0], ks, vs), step, beam, max_new, stop_ids)
 
     def greedy(self, audio_1d, n_new: int, query_ids=(), language_tail_ids=(), stop_ids=()):
         """-> dict(audio_hidden, ids_len, logits (steps, vocab), token_ids)"""

@@ -56,3 +56,55 @@ def test_oracle_heads_match_reference_goldens(fixture):
         r = orc.heads(audio, len(c["sampling_token_ids"]), c["query_ids"].tolist(), c["language_tail_ids"].tolist(), sampling=(t, int(k), p, rp),
                       noise=c["sampling_noise"])
         assert np.array_equal(r["token_ids"], c["sampling_token_ids"]), i
+
+
+def _beam_rows(hyps, max_new):
+    toks = np.full((len(hyps), max_new), -1, np.int32)
+    for r, (t, _) in enumerate(hyps):
+        toks[r, :t.size] = t
+    return toks, np.asarray([s for _, s in hyps], np.float32)
+
+
+@pytest.mark.parametrize("fixture", ["qwen_asr_tiny", "qwen_asr_mid"])
+def test_oracle_beam_search_matches_goldens_from_reference_logits(fixture):
+    """beam_search_core over THIS restatement's decoder == the same search over the reference classes' logits (the reference has no beam
+    code: what is pinned here is the decoder under a branching cache, not the search rule)."""
+    g = load_golden(fixture)
+    cfg, ck = qwen_setup(g)
+    orc = QwenAsrOracle(cfg, ck, g["head_ids"].tolist(), g["tail_ids"].tolist(), g["suffix_ids"].tolist())
+    width, max_new = (int(v) for v in g["beam"])
+    for i, c in golden_cases(g):
+        if "beam_tokens" not in c:
+            continue
+        audio = unit_audio(c["audio_seed"], c["n_samples"])
+        for tag in ("beam", "beamstop"):
+            hyps = orc.beam(audio, width, max_new, c["query_ids"].tolist(), c["language_tail_ids"].tolist(), c[tag + "_stop"].tolist())
+            toks, scores = _beam_rows(hyps, max_new)
+            assert np.array_equal(toks, c[tag + "_tokens"]), (i, tag)
+            assert np.abs(scores - c[tag + "_scores"]).max() < 5 * F32_TOL, (i, tag)
+
+
+def test_beam_search_core_rules():
+    """Known-answer cases of the search rule on a hand-made 4-word model (no decoder involved)."""
+    from oracle.qwen_asr_oracle import beam_search_core, log_softmax_f32
+    table = {(): [2.0, 1.9, 0.0, -5.0], (0,): [0.0, 0.0, 0.0, 3.0], (1,): [5.0, 0.0, 0.0, 0.0], (1, 0): [0.0, 0.0, 4.0, 0.0]}
+
+    def step(state, token):
+        seq = state + (token,)
+        return np.asarray(table.get(seq, [0.0, 0.0, 0.0, 0.0]), np.float32), seq
+    lp = lambda seq: log_softmax_f32(np.asarray(table.get(tuple(seq), [0.0] * 4), np.float32))
+    # width 1 == greedy: 0, then 3
+    (t, s), = beam_search_core(table[()], (), step, 1, 2)
+    assert t.tolist() == [0, 3] and abs(s - (lp([])[0] + lp([0])[3])) < 1e-6
+    # width 2 overtakes greedy: 1 -> 0 scores higher than 0 -> 3
+    hyps = beam_search_core(table[()], (), step, 2, 2)
+    assert hyps[0][0].tolist() == [1, 0] and hyps[1][0].tolist() == [0, 3] and hyps[0][1] > hyps[1][1]
+    # a stop id ends a hypothesis without being emitted; the search stops once the ended hypothesis leads
+    hyps = beam_search_core(table[()], (), step, 2, 4, stop_ids=[0])
+    assert hyps[0][0].tolist() == [] and abs(hyps[0][1] - lp([])[0]) < 1e-6      # "0" first: ended at once, nothing overtakes it
+    hyps = beam_search_core(table[()], (), step, 2, 4, stop_ids=[3])
+    # [0] + stop (-0.90) trails [1, 0] (-0.88) at first, leads once [1, 0] is extended, and the search ends there
+    assert hyps[0][0].tolist() == [0] and abs(hyps[0][1] - (lp([])[0] + lp([0])[3])) < 1e-6 and hyps[1][0].tolist()[:2] == [1, 0]
+    # ties -> lower id / earlier parent
+    (t, _), (t2, _) = beam_search_core([1.0, 1.0, 1.0, 1.0], (), step, 2, 1)
+    assert t.tolist() == [0] and t2.tolist() == [1]

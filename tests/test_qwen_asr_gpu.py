@@ -298,3 +298,86 @@ def test_long_prompt_bf16_vs_f32_mode():
     assert out[F32][1].tolist() == out[BF16][1].tolist() and int(out[F32][1].max()) > 380
     ref, got = out[F32][0], out[BF16][0]
     assert np.abs(got - ref).max() < 0.06 * np.abs(ref).max() + 0.05
+
+
+def _beam_arrays(hyps, max_new):
+    toks = np.full((len(hyps), max_new), -1, np.int32)
+    for r, (t, _) in enumerate(hyps):
+        toks[r, :t.size] = t
+    return toks, np.asarray([s for _, s in hyps], np.float32)
+
+
+@pytest.mark.parametrize("fixture", ["qwen_asr_tiny", "qwen_asr_mid"])
+def test_beam_search_f32_matches_goldens(fixture):
+    """Width-3 search on the device (hypothesis rows, ancestry-following attention, device-side ranking) == the search over the reference
+    classes' logits: the n-best token lists and their scores, with and without a stop id, as one ragged batch."""
+    g = load_golden(fixture)
+    cfg, ck = qwen_setup(g)
+    sess = sub("engine").QwenAsrSession.from_checkpoint(cfg, ck, precision=F32)
+    width, max_new = (int(v) for v in g["beam"])
+    cases = [c for _, c in golden_cases(g) if "beam_tokens" in c]
+    audios = [unit_audio(c["audio_seed"], c["n_samples"]) for c in cases]
+    pre, post = _prompts(g, cases)
+    sess.prefill(audios, pre, post)
+    got = sess.beam_search(width, max_new)
+    for b, c in enumerate(cases):
+        toks, scores = _beam_arrays(got[b], max_new)
+        assert np.array_equal(toks, c["beam_tokens"]), b
+        assert np.abs(scores - c["beam_scores"]).max() < 5 * TOL_F32, b
+    greedy = sess.generate(max_new)                                # the greedy state of the session is untouched by the search
+    for b, c in enumerate(cases):
+        assert np.array_equal(greedy[b], c["token_ids"][:max_new]), b
+    for b, c in enumerate(cases):                                  # stop ids differ per clip: one utterance per call
+        sess.prefill([audios[b]], [pre[b]], [post[b]])
+        toks, scores = _beam_arrays(sess.beam_search(width, max_new, c["beamstop_stop"].tolist())[0], max_new)
+        assert np.array_equal(toks, c["beamstop_tokens"]), b
+        assert np.abs(scores - c["beamstop_scores"]).max() < 5 * TOL_F32, b
+
+
+@pytest.mark.parametrize("prec", [F32, BF16])
+def test_beam_width_one_is_greedy_and_wider_beams_score_higher(prec):
+    """Size-independent properties on a batch of 6 ragged clips: width 1 == generate(); every width-5 list is sorted and holds distinct
+    hypotheses; an utterance's result does not depend on its batch neighbours."""
+    g = load_golden("qwen_asr_mid")
+    cfg, ck = qwen_setup(g)
+    sess = sub("engine").QwenAsrSession.from_checkpoint(cfg, ck, precision=prec)
+    lens = [128000, 30000, 64000, 9000, 100000, 48000]
+    audios = [unit_audio(5100 + i, n) for i, n in enumerate(lens)]
+    head, tail, suffix = g["head_ids"].tolist(), g["tail_ids"].tolist(), g["suffix_ids"].tolist()
+    pre, post = [head + suffix] * len(lens), [tail] * len(lens)
+    max_new = 8
+    sess.prefill(audios, pre, post)
+    greedy = sess.generate(max_new)
+    sess.prefill(audios, pre, post)
+    one = sess.beam_search(1, max_new)
+    for b in range(len(lens)):
+        assert np.array_equal(one[b][0][0], greedy[b]), b
+    sess.prefill(audios, pre, post)
+    five = sess.beam_search(5, max_new)
+    for b in range(len(lens)):
+        scores = [s for _, s in five[b]]
+        assert scores == sorted(scores, reverse=True), b
+        assert len({tuple(t.tolist()) for t, _ in five[b]}) == 5, b           # distinct hypotheses
+    if prec == F32:
+        sess.prefill(audios[2:4], pre[2:4], post[2:4])
+        pair = sess.beam_search(5, max_new)
+        for j, b in enumerate((2, 3)):
+            for (t1, s1), (t2, s2) in zip(pair[j], five[b]):
+                assert np.array_equal(t1, t2) and abs(s1 - s2) < 1e-3, b
+
+
+def test_beam_search_bad_arguments():
+    g = load_golden("qwen_asr_tiny")
+    cfg, ck = qwen_setup(g)
+    eng = sub("engine")
+    sess = eng.QwenAsrSession.from_checkpoint(cfg, ck, precision=F32)
+    with pytest.raises(Exception, match="prefill first"):
+        sess.beam_search(3, 4)
+    c = [c for _, c in golden_cases(g)][0]
+    pre, post = _prompts(g, [c])
+    sess.prefill([unit_audio(c["audio_seed"], c["n_samples"])], pre, post)
+    with pytest.raises(Exception, match="beam width"):
+        sess.beam_search(9, 4)
+    sess.set_penalty(0.8, 5)
+    with pytest.raises(Exception, match="do not combine"):
+        sess.beam_search(3, 4)

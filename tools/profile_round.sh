@@ -13,6 +13,8 @@ python bench.py --workload whisper --seconds 30 --steps 3 --warmup 2 --inflight 
 python bench.py --workload paraformer-streaming --steps 16 --warmup 8 > $OUT/bench_paraformer_streaming.json 2> $OUT/bench_paraformer_streaming.err
 python bench.py --workload qwen --steps 6 --warmup 2 --inflight 3 > $OUT/bench_qwen.json 2> $OUT/bench_qwen.err
 python bench.py --workload mixed --steps 6 --warmup 1 > $OUT/bench_mixed.json 2> $OUT/bench_mixed.err
+python bench.py --workload qwen --beam 5 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_qwen_beam5.json 2> $OUT/bench_qwen_beam5.err
+python bench.py --workload mixed --beam 5 --steps 6 --warmup 1 > $OUT/bench_mixed_beam5.json 2> $OUT/bench_mixed_beam5.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1

@@ -61,6 +61,17 @@ def hbm_traffic(kernel):
         return None
 
 
+def mfma_util(kernel):
+    """MFMA pipe utilisation of `kernel` from the committed SQ counter pass (profiles/r01_mfma_util.json, tools/summarize_sq_pmc.py)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_mfma_util.json")) as f:
+            rec = json.load(f)["kernels"].get(kernel)
+        return None if rec is None else {"mfma_busy_frac": rec["mfma_util"], "wave_cycles": {k: rec[k] for k in ("wait_any_share", "wait_inst_any_share",
+                                         "active_inst_share")}, "source": "profiles/r01_mfma_util.json"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, ck, audio_np, budget_s=15.0):
     """The oracle (torch CPU f32 restatement of the reference graph, batch 1 like the reference) timed on this
     host's cores on a bounded sample of the same workload. CHECKER ONLY -- never on the product path."""
@@ -253,7 +264,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_t144 (SANM out-proj / ffn1 / ffn2 launches, 144 x 128 tiles; the q|k|v projection "
                                                      "runs inside sanm_qkv_attn_kernel and is listed under kernels.sanm_fused)",
                          "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": hbm_traffic("gemm_bf16_t144"),
+                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": hbm_traffic("gemm_bf16_t144"), "pmc": mfma_util("gemm_bf16_t144"),
                          "launches_per_step": gemm_launches, "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),
                          "algorithmic_gflop_per_step": round(gemm_flops / 1e9, 1)},
             "kernels": kernels,

@@ -381,3 +381,35 @@ def test_beam_search_bad_arguments():
     sess.set_penalty(0.8, 5)
     with pytest.raises(Exception, match="do not combine"):
         sess.beam_search(3, 4)
+
+
+def test_beam_search_finished_utterance_stands_while_neighbours_continue():
+    """Two clips, one stop-id set: the clip whose best hypothesis ends early must keep its n-best list while the other clip's search goes
+    on (the device freezes a finished utterance), i.e. the batch result equals the two single-clip results; plus the edges max_new = 1
+    and the widest beam."""
+    g = load_golden("qwen_asr_tiny")
+    cfg, ck = qwen_setup(g)
+    sess = sub("engine").QwenAsrSession.from_checkpoint(cfg, ck, precision=F32)
+    cases = [c for _, c in golden_cases(g) if "beam_tokens" in c]
+    audios = [unit_audio(c["audio_seed"], c["n_samples"]) for c in cases]
+    pre, post = _prompts(g, cases)
+    stop = cases[0]["beamstop_stop"].tolist()                      # ends clip 0 after two ids; clip 1 meets it late or never
+    width, max_new = 3, 8
+    alone = []
+    for b in range(len(cases)):
+        sess.prefill([audios[b]], [pre[b]], [post[b]])
+        alone.append(sess.beam_search(width, max_new, stop)[0])
+    assert len({len(h[0][0]) for h in alone}) > 1                   # the clips do end at different steps
+    sess.prefill(audios, pre, post)
+    both = sess.beam_search(width, max_new, stop)
+    for b in range(len(cases)):
+        for (t1, s1), (t2, s2) in zip(both[b], alone[b]):
+            assert np.array_equal(t1, t2) and abs(s1 - s2) < 1e-4, b
+    sess.prefill(audios, pre, post)
+    one = sess.beam_search(width, 1)
+    for b, c in enumerate(cases):
+        assert [len(t) for t, _ in one[b]] == [1] * width and one[b][0][0][0] == c["token_ids"][0]
+    sess.prefill(audios, pre, post)
+    wide = sess.beam_search(8, 4)
+    for b in range(len(cases)):
+        assert len(wide[b]) == 8 and [s for _, s in wide[b]] == sorted((s for _, s in wide[b]), reverse=True)

@@ -19,7 +19,7 @@ CUS, SIMDS, XCDS = 256, 4, 8
 out = {"source": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS "
                  "SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline",
        "formulas": {"mfma_util": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs); kernels run serialised and ~10 % slower under counter collection", "wave shares": "X / SQ_WAVE_CYCLES",
-                    "lds_bank_conflict_share": "SQ_LDS_BANK_CONFLICT / SQ_BUSY_CYCLES (conflict cycles per busy SQ cycle; summed over SEs)"},
+                    "lds_bank_conflict_per_cu_cycle": "SQ_LDS_BANK_CONFLICT / (GPU cycles * 256 CUs): extra LDS cycles lost to bank conflicts per CU-cycle"},
        "kernels": {}}
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"]):
     n = len(seen[k])
@@ -29,7 +29,7 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"]):
     out["kernels"][k] = {"launches": n, "gpu_cycles_per_launch": round(gui / XCDS / n), "mfma_util": round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / XCDS * CUS * SIMDS), 4),
                          "wait_any_share": round(v["SQ_WAIT_ANY"] / wave, 3), "wait_inst_any_share": round(v["SQ_WAIT_INST_ANY"] / wave, 3),
                          "active_inst_share": round(v["SQ_ACTIVE_INST_ANY"] / wave, 3), "wait_inst_lds_share": round(v["SQ_WAIT_INST_LDS"] / wave, 3),
-                         "lds_bank_conflict_share": round(v["SQ_LDS_BANK_CONFLICT"] / max(v["SQ_BUSY_CYCLES"], 1.0), 4)}
+                         "lds_bank_conflict_per_cu_cycle": round(v["SQ_LDS_BANK_CONFLICT"] / (gui / XCDS * CUS), 4)}
 # the class the bench's roofline names: every 144-row-tile GEMM launch together
 t = collections.defaultdict(float); nl = 0
 for k, v in agg.items():
@@ -46,4 +46,4 @@ if nl:
 json.dump(out, open(out_path, "w"), indent=1)
 for k, v in list(out["kernels"].items())[:12]:
     print(f"{k[:60]:60s} n={v['launches']:5d} cyc={v['gpu_cycles_per_launch']:8d} mfma {v['mfma_util']:.3f} wait {v['wait_any_share']:.2f} istall {v['wait_inst_any_share']:.2f} "
-          f"active {v['active_inst_share']:.2f} lds-stall {v['wait_inst_lds_share']:.3f} bankconf {v['lds_bank_conflict_share']:.3f}")
+          f"active {v['active_inst_share']:.2f} lds-stall {v['wait_inst_lds_share']:.3f} bankconf {v['lds_bank_conflict_per_cu_cycle']:.3f}")

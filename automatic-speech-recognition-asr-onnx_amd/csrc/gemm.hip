@@ -610,6 +610,150 @@ __global__ __launch_bounds__(512, (STAGES == 2 ? 4 : 2)) void gemm_bf16_t144(con
   }
 }
 
+// ------------------------------------------------------------------------------------ bf16, 144 x 256 tile, 8 waves
+// The 144 x 128 tiles move (144 + 128) operand rows through the LDS-DMA path per 144 x 128 outputs = 68 flop / byte (ffn1 of the SANM
+// block: 285 MB of L2 -> LDS traffic per launch, ~8 TB/s chip-wide, MFMA pipe 19 % busy -- profiles/r01_mfma_util.json). 144 x 256 tiles
+// move (144 + 256) rows per twice the outputs = 92 flop / byte and read 13 LDS fragments per 36 MFMA instead of 11 per 18. Same wave
+// layout (2 K-halves x 4 column groups, now 64 columns each: 144 accumulator registers), three 50 KB stages, one workgroup per CU.
+// Used where N / 256 column tiles still fill the chip (ffn1: 64 windows x 8 = 512 tiles = two full rounds); LayerNorm-folded epilogue
+// with producer-side statistics only. Measured (SenseVoice B = 64): timed alone the launch is no faster (35.7 vs 34.3 us: one
+// workgroup per CU exposes the tile prologue / epilogue), back to back inside the step it is -- 8.99 vs 9.20 ms per step, A/B twice --
+// the quarter less L2 traffic is what the neighbouring launches gain. ASR_GEMM_T144W=0 turns it off.
+constexpr int TW = 256;
+constexpr int TW_STAGE = (TM + TW) * 128;
+constexpr int TW_NI = (TM + TW) / 8;                    // 50 LDS-DMA wave-instructions per stage: waves 0, 1 issue 7, the others 6
+constexpr int TW_RED = TM * TW * 4;
+constexpr int TW_STAGES = 3;
+
+template <int ACT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_t144w(const GemmArgs g0) {
+  GemmArgs g = g0;
+  if (g0.m_dev) g.M = min(g0.M, *g0.m_dev);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = wave >> 2, cg = wave & 3;
+  const int frow = lane & 15, fgrp = lane >> 4;
+  const int tiles_n = g.N / TW;
+  const int tile = g0.m_dev ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+  if (tile_m * TM >= g.M) return;
+  const int a_rows = (g0.M + 127) & ~127;
+
+  const int srow = lane >> 3;
+  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A);
+  const bf16_t* Wb = reinterpret_cast<const bf16_t*>(g.W);
+  const bf16_t* src[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int ii = min(wave + 8 * t, TW_NI - 1);
+    if (ii < T_AI) {
+      const int r = min(tile_m * TM + ii * 8 + srow, a_rows - 1);
+      src[t] = Ab + (size_t)r * g.lda + (((lane & 7) ^ srow) << 3);
+    } else {
+      const int wr = (ii - T_AI) * 8 + srow;
+      src[t] = Wb + (size_t)(tile_n * TW + wr) * g.ldw + (((lane & 7) ^ w_swz(wr)) << 3);
+    }
+  }
+  const bool seven = wave + 48 < TW_NI;
+  auto stage = [&](int slot, int k0) {
+    unsigned char* base = smem + slot * TW_STAGE + wave * 1024;
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + t * 8192), 16, 0, 0);
+    if (seven)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[6] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + 6 * 8192), 16, 0, 0);
+  };
+
+  f32x4_t acc[TMI][4];
+#pragma unroll
+  for (int i = 0; i < TMI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nk = g.K / BK16;
+#pragma unroll
+  for (int s = 0; s < TW_STAGES - 1; ++s)
+    if (s < nk) stage(s, s * BK16);
+
+  constexpr int T_MAIN = (TW_STAGES * TW_STAGE > TW_RED) ? TW_STAGES * TW_STAGE : TW_RED;
+  float2* st_fin = reinterpret_cast<float2*>(smem + T_MAIN);             // [144] (mean, rstd) from the producer's row statistics
+  if (tid < TM) {
+    const float2* sp = g.ln_stats_in + (size_t)min(tile_m * TM + tid, g.M - 1) * g.ln_slots;
+    const float2 ss = sum_row_partials(sp, g.ln_slots);
+    const float inv_d = 1.0f / (float)g.ln_dim;
+    const float mean = ss.x * inv_d;
+    const float var = fmaxf(ss.y * inv_d - mean * mean, 0.0f);
+    st_fin[tid] = make_float2(mean, rsqrtf(var + g.ln_eps));
+  }
+  const int c = kg * 4 + fgrp;
+  const int a_off = frow * 128 + ((c ^ (frow & 7)) << 4);
+  int w_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int r = cg * 64 + frag_col(j, frow); w_off[j] = TM * 128 + r * 128 + ((c ^ w_swz(r)) << 4); }
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = min(nk, kt + TW_STAGES - 1) - (kt + 1);
+    if (ahead >= 1) { if (seven) wait_vmcnt<7>(); else wait_vmcnt<6>(); }
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + TW_STAGES - 1 < nk) stage((kt + TW_STAGES - 1) % TW_STAGES, (kt + TW_STAGES - 1) * BK16);
+    const unsigned char* St = smem + (kt % TW_STAGES) * TW_STAGE;
+    bf16x8_t wf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(St + w_off[j]);
+    bf16x8_t af[TMI];
+#pragma unroll
+    for (int i = 0; i < TMI; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(St + a_off + i * 2048);
+#pragma unroll
+    for (int i = 0; i < TMI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+  }
+
+  // ---- sum the two K-halves: half 1 hands row fragments 0..4 to half 0, half 0 hands 5..8 to half 1
+  __syncthreads();                                        // ring dead
+  float4* red = reinterpret_cast<float4*>(smem);
+  constexpr int LO = 5, HI = TMI - LO;
+  if (kg == 1) {
+#pragma unroll
+    for (int i = 0; i < LO; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        red[((cg * LO + i) * 4 + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < HI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        red[4 * LO * 4 * 64 + ((cg * HI + i) * 4 + j) * 64 + lane] =
+            make_float4(acc[LO + i][j][0], acc[LO + i][j][1], acc[LO + i][j][2], acc[LO + i][j][3]);
+  }
+  __syncthreads();
+  const int n_wave = tile_n * TW + cg * 64;
+  if (kg == 0) {
+    f32x4_t fin[LO][4];
+#pragma unroll
+    for (int i = 0; i < LO; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 o = red[((cg * LO + i) * 4 + j) * 64 + lane];
+        fin[i][j] = f32x4_t{acc[i][j][0] + o.x, acc[i][j][1] + o.y, acc[i][j][2] + o.z, acc[i][j][3] + o.w};
+      }
+    epilogue_rows<bf16_t, ACT, EPI, 4, LO>(g, fin, tile_m * TM, n_wave, lane, st_fin);
+  } else {
+    f32x4_t fin[HI][4];
+#pragma unroll
+    for (int i = 0; i < HI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 o = red[4 * LO * 4 * 64 + ((cg * HI + i) * 4 + j) * 64 + lane];
+        fin[i][j] = f32x4_t{o.x + acc[LO + i][j][0], o.y + acc[LO + i][j][1], o.z + acc[LO + i][j][2], o.w + acc[LO + i][j][3]};
+      }
+    epilogue_rows<bf16_t, ACT, EPI, 4, HI>(g, fin, tile_m * TM + LO * 16, n_wave, lane, st_fin + LO * 16);
+  }
+}
+
 // ------------------------------------------------------------------------------------ bf16, skinny M (decode)
 // out[M <= 64][N] = A[M][K] W[N][K]^T: pure weight streaming. One workgroup = 16 output columns x all rows; its 8 waves
 // split K eight ways, each streaming its slice of the 16 weight rows straight from HBM into MFMA A-fragments
@@ -1159,6 +1303,26 @@ bool launch_t144(const GemmArgs& g, hipStream_t s) {
   return false;
 }
 
+// 144 x 256 tiles: the LayerNorm-folded FFN-1 instance, when the wide tiles still give every CU two full rounds' worth of work
+bool launch_t144w(const GemmArgs& g, hipStream_t s) {
+  static const bool on = !(getenv("ASR_GEMM_T144W") && getenv("ASR_GEMM_T144W")[0] == '0');
+  if (!on || !g.ln_colsum || !g.ln_stats_in || g.st_out || g.N % TW || g.act != ACT_RELU) return false;
+  const int epi = (g.add ? E_ADD : 0) | (g.add2 ? E_ADD2 : 0) | (g.out_f32 ? E_F32 : 0) | (g.out_lo ? E_LO : 0) | (g.bias ? E_BIAS : 0) | E_LN;
+  if (epi != (E_BIAS | E_LO | E_LN)) return false;
+  const int tiles = ((g.M + TM - 1) / TM) * (g.N / TW);
+  if (tiles < 448 || tiles % 256 > 0 && tiles % 256 < 192) return false;     // whole rounds of one workgroup per CU (or nearly)
+  constexpr int lds = (TW_STAGES * TW_STAGE > TW_RED ? TW_STAGES * TW_STAGE : TW_RED) + TM * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_t144w<ACT_RELU, E_BIAS | E_LO | E_LN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_t144w<ACT_RELU, E_BIAS | E_LO | E_LN>), dim3(tiles), dim3(512), lds, s, g);
+  HIP_CHECK(hipGetLastError());
+  return true;
+}
+
 // 144-row tiles: usable when the epilogue is one the kernel implements and the row count is close to a multiple of 144
 bool t144_geom_ok(const GemmArgs& g) {
   if (g.out_t || g.amax_val || g.lo_group || g.add2_rows || g.N % TN || g.K % BK16 || g.M < 128) return false;
@@ -1219,6 +1383,7 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
     int st = 0;
     if (g.ln_colsum) {
       ASR_REQUIRE(gemm_ln_fusable(g), "gemm: the fused LayerNorm needs the 144-row-tile kernel (check gemm_ln_fusable first)");
+      if (launch_t144w(g, s)) return;
       ASR_REQUIRE(t144_stages(g) == 4 ? launch_t144<4>(g, s) : launch_t144<2>(g, s), "gemm: no LayerNorm-fused instance for this epilogue");
       return;
     }

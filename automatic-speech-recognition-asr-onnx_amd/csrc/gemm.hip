@@ -754,6 +754,105 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t144w(const GemmArgs g0) {
   }
 }
 
+// ------------------------------------------------------------------------------------ bf16, 288 x 256 tile, 8 waves
+// Two 8 s windows x 256 columns per workgroup: (288 + 256) operand rows per 288 x 256 outputs = 135 flop / byte through the LDS-DMA
+// path (the 144 x 256 tile: 92). 8 waves = 2 row groups (one window each) x 4 column groups of 64: every wave owns 9 x 4 C fragments
+// (144 accumulator registers) over the WHOLE K-step, so no cross-wave reduction; two 68 KB stages, one workgroup per CU. For the
+// LayerNorm-folded FFN-1 when ceil(M / 288) x N / 256 is one round of <= 256 workgroups (B = 64: 32 x 8 = 256).
+constexpr int TM2 = 288, TM2I = 9;
+constexpr int T2_STAGE = (TM2 + TW) * 128;
+constexpr int T2_AI = TM2 / 8, T2_NI = (TM2 + TW) / 8;   // 36 A pieces of 68 LDS-DMA wave-instructions per stage: waves 0..3 issue 9, 4..7 issue 8
+
+template <int ACT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_t288w(const GemmArgs g0) {
+  GemmArgs g = g0;
+  if (g0.m_dev) g.M = min(g0.M, *g0.m_dev);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave >> 2, cg = wave & 3;
+  const int frow = lane & 15, fgrp = lane >> 4;
+  const int tiles_n = g.N / TW;
+  const int tile = g0.m_dev ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+  if (tile_m * TM2 >= g.M) return;
+  const int a_rows = (g0.M + 127) & ~127;
+
+  const int srow = lane >> 3;
+  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A);
+  const bf16_t* Wb = reinterpret_cast<const bf16_t*>(g.W);
+  const bf16_t* src[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int ii = min(wave + 8 * t, T2_NI - 1);
+    if (ii < T2_AI) {
+      const int r = min(tile_m * TM2 + ii * 8 + srow, a_rows - 1);
+      src[t] = Ab + (size_t)r * g.lda + (((lane & 7) ^ srow) << 3);
+    } else {
+      const int wr = (ii - T2_AI) * 8 + srow;
+      src[t] = Wb + (size_t)(tile_n * TW + wr) * g.ldw + (((lane & 7) ^ w_swz(wr)) << 3);
+    }
+  }
+  const bool nine = wave + 64 < T2_NI;
+  auto stage = [&](int slot, int k0) {
+    unsigned char* base = smem + slot * T2_STAGE + wave * 1024;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + t * 8192), 16, 0, 0);
+    if (nine)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[8] + k0),
+                                       (__attribute__((address_space(3))) void*)(base + 8 * 8192), 16, 0, 0);
+  };
+
+  f32x4_t acc[TM2I][4];
+#pragma unroll
+  for (int i = 0; i < TM2I; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nk = g.K / BK16;
+  stage(0, 0);
+
+  float2* st_fin = reinterpret_cast<float2*>(smem + 2 * T2_STAGE);       // [288] (mean, rstd) from the producer's row statistics
+  if (tid < TM2) {
+    const float2* sp = g.ln_stats_in + (size_t)min(tile_m * TM2 + tid, g.M - 1) * g.ln_slots;
+    const float2 ss = sum_row_partials(sp, g.ln_slots);
+    const float inv_d = 1.0f / (float)g.ln_dim;
+    const float mean = ss.x * inv_d;
+    const float var = fmaxf(ss.y * inv_d - mean * mean, 0.0f);
+    st_fin[tid] = make_float2(mean, rsqrtf(var + g.ln_eps));
+  }
+  int a_off[2], w_off[2][4];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int c = kk * 4 + fgrp;                          // 16-byte K-chunk of this lane inside the 128-byte stage row
+    a_off[kk] = (rg * 144 + frow) * 128 + ((c ^ (frow & 7)) << 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int r = cg * 64 + frag_col(j, frow); w_off[kk][j] = TM2 * 128 + r * 128 + ((c ^ w_swz(r)) << 4); }
+  }
+
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK16);
+    const unsigned char* St = smem + (kt & 1) * T2_STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t wf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(St + w_off[kk][j]);
+      bf16x8_t af[TM2I];
+#pragma unroll
+      for (int i = 0; i < TM2I; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(St + a_off[kk] + i * 2048);
+#pragma unroll
+      for (int i = 0; i < TM2I; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();                                        // st_fin visible (written before the loop; the loop's barriers already order it)
+  epilogue_rows<bf16_t, ACT, EPI, 4, TM2I>(g, acc, tile_m * TM2 + rg * 144, tile_n * TW + cg * 64, lane, st_fin + rg * 144);
+}
+
 // ------------------------------------------------------------------------------------ bf16, skinny M (decode)
 // out[M <= 64][N] = A[M][K] W[N][K]^T: pure weight streaming. One workgroup = 16 output columns x all rows; its 8 waves
 // split K eight ways, each streaming its slice of the 16 weight rows straight from HBM into MFMA A-fragments
@@ -1323,6 +1422,26 @@ bool launch_t144w(const GemmArgs& g, hipStream_t s) {
   return true;
 }
 
+// 288 x 256 tiles: the same instance when pairs of windows x 256 columns make exactly one round
+bool launch_t288w(const GemmArgs& g, hipStream_t s) {
+  static const bool on = !(getenv("ASR_GEMM_T288W") && getenv("ASR_GEMM_T288W")[0] == '0');
+  if (!on || !g.ln_colsum || !g.ln_stats_in || g.st_out || g.N % TW || g.act != ACT_RELU) return false;
+  const int epi = (g.add ? E_ADD : 0) | (g.add2 ? E_ADD2 : 0) | (g.out_f32 ? E_F32 : 0) | (g.out_lo ? E_LO : 0) | (g.bias ? E_BIAS : 0) | E_LN;
+  if (epi != (E_BIAS | E_LO | E_LN)) return false;
+  const int tiles = ((g.M + TM2 - 1) / TM2) * (g.N / TW);
+  if (tiles < 200 || tiles > 256) return false;
+  constexpr int lds = 2 * T2_STAGE + TM2 * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_t288w<ACT_RELU, E_BIAS | E_LO | E_LN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_t288w<ACT_RELU, E_BIAS | E_LO | E_LN>), dim3(tiles), dim3(512), lds, s, g);
+  HIP_CHECK(hipGetLastError());
+  return true;
+}
+
 // 144-row tiles: usable when the epilogue is one the kernel implements and the row count is close to a multiple of 144
 bool t144_geom_ok(const GemmArgs& g) {
   if (g.out_t || g.amax_val || g.lo_group || g.add2_rows || g.N % TN || g.K % BK16 || g.M < 128) return false;
@@ -1383,6 +1502,7 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
     int st = 0;
     if (g.ln_colsum) {
       ASR_REQUIRE(gemm_ln_fusable(g), "gemm: the fused LayerNorm needs the 144-row-tile kernel (check gemm_ln_fusable first)");
+      if (launch_t288w(g, s)) return;
       if (launch_t144w(g, s)) return;
       ASR_REQUIRE(t144_stages(g) == 4 ? launch_t144<4>(g, s) : launch_t144<2>(g, s), "gemm: no LayerNorm-fused instance for this epilogue");
       return;

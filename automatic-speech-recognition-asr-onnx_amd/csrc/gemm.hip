@@ -813,13 +813,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t288w(const GemmArgs g0) {
   stage(0, 0);
 
   float2* st_fin = reinterpret_cast<float2*>(smem + 2 * T2_STAGE);       // [288] (mean, rstd) from the producer's row statistics
-  if (tid < TM2) {
-    const float2* sp = g.ln_stats_in + (size_t)min(tile_m * TM2 + tid, g.M - 1) * g.ln_slots;
-    const float2 ss = sum_row_partials(sp, g.ln_slots);
-    const float inv_d = 1.0f / (float)g.ln_dim;
-    const float mean = ss.x * inv_d;
-    const float var = fmaxf(ss.y * inv_d - mean * mean, 0.0f);
-    st_fin[tid] = make_float2(mean, rsqrtf(var + g.ln_eps));
+  if constexpr ((EPI & E_LN) != 0) {
+    if (tid < TM2) {
+      const float2* sp = g.ln_stats_in + (size_t)min(tile_m * TM2 + tid, g.M - 1) * g.ln_slots;
+      const float2 ss = sum_row_partials(sp, g.ln_slots);
+      const float inv_d = 1.0f / (float)g.ln_dim;
+      const float mean = ss.x * inv_d;
+      const float var = fmaxf(ss.y * inv_d - mean * mean, 0.0f);
+      st_fin[tid] = make_float2(mean, rsqrtf(var + g.ln_eps));
+    }
   }
   int a_off[2], w_off[2][4];
 #pragma unroll
@@ -1442,6 +1444,26 @@ bool launch_t288w(const GemmArgs& g, hipStream_t s) {
   return true;
 }
 
+// ... and for the vocabulary head with the arg-max epilogue (CTC / decoder vocab GEMM over a whole batch: thousands of tiles)
+bool launch_t288w_amax(const GemmArgs& g, hipStream_t s) {
+  static const bool on = !(getenv("ASR_GEMM_T288W") && getenv("ASR_GEMM_T288W")[0] == '0');
+  if (!on || !g.amax_val || !g.bias || g.out_f32 || g.out_lo || g.out_t || g.add || g.add2 || g.ln_colsum || g.st_out || g.lo_group || g.act != ACT_NONE ||
+      g.N % TW || g.K % BK16 || g.M < 8 * TM2)
+    return false;
+  const int tiles = ((g.M + TM2 - 1) / TM2) * (g.N / TW);
+  if (tiles < 1024) return false;
+  constexpr int lds = 2 * T2_STAGE + TM2 * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_t288w<ACT_NONE, E_BIAS | E_AMAX>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_t288w<ACT_NONE, E_BIAS | E_AMAX>), dim3(tiles), dim3(512), lds, s, g);
+  HIP_CHECK(hipGetLastError());
+  return true;
+}
+
 // 144-row tiles: usable when the epilogue is one the kernel implements and the row count is close to a multiple of 144
 bool t144_geom_ok(const GemmArgs& g) {
   if (g.out_t || g.amax_val || g.lo_group || g.add2_rows || g.N % TN || g.K % BK16 || g.M < 128) return false;
@@ -1507,6 +1529,7 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
       ASR_REQUIRE(t144_stages(g) == 4 ? launch_t144<4>(g, s) : launch_t144<2>(g, s), "gemm: no LayerNorm-fused instance for this epilogue");
       return;
     }
+    if (launch_t288w_amax(g, s)) return;
     if (big_fits(g) && launch_big(g, s)) return;
     if (t144_enabled() && t144_fits(g, &st) && (st == 4 ? launch_t144<4>(g, s) : launch_t144<2>(g, s))) return;
     if (const int sp = tiled_splits(g); sp > 1) {

@@ -4,6 +4,7 @@ set -x
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof
+rm -rf $OUT
 mkdir -p $OUT
 cd $R
 python bench.py --steps 20 > $OUT/bench_sensevoice.json 2> $OUT/bench_sensevoice.err
@@ -16,7 +17,7 @@ python bench.py --workload mixed --steps 6 --warmup 1 > $OUT/bench_mixed.json 2>
 python bench.py --workload qwen --beam 5 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_qwen_beam5.json 2> $OUT/bench_qwen_beam5.err
 python bench.py --workload mixed --beam 5 --steps 6 --warmup 1 > $OUT/bench_mixed_beam5.json 2> $OUT/bench_mixed_beam5.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --profile-steps 1 > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1

@@ -1,15 +1,15 @@
 """Fold the two rocprofv3 PMC passes of tools/profile_round.sh (FETCH_SIZE, WRITE_SIZE; kilobytes per dispatch) into
 profiles/r01_hbm_traffic.json: memory-side bytes per launch and per kernel class. FETCH_SIZE is doubled -- on gfx950 it tallies
 128-byte requests at 64 bytes (MI355X_MICROARCH.md, HBM section); WRITE_SIZE matched the algorithmic store volume as is."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
 agg = collections.defaultdict(lambda: {"launches": 0, "fetch_kb_raw": 0.0, "write_kb": 0.0})
 for kind, key in (("fetch", "fetch_kb_raw"), ("write", "write_kb")):
-    f = glob.glob(f"{src}/pmc_{kind}/*/*_counter_collection.csv")[0]
+    f = sorted(glob.glob(f"{src}/pmc_{kind}/*/*_counter_collection.csv"), key=os.path.getmtime)[-1]
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        cls = "gemm_bf16_t144" if "gemm_bf16_t144" in name else "sanm_qkv_attn_kernel" if "sanm_qkv_attn" in name else name.split("(")[0].split("::")[-1][:48]
+        cls = "gemm_bf16_t144" if ("gemm_bf16_t144" in name or "gemm_bf16_t288w" in name) else "sanm_qkv_attn_kernel" if "sanm_qkv_attn" in name else name.split("(")[0].split("::")[-1][:48]
         for k in (cls, name[:96]):
             agg[k][key] += float(r["Counter_Value"])
             if kind == "fetch":

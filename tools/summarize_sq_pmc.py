@@ -3,11 +3,11 @@ SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_G
 kernel class the MFMA pipe utilisation (gfx94x MfmaUtil formula, MFMA busy cycles / (GPU cycles x 256 CUs x 4 SIMDs); GRBM_GUI_ACTIVE comes
 summed over the 8 XCDs, so GPU cycles = GRBM_GUI_ACTIVE / 8) and where the
 wave cycles went (WAIT_ANY = parked on s_waitcnt / barrier, WAIT_INST_ANY = issue stalls, ACTIVE_INST_ANY = issuing; quad-cycles)."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof/pmc_sq"
 out_path = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_mfma_util.json"
-f = glob.glob(f"{src}/*/*_counter_collection.csv")[0]
+f = sorted(glob.glob(f"{src}/*/*_counter_collection.csv"), key=os.path.getmtime)[-1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 seen = collections.defaultdict(set)
 for r in csv.DictReader(open(f)):
@@ -33,7 +33,7 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"]):
 # the class the bench's roofline names: every 144-row-tile GEMM launch together
 t = collections.defaultdict(float); nl = 0
 for k, v in agg.items():
-    if k.startswith("gemm_bf16_t144"):
+    if k.startswith("gemm_bf16_t144") or k.startswith("gemm_bf16_t288w"):
         nl += len(seen[k])
         for c, x in v.items():
             t[c] += x

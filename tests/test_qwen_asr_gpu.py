@@ -151,6 +151,30 @@ def test_transcriber_matches_reference_goldens():
             assert toks[b].tolist() == want[:cut], b
 
 
+def test_transcriber_beam_mode_returns_the_best_hypothesis():
+    """QwenAsrTranscriber(beam_size = 3): the host mirror's beam mode hands back the first entry of the device's n-best list, cut at the
+    generation limit; it refuses to combine with the repeat penalty."""
+    g = load_golden("qwen_asr_tiny")
+    cfg, ck = qwen_setup(g)
+    sess = sub("engine").QwenAsrSession.from_checkpoint(cfg, ck, precision=F32)
+    special = {"stop": [1, 521], "asr_text": [540], "audio_start": 524, "audio_end": 520, "audio_pad": 525, "im_start": 510, "im_end": 521,
+               "system": 511, "user": 523, "assistant": 522, "newline": 512, "language_prefix": [530, 531]}
+    meta = {"audio_pcm_scale": "32768", "max_seq_len": str(cfg.max_seq_len), "sample_rate": "16000", "special_token_ids": special,
+            "supported_languages": {"en": {"name": "English", "aliases": [], "prompt_token_ids": [77, 540]}}}
+    q = sub("qwen_asr")
+    width, max_new = (int(v) for v in g["beam"])
+    tr = q.QwenAsrTranscriber(cfg, sess, meta, beam_size=width)
+    cases = [c for _, c in golden_cases(g) if "beam_tokens" in c and len(c["language_tail_ids"]) == 0 and len(c["query_ids"]) == 0]
+    assert cases
+    clips = [np.round(unit_audio(c["audio_seed"], c["n_samples"]) * 32768.0).astype(np.int16) for c in cases]
+    out, _ = tr.transcribe(clips, max_new=max_new)
+    for b, c in enumerate(cases):          # int16 round trip of the clip: compare where the golden ranking gaps allow it
+        if float(c["beam_margin"]) > 0.01:
+            assert out[b]["tokens"].tolist() == c["beam_tokens"][0][:int(c["beam_lens"][0])].tolist(), b
+    with pytest.raises(ValueError, match="REPEAT_PENALTY"):
+        q.QwenAsrTranscriber(cfg, sess, meta, beam_size=width, repeat_penalty=0.8)
+
+
 @pytest.mark.parametrize("fixture", ["qwen_asr_tiny", "qwen_asr_mid"])
 def test_penalty_and_sampling_heads_match_reference_goldens(fixture):
     """f32 mode: penalty-greedy (window = save_id[-range:] of what exists, decode steps only) and top-k / top-p sampling with the

@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step (default 64; whisper: 32 = BASELINE.json configs[2])")
     ap.add_argument("--seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="sensevoice: skip the PCIe-inclusive and batches-in-flight legs (rocprofv3 --stats runs: their overlapped launches would skew per-kernel averages)")
@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--beam", type=int, default=1, help="qwen / mixed: beam width (1 = greedy; BASELINE.json configs[4] names beam 5)")
     ap.add_argument("--decode-tokens", type=int, default=0, help="whisper: generated tokens per utterance (default 4 per audio second)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 32 if args.workload == "whisper" else 64
     if args.workload == "whisper":
         return main_whisper(args)
     if args.workload == "paraformer":
@@ -552,7 +554,7 @@ def main_whisper(args):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     cfg = cfgm.whisper_large_v3()
-    B = args.batch if args.batch != 64 else 32
+    B = args.batch
     n_samples = int(args.seconds * cfg.sample_rate)
     n_tok = args.decode_tokens or int(round(4 * args.seconds))
     blob = ck = None

@@ -758,7 +758,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t144w(const GemmArgs g0) {
 // Two 8 s windows x 256 columns per workgroup: (288 + 256) operand rows per 288 x 256 outputs = 135 flop / byte through the LDS-DMA
 // path (the 144 x 256 tile: 92). 8 waves = 2 row groups (one window each) x 4 column groups of 64: every wave owns 9 x 4 C fragments
 // (144 accumulator registers) over the WHOLE K-step, so no cross-wave reduction; two 68 KB stages, one workgroup per CU. For the
-// LayerNorm-folded FFN-1 when ceil(M / 288) x N / 256 is one round of <= 256 workgroups (B = 64: 32 x 8 = 256).
+// LayerNorm-folded FFN-1 when ceil(M / 288) x N / 256 makes whole rounds of 256 workgroups (B = 64: 32 x 8 = 256).
 constexpr int TM2 = 288, TM2I = 9;
 constexpr int T2_STAGE = (TM2 + TW) * 128;
 constexpr int T2_AI = TM2 / 8, T2_NI = (TM2 + TW) / 8;   // 36 A pieces of 68 LDS-DMA wave-instructions per stage: waves 0..3 issue 9, 4..7 issue 8
@@ -1424,14 +1424,14 @@ bool launch_t144w(const GemmArgs& g, hipStream_t s) {
   return true;
 }
 
-// 288 x 256 tiles: the same instance when pairs of windows x 256 columns make exactly one round
+// 288 x 256 tiles: the same instance when pairs of windows x 256 columns make whole rounds
 bool launch_t288w(const GemmArgs& g, hipStream_t s) {
   static const bool on = !(getenv("ASR_GEMM_T288W") && getenv("ASR_GEMM_T288W")[0] == '0');
   if (!on || !g.ln_colsum || !g.ln_stats_in || g.st_out || g.N % TW || g.act != ACT_RELU) return false;
   const int epi = (g.add ? E_ADD : 0) | (g.add2 ? E_ADD2 : 0) | (g.out_f32 ? E_F32 : 0) | (g.out_lo ? E_LO : 0) | (g.bias ? E_BIAS : 0) | E_LN;
   if (epi != (E_BIAS | E_LO | E_LN)) return false;
   const int tiles = ((g.M + TM2 - 1) / TM2) * (g.N / TW);
-  if (tiles < 200 || tiles > 256) return false;
+  if (tiles < 200 || (tiles % 256 != 0 && tiles % 256 < 200)) return false;      // whole rounds of one workgroup per CU (or nearly)
   constexpr int lds = 2 * T2_STAGE + TM2 * 8;
   static bool attr_set = false;
   if (!attr_set) {

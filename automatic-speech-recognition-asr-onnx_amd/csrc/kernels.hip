@@ -1123,7 +1123,7 @@ void attention_geometry(int max_T, int head_dim, int* qt, int* nw) {
   // accumulator set still lets two workgroups share a CU: with 64-wide heads 3 or 4 tiles per wave cost 190-256 VGPRs (spills at 4), one
   // workgroup per CU and every chunk's DMA round trip exposed. Whisper-large-v3 encoder attention per step, 4 -> 2 tiles per wave:
   // 42.5 -> 23.2 ms (B = 32 x 30 s), 4.75 -> 2.80 ms (B = 32 x 8 s); a second chunk buffer instead bought nothing (still one workgroup).
-  const int qt_max = head_dim == 128 ? 3 : 2;
+  const int qt_max = 2;                       // (128-wide heads: 3 tiles per wave spill 15 registers)
   const int n_tiles = (max_T + 15) / 16;
   int q = 1;
   while (q < qt_max && (n_tiles + q - 1) / q > 8) ++q;

@@ -1543,6 +1543,10 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
       return;
     }
     v = tall ? 2 : 4;
+    // token-compacted rows (device-side M far below the launch bound): a handful of live workgroups, each alone on its CU, walking a
+    // long K -- a third ring stage covers the DMA round trip the missing co-resident workgroup would have covered
+    static const bool deep = !(getenv("ASR_GEMM_DEEP") && getenv("ASR_GEMM_DEEP")[0] == '0');
+    if (deep && g.m_dev && g.K >= 1024 && !tall && !g.amax_val) v = 3;
   }
   if (v == 7) {
     ASR_REQUIRE(g.N % BIG == 0 && launch_big(g, s), "gemm: variant 7 (256 x 256 tiles) has no instance for this shape / epilogue");

@@ -1536,7 +1536,8 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
       GemmArgs p = g;                                    // pass 1: raw f32 partials, no epilogue terms
       p.bias = nullptr; p.add = nullptr; p.add2 = nullptr; p.act = ACT_NONE; p.out_lo = nullptr;
       p.out_f32 = g.sk_ws; p.ld_out_f32 = g.N; p.k_splits = sp; p.st_out = nullptr;
-      launch_pipe<64, 2>(p, s);
+      static const bool deep_sk = !(getenv("ASR_GEMM_DEEP") && getenv("ASR_GEMM_DEEP")[0] == '0');
+      if (deep_sk && g.K / sp >= 256) launch_pipe<64, 3>(p, s); else launch_pipe<64, 2>(p, s);   // lone workgroups per CU: a third stage covers the DMA latency
       const size_t n = (size_t)g.M * (g.N / 4);
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, (const float*)g.sk_ws, sp);
       HIP_CHECK(hipGetLastError());

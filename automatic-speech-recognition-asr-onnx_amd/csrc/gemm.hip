@@ -1548,6 +1548,7 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
     // long K -- a third ring stage covers the DMA round trip the missing co-resident workgroup would have covered
     static const bool deep = !(getenv("ASR_GEMM_DEEP") && getenv("ASR_GEMM_DEEP")[0] == '0');
     if (deep && g.m_dev && g.K >= 1024 && !tall && !g.amax_val) v = 3;
+    if (deep && !tall && !g.amax_val && ((g.M + BM - 1) / BM) * (g.N / 64) <= 256 && g.K >= 256) v = 3;   // one round, at most one workgroup per CU
   }
   if (v == 7) {
     ASR_REQUIRE(g.N % BIG == 0 && launch_big(g, s), "gemm: variant 7 (256 x 256 tiles) has no instance for this shape / epilogue");

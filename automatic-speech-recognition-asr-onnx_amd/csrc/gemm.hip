@@ -1501,7 +1501,8 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
   if (g.ln_x) ASR_REQUIRE(g.M <= 32 && !g.A, "gemm: the fused LayerNorm prologue exists on the skinny path for M <= 32 only");
   // 33..64 rows against a vocabulary-sized N: the 128 x 128 tiles re-read the activations 8 x less often than 16-column granules do
   // (lm_head 64 x 151936 x 1024: 76 us vs 240 us)
-  const bool tall = g.M > 32 && g.N >= 16384 && !g.ln_x && g.a_rms_eps == 0.0f && g.act != ACT_SWIGLU;
+  static const int tall_min = getenv("ASR_GEMM_TALL_MIN") ? atoi(getenv("ASR_GEMM_TALL_MIN")) : 16;
+  const bool tall = g.M > tall_min && g.N >= 16384 && !g.ln_x && g.a_rms_eps == 0.0f && g.act != ACT_SWIGLU;
   if (g.M <= 64 && !tall && !g.out_t && !g.amax_val && g.lo_group == 0 && g.K % (32 * SK_WAVES) == 0 && g_gemm_variant < 0) {
     ASR_REQUIRE((g.A || g.ln_x) && g.W && g.N % 16 == 0, "gemm(skinny): bad operands");
     ASR_REQUIRE(g.ln_x || (g.lda * 2) % 16 == 0, "gemm(skinny): lda must be a 16-byte multiple");

@@ -1,0 +1,35 @@
+"""CPU: the evidence bench.py folds into its JSON line parses -- the committed rocprofv3 summaries under profiles/ (HBM traffic and SQ
+counter passes, kernel-trace stats) -- and the committed bench lines keep the contract's keys."""
+import glob
+import json
+import os
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_counter_summaries_feed_the_roofline():
+    t = bench.hbm_traffic("gemm_bf16_t144")
+    assert t and t["bytes_per_launch"] > 1e6 and t["source"].startswith("profiles/")
+    m = bench.mfma_util("gemm_bf16_t144")
+    assert m and 0.0 < m["mfma_busy_frac"] < 1.0
+    shares = m["wave_cycles"]
+    assert 0.9 < shares["wait_any_share"] + shares["wait_inst_any_share"] + shares["active_inst_share"] < 1.1   # disjoint buckets of the wave cycles
+    r = bench.rocprof_avg_us(("gemm_bf16_t144<", "gemm_bf16_t288w<1,"))
+    assert r and 5.0 < r["avg_launch_us"] < 200.0 and r["launches"] > 100
+
+
+def test_committed_bench_lines_keep_the_contract():
+    need = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "config", "roofline"}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_bench_*_n1.json"))) + [os.path.join(ROOT, "profiles", "r01_bench_n1.json")]
+    assert len(files) >= 8
+    for f in files:
+        d = json.load(open(f))
+        assert need <= set(d), (f, need - set(d))
+        assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"], f
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"]), f
+    head = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_n1.json")))
+    assert head["cpu_baseline"]["kind"] == "port" and head["cpu_baseline"]["cores"] >= 1 and head["cpu_baseline"]["sample"]
+    assert head["roofline"]["bound"] == "mfma" and abs(head["roofline"]["frac"] - head["roofline"]["achieved"] / head["roofline"]["peak"]) < 1e-3

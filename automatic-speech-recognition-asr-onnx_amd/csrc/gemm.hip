@@ -1503,7 +1503,9 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
   // (lm_head 64 x 151936 x 1024: 76 us vs 240 us)
   static const int tall_min = getenv("ASR_GEMM_TALL_MIN") ? atoi(getenv("ASR_GEMM_TALL_MIN")) : 16;
   const bool tall = g.M > tall_min && g.N >= 16384 && !g.ln_x && g.a_rms_eps == 0.0f && g.act != ACT_SWIGLU;
-  if (g.M <= 64 && !tall && !g.out_t && !g.amax_val && g.lo_group == 0 && g.K % (32 * SK_WAVES) == 0 && g_gemm_variant < 0) {
+  static const int skinny_max_plain = getenv("ASR_SKINNY_MAX_M") ? atoi(getenv("ASR_SKINNY_MAX_M")) : 32;   // rows up to which PLAIN GEMMs (no prologue) stream weights; above, the tiled split-K pass shares the activation rows across 64 columns (Whisper B = 64: 4.62 -> 3.89 ms per token)
+  const bool needs_skinny = g.ln_x || g.a_rms_eps != 0.0f || !g.sk_ws;
+  if (g.M <= 64 && (needs_skinny || g.M <= skinny_max_plain) && !tall && !g.out_t && !g.amax_val && g.lo_group == 0 && g.K % (32 * SK_WAVES) == 0 && g_gemm_variant < 0) {
     ASR_REQUIRE((g.A || g.ln_x) && g.W && g.N % 16 == 0, "gemm(skinny): bad operands");
     ASR_REQUIRE(g.ln_x || (g.lda * 2) % 16 == 0, "gemm(skinny): lda must be a 16-byte multiple");
     if (g.ln_x) ASR_REQUIRE(g.K % 4 == 0 && g.K <= 1280 && g.ld_ln_x % 4 == 0, "gemm(skinny): fused LayerNorm needs K <= 1280, float4-aligned rows");

@@ -101,9 +101,6 @@ SIGNATURES = {
     "asr_op_attention": (_i, [_i, _fp, _fp, _fp, _ip, _i, _i, _i, _fp]),
     "asr_op_fsmn": (_i, [_i, _fp, _fp, _fp, _ip, _i, _i, _i, _fp]),
     "asr_op_gemm_ln": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp]),
-    "asr_op_gemm_bench": (_i, [_i, _i, _i, _i, _i, _i, _fp]),
-    "asr_debug_grid_barrier": (_i, [_i, _i, _fp]),
-    "asr_debug_grid_barrier2": (_i, [_i, _i, _i, _fp]),
     "asr_op_ctc_collapse": (_i, [_ip, _ip, _i, _i, _ip, _i, _ip]),
 }
 
@@ -125,7 +122,7 @@ def load():
     if not os.path.isfile(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(the engine has no CPU fallback)")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError here == missing export
         fn.restype = res

@@ -1,0 +1,95 @@
+"""ctypes binding of libasr_mi355x_probe.so (include/asr_mi355x_probe.h): test / tuning hooks, NOT the product ABI.
+
+Used by tests/ and tools/ only; the transcribers, the onnxruntime shim and bench.py's timed path never import this."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+PROBE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libasr_mi355x_probe.so")
+_fp, _ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("a", _fp), ("w", _fp), ("bias", _fp), ("add", _fp),
+                ("act", C.c_int32), ("ln", C.c_int32), ("ln_eps", C.c_float), ("argmax", C.c_int32), ("n_valid", C.c_int32),
+                ("variant", C.c_int32), ("out_lo", _fp), ("out_f32", _fp), ("out_stats", _fp), ("out_ids", _ip),
+                ("kernel", C.c_char * 32)]
+
+
+SIGNATURES = {
+    "asr_probe_gemm": (C.c_int, [C.POINTER(GemmDesc)]),
+    "asr_probe_gemm_counts": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "asr_probe_gemm_bench": (C.c_int, [C.c_int] * 6 + [_fp]),
+    "asr_probe_grid_barrier": (C.c_int, [C.c_int, C.c_int, _fp]),
+    "asr_probe_grid_barrier2": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp]),
+}
+_plib = None
+
+
+def load():
+    global _plib
+    if _plib is None:
+        _lib.load()                       # the probe library resolves the product library's launchers
+        if not os.path.isfile(PROBE_PATH):
+            raise ImportError(f"{PROBE_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(PROBE_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _plib = lib
+    return _plib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def gemm(a, w, bias=None, add=None, act=0, ln=False, ln_eps=1e-5, argmax=False, n_valid=0, variant=-1, want=("lo",)):
+    """One bf16 GEMM through the product dispatcher; returns (dict of outputs, kernel family name)."""
+    a, w = _f32(a), _f32(w)
+    M, K = a.shape
+    N = w.shape[0]
+    d = GemmDesc()
+    d.M, d.N, d.K, d.act, d.ln, d.ln_eps, d.argmax, d.n_valid, d.variant = M, N, K, act, int(ln), ln_eps, int(argmax), n_valid, variant
+    keep = [a, w]
+    d.a, d.w = a.ctypes.data_as(_fp), w.ctypes.data_as(_fp)
+    if bias is not None:
+        bias = _f32(bias); keep.append(bias); d.bias = bias.ctypes.data_as(_fp)
+    if add is not None:
+        add = _f32(add); keep.append(add); d.add = add.ctypes.data_as(_fp)
+    out = {}
+    if argmax:
+        out["ids"] = np.zeros((M,), dtype=np.int32); d.out_ids = out["ids"].ctypes.data_as(_ip)
+    else:
+        if "lo" in want:
+            out["lo"] = np.zeros((M, N), dtype=np.float32); d.out_lo = out["lo"].ctypes.data_as(_fp)
+        if "f32" in want:
+            out["f32"] = np.zeros((M, N), dtype=np.float32); d.out_f32 = out["f32"].ctypes.data_as(_fp)
+        if "stats" in want:
+            out["stats"] = np.zeros((M, N // 32, 2), dtype=np.float32); d.out_stats = out["stats"].ctypes.data_as(_fp)
+    _lib.check(load().asr_probe_gemm(C.byref(d)))
+    return out, d.kernel.decode()
+
+
+def gemm_bench(M, N, K, variant=-1, epilogue=0, iters=50) -> float:
+    """Average milliseconds per launch of the bf16 GEMM (device-resident operands)."""
+    ms = C.c_float(0.0)
+    _lib.check(load().asr_probe_gemm_bench(variant, M, N, K, epilogue, iters, C.byref(ms)))
+    return ms.value
+
+
+def gemm_set_variant(variant: int = -1) -> None:
+    """Pin the bf16 GEMM kernel variant for the following op_gemm calls (-1 = heuristic)."""
+    gemm_bench(1152, 256, 64, variant, 0, 1)
+
+
+def gemm_counts(reset: bool = False) -> dict:
+    """Launches per GEMM kernel family since the last reset (host-side; a hipGraph replay does not count)."""
+    buf = C.create_string_buffer(1024)
+    _lib.check(load().asr_probe_gemm_counts(int(reset), buf, 1024))
+    return {k: int(v) for k, v in (kv.split("=") for kv in buf.value.decode().split(";") if kv)}

@@ -61,13 +61,16 @@ class ArenaWriter:
             offs.append(cur)
             cur = (cur + a.nbytes + 255) // 256 * 256
         total = cur
-        blob = np.zeros(total, dtype=np.uint8)
+        blob = np.empty(total, dtype=np.uint8)               # gigabytes for the large models: zero only the header and the alignment gaps
+        blob[:data_off] = 0
         blob[:32] = np.frombuffer(struct.pack("<8sIIQQ", b"ASRARENA", 1, n, data_off, total), dtype=np.uint8)
         for i, ((name, a, dtype), off) in enumerate(zip(self._items, offs)):
             shape = list(a.shape) + [0] * (4 - a.ndim)
             rec = struct.pack("<80sII4qQ", name.encode(), dtype, a.ndim, *shape, off)
             blob[32 + 128 * i: 32 + 128 * (i + 1)] = np.frombuffer(rec, dtype=np.uint8)
             blob[off: off + a.nbytes] = a.view(np.uint8).reshape(-1)
+            end = (off + a.nbytes + 255) // 256 * 256
+            blob[off + a.nbytes: end] = 0
         return blob
 
 
@@ -304,8 +307,8 @@ def build_whisper_arena(cfg, ck: dict, precision: int = PRECISION_BF16, suppress
     zero = np.zeros(d, dtype=np.float32)
 
     def fused_qkv(p, gamma, beta):
-        wq = np.concatenate([ck[p + "q_proj.weight"], ck[p + "k_proj.weight"], ck[p + "v_proj.weight"]], 0).copy()
-        bq = np.concatenate([ck[p + "q_proj.bias"], zero, ck[p + "v_proj.bias"]], 0).copy()
+        wq = np.concatenate([ck[p + "q_proj.weight"], ck[p + "k_proj.weight"], ck[p + "v_proj.weight"]], 0)     # a fresh array
+        bq = np.concatenate([ck[p + "q_proj.bias"], zero, ck[p + "v_proj.bias"]], 0)
         wq[:2 * d] *= scale                                      # d^-1/4 on q and k; k has no bias
         bq[:d] *= scale
         return _absorb_ln(gamma, beta, wq, bq)

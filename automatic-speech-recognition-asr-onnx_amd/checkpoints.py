@@ -14,6 +14,8 @@ affines are perturbed around (1, 0).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .config import SenseVoiceConfig, WhisperConfig
@@ -70,8 +72,38 @@ def synth_sensevoice_checkpoint(cfg: SenseVoiceConfig, seed: int = 0) -> dict:
     return ck
 
 
+class _KeyedRng:
+    """Stand-in for one sequential generator: every draw gets its own stream seeded by (seed, draw index), and the draws are
+    filled by a thread pool afterwards (numpy releases the GIL) -- 1.5 G normals in seconds instead of a minute. Values differ
+    from the sequential stream, so only configurations without sequential-stream goldens use it."""
+
+    def __init__(self, seed):
+        self.seed, self.jobs = seed, []
+
+    def standard_normal(self, shape, dtype=np.float32):
+        out = np.empty(shape, dtype=dtype)
+        self.jobs.append(out)
+        return out
+
+    def fill(self, post):
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(i):
+            a = self.jobs[i]
+            np.random.default_rng([self.seed, i]).standard_normal(a.shape, dtype=a.dtype, out=a)
+
+        with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as ex:
+            list(ex.map(run, sorted(range(len(self.jobs)), key=lambda i: -self.jobs[i].size)))
+        for fn in post:
+            fn()
+
+
 def synth_whisper_checkpoint(cfg: WhisperConfig, seed: int = 0) -> dict:
-    """Random Whisper-shaped checkpoint with HF `model.*` / `proj_out` key names."""
+    """Random Whisper-shaped checkpoint with HF `model.*` / `proj_out` key names. Full-size configurations (d_model >= 1024) draw
+    every tensor from its own stream in parallel; the small test configurations keep the single sequential stream their goldens
+    were minted from."""
+    if cfg.d_model >= 1024:
+        return _synth_whisper_checkpoint_parallel(cfg, seed)
     rng = np.random.default_rng(seed)
     ck: dict[str, np.ndarray] = {}
     d, dff = cfg.d_model, cfg.d_ffn
@@ -110,6 +142,64 @@ def synth_whisper_checkpoint(cfg: WhisperConfig, seed: int = 0) -> dict:
         ck[p + "fc2.weight"], ck[p + "fc2.bias"] = _lin(rng, d, dff)
     ck["model.decoder.layer_norm.weight"], ck["model.decoder.layer_norm.bias"] = _ln(rng, d)
     # proj_out is tied to embed_tokens in HF Whisper (no separate tensor).
+    return ck
+
+
+def _synth_whisper_checkpoint_parallel(cfg: WhisperConfig, seed: int) -> dict:
+    rng = _KeyedRng(seed)
+    ck: dict[str, np.ndarray] = {}
+    post = []
+    d, dff = cfg.d_model, cfg.d_ffn
+
+    def normal(key, shape, scale, offset=0.0):
+        a = rng.standard_normal(shape, dtype=np.float32)
+        ck[key] = a
+
+        def fin(a=a, scale=np.float32(scale), offset=np.float32(offset)):
+            a *= scale
+            if offset:
+                a += offset
+        post.append(fin)
+
+    def lin(prefix, out_f, in_f, bias=True, gain=1.0):
+        normal(prefix + ".weight", (out_f, in_f), gain / np.sqrt(in_f))
+        if bias:
+            normal(prefix + ".bias", (out_f,), 0.1)
+
+    def ln(prefix):
+        normal(prefix + ".weight", (d,), 0.1, 1.0)
+        normal(prefix + ".bias", (d,), 0.1)
+
+    def attn(prefix):
+        for name, has_bias in (("q_proj", True), ("k_proj", False), ("v_proj", True), ("out_proj", True)):
+            lin(prefix + name, d, d, bias=has_bias)
+
+    normal("model.encoder.conv1.weight", (d, cfg.n_mels, 3), 1.0 / np.sqrt(3 * cfg.n_mels))
+    normal("model.encoder.conv1.bias", (d,), 0.1)
+    normal("model.encoder.conv2.weight", (d, d, 3), 1.0 / np.sqrt(3 * d))
+    normal("model.encoder.conv2.bias", (d,), 0.1)
+    normal("model.encoder.embed_positions.weight", (cfg.max_source_positions, d), 0.1)
+    for i in range(cfg.n_enc_layers):
+        p = f"model.encoder.layers.{i}."
+        ln(p + "self_attn_layer_norm")
+        attn(p + "self_attn.")
+        ln(p + "final_layer_norm")
+        lin(p + "fc1", dff, d, gain=1.4)
+        lin(p + "fc2", d, dff)
+    ln("model.encoder.layer_norm")
+    normal("model.decoder.embed_tokens.weight", (cfg.vocab, d), 1.0 / np.sqrt(d))
+    normal("model.decoder.embed_positions.weight", (cfg.max_target_positions, d), 0.05)
+    for i in range(cfg.n_dec_layers):
+        p = f"model.decoder.layers.{i}."
+        ln(p + "self_attn_layer_norm")
+        attn(p + "self_attn.")
+        ln(p + "encoder_attn_layer_norm")
+        attn(p + "encoder_attn.")
+        ln(p + "final_layer_norm")
+        lin(p + "fc1", dff, d, gain=1.4)
+        lin(p + "fc2", d, dff)
+    ln("model.decoder.layer_norm")
+    rng.fill(post)
     return ck
 
 

@@ -222,6 +222,7 @@ extern "C" int asr_op_gemm(int precision, const float* a, const float* w, const 
   return asr_guard([&] {
     ASR_REQUIRE(a && w && out, "op_gemm: null argument");
     asr_require_device(0);
+    gemm_reload_env();
     Tmp t;
     const int Mp = round_up(M, 128), Np = round_up(N, 128), Kp = round_up(K, 64);
     void* da = upload_operand(t, precision, a, M, K, Mp, Kp);
@@ -375,70 +376,6 @@ extern "C" int asr_op_ctc_collapse(const int32_t* frame_ids, const int32_t* seq_
   });
 }
 
-extern "C" int asr_op_gemm_bench(int variant, int M, int N, int K, int epilogue, int iters, float* avg_ms) {
-  return asr_guard([&] {
-    ASR_REQUIRE(avg_ms && iters > 0, "op_gemm_bench: bad argument");
-    asr_require_device(0);
-    Tmp t;
-    const int Mp = round_up(M, 128);
-    auto rnd = [](size_t n, uint32_t seed) {
-      std::vector<bf16_t> v(n);
-      uint32_t x = seed;
-      for (size_t i = 0; i < n; ++i) { x = x * 1664525u + 1013904223u; v[i] = f32_to_bf16(((int)(x >> 9) % 2001 - 1000) * 1e-3f); }
-      return v;
-    };
-    std::vector<bf16_t> ha = rnd((size_t)Mp * K, 1), hw = rnd((size_t)N * K, 2);
-    bf16_t* da = (bf16_t*)t.alloc(ha.size() * 2);
-    bf16_t* dw = (bf16_t*)t.alloc(hw.size() * 2);
-    HIP_CHECK(hipMemcpy(da, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
-    float* bias = (float*)t.alloc((size_t)N * 4);
-    float* addm = (float*)t.alloc((size_t)Mp * N * 4);
-    float* addt = (float*)t.alloc((size_t)Mp * N * 4);
-    float* of32 = (float*)t.alloc((size_t)Mp * N * 4);
-    bf16_t* olo = (bf16_t*)t.alloc((size_t)Mp * N * 2);
-    bf16_t* ot = (bf16_t*)t.alloc((size_t)Mp * N * 2);
-    GemmArgs g;
-    g.A = da; g.lda = K; g.W = dw; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = bias;
-    switch (epilogue) {
-      case 0: g.out_lo = olo; g.ld_out_lo = N; break;
-      case 1: g.out_lo = olo; g.ld_out_lo = N; g.act = ACT_RELU; break;
-      case 2: g.add = addm; g.ld_add = N; g.out_f32 = of32; g.ld_out_f32 = N; break;
-      case 3: g.bias = nullptr; g.add = addt; g.ld_add = N; g.add2 = addm; g.ld_add2 = N; g.out_f32 = of32; g.ld_out_f32 = N; break;
-      case 4: g.out_t = ot; g.ld_out_t = Mp; break;
-      case 5: {   // FFN-1 with the LayerNorm evaluated inside (statistics handed over by the producer)
-        float2* st = (float2*)t.alloc((size_t)Mp * (K / 32) * 8);
-        HIP_CHECK(hipMemset(st, 0, (size_t)Mp * (K / 32) * 8));
-        g.out_lo = olo; g.ld_out_lo = N; g.act = ACT_RELU; g.ln_colsum = bias; g.ln_dim = K; g.ln_stats_in = st; g.ln_slots = K / 32;
-        break;
-      }
-      case 6: {   // out-projection writing the residual stream in f32 + bf16 + row statistics
-        float2* st = (float2*)t.alloc((size_t)Mp * (N / 32) * 8);
-        g.bias = nullptr; g.add = addt; g.ld_add = N; g.add2 = addm; g.ld_add2 = N; g.out_f32 = of32; g.ld_out_f32 = N;
-        g.out_lo = olo; g.ld_out_lo = N; g.st_out = st;
-        break;
-      }
-      default: ASR_THROW(ASR_ERR_INVALID, "op_gemm_bench: unknown epilogue %d", epilogue);
-    }
-    g.dbg = variant < 0 ? 0 : variant >> 8;
-    gemm_set_variant(variant < 0 ? -1 : (variant & 0xff));      // sticky: later asr_op_gemm calls use it too
-    hipEvent_t e0, e1;
-    HIP_CHECK(hipEventCreate(&e0));
-    HIP_CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) launch_gemm_bf16(g, nullptr);
-    HIP_CHECK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < iters; ++i) launch_gemm_bf16(g, nullptr);
-    HIP_CHECK(hipEventRecord(e1, nullptr));
-    HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    *avg_ms = ms / iters;
-    gemm_set_variant(-1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-  });
-}
-
 extern "C" int asr_op_gemm_ln(const float* x, const float* w, const float* bias, const float* gamma, const float* beta, int M, int N,
                               int K, float* out) {
   return asr_guard([&] {
@@ -465,152 +402,3 @@ extern "C" int asr_op_gemm_ln(const float* x, const float* w, const float* bias,
   });
 }
 
-// ---- grid-barrier latency probe (tuning hook): a cooperative launch of one workgroup per CU crossing `iters` barriers.
-namespace {
-__device__ __forceinline__ bool grid_barrier_probe_step(unsigned int* counter, unsigned int target) {
-  __syncthreads();
-  bool ok = true;
-  if (threadIdx.x == 0) {
-    __threadfence();
-    atomicAdd(counter, 1u);
-    int spins = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 22)) { ok = false; break; }       // never hang the box: give up after ~1 s
-    }
-    __threadfence();
-  }
-  __syncthreads();
-  return ok;
-}
-__global__ __launch_bounds__(512) void grid_barrier_probe_kernel(unsigned int* counter, int iters, float* sink, int* failed) {
-  float acc = 0.0f;
-  for (int it = 0; it < iters; ++it) {
-    acc += sink[(blockIdx.x * 64 + (it & 63)) & 4095];          // a little cross-workgroup traffic between barriers
-    if (threadIdx.x == 0) sink[(blockIdx.x * 64 + ((it + 1) & 63)) & 4095] = acc * 0.5f;
-    if (!grid_barrier_probe_step(counter, (unsigned int)(it + 1) * gridDim.x)) { if (threadIdx.x == 0) *failed = 1; return; }
-  }
-  if (acc == 123.456f) sink[0] = acc;
-}
-}  // namespace
-
-namespace {
-// hierarchical barrier probe: arrivals are counted per XCD (workgroup b runs on XCD b % 8), the last arrival of an XCD counts
-// itself on the chip counter, the last XCD publishes the generation. Relaxed agent-scope atomics only -- no fence, i.e. no L2
-// write-back / invalidate; payload that must cross XCDs would travel through sc1 accesses.
-struct HBar { unsigned int* xcd; unsigned int* chip; unsigned int* flag; };   // xcd[8 * 32], flag[8 * 32] (128-byte spacing)
-__device__ __forceinline__ bool hbar_step(const HBar& hb, unsigned int gen, int mode) {
-  __syncthreads();
-  bool ok = true;
-  if (threadIdx.x == 0) {
-    const int x = blockIdx.x & 7;
-    const unsigned int in_xcd = (gridDim.x + 7 - x) >> 3;
-    const unsigned int old = __hip_atomic_fetch_add(hb.xcd + x * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1 == gen * in_xcd) {
-      const unsigned int n_xcd = gridDim.x < 8 ? gridDim.x : 8;
-      const unsigned int o2 = __hip_atomic_fetch_add(hb.chip, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (o2 + 1 == gen * n_xcd) {
-        if (mode == 2) { for (int q = 0; q < 8; ++q) __hip_atomic_store(hb.flag + q * 32, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        else __hip_atomic_store(hb.flag, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    const unsigned int* f = mode == 2 ? hb.flag + x * 32 : hb.flag;
-    int spins = 0;
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 22)) { ok = false; break; }
-    }
-  }
-  __syncthreads();
-  return ok;
-}
-__global__ __launch_bounds__(512) void hbar_probe_kernel(HBar hb, int iters, int mode, float* sink, int* failed, const unsigned long long* bulk,
-                                                         int bulk_words, int bulk_sc1) {
-  float acc = 0.0f;
-  for (int it = 0; it < iters; ++it) {
-    // bulk activation read every workgroup does per phase: `bulk_words` 8-byte words of ONE shared buffer, through sc1 (relaxed
-    // agent-scope atomic loads: what a persistent kernel must use for data produced by other XCDs) or through plain cached loads
-    unsigned long long bsum = 0;
-    if (bulk_sc1) { for (int w = threadIdx.x; w < bulk_words; w += 512) bsum += __hip_atomic_load(bulk + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    else { for (int w = threadIdx.x; w < bulk_words; w += 512) bsum += bulk[w]; }
-    if (bsum == 0x123456789abcdefull) acc += 1.0f;
-    // payload through sc1 accesses: one value written by this workgroup, one read from the neighbour's slot of the previous round
-    const float v = __hip_atomic_load(sink + ((blockIdx.x + 1) % gridDim.x) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (it > 0 && v != (float)it) { if (threadIdx.x == 0) *failed = 2; }      // stale payload => visibility bug
-    acc += v;
-    if (!hbar_step(hb, 2u * it + 1u, mode)) { if (threadIdx.x == 0) *failed = 1; return; }
-    if (threadIdx.x == 0) __hip_atomic_store(sink + blockIdx.x * 32, (float)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!hbar_step(hb, 2u * it + 2u, mode)) { if (threadIdx.x == 0) *failed = 1; return; }
-  }
-  if (acc == 123.456f) sink[0] = acc;
-}
-}  // namespace
-
-extern "C" int asr_debug_grid_barrier2(int n_workgroups, int iters, int mode, float* us_per_barrier) {
-  return asr_guard([&] {
-    // mode = (1 | 2) + 16 * bulk KiB read per workgroup per round + 8 if that read goes through plain cached loads instead of sc1
-    int bulk_kib = mode >> 4, bulk_sc1 = (mode & 8) ? 0 : 1;
-    mode &= 7;
-    ASR_REQUIRE(us_per_barrier && iters > 0 && n_workgroups > 0 && n_workgroups <= 1024 && (mode == 1 || mode == 2) && bulk_kib <= 1024, "debug_grid_barrier2: bad argument");
-    asr_require_device(0);
-    Tmp t;
-    unsigned int* ctr = (unsigned int*)t.alloc(3 * 8 * 32 * 4);
-    float* sink = (float*)t.alloc(1024 * 32 * 4);
-    int* failed = (int*)t.alloc(256);
-    HIP_CHECK(hipMemset(ctr, 0, 3 * 8 * 32 * 4));
-    HIP_CHECK(hipMemset(sink, 0, 1024 * 32 * 4));
-    HIP_CHECK(hipMemset(failed, 0, 256));
-    HBar hb{ctr, ctr + 8 * 32, ctr + 2 * 8 * 32};
-    const unsigned long long* bulk = (const unsigned long long*)t.alloc((size_t)std::max(bulk_kib, 1) * 1024);
-    HIP_CHECK(hipMemset((void*)bulk, 1, (size_t)std::max(bulk_kib, 1) * 1024));
-    int bulk_words = bulk_kib * 128;
-    hipEvent_t e0, e1;
-    HIP_CHECK(hipEventCreate(&e0));
-    HIP_CHECK(hipEventCreate(&e1));
-    void* args[] = {&hb, &iters, &mode, &sink, &failed, &bulk, &bulk_words, &bulk_sc1};
-    HIP_CHECK(hipEventRecord(e0, nullptr));
-    HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(hbar_probe_kernel), dim3(n_workgroups), dim3(512), args, 0, nullptr));
-    HIP_CHECK(hipEventRecord(e1, nullptr));
-    HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0.0f;
-    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    int hf = 0;
-    HIP_CHECK(hipMemcpy(&hf, failed, 4, hipMemcpyDeviceToHost));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    ASR_REQUIRE(hf != 1, "debug_grid_barrier2: a workgroup gave up waiting (grid not co-resident?)");
-    ASR_REQUIRE(hf != 2, "debug_grid_barrier2: a payload written before the barrier was not visible after it");
-    *us_per_barrier = ms * 1e3f / (2.0f * iters);
-  });
-}
-
-extern "C" int asr_debug_grid_barrier(int n_workgroups, int iters, float* us_per_barrier) {
-  return asr_guard([&] {
-    ASR_REQUIRE(us_per_barrier && iters > 0 && n_workgroups > 0, "debug_grid_barrier: bad argument");
-    asr_require_device(0);
-    Tmp t;
-    unsigned int* counter = (unsigned int*)t.alloc(256);
-    float* sink = (float*)t.alloc(4096 * 4);
-    int* failed = (int*)t.alloc(256);
-    HIP_CHECK(hipMemset(counter, 0, 256));
-    HIP_CHECK(hipMemset(sink, 0, 4096 * 4));
-    HIP_CHECK(hipMemset(failed, 0, 256));
-    hipEvent_t e0, e1;
-    HIP_CHECK(hipEventCreate(&e0));
-    HIP_CHECK(hipEventCreate(&e1));
-    void* args[] = {&counter, &iters, &sink, &failed};
-    HIP_CHECK(hipEventRecord(e0, nullptr));
-    HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(grid_barrier_probe_kernel), dim3(n_workgroups), dim3(512), args, 0, nullptr));
-    HIP_CHECK(hipEventRecord(e1, nullptr));
-    HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0.0f;
-    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    int hf = 0;
-    HIP_CHECK(hipMemcpy(&hf, failed, 4, hipMemcpyDeviceToHost));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    ASR_REQUIRE(!hf, "debug_grid_barrier: a workgroup gave up waiting (grid not co-resident?)");
-    *us_per_barrier = ms * 1e3f / iters;
-  });
-}

@@ -64,6 +64,11 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s);
 void launch_gemm_f32(const GemmArgs& g, hipStream_t s);
 bool gemm_ln_fusable(const GemmArgs& g);   // true when launch_gemm_bf16 would accept g with ln_colsum set
 void gemm_set_variant(int v);   // tuning hook: -1 = built-in heuristic
+void gemm_reload_env();         // re-read the ASR_GEMM_* / ASR_SKINNY_* switches (called at session creation)
+const char* gemm_last_kernel(); // kernel family of this thread's last launch_gemm_bf16 ("t288w", "t144", "pipe", "skinny", ...): test hook
+bool gemm_skinny144_enabled();
+void gemm_kernel_counts_reset();
+int gemm_kernel_counts(char* buf, int cap);   // "family=launches;..." since the last reset (host-side: graph replays do not count)
 
 // reduce the per-slab arg-max partials written by the GEMM epilogue: ids[m] = first index of the row max
 void launch_argmax_reduce(const float* val, const int32_t* idx, int M, int n_slabs, int32_t* ids, hipStream_t s);

@@ -16,7 +16,51 @@
 //  * Epilogues are compile-time specialised (EPI / ACT) so they are straight-line code.
 //
 // f32 kernel: same tile on v_mfma_f32_16x16x4_f32 (exact f32 FMA chains) for verification mode.
+#include <cstring>
+#include <string>
 #include "gemm.h"
+
+// ---- tuning / ablation switches (environment), re-read by gemm_reload_env() at every session creation so that a test can flip them in-process
+struct GemmEnv {
+  bool t144 = true, t144w = true, t288w = true, big = true, splitk = true, deep = true, skinny144 = false;
+  int skinny_splitk = -1, tall_min = 16, skinny_max_plain = 32;
+  bool loaded = false;
+};
+static GemmEnv g_env;
+static thread_local const char* g_last_kernel = "";
+// launches per kernel family since the last reset (host-side counters: a hipGraph replay does not re-count): lets a test assert
+// WHICH tiling a session's batch geometry dispatched to
+struct KernelCount { const char* name; long n; };
+static KernelCount g_counts[16] = {};
+static void note_kernel(const char* tag) {
+  g_last_kernel = tag;
+  for (KernelCount& c : g_counts) {
+    if (!c.name) { c.name = tag; c.n = 1; return; }
+    if (c.name == tag || !strcmp(c.name, tag)) { ++c.n; return; }
+  }
+}
+void gemm_kernel_counts_reset() { for (KernelCount& c : g_counts) c = KernelCount{nullptr, 0}; }
+int gemm_kernel_counts(char* buf, int cap) {         // "name=count;name=count;..."
+  std::string out;
+  for (const KernelCount& c : g_counts) if (c.name) out += std::string(c.name) + "=" + std::to_string(c.n) + ";";
+  if (buf && cap > 0) snprintf(buf, cap, "%s", out.c_str());
+  return (int)out.size();
+}
+static bool env_flag(const char* name, bool dflt) { const char* e = getenv(name); return e ? e[0] != '0' : dflt; }
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+void gemm_reload_env() {
+  GemmEnv e;
+  e.t144 = env_flag("ASR_GEMM_T144", true); e.t144w = env_flag("ASR_GEMM_T144W", true); e.t288w = env_flag("ASR_GEMM_T288W", true);
+  e.big = env_flag("ASR_GEMM_BIG", true); e.splitk = env_flag("ASR_GEMM_SPLITK", true); e.deep = env_flag("ASR_GEMM_DEEP", true);
+  e.skinny144 = getenv("ASR_SKINNY_M144") && getenv("ASR_SKINNY_M144")[0] == '1';
+  e.skinny_splitk = env_int("ASR_SKINNY_SPLITK", -1); e.tall_min = env_int("ASR_GEMM_TALL_MIN", 16);
+  e.skinny_max_plain = env_int("ASR_SKINNY_MAX_M", 32);
+  e.loaded = true;
+  g_env = e;
+}
+static const GemmEnv& genv() { if (!g_env.loaded) gemm_reload_env(); return g_env; }
+const char* gemm_last_kernel() { return g_last_kernel; }
+bool gemm_skinny144_enabled() { return genv().skinny144; }
 
 namespace {
 
@@ -1087,7 +1131,7 @@ static int skinny_splits(const GemmArgs& g, int rows16) {
   // gain (3.84 -> 4.27 ms / token), so the split is opt-in (ASR_SKINNY_SPLITK=1) and kept for shapes where N / 16 is tiny
   // ... except for 33..64 rows (Qwen3-ASR decode, batch 64: 2.68 -> 2.45 ms / token), where every workgroup also re-reads 4 row tiles
   // of activations: there the split is on by default for the narrow outputs (o_proj / down_proj, N / 16 = 64 workgroups otherwise)
-  static const int on = getenv("ASR_SKINNY_SPLITK") ? atoi(getenv("ASR_SKINNY_SPLITK")) : -1;
+  const int on = genv().skinny_splitk;
   if (on == 0 || (on < 0 && rows16 <= 32) || !g.sk_ws || !g.sk_cnt || g.a_rms_eps > 0.0f) return 1;
   const int granules = g.N / 16;
   int best = 1;
@@ -1116,11 +1160,13 @@ void launch_skinny(const GemmArgs& g, hipStream_t s) {
   gg.sk_splits = skinny_splits(g, MT * 16);
   if constexpr (MT <= 2) {
     if (g.ln_x) {
+      note_kernel("skinny_ln");
       hipLaunchKernelGGL((gemm_bf16_skinny<MT, true>), dim3(g.N / 16, gg.sk_splits), dim3(64 * SK_WAVES), lds, s, gg);
       HIP_CHECK(hipGetLastError());
       return;
     }
   }
+  note_kernel("skinny");
   hipLaunchKernelGGL((gemm_bf16_skinny<MT, false>), dim3(g.N / 16, gg.sk_splits), dim3(64 * SK_WAVES), lds, s, gg);
   HIP_CHECK(hipGetLastError());
 }
@@ -1257,7 +1303,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g, co
 // split-K for the tiled kernel: a grid of at most a few dozen tiles walking a long K is one latency-bound loop per workgroup
 // (M = 144, N = 512, K = 2048: 16 workgroups x 32 K-steps = 30 us); S-way split => S x the workgroups, 1 / S the steps
 static int tiled_splits(const GemmArgs& g) {
-  static const bool off = getenv("ASR_GEMM_SPLITK") && getenv("ASR_GEMM_SPLITK")[0] == '0';
+  const bool off = !genv().splitk;
   if (off || !g.sk_ws || g.out_t || g.amax_val || g.lo_group || g.add2_rows || g.ln_colsum || g.m_dev || g.act == ACT_SWIGLU || g.N % 32) return 1;
   const int tiles = ((g.M + BM - 1) / BM) * (g.N / 64);
   if (tiles > 128 || g.K < 1024) return 1;
@@ -1283,6 +1329,7 @@ void launch_pipe_inst(const GemmArgs& g, hipStream_t s) {
   const int grid = ((g.M + BM - 1) / BM) * (g.N / BN_);
   GemmArgs gg = g;
   if ((size_t)g.N * g.K * 2 > ((size_t)3 << 20) && g.M > 2 * BM) gg.group_m = 8;     // weights beyond an XCD's L2: group the row tiles
+  note_kernel(g.k_splits > 1 ? "pipe_splitk" : "pipe");
   hipLaunchKernelGGL((gemm_bf16_pipe<BN_, STAGES, ACT, EPI, SWAP>), dim3(grid, g.k_splits > 1 ? g.k_splits : 1), dim3(256), lds, s, gg);
   HIP_CHECK(hipGetLastError());
 }
@@ -1296,13 +1343,14 @@ void launch_big_inst(const GemmArgs& g, hipStream_t s) {
     attr_set = true;
   }
   const int grid = ((g.M + BIG - 1) / BIG) * (g.N / BIG);
+  note_kernel("big");
   hipLaunchKernelGGL((gemm_bf16_big<ACT, EPI>), dim3(grid), dim3(512), lds, s, g);
   HIP_CHECK(hipGetLastError());
 }
 
 // the 256 x 256 tiling pays when it fills whole rounds of the chip (one workgroup per CU) with little padding
 bool big_fits(const GemmArgs& g) {
-  static const bool off = getenv("ASR_GEMM_BIG") && getenv("ASR_GEMM_BIG")[0] == '0';
+  const bool off = !genv().big;
   if (off || g.out_t || g.amax_val || g.lo_group || g.add2_rows || g.ln_colsum || g.st_out || g.m_dev || g.N % BIG || g.K % BK16 || g.M < 2048 || g.K < 512) return false;
   const int tiles_m = (g.M + BIG - 1) / BIG, tiles = tiles_m * (g.N / BIG);
   const int rounds = (tiles + 255) / 256;
@@ -1372,6 +1420,7 @@ void launch_t144_inst(const GemmArgs& g, hipStream_t s) {
     attr_set = true;
   }
   const int grid = ((g.M + TM - 1) / TM) * (g.N / TN);
+  note_kernel("t144");
   hipLaunchKernelGGL((gemm_bf16_t144<STAGES, ACT, EPI>), dim3(grid), dim3(512), lds, s, g);
   HIP_CHECK(hipGetLastError());
 }
@@ -1406,12 +1455,12 @@ bool launch_t144(const GemmArgs& g, hipStream_t s) {
 
 // 144 x 256 tiles: the LayerNorm-folded FFN-1 instance, when the wide tiles still give every CU two full rounds' worth of work
 bool launch_t144w(const GemmArgs& g, hipStream_t s) {
-  static const bool on = !(getenv("ASR_GEMM_T144W") && getenv("ASR_GEMM_T144W")[0] == '0');
+  const bool on = genv().t144w;
   if (!on || !g.ln_colsum || !g.ln_stats_in || g.st_out || g.N % TW || g.act != ACT_RELU) return false;
   const int epi = (g.add ? E_ADD : 0) | (g.add2 ? E_ADD2 : 0) | (g.out_f32 ? E_F32 : 0) | (g.out_lo ? E_LO : 0) | (g.bias ? E_BIAS : 0) | E_LN;
   if (epi != (E_BIAS | E_LO | E_LN)) return false;
   const int tiles = ((g.M + TM - 1) / TM) * (g.N / TW);
-  if (tiles < 448 || tiles % 256 > 0 && tiles % 256 < 192) return false;     // whole rounds of one workgroup per CU (or nearly)
+  if (tiles < 448 || (tiles % 256 > 0 && tiles % 256 < 192)) return false;     // whole rounds of one workgroup per CU (or nearly)
   constexpr int lds = (TW_STAGES * TW_STAGE > TW_RED ? TW_STAGES * TW_STAGE : TW_RED) + TM * 8;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1419,6 +1468,7 @@ bool launch_t144w(const GemmArgs& g, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
+  note_kernel("t144w");
   hipLaunchKernelGGL((gemm_bf16_t144w<ACT_RELU, E_BIAS | E_LO | E_LN>), dim3(tiles), dim3(512), lds, s, g);
   HIP_CHECK(hipGetLastError());
   return true;
@@ -1426,7 +1476,7 @@ bool launch_t144w(const GemmArgs& g, hipStream_t s) {
 
 // 288 x 256 tiles: the same instance when pairs of windows x 256 columns make whole rounds
 bool launch_t288w(const GemmArgs& g, hipStream_t s) {
-  static const bool on = !(getenv("ASR_GEMM_T288W") && getenv("ASR_GEMM_T288W")[0] == '0');
+  const bool on = genv().t288w;
   if (!on || !g.ln_colsum || !g.ln_stats_in || g.st_out || g.N % TW || g.act != ACT_RELU) return false;
   const int epi = (g.add ? E_ADD : 0) | (g.add2 ? E_ADD2 : 0) | (g.out_f32 ? E_F32 : 0) | (g.out_lo ? E_LO : 0) | (g.bias ? E_BIAS : 0) | E_LN;
   if (epi != (E_BIAS | E_LO | E_LN)) return false;
@@ -1439,6 +1489,7 @@ bool launch_t288w(const GemmArgs& g, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
+  note_kernel("t288w");
   hipLaunchKernelGGL((gemm_bf16_t288w<ACT_RELU, E_BIAS | E_LO | E_LN>), dim3(tiles), dim3(512), lds, s, g);
   HIP_CHECK(hipGetLastError());
   return true;
@@ -1446,7 +1497,7 @@ bool launch_t288w(const GemmArgs& g, hipStream_t s) {
 
 // ... and for the vocabulary head with the arg-max epilogue (CTC / decoder vocab GEMM over a whole batch: thousands of tiles)
 bool launch_t288w_amax(const GemmArgs& g, hipStream_t s) {
-  static const bool on = !(getenv("ASR_GEMM_T288W") && getenv("ASR_GEMM_T288W")[0] == '0');
+  const bool on = genv().t288w;
   if (!on || !g.amax_val || !g.bias || g.out_f32 || g.out_lo || g.out_t || g.add || g.add2 || g.ln_colsum || g.st_out || g.lo_group || g.act != ACT_NONE ||
       g.N % TW || g.K % BK16 || g.M < 8 * TM2)
     return false;
@@ -1459,6 +1510,7 @@ bool launch_t288w_amax(const GemmArgs& g, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
+  note_kernel("t288w_amax");
   hipLaunchKernelGGL((gemm_bf16_t288w<ACT_NONE, E_BIAS | E_AMAX>), dim3(tiles), dim3(512), lds, s, g);
   HIP_CHECK(hipGetLastError());
   return true;
@@ -1488,10 +1540,7 @@ int g_gemm_variant = -1;   // -1 = heuristic; 5 / 6 = 144-row tiles with a 4- / 
 
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 
-static bool t144_enabled() {
-  static const bool on = !(getenv("ASR_GEMM_T144") && getenv("ASR_GEMM_T144")[0] == '0');
-  return on;
-}
+static bool t144_enabled() { return genv().t144; }
 
 bool gemm_ln_fusable(const GemmArgs& g) {
   return g_gemm_variant < 0 && t144_enabled() && g.M > 64 && g.ln_dim > 0 && g.K == (g.ln_dim + 63) / 64 * 64 && t144_geom_ok(g);
@@ -1501,11 +1550,11 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
   if (g.ln_x) ASR_REQUIRE(g.M <= 32 && !g.A, "gemm: the fused LayerNorm prologue exists on the skinny path for M <= 32 only");
   // 33..64 rows against a vocabulary-sized N: the 128 x 128 tiles re-read the activations 8 x less often than 16-column granules do
   // (lm_head 64 x 151936 x 1024: 76 us vs 240 us)
-  static const int tall_min = getenv("ASR_GEMM_TALL_MIN") ? atoi(getenv("ASR_GEMM_TALL_MIN")) : 16;
+  const int tall_min = genv().tall_min;
   const bool tall = g.M > tall_min && g.N >= 16384 && !g.ln_x && g.a_rms_eps == 0.0f && g.act != ACT_SWIGLU;
-  static const int skinny_max_plain = getenv("ASR_SKINNY_MAX_M") ? atoi(getenv("ASR_SKINNY_MAX_M")) : 32;   // rows up to which PLAIN GEMMs (no prologue) stream weights; above, the tiled split-K pass shares the activation rows across 64 columns (Whisper B = 64: 4.62 -> 3.89 ms per token)
+  const int skinny_max_plain = genv().skinny_max_plain;   // rows up to which PLAIN GEMMs (no prologue) stream weights; above, the tiled split-K pass shares the activation rows across 64 columns (Whisper B = 64: 4.62 -> 3.89 ms per token)
   const bool needs_skinny = g.ln_x || g.a_rms_eps != 0.0f || !g.sk_ws;
-  if (g.M <= 64 && (needs_skinny || g.M <= skinny_max_plain) && !tall && !g.out_t && !g.amax_val && g.lo_group == 0 && g.K % (32 * SK_WAVES) == 0 && g_gemm_variant < 0) {
+  if (g.M <= 64 && (needs_skinny || g.M <= skinny_max_plain || g.N % 128 != 0) && !tall && !g.out_t && !g.amax_val && g.lo_group == 0 && g.K % (32 * SK_WAVES) == 0 && g_gemm_variant < 0) {
     ASR_REQUIRE((g.A || g.ln_x) && g.W && g.N % 16 == 0, "gemm(skinny): bad operands");
     ASR_REQUIRE(g.ln_x || (g.lda * 2) % 16 == 0, "gemm(skinny): lda must be a 16-byte multiple");
     if (g.ln_x) ASR_REQUIRE(g.K % 4 == 0 && g.K <= 1280 && g.ld_ln_x % 4 == 0, "gemm(skinny): fused LayerNorm needs K <= 1280, float4-aligned rows");
@@ -1515,12 +1564,13 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
     return;
   }
   // one 8 s window (<= 144 rows): a tiled GEMM would put 4..16 workgroups on the chip; stream the weights with the skinny kernel instead
-  static const bool skinny144 = getenv("ASR_SKINNY_M144") && getenv("ASR_SKINNY_M144")[0] == '1';
+  const bool skinny144 = genv().skinny144;
   if (skinny144 && g.M <= 144 && g.sk_ws && !g.ln_x && !g.ln_colsum && !g.st_out && !g.out_t && !g.amax_val && g.lo_group == 0 && g.N % 16 == 0 &&
       g.K % (32 * SK_WAVES) == 0 && (g.lda * 2) % 16 == 0 && g_gemm_variant < 0) {
     launch_skinny<9>(g, s);
     return;
   }
+  ASR_REQUIRE(g.a_rms_eps == 0.0f && !g.ln_x, "gemm: the RMSNorm / LayerNorm prologues exist on the weight-streaming (skinny) path only (M = %d, N = %d, K = %d)", g.M, g.N, g.K);
   check_args(g, BK16, 2);
   int v = g_gemm_variant;
   if (v < 0) {
@@ -1539,7 +1589,7 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
       GemmArgs p = g;                                    // pass 1: raw f32 partials, no epilogue terms
       p.bias = nullptr; p.add = nullptr; p.add2 = nullptr; p.act = ACT_NONE; p.out_lo = nullptr;
       p.out_f32 = g.sk_ws; p.ld_out_f32 = g.N; p.k_splits = sp; p.st_out = nullptr;
-      static const bool deep_sk = !(getenv("ASR_GEMM_DEEP") && getenv("ASR_GEMM_DEEP")[0] == '0');
+      const bool deep_sk = genv().deep;
       if (deep_sk && g.K / sp >= 256) launch_pipe<64, 3>(p, s); else launch_pipe<64, 2>(p, s);   // lone workgroups per CU: a third stage covers the DMA latency
       const size_t n = (size_t)g.M * (g.N / 4);
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, (const float*)g.sk_ws, sp);
@@ -1549,7 +1599,7 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
     v = tall ? 2 : 4;
     // token-compacted rows (device-side M far below the launch bound): a handful of live workgroups, each alone on its CU, walking a
     // long K -- a third ring stage covers the DMA round trip the missing co-resident workgroup would have covered
-    static const bool deep = !(getenv("ASR_GEMM_DEEP") && getenv("ASR_GEMM_DEEP")[0] == '0');
+    const bool deep = genv().deep;
     if (deep && g.m_dev && g.K >= 1024 && !tall && !g.amax_val) v = 3;
     if (deep && !tall && !g.amax_val && ((g.M + BM - 1) / BM) * (g.N / 64) <= 256 && g.K >= 256) v = 3;   // one round, at most one workgroup per CU
   }

@@ -1411,6 +1411,7 @@ extern "C" int asr_qwen_create(const asr_qwen_config* cfg, const void* arena, si
       s->cfg = *cfg;
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;
+      gemm_reload_env();
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       if (const char* e = getenv("ASR_QWEN_NO_FUSE")) s->no_fuse = e[0] == '1';
       if (const char* e = getenv("ASR_QWEN_MEGA")) s->use_mega = e[0] == '1';

@@ -227,7 +227,7 @@ void SvSession::enqueue(const SvRunCtx& r) {
     probe.M = rows; probe.N = dff; probe.K = d; probe.ln_dim = d; probe.ln_colsum = b1.c1; probe.act = ACT_RELU; probe.bias = b1.b1;
     probe.out_lo = d_ffn.ptr; probe.A = d_xblo.ptr; probe.W = b1.w1;
     // a single window is weight-streaming bound: its GEMMs take the skinny split-K kernel, which wants separately normalised rows
-    static const bool skinny144 = getenv("ASR_SKINNY_M144") && getenv("ASR_SKINNY_M144")[0] == '1';
+    const bool skinny144 = gemm_skinny144_enabled();
     alg = (rows > 144 || !skinny144) && use_ln_alg && use_fused && b1.cqkv && b1.c1 && blocks[0].cqkv &&
           sanm_fused_supported(r.max_T, c.d_head, c.n_heads, d, c.fsmn_kernel, blocks[0].kpad) && gemm_ln_fusable(probe);
   }
@@ -1023,6 +1023,7 @@ extern "C" int asr_sensevoice_create(const asr_sensevoice_config* cfg, const voi
       s->device = device_id;
       s->precision = precision;
       s->cfg = *cfg;
+      gemm_reload_env();
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       if (const char* e = getenv("ASR_SANM_FUSED")) s->use_fused = !(e[0] == '0');
       if (const char* e = getenv("ASR_LN_FUSED")) s->use_ln_alg = !(e[0] == '0');
@@ -1078,6 +1079,7 @@ extern "C" int asr_paraformer_create(const asr_paraformer_config* cfg, const voi
       c.lfr_m = cfg->lfr_m; c.lfr_n = cfg->lfr_n; c.d_model = cfg->d_model; c.n_heads = cfg->n_heads; c.d_head = cfg->d_head; c.d_ffn = cfg->d_ffn;
       c.n_blocks = cfg->n_blocks; c.n_main = cfg->n_blocks; c.fsmn_kernel = cfg->fsmn_kernel; c.vocab = cfg->vocab; c.blank_id = -1;
       c.n_prompt = 0; c.n_languages = 0; c.max_audio_len = cfg->max_audio_len;
+      gemm_reload_env();
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       if (const char* e = getenv("ASR_SANM_FUSED")) s->use_fused = !(e[0] == '0');
       if (const char* e = getenv("ASR_LN_FUSED")) s->use_ln_alg = !(e[0] == '0');

@@ -559,6 +559,7 @@ extern "C" int asr_whisper_create(const asr_whisper_config* cfg, const void* are
       s->device = device_id;
       s->precision = precision;
       s->cfg = *cfg;
+      gemm_reload_env();
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;

@@ -207,15 +207,15 @@ def op_ctc_collapse(frame_ids, seq_lens, blank_id=0):
 
 
 def op_gemm_bench(M, N, K, variant=-1, epilogue=0, iters=50) -> float:
-    """Average milliseconds per launch of the bf16 GEMM (device-resident operands)."""
-    ms = C.c_float(0.0)
-    _lib.check(_lib.load().asr_op_gemm_bench(variant, M, N, K, epilogue, iters, C.byref(ms)))
-    return ms.value
+    """Tuning hook (probe library, not the product ABI): average milliseconds per launch of the bf16 GEMM."""
+    from . import _probe
+    return _probe.gemm_bench(M, N, K, variant, epilogue, iters)
 
 
 def op_gemm_set_variant(variant: int = -1) -> None:
-    """Pin the bf16 GEMM kernel variant for the following op_gemm calls (-1 = heuristic); tuning / test hook."""
-    op_gemm_bench(1152, 256, 64, variant, 0, 1)
+    """Pin the bf16 GEMM kernel variant for the following op_gemm calls (-1 = heuristic); probe-library hook."""
+    from . import _probe
+    _probe.gemm_set_variant(variant)
 
 
 # =============================================================================== Whisper

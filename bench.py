@@ -50,42 +50,63 @@ def sensevoice_algorithmic_flops(cfg, lengths):
     return out
 
 
+PROFILE_ROUND = None        # "rNN": which round's committed profiles the roofline block cites (--round; default = newest on file)
+
+
+def profile_path(stem):
+    """profiles/<round>_<stem> for the round given by --round, else the newest round that has this file; None when none exists.
+    The cited file name is stamped into the output line, so a stale citation is visible."""
+    import glob
+    import re
+    if PROFILE_ROUND:
+        p = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{stem}")
+        return p if os.path.isfile(p) else None
+    best = None
+    for p in glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{stem}")):
+        m = re.match(r"r(\d\d)_", os.path.basename(p))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), p)
+    return best[1] if best else None
+
+
 def hbm_traffic(kernel):
-    """Memory-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_hbm_traffic.json: FETCH_SIZE
+    """Memory-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_hbm_traffic.json: FETCH_SIZE
     doubled per the gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE); None when no counter run is on file."""
+    p = profile_path("hbm_traffic.json")
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+        with open(p) as f:
             rec = json.load(f)["kernels"].get(kernel)
-        return None if rec is None else {"bytes_per_launch": rec["bytes_per_launch"], "unit": "B", "source": "profiles/r01_hbm_traffic.json"}
-    except (OSError, KeyError, ValueError):
+        return None if rec is None else {"bytes_per_launch": rec["bytes_per_launch"], "unit": "B", "source": os.path.relpath(p, ROOT)}
+    except (OSError, KeyError, ValueError, TypeError):
         return None
 
 
 def mfma_util(kernel):
-    """MFMA pipe utilisation of `kernel` from the committed SQ counter pass (profiles/r01_mfma_util.json, tools/summarize_sq_pmc.py)."""
+    """MFMA pipe utilisation of `kernel` from the committed SQ counter pass (profiles/rNN_mfma_util.json, tools/summarize_sq_pmc.py)."""
+    p = profile_path("mfma_util.json")
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_mfma_util.json")) as f:
+        with open(p) as f:
             rec = json.load(f)["kernels"].get(kernel)
         return None if rec is None else {"mfma_busy_frac": rec["mfma_util"], "wave_cycles": {k: rec[k] for k in ("wait_any_share", "wait_inst_any_share",
-                                         "active_inst_share")}, "source": "profiles/r01_mfma_util.json"}
-    except (OSError, KeyError, ValueError):
+                                         "active_inst_share")}, "source": os.path.relpath(p, ROOT)}
+    except (OSError, KeyError, ValueError, TypeError):
         return None
 
 
 def rocprof_avg_us(match, exclude=()):
     """Average kernel duration of the launches whose name contains one of `match`, from the committed rocprofv3 --kernel-trace --stats
-    summary of this command (profiles/r01_sensevoice_b64_kernel_stats.csv). The live figure next to it is bracketed by HIP events on the
+    summary of this command (profiles/rNN_sensevoice_b64_kernel_stats.csv). The live figure next to it is bracketed by HIP events on the
     session stream and so includes the gap between consecutive launches (a few us each)."""
     import csv
+    p = profile_path("sensevoice_b64_kernel_stats.csv")
     try:
         tot = calls = 0.0
-        with open(os.path.join(ROOT, "profiles", "r01_sensevoice_b64_kernel_stats.csv")) as f:
+        with open(p) as f:
             for r in csv.DictReader(f):
                 if any(m in r["Name"] for m in match) and not any(x in r["Name"] for x in exclude):
                     tot += float(r["TotalDurationNs"]); calls += float(r["Calls"])
-        return None if calls == 0 else {"avg_launch_us": round(tot / calls / 1e3, 2), "launches": int(calls),
-                                        "source": "profiles/r01_sensevoice_b64_kernel_stats.csv"}
-    except (OSError, KeyError, ValueError):
+        return None if calls == 0 else {"avg_launch_us": round(tot / calls / 1e3, 2), "launches": int(calls), "source": os.path.relpath(p, ROOT)}
+    except (OSError, KeyError, ValueError, TypeError):
         return None
 
 
@@ -125,7 +146,8 @@ def cpu_baseline(cfg, ck, audio_np, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (sensevoice default 200 = 1.7 s of timed region; other workloads 20)")
+    ap.add_argument("--round", default=None, help="rNN: cite this round's committed profiles in the roofline block (default: the newest on file)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU per step (default 64; whisper: 32 = BASELINE.json configs[2])")
     ap.add_argument("--seconds", type=float, default=8.0)
@@ -139,6 +161,10 @@ def main():
     ap.add_argument("--beam", type=int, default=1, help="qwen / mixed: beam width (1 = greedy; BASELINE.json configs[4] names beam 5)")
     ap.add_argument("--decode-tokens", type=int, default=0, help="whisper: generated tokens per utterance (default 4 per audio second)")
     args = ap.parse_args()
+    global PROFILE_ROUND
+    PROFILE_ROUND = args.round
+    if args.workload != "sensevoice" and "--steps" not in " ".join(sys.argv):
+        args.steps = 20
     if args.batch is None:
         args.batch = 32 if args.workload == "whisper" else 64
     if args.workload == "whisper":
@@ -183,16 +209,28 @@ def main():
     sess = eng.SenseVoiceSession(cfg, arena_dev, arena.PRECISION_BF16, local_rank, arena_device_ptr=arena_dev.data_ptr(),
                                  arena_bytes=arena_dev.numel())
 
-    # ---- synthetic audio, resident in HBM before the timed region
+    # ---- synthetic audio: step k's batch is resident in HBM when step k starts; the NEXT batch's host -> device copy runs on a copy
+    #      stream under it (two device buffers), so the timed region contains every upload and every token download
     audio_np = ckm.synth_audio("kaldi", B, n_samples, seed=1234 + rank)
-    audio_dev = torch.from_numpy(audio_np).to(device)
+    audio_pin = torch.from_numpy(audio_np).pin_memory()
+    audio_dev = [torch.empty_like(audio_pin, device=device) for _ in range(2)]
+    audio_dev[0].copy_(audio_pin)
+    copy_stream = torch.cuda.Stream(device=device)
+    copy_done = torch.cuda.Event()
+    torch.cuda.synchronize()
     offsets = np.arange(B + 1, dtype=np.int64) * n_samples
     lang = np.zeros(B, dtype=np.int32)
     lengths = [n_samples] * B
     max_t = cfg.seq_len(n_samples)
 
-    def step():
-        tok, num = sess.run_packed(None, offsets, lang, audio_device_ptr=audio_dev.data_ptr())
+    def step(k=0, upload=True):
+        if upload:                                         # batch k + 1: pinned host -> HBM, overlapped with batch k's kernels
+            with torch.cuda.stream(copy_stream):
+                audio_dev[(k + 1) & 1].copy_(audio_pin, non_blocking=True)
+                copy_done.record(copy_stream)
+        tok, num = sess.run_packed(None, offsets, lang, audio_device_ptr=audio_dev[k & 1].data_ptr())
+        if upload:
+            copy_done.synchronize()
         if world > 1:                                      # hypotheses to rank 0 (latency-bound, < 120 KB per rank)
             dp.gather_hypotheses(dp.pack_hypotheses(tok, num, max_t), device)
         return tok, num
@@ -202,47 +240,50 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tok, num = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(n_steps, upload):
+        fence()
+        t0 = time.perf_counter()
+        for k in range(n_steps):
+            step(k, upload)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    for k in range(args.warmup):
+        step(k)
+    elapsed = timed(args.steps, True)                      # the headline: EXACTLY --steps steps, uploads inside
+    tok, num = step(0, False)
+    elapsed_resident = timed(args.steps, False)            # same steps with the audio left in HBM (what round 1 reported as `value`)
+    steady = None
+    if args.steps < 200 and not args.no_extras:            # a short --steps run is noisy (20 x 8 ms = 0.17 s): also time 200 steps
+        steady = timed(200, True)
 
     # ---- roofline leg: per-kernel-class HIP-event timing on the session stream (separate profiled steps)
     sess.profile(True)
     sess.profile_reset()
     for _ in range(args.profile_steps):
-        sess.run_packed(None, offsets, lang, audio_device_ptr=audio_dev.data_ptr())
+        sess.run_packed(None, offsets, lang, audio_device_ptr=audio_dev[0].data_ptr())
     prof = sess.profile_read()
     sess.profile(False)
-    # PCIe-inclusive rate (host audio in, ids out) -- reported in DESIGN.md, never as `value`
-    t_pcie = t_inflight = None
-    if not args.no_extras:
-        t1 = time.perf_counter()
-        for _ in range(3):
-            sess.run_packed(audio_np.reshape(-1), offsets, lang)
-        t_pcie = (time.perf_counter() - t1) / 3
     # serving option, reported next to the headline and never as `value`: two batches in flight on two sessions / HIP streams (the
     # second session borrows the same arena); the launch gaps and round tails of one graph replay are filled by the other
     import threading
+    t_inflight = None
 
     def inflight_worker(s_, n_):
         torch.cuda.set_device(local_rank)
         for _ in range(n_):
-            s_.run_packed(None, offsets, lang, audio_device_ptr=audio_dev.data_ptr())
+            s_.run_packed(None, offsets, lang, audio_device_ptr=audio_dev[0].data_ptr())
 
     if not args.no_extras:
         sess2 = eng.SenseVoiceSession(cfg, arena_dev, arena.PRECISION_BF16, local_rank, arena_device_ptr=arena_dev.data_ptr(), arena_bytes=arena_dev.numel())
         inflight_worker(sess2, 3)
         torch.cuda.synchronize()
-        per = max(args.steps, 10)
+        per = max(min(args.steps, 50), 10)
         ths = [threading.Thread(target=inflight_worker, args=(s_, per)) for s_ in (sess, sess2)]
         t1 = time.perf_counter()
         for th in ths:
@@ -251,14 +292,18 @@ def main():
             th.join()
         torch.cuda.synchronize()
         t_inflight = (time.perf_counter() - t1) / (2 * per)
+        del sess2
 
     if rank == 0:
         audio_s_per_step = world * B * n_samples / cfg.sample_rate
         ms_per_step = elapsed / args.steps * 1e3
         value = audio_s_per_step * args.steps / elapsed
         flops = sensevoice_algorithmic_flops(cfg, lengths)
+        total_flops = sum(flops.values())                  # base classes only: the fused kernel's work is q|k|v + attention + FSMN, counted once
         if "sanm_fused" in prof:      # q|k|v projection + attention + FSMN run as one kernel per (utterance, head)
             flops["sanm_fused"] = flops["gemm_qkv"] + flops["attention"] + flops["fsmn"]
+        if "sanm_block" in prof:      # one persistent launch per SANM block: every GEMM, the attention and the FSMN of the block
+            flops["sanm_block"] = sum(flops[k] for k in ("gemm_qkv", "gemm_out", "gemm_ffn1", "gemm_ffn2", "attention", "fsmn"))
         kernels = {}
         for name, p in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
             ms = p["total_ms"] / args.profile_steps
@@ -266,57 +311,150 @@ def main():
             if name in flops and ms > 0:
                 k["tflops"] = round(flops[name] / (ms * 1e-3) / 1e12, 1)
             kernels[name] = k
-        gemm_names = [n for n in kernels if n.startswith("gemm_") and n != "gemm_ctc"]
-        gemm_ms = sum(kernels[n]["ms_per_step"] for n in gemm_names)
-        gemm_flops = sum(flops[n] for n in gemm_names)
-        gemm_launches = sum(kernels[n]["launches_per_step"] for n in gemm_names)
+        if "sanm_block" in kernels:
+            dom, dom_desc, dom_match = ["sanm_block"], "sanm_block_kernel (persistent: q|k|v + attention + FSMN + out-proj + FFN of one SANM block per launch)", ("sanm_block_kernel",)
+        else:
+            dom = [n for n in kernels if n.startswith("gemm_") and n != "gemm_ctc"]
+            dom_desc = ("gemm_bf16_t144 / gemm_bf16_t288w (SANM out-proj / ffn2: 144 x 128 tiles, ffn1: 288 x 256 tiles; the q|k|v projection "
+                        "runs inside sanm_qkv_attn_kernel and is listed under kernels.sanm_fused)")
+            dom_match = ("gemm_bf16_t144<", "gemm_bf16_t288w<1,")
+        gemm_ms = sum(kernels[n]["ms_per_step"] for n in dom)
+        gemm_flops = sum(flops[n] for n in dom)
+        gemm_launches = sum(kernels[n]["launches_per_step"] for n in dom)
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        total_flops = sum(flops.values())
+        pmc_key = "sanm_block_kernel" if "sanm_block" in kernels else "gemm_bf16_t144"
         out = {
             "metric": "audio-sec/s, SenseVoiceSmall, 8 s @ 16 kHz chunks, batch 64 per GPU (RTF = 1/value per GPU-stream)",
             "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"SenseVoiceSmall bf16 (234 M params, 70 SANM blocks), batch={B} x {args.seconds:g} s per GPU, "
-                                   "greedy CTC, audio resident in HBM, token ids returned to host",
+                                   "greedy CTC; step k's audio is resident in HBM when the step starts, batch k+1's host->device copy (pinned, copy stream) "
+                                   "and every token-id download are inside the timed region",
                        "global_batch": world * B, "audio_seconds_per_step": audio_s_per_step,
                        "parallelism": f"dp{world} (utterance sharding, RCCL arena broadcast + hypothesis gather)"},
             "rtf": round(elapsed / (audio_s_per_step * args.steps), 8),
             "audio_s_per_s_per_gpu": round(value / world, 1),
+            "audio_resident": {"audio_s_per_s_per_gpu": round(audio_s_per_step * args.steps / elapsed_resident / world, 1),
+                               "ms_per_step": round(elapsed_resident / args.steps * 1e3, 3), "what": "same steps, no uploads (audio left in HBM)"},
+            "steady": None if steady is None else {"steps": 200, "ms_per_step": round(steady / 200 * 1e3, 3),
+                                                   "audio_s_per_s_per_gpu": round(audio_s_per_step * 200 / steady / world, 1)},
             "model_tflops_per_gpu": round(total_flops / (ms_per_step * 1e-3) / 1e12, 1),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_t144 / gemm_bf16_t288w (SANM out-proj / ffn2: 144 x 128 tiles, ffn1: 288 x 256 tiles; the q|k|v projection "
-                                                     "runs inside sanm_qkv_attn_kernel and is listed under kernels.sanm_fused)",
+            "roofline": {"bound": "mfma", "kernel": dom_desc,
                          "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": hbm_traffic("gemm_bf16_t144"), "pmc": mfma_util("gemm_bf16_t144"),
+                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": hbm_traffic(pmc_key), "pmc": mfma_util(pmc_key),
                          "launches_per_step": gemm_launches, "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),
-                         "rocprof": rocprof_avg_us(("gemm_bf16_t144<", "gemm_bf16_t288w<1,")),
-                         "algorithmic_gflop_per_step": round(gemm_flops / 1e9, 1)},
+                         "rocprof": rocprof_avg_us(dom_match),
+                         "algorithmic_gflop_per_step": round(gemm_flops / 1e9, 1),
+                         "whole_step_frac": round(total_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
             "kernels": kernels,
-            "pcie_inclusive_audio_s_per_s_per_gpu": None if t_pcie is None else round(B * n_samples / cfg.sample_rate / t_pcie, 1),
             "inflight": None if t_inflight is None else {"batches_in_flight": 2, "audio_s_per_s_per_gpu": round(B * n_samples / cfg.sample_rate / t_inflight, 1),
                                                          "ms_per_batch": round(t_inflight * 1e3, 3)},
             "arena_broadcast_s": round(t_bcast, 4),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, ck, audio_np)
-            # spot check at full size: CTC logits and frame arg-max of utterance 0, bf16 engine vs f32 oracle (CHECKER ONLY)
+            # spot check AT THE TIMED BATCH SIZE (the batch-64 dispatch: 288 x 256 FFN-1 / CTC tiles): CTC logits and frame arg-max of
+            # utterances 0 and B-1 tapped from the full batch, bf16 engine vs f32 oracle (CHECKER ONLY)
             from oracle.sensevoice_oracle import SenseVoiceOracle
-            st = SenseVoiceOracle(cfg, ck).stages(audio_np[0, 0], 0)
+            orc = SenseVoiceOracle(cfg, ck)
             sess.taps(True)
-            sess.run_packed(None, offsets[:2], lang[:1], audio_device_ptr=audio_dev.data_ptr())
-            lg = sess.tap("logits")[:st["logits"].shape[0]]
+            sess.run_packed(None, offsets, lang, audio_device_ptr=audio_dev[0].data_ptr())
+            lg_all = sess.tap("logits")
+            rows = sess.utterance_rows(lengths)
             sess.taps(False)
-            srt = np.sort(st["logits"], axis=1)
-            diff = float(np.abs(lg - st["logits"]).max())
-            safe = (srt[:, -1] - srt[:, -2]) > 2.0 * diff               # frames whose top-1 / top-2 margin exceeds twice the measured error
-            out["parity_spotcheck"] = {"what": "CTC logits of utterance 0, bf16 engine vs f32 oracle", "max_abs_diff": round(diff, 4),
-                                       "logit_abs_max": round(float(np.abs(st["logits"]).max()), 3), "frames": int(safe.size),
-                                       "frames_with_safe_margin": int(safe.sum()),
-                                       "argmax_equal_on_those": bool(np.array_equal(lg.argmax(1)[safe], st["frame_ids"][safe]))}
+            checks = []
+            for b in sorted({0, B - 1}):
+                st = orc.stages(audio_np[b, 0], 0)
+                r0, T = rows[b]
+                lg = lg_all[r0:r0 + T]
+                srt = np.sort(st["logits"], axis=1)
+                diff = float(np.abs(lg - st["logits"]).max())
+                safe = (srt[:, -1] - srt[:, -2]) > 2.0 * diff               # frames whose top-1 / top-2 margin exceeds twice the measured error
+                checks.append({"utterance": b, "max_abs_diff": round(diff, 4), "logit_abs_max": round(float(np.abs(st["logits"]).max()), 3),
+                               "frames": int(safe.size), "frames_with_safe_margin": int(safe.sum()),
+                               "argmax_equal_on_those": bool(np.array_equal(lg.argmax(1)[safe], st["frame_ids"][safe]))})
+            del lg_all
+            out["parity_spotcheck"] = {"what": f"CTC logits tapped from the timed batch of {B}, bf16 engine vs f32 oracle", "utterances": checks}
+            if not args.no_extras:
+                out["secondary"] = secondary_lines(cfg, ck, audio_np, local_rank, device)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def secondary_lines(cfg, ck, audio_np, local_rank, device):
+    """The other two figures BASELINE.json's metric names, measured in the same driver-run process (secondary keys, never `value`):
+    configs[0] SenseVoiceSmall f32 mode, one 8 s chunk (the mode whose tokens equal the reference's) and Whisper-large-v3 bf16 on 8 s
+    chunks at batch 32 and 64 (encoder + prefill + 31 greedy decode steps; random weights never emit EOS)."""
+    import torch
+    ckm = importlib.import_module(PKG + ".checkpoints")
+    cfgm = importlib.import_module(PKG + ".config")
+    arena = importlib.import_module(PKG + ".arena")
+    eng = importlib.import_module(PKG + ".engine")
+    out = {}
+    n_samples = audio_np.shape[2]
+    # ---- configs[0]: f32 verification mode, batch 1 (host audio in, ids out: the reference's call shape)
+    s32 = eng.SenseVoiceSession.from_checkpoint(cfg, ck, precision=arena.PRECISION_F32, device_id=local_rank)
+    one = [audio_np[0, 0]]
+    for _ in range(3):
+        s32.run(one, [0])
+    t0 = time.perf_counter()
+    for _ in range(10):
+        s32.run(one, [0])
+    dt = (time.perf_counter() - t0) / 10
+    out["sensevoice_f32_b1"] = {"what": "SenseVoiceSmall f32 mode (logits within 1e-3 of the reference, tokens equal), one 8 s chunk, host audio in / ids out",
+                                "ms_per_chunk": round(dt * 1e3, 3), "audio_s_per_s": round(n_samples / cfg.sample_rate / dt, 1),
+                                "rtf": round(dt / (n_samples / cfg.sample_rate), 6)}
+    s16 = eng.SenseVoiceSession.from_checkpoint(cfg, ck, precision=arena.PRECISION_BF16, device_id=local_rank)
+    for _ in range(3):
+        s16.run(one, [0])
+    t0 = time.perf_counter()
+    for _ in range(20):
+        s16.run(one, [0])
+    dt = (time.perf_counter() - t0) / 20
+    out["sensevoice_bf16_b1"] = {"ms_per_chunk": round(dt * 1e3, 3), "audio_s_per_s": round(n_samples / cfg.sample_rate / dt, 1),
+                                 "rtf": round(dt / (n_samples / cfg.sample_rate), 6)}
+    del s32, s16
+    # ---- Whisper-large-v3 bf16, 8 s chunks (the other model the metric names)
+    try:
+        wcfg = cfgm.whisper_large_v3()
+        wck = ckm.synth_whisper_checkpoint(wcfg, seed=0)
+        blob = arena.build_whisper_arena(wcfg, wck, arena.PRECISION_BF16, ckm.whisper_suppress_tokens(wcfg), ckm.whisper_begin_suppress_tokens(wcfg))
+        del wck
+        a_dev = torch.from_numpy(blob).to(device)
+        del blob
+        ws = eng.WhisperSession(wcfg, a_dev, arena.PRECISION_BF16, local_rank, arena_device_ptr=a_dev.data_ptr(), arena_bytes=a_dev.numel())
+        n_tok = 32
+        for Bw in (32, 64):
+            wav = torch.from_numpy(ckm.synth_audio("unit", Bw, n_samples, seed=4321)).to(device)
+            offs = np.arange(Bw + 1, dtype=np.int64) * n_samples
+            prompt = np.tile(np.array([[wcfg.sot_id, wcfg.first_language_id, wcfg.transcribe_id, wcfg.no_timestamps_id]], np.int32), (Bw, 1))
+            parts = np.zeros(3)
+            reps = 3
+            for it in range(reps + 2):
+                t0 = time.perf_counter()
+                ws.encode_packed(None, offs, audio_device_ptr=wav.data_ptr())
+                t1 = time.perf_counter()
+                ws.prefill(prompt, want_logits=False)
+                t2 = time.perf_counter()
+                ws.generate(n_tok, eos_id=-1)
+                t3 = time.perf_counter()
+                if it >= 2:
+                    parts += (t1 - t0, t2 - t1, t3 - t2)
+            parts /= reps
+            tot = float(parts.sum())
+            out[f"whisper_large_v3_bf16_b{Bw}x8s"] = {
+                "ms_per_batch": round(tot * 1e3, 2), "audio_s_per_s": round(Bw * n_samples / wcfg.sample_rate / tot, 1),
+                "rtf": round(tot / (Bw * n_samples / wcfg.sample_rate), 7),
+                "ms": {"encode": round(parts[0] * 1e3, 2), "prefill": round(parts[1] * 1e3, 2), "decode": round(parts[2] * 1e3, 2)},
+                "decode_ms_per_token": round(parts[2] / (n_tok - 1) * 1e3, 3), "tokens_per_utterance": n_tok}
+            del wav
+        del ws, a_dev
+    except Exception as e:                                   # a secondary must never take the headline line down
+        out["whisper_large_v3_bf16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
 
 
 def paraformer_algorithmic_flops(cfg, n_samples, n_tokens):

@@ -273,16 +273,6 @@ int asr_op_fsmn(int precision, const float* v, const float* w, const float* b, c
 /* out[M<=64][N] = LayerNorm(x[M][K]; gamma, beta) w[N][K]^T + bias  (bf16 skinny GEMM with the fused LayerNorm prologue) */
 int asr_op_gemm_ln(const float* x, const float* w, const float* bias, const float* gamma, const float* beta, int M, int N, int K,
                    float* out);
-/* Tuning hook: time `iters` launches of the bf16 GEMM on device-resident pseudo-random operands.
- * variant: -1 heuristic, 0..4 kernel variants (csrc/gemm.hip). epilogue: 0 bias->lo, 1 bias+relu->lo,
- * 2 bias+residual->f32, 3 two residual terms->f32, 4 transposed store. */
-int asr_op_gemm_bench(int variant, int M, int N, int K, int epilogue, int iters, float* avg_ms);
-/* tuning hook: microseconds per grid-wide barrier of a cooperative launch with n_workgroups x 512 threads */
-int asr_debug_grid_barrier(int n_workgroups, int iters, float* us_per_barrier);
-/* same probe with a hierarchical barrier (per-XCD arrival counters, relaxed agent-scope atomics, no fence): mode 1 = one release
- * flag, 2 = one flag per XCD; also checks that an sc1 payload written before a barrier is visible after it. mode + 16 * KiB makes
- * every workgroup also read KiB kibibytes of one shared buffer per round through sc1 loads (+ 8: through plain cached loads). */
-int asr_debug_grid_barrier2(int n_workgroups, int iters, int mode, float* us_per_barrier);
 int asr_op_ctc_collapse(const int32_t* frame_ids, const int32_t* seq_lens, int batch, int blank_id, int32_t* token_ids,
                         int max_tokens, int32_t* num_id);
 

@@ -1,0 +1,54 @@
+/* Probe / test hooks of the MI355X ASR engine -- libasr_mi355x_probe.so.
+ *
+ * NOT part of the product C ABI (include/asr_mi355x.h): nothing here is what the reference's onnxruntime binding for the
+ * hot path would call. These entries exist for tests/ (kernel-selection parity at the benchmarked sizes) and tools/
+ * (tuning probes); the product library libasr_mi355x.so does not export them. */
+#ifndef ASR_MI355X_PROBE_H
+#define ASR_MI355X_PROBE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One bf16 GEMM C[M][N] = A[M][K] W[N][K]^T through the product's dispatcher with the epilogues of the batch-64 SANM path.
+ * Operands are rounded to bf16 on upload. Outputs are host arrays; `kernel` receives the kernel family that ran. */
+typedef struct asr_probe_gemm_desc {
+  int32_t M, N, K;
+  const float* a;          /* [M][K] */
+  const float* w;          /* [N][K] */
+  const float* bias;       /* [N] or NULL */
+  const float* add;        /* [M][N] f32 additive term or NULL */
+  int32_t act;             /* 0 none, 1 relu, 2 gelu(erf), 3 gelu(tanh) */
+  int32_t ln;              /* 1: C = LayerNorm_noaffine(bf16(A)) W^T + bias evaluated inside the GEMM (row statistics + column sums) */
+  float ln_eps;
+  int32_t argmax;          /* 1: fused row arg-max over n < n_valid -> out_ids[M] (no matrix output) */
+  int32_t n_valid;
+  int32_t variant;         /* -1 heuristic; 0..7 pins a kernel variant (csrc/gemm.hip) */
+  float* out_lo;           /* [M][N] bf16 results widened to f32, or NULL */
+  float* out_f32;          /* [M][N] f32 results, or NULL */
+  float* out_stats;        /* [M][N/32][2] (sum, sum of squares) of the bf16 outputs per 32-column group, or NULL */
+  int32_t* out_ids;        /* [M] when argmax */
+  char kernel[32];         /* out: "t288w", "t288w_amax", "t144w", "t144", "big", "pipe", "pipe_splitk", "skinny" */
+} asr_probe_gemm_desc;
+int asr_probe_gemm(asr_probe_gemm_desc* d);
+
+/* launches per GEMM kernel family since the last reset, as "family=count;..." (host-side counters: hipGraph replays do not
+ * count, so reset, run a session once on a new batch geometry, read). reset != 0 clears the counters after the read. */
+int asr_probe_gemm_counts(int reset, char* buf, int cap);
+
+/* Tuning hook: time `iters` launches of the bf16 GEMM on device-resident pseudo-random operands.
+ * variant: -1 heuristic, 0..7 kernel variants (csrc/gemm.hip). epilogue: 0 bias->lo, 1 bias+relu->lo,
+ * 2 bias+residual->f32, 3 two residual terms->f32, 4 transposed store, 5 LayerNorm-folded FFN-1, 6 producer epilogue. */
+int asr_probe_gemm_bench(int variant, int M, int N, int K, int epilogue, int iters, float* avg_ms);
+/* microseconds per grid-wide barrier of a cooperative launch with n_workgroups x 512 threads (single counter + __threadfence) */
+int asr_probe_grid_barrier(int n_workgroups, int iters, float* us_per_barrier);
+/* hierarchical barrier (per-XCD arrival counters, relaxed agent-scope atomics, no fence): mode 1 = one release flag, 2 = one flag
+ * per XCD; also checks that an sc1 payload written before a barrier is visible after it. mode + 16 * KiB makes every workgroup
+ * also read KiB kibibytes of one shared buffer per round through sc1 loads (+ 8: through plain cached loads). */
+int asr_probe_grid_barrier2(int n_workgroups, int iters, int mode, float* us_per_barrier);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASR_MI355X_PROBE_H */

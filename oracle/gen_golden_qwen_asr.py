@@ -19,6 +19,7 @@ CASES = [  # (fixture, config, ckpt seed, n_new, [(audio seed, n_samples, query 
                                               (4404, 7000, [], [])]),
     ("qwen_asr_mid", "qwen_asr_mid", 1, 6, [(4411, 128000, [], [77, 540]), (4412, 30000, [40, 41], []), (4413, 200000, [], [78, 540])]),
 ]
+FULL_CASE = ("qwen_asr_0p6b", "qwen_asr_0p6b", 0, 4, [(4421, 128000, [], [77, 540]), (4422, 218080, [40, 41, 42], [])])   # the real 0.6 B geometry, sub-sampled
 
 
 def reference_greedy(ref, cfg, audio, n_new, query_ids, tail_ids):
@@ -128,11 +129,11 @@ def reference_beam(ref, cfg, audio, query_ids, tail_ids, stop_ids):
                 margin=np.float32(min(margins)))
 
 
-def main():
+def main(full=False):
     from oracle import reference_harness as rh
     cfgm = importlib.import_module(PKG + ".config")
     ckm = importlib.import_module(PKG + ".checkpoints")
-    for fixture, cfg_name, ck_seed, n_new, clips in CASES:
+    for fixture, cfg_name, ck_seed, n_new, clips in ([FULL_CASE] if full else CASES):
         cfg = getattr(cfgm, cfg_name)()
         ck = ckm.synth_qwen_asr_checkpoint(cfg, ck_seed)
         ref = rh.build_reference_qwen_asr(cfg, ck, HEAD_IDS, TAIL_IDS, SUFFIX_IDS, max_seq_len=cfg.max_seq_len)
@@ -150,8 +151,12 @@ def main():
             out[p + "audio_hidden"], out[p + "ids_len"], out[p + "logits"], out[p + "token_ids"] = r["audio_hidden"], np.int64(r["ids_len"]), r["logits"], r["token_ids"]
             srt = np.sort(r["logits"], axis=1)
             out[p + "margin"] = (srt[:, -1] - srt[:, -2]).astype(np.float32)
+            if full:                                      # sub-sampled: every 8th audio-embedding column, every 151st vocabulary column + the row maxima
+                out[p + "audio_hidden"] = r["audio_hidden"][:, ::8].copy()
+                out[p + "logits"] = r["logits"][:, ::151].copy()
+                out[p + "top1"] = srt[:, -1].astype(np.float32)
             print(fixture, i, n, "audio tokens", r["audio_hidden"].shape[0], "prompt", r["ids_len"], "tokens", r["token_ids"], "min margin", float(out[p + "margin"].min()))
-            if i < 2:                                     # the other decode heads on two clips per fixture
+            if i < 2 and not full:                        # the other decode heads on two clips per fixture
                 rp_ = reference_heads(ref, cfg, audio, query, tail, "penalty")
                 srt = np.sort(rp_["logits"], axis=1)
                 out[p + "penalty_token_ids"], out[p + "penalty_logits"] = rp_["token_ids"], rp_["logits"][:, ::7].copy()
@@ -171,4 +176,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(full="--full-only" in sys.argv)

@@ -18,7 +18,7 @@ WHISPER_CASES = [
     ("whisper_tiny", "whisper_tiny_test", 0, 6, [(2234, 16000), (2235, 48000), (2236, 7040)]),
     ("whisper_mid", "whisper_mid_test", 0, 5, [(2237, 128000)]),
 ]
-FULL_CASE = ("whisper_large_v3", "whisper_large_v3", 0, 4, [(2238, 128000)])
+FULL_CASE = ("whisper_large_v3", "whisper_large_v3", 0, 4, [(2238, 480000), (2239, 128000)])     # 30 s + 8 s at the real dimensions
 
 
 PENALTY_VALUE, PENALTY_RANGE, PENALTY_STEPS = 0.8, 3, 12      # small range so the window fills inside a short golden
@@ -113,7 +113,7 @@ def gen_whisper(full=False):
     from oracle import reference_harness as rh
     cfgm = importlib.import_module(PKG + ".config")
     ckm = importlib.import_module(PKG + ".checkpoints")
-    cases = list(WHISPER_CASES) + ([FULL_CASE] if full else [])
+    cases = [FULL_CASE] if full == "only" else list(WHISPER_CASES) + ([FULL_CASE] if full else [])
     for fixture, cfg_name, ck_seed, n_new, clips in cases:
         cfg = getattr(cfgm, cfg_name)()
         ck = ckm.synth_whisper_checkpoint(cfg, ck_seed)
@@ -160,4 +160,4 @@ def gen_whisper(full=False):
 
 
 if __name__ == "__main__":
-    gen_whisper(full="--full" in sys.argv)
+    gen_whisper(full="only" if "--full-only" in sys.argv else "--full" in sys.argv)

@@ -27,6 +27,24 @@ def test_library_exports_every_declared_symbol():
     assert loaded.asr_abi_version() == 1
 
 
+def test_probe_library_is_separate_from_the_product_abi():
+    """The tuning / test hooks live in libasr_mi355x_probe.so: every symbol its header declares is exported there,
+    and the product library exports none of them (and declares no probe / debug entry)."""
+    _lib, _probe = sub("_lib"), sub("_probe")
+    if not os.path.isfile(_probe.PROBE_PATH):
+        _lib.build()
+    hdr = open(os.path.join(ROOT, "include", "asr_mi355x_probe.h")).read()
+    declared = set(re.findall(r"\b(asr_probe_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_probe.SIGNATURES), declared ^ set(_probe.SIGNATURES)
+    plib = _probe.load()
+    product = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(plib, name), f"{name} not exported by the probe library"
+        assert not hasattr(product, name), f"{name} leaked into the product library"
+    phdr = open(os.path.join(ROOT, "include", "asr_mi355x.h")).read()
+    assert not re.search(r"asr_(debug|probe)_|gemm_bench", phdr)
+
+
 def test_no_cpu_fallback_without_gpu():
     _lib = sub("_lib")
     if not os.path.isfile(_lib.LIB_PATH):

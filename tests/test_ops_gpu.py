@@ -142,7 +142,8 @@ def test_ctc_collapse_edge_cases():
 
 @pytest.mark.parametrize("M,N,K", [(32, 384, 1280), (7, 128, 256), (64, 256, 5120), (1, 1280, 1280)])
 def test_skinny_gemm_decode_shapes(M, N, K):
-    """M <= 64 rows dispatches to the weight-streaming kernel (8-way K split, LDS reduction)."""
+    """Decode shapes: up to 32 rows stream the weights (skinny kernel: 8-way K split, LDS reduction); 33..64 rows take the tiled
+    split-K pass (activation rows shared across 64 columns)."""
     eng = sub("engine")
     rng = np.random.default_rng(M * N + K)
     a = _bf16_round(rng.standard_normal((M, K), dtype=np.float32) + np.linspace(-1, 1, K, dtype=np.float32)[None, :])
@@ -241,7 +242,7 @@ def test_skinny_split_k_hand_over_is_exact(monkeypatch):
     l0 = base.tap("logits").copy()
     monkeypatch.setenv("ASR_SKINNY_SPLITK", "1")
     monkeypatch.setenv("ASR_SKINNY_M144", "1")
-    # the switches are read once per process: this test asserts reproducibility of whichever path is active, and closeness
+    # the switches are re-read at session creation
     sess = eng.SenseVoiceSession.from_checkpoint(cfg, ck, precision=0)
     sess.taps(True)
     t1 = sess.run(a, [0])
@@ -249,3 +250,95 @@ def test_skinny_split_k_hand_over_is_exact(monkeypatch):
     t2 = sess.run(a, [0])
     assert np.array_equal(t1[0], t2[0]) and np.array_equal(l1, sess.tap("logits"))
     assert np.abs(l1 - l0).max() < 0.2
+
+
+# ---- the kernels the batch-64 headline dispatches to (wide tiles), at the sizes that select them -------------------------------
+def _ln_ref(a, w, bias):
+    x = torch.from_numpy(_bf16_round(a)).double()
+    h = torch.nn.functional.layer_norm(x, (x.shape[1],), None, None, 1e-5).float()
+    return torch.relu(h @ torch.from_numpy(_bf16_round(w)).t() + torch.from_numpy(bias)).numpy()
+
+
+@pytest.mark.parametrize("M,want", [(9216, "t288w"),        # 64 windows of 144 rows: BASELINE configs[1], 32 x 8 = 256 tiles
+                                    (16272, "t288w"),       # 113 windows: 56.5 row tiles -> ragged last 288-row tile
+                                    (13824, "t144w"),       # 96 windows: 384 tiles of 288 x 256 is not whole rounds, 768 of 144 x 256 is
+                                    (1296, "t144")])        # 9 windows: the tiling the small-batch tests already reach
+def test_gemm_layernorm_folded_wide_tiles(M, want):
+    """FFN-1 as the product runs it at batch 64: LayerNorm evaluated inside the GEMM from handed-over row statistics and the column
+    sums of the bf16 weights, bias + ReLU, bf16 store -- through the dispatcher, which must pick the 288 x 256 / 144 x 256 tiles."""
+    probe = sub("_probe")
+    N, K = 2048, 512
+    rng = np.random.default_rng(M)
+    a = (rng.standard_normal((M, K)) * (1.0 + 0.5 * rng.random((M, 1))) + 0.3 * rng.standard_normal((M, 1))).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K) + np.linspace(-0.01, 0.01, N)[:, None]).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) * 0.1
+    out, kern = probe.gemm(a, w, bias, act=1, ln=True)
+    assert kern == want, kern
+    ref = _ln_ref(a, w, bias)
+    err = np.abs(out["lo"] - ref)
+    assert (err <= 2.0 ** -7 * np.abs(ref) + 6e-3).all(), float(err.max())          # bf16 store (2^-8 relative) + f32 summation order
+    # the same product through the 144 x 128 tiles (variant 6): other tiling, other summation order, same function
+    base, kern6 = probe.gemm(a[:2304], w, bias, act=1, ln=True, variant=6)
+    assert kern6 == "t144"
+    assert np.abs(base["lo"] - out["lo"][:2304]).max() < 2e-2
+
+
+@pytest.mark.parametrize("M", [9216, 9353])
+def test_gemm_argmax_wide_tiles(M):
+    """CTC head at batch 64: 288 x 256 tiles with the per-slab arg-max epilogue + reduce; ids must equal the arg-max of the f32
+    product wherever the top-2 margin exceeds the accumulation-order noise, and equal the 128 x 128-tile path's ids there."""
+    probe = sub("_probe")
+    N, K, V = 25088, 512, 25055
+    rng = np.random.default_rng(M)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.5).astype(np.float32)
+    out, kern = probe.gemm(a, w, bias, argmax=True, n_valid=V)
+    assert kern == "t288w_amax", kern
+    z = torch.from_numpy(_bf16_round(a)) @ torch.from_numpy(_bf16_round(w)).t() + torch.from_numpy(bias)
+    z[:, V:] = -np.inf
+    top2 = torch.topk(z, 2, dim=1)
+    safe = (top2.values[:, 0] - top2.values[:, 1]).numpy() > 1e-3
+    assert safe.mean() > 0.99
+    assert np.array_equal(out["ids"][safe], top2.indices[:, 0].numpy()[safe])
+    assert (out["ids"] < V).all()
+    base, kern2 = probe.gemm(a, w, bias, argmax=True, n_valid=V, variant=2)
+    assert kern2 == "pipe"
+    assert np.array_equal(base["ids"][safe], out["ids"][safe])
+
+
+def test_gemm_producer_epilogue_at_batch64():
+    """Out-projection at batch 64 (M = 9216, N = K = 512): additive term, f32 + bf16 stores and the row statistics of the bf16 values
+    (what the LayerNorm-folded consumers read) from the 144-row tiles with the 4-stage ring."""
+    probe = sub("_probe")
+    M, N, K = 9216, 512, 512
+    rng = np.random.default_rng(7)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    add = rng.standard_normal((M, N)).astype(np.float32)
+    out, kern = probe.gemm(a, w, None, add=add, want=("lo", "f32", "stats"))
+    assert kern == "t144", kern
+    ref = (torch.from_numpy(_bf16_round(a)) @ torch.from_numpy(_bf16_round(w)).t()).numpy() + add
+    assert np.abs(out["f32"] - ref).max() < 2e-3 * max(1.0, np.abs(ref).max())
+    assert np.array_equal(out["lo"], _bf16_round(out["f32"]))
+    lo = out["lo"].reshape(M, N // 32, 32).astype(np.float64)
+    assert np.abs(out["stats"][..., 0] - lo.sum(-1)).max() < 1e-3
+    assert np.abs(out["stats"][..., 1] - (lo * lo).sum(-1)).max() < 1e-2
+
+
+def test_skinny_gemm_four_row_tiles(monkeypatch):
+    """33..64 rows: plain GEMMs take the tiled split-K pass by default; ASR_SKINNY_MAX_M=64 keeps them on the weight-streaming
+    kernel's 4-row-tile instance (the one Qwen3-ASR's RMSNorm-folded projections use), which must give the same product."""
+    eng = sub("engine")
+    rng = np.random.default_rng(48)
+    for M, N, K in [(48, 384, 512), (64, 256, 1024)]:
+        a = rng.standard_normal((M, K)).astype(np.float32)
+        w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32)
+        ref = _bf16_round(a).astype(np.float64) @ _bf16_round(w).astype(np.float64).T + b
+        monkeypatch.setenv("ASR_SKINNY_MAX_M", "64")
+        got = eng.op_gemm(a, w, b, act=0, precision=0)
+        monkeypatch.delenv("ASR_SKINNY_MAX_M")
+        tiled = eng.op_gemm(a, w, b, act=0, precision=0)
+        for o in (got, tiled):
+            assert np.abs(o - ref).max() < 2e-3 * max(1.0, np.abs(ref).max())

@@ -96,3 +96,40 @@ def test_long_and_maximum_windows_f32():
                 assert np.array_equal(tok, st["token_ids"])
     with pytest.raises(Exception, match="max_audio_len"):
         sess.run([kaldi_audio(1, cfg.max_audio_len + 160)])
+
+
+def test_batch64_dispatch_vs_small_tile_paths_and_oracle(monkeypatch):
+    """Paraformer-large bf16, 64 x 8 s windows in one batch: the 50 SANM blocks' FFN-1 take the 288 x 256 tiles (a tiling no smaller
+    batch selects). Encoder output and CIF weights of all 64 utterances vs a session with the wide tilings off, token counts and
+    alphas of 3 utterances vs the f32 oracle."""
+    cfg, ck = paraformer_setup("paraformer_large")
+    eng, probe = sub("engine"), sub("_probe")
+    B = 64
+    audios = [kaldi_audio(7400 + i, 128000) for i in range(B)]
+    audios[63] = audios[0].copy()
+    out = {}
+    for wide in ("1", "0"):
+        monkeypatch.setenv("ASR_GEMM_T288W", wide)
+        monkeypatch.setenv("ASR_GEMM_T144W", wide)
+        sess = eng.ParaformerSession.from_checkpoint(cfg, ck, precision=BF16)
+        sess.taps(True)
+        probe.gemm_counts(reset=True)
+        toks = sess.run(audios)
+        out[wide] = (toks, sess.tap("enc_out"), sess.tap("alphas")[:, 0], probe.gemm_counts())
+        rows = sess.utterance_rows([a.size for a in audios])
+        del sess
+    assert out["1"][3].get("t288w", 0) >= cfg.n_enc0 + cfg.n_enc, out["1"][3]          # FFN-1 of every SANM encoder block
+    assert "t288w" not in out["0"][3] and "t144w" not in out["0"][3], out["0"][3]
+    for (r0, T) in rows:
+        assert np.abs(out["1"][1][r0:r0 + T] - out["0"][1][r0:r0 + T]).max() < 0.1
+        assert np.abs(out["1"][2][r0:r0 + T] - out["0"][2][r0:r0 + T]).max() < 0.02
+    (ra, Ta), (rb, _) = rows[0], rows[63]
+    assert np.array_equal(out["1"][1][ra:ra + Ta], out["1"][1][rb:rb + Ta]) and np.array_equal(out["1"][0][0], out["1"][0][63])
+    orc = ParaformerOracle(cfg, ck)
+    for b in (0, 17, 62):
+        r0, T = rows[b]
+        st = orc.stages(audios[b])
+        assert np.abs(out["1"][2][r0:r0 + T] - st["alphas"]).max() < 0.05
+        cs = np.cumsum(np.concatenate([st["alphas"].astype(np.float64), [cfg.tail_threshold]]))
+        if np.min(np.abs(cs - np.round(cs))) > 0.2:
+            assert out["1"][0][b].size == int(st["num_id"][0])

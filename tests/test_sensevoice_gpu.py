@@ -219,3 +219,52 @@ def test_long_and_maximum_windows_mixed_with_short_ones(prec):
         sess.run([kaldi_audio(1, cfg.max_audio_len + 160)], [0])
     with pytest.raises(Exception, match="frame"):
         sess.run([kaldi_audio(1, 399)], [0])
+
+
+def test_batch64_headline_dispatch_vs_small_tile_paths_and_oracle(monkeypatch):
+    """BASELINE.json configs[1] exactly: SenseVoiceSmall bf16, 64 x 8 s windows in one batch. At this size FFN-1 dispatches to the
+    288 x 256 tiles and the CTC head to the 288 x 256 arg-max tiles -- kernels no smaller batch reaches. All 64 utterances are
+    compared with a session that has those tilings switched off (144 x 128 / 128 x 128 tiles: same function, other summation
+    order), 4 of them with the f32 oracle, and a duplicated utterance must give identical rows wherever it sits in the batch."""
+    cfg, ck = sensevoice_setup("sensevoice_small")
+    eng, probe = sub("engine"), sub("_probe")
+    B = 64
+    audios = [kaldi_audio(6400 + i, 128000) for i in range(B)]
+    audios[63] = audios[0].copy()                        # rows 0..143 of a 288-row tile vs rows 144..287 of the last tile
+    langs = [i % 7 for i in range(B)]
+    langs[63] = langs[0]
+    out = {}
+    for wide in ("1", "0"):
+        monkeypatch.setenv("ASR_GEMM_T288W", wide)
+        monkeypatch.setenv("ASR_GEMM_T144W", wide)
+        sess = eng.SenseVoiceSession.from_checkpoint(cfg, ck, precision=BF16)
+        sess.taps(True)
+        probe.gemm_counts(reset=True)
+        toks = sess.run(audios, langs)
+        out[wide] = (toks, sess.tap("logits"), sess.tap("frame_ids", dtype=np.int32)[:, 0], probe.gemm_counts())
+        del sess
+    k1, k0 = out["1"][3], out["0"][3]
+    assert k1.get("t288w", 0) == cfg.n_blocks and k1.get("t288w_amax", 0) == 1, k1      # FFN-1 of every block + the CTC head
+    assert "t288w" not in k0 and "t288w_amax" not in k0 and "t144w" not in k0, k0
+    rows = eng.SenseVoiceSession.from_checkpoint(cfg, ck, precision=BF16).utterance_rows([a.size for a in audios])
+    lg1, lg0, ids1, ids0 = out["1"][1], out["0"][1], out["1"][2], out["0"][2]
+    same = total = 0
+    for (r0, T) in rows:
+        assert np.abs(lg1[r0:r0 + T] - lg0[r0:r0 + T]).max() < 0.12
+        same += int((ids1[r0:r0 + T] == ids0[r0:r0 + T]).sum())
+        total += T
+    assert same / total > 0.97
+    (ra, Ta), (rb, _) = rows[0], rows[63]
+    assert np.array_equal(lg1[ra:ra + Ta], lg1[rb:rb + Ta]) and np.array_equal(out["1"][0][0], out["1"][0][63])
+    orc = SenseVoiceOracle(cfg, ck)
+    agree = n = 0
+    for b in (0, 1, 31, 62):
+        r0, T = rows[b]
+        st = orc.stages(audios[b], langs[b])
+        assert np.abs(lg1[r0:r0 + T] - st["logits"]).max() < 0.25
+        srt = np.sort(st["logits"], axis=1)
+        safe = (srt[:, -1] - srt[:, -2]) > 0.5
+        assert np.array_equal(ids1[r0:r0 + T][safe], st["frame_ids"][safe])
+        agree += int((ids1[r0:r0 + T] == st["frame_ids"]).sum())
+        n += T
+    assert agree / n > 0.85

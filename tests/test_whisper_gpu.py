@@ -20,9 +20,11 @@ def _session(cfg_name, prec):
     return cfg, ck, sup, beg, sess
 
 
-@pytest.mark.parametrize("fixture", ["whisper_tiny", "whisper_mid"])
+@pytest.mark.parametrize("fixture", ["whisper_tiny", "whisper_mid", "whisper_large_v3"])
 def test_f32_mode_matches_reference_goldens(fixture):
-    """One ragged batch: encoder cross-KV, prefill logits, per-step decode logits and greedy ids."""
+    """One ragged batch: encoder cross-KV, prefill logits, per-step decode logits and greedy ids. whisper_large_v3 is the real
+    geometry (d = 1280, 32 + 32 layers, 20 heads, 51866-entry vocabulary) on a 30 s + 8 s ragged batch: BASELINE.json configs[2]'s
+    model, sub-sampled goldens minted from the reference's own classes."""
     g = load_golden(fixture)
     cfg, ck, sup, beg, sess = _session(str(g["cfg_name"]), F32)
     cases = [c for _, c in golden_cases(g)]
@@ -251,3 +253,38 @@ def test_concurrent_sessions_on_separate_streams_match_sequential_runs():
     for k in range(7):
         for b in range(3):
             assert np.array_equal(got[k][b], alone[k % 3][b]), (k, b)
+
+
+def test_large_v3_bf16_batch32x30s_vs_golden_and_oracle():
+    """BASELINE.json configs[2] at its real size: Whisper-large-v3 bf16, 32 x 30 s in one batch, prefill + 3 decode steps. This is the
+    batch that dispatches the 256 x 256 encoder tiles, the 20-head attention over 1500 keys and the skinny / tiled decode GEMMs at
+    K = 1280 / 5120 -- no smaller test reaches them. Utterance 0 (and its duplicate in slot 31) is the 30 s clip of the reference-minted
+    golden; utterance 1 is checked against the f32 oracle run here; the duplicate must match bit for bit (batch invariance)."""
+    g = load_golden("whisper_large_v3")
+    cfg, ck, sup, beg, sess = _session("whisper_large_v3", BF16)
+    c0 = [c for _, c in golden_cases(g)][0]
+    assert int(c0["n_samples"]) == 480000
+    B, n_new = 32, int(g["n_new"])
+    audios = [unit_audio(9000 + i, 480000) for i in range(B)]
+    audios[0] = unit_audio(c0["audio_seed"], c0["n_samples"])
+    audios[31] = audios[0].copy()
+    prompt = c0["prompt"]
+    prompts = np.tile(prompt[None], (B, 1))
+    npos = sess.encode(audios)
+    assert all(int(t) == 1500 for t in npos)
+    # (the cross-K/V slabs of this batch are 7.9 GB: they are pinned at full dimensions by the f32 test above, here through the logits)
+    nxt, logits = sess.prefill(prompts)
+    steps = [logits]
+    for _ in range(n_new - 1):
+        nxt, logits = sess.decode(None, want_logits=True)
+        steps.append(logits)
+    got = np.stack(steps, 1)                                        # (B, n_new, V)
+    assert np.array_equal(got[0], got[31])
+    scale = float(np.abs(c0["top1"]).max())
+    err = np.abs(got[0][:, ::53] - c0["logits"]).max()
+    assert err < 2e-3 * max(scale, 50.0), (err, scale)              # logits are O(100) with these weights: 2e-3 relative
+    assert np.abs(np.sort(got[0], axis=1)[:, -1] - c0["top1"]).max() < 2e-3 * max(scale, 50.0)
+    orc = WhisperOracle(cfg, ck, sup, beg)
+    ref = orc.greedy([audios[1]], [prompt.tolist()], 2)
+    for s in range(2):
+        assert np.abs(got[1][s] - ref["logits"][0][s]).max() < 2e-3 * max(scale, 50.0)

@@ -176,6 +176,29 @@ struct SanmFusedArgs {
   int dbg = 0;
 };
 bool sanm_fused_supported(int max_T, int d_head, int n_heads, int d, int fsmn_taps, int K);
+
+// ---- one whole SANM block per launch (csrc/sanm_block.hip): clusters of four workgroups per <= 144-row window, d = 512, 4 heads of 128,
+// FFN 2048, LayerNorms folded into the projections (bf16 mode). Buffers are the packed row-major activations of the session.
+struct SanmBlockArgs {
+  const bf16_t* wqkv; const float* bqkv; const float* cqkv;      // [1536][512] (LayerNorm affine folded), bias, column sums
+  const float* wfsmn; const float* bfsmn;                          // [512][11], [512] (linear_out.bias rides here)
+  const bf16_t* wout;                                              // [512][512]
+  const bf16_t* w1; const float* b1; const float* c1;              // [2048][512] (LayerNorm affine folded), bias, column sums
+  const bf16_t* w2; const float* b2;                               // [512][2048]
+  const bf16_t* x_lo; const float2* st_in;                         // block input rows (bf16) + their row statistics [rows][16] (null: derived in the kernel)
+  float* x;                                                        // residual stream f32 [rows][512]: read (phase B) and overwritten (phase D) in place
+  bf16_t* x_lo_out; float2* st_out;                                // bf16 copy + row statistics of the block output (may alias x_lo / st_in)
+  bf16_t* ctx; bf16_t* x1_lo; float2* st1; bf16_t* hid;            // exchange buffers: [rows][512], [rows][512], [rows][16], [rows][2048]
+  const UttPlan* plan; int utt0, n_utts;                           // windows utt0 .. utt0 + n_utts - 1 (all <= 144 rows)
+  unsigned* flags;                                                 // [n_utts][4] exchange counters of THIS launch, zeroed beforehand
+  unsigned* err;                                                   // err[0] != 0 after the run: a workgroup gave up waiting for its cluster
+  int n_rows_alloc; float ln_eps; int scatter;                     // scatter != 0: test placement (a cluster spread over four XCDs)
+  unsigned long long* times;                                       // tuning: [workgroups][16] wall-clock stamps (100 MHz) at the phase boundaries, or null
+};
+bool sanm_block_supported(int max_T, int d_head, int n_heads, int d, int d_ffn, int fsmn_taps);
+int sanm_block_max_utts();                                         // windows one launch can take (all workgroups co-resident)
+void launch_sanm_block(const SanmBlockArgs& a, hipStream_t s);
+void launch_rows_to_bf16(const float* x, bf16_t* y, size_t n, hipStream_t s);     // f32 -> bf16 (RNE) copy, n a multiple of 8
 void launch_sanm_qkv_attn(const SanmFusedArgs& a, hipStream_t s);
 
 // ---- FSMN memory: depth-wise conv (k taps, zero padded inside each utterance) over V + bias.

@@ -58,7 +58,7 @@ struct SvSession : asr_session {
   size_t h_out_cap = 0;
 
   ~SvSession() override {
-    for (DeviceBuffer* b : {&d_ctplan, &d_mdev, &d_trow, &d_skws, &d_skcnt, &d_sta, &d_stb, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
+    for (DeviceBuffer* b : {&d_times, &d_flags, &d_ctplan, &d_mdev, &d_trow, &d_skws, &d_skcnt, &d_sta, &d_stb, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
                             &d_x0lo, &d_xalo, &d_xblo, &d_plan, &d_audio, &d_mel, &d_x0, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx, &d_mem, &d_ffn,
                             &d_amax_v, &d_amax_i, &d_ids, &d_tok, &d_num, &d_logits, &d_enc_lo, &d_ck, &d_cifa, &d_alpha, &d_dec, &d_x2,
                             &d_sa, &d_ffn32, &d_tplan})
@@ -84,11 +84,16 @@ struct SvSession : asr_session {
   bool use_graph = true;
   bool use_ln_alg = true;       // LayerNorm evaluated inside the projections from row statistics (ASR_LN_FUSED=0 disables)
   bool use_fused = true;        // fused q|k|v + attention + FSMN kernel for windows of <= 144 rows (ASR_SANM_FUSED=0 disables)
+  bool use_block = true;        // one launch per SANM block (clusters of four workgroups per window; ASR_SANM_BLOCK=0 disables)
+  int block_scatter = 0;        // ASR_SANM_BLOCK_SCATTER=1: test placement, every cluster spread over four XCDs
+  DeviceBuffer d_times; int block_dbg = -1;   // ASR_SANM_BLOCK_DBG=<block index>: phase clock of that block's launch on stderr
+  DeviceBuffer d_flags;         // exchange counters of the block kernel: [n_blocks][batch][4] + the error word at the end
   hipGraphExec_t graph_exec = nullptr;
   uint64_t graph_key = 0, eager_key = 0, ws_epoch = 1;
   hipGraphExec_t st_graph = nullptr; uint64_t st_graph_key = 0, st_eager_key = 0;     // streaming chunk step
 
   void init();
+  void copy_block_status(const struct SvRunCtx& r);   // the block kernel's error word rides home behind the token counts
   template <typename T> void enqueue(const struct SvRunCtx& r);
   template <typename T> void run(const float* audio, int audio_mem, const int64_t* offs, int batch, const int32_t* lang,
                                  int32_t* tok_out, int max_tokens, int32_t* num_out);
@@ -201,6 +206,12 @@ struct SvRunCtx {
   const int32_t *d_blk_utt, *d_blk_f0, *d_qb_utt, *d_qb_q0, *d_row_utt;
 };
 
+void SvSession::copy_block_status(const SvRunCtx& r) {
+  const size_t flag_words = (size_t)cfg.n_blocks * r.batch * 4;
+  HIP_CHECK(hipMemcpyAsync((unsigned char*)h_out + (size_t)r.batch * r.max_tokens * 4 + (size_t)r.batch * 4, d_flags.as<unsigned>() + flag_words, 4,
+                           hipMemcpyDeviceToHost, stream));
+}
+
 template <typename T>
 void SvSession::enqueue(const SvRunCtx& r) {
   const auto& c = cfg;
@@ -248,6 +259,14 @@ void SvSession::enqueue(const SvRunCtx& r) {
   save_tap("enc_in", d_x0.ptr, rows, feat, kpad0, 4);
 
   // ---- 4. SANM blocks (Export_SenseVoice.py:227-269) ---------------------------------------
+  // one launch per block (csrc/sanm_block.hip) when every window fits a 144-row tile and the LayerNorms are folded into the projections
+  // (it has its own tiling, so unlike `alg` it does not need batches of near-full windows: ragged batches qualify too)
+  bool blk = false;
+  if constexpr (sizeof(T) == 2)
+    blk = use_block && use_ln_alg && use_fused && blocks[c.n_blocks - 1].cqkv && blocks[c.n_blocks - 1].c1 && c.n_blocks > 1 &&
+          sanm_block_supported(r.max_T, c.d_head, c.n_heads, d, dff, c.fsmn_kernel);
+  const size_t flag_words = (size_t)c.n_blocks * r.batch * 4;
+  HIP_CHECK(hipMemsetAsync(d_flags.ptr, 0, (flag_words + 4) * 4, stream));      // per (block, window, exchange) counters + the error word
   const float* x_in = d_x0.as<float>();
   const bf16_t* x_in_lo = x0lo;
   const float2* st_in = nullptr;            // statistics of x_in_lo's rows when its producer wrote them
@@ -264,6 +283,36 @@ void SvSession::enqueue(const SvRunCtx& r) {
   T* ffn = d_ffn.as<T>();
   for (int i = 0; i < c.n_blocks; ++i) {
     const SvBlock& b = blocks[i];
+    if constexpr (sizeof(T) == 2) {
+      if (blk && b.in_size == d && x_in == xa) {             // (block 0 maps 560 -> 512 without a residual: it keeps the separate launches)
+        if (!alg && i == 1) {                                // block 0 ran without the bf16 copy / statistics outputs: make the copy, derive the statistics in the kernel
+          ProfScope ps0(prof, "layernorm", stream);
+          launch_rows_to_bf16(xa, xalo, (size_t)Mpad * d, stream);
+          st_in = nullptr;
+        }
+        const int per = sanm_block_max_utts();
+        for (int u0 = 0; u0 < r.batch; u0 += per) {
+          ProfScope ps(prof, "sanm_block", stream);
+          SanmBlockArgs ba{};
+          ba.wqkv = (const bf16_t*)b.wqkv; ba.bqkv = b.bqkv; ba.cqkv = b.cqkv; ba.wfsmn = b.wfsmn; ba.bfsmn = b.bfsmn;
+          ba.wout = (const bf16_t*)b.wout; ba.w1 = (const bf16_t*)b.w1; ba.b1 = b.b1; ba.c1 = b.c1; ba.w2 = (const bf16_t*)b.w2; ba.b2 = b.b2;
+          ba.x_lo = xalo; ba.st_in = st_in; ba.x = xa; ba.x_lo_out = xalo; ba.st_out = sta;
+          ba.ctx = (bf16_t*)ctx; ba.x1_lo = xblo; ba.st1 = stb; ba.hid = (bf16_t*)ffn;
+          ba.plan = r.dp; ba.utt0 = u0; ba.n_utts = std::min(per, r.batch - u0);
+          ba.flags = d_flags.as<unsigned>() + ((size_t)i * r.batch + u0) * 4; ba.err = d_flags.as<unsigned>() + flag_words;
+          ba.n_rows_alloc = Mpad; ba.ln_eps = 1e-5f; ba.scatter = block_scatter;
+          if (i == block_dbg && u0 == 0) { d_times.reserve(256 * 16 * 8, stream); HIP_CHECK(hipMemsetAsync(d_times.ptr, 0, 256 * 16 * 8, stream)); ba.times = d_times.as<unsigned long long>(); }
+          launch_sanm_block(ba, stream);
+        }
+        st_in = sta;
+        if (i == c.n_main - 1 && !paraformer) {
+          ProfScope ps2(prof, "layernorm", stream);
+          launch_layernorm<bf16_t>(xa, d, rows, d, after_g, after_b, 1e-5f, xalo, d, d, stream); st_in = nullptr;
+          launch_layernorm<float>(xa, d, rows, d, after_g, after_b, 1e-5f, xa, d, d, stream);
+        }
+        continue;
+      }
+    }
     if (!alg) {
       ProfScope ps(prof, "layernorm", stream);
       launch_layernorm<T>(x_in, ld_in, rows, b.in_size, b.ln1_g, b.ln1_b, 1e-5f, h, b.kpad, b.kpad, stream);
@@ -345,7 +394,7 @@ void SvSession::enqueue(const SvRunCtx& r) {
       launch_layernorm<float>(xa, d, rows, d, after_g, after_b, 1e-5f, xa, d, d, stream);
     }
   }
-  if (paraformer) { enqueue_paraformer_tail<T>(r); return; }
+  if (paraformer) { copy_block_status(r); enqueue_paraformer_tail<T>(r); return; }
   // tp_norm -> operand dtype for the CTC GEMM (f32 copy kept only for the tap)
   if (taps_enabled) {
     launch_layernorm<float>(xa, d, rows, d, tp_g, tp_b, 1e-5f, xb, d, d, stream);
@@ -377,6 +426,7 @@ void SvSession::enqueue(const SvRunCtx& r) {
   HIP_CHECK(hipMemcpyAsync(h_out, d_tok.ptr, (size_t)r.batch * r.max_tokens * 4, hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipMemcpyAsync((unsigned char*)h_out + (size_t)r.batch * r.max_tokens * 4, d_num.ptr, (size_t)r.batch * 4,
                            hipMemcpyDeviceToHost, stream));
+  copy_block_status(r);
 }
 
 
@@ -590,6 +640,7 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   grow(d_amax_v, (size_t)Mpad * n_slabs * 4);
   grow(d_amax_i, (size_t)Mpad * n_slabs * 4);
   grow(d_ids, (size_t)Mpad * 4);
+  grow(d_flags, ((size_t)c.n_blocks * batch * 4 + 4) * 4);
   grow(d_tok, (size_t)batch * max_tokens * 4);
   grow(d_num, (size_t)batch * 4);
   if (taps_enabled) grow(d_logits, (size_t)Mpad * vpad * 4);
@@ -609,7 +660,7 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
     grow(d_mdev, 256);
     grow(d_trow, (size_t)Mpad * 4);
   }
-  const size_t out_bytes = (size_t)batch * max_tokens * 4 + (size_t)batch * 4;
+  const size_t out_bytes = (size_t)batch * max_tokens * 4 + (size_t)batch * 4 + 16;
   if (out_bytes > h_out_cap) {
     if (h_out) HIP_CHECK(hipHostFree(h_out));
     HIP_CHECK(hipHostMalloc(&h_out, out_bytes * 2, hipHostMallocDefault));
@@ -661,6 +712,30 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   }
   HIP_CHECK(hipStreamSynchronize(stream));
   if (prof.enabled) prof.collect();
+  if (block_dbg >= 0 && d_times.ptr) {
+    std::vector<unsigned long long> t(256 * 16);
+    HIP_CHECK(hipMemcpy(t.data(), d_times.ptr, t.size() * 8, hipMemcpyDeviceToHost));
+    static const char* names[13] = {"A loop", "images+attention", "ctx store+publish", "fsmn", "wait 0", "B loop", "B epilogue+publish", "wait 1", "C (both halves)", "publish 2",
+                                    "wait 2", "D loop", "D epilogue"};
+    unsigned long long t_first = ~0ull, t_last = 0;
+    int n = 0;
+    double sum[13] = {0}, mx[13] = {0};
+    for (int w = 0; w < 256; ++w) {
+      if (!t[w * 16]) continue;
+      ++n;
+      t_first = std::min(t_first, t[w * 16]); t_last = std::max(t_last, t[w * 16 + 13]);
+      for (int k = 0; k < 13; ++k) { const double us = (double)(t[w * 16 + k + 1] - t[w * 16 + k]) * 0.01; sum[k] += us; mx[k] = std::max(mx[k], us); }
+    }
+    if (n) {
+      fprintf(stderr, "[sanm_block %d] %d workgroups, first start -> last end %.1f us\n", block_dbg, n, (double)(t_last - t_first) * 0.01);
+      for (int k = 0; k < 13; ++k) fprintf(stderr, "  %-22s avg %6.2f us  max %6.2f us\n", names[k], sum[k] / n, mx[k]);
+    }
+  }
+  {
+    unsigned blk_err = 0;
+    memcpy(&blk_err, (unsigned char*)h_out + (size_t)batch * max_tokens * 4 + (size_t)batch * 4, 4);
+    ASR_REQUIRE(blk_err == 0, "sensevoice: a SANM block workgroup gave up waiting for its cluster (results are invalid)");
+  }
   memcpy(num_out, (unsigned char*)h_out + (size_t)batch * max_tokens * 4, (size_t)batch * 4);
   const int32_t* ht = (const int32_t*)h_out;
   for (int b = 0; b < batch; ++b) {
@@ -1026,6 +1101,9 @@ extern "C" int asr_sensevoice_create(const asr_sensevoice_config* cfg, const voi
       gemm_reload_env();
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       if (const char* e = getenv("ASR_SANM_FUSED")) s->use_fused = !(e[0] == '0');
+      if (const char* e = getenv("ASR_SANM_BLOCK")) s->use_block = !(e[0] == '0');
+      if (const char* e = getenv("ASR_SANM_BLOCK_SCATTER")) s->block_scatter = e[0] == '1';
+      if (const char* e = getenv("ASR_SANM_BLOCK_DBG")) s->block_dbg = atoi(e);
       if (const char* e = getenv("ASR_LN_FUSED")) s->use_ln_alg = !(e[0] == '0');
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;
@@ -1082,6 +1160,9 @@ extern "C" int asr_paraformer_create(const asr_paraformer_config* cfg, const voi
       gemm_reload_env();
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       if (const char* e = getenv("ASR_SANM_FUSED")) s->use_fused = !(e[0] == '0');
+      if (const char* e = getenv("ASR_SANM_BLOCK")) s->use_block = !(e[0] == '0');
+      if (const char* e = getenv("ASR_SANM_BLOCK_SCATTER")) s->block_scatter = e[0] == '1';
+      if (const char* e = getenv("ASR_SANM_BLOCK_DBG")) s->block_dbg = atoi(e);
       if (const char* e = getenv("ASR_LN_FUSED")) s->use_ln_alg = !(e[0] == '0');
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;

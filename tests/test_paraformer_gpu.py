@@ -108,6 +108,7 @@ def test_batch64_dispatch_vs_small_tile_paths_and_oracle(monkeypatch):
     audios = [kaldi_audio(7400 + i, 128000) for i in range(B)]
     audios[63] = audios[0].copy()
     out = {}
+    monkeypatch.setenv("ASR_SANM_BLOCK", "0")                  # the four-launch path (the block kernel has its own test below)
     for wide in ("1", "0"):
         monkeypatch.setenv("ASR_GEMM_T288W", wide)
         monkeypatch.setenv("ASR_GEMM_T144W", wide)
@@ -133,3 +134,31 @@ def test_batch64_dispatch_vs_small_tile_paths_and_oracle(monkeypatch):
         cs = np.cumsum(np.concatenate([st["alphas"].astype(np.float64), [cfg.tail_threshold]]))
         if np.min(np.abs(cs - np.round(cs))) > 0.2:
             assert out["1"][0][b].size == int(st["num_id"][0])
+
+
+def test_block_kernel_equals_separate_launches(monkeypatch):
+    """Paraformer-large bf16, 64 x 8 s + a ragged tail: one launch per SANM encoder block (the default) vs the four-launch path."""
+    cfg, ck = paraformer_setup("paraformer_large")
+    eng = sub("engine")
+    lens = [128000] * 64 + [38880, 16000, 127000]
+    audios = [kaldi_audio(7600 + i, n) for i, n in enumerate(lens)]
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ASR_SANM_BLOCK", flag)
+        sess = eng.ParaformerSession.from_checkpoint(cfg, ck, precision=BF16)
+        sess.taps(True)
+        toks = sess.run(audios)
+        out[flag] = (toks, sess.tap("enc_out"), sess.tap("alphas")[:, 0])
+        sess.taps(False)
+        sess.profile(True)
+        sess.profile_reset()
+        sess.run(audios)
+        prof = sess.profile_read()
+        assert ("sanm_block" in prof) == (flag == "1")
+        if flag == "1":
+            assert prof["sanm_block"]["launches"] == 2 * (cfg.n_enc0 + cfg.n_enc - 1)      # 67 windows: two launches of <= 64 per block
+        rows = sess.utterance_rows(lens)
+        del sess
+    for (r0, T) in rows:
+        assert np.abs(out["1"][1][r0:r0 + T] - out["0"][1][r0:r0 + T]).max() < 0.1
+        assert np.abs(out["1"][2][r0:r0 + T] - out["0"][2][r0:r0 + T]).max() < 0.02

@@ -222,49 +222,105 @@ def test_long_and_maximum_windows_mixed_with_short_ones(prec):
 
 
 def test_batch64_headline_dispatch_vs_small_tile_paths_and_oracle(monkeypatch):
-    """BASELINE.json configs[1] exactly: SenseVoiceSmall bf16, 64 x 8 s windows in one batch. At this size FFN-1 dispatches to the
-    288 x 256 tiles and the CTC head to the 288 x 256 arg-max tiles -- kernels no smaller batch reaches. All 64 utterances are
-    compared with a session that has those tilings switched off (144 x 128 / 128 x 128 tiles: same function, other summation
-    order), 4 of them with the f32 oracle, and a duplicated utterance must give identical rows wherever it sits in the batch."""
+    """BASELINE.json configs[1] exactly: SenseVoiceSmall bf16, 64 x 8 s windows in one batch, three ways:
+      block  the default: one launch per SANM block (clusters of four workgroups per window, csrc/sanm_block.hip) + 288 x 256 CTC tiles
+      wide   ASR_SANM_BLOCK=0: four launches per block, FFN-1 on the 288 x 256 tiles (round 1's headline path)
+      small  ... and the wide tilings off too (144 x 128 / 128 x 128 tiles)
+    -- kernels no smaller batch dispatches. All 64 utterances are compared across the three (same function, other summation
+    orders), 4 of them with the f32 oracle, and a duplicated utterance must give identical rows wherever it sits in the batch."""
     cfg, ck = sensevoice_setup("sensevoice_small")
     eng, probe = sub("engine"), sub("_probe")
     B = 64
     audios = [kaldi_audio(6400 + i, 128000) for i in range(B)]
-    audios[63] = audios[0].copy()                        # rows 0..143 of a 288-row tile vs rows 144..287 of the last tile
+    audios[63] = audios[0].copy()                        # first window of the first cluster group vs last window of the last
     langs = [i % 7 for i in range(B)]
     langs[63] = langs[0]
     out = {}
-    for wide in ("1", "0"):
-        monkeypatch.setenv("ASR_GEMM_T288W", wide)
-        monkeypatch.setenv("ASR_GEMM_T144W", wide)
+    for mode, env in (("block", {}), ("wide", {"ASR_SANM_BLOCK": "0"}), ("small", {"ASR_SANM_BLOCK": "0", "ASR_GEMM_T288W": "0", "ASR_GEMM_T144W": "0"})):
+        for k in ("ASR_SANM_BLOCK", "ASR_GEMM_T288W", "ASR_GEMM_T144W"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         sess = eng.SenseVoiceSession.from_checkpoint(cfg, ck, precision=BF16)
         sess.taps(True)
-        probe.gemm_counts(reset=True)
         toks = sess.run(audios, langs)
-        out[wide] = (toks, sess.tap("logits"), sess.tap("frame_ids", dtype=np.int32)[:, 0], probe.gemm_counts())
+        lg, ids = sess.tap("logits"), sess.tap("frame_ids", dtype=np.int32)[:, 0]
+        sess.taps(False)                                 # (with the logits tap on, the CTC head keeps an f32 output and takes other tiles)
+        sess.profile(True)
+        sess.profile_reset()
+        probe.gemm_counts(reset=True)
+        sess.run(audios, langs)
+        counts = probe.gemm_counts()
+        out[mode] = (toks, lg, ids, counts, sess.profile_read())
+        rows = sess.utterance_rows([a.size for a in audios])
         del sess
-    k1, k0 = out["1"][3], out["0"][3]
-    assert k1.get("t288w", 0) == cfg.n_blocks and k1.get("t288w_amax", 0) == 1, k1      # FFN-1 of every block + the CTC head
+    assert out["block"][4]["sanm_block"]["launches"] == cfg.n_blocks - 1 and out["block"][3].get("t288w_amax", 0) == 1, (out["block"][3], list(out["block"][4]))
+    assert "sanm_block" not in out["wide"][4] and out["wide"][3].get("t288w", 0) == cfg.n_blocks and out["wide"][3].get("t288w_amax", 0) == 1, out["wide"][3]
+    k0 = out["small"][3]
     assert "t288w" not in k0 and "t288w_amax" not in k0 and "t144w" not in k0, k0
-    rows = eng.SenseVoiceSession.from_checkpoint(cfg, ck, precision=BF16).utterance_rows([a.size for a in audios])
-    lg1, lg0, ids1, ids0 = out["1"][1], out["0"][1], out["1"][2], out["0"][2]
-    same = total = 0
-    for (r0, T) in rows:
-        assert np.abs(lg1[r0:r0 + T] - lg0[r0:r0 + T]).max() < 0.12
-        same += int((ids1[r0:r0 + T] == ids0[r0:r0 + T]).sum())
-        total += T
-    assert same / total > 0.97
+    for other in ("wide", "small"):
+        same = total = 0
+        for (r0, T) in rows:
+            assert np.abs(out["block"][1][r0:r0 + T] - out[other][1][r0:r0 + T]).max() < 0.12, other
+            same += int((out["block"][2][r0:r0 + T] == out[other][2][r0:r0 + T]).sum())
+            total += T
+        assert same / total > 0.97, (other, same / total)
     (ra, Ta), (rb, _) = rows[0], rows[63]
-    assert np.array_equal(lg1[ra:ra + Ta], lg1[rb:rb + Ta]) and np.array_equal(out["1"][0][0], out["1"][0][63])
+    for mode in ("block", "wide"):
+        assert np.array_equal(out[mode][1][ra:ra + Ta], out[mode][1][rb:rb + Ta]) and np.array_equal(out[mode][0][0], out[mode][0][63]), mode
     orc = SenseVoiceOracle(cfg, ck)
     agree = n = 0
     for b in (0, 1, 31, 62):
         r0, T = rows[b]
         st = orc.stages(audios[b], langs[b])
-        assert np.abs(lg1[r0:r0 + T] - st["logits"]).max() < 0.25
         srt = np.sort(st["logits"], axis=1)
         safe = (srt[:, -1] - srt[:, -2]) > 0.5
-        assert np.array_equal(ids1[r0:r0 + T][safe], st["frame_ids"][safe])
-        agree += int((ids1[r0:r0 + T] == st["frame_ids"]).sum())
+        for mode in ("block", "wide"):
+            assert np.abs(out[mode][1][r0:r0 + T] - st["logits"]).max() < 0.25, mode
+            assert np.array_equal(out[mode][2][r0:r0 + T][safe], st["frame_ids"][safe]), mode
+        agree += int((out["block"][2][r0:r0 + T] == st["frame_ids"]).sum())
         n += T
     assert agree / n > 0.85
+
+
+@pytest.mark.parametrize("scatter", ["0", "1"])
+def test_block_kernel_equals_separate_launches_ragged(monkeypatch, scatter):
+    """One launch per SANM block vs the four-launch path on a RAGGED batch (T = 137, 44, 136, 20, 12, 137, 1 + 4 prompt rows ...):
+    windows with fewer active row fragments, a window count that is not a multiple of 8 (idle cluster slots), and -- scatter = 1 --
+    every cluster deliberately spread over four XCDs: the exchange protocol (write-through payload, relaxed flag, one acquire) must
+    not depend on where the four workgroups of a window run."""
+    cfg, ck = sensevoice_setup("sensevoice_small")
+    eng = sub("engine")
+    lens = [128000, 38880, 127000, 16000, 7777, 128000, 400, 64000, 100000, 128000, 3000]
+    audios = [kaldi_audio(300 + i, n) for i, n in enumerate(lens)]
+    audios[9] = audios[0].copy()
+    langs = [i % 7 for i in range(len(lens))]
+    langs[9] = langs[0]
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ASR_SANM_BLOCK", flag)
+        monkeypatch.setenv("ASR_SANM_BLOCK_SCATTER", scatter)
+        sess = eng.SenseVoiceSession.from_checkpoint(cfg, ck, precision=BF16)
+        sess.taps(True)
+        toks = sess.run(audios, langs)
+        b0, lg = sess.tap("block0"), sess.tap("logits")
+        sess.taps(False)
+        t2 = sess.run(audios, langs)                      # eager again, then the captured graph
+        t3 = sess.run(audios, langs)
+        for x, y, z in zip(toks, t2, t3):
+            assert np.array_equal(x, y) and np.array_equal(y, z)
+        sess.profile(True)
+        sess.profile_reset()
+        sess.run(audios, langs)
+        out[flag] = (toks, b0, lg, set(sess.profile_read()))
+    assert "sanm_block" in out["1"][3] and "sanm_block" not in out["0"][3]
+    rows = sess.utterance_rows(lens)
+    same = total = 0
+    for (r0, T) in rows:
+        assert np.array_equal(out["1"][1][r0:r0 + T], out["0"][1][r0:r0 + T])                # block 0 takes the separate launches either way
+        assert np.abs(out["1"][2][r0:r0 + T] - out["0"][2][r0:r0 + T]).max() < 0.12          # logits after 69 block launches
+        same += int((out["1"][2][r0:r0 + T].argmax(1) == out["0"][2][r0:r0 + T].argmax(1)).sum())
+        total += T
+    assert same / total > 0.97
+    (ra, Ta), (rb, _) = rows[0], rows[9]
+    assert np.array_equal(out["1"][2][ra:ra + Ta], out["1"][2][rb:rb + Ta])

@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""Real-checkpoint transcript harness: wav files + a converted model folder -> a token dump, and a
+comparator for two dumps -- the piece that closes "token-for-token against the reference's ONNX CPUExecutionProvider run" on a
+machine that has the checkpoints (none exist offline; tests/test_transcribe_cpu.py round-trips synthetic models through it).
+
+    # 1. once: checkpoint -> model folder
+    python tools/convert_checkpoint.py --family whisper --checkpoint model.safetensors --out Whisper_MI355X
+    # 2. on the MI355X: wavs -> ours.json
+    python tools/transcribe.py run --family whisper --model Whisper_MI355X --tokenizer whisper-large-v3/ --language en \
+        --wav Test_Examples/en/test_sample.wav Test_Examples/zh/zh_1.wav --precision f32 --out ours.json
+    # 3. on any box with onnxruntime + the exported graphs: make the reference dump (same schema; `reference-stub` prints the few
+    #    lines to paste at the end of Inference_*_ONNX.py), then
+    python tools/transcribe.py compare ours.json reference.json
+
+Dump schema: {"family", "precision", "files": [{"path", "n_samples", "language", "windows": [[token ids], ...], "text"}]}.
+Audio ingest = audio_io.read_wav_int16 (the reference's pydub calls restated on stdlib wave / audioop); detokenisation: SentencePiece
+(SenseVoice, :305), vocabulary join (Paraformer), `tokenizer._decode_asr` (Whisper, Inference_Whisper_ONNX.py:702-715),
+`tokenizer.decode(..., skip_special_tokens=True)` + parse_asr_output (Qwen3-ASR, Inference_Qwen_ASR_ONNX.py:746-752) -- each only
+when a tokenizer is given; the token ids are what is compared.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "automatic-speech-recognition-asr-onnx_amd"
+
+
+def _m(name):
+    return importlib.import_module(f"{PKG}.{name}")
+
+
+def whisper_text(tokenizer, ids, remove_repeats=True):
+    """Inference_Whisper_ONNX.py:702-715: tail-repeat guard, then the HF tokenizer's ASR decoder."""
+    arr = np.asarray(ids, dtype=np.int64)
+    if remove_repeats:
+        arr = np.asarray(_m("whisper").remove_repeated_parts(arr.tolist(), 3, arr.shape[-1]), dtype=np.int64)
+    text, _ = tokenizer._decode_asr([{"tokens": arr.reshape(1, -1)}], return_timestamps=None, return_language=None, time_precision=0)
+    return text
+
+
+def run(a) -> dict:
+    shim, eng, audio_io, cfgm = _m("ort_shim"), _m("engine"), _m("audio_io"), _m("config")
+    prec = 0 if a.precision == "bf16" else 1
+    files = []
+    if a.family in ("sensevoice", "paraformer"):
+        mod = _m(a.family)
+        if a.family == "sensevoice":
+            tr = mod.SenseVoiceTranscriber(a.model, target_language=a.language, tokenizer_path=a.tokenizer, device_type="cuda")
+        else:
+            tr = mod.ParaformerTranscriber(a.model, vocab_path=a.tokenizer, device_type="cuda")
+        for p in a.wav:
+            pcm = audio_io.read_wav_int16(p, tr.sample_rate)
+            r = tr.transcribe(pcm, sliding_window=a.sliding_window)
+            files.append({"path": p, "n_samples": int(pcm.size), "language": r.get("language", a.language),
+                          "windows": [np.asarray(w).reshape(-1).astype(int).tolist() for w in r["token_ids"]], "text": r.get("text"), "rtf": r["rtf"]})
+    elif a.family == "whisper":
+        info, blob = shim.load_model(os.path.join(a.model, "Whisper.asrmodel"))
+        cfg = cfgm.WhisperConfig(**info["config"])
+        ckm = _m("checkpoints")
+        sess = eng.WhisperSession(cfg, blob, int(info.get("precision", prec)))
+        tok = None
+        if a.tokenizer:
+            from transformers import AutoTokenizer
+            tok = AutoTokenizer.from_pretrained(a.tokenizer)
+        tr = _m("whisper").WhisperTranscriber(cfg, sess, suppress_tokens=ckm.whisper_suppress_tokens(cfg), detect_language=a.language == "auto",
+                                              repeat_penalty=a.repeat_penalty)
+        lang_id = None
+        if a.language != "auto":
+            if tok is None:
+                raise SystemExit("--language other than 'auto' needs --tokenizer (language token ids come from its vocabulary)")
+            lang_id = tok.convert_tokens_to_ids(f"<|{a.language}|>")
+        window = cfg.max_audio_len
+        for p in a.wav:
+            pcm = audio_io.read_wav_int16(p, cfg.sample_rate)
+            clips = [pcm[s:s + window] for s in range(0, max(pcm.size, 1), window)]
+            out, stat = tr.transcribe(clips, language_ids=None if lang_id is None else [lang_id] * len(clips))
+            ids = [o["tokens"].astype(int).tolist() for o in out]
+            text = "".join(whisper_text(tok, i) for i in ids if i) if tok is not None else None
+            files.append({"path": p, "n_samples": int(pcm.size), "language": a.language, "windows": ids, "text": text, "rtf": stat["rtf"],
+                          "language_ids": [o["language_id"] for o in out], "no_speech_prob": [o["no_speech_prob"] for o in out]})
+    elif a.family == "qwen_asr":
+        info, blob = shim.load_model(os.path.join(a.model, "Qwen_ASR.asrmodel"))
+        cfg = cfgm.QwenAsrConfig(**info["config"])
+        sess = eng.QwenAsrSession(cfg, blob, int(info.get("precision", prec)))
+        tok = None
+        if a.tokenizer:
+            from transformers import AutoTokenizer
+            tok = AutoTokenizer.from_pretrained(a.tokenizer)
+        tr = _m("qwen_asr").QwenAsrTranscriber(cfg, sess, info["metadata"], tokenizer=tok, repeat_penalty=a.repeat_penalty, beam_size=a.beam)
+        for p in a.wav:
+            pcm = audio_io.read_wav_int16(p, cfg.sample_rate)
+            out, stat = tr.transcribe([pcm], language_prompts=("" if a.language == "auto" else a.language,))
+            r = out[0]
+            files.append({"path": p, "n_samples": int(pcm.size), "language": r.get("language") or a.language,
+                          "windows": [np.asarray(r["tokens"]).astype(int).tolist()], "text": r.get("text"), "rtf": stat["rtf"]})
+    else:
+        raise SystemExit(a.family)
+    return {"family": a.family, "precision": a.precision, "engine": "automatic-speech-recognition-asr-onnx_amd (MI355X)", "files": files}
+
+
+def compare(ours: dict, ref: dict) -> dict:
+    """Token-for-token comparison of two dumps, file by file and window by window (files are matched by base name)."""
+    by_name = {os.path.basename(f["path"]): f for f in ref["files"]}
+    rep, ok = [], True
+    for f in ours["files"]:
+        name = os.path.basename(f["path"])
+        g = by_name.get(name)
+        if g is None:
+            rep.append({"file": name, "status": "missing in reference"})
+            ok = False
+            continue
+        wa, wb = f["windows"], g["windows"]
+        item = {"file": name, "windows": len(wa), "reference_windows": len(wb), "mismatches": []}
+        if len(wa) != len(wb):
+            ok = False
+        for i, (x, y) in enumerate(zip(wa, wb)):
+            if list(x) != list(y):
+                ok = False
+                first = next((k for k, (p, q) in enumerate(zip(x, y)) if p != q), min(len(x), len(y)))
+                item["mismatches"].append({"window": i, "first_difference_at": first, "ours": list(x)[first:first + 8], "reference": list(y)[first:first + 8],
+                                           "len_ours": len(x), "len_reference": len(y)})
+        item["status"] = "equal" if not item["mismatches"] and len(wa) == len(wb) else "DIFFERENT"
+        if f.get("text") is not None and g.get("text") is not None:
+            item["text_equal"] = f["text"] == g["text"]
+        rep.append(item)
+    return {"token_for_token": ok, "files": rep}
+
+
+REFERENCE_STUB = '''# paste at the end of the reference's Inference_<Family>_ONNX.py (after its transcription loop) to write the dump
+# `tools/transcribe.py compare` reads; `all_windows` = the per-window id lists the script already collects.
+import json
+json.dump({"family": "<family>", "precision": "f32", "engine": "onnxruntime CPUExecutionProvider",
+           "files": [{"path": test_audio, "n_samples": int(audio_len), "language": LANGUAGE,
+                      "windows": [[int(t) for t in w] for w in all_windows], "text": text}]},
+          open("reference.json", "w"), ensure_ascii=False, indent=1)
+'''
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    r = sub.add_parser("run")
+    r.add_argument("--family", required=True, choices=("sensevoice", "paraformer", "whisper", "qwen_asr"))
+    r.add_argument("--model", required=True, help="folder written by tools/convert_checkpoint.py")
+    r.add_argument("--wav", nargs="+", required=True)
+    r.add_argument("--language", default="auto")
+    r.add_argument("--tokenizer", help="SentencePiece model (SenseVoice), vocabulary file (Paraformer) or HF tokenizer directory (Whisper / Qwen3-ASR)")
+    r.add_argument("--precision", default="f32", choices=("bf16", "f32"), help="f32 = verification mode (the mode whose tokens equal the reference's)")
+    r.add_argument("--sliding-window", type=int, default=0)
+    r.add_argument("--repeat-penalty", type=float, default=1.0, help="1.0 = plain greedy (the comparison default); the reference scripts default to 0.8")
+    r.add_argument("--beam", type=int, default=1)
+    r.add_argument("--out", required=True)
+    c = sub.add_parser("compare")
+    c.add_argument("ours")
+    c.add_argument("reference")
+    sub.add_parser("reference-stub")
+    a = ap.parse_args()
+    if a.cmd == "run":
+        dump = run(a)
+        with open(a.out, "w", encoding="utf-8") as f:
+            json.dump(dump, f, ensure_ascii=False, indent=1)
+        print(f"wrote {a.out}: {sum(len(x['windows']) for x in dump['files'])} windows over {len(dump['files'])} files")
+    elif a.cmd == "compare":
+        rep = compare(json.load(open(a.ours, encoding="utf-8")), json.load(open(a.reference, encoding="utf-8")))
+        print(json.dumps(rep, ensure_ascii=False, indent=1))
+        sys.exit(0 if rep["token_for_token"] else 1)
+    else:
+        print(REFERENCE_STUB)
+
+
+if __name__ == "__main__":
+    main()

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_by
   const int rg = wave >> 2, cg = wave & 3;
   STAMP(0);
 
+  f32x4_t xpre[3][2];                                      // this lane's part of the f32 residual slab, requested while the FSMN runs
   // ================================================================ phase A: q|k|v projection of head h, attention, FSMN
   {
     const int grp = wave >> 2, sub = wave & 3;              // grp: 0 q, 1 k, 2 v
@@ -505,6 +506,13 @@ __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_by
     }
     publish(flags + 0);
     STAMP(3);
+    // the residual rows of this workgroup's slab depend on nobody else: request them now, they arrive under the FSMN / the exchange wait
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int row = min((wave >> 2) * 48 + i * 16 + (lane & 15), rows_left - 1);
+      const float* xr = a->x + (size_t)(row0 + row) * D + h * HD + (wave & 3) * 32 + (lane >> 4) * 8;
+      xpre[i][0] = *reinterpret_cast<const f32x4_t*>(xr); xpre[i][1] = *reinterpret_cast<const f32x4_t*>(xr + 4);
+    }
     // ---- FSMN memory (thread = channel x 24-step segment, 11 taps from the V^T image) -> f32 [144][128] image at offset 0 (the q / k
     //      images are dead), 32-byte granules XOR-swizzled by the row so that the out-projection epilogue reads without conflicts
     {
@@ -555,15 +563,15 @@ __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_by
     STAMP(4);
     consume(flags + 0, NH, a->err);
     STAMP(5);
-    // the accumulators start from the FSMN term (f32 image at offset 0), so the image is dead before the first DMA lands and the
-    // operand ring of this phase can take the whole LDS (four stages in flight instead of two)
+    // the accumulators start from FSMN term (f32 image at offset 0) + residual (registers, requested before the FSMN), so the image is
+    // dead before the first DMA lands and the operand ring of this phase can take the whole LDS (four stages in flight instead of two)
     const int n = cg * 32 + fgrp * 8;                       // this lane's 8 consecutive columns inside the slab
     f32x4_t acc[3][2];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int row = rg * 48 + i * 16 + frow;
       const unsigned char* mrow = smem + row * 512 + ((((n >> 3) ^ (row & 15))) << 5);
-      if (rg * 3 + i < n_act) { acc[i][0] = *reinterpret_cast<const f32x4_t*>(mrow); acc[i][1] = *reinterpret_cast<const f32x4_t*>(mrow + 16); }
+      if (rg * 3 + i < n_act) { acc[i][0] = *reinterpret_cast<const f32x4_t*>(mrow) + xpre[i][0]; acc[i][1] = *reinterpret_cast<const f32x4_t*>(mrow + 16) + xpre[i][1]; }
       else { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
     }
     __syncthreads();
@@ -573,11 +581,9 @@ __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_by
     for (int i = 0; i < 3; ++i) {
       const int row = rg * 48 + i * 16 + frow;
       if (rg * 3 + i < n_act) {
-        const float* xr = a->x + (size_t)(row0 + row) * D + h * HD + n;
-        const float4 r0 = *reinterpret_cast<const float4*>(xr), r1 = *reinterpret_cast<const float4*>(xr + 4);
-        float* v = xres[i];
-        v[0] = acc[i][0][0] + r0.x; v[1] = acc[i][0][1] + r0.y; v[2] = acc[i][0][2] + r0.z; v[3] = acc[i][0][3] + r0.w;
-        v[4] = acc[i][1][0] + r1.x; v[5] = acc[i][1][1] + r1.y; v[6] = acc[i][1][2] + r1.z; v[7] = acc[i][1][3] + r1.w;
+        float* v = xres[i];                                 // (the accumulators started from FSMN term + residual)
+        v[0] = acc[i][0][0]; v[1] = acc[i][0][1]; v[2] = acc[i][0][2]; v[3] = acc[i][0][3];
+        v[4] = acc[i][1][0]; v[5] = acc[i][1][1]; v[6] = acc[i][1][2]; v[7] = acc[i][1][3];
         const uint4 pk = pack8(xres[i]);
         store16_wt(a->x1_lo + (size_t)(row0 + row) * D + h * HD + n, pk);
         float s1 = 0.0f, s2 = 0.0f;

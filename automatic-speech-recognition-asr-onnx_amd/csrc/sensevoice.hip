@@ -86,6 +86,7 @@ struct SvSession : asr_session {
   bool use_fused = true;        // fused q|k|v + attention + FSMN kernel for windows of <= 144 rows (ASR_SANM_FUSED=0 disables)
   bool use_block = true;        // one launch per SANM block (clusters of four workgroups per window; ASR_SANM_BLOCK=0 disables)
   int block_scatter = 0;        // ASR_SANM_BLOCK_SCATTER=1: test placement, every cluster spread over four XCDs
+  int block_min_utts = 48;      // ASR_SANM_BLOCK_MIN=<windows>: smallest batch that takes the block kernel
   DeviceBuffer d_times; int block_dbg = -1;   // ASR_SANM_BLOCK_DBG=<block index>: phase clock of that block's launch on stderr
   DeviceBuffer d_flags;         // exchange counters of the block kernel: [n_blocks][batch][4] + the error word at the end
   hipGraphExec_t graph_exec = nullptr;
@@ -264,6 +265,7 @@ void SvSession::enqueue(const SvRunCtx& r) {
   bool blk = false;
   if constexpr (sizeof(T) == 2)
     blk = use_block && use_ln_alg && use_fused && blocks[c.n_blocks - 1].cqkv && blocks[c.n_blocks - 1].c1 && c.n_blocks > 1 &&
+          r.batch >= block_min_utts &&          // four workgroups per window: a small batch leaves most CUs idle (one window: 4 of 256), the tiled GEMMs do not
           sanm_block_supported(r.max_T, c.d_head, c.n_heads, d, dff, c.fsmn_kernel);
   const size_t flag_words = (size_t)c.n_blocks * r.batch * 4;
   HIP_CHECK(hipMemsetAsync(d_flags.ptr, 0, (flag_words + 4) * 4, stream));      // per (block, window, exchange) counters + the error word
@@ -1104,6 +1106,7 @@ extern "C" int asr_sensevoice_create(const asr_sensevoice_config* cfg, const voi
       if (const char* e = getenv("ASR_SANM_BLOCK")) s->use_block = !(e[0] == '0');
       if (const char* e = getenv("ASR_SANM_BLOCK_SCATTER")) s->block_scatter = e[0] == '1';
       if (const char* e = getenv("ASR_SANM_BLOCK_DBG")) s->block_dbg = atoi(e);
+      if (const char* e = getenv("ASR_SANM_BLOCK_MIN")) s->block_min_utts = atoi(e);
       if (const char* e = getenv("ASR_LN_FUSED")) s->use_ln_alg = !(e[0] == '0');
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;
@@ -1163,6 +1166,7 @@ extern "C" int asr_paraformer_create(const asr_paraformer_config* cfg, const voi
       if (const char* e = getenv("ASR_SANM_BLOCK")) s->use_block = !(e[0] == '0');
       if (const char* e = getenv("ASR_SANM_BLOCK_SCATTER")) s->block_scatter = e[0] == '1';
       if (const char* e = getenv("ASR_SANM_BLOCK_DBG")) s->block_dbg = atoi(e);
+      if (const char* e = getenv("ASR_SANM_BLOCK_MIN")) s->block_min_utts = atoi(e);
       if (const char* e = getenv("ASR_LN_FUSED")) s->use_ln_alg = !(e[0] == '0');
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;

@@ -461,9 +461,11 @@ __global__ void qw_gather_prompt_kernel(const int32_t* __restrict__ src, const T
   }
 }
 
-__global__ void qw_hist_add_kernel(int32_t* __restrict__ hist, const UttPlan* __restrict__ plan, int B) {
+// cap: a finished sequence that generate() keeps stepping beside unfinished ones stops advancing at the last cache slot (its outputs are
+// ignored; rows that still matter never reach the cap -- the host checks them before every step)
+__global__ void qw_hist_add_kernel(int32_t* __restrict__ hist, const UttPlan* __restrict__ plan, int B, int cap) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) hist[b] += plan[b].T;
+  if (b < B) hist[b] = min(hist[b] + plan[b].T, cap);
 }
 
 // ------------------------------------------------------------------------------------ beam search
@@ -632,6 +634,7 @@ struct QwSession : asr_session {
   int batch = 0;
   std::vector<int> seq_len;                              // positions in the cache per sequence (host mirror)
   DeviceBuffer d_plan, d_audio, d_mel, d_blkmax, d_feat, d_col, d_c1, d_c2, d_c3, d_xa, d_xb, d_h, d_qk, d_vt, d_ctx, d_ffn, d_aud_out;
+  std::vector<char> frozen;      // generate(): finished sequences, allowed to sit at max_seq_len while the others go on
   DeviceBuffer d_dplan, d_x, d_x2, d_dh, d_qkv, d_q, d_dctx, d_act, d_last, d_logits, d_next, d_kc, d_vc, d_hist, d_stepplan, d_skws, d_skcnt, d_vt2, d_krows, d_xlo, d_x2lo;
   bool no_fuse = false, use_graph = true;
   // decode head (Inference_Qwen_ASR_ONNX.py:369-376): arg-max, penalty-greedy (APPLY_PENALTY + GREEDY_SEARCH) or top-k / top-p sampling
@@ -857,7 +860,8 @@ void QwSession::logits_head(const DecPass& P) {
       launch_append_ids(d_next.as<int32_t>(), B, d_save.as<int32_t>(), c.max_seq_len, d_nsaved.as<int32_t>(), stream);
       launch_add_scalar(d_nsaved.as<int32_t>(), 1, stream);
     } }
-  if (!P.hist_done) hipLaunchKernelGGL(qw_hist_add_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, P.hist ? P.hist : d_hist.as<int32_t>(), P.plan, B);
+  if (!P.hist_done) hipLaunchKernelGGL(qw_hist_add_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, P.hist ? P.hist : d_hist.as<int32_t>(), P.plan, B,
+                                       P.step ? cfg.max_seq_len - 1 : INT32_MAX);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1230,7 +1234,8 @@ void QwSession::step(const int32_t* ids_host, int32_t* next_out, float* logits_o
   ASR_REQUIRE(batch > 0, "qwen_decode: prefill first");
   HIP_CHECK(hipSetDevice(device));
   const int B = batch, d = c.d_model, Mb = round_up(B, 128);
-  for (int b = 0; b < B; ++b) ASR_REQUIRE(seq_len[b] + 1 <= c.max_seq_len, "qwen_decode: sequence %d is at max_seq_len %d", b, c.max_seq_len);
+  for (int b = 0; b < B; ++b)
+    ASR_REQUIRE(seq_len[b] + 1 <= c.max_seq_len || (b < (int)frozen.size() && frozen[b]), "qwen_decode: sequence %d is at max_seq_len %d", b, c.max_seq_len);
   if (ids_host) {
     int32_t* st = (int32_t*)pinned(h_ids, h_ids_cap, (size_t)B * 4);
     for (int b = 0; b < B; ++b) {
@@ -1256,7 +1261,7 @@ void QwSession::step(const int32_t* ids_host, int32_t* next_out, float* logits_o
     P.hist_done = true;
     logits_head<T>(P);
     noise_armed = false;
-    for (int b = 0; b < B; ++b) ++seq_len[b];
+    for (int b = 0; b < B; ++b) seq_len[b] = std::min(seq_len[b] + 1, c.max_seq_len);
     finish<T>(B, next_out, logits_out, ids_host != nullptr);
     return;
   }
@@ -1289,7 +1294,7 @@ void QwSession::step(const int32_t* ids_host, int32_t* next_out, float* logits_o
     if (graphable) dec_eager_key = key;
   }
   noise_armed = false;                                   // caller-supplied uniforms serve exactly one step
-  for (int b = 0; b < B; ++b) ++seq_len[b];
+  for (int b = 0; b < B; ++b) seq_len[b] = std::min(seq_len[b] + 1, c.max_seq_len);
   finish<T>(B, next_out, logits_out, ids_host != nullptr);
 }
 
@@ -1530,11 +1535,15 @@ extern "C" int asr_qwen_generate(asr_session* s, int max_new, const int32_t* sto
           else tokens_out[(size_t)b * max_new + n_out[b]++] = cur[b];
         }
         all_done = all_done && done[b];
-        room = room && q->seq_len[b] + 1 <= q->cfg.max_seq_len;
+        // only sequences still generating need a free position: a finished long-prompt row that has reached max_seq_len keeps
+        // re-writing its last cache slot (device-side cap) instead of ending the batch for the others
+        if (!done[b]) room = room && q->seq_len[b] + 1 <= q->cfg.max_seq_len;
       }
+      q->frozen.assign(done.begin(), done.end());
       if (all_done || t + 1 == max_new || !room) break;
       if (q->precision == ASR_PRECISION_BF16) q->step<bf16_t>(nullptr, cur.data(), nullptr);
       else q->step<float>(nullptr, cur.data(), nullptr);
     }
+    q->frozen.clear();
   });
 }

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(512) void qw_decode_mega_kernel(const QwMegaArgs a)
     if (layer + 1 < a.n_layers && !mega_barrier(a, ++gen)) return;
   }
   // every workgroup is past the last read of the history counters (P2 of the last layer): advance them
-  if (wg == 0 && tid < B) a.hist_rw[tid] += 1;
+  if (wg == 0 && tid < B) a.hist_rw[tid] = min(a.hist_rw[tid] + 1, a.S_max - 1);      // (capped: see qw_hist_add_kernel)
 }
 
 template <int MT, int G>

@@ -85,16 +85,32 @@ def unpack_hypotheses(slab: np.ndarray) -> list[np.ndarray]:
 
 
 def gather_hypotheses(slab: np.ndarray, device: torch.device, dst: int = 0):
-    """All ranks pass equal-shaped slabs; rank `dst` gets the list of per-rank slabs (others None)."""
+    """All ranks pass equal-shaped slabs; rank `dst` gets the list of per-rank slabs (others None). A true gather (the bytes move
+    once, to `dst` only): c10d's gather on both backends (on RCCL it is a group of point-to-point sends), with plain send / recv as
+    the fallback should the backend lack it."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
         return [slab]
-    t = torch.from_numpy(slab).to(device)
-    bucket = [torch.empty_like(t) for _ in range(world)] if dist.get_rank() == dst else None
-    if dist.get_backend() == "nccl":
-        # RCCL gather is not universally available through c10d; all_gather of a <1 MB slab is latency-bound anyway
-        bucket = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(bucket, t)
-        return [b.cpu().numpy() for b in bucket] if dist.get_rank() == dst else None
-    dist.gather(t, bucket, dst=dst)
-    return [b.cpu().numpy() for b in bucket] if dist.get_rank() == dst else None
+    rank = dist.get_rank()
+    t = torch.from_numpy(np.ascontiguousarray(slab)).to(device)
+    bucket = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
+    try:
+        dist.gather(t, bucket, dst=dst)
+    except (RuntimeError, NotImplementedError):
+        if rank == dst:
+            bucket[dst].copy_(t)
+            for src in range(world):
+                if src != dst:
+                    dist.recv(bucket[src], src=src)
+        else:
+            dist.send(t, dst=dst)
+    return [b.cpu().numpy() for b in bucket] if rank == dst else None
+
+
+def max_over_ranks(value: float, device: torch.device) -> float:
+    """The slowest rank's figure (bench.py: elapsed time of the timed region, bracketed by barriers on both sides)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

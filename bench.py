@@ -247,11 +247,7 @@ def main():
             step(k, upload)
         fence()
         el = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el
+        return dp.max_over_ranks(el, device)
 
     for k in range(args.warmup):
         step(k)
@@ -515,9 +511,7 @@ def main_paraformer(args):
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = dp.max_over_ranks(elapsed, device)
     sess.profile(True)
     sess.profile_reset()
     for _ in range(args.profile_steps):
@@ -616,9 +610,7 @@ def main_paraformer_streaming(args):
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = dp.max_over_ranks(elapsed, device)
     sess.profile(True)
     sess.profile_reset()
     for i in range(args.profile_steps):
@@ -742,9 +734,7 @@ def main_whisper(args):
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = dp.max_over_ranks(elapsed, device)
     # serving option (--inflight N, reported next to the headline, never as `value`): N sessions on N HIP streams, each working through
     # its own batches of the same size -- the encoder of one batch (compute-bound) runs inside the decode of another (a latency-bound
     # chain that leaves most CUs idle)
@@ -903,9 +893,7 @@ def main_qwen(args):
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = dp.max_over_ranks(elapsed, device)
     inflight = None
     if args.inflight > 1:                                  # serving option, see main_whisper: N batches in flight on N sessions / HIP streams
         import threading
@@ -1094,9 +1082,7 @@ def main_mixed(args):
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = dp.max_over_ranks(elapsed, device)
         c = torch.tensor([chunks_done[0]], dtype=torch.float64, device=device)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_chunks = float(c.item())

@@ -133,3 +133,33 @@ def test_kaldi_mel_banks_known_answers():
     # adjacent triangles partition unity between the first and last centre
     inner = (torch.arange(256) * 31.25 > float(centers[0])) & (torch.arange(256) * 31.25 < float(centers[-1]))
     assert torch.allclose(a.sum(dim=0)[inner], torch.ones(int(inner.sum())), atol=1e-4)
+
+
+def test_kaldi_mel_banks_against_an_independent_statement_of_kaldis_loop():
+    """Third, code-independent statement of Kaldi's `MelBanks::MelBanks` (feat/mel-computations.cc: per bin, per FFT bin, scalar double
+    arithmetic, strict `mel > left && mel < right` membership, the two-slope formula) -- the product (arena.py) and the oracle
+    (oracle/kaldi_mel.py) were written by the same hand in vectorised float32; a shared misreading of the published algorithm would
+    have to be repeated here in a different form to go unnoticed. torchaudio itself is absent: parity with ITS output
+    stays unpinned until a dumped (80, 256) matrix can be committed."""
+    import math
+    arena = sub("arena")
+    from oracle.kaldi_mel import get_mel_banks
+    num_bins, padded, sr, low = 80, 512, 16000.0, 20.0
+    n_fft_bins, high = padded // 2, 0.5 * sr                     # high_freq = 0 -> Nyquist
+    bin_width = sr / padded
+
+    def mel(f):
+        return 1127.0 * math.log(1.0 + f / 700.0)
+    mel_low, mel_high = mel(low), mel(high)
+    delta = (mel_high - mel_low) / (num_bins + 1)
+    want = np.zeros((num_bins, n_fft_bins), dtype=np.float64)
+    for b in range(num_bins):
+        left, center, right = mel_low + b * delta, mel_low + (b + 1) * delta, mel_low + (b + 2) * delta
+        for i in range(n_fft_bins):
+            m = mel(bin_width * i)
+            if left < m < right:
+                want[b, i] = (m - left) / (center - left) if m <= center else (right - m) / (right - center)
+    got_product = arena.kaldi_mel_banks(num_bins, padded, sr).numpy().astype(np.float64)
+    got_oracle = get_mel_banks(num_bins, padded, sr, low, 0.0, 100.0, -500.0, 1.0)[0].numpy().astype(np.float64)
+    assert np.abs(got_product - want).max() < 2e-6 and np.abs(got_oracle - want).max() < 2e-6
+    assert ((want > 0) == (got_product > 1e-7)).mean() > 0.9995      # same support up to float32 ties at a triangle's foot

@@ -54,6 +54,15 @@ def _worker(rank, world, port, out_dir):
         open(os.path.join(out_dir, "ok"), "w").write("ok")
     else:
         assert got is None
+    # bench.py's world > 1 legs: the per-step hypothesis slab of a full batch (B_local x (1 + max_T)) and the max-over-ranks clock
+    B_local, max_t = 64, 137
+    tok2 = np.full((B_local, max_t), rank + 1, np.int32)
+    num2 = np.full((B_local,), 5 + rank, np.int32)
+    got2 = d.gather_hypotheses(d.pack_hypotheses(tok2, num2, max_t), dev)
+    if rank == 0:
+        assert len(got2) == world and all(s.shape == (B_local, 1 + max_t) for s in got2)
+        assert [int(s[0, 0]) for s in got2] == [5, 6] and [int(s[3, 1]) for s in got2] == [1, 2]
+    assert d.max_over_ranks(1.0 + rank, dev) == float(world)
     dist.barrier()
     dist.destroy_process_group()
 

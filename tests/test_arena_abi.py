@@ -161,5 +161,5 @@ def test_kaldi_mel_banks_against_an_independent_statement_of_kaldis_loop():
                 want[b, i] = (m - left) / (center - left) if m <= center else (right - m) / (right - center)
     got_product = arena.kaldi_mel_banks(num_bins, padded, sr).numpy().astype(np.float64)
     got_oracle = get_mel_banks(num_bins, padded, sr, low, 0.0, 100.0, -500.0, 1.0)[0].numpy().astype(np.float64)
-    assert np.abs(got_product - want).max() < 2e-6 and np.abs(got_oracle - want).max() < 2e-6
-    assert ((want > 0) == (got_product > 1e-7)).mean() > 0.9995      # same support up to float32 ties at a triangle's foot
+    assert np.abs(got_product - want).max() < 5e-5 and np.abs(got_oracle - want).max() < 5e-5      # float32 mel arithmetic (mel ~ 2840, slope 1 / 34) vs double
+    assert ((want > 1e-4) == (got_product > 1e-4)).mean() > 0.9995      # same support up to float32 ties at a triangle's foot

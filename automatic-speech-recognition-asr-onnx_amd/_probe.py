@@ -23,6 +23,8 @@ class GemmDesc(C.Structure):
 
 SIGNATURES = {
     "asr_probe_gemm": (C.c_int, [C.POINTER(GemmDesc)]),
+    "asr_probe_gemm_chain": (C.c_int, [C.c_int] * 6 + [_fp]),
+    "asr_probe_last_kernel": (C.c_char_p, []),
     "asr_probe_gemm_counts": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "asr_probe_gemm_bench": (C.c_int, [C.c_int] * 6 + [_fp]),
     "asr_probe_grid_barrier": (C.c_int, [C.c_int, C.c_int, _fp]),
@@ -93,3 +95,10 @@ def gemm_counts(reset: bool = False) -> dict:
     buf = C.create_string_buffer(1024)
     _lib.check(load().asr_probe_gemm_counts(int(reset), buf, 1024))
     return {k: int(v) for k, v in (kv.split("=") for kv in buf.value.decode().split(";") if kv)}
+
+
+def gemm_chain(M, N, K, epilogue=0, cold_mb=768, replays=5):
+    """(microseconds per launch, kernel family) of a captured chain of decode-shaped GEMMs over cold weights."""
+    us = C.c_float(0.0)
+    _lib.check(load().asr_probe_gemm_chain(M, N, K, epilogue, cold_mb, replays, C.byref(us)))
+    return us.value, load().asr_probe_last_kernel().decode()

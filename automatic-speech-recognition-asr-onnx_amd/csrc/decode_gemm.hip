@@ -1,0 +1,233 @@
+// Decode-step GEMM: out[M <= 64][N] = A[M][K] W[N][K]^T for the autoregressive decoders (Whisper/Export_Whisper.py:614-667, one row per
+// sequence), where every launch streams a few MB of cold weights from HBM once and the activation rows come from L2.
+//
+// What bounds these launches (tools/probes/decode_gemm_chain.py, cold weights, M = 32): not HBM (3-13 MB at 5 TB/s is 0.7-2.6 us) but
+// what ONE CU can pull -- ~40 GB/s of weights + activation rows together -- times how unevenly the workgroups cover the chip:
+//   * a workgroup owns 16 NT output columns x all rows and must read every activation row once per column granule, so the rows move
+//     (N / 16 NT) times through L2 -> CU paths: 16-column granules move 2 bytes of activations per byte of weights at 32 rows;
+//   * N = 1280 gives 80 granules = 80 busy CUs (fc2: 164 KB of weights + 328 KB of rows each = 13 us), N = 5120 gives 320 = a second,
+//     quarter-full round (fc1: 11.7 us against 7.1 us for the 240 granules of q|k|v).
+// So the launcher shapes the grid to <= 256 EVEN workgroups: NT = 2 (32-column granules: half the activation traffic) where 16-column
+// granules would overflow the chip, and K split across workgroups where the granules alone leave CUs idle; the partial tiles are handed
+// over with 16-byte write-through stores + one ticket and summed in split order by the last arriver (bit-reproducible).
+//
+// LayerNorm folded in (FOLD): the pre-LN decoder applies an affine-free LayerNorm before q|k|v, cross-q and fc1 (the affine is folded
+// into the weights at arena build, Export_Whisper.py:215-225). A then holds the RAW residual rows in bf16 (second output of the
+// producing GEMM) and  LN(x) W^T = rstd (x W^T - mean c),  c[n] = sum_k W[n][k];  sum(x) and sum(x^2) of every row come from two extra
+// MFMAs per activation fragment (ones x A^T, A A^T) on the otherwise idle matrix pipe. This removes the per-workgroup LayerNorm prologue
+// of the weight-streaming kernel (every workgroup re-normalising all rows: +4.7 us per launch) and the stand-alone LayerNorm launch.
+#include "gemm.h"
+
+namespace {
+
+constexpr int DW = 8;                           // waves per workgroup; each takes one K sub-slice
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+template <int MT, int NT, bool FOLD>
+__global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 15, fgrp = lane >> 4;
+  const int n0 = blockIdx.x * 16 * NT;
+  const int KS = gridDim.y, ks = blockIdx.y;
+  const int kslice = g.K / (DW * KS);                  // multiple of 32 (host-checked)
+  const int kw = (wave + (int)blockIdx.x) & (DW - 1);    // rotate the wave -> slice map per workgroup: the shared activation rows are not hit in lock-step
+  const int k_begin = (ks * DW + kw) * kslice;
+  const bf16_t* wp = g.W + (size_t)(n0 + frow) * g.ldw + k_begin + fgrp * 8;
+  const bf16_t* ap = g.A + (size_t)frow * g.lda + k_begin + fgrp * 8;
+  constexpr int U = 8 / NT;                            // K-steps per trip: U x NT weight fragments (16 B per lane each) in flight per wave
+
+  f32x4_t acc[MT][NT], sx[MT], sxx[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    sx[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; sxx[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  // the residual term of the epilogue does not depend on the product: requested first, it arrives under the weight stream
+  constexpr int TILES = MT * NT;                       // output tiles of 16 x 16; wave t finishes tile t (TILES <= 8)
+  static_assert(TILES <= DW, "one finishing wave per output tile");
+  const int ti = wave / NT, tj = wave % NT;            // tile of this wave in the epilogue
+  float4 addv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (wave < TILES && g.add && ti * 16 + frow < g.M) addv = *reinterpret_cast<const float4*>(g.add + (size_t)(ti * 16 + frow) * g.ld_add + n0 + tj * 16 + fgrp * 4);
+  const bf16x8_t ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+
+  for (int k = 0; k < kslice; k += 32 * U) {
+    bf16x8_t wf[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (k + u * 32 < kslice) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[u][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)j * 16 * g.ldw + k + u * 32));
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (k + u * 32 < kslice) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(ap + (size_t)i * 16 * g.lda + k + u * 32);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][j], af, acc[i][j], 0, 0, 0);   // D[n = 4 fgrp + r][m = frow]
+          if constexpr (FOLD) {
+            sx[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af, sx[i], 0, 0, 0);       // D[*][m = frow] = sum_k x[m][k]
+            sxx[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, af, sxx[i], 0, 0, 0);       // D[a][b] = x[a] . x[b]: the diagonal is sum(x^2)
+          }
+        }
+      }
+  }
+  // ---- cross-wave reduction through LDS: red[wave][tile][lane] (float4), statistics st[wave][row] (float2)
+  float4* red = reinterpret_cast<float4*>(smem);
+  float2* st = reinterpret_cast<float2*>(smem + DW * TILES * 1024);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) red[(wave * TILES + i * NT + j) * 64 + lane] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+      if (fgrp == (frow >> 2)) st[wave * MT * 16 + i * 16 + frow] = make_float2(sx[i][0], sxx[i][frow & 3]);
+  }
+  __syncthreads();
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int tile = wave;
+  if (wave < TILES) {
+    sum = red[tile * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < DW; ++w) { const float4 q = red[(w * TILES + tile) * 64 + lane]; sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w; }
+  }
+  const int rows16 = MT * 16;
+  if (KS > 1) {            // hand the partial tiles over (write-through, 16 bytes per lane); the last workgroup of this column granule finishes
+    if (wave < TILES) {
+      float* dst = g.ws + ((size_t)ks * rows16 + ti * 16 + frow) * g.N + n0 + tj * 16 + fgrp * 4;
+      const f32x4_t v = {sum.x, sum.y, sum.z, sum.w};
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // (also: every wave is done with `red`, whose first word now carries the verdict)
+    int* last = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      const int ticket = __hip_atomic_fetch_add(g.cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *last = ticket == KS - 1;
+      if (ticket == KS - 1) __hip_atomic_store(g.cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    if (!*last) return;
+    if (wave < TILES) {
+      sum = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s2 = 0; s2 < KS; ++s2) {               // fixed order => bit-reproducible; sc1 loads bypass this CU's L1
+        const float* src = g.ws + ((size_t)s2 * rows16 + ti * 16 + frow) * g.N + n0 + tj * 16 + fgrp * 4;
+        f32x4_t q;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(src) : "memory");
+        sum.x += q[0]; sum.y += q[1]; sum.z += q[2]; sum.w += q[3];
+      }
+    }
+  }
+  if (wave >= TILES) return;
+  const int m = ti * 16 + frow, n = n0 + tj * 16 + fgrp * 4;
+  if (m >= g.M) return;
+  if constexpr (FOLD) {                                  // rstd (x W^T - mean c): statistics summed over the waves in a fixed order
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int w = 0; w < DW; ++w) { const float2 q = st[w * MT * 16 + m]; s1 += q.x; s2 += q.y; }
+    const float inv_k = 1.0f / (float)g.K;
+    const float mean = s1 * inv_k;
+    const float rstd = rsqrtf(fmaxf(s2 * inv_k - mean * mean, 0.0f) + g.ln_eps);
+    const float4 c = *reinterpret_cast<const float4*>(g.colsum + n);
+    sum.x = (sum.x - mean * c.x) * rstd; sum.y = (sum.y - mean * c.y) * rstd; sum.z = (sum.z - mean * c.z) * rstd; sum.w = (sum.w - mean * c.w) * rstd;
+  }
+  if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + n); sum.x += b.x; sum.y += b.y; sum.z += b.z; sum.w += b.w; }
+  sum.x += addv.x; sum.y += addv.y; sum.z += addv.z; sum.w += addv.w;
+  if (g.act == ACT_GELU_ERF) {
+    sum.x = 0.5f * sum.x * (1.0f + erff(sum.x * 0.70710678118654752440f)); sum.y = 0.5f * sum.y * (1.0f + erff(sum.y * 0.70710678118654752440f));
+    sum.z = 0.5f * sum.z * (1.0f + erff(sum.z * 0.70710678118654752440f)); sum.w = 0.5f * sum.w * (1.0f + erff(sum.w * 0.70710678118654752440f));
+  } else if (g.act == ACT_GELU_TANH) {
+    auto gt = [](float v) { const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v); return 0.5f * v * (1.0f + tanhf(u)); };
+    sum.x = gt(sum.x); sum.y = gt(sum.y); sum.z = gt(sum.z); sum.w = gt(sum.w);
+  } else if (g.act == ACT_RELU) {
+    sum.x = fmaxf(sum.x, 0.f); sum.y = fmaxf(sum.y, 0.f); sum.z = fmaxf(sum.z, 0.f); sum.w = fmaxf(sum.w, 0.f);
+  }
+  if (g.out_f32) *reinterpret_cast<float4*>(g.out_f32 + (size_t)m * g.ld_out_f32 + n) = sum;
+  if (g.out_lo) {
+    uint2 w;
+    w.x = pack_bf16x2(sum.x, sum.y); w.y = pack_bf16x2(sum.z, sum.w);
+    *reinterpret_cast<uint2*>(g.out_lo + (size_t)m * g.ld_out_lo + n) = w;
+  }
+}
+
+// c[n] = sum_k W[n][k] of the bf16 weights, accumulated in double (one wave per row)
+__global__ void colsum_kernel(const bf16_t* __restrict__ W, int ldw, int N, int K, float* __restrict__ c) {
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  double s = 0.0;
+  for (int k = lane; k < K; k += 64) s += (double)bf16_to_f32(W[(size_t)n * ldw + k]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) c[n] = (float)s;
+}
+
+template <int MT, int NT>
+void launch_inst(const DecGemmArgs& g, int splits, hipStream_t s) {
+  const size_t lds = (size_t)DW * MT * NT * 1024 + (size_t)DW * MT * 16 * 8;
+  const dim3 grid(g.N / (16 * NT), splits);
+  if (g.colsum) hipLaunchKernelGGL((decode_gemm_kernel<MT, NT, true>), grid, dim3(64 * DW), lds, s, g);
+  else hipLaunchKernelGGL((decode_gemm_kernel<MT, NT, false>), grid, dim3(64 * DW), lds, s, g);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+
+bool decode_gemm_supported(const DecGemmArgs& g) {
+  return g.M >= 1 && g.M <= 64 && g.N % 32 == 0 && g.K % (32 * DW) == 0 && (g.lda * 2) % 16 == 0 && (g.ldw * 2) % 16 == 0 && !(g.colsum && !g.A);
+}
+
+// grid shape: column granules of 16 NT, K split across `splits` workgroups -- at most one even round of the chip's CUs
+void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits) {
+  const int cus = 256;
+  int NT = (g.N / 16 > cus && g.M <= 32) ? 2 : 1;      // (two column tiles x four row tiles would need 8+ finishing waves and 128 accumulator registers)
+  if (g.M > 32) NT = 1;
+  int granules = g.N / (16 * NT), best = 1;
+  if (!g.colsum && g.ws && g.cnt) {                     // (the folded LayerNorm needs whole rows in one workgroup: K is never split there)
+    for (int sp : {2, 3, 4, 5, 6, 8, 10}) {
+      if (g.K % (32 * DW * sp) != 0 || granules * sp > cus) continue;
+      if ((size_t)sp * ((g.M + 15) / 16 * 16) * g.N * 4 > g.ws_bytes) continue;
+      // a split pays once the un-split workgroup streams much more than a CU moves in the time a hand-over costs (~2 us ~ 80 KB)
+      const size_t per_wg = (size_t)(16 * NT + ((g.M + 15) / 16 * 16)) * g.K * 2 / best;
+      if (per_wg < 160 * 1024) break;
+      best = sp;
+    }
+    // N = 1280, K = 5120 at NT = 1 reaches only 240 workgroups with 3 splits (K % 768 != 0): wider granules + more splits cover the chip better
+    if (g.M <= 32 && g.N / 16 <= 128 && g.K >= 4096 && NT == 1) {
+      for (int sp : {5, 4, 6, 8}) {
+        if (g.K % (32 * DW * sp) == 0 && (g.N / 32) * sp <= cus && (size_t)sp * 32 * g.N * 4 <= g.ws_bytes && (g.N / 32) * sp > granules * best) { NT = 2; best = sp; break; }
+      }
+    }
+  }
+  *nt = NT; *splits = best;
+}
+
+void launch_decode_gemm(const DecGemmArgs& g, hipStream_t s) {
+  ASR_REQUIRE(decode_gemm_supported(g), "decode_gemm: unsupported shape (M = %d, N = %d, K = %d)", g.M, g.N, g.K);
+  ASR_REQUIRE(g.A && g.W && (g.out_f32 || g.out_lo), "decode_gemm: null operand");
+  int nt = 1, splits = 1;
+  decode_gemm_plan(g, &nt, &splits);
+  ASR_REQUIRE(g.N % (16 * nt) == 0, "decode_gemm: N = %d", g.N);
+  static bool attr = false;
+  if (!attr) {
+    const int cap = 96 * 1024;
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_gemm_kernel<4, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_gemm_kernel<4, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_gemm_kernel<2, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_gemm_kernel<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    attr = true;
+  }
+  const int mt = g.M <= 16 ? 1 : g.M <= 32 ? 2 : 4;
+  if (nt == 2) { if (mt == 1) launch_inst<1, 2>(g, splits, s); else launch_inst<2, 2>(g, splits, s); }
+  else if (mt == 1) launch_inst<1, 1>(g, splits, s);
+  else if (mt == 2) launch_inst<2, 1>(g, splits, s);
+  else launch_inst<4, 1>(g, splits, s);
+}
+
+void launch_colsum_bf16(const bf16_t* W, int ldw, int N, int K, float* c, hipStream_t s) {
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 3) / 4), dim3(256), 0, s, W, ldw, N, K, c);
+  HIP_CHECK(hipGetLastError());
+}

@@ -70,5 +70,24 @@ bool gemm_skinny144_enabled();
 void gemm_kernel_counts_reset();
 int gemm_kernel_counts(char* buf, int cap);   // "family=launches;..." since the last reset (host-side: graph replays do not count)
 
+// ---- decode-step GEMM (csrc/decode_gemm.hip): out[M <= 64][N] = A W^T with the grid shaped to one even round of the chip (32-column
+// granules / K split across workgroups) and, with `colsum`, the affine-free LayerNorm of the raw bf16 rows in A folded into the product
+struct DecGemmArgs {
+  const bf16_t* A = nullptr; int lda = 0;            // [M][K] bf16 (colsum set: the RAW residual rows, LayerNorm applied inside)
+  const bf16_t* W = nullptr; int ldw = 0;            // [N][K]
+  int M = 0, N = 0, K = 0;
+  const float* bias = nullptr;
+  const float* colsum = nullptr; float ln_eps = 1e-5f;      // c[n] = sum_k W[n][k]: out = rstd (A W^T - mean c) + bias
+  const float* add = nullptr; int ld_add = 0;        // + f32 residual rows
+  int act = ACT_NONE;                                // NONE / RELU / GELU_ERF / GELU_TANH
+  float* out_f32 = nullptr; int ld_out_f32 = 0;      // either or both outputs
+  bf16_t* out_lo = nullptr; int ld_out_lo = 0;
+  float* ws = nullptr; size_t ws_bytes = 0; int32_t* cnt = nullptr;     // split-K partials [splits][rows16][N] + self-resetting tickets [N / 16] (per session)
+};
+bool decode_gemm_supported(const DecGemmArgs& g);
+void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits);
+void launch_decode_gemm(const DecGemmArgs& g, hipStream_t s);
+void launch_colsum_bf16(const bf16_t* W, int ldw, int N, int K, float* c, hipStream_t s);
+
 // reduce the per-slab arg-max partials written by the GEMM epilogue: ids[m] = first index of the row max
 void launch_argmax_reduce(const float* val, const int32_t* idx, int M, int n_slabs, int32_t* ids, hipStream_t s);

@@ -1007,13 +1007,14 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
 #pragma unroll
   for (int i = 0; i < MT; ++i) { acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; gram[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   const bool a_rms = g.a_rms_eps > 0.0f;
-  for (int k = 0; k < kslice; k += 32 * U) {
-    bf16x8_t wf[U];
+  // Two register sets of U weight fragments: the loads of trip t + 1 are issued BEFORE the MFMAs of trip t, so a long K slice (fc2:
+  // K = 5120 -> 20 K-steps per wave = 3 trips) pays one HBM round trip, not one per trip (19.2 -> ~10 us per launch at 32 rows).
+  auto load_set = [&](bf16x8_t (&wf)[U], int k) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (k == 0) wf[u] = wf0[u];
-      else if (k + u * 32 < kslice) wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + k + u * 32));
-    }
+    for (int u = 0; u < U; ++u)
+      if (k + u * 32 < kslice) wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + k + u * 32));
+  };
+  auto mma_set = [&](const bf16x8_t (&wf)[U], int k) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (k + u * 32 < kslice) {
@@ -1025,6 +1026,13 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
         }
       }
     }
+  };
+  bf16x8_t wf1[U];
+  for (int k = 0; k < kslice; k += 64 * U) {
+    if (k + 32 * U < kslice) load_set(wf1, k + 32 * U);
+    mma_set(wf0, k);
+    if (k + 64 * U < kslice) load_set(wf0, k + 64 * U);
+    if (k + 32 * U < kslice) mma_set(wf1, k + 32 * U);
   }
   // ---- cross-wave reduction
   float4* red = reinterpret_cast<float4*>(smem);                                     // [wave][MT][64]
@@ -1060,12 +1068,10 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
 #pragma unroll
     for (int t = 0; t < (MT + SK_WAVES - 1) / SK_WAVES; ++t) {
       const int i = wave + t * SK_WAVES;
-      if (i < MT) {
+      if (i < MT) {        // one 16-byte write-through store per lane (four 4-byte sc1 stores are four fabric writes: ~6x the time per byte)
         float* dst = g.sk_ws + ((size_t)ks * rows16 + i * 16 + frow) * g.N + n0 + fgrp * 4;
-        __hip_atomic_store(dst + 0, sums[t].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 1, sums[t].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 2, sums[t].z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 3, sums[t].w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const f32x4_t v = {sums[t].x, sums[t].y, sums[t].z, sums[t].w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1083,12 +1089,11 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
       const int i = wave + t * SK_WAVES;
       if (i < MT) {
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s2 = 0; s2 < KS; ++s2) {              // fixed order => bit-reproducible
+        for (int s2 = 0; s2 < KS; ++s2) {              // fixed order => bit-reproducible; 16-byte sc1 loads (L1 bypassed: the partials were stored write-through)
           const float* src = g.sk_ws + ((size_t)s2 * rows16 + i * 16 + frow) * g.N + n0 + fgrp * 4;
-          sum.x += __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          sum.y += __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          sum.z += __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          sum.w += __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          f32x4_t q;
+          asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(src) : "memory");
+          sum.x += q[0]; sum.y += q[1]; sum.z += q[2]; sum.w += q[3];
         }
         sums[t] = sum;
       }
@@ -1132,13 +1137,16 @@ static int skinny_splits(const GemmArgs& g, int rows16) {
   // ... except for 33..64 rows (Qwen3-ASR decode, batch 64: 2.68 -> 2.45 ms / token), where every workgroup also re-reads 4 row tiles
   // of activations: there the split is on by default for the narrow outputs (o_proj / down_proj, N / 16 = 64 workgroups otherwise)
   const int on = genv().skinny_splitk;
-  if (on == 0 || (on < 0 && rows16 <= 32) || !g.sk_ws || !g.sk_cnt || g.a_rms_eps > 0.0f) return 1;
   const int granules = g.N / 16;
+  // ... and for a long K behind few column granules (Whisper fc2: 80 workgroups x 164 KB of weights + 328 KB of activation rows each): a
+  // CU streams ~40 GB/s, so 80 CUs alone take 13 us; four K slices put every CU to work (19.2 -> ~10 us with the 16-byte hand-over)
+  const bool long_k = g.K >= 3072 && granules <= 128;
+  if (on == 0 || (on < 0 && rows16 <= 32 && !long_k) || !g.sk_ws || !g.sk_cnt || g.a_rms_eps > 0.0f) return 1;
   int best = 1;
   for (int s : {2, 3, 4, 5, 8}) {
     if (g.K % (SK_WAVES * 32 * s) != 0) continue;
     if ((size_t)s * rows16 * g.N * 4 > g.sk_ws_bytes) continue;
-    if (granules * best >= 160) break;
+    if (granules * best >= (long_k ? 256 : 160)) break;
     best = s;
   }
   return best;

@@ -27,6 +27,7 @@ struct Tmp {
 };
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+char g_chain_kernel[32] = "";
 inline float bf16_bits_to_f32(bf16_t b) { union { uint32_t u; float f; } c; c.u = ((uint32_t)b) << 16; return c.f; }
 
 }  // namespace
@@ -95,6 +96,89 @@ extern "C" int asr_probe_gemm_bench(int variant, int M, int N, int K, int epilog
   });
 }
 
+
+// Decode-shaped GEMM in a captured chain with COLD weights: `copies` weight matrices (together larger than the 256 MB Infinity Cache when
+// cold_mb says so) are walked round-robin by dependent launches of one hipGraph, the way a decoder layer stack streams its weights from
+// HBM once per token. Reports microseconds per launch (graph replay, device time between events).
+extern "C" int asr_probe_gemm_chain(int M, int N, int K, int epilogue, int cold_mb, int replays, float* us_per_launch) {
+  return asr_guard([&] {
+    ASR_REQUIRE(us_per_launch && replays > 0 && M > 0 && N % 16 == 0 && K % 256 == 0, "probe_gemm_chain: bad argument");
+    asr_require_device(0);
+    gemm_reload_env();
+    Tmp t;
+    const int Mp = round_up(M, 128);
+    const size_t wbytes = (size_t)N * K * 2;
+    const int copies = std::max(1, std::min(512, (int)(((size_t)cold_mb << 20) / wbytes) + 1));
+    std::vector<bf16_t> hw((size_t)N * K), ha((size_t)Mp * K);
+    uint32_t x = 12345;
+    for (auto& v : hw) { x = x * 1664525u + 1013904223u; v = f32_to_bf16(((int)(x >> 9) % 2001 - 1000) * 1e-3f); }
+    for (auto& v : ha) { x = x * 1664525u + 1013904223u; v = f32_to_bf16(((int)(x >> 9) % 2001 - 1000) * 1e-3f); }
+    bf16_t* dw = (bf16_t*)t.alloc(wbytes * copies);
+    for (int c = 0; c < copies; ++c) HIP_CHECK(hipMemcpy((char*)dw + wbytes * c, hw.data(), wbytes, hipMemcpyHostToDevice));
+    bf16_t* da = (bf16_t*)t.alloc(ha.size() * 2);
+    HIP_CHECK(hipMemcpy(da, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
+    float* bias = (float*)t.alloc((size_t)N * 4);
+    float* addm = (float*)t.alloc((size_t)Mp * N * 4);
+    float* of32 = (float*)t.alloc((size_t)Mp * N * 4);
+    bf16_t* olo = (bf16_t*)t.alloc((size_t)Mp * N * 2);
+    float* lnx = (float*)t.alloc((size_t)Mp * K * 4);
+    GemmArgs g;
+    g.A = da; g.lda = K; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = bias;
+    g.sk_ws = (float*)t.alloc((size_t)16 << 20); g.sk_ws_bytes = (size_t)16 << 20; g.sk_cnt = (int32_t*)t.alloc(4096 * 4);
+    switch (epilogue >= 10 ? 0 : epilogue) {
+      case 0: g.out_lo = olo; g.ld_out_lo = N; break;                                                  // bias -> bf16 (q|k|v, cross-q with a separate LayerNorm)
+      case 1: g.out_lo = olo; g.ld_out_lo = N; g.act = ACT_GELU_ERF; break;                            // fc1
+      case 2: g.add = addm; g.ld_add = N; g.out_f32 = of32; g.ld_out_f32 = N; break;                   // out-proj / fc2: + residual -> f32
+      case 3: g.A = nullptr; g.ln_x = lnx; g.ld_ln_x = K; g.out_lo = olo; g.ld_out_lo = N; break;      // LayerNorm prologue -> bf16
+      default: ASR_THROW(ASR_ERR_INVALID, "probe_gemm_chain: unknown epilogue %d", epilogue);
+    }
+    hipStream_t s;
+    HIP_CHECK(hipStreamCreate(&s));
+    const int chain = std::max(copies, 64);
+    DecGemmArgs dg;                                      // epilogue >= 10: the decode GEMM (csrc/decode_gemm.hip)
+    const bool use_dg = epilogue >= 10;
+    if (use_dg) {
+      const int e = epilogue - 10;
+      float* cs = (float*)t.alloc((size_t)N * 4);
+      dg.A = da; dg.lda = K; dg.ldw = K; dg.M = M; dg.N = N; dg.K = K; dg.bias = bias;
+      dg.ws = g.sk_ws; dg.ws_bytes = g.sk_ws_bytes; dg.cnt = g.sk_cnt;
+      if (e == 0) { dg.out_lo = olo; dg.ld_out_lo = N; }
+      else if (e == 1) { dg.out_lo = olo; dg.ld_out_lo = N; dg.act = ACT_GELU_ERF; dg.colsum = cs; }
+      else if (e == 2) { dg.add = addm; dg.ld_add = N; dg.out_f32 = of32; dg.ld_out_f32 = N; dg.out_lo = olo; dg.ld_out_lo = N; }
+      else if (e == 3) { dg.out_lo = olo; dg.ld_out_lo = N; dg.colsum = cs; }
+      else ASR_THROW(ASR_ERR_INVALID, "probe_gemm_chain: unknown decode epilogue %d", e);
+      int nt = 1, sp = 1;
+      decode_gemm_plan(dg, &nt, &sp);
+      snprintf(g_chain_kernel, sizeof(g_chain_kernel), "decode nt%d ks%d", nt, sp);
+    }
+    auto enqueue = [&] {
+      for (int i = 0; i < chain; ++i) {
+        if (use_dg) { DecGemmArgs gi = dg; gi.W = (const bf16_t*)((char*)dw + wbytes * (i % copies)); launch_decode_gemm(gi, s); }
+        else { GemmArgs gi = g; gi.W = (char*)dw + wbytes * (i % copies); launch_gemm_bf16(gi, s); }
+      }
+    };
+    enqueue();                                                 // eager once (lazy attributes)
+    HIP_CHECK(hipStreamSynchronize(s));
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    enqueue();
+    HIP_CHECK(hipStreamEndCapture(s, &graph));
+    HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(hipGraphLaunch(exec, s));
+    HIP_CHECK(hipEventRecord(e0, s));
+    for (int r = 0; r < replays; ++r) HIP_CHECK(hipGraphLaunch(exec, s));
+    HIP_CHECK(hipEventRecord(e1, s));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *us_per_launch = ms * 1e3f / ((float)replays * chain);
+    if (!use_dg) snprintf(g_chain_kernel, sizeof(g_chain_kernel), "%s", gemm_last_kernel());
+    (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+  });
+}
+extern "C" const char* asr_probe_last_kernel(void) { return g_chain_kernel; }
 
 extern "C" int asr_probe_gemm_counts(int reset, char* buf, int cap) {
   return asr_guard([&] {

@@ -51,6 +51,8 @@ struct WhSession : asr_session {
   bool track_history = false;          // GREEDY_SEARCH graphs append every pick to save_id even while the penalty value is 1.0
   int penalty_range = 20;
   bool use_graph = true;
+  bool use_decode_gemm = true;         // ASR_DECODE_GEMM=0: decode steps through the generic weight-streaming GEMM + LayerNorm prologues
+  DeviceBuffer d_colsum, d_dlo;        // column sums of the LayerNorm-folded decoder projections; bf16 copies of the decoder's residual rows
   hipGraphExec_t dec_graph = nullptr;
   uint64_t dec_key = 0, dec_eager_key = 0, ws_epoch = 1;
   void* h_plan = nullptr; size_t h_plan_cap = 0;
@@ -58,7 +60,7 @@ struct WhSession : asr_session {
 
   ~WhSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_x0, &d_h1, &d_xa, &d_xb, &d_xc, &d_h, &d_qk, &d_vt, &d_ctx,
-                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise, &d_nsp, &d_skws, &d_skcnt})
+                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise, &d_nsp, &d_skws, &d_skcnt, &d_colsum, &d_dlo})
       b->release();
     if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
     for (auto& kv : taps) kv.second.buf.release();
@@ -134,6 +136,17 @@ void WhSession::init() {
     dec[i] = DecLayer{W(p + "wqkv", {3 * d, d}), W(p + "wo", {d, d}), W(p + "wcq", {d, d}), W(p + "wco", {d, d}),
                       W(p + "w1", {dff, d}), W(p + "w2", {d, dff}),
                       F(p + "bqkv", {3 * d}), F(p + "bo", {d}), F(p + "bcq", {d}), F(p + "bco", {d}), F(p + "b1", {dff}), F(p + "b2", {d})};
+  }
+  if (precision == ASR_PRECISION_BF16 && use_decode_gemm) {      // column sums of the three LayerNorm-folded projections of every decoder layer: [3d | d | dff]
+    const size_t per = (size_t)3 * d + d + dff;
+    d_colsum.reserve((size_t)Ld * per * 4, stream);
+    for (int i = 0; i < Ld; ++i) {
+      float* c0 = d_colsum.as<float>() + i * per;
+      launch_colsum_bf16((const bf16_t*)dec[i].wqkv, d, 3 * d, d, c0, stream);
+      launch_colsum_bf16((const bf16_t*)dec[i].wcq, d, d, d, c0 + 3 * d, stream);
+      launch_colsum_bf16((const bf16_t*)dec[i].w1, d, dff, d, c0 + 4 * d, stream);
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
   }
 }
 
@@ -371,9 +384,30 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
     ProfScope ps(prof, "dec_gemm", stream);
     gemm(g);
   };
+  // bf16 decode steps of <= 64 rows: the decode GEMM (csrc/decode_gemm.hip) with the three LayerNorms folded into q|k|v, cross-q and fc1
+  bool dgm = false;
+  bf16_t *xa_lo = nullptr, *xb_lo = nullptr, *xc_lo = nullptr;
+  const float* csum = d_colsum.as<float>();
+  const size_t cs_l = (size_t)3 * d + d + dff;
+  if constexpr (sizeof(T) == 2) {
+    dgm = use_decode_gemm && R <= 64 && d_colsum.ptr != nullptr && d % 256 == 0 && dff % 256 == 0;
+    xa_lo = d_dlo.as<bf16_t>(); xb_lo = xa_lo + (size_t)Rp * d; xc_lo = xb_lo + (size_t)Rp * d;
+  }
+  auto dg = [&](const void* A, int lda, const void* Wt, int N, int K, const float* bias, const float* colsum, const float* add, int act_, float* of32,
+                void* olo, int ld_lo) {
+    ProfScope ps(prof, "dec_gemm", stream);
+    if (!d_skws.ptr) { d_skws.reserve((size_t)16 << 20, stream); d_skcnt.reserve(4096 * 4, stream); }
+    DecGemmArgs g;
+    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)Wt; g.ldw = K; g.M = R; g.N = N; g.K = K; g.bias = bias; g.colsum = colsum;
+    g.add = add; g.ld_add = d; g.act = act_; g.out_f32 = of32; g.ld_out_f32 = d; g.out_lo = (bf16_t*)olo; g.ld_out_lo = ld_lo;
+    g.ws = d_skws.as<float>(); g.ws_bytes = d_skws.cap; g.cnt = d_skcnt.as<int32_t>();
+    launch_decode_gemm(g, stream);
+  };
+  if (dgm) { ProfScope ps(prof, "dec_embed", stream); launch_rows_to_bf16(xa, xa_lo, (size_t)Rp * d, stream); }
   for (int l = 0; l < Ld; ++l) {
     const DecLayer& L = dec[l];
-    {
+    if (dgm) dg(xa_lo, d, L.wqkv, 3 * d, d, L.bqkv, csum + l * cs_l, nullptr, ACT_NONE, nullptr, qkv, 3 * d);
+    else {
       GemmArgs g;
       g.W = L.wqkv; g.ldw = d; g.M = R; g.N = 3 * d; g.K = d; g.bias = L.bqkv; g.out_lo = qkv; g.ld_out_lo = 3 * d;
       ln_gemm(xa, g);
@@ -388,13 +422,16 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
       a.max_keys = c.max_target_positions;
       launch_decode_attention<T>(a, B, stream);
     }
-    {
-      ProfScope ps(prof, "dec_gemm", stream);
-      GemmArgs g;
-      g.A = ctx; g.lda = d; g.W = L.wo; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bo; g.add = xa; g.ld_add = d; g.out_f32 = xb; g.ld_out_f32 = d;
-      gemm(g);
-    }
-    {
+    if (dgm) {
+      dg(ctx, d, L.wo, d, d, L.bo, nullptr, xa, ACT_NONE, xb, xb_lo, d);
+      dg(xb_lo, d, L.wcq, d, d, L.bcq, csum + l * cs_l + 3 * d, nullptr, ACT_NONE, nullptr, cq, d);
+    } else {
+      {
+        ProfScope ps(prof, "dec_gemm", stream);
+        GemmArgs g;
+        g.A = ctx; g.lda = d; g.W = L.wo; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bo; g.add = xa; g.ld_add = d; g.out_f32 = xb; g.ld_out_f32 = d;
+        gemm(g);
+      }
       GemmArgs g;
       g.W = L.wcq; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bcq; g.out_lo = cq; g.ld_out_lo = d;
       ln_gemm(xb, g);
@@ -410,13 +447,24 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
       a.out = ctx; a.ld_out = d;
       launch_decode_attention<T>(a, B, stream);
     }
-    {
-      ProfScope ps(prof, "dec_gemm", stream);
-      GemmArgs g;
-      g.A = ctx; g.lda = d; g.W = L.wco; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bco; g.add = xb; g.ld_add = d; g.out_f32 = xc; g.ld_out_f32 = d;
-      gemm(g);
-    }
-    {
+    if (dgm) {
+      dg(ctx, d, L.wco, d, d, L.bco, nullptr, xb, ACT_NONE, xc, xc_lo, d);
+      dg(xc_lo, d, L.w1, dff, d, L.b1, csum + l * cs_l + 4 * d, nullptr, act, nullptr, ffn, dff);
+      if (R <= 32) dg(ffn, dff, L.w2, d, dff, L.b2, nullptr, xc, ACT_NONE, xa, xa_lo, d);
+      else {               // 33..64 rows: the tiled split-K pass shares the activation rows across 64 columns (13.8 vs 17.9 us); it writes the bf16 copy too
+        ProfScope ps(prof, "dec_gemm", stream);
+        GemmArgs g2;
+        g2.A = ffn; g2.lda = dff; g2.W = L.w2; g2.ldw = dff; g2.M = R; g2.N = d; g2.K = dff; g2.bias = L.b2; g2.add = xc; g2.ld_add = d;
+        g2.out_f32 = xa; g2.ld_out_f32 = d; g2.out_lo = xa_lo; g2.ld_out_lo = d;
+        gemm(g2);
+      }
+    } else {
+      {
+        ProfScope ps(prof, "dec_gemm", stream);
+        GemmArgs g;
+        g.A = ctx; g.lda = d; g.W = L.wco; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bco; g.add = xb; g.ld_add = d; g.out_f32 = xc; g.ld_out_f32 = d;
+        gemm(g);
+      }
       GemmArgs g;
       g.W = L.w1; g.ldw = d; g.M = R; g.N = dff; g.K = d; g.bias = L.b1; g.act = act; g.out_lo = ffn; g.ld_out_lo = dff;
       ln_gemm(xc, g);
@@ -486,6 +534,7 @@ void WhSession::step(const int32_t* ids_host, int n, bool is_prefill, int32_t* n
   grow(d_save, (size_t)B * c.max_target_positions * 4);
   grow(d_logits, (size_t)Bp * vpad * 4);
   grow(d_dx, (size_t)3 * Rp * d * 4);                  // three f32 residual-stream buffers
+  if (precision == ASR_PRECISION_BF16) grow(d_dlo, (size_t)3 * Rp * d * 2);     // ... and their bf16 copies (operands of the LayerNorm-folded projections)
   grow(d_dqkv, (size_t)Rp * (3 * d + d + d + dff + d) * eT + (size_t)Bp * d * eT);
   const int32_t* ids_dev;
   if (ids_host) {
@@ -561,6 +610,7 @@ extern "C" int asr_whisper_create(const asr_whisper_config* cfg, const void* are
       s->cfg = *cfg;
       gemm_reload_env();
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
+      if (const char* e = getenv("ASR_DECODE_GEMM")) s->use_decode_gemm = !(e[0] == '0');
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;
       s->arena.load(arena, arena_bytes, arena_mem, s->stream);

@@ -33,6 +33,12 @@ typedef struct asr_probe_gemm_desc {
 } asr_probe_gemm_desc;
 int asr_probe_gemm(asr_probe_gemm_desc* d);
 
+/* Decode-shaped GEMM (M <= 64 rows) as a captured chain of dependent launches over `cold_mb` megabytes of weight copies (larger than
+ * the Infinity Cache => every launch streams its weights from HBM, like a decoder stack does once per token): microseconds per launch.
+ * epilogue: 0 bias -> bf16, 1 bias + GELU -> bf16, 2 bias + residual -> f32, 3 LayerNorm prologue (f32 rows in) -> bf16. */
+int asr_probe_gemm_chain(int M, int N, int K, int epilogue, int cold_mb, int replays, float* us_per_launch);
+const char* asr_probe_last_kernel(void);      /* kernel family of the last asr_probe_gemm_chain */
+
 /* launches per GEMM kernel family since the last reset, as "family=count;..." (host-side counters: hipGraph replays do not
  * count, so reset, run a session once on a new batch geometry, read). reset != 0 clears the counters after the read. */
 int asr_probe_gemm_counts(int reset, char* buf, int cap);

@@ -52,15 +52,12 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 // write-through (sc1) stores: the payload of an exchange must be in memory, not dirty in this XCD's L2, when the flag is raised
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-__device__ int g_plain_stores;
-__device__ int g_loop_dbg;          // timing-only ablations of the GEMM loops (ASR_SANM_BLOCK_ABL): 1 = no refills after the prologue, 2 = no MFMA, 4 = no fragment reads      // tuning experiment (ASR_SANM_BLOCK_PLAIN=1): exchange payload through ordinary stores (valid only for same-XCD clusters)
+__device__ int g_loop_dbg;          // timing-only ablations of the GEMM loops (ASR_SANM_BLOCK_ABL): 1 = no refills after the prologue, 2 = no MFMA, 4 = no fragment reads
 __device__ __forceinline__ void store16_wt(void* p, uint4 v) {
-  if (g_plain_stores) { *reinterpret_cast<uint4*>(p) = v; return; }
   const u32x4_t w = {v.x, v.y, v.z, v.w};
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
 }
 __device__ __forceinline__ void store8_wt(void* p, float2 v) {
-  if (g_plain_stores) { *reinterpret_cast<float2*>(p) = v; return; }
   const f32x2_t w = {v.x, v.y};
   asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
 }
@@ -729,8 +726,6 @@ void launch_sanm_block(const SanmBlockArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sanm_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    const int plain = getenv("ASR_SANM_BLOCK_PLAIN") && getenv("ASR_SANM_BLOCK_PLAIN")[0] == '1';
-    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_plain_stores), &plain, sizeof(int)));
     const int abl = getenv("ASR_SANM_BLOCK_ABL") ? atoi(getenv("ASR_SANM_BLOCK_ABL")) : 0;
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_loop_dbg), &abl, sizeof(int)));
     attr_set = true;

@@ -527,8 +527,14 @@ def main_paraformer(args):
         gemm_ms = sum(v["ms_per_step"] for k, v in kernels.items() if k.startswith("gemm_"))
         T, nb, d = cfg.seq_len(n_samples), cfg.n_enc0 + cfg.n_enc, cfg.d_model
         enc_gemm = B * 2.0 * T * (3 * d * (cfg.feat_dim * cfg.n_enc0 + d * cfg.n_enc) + nb * (d * d + 2 * d * cfg.d_ffn))
-        enc_ms = sum(kernels[k]["ms_per_step"] for k in ("gemm_qkv", "gemm_ffn1", "gemm_ffn2") if k in kernels)
-        enc_ms += kernels.get("gemm_out", {"ms_per_step": 0})["ms_per_step"]
+        if "sanm_block" in kernels:        # one launch per encoder block: its GEMMs + attention + FSMN (block 0 keeps the separate launches)
+            enc_gemm += B * (4.0 * T * T * d + 2.0 * T * d * cfg.fsmn_kernel) * nb
+            enc_ms = kernels["sanm_block"]["ms_per_step"] + sum(kernels[k]["ms_per_step"] for k in ("sanm_fused", "gemm_qkv", "gemm_ffn1", "gemm_ffn2") if k in kernels)
+            dom_desc = "sanm_block_kernel (one launch per SANM encoder block: q|k|v + attention + FSMN + out-proj + FFN; csrc/sanm_block.hip)"
+        else:
+            enc_ms = sum(kernels[k]["ms_per_step"] for k in ("gemm_qkv", "gemm_ffn1", "gemm_ffn2") if k in kernels)
+            enc_ms += kernels.get("gemm_out", {"ms_per_step": 0})["ms_per_step"]
+            dom_desc = "gemm_bf16_pipe (encoder qkv/out/ffn launches; the out class also holds the vocab GEMM)"
         ach = enc_gemm / (enc_ms * 1e-3) / 1e12 if enc_ms else 0.0
         out = {"metric": "audio-sec/s, Paraformer-large (non-streaming), 8 s @ 16 kHz chunks, batch %d per GPU" % B,
                "value": round(audio_s * args.steps / elapsed, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
@@ -540,7 +546,7 @@ def main_paraformer(args):
                           "parallelism": f"dp{world}"},
                "rtf": round(elapsed / (audio_s * args.steps), 8),
                "model_tflops_per_gpu": round(flops / (ms * 1e-3) / 1e12, 1),
-               "roofline": {"bound": "mfma", "kernel": "gemm_bf16_pipe (encoder qkv/out/ffn launches; the out class also holds the vocab GEMM)",
+               "roofline": {"bound": "mfma", "kernel": dom_desc,
                             "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "gemm_ms_per_step": round(gemm_ms, 3)},
                "kernels": kernels}

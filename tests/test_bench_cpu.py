@@ -23,13 +23,17 @@ def test_committed_counter_summaries_feed_the_roofline():
 def test_committed_bench_lines_keep_the_contract():
     need = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
             "config", "roofline"}
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_bench_*_n1.json"))) + [os.path.join(ROOT, "profiles", "r01_bench_n1.json")]
-    assert len(files) >= 8
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[0-9]_bench_*n1.json")))
+    assert len(files) >= 18 and os.path.join(ROOT, "profiles", "r02_bench_n1.json") in files
     for f in files:
         d = json.load(open(f))
         assert need <= set(d), (f, need - set(d))
         assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"], f
         assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"]), f
-    head = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_n1.json")))
-    assert head["cpu_baseline"]["kind"] == "port" and head["cpu_baseline"]["cores"] >= 1 and head["cpu_baseline"]["sample"]
-    assert head["roofline"]["bound"] == "mfma" and abs(head["roofline"]["frac"] - head["roofline"]["achieved"] / head["roofline"]["peak"]) < 1e-3
+    for rnd in ("r01", "r02"):
+        head = json.load(open(os.path.join(ROOT, "profiles", rnd + "_bench_n1.json")))
+        assert head["cpu_baseline"]["kind"] == "port" and head["cpu_baseline"]["cores"] >= 1 and head["cpu_baseline"]["sample"]
+        assert head["roofline"]["bound"] == "mfma" and abs(head["roofline"]["frac"] - head["roofline"]["achieved"] / head["roofline"]["peak"]) < 1e-3
+    for f in files:      # no line prices a kernel above the machine
+        frac = json.load(open(f))["roofline"]["frac"]
+        assert frac is None or 0.0 < frac < 1.0, f

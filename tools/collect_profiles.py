@@ -1,0 +1,27 @@
+#!/usr/bin/env python
+"""Fold what tools/profile_round.sh left under gpurun_out/prof into the tracked profiles/<round>_* files (run locally after gpurun)."""
+import glob, os, shutil, subprocess, sys
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof"
+os.makedirs("profiles", exist_ok=True)
+names = {"bench_sensevoice": "bench_n1", "bench_sensevoice_4launch": "bench_4launch_n1", "bench_paraformer": "bench_paraformer_n1", "bench_whisper": "bench_whisper_n1",
+         "bench_whisper_b64": "bench_whisper_b64_n1", "bench_whisper30": "bench_whisper30_n1", "bench_paraformer_streaming": "bench_paraformer_streaming_n1",
+         "bench_qwen": "bench_qwen_n1", "bench_qwen_beam5": "bench_qwen_beam5_n1", "bench_mixed_beam5": "bench_mixed_beam5_n1"}
+for a, b in names.items():
+    p = os.path.join(src, a + ".json")
+    if os.path.isfile(p) and os.path.getsize(p) > 10:
+        shutil.copy(p, f"profiles/{rnd}_{b}.json")
+for d, out in (("stats", "sensevoice_b64"), ("stats_whisper", "whisper_b32"), ("stats_whisper30", "whisper30_b32"), ("stats_qwen", "qwen_b64"), ("stats_paraformer", "paraformer_b64")):
+    fs = glob.glob(os.path.join(src, d, "*", "*kernel_stats.csv"))
+    if fs:
+        shutil.copy(sorted(fs, key=os.path.getmtime)[-1], f"profiles/{rnd}_{out}_kernel_stats.csv")
+for w in ("whisper", "qwen"):
+    p = os.path.join(src, f"{w}_trace_summary.txt")
+    if os.path.isfile(p):
+        shutil.copy(p, f"profiles/{rnd}_{w}_trace_summary.txt")
+if glob.glob(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv")):
+    subprocess.run([sys.executable, "tools/summarize_pmc.py", src, f"profiles/{rnd}_hbm_traffic.json"], check=True)
+if glob.glob(os.path.join(src, "pmc_sq", "*", "*_counter_collection.csv")):
+    subprocess.run([sys.executable, "tools/summarize_sq_pmc.py", os.path.join(src, "pmc_sq"), f"profiles/{rnd}_mfma_util.json"], check=True)
+print(sorted(f for f in os.listdir("profiles") if f.startswith(rnd)))

@@ -1,5 +1,7 @@
 #!/bin/bash
-# Round profile: kernel-trace stats + two PMC passes (FETCH_SIZE, WRITE_SIZE) of the headline bench, plus the bench lines.
+# Round profile (run on the GPU box through gpurun): bench lines of every workload, rocprofv3 kernel-trace stats of the headline and of
+# the other families, three PMC passes of the headline (FETCH_SIZE, WRITE_SIZE, SQ counters -- each in its own run, kernel-trace only).
+# Everything lands under gpurun_out/prof; tools/collect_profiles.py then folds it into profiles/<round>_*.
 set -x
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -7,26 +9,26 @@ OUT=$R/gpurun_out/prof
 rm -rf $OUT
 mkdir -p $OUT
 cd $R
-python bench.py --steps 20 > $OUT/bench_sensevoice.json 2> $OUT/bench_sensevoice.err
+python bench.py --steps 20 --warmup 5 > $OUT/bench_sensevoice.json 2> $OUT/bench_sensevoice.err
+ASR_SANM_BLOCK=0 python bench.py --steps 100 --warmup 5 --no-extras --no-cpu-baseline > $OUT/bench_sensevoice_4launch.json 2> $OUT/bench_sensevoice_4launch.err
 python bench.py --workload paraformer --steps 10 > $OUT/bench_paraformer.json 2> $OUT/bench_paraformer.err
 python bench.py --workload whisper --steps 6 --warmup 3 --inflight 3 > $OUT/bench_whisper.json 2> $OUT/bench_whisper.err
 python bench.py --workload whisper --batch 64 --steps 5 --warmup 3 --inflight 2 --no-cpu-baseline > $OUT/bench_whisper_b64.json 2> $OUT/bench_whisper_b64.err
 python bench.py --workload whisper --seconds 30 --steps 3 --warmup 2 --inflight 3 --no-cpu-baseline > $OUT/bench_whisper30.json 2> $OUT/bench_whisper30.err
 python bench.py --workload paraformer-streaming --steps 16 --warmup 8 > $OUT/bench_paraformer_streaming.json 2> $OUT/bench_paraformer_streaming.err
 python bench.py --workload qwen --steps 6 --warmup 2 --inflight 3 > $OUT/bench_qwen.json 2> $OUT/bench_qwen.err
-python bench.py --workload mixed --steps 6 --warmup 1 > $OUT/bench_mixed.json 2> $OUT/bench_mixed.err
 python bench.py --workload qwen --beam 5 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_qwen_beam5.json 2> $OUT/bench_qwen_beam5.err
 python bench.py --workload mixed --beam 5 --steps 6 --warmup 1 > $OUT/bench_mixed_beam5.json 2> $OUT/bench_mixed_beam5.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --profile-steps 1 > $OUT/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extras > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extras > $OUT/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_whisper -- python $R/bench.py --workload whisper --steps 2 --warmup 2 --no-cpu-baseline > $OUT/stats_whisper.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_whisper30 -- python $R/bench.py --workload whisper --seconds 30 --steps 2 --warmup 2 --no-cpu-baseline > $OUT/stats_whisper30.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_qwen -- python $R/bench.py --workload qwen --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats_qwen.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_paraformer -- python $R/bench.py --workload paraformer --steps 10 --warmup 3 --no-cpu-baseline > $OUT/stats_paraformer.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_whisper30 -- python $R/bench.py --workload whisper --seconds 30 --steps 2 --warmup 2 --no-cpu-baseline > $OUT/stats_whisper30.log 2>&1
-for f in $(find $OUT/stats_qwen -name "*kernel_trace.csv"); do python $R/tools/trace_summary.py $f > $OUT/qwen_trace_summary.txt; done
-find $OUT -name "*.csv" | head -30
-for f in $(find $OUT/pmc_fetch $OUT/pmc_write -name "*counter_collection.csv"); do echo $f; head -3 $f; wc -l $f; done
-find $OUT -name "*kernel_trace.csv" -size +20M -delete
+for w in whisper qwen; do for f in $(find $OUT/stats_$w -name "*kernel_trace.csv"); do python $R/tools/trace_summary.py $f > $OUT/${w}_trace_summary.txt; done; done
+find $OUT -name "*kernel_trace.csv" -size +8M -delete
+find $OUT -name "*.csv" | head -40
 du -sh $OUT

@@ -1,9 +1,10 @@
 """Fold the two rocprofv3 PMC passes of tools/profile_round.sh (FETCH_SIZE, WRITE_SIZE; kilobytes per dispatch) into
-profiles/r01_hbm_traffic.json: memory-side bytes per launch and per kernel class. FETCH_SIZE is doubled -- on gfx950 it tallies
+profiles/rNN_hbm_traffic.json: memory-side bytes per launch and per kernel class. FETCH_SIZE is doubled -- on gfx950 it tallies
 128-byte requests at 64 bytes (MI355X_MICROARCH.md, HBM section); WRITE_SIZE matched the algorithmic store volume as is."""
 import collections, csv, glob, json, os, sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
+out_path = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_hbm_traffic.json"
 agg = collections.defaultdict(lambda: {"launches": 0, "fetch_kb_raw": 0.0, "write_kb": 0.0})
 for kind, key in (("fetch", "fetch_kb_raw"), ("write", "write_kb")):
     f = sorted(glob.glob(f"{src}/pmc_{kind}/*/*_counter_collection.csv"), key=os.path.getmtime)[-1]
@@ -24,6 +25,6 @@ for k, v in sorted(agg.items(), key=lambda kv: -(2 * kv[1]["fetch_kb_raw"] + kv[
     write = v["write_kb"] * 1024 / v["launches"]
     out["kernels"][k] = {"launches": v["launches"], "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
                          "bytes_per_launch": round(fetch + write)}
-json.dump(out, open("profiles/r01_hbm_traffic.json", "w"), indent=1)
+json.dump(out, open(out_path, "w"), indent=1)
 for k, v in list(out["kernels"].items())[:10]:
     print(f"{k[:80]:80s} {v['launches']:5d}  fetch {v['fetch_bytes_per_launch']/1e6:8.1f} MB  write {v['write_bytes_per_launch']/1e6:8.1f} MB")

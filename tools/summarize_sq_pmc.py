@@ -1,12 +1,12 @@
 """Fold one rocprofv3 SQ counter pass (tools/profile_round.sh: SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY
-SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE) into profiles/r01_mfma_util.json: per
+SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE) into profiles/rNN_mfma_util.json: per
 kernel class the MFMA pipe utilisation (gfx94x MfmaUtil formula, MFMA busy cycles / (GPU cycles x 256 CUs x 4 SIMDs); GRBM_GUI_ACTIVE comes
 summed over the 8 XCDs, so GPU cycles = GRBM_GUI_ACTIVE / 8) and where the
 wave cycles went (WAIT_ANY = parked on s_waitcnt / barrier, WAIT_INST_ANY = issue stalls, ACTIVE_INST_ANY = issuing; quad-cycles)."""
 import collections, csv, glob, json, os, sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof/pmc_sq"
-out_path = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_mfma_util.json"
+out_path = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_mfma_util.json"
 f = sorted(glob.glob(f"{src}/*/*_counter_collection.csv"), key=os.path.getmtime)[-1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 seen = collections.defaultdict(set)

@@ -10,7 +10,7 @@ for kind, key in (("fetch", "fetch_kb_raw"), ("write", "write_kb")):
     f = sorted(glob.glob(f"{src}/pmc_{kind}/*/*_counter_collection.csv"), key=os.path.getmtime)[-1]
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        cls = "gemm_bf16_t144" if ("gemm_bf16_t144" in name or "gemm_bf16_t288w" in name) else "sanm_qkv_attn_kernel" if "sanm_qkv_attn" in name else name.split("(")[0].split("::")[-1][:48]
+        cls = "gemm_bf16_t144" if ("gemm_bf16_t144" in name or "gemm_bf16_t288w" in name) else "sanm_qkv_attn_kernel" if "sanm_qkv_attn" in name else name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0][:48]
         for k in (cls, name[:96]):
             agg[k][key] += float(r["Counter_Value"])
             if kind == "fetch":

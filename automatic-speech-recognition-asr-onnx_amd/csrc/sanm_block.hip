@@ -52,8 +52,9 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 // write-through (sc1) stores: the payload of an exchange must be in memory, not dirty in this XCD's L2, when the flag is raised
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-__device__ int g_loop_dbg;          // timing-only ablations of the GEMM loops (ASR_SANM_BLOCK_ABL): 1 = no refills after the prologue, 2 = no MFMA, 4 = no fragment reads
+__device__ int g_loop_dbg;          // timing-only ablations of the GEMM loops (ASR_SANM_BLOCK_ABL): 1 = no refills after the prologue, 2 = no MFMA, 4 = no fragment reads, 8 = weight rows alias one 64-row region (every weight load hits L2), 16 = payload / output stores skipped
 __device__ __forceinline__ void store16_wt(void* p, uint4 v) {
+  if (g_loop_dbg & 16) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); return; }
   const u32x4_t w = {v.x, v.y, v.z, v.w};
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
 }
@@ -113,7 +114,7 @@ __device__ __forceinline__ void tile_loop_impl(unsigned char* ring, const bf16_t
       src[t] = a0 + (size_t)min(r, a_rows_left - 1) * lda + (((lane & 7) ^ srow) << 3);
     } else {
       const int wr = (ii - R / 8) * 8 + srow;
-      src[t] = w0 + (size_t)wr * ldw + (((lane & 7) ^ w_swz(wr)) << 3);
+      src[t] = w0 + (size_t)((g_loop_dbg & 8) ? (wr & 63) : wr) * ldw + (((lane & 7) ^ w_swz(wr)) << 3);
     }
   }
   auto stage = [&](int slot, int k0) {
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_by
         src[t] = hb + (size_t)(row0 + min(ii * 16 + r16, rows_left - 1)) * D + ch;
       } else {
         const int wr = (ii - A_AI) * 16 + r16;              // 0..383: q | k | v rows of this head
-        src[t] = wb + (size_t)((wr >> 7) * D + h * HD + (wr & 127)) * D + ch;
+        src[t] = wb + (size_t)((g_loop_dbg & 8) ? (wr & 63) : (wr >> 7) * D + h * HD + (wr & 127)) * D + ch;
       }
     }
     auto stage = [&](int slot, int k0) {
@@ -619,7 +620,9 @@ __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_by
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const unsigned long long tc0 = a->times ? wall_clock64() : 0ull;
       tile_loop<256, 3, 4, false>(smem, a->x1_lo + (size_t)row0 * D, D, rows_left, a->w1 + (size_t)col0 * D, D, D / 64, n_act, acc, lane, wave);
+      if (a->times && threadIdx.x == 0) a->times[(size_t)blockIdx.x * 16 + 14] += wall_clock64() - tc0;
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int n = col0 + cg * 64 + p * 32 + fgrp * 8;
@@ -671,10 +674,12 @@ __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_by
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += b8[e] + xres[i][e];
         float* xo = a->x + (size_t)(row0 + row) * D + h * HD + n;
-        *reinterpret_cast<float4*>(xo) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(xo + 4) = make_float4(v[4], v[5], v[6], v[7]);
         const uint4 pk = pack8(v);
-        *reinterpret_cast<uint4*>(a->x_lo_out + (size_t)(row0 + row) * D + h * HD + n) = pk;
+        if (!(g_loop_dbg & 16)) {
+          *reinterpret_cast<float4*>(xo) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(xo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          *reinterpret_cast<uint4*>(a->x_lo_out + (size_t)(row0 + row) * D + h * HD + n) = pk;
+        }
         float s1 = 0.0f, s2 = 0.0f;
         stats8(pk, s1, s2);
         s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);

@@ -731,6 +731,9 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
     if (n) {
       fprintf(stderr, "[sanm_block %d] %d workgroups, first start -> last end %.1f us\n", block_dbg, n, (double)(t_last - t_first) * 0.01);
       for (int k = 0; k < 13; ++k) fprintf(stderr, "  %-22s avg %6.2f us  max %6.2f us\n", names[k], sum[k] / n, mx[k]);
+      double c_loops = 0.0;
+      for (int w = 0; w < 256; ++w) if (t[w * 16]) c_loops += (double)t[w * 16 + 14] * 0.01;
+      fprintf(stderr, "  %-22s avg %6.2f us  (inside C: the two GEMM loops without their epilogues)\n", "C loops", c_loops / n);
     }
   }
   {

@@ -25,6 +25,8 @@ SIGNATURES = {
     "asr_probe_gemm": (C.c_int, [C.POINTER(GemmDesc)]),
     "asr_probe_gemm_chain": (C.c_int, [C.c_int] * 6 + [_fp]),
     "asr_probe_last_kernel": (C.c_char_p, []),
+    "asr_probe_quantize_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, _fp, C.c_void_p]),
+    "asr_probe_decode_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _fp, _fp, C.c_int, _fp]),
     "asr_probe_gemm_counts": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "asr_probe_gemm_bench": (C.c_int, [C.c_int] * 6 + [_fp]),
     "asr_probe_grid_barrier": (C.c_int, [C.c_int, C.c_int, _fp]),
@@ -102,3 +104,38 @@ def gemm_chain(M, N, K, epilogue=0, cold_mb=768, replays=5):
     us = C.c_float(0.0)
     _lib.check(load().asr_probe_gemm_chain(M, N, K, epilogue, cold_mb, replays, C.byref(us)))
     return us.value, load().asr_probe_last_kernel().decode()
+
+
+def _bf16_bits(x):
+    """f32 array -> bf16 bit patterns (round to nearest even), as uint16."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+
+
+def _bf16_to_f32(bits):
+    return (np.ascontiguousarray(bits, np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def quantize_fp8(w):
+    """Row quantiser of the FP8 mode on an f32 array (rounded to bf16 first): (bytes [N][K] uint8, scale [N] f32, dequantised f32 [N][K])."""
+    wb = _bf16_bits(w)
+    N, K = wb.shape
+    q = np.zeros((N, K), np.uint8); sc = np.zeros((N,), np.float32); dq = np.zeros((N, K), np.uint16)
+    _lib.check(load().asr_probe_quantize_fp8(wb.ctypes.data, N, K, q.ctypes.data, sc.ctypes.data_as(_fp), dq.ctypes.data))
+    return q, sc, _bf16_to_f32(dq)
+
+
+def decode_gemm(a, w=None, w8=None, scale=None, bias=None, fold=False):
+    """Decode GEMM (<= 64 rows) on host arrays: a [M][K] f32 (rounded to bf16), weights either f32 `w` (rounded to bf16) or (w8, scale)."""
+    ab = _bf16_bits(a)
+    M, K = ab.shape
+    wb = None if w is None else _bf16_bits(w)
+    N = (wb if wb is not None else w8).shape[0]
+    out = np.zeros((M, N), np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    s = None if scale is None else np.ascontiguousarray(scale, np.float32)
+    q = None if w8 is None else np.ascontiguousarray(w8, np.uint8)
+    _lib.check(load().asr_probe_decode_gemm(M, N, K, ab.ctypes.data, None if wb is None else wb.ctypes.data, None if q is None else q.ctypes.data,
+                                            None if s is None else s.ctypes.data_as(_fp), None if b is None else b.ctypes.data_as(_fp), int(fold),
+                                            out.ctypes.data_as(_fp)))
+    return out

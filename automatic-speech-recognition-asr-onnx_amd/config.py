@@ -129,6 +129,14 @@ def whisper_mid_test() -> WhisperConfig:
                          no_speech_id=4993, first_language_id=4901, n_languages=80)
 
 
+def whisper_d256_test() -> WhisperConfig:
+    """Smallest geometry the decode GEMM and the FP8 mode accept (d_model and d_ffn multiples of 256): 4 heads x 64, 2 + 3 layers."""
+    return WhisperConfig(n_mels=128, d_model=256, n_heads=4, d_head=64, d_ffn=1024, n_enc_layers=2, n_dec_layers=3, vocab=3000,
+                         max_source_positions=1500, max_target_positions=448,
+                         sot_id=2900, eot_id=2899, transcribe_id=2990, translate_id=2989, no_timestamps_id=2994,
+                         no_speech_id=2993, first_language_id=2901, n_languages=80)
+
+
 @dataclass(frozen=True)
 class ParaformerConfig:
     """Paraformer-large (non-streaming): Paraformer/Non-Streaming/Export_Paraformer.py:73-96,389-431."""

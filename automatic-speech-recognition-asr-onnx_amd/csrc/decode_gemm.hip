@@ -16,6 +16,12 @@
 // producing GEMM) and  LN(x) W^T = rstd (x W^T - mean c),  c[n] = sum_k W[n][k];  sum(x) and sum(x^2) of every row come from two extra
 // MFMAs per activation fragment (ones x A^T, A A^T) on the otherwise idle matrix pipe. This removes the per-workgroup LayerNorm prologue
 // of the weight-streaming kernel (every workgroup re-normalising all rows: +4.7 us per launch) and the stand-alone LayerNorm launch.
+//
+// FP8 weights (W8, precision mode ASR_PRECISION_FP8W): W holds OCP e4m3 bytes [N][K] with one power-of-two f32 scale per output
+// column; a lane loads 8 bytes per fragment, widens them to bf16 in registers (exact: 4 significant bits) and the epilogue multiplies the
+// finished sum by the scale. With power-of-two scales  (sum_k a w8) * s  ==  sum_k a (w8 * s)  bit for bit, so the same kernel over the
+// dequantised bf16 copy of the weights is an exact reference for this path (tests/test_whisper_fp8_gpu.py).
+#include <type_traits>
 #include "gemm.h"
 
 namespace {
@@ -23,7 +29,17 @@ namespace {
 constexpr int DW = 8;                           // waves per workgroup; each takes one K sub-slice
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-template <int MT, int NT, bool FOLD>
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+// 8 e4m3 bytes -> one bf16x8 MFMA fragment (v_cvt_scalef32_pk_bf16_fp8: two bytes -> two bf16 per instruction, scale 1)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw_t;
+__device__ __forceinline__ bf16x8_t fp8x8_to_bf16x8(u32x2_t r) {
+  union { bf16x8_t v; bf16x2_hw_t p[4]; } u;
+  u.p[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[0], 1.0f, false); u.p[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[0], 1.0f, true);
+  u.p[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[1], 1.0f, false); u.p[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[1], 1.0f, true);
+  return u.v;
+}
+
+template <int MT, int NT, bool FOLD, bool W8>
 __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -34,8 +50,9 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
   const int kw = (wave + (int)blockIdx.x) & (DW - 1);    // rotate the wave -> slice map per workgroup: the shared activation rows are not hit in lock-step
   const int k_begin = (ks * DW + kw) * kslice;
   const bf16_t* wp = g.W + (size_t)(n0 + frow) * g.ldw + k_begin + fgrp * 8;
+  const unsigned char* wp8 = g.W8 + (size_t)(n0 + frow) * g.ldw + k_begin + fgrp * 8;     // (W8: ldw counts bytes = elements)
   const bf16_t* ap = g.A + (size_t)frow * g.lda + k_begin + fgrp * 8;
-  constexpr int U = 8 / NT;                            // K-steps per trip: U x NT weight fragments (16 B per lane each) in flight per wave
+  constexpr int U = (W8 ? 16 : 8) / NT;                // K-steps per trip: U x NT weight fragments in flight per wave (16 B per lane each; byte weights: 8 B, twice as many)
 
   f32x4_t acc[MT][NT], sx[MT], sxx[MT];
 #pragma unroll
@@ -53,12 +70,16 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
   const bf16x8_t ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
   for (int k = 0; k < kslice; k += 32 * U) {
-    bf16x8_t wf[U][NT];
+    using raw_t = typename std::conditional<W8, u32x2_t, bf16x8_t>::type;
+    raw_t wf[U][NT];
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (k + u * 32 < kslice) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wf[u][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)j * 16 * g.ldw + k + u * 32));
+        for (int j = 0; j < NT; ++j) {
+          if constexpr (W8) wf[u][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(wp8 + (size_t)j * 16 * g.ldw + k + u * 32));
+          else wf[u][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)j * 16 * g.ldw + k + u * 32));
+        }
       }
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -67,7 +88,11 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
         for (int i = 0; i < MT; ++i) {
           const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(ap + (size_t)i * 16 * g.lda + k + u * 32);
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][j], af, acc[i][j], 0, 0, 0);   // D[n = 4 fgrp + r][m = frow]
+          for (int j = 0; j < NT; ++j) {
+            bf16x8_t wv;
+            if constexpr (W8) wv = fp8x8_to_bf16x8(wf[u][j]); else wv = wf[u][j];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, af, acc[i][j], 0, 0, 0);   // D[n = 4 fgrp + r][m = frow]
+          }
           if constexpr (FOLD) {
             sx[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af, sx[i], 0, 0, 0);       // D[*][m = frow] = sum_k x[m][k]
             sxx[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, af, sxx[i], 0, 0, 0);       // D[a][b] = x[a] . x[b]: the diagonal is sum(x^2)
@@ -125,6 +150,11 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
   if (wave >= TILES) return;
   const int m = ti * 16 + frow, n = n0 + tj * 16 + fgrp * 4;
   if (m >= g.M) return;
+  if constexpr (W8) {      // (an opaque v_mul_f32: the exact power-of-two product must not be contracted into the fused multiply-adds below, or the rounding order would differ from the bf16 kernel's)
+    const float4 sc = *reinterpret_cast<const float4*>(g.w_scale + n);
+    auto mul = [](float a, float b) { float r; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+    sum.x = mul(sum.x, sc.x); sum.y = mul(sum.y, sc.y); sum.z = mul(sum.z, sc.z); sum.w = mul(sum.w, sc.w);
+  }
   if constexpr (FOLD) {                                  // rstd (x W^T - mean c): statistics summed over the waves in a fixed order
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -169,15 +199,23 @@ template <int MT, int NT>
 void launch_inst(const DecGemmArgs& g, int splits, hipStream_t s) {
   const size_t lds = (size_t)DW * MT * NT * 1024 + (size_t)DW * MT * 16 * 8;
   const dim3 grid(g.N / (16 * NT), splits);
-  if (g.colsum) hipLaunchKernelGGL((decode_gemm_kernel<MT, NT, true>), grid, dim3(64 * DW), lds, s, g);
-  else hipLaunchKernelGGL((decode_gemm_kernel<MT, NT, false>), grid, dim3(64 * DW), lds, s, g);
+  auto go = [&](auto kern) {
+    if (lds > 48 * 1024) {
+      static bool set = false;          // (per instantiation of this lambda: one kernel each)
+      if (!set) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); set = true; }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(64 * DW), lds, s, g);
+  };
+  if (g.W8) { if (g.colsum) go(decode_gemm_kernel<MT, NT, true, true>); else go(decode_gemm_kernel<MT, NT, false, true>); }
+  else { if (g.colsum) go(decode_gemm_kernel<MT, NT, true, false>); else go(decode_gemm_kernel<MT, NT, false, false>); }
   HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace
 
 bool decode_gemm_supported(const DecGemmArgs& g) {
-  return g.M >= 1 && g.M <= 64 && g.N % 32 == 0 && g.K % (32 * DW) == 0 && (g.lda * 2) % 16 == 0 && (g.ldw * 2) % 16 == 0 && !(g.colsum && !g.A);
+  return g.M >= 1 && g.M <= 64 && g.N % 32 == 0 && g.K % (32 * DW) == 0 && (g.lda * 2) % 16 == 0 && (g.ldw * (g.W8 ? 1 : 2)) % 16 == 0 && !(g.colsum && !g.A) &&
+         !(g.W8 && !g.w_scale);
 }
 
 // grid shape: column granules of 16 NT, K split across `splits` workgroups -- at most one even round of the chip's CUs
@@ -207,19 +245,10 @@ void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits) {
 
 void launch_decode_gemm(const DecGemmArgs& g, hipStream_t s) {
   ASR_REQUIRE(decode_gemm_supported(g), "decode_gemm: unsupported shape (M = %d, N = %d, K = %d)", g.M, g.N, g.K);
-  ASR_REQUIRE(g.A && g.W && (g.out_f32 || g.out_lo), "decode_gemm: null operand");
+  ASR_REQUIRE(g.A && (g.W || g.W8) && (g.out_f32 || g.out_lo), "decode_gemm: null operand");
   int nt = 1, splits = 1;
   decode_gemm_plan(g, &nt, &splits);
   ASR_REQUIRE(g.N % (16 * nt) == 0, "decode_gemm: N = %d", g.N);
-  static bool attr = false;
-  if (!attr) {
-    const int cap = 96 * 1024;
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_gemm_kernel<4, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_gemm_kernel<4, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_gemm_kernel<2, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_gemm_kernel<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    attr = true;
-  }
   const int mt = g.M <= 16 ? 1 : g.M <= 32 ? 2 : 4;
   if (nt == 2) { if (mt == 1) launch_inst<1, 2>(g, splits, s); else launch_inst<2, 2>(g, splits, s); }
   else if (mt == 1) launch_inst<1, 1>(g, splits, s);

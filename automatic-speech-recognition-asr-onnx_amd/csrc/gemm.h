@@ -75,6 +75,7 @@ int gemm_kernel_counts(char* buf, int cap);   // "family=launches;..." since the
 struct DecGemmArgs {
   const bf16_t* A = nullptr; int lda = 0;            // [M][K] bf16 (colsum set: the RAW residual rows, LayerNorm applied inside)
   const bf16_t* W = nullptr; int ldw = 0;            // [N][K]
+  const unsigned char* W8 = nullptr; const float* w_scale = nullptr;    // FP8 mode instead of W: e4m3 bytes [N][K] (pitch ldw) + one power-of-two scale per output column
   int M = 0, N = 0, K = 0;
   const float* bias = nullptr;
   const float* colsum = nullptr; float ln_eps = 1e-5f;      // c[n] = sum_k W[n][k]: out = rstd (A W^T - mean c) + bias

@@ -70,7 +70,12 @@ struct DecAttnArgs {
   int sc_ld = 0;                                               // (set by the launcher)
   const int32_t* hist_dev;                                     // when set, the history length is read from device memory (graph replay)
   void* out; int ld_out;
+  const float* k_scale = nullptr; const float* v_scale = nullptr;   // FP8 cross-K/V: k_base / v_base hold e4m3 bytes, scale[head][sequence] per slab
 };
+// FP8 (OCP e4m3, power-of-two scales) quantisers of precision mode ASR_PRECISION_FP8W
+void launch_quantize_rows_fp8(const bf16_t* W, int ld, int N, int K, unsigned char* W8, float* scale, bf16_t* Wdq, hipStream_t s);
+void launch_quantize_crosskv_fp8(bf16_t* slabs, size_t slab_elems, int n_slabs, const UttPlan* plan, int batch, unsigned char* out8, float* scale,
+                                 int dq_in_place, hipStream_t s);
 template <typename T>
 void launch_decode_attention(const DecAttnArgs& a, int batch, hipStream_t s);
 

@@ -2,6 +2,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -625,12 +626,26 @@ template <> struct Raw8<float> {
   __device__ __forceinline__ void get(float (&o)[8]) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
 };
 
+// 8 OCP e4m3 bytes of a cached K / V row (FP8 cross-K/V, precision mode ASR_PRECISION_FP8W); the slab's scale is applied by the caller
+struct fp8_t { unsigned char v; };
+template <> struct Raw8<fp8_t> {
+  uint2 v;
+  __device__ __forceinline__ void load(const fp8_t* p) { v = *reinterpret_cast<const uint2*>(p); }
+  __device__ __forceinline__ void get(float (&o)[8]) const {
+    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(v.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(v.x, true);
+    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(v.y, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(v.y, true);
+    o[0] = a[0]; o[1] = a[1]; o[2] = b[0]; o[3] = b[1]; o[4] = c[0]; o[5] = c[1]; o[6] = d[0]; o[7] = d[1];
+  }
+};
+
 template <typename T> __device__ __forceinline__ void load8dims(const T* p, float (&o)[8]) { load8<T>(p, o); }
 
 // NQ = compile-time bound on the queries per sequence: 1 for single-token decode steps (lean registers: more loads in flight),
 // DA_MAXN for prefills.
-template <typename T, int NQ>
+// KV8: the cached K / V rows are e4m3 bytes with one power-of-two scale per (sequence, head) slab (cross-attention only: no new rows)
+template <typename T, int NQ, bool KV8 = false>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
+  using KT = typename std::conditional<KV8, fp8_t, T>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char da_smem[];
   float* sc = reinterpret_cast<float*>(da_smem);          // [n][sc_ld]
   const int sc_ld = a.sc_ld;
@@ -645,13 +660,14 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
   if (a.plan) { n_cached = a.plan[b].n_lfr; row0 = a.plan[b].row_off; }
   else n_cached = hist;
   const int S = a.plan ? n_cached : hist + n;
-  const T* Kc = reinterpret_cast<const T*>(a.k_base) + (size_t)b * a.stride_b + (size_t)h * a.stride_h + (size_t)row0 * 64;
-  const T* Vc = reinterpret_cast<const T*>(a.v_base) + (size_t)b * a.stride_b + (size_t)h * a.stride_h + (size_t)row0 * 64;
+  const KT* Kc = reinterpret_cast<const KT*>(a.k_base) + (size_t)b * a.stride_b + (size_t)h * a.stride_h + (size_t)row0 * 64;
+  const KT* Vc = reinterpret_cast<const KT*>(a.v_base) + (size_t)b * a.stride_b + (size_t)h * a.stride_h + (size_t)row0 * 64;
   const T* Q = reinterpret_cast<const T*>(a.q);
-  const T* NEW = reinterpret_cast<const T*>(a.kv_new);
+  const T* NEW = KV8 ? nullptr : reinterpret_cast<const T*>(a.kv_new);
+  const float k_scale = KV8 ? a.k_scale[(size_t)h * gridDim.x + b] : 1.0f, v_scale = KV8 ? a.v_scale[(size_t)h * gridDim.x + b] : 1.0f;
 
   for (int i = tid; i < n * 64; i += 256) qs[i >> 6][i & 63] = Elem<T>::load(Q + (size_t)(b * n + (i >> 6)) * a.ld_q + a.q_col0 + h * 64 + (i & 63));
-  if (NEW) {                                   // append the new rows to the cache (read back only by later steps)
+  if constexpr (!KV8) if (NEW) {               // append the new rows to the cache (read back only by later steps)
     T* Kw = const_cast<T*>(Kc);
     T* Vw = const_cast<T*>(Vc);
     for (int i = tid; i < n * 64; i += 256) {
@@ -663,18 +679,20 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
   __syncthreads();
   // ---- scores: the row segments of the NEXT trip are already in flight while this trip is reduced
   constexpr int DU = 8;                          // rows in flight per 8-lane group and trip
-  auto k_ptr = [&](int s0) -> const T* {
-    return s0 < n_cached ? Kc + (size_t)s0 * 64 + sub * 8 : NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.k_col0 + h * 64 + sub * 8;
+  auto k_ptr = [&](int s0) -> const KT* {
+    if constexpr (KV8) return Kc + (size_t)s0 * 64 + sub * 8;
+    else return s0 < n_cached ? Kc + (size_t)s0 * 64 + sub * 8 : NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.k_col0 + h * 64 + sub * 8;
   };
-  auto v_ptr = [&](int s0) -> const T* {
-    return s0 < n_cached ? Vc + (size_t)s0 * 64 + sub * 8 : NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.v_col0 + h * 64 + sub * 8;
+  auto v_ptr = [&](int s0) -> const KT* {
+    if constexpr (KV8) return Vc + (size_t)s0 * 64 + sub * 8;
+    else return s0 < n_cached ? Vc + (size_t)s0 * 64 + sub * 8 : NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.v_col0 + h * 64 + sub * 8;
   };
   {
-    Raw8<T> nxt[DU];
+    Raw8<KT> nxt[DU];
 #pragma unroll
     for (int u = 0; u < DU; ++u) { const int s0 = (tid >> 3) + u * 32; if (s0 < S) nxt[u].load(k_ptr(s0)); }
     for (int sb = (tid >> 3); sb < S; sb += 32 * DU) {
-      Raw8<T> cur[DU];
+      Raw8<KT> cur[DU];
 #pragma unroll
       for (int u = 0; u < DU; ++u) cur[u] = nxt[u];
 #pragma unroll
@@ -695,7 +713,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
             acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0xB1, 0xf, 0xf, true));
             acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x4E, 0xf, 0xf, true));
             acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x141, 0xf, 0xf, true));
-            if (sub == 0) sc[i * sc_ld + s0] = acc + ((a.causal && s0 > hist + i) ? -128.0f : 0.0f);
+            if (sub == 0) sc[i * sc_ld + s0] = acc * k_scale + ((a.causal && s0 > hist + i) ? -128.0f : 0.0f);
           }
         }
       }
@@ -703,7 +721,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
   }
   __syncthreads();
   // the V stream does not depend on the scores: its first trip is requested before the soft-max statistics are computed
-  Raw8<T> vnxt[DU];
+  Raw8<KT> vnxt[DU];
 #pragma unroll
   for (int u = 0; u < DU; ++u) { const int s0 = (tid >> 3) + u * 32; if (s0 < S) vnxt[u].load(v_ptr(s0)); }
   // ---- soft-max statistics per query (wave w handles queries w, w+4)
@@ -729,7 +747,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
     for (int e = 0; e < 8; ++e) acc[i][e] = 0.0f;
   {
     for (int sb = (tid >> 3); sb < S; sb += 32 * DU) {
-      Raw8<T> cur[DU];
+      Raw8<KT> cur[DU];
 #pragma unroll
       for (int u = 0; u < DU; ++u) cur[u] = vnxt[u];
 #pragma unroll
@@ -770,7 +788,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
   for (int i = tid; i < n * 64; i += 256) {
     const int qi = i >> 6, dd = i & 63;
     const float v = (red[0][qi][dd] + red[1][qi][dd]) + (red[2][qi][dd] + red[3][qi][dd]);
-    Elem<T>::store(O + (size_t)(b * n + qi) * a.ld_out + h * 64 + dd, v * stat[0][qi]);
+    Elem<T>::store(O + (size_t)(b * n + qi) * a.ld_out + h * 64 + dd, v * stat[0][qi] * v_scale);
   }
 }
 
@@ -1217,8 +1235,106 @@ void launch_decode_attention(const DecAttnArgs& a, int batch, hipStream_t s) {
   DecAttnArgs b = a;
   b.sc_ld = (std::min(a.max_keys > 0 ? a.max_keys : DA_MAXKEYS, DA_MAXKEYS) + 63) & ~63;
   const size_t lds = (size_t)a.n * b.sc_ld * 4;
-  if (a.n == 1) hipLaunchKernelGGL((decode_attn_kernel<T, 1>), dim3(batch, a.n_heads), dim3(256), lds, s, b);
+  if (a.k_scale || a.v_scale) {
+    if constexpr (std::is_same<T, bf16_t>::value) {
+      ASR_REQUIRE(a.k_scale && a.v_scale && !a.kv_new && a.plan, "decode attention: the FP8 cache path is the cross-attention of bf16 sessions");
+      if (a.n == 1) hipLaunchKernelGGL((decode_attn_kernel<T, 1, true>), dim3(batch, a.n_heads), dim3(256), lds, s, b);
+      else hipLaunchKernelGGL((decode_attn_kernel<T, DA_MAXN, true>), dim3(batch, a.n_heads), dim3(256), lds, s, b);
+    } else ASR_REQUIRE(false, "decode attention: FP8 K / V need a bf16 session");
+  }
+  else if (a.n == 1) hipLaunchKernelGGL((decode_attn_kernel<T, 1>), dim3(batch, a.n_heads), dim3(256), lds, s, b);
   else hipLaunchKernelGGL((decode_attn_kernel<T, DA_MAXN>), dim3(batch, a.n_heads), dim3(256), lds, s, b);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- FP8 (OCP e4m3) quantisers of precision mode ASR_PRECISION_FP8W. Scales are powers of two (amax lands in (224, 448]): dequantised
+//      values are then exact in bf16, so a bf16 run over the dequantised copies reproduces the FP8 kernels bit for bit (the tests use that).
+namespace {
+__device__ __forceinline__ float pow2_scale(float amax) {          // smallest power of two s with amax / s <= 448
+  if (!(amax > 0.0f)) return 1.0f;
+  int e;
+  const float m = frexpf(amax * (1.0f / 448.0f), &e);                // amax / 448 = m 2^e, m in [0.5, 1)
+  return ldexpf(1.0f, m == 0.5f ? e - 1 : e);
+}
+__device__ __forceinline__ float block_amax(float v, float* sh) {    // 256 threads
+  v = wave_max(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+// 8 consecutive bf16 -> 8 e4m3 bytes (and, optionally, their exact bf16 dequantisation)
+__device__ __forceinline__ uint2 quant8(const uint4 raw, float inv_s, float s, uint4* dq) {
+  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+  float f[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f[2 * e] = __uint_as_float(w[e] << 16) * inv_s; f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u) * inv_s; }
+  uint2 q;
+  unsigned p = 0;
+  p = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], p, false); p = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], p, true); q.x = p;
+  p = 0;
+  p = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], p, false); p = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], p, true); q.y = p;
+  if (dq) {
+    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(q.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(q.x, true);
+    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(q.y, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(q.y, true);
+    dq->x = pack_bf16x2(a[0] * s, a[1] * s); dq->y = pack_bf16x2(b[0] * s, b[1] * s); dq->z = pack_bf16x2(c[0] * s, c[1] * s); dq->w = pack_bf16x2(d[0] * s, d[1] * s);
+  }
+  return q;
+}
+__device__ __forceinline__ float amax8(const uint4 raw) {
+  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+  float m = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(fabsf(__uint_as_float(w[e] << 16)), fabsf(__uint_as_float(w[e] & 0xffff0000u))));
+  return m;
+}
+// one workgroup per weight row: W [N][K] bf16 (pitch ld) -> W8 [N][K] bytes + scale[N] (+ Wdq [N][K] bf16)
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __restrict__ W, int ld, int K, unsigned char* __restrict__ W8, float* __restrict__ scale,
+                                                                bf16_t* __restrict__ Wdq) {
+  __shared__ float sh[4];
+  const int n = blockIdx.x;
+  const bf16_t* row = W + (size_t)n * ld;
+  float m = 0.0f;
+  for (int k = threadIdx.x * 8; k < K; k += 256 * 8) m = fmaxf(m, amax8(*reinterpret_cast<const uint4*>(row + k)));
+  const float s = pow2_scale(block_amax(m, sh)), inv_s = 1.0f / s;
+  if (threadIdx.x == 0) scale[n] = s;
+  for (int k = threadIdx.x * 8; k < K; k += 256 * 8) {
+    uint4 dq;
+    const uint2 q = quant8(*reinterpret_cast<const uint4*>(row + k), inv_s, s, Wdq ? &dq : nullptr);
+    *reinterpret_cast<uint2*>(W8 + (size_t)n * K + k) = q;
+    if (Wdq) *reinterpret_cast<uint4*>(Wdq + (size_t)n * K + k) = dq;
+  }
+}
+// one workgroup per (sequence, slab): the T rows x 64 dims of sequence b inside slab (kv, layer, head) -> bytes + scale[slab][b];
+// dq_in_place: additionally overwrite the bf16 rows with their dequantisation (the bf16 reference of the FP8 path)
+__global__ __launch_bounds__(256) void quantize_crosskv_fp8_kernel(bf16_t* __restrict__ slabs, size_t slab_elems, const UttPlan* __restrict__ plan,
+                                                                   unsigned char* __restrict__ out8, float* __restrict__ scale, int dq_in_place) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x, slab = blockIdx.y, B = gridDim.x;
+  const UttPlan p = plan[b];
+  bf16_t* src = slabs + (size_t)slab * slab_elems + (size_t)p.row_off * 64;
+  unsigned char* dst = out8 + (size_t)slab * slab_elems + (size_t)p.row_off * 64;
+  const int n8 = p.n_lfr * 8;                                        // 16-byte groups of the region
+  float m = 0.0f;
+  for (int i = threadIdx.x; i < n8; i += 256) m = fmaxf(m, amax8(reinterpret_cast<const uint4*>(src)[i]));
+  const float s = pow2_scale(block_amax(m, sh)), inv_s = 1.0f / s;
+  if (threadIdx.x == 0) scale[(size_t)slab * B + b] = s;
+  for (int i = threadIdx.x; i < n8; i += 256) {
+    uint4 dq;
+    const uint2 q = quant8(reinterpret_cast<const uint4*>(src)[i], inv_s, s, dq_in_place ? &dq : nullptr);
+    reinterpret_cast<uint2*>(dst)[i] = q;
+    if (dq_in_place) reinterpret_cast<uint4*>(src)[i] = dq;
+  }
+}
+}  // namespace
+
+void launch_quantize_rows_fp8(const bf16_t* W, int ld, int N, int K, unsigned char* W8, float* scale, bf16_t* Wdq, hipStream_t s) {
+  ASR_REQUIRE(K % 8 == 0 && ld % 8 == 0, "quantize_rows_fp8: K and the row pitch must be multiples of 8");
+  hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(N), dim3(256), 0, s, W, ld, K, W8, scale, Wdq);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_quantize_crosskv_fp8(bf16_t* slabs, size_t slab_elems, int n_slabs, const UttPlan* plan, int batch, unsigned char* out8, float* scale,
+                                 int dq_in_place, hipStream_t s) {
+  hipLaunchKernelGGL(quantize_crosskv_fp8_kernel, dim3(batch, n_slabs), dim3(256), 0, s, slabs, slab_elems, plan, out8, scale, dq_in_place);
   HIP_CHECK(hipGetLastError());
 }
 template void launch_decode_attention<float>(const DecAttnArgs&, int, hipStream_t);

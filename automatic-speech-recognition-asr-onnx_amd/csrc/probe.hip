@@ -178,6 +178,53 @@ extern "C" int asr_probe_gemm_chain(int M, int N, int K, int epilogue, int cold_
     (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
   });
 }
+
+// ---- FP8 mode (ASR_PRECISION_FP8W): the row quantiser and the decode GEMM over byte weights, on host arrays
+extern "C" int asr_probe_quantize_fp8(const uint16_t* w_bf16, int N, int K, uint8_t* out8, float* scale, uint16_t* dq_bf16) {
+  return asr_guard([&] {
+    ASR_REQUIRE(w_bf16 && out8 && scale && N > 0 && K > 0 && K % 8 == 0, "probe_quantize_fp8: bad argument");
+    asr_require_device(0);
+    DeviceBuffer w, q, sc, dq;
+    w.reserve((size_t)N * K * 2, nullptr); q.reserve((size_t)N * K, nullptr); sc.reserve((size_t)N * 4, nullptr); dq.reserve((size_t)N * K * 2, nullptr);
+    HIP_CHECK(hipMemcpy(w.ptr, w_bf16, (size_t)N * K * 2, hipMemcpyHostToDevice));
+    launch_quantize_rows_fp8(w.as<bf16_t>(), K, N, K, q.as<unsigned char>(), sc.as<float>(), dq.as<bf16_t>(), nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out8, q.ptr, (size_t)N * K, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(scale, sc.ptr, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (dq_bf16) HIP_CHECK(hipMemcpy(dq_bf16, dq.ptr, (size_t)N * K * 2, hipMemcpyDeviceToHost));
+    w.release(); q.release(); sc.release(); dq.release();
+  });
+}
+
+// out[M][N] (f32) = decode GEMM of a[M][K] (bf16) with EITHER w_bf16[N][K] OR (w8[N][K], scale[N]); fold != 0: LayerNorm folded in
+// (column sums taken from w_bf16, which a byte-weight caller passes as the dequantised copy); bias may be null
+extern "C" int asr_probe_decode_gemm(int M, int N, int K, const uint16_t* a, const uint16_t* w_bf16, const uint8_t* w8, const float* scale,
+                                     const float* bias, int fold, float* out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(a && out && (w_bf16 || w8) && !(w8 && !scale) && !(fold && !w_bf16), "probe_decode_gemm: bad argument");
+    asr_require_device(0);
+    DeviceBuffer da, dw, dw8, dsc, db, dcs, dout, ws, cnt;
+    da.reserve((size_t)64 * K * 2, nullptr); dout.reserve((size_t)64 * N * 4, nullptr); ws.reserve((size_t)16 << 20, nullptr); cnt.reserve(4096 * 4, nullptr);
+    HIP_CHECK(hipMemset(da.ptr, 0, (size_t)64 * K * 2)); HIP_CHECK(hipMemset(cnt.ptr, 0, 4096 * 4));
+    HIP_CHECK(hipMemcpy(da.ptr, a, (size_t)M * K * 2, hipMemcpyHostToDevice));
+    DecGemmArgs g;
+    g.A = da.as<bf16_t>(); g.lda = K; g.ldw = K; g.M = M; g.N = N; g.K = K; g.out_f32 = dout.as<float>(); g.ld_out_f32 = N;
+    g.ws = ws.as<float>(); g.ws_bytes = ws.cap; g.cnt = cnt.as<int32_t>();
+    if (w_bf16) { dw.reserve((size_t)N * K * 2, nullptr); HIP_CHECK(hipMemcpy(dw.ptr, w_bf16, (size_t)N * K * 2, hipMemcpyHostToDevice)); g.W = dw.as<bf16_t>(); }
+    if (w8) {
+      dw8.reserve((size_t)N * K, nullptr); dsc.reserve((size_t)N * 4, nullptr);
+      HIP_CHECK(hipMemcpy(dw8.ptr, w8, (size_t)N * K, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(dsc.ptr, scale, (size_t)N * 4, hipMemcpyHostToDevice));
+      g.W = nullptr; g.W8 = dw8.as<unsigned char>(); g.w_scale = dsc.as<float>();
+    }
+    if (bias) { db.reserve((size_t)N * 4, nullptr); HIP_CHECK(hipMemcpy(db.ptr, bias, (size_t)N * 4, hipMemcpyHostToDevice)); g.bias = db.as<float>(); }
+    if (fold) { dcs.reserve((size_t)N * 4, nullptr); launch_colsum_bf16(dw.as<bf16_t>(), K, N, K, dcs.as<float>(), nullptr); g.colsum = dcs.as<float>(); }
+    launch_decode_gemm(g, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out, dout.ptr, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    for (DeviceBuffer* b : {&da, &dw, &dw8, &dsc, &db, &dcs, &dout, &ws, &cnt}) b->release();
+  });
+}
+
 extern "C" const char* asr_probe_last_kernel(void) { return g_chain_kernel; }
 
 extern "C" int asr_probe_gemm_counts(int reset, char* buf, int cap) {

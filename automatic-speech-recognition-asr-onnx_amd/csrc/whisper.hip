@@ -22,6 +22,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct EncLayer { const void *wqkv, *wo, *w1, *w2; const float *bqkv, *bo, *b1, *b2; };
 struct DecLayer { const void *wqkv, *wo, *wcq, *wco, *w1, *w2; const float *bqkv, *bo, *bcq, *bco, *b1, *b2; };
+struct Dec8Layer { const unsigned char* w[6]; const float* s[6]; };        // FP8 mode: e4m3 bytes + per-column scales of wqkv, wo, wcq, wco, w1, w2
 
 struct WhSession : asr_session {
   asr_whisper_config cfg;
@@ -53,6 +54,13 @@ struct WhSession : asr_session {
   bool use_graph = true;
   bool use_decode_gemm = true;         // ASR_DECODE_GEMM=0: decode steps through the generic weight-streaming GEMM + LayerNorm prologues
   DeviceBuffer d_colsum, d_dlo;        // column sums of the LayerNorm-folded decoder projections; bf16 copies of the decoder's residual rows
+  // precision mode ASR_PRECISION_FP8W (opt-in; everything else as in bf16 mode): the six projections of every decoder layer as e4m3 bytes with a
+  // power-of-two scale per output column, read by the decode GEMM (<= 64 rows); their exact bf16 dequantisation serves every other path
+  // (prefill, > 64 rows), so all steps of a session see the same effective weights. The cross-K/V slabs are quantised once per batch with a
+  // scale per (sequence, head) and streamed as bytes by the decode attention. ASR_FP8_FAKE=1: same quantisation, bf16 kernels throughout.
+  bool fp8 = false, fp8_fake = false, fp8_weights = true, fp8_kv = true;     // ASR_FP8_WEIGHTS=0 / ASR_FP8_KV=0: leave that half in bf16 (to price the halves separately)
+  std::vector<Dec8Layer> dec8;
+  DeviceBuffer d_w8, d_wscale, d_wdq, d_cross8, d_cscale;
   hipGraphExec_t dec_graph = nullptr;
   uint64_t dec_key = 0, dec_eager_key = 0, ws_epoch = 1;
   void* h_plan = nullptr; size_t h_plan_cap = 0;
@@ -60,7 +68,7 @@ struct WhSession : asr_session {
 
   ~WhSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_x0, &d_h1, &d_xa, &d_xb, &d_xc, &d_h, &d_qk, &d_vt, &d_ctx,
-                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise, &d_nsp, &d_skws, &d_skcnt, &d_colsum, &d_dlo})
+                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise, &d_nsp, &d_skws, &d_skcnt, &d_colsum, &d_dlo, &d_w8, &d_wscale, &d_wdq, &d_cross8, &d_cscale})
       b->release();
     if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
     for (auto& kv : taps) kv.second.buf.release();
@@ -136,6 +144,26 @@ void WhSession::init() {
     dec[i] = DecLayer{W(p + "wqkv", {3 * d, d}), W(p + "wo", {d, d}), W(p + "wcq", {d, d}), W(p + "wco", {d, d}),
                       W(p + "w1", {dff, d}), W(p + "w2", {d, dff}),
                       F(p + "bqkv", {3 * d}), F(p + "bo", {d}), F(p + "bcq", {d}), F(p + "bco", {d}), F(p + "b1", {dff}), F(p + "b2", {d})};
+  }
+  if (fp8 && fp8_weights) {
+    ASR_REQUIRE(d % 256 == 0 && dff % 256 == 0, "whisper: FP8 mode needs d_model and d_ffn to be multiples of 256");
+    const size_t w_elems = (size_t)6 * d * d + (size_t)2 * d * dff, n_scales = (size_t)7 * d + dff;      // per layer
+    d_w8.reserve(Ld * w_elems, stream); d_wscale.reserve(Ld * n_scales * 4, stream); d_wdq.reserve(Ld * w_elems * 2, stream);
+    dec8.resize(Ld);
+    for (int i = 0; i < Ld; ++i) {
+      DecLayer& L = dec[i];
+      const void** slot[6] = {&L.wqkv, &L.wo, &L.wcq, &L.wco, &L.w1, &L.w2};
+      const int Ns[6] = {3 * d, d, d, d, dff, d}, Ks[6] = {d, d, d, d, d, dff};
+      unsigned char* w8 = d_w8.as<unsigned char>() + i * w_elems;
+      bf16_t* dq = d_wdq.as<bf16_t>() + i * w_elems;
+      float* sc = d_wscale.as<float>() + i * n_scales;
+      for (int j = 0; j < 6; ++j) {
+        launch_quantize_rows_fp8((const bf16_t*)*slot[j], Ks[j], Ns[j], Ks[j], w8, sc, dq, stream);
+        dec8[i].w[j] = w8; dec8[i].s[j] = sc;
+        *slot[j] = dq;                                     // from here on "the weights" are the dequantised copies
+        w8 += (size_t)Ns[j] * Ks[j]; dq += (size_t)Ns[j] * Ks[j]; sc += Ns[j];
+      }
+    }
   }
   if (precision == ASR_PRECISION_BF16 && use_decode_gemm) {      // column sums of the three LayerNorm-folded projections of every decoder layer: [3d | d | dff]
     const size_t per = (size_t)3 * d + d + dff;
@@ -348,6 +376,14 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
     g.out_lo = d_cross.ptr; g.lo_group = 64; g.ld_out_lo = Mpad * 64;
     gemm(g);
   }
+  if constexpr (sizeof(T) == 2) {
+    if (fp8 && fp8_kv) {
+      ProfScope ps(prof, "quant_crosskv", stream);
+      { void* before = d_cross8.ptr; d_cross8.reserve((size_t)2 * Ld * H * Mpad * 64, stream); d_cscale.reserve((size_t)2 * Ld * H * B * 4, stream); if (d_cross8.ptr != before) ++ws_epoch; }
+      launch_quantize_crosskv_fp8(d_cross.as<bf16_t>(), (size_t)Mpad * 64, 2 * Ld * H, d_plan.as<UttPlan>(), B, d_cross8.as<unsigned char>(), d_cscale.as<float>(),
+                                  fp8_fake ? 1 : 0, stream);
+    }
+  }
   if (taps_enabled) save_tap("cross", d_cross.ptr, (int64_t)2 * Ld * H * Mpad, 64, 64, (int)eT);
   HIP_CHECK(hipStreamSynchronize(stream));
   if (prof.enabled) prof.collect();
@@ -393,12 +429,15 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
     dgm = use_decode_gemm && R <= 64 && d_colsum.ptr != nullptr && d % 256 == 0 && dff % 256 == 0;
     xa_lo = d_dlo.as<bf16_t>(); xb_lo = xa_lo + (size_t)Rp * d; xc_lo = xb_lo + (size_t)Rp * d;
   }
-  auto dg = [&](const void* A, int lda, const void* Wt, int N, int K, const float* bias, const float* colsum, const float* add, int act_, float* of32,
+  const bool w8 = fp8 && fp8_weights && !fp8_fake;
+  int cur_layer = 0;
+  auto dg = [&](const void* A, int lda, const void* Wt, int wi, int N, int K, const float* bias, const float* colsum, const float* add, int act_, float* of32,
                 void* olo, int ld_lo) {
     ProfScope ps(prof, "dec_gemm", stream);
     if (!d_skws.ptr) { d_skws.reserve((size_t)16 << 20, stream); d_skcnt.reserve(4096 * 4, stream); }
     DecGemmArgs g;
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)Wt; g.ldw = K; g.M = R; g.N = N; g.K = K; g.bias = bias; g.colsum = colsum;
+    if (w8) { g.W = nullptr; g.W8 = dec8[cur_layer].w[wi]; g.w_scale = dec8[cur_layer].s[wi]; }
     g.add = add; g.ld_add = d; g.act = act_; g.out_f32 = of32; g.ld_out_f32 = d; g.out_lo = (bf16_t*)olo; g.ld_out_lo = ld_lo;
     g.ws = d_skws.as<float>(); g.ws_bytes = d_skws.cap; g.cnt = d_skcnt.as<int32_t>();
     launch_decode_gemm(g, stream);
@@ -406,7 +445,8 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
   if (dgm) { ProfScope ps(prof, "dec_embed", stream); launch_rows_to_bf16(xa, xa_lo, (size_t)Rp * d, stream); }
   for (int l = 0; l < Ld; ++l) {
     const DecLayer& L = dec[l];
-    if (dgm) dg(xa_lo, d, L.wqkv, 3 * d, d, L.bqkv, csum + l * cs_l, nullptr, ACT_NONE, nullptr, qkv, 3 * d);
+    cur_layer = l;
+    if (dgm) dg(xa_lo, d, L.wqkv, 0, 3 * d, d, L.bqkv, csum + l * cs_l, nullptr, ACT_NONE, nullptr, qkv, 3 * d);
     else {
       GemmArgs g;
       g.W = L.wqkv; g.ldw = d; g.M = R; g.N = 3 * d; g.K = d; g.bias = L.bqkv; g.out_lo = qkv; g.ld_out_lo = 3 * d;
@@ -423,8 +463,8 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
       launch_decode_attention<T>(a, B, stream);
     }
     if (dgm) {
-      dg(ctx, d, L.wo, d, d, L.bo, nullptr, xa, ACT_NONE, xb, xb_lo, d);
-      dg(xb_lo, d, L.wcq, d, d, L.bcq, csum + l * cs_l + 3 * d, nullptr, ACT_NONE, nullptr, cq, d);
+      dg(ctx, d, L.wo, 1, d, d, L.bo, nullptr, xa, ACT_NONE, xb, xb_lo, d);
+      dg(xb_lo, d, L.wcq, 2, d, d, L.bcq, csum + l * cs_l + 3 * d, nullptr, ACT_NONE, nullptr, cq, d);
     } else {
       {
         ProfScope ps(prof, "dec_gemm", stream);
@@ -445,12 +485,17 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
       a.stride_b = 0; a.stride_h = (int64_t)Mpad * 64; a.plan = dp; a.hist = 0; a.hist_dev = nullptr; a.n = n; a.n_heads = H; a.causal = 0;
       a.max_keys = max_T_enc;
       a.out = ctx; a.ld_out = d;
+      if (fp8 && fp8_kv && !fp8_fake) {
+        a.k_base = d_cross8.as<unsigned char>() + (size_t)(0 * Ld + l) * H * Mpad * 64;
+        a.v_base = d_cross8.as<unsigned char>() + (size_t)(1 * Ld + l) * H * Mpad * 64;
+        a.k_scale = d_cscale.as<float>() + (size_t)(0 * Ld + l) * H * B; a.v_scale = d_cscale.as<float>() + (size_t)(1 * Ld + l) * H * B;
+      }
       launch_decode_attention<T>(a, B, stream);
     }
     if (dgm) {
-      dg(ctx, d, L.wco, d, d, L.bco, nullptr, xb, ACT_NONE, xc, xc_lo, d);
-      dg(xc_lo, d, L.w1, dff, d, L.b1, csum + l * cs_l + 4 * d, nullptr, act, nullptr, ffn, dff);
-      if (R <= 32) dg(ffn, dff, L.w2, d, dff, L.b2, nullptr, xc, ACT_NONE, xa, xa_lo, d);
+      dg(ctx, d, L.wco, 3, d, d, L.bco, nullptr, xb, ACT_NONE, xc, xc_lo, d);
+      dg(xc_lo, d, L.w1, 4, dff, d, L.b1, csum + l * cs_l + 4 * d, nullptr, act, nullptr, ffn, dff);
+      if (R <= 32 || w8) dg(ffn, dff, L.w2, 5, d, dff, L.b2, nullptr, xc, ACT_NONE, xa, xa_lo, d);
       else {               // 33..64 rows: the tiled split-K pass shares the activation rows across 64 columns (13.8 vs 17.9 us); it writes the bf16 copy too
         ProfScope ps(prof, "dec_gemm", stream);
         GemmArgs g2;
@@ -600,15 +645,19 @@ extern "C" int asr_whisper_create(const asr_whisper_config* cfg, const void* are
                                   int device_id, int precision, asr_session** out) {
   return asr_guard([&] {
     ASR_REQUIRE(cfg && arena && out, "whisper_create: null argument");
-    ASR_REQUIRE(precision == ASR_PRECISION_BF16 || precision == ASR_PRECISION_F32, "whisper_create: bad precision %d", precision);
+    ASR_REQUIRE(precision == ASR_PRECISION_BF16 || precision == ASR_PRECISION_F32 || precision == ASR_PRECISION_FP8W, "whisper_create: bad precision %d", precision);
     asr_require_device(device_id);
     WhSession* s = new WhSession();
     try {
       s->kind = 2;
       s->device = device_id;
-      s->precision = precision;
+      s->fp8 = precision == ASR_PRECISION_FP8W;
+      s->precision = s->fp8 ? ASR_PRECISION_BF16 : precision;        // FP8 mode = bf16 mode with byte-wide decoder weights and cross-K/V
       s->cfg = *cfg;
       gemm_reload_env();
+      if (const char* e = getenv("ASR_FP8_FAKE")) s->fp8_fake = e[0] == '1';
+      if (const char* e = getenv("ASR_FP8_WEIGHTS")) s->fp8_weights = !(e[0] == '0');
+      if (const char* e = getenv("ASR_FP8_KV")) s->fp8_kv = !(e[0] == '0');
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       if (const char* e = getenv("ASR_DECODE_GEMM")) s->use_decode_gemm = !(e[0] == '0');
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));

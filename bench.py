@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=1, help="whisper / qwen: also measure N batches in flight on N sessions / HIP streams")
     ap.add_argument("--streams", type=int, default=256, help="mixed: concurrent Paraformer streams per GPU")
     ap.add_argument("--beam", type=int, default=1, help="qwen / mixed: beam width (1 = greedy; BASELINE.json configs[4] names beam 5)")
+    ap.add_argument("--fp8", action="store_true", help="whisper: opt-in precision mode ASR_PRECISION_FP8W (decoder projections and cross-K/V as e4m3 bytes); a secondary figure, never the headline")
     ap.add_argument("--decode-tokens", type=int, default=0, help="whisper: generated tokens per utterance (default 4 per audio second)")
     args = ap.parse_args()
     global PROFILE_ROUND
@@ -662,7 +663,7 @@ def main_paraformer_streaming(args):
         dist.destroy_process_group()
 
 
-def whisper_algorithmic(cfg, n_samples, B, n_tokens, prompt_len):
+def whisper_algorithmic(cfg, n_samples, B, n_tokens, prompt_len, fp8=False):
     """Algorithmic FLOPs / bytes: encoder GEMM 2MNK + attention 4 T^2 d per layer + conv stem + cross-KV
     projection; decode: weights read once per step for the batch + cross-KV + self-KV streamed per utterance."""
     d, dff, Le, Ld, T = cfg.d_model, cfg.d_ffn, cfg.n_enc_layers, cfg.n_dec_layers, cfg.n_enc_pos(n_samples)
@@ -672,6 +673,8 @@ def whisper_algorithmic(cfg, n_samples, B, n_tokens, prompt_len):
     dec_w_params = Ld * (4 * d * d + 2 * d * d + 2 * d * dff) + cfg.vocab * d
     dec_tok = 2.0 * dec_w_params + Ld * 4.0 * T * d
     step_bytes = 2.0 * dec_w_params + B * Ld * 2 * T * d * 2.0          # bf16 weights once per step + bf16 cross-KV per utterance
+    if fp8:                                                              # FP8W mode: the decoder layers' projections and the cross-K/V are bytes (proj_out stays bf16)
+        step_bytes = 1.0 * (dec_w_params - cfg.vocab * d) + 2.0 * cfg.vocab * d + B * Ld * 2 * T * d * 1.0
     return {"encoder_flops": B * enc, "decode_flops_per_step": B * dec_tok, "decode_bytes_per_step": step_bytes}
 
 
@@ -704,7 +707,8 @@ def main_whisper(args):
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t0
     blob = None
-    sess = eng.WhisperSession(cfg, arena_dev, arena.PRECISION_BF16, local_rank, arena_device_ptr=arena_dev.data_ptr(), arena_bytes=arena_dev.numel())
+    prec = arena.PRECISION_FP8W if args.fp8 else arena.PRECISION_BF16
+    sess = eng.WhisperSession(cfg, arena_dev, prec, local_rank, arena_device_ptr=arena_dev.data_ptr(), arena_bytes=arena_dev.numel())
     audio_np = ckm.synth_audio("unit", B, n_samples, seed=1234 + rank)
     audio_dev = torch.from_numpy(audio_np).to(device)
     offsets = np.arange(B + 1, dtype=np.int64) * n_samples
@@ -747,7 +751,7 @@ def main_whisper(args):
     inflight = None
     if args.inflight > 1:
         import threading
-        others = [eng.WhisperSession(cfg, arena_dev, arena.PRECISION_BF16, local_rank, arena_device_ptr=arena_dev.data_ptr(), arena_bytes=arena_dev.numel())
+        others = [eng.WhisperSession(cfg, arena_dev, prec, local_rank, arena_device_ptr=arena_dev.data_ptr(), arena_bytes=arena_dev.numel())
                   for _ in range(args.inflight - 1)]
         sessions = [sess] + others
 
@@ -778,7 +782,7 @@ def main_whisper(args):
     prof = sess.profile_read()
     sess.profile(False)
     if rank == 0:
-        alg = whisper_algorithmic(cfg, n_samples, B, n_tok, 4)
+        alg = whisper_algorithmic(cfg, n_samples, B, n_tok, 4, fp8=args.fp8)
         audio_s = world * B * args.seconds
         kernels = {k: {"ms_per_step": round(v["total_ms"], 3), "launches_per_step": v["launches"]}
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
@@ -789,11 +793,12 @@ def main_whisper(args):
         achieved = enc_gemm_flops / (enc_gemm_ms * 1e-3) / 1e12 if enc_gemm_ms else 0.0
         t_dec = t_parts["decode"] / args.steps
         out = {
-            "metric": "audio-sec/s, Whisper-large-v3, %g s @ 16 kHz chunks, batch %d per GPU, greedy, %d tokens/utterance" % (args.seconds, B, n_tok),
+            "metric": "audio-sec/s, Whisper-large-v3, %g s @ 16 kHz chunks, batch %d per GPU, greedy, %d tokens/utterance" % (args.seconds, B, n_tok)
+                      + (" [opt-in FP8W mode: decoder projections + cross-K/V stored as e4m3, NOT the reference's precision]" if args.fp8 else ""),
             "value": round(audio_s * args.steps / elapsed, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "Whisper-large-v3 bf16 (1.54 B params), batch=%d x %g s per GPU, encoder + cross-KV + prefill(4) + %d greedy decode steps, audio resident in HBM" % (B, args.seconds, n_tok - 1),
+            "dtype": "bf16 (e4m3 storage of decoder weights and cross-K/V)" if args.fp8 else "bf16", "data": "synthetic",
+            "config": {"workload": "Whisper-large-v3 %s (1.54 B params), batch=%d x %g s per GPU, encoder + cross-KV + prefill(4) + %d greedy decode steps, audio resident in HBM" % ("bf16 + FP8W" if args.fp8 else "bf16", B, args.seconds, n_tok - 1),
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "rtf": round(elapsed / (audio_s * args.steps), 7),
             "ms": {k: round(v / args.steps * 1e3, 2) for k, v in t_parts.items()},
@@ -828,7 +833,7 @@ def main_whisper(args):
             sess.encode_packed(None, offsets, audio_device_ptr=audio_dev.data_ptr())
             _, lg = sess.prefill(prompt)
             ref0 = first["logits"][0][0]
-            out["parity_spotcheck"] = {"what": "prefill logits of utterance 0, bf16 engine vs f32 oracle", "max_abs_diff": round(float(np.abs(lg[0] - ref0).max()), 4),
+            out["parity_spotcheck"] = {"what": "prefill logits of utterance 0, %s engine vs f32 oracle" % ("FP8W" if args.fp8 else "bf16"), "max_abs_diff": round(float(np.abs(lg[0] - ref0).max()), 4),
                                        "logit_abs_max": round(float(np.abs(ref0).max()), 3)}
         print(json.dumps(out))
     if world > 1:
@@ -983,7 +988,7 @@ def main_qwen(args):
                 if el >= 15.0 or n_done >= 16:
                     break
             _, lg, _ = sess.prefill_packed(None, offsets, pre, post, want_logits=True, audio_device_ptr=audio_dev.data_ptr())
-            out["parity_spotcheck"] = {"what": "prefill logits of utterance 0, bf16 engine vs f32 oracle", "max_abs_diff": round(float(np.abs(lg[0] - first["logits"][0]).max()), 4),
+            out["parity_spotcheck"] = {"what": "prefill logits of utterance 0, %s engine vs f32 oracle" % ("FP8W" if args.fp8 else "bf16"), "max_abs_diff": round(float(np.abs(lg[0] - first["logits"][0]).max()), 4),
                                        "logit_abs_max": round(float(np.abs(first["logits"][0]).max()), 3)}
             out["cpu_baseline"] = {"value": round(n_done * args.seconds / el, 2), "unit": "audio-s/s", "cores": int(torch.get_num_threads()),
                                    "host_cores": int(os.cpu_count() or 0), "kind": "port",

@@ -45,8 +45,13 @@ enum asr_status {
 
 /* Arithmetic mode. BF16: bf16 MFMA operands, f32 accumulate, f32 residual stream / LayerNorm /
  * soft-max / front-end. F32: exact-f32 MFMA everywhere (verification mode for the
- * "logits within 1e-3" parity bar). The weight arena must be built for the same mode. */
-enum asr_precision { ASR_PRECISION_BF16 = 0, ASR_PRECISION_F32 = 1 };
+ * "logits within 1e-3" parity bar). The weight arena must be built for the same mode.
+ *
+ * FP8W (opt-in, Whisper sessions only; the low-bit counterpart of the reference's quantised decoders, Whisper/Optimize_ONNX.py:81-96,
+ * Optimize_ONNX_Common.py:55-60): bf16 mode whose decoder projection weights and cross-K/V cache are stored as OCP e4m3 bytes with
+ * power-of-two scales (per output column / per (sequence, head) slab) and widened to bf16 in registers -- activations, accumulation,
+ * self-KV cache, encoder and vocabulary projection are unchanged. Takes a bf16 arena; quantisation happens at session creation. */
+enum asr_precision { ASR_PRECISION_BF16 = 0, ASR_PRECISION_F32 = 1, ASR_PRECISION_FP8W = 2 };
 
 enum asr_mem { ASR_MEM_HOST = 0, ASR_MEM_DEVICE = 1 };
 

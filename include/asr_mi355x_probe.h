@@ -39,6 +39,13 @@ int asr_probe_gemm(asr_probe_gemm_desc* d);
 int asr_probe_gemm_chain(int M, int N, int K, int epilogue, int cold_mb, int replays, float* us_per_launch);
 const char* asr_probe_last_kernel(void);      /* kernel family of the last asr_probe_gemm_chain */
 
+/* FP8 mode (ASR_PRECISION_FP8W). Row quantiser: w_bf16[N][K] -> e4m3 bytes out8[N][K], power-of-two scale[N], optional exact bf16
+ * dequantisation dq_bf16[N][K]. Decode GEMM on host arrays: out[M][N] f32 = a[M][K] (bf16, M <= 64) x either w_bf16 or (w8, scale);
+ * fold != 0 applies the folded LayerNorm (column sums from w_bf16: pass the dequantised copy next to byte weights). */
+int asr_probe_quantize_fp8(const uint16_t* w_bf16, int N, int K, uint8_t* out8, float* scale, uint16_t* dq_bf16);
+int asr_probe_decode_gemm(int M, int N, int K, const uint16_t* a, const uint16_t* w_bf16, const uint8_t* w8, const float* scale,
+                          const float* bias, int fold, float* out);
+
 /* launches per GEMM kernel family since the last reset, as "family=count;..." (host-side counters: hipGraph replays do not
  * count, so reset, run a session once on a new batch geometry, read). reset != 0 clears the counters after the read. */
 int asr_probe_gemm_counts(int reset, char* buf, int cap);

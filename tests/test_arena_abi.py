@@ -27,6 +27,15 @@ def test_library_exports_every_declared_symbol():
     assert loaded.asr_abi_version() == 1
 
 
+def test_precision_modes_agree_between_header_and_host():
+    import re
+    hdr = open(os.path.join(ROOT, "include", "asr_mi355x.h")).read()
+    m = re.search(r"enum asr_precision \{([^}]*)\}", hdr)
+    vals = dict((k.strip(), int(v)) for k, v in (item.split("=") for item in m.group(1).split(",")))
+    arena = sub("arena")
+    assert vals == {"ASR_PRECISION_BF16": arena.PRECISION_BF16, "ASR_PRECISION_F32": arena.PRECISION_F32, "ASR_PRECISION_FP8W": arena.PRECISION_FP8W}
+
+
 def test_probe_library_is_separate_from_the_product_abi():
     """The tuning / test hooks live in libasr_mi355x_probe.so: every symbol its header declares is exported there,
     and the product library exports none of them (and declares no probe / debug entry)."""

@@ -1,0 +1,140 @@
+"""GPU: precision mode ASR_PRECISION_FP8W (include/asr_mi355x.h) -- Whisper decoder projections and cross-K/V as OCP e4m3 bytes.
+
+What pins it:
+  * the row quantiser against torch's float8_e4m3fn conversion (format, round-to-nearest-even, power-of-two scales);
+  * the byte-weight decode GEMM against the SAME kernel over the dequantised bf16 weights (bit for bit: power-of-two scales commute with
+    every rounding) and against a float64 product;
+  * a whole session in FP8 mode against the same session with ASR_FP8_FAKE=1 (identical quantisation, bf16 kernels throughout), bit for
+    bit on the logits of prefill + decode steps, i.e. the byte paths of the decode GEMM and of the cross-attention add no error of their own;
+  * the quantisation error itself against the f32 oracle, with the budget written down next to the bf16 mode's error on the same input."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import sub
+from helpers import golden_cases, load_golden
+from oracle.whisper_oracle import WhisperOracle
+from test_oracle_whisper import unit_audio, whisper_setup
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32, FP8W = 0, 1, 2
+
+
+def _session(cfg_name, prec, env=None):
+    cfg, ck, sup, beg = whisper_setup(cfg_name)
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        sess = sub("engine").WhisperSession.from_checkpoint(cfg, ck, precision=prec, suppress_tokens=sup, begin_suppress_tokens=beg)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    return cfg, ck, sup, beg, sess
+
+
+def _pow2_scale(amax):
+    s = np.ones_like(amax, dtype=np.float32)
+    nz = amax > 0
+    m, e = np.frexp(amax[nz].astype(np.float32) / np.float32(448.0))
+    s[nz] = np.ldexp(np.float32(1.0), np.where(m == 0.5, e - 1, e)).astype(np.float32)
+    return s
+
+
+def test_row_quantiser_is_ocp_e4m3_with_power_of_two_scales():
+    probe = sub("_probe")
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((48, 512)) * np.exp(rng.uniform(-6, 3, (48, 1)))).astype(np.float32)
+    w[3] = 0.0                                               # an all-zero row keeps scale 1
+    w[5, :16] = [448.0, -448.0, 447.9, 0.0009765625, 1e-4, 464.0, 0.017, -0.0195, 240.0, 208.0, 0.06, 1.0, -1.0, 3.5, 0.4375, 30.0]
+    q, sc, dq = probe.quantize_fp8(w)
+    wb = probe._bf16_to_f32(probe._bf16_bits(w))             # the kernel sees bf16-rounded weights
+    want_s = _pow2_scale(np.abs(wb).max(axis=1))
+    assert np.array_equal(sc, want_s)
+    assert ((np.abs(wb).max(axis=1) / sc <= 448.0) & ((np.abs(wb).max(axis=1) / sc > 224.0) | (np.abs(wb).max(axis=1) == 0))).all()
+    t8 = torch.from_numpy(wb / sc[:, None]).to(torch.float8_e4m3fn)
+    assert np.array_equal(q, t8.view(torch.uint8).numpy())   # same bytes as torch: OCP e4m3fn, round to nearest even
+    assert np.array_equal(dq, t8.to(torch.float32).numpy() * sc[:, None])     # and the dequantisation is exact in bf16
+
+
+@pytest.mark.parametrize("M,N,K,fold", [(32, 768, 256, True), (7, 256, 1024, False), (64, 1280, 1280, True), (32, 1280, 5120, False)])
+def test_byte_weight_decode_gemm_equals_the_bf16_kernel_over_dequantised_weights(M, N, K, fold):
+    probe = sub("_probe")
+    rng = np.random.default_rng(M + N + K)
+    a = rng.standard_normal((M, K)).astype(np.float32) * 1.5 + (0.3 if fold else 0.0)
+    w = (rng.standard_normal((N, K)) * 0.04 * np.exp(rng.uniform(-2, 2, (N, 1)))).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    q, sc, dq = probe.quantize_fp8(w)
+    byte_path = probe.decode_gemm(a, w=dq, w8=q, scale=sc, bias=bias, fold=fold)
+    bf16_path = probe.decode_gemm(a, w=dq, bias=bias, fold=fold)
+    assert np.array_equal(byte_path, bf16_path)              # bit for bit (incl. the split-K hand-over of the K = 5120 case)
+    ab = probe._bf16_to_f32(probe._bf16_bits(a)).astype(np.float64)
+    if fold:
+        mu, var = ab.mean(1, keepdims=True), ab.var(1, keepdims=True)
+        ab = (ab - mu) / np.sqrt(var + 1e-5)
+    want = ab @ dq.astype(np.float64).T + bias
+    assert np.abs(byte_path - want).max() < 2e-3 * np.abs(want).max()
+
+
+def _run(sess, audios, prompts, forced):
+    """prefill + teacher-forced decode steps -> logits (B, 1 + steps, V)"""
+    sess.encode(audios)
+    _, logits = sess.prefill(prompts)
+    out = [logits]
+    for s in range(forced.shape[1]):
+        _, logits = sess.decode(np.ascontiguousarray(forced[:, s:s + 1]), want_logits=True)
+        out.append(logits)
+    return np.stack(out, 1)
+
+
+def test_fp8_session_equals_fake_quantised_bf16_session_and_stays_within_budget_of_the_oracle():
+    name = "whisper_d256_test"
+    cfg, ck, sup, beg, s8 = _session(name, FP8W)
+    _, _, _, _, sfake = _session(name, FP8W, {"ASR_FP8_FAKE": "1"})
+    _, _, _, _, sbf = _session(name, BF16)
+    audios = [unit_audio(71, 64000), unit_audio(72, 25600), unit_audio(73, 128000)]
+    prompt = [cfg.sot_id, cfg.first_language_id, cfg.transcribe_id, cfg.no_timestamps_id]
+    prompts = np.array([prompt] * 3, np.int32)
+    orc = WhisperOracle(cfg, ck, sup, beg)
+    ref = orc.greedy(audios, [prompt] * 3, 5)
+    forced = np.stack([np.asarray(ref["token_ids"][b][:4], np.int32) for b in range(3)])
+    want = np.stack([np.stack(ref["logits"][b][:5]) for b in range(3)])       # (3, 5, V): the oracle is teacher-forced on its own picks
+    l8, lf, lb = _run(s8, audios, prompts, forced), _run(sfake, audios, prompts, forced), _run(sbf, audios, prompts, forced)
+    V = cfg.vocab
+    assert np.array_equal(l8[..., :V], lf[..., :V])          # the byte kernels add no error of their own
+    scale = float(np.abs(want).max())
+    e_bf, e_8 = float(np.abs(lb[..., :V] - want).max()), float(np.abs(l8[..., :V] - want).max())
+    print(f"whisper_d256 logits |max| {scale:.2f}: bf16 error {e_bf:.4f}, fp8w error {e_8:.4f}")
+    assert e_bf < 1e-3 * scale                                # measured 2e-4
+    assert e_8 < 6e-3 * scale                                 # measured 1.5e-3 (e4m3 keeps 4 significant bits: ~3 % rms per weight / cache entry, averaged over K >= 256 terms)
+    assert e_8 > e_bf                                         # (sanity: the mode really quantises)
+    # FP8 mode rejects what it cannot serve, loudly
+    with pytest.raises(RuntimeError):
+        _session("whisper_mid_test", FP8W)                    # d_model 384 is not a multiple of 256
+    cfgs, cks = sub("config").sensevoice_tiny(), None
+    with pytest.raises(Exception):
+        sub("engine").SenseVoiceSession.from_checkpoint(cfgs, sub("checkpoints").synth_sensevoice_checkpoint(cfgs, 0), precision=FP8W)
+
+
+def test_large_v3_fp8_30s_vs_golden_budget():
+    """Whisper-large-v3 at full dimensions, the 30 s clip of the reference-minted golden in a batch of 4: FP8 mode's logit error next to
+    bf16 mode's, teacher-forced on the golden's token ids."""
+    g = load_golden("whisper_large_v3")
+    c0 = [c for _, c in golden_cases(g)][0]
+    cfg, ck, sup, beg, s8 = _session("whisper_large_v3", FP8W)
+    audios = [unit_audio(c0["audio_seed"], c0["n_samples"])] + [unit_audio(9100 + i, 480000) for i in range(3)]
+    prompts = np.tile(c0["prompt"][None], (4, 1))
+    n_new = int(g["n_new"])
+    forced = np.tile(c0["token_ids"][None, :n_new - 1], (4, 1)).astype(np.int32)
+    l8 = _run(s8, audios, prompts, forced)
+    del s8
+    _, _, _, _, sbf = _session("whisper_large_v3", BF16)
+    lb = _run(sbf, audios, prompts, forced)
+    scale = max(float(np.abs(c0["top1"]).max()), 50.0)
+    e_bf = float(np.abs(lb[0][:, ::53][:, :c0["logits"].shape[1]] - c0["logits"]).max())
+    e_8 = float(np.abs(l8[0][:, ::53][:, :c0["logits"].shape[1]] - c0["logits"]).max())
+    print(f"whisper_large_v3 logits scale {scale:.1f}: bf16 error {e_bf:.3f}, fp8w error {e_8:.3f}")
+    assert e_bf < 2e-3 * scale                                # measured 6e-4
+    assert e_8 < 1.2e-2 * scale                               # measured 4e-3

@@ -474,3 +474,40 @@ def test_0p6b_bf16_batch64_vs_golden_and_oracle():
     r = orc.greedy(audios[1], 2, c0["query_ids"].tolist(), c0["language_tail_ids"].tolist())
     for t in range(2):
         assert np.abs(got[1][t] - r["logits"][t]).max() < 0.03 * scale + 0.1
+
+
+def test_0p6b_bf16_beam5_batch64_vs_oracle_rule():
+    """The Qwen3-ASR half of BASELINE.json configs[4] as written: 0.6B dimensions, bf16, beam = 5, 64 x 8 s in one batch = 320 hypothesis
+    rows per step (tiled decode GEMMs at 320 rows, the ancestry-table attention over 8 kv heads, device-side top-k over 151936 columns).
+    Size-independent properties on all 64 utterances + the search rule of the oracle on one of them."""
+    g = load_golden("qwen_asr_0p6b")
+    cfg, ck = qwen_setup(g)
+    sess = sub("engine").QwenAsrSession.from_checkpoint(cfg, ck, precision=BF16)
+    c0 = [c for _, c in golden_cases(g)][0]
+    head, tail, suffix = g["head_ids"].tolist(), g["tail_ids"].tolist(), g["suffix_ids"].tolist()
+    B, max_new = 64, 4
+    audios = [unit_audio(8300 + i, 128000) for i in range(B)]
+    audios[63] = audios[0].copy()
+    pre = [head + c0["query_ids"].tolist() + suffix] * B
+    post = [tail + c0["language_tail_ids"].tolist()] * B
+    sess.prefill(audios, pre, post)
+    greedy = sess.generate(max_new)
+    sess.prefill(audios, pre, post)
+    one = sess.beam_search(1, max_new)
+    sess.prefill(audios, pre, post)
+    five = sess.beam_search(5, max_new)
+    for b in range(B):
+        assert np.array_equal(one[b][0][0], greedy[b]), b                        # width 1 is greedy
+        scores = [s for _, s in five[b]]
+        assert scores == sorted(scores, reverse=True), b
+        assert len({tuple(t.tolist()) for t, _ in five[b]}) == 5, b               # five distinct hypotheses
+        assert five[b][0][1] >= one[b][0][1] - 1e-3, b                            # the wider beam never scores below the greedy path
+    for (t0, s0), (t1, s1) in zip(five[0], five[63]):                              # batch invariance, bit for bit
+        assert np.array_equal(t0, t1) and s0 == s1
+    orc = QwenAsrOracle(cfg, ck, head, tail, suffix)
+    ref = orc.beam(audios[1], 5, max_new, c0["query_ids"].tolist(), c0["language_tail_ids"].tolist())
+    scale = max(float(np.abs(c0["top1"]).max()), 1.0)
+    tol = max_new * (0.03 * scale + 0.1)                                            # summed log-probabilities of max_new bf16 steps
+    assert abs(five[1][0][1] - ref[0][1]) < tol, (five[1][0][1], ref[0][1])
+    ref_sets = {tuple(t.tolist()) for t, _ in ref}
+    assert len(ref_sets & {tuple(t.tolist()) for t, _ in five[1]}) >= 3             # most of the oracle's list survives bf16 rank flips

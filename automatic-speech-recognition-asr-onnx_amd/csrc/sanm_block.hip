@@ -52,9 +52,12 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 // write-through (sc1) stores: the payload of an exchange must be in memory, not dirty in this XCD's L2, when the flag is raised
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+// (The hooks live in a second instantiation of the kernel, ABL = true, launched only when ASR_SANM_BLOCK_ABL is set: in the product instance
+//  they would put branches between the fragment reads and the MFMAs, and the compiler then falls back to s_waitcnt lgkmcnt(0) everywhere.)
 __device__ int g_loop_dbg;          // timing-only ablations of the GEMM loops (ASR_SANM_BLOCK_ABL): 1 = no refills after the prologue, 2 = no MFMA, 4 = no fragment reads, 8 = weight rows alias one 64-row region (every weight load hits L2), 16 = payload / output stores skipped
+template <bool ABL = false>
 __device__ __forceinline__ void store16_wt(void* p, uint4 v) {
-  if (g_loop_dbg & 16) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); return; }
+  if (ABL && (g_loop_dbg & 16)) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); return; }
   const u32x4_t w = {v.x, v.y, v.z, v.w};
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
 }
@@ -96,7 +99,7 @@ __device__ __forceinline__ int hk(int sel) { return (0x78 >> (2 * (sel & 3))) & 
 // by LDS-DMA with the 16-byte-slot swizzle on the global side. 12 waves = 3 row groups (48 rows) x 4 column groups (NJ fragments = 16 NJ
 // columns); W rows are fetched in the paired-fragment order so that a lane ends with 8 consecutive output columns per fragment pair.
 // Every wave issues P = ceil(pieces / 12) loads per stage (the last piece is re-loaded by the spare slots: same bytes, same place).
-template <int RW, int NS, int NJ, bool FULL, bool PIPE>     // FULL: all 9 row fragments active (an 8 s window): straight-line MFMA body, no per-fragment branches
+template <int RW, int NS, int NJ, bool FULL, bool PIPE, bool ABL>     // FULL: all 9 row fragments active (an 8 s window): straight-line MFMA body, no per-fragment branches
 __device__ __forceinline__ void tile_loop_impl(unsigned char* ring, const bf16_t* a0, int lda, int a_rows_left, const bf16_t* w0, int ldw, int nk,
                                           int n_act, f32x4_t (&acc)[3][NJ], int lane, int wave) {
   constexpr int NP = (R + RW) / 8, P = (NP + NW - 1) / NW, STAGE = (R + RW) * 128;
@@ -114,7 +117,7 @@ __device__ __forceinline__ void tile_loop_impl(unsigned char* ring, const bf16_t
       src[t] = a0 + (size_t)min(r, a_rows_left - 1) * lda + (((lane & 7) ^ srow) << 3);
     } else {
       const int wr = (ii - R / 8) * 8 + srow;
-      src[t] = w0 + (size_t)((g_loop_dbg & 8) ? (wr & 63) : wr) * ldw + (((lane & 7) ^ w_swz(wr)) << 3);
+      src[t] = w0 + (size_t)((ABL && (g_loop_dbg & 8)) ? (wr & 63) : wr) * ldw + (((lane & 7) ^ w_swz(wr)) << 3);
     }
   }
   auto stage = [&](int slot, int k0) {
@@ -133,7 +136,7 @@ __device__ __forceinline__ void tile_loop_impl(unsigned char* ring, const bf16_t
     for (int j = 0; j < NJ; ++j) { const int r = cg * (NJ * 16) + frag_col(j, frow); w_off[kk][j] = R * 128 + r * 128 + ((c ^ w_swz(r)) << 4); }
   }
   const int my_frags = min(3, max(0, n_act - rg * 3));         // active row fragments of this wave (wave-uniform)
-  const int dbg = g_loop_dbg;
+  const int dbg = ABL ? g_loop_dbg : 0;
   // Software pipeline across the per-K-step barrier: the fragments of (stage kt, k-half 1) are read while the MFMAs of k-half 0 run,
   // the barrier that makes stage kt + 1 visible sits between the two MFMA groups, and the fragments of (stage kt + 1, k-half 0) are read
   // while the MFMAs of k-half 1 run -- a wave never waits on an LDS round trip with an idle matrix pipe.
@@ -196,11 +199,11 @@ __device__ __forceinline__ void tile_loop_impl(unsigned char* ring, const bf16_t
   }
   __syncthreads();          // every wave is done with the ring (and no DMA is in flight): the caller may reuse the space
 }
-template <int RW, int NS, int NJ, bool PIPE = true>
+template <int RW, int NS, int NJ, bool PIPE, bool ABL>
 __device__ __forceinline__ void tile_loop(unsigned char* ring, const bf16_t* a0, int lda, int a_rows_left, const bf16_t* w0, int ldw, int nk,
                                           int n_act, f32x4_t (&acc)[3][NJ], int lane, int wave) {
-  if (n_act == RF) tile_loop_impl<RW, NS, NJ, true, PIPE>(ring, a0, lda, a_rows_left, w0, ldw, nk, n_act, acc, lane, wave);
-  else tile_loop_impl<RW, NS, NJ, false, false>(ring, a0, lda, a_rows_left, w0, ldw, nk, n_act, acc, lane, wave);
+  if (n_act == RF) tile_loop_impl<RW, NS, NJ, true, PIPE, ABL>(ring, a0, lda, a_rows_left, w0, ldw, nk, n_act, acc, lane, wave);
+  else tile_loop_impl<RW, NS, NJ, false, false, ABL>(ring, a0, lda, a_rows_left, w0, ldw, nk, n_act, acc, lane, wave);
 }
 
 __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
@@ -232,6 +235,7 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); retur
 
 #define STAMP(k) do { if (a->times && threadIdx.x == 0) a->times[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 
+template <bool ABL>
 __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_byval) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_by
         src[t] = hb + (size_t)(row0 + min(ii * 16 + r16, rows_left - 1)) * D + ch;
       } else {
         const int wr = (ii - A_AI) * 16 + r16;              // 0..383: q | k | v rows of this head
-        src[t] = wb + (size_t)((g_loop_dbg & 8) ? (wr & 63) : (wr >> 7) * D + h * HD + (wr & 127)) * D + ch;
+        src[t] = wb + (size_t)((ABL && (g_loop_dbg & 8)) ? (wr & 63) : (wr >> 7) * D + h * HD + (wr & 127)) * D + ch;
       }
     }
     auto stage = [&](int slot, int k0) {
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_by
         const int row = c >> 4, ch = c & 15;
         uint4 v = *reinterpret_cast<const uint4*>(smem + QS + row * 256 + ((ch ^ (row & 15)) << 4));
         if (row >= T) v = make_uint4(0, 0, 0, 0);          // alignment rows past the window: zeros, like the separate kernels leave them
-        store16_wt(cg_ + (size_t)row * D + ch * 8, v);
+        store16_wt<ABL>(cg_ + (size_t)row * D + ch * 8, v);
       }
     }
     publish(flags + 0);
@@ -573,7 +577,7 @@ __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_by
       else { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
     }
     __syncthreads();
-    tile_loop<128, 4, 2>(smem, a->ctx + (size_t)row0 * D, D, rows_left, a->wout + (size_t)h * HD * D, D, D / 64, n_act, acc, lane, wave);
+    tile_loop<128, 4, 2, true, ABL>(smem, a->ctx + (size_t)row0 * D, D, rows_left, a->wout + (size_t)h * HD * D, D, D / 64, n_act, acc, lane, wave);
     STAMP(6);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_by
         v[0] = acc[i][0][0]; v[1] = acc[i][0][1]; v[2] = acc[i][0][2]; v[3] = acc[i][0][3];
         v[4] = acc[i][1][0]; v[5] = acc[i][1][1]; v[6] = acc[i][1][2]; v[7] = acc[i][1][3];
         const uint4 pk = pack8(xres[i]);
-        store16_wt(a->x1_lo + (size_t)(row0 + row) * D + h * HD + n, pk);
+        store16_wt<ABL>(a->x1_lo + (size_t)(row0 + row) * D + h * HD + n, pk);
         float s1 = 0.0f, s2 = 0.0f;
         stats8(pk, s1, s2);
         s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
@@ -621,7 +625,7 @@ __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_by
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       const unsigned long long tc0 = a->times ? wall_clock64() : 0ull;
-      tile_loop<256, 3, 4, false>(smem, a->x1_lo + (size_t)row0 * D, D, rows_left, a->w1 + (size_t)col0 * D, D, D / 64, n_act, acc, lane, wave);
+      tile_loop<256, 3, 4, false, ABL>(smem, a->x1_lo + (size_t)row0 * D, D, rows_left, a->w1 + (size_t)col0 * D, D, D / 64, n_act, acc, lane, wave);
       if (a->times && threadIdx.x == 0) a->times[(size_t)blockIdx.x * 16 + 14] += wall_clock64() - tc0;
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
@@ -640,7 +644,7 @@ __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_by
             for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * p][r]; v[4 + r] = acc[i][2 * p + 1][r]; }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf((v[e] - mr.x * c8[e]) * mr.y + b8[e], 0.0f);
-            store16_wt(a->hid + (size_t)(row0 + row) * DFF + n, pack8(v));
+            store16_wt<ABL>(a->hid + (size_t)(row0 + row) * DFF + n, pack8(v));
           }
         }
       }
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_by
     f32x4_t acc[3][2];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-    tile_loop<128, 4, 2>(smem, a->hid + (size_t)row0 * DFF, DFF, rows_left, a->w2 + (size_t)h * HD * DFF, DFF, DFF / 64, n_act, acc, lane, wave);
+    tile_loop<128, 4, 2, true, ABL>(smem, a->hid + (size_t)row0 * DFF, DFF, rows_left, a->w2 + (size_t)h * HD * DFF, DFF, DFF / 64, n_act, acc, lane, wave);
     STAMP(12);
     const int n = cg * 32 + fgrp * 8;
     const float4 b0 = *reinterpret_cast<const float4*>(a->b2 + h * HD + n), b1v = *reinterpret_cast<const float4*>(a->b2 + h * HD + n + 4);
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_by
         for (int e = 0; e < 8; ++e) v[e] += b8[e] + xres[i][e];
         float* xo = a->x + (size_t)(row0 + row) * D + h * HD + n;
         const uint4 pk = pack8(v);
-        if (!(g_loop_dbg & 16)) {
+        if (!(ABL && (g_loop_dbg & 16))) {
           *reinterpret_cast<float4*>(xo) = make_float4(v[0], v[1], v[2], v[3]);
           *reinterpret_cast<float4*>(xo + 4) = make_float4(v[4], v[5], v[6], v[7]);
           *reinterpret_cast<uint4*>(a->x_lo_out + (size_t)(row0 + row) * D + h * HD + n) = pk;
@@ -729,13 +733,16 @@ void launch_sanm_block(const SanmBlockArgs& a, hipStream_t s) {
   ASR_REQUIRE(a.n_utts > 0 && a.n_utts <= sanm_block_max_utts(), "sanm_block: %d windows per launch (max %d)", a.n_utts, sanm_block_max_utts());
   ASR_REQUIRE(a.x_lo && a.x && a.ctx && a.x1_lo && a.st1 && a.hid && a.x_lo_out && a.st_out && a.flags && a.err && a.plan, "sanm_block: null buffer");
   static bool attr_set = false;
+  static int abl = 0;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sanm_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    const int abl = getenv("ASR_SANM_BLOCK_ABL") ? atoi(getenv("ASR_SANM_BLOCK_ABL")) : 0;
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sanm_block_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sanm_block_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    abl = getenv("ASR_SANM_BLOCK_ABL") ? atoi(getenv("ASR_SANM_BLOCK_ABL")) : 0;
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_loop_dbg), &abl, sizeof(int)));
     attr_set = true;
   }
   const int grid = a.scatter ? a.n_utts * 4 : ((a.n_utts + 7) / 8) * 32;
-  hipLaunchKernelGGL(sanm_block_kernel, dim3(grid), dim3(NT), LDS_BYTES, s, a);
+  if (abl) hipLaunchKernelGGL(sanm_block_kernel<true>, dim3(grid), dim3(NT), LDS_BYTES, s, a);     // the ablation build (timing only)
+  else hipLaunchKernelGGL(sanm_block_kernel<false>, dim3(grid), dim3(NT), LDS_BYTES, s, a);
   HIP_CHECK(hipGetLastError());
 }

@@ -1204,7 +1204,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_128x128x16(const GemmArgs g) 
   const int frow = lane & 15, fgrp = lane >> 4;
   // 128 rows x 16 floats = 512 float4 per operand; thread t loads float4 #t and #t+256
   const int lrow = tid >> 2, lcol = (tid & 3) * 4;
-  for (int k0 = 0; k0 < g.K; k0 += BK32) {
+  // split-K (gridDim.y slices, pass 1 of launch_gemm_f32): this workgroup's K range; its raw partial tile goes to slice blockIdx.y of the workspace
+  const int k_len = g.K / (int)gridDim.y, k_first = (int)blockIdx.y * k_len;
+  for (int k0 = k_first; k0 < k_first + k_len; k0 += BK32) {
     const float4 a0 = *reinterpret_cast<const float4*>(A + (size_t)(tile_m * BM + lrow) * g.lda + k0 + lcol);
     const float4 a1 = *reinterpret_cast<const float4*>(A + (size_t)(tile_m * BM + lrow + 64) * g.lda + k0 + lcol);
     const float4 w0 = *reinterpret_cast<const float4*>(W + (size_t)(tile_n * 128 + lrow) * g.ldw + k0 + lcol);
@@ -1236,8 +1238,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_128x128x16(const GemmArgs g) 
     }
   }
   const int m_wave = tile_m * BM + wm * 64, n_wave = tile_n * 128 + wn * 64;
-  if constexpr (SWAP) epilogue_rows<float, -1, -1, 4>(g, acc, m_wave, n_wave, lane);
-  else epilogue_transposed<float, 4>(g, acc, m_wave, n_wave, lane);
+  if constexpr (SWAP) {
+    if (gridDim.y > 1) { GemmArgs gs = g; gs.out_f32 = g.out_f32 + (size_t)blockIdx.y * g.M * g.N; epilogue_rows<float, -1, -1, 4>(gs, acc, m_wave, n_wave, lane); }
+    else epilogue_rows<float, -1, -1, 4>(g, acc, m_wave, n_wave, lane);
+  } else epilogue_transposed<float, 4>(g, acc, m_wave, n_wave, lane);
 }
 
 __global__ void argmax_reduce_kernel(const float* __restrict__ val, const int32_t* __restrict__ idx, int M, int n_slabs,
@@ -1282,6 +1286,7 @@ void check_args(const GemmArgs& g, int kstep, int elt) {
 }
 
 // second launch of a split-K GEMM: out = epilogue(sum over splits, in split order); 4 columns per thread
+template <typename LoT>      // element type behind out_lo: bf16 in bf16 sessions, float in verification mode
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g, const float* __restrict__ ws, int splits) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int n4 = g.N >> 2;
@@ -1297,7 +1302,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g, co
   if (g.act != ACT_NONE) { v.x = apply_act_rt(v.x, g.act); v.y = apply_act_rt(v.y, g.act); v.z = apply_act_rt(v.z, g.act); v.w = apply_act_rt(v.w, g.act); }
   if (g.add2) { const float4 q = *reinterpret_cast<const float4*>(g.add2 + (size_t)m * g.ld_add2 + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
   if (g.out_f32) store4<float>(g.out_f32 + (size_t)m * g.ld_out_f32 + n, v.x, v.y, v.z, v.w);
-  if (g.out_lo) store4<bf16_t>(reinterpret_cast<bf16_t*>(g.out_lo) + (size_t)m * g.ld_out_lo + n, v.x, v.y, v.z, v.w);
+  if (g.out_lo) store4<LoT>(reinterpret_cast<LoT*>(g.out_lo) + (size_t)m * g.ld_out_lo + n, v.x, v.y, v.z, v.w);
   if (g.st_out) {                                // (sum, sum of squares) of the bf16-rounded values per 32-column group = 8 consecutive threads
     const uint32_t p0 = pack_bf16x2(v.x, v.y), p1 = pack_bf16x2(v.z, v.w);
     const float a = __uint_as_float(p0 << 16), b = __uint_as_float(p0 & 0xffff0000u), c = __uint_as_float(p1 << 16), d = __uint_as_float(p1 & 0xffff0000u);
@@ -1600,7 +1605,7 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
       const bool deep_sk = genv().deep;
       if (deep_sk && g.K / sp >= 256) launch_pipe<64, 3>(p, s); else launch_pipe<64, 2>(p, s);   // lone workgroups per CU: a third stage covers the DMA latency
       const size_t n = (size_t)g.M * (g.N / 4);
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, (const float*)g.sk_ws, sp);
+      hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, (const float*)g.sk_ws, sp);
       HIP_CHECK(hipGetLastError());
       return;
     }
@@ -1633,9 +1638,36 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
   }
 }
 
+// verification mode, small grids (a single window: 8 .. 32 tiles walking K = 512 .. 2048 in 16-column steps, one barrier pair each): K split
+// across workgroups, partial tiles summed in split order by splitk_reduce_kernel, which also runs the epilogue. Only for callers that hand
+// in a workspace (sk_ws); the summation order then depends on the split count, i.e. on the batch geometry -- within the mode's 1e-3 bar.
+static int f32_splits(const GemmArgs& g) {
+  if (!g.sk_ws || g.out_t || g.amax_val || g.lo_group || g.add2_rows || g.ln_colsum || g.m_dev || g.act == ACT_SWIGLU || g.ln_x || g.a_rms_eps != 0.0f || g.st_out) return 1;
+  const int tiles = ((g.M + BM - 1) / BM) * (g.N / 128);
+  if (tiles > 64 || g.K < 512) return 1;
+  int best = 1;
+  for (int sp : {2, 4, 8, 16}) {
+    if (g.K % (sp * BK32) != 0 || g.K / sp < 64) break;
+    if ((size_t)sp * g.M * g.N * 4 > g.sk_ws_bytes) break;
+    best = sp;
+    if (tiles * sp >= 160) break;
+  }
+  return best;
+}
+
 void launch_gemm_f32(const GemmArgs& g, hipStream_t s) {
   check_args(g, BK32, 4);
   const int grid = ((g.M + BM - 1) / BM) * (g.N / 128);
+  if (const int sp = f32_splits(g); sp > 1) {
+    GemmArgs p = g;                                    // pass 1: raw f32 partials, no epilogue terms
+    p.bias = nullptr; p.add = nullptr; p.add2 = nullptr; p.act = ACT_NONE; p.out_lo = nullptr;
+    p.out_f32 = g.sk_ws; p.ld_out_f32 = g.N;
+    hipLaunchKernelGGL(gemm_f32_128x128x16<true>, dim3(grid, sp), dim3(256), 0, s, p);
+    const size_t n = (size_t)g.M * (g.N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, (const float*)g.sk_ws, sp);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (g.out_t) hipLaunchKernelGGL(gemm_f32_128x128x16<false>, dim3(grid), dim3(256), 0, s, g);
   else hipLaunchKernelGGL(gemm_f32_128x128x16<true>, dim3(grid), dim3(256), 0, s, g);
   HIP_CHECK(hipGetLastError());

@@ -378,7 +378,9 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(const AttnArgs a, int n_
 }
 
 // ------------------------------------------------------------------------------------ attention (f32, verification mode)
-// One wave per query row; lanes over keys for the scores, lanes over d for the context. Plain f32 FMA.
+// One wave per query row; lanes over keys for the scores, lanes over d for the context. Plain f32 FMA. A query block of the plan (64 rows)
+// is spread over gridDim.z workgroups (wave w of workgroup z takes rows w + 4 z, w + 4 z + 4 gridDim.z, ...): a single 8 s window is then
+// ~140 workgroups instead of 12 (the row's arithmetic and its order are unchanged).
 constexpr int ATT32_MAXT = 2048;
 __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs a, int HD) {
   __shared__ float sc[4][ATT32_MAXT];
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs a, int HD)
   const float* K = reinterpret_cast<const float*>(a.k);
   const float* Vt = reinterpret_cast<const float*>(a.vt);
   float* C = reinterpret_cast<float*>(a.ctx);
-  for (int qi = wave; qi < 64; qi += 4) {
+  for (int qi = wave + 4 * blockIdx.z; qi < 64; qi += 4 * gridDim.z) {
     const int qrow = q0 + qi;
     if (qrow >= Tq) break;                     // wave-uniform
     const float* qp = Q + (size_t)(rowq0 + qrow) * a.ld_q + h * HD;
@@ -1175,7 +1177,9 @@ void launch_attention_f32(const AttnArgs& a, int head_dim, hipStream_t s) {
   ASR_REQUIRE(head_dim <= 128 && head_dim % 4 == 0, "attention_f32: head_dim %d unsupported", head_dim);
   AttnArgs b = a;
   if (b.ld_q == 0) b.ld_q = b.ld_qk;
-  hipLaunchKernelGGL(attn_f32_kernel, dim3(a.n_qblocks, a.n_heads), dim3(256), 0, s, b, head_dim);
+  const int wgs = a.n_qblocks * a.n_heads;
+  const int z = wgs >= 1024 ? 1 : wgs >= 256 ? 4 : 16;           // few query blocks (single utterances): one row per wave
+  hipLaunchKernelGGL(attn_f32_kernel, dim3(a.n_qblocks, a.n_heads, z), dim3(256), 0, s, b, head_dim);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -100,10 +100,10 @@ struct SvSession : asr_session {
                                  int32_t* tok_out, int max_tokens, int32_t* num_out);
   DeviceBuffer d_skws, d_skcnt;        // split-K workspace + tickets of the skinny GEMM (per session: sessions may run concurrently)
   void gemm(const GemmArgs& g0) {
-    if (precision != ASR_PRECISION_BF16) { launch_gemm_f32(g0, stream); return; }
     if (!d_skws.ptr) { d_skws.reserve((size_t)16 << 20, stream); d_skcnt.reserve(4096 * 4, stream); }
     GemmArgs g = g0;
     g.sk_ws = d_skws.as<float>(); g.sk_ws_bytes = d_skws.cap; g.sk_cnt = d_skcnt.as<int32_t>();
+    if (precision != ASR_PRECISION_BF16) { launch_gemm_f32(g, stream); return; }      // (the workspace lets single windows split K)
     launch_gemm_bf16(g, stream);
   }
 };

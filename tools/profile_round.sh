@@ -15,6 +15,10 @@ python bench.py --workload paraformer --steps 10 > $OUT/bench_paraformer.json 2>
 python bench.py --workload whisper --steps 6 --warmup 3 --inflight 3 > $OUT/bench_whisper.json 2> $OUT/bench_whisper.err
 python bench.py --workload whisper --batch 64 --steps 5 --warmup 3 --inflight 2 --no-cpu-baseline > $OUT/bench_whisper_b64.json 2> $OUT/bench_whisper_b64.err
 python bench.py --workload whisper --seconds 30 --steps 3 --warmup 2 --inflight 3 --no-cpu-baseline > $OUT/bench_whisper30.json 2> $OUT/bench_whisper30.err
+python bench.py --workload whisper --fp8 --seconds 30 --steps 3 --warmup 2 --no-cpu-baseline > $OUT/bench_whisper30_fp8.json 2> $OUT/bench_whisper30_fp8.err
+python bench.py --workload whisper --fp8 --steps 6 --warmup 3 --no-cpu-baseline > $OUT/bench_whisper_fp8.json 2> $OUT/bench_whisper_fp8.err
+ASR_SANM_BLOCK_DBG=10 python tools/probes/sanm_block_clock.py > $OUT/sanm_block_phase_clock.txt 2>&1
+python tools/probes/f32_b1_profile.py > $OUT/sensevoice_f32_b1_profile.txt 2>&1
 python bench.py --workload paraformer-streaming --steps 16 --warmup 8 > $OUT/bench_paraformer_streaming.json 2> $OUT/bench_paraformer_streaming.err
 python bench.py --workload qwen --steps 6 --warmup 2 --inflight 3 > $OUT/bench_qwen.json 2> $OUT/bench_qwen.err
 python bench.py --workload qwen --beam 5 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_qwen_beam5.json 2> $OUT/bench_qwen_beam5.err

@@ -35,8 +35,14 @@ struct FbankArgs {
   // log10 instead of ln, and the per-workgroup maximum written to blk_max for the per-utterance clamp
   int whisper;
   float* blk_max;
+  // bf16 sessions: the DFT on the bf16 matrix pipe with split operands (launch_fbank_split_table): null = exact-f32 MFMA
+  const void* dft_split = nullptr;
 };
 void launch_fbank(const FbankArgs& a, int n_blocks, hipStream_t s);
+// three-term bf16 split (hi + mid + lo = the f32 value to 2^-24) of the packed DFT basis, as 16x16x32 fragments:
+// out[(bin tile * 2 + re/im) * ceil(win / 32) + k chunk][term][lane] x 16 bytes; rows k >= win are zero
+size_t fbank_split_table_bytes(int n_bin_tiles, int win);
+void launch_fbank_split_table(const float* dft_packed, int n_bin_tiles, int n_kchunks16, void* out, hipStream_t s);
 
 // ---- Whisper log-mel finish (Export_Whisper.py:425-427): max(x, utterance_max - 8), (x + 4) / 4, written in the
 // GAPPED time-major layout the conv stem reads: utterance b owns rows [2*row_off_b, 2*row_off_b + 2*rows_b); row

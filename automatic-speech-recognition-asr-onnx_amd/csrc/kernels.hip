@@ -122,6 +122,156 @@ __global__ __launch_bounds__(256) void fbank_kernel(const FbankArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------ fbank, bf16 sessions: split-operand DFT
+// The DFT is 92 % of the front-end's flops and the exact-f32 MFMA runs at 1/16 of the bf16 rate. Here both operands are split into bf16
+// terms and the product is summed on the bf16 pipe with f32 accumulation:  x = xh + xl  (two terms: exact for 16-bit PCM values, 2^-17
+// relative otherwise -- below the quantisation noise of the audio itself),  b = bh + bm + bl  (three terms: the basis to 2^-24);
+// x b ~= xh bh + xh bm + xh bl + xl bh + xl bm  -- five 16x16x32 MFMAs (80 cycles) per 32 samples against eight 16x16x4 f32 MFMAs (256).
+// The dropped terms (xl bl, xl ... ) are below 2^-24 of |x||b|. Power, mel projection and log stay in exact f32 as before.
+constexpr int FB_HP = HOP + 8;                                   // bf16 audio row pitch per hop: +8 elements => 16 rows of a fragment hit 16 different 16-byte slots
+constexpr int FB_K32 = (WIN + 31) / 32;                          // 13 chunks of 32 samples (the last one half empty: basis rows >= 400 are zero)
+constexpr int FB_A16 = ((FB_SPAN + 32 + HOP - 1) / HOP) * FB_HP; // bf16 elements per split array (span + the tail the last chunk reads)
+
+__global__ __launch_bounds__(256) void fbank_split_kernel(const FbankArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* audh = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* audl = audh + FB_A16;
+  float* pw = reinterpret_cast<float*>(audl + FB_A16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u = a.blk_utt[blockIdx.x], f0 = a.blk_f0[blockIdx.x];
+  const UttPlan up = a.plan[u];
+  const float* src = a.audio + up.audio_off;
+  const int s0 = f0 * HOP;
+  for (int i = tid; i < FB_SPAN + 32; i += 256) {
+    float v = 0.0f;
+    if (!a.whisper) {
+      const int s = s0 + i;
+      if (s < up.n_samples) v = src[s];
+    } else {                     // padded signal = [x[200..1] | x | x[L-2 .. L-41]]  (reflect, right pad shortened by one hop)
+      const int L = up.n_samples, half = WIN / 2, p = s0 + i;
+      if (p < half) v = src[half - p];
+      else if (p < half + L) v = src[p - half];
+      else if (p < L + WIN - HOP) v = src[2 * L + half - 2 - p];
+    }
+    const uint32_t hb = pack_bf16x2(v, 0.0f) & 0xffffu;
+    const float hi = __uint_as_float(hb << 16);
+    const int pos = i + (i / HOP) * 8;
+    audh[pos] = (bf16_t)hb;
+    audl[pos] = (bf16_t)(pack_bf16x2(v - hi, 0.0f) & 0xffffu);
+  }
+  __syncthreads();
+
+  const int frow = lane & 15, fgrp = lane >> 4;
+  const uint4* tab = reinterpret_cast<const uint4*>(a.dft_split);
+  for (int t = wave; t < a.n_bin_tiles; t += 4) {
+    f32x4_t re[4], im[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) { re[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; im[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    const uint4* tre = tab + ((size_t)(t * 2 + 0) * FB_K32) * 3 * 64 + lane;
+    const uint4* tim = tab + ((size_t)(t * 2 + 1) * FB_K32) * 3 * 64 + lane;
+    union BF { uint4 q; bf16x8_t v; };
+    BF br[3], bi[3];
+#pragma unroll
+    for (int z = 0; z < 3; ++z) { br[z].q = tre[z * 64]; bi[z].q = tim[z * 64]; }
+    for (int kc = 0; kc < FB_K32; ++kc) {
+      BF brn[3], bin[3];                           // the next chunk's basis fragments are requested before this chunk's MFMAs
+#pragma unroll
+      for (int z = 0; z < 3; ++z) { brn[z] = br[z]; bin[z] = bi[z]; }
+      if (kc + 1 < FB_K32) {
+#pragma unroll
+        for (int z = 0; z < 3; ++z) { brn[z].q = tre[((kc + 1) * 3 + z) * 64]; bin[z].q = tim[((kc + 1) * 3 + z) * 64]; }
+      }
+      const int k = kc * 32 + fgrp * 8;
+      const int koff = k + (k / HOP) * 8;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int pos = (mt * 16 + frow) * FB_HP + koff;
+        const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(audh + pos), al = *reinterpret_cast<const bf16x8_t*>(audl + pos);
+        // smallest terms first: the f32 accumulator then rounds the dominant product last
+        re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, br[1].v, re[mt], 0, 0, 0);
+        im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bi[1].v, im[mt], 0, 0, 0);
+        re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, br[2].v, re[mt], 0, 0, 0);
+        im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bi[2].v, im[mt], 0, 0, 0);
+        re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, br[0].v, re[mt], 0, 0, 0);
+        im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bi[0].v, im[mt], 0, 0, 0);
+        re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, br[1].v, re[mt], 0, 0, 0);
+        im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bi[1].v, im[mt], 0, 0, 0);
+        re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, br[0].v, re[mt], 0, 0, 0);
+        im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bi[0].v, im[mt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int z = 0; z < 3; ++z) { br[z] = brn[z]; bi[z] = bin[z]; }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        pw[(mt * 16 + fgrp * 4 + r) * FB_PLD + t * 16 + frow] = re[mt][r] * re[mt][r] + im[mt][r] * im[mt][r];
+  }
+  __syncthreads();
+
+  // mel: wave w owns frames [16w, 16w+16); all mel tiles (exact f32, as in fbank_kernel)
+  float wmax = -INFINITY;
+  const float4* melp = reinterpret_cast<const float4*>(a.mel_packed);
+  for (int nt = 0; nt < a.n_mel_tiles; ++nt) {
+    f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float4 b4 = melp[(size_t)(nt * a.n_bin_tiles) * 64 + lane];
+    for (int kc = 0; kc < a.n_bin_tiles; ++kc) {
+      float4 b4n = b4;
+      if (kc + 1 < a.n_bin_tiles) b4n = melp[(size_t)(nt * a.n_bin_tiles + kc + 1) * 64 + lane];
+      const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float av = pw[(wave * 16 + frow) * FB_PLD + kc * 16 + j * 4 + fgrp];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc, 0, 0, 0);
+      }
+      b4 = b4n;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = f0 + wave * 16 + fgrp * 4 + r;
+      if (f < up.n_frames) {
+        const float c = fmaxf(acc[r], a.log_floor);
+        const float v = a.whisper ? log10f(c) : logf(c);
+        a.mel_out[(size_t)(up.frame_off + f) * a.n_mels + nt * 16 + frow] = v;
+        wmax = fmaxf(wmax, v);
+      }
+    }
+  }
+  if (a.whisper) {
+    __shared__ float red[4];
+    wmax = wave_max(wmax);
+    if (lane == 0) red[wave] = wmax;
+    __syncthreads();
+    if (tid == 0) a.blk_max[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  }
+}
+
+// one thread per (fragment, lane): gathers the 8 basis values B[k][n] of its slot from the f32 fragment table and writes the three bf16 terms
+__global__ void fbank_split_table_kernel(const float* __restrict__ dft_packed, int n_bin_tiles, int n_kchunks16, uint4* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = n_bin_tiles * 2 * FB_K32 * 64;
+  if (idx >= total) return;
+  const int lane = idx & 63, kc = (idx >> 6) % FB_K32, tr = (idx >> 6) / FB_K32;     // tr = bin tile * 2 + (re | im)
+  const int frow = lane & 15, fgrp = lane >> 4;
+  uint32_t w[3][4] = {};
+  for (int e = 0; e < 8; ++e) {
+    const int k = kc * 32 + fgrp * 8 + e;
+    float v = 0.0f;
+    if (k < n_kchunks16 * 16) {
+      // packed[((tr) * n_kchunks16 + k / 16) * 64 + ((k % 4) * 16 + frow)].component[(k % 16) / 4]  =  B[k][16 t + frow]
+      v = dft_packed[(((size_t)tr * n_kchunks16 + (k >> 4)) * 64 + ((k & 3) * 16 + frow)) * 4 + ((k & 15) >> 2)];
+    }
+    float r = v;
+    for (int z = 0; z < 3; ++z) {
+      const uint32_t b = pack_bf16x2(r, 0.0f) & 0xffffu;
+      r -= __uint_as_float(b << 16);
+      w[z][e >> 1] |= b << ((e & 1) * 16);
+    }
+  }
+  for (int z = 0; z < 3; ++z) out[((size_t)(tr * FB_K32 + kc) * 3 + z) * 64 + lane] = make_uint4(w[z][0], w[z][1], w[z][2], w[z][3]);
+}
+
 // ------------------------------------------------------------------------------------ LFR + CMVN
 __global__ void lfr_cmvn_kernel(const LfrArgs a) {
   const int m = blockIdx.x;
@@ -1103,7 +1253,28 @@ void launch_fbank(const FbankArgs& a, int n_blocks, hipStream_t s) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fbank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
+  if (a.dft_split) {
+    const size_t lds2 = (size_t)FB_A16 * 2 * 2 + (size_t)FB_FRAMES * FB_PLD * sizeof(float);
+    static bool attr2 = false;
+    if (!attr2) {
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fbank_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      attr2 = true;
+    }
+    hipLaunchKernelGGL(fbank_split_kernel, dim3(n_blocks), dim3(256), lds2, s, a);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL(fbank_kernel, dim3(n_blocks), dim3(256), lds, s, a);
+  HIP_CHECK(hipGetLastError());
+}
+
+size_t fbank_split_table_bytes(int n_bin_tiles, int win) {
+  ASR_REQUIRE(win == WIN, "fbank: only win=400 is built (got %d)", win);
+  return (size_t)n_bin_tiles * 2 * FB_K32 * 3 * 64 * 16;
+}
+void launch_fbank_split_table(const float* dft_packed, int n_bin_tiles, int n_kchunks16, void* out, hipStream_t s) {
+  const int total = n_bin_tiles * 2 * FB_K32 * 64;
+  hipLaunchKernelGGL(fbank_split_table_kernel, dim3((total + 255) / 256), dim3(256), 0, s, dft_packed, n_bin_tiles, n_kchunks16, reinterpret_cast<uint4*>(out));
   HIP_CHECK(hipGetLastError());
 }
 

@@ -58,7 +58,7 @@ struct SvSession : asr_session {
   size_t h_out_cap = 0;
 
   ~SvSession() override {
-    for (DeviceBuffer* b : {&d_times, &d_flags, &d_ctplan, &d_mdev, &d_trow, &d_skws, &d_skcnt, &d_sta, &d_stb, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
+    for (DeviceBuffer* b : {&d_dft_split, &d_times, &d_flags, &d_ctplan, &d_mdev, &d_trow, &d_skws, &d_skcnt, &d_sta, &d_stb, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
                             &d_x0lo, &d_xalo, &d_xblo, &d_plan, &d_audio, &d_mel, &d_x0, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx, &d_mem, &d_ffn,
                             &d_amax_v, &d_amax_i, &d_ids, &d_tok, &d_num, &d_logits, &d_enc_lo, &d_ck, &d_cifa, &d_alpha, &d_dec, &d_x2,
                             &d_sa, &d_ffn32, &d_tplan})
@@ -85,6 +85,8 @@ struct SvSession : asr_session {
   bool use_ln_alg = true;       // LayerNorm evaluated inside the projections from row statistics (ASR_LN_FUSED=0 disables)
   bool use_fused = true;        // fused q|k|v + attention + FSMN kernel for windows of <= 144 rows (ASR_SANM_FUSED=0 disables)
   bool use_block = true;        // one launch per SANM block (clusters of four workgroups per window; ASR_SANM_BLOCK=0 disables)
+  bool use_fbank_split = true;  // ASR_FBANK_SPLIT=0: exact-f32 MFMA DFT in bf16 sessions too
+  DeviceBuffer d_dft_split;
   int block_scatter = 0;        // ASR_SANM_BLOCK_SCATTER=1: test placement, every cluster spread over four XCDs
   int block_min_utts = 48;      // ASR_SANM_BLOCK_MIN=<windows>: smallest batch that takes the block kernel
   DeviceBuffer d_times; int block_dbg = -1;   // ASR_SANM_BLOCK_DBG=<block index>: phase clock of that block's launch on stderr
@@ -130,6 +132,11 @@ void SvSession::init() {
   const int d = c.d_model, dff = c.d_ffn;
 
   dft = (const float*)arena.get("fe.dft", ARENA_F32, {(int64_t)n_bin_tiles * 2 * n_kchunks * 64 * 4}).ptr;
+  if (precision == ASR_PRECISION_BF16 && use_fbank_split) {       // bf16 sessions: the DFT on the bf16 pipe with split operands (kernels.hip: fbank_split_kernel)
+    d_dft_split.reserve(fbank_split_table_bytes(n_bin_tiles, cfg.win_length), stream);
+    launch_fbank_split_table(dft, n_bin_tiles, n_kchunks, d_dft_split.ptr, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
   melp = (const float*)arena.get("fe.mel", ARENA_F32, {(int64_t)(c.n_mels / 16) * n_bin_tiles * 64 * 4}).ptr;
   cmvn_means = opt("fe.cmvn_means", {feat});
   cmvn_vars = (const float*)arena.get("fe.cmvn_vars", ARENA_F32, {feat}).ptr;
@@ -226,6 +233,7 @@ void SvSession::enqueue(const SvRunCtx& r) {
     fa.dft_packed = dft; fa.mel_packed = melp; fa.mel_out = d_mel.as<float>();
     fa.n_bin_tiles = n_bin_tiles; fa.n_kchunks = n_kchunks; fa.n_mel_tiles = c.n_mels / 16; fa.n_mels = c.n_mels;
     fa.win = c.win_length; fa.hop = c.hop_length; fa.log_floor = 1.1920928955078125e-07f; fa.whisper = 0; fa.blk_max = nullptr;
+    fa.dft_split = d_dft_split.ptr;
     launch_fbank(fa, r.n_fb, stream);
   }
   save_tap("mel", d_mel.ptr, r.frames, c.n_mels, c.n_mels, 4);
@@ -885,6 +893,7 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
     fa.dft_packed = dft; fa.mel_packed = melp; fa.mel_out = d_mel.as<float>();
     fa.n_bin_tiles = n_bin_tiles; fa.n_kchunks = n_kchunks; fa.n_mel_tiles = c.n_mels / 16; fa.n_mels = c.n_mels;
     fa.win = c.win_length; fa.hop = c.hop_length; fa.log_floor = 1.1920928955078125e-07f; fa.whisper = 0; fa.blk_max = nullptr;
+    fa.dft_split = d_dft_split.ptr;
     launch_fbank(fa, n, stream);
   }
   {
@@ -1107,6 +1116,7 @@ extern "C" int asr_sensevoice_create(const asr_sensevoice_config* cfg, const voi
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       if (const char* e = getenv("ASR_SANM_FUSED")) s->use_fused = !(e[0] == '0');
       if (const char* e = getenv("ASR_SANM_BLOCK")) s->use_block = !(e[0] == '0');
+      if (const char* e = getenv("ASR_FBANK_SPLIT")) s->use_fbank_split = !(e[0] == '0');
       if (const char* e = getenv("ASR_SANM_BLOCK_SCATTER")) s->block_scatter = e[0] == '1';
       if (const char* e = getenv("ASR_SANM_BLOCK_DBG")) s->block_dbg = atoi(e);
       if (const char* e = getenv("ASR_SANM_BLOCK_MIN")) s->block_min_utts = atoi(e);
@@ -1167,6 +1177,7 @@ extern "C" int asr_paraformer_create(const asr_paraformer_config* cfg, const voi
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       if (const char* e = getenv("ASR_SANM_FUSED")) s->use_fused = !(e[0] == '0');
       if (const char* e = getenv("ASR_SANM_BLOCK")) s->use_block = !(e[0] == '0');
+      if (const char* e = getenv("ASR_FBANK_SPLIT")) s->use_fbank_split = !(e[0] == '0');
       if (const char* e = getenv("ASR_SANM_BLOCK_SCATTER")) s->block_scatter = e[0] == '1';
       if (const char* e = getenv("ASR_SANM_BLOCK_DBG")) s->block_dbg = atoi(e);
       if (const char* e = getenv("ASR_SANM_BLOCK_MIN")) s->block_min_utts = atoi(e);

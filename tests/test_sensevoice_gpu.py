@@ -325,3 +325,33 @@ def test_block_kernel_equals_separate_launches_ragged(monkeypatch, scatter):
     assert same / total > 0.97
     (ra, Ta), (rb, _) = rows[0], rows[9]
     assert np.array_equal(out["1"][2][ra:ra + Ta], out["1"][2][rb:rb + Ta])
+
+
+def test_split_operand_dft_of_bf16_sessions_matches_the_golden_mel(monkeypatch):
+    """bf16 sessions run the front-end's DFT on the bf16 matrix pipe with split operands (audio = hi + lo, basis = hi + mid + lo,
+    csrc/kernels.hip: fbank_split_kernel). Its log-mel must meet the SAME 2e-4 bar against the reference-minted golden as the exact-f32
+    path, and stay close to the exact path on a clip with 66 dB between a loud low tone and a quiet high one (the case where a
+    truncated basis would leak)."""
+    g = load_golden("sensevoice_small")
+    cfg, ck, sess = _session("sensevoice_small", BF16)
+    cases = [c for _, c in golden_cases(g)]
+    audios = [kaldi_audio(c["audio_seed"], c["n_samples"]) for c in cases]
+    t = np.arange(128000) / 16000.0
+    tone = np.round(12000 * np.sin(2 * np.pi * 180 * t) + 6 * np.sin(2 * np.pi * 6500 * t) + np.random.default_rng(0).normal(0, 1.5, t.size)).astype(np.float32)
+    sess.taps(True)
+    sess.run(audios + [tone], [int(c["lang"]) for c in cases] + [0])
+    mel = sess.tap("mel").copy()
+    f_off = 0
+    for c in cases:
+        nf = cfg.n_frames(int(c["n_samples"]))
+        ref = c["mel"]
+        got = mel[f_off:f_off + nf] if ref.shape[0] == nf else mel[f_off:f_off + nf][::8]
+        assert np.abs(got - ref).max() < 2e-4
+        f_off += nf
+    monkeypatch.setenv("ASR_FBANK_SPLIT", "0")
+    _, _, exact = _session("sensevoice_small", BF16)
+    exact.taps(True)
+    exact.run(audios + [tone], [int(c["lang"]) for c in cases] + [0])
+    mel0 = exact.tap("mel")
+    assert np.abs(mel - mel0)[:f_off].max() < 1e-4
+    assert np.abs(mel - mel0)[f_off:].max() < 1e-3            # the 66 dB clip: measured 2.3e-4 (both paths round f32 partial sums of the loud tone)

@@ -54,6 +54,10 @@ struct GemmArgs {
   // tiled path, split-K across workgroups (set by the launcher for small grids with long K): grid.y = k_splits, every split writes its f32
   // partial product to sk_ws[split][M][N]; a second launch sums the partials in split order and runs the epilogue -- deterministic
   int k_splits = 0;
+  // split-K second pass only, N == 1024 (one output row per 256-thread workgroup of the reduce launch): the finished f32 row is also RMS-normalised
+  // (affine-free: rsqrt(mean(x^2) + rms_eps)) and stored as the operand rows of the NEXT GEMM -- the stand-alone RMSNorm launch between a
+  // residual-producing projection and the projection that consumes its norm disappears. Ask gemm_reduce_can_norm() first.
+  void* rms_out = nullptr; int ld_rms_out = 0; float rms_eps = 1e-6f;
   const int32_t* m_dev = nullptr;
   int group_m = 0;   // (set by the launcher) row tiles walked per column tile before moving on: keeps wide weight matrices L2-resident
   int dbg = 0;   // tuning ablations (bench hook only): 1 = no refills, 2 = no MFMA, 4 = no epilogue
@@ -61,6 +65,7 @@ struct GemmArgs {
 
 // operand dtype selects the kernel: bf16 MFMA (performance mode) or exact-f32 MFMA (verification mode)
 void launch_gemm_bf16(const GemmArgs& g, hipStream_t s);
+bool gemm_reduce_can_norm(const GemmArgs& g);     // true when launch_gemm_bf16(g) takes the tiled split-K pass whose reduce launch can also write rms_out
 void launch_gemm_f32(const GemmArgs& g, hipStream_t s);
 bool gemm_ln_fusable(const GemmArgs& g);   // true when launch_gemm_bf16 would accept g with ln_colsum set
 void gemm_set_variant(int v);   // tuning hook: -1 = built-in heuristic

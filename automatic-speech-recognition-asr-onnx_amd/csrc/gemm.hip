@@ -1303,6 +1303,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g, co
   if (g.add2) { const float4 q = *reinterpret_cast<const float4*>(g.add2 + (size_t)m * g.ld_add2 + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
   if (g.out_f32) store4<float>(g.out_f32 + (size_t)m * g.ld_out_f32 + n, v.x, v.y, v.z, v.w);
   if (g.out_lo) store4<LoT>(reinterpret_cast<LoT*>(g.out_lo) + (size_t)m * g.ld_out_lo + n, v.x, v.y, v.z, v.w);
+  if (g.rms_out) {                               // N == 1024: this workgroup holds exactly row m; sum(x^2) over its 256 threads in a fixed order
+    __shared__ float rs[4];
+    float ss = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) rs[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float r = rsqrtf(((rs[0] + rs[1]) + (rs[2] + rs[3])) / (float)g.N + g.rms_eps);
+    store4<LoT>(reinterpret_cast<LoT*>(g.rms_out) + (size_t)m * g.ld_rms_out + n, v.x * r, v.y * r, v.z * r, v.w * r);
+  }
   if (g.st_out) {                                // (sum, sum of squares) of the bf16-rounded values per 32-column group = 8 consecutive threads
     const uint32_t p0 = pack_bf16x2(v.x, v.y), p1 = pack_bf16x2(v.z, v.w);
     const float a = __uint_as_float(p0 << 16), b = __uint_as_float(p0 & 0xffff0000u), c = __uint_as_float(p1 << 16), d = __uint_as_float(p1 & 0xffff0000u);
@@ -1559,7 +1568,19 @@ bool gemm_ln_fusable(const GemmArgs& g) {
   return g_gemm_variant < 0 && t144_enabled() && g.M > 64 && g.ln_dim > 0 && g.K == (g.ln_dim + 63) / 64 * 64 && t144_geom_ok(g);
 }
 
+// mirrors the routing of launch_gemm_bf16 (conservatively: "false" only costs the caller a stand-alone RMSNorm launch)
+bool gemm_reduce_can_norm(const GemmArgs& g) {
+  if (g.N != 1024 || g_gemm_variant >= 0 || g.ln_x || g.a_rms_eps != 0.0f || g.ln_colsum || g.amax_val || g.out_t || g.lo_group) return false;
+  const bool needs_skinny = !g.sk_ws;
+  if (g.M <= 64 && (needs_skinny || g.M <= genv().skinny_max_plain) && g.K % (32 * SK_WAVES) == 0) return false;
+  if (genv().skinny144 && g.M <= 144 && g.sk_ws && !g.st_out && g.K % (32 * SK_WAVES) == 0 && (g.lda * 2) % 16 == 0) return false;
+  int st = 0;
+  if (big_fits(g) || (t144_enabled() && t144_fits(g, &st))) return false;
+  return tiled_splits(g) > 1;
+}
+
 void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
+  if (g.rms_out) ASR_REQUIRE(gemm_reduce_can_norm(g), "gemm: rms_out is written by the split-K reduce launch only (check gemm_reduce_can_norm first; M = %d, N = %d, K = %d)", g.M, g.N, g.K);
   if (g.ln_x) ASR_REQUIRE(g.M <= 32 && !g.A, "gemm: the fused LayerNorm prologue exists on the skinny path for M <= 32 only");
   // 33..64 rows against a vocabulary-sized N: the 128 x 128 tiles re-read the activations 8 x less often than 16-column granules do
   // (lm_head 64 x 151936 x 1024: 76 us vs 240 us)
@@ -1599,7 +1620,9 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
     if (big_fits(g) && launch_big(g, s)) return;
     if (t144_enabled() && t144_fits(g, &st) && (st == 4 ? launch_t144<4>(g, s) : launch_t144<2>(g, s))) return;
     if (const int sp = tiled_splits(g); sp > 1) {
+      ASR_REQUIRE(!g.rms_out || g.N == 1024, "gemm: rms_out needs N == 1024 (one row per reduce workgroup)");
       GemmArgs p = g;                                    // pass 1: raw f32 partials, no epilogue terms
+      p.rms_out = nullptr;
       p.bias = nullptr; p.add = nullptr; p.add2 = nullptr; p.act = ACT_NONE; p.out_lo = nullptr;
       p.out_f32 = g.sk_ws; p.ld_out_f32 = g.N; p.k_splits = sp; p.st_out = nullptr;
       const bool deep_sk = genv().deep;

@@ -759,10 +759,21 @@ void QwSession::decoder_pass(const DecPass& P) {
   // rows (bf16 copy written by the producing GEMM), sums x^2 from the fragments it streams anyway and scales its output rows
   const bool rms_in_gemm = P.step && bf && rows <= 64 && d % 256 == 0 && !no_fuse;
   const bool fused_attn = P.step && (G == 1 || G == 2 || G == 4) && !no_fuse;
+  const bool norm_in_reduce = bf && !rms_in_gemm && !no_fuse && d == 1024;
+  auto can_norm = [&](const GemmArgs& g0) {           // (the session's gemm() adds the split-K workspace: ask with it in place)
+    if (!d_skws.ptr) { d_skws.reserve((size_t)16 << 20, stream); d_skcnt.reserve(4096 * 4, stream); }
+    GemmArgs g = g0;
+    g.sk_ws = d_skws.as<float>(); g.sk_ws_bytes = d_skws.cap; g.sk_cnt = d_skcnt.as<int32_t>();
+    return gemm_reduce_can_norm(g);
+  };
   T* xlo = d_xlo.as<T>();
   T* x2lo = d_x2lo.as<T>();
+  // 65+ rows (beam search, prefill of short prompts): o_proj / down_proj take the tiled split-K pass; its reduce launch then also writes
+  // RMSNorm(row) as the operand rows of the next projection (GemmArgs.rms_out), so the stand-alone RMSNorm launches disappear
+  bool h_is_norm = false;                     // `h` already holds RMSNorm of the stream the next normed_gemm will ask for
   auto normed_gemm = [&](const float* src, const T* src_lo, GemmArgs& g) {          // g = RMSNorm(src) W^T
     if (rms_in_gemm) { g.A = src_lo; g.lda = d; g.a_rms_eps = c.rms_eps; }
+    else if (h_is_norm) { g.A = h; g.lda = d; h_is_norm = false; }
     else {
       ProfScope ps(prof, "dec_norm", stream);
       hipLaunchKernelGGL(qw_rmsnorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, stream, src, d, rows, d, (const float*)nullptr, c.rms_eps, h, d, (const int32_t*)nullptr);
@@ -816,6 +827,7 @@ void QwSession::decoder_pass(const DecPass& P) {
       GemmArgs g; g.A = ctx; g.lda = H * hd; g.W = L.wo; g.ldw = H * hd; g.M = rows; g.N = d; g.K = H * hd; g.add = x; g.ld_add = d;
       g.out_f32 = x2; g.ld_out_f32 = d;
       if (rms_in_gemm) { g.out_lo = x2lo; g.ld_out_lo = d; }
+      else if (norm_in_reduce && can_norm(g)) { g.rms_out = h; g.ld_rms_out = d; g.rms_eps = c.rms_eps; h_is_norm = true; }
       gemm(g); }
     // gate|up rows are interleaved in the arena: the epilogue stores silu(gate) * up directly (:1322-1325)
     { GemmArgs g; g.W = L.gate_up; g.ldw = d; g.M = rows; g.N = 2 * I; g.K = d; g.act = ACT_SWIGLU; g.out_lo = act; g.ld_out_lo = I; normed_gemm(x2, x2lo, g); }
@@ -823,6 +835,7 @@ void QwSession::decoder_pass(const DecPass& P) {
       GemmArgs g2; g2.A = act; g2.lda = I; g2.W = L.down; g2.ldw = I; g2.M = rows; g2.N = d; g2.K = I; g2.add = x2; g2.ld_add = d;
       g2.out_f32 = x; g2.ld_out_f32 = d;
       if (rms_in_gemm) { g2.out_lo = xlo; g2.ld_out_lo = d; }
+      else if (norm_in_reduce && i + 1 < c.n_layers && can_norm(g2)) { g2.rms_out = h; g2.ld_rms_out = d; g2.rms_eps = c.rms_eps; h_is_norm = true; }
       gemm(g2); }
   }
   logits_head<T>(P);

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void qw_decode_attn_kernel(const float* __rest
                                                              T* __restrict__ ctx, const int32_t* __restrict__ src = nullptr, int ld_src = 0,
                                                              const int32_t* __restrict__ p0 = nullptr, const T* __restrict__ kc_p = nullptr,
                                                              const T* __restrict__ vc_p = nullptr, int S_p = 0, int beam = 1) {
-  constexpr int HD = 128, KPI = 4, NTASK = (2 + G + 3) / 4;
+  constexpr int HD = 128, KPI = BEAM ? 2 : 4, NTASK = (2 + G + 3) / 4;     // (beam search: 5 x the workgroups -- fewer rows in flight per wave, 128 registers, four workgroups per CU instead of three)
   __shared__ float qsh[G][HD];
   __shared__ float knew[HD], vnew[HD];
   __shared__ float pm[16][G], pl[16][G];

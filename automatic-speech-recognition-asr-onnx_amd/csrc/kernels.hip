@@ -1686,12 +1686,21 @@ __global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a
       Qs[q][c] = Elem<T>::load(qq + (size_t)(row0 + q0 + q) * a.ld_q + a.q_col0 + h * SA_HD + c);
     }
     __syncthreads();
-    for (int e = tid; e < nq * nk; e += 256) {
-      const int q = e / nk, k = e - q * nk;
-      float sc = 0.0f;
+    {   // scores: thread = (key, query group); the key row is read once and serves four queries (independent FMA chains, each in the
+        // original c order -- bit-identical to one chain per (query, key))
+      const int k = tid & 63, qg = tid >> 6;
+      if (k < nk) {
+        float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 8
-      for (int c = 0; c < SA_HD; ++c) sc = fmaf(Qs[q][c], Ks[k][c], sc);
-      Ps[q][k] = sc;
+        for (int c = 0; c < SA_HD; ++c) {
+          const float kv = Ks[k][c];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s4[j] = fmaf(Qs[qg + 4 * j][c], kv, s4[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (qg + 4 * j < nq) Ps[qg + 4 * j][k] = s4[j];
+      }
     }
     __syncthreads();
     for (int q = wave; q < nq; q += 4) {                 // nk <= 64: one lane per key
@@ -1702,23 +1711,39 @@ __global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a
       if (lane < nk) Ps[q][lane] = ex / sum;
     }
     __syncthreads();
-    for (int e = tid; e < nq * SA_HD; e += 256) {
-      const int q = e >> 7, c = e & 127;
-      float acc = 0.0f;
-      for (int p = 0; p < nk; ++p) acc = fmaf(Ps[q][p], Vs[p][c], acc);
-      Elem<T>::store(out + (size_t)(row0 + q0 + q) * a.ld_ctx + h * SA_HD + c, acc);
+    {   // context: thread = (channel, query parity); one V read serves eight queries
+      const int c = tid & 127, qh = tid >> 7;
+      float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+      for (int p = 0; p < nk; ++p) {
+        const float v = Vs[p][c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(Ps[qh + 2 * j][p], v, acc[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int q = qh + 2 * j;
+        if (q < nq) Elem<T>::store(out + (size_t)(row0 + q0 + q) * a.ld_ctx + h * SA_HD + c, acc[j]);
+      }
     }
   }
   if (a.mem) {                                           // FSMN memory term of the 16-row slot (rows >= n_cur are zero), channels of this head
     const int pad = (a.ktaps - 1) / 2;
-    for (int e = tid; e < 16 * SA_HD; e += 256) {
-      const int t = e >> 7, c = e & 127, hc = h * SA_HD + c;
+    const int c = tid & 127, hc = h * SA_HD + c;        // (256 % 128 == 0: a thread keeps its channel, its taps are loaded once)
+    float wc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) wc[j] = j < a.ktaps ? a.fsmn_w[hc * a.ktaps + j] : 0.0f;
+    const float bc = a.fsmn_b[hc];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = (tid >> 7) + 2 * i;
       float acc = 0.0f;
       if (t < a.n_cur) {
-        acc = a.fsmn_b[hc];
-        for (int j = 0; j < a.ktaps; ++j) {
+        acc = bc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
           const int tt = t + j - pad;
-          if (tt >= 0 && tt < a.n_cur) acc = fmaf(a.fsmn_w[hc * a.ktaps + j], Vs[len + tt][c], acc);
+          if (j < a.ktaps && tt >= 0 && tt < a.n_cur) acc = fmaf(wc[j], Vs[len + tt][c], acc);
         }
       }
       a.mem[(size_t)(row0 + t) * a.d + hc] = acc;

@@ -221,8 +221,7 @@ bool decode_gemm_supported(const DecGemmArgs& g) {
 // grid shape: column granules of 16 NT, K split across `splits` workgroups -- at most one even round of the chip's CUs
 void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits) {
   const int cus = 256;
-  int NT = (g.N / 16 > cus && g.M <= 32) ? 2 : 1;      // (two column tiles x four row tiles would need 8+ finishing waves and 128 accumulator registers)
-  if (g.M > 32) NT = 1;
+  int NT = g.N / 16 > cus ? 2 : 1;                      // 32-column granules where 16-column ones would overflow the chip (33..64 rows: 4 x 2 output tiles = the 8 finishing waves)
   int granules = g.N / (16 * NT), best = 1;
   if (!g.colsum && g.ws && g.cnt) {                     // (the folded LayerNorm needs whole rows in one workgroup: K is never split there)
     for (int sp : {2, 3, 4, 5, 6, 8, 10}) {
@@ -250,7 +249,7 @@ void launch_decode_gemm(const DecGemmArgs& g, hipStream_t s) {
   decode_gemm_plan(g, &nt, &splits);
   ASR_REQUIRE(g.N % (16 * nt) == 0, "decode_gemm: N = %d", g.N);
   const int mt = g.M <= 16 ? 1 : g.M <= 32 ? 2 : 4;
-  if (nt == 2) { if (mt == 1) launch_inst<1, 2>(g, splits, s); else launch_inst<2, 2>(g, splits, s); }
+  if (nt == 2) { if (mt == 1) launch_inst<1, 2>(g, splits, s); else if (mt == 2) launch_inst<2, 2>(g, splits, s); else launch_inst<4, 2>(g, splits, s); }
   else if (mt == 1) launch_inst<1, 1>(g, splits, s);
   else if (mt == 2) launch_inst<2, 1>(g, splits, s);
   else launch_inst<4, 1>(g, splits, s);

@@ -205,6 +205,7 @@ struct SanmBlockArgs {
   unsigned* err;                                                   // err[0] != 0 after the run: a workgroup gave up waiting for its cluster
   int n_rows_alloc; float ln_eps; int scatter;                     // scatter != 0: test placement (a cluster spread over four XCDs)
   unsigned long long* times;                                       // tuning: [workgroups][16] wall-clock stamps (100 MHz) at the phase boundaries, or null
+  int fault = 0;                                                   // tests: workgroup 5 withholds its first exchange count (its cluster then gives up after the bounded spin)
 };
 bool sanm_block_supported(int max_T, int d_head, int n_heads, int d, int d_ffn, int fsmn_taps);
 int sanm_block_max_utts();                                         // windows one launch can take (all workgroups co-resident)

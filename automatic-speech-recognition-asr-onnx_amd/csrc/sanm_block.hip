@@ -67,10 +67,10 @@ __device__ __forceinline__ void store8_wt(void* p, float2 v) {
 }
 
 // count this workgroup in on an exchange flag: every wave's stores drained, then one relaxed agent-scope add
-__device__ __forceinline__ void publish(unsigned* flag) {
+__device__ __forceinline__ void publish(unsigned* flag, bool withhold = false) {     // withhold: fault injection (tests), the count never arrives
   wait_vm<0>();
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0 && !withhold) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // wait until all `need` workgroups of the cluster are in; ONE acquire (drops this CU's stale L1 lines), then ordinary loads
 __device__ __forceinline__ void consume(unsigned* flag, unsigned need, unsigned* err) {
@@ -79,6 +79,7 @@ __device__ __forceinline__ void consume(unsigned* flag, unsigned need, unsigned*
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
       __builtin_amdgcn_s_sleep(2);
       if (++spins > (1u << 21)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // ~0.5 s: give up, never hang
+      if ((spins & 4095u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;          // somebody already gave up: the launch is void anyway
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(NT) void sanm_block_kernel(const SanmBlockArgs a_by
         store16_wt<ABL>(cg_ + (size_t)row * D + ch * 8, v);
       }
     }
-    publish(flags + 0);
+    publish(flags + 0, a->fault != 0 && blockIdx.x == 5);
     STAMP(3);
     // the residual rows of this workgroup's slab depend on nobody else: request them now, they arrive under the FSMN / the exchange wait
 #pragma unroll

@@ -87,6 +87,8 @@ struct SvSession : asr_session {
   bool use_block = true;        // one launch per SANM block (clusters of four workgroups per window; ASR_SANM_BLOCK=0 disables)
   bool use_fbank_split = true;  // ASR_FBANK_SPLIT=0: exact-f32 MFMA DFT in bf16 sessions too
   DeviceBuffer d_dft_split;
+  int block_fault = 0;          // ASR_SANM_BLOCK_FAULT=1 (tests): one workgroup of the first block launch withholds an exchange count
+  int block_giveups = 0;        // forward passes redone on the four-launch path because a cluster gave up (see run())
   int block_scatter = 0;        // ASR_SANM_BLOCK_SCATTER=1: test placement, every cluster spread over four XCDs
   int block_min_utts = 48;      // ASR_SANM_BLOCK_MIN=<windows>: smallest batch that takes the block kernel
   DeviceBuffer d_times; int block_dbg = -1;   // ASR_SANM_BLOCK_DBG=<block index>: phase clock of that block's launch on stderr
@@ -310,7 +312,7 @@ void SvSession::enqueue(const SvRunCtx& r) {
           ba.ctx = (bf16_t*)ctx; ba.x1_lo = xblo; ba.st1 = stb; ba.hid = (bf16_t*)ffn;
           ba.plan = r.dp; ba.utt0 = u0; ba.n_utts = std::min(per, r.batch - u0);
           ba.flags = d_flags.as<unsigned>() + ((size_t)i * r.batch + u0) * 4; ba.err = d_flags.as<unsigned>() + flag_words;
-          ba.n_rows_alloc = Mpad; ba.ln_eps = 1e-5f; ba.scatter = block_scatter;
+          ba.n_rows_alloc = Mpad; ba.ln_eps = 1e-5f; ba.scatter = block_scatter; ba.fault = (block_fault && i == 1) ? 1 : 0;
           if (i == block_dbg && u0 == 0) { d_times.reserve(256 * 16 * 8, stream); HIP_CHECK(hipMemsetAsync(d_times.ptr, 0, 256 * 16 * 8, stream)); ba.times = d_times.as<unsigned long long>(); }
           launch_sanm_block(ba, stream);
         }
@@ -745,8 +747,20 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
     }
   }
   {
+    // The four workgroups of a cluster must be resident together. That holds when the launch has the chip to itself; when another stream's
+    // kernels hold CUs (several sessions in flight) a cluster can be split across dispatch waves and, in the worst case, wait in a circle
+    // with another session's clusters until the bounded spin gives up. Such a forward pass is void: it is redone here on the four-launch
+    // path (no cross-workgroup waits), still on the GPU; the error is raised only if that fails too.
     unsigned blk_err = 0;
     memcpy(&blk_err, (unsigned char*)h_out + (size_t)batch * max_tokens * 4 + (size_t)batch * 4, 4);
+    if (blk_err != 0 && use_block) {
+      if (block_giveups++ == 0)
+        fprintf(stderr, "[asr_mi355x] sanm_block: a workgroup gave up waiting for its cluster; the batch is redone on the four-launch path\n");
+      use_block = false;
+      try { enqueue<T>(r); HIP_CHECK(hipStreamSynchronize(stream)); } catch (...) { use_block = true; throw; }
+      use_block = true;
+      memcpy(&blk_err, (unsigned char*)h_out + (size_t)batch * max_tokens * 4 + (size_t)batch * 4, 4);
+    }
     ASR_REQUIRE(blk_err == 0, "sensevoice: a SANM block workgroup gave up waiting for its cluster (results are invalid)");
   }
   memcpy(num_out, (unsigned char*)h_out + (size_t)batch * max_tokens * 4, (size_t)batch * 4);
@@ -1118,6 +1132,7 @@ extern "C" int asr_sensevoice_create(const asr_sensevoice_config* cfg, const voi
       if (const char* e = getenv("ASR_SANM_BLOCK")) s->use_block = !(e[0] == '0');
       if (const char* e = getenv("ASR_FBANK_SPLIT")) s->use_fbank_split = !(e[0] == '0');
       if (const char* e = getenv("ASR_SANM_BLOCK_SCATTER")) s->block_scatter = e[0] == '1';
+      if (const char* e = getenv("ASR_SANM_BLOCK_FAULT")) s->block_fault = e[0] == '1';
       if (const char* e = getenv("ASR_SANM_BLOCK_DBG")) s->block_dbg = atoi(e);
       if (const char* e = getenv("ASR_SANM_BLOCK_MIN")) s->block_min_utts = atoi(e);
       if (const char* e = getenv("ASR_LN_FUSED")) s->use_ln_alg = !(e[0] == '0');
@@ -1179,6 +1194,7 @@ extern "C" int asr_paraformer_create(const asr_paraformer_config* cfg, const voi
       if (const char* e = getenv("ASR_SANM_BLOCK")) s->use_block = !(e[0] == '0');
       if (const char* e = getenv("ASR_FBANK_SPLIT")) s->use_fbank_split = !(e[0] == '0');
       if (const char* e = getenv("ASR_SANM_BLOCK_SCATTER")) s->block_scatter = e[0] == '1';
+      if (const char* e = getenv("ASR_SANM_BLOCK_FAULT")) s->block_fault = e[0] == '1';
       if (const char* e = getenv("ASR_SANM_BLOCK_DBG")) s->block_dbg = atoi(e);
       if (const char* e = getenv("ASR_SANM_BLOCK_MIN")) s->block_min_utts = atoi(e);
       if (const char* e = getenv("ASR_LN_FUSED")) s->use_ln_alg = !(e[0] == '0');

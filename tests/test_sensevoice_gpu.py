@@ -355,3 +355,28 @@ def test_split_operand_dft_of_bf16_sessions_matches_the_golden_mel(monkeypatch):
     mel0 = exact.tap("mel")
     assert np.abs(mel - mel0)[:f_off].max() < 1e-4
     assert np.abs(mel - mel0)[f_off:].max() < 1e-3            # the 66 dB clip: measured 2.3e-4 (both paths round f32 partial sums of the loud tone)
+
+
+def test_a_cluster_that_gives_up_is_redone_on_the_four_launch_path(monkeypatch, capfd):
+    """The block kernel's clusters need their four workgroups resident together; when that fails (other streams holding CUs) the bounded
+    spin gives up and raises the launch's error word. ASR_SANM_BLOCK_FAULT=1 makes one workgroup withhold an exchange count: the forward
+    pass must then come back with the tokens of the four-launch path (same GPU, no cross-workgroup waits), say so once on stderr, and a
+    later batch on the same session must work again."""
+    cfg, ck = sensevoice_setup("sensevoice_small")
+    eng = sub("engine")
+    B = 64
+    audios = [kaldi_audio(6600 + i, 128000) for i in range(B)]
+    langs = [0] * B
+    monkeypatch.setenv("ASR_SANM_BLOCK", "0")
+    ref = eng.SenseVoiceSession.from_checkpoint(cfg, ck, precision=BF16).run(audios, langs)
+    monkeypatch.delenv("ASR_SANM_BLOCK")
+    monkeypatch.setenv("ASR_SANM_BLOCK_FAULT", "1")
+    sess = eng.SenseVoiceSession.from_checkpoint(cfg, ck, precision=BF16)
+    capfd.readouterr()
+    got = sess.run(audios, langs)
+    err = capfd.readouterr().err
+    assert "redone on the four-launch path" in err
+    assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+    again = sess.run(audios, langs)                       # the message appears once per session; the retry happens every time
+    assert all(np.array_equal(a, b) for a, b in zip(again, ref))
+    assert "redone" not in capfd.readouterr().err

@@ -384,7 +384,7 @@ def main():
 def secondary_lines(cfg, ck, audio_np, local_rank, device):
     """The other two figures BASELINE.json's metric names, measured in the same driver-run process (secondary keys, never `value`):
     configs[0] SenseVoiceSmall f32 mode, one 8 s chunk (the mode whose tokens equal the reference's) and Whisper-large-v3 bf16 on 8 s
-    chunks at batch 32 and 64 (encoder + prefill + 31 greedy decode steps; random weights never emit EOS)."""
+    chunks at batch 1, 32 and 64 (encoder + prefill + 31 greedy decode steps; random weights never emit EOS)."""
     import torch
     ckm = importlib.import_module(PKG + ".checkpoints")
     cfgm = importlib.import_module(PKG + ".config")
@@ -424,7 +424,7 @@ def secondary_lines(cfg, ck, audio_np, local_rank, device):
         del blob
         ws = eng.WhisperSession(wcfg, a_dev, arena.PRECISION_BF16, local_rank, arena_device_ptr=a_dev.data_ptr(), arena_bytes=a_dev.numel())
         n_tok = 32
-        for Bw in (32, 64):
+        for Bw in (1, 32, 64):                               # BASELINE's target points are batch 1 and batch 64; 32 is configs[2]'s batch
             wav = torch.from_numpy(ckm.synth_audio("unit", Bw, n_samples, seed=4321)).to(device)
             offs = np.arange(Bw + 1, dtype=np.int64) * n_samples
             prompt = np.tile(np.array([[wcfg.sot_id, wcfg.first_language_id, wcfg.transcribe_id, wcfg.no_timestamps_id]], np.int32), (Bw, 1))
@@ -680,7 +680,7 @@ def whisper_algorithmic(cfg, n_samples, B, n_tokens, prompt_len, fp8=False):
 
 def main_whisper(args):
     """Whisper-large-v3 bf16: encoder + fused cross-KV once per batch, then prefill(4-token prompt) + greedy decode of a
-    FIXED number of tokens (random weights never emit EOS; SURVEY.md section 8d: 4 tokens per audio second)."""
+    FIXED number of tokens (random weights never emit EOS; SURVEY.md section 8d: 32 tokens per 8 s chunk, 128 per 30 s)."""
     import torch
     import torch.distributed as dist
     cfgm = importlib.import_module(PKG + ".config")
@@ -695,7 +695,7 @@ def main_whisper(args):
     cfg = cfgm.whisper_large_v3()
     B = args.batch
     n_samples = int(args.seconds * cfg.sample_rate)
-    n_tok = args.decode_tokens or int(round(4 * args.seconds))
+    n_tok = args.decode_tokens or 32 * int(np.ceil(args.seconds / 8.0))        # 32 tokens per 8 s chunk, 128 per 30 s
     blob = ck = None
     if rank == 0:
         ck = ckm.synth_whisper_checkpoint(cfg, seed=0)
@@ -843,7 +843,7 @@ def main_whisper(args):
 
 def main_qwen(args):
     """Qwen3-ASR-0.6B bf16 greedy: one prefill launch (log-mel + conv stem + windowed encoder + prompt assembly + decoder prefill) and a
-    FIXED number of decode steps (random weights never emit a stop id; SURVEY.md section 8d: 4 tokens per audio second)."""
+    FIXED number of decode steps (random weights never emit a stop id; SURVEY.md section 8d: 32 tokens per 8 s chunk, 128 per 30 s)."""
     import torch
     import torch.distributed as dist
     cfgm = importlib.import_module(PKG + ".config")
@@ -858,7 +858,7 @@ def main_qwen(args):
     cfg = cfgm.qwen_asr_0p6b()
     B = args.batch
     n_samples = int(args.seconds * cfg.sample_rate)
-    n_tok = args.decode_tokens or int(round(4 * args.seconds))
+    n_tok = args.decode_tokens or 32 * int(np.ceil(args.seconds / 8.0))        # 32 tokens per 8 s chunk, 128 per 30 s
     blob = ck = None
     if rank == 0:
         ck = ckm.synth_qwen_asr_checkpoint(cfg, seed=0)
@@ -1021,7 +1021,7 @@ def main_mixed(args):
     # ---- Qwen3-ASR batch path
     qcfg = cfgm.qwen_asr_0p6b()
     B, n_samples = args.batch, int(args.seconds * qcfg.sample_rate)
-    n_tok = args.decode_tokens or int(round(4 * args.seconds))
+    n_tok = args.decode_tokens or 32 * int(np.ceil(args.seconds / 8.0))        # 32 tokens per 8 s chunk, 128 per 30 s
     blob = None
     if rank == 0:
         blob = arena.build_qwen_asr_arena(qcfg, ckm.synth_qwen_asr_checkpoint(qcfg, seed=0), arena.PRECISION_BF16)

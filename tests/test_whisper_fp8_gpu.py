@@ -59,7 +59,8 @@ def test_row_quantiser_is_ocp_e4m3_with_power_of_two_scales():
     assert np.array_equal(dq, t8.to(torch.float32).numpy() * sc[:, None])     # and the dequantisation is exact in bf16
 
 
-@pytest.mark.parametrize("M,N,K,fold", [(32, 768, 256, True), (7, 256, 1024, False), (64, 1280, 1280, True), (32, 1280, 5120, False)])
+@pytest.mark.parametrize("M,N,K,fold", [(32, 768, 256, True), (7, 256, 1024, False), (64, 1280, 1280, True), (32, 1280, 5120, False),
+                                         (64, 5120, 1280, True), (48, 5120, 1280, False), (32, 5120, 1280, True), (16, 3840, 1280, True)])
 def test_byte_weight_decode_gemm_equals_the_bf16_kernel_over_dequantised_weights(M, N, K, fold):
     probe = sub("_probe")
     rng = np.random.default_rng(M + N + K)
@@ -69,7 +70,7 @@ def test_byte_weight_decode_gemm_equals_the_bf16_kernel_over_dequantised_weights
     q, sc, dq = probe.quantize_fp8(w)
     byte_path = probe.decode_gemm(a, w=dq, w8=q, scale=sc, bias=bias, fold=fold)
     bf16_path = probe.decode_gemm(a, w=dq, bias=bias, fold=fold)
-    assert np.array_equal(byte_path, bf16_path)              # bit for bit (incl. the split-K hand-over of the K = 5120 case)
+    assert np.array_equal(byte_path, bf16_path)              # bit for bit (incl. the split-K hand-over of the K = 5120 case and the 4 x 2 / 2 x 2 tile instances of N = 5120)
     ab = probe._bf16_to_f32(probe._bf16_bits(a)).astype(np.float64)
     if fold:
         mu, var = ab.mean(1, keepdims=True), ab.var(1, keepdims=True)

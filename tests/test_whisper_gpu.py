@@ -288,3 +288,36 @@ def test_large_v3_bf16_batch32x30s_vs_golden_and_oracle():
     ref = orc.greedy([audios[1]], [prompt.tolist()], 2)
     for s in range(2):
         assert np.abs(got[1][s] - ref["logits"][0][s]).max() < 2e-3 * max(scale, 50.0)
+
+
+def test_large_v3_bf16_batch64x8s_vs_golden_and_oracle():
+    """The north-star's batch-64 point: Whisper-large-v3 bf16, 64 x 8 s in one batch, prefill + 3 decode steps. 64 decoder rows take the
+    four-row-tile instances of the decode GEMM (4 x 1 and 4 x 2 tiles, LayerNorm folded in) and the tiled split-K pass for fc2 -- no smaller
+    batch dispatches them. Slot 0 (duplicated in slot 63) is the 8 s clip of the reference-minted golden; slot 1 is checked against the
+    f32 oracle run here; the duplicate must match bit for bit."""
+    g = load_golden("whisper_large_v3")
+    cfg, ck, sup, beg, sess = _session("whisper_large_v3", BF16)
+    c1 = [c for _, c in golden_cases(g)][1]
+    assert int(c1["n_samples"]) == 128000
+    B, n_new = 64, int(g["n_new"])
+    audios = [unit_audio(9500 + i, 128000) for i in range(B)]
+    audios[0] = unit_audio(c1["audio_seed"], c1["n_samples"])
+    audios[63] = audios[0].copy()
+    prompt = c1["prompt"]
+    prompts = np.tile(prompt[None], (B, 1))
+    npos = sess.encode(audios)
+    assert all(int(t) == 400 for t in npos)
+    nxt, logits = sess.prefill(prompts)
+    steps = [logits]
+    for _ in range(n_new - 1):
+        nxt, logits = sess.decode(None, want_logits=True)
+        steps.append(logits)
+    got = np.stack(steps, 1)                                        # (B, n_new, V)
+    assert np.array_equal(got[0], got[63])
+    scale = max(float(np.abs(c1["top1"]).max()), 50.0)
+    assert np.abs(got[0][:, ::53] - c1["logits"]).max() < 2e-3 * scale
+    assert np.abs(np.sort(got[0], axis=1)[:, -1] - c1["top1"]).max() < 2e-3 * scale
+    orc = WhisperOracle(cfg, ck, sup, beg)
+    ref = orc.greedy([audios[1]], [prompt.tolist()], 2)
+    for s in range(2):
+        assert np.abs(got[1][s] - ref["logits"][0][s]).max() < 2e-3 * scale

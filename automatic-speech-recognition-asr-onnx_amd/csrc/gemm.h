@@ -60,6 +60,7 @@ struct GemmArgs {
   void* rms_out = nullptr; int ld_rms_out = 0; float rms_eps = 1e-6f;
   const int32_t* m_dev = nullptr;
   int group_m = 0;   // (set by the launcher) row tiles walked per column tile before moving on: keeps wide weight matrices L2-resident
+  uint32_t* dbg_clk = nullptr;   // ping-pong kernel, timed instance (bench hook): per-phase segment clocks of two waves of workgroup 0
   int dbg = 0;   // tuning ablations (bench hook only): 1 = no refills, 2 = no MFMA, 4 = no epilogue
 };
 
@@ -67,6 +68,10 @@ struct GemmArgs {
 void launch_gemm_bf16(const GemmArgs& g, hipStream_t s);
 bool gemm_reduce_can_norm(const GemmArgs& g);     // true when launch_gemm_bf16(g) takes the tiled split-K pass whose reduce launch can also write rms_out
 void launch_gemm_f32(const GemmArgs& g, hipStream_t s);
+// csrc/gemm_pp.hip: 256 x 256 tiles, two wave groups alternating matrix / memory segments. launch_gemm_pp returns false when the shape or the
+// epilogue has no instance (the caller then takes the other tilings).
+bool gemm_pp_supported(const GemmArgs& g);
+bool launch_gemm_pp(const GemmArgs& g, hipStream_t s, int var = 0);
 bool gemm_ln_fusable(const GemmArgs& g);   // true when launch_gemm_bf16 would accept g with ln_colsum set
 void gemm_set_variant(int v);   // tuning hook: -1 = built-in heuristic
 void gemm_reload_env();         // re-read the ASR_GEMM_* / ASR_SKINNY_* switches (called at session creation)

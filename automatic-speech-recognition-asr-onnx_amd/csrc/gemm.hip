@@ -19,10 +19,11 @@
 #include <cstring>
 #include <string>
 #include "gemm.h"
+#include "gemm_dev.h"
 
 // ---- tuning / ablation switches (environment), re-read by gemm_reload_env() at every session creation so that a test can flip them in-process
 struct GemmEnv {
-  bool t144 = true, t144w = true, t288w = true, big = true, splitk = true, deep = true, skinny144 = false;
+  bool t144 = true, t144w = true, t288w = true, big = true, pp = true, splitk = true, deep = true, skinny144 = false;
   int skinny_splitk = -1, tall_min = 16, skinny_max_plain = 32;
   bool loaded = false;
 };
@@ -51,7 +52,7 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 void gemm_reload_env() {
   GemmEnv e;
   e.t144 = env_flag("ASR_GEMM_T144", true); e.t144w = env_flag("ASR_GEMM_T144W", true); e.t288w = env_flag("ASR_GEMM_T288W", true);
-  e.big = env_flag("ASR_GEMM_BIG", true); e.splitk = env_flag("ASR_GEMM_SPLITK", true); e.deep = env_flag("ASR_GEMM_DEEP", true);
+  e.big = env_flag("ASR_GEMM_BIG", true); e.pp = env_flag("ASR_GEMM_PP", true); e.splitk = env_flag("ASR_GEMM_SPLITK", true); e.deep = env_flag("ASR_GEMM_DEEP", true);
   e.skinny144 = getenv("ASR_SKINNY_M144") && getenv("ASR_SKINNY_M144")[0] == '1';
   e.skinny_splitk = env_int("ASR_SKINNY_SPLITK", -1); e.tall_min = env_int("ASR_GEMM_TALL_MIN", 16);
   e.skinny_max_plain = env_int("ASR_SKINNY_MAX_M", 32);
@@ -67,223 +68,6 @@ namespace {
 constexpr int BM = 128;
 constexpr int BK16 = 64;                       // bf16 K-step
 
-enum { E_ADD = 1, E_ADD2 = 2, E_F32 = 4, E_LO = 8, E_AMAX = 32, E_BIAS = 64, E_LN = 128, E_ST = 256 };
-
-template <int ACT>
-__device__ __forceinline__ float apply_act_ct(float v) {
-  if constexpr (ACT == ACT_RELU) return fmaxf(v, 0.0f);
-  else if constexpr (ACT == ACT_GELU_ERF) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-  else if constexpr (ACT == ACT_GELU_TANH) {
-    const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
-    return 0.5f * v * (1.0f + tanhf(u));
-  } else return v;
-}
-
-__device__ __forceinline__ float apply_act_rt(float v, int act) {
-  switch (act) {
-    case ACT_RELU: return apply_act_ct<ACT_RELU>(v);
-    case ACT_GELU_ERF: return apply_act_ct<ACT_GELU_ERF>(v);
-    case ACT_GELU_TANH: return apply_act_ct<ACT_GELU_TANH>(v);
-    default: return v;
-  }
-}
-
-// XCD-aware bijective remap (8 XCDs, block b runs on XCD b % 8): XCD x gets a contiguous tile range.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7;
-  const int xcd = bid & 7, idx = bid >> 3;
-  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + idx;
-}
-
-// Column owned by fragment j, fragment-row index fr (0..15) inside a wave's column block. Fragments are paired
-// (2p, 2p+1) and the W rows they load are permuted so that the C fragment of the pair gives every lane EIGHT
-// consecutive output columns (8 * (fr / 4) + 4 * (j & 1) + fr % 4 inside the 32-column pair): one 16-byte bf16
-// store / two adjacent 16-byte f32 stores per lane, and the four lanes of a row cover 64 / 128 contiguous bytes.
-__device__ __forceinline__ int frag_col(int j, int fr) { return (j >> 1) * 32 + ((fr >> 2) << 3) + ((j & 1) << 2) + (fr & 3); }
-// LDS slot-swizzle key of a W-tile row. A fragment's 16 permuted rows are {8a + b (+4)}: within one row parity (the two
-// 128-byte halves of the 256-byte bank row) the 8 rows must get 8 different keys => key = 2 * ((r >> 3) & 3) + ((r >> 1) & 1).
-__device__ __forceinline__ int w_swz(int r) { return (((r >> 3) & 3) << 1) | ((r >> 1) & 1); }
-
-template <int EPI, int F> __device__ __forceinline__ bool epi_has(const void* p) {
-  if constexpr (EPI < 0) return p != nullptr; else return (EPI & F) != 0;
-}
-
-template <typename OutT> __device__ __forceinline__ void store4(OutT* p, float a, float b, float c, float d);
-template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
-  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
-}
-template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
-  uint2 w;
-  w.x = pack_bf16x2(a, b);
-  w.y = pack_bf16x2(c, d);
-  *reinterpret_cast<uint2*>(p) = w;
-}
-
-// ---- swapped orientation: acc[i][j][r] = C[m_wave + 16 i + (lane & 15)][n_wave + frag_col(j, 4 (lane >> 4) + r)]
-template <typename OutT> __device__ __forceinline__ void store8(OutT* p, const float (&v)[8]);
-template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
-  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
-}
-template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
-  uint4 w;
-  w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]); w.z = pack_bf16x2(v[4], v[5]); w.w = pack_bf16x2(v[6], v[7]);
-  *reinterpret_cast<uint4*>(p) = w;
-}
-
-template <typename OutT, int ACT, int EPI, int NJ, int MI = 4>
-__device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[MI][NJ], int m_wave, int n_wave, int lane,
-                                              const float2* ln_stats = nullptr) {   // (mean, rstd) of row m_wave + i, in LDS
-  static_assert(NJ % 2 == 0, "fragments are paired");
-  const int frow = lane & 15, fgrp = lane >> 4;
-  const bool has_bias = epi_has<EPI, E_BIAS>(g.bias), has_add = epi_has<EPI, E_ADD>(g.add), has_add2 = epi_has<EPI, E_ADD2>(g.add2);
-  const bool want_f32 = epi_has<EPI, E_F32>(g.out_f32), want_lo = epi_has<EPI, E_LO>(g.out_lo);
-  if (epi_has<EPI, E_AMAX>(g.amax_val)) {
-    const int n_slabs = g.N / (NJ * 16), slab = n_wave / (NJ * 16);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      float best = -INFINITY;
-      int bidx = 0x7fffffff;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {            // (pair, half, r) ascending == ascending column inside the lane
-        const int n0 = n_wave + frag_col(j, fgrp * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[i][j][r] + (has_bias ? g.bias[n0 + r] : 0.0f);
-          if (n0 + r >= g.n_valid) v = -INFINITY;
-          if (v > best) { best = v; bidx = n0 + r; }          // first max wins
-        }
-      }
-#pragma unroll
-      for (int o = 16; o < 64; o <<= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bidx, o, 64);
-        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-      }
-      const int m = m_wave + i * 16 + frow;
-      if (fgrp == 0 && m < g.M) {
-        g.amax_val[(size_t)m * n_slabs + slab] = best;
-        g.amax_idx[(size_t)m * n_slabs + slab] = bidx;
-      }
-    }
-  }
-  if (!(want_f32 || want_lo)) return;
-#pragma unroll
-  for (int p = 0; p < NJ / 2; ++p) {
-    const int n = n_wave + p * 32 + fgrp * 8;              // this lane's 8 consecutive columns
-    float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (has_bias) {
-      const float4 lo = *reinterpret_cast<const float4*>(g.bias + n), hi = *reinterpret_cast<const float4*>(g.bias + n + 4);
-      b8[0] = lo.x; b8[1] = lo.y; b8[2] = lo.z; b8[3] = lo.w; b8[4] = hi.x; b8[5] = hi.y; b8[6] = hi.z; b8[7] = hi.w;
-    }
-    float c8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if constexpr (EPI >= 0 && (EPI & E_LN) != 0) {
-      const float4 lo = *reinterpret_cast<const float4*>(g.ln_colsum + n), hi = *reinterpret_cast<const float4*>(g.ln_colsum + n + 4);
-      c8[0] = lo.x; c8[1] = lo.y; c8[2] = lo.z; c8[3] = lo.w; c8[4] = hi.x; c8[5] = hi.y; c8[6] = hi.z; c8[7] = hi.w;
-    }
-    float4 t1[MI][2], t2[MI][2];
-    if (has_add) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {      // rows up to the 128-row tile edge are readable (padded buffers)
-        const float* q = g.add + (size_t)min(m_wave + i * 16 + frow, g.M - 1) * g.ld_add + n;
-        t1[i][0] = *reinterpret_cast<const float4*>(q);
-        t1[i][1] = *reinterpret_cast<const float4*>(q + 4);
-      }
-    }
-    if (has_add2) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int m = min(m_wave + i * 16 + frow, g.M - 1);
-        const float* q = g.add2 + (size_t)(g.add2_rows ? g.add2_rows[m] : m) * g.ld_add2 + n;
-        t2[i][0] = *reinterpret_cast<const float4*>(q);
-        t2[i][1] = *reinterpret_cast<const float4*>(q + 4);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = m_wave + i * 16 + frow;
-      float v[8];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * p][r]; v[4 + r] = acc[i][2 * p + 1][r]; }
-      if constexpr (EPI >= 0 && (EPI & E_LN) != 0) {
-        const float2 mr = ln_stats[i * 16 + frow];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (v[e] - mr.x * c8[e]) * mr.y;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += b8[e];
-      if (has_add) {
-        v[0] += t1[i][0].x; v[1] += t1[i][0].y; v[2] += t1[i][0].z; v[3] += t1[i][0].w;
-        v[4] += t1[i][1].x; v[5] += t1[i][1].y; v[6] += t1[i][1].z; v[7] += t1[i][1].w;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if constexpr (ACT >= 0) v[e] = apply_act_ct<ACT>(v[e]); else v[e] = apply_act_rt(v[e], g.act);
-      }
-      if (has_add2) {                                         // post-activation term
-        v[0] += t2[i][0].x; v[1] += t2[i][0].y; v[2] += t2[i][0].z; v[3] += t2[i][0].w;
-        v[4] += t2[i][1].x; v[5] += t2[i][1].y; v[6] += t2[i][1].z; v[7] += t2[i][1].w;
-      }
-      if constexpr (EPI >= 0 && (EPI & E_ST) != 0) {           // statistics of the bf16-rounded row segment (32 columns per wave pair)
-        float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-          const uint32_t pk = pack_bf16x2(v[e], v[e + 1]);
-          const float lo = __uint_as_float(pk << 16), hi = __uint_as_float(pk & 0xffff0000u);
-          s1 += lo + hi;
-          s2 = fmaf(lo, lo, fmaf(hi, hi, s2));
-        }
-        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-        if (fgrp == 0 && m < g.M) g.st_out[(size_t)m * (g.N >> 5) + ((n_wave >> 5) + p)] = make_float2(s1, s2);
-      }
-      if ((ACT >= 0 ? ACT == ACT_SWIGLU : g.act == ACT_SWIGLU)) {      // interleaved (gate, up) columns -> N / 2 activations
-        if (m < g.M && want_lo) {
-          float y[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = v[2 * e] / (1.0f + __expf(-v[2 * e])) * v[2 * e + 1];
-          store4<OutT>(reinterpret_cast<OutT*>(g.out_lo) + (size_t)m * g.ld_out_lo + (n >> 1), y[0], y[1], y[2], y[3]);
-        }
-        continue;
-      }
-      if (m < g.M) {
-        if (want_f32) store8<float>(g.out_f32 + (size_t)m * g.ld_out_f32 + n, v);
-        if (want_lo) {
-          OutT* o = reinterpret_cast<OutT*>(g.out_lo);
-          if (g.lo_group > 0) o += (size_t)(n / g.lo_group) * g.ld_out_lo + (size_t)m * g.lo_group + (n % g.lo_group);
-          else o += (size_t)m * g.ld_out_lo + n;
-          store8<OutT>(o, v);
-        }
-      }
-    }
-  }
-}
-
-// ---- un-swapped orientation: acc[i][j][r] = C[m_wave + 16 i + 4 (lane >> 4) + r][n_wave + frag_col(j, lane & 15)]
-template <typename OutT, int NJ>
-__device__ __forceinline__ void epilogue_transposed(const GemmArgs& g, f32x4_t (&acc)[4][NJ], int m_wave, int n_wave, int lane) {
-  const int frow = lane & 15, fgrp = lane >> 4;
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int n = n_wave + frag_col(j, frow);
-    const float b = g.bias ? g.bias[n] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m0 = m_wave + i * 16 + fgrp * 4;
-      OutT* o = reinterpret_cast<OutT*>(g.out_t) + (size_t)n * g.ld_out_t + m0;
-      if (m0 + 3 < g.M) {
-        store4<OutT>(o, acc[i][j][0] + b, acc[i][j][1] + b, acc[i][j][2] + b, acc[i][j][3] + b);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (m0 + r < g.M) Elem<OutT>::store(o + r, acc[i][j][r] + b);
-      }
-    }
-  }
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // ------------------------------------------------------------------------------------ bf16, ring-pipelined
 template <int BN_, int STAGES, int ACT, int EPI, bool SWAP>
@@ -1379,6 +1163,14 @@ bool big_fits(const GemmArgs& g) {
   return (double)tiles / (rounds * 256.0) >= 0.85 && (double)g.M / (tiles_m * BIG) >= 0.9;
 }
 
+// the ping-pong 256 x 256 kernel (gemm_pp.hip): one workgroup per CU, so it pays when its tiles fill whole rounds of the chip
+bool pp_fits(const GemmArgs& g) {
+  if (!genv().pp || !gemm_pp_supported(g) || g.M < 1024 || g.K < 256) return false;
+  const int tiles_m = (g.M + 255) / 256, tiles = tiles_m * (g.N / 256);
+  const int rounds = (tiles + 255) / 256;
+  return (double)tiles / (rounds * 256.0) >= 0.8 && (double)g.M / (tiles_m * 256) >= 0.9;
+}
+
 bool launch_big(const GemmArgs& g, hipStream_t s) {
   const int epi = (g.add ? E_ADD : 0) | (g.add2 ? E_ADD2 : 0) | (g.out_f32 ? E_F32 : 0) | (g.out_lo ? E_LO : 0) | (g.bias ? E_BIAS : 0);
 #define ASR_BIG_CASE(ACT_, EPI_) \
@@ -1575,7 +1367,7 @@ bool gemm_reduce_can_norm(const GemmArgs& g) {
   if (g.M <= 64 && (needs_skinny || g.M <= genv().skinny_max_plain) && g.K % (32 * SK_WAVES) == 0) return false;
   if (genv().skinny144 && g.M <= 144 && g.sk_ws && !g.st_out && g.K % (32 * SK_WAVES) == 0 && (g.lda * 2) % 16 == 0) return false;
   int st = 0;
-  if (big_fits(g) || (t144_enabled() && t144_fits(g, &st))) return false;
+  if (pp_fits(g) || big_fits(g) || (t144_enabled() && t144_fits(g, &st))) return false;
   return tiled_splits(g) > 1;
 }
 
@@ -1617,6 +1409,7 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
       return;
     }
     if (launch_t288w_amax(g, s)) return;
+    if (pp_fits(g) && launch_gemm_pp(g, s)) { note_kernel("pp"); return; }
     if (big_fits(g) && launch_big(g, s)) return;
     if (t144_enabled() && t144_fits(g, &st) && (st == 4 ? launch_t144<4>(g, s) : launch_t144<2>(g, s))) return;
     if (const int sp = tiled_splits(g); sp > 1) {
@@ -1638,6 +1431,11 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
     const bool deep = genv().deep;
     if (deep && g.m_dev && g.K >= 1024 && !tall && !g.amax_val) v = 3;
     if (deep && !tall && !g.amax_val && ((g.M + BM - 1) / BM) * (g.N / 64) <= 256 && g.K >= 256) v = 3;   // one round, at most one workgroup per CU
+  }
+  if (v >= 8 && v < 8 + 128) {
+    ASR_REQUIRE(launch_gemm_pp(g, s, v - 8), "gemm: variant 8 (ping-pong 256 x 256 tiles) has no instance for this shape / epilogue");
+    note_kernel("pp");
+    return;
   }
   if (v == 7) {
     ASR_REQUIRE(g.N % BIG == 0 && launch_big(g, s), "gemm: variant 7 (256 x 256 tiles) has no instance for this shape / epilogue");

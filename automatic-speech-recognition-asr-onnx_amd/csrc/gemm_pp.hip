@@ -1,0 +1,439 @@
+// Ping-pong bf16 GEMM for the large-M stacks (Whisper encoder, Qwen3-ASR prefill, vocabulary heads): C[M][N] = A[M][K] W[N][K]^T.
+//
+// 256 x 256 x 64 tiles, 8 waves as 2 (rows) x 4 (columns): a wave owns 128 x 64 outputs = 32 C fragments (128 accumulator registers).
+// The two wave groups (waves 0-3 = rows 0..127, waves 4-7 = rows 128..255; one wave of each group per SIMD) run the SAME instruction
+// stream shifted by one barrier: while one group is in a "matrix" segment (16 MFMAs = one 64 x 32 quadrant of its tile over the whole
+// K-step) its SIMD partner is in a "memory" segment (fragment reads for its next quadrant, two LDS-DMA instructions of the operand
+// stream, the counted wait). Every segment ends in a raw s_barrier, so the matrix pipe of a SIMD always has one wave feeding it and
+// fragment reads / DMA issue never sit between two MFMAs of the same wave (cdna_hip_programming.md T3 + T4 + T5, MI355X_MICROARCH.md
+// "Two waves per SIMD").
+//
+// Operand stream. A K-step (64 k) of the tile is four 16 KB UNITS, each 128 operand rows x 128 B, ordered as the phases consume them:
+//   U0 = W rows of every wave's columns  0..31   (read in phase 0)        U1 = A rows of every wave's rows  0..63  (phase 0)
+//   U2 = W rows of every wave's columns 32..63   (phase 1)                U3 = A rows of every wave's rows 64..127 (phase 2)
+// phase 3 multiplies the second row half with the W fragments of U0 that stayed in registers. One unit is issued per phase
+// (2 x global_load_lds_dwordx4 per thread), six phases ahead of its first read; `s_waitcnt vmcnt(8)` after the issue leaves four units
+// (64 KB per CU) in flight across every barrier and retires the unit that the NEXT phase reads (a unit is read one phase after the wait
+// that retired it, by waves that have passed a barrier behind every issuing wave's wait). Two 64 KB buffers: the unit issued in phase p
+// overwrites the one read two or more phases earlier.
+// The LDS image of a DMA is lane-linear; the 16-byte-slot XOR swizzle that keeps the ds_read_b128 fragment reads conflict-free is applied
+// on the per-lane global source address and again on the read address (rule 21).
+#include <type_traits>
+#include "gemm_dev.h"
+
+namespace {
+
+constexpr int PP_T = 256;                      // tile edge
+constexpr int PP_UNIT = 128 * 128;             // bytes per unit
+constexpr int PP_BUF = 4 * PP_UNIT;            // bytes per K-step
+
+#define PP_GLDS(gptr, lptr) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+// VAR (tuning experiments, bench hook): 1 = no s_setprio around the MFMA segments, 2 = W columns 0..31 of the NEXT K-step pre-read in phase 3
+// SWAP = false: un-swapped MFMA operand order (four consecutive ROWS per lane) for the transposed store (out_t: V^T for the attention kernels)
+template <int ACT, int EPI, int VAR = 0, bool SWAP = true>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = g.N / PP_T;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+  if (g.group_m > 1) {       // consecutive workgroups (one XCD's L2) walk group_m row tiles per column tile
+    const int tiles_m = gridDim.x / tiles_n, gsz = g.group_m * tiles_n;
+    const int grp = tile / gsz, first = grp * g.group_m, local = tile - grp * gsz;
+    const int rows_in = min(g.group_m, tiles_m - first);
+    tile_m = first + local % rows_in;
+    tile_n = local / rows_in;
+  }
+
+  // ---- staging sources: unit row q = p * 64 + wave * 8 + (lane >> 3) of round p; A units hold tile rows p * 128 + a * 64 + (q & 63),
+  // W units tile rows (q >> 5) * 64 + b * 32 + (q & 31)
+  const int srow = lane >> 3;
+  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A);
+  const bf16_t* Wb = reinterpret_cast<const bf16_t*>(g.W);
+  const int a_slot = ((lane & 7) ^ srow) << 3;
+  const int w_slot = ((lane & 7) ^ w_swz(wave * 8 + srow)) << 3;
+  const bf16_t* a_src[2][2];
+  const bf16_t* w_src[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      a_src[h][p] = Ab + (size_t)min(tile_m * PP_T + p * 128 + h * 64 + wave * 8 + srow, g.M - 1) * g.lda + a_slot;
+      w_src[h][p] = Wb + (size_t)(tile_n * PP_T + (2 * p + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + srow) * g.ldw + w_slot;
+    }
+  unsigned char* const lds_w = smem + wave * 1024;
+
+  // unit u (0..3) of K-step kt into buffer (kt & 1)
+  constexpr int dbg = VAR >> 4;     // timing-only ablations (bench hook): 1 no operand stream, 2 no MFMA, 4 no fragment reads
+  auto issue = [&](int u, int kt) {
+    if constexpr (dbg & 1) return;
+    unsigned char* dst = lds_w + (kt & 1) * PP_BUF + u * PP_UNIT;
+    const int k0 = kt * 64;
+    if (u == 0) { PP_GLDS(w_src[0][0] + k0, dst); PP_GLDS(w_src[0][1] + k0, dst + 8192); }
+    else if (u == 1) { PP_GLDS(a_src[0][0] + k0, dst); PP_GLDS(a_src[0][1] + k0, dst + 8192); }
+    else if (u == 2) { PP_GLDS(w_src[1][0] + k0, dst); PP_GLDS(w_src[1][1] + k0, dst + 8192); }
+    else { PP_GLDS(a_src[1][0] + k0, dst); PP_GLDS(a_src[1][1] + k0, dst + 8192); }
+  };
+
+  // ---- fragment read offsets inside a unit (swizzled); row fragment i adds i * 2048, column fragment jj adds 512
+  const int frow = lane & 15, fgrp = lane >> 4;
+  int a_rd[2], w_rd[2];
+  {
+    const int ra = wr * 64 + frow, rw = wc * 32 + ((frow >> 2) << 3) + (frow & 3);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int c = kk * 4 + fgrp;
+      a_rd[kk] = ra * 128 + ((c ^ (ra & 7)) << 4);
+      w_rd[kk] = rw * 128 + ((c ^ w_swz(rw)) << 4);
+    }
+  }
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8_t af[2][4] = {}, wf0[2][2] = {}, wf1[2][2] = {}, wf2[2][2] = {};
+  const int nk = g.K / 64;
+
+  auto rd_a = [&](const unsigned char* buf, int h) {
+    if constexpr (dbg & 4) return;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[kk][i] = *reinterpret_cast<const bf16x8_t*>(buf + (1 + 2 * h) * PP_UNIT + a_rd[kk] + i * 2048);
+  };
+  auto rd_w = [&](const unsigned char* buf, int h, bf16x8_t (&wf)[2][2]) {
+    if constexpr (dbg & 4) return;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) wf[kk][jj] = *reinterpret_cast<const bf16x8_t*>(buf + 2 * h * PP_UNIT + w_rd[kk] + jj * 512);
+  };
+  // VAR 8 (timed instance): s_memtime stamps at the segment boundaries of phase type r, summed per workgroup-0 wave: [r][0] fragment reads issued AND
+  // returned + DMA issued, [1] counted vmcnt wait, [2] barrier, [3] MFMAs issued, [4] barrier
+  constexpr bool TIMED = (VAR & 8) != 0;
+  uint32_t tacc[4][5] = {};
+  uint32_t tprev = 0;
+  int tphase = 0;
+  auto stamp = [&](int k) {
+    if constexpr (TIMED) {
+      const uint32_t t = (uint32_t)__builtin_readcyclecounter();
+      tacc[tphase][k] += t - tprev;
+      tprev = t;
+    }
+  };
+  auto mma = [&](int ha, int hb, const bf16x8_t (&wf)[2][2]) {
+    stamp(2);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(1);
+    if constexpr (!(dbg & 2))
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          if constexpr (SWAP) acc[ha * 4 + i][hb * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][jj], af[kk][i], acc[ha * 4 + i][hb * 2 + jj], 0, 0, 0);
+          else acc[ha * 4 + i][hb * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], wf[kk][jj], acc[ha * 4 + i][hb * 2 + jj], 0, 0, 0);
+    if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(3);
+    __builtin_amdgcn_s_barrier();
+    stamp(4);
+  };
+  // end of a memory segment: VM = LDS-DMA instructions that may stay in flight across the barrier (< 0: nothing to wait for)
+  auto mem_end = [&](auto vm) {
+    stamp(0);
+    if constexpr (decltype(vm)::value >= 0) wait_vmcnt<decltype(vm)::value>();
+    stamp(1);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using std::integral_constant;
+
+  // one K-step = four phases; phase p = 4 kt + r issues unit p + 6 and needs units <= p + 2 landed at its end. TAIL 0: steady state (four units
+  // stay in flight), 1: K-step nk - 2 (the stream ends in its phase 1), 2: K-step nk - 1
+  auto kstep = [&](auto tail, int kt, const unsigned char* buf, const unsigned char* nbuf, bf16x8_t (&wb0)[2][2], bf16x8_t (&wnext)[2][2]) {
+    constexpr int TAIL = decltype(tail)::value;
+    // phase 0: W columns 0..31 (unless the previous K-step's phase 3 pre-read them) + A rows 0..63
+    tphase = 0;
+    if (!(VAR & 2) || kt == 0) rd_w(buf, 0, wb0);
+    rd_a(buf, 0);
+    if constexpr (TAIL <= 1) issue(2, kt + 1);
+    mem_end(integral_constant<int, (TAIL <= 1 ? 8 : 2)>{});
+    mma(0, 0, wb0);
+    // phase 1: W columns 32..63
+    tphase = 1;
+    rd_w(buf, 1, wf1);
+    if constexpr (TAIL <= 1) issue(3, kt + 1);
+    mem_end(integral_constant<int, (TAIL <= 1 ? 8 : 0)>{});
+    mma(0, 1, wf1);
+    // phase 2: A rows 64..127
+    tphase = 2;
+    rd_a(buf, 1);
+    if constexpr (TAIL == 0) issue(0, kt + 2);
+    mem_end(integral_constant<int, (TAIL == 0 ? 8 : TAIL == 1 ? 6 : -1)>{});
+    mma(1, 1, wf1);
+    // phase 3: W columns 0..31 are still in registers; VAR 2: pre-read the next K-step's (unit 4 (kt + 1), landed behind phase 2's wait)
+    tphase = 3;
+    if constexpr ((VAR & 2) && TAIL <= 1) rd_w(nbuf, 0, wnext);
+    if constexpr (TAIL == 0) issue(1, kt + 2);
+    mem_end(integral_constant<int, (TAIL == 0 ? 8 : TAIL == 1 ? 4 : -1)>{});
+    mma(1, 0, wb0);
+  };
+
+  // ---- prologue: units 0..5 (K-step 0 whole, K-step 1 units 0 and 1); units 0, 1 landed behind vmcnt(8). nk is even and >= 2.
+  issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0); issue(0, 1); issue(1, 1);
+  wait_vmcnt<8>();
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();           // the second group runs one segment behind the first
+  __builtin_amdgcn_sched_barrier(0);
+
+  if constexpr (TIMED) tprev = (uint32_t)__builtin_readcyclecounter();
+  for (int kt = 0; kt < nk - 2; kt += 2) {
+    kstep(integral_constant<int, 0>{}, kt, smem, smem + PP_BUF, wf0, wf2);
+    kstep(integral_constant<int, 0>{}, kt + 1, smem + PP_BUF, smem, wf2, wf0);
+  }
+  kstep(integral_constant<int, 1>{}, nk - 2, smem, smem + PP_BUF, wf0, wf2);
+  kstep(integral_constant<int, 2>{}, nk - 1, smem + PP_BUF, smem, wf2, wf0);
+  if (wr == 0) __builtin_amdgcn_s_barrier();           // pairs with the second group's last segment
+  if constexpr (TIMED) {
+    if (g.dbg_clk && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) g.dbg_clk[wr * 20 + r * 5 + k] = tacc[r][k];
+  }
+
+  const int m_wave = tile_m * PP_T + wr * 128, n_wave = tile_n * PP_T + wc * 64;
+  if constexpr (SWAP) {
+    epilogue_rows<bf16_t, ACT, EPI, 4, 4>(g, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc[0]), m_wave, n_wave, lane);
+    epilogue_rows<bf16_t, ACT, EPI, 4, 4>(g, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc[4]), m_wave + 64, n_wave, lane);
+  } else {
+    epilogue_transposed<bf16_t, 4>(g, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc[0]), m_wave, n_wave, lane);
+    epilogue_transposed<bf16_t, 4>(g, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc[4]), m_wave + 64, n_wave, lane);
+  }
+}
+
+template <int ACT, int EPI, int VAR = 0, bool SWAP = true>
+void launch_pp_inst(const GemmArgs& g, hipStream_t s) {
+  constexpr int lds = 2 * PP_BUF;
+  static bool attr_set[16] = {};
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  if (!attr_set[dev & 15]) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp<ACT, EPI, VAR, SWAP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set[dev & 15] = true;
+  }
+  const int tiles_m = (g.M + PP_T - 1) / PP_T, grid = tiles_m * (g.N / PP_T);
+  GemmArgs gg = g;
+  gg.group_m = tiles_m >= 16 ? 8 : 0;
+  hipLaunchKernelGGL((gemm_bf16_pp<ACT, EPI, VAR, SWAP>), dim3(grid), dim3(512), lds, s, gg);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- the same schedule on v_mfma_f32_32x32x16_bf16: a phase is 8 MFMAs of 32 cycles (two 32-row fragments x one 32-column fragment x four
+// 16-deep k sub-steps), i.e. half the matrix instructions per segment -- the SIMD partner's memory segment gets the issue slots in between.
+// W rows are staged in fragment-POSITION order (see epilogue_rows32), so A and W units share one swizzle key: slot ^= (row >> 1) & 7, which
+// spreads every 16-lane group of a 32-row ds_read_b128 over the 16 slots of a 256-byte bank row.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v_t;
+
+template <int ACT, int EPI, int VAR = 0>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp32(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = g.N / PP_T;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+  if (g.group_m > 1) {
+    const int tiles_m = gridDim.x / tiles_n, gsz = g.group_m * tiles_n;
+    const int grp = tile / gsz, first = grp * g.group_m, local = tile - grp * gsz;
+    const int rows_in = min(g.group_m, tiles_m - first);
+    tile_m = first + local % rows_in;
+    tile_n = local / rows_in;
+  }
+
+  // ---- staging sources: unit row q = p * 64 + wave * 8 + srow. A units: tile row p * 128 + h * 64 + (q & 63). W units: q = wc' * 32 + pos with
+  // wc' = 2 p + (wave >> 2), pos = (wave & 3) * 8 + srow -> tile column wc' * 64 + h * 32 + 16 ((pos >> 2) & 1) + 4 (pos >> 3) + (pos & 3)
+  const int srow = lane >> 3;
+  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(g.A);
+  const bf16_t* Wb = reinterpret_cast<const bf16_t*>(g.W);
+  const int skey = (((wave & 1) << 2) + (srow >> 1)) & 7;
+  const int s_slot = ((lane & 7) ^ skey) << 3;
+  const int w_nat = 16 * ((srow >> 2) & 1) + 4 * (wave & 3) + (srow & 3);
+  const bf16_t* a_src[2][2];
+  const bf16_t* w_src[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      a_src[h][p] = Ab + (size_t)min(tile_m * PP_T + p * 128 + h * 64 + wave * 8 + srow, g.M - 1) * g.lda + s_slot;
+      w_src[h][p] = Wb + (size_t)(tile_n * PP_T + (2 * p + (wave >> 2)) * 64 + h * 32 + w_nat) * g.ldw + s_slot;
+    }
+  unsigned char* const lds_w = smem + wave * 1024;
+  constexpr int dbg = VAR >> 4;
+  auto issue = [&](int u, int kt) {
+    if constexpr (dbg & 1) return;
+    unsigned char* dst = lds_w + (kt & 1) * PP_BUF + u * PP_UNIT;
+    const int k0 = kt * 64;
+    if (u == 0) { PP_GLDS(w_src[0][0] + k0, dst); PP_GLDS(w_src[0][1] + k0, dst + 8192); }
+    else if (u == 1) { PP_GLDS(a_src[0][0] + k0, dst); PP_GLDS(a_src[0][1] + k0, dst + 8192); }
+    else if (u == 2) { PP_GLDS(w_src[1][0] + k0, dst); PP_GLDS(w_src[1][1] + k0, dst + 8192); }
+    else { PP_GLDS(a_src[1][0] + k0, dst); PP_GLDS(a_src[1][1] + k0, dst + 8192); }
+  };
+
+  // ---- fragment read offsets: row = lane & 31 of the fragment, 16-byte slot 2 ks + (lane >> 5), swizzled; row fragment ii adds 4096
+  const int f32r = lane & 31, fh = lane >> 5, rkey = (f32r >> 1) & 7;
+  int a_rd[4], w_rd[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int c = (2 * ks + fh) ^ rkey;
+    a_rd[ks] = (wr * 64 + f32r) * 128 + (c << 4);
+    w_rd[ks] = (wc * 32 + f32r) * 128 + (c << 4);
+  }
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][b][r] = 0.0f;
+
+  bf16x8v_t af[4][2] = {}, wf0[4] = {}, wf1[4] = {}, wf2[4] = {};
+  const int nk = g.K / 64;
+
+  auto rd_a = [&](const unsigned char* buf, int h) {
+    if constexpr (dbg & 4) return;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) af[ks][ii] = *reinterpret_cast<const bf16x8v_t*>(buf + (1 + 2 * h) * PP_UNIT + a_rd[ks] + ii * 4096);
+  };
+  auto rd_w = [&](const unsigned char* buf, int h, bf16x8v_t (&wf)[4]) {
+    if constexpr (dbg & 4) return;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wf[ks] = *reinterpret_cast<const bf16x8v_t*>(buf + 2 * h * PP_UNIT + w_rd[ks]);
+  };
+  auto mma = [&](int ha, int hb, const bf16x8v_t (&wf)[4]) {
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(1);
+    if constexpr (!(dbg & 2))
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+        acc[ha * 2 + ii][hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], af[ks][ii], acc[ha * 2 + ii][hb], 0, 0, 0);
+    if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  auto mem_end = [&](auto vm) {
+    if constexpr (decltype(vm)::value >= 0) wait_vmcnt<decltype(vm)::value>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using std::integral_constant;
+  auto kstep = [&](auto tail, int kt, const unsigned char* buf, const unsigned char* nbuf, bf16x8v_t (&wb0)[4], bf16x8v_t (&wnext)[4]) {
+    constexpr int TAIL = decltype(tail)::value;
+    if (!(VAR & 2) || kt == 0) rd_w(buf, 0, wb0);
+    rd_a(buf, 0);
+    if constexpr (TAIL <= 1) issue(2, kt + 1);
+    mem_end(integral_constant<int, (TAIL <= 1 ? 8 : 2)>{});
+    mma(0, 0, wb0);
+    rd_w(buf, 1, wf1);
+    if constexpr (TAIL <= 1) issue(3, kt + 1);
+    mem_end(integral_constant<int, (TAIL <= 1 ? 8 : 0)>{});
+    mma(0, 1, wf1);
+    rd_a(buf, 1);
+    if constexpr (TAIL == 0) issue(0, kt + 2);
+    mem_end(integral_constant<int, (TAIL == 0 ? 8 : TAIL == 1 ? 6 : -1)>{});
+    mma(1, 1, wf1);
+    if constexpr ((VAR & 2) && TAIL <= 1) rd_w(nbuf, 0, wnext);
+    if constexpr (TAIL == 0) issue(1, kt + 2);
+    mem_end(integral_constant<int, (TAIL == 0 ? 8 : TAIL == 1 ? 4 : -1)>{});
+    mma(1, 0, wb0);
+  };
+
+  issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0); issue(0, 1); issue(1, 1);
+  wait_vmcnt<8>();
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  for (int kt = 0; kt < nk - 2; kt += 2) {
+    kstep(integral_constant<int, 0>{}, kt, smem, smem + PP_BUF, wf0, wf2);
+    kstep(integral_constant<int, 0>{}, kt + 1, smem + PP_BUF, smem, wf2, wf0);
+  }
+  kstep(integral_constant<int, 1>{}, nk - 2, smem, smem + PP_BUF, wf0, wf2);
+  kstep(integral_constant<int, 2>{}, nk - 1, smem + PP_BUF, smem, wf2, wf0);
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+
+  epilogue_rows32<bf16_t, ACT, EPI, 4, 2>(g, acc, tile_m * PP_T + wr * 128, tile_n * PP_T + wc * 64, lane);
+}
+
+template <int ACT, int EPI, int VAR = 0>
+void launch_pp32_inst(const GemmArgs& g, hipStream_t s) {
+  constexpr int lds = 2 * PP_BUF;
+  static bool attr_set[16] = {};
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  if (!attr_set[dev & 15]) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp32<ACT, EPI, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set[dev & 15] = true;
+  }
+  const int tiles_m = (g.M + PP_T - 1) / PP_T, grid = tiles_m * (g.N / PP_T);
+  GemmArgs gg = g;
+  gg.group_m = tiles_m >= 16 ? 8 : 0;
+  hipLaunchKernelGGL((gemm_bf16_pp32<ACT, EPI, VAR>), dim3(grid), dim3(512), lds, s, gg);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+
+bool gemm_pp_supported(const GemmArgs& g) {
+  if (g.out_t && (g.add || g.add2 || g.out_f32 || g.out_lo || g.act != ACT_NONE)) return false;
+  return !g.amax_val && !g.ln_colsum && !g.st_out && !g.m_dev && !g.rms_out && g.k_splits <= 1 && g.N % PP_T == 0 && g.K % 128 == 0 &&
+         g.K >= 128 && g.M >= 1;
+}
+
+bool launch_gemm_pp(const GemmArgs& g, hipStream_t s, int var) {
+  if (!gemm_pp_supported(g)) return false;
+  if (var > 0) {                       // tuning experiments: the bf16-out epilogue only
+    if (var == 8 && g.act == ACT_NONE && g.bias && g.add && g.out_f32 && !g.out_lo && !g.add2) { launch_pp32_inst<ACT_NONE, E_BIAS | E_ADD | E_F32, 0>(g, s); return true; }
+    if (g.act != ACT_NONE || !g.bias || !g.out_lo || g.add || g.add2 || g.out_f32) return false;
+    switch (var) {
+#define ASR_PP_VAR(V_) case V_: launch_pp_inst<ACT_NONE, E_BIAS | E_LO, V_>(g, s); return true;
+      ASR_PP_VAR(1) ASR_PP_VAR(2) ASR_PP_VAR(3) ASR_PP_VAR(8) ASR_PP_VAR(9)
+      case 4: launch_pp32_inst<ACT_NONE, E_BIAS | E_LO, 0>(g, s); return true;
+      case 5: launch_pp32_inst<ACT_NONE, E_BIAS | E_LO, 1>(g, s); return true;
+      case 6: launch_pp32_inst<ACT_NONE, E_BIAS | E_LO, 2>(g, s); return true;
+      case 7: launch_pp32_inst<ACT_NONE, E_BIAS | E_LO, 3>(g, s); return true;
+      ASR_PP_VAR(16) ASR_PP_VAR(32) ASR_PP_VAR(48) ASR_PP_VAR(64) ASR_PP_VAR(80) ASR_PP_VAR(96) ASR_PP_VAR(112)
+#undef ASR_PP_VAR
+      default: return false;
+    }
+  }
+  if (g.out_t) { launch_pp_inst<ACT_NONE, 0, 0, false>(g, s); return true; }          // V^T (bias handled at run time by the transposed epilogue)
+  const int epi = (g.add ? E_ADD : 0) | (g.add2 ? E_ADD2 : 0) | (g.out_f32 ? E_F32 : 0) | (g.out_lo ? E_LO : 0) | (g.bias ? E_BIAS : 0);
+#define ASR_PP_CASE(ACT_, EPI_) \
+  if (g.act == (ACT_) && epi == (EPI_)) { launch_pp_inst<ACT_, EPI_>(g, s); return true; }
+  ASR_PP_CASE(ACT_NONE, E_BIAS | E_LO)                      // q|k projections, cross-K/V slabs (lo_group)
+  ASR_PP_CASE(ACT_GELU_ERF, E_BIAS | E_LO)                  // Whisper fc1
+  ASR_PP_CASE(ACT_GELU_TANH, E_BIAS | E_LO)                 // Qwen3-ASR encoder fc1 / conv stem
+  ASR_PP_CASE(ACT_NONE, E_BIAS | E_ADD | E_F32)             // out-proj / fc2 + residual
+  ASR_PP_CASE(ACT_NONE, E_F32)                              // Qwen3 decoder q|k|v
+  ASR_PP_CASE(ACT_SWIGLU, E_LO)                             // Qwen3 decoder gate|up
+  ASR_PP_CASE(ACT_NONE, E_ADD | E_F32)                      // Qwen3 decoder o_proj / down_proj
+  ASR_PP_CASE(ACT_NONE, E_BIAS | E_F32)                     // logits
+  ASR_PP_CASE(ACT_RELU, E_BIAS | E_LO)
+  ASR_PP_CASE(ACT_GELU_ERF, E_BIAS | E_ADD2 | E_F32)        // Whisper conv2: gelu(conv) + positions
+  ASR_PP_CASE(ACT_GELU_TANH, E_BIAS | E_ADD2 | E_F32)
+#undef ASR_PP_CASE
+  return false;
+}

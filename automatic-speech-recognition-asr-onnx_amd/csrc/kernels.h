@@ -51,6 +51,8 @@ template <typename T>
 void launch_whisper_mel_finish(const float* mel, const float* blk_max, const UttPlan* plan, const int32_t* grow_utt,
                                int n_gapped_rows, int n_mels, T* out, hipStream_t s);
 // zero the rows of a gapped-layout matrix that are not frames (conv zero padding after conv1)
+// dst row m (row space of `to`, utterance row_utt[m]) = src row of the same (utterance, position) in the row space of `from`; pad rows zero
+void launch_compact_rows(const float* src, const UttPlan* from, const UttPlan* to, const int32_t* row_utt, int rows, int d, float* dst, hipStream_t s);
 template <typename T>
 void launch_zero_gap_rows(T* buf, int ld, int n_cols, const UttPlan* plan, const int32_t* grow_utt, int n_gapped_rows,
                           hipStream_t s);

@@ -744,6 +744,20 @@ __global__ void zero_gap_rows_kernel(T* __restrict__ buf, int ld, int n_cols, co
   for (int c = threadIdx.x; c < n_cols; c += blockDim.x) Elem<T>::store(o + c, 0.0f);
 }
 
+// rows of a packed f32 matrix from one utterance plan's row space to another's (Whisper: conv stem rows -> encoder rows); pad rows become zero
+__global__ void compact_rows_kernel(const float* __restrict__ src, const UttPlan* __restrict__ from, const UttPlan* __restrict__ to,
+                                    const int32_t* __restrict__ row_utt, int d, float* __restrict__ dst) {
+  const int m = blockIdx.x, u = row_utt[m];
+  float4* o = reinterpret_cast<float4*>(dst + (size_t)m * d);
+  const int t = u >= 0 ? m - to[u].row_off : -1;
+  if (u < 0 || t >= to[u].T) {
+    for (int c = threadIdx.x; c < d / 4; c += blockDim.x) o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const float4* i = reinterpret_cast<const float4*>(src + (size_t)(from[u].row_off + t) * d);
+  for (int c = threadIdx.x; c < d / 4; c += blockDim.x) o[c] = i[c];
+}
+
 // ------------------------------------------------------------------------------------ decoder embedding
 template <typename T>
 __global__ void embed_pos_kernel(const int32_t* __restrict__ ids, int n, int hist, const int32_t* __restrict__ hist_dev,
@@ -1387,6 +1401,12 @@ void launch_zero_gap_rows(T* buf, int ld, int n_cols, const UttPlan* plan, const
 }
 template void launch_zero_gap_rows<float>(float*, int, int, const UttPlan*, const int32_t*, int, hipStream_t);
 template void launch_zero_gap_rows<bf16_t>(bf16_t*, int, int, const UttPlan*, const int32_t*, int, hipStream_t);
+
+void launch_compact_rows(const float* src, const UttPlan* from, const UttPlan* to, const int32_t* row_utt, int rows, int d, float* dst, hipStream_t s) {
+  ASR_REQUIRE(d % 4 == 0, "compact_rows: row length must be a multiple of 4");
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(rows), dim3(256), 0, s, src, from, to, row_utt, d, dst);
+  HIP_CHECK(hipGetLastError());
+}
 
 template <typename T>
 void launch_embed_pos(const int32_t* ids, int rows, int n, int hist, const int32_t* hist_dev, const T* embed, const float* pos, int d,

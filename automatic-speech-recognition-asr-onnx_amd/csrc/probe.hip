@@ -78,6 +78,8 @@ extern "C" int asr_probe_gemm_bench(int variant, int M, int N, int K, int epilog
       default: ASR_THROW(ASR_ERR_INVALID, "probe_gemm_bench: unknown epilogue %d", epilogue);
     }
     g.dbg = variant < 0 ? 0 : variant >> 8;
+    uint32_t* clk = nullptr;
+    if (getenv("ASR_PP_CLK")) { clk = (uint32_t*)t.alloc(64 * 4); HIP_CHECK(hipMemset(clk, 0, 64 * 4)); g.dbg_clk = clk; }
     gemm_set_variant(variant < 0 ? -1 : (variant & 0xff));      // sticky: later asr_op_gemm calls use it too
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
@@ -90,6 +92,16 @@ extern "C" int asr_probe_gemm_bench(int variant, int M, int N, int K, int epilog
     float ms = 0.f;
     HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     *avg_ms = ms / iters;
+    if (clk) {
+      uint32_t h[40];
+      HIP_CHECK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost));
+      const int ksteps = K / 64 - 2;
+      for (int w = 0; w < 2; ++w)
+        for (int r = 0; r < 4; ++r)
+          fprintf(stderr, "pp clock: group %d phase %d: reads %6.1f  vmcnt %6.1f  barrier %6.1f | mfma %6.1f  barrier %6.1f  (cycles per phase)\n", w, r,
+                  h[w * 20 + r * 5] / (double)ksteps, h[w * 20 + r * 5 + 1] / (double)ksteps, h[w * 20 + r * 5 + 2] / (double)ksteps,
+                  h[w * 20 + r * 5 + 3] / (double)ksteps, h[w * 20 + r * 5 + 4] / (double)ksteps);
+    }
     gemm_set_variant(-1);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

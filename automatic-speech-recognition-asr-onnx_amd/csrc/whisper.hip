@@ -186,7 +186,8 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
   HIP_CHECK(hipSetDevice(device));
   const int d = c.d_model, dff = c.d_ffn, Ld = c.n_dec_layers, H = c.n_heads;
   plan.assign(B, UttPlan{});
-  int r = 0, frames = 0, n_fb = 0, n_qb = 0, max_T = 0;
+  std::vector<UttPlan> splan(B);                          // the conv stem's view: same utterances, row_off in the gapped layout's row space
+  int r = 0, rg = 0, frames = 0, n_fb = 0, n_qb = 0, max_T = 0;
   const int64_t base0 = offs[0];
   for (int b = 0; b < B; ++b) {
     const int64_t n = offs[b + 1] - offs[b];
@@ -204,20 +205,24 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
     p.lang = 0;
     p.blk0 = n_fb;
     frames += p.n_frames;
-    r += round_up(p.T + 1, 16);                          // +1: room for the conv stem's right zero-pad frame
+    splan[b] = p;
+    splan[b].row_off = rg;
+    r += round_up(p.T, 16);                              // encoder stream: compact, 16-row aligned (8 s: 400 rows per utterance)
+    rg += round_up(p.T + 1, 16);                         // conv stem: +1 = room for the right zero-pad frame
     n_fb += (p.n_frames + 63) / 64;
     max_T = std::max(max_T, p.T);
     if (n_pos_out) n_pos_out[b] = p.T;
   }
   batch = B; rows = r; Mpad = round_up(r, 128); hist = 0; max_T_enc = max_T;
+  const int rows_g = rg, Mg = round_up(rg, 128);
   int att_qt = 0, att_nw = 4, q_rows = 64;
   if (precision == ASR_PRECISION_BF16) { attention_geometry(max_T, c.d_head, &att_qt, &att_nw); q_rows = 16 * att_qt * att_nw; }
   for (int b = 0; b < B; ++b) n_qb += (plan[b].T + q_rows - 1) / q_rows;
-  const int R = 2 * Mpad;                                // gapped (frame-rate) rows
+  const int R = 2 * Mg;                                  // gapped (frame-rate) rows
   const int64_t total_samples = offs[B] - base0;
 
-  // plan blob: [UttPlan B][blk_utt][blk_f0][qb_utt][qb_q0][row_utt Mpad][pos_rows Mpad][grow_utt R]
-  const size_t plan_bytes = sizeof(UttPlan) * B + 4 * (2 * (size_t)n_fb + 2 * (size_t)n_qb + 2 * (size_t)Mpad + R);
+  // plan blob: [UttPlan B (encoder rows)][UttPlan B (stem rows)][blk_utt][blk_f0][qb_utt][qb_q0][row_utt Mpad][pos_rows Mg][grow_utt R]
+  const size_t plan_bytes = 2 * sizeof(UttPlan) * B + 4 * (2 * (size_t)n_fb + 2 * (size_t)n_qb + (size_t)Mpad + (size_t)Mg + R);
   if (plan_bytes > h_plan_cap) {
     if (h_plan) HIP_CHECK(hipHostFree(h_plan));
     HIP_CHECK(hipHostMalloc(&h_plan, plan_bytes * 2, hipHostMallocDefault));
@@ -225,40 +230,42 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
   }
   unsigned char* hp = (unsigned char*)h_plan;
   memcpy(hp, plan.data(), sizeof(UttPlan) * B);
-  int32_t* blk_utt = (int32_t*)(hp + sizeof(UttPlan) * B);
+  memcpy(hp + sizeof(UttPlan) * B, splan.data(), sizeof(UttPlan) * B);
+  int32_t* blk_utt = (int32_t*)(hp + 2 * sizeof(UttPlan) * B);
   int32_t* blk_f0 = blk_utt + n_fb;
   int32_t* qb_utt = blk_f0 + n_fb;
   int32_t* qb_q0 = qb_utt + n_qb;
   int32_t* row_utt = qb_q0 + n_qb;
   int32_t* pos_rows = row_utt + Mpad;
-  int32_t* grow_utt = pos_rows + Mpad;
-  for (int i = 0; i < Mpad; ++i) { row_utt[i] = -1; pos_rows[i] = 0; }
+  int32_t* grow_utt = pos_rows + Mg;
+  for (int i = 0; i < Mpad; ++i) row_utt[i] = -1;
+  for (int i = 0; i < Mg; ++i) pos_rows[i] = 0;
   for (int i = 0; i < R; ++i) grow_utt[i] = -1;
   {
     int fi = 0, qi = 0;
     for (int b = 0; b < B; ++b) {
       for (int f0 = 0; f0 < plan[b].n_frames; f0 += 64) { blk_utt[fi] = b; blk_f0[fi++] = f0; }
       for (int q0 = 0; q0 < plan[b].T; q0 += q_rows) { qb_utt[qi] = b; qb_q0[qi++] = q0; }
-      const int rb = round_up(plan[b].T + 1, 16);
+      const int rb = round_up(plan[b].T + 1, 16), rc = round_up(plan[b].T, 16);
+      for (int t = 0; t < rc; ++t) row_utt[plan[b].row_off + t] = b;
       for (int t = 0; t < rb; ++t) {
-        row_utt[plan[b].row_off + t] = b;
-        pos_rows[plan[b].row_off + t] = t < plan[b].T ? t : 0;
-        grow_utt[2 * (plan[b].row_off + t)] = b;
-        grow_utt[2 * (plan[b].row_off + t) + 1] = b;
+        pos_rows[splan[b].row_off + t] = t < plan[b].T ? t : 0;
+        grow_utt[2 * (splan[b].row_off + t)] = b;
+        grow_utt[2 * (splan[b].row_off + t) + 1] = b;
       }
     }
   }
   { void* before = d_plan.ptr; d_plan.reserve(plan_bytes, stream); if (d_plan.ptr != before) ++ws_epoch; }
   HIP_CHECK(hipMemcpyAsync(d_plan.ptr, h_plan, plan_bytes, hipMemcpyHostToDevice, stream));
   const UttPlan* dp = d_plan.as<UttPlan>();
-  const int32_t* d_blk_utt = (const int32_t*)((unsigned char*)d_plan.ptr + sizeof(UttPlan) * B);
+  const UttPlan* dps = dp + B;                            // stem rows
+  const int32_t* d_blk_utt = (const int32_t*)((unsigned char*)d_plan.ptr + 2 * sizeof(UttPlan) * B);
   const int32_t* d_blk_f0 = d_blk_utt + n_fb;
   const int32_t* d_qb_utt = d_blk_f0 + n_fb;
   const int32_t* d_qb_q0 = d_qb_utt + n_qb;
   const int32_t* d_row_utt = d_qb_q0 + n_qb;
   const int32_t* d_pos_rows = d_row_utt + Mpad;
-  const int32_t* d_grow_utt = d_pos_rows + Mpad;
-  (void)d_row_utt;
+  const int32_t* d_grow_utt = d_pos_rows + Mg;
 
   const size_t eT = sizeof(T);
   const float* d_aud;
@@ -280,7 +287,7 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
   d_qk.reserve((size_t)Mpad * 2 * d * eT, stream);
   d_vt.reserve((size_t)Mpad * d * eT, stream);
   d_ctx.reserve((size_t)Mpad * d * eT, stream);
-  d_ffn.reserve((size_t)Mpad * dff * eT, stream);
+  d_ffn.reserve(std::max((size_t)Mpad * dff * eT, (size_t)Mg * d * 4), stream);
   { void* before = d_cross.ptr; d_cross.reserve((size_t)2 * Ld * H * Mpad * 64 * eT, stream); if (d_cross.ptr != before) ++ws_epoch; }
 
   // ---- STFT power -> mel -> log10 (STFT_Process.py:224-246, Export_Whisper.py:424-425)
@@ -295,7 +302,7 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
     // per-utterance max clamp + (x+4)/4, written behind one leading zero row (the conv view of row j starts at j-1)
     T* x0 = d_x0.as<T>();
     HIP_CHECK(hipMemsetAsync(x0, 0, (size_t)c.n_mels * eT, stream));
-    launch_whisper_mel_finish<T>(d_mel.as<float>(), d_blkmax.as<float>(), dp, d_grow_utt, R, c.n_mels, x0 + c.n_mels, stream);
+    launch_whisper_mel_finish<T>(d_mel.as<float>(), d_blkmax.as<float>(), dps, d_grow_utt, R, c.n_mels, x0 + c.n_mels, stream);
   }
   if (taps_enabled) save_tap("mel_gapped", d_x0.as<T>() + c.n_mels, R, c.n_mels, c.n_mels, (int)eT);
   // ---- conv stem as two GEMMs over strided views (no im2col): conv1 row j = frames j-1..j+1, conv2 row m = rows 2m..2m+2
@@ -305,11 +312,15 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
     g1.A = d_x0.ptr; g1.lda = c.n_mels; g1.W = conv1_w; g1.ldw = 3 * c.n_mels; g1.M = R; g1.N = d; g1.K = 3 * c.n_mels;
     g1.bias = conv1_b; g1.act = act; g1.out_lo = d_h1.ptr; g1.ld_out_lo = d;
     gemm(g1);
-    launch_zero_gap_rows<T>(d_h1.as<T>(), d, d, dp, d_grow_utt, R, stream);      // conv2's zero padding
+    launch_zero_gap_rows<T>(d_h1.as<T>(), d, d, dps, d_grow_utt, R, stream);     // conv2's zero padding
+    // conv2's output rows live in the stem's row space (row m = gapped rows 2m .. 2m + 2); they land in the (still unused) FFN buffer and are
+    // moved to the encoder's compact rows: every encoder GEMM then sees 16-row-aligned utterances without the pad row (8 s: 400, not 416)
+    float* stem_out = d_ffn.as<float>();
     GemmArgs g2;
-    g2.A = d_h1.ptr; g2.lda = 2 * d; g2.W = conv2_w; g2.ldw = 3 * d; g2.M = rows; g2.N = d; g2.K = 3 * d; g2.bias = conv2_b;
-    g2.act = act; g2.add2 = enc_pos; g2.ld_add2 = d; g2.add2_rows = d_pos_rows; g2.out_f32 = d_xa.as<float>(); g2.ld_out_f32 = d;
+    g2.A = d_h1.ptr; g2.lda = 2 * d; g2.W = conv2_w; g2.ldw = 3 * d; g2.M = rows_g; g2.N = d; g2.K = 3 * d; g2.bias = conv2_b;
+    g2.act = act; g2.add2 = enc_pos; g2.ld_add2 = d; g2.add2_rows = d_pos_rows; g2.out_f32 = stem_out; g2.ld_out_f32 = d;
     gemm(g2);
+    launch_compact_rows(stem_out, dps, dp, d_row_utt, rows, d, d_xa.as<float>(), stream);
   }
   if (taps_enabled) save_tap("stem", d_xa.ptr, rows, d, d, 4);
   // ---- encoder layers (:430-437)

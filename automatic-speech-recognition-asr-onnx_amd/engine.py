@@ -332,7 +332,7 @@ class WhisperSession(_Session):
         out, r = [], 0
         for t in lengths_pos:
             out.append((slabs[0, :, :, r:r + t], slabs[1, :, :, r:r + t]))
-            r += (t + 1 + 15) // 16 * 16
+            r += (t + 15) // 16 * 16
         return out
 
 

@@ -4,23 +4,34 @@ The reference decodes with pydub (`AudioSegment.from_file(p).set_channels(1).set
 .get_array_of_samples()`, SenseVoice/Inference_SenseVoice_ONNX.py:236-242, Whisper/Inference_Whisper_ONNX.py:735-741). For PCM
 .wav input pydub's two conversions are thin wrappers over the standard library: `set_channels(1)` = `audioop.tomono(data, width,
 0.5, 0.5)` (stereo) and `set_frame_rate(r)` = `audioop.ratecv(data, width, channels, rate, r, None)`; this module performs the same
-two calls in the same order on the frames `wave` reads, so a wav file yields the samples the reference would feed its graphs --
-without pydub / ffmpeg (neither ships here). Compressed inputs (.mp3 ...) are out of scope: convert them to .wav first.
+two calls in the same order on the frames `wave` reads, so a **16-bit** wav file yields exactly the samples the reference would feed
+its graphs -- without pydub / ffmpeg (neither ships here). Other sample widths are accepted but are NOT sample-exact against the
+reference: it casts pydub's sample array straight to int16 (no rescale of 24- / 32-bit data), whereas this module rescales with
+`audioop.lin2lin`; the parity harness (tools/transcribe.py compare) therefore takes 16-bit wav only (`exact_width=True`).
+Compressed inputs (.mp3 ...) are out of scope: convert them to .wav first.
 """
 from __future__ import annotations
 
-import audioop
 import wave
+
+try:
+    import audioop                                   # standard library up to Python 3.12
+except ImportError as e:                             # removed in 3.13 (PEP 594)
+    raise ImportError("audio_io needs the standard-library `audioop` module (Python <= 3.12); on newer interpreters install the "
+                      "`audioop-lts` backport or convert audio to 16 kHz mono int16 yourself and pass arrays") from e
 
 import numpy as np
 
 
-def read_wav_int16(path: str, sample_rate: int = 16000) -> np.ndarray:
-    """Mono int16 samples at `sample_rate`. PCM wav of any width / channel count / rate."""
+def read_wav_int16(path: str, sample_rate: int = 16000, exact_width: bool = False) -> np.ndarray:
+    """Mono int16 samples at `sample_rate`. PCM wav of any width / channel count / rate; `exact_width` rejects everything but 16-bit
+    input (the only width for which the samples equal the reference's)."""
     with wave.open(path, "rb") as w:
         n_ch, width, rate, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
         if w.getcomptype() != "NONE":
             raise ValueError(f"{path}: compressed wav ({w.getcomptype()}) is not supported")
+        if exact_width and width != 2:
+            raise ValueError(f"{path}: {8 * width}-bit samples; sample-exact parity with the reference holds for 16-bit wav only")
         data = w.readframes(n)
     if width == 1:                                   # 8-bit wav is unsigned: pydub biases it to signed before any conversion
         data = audioop.bias(data, 1, -128)

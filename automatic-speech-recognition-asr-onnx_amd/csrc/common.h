@@ -69,6 +69,20 @@ __device__ __forceinline__ float2 sum_row_partials(const float2* sp, int n) {
   return make_float2(sx, sy);
 }
 
+// One-time per-DEVICE setup (hipFuncSetAttribute / hipMemcpyToSymbol act on the current device): first() is true the first time it is asked on
+// the current device. A process that opens sessions on several GPUs thus sets up every large-LDS kernel on each of them.
+struct PerDeviceOnce {
+  bool done[32] = {};
+  bool first() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    d &= 31;
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
+
 // ---- host-side error plumbing (thread-local message, integer status) -------------------
 enum {
   ASR_OK = 0,

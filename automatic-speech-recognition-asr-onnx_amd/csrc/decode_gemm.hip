@@ -201,8 +201,8 @@ void launch_inst(const DecGemmArgs& g, int splits, hipStream_t s) {
   const dim3 grid(g.N / (16 * NT), splits);
   auto go = [&](auto kern) {
     if (lds > 48 * 1024) {
-      static bool set = false;          // (per instantiation of this lambda: one kernel each)
-      if (!set) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); set = true; }
+      static PerDeviceOnce once;        // (per instantiation of this lambda: one kernel each)
+      if (once.first()) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     }
     hipLaunchKernelGGL(kern, grid, dim3(64 * DW), lds, s, g);
   };
@@ -223,10 +223,11 @@ void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits) {
   const int cus = 256;
   int NT = g.N / 16 > cus ? 2 : 1;                      // 32-column granules where 16-column ones would overflow the chip (33..64 rows: 4 x 2 output tiles = the 8 finishing waves)
   int granules = g.N / (16 * NT), best = 1;
+  const int ws_rows = g.M <= 16 ? 16 : g.M <= 32 ? 32 : 64;      // rows per split slab as the kernel addresses them: [ks][MT * 16][N]
   if (!g.colsum && g.ws && g.cnt) {                     // (the folded LayerNorm needs whole rows in one workgroup: K is never split there)
     for (int sp : {2, 3, 4, 5, 6, 8, 10}) {
       if (g.K % (32 * DW * sp) != 0 || granules * sp > cus) continue;
-      if ((size_t)sp * ((g.M + 15) / 16 * 16) * g.N * 4 > g.ws_bytes) continue;
+      if ((size_t)sp * ws_rows * g.N * 4 > g.ws_bytes) continue;
       // a split pays once the un-split workgroup streams much more than a CU moves in the time a hand-over costs (~2 us ~ 80 KB)
       const size_t per_wg = (size_t)(16 * NT + ((g.M + 15) / 16 * 16)) * g.K * 2 / best;
       if (per_wg < 160 * 1024) break;

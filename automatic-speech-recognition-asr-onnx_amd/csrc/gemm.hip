@@ -1126,11 +1126,10 @@ static int tiled_splits(const GemmArgs& g) {
 template <int BN_, int STAGES, int ACT, int EPI, bool SWAP>
 void launch_pipe_inst(const GemmArgs& g, hipStream_t s) {
   constexpr int lds = STAGES * (BM * 128 + BN_ * 128);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pipe<BN_, STAGES, ACT, EPI, SWAP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
   }
   const int grid = ((g.M + BM - 1) / BM) * (g.N / BN_);
   GemmArgs gg = g;
@@ -1143,10 +1142,9 @@ void launch_pipe_inst(const GemmArgs& g, hipStream_t s) {
 template <int ACT, int EPI>
 void launch_big_inst(const GemmArgs& g, hipStream_t s) {
   constexpr int lds = 2 * 2 * BIG * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big<ACT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
   }
   const int grid = ((g.M + BIG - 1) / BIG) * (g.N / BIG);
   note_kernel("big");
@@ -1227,11 +1225,10 @@ template <int STAGES, int ACT, int EPI>
 void launch_t144_inst(const GemmArgs& g, hipStream_t s) {
   constexpr int ring = STAGES * T_STAGE;
   constexpr int lds = (ring > T_RED ? ring : T_RED) + 3 * TM * 8;      // + LayerNorm statistics
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_t144<STAGES, ACT, EPI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
   }
   const int grid = ((g.M + TM - 1) / TM) * (g.N / TN);
   note_kernel("t144");
@@ -1276,11 +1273,10 @@ bool launch_t144w(const GemmArgs& g, hipStream_t s) {
   const int tiles = ((g.M + TM - 1) / TM) * (g.N / TW);
   if (tiles < 448 || (tiles % 256 > 0 && tiles % 256 < 192)) return false;     // whole rounds of one workgroup per CU (or nearly)
   constexpr int lds = (TW_STAGES * TW_STAGE > TW_RED ? TW_STAGES * TW_STAGE : TW_RED) + TM * 8;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_t144w<ACT_RELU, E_BIAS | E_LO | E_LN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
   }
   note_kernel("t144w");
   hipLaunchKernelGGL((gemm_bf16_t144w<ACT_RELU, E_BIAS | E_LO | E_LN>), dim3(tiles), dim3(512), lds, s, g);
@@ -1297,11 +1293,10 @@ bool launch_t288w(const GemmArgs& g, hipStream_t s) {
   const int tiles = ((g.M + TM2 - 1) / TM2) * (g.N / TW);
   if (tiles < 200 || (tiles % 256 != 0 && tiles % 256 < 200)) return false;      // whole rounds of one workgroup per CU (or nearly)
   constexpr int lds = 2 * T2_STAGE + TM2 * 8;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_t288w<ACT_RELU, E_BIAS | E_LO | E_LN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
   }
   note_kernel("t288w");
   hipLaunchKernelGGL((gemm_bf16_t288w<ACT_RELU, E_BIAS | E_LO | E_LN>), dim3(tiles), dim3(512), lds, s, g);
@@ -1318,11 +1313,10 @@ bool launch_t288w_amax(const GemmArgs& g, hipStream_t s) {
   const int tiles = ((g.M + TM2 - 1) / TM2) * (g.N / TW);
   if (tiles < 1024) return false;
   constexpr int lds = 2 * T2_STAGE + TM2 * 8;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_t288w<ACT_NONE, E_BIAS | E_AMAX>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
   }
   note_kernel("t288w_amax");
   hipLaunchKernelGGL((gemm_bf16_t288w<ACT_NONE, E_BIAS | E_AMAX>), dim3(tiles), dim3(512), lds, s, g);
@@ -1432,8 +1426,8 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
     if (deep && g.m_dev && g.K >= 1024 && !tall && !g.amax_val) v = 3;
     if (deep && !tall && !g.amax_val && ((g.M + BM - 1) / BM) * (g.N / 64) <= 256 && g.K >= 256) v = 3;   // one round, at most one workgroup per CU
   }
-  if (v >= 8 && v < 8 + 128) {
-    ASR_REQUIRE(launch_gemm_pp(g, s, v - 8), "gemm: variant 8 (ping-pong 256 x 256 tiles) has no instance for this shape / epilogue");
+  if (v >= 8 && v <= 8 + 128) {                // 8: persistent ping-pong kernel; 9..135: its tuning instances; 136: one workgroup per tile
+    ASR_REQUIRE(launch_gemm_pp(g, s, v == 136 ? -1 : v - 8), "gemm: variant 8 (ping-pong 256 x 256 tiles) has no instance for this shape / epilogue");
     note_kernel("pp");
     return;
   }

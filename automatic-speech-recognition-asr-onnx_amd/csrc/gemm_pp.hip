@@ -18,6 +18,7 @@
 // overwrites the one read two or more phases earlier.
 // The LDS image of a DMA is lane-linear; the 16-byte-slot XOR swizzle that keeps the ds_read_b128 fragment reads conflict-free is applied
 // on the per-lane global source address and again on the read address (rule 21).
+#include <algorithm>
 #include <type_traits>
 #include "gemm_dev.h"
 
@@ -223,17 +224,210 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp(const GemmArgs g) {
 template <int ACT, int EPI, int VAR = 0, bool SWAP = true>
 void launch_pp_inst(const GemmArgs& g, hipStream_t s) {
   constexpr int lds = 2 * PP_BUF;
-  static bool attr_set[16] = {};
-  int dev = 0;
-  HIP_CHECK(hipGetDevice(&dev));
-  if (!attr_set[dev & 15]) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp<ACT, EPI, VAR, SWAP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set[dev & 15] = true;
   }
   const int tiles_m = (g.M + PP_T - 1) / PP_T, grid = tiles_m * (g.N / PP_T);
   GemmArgs gg = g;
   gg.group_m = tiles_m >= 16 ? 8 : 0;
   hipLaunchKernelGGL((gemm_bf16_pp<ACT, EPI, VAR, SWAP>), dim3(grid), dim3(512), lds, s, gg);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- persistent form: one workgroup per CU walks its tiles (virtual block id = workgroup + i * grid, same XCD-aware order), and the operand
+// stream runs THROUGH the tile boundary: the last two K-steps of a tile issue the first six units of the next one, so a tile costs its K loop
+// plus one exposed epilogue (both wave groups store together between an un-stagger and a re-stagger barrier) instead of a workgroup launch, a
+// cold pipeline fill and an epilogue per tile -- K = 1280 tiles spent 30 % of their time there. One code path: the K loop is the steady-state
+// pair of K-steps throughout; the workgroup's LAST tile keeps the stream going with six units nobody reads (its own first K-steps again, 96 KB
+// once per workgroup) instead of a second, draining copy of the loop, and the queue is drained before the workgroup ends.
+// Staging sources are 32-bit byte offsets from the operand bases (operands below 4 GiB: gemm_pp_supported).
+template <int ACT, int EPI, bool SWAP = true>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_ppp(const GemmArgs g, const int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = g.N / PP_T, tiles_m = total_tiles / tiles_n;
+  auto tile_of = [&](int vb, int& tm, int& tn) {
+    const int tile = xcd_remap(vb, total_tiles);
+    tm = tile / tiles_n; tn = tile % tiles_n;
+    if (g.group_m > 1) {
+      const int gsz = g.group_m * tiles_n;
+      const int grp = tile / gsz, first = grp * g.group_m, local = tile - grp * gsz;
+      const int rows_in = min(g.group_m, tiles_m - first);
+      tm = first + local % rows_in;
+      tn = local / rows_in;
+    }
+  };
+
+  const int srow = lane >> 3;
+  const unsigned char* Ab = reinterpret_cast<const unsigned char*>(g.A);
+  const unsigned char* Wb = reinterpret_cast<const unsigned char*>(g.W);
+  const int a_slot = ((lane & 7) ^ srow) << 4;
+  const int w_slot = ((lane & 7) ^ w_swz(wave * 8 + srow)) << 4;
+  uint32_t a_src[2][2], w_src[2][2];
+  auto set_src = [&](int tm, int tn) {                 // staging sources of the tile the stream is in
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        a_src[h][p] = (uint32_t)min(tm * PP_T + p * 128 + h * 64 + wave * 8 + srow, g.M - 1) * (uint32_t)(g.lda * 2) + a_slot;
+        w_src[h][p] = (uint32_t)(tn * PP_T + (2 * p + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + srow) * (uint32_t)(g.ldw * 2) + w_slot;
+      }
+  };
+  unsigned char* const lds_w = smem + wave * 1024;
+  auto issue = [&](int u, int kt) {
+    unsigned char* dst = lds_w + (kt & 1) * PP_BUF + u * PP_UNIT;
+    const uint32_t k0 = (uint32_t)kt * 128u;
+    if (u == 0) { PP_GLDS(Wb + (w_src[0][0] + k0), dst); PP_GLDS(Wb + (w_src[0][1] + k0), dst + 8192); }
+    else if (u == 1) { PP_GLDS(Ab + (a_src[0][0] + k0), dst); PP_GLDS(Ab + (a_src[0][1] + k0), dst + 8192); }
+    else if (u == 2) { PP_GLDS(Wb + (w_src[1][0] + k0), dst); PP_GLDS(Wb + (w_src[1][1] + k0), dst + 8192); }
+    else { PP_GLDS(Ab + (a_src[1][0] + k0), dst); PP_GLDS(Ab + (a_src[1][1] + k0), dst + 8192); }
+  };
+
+  const int frow = lane & 15, fgrp = lane >> 4;
+  int a_rd[2], w_rd[2];
+  {
+    const int ra = wr * 64 + frow, rw = wc * 32 + ((frow >> 2) << 3) + (frow & 3);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int c = kk * 4 + fgrp;
+      a_rd[kk] = ra * 128 + ((c ^ (ra & 7)) << 4);
+      w_rd[kk] = rw * 128 + ((c ^ w_swz(rw)) << 4);
+    }
+  }
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t af[2][4], wf0[2][2], wf1[2][2];
+  const int nk = g.K / 64;
+
+  auto rd_a = [&](const unsigned char* buf, int h) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[kk][i] = *reinterpret_cast<const bf16x8_t*>(buf + (1 + 2 * h) * PP_UNIT + a_rd[kk] + i * 2048);
+  };
+  auto rd_w = [&](const unsigned char* buf, int h, bf16x8_t (&wf)[2][2]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) wf[kk][jj] = *reinterpret_cast<const bf16x8_t*>(buf + 2 * h * PP_UNIT + w_rd[kk] + jj * 512);
+  };
+  auto mma = [&](int ha, int hb, const bf16x8_t (&wf)[2][2]) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          if constexpr (SWAP) acc[ha * 4 + i][hb * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][jj], af[kk][i], acc[ha * 4 + i][hb * 2 + jj], 0, 0, 0);
+          else acc[ha * 4 + i][hb * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], wf[kk][jj], acc[ha * 4 + i][hb * 2 + jj], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  auto mem_end = [&]() {
+    wait_vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // one K-step = four phases: phases 0, 1 issue units 2, 3 of K-step kA, phases 2, 3 units 0, 1 of K-step kB
+  auto kstep = [&](const unsigned char* buf, int kA, int kB) {
+    rd_w(buf, 0, wf0); rd_a(buf, 0);
+    issue(2, kA);
+    mem_end();
+    mma(0, 0, wf0);
+    rd_w(buf, 1, wf1);
+    issue(3, kA);
+    mem_end();
+    mma(0, 1, wf1);
+    rd_a(buf, 1);
+    issue(0, kB);
+    mem_end();
+    mma(1, 1, wf1);
+    issue(1, kB);
+    mem_end();
+    mma(1, 0, wf0);
+  };
+
+  int vb = blockIdx.x, tm, tn;
+  tile_of(vb, tm, tn);
+  set_src(tm, tn);
+  issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0); issue(0, 1); issue(1, 1);
+  wait_vmcnt<8>();
+  __builtin_amdgcn_s_barrier();
+
+  for (;;) {
+    if (wr == 1) __builtin_amdgcn_s_barrier();           // the second group runs one segment behind the first
+    __builtin_amdgcn_sched_barrier(0);
+    const int nvb = vb + (int)gridDim.x;
+    const bool has_next = nvb < total_tiles;
+    int ntm = tm, ntn = tn;                              // last tile: the stream re-reads this tile's first K-steps (never consumed)
+    if (has_next) tile_of(nvb, ntm, ntn);
+    for (int kt = 0; kt < nk - 2; kt += 2) {
+      kstep(smem, kt + 1, kt + 2);
+      kstep(smem + PP_BUF, kt + 2, kt + 3);
+    }
+    // last two K-steps of the tile: their phases 0, 1 finish this tile's stream, then the sources turn to the next tile
+    {
+      const unsigned char* buf = smem;
+      rd_w(buf, 0, wf0); rd_a(buf, 0);
+      issue(2, nk - 1);
+      mem_end();
+      mma(0, 0, wf0);
+      rd_w(buf, 1, wf1);
+      issue(3, nk - 1);
+      mem_end();
+      mma(0, 1, wf1);
+      rd_a(buf, 1);
+      set_src(ntm, ntn);
+      issue(0, 0);
+      mem_end();
+      mma(1, 1, wf1);
+      issue(1, 0);
+      mem_end();
+      mma(1, 0, wf0);
+    }
+    kstep(smem + PP_BUF, 0, 1);
+    if (wr == 0) __builtin_amdgcn_s_barrier();           // pairs with the second group's last segment: both groups store together
+    __builtin_amdgcn_sched_barrier(0);
+    const int m_wave = tm * PP_T + wr * 128, n_wave = tn * PP_T + wc * 64;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {                      // 64 rows at a time (register copies: the epilogue's temporaries are sized per 4 row fragments)
+      f32x4_t part[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { part[i][j] = acc[hh * 4 + i][j]; acc[hh * 4 + i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+      if constexpr (SWAP) epilogue_rows<bf16_t, ACT, EPI, 4, 4>(g, part, m_wave + hh * 64, n_wave, lane);
+      else epilogue_transposed<bf16_t, 4>(g, part, m_wave + hh * 64, n_wave, lane);
+    }
+    if (!has_next) break;
+    vb = nvb; tm = ntm; tn = ntn;
+  }
+  wait_vmcnt<0>();                                       // the units nobody reads must land before the LDS is handed to another workgroup
+}
+
+template <int ACT, int EPI, bool SWAP = true>
+void launch_ppp_inst(const GemmArgs& g, hipStream_t s) {
+  constexpr int lds = 2 * PP_BUF;
+  static PerDeviceOnce attr_once;
+  static int n_cu[32] = {};
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  if (attr_once.first()) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_ppp<ACT, EPI, SWAP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_CHECK(hipDeviceGetAttribute(&n_cu[dev & 31], hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const int tiles_m = (g.M + PP_T - 1) / PP_T, tiles = tiles_m * (g.N / PP_T);
+  GemmArgs gg = g;
+  gg.group_m = tiles_m >= 16 ? 8 : 0;
+  const int grid = std::min(tiles, n_cu[dev & 31] > 0 ? n_cu[dev & 31] : 256);
+  hipLaunchKernelGGL((gemm_bf16_ppp<ACT, EPI, SWAP>), dim3(grid), dim3(512), lds, s, gg, tiles);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -380,12 +574,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp32(const GemmArgs g) {
 template <int ACT, int EPI, int VAR = 0>
 void launch_pp32_inst(const GemmArgs& g, hipStream_t s) {
   constexpr int lds = 2 * PP_BUF;
-  static bool attr_set[16] = {};
-  int dev = 0;
-  HIP_CHECK(hipGetDevice(&dev));
-  if (!attr_set[dev & 15]) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_pp32<ACT, EPI, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set[dev & 15] = true;
   }
   const int tiles_m = (g.M + PP_T - 1) / PP_T, grid = tiles_m * (g.N / PP_T);
   GemmArgs gg = g;
@@ -398,6 +589,7 @@ void launch_pp32_inst(const GemmArgs& g, hipStream_t s) {
 
 bool gemm_pp_supported(const GemmArgs& g) {
   if (g.out_t && (g.add || g.add2 || g.out_f32 || g.out_lo || g.act != ACT_NONE)) return false;
+  if ((size_t)g.M * g.lda * 2 >= ((size_t)1 << 32) || (size_t)g.N * g.ldw * 2 >= ((size_t)1 << 32)) return false;
   return !g.amax_val && !g.ln_colsum && !g.st_out && !g.m_dev && !g.rms_out && g.k_splits <= 1 && g.N % PP_T == 0 && g.K % 128 == 0 &&
          g.K >= 128 && g.M >= 1;
 }
@@ -405,6 +597,8 @@ bool gemm_pp_supported(const GemmArgs& g) {
 bool launch_gemm_pp(const GemmArgs& g, hipStream_t s, int var) {
   if (!gemm_pp_supported(g)) return false;
   if (var > 0) {                       // tuning experiments: the bf16-out epilogue only
+    if (var == 100 && g.act == ACT_NONE && g.bias && g.out_lo && !g.add && !g.add2 && !g.out_f32) { launch_ppp_inst<ACT_NONE, E_BIAS | E_LO>(g, s); return true; }
+    if (var == 100 && g.act == ACT_NONE && g.bias && g.add && g.out_f32 && !g.out_lo && !g.add2) { launch_ppp_inst<ACT_NONE, E_BIAS | E_ADD | E_F32>(g, s); return true; }
     if (var == 8 && g.act == ACT_NONE && g.bias && g.add && g.out_f32 && !g.out_lo && !g.add2) { launch_pp32_inst<ACT_NONE, E_BIAS | E_ADD | E_F32, 0>(g, s); return true; }
     if (g.act != ACT_NONE || !g.bias || !g.out_lo || g.add || g.add2 || g.out_f32) return false;
     switch (var) {
@@ -419,10 +613,10 @@ bool launch_gemm_pp(const GemmArgs& g, hipStream_t s, int var) {
       default: return false;
     }
   }
-  if (g.out_t) { launch_pp_inst<ACT_NONE, 0, 0, false>(g, s); return true; }          // V^T (bias handled at run time by the transposed epilogue)
+  if (g.out_t) { launch_ppp_inst<ACT_NONE, 0, false>(g, s); return true; }          // V^T (bias handled at run time by the transposed epilogue)
   const int epi = (g.add ? E_ADD : 0) | (g.add2 ? E_ADD2 : 0) | (g.out_f32 ? E_F32 : 0) | (g.out_lo ? E_LO : 0) | (g.bias ? E_BIAS : 0);
 #define ASR_PP_CASE(ACT_, EPI_) \
-  if (g.act == (ACT_) && epi == (EPI_)) { launch_pp_inst<ACT_, EPI_>(g, s); return true; }
+  if (g.act == (ACT_) && epi == (EPI_)) { if (var < 0) launch_pp_inst<ACT_, EPI_>(g, s); else launch_ppp_inst<ACT_, EPI_>(g, s); return true; }
   ASR_PP_CASE(ACT_NONE, E_BIAS | E_LO)                      // q|k projections, cross-K/V slabs (lo_group)
   ASR_PP_CASE(ACT_GELU_ERF, E_BIAS | E_LO)                  // Whisper fc1
   ASR_PP_CASE(ACT_GELU_TANH, E_BIAS | E_LO)                 // Qwen3-ASR encoder fc1 / conv stem

@@ -1262,17 +1262,15 @@ void launch_fbank(const FbankArgs& a, int n_blocks, hipStream_t s) {
   ASR_REQUIRE(a.n_bin_tiles * 16 <= FB_PLD - 1, "fbank: too many frequency bins");
   ASR_REQUIRE(a.n_kchunks * 16 == WIN, "fbank: k-chunks must cover the window");
   const size_t lds = (size_t)(FB_AUDIO_LDS + FB_FRAMES * FB_PLD) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fbank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
   }
   if (a.dft_split) {
     const size_t lds2 = (size_t)FB_A16 * 2 * 2 + (size_t)FB_FRAMES * FB_PLD * sizeof(float);
-    static bool attr2 = false;
-    if (!attr2) {
+    static PerDeviceOnce attr2_once;
+    if (attr2_once.first()) {
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fbank_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-      attr2 = true;
     }
     hipLaunchKernelGGL(fbank_split_kernel, dim3(n_blocks), dim3(256), lds2, s, a);
     HIP_CHECK(hipGetLastError());
@@ -1311,11 +1309,10 @@ template void launch_layernorm<bf16_t>(const float*, int, int, int, const float*
 template <int HD, int CHUNK, int QT>
 static void launch_attn_inst(const AttnArgs& a, hipStream_t s) {
   constexpr int lds = CHUNK * HD * 2 * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel<HD, CHUNK, QT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
   }
   AttnArgs b = a;
   if (b.ld_q == 0) b.ld_q = b.ld_qk;

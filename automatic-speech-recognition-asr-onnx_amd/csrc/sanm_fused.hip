@@ -354,10 +354,9 @@ bool sanm_fused_supported(int max_T, int d_head, int n_heads, int d, int fsmn_ta
 void launch_sanm_qkv_attn(const SanmFusedArgs& a, hipStream_t s) {
   ASR_REQUIRE(a.K % 64 == 0 && a.ld_h % 8 == 0 && a.ldw % 8 == 0 && a.n_heads * FHD == a.d && a.ld_mem % 4 == 0 && a.ld_ctx % 4 == 0,
               "sanm_fused: bad geometry (K=%d d=%d heads=%d)", a.K, a.d, a.n_heads);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sanm_qkv_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FLDS));
-    attr_set = true;
   }
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("ASR_FUSED_DBG"); dbg = e ? atoi(e) : 0; }     // kernel ablation switches (timing only)

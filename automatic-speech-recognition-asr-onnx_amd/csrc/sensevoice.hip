@@ -89,6 +89,19 @@ struct SvSession : asr_session {
   DeviceBuffer d_dft_split;
   int block_fault = 0;          // ASR_SANM_BLOCK_FAULT=1 (tests): one workgroup of the first block launch withholds an exchange count
   int block_giveups = 0;        // forward passes redone on the four-launch path because a cluster gave up (see run())
+  int block_cooldown = 0;       // batches left on the four-launch path after a give-up (other sessions are holding CUs: do not walk into the same wait again)
+  void load_env() {             // debug / ablation switches, re-read at every session creation
+    gemm_reload_env();
+    if (const char* e = getenv("ASR_NO_GRAPH")) use_graph = !(e[0] == '1');
+    if (const char* e = getenv("ASR_SANM_FUSED")) use_fused = !(e[0] == '0');
+    if (const char* e = getenv("ASR_SANM_BLOCK")) use_block = !(e[0] == '0');
+    if (const char* e = getenv("ASR_FBANK_SPLIT")) use_fbank_split = !(e[0] == '0');
+    if (const char* e = getenv("ASR_SANM_BLOCK_SCATTER")) block_scatter = e[0] == '1';
+    if (const char* e = getenv("ASR_SANM_BLOCK_FAULT")) block_fault = e[0] == '1';
+    if (const char* e = getenv("ASR_SANM_BLOCK_DBG")) block_dbg = atoi(e);
+    if (const char* e = getenv("ASR_SANM_BLOCK_MIN")) block_min_utts = atoi(e);
+    if (const char* e = getenv("ASR_LN_FUSED")) use_ln_alg = !(e[0] == '0');
+  }
   int block_scatter = 0;        // ASR_SANM_BLOCK_SCATTER=1: test placement, every cluster spread over four XCDs
   int block_min_utts = 48;      // ASR_SANM_BLOCK_MIN=<windows>: smallest batch that takes the block kernel
   DeviceBuffer d_times; int block_dbg = -1;   // ASR_SANM_BLOCK_DBG=<block index>: phase clock of that block's launch on stderr
@@ -274,7 +287,7 @@ void SvSession::enqueue(const SvRunCtx& r) {
   // (it has its own tiling, so unlike `alg` it does not need batches of near-full windows: ragged batches qualify too)
   bool blk = false;
   if constexpr (sizeof(T) == 2)
-    blk = use_block && use_ln_alg && use_fused && blocks[c.n_blocks - 1].cqkv && blocks[c.n_blocks - 1].c1 && c.n_blocks > 1 &&
+    blk = use_block && block_cooldown == 0 && use_ln_alg && use_fused && blocks[c.n_blocks - 1].cqkv && blocks[c.n_blocks - 1].c1 && c.n_blocks > 1 &&
           r.batch >= block_min_utts &&          // four workgroups per window: a small batch leaves most CUs idle (one window: 4 of 256), the tiled GEMMs do not
           sanm_block_supported(r.max_T, c.d_head, c.n_heads, d, dff, c.fsmn_kernel);
   const size_t flag_words = (size_t)c.n_blocks * r.batch * 4;
@@ -696,6 +709,7 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   r.d_qb_q0 = r.d_qb_utt + n_qb;
   r.d_row_utt = r.d_qb_q0 + n_qb;
   mix((uint64_t)batch); mix((uint64_t)max_tokens); mix((uint64_t)(uintptr_t)r.d_aud); mix(ws_epoch); mix((uint64_t)(uintptr_t)stream);
+  mix((uint64_t)(block_cooldown > 0));        // a session cooling down after a cluster give-up replays the four-launch capture, not the block one
 
   // ---- launch: eager the first time a geometry is seen (allocations settle), then capture once and replay ----
   // 570 launches per forward are host-launch-bound when issued eagerly (~13 us each); replay costs ~1 us per node.
@@ -756,11 +770,12 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
     if (blk_err != 0 && use_block) {
       if (block_giveups++ == 0)
         fprintf(stderr, "[asr_mi355x] sanm_block: a workgroup gave up waiting for its cluster; the batch is redone on the four-launch path\n");
-      use_block = false;
-      try { enqueue<T>(r); HIP_CHECK(hipStreamSynchronize(stream)); } catch (...) { use_block = true; throw; }
-      use_block = true;
+      block_cooldown = 16;                       // this batch and the next ones stay on the four-launch path
+      enqueue<T>(r);
+      HIP_CHECK(hipStreamSynchronize(stream));
       memcpy(&blk_err, (unsigned char*)h_out + (size_t)batch * max_tokens * 4 + (size_t)batch * 4, 4);
     }
+    else if (block_cooldown > 0) --block_cooldown;
     ASR_REQUIRE(blk_err == 0, "sensevoice: a SANM block workgroup gave up waiting for its cluster (results are invalid)");
   }
   memcpy(num_out, (unsigned char*)h_out + (size_t)batch * max_tokens * 4, (size_t)batch * 4);
@@ -1126,16 +1141,7 @@ extern "C" int asr_sensevoice_create(const asr_sensevoice_config* cfg, const voi
       s->device = device_id;
       s->precision = precision;
       s->cfg = *cfg;
-      gemm_reload_env();
-      if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
-      if (const char* e = getenv("ASR_SANM_FUSED")) s->use_fused = !(e[0] == '0');
-      if (const char* e = getenv("ASR_SANM_BLOCK")) s->use_block = !(e[0] == '0');
-      if (const char* e = getenv("ASR_FBANK_SPLIT")) s->use_fbank_split = !(e[0] == '0');
-      if (const char* e = getenv("ASR_SANM_BLOCK_SCATTER")) s->block_scatter = e[0] == '1';
-      if (const char* e = getenv("ASR_SANM_BLOCK_FAULT")) s->block_fault = e[0] == '1';
-      if (const char* e = getenv("ASR_SANM_BLOCK_DBG")) s->block_dbg = atoi(e);
-      if (const char* e = getenv("ASR_SANM_BLOCK_MIN")) s->block_min_utts = atoi(e);
-      if (const char* e = getenv("ASR_LN_FUSED")) s->use_ln_alg = !(e[0] == '0');
+      s->load_env();
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;
       s->arena.load(arena, arena_bytes, arena_mem, s->stream);
@@ -1188,16 +1194,7 @@ extern "C" int asr_paraformer_create(const asr_paraformer_config* cfg, const voi
       c.lfr_m = cfg->lfr_m; c.lfr_n = cfg->lfr_n; c.d_model = cfg->d_model; c.n_heads = cfg->n_heads; c.d_head = cfg->d_head; c.d_ffn = cfg->d_ffn;
       c.n_blocks = cfg->n_blocks; c.n_main = cfg->n_blocks; c.fsmn_kernel = cfg->fsmn_kernel; c.vocab = cfg->vocab; c.blank_id = -1;
       c.n_prompt = 0; c.n_languages = 0; c.max_audio_len = cfg->max_audio_len;
-      gemm_reload_env();
-      if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
-      if (const char* e = getenv("ASR_SANM_FUSED")) s->use_fused = !(e[0] == '0');
-      if (const char* e = getenv("ASR_SANM_BLOCK")) s->use_block = !(e[0] == '0');
-      if (const char* e = getenv("ASR_FBANK_SPLIT")) s->use_fbank_split = !(e[0] == '0');
-      if (const char* e = getenv("ASR_SANM_BLOCK_SCATTER")) s->block_scatter = e[0] == '1';
-      if (const char* e = getenv("ASR_SANM_BLOCK_FAULT")) s->block_fault = e[0] == '1';
-      if (const char* e = getenv("ASR_SANM_BLOCK_DBG")) s->block_dbg = atoi(e);
-      if (const char* e = getenv("ASR_SANM_BLOCK_MIN")) s->block_min_utts = atoi(e);
-      if (const char* e = getenv("ASR_LN_FUSED")) s->use_ln_alg = !(e[0] == '0');
+      s->load_env();
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;
       s->arena.load(arena, arena_bytes, arena_mem, s->stream);

@@ -390,7 +390,9 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
   if constexpr (sizeof(T) == 2) {
     if (fp8 && fp8_kv) {
       ProfScope ps(prof, "quant_crosskv", stream);
-      { void* before = d_cross8.ptr; d_cross8.reserve((size_t)2 * Ld * H * Mpad * 64, stream); d_cscale.reserve((size_t)2 * Ld * H * B * 4, stream); if (d_cross8.ptr != before) ++ws_epoch; }
+      { void* before = d_cross8.ptr; void* before_s = d_cscale.ptr;      // either buffer moving invalidates the captured decode graph (the scales grow with B, the bytes with the rows)
+        d_cross8.reserve((size_t)2 * Ld * H * Mpad * 64, stream); d_cscale.reserve((size_t)2 * Ld * H * B * 4, stream);
+        if (d_cross8.ptr != before || d_cscale.ptr != before_s) ++ws_epoch; }
       launch_quantize_crosskv_fp8(d_cross.as<bf16_t>(), (size_t)Mpad * 64, 2 * Ld * H, d_plan.as<UttPlan>(), B, d_cross8.as<unsigned char>(), d_cscale.as<float>(),
                                   fp8_fake ? 1 : 0, stream);
     }

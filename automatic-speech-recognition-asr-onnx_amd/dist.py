@@ -17,6 +17,9 @@ import torch
 import torch.distributed as dist
 
 
+_GATHER_OK = None        # gather vs send / recv: decided ONCE per process group, by every rank together (a per-call try / except could split the ranks)
+
+
 def init_from_env(backend: str | None = None):
     """Returns (rank, local_rank, world_size). Initialises the process group when WORLD_SIZE > 1."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -30,6 +33,8 @@ def init_from_env(backend: str | None = None):
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        global _GATHER_OK
+        _GATHER_OK = None                      # a new process group decides again
     return rank, local_rank, world
 
 
@@ -84,19 +89,36 @@ def unpack_hypotheses(slab: np.ndarray) -> list[np.ndarray]:
     return [row[1:1 + row[0]].copy() for row in slab]
 
 
+def _backend_has_gather(device: torch.device) -> bool:
+    """Probe c10d.gather on a one-element tensor; the verdict is all-reduced (MIN) so that every rank takes the same path afterwards."""
+    global _GATHER_OK
+    if _GATHER_OK is None:
+        ok = 1
+        try:
+            t = torch.zeros(1, dtype=torch.int32, device=device)
+            bucket = [torch.empty_like(t) for _ in range(dist.get_world_size())] if dist.get_rank() == 0 else None
+            dist.gather(t, bucket, dst=0)
+        except (RuntimeError, NotImplementedError):
+            ok = 0
+        v = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        _GATHER_OK = bool(int(v.item()))
+    return _GATHER_OK
+
+
 def gather_hypotheses(slab: np.ndarray, device: torch.device, dst: int = 0):
     """All ranks pass equal-shaped slabs; rank `dst` gets the list of per-rank slabs (others None). A true gather (the bytes move
-    once, to `dst` only): c10d's gather on both backends (on RCCL it is a group of point-to-point sends), with plain send / recv as
-    the fallback should the backend lack it."""
+    once, to `dst` only): c10d's gather on both backends (on RCCL it is a group of point-to-point sends), with plain send / recv for a
+    backend that lacks it -- which of the two is decided once, collectively (`_backend_has_gather`)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
         return [slab]
     rank = dist.get_rank()
     t = torch.from_numpy(np.ascontiguousarray(slab)).to(device)
     bucket = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-    try:
+    if _backend_has_gather(device):
         dist.gather(t, bucket, dst=dst)
-    except (RuntimeError, NotImplementedError):
+    else:
         if rank == dst:
             bucket[dst].copy_(t)
             for src in range(world):

@@ -71,3 +71,30 @@ def test_broadcast_and_gather_world2(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok").read_text() == "ok"
+
+
+def test_bench_self_launches_under_torchrun():
+    """`python bench.py --gpus 2` with no launcher in the environment re-executes itself under torch.distributed.run (127.0.0.1 rendezvous):
+    two ranks start, meet at the barrier, rank 0 prints ONE JSON line with n_gpus = 2 (ASR_BENCH_DRYRUN=1: the step loop's launch / clock path
+    on gloo, no GPU work). The round-2 bench died on `assert world == args.gpus` here."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ASR_BENCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+
+
+def test_bench_self_launch_command_shape():
+    import importlib.util, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    cmd = b.self_launch_command(4, ["--gpus", "4", "--steps", "7"], port=12345)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "12345" and cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py")

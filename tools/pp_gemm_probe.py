@@ -37,6 +37,10 @@ for (M, N, K) in [(256, 256, 128), (512, 512, 256), (300, 256, 384), (1000, 768,
     ok &= check(M, N, K, 8, add=True, seed=1)
     ok &= check(M, N, K, 12, seed=3)                  # 32 x 32 x 16 MFMA variant
     ok &= check(M, N, K, 16, add=True, seed=4)
+    ok &= check(M, N, K, 108, seed=5)                 # persistent form
+    ok &= check(M, N, K, 108, add=True, seed=6)
+ok &= check(9000, 2560, 1280, 108, seed=7)            # several tiles per workgroup
+ok &= check(9000, 2560, 1280, 108, add=True, seed=8)
 ok &= check(777, 512, 512, 8, act=1, seed=2)
 print("CORRECTNESS", "PASS" if ok else "FAIL", flush=True)
 
@@ -50,7 +54,7 @@ except Exception:
     torch = None
 for name, M, N, K in shapes:
     row = []
-    for v, ep in ((8, 0), (12, 0), (8, 2), (16, 2), (7, 0)):
+    for v, ep in ((8, 0), (108, 0), (8, 2), (108, 2)):
         try:
             best = min(eng.op_gemm_bench(M, N, K, v, ep, 20) for _ in range(3))
             row.append(f"v{v}/e{ep}: {best*1e3:7.1f} us {2*M*N*K/best/1e9:6.0f} TF")

@@ -46,9 +46,13 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
   const int frow = lane & 15, fgrp = lane >> 4;
   const int n0 = blockIdx.x * 16 * NT;
   const int KS = gridDim.y, ks = blockIdx.y;
-  const int kslice = g.K / (DW * KS);                  // multiple of 32 (host-checked)
   const int kw = (wave + (int)blockIdx.x) & (DW - 1);    // rotate the wave -> slice map per workgroup: the shared activation rows are not hit in lock-step
-  const int k_begin = (ks * DW + kw) * kslice;
+  // K in steps of 32: this workgroup's share of the steps, then this wave's share of those (shares differ by at most one step, so any split
+  // count divides any K)
+  const int steps = g.K >> 5;
+  const int wg_lo = steps * ks / KS, wg_n = steps * (ks + 1) / KS - wg_lo;
+  const int w_lo = wg_lo + wg_n * kw / DW, w_hi = wg_lo + wg_n * (kw + 1) / DW;
+  const int k_begin = w_lo * 32, kslice = (w_hi - w_lo) * 32;
   const bf16_t* wp = g.W + (size_t)(n0 + frow) * g.ldw + k_begin + fgrp * 8;
   const unsigned char* wp8 = g.W8 + (size_t)(n0 + frow) * g.ldw + k_begin + fgrp * 8;     // (W8: ldw counts bytes = elements)
   const bf16_t* ap = g.A + (size_t)frow * g.lda + k_begin + fgrp * 8;
@@ -121,11 +125,23 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
     for (int w = 1; w < DW; ++w) { const float4 q = red[(w * TILES + tile) * 64 + lane]; sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w; }
   }
   const int rows16 = MT * 16;
+  float fold_s1 = 0.0f, fold_s2 = 0.0f;              // FOLD with K split across workgroups: the statistics summed over the splits
   if (KS > 1) {            // hand the partial tiles over (write-through, 16 bytes per lane); the last workgroup of this column granule finishes
     if (wave < TILES) {
       float* dst = g.ws + ((size_t)ks * rows16 + ti * 16 + frow) * g.N + n0 + tj * 16 + fgrp * 4;
       const f32x4_t v = {sum.x, sum.y, sum.z, sum.w};
       asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+    }
+    float2* stat_ws = reinterpret_cast<float2*>(g.ws + (size_t)KS * rows16 * g.N) + ((size_t)blockIdx.x * KS) * rows16;   // [granule][split][row]
+    if constexpr (FOLD) {                             // this workgroup's (sum x, sum x^2) over its K share, waves added in a fixed order
+      if (wave < MT && fgrp == 0) {
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < DW; ++w) { const float2 q = st[w * MT * 16 + wave * 16 + frow]; s1 += q.x; s2 += q.y; }
+        const u32x2_t v = {__float_as_uint(s1), __float_as_uint(s2)};
+        float2* dst = stat_ws + (size_t)ks * rows16 + wave * 16 + frow;
+        asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                  // (also: every wave is done with `red`, whose first word now carries the verdict)
@@ -145,6 +161,15 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
         asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(src) : "memory");
         sum.x += q[0]; sum.y += q[1]; sum.z += q[2]; sum.w += q[3];
       }
+      if constexpr (FOLD) {                           // the row's statistics over all splits, in split order, parked where the epilogue looks for wave 0's
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int s3 = 0; s3 < KS; ++s3) {
+          u32x2_t q;
+          asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(stat_ws + (size_t)s3 * rows16 + ti * 16 + frow) : "memory");
+          s1 += __uint_as_float(q[0]); s2 += __uint_as_float(q[1]);
+        }
+        fold_s1 = s1; fold_s2 = s2;
+      }
     }
   }
   if (wave >= TILES) return;
@@ -157,8 +182,11 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
   }
   if constexpr (FOLD) {                                  // rstd (x W^T - mean c): statistics summed over the waves in a fixed order
     float s1 = 0.0f, s2 = 0.0f;
+    if (KS > 1) { s1 = fold_s1; s2 = fold_s2; }
+    else {
 #pragma unroll
-    for (int w = 0; w < DW; ++w) { const float2 q = st[w * MT * 16 + m]; s1 += q.x; s2 += q.y; }
+      for (int w = 0; w < DW; ++w) { const float2 q = st[w * MT * 16 + m]; s1 += q.x; s2 += q.y; }
+    }
     const float inv_k = 1.0f / (float)g.K;
     const float mean = s1 * inv_k;
     const float rstd = rsqrtf(fmaxf(s2 * inv_k - mean * mean, 0.0f) + g.ln_eps);
@@ -214,33 +242,42 @@ void launch_inst(const DecGemmArgs& g, int splits, hipStream_t s) {
 }  // namespace
 
 bool decode_gemm_supported(const DecGemmArgs& g) {
-  return g.M >= 1 && g.M <= 64 && g.N % 32 == 0 && g.K % (32 * DW) == 0 && (g.lda * 2) % 16 == 0 && (g.ldw * (g.W8 ? 1 : 2)) % 16 == 0 && !(g.colsum && !g.A) &&
+  return g.M >= 1 && g.M <= 64 && g.N % 32 == 0 && g.K % 32 == 0 && g.K >= 32 * DW && (g.lda * 2) % 16 == 0 && (g.ldw * (g.W8 ? 1 : 2)) % 16 == 0 && !(g.colsum && !g.A) &&
          !(g.W8 && !g.w_scale);
 }
 
-// grid shape: column granules of 16 NT, K split across `splits` workgroups -- at most one even round of the chip's CUs
+// grid shape: column granules of 16 NT, K split across `splits` workgroups -- at most one even round of the chip's CUs.
+// A workgroup pulls (16 NT weight rows + the activation rows) x its K share through one CU's L2 path (the rows come once per granule), and a
+// split costs a hand-over (partial tiles written through, a ticket, the last arriver re-reading `splits` tiles): the plan minimises
+//   bytes per workgroup / RATE + (splits > 1 ? HAND + splits * PER_SPLIT : 0)
+// over NT in {1, 2} and the split counts that keep granules x splits within one round; constants from tools/probes/decode_split_sweep.sh.
 void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits) {
   const int cus = 256;
-  int NT = g.N / 16 > cus ? 2 : 1;                      // 32-column granules where 16-column ones would overflow the chip (33..64 rows: 4 x 2 output tiles = the 8 finishing waves)
-  int granules = g.N / (16 * NT), best = 1;
+  static const int force_nt = getenv("ASR_DECODE_NT") ? atoi(getenv("ASR_DECODE_NT")) : 0;          // tuning hooks
+  static const int force_ks = getenv("ASR_DECODE_KS") ? atoi(getenv("ASR_DECODE_KS")) : 0;
   const int ws_rows = g.M <= 16 ? 16 : g.M <= 32 ? 32 : 64;      // rows per split slab as the kernel addresses them: [ks][MT * 16][N]
-  if (!g.colsum && g.ws && g.cnt) {                     // (the folded LayerNorm needs whole rows in one workgroup: K is never split there)
-    for (int sp : {2, 3, 4, 5, 6, 8, 10}) {
-      if (g.K % (32 * DW * sp) != 0 || granules * sp > cus) continue;
-      if ((size_t)sp * ws_rows * g.N * 4 > g.ws_bytes) continue;
-      // a split pays once the un-split workgroup streams much more than a CU moves in the time a hand-over costs (~2 us ~ 80 KB)
-      const size_t per_wg = (size_t)(16 * NT + ((g.M + 15) / 16 * 16)) * g.K * 2 / best;
-      if (per_wg < 160 * 1024) break;
-      best = sp;
-    }
-    // N = 1280, K = 5120 at NT = 1 reaches only 240 workgroups with 3 splits (K % 768 != 0): wider granules + more splits cover the chip better
-    if (g.M <= 32 && g.N / 16 <= 128 && g.K >= 4096 && NT == 1) {
-      for (int sp : {5, 4, 6, 8}) {
-        if (g.K % (32 * DW * sp) == 0 && (g.N / 32) * sp <= cus && (size_t)sp * 32 * g.N * 4 <= g.ws_bytes && (g.N / 32) * sp > granules * best) { NT = 2; best = sp; break; }
-      }
+  const int mt = ws_rows / 16;
+  const bool can_split = g.ws && g.cnt;
+  double best_cost = 1e30;
+  int best_nt = 1, best_ks = 1;
+  for (int NT = 1; NT <= 2; ++NT) {
+    if (g.N % (16 * NT) != 0 || mt * NT > DW) continue;          // one finishing wave per 16 x 16 output tile
+    if (force_nt && NT != force_nt) continue;
+    const int granules = g.N / (16 * NT);
+    for (int sp = 1; sp <= 16; ++sp) {
+      if (force_ks && sp != force_ks) continue;
+      if (sp > 1 && (!can_split || (g.K >> 5) < sp * 2)) break;
+      if (granules * sp > cus && !(sp == 1 && NT == 2)) continue;                                      // more than a round: only as the last resort (NT = 2, no split)
+      if (sp > 1 && (size_t)sp * ws_rows * g.N * 4 + (size_t)granules * sp * ws_rows * 8 > g.ws_bytes) continue;
+      const double bytes = (double)(16 * NT + ws_rows) * g.K * 2 / sp;
+      const double rounds = (granules * sp + cus - 1) / cus;
+      // us: ~45 GB/s per CU; a hand-over costs ~2 us (2.8 with the statistics of a folded LayerNorm) + 0.1 us per split tile the last arriver
+      // re-reads -- measured on the Whisper shapes at 32 / 64 rows: out-proj 6.7 (no split) vs 6.9 (3 splits) at 32 rows, 9.2 vs 8.0 at 64
+      double cost = rounds * bytes / 45e3 + (sp > 1 ? (g.colsum ? 2.8 : 2.0) + 0.1 * sp : 0.0);
+      if (cost < best_cost) { best_cost = cost; best_nt = NT; best_ks = sp; }
     }
   }
-  *nt = NT; *splits = best;
+  *nt = best_nt; *splits = best_ks;
 }
 
 void launch_decode_gemm(const DecGemmArgs& g, hipStream_t s) {

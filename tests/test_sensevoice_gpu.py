@@ -380,3 +380,43 @@ def test_a_cluster_that_gives_up_is_redone_on_the_four_launch_path(monkeypatch, 
     again = sess.run(audios, langs)                       # the message appears once per session; the retry happens every time
     assert all(np.array_equal(a, b) for a, b in zip(again, ref))
     assert "redone" not in capfd.readouterr().err
+
+
+def test_two_block_kernel_sessions_in_flight_never_stall(capfd):
+    """Two sessions on two HIP streams, each driving batch-64 passes through the one-launch-per-block kernel from its own host thread (the
+    serving shape of pool.SessionPool and of bench.py's `inflight` leg): every pass must return the sequential run's tokens, no cluster may
+    give up (no "redone on the four-launch path" on stderr) and no pass may take more than 3 x the median (a cluster split across dispatch
+    waves would spin for milliseconds before giving up)."""
+    import threading
+    import time
+    cfg, ck = sensevoice_setup("sensevoice_small")
+    eng = sub("engine")
+    B, iters = 64, 50
+    audios = [[kaldi_audio(7700 + 100 * s + i, 128000) for i in range(B)] for s in range(2)]
+    langs = [0] * B
+    sessions = [eng.SenseVoiceSession.from_checkpoint(cfg, ck, precision=BF16) for _ in range(2)]
+    refs = [sessions[s].run(audios[s], langs) for s in range(2)]                 # sequential: one session at a time
+    for s in range(2):
+        sessions[s].run(audios[s], langs)                                       # second pass: the captured graph
+    capfd.readouterr()
+    lat = [[], []]
+    bad = []
+
+    def drive(s):
+        for it in range(iters):
+            t0 = time.perf_counter()
+            got = sessions[s].run(audios[s], langs)
+            lat[s].append(time.perf_counter() - t0)
+            if not all(np.array_equal(a, b) for a, b in zip(got, refs[s])):
+                bad.append((s, it))
+    threads = [threading.Thread(target=drive, args=(s,)) for s in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    err = capfd.readouterr().err
+    assert not bad, f"passes with different tokens than the sequential run: {bad[:5]}"
+    assert "redone on the four-launch path" not in err and "gave up" not in err, err[-500:]
+    for s in range(2):
+        med = float(np.median(lat[s]))
+        assert max(lat[s]) < 3.0 * med, f"session {s}: max {max(lat[s]) * 1e3:.1f} ms vs median {med * 1e3:.1f} ms"

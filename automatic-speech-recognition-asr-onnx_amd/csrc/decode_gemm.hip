@@ -271,9 +271,10 @@ void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits) {
       if (sp > 1 && (size_t)sp * ws_rows * g.N * 4 + (size_t)granules * sp * ws_rows * 8 > g.ws_bytes) continue;
       const double bytes = (double)(16 * NT + ws_rows) * g.K * 2 / sp;
       const double rounds = (granules * sp + cus - 1) / cus;
-      // us: ~45 GB/s per CU; a hand-over costs ~2 us (2.8 with the statistics of a folded LayerNorm) + 0.1 us per split tile the last arriver
-      // re-reads -- measured on the Whisper shapes at 32 / 64 rows: out-proj 6.7 (no split) vs 6.9 (3 splits) at 32 rows, 9.2 vs 8.0 at 64
-      double cost = rounds * bytes / 45e3 + (sp > 1 ? (g.colsum ? 2.8 : 2.0) + 0.1 * sp : 0.0);
+      // us: ~45 GB/s per CU; a hand-over costs ~2 us (4 with the statistics of a folded LayerNorm) + 0.25 us per split tile the last arriver
+      // re-reads -- measured on the Whisper shapes at 32 / 64 rows: out-proj 6.7 (no split) vs 6.9 (3 splits) at 32 rows, 9.2 vs 8.0 at 64;
+      // cross-q with the fold 9.4 (no split) vs 10.4 (32-column granules x 6 splits) at 64 rows
+      double cost = rounds * bytes / 45e3 + (sp > 1 ? (g.colsum ? 4.0 : 2.0) + 0.25 * sp : 0.0);
       if (cost < best_cost) { best_cost = cost; best_nt = NT; best_ks = sp; }
     }
   }

@@ -87,9 +87,9 @@ def hbm_traffic(kernel):
         return None
 
 
-def mfma_util(kernel):
+def mfma_util(kernel, stem="mfma_util.json"):
     """MFMA pipe utilisation of `kernel` from the committed SQ counter pass (profiles/rNN_mfma_util.json, tools/summarize_sq_pmc.py)."""
-    p = profile_path("mfma_util.json")
+    p = profile_path(stem)
     try:
         with open(p) as f:
             ks = json.load(f)["kernels"]
@@ -97,8 +97,13 @@ def mfma_util(kernel):
         if rec is None:                                   # template instances are keyed with their arguments ("sanm_block_kernel<false>")
             cand = [k for k in ks if k.startswith(kernel + "<") or k.startswith(kernel + "(")]
             rec = ks[max(cand, key=lambda k: ks[k].get("launches", 0))] if cand else None
-        return None if rec is None else {"mfma_busy_frac": rec["mfma_util"], "wave_cycles": {k: rec[k] for k in ("wait_any_share", "wait_inst_any_share",
-                                         "active_inst_share")}, "source": os.path.relpath(p, ROOT)}
+        if rec is None:
+            return None
+        out = {"mfma_busy_frac": rec["mfma_util"], "wave_cycles": {k: rec[k] for k in ("wait_any_share", "wait_inst_any_share", "active_inst_share")},
+               "source": os.path.relpath(p, ROOT)}
+        if "effective_clock_ghz" in rec:                  # GRBM_GUI_ACTIVE cycles / kernel-trace duration: the clock the chip held under this kernel
+            out["effective_clock_ghz"] = rec["effective_clock_ghz"]
+        return out
     except (OSError, KeyError, ValueError, TypeError):
         return None
 
@@ -877,8 +882,10 @@ def main_whisper(args):
             "rtf": round(elapsed / (audio_s * args.steps), 7),
             "ms": {k: round(v / args.steps * 1e3, 2) for k, v in t_parts.items()},
             "decode_ms_per_token": round(t_dec / max(n_tok - 1, 1) * 1e3, 3),
-            "roofline": {"bound": "mfma", "kernel": "encoder GEMM launches: qkv / out / fc1 / fc2 / cross-KV (gemm_bf16_big 256x256 tiles where they fill whole rounds, else gemm_bf16_t144 / gemm_bf16_pipe)", "achieved": round(achieved, 1),
-                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None},
+            "roofline": {"bound": "mfma", "kernel": "encoder GEMM launches: qkv / out / fc1 / fc2 / cross-KV (gemm_bf16_ppp: persistent ping-pong 256 x 256 tiles, csrc/gemm_pp.hip, "
+                                                      "where they fill whole rounds of the chip, else gemm_bf16_t144 / gemm_bf16_pipe)", "achieved": round(achieved, 1),
+                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "pmc": mfma_util("gemm_bf16_ppp", "whisper_mfma_util.json")},
             "roofline_decode": {"bound": "hbm", "kernel": "decode step (weights + cross-KV stream)",
                                 "achieved": round(alg["decode_bytes_per_step"] / (t_dec / max(n_tok - 1, 1)) / 1e9, 1),
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",

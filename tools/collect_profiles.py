@@ -29,4 +29,9 @@ if glob.glob(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv")):
     subprocess.run([sys.executable, "tools/summarize_pmc.py", src, f"profiles/{rnd}_hbm_traffic.json"], check=True)
 if glob.glob(os.path.join(src, "pmc_sq", "*", "*_counter_collection.csv")):
     subprocess.run([sys.executable, "tools/summarize_sq_pmc.py", os.path.join(src, "pmc_sq"), f"profiles/{rnd}_mfma_util.json"], check=True)
+if glob.glob(os.path.join(src, "pmc_sq_whisper", "*", "*_counter_collection.csv")):
+    subprocess.run([sys.executable, "tools/summarize_sq_pmc.py", os.path.join(src, "pmc_sq_whisper"), f"profiles/{rnd}_whisper_mfma_util.json"], check=True)
+p = os.path.join(src, "pp_gemm_probe.txt")
+if os.path.isfile(p):
+    shutil.copy(p, f"profiles/{rnd}_pp_gemm_probe.txt")
 print(sorted(f for f in os.listdir("profiles") if f.startswith(rnd)))

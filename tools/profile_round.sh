@@ -28,6 +28,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extras > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extras > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq_whisper -- python $R/bench.py --workload whisper --batch 64 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq_whisper.log 2>&1
+python $R/tools/pp_gemm_probe.py > $OUT/pp_gemm_probe.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_whisper -- python $R/bench.py --workload whisper --steps 2 --warmup 2 --no-cpu-baseline > $OUT/stats_whisper.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_whisper30 -- python $R/bench.py --workload whisper --seconds 30 --steps 2 --warmup 2 --no-cpu-baseline > $OUT/stats_whisper30.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_qwen -- python $R/bench.py --workload qwen --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats_qwen.log 2>&1

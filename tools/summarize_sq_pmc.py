@@ -10,10 +10,13 @@ out_path = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_mfma_util.json"
 f = sorted(glob.glob(f"{src}/*/*_counter_collection.csv"), key=os.path.getmtime)[-1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 seen = collections.defaultdict(set)
+dur = collections.defaultdict(float)                  # kernel-trace durations (ns) per class, one per dispatch
 for r in csv.DictReader(open(f)):
     name = r["Kernel_Name"]
     cls = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:64]
     agg[cls][r["Counter_Name"]] += float(r["Counter_Value"])
+    if r["Dispatch_Id"] not in seen[cls] and "End_Timestamp" in r:
+        dur[cls] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     seen[cls].add(r["Dispatch_Id"])
 CUS, SIMDS, XCDS = 256, 4, 8
 out = {"source": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS "
@@ -30,6 +33,8 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"]):
                          "wait_any_share": round(v["SQ_WAIT_ANY"] / wave, 3), "wait_inst_any_share": round(v["SQ_WAIT_INST_ANY"] / wave, 3),
                          "active_inst_share": round(v["SQ_ACTIVE_INST_ANY"] / wave, 3), "wait_inst_lds_share": round(v["SQ_WAIT_INST_LDS"] / wave, 3),
                          "lds_bank_conflict_per_cu_cycle": round(v["SQ_LDS_BANK_CONFLICT"] / (gui / XCDS * CUS), 4)}
+    if dur[k] > 0:       # GPU-active cycles / wall time of the same dispatches: the clock the chip actually ran at under this kernel (power management)
+        out["kernels"][k]["effective_clock_ghz"] = round(gui / XCDS / dur[k], 3)
 # the class the bench's roofline names: every 144-row-tile GEMM launch together
 t = collections.defaultdict(float); nl = 0
 for k, v in agg.items():

@@ -86,7 +86,8 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
 
 template <typename OutT, int ACT, int EPI, int NJ, int MI = 4>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[MI][NJ], int m_wave, int n_wave, int lane,
-                                              const float2* ln_stats = nullptr) {   // (mean, rstd) of row m_wave + i, in LDS
+                                              const float2* ln_stats = nullptr,     // (mean, rstd) of row m_wave + i, in LDS
+                                              const float* bias_at = nullptr) {     // non-null: the bias vector is read from here (e.g. a copy staged in LDS) instead of g.bias
   static_assert(NJ % 2 == 0, "fragments are paired");
   const int frow = lane & 15, fgrp = lane >> 4;
   const bool has_bias = epi_has<EPI, E_BIAS>(g.bias), has_add = epi_has<EPI, E_ADD>(g.add), has_add2 = epi_has<EPI, E_ADD2>(g.add2);
@@ -126,7 +127,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[
     const int n = n_wave + p * 32 + fgrp * 8;              // this lane's 8 consecutive columns
     float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (has_bias) {
-      const float4 lo = *reinterpret_cast<const float4*>(g.bias + n), hi = *reinterpret_cast<const float4*>(g.bias + n + 4);
+      const float* bp = bias_at ? bias_at : g.bias;
+      const float4 lo = *reinterpret_cast<const float4*>(bp + n), hi = *reinterpret_cast<const float4*>(bp + n + 4);
       b8[0] = lo.x; b8[1] = lo.y; b8[2] = lo.z; b8[3] = lo.w; b8[4] = hi.x; b8[5] = hi.y; b8[6] = hi.z; b8[7] = hi.w;
     }
     float c8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

@@ -25,11 +25,14 @@ for w in ("whisper", "qwen"):
     p = os.path.join(src, f"{w}_trace_summary.txt")
     if os.path.isfile(p):
         shutil.copy(p, f"profiles/{rnd}_{w}_trace_summary.txt")
-if glob.glob(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv")):
+for j in ("hbm_traffic.json", "mfma_util.json", "whisper_mfma_util.json"):          # folded on the GPU box by profile_round.sh
+    if os.path.isfile(os.path.join(src, j)) and os.path.getsize(os.path.join(src, j)) > 50:
+        shutil.copy(os.path.join(src, j), f"profiles/{rnd}_{j}")
+if not os.path.isfile(os.path.join(src, "hbm_traffic.json")) and glob.glob(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv")):
     subprocess.run([sys.executable, "tools/summarize_pmc.py", src, f"profiles/{rnd}_hbm_traffic.json"], check=True)
-if glob.glob(os.path.join(src, "pmc_sq", "*", "*_counter_collection.csv")):
+if not os.path.isfile(os.path.join(src, "mfma_util.json")) and glob.glob(os.path.join(src, "pmc_sq", "*", "*_counter_collection.csv")):
     subprocess.run([sys.executable, "tools/summarize_sq_pmc.py", os.path.join(src, "pmc_sq"), f"profiles/{rnd}_mfma_util.json"], check=True)
-if glob.glob(os.path.join(src, "pmc_sq_whisper", "*", "*_counter_collection.csv")):
+if not os.path.isfile(os.path.join(src, "whisper_mfma_util.json")) and glob.glob(os.path.join(src, "pmc_sq_whisper", "*", "*_counter_collection.csv")):
     subprocess.run([sys.executable, "tools/summarize_sq_pmc.py", os.path.join(src, "pmc_sq_whisper"), f"profiles/{rnd}_whisper_mfma_util.json"], check=True)
 p = os.path.join(src, "pp_gemm_probe.txt")
 if os.path.isfile(p):

@@ -35,6 +35,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_whisper30 -- 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_qwen -- python $R/bench.py --workload qwen --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats_qwen.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_paraformer -- python $R/bench.py --workload paraformer --steps 10 --warmup 3 --no-cpu-baseline > $OUT/stats_paraformer.log 2>&1
 for w in whisper qwen; do for f in $(find $OUT/stats_$w -name "*kernel_trace.csv"); do python $R/tools/trace_summary.py $f > $OUT/${w}_trace_summary.txt; done; done
-find $OUT -name "*kernel_trace.csv" -size +8M -delete
+# fold the counter passes here (the raw per-dispatch CSVs are tens of MB; gpurun copies back at most 64 MiB)
+python $R/tools/summarize_pmc.py $OUT $OUT/hbm_traffic.json > $OUT/summarize_pmc.log 2>&1
+python $R/tools/summarize_sq_pmc.py $OUT/pmc_sq $OUT/mfma_util.json > $OUT/summarize_sq.log 2>&1
+python $R/tools/summarize_sq_pmc.py $OUT/pmc_sq_whisper $OUT/whisper_mfma_util.json > $OUT/summarize_sq_whisper.log 2>&1
+find $OUT -name "*kernel_trace.csv" -size +4M -delete
+find $OUT -name "*counter_collection.csv" -size +2M -delete
 find $OUT -name "*.csv" | head -40
 du -sh $OUT

@@ -215,6 +215,59 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[
   }
 }
 
+// ---- bias (+ activation) -> operand-dtype store for the 16 x 16 swapped layout with FULL-LINE stores. In epilogue_rows a store instruction covers
+// 16 rows x 64 B (the four lanes of a row hold 32 consecutive columns): sixteen half cache lines per wave-instruction (cdna_hip_programming.md T21). Here the two 32-column halves of a row meet in one instruction:
+// lanes of fragment rows 0..7 and 8..15 swap one half through a DPP row rotate (row_ror:8 pairs lane r with lane r ^ 8 of its 16-lane row), so
+// instruction A writes rows 0..7 and instruction B rows 8..15 of the fragment, each as eight whole 128-byte lines. Worth 2 % on Whisper fc1 (in-run A/B 309 -> 302 us):
+// what a tile's epilogue really costs is the write burst itself -- every CU stores its 128 KB tile at the same moment, 33 MB at the ~6 TB/s the memory side takes
+// (5 us per tile; the same launch without its stores: 262 us).
+// acc[i][j] as in epilogue_rows (NJ = 4: 64 columns per wave); bias_at: the bias vector (global or an LDS copy); handles the lo_group slab layout.
+__device__ __forceinline__ uint32_t dpp_ror8(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false); }
+
+template <int ACT, int MI>
+__device__ __forceinline__ void epilogue_rows_lo_lines(const GemmArgs& g, f32x4_t (&acc)[MI][4], int m_wave, int n_wave, int lane, const float* bias_at) {
+  const int frow = lane & 15, fgrp = lane >> 4;
+  const bool low = frow < 8;
+  float b8[2][8];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float* bp = bias_at + n_wave + p * 32 + fgrp * 8;
+    const float4 lo = *reinterpret_cast<const float4*>(bp), hi = *reinterpret_cast<const float4*>(bp + 4);
+    b8[p][0] = lo.x; b8[p][1] = lo.y; b8[p][2] = lo.z; b8[p][3] = lo.w; b8[p][4] = hi.x; b8[p][5] = hi.y; b8[p][6] = hi.z; b8[p][7] = hi.w;
+  }
+  bf16_t* const out = reinterpret_cast<bf16_t*>(g.out_lo);
+  const int ncol = n_wave + (low ? 0 : 32) + fgrp * 8;            // both instructions: this lane's 8 columns
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    uint4 w[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * p][r] + b8[p][r]; v[4 + r] = acc[i][2 * p + 1][r] + b8[p][4 + r]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if constexpr (ACT == ACT_GELU_ERF) v[e] = gelu_erf_fast(v[e]); else v[e] = apply_act_ct<ACT>(v[e]);
+      }
+      w[p].x = pack_bf16x2(v[0], v[1]); w[p].y = pack_bf16x2(v[2], v[3]); w[p].z = pack_bf16x2(v[4], v[5]); w[p].w = pack_bf16x2(v[6], v[7]);
+    }
+    const uint4 send = low ? w[1] : w[0];
+    uint4 recv;
+    recv.x = dpp_ror8(send.x); recv.y = dpp_ror8(send.y); recv.z = dpp_ror8(send.z); recv.w = dpp_ror8(send.w);
+    const uint4 va = low ? w[0] : recv, vb = low ? recv : w[1];
+    const int ma = m_wave + i * 16 + (frow & 7), mb = ma + 8;
+    if (g.dbg & 8) { asm volatile("" ::"v"(va.x), "v"(va.y), "v"(va.z), "v"(va.w), "v"(vb.x), "v"(vb.y), "v"(vb.z), "v"(vb.w)); continue; }      // timing probe: everything but the stores
+    if (g.lo_group > 0) {
+      bf16_t* o = out + (size_t)(ncol / g.lo_group) * g.ld_out_lo + (ncol % g.lo_group);
+      if (ma < g.M) *reinterpret_cast<uint4*>(o + (size_t)ma * g.lo_group) = va;
+      if (mb < g.M) *reinterpret_cast<uint4*>(o + (size_t)mb * g.lo_group) = vb;
+    } else {
+      if (ma < g.M) *reinterpret_cast<uint4*>(out + (size_t)ma * g.ld_out_lo + ncol) = va;
+      if (mb < g.M) *reinterpret_cast<uint4*>(out + (size_t)mb * g.ld_out_lo + ncol) = vb;
+    }
+  }
+}
+
 // ---- un-swapped orientation: acc[i][j][r] = C[m_wave + 16 i + 4 (lane >> 4) + r][n_wave + frag_col(j, lane & 15)]
 template <typename OutT, int NJ>
 __device__ __forceinline__ void epilogue_transposed(const GemmArgs& g, f32x4_t (&acc)[4][NJ], int m_wave, int n_wave, int lane) {

@@ -527,137 +527,6 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(const AttnArgs a, int n_
   }
 }
 
-// ------------------------------------------------------------------------------------ attention (bf16), whole key range in registers
-// Utterances of at most 416 keys (Whisper 8 s chunks: 400 encoder positions; Qwen3-ASR encoder windows: 104): a wave holds the scores of its
-// 16 queries against EVERY key (13 sub-tiles x 8 floats per lane), so the soft-max is one pass -- one row maximum, one exponential per score,
-// no running rescale of the output tile. The flash-style kernel above spends ~70 VALU instructions per 32-key sub-tile and query tile (maximum,
-// two shuffles, nine exponentials, sixteen rescale multiplies) against 8 MFMAs; here it is ~30. K ([keys][64]) and V^T ([64][512-key rows]) take
-// turns in ONE 64 KB LDS region (two workgroups per CU): K lands, S^T = K Q^T for all sub-tiles, barrier, the V^T DMA is issued and flies under the
-// soft-max arithmetic, barrier, O^T = V^T P^T. Fragment conventions are the kernel's above (S^T so that a lane owns one query column; P is
-// directly the B fragment of the second product).
-constexpr int AF_MAXK = 416, AF_NS = AF_MAXK / 32, AF_VROWB = 1024;
-template <int HD>
-__global__ __launch_bounds__(512, 2) void attn_bf16_full_kernel(const AttnArgs a, int n_rows_alloc) {
-  static_assert(HD == 64, "64-wide heads");
-  constexpr int SLOTS = HD / 8, KROWB = HD * 2, K_RPI = 64 / SLOTS;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Ks = smem;
-  unsigned char* Vs = smem;                                  // after the barrier behind the last K read
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), NW = blockDim.x >> 6;
-  const int fq = lane & 15, g = lane >> 4;
-  const int u = a.qb_utt[blockIdx.x], q_base = a.qb_q0[blockIdx.x], h = blockIdx.y;
-  const UttPlan up = a.plan[u];
-  const int T = up.T, row0 = up.row_off;
-  const int q0 = q_base + wave * 16;
-  const bool act = q0 < T;                                   // wave-uniform
-  const int nkeys = (T + 31) & ~31, ns = nkeys >> 5;
-
-  bf16x8_t qf[HD / 32];
-  {
-    const bf16_t* qp = reinterpret_cast<const bf16_t*>(a.q) + (size_t)(row0 + (act ? q0 : 0) + fq) * a.ld_q + h * HD + g * 8;
-#pragma unroll
-    for (int ks = 0; ks < HD / 32; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
-  }
-  const bf16_t* kbase = reinterpret_cast<const bf16_t*>(a.k) + h * HD;
-  const bf16_t* vbase = reinterpret_cast<const bf16_t*>(a.vt) + (size_t)h * HD * a.ld_vt;
-  for (int ii = wave; ii * K_RPI < nkeys; ii += NW) {
-    const int key = ii * K_RPI + lane / SLOTS;
-    const int sslot = (lane % SLOTS) ^ (key & (SLOTS - 1));
-    const int grow = min(row0 + key, n_rows_alloc - 1);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (size_t)grow * a.ld_qk + sslot * 8),
-                                     (__attribute__((address_space(3))) void*)(Ks + ii * 1024), 16, 0, 0);
-  }
-  __syncthreads();                                           // K landed (the barrier drains the LDS-DMA queue)
-  f32x4_t st[AF_NS][2];
-#pragma unroll
-  for (int s = 0; s < AF_NS; ++s) {
-    st[s][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; st[s][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (s < ns && act) {
-      const int key0 = s * 32 + fq, key1 = key0 + 16;
-#pragma unroll
-      for (int ks = 0; ks < HD / 32; ++ks) {
-        const int c = ks * 4 + g;
-        const bf16x8_t kf0 = *reinterpret_cast<const bf16x8_t*>(Ks + key0 * KROWB + ((c ^ (key0 & (SLOTS - 1))) << 4));
-        const bf16x8_t kf1 = *reinterpret_cast<const bf16x8_t*>(Ks + key1 * KROWB + ((c ^ (key1 & (SLOTS - 1))) << 4));
-        st[s][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[ks], st[s][0], 0, 0, 0);
-        st[s][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[ks], st[s][1], 0, 0, 0);
-      }
-    }
-  }
-  __syncthreads();                                           // every wave is done with K: V^T may overwrite it
-  for (int d = wave; d < HD; d += NW) {                      // one 1 KiB V^T row (512 key slots) per wave-instruction
-    const int sslot = lane ^ (d & 15);
-    if (sslot * 8 < nkeys) {
-      const int gcol = min(row0 + sslot * 8, a.ld_vt - 8);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + (size_t)d * a.ld_vt + gcol),
-                                       (__attribute__((address_space(3))) void*)(Vs + d * AF_VROWB), 16, 0, 0);
-    }
-  }
-  // ---- one-pass soft-max over the whole key range (under the V^T DMA)
-  float mx = -INFINITY;
-#pragma unroll
-  for (int s = 0; s < AF_NS; ++s) {
-    if (s < ns) {
-      const int kb = s * 32 + g * 4;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int key = kb + (r & 3) + ((r >> 2) << 4);
-        if (key >= T) st[s][r >> 2][r & 3] = -INFINITY;
-        mx = fmaxf(mx, st[s][r >> 2][r & 3]);
-      }
-    }
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  float l = 0.0f;
-  bf16x8_t pfv[AF_NS];
-#pragma unroll
-  for (int s = 0; s < AF_NS; ++s) {
-    float p[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { p[r] = (s < ns) ? __expf(st[s][r >> 2][r & 3] - mx) : 0.0f; l += p[r]; }
-    union { bf16x8_t v; uint32_t w[4]; } pf;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pf.w[r] = pack_bf16x2(p[2 * r], p[2 * r + 1]);
-    pfv[s] = pf.v;
-  }
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  __syncthreads();                                           // V^T landed
-  f32x4_t ot[HD / 16];
-#pragma unroll
-  for (int dt = 0; dt < HD / 16; ++dt) ot[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  if (act) {
-#pragma unroll
-    for (int s = 0; s < AF_NS; ++s) {
-      if (s < ns) {
-#pragma unroll
-        for (int dt = 0; dt < HD / 16; ++dt) {
-          const int d = dt * 16 + fq;
-          const unsigned char* vr = Vs + d * AF_VROWB + (g & 1) * 8;
-          union { bf16x8_t v; uint2 h2[2]; } vf;
-          vf.h2[0] = *reinterpret_cast<const uint2*>(vr + (((s * 4 + (g >> 1)) ^ (d & 15)) << 4));
-          vf.h2[1] = *reinterpret_cast<const uint2*>(vr + (((s * 4 + 2 + (g >> 1)) ^ (d & 15)) << 4));
-          ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pfv[s], ot[dt], 0, 0, 0);
-        }
-      }
-    }
-    const int qrow = q0 + fq;
-    if (qrow < T) {
-      const float inv = 1.0f / l;
-      bf16_t* op = reinterpret_cast<bf16_t*>(a.ctx) + (size_t)(row0 + qrow) * a.ld_ctx + h * HD + g * 4;
-#pragma unroll
-      for (int dt = 0; dt < HD / 16; ++dt) {
-        uint2 w;
-        w.x = pack_bf16x2(ot[dt][0] * inv, ot[dt][1] * inv);
-        w.y = pack_bf16x2(ot[dt][2] * inv, ot[dt][3] * inv);
-        *reinterpret_cast<uint2*>(op + dt * 16) = w;
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------ attention (f32, verification mode)
 // One wave per query row; lanes over keys for the scores, lanes over d for the context. Plain f32 FMA. A query block of the plan (64 rows)
 // is spread over gridDim.z workgroups (wave w of workgroup z takes rows w + 4 z, w + 4 z + 4 gridDim.z, ...): a single 8 s window is then
@@ -1459,9 +1328,7 @@ void attention_geometry(int max_T, int head_dim, int* qt, int* nw) {
   const int qt_max = 2;                       // (128-wide heads: 3 tiles per wave spill 15 registers)
   const int n_tiles = (max_T + 15) / 16;
   int q = 1;
-  // 64-wide heads, at most 416 keys: one tile per wave so that launch_attention_bf16_hd64 takes the one-pass kernel (several workgroups per utterance and head)
-  const bool full = head_dim == 64 && max_T <= 416 && !(getenv("ASR_ATTN_FULL") && getenv("ASR_ATTN_FULL")[0] == '0');
-  while (!full && q < qt_max && (n_tiles + q - 1) / q > 8) ++q;
+  while (q < qt_max && (n_tiles + q - 1) / q > 8) ++q;
   if (const char* e = getenv("ASR_ATTN_QT")) q = std::max(1, std::min(qt_max, atoi(e)));
   int w = std::min(8, (n_tiles + q - 1) / q);
   if (const char* e = getenv("ASR_ATTN_NW")) w = std::max(1, std::min(8, atoi(e)));
@@ -1480,17 +1347,6 @@ void launch_attention_bf16_hd128(const AttnArgs& a, hipStream_t s) {
 }
 void launch_attention_bf16_hd64(const AttnArgs& a, hipStream_t s) {
   ASR_REQUIRE(a.qt >= 1 && a.qt <= 4 && a.n_waves >= 1 && a.n_waves <= 8, "attention: bad geometry qt=%d nw=%d", a.qt, a.n_waves);
-  static const bool full_on = !(getenv("ASR_ATTN_FULL") && getenv("ASR_ATTN_FULL")[0] == '0');
-  if (full_on && a.qt == 1 && !a.causal && a.kv_group <= 1 && !a.q_plan && a.max_T <= AF_MAXK) {      // whole key range in registers, one-pass soft-max
-    constexpr int lds = 64 * AF_VROWB;
-    static PerDeviceOnce attr_once;
-    if (attr_once.first()) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_full_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    AttnArgs b = a;
-    if (b.ld_q == 0) b.ld_q = b.ld_qk;
-    hipLaunchKernelGGL(attn_bf16_full_kernel<64>, dim3(a.n_qblocks, a.n_heads), dim3(64 * a.n_waves), lds, s, b, a.ld_vt);
-    HIP_CHECK(hipGetLastError());
-    return;
-  }
   switch (a.qt) {
     case 1: launch_attn_inst<64, 256, 1>(a, s); break;
     case 2: launch_attn_inst<64, 256, 2>(a, s); break;

@@ -1420,10 +1420,122 @@ void launch_add_scalar(int32_t* p, int v, hipStream_t s) {
   HIP_CHECK(hipGetLastError());
 }
 
+namespace {
+// ---- single-token self-attention, one WAVE per (sequence, head): the launch above spends four workgroup barriers and three dependent
+// global-load rounds on <= 40 cached positions (15 us per launch at 64 sequences: 22 % of a Whisper decode step). Here every load a wave needs
+// (its query, the new K / V row, up to 64 cached K and V rows) is requested at once, 8 lanes per 128-byte row (16 B each, coalesced), the dot
+// products are reduced inside the 8-lane groups by DPP, the soft-max runs online over blocks of 64 keys with wave shuffles, and nothing goes through LDS.
+__global__ __launch_bounds__(256) void decode_self_attn_wave_kernel(const DecAttnArgs a) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = blockIdx.y * 4 + wave;
+  if (h >= a.n_heads) return;
+  const int hist = a.hist_dev ? *a.hist_dev : a.hist;          // keys 0 .. hist - 1 are cached, key `hist` is the new row
+  const int sub = lane & 7, grp = lane >> 3;
+  bf16_t* Kc = reinterpret_cast<bf16_t*>(a.k_base) + (size_t)b * a.stride_b + (size_t)h * a.stride_h;
+  bf16_t* Vc = reinterpret_cast<bf16_t*>(a.v_base) + (size_t)b * a.stride_b + (size_t)h * a.stride_h;
+  const bf16_t* NEW = reinterpret_cast<const bf16_t*>(a.kv_new) + (size_t)b * a.ld_new + h * 64 + sub * 8;
+  Raw8<bf16_t> q8, nk, nv;
+  q8.load(reinterpret_cast<const bf16_t*>(a.q) + (size_t)b * a.ld_q + a.q_col0 + h * 64 + sub * 8);
+  nk.load(NEW + a.k_col0);
+  nv.load(NEW + a.v_col0);
+  auto dot8 = [&](const float (&x)[8], const float (&y)[8]) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc = fmaf(x[e], y[e], acc);
+    acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0xB1, 0xf, 0xf, true));
+    acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x4E, 0xf, 0xf, true));
+    acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x141, 0xf, 0xf, true));
+    return acc;                                              // the row's dot product, in all 8 lanes of the group
+  };
+  float m = -INFINITY, l = 0.0f, acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+  Raw8<bf16_t> kr[8], vr[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    kr[u].v = make_uint4(0, 0, 0, 0); vr[u].v = make_uint4(0, 0, 0, 0);      // slots past the history stay finite: 0 x garbage could be NaN
+    const int s0 = u * 8 + grp;
+    if (s0 < hist) { kr[u].load(Kc + (size_t)s0 * 64 + sub * 8); vr[u].load(Vc + (size_t)s0 * 64 + sub * 8); }
+  }
+  if (grp == 0) {                                            // append the new row (read back only by later steps)
+    *reinterpret_cast<uint4*>(Kc + (size_t)hist * 64 + sub * 8) = nk.v;
+    *reinterpret_cast<uint4*>(Vc + (size_t)hist * 64 + sub * 8) = nv.v;
+  }
+  float qf[8];
+  q8.get(qf);
+  for (int blk = 0; blk < hist; blk += 64) {
+    float sc[8], vf[8][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float kf[8];
+      kr[u].get(kf);
+      vr[u].get(vf[u]);
+      const float d = dot8(qf, kf);
+      sc[u] = blk + u * 8 + grp < hist ? d : -INFINITY;
+      mx = fmaxf(mx, sc[u]);
+    }
+    if (blk + 64 < hist) {                                   // the next block's rows (more than 64 positions of history)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int s1 = blk + 64 + u * 8 + grp;
+        kr[u].v = make_uint4(0, 0, 0, 0); vr[u].v = make_uint4(0, 0, 0, 0);
+        if (s1 < hist) { kr[u].load(Kc + (size_t)s1 * 64 + sub * 8); vr[u].load(Vc + (size_t)s1 * 64 + sub * 8); }
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx), alpha = __expf(m - m_new);
+    l *= alpha;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= alpha;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float p = __expf(sc[u] - m_new);                 // exp(-inf) = 0 for the slots past the history
+      l += p;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, vf[u][e], acc[e]);
+    }
+    m = m_new;
+  }
+  // partial sums of the 8 key groups -> totals (every lane of a column group ends with the same values)
+  l += __shfl_xor(l, 8, 64); l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    acc[e] += __shfl_xor(acc[e], 8, 64); acc[e] += __shfl_xor(acc[e], 16, 64); acc[e] += __shfl_xor(acc[e], 32, 64);
+  }
+  float nkf[8], nvf[8];
+  nk.get(nkf);
+  nv.get(nvf);
+  const float s_new = dot8(qf, nkf);
+  const float m_fin = fmaxf(m, s_new), alpha = __expf(m - m_fin), p_new = __expf(s_new - m_fin);
+  const float inv = 1.0f / (l * alpha + p_new);
+  if (grp == 0) {
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (acc[e] * alpha + p_new * nvf[e]) * inv;
+    uint4 w;
+    w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]); w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)b * a.ld_out + h * 64 + sub * 8) = w;
+  }
+}
+
+}  // namespace
+
 template <typename T>
 void launch_decode_attention(const DecAttnArgs& a, int batch, hipStream_t s) {
   ASR_REQUIRE(a.n >= 1 && a.n <= DA_MAXN, "decode attention: %d new positions per call (max %d)", a.n, DA_MAXN);
   ASR_REQUIRE(a.plan || a.hist_dev || a.hist + a.n <= DA_MAXKEYS, "decode attention: %d keys exceed %d", a.hist + a.n, DA_MAXKEYS);
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    static const bool wave_on = !(getenv("ASR_DECODE_ATTN_WAVE") && getenv("ASR_DECODE_ATTN_WAVE")[0] == '0');
+    if (wave_on && a.n == 1 && !a.plan && a.kv_new && !a.k_scale && !a.v_scale && (a.ld_q % 8) == 0 && (a.ld_new % 8) == 0 && (a.q_col0 % 8) == 0 &&
+        (a.k_col0 % 8) == 0 && (a.v_col0 % 8) == 0 && (a.ld_out % 8) == 0) {                 // single-token self-attention: one wave per (sequence, head)
+      hipLaunchKernelGGL(decode_self_attn_wave_kernel, dim3(batch, (a.n_heads + 3) / 4), dim3(256), 0, s, a);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
+  }
   DecAttnArgs b = a;
   b.sc_ld = (std::min(a.max_keys > 0 ? a.max_keys : DA_MAXKEYS, DA_MAXKEYS) + 63) & ~63;
   const size_t lds = (size_t)a.n * b.sc_ld * 4;

@@ -28,6 +28,7 @@ SIGNATURES = {
     "asr_probe_quantize_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, _fp, C.c_void_p]),
     "asr_probe_decode_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _fp, _fp, C.c_int, _fp]),
     "asr_probe_gemm_counts": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "asr_probe_gemm_fp8": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, _fp, C.c_float, _fp, _fp, C.c_int, C.c_void_p, _fp, C.c_int, _fp]),
     "asr_probe_gemm_bench": (C.c_int, [C.c_int] * 6 + [_fp]),
     "asr_probe_grid_barrier": (C.c_int, [C.c_int, C.c_int, _fp]),
     "asr_probe_grid_barrier2": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp]),
@@ -139,3 +140,35 @@ def decode_gemm(a, w=None, w8=None, scale=None, bias=None, fold=False):
                                             None if s is None else s.ctypes.data_as(_fp), None if b is None else b.ctypes.data_as(_fp), int(fold),
                                             out.ctypes.data_as(_fp)))
     return out
+
+
+def e4m3_table():
+    """The 256 OCP e4m3 values (index = byte; 0x7f / 0xff are NaN)."""
+    t = np.zeros(256, np.float64)
+    for v in range(256):
+        s, e, m = v >> 7, (v >> 3) & 15, v & 7
+        x = (m / 8.0) * 2.0 ** -6 if e == 0 else (1.0 + m / 8.0) * 2.0 ** (e - 7)
+        if e == 15 and m == 7:
+            x = np.nan
+        t[v] = -x if s else x
+    return t
+
+
+def gemm_fp8(a8, w8, w_scale, bias, a_scale=1.0, add=None, act=0, iters=0):
+    """FP8 matrix-pipe GEMM on host arrays: a8 [M][K], w8 [N][K] uint8 (e4m3). Returns (out, us): out uint8 [M][N] (bytes of act(...)) without `add`,
+    else float32 [M][N]."""
+    a8, w8 = np.ascontiguousarray(a8, np.uint8), np.ascontiguousarray(w8, np.uint8)
+    M, K = a8.shape
+    N = w8.shape[0]
+    sc, b = _f32(w_scale), _f32(bias)
+    us = C.c_float(0.0)
+    if add is None:
+        out = np.zeros((M, N), np.uint8)
+        _lib.check(load().asr_probe_gemm_fp8(M, N, K, a8.ctypes.data, w8.ctypes.data, sc.ctypes.data_as(_fp), a_scale, b.ctypes.data_as(_fp), None, act,
+                                             out.ctypes.data, None, iters, C.byref(us)))
+    else:
+        r = _f32(add)
+        out = np.zeros((M, N), np.float32)
+        _lib.check(load().asr_probe_gemm_fp8(M, N, K, a8.ctypes.data, w8.ctypes.data, sc.ctypes.data_as(_fp), a_scale, b.ctypes.data_as(_fp), r.ctypes.data_as(_fp), act,
+                                             None, out.ctypes.data_as(_fp), iters, C.byref(us)))
+    return out, us.value

@@ -71,6 +71,12 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
   const int ti = wave / NT, tj = wave % NT;            // tile of this wave in the epilogue
   float4 addv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (wave < TILES && g.add && ti * 16 + frow < g.M) addv = *reinterpret_cast<const float4*>(g.add + (size_t)(ti * 16 + frow) * g.ld_add + n0 + tj * 16 + fgrp * 4);
+  // ... and so do the bias and the column sums of the fold: a global load issued in the epilogue would sit on the launch's critical path
+  float4 biasv = make_float4(0.f, 0.f, 0.f, 0.f), csumv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (wave < TILES) {
+    if (g.bias) biasv = *reinterpret_cast<const float4*>(g.bias + n0 + tj * 16 + fgrp * 4);
+    if constexpr (FOLD) csumv = *reinterpret_cast<const float4*>(g.colsum + n0 + tj * 16 + fgrp * 4);
+  }
   const bf16x8_t ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
   for (int k = 0; k < kslice; k += 32 * U) {
@@ -190,10 +196,10 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
     const float inv_k = 1.0f / (float)g.K;
     const float mean = s1 * inv_k;
     const float rstd = rsqrtf(fmaxf(s2 * inv_k - mean * mean, 0.0f) + g.ln_eps);
-    const float4 c = *reinterpret_cast<const float4*>(g.colsum + n);
+    const float4 c = csumv;
     sum.x = (sum.x - mean * c.x) * rstd; sum.y = (sum.y - mean * c.y) * rstd; sum.z = (sum.z - mean * c.z) * rstd; sum.w = (sum.w - mean * c.w) * rstd;
   }
-  if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + n); sum.x += b.x; sum.y += b.y; sum.z += b.z; sum.w += b.w; }
+  sum.x += biasv.x; sum.y += biasv.y; sum.z += biasv.z; sum.w += biasv.w;
   sum.x += addv.x; sum.y += addv.y; sum.z += addv.z; sum.w += addv.w;
   if (g.act == ACT_GELU_ERF) {
     sum.x = 0.5f * sum.x * (1.0f + erff(sum.x * 0.70710678118654752440f)); sum.y = 0.5f * sum.y * (1.0f + erff(sum.y * 0.70710678118654752440f));

@@ -100,5 +100,20 @@ void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits);
 void launch_decode_gemm(const DecGemmArgs& g, hipStream_t s);
 void launch_colsum_bf16(const bf16_t* W, int ldw, int N, int K, float* c, hipStream_t s);
 
+// ---- FP8 matrix-pipe GEMM (csrc/gemm_fp8.hip, precision mode ASR_PRECISION_FP8MM): e4m3 operands [rows][K bytes], power-of-two scales applied in the epilogue
+struct Fp8GemmArgs {
+  const unsigned char* A = nullptr; int lda = 0;      // [M][K] e4m3 bytes (pitch in bytes); value = byte * a_scale
+  const unsigned char* W = nullptr; int ldw = 0;      // [N][K] e4m3 bytes; value = byte * w_scale[n]
+  int M = 0, N = 0, K = 0;                            // N % 256 == 0, K % 256 == 0
+  const float* w_scale = nullptr; float a_scale = 1.0f;
+  const float* bias = nullptr;                        // [N]
+  const float* add = nullptr; int ld_add = 0;         // f32 residual rows (f32 output only)
+  int act = ACT_NONE;                                 // byte output only
+  unsigned char* out8 = nullptr; int ld_out8 = 0; float out_inv_scale = 1.0f;    // e4m3 bytes of act(...) * out_inv_scale, saturating at +-448
+  float* out_f32 = nullptr; int ld_out_f32 = 0;
+  int group_m = 0;                                    // (set by the launcher)
+};
+void launch_gemm_fp8(const Fp8GemmArgs& g, hipStream_t s);
+
 // reduce the per-slab arg-max partials written by the GEMM epilogue: ids[m] = first index of the row max
 void launch_argmax_reduce(const float* val, const int32_t* idx, int M, int n_slabs, int32_t* ids, hipStream_t s);

@@ -57,6 +57,9 @@ template <typename T>
 void launch_zero_gap_rows(T* buf, int ld, int n_cols, const UttPlan* plan, const int32_t* grow_utt, int n_gapped_rows,
                           hipStream_t s);
 
+// affine-free LayerNorm of f32 rows written as OCP e4m3 bytes of y * inv_scale (saturating): operand rows of the FP8 matrix-pipe GEMM (csrc/gemm_fp8.hip)
+void launch_layernorm_fp8(const float* x, int ld_x, int rows, int D, float eps, float inv_scale, unsigned char* out, int ld_out, hipStream_t s);
+
 // ---- decoder token + position embedding: x[b*n + i] = embed[ids[b*n + i]] + pos[hist + i]   (Export_Whisper.py:450-497)
 template <typename T>
 void launch_embed_pos(const int32_t* ids, int rows, int n, int hist, const int32_t* hist_dev, const T* embed, const float* pos, int d,

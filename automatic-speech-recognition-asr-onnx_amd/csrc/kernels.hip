@@ -366,6 +366,37 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int i = D + lane; i < fill_to; i += 64) Elem<OutT>::store(o + i, 0.0f);
 }
 
+// ------------------------------------------------------------------------------------ LayerNorm (affine-free) -> e4m3 bytes
+// Operand rows of the FP8 matrix-pipe GEMM (precision mode ASR_PRECISION_FP8MM): y = (x - mean) * rstd * inv_scale, saturated at +-448, OCP e4m3 (RNE).
+// One wave per row; D <= 2048, D % 256 == 0.
+__global__ __launch_bounds__(256) void layernorm_fp8_kernel(const float* __restrict__ x, int ld_x, int rows, int D, float eps, float inv_scale,
+                                                            unsigned char* __restrict__ out, int ld_out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * ld_x;
+  float4 v[8];
+  const int nv = D >> 8;                                       // float4 per lane
+  float s1 = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (k < nv) { v[k] = *reinterpret_cast<const float4*>(xr + k * 256 + lane * 4); s1 += (v[k].x + v[k].y) + (v[k].z + v[k].w); }
+  const float mean = wave_sum(s1) / (float)D;
+  float s2 = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (k < nv) { const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean; s2 += (a * a + b * b) + (c * c + d * d); }
+  const float rstd = rsqrtf(wave_sum(s2) / (float)D + eps) * inv_scale;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (k < nv) {
+      auto q = [&](float t) { return fminf(fmaxf((t - mean) * rstd, -448.0f), 448.0f); };
+      int w = 0;
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(q(v[k].x), q(v[k].y), w, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(q(v[k].z), q(v[k].w), w, true);
+      *reinterpret_cast<int*>(out + (size_t)row * ld_out + k * 256 + lane * 4) = w;
+    }
+}
+
 // ------------------------------------------------------------------------------------ attention (bf16, flash-style)
 // One workgroup = a block of NW*QT 16-row query tiles of one (utterance, head); wave w owns tiles w, w+NW, ...
 // (QT of them, all live in registers). K and V^T chunks of CHUNK keys are staged ONCE per workgroup by LDS-DMA
@@ -1305,6 +1336,12 @@ void launch_layernorm(const float* x, int ld_x, int rows, int D, const float* ga
 }
 template void launch_layernorm<float>(const float*, int, int, int, const float*, const float*, float, float*, int, int, hipStream_t, const int32_t*);
 template void launch_layernorm<bf16_t>(const float*, int, int, int, const float*, const float*, float, bf16_t*, int, int, hipStream_t, const int32_t*);
+
+void launch_layernorm_fp8(const float* x, int ld_x, int rows, int D, float eps, float inv_scale, unsigned char* out, int ld_out, hipStream_t s) {
+  ASR_REQUIRE(D % 256 == 0 && D <= 2048 && ld_x % 4 == 0 && ld_out % 4 == 0, "layernorm_fp8: D=%d unsupported", D);
+  hipLaunchKernelGGL(layernorm_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld_x, rows, D, eps, inv_scale, out, ld_out);
+  HIP_CHECK(hipGetLastError());
+}
 
 template <int HD, int CHUNK, int QT>
 static void launch_attn_inst(const AttnArgs& a, hipStream_t s) {

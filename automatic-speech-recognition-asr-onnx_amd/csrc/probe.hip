@@ -237,6 +237,47 @@ extern "C" int asr_probe_decode_gemm(int M, int N, int K, const uint16_t* a, con
   });
 }
 
+// FP8 matrix-pipe GEMM on host arrays (csrc/gemm_fp8.hip): a8 [M][K], w8 [N][K] e4m3 bytes, w_scale [N], bias [N]; either out8 [M][N] (act, bytes) or
+// out_f32 [M][N] (+ add [M][N]). iters > 0: also times that many launches (microseconds per launch in *us).
+extern "C" int asr_probe_gemm_fp8(int M, int N, int K, const uint8_t* a8, const uint8_t* w8, const float* w_scale, float a_scale, const float* bias,
+                                  const float* add, int act, uint8_t* out8, float* out_f32, int iters, float* us) {
+  return asr_guard([&] {
+    ASR_REQUIRE(a8 && w8 && w_scale && bias && (out8 || out_f32), "probe_gemm_fp8: bad argument");
+    asr_require_device(0);
+    DeviceBuffer da, dw, dsc, db, dadd, dout;
+    da.reserve((size_t)M * K, nullptr); dw.reserve((size_t)N * K, nullptr); dsc.reserve((size_t)N * 4, nullptr); db.reserve((size_t)N * 4, nullptr);
+    HIP_CHECK(hipMemcpy(da.ptr, a8, (size_t)M * K, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(dw.ptr, w8, (size_t)N * K, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dsc.ptr, w_scale, (size_t)N * 4, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(db.ptr, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+    Fp8GemmArgs g;
+    g.A = da.as<unsigned char>(); g.lda = K; g.W = dw.as<unsigned char>(); g.ldw = K; g.M = M; g.N = N; g.K = K; g.w_scale = dsc.as<float>(); g.a_scale = a_scale;
+    g.bias = db.as<float>(); g.act = act;
+    if (out8) { dout.reserve((size_t)M * N, nullptr); g.out8 = dout.as<unsigned char>(); g.ld_out8 = N; }
+    else {
+      ASR_REQUIRE(add, "probe_gemm_fp8: the f32 output needs the residual rows");
+      dadd.reserve((size_t)M * N * 4, nullptr); HIP_CHECK(hipMemcpy(dadd.ptr, add, (size_t)M * N * 4, hipMemcpyHostToDevice));
+      dout.reserve((size_t)M * N * 4, nullptr); g.add = dadd.as<float>(); g.ld_add = N; g.out_f32 = dout.as<float>(); g.ld_out_f32 = N;
+    }
+    launch_gemm_fp8(g, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    if (out8) HIP_CHECK(hipMemcpy(out8, dout.ptr, (size_t)M * N, hipMemcpyDeviceToHost));
+    else HIP_CHECK(hipMemcpy(out_f32, dout.ptr, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    if (iters > 0 && us) {
+      hipEvent_t e0, e1;
+      HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+      for (int i = 0; i < 3; ++i) launch_gemm_fp8(g, nullptr);
+      HIP_CHECK(hipEventRecord(e0, nullptr));
+      for (int i = 0; i < iters; ++i) launch_gemm_fp8(g, nullptr);
+      HIP_CHECK(hipEventRecord(e1, nullptr));
+      HIP_CHECK(hipEventSynchronize(e1));
+      float ms = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      *us = ms * 1e3f / iters;
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    for (DeviceBuffer* b : {&da, &dw, &dsc, &db, &dadd, &dout}) b->release();
+  });
+}
+
 extern "C" const char* asr_probe_last_kernel(void) { return g_chain_kernel; }
 
 extern "C" int asr_probe_gemm_counts(int reset, char* buf, int cap) {

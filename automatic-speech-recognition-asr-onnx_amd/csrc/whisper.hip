@@ -22,7 +22,8 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct EncLayer { const void *wqkv, *wo, *w1, *w2; const float *bqkv, *bo, *b1, *b2; };
 struct DecLayer { const void *wqkv, *wo, *wcq, *wco, *w1, *w2; const float *bqkv, *bo, *bcq, *bco, *b1, *b2; };
-struct Dec8Layer { const unsigned char* w[6]; const float* s[6]; };        // FP8 mode: e4m3 bytes + per-column scales of wqkv, wo, wcq, wco, w1, w2
+struct Dec8Layer { const unsigned char* w[6]; const float* s[6]; };
+struct Enc8Layer { const unsigned char *w1, *w2; const float *s1, *s2; };     // FP8MM mode: the encoder FFN pair as e4m3 bytes + per-row scales        // FP8 mode: e4m3 bytes + per-column scales of wqkv, wo, wcq, wco, w1, w2
 
 struct WhSession : asr_session {
   asr_whisper_config cfg;
@@ -58,6 +59,11 @@ struct WhSession : asr_session {
   // power-of-two scale per output column, read by the decode GEMM (<= 64 rows); their exact bf16 dequantisation serves every other path
   // (prefill, > 64 rows), so all steps of a session see the same effective weights. The cross-K/V slabs are quantised once per batch with a
   // scale per (sequence, head) and streamed as bytes by the decode attention. ASR_FP8_FAKE=1: same quantisation, bf16 kernels throughout.
+  // precision mode ASR_PRECISION_FP8MM (opt-in): FP8W plus the encoder's FFN pair on the FP8 matrix pipe (csrc/gemm_fp8.hip): fc1 / fc2 weights as e4m3 bytes with
+  // per-row power-of-two scales, their activation operands (the second LayerNorm's output, the GELU output) as e4m3 bytes at unit scale
+  bool fp8_mm = false;
+  std::vector<Enc8Layer> enc8;
+  DeviceBuffer d_ew8, d_ewscale, d_h8, d_ffn8;
   bool fp8 = false, fp8_fake = false, fp8_weights = true, fp8_kv = true;     // ASR_FP8_WEIGHTS=0 / ASR_FP8_KV=0: leave that half in bf16 (to price the halves separately)
   std::vector<Dec8Layer> dec8;
   DeviceBuffer d_w8, d_wscale, d_wdq, d_cross8, d_cscale;
@@ -68,7 +74,7 @@ struct WhSession : asr_session {
 
   ~WhSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_x0, &d_h1, &d_xa, &d_xb, &d_xc, &d_h, &d_qk, &d_vt, &d_ctx,
-                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise, &d_nsp, &d_skws, &d_skcnt, &d_colsum, &d_dlo, &d_w8, &d_wscale, &d_wdq, &d_cross8, &d_cscale})
+                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise, &d_nsp, &d_skws, &d_skcnt, &d_colsum, &d_dlo, &d_w8, &d_wscale, &d_wdq, &d_cross8, &d_cscale, &d_ew8, &d_ewscale, &d_h8, &d_ffn8})
       b->release();
     if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
     for (auto& kv : taps) kv.second.buf.release();
@@ -144,6 +150,19 @@ void WhSession::init() {
     dec[i] = DecLayer{W(p + "wqkv", {3 * d, d}), W(p + "wo", {d, d}), W(p + "wcq", {d, d}), W(p + "wco", {d, d}),
                       W(p + "w1", {dff, d}), W(p + "w2", {d, dff}),
                       F(p + "bqkv", {3 * d}), F(p + "bo", {d}), F(p + "bcq", {d}), F(p + "bco", {d}), F(p + "b1", {dff}), F(p + "b2", {d})};
+  }
+  if (fp8_mm) {
+    ASR_REQUIRE(d % 256 == 0 && dff % 256 == 0, "whisper: FP8MM mode needs d_model and d_ffn to be multiples of 256");
+    const size_t per = (size_t)2 * d * dff;
+    d_ew8.reserve((size_t)c.n_enc_layers * per, stream); d_ewscale.reserve((size_t)c.n_enc_layers * (d + dff) * 4, stream);
+    enc8.resize(c.n_enc_layers);
+    for (int i = 0; i < c.n_enc_layers; ++i) {
+      unsigned char* w8 = d_ew8.as<unsigned char>() + i * per;
+      float* sc = d_ewscale.as<float>() + (size_t)i * (d + dff);
+      launch_quantize_rows_fp8((const bf16_t*)enc[i].w1, d, dff, d, w8, sc, nullptr, stream);
+      launch_quantize_rows_fp8((const bf16_t*)enc[i].w2, dff, d, dff, w8 + (size_t)dff * d, sc + dff, nullptr, stream);
+      enc8[i] = Enc8Layer{w8, w8 + (size_t)dff * d, sc, sc + dff};
+    }
   }
   if (fp8 && fp8_weights) {
     ASR_REQUIRE(d % 256 == 0 && dff % 256 == 0, "whisper: FP8 mode needs d_model and d_ffn to be multiples of 256");
@@ -288,6 +307,7 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
   d_vt.reserve((size_t)Mpad * d * eT, stream);
   d_ctx.reserve((size_t)Mpad * d * eT, stream);
   d_ffn.reserve(std::max((size_t)Mpad * dff * eT, (size_t)Mg * d * 4), stream);
+  if (fp8_mm) { d_h8.reserve((size_t)Mpad * d, stream); d_ffn8.reserve((size_t)Mpad * dff, stream); }
   { void* before = d_cross.ptr; d_cross.reserve((size_t)2 * Ld * H * Mpad * 64 * eT, stream); if (d_cross.ptr != before) ++ws_epoch; }
 
   // ---- STFT power -> mel -> log10 (STFT_Process.py:224-246, Export_Whisper.py:424-425)
@@ -358,6 +378,24 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
       g.A = ctx; g.lda = d; g.W = L.wo; g.ldw = d; g.M = rows; g.N = d; g.K = d; g.bias = L.bo; g.add = xa; g.ld_add = d;
       g.out_f32 = xb; g.ld_out_f32 = d;
       gemm(g);
+    }
+    if (fp8_mm && sizeof(T) == 2) {                       // FFN pair on the FP8 matrix pipe: e4m3 operand rows, twice the bf16 MFMA rate
+      { ProfScope ps(prof, "layernorm", stream); launch_layernorm_fp8(xb, d, rows, d, 1e-5f, 1.0f, d_h8.as<unsigned char>(), d, stream); }
+      {
+        ProfScope ps(prof, "gemm_ffn1", stream);
+        Fp8GemmArgs g;
+        g.A = d_h8.as<unsigned char>(); g.lda = d; g.W = enc8[i].w1; g.ldw = d; g.M = rows; g.N = dff; g.K = d; g.w_scale = enc8[i].s1; g.bias = L.b1;
+        g.act = act; g.out8 = d_ffn8.as<unsigned char>(); g.ld_out8 = dff;
+        launch_gemm_fp8(g, stream);
+      }
+      {
+        ProfScope ps(prof, "gemm_ffn2", stream);
+        Fp8GemmArgs g;
+        g.A = d_ffn8.as<unsigned char>(); g.lda = dff; g.W = enc8[i].w2; g.ldw = dff; g.M = rows; g.N = d; g.K = dff; g.w_scale = enc8[i].s2; g.bias = L.b2;
+        g.add = xb; g.ld_add = d; g.out_f32 = xa; g.ld_out_f32 = d;
+        launch_gemm_fp8(g, stream);
+      }
+      continue;
     }
     { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(xb, d, rows, d, nullptr, nullptr, 1e-5f, h, d, d, stream); }
     {
@@ -658,13 +696,14 @@ extern "C" int asr_whisper_create(const asr_whisper_config* cfg, const void* are
                                   int device_id, int precision, asr_session** out) {
   return asr_guard([&] {
     ASR_REQUIRE(cfg && arena && out, "whisper_create: null argument");
-    ASR_REQUIRE(precision == ASR_PRECISION_BF16 || precision == ASR_PRECISION_F32 || precision == ASR_PRECISION_FP8W, "whisper_create: bad precision %d", precision);
+    ASR_REQUIRE(precision == ASR_PRECISION_BF16 || precision == ASR_PRECISION_F32 || precision == ASR_PRECISION_FP8W || precision == ASR_PRECISION_FP8MM, "whisper_create: bad precision %d", precision);
     asr_require_device(device_id);
     WhSession* s = new WhSession();
     try {
       s->kind = 2;
       s->device = device_id;
-      s->fp8 = precision == ASR_PRECISION_FP8W;
+      s->fp8 = precision == ASR_PRECISION_FP8W || precision == ASR_PRECISION_FP8MM;
+      s->fp8_mm = precision == ASR_PRECISION_FP8MM;
       s->precision = s->fp8 ? ASR_PRECISION_BF16 : precision;        // FP8 mode = bf16 mode with byte-wide decoder weights and cross-K/V
       s->cfg = *cfg;
       gemm_reload_env();

@@ -206,6 +206,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=1, help="whisper / qwen: also measure N batches in flight on N sessions / HIP streams")
     ap.add_argument("--streams", type=int, default=256, help="mixed: concurrent Paraformer streams per GPU")
     ap.add_argument("--beam", type=int, default=1, help="qwen / mixed: beam width (1 = greedy; BASELINE.json configs[4] names beam 5)")
+    ap.add_argument("--fp8mm", action="store_true", help="whisper: opt-in precision mode ASR_PRECISION_FP8MM (FP8W + the encoder's FFN pair on the FP8 matrix pipe); a secondary figure, never the headline")
     ap.add_argument("--fp8", action="store_true", help="whisper: opt-in precision mode ASR_PRECISION_FP8W (decoder projections and cross-K/V as e4m3 bytes); a secondary figure, never the headline")
     ap.add_argument("--decode-tokens", type=int, default=0, help="whisper: generated tokens per utterance (default 4 per audio second)")
     args = ap.parse_args()
@@ -786,7 +787,8 @@ def main_whisper(args):
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t0
     blob = None
-    prec = arena.PRECISION_FP8W if args.fp8 else arena.PRECISION_BF16
+    if args.fp8mm: args.fp8 = True
+    prec = arena.PRECISION_FP8MM if args.fp8mm else arena.PRECISION_FP8W if args.fp8 else arena.PRECISION_BF16
     sess = eng.WhisperSession(cfg, arena_dev, prec, local_rank, arena_device_ptr=arena_dev.data_ptr(), arena_bytes=arena_dev.numel())
     audio_np = ckm.synth_audio("unit", B, n_samples, seed=1234 + rank)
     audio_dev = torch.from_numpy(audio_np).to(device)
@@ -873,11 +875,12 @@ def main_whisper(args):
         t_dec = t_parts["decode"] / args.steps
         out = {
             "metric": "audio-sec/s, Whisper-large-v3, %g s @ 16 kHz chunks, batch %d per GPU, greedy, %d tokens/utterance" % (args.seconds, B, n_tok)
-                      + (" [opt-in FP8W mode: decoder projections + cross-K/V stored as e4m3, NOT the reference's precision]" if args.fp8 else ""),
+                      + (" [opt-in FP8W mode: decoder projections + cross-K/V stored as e4m3, NOT the reference's precision]" if args.fp8 else "")
+                      + (" [+ FP8MM: encoder fc1 / fc2 on the FP8 matrix pipe, e4m3 activations]" if args.fp8mm else ""),
             "value": round(audio_s * args.steps / elapsed, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 (e4m3 storage of decoder weights and cross-K/V)" if args.fp8 else "bf16", "data": "synthetic",
-            "config": {"workload": "Whisper-large-v3 %s (1.54 B params), batch=%d x %g s per GPU, encoder + cross-KV + prefill(4) + %d greedy decode steps, audio resident in HBM" % ("bf16 + FP8W" if args.fp8 else "bf16", B, args.seconds, n_tok - 1),
+            "config": {"workload": "Whisper-large-v3 %s (1.54 B params), batch=%d x %g s per GPU, encoder + cross-KV + prefill(4) + %d greedy decode steps, audio resident in HBM" % ("bf16 + FP8MM" if args.fp8mm else "bf16 + FP8W" if args.fp8 else "bf16", B, args.seconds, n_tok - 1),
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "rtf": round(elapsed / (audio_s * args.steps), 7),
             "ms": {k: round(v / args.steps * 1e3, 2) for k, v in t_parts.items()},
@@ -914,7 +917,7 @@ def main_whisper(args):
             sess.encode_packed(None, offsets, audio_device_ptr=audio_dev.data_ptr())
             _, lg = sess.prefill(prompt)
             ref0 = first["logits"][0][0]
-            out["parity_spotcheck"] = {"what": "prefill logits of utterance 0, %s engine vs f32 oracle" % ("FP8W" if args.fp8 else "bf16"), "max_abs_diff": round(float(np.abs(lg[0] - ref0).max()), 4),
+            out["parity_spotcheck"] = {"what": "prefill logits of utterance 0, %s engine vs f32 oracle" % ("FP8MM" if args.fp8mm else "FP8W" if args.fp8 else "bf16"), "max_abs_diff": round(float(np.abs(lg[0] - ref0).max()), 4),
                                        "logit_abs_max": round(float(np.abs(ref0).max()), 3)}
         print(json.dumps(out))
     if world > 1:
@@ -1069,7 +1072,7 @@ def main_qwen(args):
                 if el >= 15.0 or n_done >= 16:
                     break
             _, lg, _ = sess.prefill_packed(None, offsets, pre, post, want_logits=True, audio_device_ptr=audio_dev.data_ptr())
-            out["parity_spotcheck"] = {"what": "prefill logits of utterance 0, %s engine vs f32 oracle" % ("FP8W" if args.fp8 else "bf16"), "max_abs_diff": round(float(np.abs(lg[0] - first["logits"][0]).max()), 4),
+            out["parity_spotcheck"] = {"what": "prefill logits of utterance 0, %s engine vs f32 oracle" % ("FP8MM" if args.fp8mm else "FP8W" if args.fp8 else "bf16"), "max_abs_diff": round(float(np.abs(lg[0] - first["logits"][0]).max()), 4),
                                        "logit_abs_max": round(float(np.abs(first["logits"][0]).max()), 3)}
             out["cpu_baseline"] = {"value": round(n_done * args.seconds / el, 2), "unit": "audio-s/s", "cores": int(torch.get_num_threads()),
                                    "host_cores": int(os.cpu_count() or 0), "kind": "port",

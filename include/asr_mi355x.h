@@ -50,8 +50,14 @@ enum asr_status {
  * FP8W (opt-in, Whisper sessions only; the low-bit counterpart of the reference's quantised decoders, Whisper/Optimize_ONNX.py:81-96,
  * Optimize_ONNX_Common.py:55-60): bf16 mode whose decoder projection weights and cross-K/V cache are stored as OCP e4m3 bytes with
  * power-of-two scales (per output column / per (sequence, head) slab) and widened to bf16 in registers -- activations, accumulation,
- * self-KV cache, encoder and vocabulary projection are unchanged. Takes a bf16 arena; quantisation happens at session creation. */
-enum asr_precision { ASR_PRECISION_BF16 = 0, ASR_PRECISION_F32 = 1, ASR_PRECISION_FP8W = 2 };
+ * self-KV cache, encoder and vocabulary projection are unchanged. Takes a bf16 arena; quantisation happens at session creation.
+ *
+ * FP8MM (opt-in, Whisper sessions only): FP8W plus the encoder's feed-forward pair on the FP8 MATRIX pipe -- fc1 / fc2 weights as e4m3 bytes with one
+ * power-of-two scale per output column, their activation operands (the second LayerNorm's output, the GELU output) as e4m3 bytes at unit scale
+ * (saturating at 448), products on v_mfma_scale_f32_16x16x128_f8f6f4 at unit block scales with f32 accumulation; attention, the other projections,
+ * the residual stream and the decoder are FP8W's. Needs d_model and d_ffn multiples of 256. The reference's counterpart: its MatMulNBits /
+ * dynamic-int8 graphs (Optimize_ONNX_Common.py:55-60). */
+enum asr_precision { ASR_PRECISION_BF16 = 0, ASR_PRECISION_F32 = 1, ASR_PRECISION_FP8W = 2, ASR_PRECISION_FP8MM = 3 };
 
 enum asr_mem { ASR_MEM_HOST = 0, ASR_MEM_DEVICE = 1 };
 

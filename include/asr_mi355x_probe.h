@@ -46,6 +46,11 @@ int asr_probe_quantize_fp8(const uint16_t* w_bf16, int N, int K, uint8_t* out8, 
 int asr_probe_decode_gemm(int M, int N, int K, const uint16_t* a, const uint16_t* w_bf16, const uint8_t* w8, const float* scale,
                           const float* bias, int fold, float* out);
 
+/* FP8 matrix-pipe GEMM (precision mode ASR_PRECISION_FP8MM) on host arrays: out = act((a8 w8^T) a_scale w_scale[n] + bias) as e4m3 bytes (out8), or
+ * (a8 w8^T) a_scale w_scale[n] + bias + add as f32 (out_f32). iters > 0 also times the launch (microseconds in *us). */
+int asr_probe_gemm_fp8(int M, int N, int K, const uint8_t* a8, const uint8_t* w8, const float* w_scale, float a_scale, const float* bias,
+                       const float* add, int act, uint8_t* out8, float* out_f32, int iters, float* us);
+
 /* launches per GEMM kernel family since the last reset, as "family=count;..." (host-side counters: hipGraph replays do not
  * count, so reset, run a session once on a new batch geometry, read). reset != 0 clears the counters after the read. */
 int asr_probe_gemm_counts(int reset, char* buf, int cap);

@@ -33,7 +33,8 @@ def test_precision_modes_agree_between_header_and_host():
     m = re.search(r"enum asr_precision \{([^}]*)\}", hdr)
     vals = dict((k.strip(), int(v)) for k, v in (item.split("=") for item in m.group(1).split(",")))
     arena = sub("arena")
-    assert vals == {"ASR_PRECISION_BF16": arena.PRECISION_BF16, "ASR_PRECISION_F32": arena.PRECISION_F32, "ASR_PRECISION_FP8W": arena.PRECISION_FP8W}
+    assert vals == {"ASR_PRECISION_BF16": arena.PRECISION_BF16, "ASR_PRECISION_F32": arena.PRECISION_F32, "ASR_PRECISION_FP8W": arena.PRECISION_FP8W,
+                    "ASR_PRECISION_FP8MM": arena.PRECISION_FP8MM}
 
 
 def test_probe_library_is_separate_from_the_product_abi():

@@ -6,7 +6,13 @@ What pins it:
     every rounding) and against a float64 product;
   * a whole session in FP8 mode against the same session with ASR_FP8_FAKE=1 (identical quantisation, bf16 kernels throughout), bit for
     bit on the logits of prefill + decode steps, i.e. the byte paths of the decode GEMM and of the cross-attention add no error of their own;
-  * the quantisation error itself against the f32 oracle, with the budget written down next to the bf16 mode's error on the same input."""
+  * the quantisation error itself against the f32 oracle, with the budget written down next to the bf16 mode's error on the same input.
+
+Precision mode ASR_PRECISION_FP8MM adds the encoder's feed-forward pair on the FP8 matrix pipe (csrc/gemm_fp8.hip):
+  * the byte x byte GEMM against a float64 product of the DECODED bytes (the only error left is f32 accumulation order), its e4m3 output
+    bytes within half an e4m3 ulp of the exact GELU;
+  * a whole FP8MM session against the f32 oracle next to FP8W on the same input (activation quantisation costs more than weight
+    quantisation: the budget says how much)."""
 import os
 
 import numpy as np
@@ -20,7 +26,7 @@ from test_oracle_whisper import unit_audio, whisper_setup
 
 pytestmark = pytest.mark.gpu
 
-BF16, F32, FP8W = 0, 1, 2
+BF16, F32, FP8W, FP8MM = 0, 1, 2, 3
 
 
 def _session(cfg_name, prec, env=None):
@@ -139,3 +145,57 @@ def test_large_v3_fp8_30s_vs_golden_budget():
     print(f"whisper_large_v3 logits scale {scale:.1f}: bf16 error {e_bf:.3f}, fp8w error {e_8:.3f}")
     assert e_bf < 2e-3 * scale                                # measured 6e-4
     assert e_8 < 1.2e-2 * scale                               # measured 4e-3
+
+
+def _nearest_e4m3(x, tab):
+    finite = np.where(np.isnan(tab), np.inf, tab)
+    order = np.argsort(finite)
+    vals = finite[order]
+    keep = np.isfinite(vals)
+    vals, order = vals[keep], order[keep]
+    pos = np.clip(np.searchsorted(vals, x), 1, vals.size - 1)
+    return np.where(np.abs(x - vals[pos - 1]) <= np.abs(x - vals[pos]), order[pos - 1], order[pos]).astype(np.uint8)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 512, 512), (1000, 1280, 1280), (777, 1024, 256), (1500, 256, 1024), (2048, 1280, 5120)])
+def test_fp8_matrix_pipe_gemm_against_float64_over_the_decoded_bytes(M, N, K):
+    from math import erf
+    probe = sub("_probe")
+    tab = probe.e4m3_table()
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    a8, w8 = _nearest_e4m3(rng.standard_normal((M, K)), tab), _nearest_e4m3(rng.standard_normal((N, K)) * 32.0, tab)
+    sc = 2.0 ** rng.integers(-12, -8, N).astype(np.float64)
+    bias = rng.standard_normal(N)
+    add = rng.standard_normal((M, N)).astype(np.float32)
+    ref = (tab[a8] @ tab[w8].T) * sc[None, :] + bias[None, :]
+    mag = (np.abs(tab[a8]) @ np.abs(tab[w8]).T) * sc[None, :] + 1.0
+    got, _ = probe.gemm_fp8(a8, w8, sc, bias, add=add)                       # f32 out + residual (the fc2 form)
+    assert (np.abs(got - (ref + add)) / mag).max() < 2e-5                     # products are exact; f32 accumulation order only (measured 1e-6)
+    out8, _ = probe.gemm_fp8(a8, w8, sc, bias, act=2)                        # erf-GELU -> e4m3 bytes (the fc1 form)
+    sub_rows = slice(0, min(M, 128))
+    gelu = np.clip(0.5 * ref[sub_rows] * (1.0 + np.vectorize(erf)(ref[sub_rows] / np.sqrt(2.0))), -448, 448)
+    rel = np.abs(tab[out8[sub_rows]] - gelu) / np.maximum(np.abs(gelu), 2.0 ** -6)
+    assert rel.max() < 0.07                                                  # half an e4m3 ulp = 1/16 of the value (+ the fast erf's 1e-6)
+
+
+def test_fp8mm_session_stays_within_budget_of_the_oracle_and_rejects_what_it_cannot_serve():
+    name = "whisper_d256_test"
+    cfg, ck, sup, beg, smm = _session(name, FP8MM)
+    _, _, _, _, s8 = _session(name, FP8W)
+    audios = [unit_audio(81, 64000), unit_audio(82, 25600), unit_audio(83, 128000)]
+    prompt = [cfg.sot_id, cfg.first_language_id, cfg.transcribe_id, cfg.no_timestamps_id]
+    prompts = np.array([prompt] * 3, np.int32)
+    orc = WhisperOracle(cfg, ck, sup, beg)
+    ref = orc.greedy(audios, [prompt] * 3, 5)
+    forced = np.stack([np.asarray(ref["token_ids"][b][:4], np.int32) for b in range(3)])
+    want = np.stack([np.stack(ref["logits"][b][:5]) for b in range(3)])
+    lmm, l8 = _run(smm, audios, prompts, forced), _run(s8, audios, prompts, forced)
+    V = cfg.vocab
+    scale = float(np.abs(want).max())
+    e_mm, e_8 = float(np.abs(lmm[..., :V] - want).max()), float(np.abs(l8[..., :V] - want).max())
+    print(f"whisper_d256 logits |max| {scale:.2f}: fp8w error {e_8:.4f}, fp8mm error {e_mm:.4f}")
+    assert not np.array_equal(lmm[..., :V], l8[..., :V])     # (sanity: the encoder FFN really ran on bytes)
+    assert e_mm < 3e-2 * scale                                # activations at 4 significant bits in 2 of the encoder's 6 GEMMs per layer
+    assert np.array_equal(_run(smm, audios, prompts, forced), lmm)            # deterministic
+    with pytest.raises(RuntimeError):
+        _session("whisper_mid_test", FP8MM)                   # d_model 384 is not a multiple of 256

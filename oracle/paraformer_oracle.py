@@ -165,7 +165,8 @@ class ParaformerOracle:
         return alphas, completed[1:] - completed[:-1], int(floor[-1])
 
     # ---- :521-563
-    def decode(self, acoustic, memory, num_id):
+    def decode_hidden(self, acoustic, memory, num_id):
+        """decoder rows up to (not including) the output projection: after_norm without its affine, which __init__ folded into w_out / b_out"""
         c = self.cfg
         d, H, hd = c.d_model, c.n_heads, c.d_head
         n = max(num_id, 1)
@@ -184,16 +185,20 @@ class ParaformerOracle:
             dec = x + ctx @ L["wo"].t() + L["bo"]
         for L in self.dec3:
             dec = F.layer_norm(torch.relu(F.layer_norm(dec, (d,)) @ L["w1"].t() + L["b1"]), (c.d_dec_ffn,)) @ L["w2"].t() + L["b2"]
-        return F.layer_norm(dec, (d,)) @ self.w_out.t() + self.b_out
+        return F.layer_norm(dec, (d,))
+
+    def decode(self, acoustic, memory, num_id):
+        return self.decode_hidden(acoustic, memory, num_id) @ self.w_out.t() + self.b_out
 
     def stages(self, audio_1d):
         with torch.inference_mode():
             mel = self.fbank(torch.as_tensor(np.asarray(audio_1d, dtype=np.float32).reshape(-1)))
             enc_out = self.encode(mel)
             alphas, acoustic, num_id = self.cif(enc_out)
-            logits = self.decode(acoustic, enc_out, num_id)
+            hidden = self.decode_hidden(acoustic, enc_out, num_id)
+            logits = hidden @ self.w_out.t() + self.b_out
             ids = logits.argmax(-1).int()[:num_id]
-        return dict(mel=mel.numpy(), enc_out=enc_out.numpy(), alphas=alphas.numpy(), acoustic=acoustic.numpy(), logits=logits.numpy(),
+        return dict(dec_hidden=hidden.numpy(), mel=mel.numpy(), enc_out=enc_out.numpy(), alphas=alphas.numpy(), acoustic=acoustic.numpy(), logits=logits.numpy(),
                     token_ids=ids.numpy().astype(np.int32), num_id=np.array([num_id], np.int32))
 
     def __call__(self, audio_1d):

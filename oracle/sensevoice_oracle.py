@@ -175,6 +175,13 @@ class SenseVoiceOracle:
         nxt = torch.roll(ids, -1, 0)
         return ids[(ids != nxt) & (ids != blank_id)].to(torch.int32)
 
+    def ctc_head(self, enc_out):
+        """CTC projection + greedy pick + collapse of one utterance's encoder rows (Export_SenseVoice.py:289-296)."""
+        enc_out = self._c(torch.as_tensor(enc_out))
+        logits = enc_out @ self._c(self.ck["ctc.ctc_lo.weight"]).t() + self._c(self.ck["ctc.ctc_lo.bias"])
+        ids = logits.argmax(dim=-1)
+        return logits, ids, self.ctc_collapse(ids, self.cfg.blank_id)
+
     def stages(self, audio_1d, language_idx: int) -> dict:
         with torch.inference_mode():
             a = torch.as_tensor(np.asarray(audio_1d, dtype=np.float32).reshape(-1))
@@ -182,9 +189,7 @@ class SenseVoiceOracle:
             enc_in = self.lfr_cmvn(mel, language_idx)
             taps = {}
             enc_out = self.encode(enc_in, taps)
-            logits = enc_out @ self._c(self.ck["ctc.ctc_lo.weight"]).t() + self._c(self.ck["ctc.ctc_lo.bias"])
-            ids = logits.argmax(dim=-1)
-            tok = self.ctc_collapse(ids, self.cfg.blank_id)
+            logits, ids, tok = self.ctc_head(enc_out)
         f = lambda z: z.float().numpy() if z.dtype != torch.float64 else z.numpy()
         return dict(mel=f(mel), enc_in=f(enc_in), block0=f(taps["block0"]), enc_out=f(enc_out), logits=f(logits),
                     frame_ids=ids.numpy().astype(np.int32), token_ids=tok.numpy(),

@@ -162,3 +162,92 @@ def test_block_kernel_equals_separate_launches(monkeypatch):
     for (r0, T) in rows:
         assert np.abs(out["1"][1][r0:r0 + T] - out["0"][1][r0:r0 + T]).max() < 0.1
         assert np.abs(out["1"][2][r0:r0 + T] - out["0"][2][r0:r0 + T]).max() < 0.02
+
+
+def _prototype_output_layer(cfg, ck, hidden):
+    """An output projection with the decision structure of a trained one, built on the ORACLE's decoder rows (list of (n_b, d) arrays, the
+    after_norm output without its affine): every token of every utterance is a class of its own (ids from 10 up) whose row is the
+    nearest-prototype classifier  logit_v(x) = (x - mu) . p_v - |p_v|^2 / 2; all other rows keep a tenth of their random weight; the
+    after_norm affine becomes the identity so that the rows act on exactly those hidden states."""
+    X = np.concatenate(hidden).astype(np.float64)
+    mu = X.mean(0)
+    P = X - mu
+    K = X.shape[0]
+    assert 10 + K <= cfg.vocab
+    W = ck["decoder.output_layer.weight"].astype(np.float64) * 0.1
+    bias = ck["decoder.output_layer.bias"].astype(np.float64) * 0.1
+    W[10:10 + K] = P
+    bias[10:10 + K] = -(P @ mu) - 0.5 * (P ** 2).sum(1)
+    ck2 = dict(ck)
+    ck2["decoder.output_layer.weight"], ck2["decoder.output_layer.bias"] = W.astype(np.float32), bias.astype(np.float32)
+    ck2["decoder.after_norm.weight"] = np.ones_like(ck["decoder.after_norm.weight"])
+    ck2["decoder.after_norm.bias"] = np.zeros_like(ck["decoder.after_norm.bias"])
+    return ck2, 10 + np.arange(K)
+
+
+def test_bf16_batch64_tokens_equal_the_oracle_on_a_head_with_trained_margins():
+    """bf16 parity without near-tie exclusions, Paraformer-large, 64 utterances of 2.5 s in one batch (the SenseVoice twin of this test
+    explains the idea: tests/test_sensevoice_gpu.py). Two decisions are discrete here:
+      * the token COUNT, floor of the summed CIF weights (Export_Paraformer.py:501-518). A sum within the bf16 error of an integer can go
+        either way, in the reference's own f16 / int8 exports as well; the 64 utterances are the first of the candidate seeds whose oracle
+        sum stays `slack` away from one (the test prints how many candidates that took and the measured error of the sum);
+      * the token ids: the output layer is rebuilt on the oracle's decoder rows so that every token clears twice the measured bf16 error
+        of the logit differences that decide the pick.
+    Demanded: the oracle's token ids, all of them, for all 64 utterances.
+
+    Why 2.5 s and not the 8 s of the headline batch: rounding the weights to bf16 perturbs the FUNCTION, and because the encoder rows of a
+    random-weight model are nearly parallel (cos 0.98 between frames) the CIF weights come out with a common relative bias (8 s: each within
+    0.006 of the oracle's, but their SUM off by up to 0.23 tokens -- tools/probes/peaky_para_probe.py). CIF integrates that bias: by the end
+    of an 8 s window every segment boundary has moved by a fifth of a token and the late tokens' decoder rows with it (error of the deciding
+    logit differences 0.17 on the first token, 0.9 - 1.6 on the last two, against margins of 0.7 - 1.2). That is a property of CIF under any
+    reduced precision, not of a kernel; within 2.5 s the drift stays inside the margins."""
+    cfg, ck = paraformer_setup("paraformer_large")
+    eng = sub("engine")
+    B, window, slack, n_samples = 64, 2.0, 0.15, 40000
+    orc = ParaformerOracle(cfg, ck)
+    audios, stages, tried = [], [], 0
+    while len(audios) < B:
+        a = kaldi_audio(7400 + tried, n_samples)
+        st = orc.stages(a)
+        total = float(np.sum(st["alphas"].astype(np.float64)) + cfg.tail_threshold)
+        tried += 1
+        if abs(total - round(total)) > slack and int(st["num_id"][0]) > 0:
+            audios.append(a); stages.append(st)
+        assert tried <= 4 * B
+    hidden = [st["dec_hidden"][:int(st["num_id"][0])] for st in stages]
+    ck2, cls = _prototype_output_layer(cfg, ck, hidden)
+    orc2 = ParaformerOracle(cfg, ck2)
+    W, bvec = orc2.w_out.numpy(), orc2.b_out.numpy()
+    sess = eng.ParaformerSession.from_checkpoint(cfg, ck2, precision=BF16)
+    sess.taps(True)
+    toks = sess.run(audios)
+    rows = sess.utterance_rows([a.size for a in audios])
+    alphas, logits = sess.tap("alphas")[:, 0], sess.tap("logits")
+    trow = sess.token_rows([t.size for t in toks])
+    margins, wrong, e_all, e_near, e_sum, e_alpha, k = [], [], 0.0, 0.0, 0.0, 0.0, 0
+    for b, (st, (r0, T), t0) in enumerate(zip(stages, rows, trow)):
+        n = int(st["num_id"][0])
+        da = alphas[r0:r0 + T].astype(np.float64) - st["alphas"].astype(np.float64)
+        e_sum, e_alpha = max(e_sum, abs(float(da.sum()))), max(e_alpha, float(np.abs(da).max()))
+        lo = hidden[b] @ W.T + bvec                                           # the oracle's output layer on the oracle's rows (ParaformerOracle.decode)
+        want = lo.argmax(1)
+        assert np.array_equal(want, cls[k:k + n])                             # the layer does what it was built to do (in f32)
+        k += n
+        if toks[b].size != n or not np.array_equal(toks[b], want):
+            wrong.append((b, toks[b].tolist(), want.tolist()))
+            continue
+        lg = logits[t0:t0 + n, :cfg.vocab]
+        d_orc = lo[np.arange(n), want][:, None] - lo
+        err = np.abs((lg[np.arange(n), want][:, None] - lg) - d_orc)
+        margins.append(np.partition(d_orc, 1, axis=1)[:, 1])
+        e_all, e_near = max(e_all, float(err.max())), max(e_near, float(err[d_orc <= window].max()))
+    margins = np.concatenate(margins)
+    print(f"prototype output layer, B = {B} x {n_samples / 16000} s ({tried} candidate seeds): {k} tokens; CIF weights off by <= {e_alpha:.4f} each, <= {e_sum:.4f} "
+          f"summed (slack {slack}); oracle margin min {margins.min():.3f} median {np.median(margins):.3f}; bf16 error of logit differences: {e_near:.3f} "
+          f"within {window} of the winner, {e_all:.3f} over all classes")
+    assert not wrong, wrong[:3]
+    assert e_sum < slack
+    assert margins.min() > 2 * e_near, (margins.min(), e_near)
+    assert e_all < window
+    sess.taps(False)
+    assert all(np.array_equal(x, y) for x, y in zip(sess.run(audios), toks))              # the production path (no f32 logits tap)

@@ -17,18 +17,28 @@ __device__ __forceinline__ float apply_act_ct(float v) {
   } else return v;
 }
 
-// erf-GELU for the bf16 kernels' epilogues: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. far below a bf16 ulp of the result and
-// below the f32 rounding of the reference's own erf) -- one v_rcp_f32, one v_exp_f32 and six FMAs instead of the library erff's two-branch
-// polynomial, which cost a 256 x 256 tile's epilogue ~8 us (Whisper fc1: 45 us per layer). Verification mode keeps erff.
+// erf-GELU for the bf16 / e4m3 kernels' epilogues. With a = |v|:  gelu(v) = max(v, 0) - a * Phi(-a),  and  Phi(-a) = erfc(a / sqrt 2) / 2 = 2^q(a)  with q a
+// degree-6 polynomial fitted to log2 Phi(-a) on [0, 13] (weighted for the absolute error of the product; tools/probes/gelu_fit.py): |error| <= 6e-8
+// absolute -- below the f32 rounding of the reference's own erf -- and <= 4e-4 relative in the negative tail, a tenth of a bf16 ulp. Cost per value: one
+// v_exp_f32 and, on pairs of values, six v_pk_fma_f32 plus min / max / fma -- about half of the Abramowitz-Stegun 7.1.26 form used before (one v_rcp_f32 more and
+// no packed arithmetic), which itself replaced the library erff's two-branch polynomial (8 us of a 256 x 256 tile's epilogue). a is clamped at 12, where
+// the term is below 1e-30 and before the polynomial's leading coefficient turns it around. Verification mode keeps erff.
+typedef float f32pair_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_erf_fast2(float& v0, float& v1) {
+  const f32pair_t a = {fminf(fabsf(v0), 12.0f), fminf(fabsf(v1), 12.0f)};
+  f32pair_t q = a * 3.30953373e-05f + -0.000769241955f;
+  q = q * a + 0.00808078996f;
+  q = q * a + -0.0534122179f;
+  q = q * a + -0.458770889f;
+  q = q * a + -1.15120173f;
+  q = q * a + -0.999993058f;
+  v0 = fmaf(-a.x, __builtin_amdgcn_exp2f(q.x), fmaxf(v0, 0.0f));
+  v1 = fmaf(-a.y, __builtin_amdgcn_exp2f(q.y), fmaxf(v1, 0.0f));
+}
 __device__ __forceinline__ float gelu_erf_fast(float v) {
-  const float z = fabsf(v) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = 1.0f - p * t * __expf(-z * z);          // erf(|v| / sqrt 2)
-  return 0.5f * v * (1.0f + copysignf(e, v));
+  float w = v;
+  gelu_erf_fast2(v, w);
+  return v;
 }
 
 __device__ __forceinline__ float apply_act_rt(float v, int act) {
@@ -172,9 +182,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[
         v[4] += t1[i][1].x; v[5] += t1[i][1].y; v[6] += t1[i][1].z; v[7] += t1[i][1].w;
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if constexpr (ACT == ACT_GELU_ERF && sizeof(OutT) == 2) v[e] = gelu_erf_fast(v[e]);
-        else if constexpr (ACT >= 0) v[e] = apply_act_ct<ACT>(v[e]); else v[e] = apply_act_rt(v[e], g.act);
+      for (int e = 0; e < 8; e += 2) {
+        if constexpr (ACT == ACT_GELU_ERF && sizeof(OutT) == 2) gelu_erf_fast2(v[e], v[e + 1]);
+        else if constexpr (ACT >= 0) { v[e] = apply_act_ct<ACT>(v[e]); v[e + 1] = apply_act_ct<ACT>(v[e + 1]); }
+        else { v[e] = apply_act_rt(v[e], g.act); v[e + 1] = apply_act_rt(v[e + 1], g.act); }
       }
       if (has_add2) {                                         // post-activation term
         v[0] += t2[i][0].x; v[1] += t2[i][0].y; v[2] += t2[i][0].z; v[3] += t2[i][0].w;
@@ -246,8 +257,8 @@ __device__ __forceinline__ void epilogue_rows_lo_lines(const GemmArgs& g, f32x4_
 #pragma unroll
       for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * p][r] + b8[p][r]; v[4 + r] = acc[i][2 * p + 1][r] + b8[p][4 + r]; }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if constexpr (ACT == ACT_GELU_ERF) v[e] = gelu_erf_fast(v[e]); else v[e] = apply_act_ct<ACT>(v[e]);
+      for (int e = 0; e < 8; e += 2) {
+        if constexpr (ACT == ACT_GELU_ERF) gelu_erf_fast2(v[e], v[e + 1]); else { v[e] = apply_act_ct<ACT>(v[e]); v[e + 1] = apply_act_ct<ACT>(v[e + 1]); }
       }
       w[p].x = pack_bf16x2(v[0], v[1]); w[p].y = pack_bf16x2(v[2], v[3]); w[p].z = pack_bf16x2(v[4], v[5]); w[p].w = pack_bf16x2(v[6], v[7]);
     }

@@ -197,9 +197,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_ppp(const Fp8GemmArgs g, cons
             }
           } else {                                                    // activation -> e4m3 bytes (saturating), the next GEMM's operand
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              if constexpr (ACT == ACT_GELU_ERF) v[e] = gelu_erf_fast(v[e]); else v[e] = apply_act_ct<ACT>(v[e]);
+            for (int e = 0; e < 8; e += 2) {
+              if constexpr (ACT == ACT_GELU_ERF) gelu_erf_fast2(v[e], v[e + 1]); else { v[e] = apply_act_ct<ACT>(v[e]); v[e + 1] = apply_act_ct<ACT>(v[e + 1]); }
               v[e] = fminf(fmaxf(v[e] * g.out_inv_scale, -448.0f), 448.0f);
+              v[e + 1] = fminf(fmaxf(v[e + 1] * g.out_inv_scale, -448.0f), 448.0f);
             }
             int w0 = 0, w1 = 0;
             w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w0, true);

@@ -61,6 +61,7 @@ extern "C" int asr_probe_gemm_bench(int variant, int M, int N, int K, int epilog
       case 0: g.out_lo = olo; g.ld_out_lo = N; break;
       case 1: g.out_lo = olo; g.ld_out_lo = N; g.act = ACT_RELU; break;
       case 2: g.add = addm; g.ld_add = N; g.out_f32 = of32; g.ld_out_f32 = N; break;
+      case 7: g.out_lo = olo; g.ld_out_lo = N; g.act = ACT_GELU_ERF; break;
       case 3: g.bias = nullptr; g.add = addt; g.ld_add = N; g.add2 = addm; g.ld_add2 = N; g.out_f32 = of32; g.ld_out_f32 = N; break;
       case 4: g.out_t = ot; g.ld_out_t = Mp; break;
       case 5: {   // FFN-1 with the LayerNorm evaluated inside (statistics handed over by the producer)

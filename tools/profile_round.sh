@@ -17,6 +17,11 @@ python bench.py --workload whisper --batch 64 --steps 5 --warmup 3 --inflight 2 
 python bench.py --workload whisper --seconds 30 --steps 3 --warmup 2 --inflight 3 --no-cpu-baseline > $OUT/bench_whisper30.json 2> $OUT/bench_whisper30.err
 python bench.py --workload whisper --fp8 --seconds 30 --steps 3 --warmup 2 --no-cpu-baseline > $OUT/bench_whisper30_fp8.json 2> $OUT/bench_whisper30_fp8.err
 python bench.py --workload whisper --fp8 --steps 6 --warmup 3 --no-cpu-baseline > $OUT/bench_whisper_fp8.json 2> $OUT/bench_whisper_fp8.err
+python bench.py --workload whisper --fp8mm --batch 64 --steps 5 --warmup 3 --inflight 2 --no-cpu-baseline > $OUT/bench_whisper_b64_fp8mm.json 2> $OUT/bench_whisper_b64_fp8mm.err
+python bench.py --workload whisper --fp8mm --seconds 30 --steps 3 --warmup 2 --no-cpu-baseline > $OUT/bench_whisper30_fp8mm.json 2> $OUT/bench_whisper30_fp8mm.err
+python tools/fp8_gemm_probe.py > $OUT/fp8_gemm_probe.txt 2>&1
+python tools/probes/gelu_cost.py > $OUT/gelu_epilogue_cost.txt 2>&1
+for a in 0 1 2 3 16; do echo "=== ASR_SANM_BLOCK_ABL=$a (1 no refills after the prologue, 2 no MFMA, 16 no payload / output stores)"; ASR_SANM_BLOCK_ABL=$a ASR_SANM_BLOCK_DBG=10 python tools/probes/sanm_block_clock.py 2>&1 | grep -v amdgpu.ids | tail -15; done > $OUT/sanm_block_ablations.txt 2>&1
 ASR_SANM_BLOCK_DBG=10 python tools/probes/sanm_block_clock.py > $OUT/sanm_block_phase_clock.txt 2>&1
 python tools/probes/f32_b1_profile.py > $OUT/sensevoice_f32_b1_profile.txt 2>&1
 python bench.py --workload paraformer-streaming --steps 16 --warmup 8 > $OUT/bench_paraformer_streaming.json 2> $OUT/bench_paraformer_streaming.err

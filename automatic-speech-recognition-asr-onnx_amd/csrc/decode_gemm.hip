@@ -229,6 +229,22 @@ __global__ void colsum_kernel(const bf16_t* __restrict__ W, int ldw, int N, int 
   if (lane == 0) c[n] = (float)s;
 }
 
+// Weight prefetch for the NEXT decode GEMM of the chain (launched on a side branch of the decode graph while the current GEMM runs): same grid as the GEMM it serves,
+// workgroup (x, y) touches one dword of every 128-byte line of exactly the weight bytes that GEMM workgroup (x, y) will stream -- so the lines wait in the L2 of the XCD
+// that workgroup lands on (dispatch is round-robin over XCDs by workgroup id for both kernels; if it were not, the prefetch would merely be useless). No output.
+__global__ __launch_bounds__(256) void decode_gemm_prefetch_kernel(const unsigned char* __restrict__ W, int row_bytes, int elem, int rows_per_wg, int steps, unsigned* sink) {
+  const int KS = gridDim.y, ks = blockIdx.y;
+  const int lo = steps * ks / KS, n = steps * (ks + 1) / KS - lo;          // this workgroup's K-steps of 32 elements (the GEMM kernel's split rule)
+  const int seg0 = lo * 32 * elem, seg_bytes = n * 32 * elem;
+  const int lines = (seg_bytes + 127) >> 7;
+  unsigned acc = 0;
+  for (int i = threadIdx.x; i < rows_per_wg * lines; i += 256) {
+    const int r = i / lines, l = i - r * lines;
+    acc += *reinterpret_cast<const unsigned*>(W + (size_t)(blockIdx.x * rows_per_wg + r) * row_bytes + seg0 + (l << 7));
+  }
+  if (acc == 0x9e3779b9u && sink) *sink = acc;                              // keeps the loads alive
+}
+
 template <int MT, int NT>
 void launch_inst(const DecGemmArgs& g, int splits, hipStream_t s) {
   const size_t lds = (size_t)DW * MT * NT * 1024 + (size_t)DW * MT * 16 * 8;
@@ -302,5 +318,14 @@ void launch_decode_gemm(const DecGemmArgs& g, hipStream_t s) {
 
 void launch_colsum_bf16(const bf16_t* W, int ldw, int N, int K, float* c, hipStream_t s) {
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 3) / 4), dim3(256), 0, s, W, ldw, N, K, c);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_decode_gemm_prefetch(const DecGemmArgs& g, hipStream_t s) {
+  int nt = 1, splits = 1;
+  decode_gemm_plan(g, &nt, &splits);
+  const unsigned char* w = g.W8 ? g.W8 : reinterpret_cast<const unsigned char*>(g.W);
+  const int elem = g.W8 ? 1 : 2;
+  hipLaunchKernelGGL(decode_gemm_prefetch_kernel, dim3(g.N / (16 * nt), splits), dim3(256), 0, s, w, g.ldw * elem, elem, 16 * nt, g.K >> 5, (unsigned*)nullptr);
   HIP_CHECK(hipGetLastError());
 }

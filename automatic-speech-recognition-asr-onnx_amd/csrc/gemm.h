@@ -98,6 +98,8 @@ struct DecGemmArgs {
 bool decode_gemm_supported(const DecGemmArgs& g);
 void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits);
 void launch_decode_gemm(const DecGemmArgs& g, hipStream_t s);
+// touch the weight bytes of a coming launch_decode_gemm(g) from the workgroups (hence XCDs) that will stream them; for a side branch of the decode graph
+void launch_decode_gemm_prefetch(const DecGemmArgs& g, hipStream_t s);
 void launch_colsum_bf16(const bf16_t* W, int ldw, int N, int K, float* c, hipStream_t s);
 
 // ---- FP8 matrix-pipe GEMM (csrc/gemm_fp8.hip, precision mode ASR_PRECISION_FP8MM): e4m3 operands [rows][K bytes], power-of-two scales applied in the epilogue

@@ -164,14 +164,31 @@ extern "C" int asr_probe_gemm_chain(int M, int N, int K, int epilogue, int cold_
       decode_gemm_plan(dg, &nt, &sp);
       snprintf(g_chain_kernel, sizeof(g_chain_kernel), "decode nt%d ks%d", nt, sp);
     }
+    // ASR_PROBE_PREFETCH=1: while node i runs, a side branch touches node i + 1's weights from the workgroups that will stream them (launch_decode_gemm_prefetch)
+    const bool prefetch = use_dg && getenv("ASR_PROBE_PREFETCH") && getenv("ASR_PROBE_PREFETCH")[0] == '1';
+    hipStream_t s2 = nullptr;
+    std::vector<hipEvent_t> evs;
+    if (prefetch) {
+      HIP_CHECK(hipStreamCreate(&s2));
+      evs.resize(chain + 1);
+      for (auto& e : evs) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     auto enqueue = [&] {
       for (int i = 0; i < chain; ++i) {
+        if (prefetch) {
+          DecGemmArgs gn = dg; gn.W = (const bf16_t*)((char*)dw + wbytes * ((i + 1) % copies));
+          HIP_CHECK(hipEventRecord(evs[i], s));
+          HIP_CHECK(hipStreamWaitEvent(s2, evs[i], 0));
+          launch_decode_gemm_prefetch(gn, s2);
+        }
         if (use_dg) { DecGemmArgs gi = dg; gi.W = (const bf16_t*)((char*)dw + wbytes * (i % copies)); launch_decode_gemm(gi, s); }
         else { GemmArgs gi = g; gi.W = (char*)dw + wbytes * (i % copies); launch_gemm_bf16(gi, s); }
       }
+      if (prefetch) { HIP_CHECK(hipEventRecord(evs[chain], s2)); HIP_CHECK(hipStreamWaitEvent(s, evs[chain], 0)); }
     };
     enqueue();                                                 // eager once (lazy attributes)
     HIP_CHECK(hipStreamSynchronize(s));
+    if (s2) HIP_CHECK(hipStreamSynchronize(s2));
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
     HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     enqueue();
@@ -189,6 +206,8 @@ extern "C" int asr_probe_gemm_chain(int M, int N, int K, int epilogue, int cold_
     *us_per_launch = ms * 1e3f / ((float)replays * chain);
     if (!use_dg) snprintf(g_chain_kernel, sizeof(g_chain_kernel), "%s", gemm_last_kernel());
     (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    if (s2) (void)hipStreamDestroy(s2);
+    for (auto& e : evs) (void)hipEventDestroy(e);
   });
 }
 

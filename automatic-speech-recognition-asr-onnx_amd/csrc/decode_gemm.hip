@@ -78,7 +78,6 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
     if constexpr (FOLD) csumv = *reinterpret_cast<const float4*>(g.colsum + n0 + tj * 16 + fgrp * 4);
   }
   const bf16x8_t ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
-
   for (int k = 0; k < kslice; k += 32 * U) {
     using raw_t = typename std::conditional<W8, u32x2_t, bf16x8_t>::type;
     raw_t wf[U][NT];

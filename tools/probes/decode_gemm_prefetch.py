@@ -14,5 +14,5 @@ for M in (1, 32, 64):
         pre, _ = probe.gemm_chain(M, N, K, epi, 768, 5)
         w = 2 if "out" in name else 1
         for i, v in enumerate((cold, pre, hot)): tot[i] += v * w
-        print(f"M={M:3d} {name:24s} cold {cold:6.2f} us  cold + prefetch branch {pre:6.2f} us  hot {hot:6.2f} us  ({kern})", flush=True)
+        print(f"M={M:3d} {name:24s} cold {cold:6.2f} us  cold + prefetch {pre:6.2f} us  hot {hot:6.2f} us  ({kern})", flush=True)
     print(f"M={M:3d} six GEMMs of a layer: cold {tot[0]:.1f}, with prefetch {tot[1]:.1f}, hot {tot[2]:.1f} us", flush=True)

@@ -82,6 +82,9 @@ struct DecAttnArgs {
   const int32_t* hist_dev;                                     // when set, the history length is read from device memory (graph replay)
   void* out; int ld_out;
   const float* k_scale = nullptr; const float* v_scale = nullptr;   // FP8 cross-K/V: k_base / v_base hold e4m3 bytes, scale[head][sequence] per slab
+  // paged self-KV cache (block table; stride_b / stride_h unused): position s of (sequence b, head h) lives at
+  //   k_base + page_table[b * pages_per_seq + (s >> 4)] * page_stride + h * 1024 + (s & 15) * 64       (pages of 16 positions x 64 dims per head)
+  const int32_t* page_table = nullptr; int pages_per_seq = 0; int64_t page_stride = 0;
 };
 // FP8 (OCP e4m3, power-of-two scales) quantisers of precision mode ASR_PRECISION_FP8W
 void launch_quantize_rows_fp8(const bf16_t* W, int ld, int N, int K, unsigned char* W8, float* scale, bf16_t* Wdq, hipStream_t s);

@@ -857,8 +857,11 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
   if (a.plan) { n_cached = a.plan[b].n_lfr; row0 = a.plan[b].row_off; }
   else n_cached = hist;
   const int S = a.plan ? n_cached : hist + n;
-  const KT* Kc = reinterpret_cast<const KT*>(a.k_base) + (size_t)b * a.stride_b + (size_t)h * a.stride_h + (size_t)row0 * 64;
-  const KT* Vc = reinterpret_cast<const KT*>(a.v_base) + (size_t)b * a.stride_b + (size_t)h * a.stride_h + (size_t)row0 * 64;
+  // cache row s of this (sequence, head): contiguous extent, or through the block table of the paged self-KV cache (pages of 16 positions)
+  const int32_t* pt = a.page_table ? a.page_table + (size_t)b * a.pages_per_seq : nullptr;
+  const KT* Kc = reinterpret_cast<const KT*>(a.k_base) + (pt ? (size_t)h * 1024 : (size_t)b * a.stride_b + (size_t)h * a.stride_h + (size_t)row0 * 64);
+  const KT* Vc = reinterpret_cast<const KT*>(a.v_base) + (pt ? (size_t)h * 1024 : (size_t)b * a.stride_b + (size_t)h * a.stride_h + (size_t)row0 * 64);
+  auto crow = [&](int s) -> size_t { return pt ? (size_t)pt[s >> 4] * (size_t)a.page_stride + (size_t)(s & 15) * 64 : (size_t)s * 64; };
   const T* Q = reinterpret_cast<const T*>(a.q);
   const T* NEW = KV8 ? nullptr : reinterpret_cast<const T*>(a.kv_new);
   const float k_scale = KV8 ? a.k_scale[(size_t)h * gridDim.x + b] : 1.0f, v_scale = KV8 ? a.v_scale[(size_t)h * gridDim.x + b] : 1.0f;
@@ -869,8 +872,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
     T* Vw = const_cast<T*>(Vc);
     for (int i = tid; i < n * 64; i += 256) {
       const size_t src = (size_t)(b * n + (i >> 6)) * a.ld_new + h * 64 + (i & 63);
-      Kw[(size_t)(hist + (i >> 6)) * 64 + (i & 63)] = NEW[src + a.k_col0];
-      Vw[(size_t)(hist + (i >> 6)) * 64 + (i & 63)] = NEW[src + a.v_col0];
+      Kw[crow(hist + (i >> 6)) + (i & 63)] = NEW[src + a.k_col0];
+      Vw[crow(hist + (i >> 6)) + (i & 63)] = NEW[src + a.v_col0];
     }
   }
   __syncthreads();
@@ -878,11 +881,11 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
   constexpr int DU = 8;                          // rows in flight per 8-lane group and trip
   auto k_ptr = [&](int s0) -> const KT* {
     if constexpr (KV8) return Kc + (size_t)s0 * 64 + sub * 8;
-    else return s0 < n_cached ? Kc + (size_t)s0 * 64 + sub * 8 : NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.k_col0 + h * 64 + sub * 8;
+    else return s0 < n_cached ? Kc + crow(s0) + sub * 8 : NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.k_col0 + h * 64 + sub * 8;
   };
   auto v_ptr = [&](int s0) -> const KT* {
     if constexpr (KV8) return Vc + (size_t)s0 * 64 + sub * 8;
-    else return s0 < n_cached ? Vc + (size_t)s0 * 64 + sub * 8 : NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.v_col0 + h * 64 + sub * 8;
+    else return s0 < n_cached ? Vc + crow(s0) + sub * 8 : NEW + (size_t)(b * n + (s0 - n_cached)) * a.ld_new + a.v_col0 + h * 64 + sub * 8;
   };
   {
     Raw8<KT> nxt[DU];
@@ -1468,8 +1471,11 @@ __global__ __launch_bounds__(256) void decode_self_attn_wave_kernel(const DecAtt
   if (h >= a.n_heads) return;
   const int hist = a.hist_dev ? *a.hist_dev : a.hist;          // keys 0 .. hist - 1 are cached, key `hist` is the new row
   const int sub = lane & 7, grp = lane >> 3;
-  bf16_t* Kc = reinterpret_cast<bf16_t*>(a.k_base) + (size_t)b * a.stride_b + (size_t)h * a.stride_h;
-  bf16_t* Vc = reinterpret_cast<bf16_t*>(a.v_base) + (size_t)b * a.stride_b + (size_t)h * a.stride_h;
+  // cache row s: contiguous extent, or through the block table (a wave instruction covers 8 consecutive rows = one 16-position page: the lookup is wave-uniform)
+  const int32_t* pt = a.page_table ? a.page_table + (size_t)b * a.pages_per_seq : nullptr;
+  bf16_t* Kc = reinterpret_cast<bf16_t*>(a.k_base) + (pt ? (size_t)h * 1024 : (size_t)b * a.stride_b + (size_t)h * a.stride_h);
+  bf16_t* Vc = reinterpret_cast<bf16_t*>(a.v_base) + (pt ? (size_t)h * 1024 : (size_t)b * a.stride_b + (size_t)h * a.stride_h);
+  auto crow = [&](int s) -> size_t { return pt ? (size_t)pt[s >> 4] * (size_t)a.page_stride + (size_t)(s & 15) * 64 : (size_t)s * 64; };
   const bf16_t* NEW = reinterpret_cast<const bf16_t*>(a.kv_new) + (size_t)b * a.ld_new + h * 64 + sub * 8;
   Raw8<bf16_t> q8, nk, nv;
   q8.load(reinterpret_cast<const bf16_t*>(a.q) + (size_t)b * a.ld_q + a.q_col0 + h * 64 + sub * 8);
@@ -1492,11 +1498,12 @@ __global__ __launch_bounds__(256) void decode_self_attn_wave_kernel(const DecAtt
   for (int u = 0; u < 8; ++u) {
     kr[u].v = make_uint4(0, 0, 0, 0); vr[u].v = make_uint4(0, 0, 0, 0);      // slots past the history stay finite: 0 x garbage could be NaN
     const int s0 = u * 8 + grp;
-    if (s0 < hist) { kr[u].load(Kc + (size_t)s0 * 64 + sub * 8); vr[u].load(Vc + (size_t)s0 * 64 + sub * 8); }
+    if (s0 < hist) { const size_t ro = crow(s0); kr[u].load(Kc + ro + sub * 8); vr[u].load(Vc + ro + sub * 8); }
   }
   if (grp == 0) {                                            // append the new row (read back only by later steps)
-    *reinterpret_cast<uint4*>(Kc + (size_t)hist * 64 + sub * 8) = nk.v;
-    *reinterpret_cast<uint4*>(Vc + (size_t)hist * 64 + sub * 8) = nv.v;
+    const size_t ro = crow(hist);
+    *reinterpret_cast<uint4*>(Kc + ro + sub * 8) = nk.v;
+    *reinterpret_cast<uint4*>(Vc + ro + sub * 8) = nv.v;
   }
   float qf[8];
   q8.get(qf);
@@ -1517,7 +1524,7 @@ __global__ __launch_bounds__(256) void decode_self_attn_wave_kernel(const DecAtt
       for (int u = 0; u < 8; ++u) {
         const int s1 = blk + 64 + u * 8 + grp;
         kr[u].v = make_uint4(0, 0, 0, 0); vr[u].v = make_uint4(0, 0, 0, 0);
-        if (s1 < hist) { kr[u].load(Kc + (size_t)s1 * 64 + sub * 8); vr[u].load(Vc + (size_t)s1 * 64 + sub * 8); }
+        if (s1 < hist) { const size_t ro = crow(s1); kr[u].load(Kc + ro + sub * 8); vr[u].load(Vc + ro + sub * 8); }
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 8, 64));

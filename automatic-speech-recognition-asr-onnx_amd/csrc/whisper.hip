@@ -41,6 +41,17 @@ struct WhSession : asr_session {
   DeviceBuffer d_plan, d_audio, d_mel, d_blkmax, d_x0, d_h1, d_xa, d_xb, d_xc, d_h, d_qk, d_vt, d_ctx, d_ffn, d_cross;
   // decoder state
   DeviceBuffer d_kc, d_vc, d_ids, d_next, d_logits, d_dx, d_dqkv, d_dtok, d_hist;
+  // Paged self-KV cache (the default; ASR_KV_PAGED=0 keeps one contiguous max_target_positions extent per sequence and head in d_kc / d_vc).
+  // Pool d_kvpool: pages of KV_PAGE positions, page-major [page][layer][K | V][head][KV_PAGE][64], so a page carries one 16-position slice of a
+  // sequence for every layer and the pool grows by appending pages (the old pool is a prefix of the new one: one copy). Block table d_ptable
+  // [batch][pages_per_seq] (int32 page ids, -1 = not allocated), shared by all layers. Pages are handed out a generation at a time (generation j = the
+  // j-th page of every sequence of the batch: all sequences of a batch stand at the same position), first for the prompt + 48 positions, then doubling,
+  // so a 32-token batch of 64 holds 4 x 64 pages (0.67 GB at large-v3) instead of 64 x 448 positions (9.4 GB).
+  static constexpr int KV_PAGE = 16;
+  DeviceBuffer d_kvpool, d_ptable;
+  bool kv_paged = true;
+  int kv_gens = 0, kv_batch = 0, kv_shuffle = 0;      // generations allocated, the batch they were cut for; kv_shuffle (tests): permute the page ids inside every generation
+  void ensure_kv_pages(int B, int positions, size_t elem_bytes);
   DeviceBuffer d_save, d_nsaved;       // penalty-greedy: generated ids per sequence [B][max_target_positions] + their count
   bool sampling = false;               // TOPK_TOPP_SAMPLING head (USE_SAMPLING, Inference_Whisper_ONNX.py:71-75)
   float temperature = 0.8f, top_p = 0.95f, samp_rep_penalty = 1.0f;
@@ -74,7 +85,7 @@ struct WhSession : asr_session {
 
   ~WhSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_x0, &d_h1, &d_xa, &d_xb, &d_xc, &d_h, &d_qk, &d_vt, &d_ctx,
-                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise, &d_nsp, &d_skws, &d_skcnt, &d_colsum, &d_dlo, &d_w8, &d_wscale, &d_wdq, &d_cross8, &d_cscale, &d_ew8, &d_ewscale, &d_h8, &d_ffn8})
+                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_kvpool, &d_ptable, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise, &d_nsp, &d_skws, &d_skcnt, &d_colsum, &d_dlo, &d_w8, &d_wscale, &d_wdq, &d_cross8, &d_cscale, &d_ew8, &d_ewscale, &d_h8, &d_ffn8})
       b->release();
     if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
     for (auto& kv : taps) kv.second.buf.release();
@@ -507,8 +518,14 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
       ProfScope ps(prof, "dec_self_attn", stream);
       DecAttnArgs a;
       a.q = qkv; a.ld_q = 3 * d; a.q_col0 = 0; a.kv_new = qkv; a.ld_new = 3 * d; a.k_col0 = d; a.v_col0 = 2 * d;
-      a.k_base = d_kc.as<T>() + l * cache_l; a.v_base = d_vc.as<T>() + l * cache_l;
-      a.stride_b = (int64_t)H * c.max_target_positions * 64; a.stride_h = (int64_t)c.max_target_positions * 64;
+      if (kv_paged) {
+        a.k_base = d_kvpool.as<T>() + (size_t)(l * 2) * H * KV_PAGE * 64; a.v_base = d_kvpool.as<T>() + (size_t)(l * 2 + 1) * H * KV_PAGE * 64;
+        a.page_table = d_ptable.as<int32_t>(); a.pages_per_seq = (c.max_target_positions + KV_PAGE - 1) / KV_PAGE;
+        a.page_stride = (int64_t)Ld * 2 * H * KV_PAGE * 64;
+      } else {
+        a.k_base = d_kc.as<T>() + l * cache_l; a.v_base = d_vc.as<T>() + l * cache_l;
+        a.stride_b = (int64_t)H * c.max_target_positions * 64; a.stride_h = (int64_t)c.max_target_positions * 64;
+      }
       a.plan = nullptr; a.hist = hist; a.hist_dev = hd; a.n = n; a.n_heads = H; a.causal = 1; a.out = ctx; a.ld_out = d;
       a.max_keys = c.max_target_positions;
       launch_decode_attention<T>(a, B, stream);
@@ -608,6 +625,36 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
   }
 }
 
+// Block table + pool of the paged self-KV cache: make sure every sequence of the batch owns pages for `positions` positions. Growth appends whole
+// generations (page ids j * B + slot, slot = b or -- tests -- a permutation of the batch), copies the old pool (a prefix of the new one), rewrites the table and
+// invalidates the captured decode graph; with the first cut at prompt + 48 positions and doubling, a 448-position generation regrows at most three times.
+void WhSession::ensure_kv_pages(int B, int positions, size_t elem_bytes) {
+  const auto& c = cfg;
+  const int P = (c.max_target_positions + KV_PAGE - 1) / KV_PAGE;
+  const int need = std::min(P, (positions + KV_PAGE - 1) / KV_PAGE);
+  if (B != kv_batch) { kv_gens = 0; kv_batch = B; }                       // another batch: the cache restarts with its prefill
+  if (need <= kv_gens && d_kvpool.ptr && d_ptable.ptr) return;
+  const int gens = std::min(P, std::max(need, kv_gens ? 2 * kv_gens : (positions + 48 + KV_PAGE - 1) / KV_PAGE));
+  const size_t page_bytes = (size_t)c.n_dec_layers * 2 * c.n_heads * KV_PAGE * 64 * elem_bytes;
+  const size_t bytes = (size_t)gens * B * page_bytes, old_bytes = std::min(d_kvpool.cap, (size_t)kv_gens * B * page_bytes);
+  if (bytes > d_kvpool.cap) {
+    DeviceBuffer fresh;
+    fresh.reserve(bytes, stream);
+    if (hist > 0 && old_bytes) HIP_CHECK(hipMemcpyAsync(fresh.ptr, d_kvpool.ptr, old_bytes, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    d_kvpool.release();
+    d_kvpool = fresh;
+  }
+  d_ptable.reserve((size_t)B * P * 4, stream);
+  int32_t* tab = (int32_t*)pinned((size_t)B * P * 4 + 64);
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < P; ++j) tab[(size_t)b * P + j] = j < gens ? j * B + (kv_shuffle ? (B - 1 - b + j) % B : b) : -1;
+  HIP_CHECK(hipMemcpyAsync(d_ptable.ptr, tab, (size_t)B * P * 4, hipMemcpyHostToDevice, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));                                 // (the pinned staging buffer is reused by the step that follows)
+  kv_gens = gens;
+  ++ws_epoch;
+}
+
 template <typename T>
 void WhSession::step(const int32_t* ids_host, int n, bool is_prefill, int32_t* next_out, float* logits_out) {
   const auto& c = cfg;
@@ -621,8 +668,8 @@ void WhSession::step(const int32_t* ids_host, int n, bool is_prefill, int32_t* n
   const size_t eT = sizeof(T);
   const size_t cache_elems = (size_t)Ld * B * H * c.max_target_positions * 64;
   auto grow = [&](DeviceBuffer& buf, size_t bytes) { void* before = buf.ptr; buf.reserve(bytes, stream); if (buf.ptr != before) ++ws_epoch; };
-  grow(d_kc, cache_elems * eT);
-  grow(d_vc, cache_elems * eT);
+  if (kv_paged) ensure_kv_pages(B, hist + n, eT);
+  else { grow(d_kc, cache_elems * eT); grow(d_vc, cache_elems * eT); }
   grow(d_ids, (size_t)B * 8 * 4);
   grow(d_next, (size_t)B * 4);
   grow(d_hist, 256);
@@ -711,6 +758,8 @@ extern "C" int asr_whisper_create(const asr_whisper_config* cfg, const void* are
       if (const char* e = getenv("ASR_FP8_WEIGHTS")) s->fp8_weights = !(e[0] == '0');
       if (const char* e = getenv("ASR_FP8_KV")) s->fp8_kv = !(e[0] == '0');
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
+      if (const char* e = getenv("ASR_KV_PAGED")) s->kv_paged = !(e[0] == '0');
+      if (const char* e = getenv("ASR_KV_PAGE_SHUFFLE")) s->kv_shuffle = e[0] == '1';
       if (const char* e = getenv("ASR_DECODE_GEMM")) s->use_decode_gemm = !(e[0] == '0');
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;

@@ -142,7 +142,8 @@ int asr_paraformer_stream_step(asr_session* s, const float* audio, int audio_mem
  * STFT_Process + WHISPER_ENCODER.forward (Export_Whisper.py:422-447), WHISPER_DECODER_EMBED / _PREFILL / _DECODE /
  * WHISPER_DECODER.forward (:450-497,614-667) and the BEGIN_SUPPRESS / ARGMAX heads (:228-260).
  * The reference passes 2 x n_layers self-KV and 2 x n_layers cross-KV tensors through Python on every call; here
- * they are session state: `encode` fills the cross-KV slabs, `prefill` resets and fills the self-KV cache, `decode`
+ * they are session state: `encode` fills the cross-KV slabs, `prefill` resets and fills the self-KV cache (paged: 16-position
+ * pages from a per-session pool behind a block table that grows with the sequences; ASR_KV_PAGED=0 keeps contiguous extents), `decode`
  * appends one position in place. Batch B = independent utterances (the reference is batch 1). */
 typedef struct asr_whisper_config {
   int32_t sample_rate, n_mels, nfft, hop_length;

@@ -321,3 +321,42 @@ def test_large_v3_bf16_batch64x8s_vs_golden_and_oracle():
     ref = orc.greedy([audios[1]], [prompt.tolist()], 2)
     for s in range(2):
         assert np.abs(got[1][s] - ref["logits"][0][s]).max() < 2e-3 * scale
+
+
+@pytest.mark.parametrize("prec", [BF16, F32])
+def test_paged_self_kv_cache_equals_the_contiguous_extents_bit_for_bit(prec, monkeypatch):
+    """The decoder's self-KV cache is PAGED (the default): 16-position pages from a pool, one block table per batch shared by the layers, pages handed
+    out a generation at a time as the sequences grow (csrc/whisper.hip: ensure_kv_pages; the attention kernels address rows through the table). Three
+    sessions on the same batch -- paged, paged with the page ids of every generation permuted (ASR_KV_PAGE_SHUFFLE=1: the kernels must follow the table,
+    not an assumed order), and one contiguous max_target_positions extent per sequence and head (ASR_KV_PAGED=0, the layout of rounds 1-2) -- must
+    return the same logits bit for bit over a prefill and 75 teacher-forced steps: that crosses four page boundaries and the first growth of the pool
+    (prompt + 48 positions = 4 generations, doubled at position 64: old pages copied, table rewritten, graph re-captured)."""
+    cfg, ck, sup, beg = whisper_setup("whisper_d256_test")
+    eng = sub("engine")
+    audios = [unit_audio(501, 64000), unit_audio(502, 25600), unit_audio(503, 128000)]
+    prompt = [cfg.sot_id, cfg.first_language_id, cfg.transcribe_id, cfg.no_timestamps_id]
+    prompts = np.array([prompt] * 3, np.int32)
+    rng = np.random.default_rng(77)
+    forced = rng.integers(0, cfg.eot_id, (3, 75)).astype(np.int32)
+    out = {}
+    for mode, env in (("paged", {}), ("shuffled", {"ASR_KV_PAGE_SHUFFLE": "1"}), ("contiguous", {"ASR_KV_PAGED": "0"})):
+        for k in ("ASR_KV_PAGE_SHUFFLE", "ASR_KV_PAGED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sess = eng.WhisperSession.from_checkpoint(cfg, ck, precision=prec, suppress_tokens=sup, begin_suppress_tokens=beg)
+        sess.encode(audios)
+        _, logits = sess.prefill(prompts)
+        steps = [logits]
+        for s in range(forced.shape[1]):
+            _, logits = sess.decode(np.ascontiguousarray(forced[:, s:s + 1]), want_logits=True)
+            steps.append(logits)
+        first = np.stack(steps, 1)
+        sess.encode(audios[::-1])                        # a second batch on the same session reuses pool and table
+        _, again = sess.prefill(prompts)
+        out[mode] = (first, again)
+        del sess
+    for mode in ("shuffled", "contiguous"):
+        assert np.array_equal(out["paged"][0], out[mode][0]), mode
+        assert np.array_equal(out["paged"][1], out[mode][1]), mode
+    assert np.isfinite(out["paged"][0]).all()

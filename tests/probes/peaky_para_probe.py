@@ -1,7 +1,7 @@
 """GPU probe: Paraformer-large bf16 vs oracle on a nearest-prototype output layer -- where do picks flip, and how large is the per-token error?"""
 import os, sys
 import numpy as np
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # (checker-side probe: lives under tests/ because it runs the oracle)
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from conftest import sub
 from helpers import kaldi_audio

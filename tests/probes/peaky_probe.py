@@ -2,7 +2,7 @@
 nearest-prototype CTC head built on the oracle's encoder outputs leave (tests/test_sensevoice_gpu.py: peaky-head parity test)."""
 import importlib, os, sys
 import numpy as np
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # (checker-side probe: lives under tests/ because it runs the oracle)
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from conftest import sub
 from helpers import sensevoice_setup, kaldi_audio

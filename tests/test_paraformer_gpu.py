@@ -197,7 +197,7 @@ def test_bf16_batch64_tokens_equal_the_oracle_on_a_head_with_trained_margins():
 
     Why 2.5 s and not the 8 s of the headline batch: rounding the weights to bf16 perturbs the FUNCTION, and because the encoder rows of a
     random-weight model are nearly parallel (cos 0.98 between frames) the CIF weights come out with a common relative bias (8 s: each within
-    0.006 of the oracle's, but their SUM off by up to 0.23 tokens -- tools/probes/peaky_para_probe.py). CIF integrates that bias: by the end
+    0.006 of the oracle's, but their SUM off by up to 0.23 tokens -- tests/probes/peaky_para_probe.py). CIF integrates that bias: by the end
     of an 8 s window every segment boundary has moved by a fifth of a token and the late tokens' decoder rows with it (error of the deciding
     logit differences 0.17 on the first token, 0.9 - 1.6 on the last two, against margins of 0.7 - 1.2). That is a property of CIF under any
     reduced precision, not of a kernel; within 2.5 s the drift stays inside the margins."""

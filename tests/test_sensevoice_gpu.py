@@ -507,7 +507,7 @@ def test_bf16_batch64_tokens_equal_the_oracle_on_a_head_with_trained_margins():
 
     'The measured bf16 error' is the error of the quantity the pick depends on -- logit differences to the oracle's winner -- over the
     classes within `window` of the winner; classes further away are covered by the all-class bound (they would need an error of more
-    than `window` to overtake). The encoder output itself moves by |dh| = 0.18 of |h| = 22.8 in bf16 mode (tools/probes/peaky_probe.py)."""
+    than `window` to overtake). The encoder output itself moves by |dh| = 0.18 of |h| = 22.8 in bf16 mode (tests/probes/peaky_probe.py)."""
     cfg, ck = sensevoice_setup("sensevoice_small")
     eng = sub("engine")
     B, window = 64, 1.0

@@ -245,3 +245,30 @@ def test_batch64_32_steps_every_disagreement_with_the_oracle_is_an_oracle_near_t
     assert (gap <= 2 * e).all(), float(gap.max())
     print(f"whisper_d256 B = {B} x {S} steps, precision {prec}: logit error {e:.4f} of scale {scale:.1f}; {int((picks != top).sum())} of {B * S} picks "
           f"differ (all inside 2 e); {int(clear.sum())} pairs clear 2 e")
+
+
+def test_large_v3_fp8mm_30s_vs_golden_budget():
+    """FP8MM at full dimensions (d_model 1280, d_ffn 5120, 32 + 32 layers): the 30 s clip of the reference-minted golden in a ragged batch of 4 (30 s, 8 s, 30 s,
+    2.5 s -- compacted encoder rows of different counts go through the FP8 GEMM's row tiles), prefill + decode steps teacher-forced on the golden's ids; the
+    logit error next to FP8W's on the same batch, with the budget written down (activations at 4 significant bits in 64 of the encoder's 192 GEMMs)."""
+    g = load_golden("whisper_large_v3")
+    c0 = [c for _, c in golden_cases(g)][0]
+    audios = [unit_audio(c0["audio_seed"], c0["n_samples"]), unit_audio(9201, 128000), unit_audio(9202, 480000), unit_audio(9203, 40000)]
+    prompts = np.tile(c0["prompt"][None], (4, 1))
+    n_new = int(g["n_new"])
+    forced = np.tile(c0["token_ids"][None, :n_new - 1], (4, 1)).astype(np.int32)
+    cfg, ck, sup, beg, smm = _session("whisper_large_v3", FP8MM)
+    lmm = _run(smm, audios, prompts, forced)
+    del smm
+    _, _, _, _, s8 = _session("whisper_large_v3", FP8W)
+    l8 = _run(s8, audios, prompts, forced)
+    scale = max(float(np.abs(c0["top1"]).max()), 50.0)
+    cols = c0["logits"].shape[1]
+    e_mm = float(np.abs(lmm[0][:, ::53][:, :cols] - c0["logits"]).max())
+    e_8 = float(np.abs(l8[0][:, ::53][:, :cols] - c0["logits"]).max())
+    d_rest = float(np.abs(lmm[1:] - l8[1:]).max())
+    print(f"whisper_large_v3 logits scale {scale:.1f}: fp8w error {e_8:.3f}, fp8mm error {e_mm:.3f}; fp8mm vs fp8w on the other three utterances {d_rest:.3f}")
+    assert np.isfinite(lmm).all()
+    assert e_8 < 1.2e-2 * scale
+    assert e_mm < 1.5e-2 * scale                              # measured 4.9e-3 (0.244 of 50)
+    assert d_rest < 1.5e-2 * scale                            # measured 4.6e-3

@@ -885,7 +885,8 @@ def main_whisper(args):
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 (e4m3 storage of decoder weights and cross-K/V)" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": "Whisper-large-v3 %s (1.54 B params), batch=%d x %g s per GPU, encoder + cross-KV + prefill(4) + %d greedy decode steps, audio resident in HBM" % ("bf16 + FP8MM" if args.fp8mm else "bf16 + FP8W" if args.fp8 else "bf16", B, args.seconds, n_tok - 1),
-                       "global_batch": world * B, "parallelism": f"dp{world}"},
+                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "kv_cache": "self-KV paged (16-position pages, block table shared by the layers); cross-K/V ragged extents" if os.environ.get("ASR_KV_PAGED", "1") != "0" else "contiguous extents (ASR_KV_PAGED=0)"},
             "rtf": round(elapsed / (audio_s * args.steps), 7),
             "ms": {k: round(v / args.steps * 1e3, 2) for k, v in t_parts.items()},
             "decode_ms_per_token": round(t_dec / max(n_tok - 1, 1) * 1e3, 3),

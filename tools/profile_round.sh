@@ -39,6 +39,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_whisper -- py
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_whisper30 -- python $R/bench.py --workload whisper --seconds 30 --steps 2 --warmup 2 --no-cpu-baseline > $OUT/stats_whisper30.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_qwen -- python $R/bench.py --workload qwen --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats_qwen.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_paraformer -- python $R/bench.py --workload paraformer --steps 10 --warmup 3 --no-cpu-baseline > $OUT/stats_paraformer.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/b1trace -- python $R/tools/probes/bf16_b1_trace.py > $OUT/b1trace.log 2>&1
+for f in $(find $OUT/b1trace -name "*kernel_trace.csv"); do python $R/tools/trace_summary.py $f > $OUT/sensevoice_bf16_b1_trace_summary.txt; done
 for w in whisper qwen; do for f in $(find $OUT/stats_$w -name "*kernel_trace.csv"); do python $R/tools/trace_summary.py $f > $OUT/${w}_trace_summary.txt; done; done
 # fold the counter passes here (the raw per-dispatch CSVs are tens of MB; gpurun copies back at most 64 MiB)
 python $R/tools/summarize_pmc.py $OUT $OUT/hbm_traffic.json > $OUT/summarize_pmc.log 2>&1

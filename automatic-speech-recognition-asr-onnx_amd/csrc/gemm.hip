@@ -1076,10 +1076,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g, co
   const int n4 = g.N >> 2;
   if (idx >= (size_t)g.M * n4) return;
   const int m = (int)(idx / n4), n = (int)(idx - (size_t)m * n4) * 4;
+  // every partial of this thread is requested before the first add (the summation order stays split order): as a load-add loop the compiler chained the
+  // L2 round trips, 5.5 us for 8 splits of a single window's FFN-2
   float4 v = *reinterpret_cast<const float4*>(ws + (size_t)m * g.N + n);
-  for (int sp = 1; sp < splits; ++sp) {
-    const float4 q = *reinterpret_cast<const float4*>(ws + ((size_t)sp * g.M + m) * g.N + n);
-    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+  for (int sp0 = 1; sp0 < splits; sp0 += 8) {
+    float4 q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = *reinterpret_cast<const float4*>(ws + ((size_t)min(sp0 + j, splits - 1) * g.M + m) * g.N + n);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (sp0 + j < splits) { v.x += q[j].x; v.y += q[j].y; v.z += q[j].z; v.w += q[j].w; }
   }
   if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
   if (g.add) { const float4 q = *reinterpret_cast<const float4*>(g.add + (size_t)m * g.ld_add + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }

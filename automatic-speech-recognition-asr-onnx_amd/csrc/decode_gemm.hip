@@ -160,21 +160,31 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
     if (!*last) return;
     if (wave < TILES) {
       sum = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s2 = 0; s2 < KS; ++s2) {               // fixed order => bit-reproducible; sc1 loads bypass this CU's L1
-        const float* src = g.ws + ((size_t)s2 * rows16 + ti * 16 + frow) * g.N + n0 + tj * 16 + fgrp * 4;
-        f32x4_t q;
-        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(src) : "memory");
-        sum.x += q[0]; sum.y += q[1]; sum.z += q[2]; sum.w += q[3];
-      }
-      if constexpr (FOLD) {                           // the row's statistics over all splits, in split order, parked where the epilogue looks for wave 0's
-        float s1 = 0.0f, s2 = 0.0f;
-        for (int s3 = 0; s3 < KS; ++s3) {
-          u32x2_t q;
-          asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(stat_ws + (size_t)s3 * rows16 + ti * 16 + frow) : "memory");
-          s1 += __uint_as_float(q[0]); s2 += __uint_as_float(q[1]);
+      // fixed order => bit-reproducible; sc1 loads bypass this CU's L1. Up to eight splits' tiles (and statistics) are requested together and waited for ONCE
+      // (the wait names the registers, so no add can move above it): one memory-side round trip per eight splits instead of one per split.
+      u32x2_t sq[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sq[j] = u32x2_t{0u, 0u};
+      float s1 = 0.0f, s2f = 0.0f;
+      for (int s0 = 0; s0 < KS; s0 += 8) {
+        f32x4_t q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int sj = min(s0 + j, KS - 1);
+          const float* src = g.ws + ((size_t)sj * rows16 + ti * 16 + frow) * g.N + n0 + tj * 16 + fgrp * 4;
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(q[j]) : "v"(src) : "memory");
+          if constexpr (FOLD) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=&v"(sq[j]) : "v"(stat_ws + (size_t)sj * rows16 + ti * 16 + frow) : "memory");
         }
-        fold_s1 = s1; fold_s2 = s2;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]),
+                                            "+v"(sq[0]), "+v"(sq[1]), "+v"(sq[2]), "+v"(sq[3]), "+v"(sq[4]), "+v"(sq[5]), "+v"(sq[6]), "+v"(sq[7]) :: "memory");
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (s0 + j < KS) {
+            sum.x += q[j][0]; sum.y += q[j][1]; sum.z += q[j][2]; sum.w += q[j][3];
+            if constexpr (FOLD) { s1 += __uint_as_float(sq[j][0]); s2f += __uint_as_float(sq[j][1]); }
+          }
       }
+      if constexpr (FOLD) { fold_s1 = s1; fold_s2 = s2f; }     // the row's statistics over all splits, in split order, where the epilogue looks for them
     }
   }
   if (wave >= TILES) return;

@@ -873,11 +873,19 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
       const int i = wave + t * SK_WAVES;
       if (i < MT) {
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s2 = 0; s2 < KS; ++s2) {              // fixed order => bit-reproducible; 16-byte sc1 loads (L1 bypassed: the partials were stored write-through)
-          const float* src = g.sk_ws + ((size_t)s2 * rows16 + i * 16 + frow) * g.N + n0 + fgrp * 4;
-          f32x4_t q;
-          asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(src) : "memory");
-          sum.x += q[0]; sum.y += q[1]; sum.z += q[2]; sum.w += q[3];
+        // fixed order => bit-reproducible; 16-byte sc1 loads (L1 bypassed: the partials were stored write-through). Up to eight splits are requested together
+        // and waited for once (the wait names the registers, so no add moves above it)
+        for (int s0 = 0; s0 < KS; s0 += 8) {
+          f32x4_t q[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float* src = g.sk_ws + ((size_t)min(s0 + j, KS - 1) * rows16 + i * 16 + frow) * g.N + n0 + fgrp * 4;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(q[j]) : "v"(src) : "memory");
+          }
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) :: "memory");
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (s0 + j < KS) { sum.x += q[j][0]; sum.y += q[j][1]; sum.z += q[j][2]; sum.w += q[j][3]; }
         }
         sums[t] = sum;
       }

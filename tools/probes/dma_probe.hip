@@ -20,7 +20,7 @@ struct Args {
   int drain;          // 1: vmcnt(0) + barrier per stage; 0: never wait inside the loop; 2: counted (one stage in flight)
   int region_rows;    // rows of the region a workgroup walks (tile rows); regions of the workgroups of one XCD may coincide
   int share;          // workgroups of an XCD use region (wg_in_xcd % share)
-  int to_vgpr;        // 1: plain global_load_dwordx4 into registers instead of the LDS-DMA
+  int to_vgpr;        // 1: plain global_load_dwordx4 into registers instead of the LDS-DMA; 2: MIXED -- odd pieces into registers, even pieces by LDS-DMA (do the two paths add up?)
 };
 
 __global__ __launch_bounds__(512) void probe(const Args a, unsigned* sink) {
@@ -53,14 +53,15 @@ __global__ __launch_bounds__(512) void probe(const Args a, unsigned* sink) {
         const int row = (piece * piece_rows + row_in_piece) % a.region_rows;
         const unsigned char* src = base + (size_t)row * a.pitch + (size_t)ks * kwidth + off_in_row;
         if (a.pattern == 0) src = base + ((size_t)(ks * pieces + piece) * 1024) % ((size_t)a.region_rows * a.pitch) + lane * 16;
-        if (a.to_vgpr) {
+        if (a.to_vgpr == 1 || (a.to_vgpr == 2 && (t & 1))) {
           r[t] = *reinterpret_cast<const uint4*>(src);
         } else {
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                            (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
         }
       }
-      if (a.to_vgpr) { for (int t = 0; t < per_wave; ++t) acc += r[t].x ^ r[t].w; }
+      if (a.to_vgpr == 1) { for (int t = 0; t < per_wave; ++t) acc += r[t].x ^ r[t].w; }
+      if (a.to_vgpr == 2) { for (int t = 1; t < per_wave; t += 2) acc += r[t].x ^ r[t].w; }
       if (a.drain == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
     }
   }
@@ -90,6 +91,10 @@ int main() {
   cases.push_back({"8x128 xor-row pitch4K", 2, 1, 544, 4096, 1, 0, 544});
   cases.push_back({"8x128 linear pitch4K", 1, 1, 544, 4096, 1, 0, 544});
   cases.push_back({"4x256 xor pitch4K", 3, 1, 272, 4096, 1, 0, 272});
+  for (int drain = 0; drain < 2; ++drain) {
+    cases.push_back({"8x128 xor-row MIXED", 2, drain, 544, 1024, 4, 2, 544});
+    cases.push_back({"8x128 linear MIXED", 1, drain, 544, 1024, 4, 2, 544});
+  }
   printf("%-28s %5s %5s %6s %9s %10s %9s\n", "pattern", "vgpr", "drain", "rows", "GB/s/CU", "TB/s chip", "B/clk@2.4");
   for (const Case& c : cases) {
     Args a;

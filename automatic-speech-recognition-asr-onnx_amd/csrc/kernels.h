@@ -204,6 +204,7 @@ struct SanmBlockArgs {
   const bf16_t* wout;                                              // [512][512]
   const bf16_t* w1; const float* b1; const float* c1;              // [2048][512] (LayerNorm affine folded), bias, column sums
   const bf16_t* w2; const float* b2;                               // [512][2048]
+  const void* wpack = nullptr;                                     // round-4 kernel (sanm_block8.hip): fragment-major copy of the four matrices (launch_sanm_block8_pack)
   const bf16_t* x_lo; const float2* st_in;                         // block input rows (bf16) + their row statistics [rows][16] (null: derived in the kernel)
   float* x;                                                        // residual stream f32 [rows][512]: read (phase B) and overwritten (phase D) in place
   bf16_t* x_lo_out; float2* st_out;                                // bf16 copy + row statistics of the block output (may alias x_lo / st_in)
@@ -217,7 +218,10 @@ struct SanmBlockArgs {
 };
 bool sanm_block_supported(int max_T, int d_head, int n_heads, int d, int d_ffn, int fsmn_taps);
 int sanm_block_max_utts();                                         // windows one launch can take (all workgroups co-resident)
-void launch_sanm_block(const SanmBlockArgs& a, hipStream_t s);
+void launch_sanm_block(const SanmBlockArgs& a, hipStream_t s);        // round-2 form: 12 waves, operands staged through LDS rings (ASR_SANM_BLOCK_V=1)
+void launch_sanm_block8(const SanmBlockArgs& a, hipStream_t s);       // round-4 form: 8 waves, chunked A operand, register-streamed packed weights (needs a.wpack)
+size_t sanm_block8_pack_bytes();                                      // bytes of one block's packed weights
+void launch_sanm_block8_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, hipStream_t s);
 void launch_rows_to_bf16(const float* x, bf16_t* y, size_t n, hipStream_t s);     // f32 -> bf16 (RNE) copy, n a multiple of 8
 void launch_sanm_qkv_attn(const SanmFusedArgs& a, hipStream_t s);
 

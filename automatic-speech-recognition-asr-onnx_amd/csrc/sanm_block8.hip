@@ -1,0 +1,782 @@
+// One SANM encoder block (Export_SenseVoice.py:227-258: LayerNorm -> q|k|v -> soft-max attention + FSMN -> out-projection + residual
+// -> LayerNorm -> FFN + residual) as ONE launch for batches of <= 144-row windows (8 s chunks): the bf16 headline path, round-4 form.
+//
+// Decomposition (as in round 2): 64 windows x 4 heads = 256 = one workgroup per CU; the four workgroups (w, h) of window w form a CLUSTER,
+// workgroup h owns head h of the attention half and column slab h of every GEMM, and the A operand of each GEMM phase is what the cluster
+// exchanged at the previous phase boundary. What changed is how a workgroup multiplies:
+//
+//   * 8 waves (512 threads, 256 registers per lane) instead of 12: a wave tile is 144 rows x 48 / 32 / 64 columns, so one A fragment read
+//     from LDS feeds 3 / 2 / 4 MFMAs (the 48 x 32 and 48 x 64 tiles of the 12-wave kernel needed 5 reads per 6 MFMAs and ran the LDS port at 83 %).
+//   * WEIGHTS NEVER TOUCH LDS. Every wave streams the fragments of its own output columns straight from global memory into registers, from a
+//     fragment-major copy of the block's weights made once per session (`launch_sanm_block8_pack`: one contiguous KB per wave instruction, in
+//     the order the wave consumes them). Nothing about W is shared between the waves of a workgroup, so there is nothing to stage.
+//   * The A operand lives in LDS as four 36 KB CHUNKS of 128 columns ([144 rows][256 B], 16-byte slots XOR-swizzled by the row). An exchanged
+//     operand arrives by LDS-DMA, one chunk per `s_barrier`; the workgroup's OWN quarter of every exchange is written into its chunk slot by
+//     the producing epilogue and never comes back from memory: a phase starts multiplying its own chunk while the three foreign ones are in
+//     flight. FFN-2 walks the 16 chunks of `hid` starting with its own four (already in LDS), the ring refilling behind it.
+//   * No barrier inside a chunk, hand-counted `s_waitcnt vmcnt(N)` for both streams (see `Sched`): the compiler's own bookkeeping gives up
+//     (vmcnt(0) / lgkmcnt(0)) while an LDS-DMA is pending, so the W loads are inline asm and their waits are tied to the registers they fill.
+//
+//   A  q|k|v projection of head h (LayerNorm folded in) -> q / k / v^T images in LDS, attention (wave = one 16-query tile; the ninth tile is
+//      shared by all waves: scores redundantly, context split over the head dimension), FSMN        ctx[:, 128 h ..] (bf16)  -- exchange 0 -->
+//   B  out-projection slab (wave = K-half x 32 columns; accumulators start from FSMN term + residual)
+//        -> x1 slab: f32 to memory (own rows, read back in D), bf16 copy + row statistics                                   -- exchange 1 -->
+//   C  FFN-1 slab: relu(LN(x1) W1[512 h ..]^T + b1) -> hid[:, 512 h ..] (bf16)                                              -- exchange 2 -->
+//   D  FFN-2 slab (wave = K-half x 32 columns) + b2 + x1 -> x (f32), bf16 copy + row statistics of the next block
+//
+// Exchange protocol, give-up bound, placement and launch limits are those of round 2 (csrc/sanm_block.hip, which stays as `ASR_SANM_BLOCK_V=1`).
+#include <algorithm>
+#include <type_traits>
+#include <utility>
+#include "kernels.h"
+
+namespace {
+
+constexpr int R = 144, RF = 9;                  // rows / row fragments of a window tile
+constexpr int HD = 128, NH = 4, D = 512, DFF = 2048;
+constexpr int NW = 8, NT = NW * 64;             // waves / threads per workgroup
+constexpr int TAPS = 11;
+constexpr int LDS_BYTES = 160 * 1024;
+// ---- LDS map (bytes)
+constexpr int CH = R * 256;                      // one chunk: 144 rows x 128 bf16 columns = 36864
+constexpr int NSLOT = 4;                         // chunk slots 0 .. 3 at q * CH
+constexpr int QS = 0, KS = CH, KEYS = 160, VS = KS + KEYS * 256, IMG_END = VS + HD * 512;       // phase A images: q (= slot 0, later the ctx chunk), k, v^T
+constexpr int TERM = CH;                         // FSMN term f32 [144][128] over slots 1, 2 (the k image and the head of v^T are dead by then)
+constexpr int RED = 2 * CH;                      // K-half exchange of phases B / D over slots 2, 3 (72 KB)
+constexpr int ST_F = NSLOT * CH;                 // (mean, rstd) [144] float2
+constexpr int ST_P = ST_F + R * 8;               // statistics partials [2][144] float2 (blocks without producer statistics)
+static_assert(IMG_END <= ST_F && TERM + R * HD * 4 <= ST_F && ST_P + 2 * R * 8 <= LDS_BYTES, "LDS map");
+
+// ---- fragment-major weight copy of one block, bytes from the block's base (see launch_sanm_block8_pack for the element order)
+constexpr size_t PK_QKV = 0, PK_QKV_WAVE = 16 * 3 * 1024;                       // [h][wave][16 steps][3 frags][64 lanes][16 B]
+constexpr size_t PK_OUT = PK_QKV + (size_t)NH * NW * PK_QKV_WAVE, PK_OUT_WAVE = 8 * 2 * 1024;
+constexpr size_t PK_W1 = PK_OUT + (size_t)NH * NW * PK_OUT_WAVE, PK_W1_WAVE = 16 * 4 * 1024;
+constexpr size_t PK_W2 = PK_W1 + (size_t)NH * NW * PK_W1_WAVE, PK_W2_WAVE = 32 * 2 * 1024;
+constexpr size_t PK_BYTES = PK_W2 + (size_t)NH * NW * PK_W2_WAVE;
+static_assert(PK_BYTES == (size_t)(3 * D * D + D * D + 2 * DFF * D) * 2, "the packed copy holds every weight element once");
+
+__device__ __host__ constexpr int frag_col(int j, int fr) { return (j >> 1) * 32 + ((fr >> 2) << 3) + ((j & 1) << 2) + (fr & 3); }
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+// write-through (sc1) stores: the payload of an exchange must be in memory, not dirty in this XCD's L2, when the flag is raised
+__device__ __forceinline__ void store16_wt(void* p, uint4 v) {
+  const u32x4_t w = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ void store8_wt(void* p, float2 v) {
+  const f32x2_t w = {v.x, v.y};
+  asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+}
+
+// count this workgroup in on an exchange flag: every wave's stores drained, then one relaxed agent-scope add
+__device__ __forceinline__ void publish(unsigned* flag, bool withhold = false) {     // withhold: fault injection (tests), the count never arrives
+  wait_vm<0>();
+  __syncthreads();
+  if (threadIdx.x == 0 && !withhold) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wait until all `need` workgroups of the cluster are in; ONE acquire (drops this CU's stale L1 lines), then ordinary loads
+__device__ __forceinline__ void consume(unsigned* flag, unsigned need, unsigned* err) {
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      __builtin_amdgcn_s_sleep(2);
+      // a cluster in step waits a few us here; 2^13 polls (about 8 ms with the sleep and the L2 round trip) means the cluster is not
+      // co-resident: give up, never hang -- the host redoes the pass on the four-launch path and keeps the session there for a while
+      if (++spins > (1u << 13)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if ((spins & 255u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;           // somebody already gave up: the launch is void anyway
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+  uint4 w;
+  w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]); w.z = pack_bf16x2(v[4], v[5]); w.w = pack_bf16x2(v[6], v[7]);
+  return w;
+}
+// (sum, sum of squares) of the 8 bf16-ROUNDED values of a packed group
+__device__ __forceinline__ void stats8(const uint4& w, float& s1, float& s2) {
+  const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float lo = __uint_as_float(wd[e] << 16), hi = __uint_as_float(wd[e] & 0xffff0000u);
+    s1 += lo + hi;
+    s2 = fmaf(lo, lo, fmaf(hi, hi, s2));
+  }
+}
+
+template <int... I, typename F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+#define GLDS(gptr, lptr) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+// one chunk (144 rows x 256 B of a row-major bf16 matrix) -> an LDS slot. One wave instruction lands four rows; 36 pieces over 8 waves = five per
+// wave (the spare slots reload the last piece: same bytes, same place), so every wave's queue sees exactly five operations per chunk.
+constexpr int DMA_PER_CHUNK = 5;
+__device__ __forceinline__ void issue_chunk(const unsigned char* src, int ld_bytes, int rows_left, unsigned char* slot, int wave, int lane) {
+#pragma unroll
+  for (int t = 0; t < DMA_PER_CHUNK; ++t) {
+    const int piece = min(wave + NW * t, R / 4 - 1);
+    const int m = piece * 4 + (lane >> 4);
+    GLDS(src + (size_t)min(m, rows_left - 1) * ld_bytes + (((lane & 15) ^ (m & 15)) << 4), slot + piece * 1024);
+  }
+}
+
+// ---- the in-order queue of one wave inside a chunk loop, as compile-time arithmetic. A loop walks NQ chunks, this wave multiplies TPC K-steps
+// of each with NJ W fragments per step; the W fragment sets are PF deep: the PF first are prefetched by the caller, set (s % PF) is refilled
+// right after the MFMAs of step s were issued (for step s + PF). Chunks below SEEDED are already in LDS; chunks SEEDED .. 3 are requested in
+// front of the loop (after the prefetch), chunk q >= 4 at the start of iteration q - 3 (behind that iteration's barrier).
+//   after_dma(q): operations this wave issued behind chunk q's DMA when iteration q starts  -> vmcnt bound for "chunk q has landed"
+//   after_w(s):   operations issued behind the W set of step s when step s starts           -> vmcnt bound for "the set is in its registers"
+// Operations the bookkeeping does not know of can only make a bound stricter than necessary, never unsafe.
+template <int NJ, int NQ, int TPC, int PF, int SEEDED>
+struct Sched {
+  static constexpr int NS = NQ * TPC;
+  static constexpr bool refill(int s) { return s >= 0 && s + PF < NS; }
+  static constexpr bool dma_exists(int q) { return q >= SEEDED && q < NQ; }
+  static constexpr bool inloop_dma(int it) { return it >= 1 && it + 3 >= 4 && dma_exists(it + 3); }
+  static constexpr int cap(int n) { return n > 63 ? 63 : n; }
+  static constexpr int refills_in_iter(int it) { int n = 0; for (int t = 0; t < TPC; ++t) n += refill(it * TPC + t) ? NJ : 0; return n; }
+  static constexpr int after_dma(int q) {
+    int n = 0;
+    if (q < 4) {
+      for (int p = q + 1; p < 4; ++p) n += dma_exists(p) ? DMA_PER_CHUNK : 0;
+      for (int it = 1; it < q; ++it) n += inloop_dma(it) ? DMA_PER_CHUNK : 0;
+      for (int it = 0; it < q; ++it) n += refills_in_iter(it);
+    } else {
+      for (int it = q - 3 + 1; it < q; ++it) n += inloop_dma(it) ? DMA_PER_CHUNK : 0;
+      for (int it = q - 3; it < q; ++it) n += refills_in_iter(it);
+    }
+    return cap(n);
+  }
+  static constexpr int after_w(int s) {
+    int n = 0;
+    if (s < PF) {
+      n += (PF - 1 - s) * NJ;
+      for (int p = 0; p < 4; ++p) n += dma_exists(p) ? DMA_PER_CHUNK : 0;
+      for (int p = 0; p < s; ++p) n += refill(p) ? NJ : 0;
+      for (int it = 1; it <= s / TPC; ++it) n += inloop_dma(it) ? DMA_PER_CHUNK : 0;
+    } else {
+      for (int p = s - PF + 1; p < s; ++p) n += refill(p) ? NJ : 0;
+      for (int it = (s - PF) / TPC + 1; it <= s / TPC; ++it) n += inloop_dma(it) ? DMA_PER_CHUNK : 0;
+    }
+    return cap(n);
+  }
+};
+
+// W fragment loads by inline asm (see the header): `p` = this lane's position in the wave's stream, one set = NJ consecutive KB
+#define ASR_WLOAD(J) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(set[J]) : "v"(p), "n"((J) * 1024) : "memory")
+template <int NJ>
+__device__ __forceinline__ void wload_set(bf16x8_t (&set)[NJ], const unsigned char* p) {
+  ASR_WLOAD(0); ASR_WLOAD(1);
+  if constexpr (NJ > 2) ASR_WLOAD(2);
+  if constexpr (NJ > 3) ASR_WLOAD(3);
+}
+#undef ASR_WLOAD
+template <int N> __device__ __forceinline__ void wait_set(bf16x8_t (&s)[2]) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s[0]), "+v"(s[1]) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_set(bf16x8_t (&s)[3]) { asm volatile("s_waitcnt vmcnt(%3)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_set(bf16x8_t (&s)[4]) { asm volatile("s_waitcnt vmcnt(%4)" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]) : "n"(N) : "memory"); }
+
+template <int NJ, int PF>
+__device__ __forceinline__ void w_prefetch(bf16x8_t (&wf)[PF][NJ], const unsigned char* wp) {
+  static_for<PF>([&](auto s) __attribute__((always_inline)) { wload_set<NJ>(wf[decltype(s)::value], wp + (size_t)decltype(s)::value * NJ * 1024); });
+}
+
+// ---- acc[144][16 NJ] += chunks x W. VMASK: fragments j with bit j set multiply in the un-swapped operand order (acc[i][j][r] = C[16 i + 4 (lane >> 4) + r][lane & 15]: the
+// time-contiguous V^T); the others in the swapped order (acc[i][j][r] = C[16 i + (lane & 15)][4 (lane >> 4) + r] within the fragment's 16 columns).
+// kg0 = first K-step of a chunk this wave multiplies (a K-half wave: 0 or TPC); issue(q) requests chunk q into slot q & 3; gate() runs once, in front of the
+// first request (the exchange wait).
+template <int NJ, int NQ, int TPC, int PF, int SEEDED, int VMASK, typename IssueF, typename GateF>
+__device__ __forceinline__ void chunk_gemm(unsigned char* smem, const unsigned char* wp, bf16x8_t (&wf)[PF][NJ], int kg0, int lane, f32x4_t (&acc)[RF][NJ], IssueF&& issue, GateF&& gate) {
+  using S = Sched<NJ, NQ, TPC, PF, SEEDED>;
+  const int frow = lane & 15, fgrp = lane >> 4;
+  const unsigned char* ab[TPC];
+#pragma unroll
+  for (int t = 0; t < TPC; ++t) ab[t] = smem + frow * 256 + ((((kg0 + t) & 3) ^ (frow >> 2)) << 6) + ((fgrp ^ (frow & 3)) << 4);
+  if constexpr (SEEDED < 4) {
+    gate();
+    static_for<4>([&](auto q) __attribute__((always_inline)) { if constexpr (S::dma_exists(decltype(q)::value)) issue(decltype(q)::value); });
+  }
+  static_for<NQ>([&](auto qt) __attribute__((always_inline)) {
+    constexpr int q = decltype(qt)::value;
+    if constexpr (S::dma_exists(q)) wait_vm<S::after_dma(q)>();
+    __builtin_amdgcn_s_barrier();          // raw barrier (the fence of a __syncthreads would drain the queues): chunk q is in LDS for everyone, chunk q - 1 is consumed
+    if constexpr (S::inloop_dma(q)) {
+      if constexpr (SEEDED >= 4 && q == SEEDED - 3) gate();
+      issue(q + 3);
+    }
+    static_for<TPC>([&](auto tt) __attribute__((always_inline)) {
+      constexpr int t = decltype(tt)::value, s = q * TPC + t, set = s % PF;
+      bf16x8_t af[RF];
+#pragma unroll
+      for (int i = 0; i < RF; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(ab[t] + (q & 3) * CH + i * 4096);
+      wait_set<S::after_w(s)>(wf[set]);
+#pragma unroll
+      for (int i = 0; i < RF; ++i)
+        static_for<NJ>([&](auto jt) __attribute__((always_inline)) {
+          constexpr int j = decltype(jt)::value;
+          if constexpr ((VMASK >> j) & 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[set][j], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[set][j], af[i], acc[i][j], 0, 0, 0);
+        });
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (S::refill(s)) wload_set<NJ>(wf[set], wp + (size_t)(s + PF) * NJ * 1024);
+    });
+  });
+}
+
+// K-half exchange of phases B / D: wave (kh, cg) holds a [144][32] partial over its half of K; kh = 0 ends up with row fragments 0 .. 4, kh = 1 with 5 .. 8 of the
+// sum (always kh 0 + kh 1). `red` = 72 KB of LDS nobody reads any more.
+__device__ __forceinline__ void khalf_exchange(unsigned char* red, int kh, int cg, int lane, f32x4_t (&acc)[RF][2]) {
+  // (value selects, not branches over the two halves: a branch per half makes the compiler merge the two store sequences through a pointer phi, and the
+  //  accumulator array then lives in scratch memory)
+  unsigned char* mine = red + (size_t)cg * RF * 2048 + lane * 16;
+  const bool lo = kh == 0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {             // slot k: fragment 5 + k of K-half 0 (k < 4) / fragment k of K-half 1
+    const int i0 = k < 4 ? 5 + k : 8;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x4_t v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = lo ? acc[i0][j][r] : acc[k][j][r];
+      if (k < 4 || !lo) *reinterpret_cast<f32x4_t*>(mine + (lo ? i0 : k) * 2048 + j * 1024) = v;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {             // K-half 0 adds fragments 0 .. 4 of K-half 1; K-half 1 adds fragments 5 .. 8 of K-half 0
+    const int i0 = k < 4 ? 5 + k : 8;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x4_t r4 = *reinterpret_cast<const f32x4_t*>(mine + (lo ? k : i0) * 2048 + j * 1024);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[k][j][r] += lo ? r4[r] : 0.0f;
+        if (k < 4) acc[i0][j][r] += lo ? 0.0f : r4[r];
+      }
+    }
+  }
+}
+
+// Per-phase views: the kernel arguments are re-read from the kernarg segment and the lane id is made opaque at every phase start, so the compiler cannot
+// hoist a later phase's pointers / per-lane offsets above an earlier loop (they would be spilled around it, and a scratch reload next to hand-counted
+// vmcnt waits costs a full drain -- or, worse, falsifies the count)
+typedef const __attribute__((address_space(4))) SanmBlockArgs* KernArgs;
+__device__ __forceinline__ KernArgs phase_args() {
+  KernArgs p = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+#define STAMP(k) do { if (a->times && threadIdx.x == 0) a->times[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+
+__global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_byval) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  KernArgs a = phase_args();
+  int lane = tid & 63;
+  int frow = lane & 15, fgrp = lane >> 4;
+  // cluster placement: workgroup b runs on XCD b % 8 (observed, not guaranteed): the four workgroups of a window get ids 8 apart
+  int cl, h;
+  if (a->scatter) { cl = blockIdx.x >> 2; h = blockIdx.x & 3; }            // test mode: a cluster spread over four XCDs
+  else { const int idx = blockIdx.x >> 3; cl = ((idx >> 2) << 3) + (blockIdx.x & 7); h = idx & 3; }
+  if (cl >= a->n_utts) return;
+  const int u = a->utt0 + cl;
+  const UttPlan up = a->plan[u];
+  const int T = up.T, row0 = up.row_off;
+  const int n_act = (T + 15) >> 4;                        // active row fragments (cluster-uniform)
+  const int rows_left = a->n_rows_alloc - row0;            // readable rows from row0 on
+  unsigned* flags = a->flags + (size_t)cl * 4;
+  const int kh = wave >> 2, cg = wave & 3;                 // phases B / D: K-half, 32-column group
+  STAMP(0);
+
+  f32x4_t accb[RF][2];                                     // phase B accumulators: start from the residual (requested before the FSMN), then + FSMN term
+  // ================================================================ phase A: q|k|v projection of head h, attention, FSMN
+  {
+    float2* st_fin = reinterpret_cast<float2*>(smem + ST_F);
+    const bool ln_here = !a->st_in;                        // no producer statistics (first block after a stand-alone LayerNorm): derive them from the rows
+    {
+      const unsigned char* wp = reinterpret_cast<const unsigned char*>(a->wpack) + PK_QKV + (size_t)(h * NW + wave) * PK_QKV_WAVE + lane * 16;
+      bf16x8_t wf[3][3];
+      w_prefetch<3, 3>(wf, wp);
+      const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(a->x_lo + (size_t)row0 * D);
+      f32x4_t acc[RF][3];
+#pragma unroll
+      for (int i = 0; i < RF; ++i) { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][2] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+      chunk_gemm<3, 4, 4, 3, 0, 4>(smem, wp, wf, 0, lane, acc,
+                                   [&](int q) __attribute__((always_inline)) { issue_chunk(xsrc + q * 256, D * 2, rows_left, smem + q * CH, wave, lane); }, []() __attribute__((always_inline)) {});
+      if (!ln_here && tid < R) {                           // (in flight under the loop's tail: consumed after the barriers below)
+        const float2 ss = sum_row_partials(a->st_in + (size_t)(row0 + min(tid, rows_left - 1)) * (D / 32), D / 32);
+        const float mean = ss.x * (1.0f / D);
+        const float var = fmaxf(ss.y * (1.0f / D) - mean * mean, 0.0f);
+        st_fin[tid] = make_float2(mean, rsqrtf(var + a->ln_eps));
+      }
+      __syncthreads();                                      // every wave is done with the chunks
+      STAMP(1);
+      if (ln_here) {                                        // two threads per row, two chunks each
+        float2* st_part = reinterpret_cast<float2*>(smem + ST_P);
+        if (tid < 2 * R) {
+          const int row = tid % R, part = tid / R;
+          float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int p = 0; p < 16; ++p) stats8(*reinterpret_cast<const uint4*>(smem + (2 * part + c) * CH + row * 256 + p * 16), s1, s2);
+          st_part[part * R + row] = make_float2(s1, s2);
+        }
+        __syncthreads();
+        if (tid < R) {
+          const float2 p0 = st_part[tid], p1 = st_part[R + tid];
+          const float mean = (p0.x + p1.x) * (1.0f / D);
+          const float var = fmaxf((p0.y + p1.y) * (1.0f / D) - mean * mean, 0.0f);
+          st_fin[tid] = make_float2(mean, rsqrtf(var + a->ln_eps));
+        }
+        __syncthreads();
+      }
+      // ---- images. Waves 0-3 hold q columns 32 (w & 3) .., waves 4-7 the k columns (swapped order, fragment pair = 8 consecutive columns per lane);
+      //      every wave holds v column 16 w + (lane & 15) for rows 16 i + 4 (lane >> 4) .. + 3 (un-swapped order: time-contiguous V^T)
+      {
+        const int grp = wave >> 2, sub = wave & 3;
+        unsigned char* dst = smem + (grp == 0 ? QS : KS);
+        const int col = sub * 32 + fgrp * 8;
+        const float* bp = a->bqkv + grp * D + h * HD + col;
+        const float* cp = a->cqkv + grp * D + h * HD + col;
+        const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+        const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
+        const float b8[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, c8[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+        for (int i = 0; i < RF; ++i) {
+          const int row = i * 16 + frow;
+          const float2 mr = st_fin[row];
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] = acc[i][0][r]; v[4 + r] = acc[i][1][r]; }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (v[e] - mr.x * c8[e]) * mr.y + b8[e];
+          *reinterpret_cast<uint4*>(dst + row * 256 + ((((col >> 3)) ^ (row & 15)) << 4)) = pack8(v);
+        }
+        const int dcol = wave * 16 + frow;
+        const float bv = a->bqkv[2 * D + h * HD + dcol], cs = a->cqkv[2 * D + h * HD + dcol];
+        unsigned char* vdst = smem + VS + dcol * 512 + (fgrp & 1) * 8;
+#pragma unroll
+        for (int i = 0; i < RF; ++i) {
+          float v[4] = {acc[i][2][0], acc[i][2][1], acc[i][2][2], acc[i][2][3]};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float2 mr = st_fin[i * 16 + fgrp * 4 + r]; v[r] = (v[r] - mr.x * cs) * mr.y + bv; }
+          uint2 w;
+          w.x = pack_bf16x2(v[0], v[1]);
+          w.y = pack_bf16x2(v[2], v[3]);
+          *reinterpret_cast<uint2*>(vdst + (((2 * i + (fgrp >> 1)) ^ (dcol & 15)) << 4)) = w;
+        }
+        if (tid < 2 * HD) {       // keys 144..159 of the last 32-key sub-tile: zeros so that 0 * v stays 0
+          const int d = tid & (HD - 1), slot = 18 + (tid >> 7);
+          *reinterpret_cast<uint4*>(smem + VS + d * 512 + ((slot ^ (d & 15)) << 4)) = make_uint4(0, 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- attention: wave w = the 16-query tile w with all <= 160 scores in registers (one soft-max pass); the ninth tile (queries 128..143) is shared:
+    //      every wave computes its scores and multiplies ONE 16-wide slice of the head dimension. A context tile goes back into the (dead) q rows of
+    //      the image, which is exactly the chunk format phase B reads.
+    {
+      const unsigned char* Qs = smem + QS;
+      const unsigned char* Ks = smem + KS;
+      const unsigned char* Vs = smem + VS;
+      const int fq = frow, g = fgrp;
+      const int n_sub = (T + 31) >> 5;
+      const bool shared_tile = T > 128;
+      bf16x8_t qf8[HD / 32];                               // the shared tile's q fragments are read BEFORE any wave may overwrite those rows with context
+      if (shared_tile) {
+        const int qrow = 128 + fq;
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) qf8[ks] = *reinterpret_cast<const bf16x8_t*>(Qs + qrow * 256 + (((ks * 4 + g) ^ (qrow & 15)) << 4));
+      }
+      auto scores = [&](const bf16x8_t (&qf)[HD / 32], bf16x8_t (&pf)[5], float& inv) {
+        f32x4_t st[5][2];
+#pragma unroll
+        for (int s = 0; s < 5; ++s) { st[s][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; st[s][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+          if (s < n_sub) {
+            const int key0 = s * 32 + fq, key1 = key0 + 16;
+#pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks) {
+              const int c = ks * 4 + g;
+              const bf16x8_t kf0 = *reinterpret_cast<const bf16x8_t*>(Ks + key0 * 256 + ((c ^ (key0 & 15)) << 4));
+              const bf16x8_t kf1 = *reinterpret_cast<const bf16x8_t*>(Ks + key1 * 256 + ((c ^ (key1 & 15)) << 4));
+              st[s][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[ks], st[s][0], 0, 0, 0);
+              st[s][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[ks], st[s][1], 0, 0, 0);
+            }
+          }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < 5; ++s)
+#pragma unroll
+          for (int hlf = 0; hlf < 2; ++hlf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = s * 32 + hlf * 16 + g * 4 + r;
+              if (key >= T) st[s][hlf][r] = -INFINITY;
+              mx = fmaxf(mx, st[s][hlf][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float l = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+          float p[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) { p[r] = __expf(st[s][r >> 2][r & 3] - mx); l += p[r]; }
+          union { bf16x8_t v; uint32_t w[4]; } u8;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) u8.w[r] = pack_bf16x2(p[2 * r], p[2 * r + 1]);
+          pf[s] = u8.v;
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        inv = 1.0f / l;
+      };
+      // O^T[d = 16 dt + 4 g + r][q = fq] for dt in [dt0, dt0 + ND) -> context image row qrow, 16-byte chunk dt * 2 + g / 2
+      auto context = [&](const bf16x8_t (&pf)[5], float inv, int qrow, auto dt0_tag, auto nd_tag) {
+        constexpr int ND = decltype(nd_tag)::value;
+        const int dt0 = dt0_tag;
+        f32x4_t ot[ND];
+#pragma unroll
+        for (int e = 0; e < ND; ++e) ot[e] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+          if (s < n_sub) {
+#pragma unroll
+            for (int e = 0; e < ND; ++e) {
+              const int d = (dt0 + e) * 16 + fq;
+              const unsigned char* vr = Vs + d * 512 + (g & 1) * 8;
+              union { bf16x8_t v; uint2 h2[2]; } vf;
+              vf.h2[0] = *reinterpret_cast<const uint2*>(vr + (((s * 4 + (g >> 1)) ^ (d & 15)) << 4));
+              vf.h2[1] = *reinterpret_cast<const uint2*>(vr + (((s * 4 + 2 + (g >> 1)) ^ (d & 15)) << 4));
+              ot[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[s], ot[e], 0, 0, 0);
+            }
+          }
+        }
+        unsigned char* crow = smem + QS + qrow * 256;
+#pragma unroll
+        for (int e = 0; e < ND; ++e) {
+          uint2 w;
+          w.x = pack_bf16x2(ot[e][0] * inv, ot[e][1] * inv);
+          w.y = pack_bf16x2(ot[e][2] * inv, ot[e][3] * inv);
+          *reinterpret_cast<uint2*>(crow + ((((dt0 + e) * 2 + (g >> 1)) ^ (qrow & 15)) << 4) + (g & 1) * 8) = w;
+        }
+      };
+      if (wave * 16 < T) {
+        const int qrow = wave * 16 + fq;
+        bf16x8_t qf[HD / 32], pf[5];
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(Qs + qrow * 256 + (((ks * 4 + g) ^ (qrow & 15)) << 4));
+        float inv;
+        scores(qf, pf, inv);
+        context(pf, inv, qrow, 0, std::integral_constant<int, HD / 16>{});
+      }
+      if (shared_tile) {
+        bf16x8_t pf[5];
+        float inv;
+        scores(qf8, pf, inv);
+        __syncthreads();                                    // every wave holds the shared tile's q fragments: its rows may now take the context
+        context(pf, inv, 128 + fq, wave, std::integral_constant<int, 1>{});
+      }
+    }
+    __syncthreads();
+    STAMP(2);
+    // ---- context rows of this head -> memory (whole 16-byte chunks, write-through) and count the workgroup in on exchange 0; alignment rows past the
+    //      window become zeros in memory AND in the image (the own chunk of phase B must equal what the other heads read back)
+    {
+      bf16_t* cg_ = a->ctx + (size_t)row0 * D + h * HD;
+      for (int c = tid; c < n_act * 16 * 16; c += NT) {
+        const int row = c >> 4, ch = c & 15;
+        unsigned char* src = smem + QS + row * 256 + ((ch ^ (row & 15)) << 4);
+        uint4 v = *reinterpret_cast<const uint4*>(src);
+        if (row >= T) { v = make_uint4(0, 0, 0, 0); *reinterpret_cast<uint4*>(src) = v; }
+        store16_wt(cg_ + (size_t)row * D + ch * 8, v);
+      }
+    }
+    publish(flags + 0, a->fault != 0 && blockIdx.x == 5);
+    STAMP(3);
+    // the residual rows of this workgroup's slab depend on nobody else: request them now (K-half 0 starts from them), they arrive under the FSMN
+#pragma unroll
+    for (int i = 0; i < RF; ++i) {
+      if (kh == 0) {
+        const float* xr = a->x + (size_t)(row0 + min(i * 16 + frow, rows_left - 1)) * D + h * HD + cg * 32 + fgrp * 8;
+        accb[i][0] = *reinterpret_cast<const f32x4_t*>(xr); accb[i][1] = *reinterpret_cast<const f32x4_t*>(xr + 4);
+      } else { accb[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accb[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    }
+    // ---- FSMN memory (thread = channel x time segment of 40 / 40 / 32 / 32 steps, 11 taps from the V^T image) -> registers; once every thread is done
+    //      with the image, -> f32 [144][128] at TERM, 32-byte granules XOR-swizzled by the row so that the phase B prologue reads without conflicts
+    {
+      constexpr int PAD = (TAPS - 1) / 2;
+      const int c = tid & (HD - 1), seg = tid >> 7, cgl = h * HD + c;
+      const int t0 = seg < 2 ? seg * 40 : 80 + (seg - 2) * 32, len = seg < 2 ? 40 : 32;
+      const unsigned char* vrow = smem + VS + c * 512;
+      float wc[TAPS];
+#pragma unroll
+      for (int j = 0; j < TAPS; ++j) wc[j] = a->wfsmn[cgl * TAPS + j];
+      const float bc = a->bfsmn[cgl];
+      float x[56];                                           // time steps t0 - 8 .. t0 + 47
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const int sl = (t0 >> 3) - 1 + q;
+        if (sl < 0 || sl * 8 >= T) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[q * 8 + e] = 0.0f;
+        } else {
+          const uint4 raw = *reinterpret_cast<const uint4*>(vrow + ((sl ^ (c & 15)) << 4));
+          const uint32_t wds[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            x[q * 8 + 2 * e] = (sl * 8 + 2 * e < T) ? __uint_as_float(wds[e] << 16) : 0.0f;
+            x[q * 8 + 2 * e + 1] = (sl * 8 + 2 * e + 1 < T) ? __uint_as_float(wds[e] & 0xffff0000u) : 0.0f;
+          }
+        }
+      }
+      float y[40];
+#pragma unroll
+      for (int i = 0; i < 40; ++i) {
+        float accv = bc;
+#pragma unroll
+        for (int j = 0; j < TAPS; ++j) accv = fmaf(wc[j], x[8 + i + j - PAD], accv);
+        y[i] = accv;
+      }
+      __syncthreads();                                        // the V^T image is dead
+#pragma unroll
+      for (int i = 0; i < 40; ++i) {
+        const int t = t0 + i;
+        if (i < len) *reinterpret_cast<float*>(smem + TERM + t * 512 + (((c >> 3) ^ (t & 15)) << 5) + (c & 7) * 4) = (t < T) ? y[i] : 0.0f;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ================================================================ phase B: out-projection slab + FSMN term + residual -> x1
+  {
+    a = phase_args();
+    lane = opaque(tid & 63); frow = lane & 15; fgrp = lane >> 4;
+    STAMP(4);
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a->wpack) + PK_OUT + (size_t)(h * NW + wave) * PK_OUT_WAVE + lane * 16;
+    bf16x8_t wf[4][2];
+    w_prefetch<2, 4>(wf, wp);
+    if (kh == 0) {
+      const int n = cg * 32 + fgrp * 8;
+#pragma unroll
+      for (int i = 0; i < RF; ++i) {
+        const int row = i * 16 + frow;
+        const unsigned char* mrow = smem + TERM + row * 512 + (((n >> 3) ^ (row & 15)) << 5);
+        accb[i][0] += *reinterpret_cast<const f32x4_t*>(mrow); accb[i][1] += *reinterpret_cast<const f32x4_t*>(mrow + 16);
+      }
+    }
+    __syncthreads();                                          // the term is in registers: slots 1..3 may take the other heads' context chunks
+    const unsigned char* csrc = reinterpret_cast<const unsigned char*>(a->ctx + (size_t)row0 * D);
+    chunk_gemm<2, 4, 2, 4, 1, 0>(smem, wp, wf, 2 * kh, lane, accb,
+                                 [&](int q) __attribute__((always_inline)) { issue_chunk(csrc + ((h + q) & 3) * 256, D * 2, rows_left, smem + q * CH, wave, lane); },
+                                 [&]() __attribute__((always_inline)) { consume(flags + 0, NH, a->err); STAMP(5); });
+    __syncthreads();
+    STAMP(6);
+    khalf_exchange(smem + RED, kh, cg, lane, accb);
+    // x1 rows: f32 -> memory (this workgroup's own slab: phase D reads it back), bf16 -> exchange 1 + the own chunk of phase C (slot 0), row statistics
+    {
+      const int n = cg * 32 + fgrp * 8;
+      float* xo = a->x + (size_t)row0 * D + h * HD + n;
+      bf16_t* xl = a->x1_lo + (size_t)row0 * D + h * HD + n;
+#pragma unroll
+      for (int i = 0; i < RF; ++i) {
+        if ((kh == 0) == (i < 5) && i < n_act) {
+          const int row = i * 16 + frow;
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] = accb[i][0][r]; v[4 + r] = accb[i][1][r]; }
+          *reinterpret_cast<float4*>(xo + (size_t)row * D) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(xo + (size_t)row * D + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          const uint4 pk = pack8(v);
+          store16_wt(xl + (size_t)row * D, pk);
+          *reinterpret_cast<uint4*>(smem + row * 256 + ((((n >> 3)) ^ (row & 15)) << 4)) = pk;
+          float s1 = 0.0f, s2 = 0.0f;
+          stats8(pk, s1, s2);
+          s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+          s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+          if (fgrp == 0) store8_wt(a->st1 + (size_t)(row0 + row) * (D / 32) + h * 4 + cg, make_float2(s1, s2));
+        }
+      }
+    }
+    publish(flags + 1);
+    STAMP(7);
+  }
+
+  // ================================================================ phase C: FFN-1 slab, LayerNorm folded in -> hid slab (exchange 2 + the four own chunks of phase D)
+  {
+    a = phase_args();
+    lane = opaque(tid & 63); frow = lane & 15; fgrp = lane >> 4;
+    float2* st_fin = reinterpret_cast<float2*>(smem + ST_F);
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a->wpack) + PK_W1 + (size_t)(h * NW + wave) * PK_W1_WAVE + lane * 16;
+    bf16x8_t wf[3][4];
+    w_prefetch<4, 3>(wf, wp);
+    f32x4_t acc[RF][4];
+#pragma unroll
+    for (int i = 0; i < RF; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(a->x1_lo + (size_t)row0 * D);
+    chunk_gemm<4, 4, 4, 3, 1, 0>(smem, wp, wf, 0, lane, acc,
+                                 [&](int q) __attribute__((always_inline)) { issue_chunk(xsrc + ((h + q) & 3) * 256, D * 2, rows_left, smem + q * CH, wave, lane); },
+                                 [&]() __attribute__((always_inline)) {
+                                   consume(flags + 1, NH, a->err);
+                                   STAMP(8);
+                                   if (tid < R) {
+                                     const float2 ss = sum_row_partials(a->st1 + (size_t)(row0 + min(tid, rows_left - 1)) * (D / 32), D / 32);
+                                     const float mean = ss.x * (1.0f / D);
+                                     const float var = fmaxf(ss.y * (1.0f / D) - mean * mean, 0.0f);
+                                     st_fin[tid] = make_float2(mean, rsqrtf(var + a->ln_eps));
+                                   }
+                                 });
+    __syncthreads();                                          // every wave is done with the x1 chunks (and the statistics are in LDS)
+    STAMP(9);
+    {
+      bf16_t* hg = a->hid + (size_t)row0 * DFF + h * 512 + wave * 64;
+      unsigned char* slot = smem + (wave >> 1) * CH;           // this wave's 64 hidden columns = half of own chunk wave / 2
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int n = h * 512 + wave * 64 + p * 32 + fgrp * 8;
+        const float4 b0 = *reinterpret_cast<const float4*>(a->b1 + n), b1v = *reinterpret_cast<const float4*>(a->b1 + n + 4);
+        const float4 c0 = *reinterpret_cast<const float4*>(a->c1 + n), c1v = *reinterpret_cast<const float4*>(a->c1 + n + 4);
+        const float b8[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
+        const float c8[8] = {c0.x, c0.y, c0.z, c0.w, c1v.x, c1v.y, c1v.z, c1v.w};
+#pragma unroll
+        for (int i = 0; i < RF; ++i) {
+          const int row = i * 16 + frow;
+          const float2 mr = st_fin[row];
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * p][r]; v[4 + r] = acc[i][2 * p + 1][r]; }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf((v[e] - mr.x * c8[e]) * mr.y + b8[e], 0.0f);
+          const uint4 pk = pack8(v);
+          if (i < n_act) store16_wt(hg + (size_t)row * DFF + p * 32 + fgrp * 8, pk);
+          *reinterpret_cast<uint4*>(slot + row * 256 + (((8 * (wave & 1) + 4 * p + fgrp) ^ (row & 15)) << 4)) = pk;
+        }
+      }
+    }
+    STAMP(10);
+    publish(flags + 2);
+    STAMP(11);
+  }
+
+  // ================================================================ phase D: FFN-2 slab + bias + x1 -> x (f32), bf16 copy + row statistics
+  {
+    a = phase_args();
+    lane = opaque(tid & 63); frow = lane & 15; fgrp = lane >> 4;
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a->wpack) + PK_W2 + (size_t)(h * NW + wave) * PK_W2_WAVE + lane * 16;
+    bf16x8_t wf[4][2];
+    w_prefetch<2, 4>(wf, wp);
+    f32x4_t acc[RF][2];
+#pragma unroll
+    for (int i = 0; i < RF; ++i) { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    const unsigned char* hsrc = reinterpret_cast<const unsigned char*>(a->hid + (size_t)row0 * DFF);
+    chunk_gemm<2, 16, 2, 4, 4, 0>(smem, wp, wf, 2 * kh, lane, acc,
+                                  [&](int q) __attribute__((always_inline)) { issue_chunk(hsrc + ((4 * h + q) & 15) * 256, DFF * 2, rows_left, smem + (q & 3) * CH, wave, lane); },
+                                  [&]() __attribute__((always_inline)) { consume(flags + 2, NH, a->err); STAMP(12); });
+    __syncthreads();
+    STAMP(13);
+    khalf_exchange(smem + RED, kh, cg, lane, acc);
+    const int n = cg * 32 + fgrp * 8;
+    const float4 b0 = *reinterpret_cast<const float4*>(a->b2 + h * HD + n), b1v = *reinterpret_cast<const float4*>(a->b2 + h * HD + n + 4);
+    const float b8[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
+    float* xo = a->x + (size_t)row0 * D + h * HD + n;
+    bf16_t* xl = a->x_lo_out + (size_t)row0 * D + h * HD + n;
+#pragma unroll
+    for (int i = 0; i < RF; ++i) {
+      if ((kh == 0) == (i < 5) && i < n_act) {
+        const int row = i * 16 + frow;
+        const float4 r0 = *reinterpret_cast<const float4*>(xo + (size_t)row * D), r1 = *reinterpret_cast<const float4*>(xo + (size_t)row * D + 4);
+        const float x1[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = acc[i][0][r]; v[4 + r] = acc[i][1][r]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += b8[e] + x1[e];
+        *reinterpret_cast<float4*>(xo + (size_t)row * D) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(xo + (size_t)row * D + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        const uint4 pk = pack8(v);
+        *reinterpret_cast<uint4*>(xl + (size_t)row * D) = pk;
+        float s1 = 0.0f, s2 = 0.0f;
+        stats8(pk, s1, s2);
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (fgrp == 0) a->st_out[(size_t)(row0 + row) * (D / 32) + h * 4 + cg] = make_float2(s1, s2);
+      }
+    }
+    wait_vm<0>();
+    STAMP(14);
+  }
+}
+
+// ---- fragment-major copy of one block's weights (bf16, torch Linear layout [N][K], K contiguous). One thread = one 16-byte lane slot of one fragment.
+// A swapped-order fragment of 16 columns: lane (fr = lane & 15, g = lane >> 4) holds W[n0 + perm(fr)][k0 + 8 g .. + 7]; perm pairs two fragments so that a
+// lane ends with 8 consecutive output columns (frag_col); the un-swapped V fragment holds W[n0 + fr][...].
+struct PackSrc { const bf16_t* wqkv; const bf16_t* wout; const bf16_t* w1; const bf16_t* w2; };
+__global__ void sanm_block8_pack_kernel(PackSrc src, unsigned char* dst) {
+  const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // 16-byte slot of the packed copy
+  if (slot * 16 >= PK_BYTES) return;
+  const size_t byte = slot * 16;
+  const int lane = (int)(slot & 63), fr = lane & 15, g = lane >> 4;
+  const bf16_t* w;
+  int row, k0, ld;
+  if (byte < PK_OUT) {                                  // [h][wave][16 steps][3 frags]: fragments 0, 1 = q (waves 0-3) / k (waves 4-7) columns 32 (wave & 3) .., fragment 2 = v columns 16 wave ..
+    const size_t e = (byte - PK_QKV) / 1024;
+    const int j = (int)(e % 3), s = (int)((e / 3) % 16), wave = (int)((e / 48) % NW), h = (int)(e / (48 * NW));
+    w = src.wqkv; ld = D; k0 = 32 * s + 8 * g;
+    if (j < 2) row = (wave >> 2) * D + h * HD + (wave & 3) * 32 + frag_col(j, fr);
+    else row = 2 * D + h * HD + wave * 16 + fr;
+  } else if (byte < PK_W1) {                            // [h][wave = (kh, cg)][8 steps = chunk order (h + q) & 3, K-steps 2 kh + t][2 frags]
+    const size_t e = (byte - PK_OUT) / 1024;
+    const int j = (int)(e % 2), s = (int)((e / 2) % 8), wave = (int)((e / 16) % NW), h = (int)(e / (16 * NW));
+    const int kh = wave >> 2, cg = wave & 3, q = s >> 1, t = s & 1;
+    w = src.wout; ld = D; k0 = 128 * ((h + q) & 3) + 32 * (2 * kh + t) + 8 * g;
+    row = h * HD + cg * 32 + frag_col(j, fr);
+  } else if (byte < PK_W2) {                            // [h][wave][16 steps = chunk order (h + q) & 3, K-steps t][4 frags]: hidden columns 512 h + 64 wave ..
+    const size_t e = (byte - PK_W1) / 1024;
+    const int j = (int)(e % 4), s = (int)((e / 4) % 16), wave = (int)((e / 64) % NW), h = (int)(e / (64 * NW));
+    const int q = s >> 2, t = s & 3;
+    w = src.w1; ld = D; k0 = 128 * ((h + q) & 3) + 32 * t + 8 * g;
+    row = h * 512 + wave * 64 + frag_col(j, fr);
+  } else {                                              // [h][wave = (kh, cg)][32 steps = chunk order (4 h + q) & 15, K-steps 2 kh + t][2 frags]
+    const size_t e = (byte - PK_W2) / 1024;
+    const int j = (int)(e % 2), s = (int)((e / 2) % 32), wave = (int)((e / 64) % NW), h = (int)(e / (64 * NW));
+    const int kh = wave >> 2, cg = wave & 3, q = s >> 1, t = s & 1;
+    w = src.w2; ld = DFF; k0 = 128 * ((4 * h + q) & 15) + 32 * (2 * kh + t) + 8 * g;
+    row = h * HD + cg * 32 + frag_col(j, fr);
+  }
+  *reinterpret_cast<uint4*>(dst + byte) = *reinterpret_cast<const uint4*>(w + (size_t)row * ld + k0);
+}
+
+}  // namespace
+
+size_t sanm_block8_pack_bytes() { return PK_BYTES; }
+
+void launch_sanm_block8_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, hipStream_t s) {
+  const PackSrc src{wqkv, wout, w1, w2};
+  const unsigned n = (unsigned)(PK_BYTES / 16);
+  hipLaunchKernelGGL(sanm_block8_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, reinterpret_cast<unsigned char*>(dst));
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_sanm_block8(const SanmBlockArgs& a, hipStream_t s) {
+  ASR_REQUIRE(a.n_utts > 0 && a.n_utts <= sanm_block_max_utts(), "sanm_block8: %d windows per launch (max %d)", a.n_utts, sanm_block_max_utts());
+  ASR_REQUIRE(a.wpack && a.x_lo && a.x && a.ctx && a.x1_lo && a.st1 && a.hid && a.x_lo_out && a.st_out && a.flags && a.err && a.plan, "sanm_block8: null buffer");
+  static PerDeviceOnce attr_once;
+  if (attr_once.first())
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sanm_block8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  const int grid = a.scatter ? a.n_utts * 4 : ((a.n_utts + 7) / 8) * 32;
+  hipLaunchKernelGGL(sanm_block8_kernel, dim3(grid), dim3(NT), LDS_BYTES, s, a);
+  HIP_CHECK(hipGetLastError());
+}

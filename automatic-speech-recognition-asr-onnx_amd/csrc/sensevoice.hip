@@ -87,6 +87,10 @@ struct SvSession : asr_session {
   bool use_block = true;        // one launch per SANM block (clusters of four workgroups per window; ASR_SANM_BLOCK=0 disables)
   bool use_fbank_split = true;  // ASR_FBANK_SPLIT=0: exact-f32 MFMA DFT in bf16 sessions too
   DeviceBuffer d_dft_split;
+  int block_v = 8;              // ASR_SANM_BLOCK_V=1: the round-2 form of the block kernel (12 waves, csrc/sanm_block.hip); default: the 8-wave form (csrc/sanm_block8.hip)
+  DeviceBuffer d_wpack;         // 8-wave form: fragment-major copy of every 512 -> 512 block's weights, made once per session (ensure_block_pack)
+  bool wpack_ready = false;
+  void ensure_block_pack();
   int block_fault = 0;          // ASR_SANM_BLOCK_FAULT=1 (tests): one workgroup of the first block launch withholds an exchange count
   int block_giveups = 0;        // forward passes redone on the four-launch path because a cluster gave up (see run())
   int block_cooldown = 0;       // batches left on the four-launch path after a give-up (other sessions are holding CUs: do not walk into the same wait again)
@@ -96,6 +100,7 @@ struct SvSession : asr_session {
     if (const char* e = getenv("ASR_SANM_FUSED")) use_fused = !(e[0] == '0');
     if (const char* e = getenv("ASR_SANM_BLOCK")) use_block = !(e[0] == '0');
     if (const char* e = getenv("ASR_FBANK_SPLIT")) use_fbank_split = !(e[0] == '0');
+    if (const char* e = getenv("ASR_SANM_BLOCK_V")) block_v = (e[0] == '1') ? 1 : 8;
     if (const char* e = getenv("ASR_SANM_BLOCK_SCATTER")) block_scatter = e[0] == '1';
     if (const char* e = getenv("ASR_SANM_BLOCK_FAULT")) block_fault = e[0] == '1';
     if (const char* e = getenv("ASR_SANM_BLOCK_DBG")) block_dbg = atoi(e);
@@ -229,6 +234,20 @@ struct SvRunCtx {
   const int32_t *d_blk_utt, *d_blk_f0, *d_qb_utt, *d_qb_q0, *d_row_utt;
 };
 
+// fragment-major weight copies for the 8-wave block kernel: one pass over the arena's bf16 matrices per session, outside any graph capture
+void SvSession::ensure_block_pack() {
+  if (wpack_ready) return;
+  const size_t per = sanm_block8_pack_bytes();
+  d_wpack.reserve(per * cfg.n_blocks, stream);
+  for (int i = 0; i < cfg.n_blocks; ++i) {
+    const SvBlock& b = blocks[i];
+    if (b.in_size != cfg.d_model) continue;              // (block 0 maps 560 -> 512: it keeps the separate launches)
+    launch_sanm_block8_pack((const bf16_t*)b.wqkv, (const bf16_t*)b.wout, (const bf16_t*)b.w1, (const bf16_t*)b.w2, (unsigned char*)d_wpack.ptr + per * i, stream);
+  }
+  HIP_CHECK(hipStreamSynchronize(stream));
+  wpack_ready = true;
+}
+
 void SvSession::copy_block_status(const SvRunCtx& r) {
   const size_t flag_words = (size_t)cfg.n_blocks * r.batch * 4;
   HIP_CHECK(hipMemcpyAsync((unsigned char*)h_out + (size_t)r.batch * r.max_tokens * 4 + (size_t)r.batch * 4, d_flags.as<unsigned>() + flag_words, 4,
@@ -327,7 +346,8 @@ void SvSession::enqueue(const SvRunCtx& r) {
           ba.flags = d_flags.as<unsigned>() + ((size_t)i * r.batch + u0) * 4; ba.err = d_flags.as<unsigned>() + flag_words;
           ba.n_rows_alloc = Mpad; ba.ln_eps = 1e-5f; ba.scatter = block_scatter; ba.fault = (block_fault && i == 1) ? 1 : 0;
           if (i == block_dbg && u0 == 0) { d_times.reserve(256 * 16 * 8, stream); HIP_CHECK(hipMemsetAsync(d_times.ptr, 0, 256 * 16 * 8, stream)); ba.times = d_times.as<unsigned long long>(); }
-          launch_sanm_block(ba, stream);
+          if (block_v == 8) { ba.wpack = (const unsigned char*)d_wpack.ptr + sanm_block8_pack_bytes() * i; launch_sanm_block8(ba, stream); }
+          else launch_sanm_block(ba, stream);
         }
         st_in = sta;
         if (i == c.n_main - 1 && !paraformer) {
@@ -711,6 +731,9 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   mix((uint64_t)batch); mix((uint64_t)max_tokens); mix((uint64_t)(uintptr_t)r.d_aud); mix(ws_epoch); mix((uint64_t)(uintptr_t)stream);
   mix((uint64_t)(block_cooldown > 0));        // a session cooling down after a cluster give-up replays the four-launch capture, not the block one
 
+  if (sizeof(T) == 2 && use_block && block_v == 8 && cfg.n_blocks > 1 && blocks[cfg.n_blocks - 1].cqkv && blocks[cfg.n_blocks - 1].c1 && batch >= block_min_utts &&
+      sanm_block_supported(max_T, cfg.d_head, cfg.n_heads, cfg.d_model, cfg.d_ffn, cfg.fsmn_kernel))
+    ensure_block_pack();
   // ---- launch: eager the first time a geometry is seen (allocations settle), then capture once and replay ----
   // 570 launches per forward are host-launch-bound when issued eagerly (~13 us each); replay costs ~1 us per node.
   const bool graphable = use_graph && !taps_enabled && !prof.enabled;
@@ -741,23 +764,29 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   if (block_dbg >= 0 && d_times.ptr) {
     std::vector<unsigned long long> t(256 * 16);
     HIP_CHECK(hipMemcpy(t.data(), d_times.ptr, t.size() * 8, hipMemcpyDeviceToHost));
-    static const char* names[13] = {"A loop", "images+attention", "ctx store+publish", "fsmn", "wait 0", "B loop", "B epilogue+publish", "wait 1", "C (both halves)", "publish 2",
-                                    "wait 2", "D loop", "D epilogue"};
+    static const char* names12[13] = {"A loop", "images+attention", "ctx store+publish", "fsmn", "wait 0", "B loop", "B epilogue+publish", "wait 1", "C (both halves)", "publish 2",
+                                      "wait 2", "D loop", "D epilogue"};
+    static const char* names8[14] = {"A loop (4 chunks)", "stats+images+attention", "ctx store+publish", "fsmn", "B prologue+wait 0", "B loop", "B epilogue+publish", "C wait 1+stats",
+                                     "C loop", "C epilogue (hid)", "publish 2", "D own chunk+wait 2", "D loop (rest)", "D epilogue"};
+    const int nk = block_v == 8 ? 14 : 13;
+    const char* const* names = block_v == 8 ? names8 : names12;
     unsigned long long t_first = ~0ull, t_last = 0;
     int n = 0;
-    double sum[13] = {0}, mx[13] = {0};
+    double sum[14] = {0}, mx[14] = {0};
     for (int w = 0; w < 256; ++w) {
       if (!t[w * 16]) continue;
       ++n;
-      t_first = std::min(t_first, t[w * 16]); t_last = std::max(t_last, t[w * 16 + 13]);
-      for (int k = 0; k < 13; ++k) { const double us = (double)(t[w * 16 + k + 1] - t[w * 16 + k]) * 0.01; sum[k] += us; mx[k] = std::max(mx[k], us); }
+      t_first = std::min(t_first, t[w * 16]); t_last = std::max(t_last, t[w * 16 + nk]);
+      for (int k = 0; k < nk; ++k) { const double us = (double)(t[w * 16 + k + 1] - t[w * 16 + k]) * 0.01; sum[k] += us; mx[k] = std::max(mx[k], us); }
     }
     if (n) {
       fprintf(stderr, "[sanm_block %d] %d workgroups, first start -> last end %.1f us\n", block_dbg, n, (double)(t_last - t_first) * 0.01);
-      for (int k = 0; k < 13; ++k) fprintf(stderr, "  %-22s avg %6.2f us  max %6.2f us\n", names[k], sum[k] / n, mx[k]);
-      double c_loops = 0.0;
-      for (int w = 0; w < 256; ++w) if (t[w * 16]) c_loops += (double)t[w * 16 + 14] * 0.01;
-      fprintf(stderr, "  %-22s avg %6.2f us  (inside C: the two GEMM loops without their epilogues)\n", "C loops", c_loops / n);
+      for (int k = 0; k < nk; ++k) fprintf(stderr, "  %-22s avg %6.2f us  max %6.2f us\n", names[k], sum[k] / n, mx[k]);
+      if (block_v != 8) {
+        double c_loops = 0.0;
+        for (int w = 0; w < 256; ++w) if (t[w * 16]) c_loops += (double)t[w * 16 + 14] * 0.01;
+        fprintf(stderr, "  %-22s avg %6.2f us  (inside C: the two GEMM loops without their epilogues)\n", "C loops", c_loops / n);
+      }
     }
   }
   {

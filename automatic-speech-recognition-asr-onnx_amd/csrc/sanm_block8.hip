@@ -44,8 +44,9 @@ constexpr int QS = 0, KS = CH, KEYS = 160, VS = KS + KEYS * 256, IMG_END = VS + 
 constexpr int TERM = CH;                         // FSMN term f32 [144][128] over slots 1, 2 (the k image and the head of v^T are dead by then)
 constexpr int RED = 2 * CH;                      // K-half exchange of phases B / D over slots 2, 3 (72 KB)
 constexpr int ST_F = NSLOT * CH;                 // (mean, rstd) [144] float2
-constexpr int ST_P = ST_F + R * 8;               // statistics partials [2][144] float2 (blocks without producer statistics)
-static_assert(IMG_END <= ST_F && TERM + R * HD * 4 <= ST_F && ST_P + 2 * R * 8 <= LDS_BYTES, "LDS map");
+constexpr int ST_P = ST_F + R * 8;               // statistics partials [4 slots][144] float2
+constexpr int DUMMY = ST_P + NSLOT * R * 8;          // landing area of the L2 warm-up loads (256 B per wave, never read)
+static_assert(IMG_END <= ST_F && TERM + R * HD * 4 <= ST_F && DUMMY + NW * 256 <= LDS_BYTES, "LDS map");
 
 // ---- fragment-major weight copy of one block, bytes from the block's base (see launch_sanm_block8_pack for the element order)
 constexpr size_t PK_QKV = 0, PK_QKV_WAVE = 16 * 3 * 1024;                       // [h][wave][16 steps][3 frags][64 lanes][16 B]
@@ -60,11 +61,13 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 // write-through (sc1) stores: the payload of an exchange must be in memory, not dirty in this XCD's L2, when the flag is raised
-__device__ __forceinline__ void store16_wt(void* p, uint4 v) {
+__device__ __forceinline__ void store16_wt(void* p, uint4 v, bool plain = false) {
+  if (plain) { *reinterpret_cast<uint4*>(p) = v; return; }
   const u32x4_t w = {v.x, v.y, v.z, v.w};
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
 }
-__device__ __forceinline__ void store8_wt(void* p, float2 v) {
+__device__ __forceinline__ void store8_wt(void* p, float2 v, bool plain = false) {
+  if (plain) { *reinterpret_cast<float2*>(p) = v; return; }
   const f32x2_t w = {v.x, v.y};
   asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
 }
@@ -123,6 +126,18 @@ __device__ __forceinline__ void issue_chunk(const unsigned char* src, int ld_byt
     const int m = piece * 4 + (lane >> 4);
     GLDS(src + (size_t)min(m, rows_left - 1) * ld_bytes + (((lane & 15) ^ (m & 15)) << 4), slot + piece * 1024);
   }
+}
+
+// L2 warm-up: the 32 workgroups of an XCD stream the same packed weights a phase later, and the first one to ask for a line pays the trip to HBM with
+// a one-microsecond prefetch distance. Each workgroup asks for its 1 / 32 of the region a phase ahead: one dword per 128-byte line, landed in a dummy
+// LDS area by LDS-DMA (no destination register to keep alive), never waited for on purpose.
+__device__ __forceinline__ void l2_touch(const unsigned char* base, int n_lines, unsigned char* smem, int wave, int tid) {
+  if (!base) return;
+  const int part = blockIdx.x >> 3, n_parts = max(1, (int)(gridDim.x >> 3));
+  const int per = (n_lines + n_parts - 1) / n_parts, l1 = min((part + 1) * per, n_lines);
+  for (int l = part * per + tid; l < l1; l += NT)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)l * 128),
+                                     (__attribute__((address_space(3))) void*)(smem + DUMMY + wave * 256), 4, 0, 0);
 }
 
 // ---- the in-order queue of one wave inside a chunk loop, as compile-time arithmetic. A loop walks NQ chunks, this wave multiplies TPC K-steps
@@ -189,7 +204,8 @@ __device__ __forceinline__ void w_prefetch(bf16x8_t (&wf)[PF][NJ], const unsigne
 // time-contiguous V^T); the others in the swapped order (acc[i][j][r] = C[16 i + (lane & 15)][4 (lane >> 4) + r] within the fragment's 16 columns).
 // kg0 = first K-step of a chunk this wave multiplies (a K-half wave: 0 or TPC); issue(q) requests chunk q into slot q & 3; gate() runs once, in front of the
 // first request (the exchange wait).
-template <int NJ, int NQ, int TPC, int PF, int SEEDED, int VMASK, typename IssueF, typename GateF>
+// ABL: timing-only ablations (results are garbage by design): 1 no MFMA, 2 no A fragment reads after the first, 4 no W refills, 8 no chunk DMA
+template <int NJ, int NQ, int TPC, int PF, int SEEDED, int VMASK, int ABL, typename IssueF, typename GateF>
 __device__ __forceinline__ void chunk_gemm(unsigned char* smem, const unsigned char* wp, bf16x8_t (&wf)[PF][NJ], int kg0, int lane, f32x4_t (&acc)[RF][NJ], IssueF&& issue, GateF&& gate) {
   using S = Sched<NJ, NQ, TPC, PF, SEEDED>;
   const int frow = lane & 15, fgrp = lane >> 4;
@@ -198,31 +214,44 @@ __device__ __forceinline__ void chunk_gemm(unsigned char* smem, const unsigned c
   for (int t = 0; t < TPC; ++t) ab[t] = smem + frow * 256 + ((((kg0 + t) & 3) ^ (frow >> 2)) << 6) + ((fgrp ^ (frow & 3)) << 4);
   if constexpr (SEEDED < 4) {
     gate();
-    static_for<4>([&](auto q) __attribute__((always_inline)) { if constexpr (S::dma_exists(decltype(q)::value)) issue(decltype(q)::value); });
+    static_for<4>([&](auto q) __attribute__((always_inline)) { if constexpr (S::dma_exists(decltype(q)::value) && !(ABL & 8)) issue(decltype(q)::value); });
   }
   static_for<NQ>([&](auto qt) __attribute__((always_inline)) {
     constexpr int q = decltype(qt)::value;
-    if constexpr (S::dma_exists(q)) wait_vm<S::after_dma(q)>();
+    if constexpr (S::dma_exists(q) && !(ABL & (4 | 8))) wait_vm<S::after_dma(q)>();
     __builtin_amdgcn_s_barrier();          // raw barrier (the fence of a __syncthreads would drain the queues): chunk q is in LDS for everyone, chunk q - 1 is consumed
     if constexpr (S::inloop_dma(q)) {
       if constexpr (SEEDED >= 4 && q == SEEDED - 3) gate();
-      issue(q + 3);
+      if constexpr (!(ABL & 8)) issue(q + 3);
     }
     static_for<TPC>([&](auto tt) __attribute__((always_inline)) {
       constexpr int t = decltype(tt)::value, s = q * TPC + t, set = s % PF;
       bf16x8_t af[RF];
+      if constexpr (!(ABL & 2) || s == 0) {
 #pragma unroll
-      for (int i = 0; i < RF; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(ab[t] + (q & 3) * CH + i * 4096);
-      wait_set<S::after_w(s)>(wf[set]);
+        for (int i = 0; i < RF; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(ab[t] + (q & 3) * CH + i * 4096);
+      } else {
 #pragma unroll
-      for (int i = 0; i < RF; ++i)
-        static_for<NJ>([&](auto jt) __attribute__((always_inline)) {
-          constexpr int j = decltype(jt)::value;
-          if constexpr ((VMASK >> j) & 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[set][j], acc[i][j], 0, 0, 0);
-          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[set][j], af[i], acc[i][j], 0, 0, 0);
-        });
+        for (int i = 0; i < RF; ++i) af[i] = wf[set][i % NJ];
+      }
+      if constexpr (!(ABL & 4)) wait_set<S::after_w(s)>(wf[set]); else if constexpr (s < PF) wait_set<0>(wf[set]);
+      if constexpr (ABL & 1) {
+#pragma unroll
+        for (int i = 0; i < RF; ++i) asm volatile("" ::"v"(af[i]));
+        asm volatile("" ::"v"(wf[set][0]), "v"(wf[set][1]));
+        if constexpr (NJ > 2) asm volatile("" ::"v"(wf[set][2]));
+        if constexpr (NJ > 3) asm volatile("" ::"v"(wf[set][3]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < RF; ++i)
+          static_for<NJ>([&](auto jt) __attribute__((always_inline)) {
+            constexpr int j = decltype(jt)::value;
+            if constexpr ((VMASK >> j) & 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[set][j], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[set][j], af[i], acc[i][j], 0, 0, 0);
+          });
+      }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (S::refill(s)) wload_set<NJ>(wf[set], wp + (size_t)(s + PF) * NJ * 1024);
+      if constexpr (S::refill(s) && !(ABL & 4)) wload_set<NJ>(wf[set], wp + (size_t)(s + PF) * NJ * 1024);
     });
   });
 }
@@ -261,6 +290,78 @@ __device__ __forceinline__ void khalf_exchange(unsigned char* red, int kh, int c
   }
 }
 
+// LayerNorm statistics of the 144 bf16 rows whose four chunks sit in the slots (chunk c in slot (c - rot) & 3). One work item = one row of one slot: sixteen
+// 16-byte reads into four independent (sum, sum of squares) accumulator pairs; 576 items over 512 threads. The four partials of a row are then summed in
+// CHUNK order, so the four workgroups of a cluster get the same bits whatever their rotation; (mean, rstd) -> st_fin. Called between barriers. (The row
+// statistics no longer travel with the exchanges: three dependent global loads in front of the loop and the producers' 8-byte write-through stores cost
+// more than this pass over LDS. v_dot2c_f32_bf16 would do it in a third of the instructions, but inline asm escapes the compiler's hazard bookkeeping for
+// dependent DOT operations: measured, results depended on timing.)
+__device__ __forceinline__ void row_stats_from_chunks(unsigned char* smem, int rot, float eps, int tid) {
+  float2* st_part = reinterpret_cast<float2*>(smem + ST_P);
+  for (int v = tid; v < NSLOT * R; v += NT) {
+    const int slot = v / R, row = v - slot * R;
+    const unsigned char* src = smem + slot * CH + row * 256;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const uint4 w = *reinterpret_cast<const uint4*>(src + (((p + row) & 15) << 4));       // (rows are 256 B apart: a common position would be a 16-way bank conflict)
+      const uint32_t wd[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = __uint_as_float(wd[e] << 16), hi = __uint_as_float(wd[e] & 0xffff0000u);
+        s1[e] += lo + hi;
+        s2[e] = fmaf(lo, lo, fmaf(hi, hi, s2[e]));
+      }
+    }
+    st_part[v] = make_float2((s1[0] + s1[1]) + (s1[2] + s1[3]), (s2[0] + s2[1]) + (s2[2] + s2[3]));
+  }
+  __syncthreads();
+  if (tid < R) {
+    float sx = 0.0f, sy = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NSLOT; ++c) { const float2 p = st_part[((c - rot) & 3) * R + tid]; sx += p.x; sy += p.y; }
+    const float mean = sx * (1.0f / D);
+    const float var = fmaxf(sy * (1.0f / D) - mean * mean, 0.0f);
+    reinterpret_cast<float2*>(smem + ST_F)[tid] = make_float2(mean, rsqrtf(var + eps));
+  }
+  __syncthreads();
+}
+
+// ---- row statistics riding the exchanges. A producer epilogue reduces (sum, sum of squares) of its own 128 bf16-rounded columns per row -- lanes -> 32-column
+// groups by two shuffles -> st_part[cg][row] -> one thread per row -> ONE float2 per row and workgroup, stored next to the payload (slot h of the row's 16-slot
+// record). The consumer asks for the four records of its rows (32 B per row, one thread per row) by inline asm in front of its chunk loop and finishes them
+// behind it: no load latency is exposed and nobody passes over the rows a second time.
+// (By LDS-DMA into the partials area, which no producer epilogue uses at that time: registers filled by an asynchronous load must not live across a
+// 230-register loop -- if the compiler spilled them it would store whatever they held before the data arrived.) Every wave issues exactly one instruction.
+__device__ __forceinline__ void row_stats_request(const float2* rec0, int rows_left, unsigned char* smem, int wave, int lane) {
+  const int item = min(wave * 64 + lane, 2 * R - 1), row = item >> 1;          // item = (row, 16-byte half of the 32-byte record head)
+  GLDS(reinterpret_cast<const unsigned char*>(rec0 + (size_t)min(row, rows_left - 1) * (D / 32)) + (item & 1) * 16, smem + ST_P + wave * 1024);
+}
+__device__ __forceinline__ void row_stats_finish(unsigned char* smem, float eps, int tid) {      // tid < R, behind the loop's last barrier
+  const float4 a = *reinterpret_cast<const float4*>(smem + ST_P + tid * 32), b = *reinterpret_cast<const float4*>(smem + ST_P + tid * 32 + 16);
+  const float sx = (a.x + a.z) + (b.x + b.z), sy = (a.y + a.w) + (b.y + b.w);
+  const float mean = sx * (1.0f / D);
+  const float var = fmaxf(sy * (1.0f / D) - mean * mean, 0.0f);
+  reinterpret_cast<float2*>(smem + ST_F)[tid] = make_float2(mean, rsqrtf(var + eps));
+}
+// producer side, step 1 (inside the epilogue's row loop): this lane's 8 values -> its 32-column group's partial
+__device__ __forceinline__ void row_stats_group(const uint4& pk, unsigned char* smem, int cg, int row, int fgrp) {
+  float s1 = 0.0f, s2 = 0.0f;
+  stats8(pk, s1, s2);
+  s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+  s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+  if (fgrp == 0) reinterpret_cast<float2*>(smem + ST_P)[cg * R + row] = make_float2(s1, s2);
+}
+// producer side, step 2 (after a barrier): one thread per row sums the four groups and stores the record slot
+__device__ __forceinline__ void row_stats_publish(unsigned char* smem, float2* rec_slot, int n_rows, bool write_through, bool plain, int tid) {
+  if (tid < n_rows) {
+    const float2* part = reinterpret_cast<const float2*>(smem + ST_P);
+    const float2 p0 = part[tid], p1 = part[R + tid], p2 = part[2 * R + tid], p3 = part[3 * R + tid];
+    const float2 v = make_float2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
+    if (write_through) store8_wt(rec_slot + (size_t)tid * (D / 32), v, plain); else rec_slot[(size_t)tid * (D / 32)] = v;
+  }
+}
+
 // Per-phase views: the kernel arguments are re-read from the kernarg segment and the lane id is made opaque at every phase start, so the compiler cannot
 // hoist a later phase's pointers / per-lane offsets above an earlier loop (they would be spilled around it, and a scratch reload next to hand-counted
 // vmcnt waits costs a full drain -- or, worse, falsifies the count)
@@ -272,8 +373,18 @@ __device__ __forceinline__ KernArgs phase_args() {
 }
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
+constexpr int GETREG_XCC_ID = 20 | (0 << 6) | ((4 - 1) << 11);          // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4)
+// all four workgroups of the cluster on this XCD? (wave-uniform: one relaxed load per wave)
+__device__ __forceinline__ bool cluster_shares_l2(const unsigned* flags, int opt) {
+  if (!(opt & 4)) return false;
+  const unsigned w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flags + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  const unsigned b = w & 0xffu;
+  return b != 0u && w == b * 0x01010101u;
+}
+
 #define STAMP(k) do { if (a->times && threadIdx.x == 0) a->times[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 
+template <int PFA, int PFB, int PFC, int PFD, int ABL>
 __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_byval) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -292,61 +403,54 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
   const int rows_left = a->n_rows_alloc - row0;            // readable rows from row0 on
   unsigned* flags = a->flags + (size_t)cl * 4;
   const int kh = wave >> 2, cg = wave & 3;                 // phases B / D: K-half, 32-column group
+  // placement word: byte h = this workgroup's XCD + 1. A writer may leave an exchange payload in its XCD's L2 (ordinary stores) only when all four
+  // bytes are equal, i.e. every reader shares that L2; any other reading (a byte still 0: that workgroup has not started) keeps the write-through form.
+  if ((a->opt & 4) && tid == 0) __hip_atomic_fetch_add(flags + 3, (unsigned)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 0xf) + 1u << (8 * h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   STAMP(0);
 
   f32x4_t accb[RF][2];                                     // phase B accumulators: start from the residual (requested before the FSMN), then + FSMN term
   // ================================================================ phase A: q|k|v projection of head h, attention, FSMN
   {
     float2* st_fin = reinterpret_cast<float2*>(smem + ST_F);
-    const bool ln_here = !a->st_in;                        // no producer statistics (first block after a stand-alone LayerNorm): derive them from the rows
     {
       const unsigned char* wp = reinterpret_cast<const unsigned char*>(a->wpack) + PK_QKV + (size_t)(h * NW + wave) * PK_QKV_WAVE + lane * 16;
-      bf16x8_t wf[3][3];
-      w_prefetch<3, 3>(wf, wp);
+      bf16x8_t wf[PFA][3];
+      w_prefetch<3, PFA>(wf, wp);
       const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(a->x_lo + (size_t)row0 * D);
+      const bool st4 = a->st_in && a->st_in_n == 4;        // the rows' producer was this kernel: four partials per row
+      if (st4) row_stats_request(a->st_in + (size_t)row0 * (D / 32), rows_left, smem, wave, lane);
       f32x4_t acc[RF][3];
 #pragma unroll
       for (int i = 0; i < RF; ++i) { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][2] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-      chunk_gemm<3, 4, 4, 3, 0, 4>(smem, wp, wf, 0, lane, acc,
+      chunk_gemm<3, 4, 4, PFA, 0, 4, ABL>(smem, wp, wf, 0, lane, acc,
                                    [&](int q) __attribute__((always_inline)) { issue_chunk(xsrc + q * 256, D * 2, rows_left, smem + q * CH, wave, lane); }, []() __attribute__((always_inline)) {});
-      if (!ln_here && tid < R) {                           // (in flight under the loop's tail: consumed after the barriers below)
-        const float2 ss = sum_row_partials(a->st_in + (size_t)(row0 + min(tid, rows_left - 1)) * (D / 32), D / 32);
-        const float mean = ss.x * (1.0f / D);
-        const float var = fmaxf(ss.y * (1.0f / D) - mean * mean, 0.0f);
-        st_fin[tid] = make_float2(mean, rsqrtf(var + a->ln_eps));
-      }
+      // epilogue constants: requested here, they arrive under the statistics pass
+      const int grp = wave >> 2, sub = wave & 3;
+      const int col = sub * 32 + fgrp * 8;
+      const float* bp = a->bqkv + grp * D + h * HD + col;
+      const float* cp = a->cqkv + grp * D + h * HD + col;
+      const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+      const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
+      const int dcol = wave * 16 + frow;
+      const float bv = a->bqkv[2 * D + h * HD + dcol], cs = a->cqkv[2 * D + h * HD + dcol];
       __syncthreads();                                      // every wave is done with the chunks
       STAMP(1);
-      if (ln_here) {                                        // two threads per row, two chunks each
-        float2* st_part = reinterpret_cast<float2*>(smem + ST_P);
-        if (tid < 2 * R) {
-          const int row = tid % R, part = tid / R;
-          float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-          for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int p = 0; p < 16; ++p) stats8(*reinterpret_cast<const uint4*>(smem + (2 * part + c) * CH + row * 256 + p * 16), s1, s2);
-          st_part[part * R + row] = make_float2(s1, s2);
-        }
-        __syncthreads();
+      // LayerNorm statistics of the bf16 rows: the producer's records (requested in front of the loop), the 16-slot records of a GEMM epilogue (block 1
+      // behind the four-launch block 0), or -- behind a stand-alone LayerNorm -- a pass over the chunks
+      if (st4) { if (tid < R) row_stats_finish(smem, a->ln_eps, tid); __syncthreads(); }
+      else if (a->st_in) {
         if (tid < R) {
-          const float2 p0 = st_part[tid], p1 = st_part[R + tid];
-          const float mean = (p0.x + p1.x) * (1.0f / D);
-          const float var = fmaxf((p0.y + p1.y) * (1.0f / D) - mean * mean, 0.0f);
+          const float2 ss = sum_row_partials(a->st_in + (size_t)(row0 + min(tid, rows_left - 1)) * (D / 32), D / 32);
+          const float mean = ss.x * (1.0f / D);
+          const float var = fmaxf(ss.y * (1.0f / D) - mean * mean, 0.0f);
           st_fin[tid] = make_float2(mean, rsqrtf(var + a->ln_eps));
         }
         __syncthreads();
-      }
+      } else row_stats_from_chunks(smem, 0, a->ln_eps, tid);
       // ---- images. Waves 0-3 hold q columns 32 (w & 3) .., waves 4-7 the k columns (swapped order, fragment pair = 8 consecutive columns per lane);
       //      every wave holds v column 16 w + (lane & 15) for rows 16 i + 4 (lane >> 4) .. + 3 (un-swapped order: time-contiguous V^T)
       {
-        const int grp = wave >> 2, sub = wave & 3;
         unsigned char* dst = smem + (grp == 0 ? QS : KS);
-        const int col = sub * 32 + fgrp * 8;
-        const float* bp = a->bqkv + grp * D + h * HD + col;
-        const float* cp = a->cqkv + grp * D + h * HD + col;
-        const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
-        const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
         const float b8[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, c8[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
         for (int i = 0; i < RF; ++i) {
@@ -359,8 +463,6 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
           for (int e = 0; e < 8; ++e) v[e] = (v[e] - mr.x * c8[e]) * mr.y + b8[e];
           *reinterpret_cast<uint4*>(dst + row * 256 + ((((col >> 3)) ^ (row & 15)) << 4)) = pack8(v);
         }
-        const int dcol = wave * 16 + frow;
-        const float bv = a->bqkv[2 * D + h * HD + dcol], cs = a->cqkv[2 * D + h * HD + dcol];
         unsigned char* vdst = smem + VS + dcol * 512 + (fgrp & 1) * 8;
 #pragma unroll
         for (int i = 0; i < RF; ++i) {
@@ -379,6 +481,11 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
       }
     }
     __syncthreads();
+    // FSMN taps of this thread's channel: requested before the attention, used after it
+    float wc[TAPS];
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j) wc[j] = a->wfsmn[(h * HD + (tid & (HD - 1))) * TAPS + j];
+    const float bc = a->bfsmn[h * HD + (tid & (HD - 1))];
 
     // ---- attention: wave w = the 16-query tile w with all <= 160 scores in registers (one soft-max pass); the ninth tile (queries 128..143) is shared:
     //      every wave computes its scores and multiplies ONE 16-wide slice of the head dimension. A context tile goes back into the (dead) q rows of
@@ -494,13 +601,15 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     // ---- context rows of this head -> memory (whole 16-byte chunks, write-through) and count the workgroup in on exchange 0; alignment rows past the
     //      window become zeros in memory AND in the image (the own chunk of phase B must equal what the other heads read back)
     {
+      const bool plain = cluster_shares_l2(flags, a->opt);
       bf16_t* cg_ = a->ctx + (size_t)row0 * D + h * HD;
+      if (a->times && tid == 0) a->times[(size_t)blockIdx.x * 16 + 15] = plain ? 1ull : 0ull;
       for (int c = tid; c < n_act * 16 * 16; c += NT) {
         const int row = c >> 4, ch = c & 15;
         unsigned char* src = smem + QS + row * 256 + ((ch ^ (row & 15)) << 4);
         uint4 v = *reinterpret_cast<const uint4*>(src);
         if (row >= T) { v = make_uint4(0, 0, 0, 0); *reinterpret_cast<uint4*>(src) = v; }
-        store16_wt(cg_ + (size_t)row * D + ch * 8, v);
+        store16_wt(cg_ + (size_t)row * D + ch * 8, v, plain);
       }
     }
     publish(flags + 0, a->fault != 0 && blockIdx.x == 5);
@@ -517,13 +626,9 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     //      with the image, -> f32 [144][128] at TERM, 32-byte granules XOR-swizzled by the row so that the phase B prologue reads without conflicts
     {
       constexpr int PAD = (TAPS - 1) / 2;
-      const int c = tid & (HD - 1), seg = tid >> 7, cgl = h * HD + c;
+      const int c = tid & (HD - 1), seg = tid >> 7;
       const int t0 = seg < 2 ? seg * 40 : 80 + (seg - 2) * 32, len = seg < 2 ? 40 : 32;
       const unsigned char* vrow = smem + VS + c * 512;
-      float wc[TAPS];
-#pragma unroll
-      for (int j = 0; j < TAPS; ++j) wc[j] = a->wfsmn[cgl * TAPS + j];
-      const float bc = a->bfsmn[cgl];
       float x[56];                                           // time steps t0 - 8 .. t0 + 47
 #pragma unroll
       for (int q = 0; q < 7; ++q) {
@@ -565,8 +670,8 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     lane = opaque(tid & 63); frow = lane & 15; fgrp = lane >> 4;
     STAMP(4);
     const unsigned char* wp = reinterpret_cast<const unsigned char*>(a->wpack) + PK_OUT + (size_t)(h * NW + wave) * PK_OUT_WAVE + lane * 16;
-    bf16x8_t wf[4][2];
-    w_prefetch<2, 4>(wf, wp);
+    bf16x8_t wf[PFB][2];
+    w_prefetch<2, PFB>(wf, wp);
     if (kh == 0) {
       const int n = cg * 32 + fgrp * 8;
 #pragma unroll
@@ -578,7 +683,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     }
     __syncthreads();                                          // the term is in registers: slots 1..3 may take the other heads' context chunks
     const unsigned char* csrc = reinterpret_cast<const unsigned char*>(a->ctx + (size_t)row0 * D);
-    chunk_gemm<2, 4, 2, 4, 1, 0>(smem, wp, wf, 2 * kh, lane, accb,
+    chunk_gemm<2, 4, 2, PFB, 1, 0, ABL>(smem, wp, wf, 2 * kh, lane, accb,
                                  [&](int q) __attribute__((always_inline)) { issue_chunk(csrc + ((h + q) & 3) * 256, D * 2, rows_left, smem + q * CH, wave, lane); },
                                  [&]() __attribute__((always_inline)) { consume(flags + 0, NH, a->err); STAMP(5); });
     __syncthreads();
@@ -586,6 +691,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     khalf_exchange(smem + RED, kh, cg, lane, accb);
     // x1 rows: f32 -> memory (this workgroup's own slab: phase D reads it back), bf16 -> exchange 1 + the own chunk of phase C (slot 0), row statistics
     {
+      const bool plain = cluster_shares_l2(flags, a->opt);
       const int n = cg * 32 + fgrp * 8;
       float* xo = a->x + (size_t)row0 * D + h * HD + n;
       bf16_t* xl = a->x1_lo + (size_t)row0 * D + h * HD + n;
@@ -599,15 +705,13 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
           *reinterpret_cast<float4*>(xo + (size_t)row * D) = make_float4(v[0], v[1], v[2], v[3]);
           *reinterpret_cast<float4*>(xo + (size_t)row * D + 4) = make_float4(v[4], v[5], v[6], v[7]);
           const uint4 pk = pack8(v);
-          store16_wt(xl + (size_t)row * D, pk);
+          store16_wt(xl + (size_t)row * D, pk, plain);
           *reinterpret_cast<uint4*>(smem + row * 256 + ((((n >> 3)) ^ (row & 15)) << 4)) = pk;
-          float s1 = 0.0f, s2 = 0.0f;
-          stats8(pk, s1, s2);
-          s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-          s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-          if (fgrp == 0) store8_wt(a->st1 + (size_t)(row0 + row) * (D / 32) + h * 4 + cg, make_float2(s1, s2));
+          row_stats_group(pk, smem, cg, row, fgrp);
         }
       }
+      __syncthreads();
+      row_stats_publish(smem, a->st1 + (size_t)row0 * (D / 32) + h, n_act * 16, true, plain, tid);
     }
     publish(flags + 1);
     STAMP(7);
@@ -619,29 +723,27 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     lane = opaque(tid & 63); frow = lane & 15; fgrp = lane >> 4;
     float2* st_fin = reinterpret_cast<float2*>(smem + ST_F);
     const unsigned char* wp = reinterpret_cast<const unsigned char*>(a->wpack) + PK_W1 + (size_t)(h * NW + wave) * PK_W1_WAVE + lane * 16;
-    bf16x8_t wf[3][4];
-    w_prefetch<4, 3>(wf, wp);
+    bf16x8_t wf[PFC][4];
+    w_prefetch<4, PFC>(wf, wp);
     f32x4_t acc[RF][4];
 #pragma unroll
     for (int i = 0; i < RF; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(a->x1_lo + (size_t)row0 * D);
-    chunk_gemm<4, 4, 4, 3, 1, 0>(smem, wp, wf, 0, lane, acc,
+    chunk_gemm<4, 4, 4, PFC, 1, 0, ABL>(smem, wp, wf, 0, lane, acc,
                                  [&](int q) __attribute__((always_inline)) { issue_chunk(xsrc + ((h + q) & 3) * 256, D * 2, rows_left, smem + q * CH, wave, lane); },
                                  [&]() __attribute__((always_inline)) {
                                    consume(flags + 1, NH, a->err);
                                    STAMP(8);
-                                   if (tid < R) {
-                                     const float2 ss = sum_row_partials(a->st1 + (size_t)(row0 + min(tid, rows_left - 1)) * (D / 32), D / 32);
-                                     const float mean = ss.x * (1.0f / D);
-                                     const float var = fmaxf(ss.y * (1.0f / D) - mean * mean, 0.0f);
-                                     st_fin[tid] = make_float2(mean, rsqrtf(var + a->ln_eps));
-                                   }
+                                   row_stats_request(a->st1 + (size_t)row0 * (D / 32), rows_left, smem, wave, lane);
                                  });
-    __syncthreads();                                          // every wave is done with the x1 chunks (and the statistics are in LDS)
+    __syncthreads();                                          // every wave is done multiplying the x1 chunks; the statistics records have landed
+    if (tid < R) row_stats_finish(smem, a->ln_eps, tid);
+    __syncthreads();
     STAMP(9);
     {
+      const bool plain = cluster_shares_l2(flags, a->opt);
       bf16_t* hg = a->hid + (size_t)row0 * DFF + h * 512 + wave * 64;
       unsigned char* slot = smem + (wave >> 1) * CH;           // this wave's 64 hidden columns = half of own chunk wave / 2
 #pragma unroll
@@ -661,7 +763,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf((v[e] - mr.x * c8[e]) * mr.y + b8[e], 0.0f);
           const uint4 pk = pack8(v);
-          if (i < n_act) store16_wt(hg + (size_t)row * DFF + p * 32 + fgrp * 8, pk);
+          if (i < n_act) store16_wt(hg + (size_t)row * DFF + p * 32 + fgrp * 8, pk, plain);
           *reinterpret_cast<uint4*>(slot + row * 256 + (((8 * (wave & 1) + 4 * p + fgrp) ^ (row & 15)) << 4)) = pk;
         }
       }
@@ -676,13 +778,13 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     a = phase_args();
     lane = opaque(tid & 63); frow = lane & 15; fgrp = lane >> 4;
     const unsigned char* wp = reinterpret_cast<const unsigned char*>(a->wpack) + PK_W2 + (size_t)(h * NW + wave) * PK_W2_WAVE + lane * 16;
-    bf16x8_t wf[4][2];
-    w_prefetch<2, 4>(wf, wp);
+    bf16x8_t wf[PFD][2];
+    w_prefetch<2, PFD>(wf, wp);
     f32x4_t acc[RF][2];
 #pragma unroll
     for (int i = 0; i < RF; ++i) { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
     const unsigned char* hsrc = reinterpret_cast<const unsigned char*>(a->hid + (size_t)row0 * DFF);
-    chunk_gemm<2, 16, 2, 4, 4, 0>(smem, wp, wf, 2 * kh, lane, acc,
+    chunk_gemm<2, 16, 2, PFD, 4, 0, ABL>(smem, wp, wf, 2 * kh, lane, acc,
                                   [&](int q) __attribute__((always_inline)) { issue_chunk(hsrc + ((4 * h + q) & 15) * 256, DFF * 2, rows_left, smem + (q & 3) * CH, wave, lane); },
                                   [&]() __attribute__((always_inline)) { consume(flags + 2, NH, a->err); STAMP(12); });
     __syncthreads();
@@ -708,14 +810,12 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
         *reinterpret_cast<float4*>(xo + (size_t)row * D + 4) = make_float4(v[4], v[5], v[6], v[7]);
         const uint4 pk = pack8(v);
         *reinterpret_cast<uint4*>(xl + (size_t)row * D) = pk;
-        float s1 = 0.0f, s2 = 0.0f;
-        stats8(pk, s1, s2);
-        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-        if (fgrp == 0) a->st_out[(size_t)(row0 + row) * (D / 32) + h * 4 + cg] = make_float2(s1, s2);
+        row_stats_group(pk, smem, cg, row, fgrp);
       }
     }
-    wait_vm<0>();
+    __syncthreads();
+    row_stats_publish(smem, a->st_out + (size_t)row0 * (D / 32) + h, n_act * 16, false, false, tid);
+    if (a->times) wait_vm<0>();
     STAMP(14);
   }
 }
@@ -773,10 +873,16 @@ void launch_sanm_block8_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_
 void launch_sanm_block8(const SanmBlockArgs& a, hipStream_t s) {
   ASR_REQUIRE(a.n_utts > 0 && a.n_utts <= sanm_block_max_utts(), "sanm_block8: %d windows per launch (max %d)", a.n_utts, sanm_block_max_utts());
   ASR_REQUIRE(a.wpack && a.x_lo && a.x && a.ctx && a.x1_lo && a.st1 && a.hid && a.x_lo_out && a.st_out && a.flags && a.err && a.plan, "sanm_block8: null buffer");
+  // opt bit 2: deeper W fragment queues; opt bits 4..7: a timing-only ablation of the GEMM loops (chunk_gemm's ABL)
+  typedef void (*Kern)(const SanmBlockArgs);
+  static const Kern kerns[] = {sanm_block8_kernel<3, 4, 3, 4, 0>, sanm_block8_kernel<6, 8, 4, 8, 0>, sanm_block8_kernel<3, 4, 3, 4, 1>, sanm_block8_kernel<3, 4, 3, 4, 2>,
+                               sanm_block8_kernel<3, 4, 3, 4, 4>, sanm_block8_kernel<3, 4, 3, 4, 8>, sanm_block8_kernel<3, 4, 3, 4, 12>, sanm_block8_kernel<3, 4, 3, 4, 14>};
   static PerDeviceOnce attr_once;
   if (attr_once.first())
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sanm_block8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    for (Kern k : kerns) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   const int grid = a.scatter ? a.n_utts * 4 : ((a.n_utts + 7) / 8) * 32;
-  hipLaunchKernelGGL(sanm_block8_kernel, dim3(grid), dim3(NT), LDS_BYTES, s, a);
+  const int abl = (a.opt >> 4) & 15;
+  const Kern k = abl == 1 ? kerns[2] : abl == 2 ? kerns[3] : abl == 4 ? kerns[4] : abl == 8 ? kerns[5] : abl == 12 ? kerns[6] : abl == 14 ? kerns[7] : (a.opt & 2) ? kerns[1] : kerns[0];
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NT), LDS_BYTES, s, a);
   HIP_CHECK(hipGetLastError());
 }

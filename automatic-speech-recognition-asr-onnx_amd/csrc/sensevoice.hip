@@ -87,6 +87,7 @@ struct SvSession : asr_session {
   bool use_block = true;        // one launch per SANM block (clusters of four workgroups per window; ASR_SANM_BLOCK=0 disables)
   bool use_fbank_split = true;  // ASR_FBANK_SPLIT=0: exact-f32 MFMA DFT in bf16 sessions too
   DeviceBuffer d_dft_split;
+  int block8_opt = 0;           // ASR_SANM_BLOCK8_OPT: tuning switches of the 8-wave kernel (SanmBlockArgs::opt)
   int block_v = 8;              // ASR_SANM_BLOCK_V=1: the round-2 form of the block kernel (12 waves, csrc/sanm_block.hip); default: the 8-wave form (csrc/sanm_block8.hip)
   DeviceBuffer d_wpack;         // 8-wave form: fragment-major copy of every 512 -> 512 block's weights, made once per session (ensure_block_pack)
   bool wpack_ready = false;
@@ -101,6 +102,7 @@ struct SvSession : asr_session {
     if (const char* e = getenv("ASR_SANM_BLOCK")) use_block = !(e[0] == '0');
     if (const char* e = getenv("ASR_FBANK_SPLIT")) use_fbank_split = !(e[0] == '0');
     if (const char* e = getenv("ASR_SANM_BLOCK_V")) block_v = (e[0] == '1') ? 1 : 8;
+    if (const char* e = getenv("ASR_SANM_BLOCK8_OPT")) block8_opt = atoi(e);
     if (const char* e = getenv("ASR_SANM_BLOCK_SCATTER")) block_scatter = e[0] == '1';
     if (const char* e = getenv("ASR_SANM_BLOCK_FAULT")) block_fault = e[0] == '1';
     if (const char* e = getenv("ASR_SANM_BLOCK_DBG")) block_dbg = atoi(e);
@@ -314,6 +316,7 @@ void SvSession::enqueue(const SvRunCtx& r) {
   const float* x_in = d_x0.as<float>();
   const bf16_t* x_in_lo = x0lo;
   const float2* st_in = nullptr;            // statistics of x_in_lo's rows when its producer wrote them
+  bool st_in_block8 = false;                // ... by the 8-wave block kernel: one record per row and workgroup instead of one per 32 columns
   float2* sta = d_sta.as<float2>();
   float2* stb = d_stb.as<float2>();
   int ld_in = kpad0;
@@ -346,10 +349,16 @@ void SvSession::enqueue(const SvRunCtx& r) {
           ba.flags = d_flags.as<unsigned>() + ((size_t)i * r.batch + u0) * 4; ba.err = d_flags.as<unsigned>() + flag_words;
           ba.n_rows_alloc = Mpad; ba.ln_eps = 1e-5f; ba.scatter = block_scatter; ba.fault = (block_fault && i == 1) ? 1 : 0;
           if (i == block_dbg && u0 == 0) { d_times.reserve(256 * 16 * 8, stream); HIP_CHECK(hipMemsetAsync(d_times.ptr, 0, 256 * 16 * 8, stream)); ba.times = d_times.as<unsigned long long>(); }
-          if (block_v == 8) { ba.wpack = (const unsigned char*)d_wpack.ptr + sanm_block8_pack_bytes() * i; launch_sanm_block8(ba, stream); }
+          if (block_v == 8) {
+            ba.wpack = (const unsigned char*)d_wpack.ptr + sanm_block8_pack_bytes() * i; ba.opt = block8_opt;
+            ba.st_in_n = st_in_block8 ? 4 : 16;
+            if (i + 1 < c.n_blocks) ba.wpack_next = (const unsigned char*)d_wpack.ptr + sanm_block8_pack_bytes() * (i + 1);
+            launch_sanm_block8(ba, stream);
+          }
           else launch_sanm_block(ba, stream);
         }
         st_in = sta;
+        st_in_block8 = block_v == 8;
         if (i == c.n_main - 1 && !paraformer) {
           ProfScope ps2(prof, "layernorm", stream);
           launch_layernorm<bf16_t>(xa, d, rows, d, after_g, after_b, 1e-5f, xalo, d, d, stream); st_in = nullptr;
@@ -782,6 +791,11 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
     if (n) {
       fprintf(stderr, "[sanm_block %d] %d workgroups, first start -> last end %.1f us\n", block_dbg, n, (double)(t_last - t_first) * 0.01);
       for (int k = 0; k < nk; ++k) fprintf(stderr, "  %-22s avg %6.2f us  max %6.2f us\n", names[k], sum[k] / n, mx[k]);
+      if (block_v == 8) {
+        int n_plain = 0;
+        for (int w = 0; w < 256; ++w) if (t[w * 16]) n_plain += (int)t[w * 16 + 15];
+        fprintf(stderr, "  exchange payloads left in the L2 (cluster on one XCD) by %d of %d workgroups\n", n_plain, n);
+      }
       if (block_v != 8) {
         double c_loops = 0.0;
         for (int w = 0; w < 256; ++w) if (t[w * 16]) c_loops += (double)t[w * 16 + 14] * 0.01;

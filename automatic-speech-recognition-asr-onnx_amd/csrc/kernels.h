@@ -205,7 +205,7 @@ struct SanmBlockArgs {
   const bf16_t* w1; const float* b1; const float* c1;              // [2048][512] (LayerNorm affine folded), bias, column sums
   const bf16_t* w2; const float* b2;                               // [512][2048]
   int st_in_n = 16;                                                // partials per row in st_in: 16 (a GEMM epilogue's 32-column groups) or 4 (the 8-wave kernel's own records, one per workgroup, slots 0..3)
-  int opt = 0;                                                     // tuning switches of the 8-wave kernel (ASR_SANM_BLOCK8_OPT): 1 = no L2 warm-up loads, 2 = deeper W fragment queues, 4 = exchange payloads stay in the L2 when the cluster shares an XCD
+  int opt = 0;                                                     // tuning switches of the 8-wave kernel (ASR_SANM_BLOCK8_OPT): 1 = no L2 warm-up loads, 2 = deeper W fragment queues, 4 = always acquire-fence at an exchange (default: clusters that share an XCD read the payload with sc1 loads instead)
   const void* wpack_next = nullptr;                                // ... and the next block's copy (L2 warm-up of its q|k|v weights; null for the last block)
   const void* wpack = nullptr;                                     // round-4 kernel (sanm_block8.hip): fragment-major copy of the four matrices (launch_sanm_block8_pack)
   const bf16_t* x_lo; const float2* st_in;                         // block input rows (bf16) + their row statistics [rows][16] (null: derived in the kernel)

@@ -79,7 +79,10 @@ __device__ __forceinline__ void publish(unsigned* flag, bool withhold = false) {
   if (threadIdx.x == 0 && !withhold) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // wait until all `need` workgroups of the cluster are in; ONE acquire (drops this CU's stale L1 lines), then ordinary loads
-__device__ __forceinline__ void consume(unsigned* flag, unsigned need, unsigned* err) {
+// fence = false (only when the whole cluster shares this XCD's L2 and the payload is then read by sc1 loads, which bypass the CU's L1): no acquire. On gfx950 the
+// agent-scope acquire (buffer_inv sc1) does not only drop this CU's L1 lines, and four of them per cluster and exchange keep emptying the XCD's L2 of what its
+// 32 workgroups share (weights, the cluster's exchanged lines).
+__device__ __forceinline__ void consume(unsigned* flag, unsigned need, unsigned* err, bool fence = true) {
   if (threadIdx.x == 0) {
     unsigned spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
@@ -89,7 +92,7 @@ __device__ __forceinline__ void consume(unsigned* flag, unsigned need, unsigned*
       if (++spins > (1u << 13)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       if ((spins & 255u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;           // somebody already gave up: the launch is void anyway
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
 }
@@ -115,6 +118,8 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 
 #define GLDS(gptr, lptr) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+#define GLDS_SC1(gptr, lptr) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 16)
 
 // one chunk (144 rows x 256 B of a row-major bf16 matrix) -> an LDS slot. One wave instruction lands four rows; 36 pieces over 8 waves = five per
 // wave (the spare slots reload the last piece: same bytes, same place), so every wave's queue sees exactly five operations per chunk.
@@ -125,6 +130,26 @@ __device__ __forceinline__ void issue_chunk(const unsigned char* src, int ld_byt
     const int piece = min(wave + NW * t, R / 4 - 1);
     const int m = piece * 4 + (lane >> 4);
     GLDS(src + (size_t)min(m, rows_left - 1) * ld_bytes + (((lane & 15) ^ (m & 15)) << 4), slot + piece * 1024);
+  }
+}
+
+// The cluster's exchange buffers (ctx, x1, hid) hold CHUNK IMAGES: inside the window's own rows of the buffer, chunk c is the T16 x 256-byte LDS image of
+// its 128 columns, swizzled slots and all, at c * T16 * 256 bytes. Producers write the image into an LDS slot first (it is the own chunk of the next phase
+// anyway) and store it piece by piece -- one wave instruction = four rows = one contiguous KB, against sixteen 64-byte segments per instruction when the
+// rows went out of registers (the epilogues were store-ISSUE-bound: 147 KB of hid took 5 us per workgroup); consumers read it back the same way.
+__device__ __forceinline__ void issue_chunk_img(const unsigned char* img, int n_pieces, unsigned char* slot, int wave, int lane, bool sc1 = false) {
+#pragma unroll
+  for (int t = 0; t < DMA_PER_CHUNK; ++t) {
+    const int piece = min(wave + NW * t, R / 4 - 1);                       // (pieces past a short window reload its last piece into rows nobody stores)
+    const unsigned char* src = img + (size_t)min(piece, n_pieces - 1) * 1024 + lane * 16;
+    if (sc1) GLDS_SC1(src, slot + piece * 1024); else GLDS(src, slot + piece * 1024);
+  }
+}
+__device__ __forceinline__ void store_chunk_img(unsigned char* img, const unsigned char* slot, int n_pieces, int wave, int lane, bool plain) {
+#pragma unroll
+  for (int t = 0; t < DMA_PER_CHUNK; ++t) {
+    const int piece = wave + NW * t;
+    if (piece < n_pieces) store16_wt(img + (size_t)piece * 1024 + lane * 16, *reinterpret_cast<const uint4*>(slot + piece * 1024 + lane * 16), plain);
   }
 }
 
@@ -333,9 +358,10 @@ __device__ __forceinline__ void row_stats_from_chunks(unsigned char* smem, int r
 // behind it: no load latency is exposed and nobody passes over the rows a second time.
 // (By LDS-DMA into the partials area, which no producer epilogue uses at that time: registers filled by an asynchronous load must not live across a
 // 230-register loop -- if the compiler spilled them it would store whatever they held before the data arrived.) Every wave issues exactly one instruction.
-__device__ __forceinline__ void row_stats_request(const float2* rec0, int rows_left, unsigned char* smem, int wave, int lane) {
+__device__ __forceinline__ void row_stats_request(const float2* rec0, int rows_left, unsigned char* smem, int wave, int lane, bool sc1 = false) {
   const int item = min(wave * 64 + lane, 2 * R - 1), row = item >> 1;          // item = (row, 16-byte half of the 32-byte record head)
-  GLDS(reinterpret_cast<const unsigned char*>(rec0 + (size_t)min(row, rows_left - 1) * (D / 32)) + (item & 1) * 16, smem + ST_P + wave * 1024);
+  const unsigned char* src = reinterpret_cast<const unsigned char*>(rec0 + (size_t)min(row, rows_left - 1) * (D / 32)) + (item & 1) * 16;
+  if (sc1) GLDS_SC1(src, smem + ST_P + wave * 1024); else GLDS(src, smem + ST_P + wave * 1024);
 }
 __device__ __forceinline__ void row_stats_finish(unsigned char* smem, float eps, int tid) {      // tid < R, behind the loop's last barrier
   const float4 a = *reinterpret_cast<const float4*>(smem + ST_P + tid * 32), b = *reinterpret_cast<const float4*>(smem + ST_P + tid * 32 + 16);
@@ -376,7 +402,7 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); retur
 constexpr int GETREG_XCC_ID = 20 | (0 << 6) | ((4 - 1) << 11);          // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4)
 // all four workgroups of the cluster on this XCD? (wave-uniform: one relaxed load per wave)
 __device__ __forceinline__ bool cluster_shares_l2(const unsigned* flags, int opt) {
-  if (!(opt & 4)) return false;
+  if (opt & 4) return false;                            // tuning switch: always fence
   const unsigned w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flags + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   const unsigned b = w & 0xffu;
   return b != 0u && w == b * 0x01010101u;
@@ -403,9 +429,9 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
   const int rows_left = a->n_rows_alloc - row0;            // readable rows from row0 on
   unsigned* flags = a->flags + (size_t)cl * 4;
   const int kh = wave >> 2, cg = wave & 3;                 // phases B / D: K-half, 32-column group
-  // placement word: byte h = this workgroup's XCD + 1. A writer may leave an exchange payload in its XCD's L2 (ordinary stores) only when all four
-  // bytes are equal, i.e. every reader shares that L2; any other reading (a byte still 0: that workgroup has not started) keeps the write-through form.
-  if ((a->opt & 4) && tid == 0) __hip_atomic_fetch_add(flags + 3, (unsigned)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 0xf) + 1u << (8 * h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // placement word: byte h = this workgroup's XCD + 1. A consumer may skip the acquire (and read the payload with sc1 loads) only when all four bytes are
+  // equal, i.e. every writer of the cluster shares its L2; any other reading (a byte still 0: that workgroup has not started) keeps the fenced form.
+  if (tid == 0) __hip_atomic_fetch_add(flags + 3, (unsigned)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 0xf) + 1u << (8 * h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   STAMP(0);
 
   f32x4_t accb[RF][2];                                     // phase B accumulators: start from the residual (requested before the FSMN), then + FSMN term
@@ -601,16 +627,12 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     // ---- context rows of this head -> memory (whole 16-byte chunks, write-through) and count the workgroup in on exchange 0; alignment rows past the
     //      window become zeros in memory AND in the image (the own chunk of phase B must equal what the other heads read back)
     {
-      const bool plain = cluster_shares_l2(flags, a->opt);
-      bf16_t* cg_ = a->ctx + (size_t)row0 * D + h * HD;
+      const bool plain = false;
       if (a->times && tid == 0) a->times[(size_t)blockIdx.x * 16 + 15] = plain ? 1ull : 0ull;
-      for (int c = tid; c < n_act * 16 * 16; c += NT) {
-        const int row = c >> 4, ch = c & 15;
-        unsigned char* src = smem + QS + row * 256 + ((ch ^ (row & 15)) << 4);
-        uint4 v = *reinterpret_cast<const uint4*>(src);
-        if (row >= T) { v = make_uint4(0, 0, 0, 0); *reinterpret_cast<uint4*>(src) = v; }
-        store16_wt(cg_ + (size_t)row * D + ch * 8, v, plain);
-      }
+      const int T16 = n_act * 16;
+      for (int c = T * 16 + tid; c < T16 * 16; c += NT) *reinterpret_cast<uint4*>(smem + QS + c * 16) = make_uint4(0, 0, 0, 0);
+      __syncthreads();
+      store_chunk_img(reinterpret_cast<unsigned char*>(a->ctx + (size_t)row0 * D) + (size_t)h * T16 * 256, smem + QS, n_act * 4, wave, lane, plain);
     }
     publish(flags + 0, a->fault != 0 && blockIdx.x == 5);
     STAMP(3);
@@ -683,18 +705,18 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     }
     __syncthreads();                                          // the term is in registers: slots 1..3 may take the other heads' context chunks
     const unsigned char* csrc = reinterpret_cast<const unsigned char*>(a->ctx + (size_t)row0 * D);
+    const bool nofence = cluster_shares_l2(flags, a->opt);      // (every workgroup of the cluster has published its placement byte long before it can publish an exchange)
     chunk_gemm<2, 4, 2, PFB, 1, 0, ABL>(smem, wp, wf, 2 * kh, lane, accb,
-                                 [&](int q) __attribute__((always_inline)) { issue_chunk(csrc + ((h + q) & 3) * 256, D * 2, rows_left, smem + q * CH, wave, lane); },
-                                 [&]() __attribute__((always_inline)) { consume(flags + 0, NH, a->err); STAMP(5); });
+                                 [&](int q) __attribute__((always_inline)) { issue_chunk_img(csrc + (size_t)((h + q) & 3) * n_act * 4096, n_act * 4, smem + q * CH, wave, lane, nofence); },
+                                 [&]() __attribute__((always_inline)) { consume(flags + 0, NH, a->err, !nofence); STAMP(5); });
     __syncthreads();
     STAMP(6);
     khalf_exchange(smem + RED, kh, cg, lane, accb);
     // x1 rows: f32 -> memory (this workgroup's own slab: phase D reads it back), bf16 -> exchange 1 + the own chunk of phase C (slot 0), row statistics
     {
-      const bool plain = cluster_shares_l2(flags, a->opt);
+      const bool plain = false;
       const int n = cg * 32 + fgrp * 8;
       float* xo = a->x + (size_t)row0 * D + h * HD + n;
-      bf16_t* xl = a->x1_lo + (size_t)row0 * D + h * HD + n;
 #pragma unroll
       for (int i = 0; i < RF; ++i) {
         if ((kh == 0) == (i < 5) && i < n_act) {
@@ -705,12 +727,12 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
           *reinterpret_cast<float4*>(xo + (size_t)row * D) = make_float4(v[0], v[1], v[2], v[3]);
           *reinterpret_cast<float4*>(xo + (size_t)row * D + 4) = make_float4(v[4], v[5], v[6], v[7]);
           const uint4 pk = pack8(v);
-          store16_wt(xl + (size_t)row * D, pk, plain);
           *reinterpret_cast<uint4*>(smem + row * 256 + ((((n >> 3)) ^ (row & 15)) << 4)) = pk;
           row_stats_group(pk, smem, cg, row, fgrp);
         }
       }
       __syncthreads();
+      store_chunk_img(reinterpret_cast<unsigned char*>(a->x1_lo + (size_t)row0 * D) + (size_t)h * n_act * 4096, smem, n_act * 4, wave, lane, plain);
       row_stats_publish(smem, a->st1 + (size_t)row0 * (D / 32) + h, n_act * 16, true, plain, tid);
     }
     publish(flags + 1);
@@ -731,20 +753,20 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(a->x1_lo + (size_t)row0 * D);
+    const bool nofence = cluster_shares_l2(flags, a->opt);
     chunk_gemm<4, 4, 4, PFC, 1, 0, ABL>(smem, wp, wf, 0, lane, acc,
-                                 [&](int q) __attribute__((always_inline)) { issue_chunk(xsrc + ((h + q) & 3) * 256, D * 2, rows_left, smem + q * CH, wave, lane); },
+                                 [&](int q) __attribute__((always_inline)) { issue_chunk_img(xsrc + (size_t)((h + q) & 3) * n_act * 4096, n_act * 4, smem + q * CH, wave, lane, nofence); },
                                  [&]() __attribute__((always_inline)) {
-                                   consume(flags + 1, NH, a->err);
+                                   consume(flags + 1, NH, a->err, !nofence);
                                    STAMP(8);
-                                   row_stats_request(a->st1 + (size_t)row0 * (D / 32), rows_left, smem, wave, lane);
+                                   row_stats_request(a->st1 + (size_t)row0 * (D / 32), rows_left, smem, wave, lane, nofence);
                                  });
     __syncthreads();                                          // every wave is done multiplying the x1 chunks; the statistics records have landed
     if (tid < R) row_stats_finish(smem, a->ln_eps, tid);
     __syncthreads();
     STAMP(9);
+    const bool plain = false;
     {
-      const bool plain = cluster_shares_l2(flags, a->opt);
-      bf16_t* hg = a->hid + (size_t)row0 * DFF + h * 512 + wave * 64;
       unsigned char* slot = smem + (wave >> 1) * CH;           // this wave's 64 hidden columns = half of own chunk wave / 2
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
@@ -763,10 +785,15 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf((v[e] - mr.x * c8[e]) * mr.y + b8[e], 0.0f);
           const uint4 pk = pack8(v);
-          if (i < n_act) store16_wt(hg + (size_t)row * DFF + p * 32 + fgrp * 8, pk, plain);
           *reinterpret_cast<uint4*>(slot + row * 256 + (((8 * (wave & 1) + 4 * p + fgrp) ^ (row & 15)) << 4)) = pk;
         }
       }
+    }
+    __syncthreads();
+    {
+      unsigned char* himg = reinterpret_cast<unsigned char*>(a->hid + (size_t)row0 * DFF) + (size_t)(4 * h) * n_act * 4096;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) store_chunk_img(himg + (size_t)c * n_act * 4096, smem + c * CH, n_act * 4, wave, lane, plain);
     }
     STAMP(10);
     publish(flags + 2);
@@ -784,9 +811,10 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
 #pragma unroll
     for (int i = 0; i < RF; ++i) { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
     const unsigned char* hsrc = reinterpret_cast<const unsigned char*>(a->hid + (size_t)row0 * DFF);
+    const bool nofence = cluster_shares_l2(flags, a->opt);
     chunk_gemm<2, 16, 2, PFD, 4, 0, ABL>(smem, wp, wf, 2 * kh, lane, acc,
-                                  [&](int q) __attribute__((always_inline)) { issue_chunk(hsrc + ((4 * h + q) & 15) * 256, DFF * 2, rows_left, smem + (q & 3) * CH, wave, lane); },
-                                  [&]() __attribute__((always_inline)) { consume(flags + 2, NH, a->err); STAMP(12); });
+                                  [&](int q) __attribute__((always_inline)) { issue_chunk_img(hsrc + (size_t)((4 * h + q) & 15) * n_act * 4096, n_act * 4, smem + (q & 3) * CH, wave, lane, nofence); },
+                                  [&]() __attribute__((always_inline)) { consume(flags + 2, NH, a->err, !nofence); STAMP(12); });
     __syncthreads();
     STAMP(13);
     khalf_exchange(smem + RED, kh, cg, lane, acc);

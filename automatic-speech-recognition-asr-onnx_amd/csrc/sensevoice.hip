@@ -794,7 +794,7 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
       if (block_v == 8) {
         int n_plain = 0;
         for (int w = 0; w < 256; ++w) if (t[w * 16]) n_plain += (int)t[w * 16 + 15];
-        fprintf(stderr, "  exchange payloads left in the L2 (cluster on one XCD) by %d of %d workgroups\n", n_plain, n);
+        fprintf(stderr, "  (debug word 15: %d of %d workgroups)\n", n_plain, n);
       }
       if (block_v != 8) {
         double c_loops = 0.0;

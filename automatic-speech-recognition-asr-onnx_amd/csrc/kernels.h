@@ -198,15 +198,23 @@ bool sanm_fused_supported(int max_T, int d_head, int n_heads, int d, int fsmn_ta
 
 // ---- one whole SANM block per launch (csrc/sanm_block.hip): clusters of four workgroups per <= 144-row window, d = 512, 4 heads of 128,
 // FFN 2048, LayerNorms folded into the projections (bf16 mode). Buffers are the packed row-major activations of the session.
+// per-block constants of the 8-wave kernel (a launch walks `n_layers` consecutive entries of a device-side table)
+struct SanmBlockLayer {
+  const float *bqkv, *cqkv, *wfsmn, *bfsmn, *b1, *c1, *b2;
+  const void* wpack;                                               // fragment-major copy of the block's four matrices (launch_sanm_block8_pack)
+};
 struct SanmBlockArgs {
   const bf16_t* wqkv; const float* bqkv; const float* cqkv;      // [1536][512] (LayerNorm affine folded), bias, column sums
   const float* wfsmn; const float* bfsmn;                          // [512][11], [512] (linear_out.bias rides here)
   const bf16_t* wout;                                              // [512][512]
   const bf16_t* w1; const float* b1; const float* c1;              // [2048][512] (LayerNorm affine folded), bias, column sums
   const bf16_t* w2; const float* b2;                               // [512][2048]
+  const SanmBlockLayer* layers = nullptr; int n_layers = 1;        // 8-wave kernel: the launch's blocks (device table), first entry = the first block of the launch
+  int flag_stride = 0;                                             // ... words between the exchange counters of consecutive blocks (flags points at the first block's)
+  unsigned* place = nullptr;                                       // ... [n_utts] placement words of this launch (zeroed beforehand): byte h = XCD + 1 of workgroup (w, h)
+  int times_layer = 0;                                             // ... which block of the launch `times` stamps
   int st_in_n = 16;                                                // partials per row in st_in: 16 (a GEMM epilogue's 32-column groups) or 4 (the 8-wave kernel's own records, one per workgroup, slots 0..3)
   int opt = 0;                                                     // tuning switches of the 8-wave kernel (ASR_SANM_BLOCK8_OPT): 1 = no L2 warm-up loads, 2 = deeper W fragment queues, 4 = always acquire-fence at an exchange (default: clusters that share an XCD read the payload with sc1 loads instead)
-  const void* wpack_next = nullptr;                                // ... and the next block's copy (L2 warm-up of its q|k|v weights; null for the last block)
   const void* wpack = nullptr;                                     // round-4 kernel (sanm_block8.hip): fragment-major copy of the four matrices (launch_sanm_block8_pack)
   const bf16_t* x_lo; const float2* st_in;                         // block input rows (bf16) + their row statistics [rows][16] (null: derived in the kernel)
   float* x;                                                        // residual stream f32 [rows][512]: read (phase B) and overwritten (phase D) in place

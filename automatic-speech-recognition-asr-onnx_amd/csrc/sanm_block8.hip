@@ -87,9 +87,10 @@ __device__ __forceinline__ void consume(unsigned* flag, unsigned need, unsigned*
     unsigned spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
       __builtin_amdgcn_s_sleep(2);
-      // a cluster in step waits a few us here; 2^13 polls (about 8 ms with the sleep and the L2 round trip) means the cluster is not
-      // co-resident: give up, never hang -- the host redoes the pass on the four-launch path and keeps the session there for a while
-      if (++spins > (1u << 13)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      // a cluster in step waits a few us here; 2^15 polls (about 30 ms with the sleep and the L2 round trip: a launch now walks up to 49 blocks, and a
+      // cluster may wait behind another session's whole launch) means the cluster is not co-resident: give up, never hang -- the host redoes the pass
+      // on the four-launch path and keeps the session there for a while
+      if (++spins > (1u << 15)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       if ((spins & 255u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;           // somebody already gave up: the launch is void anyway
     }
     if (fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -398,40 +399,53 @@ __device__ __forceinline__ KernArgs phase_args() {
   return p;
 }
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ int opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }          // wave-uniform values
 
 constexpr int GETREG_XCC_ID = 20 | (0 << 6) | ((4 - 1) << 11);          // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4)
 // all four workgroups of the cluster on this XCD? (wave-uniform: one relaxed load per wave)
-__device__ __forceinline__ bool cluster_shares_l2(const unsigned* flags, int opt) {
+__device__ __forceinline__ bool cluster_shares_l2(const unsigned* place, int opt) {
   if (opt & 4) return false;                            // tuning switch: always fence
-  const unsigned w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flags + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  const unsigned w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(place, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   const unsigned b = w & 0xffu;
   return b != 0u && w == b * 0x01010101u;
 }
 
-#define STAMP(k) do { if (a->times && threadIdx.x == 0) a->times[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#define STAMP(k) do { if (a->times && li == a->times_layer && threadIdx.x == 0) a->times[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 
 template <int PFA, int PFB, int PFC, int PFD, int ABL>
 __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_byval) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid_0 = threadIdx.x, wave_0 = __builtin_amdgcn_readfirstlane(tid_0 >> 6);
   KernArgs a = phase_args();
-  int lane = tid & 63;
-  int frow = lane & 15, fgrp = lane >> 4;
+  int lane, frow, fgrp;
   // cluster placement: workgroup b runs on XCD b % 8 (observed, not guaranteed): the four workgroups of a window get ids 8 apart
-  int cl, h;
-  if (a->scatter) { cl = blockIdx.x >> 2; h = blockIdx.x & 3; }            // test mode: a cluster spread over four XCDs
-  else { const int idx = blockIdx.x >> 3; cl = ((idx >> 2) << 3) + (blockIdx.x & 7); h = idx & 3; }
-  if (cl >= a->n_utts) return;
-  const int u = a->utt0 + cl;
-  const UttPlan up = a->plan[u];
-  const int T = up.T, row0 = up.row_off;
-  const int n_act = (T + 15) >> 4;                        // active row fragments (cluster-uniform)
-  const int rows_left = a->n_rows_alloc - row0;            // readable rows from row0 on
-  unsigned* flags = a->flags + (size_t)cl * 4;
-  const int kh = wave >> 2, cg = wave & 3;                 // phases B / D: K-half, 32-column group
+  int cl_0, h_0;
+  if (a->scatter) { cl_0 = blockIdx.x >> 2; h_0 = blockIdx.x & 3; }            // test mode: a cluster spread over four XCDs
+  else { const int idx = blockIdx.x >> 3; cl_0 = ((idx >> 2) << 3) + (blockIdx.x & 7); h_0 = idx & 3; }
+  if (cl_0 >= a->n_utts) return;
+  const UttPlan up = a->plan[a->utt0 + cl_0];
+  const int T_0 = __builtin_amdgcn_readfirstlane(up.T), row0_0 = __builtin_amdgcn_readfirstlane(up.row_off);
   // placement word: byte h = this workgroup's XCD + 1. A consumer may skip the acquire (and read the payload with sc1 loads) only when all four bytes are
   // equal, i.e. every writer of the cluster shares its L2; any other reading (a byte still 0: that workgroup has not started) keeps the fenced form.
-  if (tid == 0) __hip_atomic_fetch_add(flags + 3, (unsigned)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 0xf) + 1u << (8 * h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid_0 == 0) __hip_atomic_fetch_add(a->place + cl_0, ((unsigned)(__builtin_amdgcn_s_getreg(GETREG_XCC_ID) & 0xf) + 1u) << (8 * h_0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- the blocks of this launch. A window's blocks depend on nothing but the window's own cluster, so a launch walks n_layers consecutive blocks with no
+  // chip-wide synchronisation at all: the fourth exchange of a block (the bf16 copy of its output + its row statistics) takes the place of the kernel boundary.
+  // Clusters drift apart (their bursts of exchange traffic no longer hit the memory side together), 68 launch boundaries and their single-wave ramps go,
+  // and the q|k|v projection of every block but the first starts on a chunk that is already in LDS.
+#pragma unroll 1
+  for (int li = 0; li < a->n_layers; ++li) {
+  a = phase_args();
+  // (per-block copies behind an opaque move: whatever the phases derive from them must not be hoisted out of the block loop and kept alive -- spilled -- across it)
+  const int tid = opaque(tid_0);
+  const int wave = opaque_s(wave_0), cl = opaque_s(cl_0), h = opaque_s(h_0), T = opaque_s(T_0), row0 = opaque_s(row0_0);
+  const int n_act = (T + 15) >> 4;                        // active row fragments (cluster-uniform)
+  const int rows_left = a->n_rows_alloc - row0;            // readable rows from row0 on
+  const unsigned* place = a->place + cl;
+  const int kh = wave >> 2, cg = wave & 3;                 // phases B / D: K-half, 32-column group
+  lane = opaque(tid & 63); frow = lane & 15; fgrp = lane >> 4;
+  const SanmBlockLayer* L = a->layers + li;
+  unsigned* flags = a->flags + (size_t)li * a->flag_stride + (size_t)cl * 4;
+  const bool first = li == 0, last = li + 1 == a->n_layers;
   STAMP(0);
 
   f32x4_t accb[RF][2];                                     // phase B accumulators: start from the residual (requested before the FSMN), then + FSMN term
@@ -439,32 +453,45 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
   {
     float2* st_fin = reinterpret_cast<float2*>(smem + ST_F);
     {
-      const unsigned char* wp = reinterpret_cast<const unsigned char*>(a->wpack) + PK_QKV + (size_t)(h * NW + wave) * PK_QKV_WAVE + lane * 16;
+      const unsigned char* wp = reinterpret_cast<const unsigned char*>(L->wpack) + PK_QKV + (size_t)(h * NW + wave) * PK_QKV_WAVE + lane * 16;
       bf16x8_t wf[PFA][3];
       w_prefetch<3, PFA>(wf, wp);
       const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(a->x_lo + (size_t)row0 * D);
-      const bool st4 = a->st_in && a->st_in_n == 4;        // the rows' producer was this kernel: four partials per row
-      if (st4) row_stats_request(a->st_in + (size_t)row0 * (D / 32), rows_left, smem, wave, lane);
+      const bool st4 = !first || (a->st_in && a->st_in_n == 4);        // the rows' producer was this kernel: four partials per row
       f32x4_t acc[RF][3];
 #pragma unroll
       for (int i = 0; i < RF; ++i) { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][2] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-      chunk_gemm<3, 4, 4, PFA, 0, 4, ABL>(smem, wp, wf, 0, lane, acc,
-                                   [&](int q) __attribute__((always_inline)) { issue_chunk(xsrc + q * 256, D * 2, rows_left, smem + q * CH, wave, lane); }, []() __attribute__((always_inline)) {});
+      // chunk q of the loop = columns 128 ((h + q) & 3) .., as in every phase: the own quarter first
+      if (first) {           // the rows come from another launch: row-major, all four chunks by DMA
+        if (st4) row_stats_request(a->st_in + (size_t)row0 * (D / 32), rows_left, smem, wave, lane);
+        chunk_gemm<3, 4, 4, PFA, 0, 4, ABL>(smem, wp, wf, 0, lane, acc,
+                                     [&](int q) __attribute__((always_inline)) { issue_chunk(xsrc + ((h + q) & 3) * 256, D * 2, rows_left, smem + q * CH, wave, lane); },
+                                     []() __attribute__((always_inline)) {});
+      } else {               // the previous block of this launch left its own chunk in slot 0 and the cluster's images + records behind exchange 3
+        const bool nofence = cluster_shares_l2(place, a->opt);
+        unsigned* pflags = flags - a->flag_stride;
+        chunk_gemm<3, 4, 4, PFA, 1, 4, ABL>(smem, wp, wf, 0, lane, acc,
+                                     [&](int q) __attribute__((always_inline)) { issue_chunk_img(xsrc + (size_t)((h + q) & 3) * n_act * 4096, n_act * 4, smem + q * CH, wave, lane, nofence); },
+                                     [&]() __attribute__((always_inline)) {
+                                       consume(pflags + 3, NH, a->err, !nofence);
+                                       row_stats_request(a->st_out + (size_t)row0 * (D / 32), rows_left, smem, wave, lane, nofence);
+                                     });
+      }
       // epilogue constants: requested here, they arrive under the statistics pass
       const int grp = wave >> 2, sub = wave & 3;
       const int col = sub * 32 + fgrp * 8;
-      const float* bp = a->bqkv + grp * D + h * HD + col;
-      const float* cp = a->cqkv + grp * D + h * HD + col;
+      const float* bp = L->bqkv + grp * D + h * HD + col;
+      const float* cp = L->cqkv + grp * D + h * HD + col;
       const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
       const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
       const int dcol = wave * 16 + frow;
-      const float bv = a->bqkv[2 * D + h * HD + dcol], cs = a->cqkv[2 * D + h * HD + dcol];
+      const float bv = L->bqkv[2 * D + h * HD + dcol], cs = L->cqkv[2 * D + h * HD + dcol];
       __syncthreads();                                      // every wave is done with the chunks
       STAMP(1);
       // LayerNorm statistics of the bf16 rows: the producer's records (requested in front of the loop), the 16-slot records of a GEMM epilogue (block 1
       // behind the four-launch block 0), or -- behind a stand-alone LayerNorm -- a pass over the chunks
       if (st4) { if (tid < R) row_stats_finish(smem, a->ln_eps, tid); __syncthreads(); }
-      else if (a->st_in) {
+      else if (a->st_in) {           // (only the first block of a launch gets here)
         if (tid < R) {
           const float2 ss = sum_row_partials(a->st_in + (size_t)(row0 + min(tid, rows_left - 1)) * (D / 32), D / 32);
           const float mean = ss.x * (1.0f / D);
@@ -472,7 +499,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
           st_fin[tid] = make_float2(mean, rsqrtf(var + a->ln_eps));
         }
         __syncthreads();
-      } else row_stats_from_chunks(smem, 0, a->ln_eps, tid);
+      } else row_stats_from_chunks(smem, h, a->ln_eps, tid);
       // ---- images. Waves 0-3 hold q columns 32 (w & 3) .., waves 4-7 the k columns (swapped order, fragment pair = 8 consecutive columns per lane);
       //      every wave holds v column 16 w + (lane & 15) for rows 16 i + 4 (lane >> 4) .. + 3 (un-swapped order: time-contiguous V^T)
       {
@@ -510,8 +537,8 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     // FSMN taps of this thread's channel: requested before the attention, used after it
     float wc[TAPS];
 #pragma unroll
-    for (int j = 0; j < TAPS; ++j) wc[j] = a->wfsmn[(h * HD + (tid & (HD - 1))) * TAPS + j];
-    const float bc = a->bfsmn[h * HD + (tid & (HD - 1))];
+    for (int j = 0; j < TAPS; ++j) wc[j] = L->wfsmn[(h * HD + (tid & (HD - 1))) * TAPS + j];
+    const float bc = L->bfsmn[h * HD + (tid & (HD - 1))];
 
     // ---- attention: wave w = the 16-query tile w with all <= 160 scores in registers (one soft-max pass); the ninth tile (queries 128..143) is shared:
     //      every wave computes its scores and multiplies ONE 16-wide slice of the head dimension. A context tile goes back into the (dead) q rows of
@@ -523,12 +550,6 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
       const int fq = frow, g = fgrp;
       const int n_sub = (T + 31) >> 5;
       const bool shared_tile = T > 128;
-      bf16x8_t qf8[HD / 32];                               // the shared tile's q fragments are read BEFORE any wave may overwrite those rows with context
-      if (shared_tile) {
-        const int qrow = 128 + fq;
-#pragma unroll
-        for (int ks = 0; ks < HD / 32; ++ks) qf8[ks] = *reinterpret_cast<const bf16x8_t*>(Qs + qrow * 256 + (((ks * 4 + g) ^ (qrow & 15)) << 4));
-      }
       auto scores = [&](const bf16x8_t (&qf)[HD / 32], bf16x8_t (&pf)[5], float& inv) {
         f32x4_t st[5][2];
 #pragma unroll
@@ -615,10 +636,14 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
         context(pf, inv, qrow, 0, std::integral_constant<int, HD / 16>{});
       }
       if (shared_tile) {
-        bf16x8_t pf[5];
+        // (the waves' own tiles are rows 0..127: nobody has written rows 128..143 yet, and nobody will before the barrier below)
+        bf16x8_t qf8[HD / 32], pf[5];
+        const int qrow8 = 128 + fq;
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) qf8[ks] = *reinterpret_cast<const bf16x8_t*>(Qs + qrow8 * 256 + (((ks * 4 + g) ^ (qrow8 & 15)) << 4));
         float inv;
         scores(qf8, pf, inv);
-        __syncthreads();                                    // every wave holds the shared tile's q fragments: its rows may now take the context
+        __syncthreads();                                    // every wave holds the shared tile's q fragments and scores: its rows may now take the context
         context(pf, inv, 128 + fq, wave, std::integral_constant<int, 1>{});
       }
     }
@@ -682,15 +707,16 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
         if (i < len) *reinterpret_cast<float*>(smem + TERM + t * 512 + (((c >> 3) ^ (t & 15)) << 5) + (c & 7) * 4) = (t < T) ? y[i] : 0.0f;
       }
     }
-    publish(flags + 0, a->fault != 0 && blockIdx.x == 5);     // (its barrier also closes the term image)
+    publish(flags + 0, first && a->fault != 0 && blockIdx.x == 5);     // (its barrier also closes the term image)
   }
 
   // ================================================================ phase B: out-projection slab + FSMN term + residual -> x1
   {
     a = phase_args();
+    L = a->layers + li;
     lane = opaque(tid & 63); frow = lane & 15; fgrp = lane >> 4;
     STAMP(4);
-    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a->wpack) + PK_OUT + (size_t)(h * NW + wave) * PK_OUT_WAVE + lane * 16;
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(L->wpack) + PK_OUT + (size_t)(h * NW + wave) * PK_OUT_WAVE + lane * 16;
     bf16x8_t wf[PFB][2];
     w_prefetch<2, PFB>(wf, wp);
     if (kh == 0) {
@@ -704,7 +730,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     }
     __syncthreads();                                          // the term is in registers: slots 1..3 may take the other heads' context chunks
     const unsigned char* csrc = reinterpret_cast<const unsigned char*>(a->ctx + (size_t)row0 * D);
-    const bool nofence = cluster_shares_l2(flags, a->opt);      // (every workgroup of the cluster has published its placement byte long before it can publish an exchange)
+    const bool nofence = cluster_shares_l2(place, a->opt);      // (every workgroup of the cluster has published its placement byte long before it can publish an exchange)
     chunk_gemm<2, 4, 2, PFB, 1, 0, ABL>(smem, wp, wf, 2 * kh, lane, accb,
                                  [&](int q) __attribute__((always_inline)) { issue_chunk_img(csrc + (size_t)((h + q) & 3) * n_act * 4096, n_act * 4, smem + q * CH, wave, lane, nofence); },
                                  [&]() __attribute__((always_inline)) { consume(flags + 0, NH, a->err, !nofence); STAMP(5); });
@@ -744,9 +770,10 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
   // ================================================================ phase C: FFN-1 slab, LayerNorm folded in -> hid slab (exchange 2 + the four own chunks of phase D)
   {
     a = phase_args();
+    L = a->layers + li;
     lane = opaque(tid & 63); frow = lane & 15; fgrp = lane >> 4;
     float2* st_fin = reinterpret_cast<float2*>(smem + ST_F);
-    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a->wpack) + PK_W1 + (size_t)(h * NW + wave) * PK_W1_WAVE + lane * 16;
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(L->wpack) + PK_W1 + (size_t)(h * NW + wave) * PK_W1_WAVE + lane * 16;
     bf16x8_t wf[PFC][4];
     w_prefetch<4, PFC>(wf, wp);
     f32x4_t acc[RF][4];
@@ -755,7 +782,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(a->x1_lo + (size_t)row0 * D);
-    const bool nofence = cluster_shares_l2(flags, a->opt);
+    const bool nofence = cluster_shares_l2(place, a->opt);
     chunk_gemm<4, 4, 4, PFC, 1, 0, ABL>(smem, wp, wf, 0, lane, acc,
                                  [&](int q) __attribute__((always_inline)) { issue_chunk_img(xsrc + (size_t)((h + q) & 3) * n_act * 4096, n_act * 4, smem + q * CH, wave, lane, nofence); },
                                  [&]() __attribute__((always_inline)) {
@@ -775,8 +802,8 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int n = h * 512 + wave * 64 + p * 32 + fgrp * 8;
-        const float4 b0 = *reinterpret_cast<const float4*>(a->b1 + n), b1v = *reinterpret_cast<const float4*>(a->b1 + n + 4);
-        const float4 c0 = *reinterpret_cast<const float4*>(a->c1 + n), c1v = *reinterpret_cast<const float4*>(a->c1 + n + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(L->b1 + n), b1v = *reinterpret_cast<const float4*>(L->b1 + n + 4);
+        const float4 c0 = *reinterpret_cast<const float4*>(L->c1 + n), c1v = *reinterpret_cast<const float4*>(L->c1 + n + 4);
         const float b8[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
         const float c8[8] = {c0.x, c0.y, c0.z, c0.w, c1v.x, c1v.y, c1v.z, c1v.w};
 #pragma unroll
@@ -807,15 +834,16 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
   // ================================================================ phase D: FFN-2 slab + bias + x1 -> x (f32), bf16 copy + row statistics
   {
     a = phase_args();
+    L = a->layers + li;
     lane = opaque(tid & 63); frow = lane & 15; fgrp = lane >> 4;
-    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a->wpack) + PK_W2 + (size_t)(h * NW + wave) * PK_W2_WAVE + lane * 16;
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(L->wpack) + PK_W2 + (size_t)(h * NW + wave) * PK_W2_WAVE + lane * 16;
     bf16x8_t wf[PFD][2];
     w_prefetch<2, PFD>(wf, wp);
     f32x4_t acc[RF][2];
 #pragma unroll
     for (int i = 0; i < RF; ++i) { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
     const unsigned char* hsrc = reinterpret_cast<const unsigned char*>(a->hid + (size_t)row0 * DFF);
-    const bool nofence = cluster_shares_l2(flags, a->opt);
+    const bool nofence = cluster_shares_l2(place, a->opt);
     chunk_gemm<2, 16, 2, PFD, 4, 0, ABL>(smem, wp, wf, 2 * kh, lane, acc,
                                   [&](int q) __attribute__((always_inline)) { issue_chunk_img(hsrc + (size_t)((4 * h + q) & 15) * n_act * 4096, n_act * 4, smem + (q & 3) * CH, wave, lane, nofence); },
                                   [&]() __attribute__((always_inline)) { consume(flags + 2, NH, a->err, !nofence); STAMP(12); });
@@ -823,10 +851,11 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     STAMP(13);
     khalf_exchange(smem + RED, kh, cg, lane, acc);
     const int n = cg * 32 + fgrp * 8;
-    const float4 b0 = *reinterpret_cast<const float4*>(a->b2 + h * HD + n), b1v = *reinterpret_cast<const float4*>(a->b2 + h * HD + n + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(L->b2 + h * HD + n), b1v = *reinterpret_cast<const float4*>(L->b2 + h * HD + n + 4);
     const float b8[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
     float* xo = a->x + (size_t)row0 * D + h * HD + n;
     bf16_t* xl = a->x_lo_out + (size_t)row0 * D + h * HD + n;
+    unsigned char* ximg = reinterpret_cast<unsigned char*>(a->x_lo_out + (size_t)row0 * D) + (size_t)h * n_act * 4096;        // (x_lo == x_lo_out inside a multi-block launch)
 #pragma unroll
     for (int i = 0; i < RF; ++i) {
       if ((kh == 0) == (i < 5) && i < n_act) {
@@ -841,15 +870,22 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
         *reinterpret_cast<float4*>(xo + (size_t)row * D) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(xo + (size_t)row * D + 4) = make_float4(v[4], v[5], v[6], v[7]);
         const uint4 pk = pack8(v);
-        *reinterpret_cast<uint4*>(xl + (size_t)row * D) = pk;
+        if (last) *reinterpret_cast<uint4*>(xl + (size_t)row * D) = pk;                      // for another launch: row-major, ordinary stores
+        else {                                                                                 // for the next block of this launch: the own chunk (slot 0) + the image, exchange 3
+          const int pos = (((n >> 3)) ^ (row & 15)) << 4;
+          *reinterpret_cast<uint4*>(smem + row * 256 + pos) = pk;
+          store16_wt(ximg + row * 256 + pos, pk);
+        }
         row_stats_group(pk, smem, cg, row, fgrp);
       }
     }
     __syncthreads();
-    row_stats_publish(smem, a->st_out + (size_t)row0 * (D / 32) + h, n_act * 16, false, false, tid);
-    if (a->times) wait_vm<0>();
+    row_stats_publish(smem, a->st_out + (size_t)row0 * (D / 32) + h, n_act * 16, !last, false, tid);
+    if (!last) publish(flags + 3);
+    else if (a->times) wait_vm<0>();
     STAMP(14);
   }
+  }        // blocks of this launch
 }
 
 // ---- fragment-major copy of one block's weights (bf16, torch Linear layout [N][K], K contiguous). One thread = one 16-byte lane slot of one fragment.
@@ -866,7 +902,7 @@ __global__ void sanm_block8_pack_kernel(PackSrc src, unsigned char* dst) {
   if (byte < PK_OUT) {                                  // [h][wave][16 steps][3 frags]: fragments 0, 1 = q (waves 0-3) / k (waves 4-7) columns 32 (wave & 3) .., fragment 2 = v columns 16 wave ..
     const size_t e = (byte - PK_QKV) / 1024;
     const int j = (int)(e % 3), s = (int)((e / 3) % 16), wave = (int)((e / 48) % NW), h = (int)(e / (48 * NW));
-    w = src.wqkv; ld = D; k0 = 32 * s + 8 * g;
+    w = src.wqkv; ld = D; k0 = 128 * ((h + (s >> 2)) & 3) + 32 * (s & 3) + 8 * g;        // chunk order (h + q) & 3, as in every phase
     if (j < 2) row = (wave >> 2) * D + h * HD + (wave & 3) * 32 + frag_col(j, fr);
     else row = 2 * D + h * HD + wave * 16 + fr;
   } else if (byte < PK_W1) {                            // [h][wave = (kh, cg)][8 steps = chunk order (h + q) & 3, K-steps 2 kh + t][2 frags]
@@ -904,7 +940,7 @@ void launch_sanm_block8_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_
 
 void launch_sanm_block8(const SanmBlockArgs& a, hipStream_t s) {
   ASR_REQUIRE(a.n_utts > 0 && a.n_utts <= sanm_block_max_utts(), "sanm_block8: %d windows per launch (max %d)", a.n_utts, sanm_block_max_utts());
-  ASR_REQUIRE(a.wpack && a.x_lo && a.x && a.ctx && a.x1_lo && a.st1 && a.hid && a.x_lo_out && a.st_out && a.flags && a.err && a.plan, "sanm_block8: null buffer");
+  ASR_REQUIRE(a.layers && a.place && a.n_layers >= 1 && (a.n_layers == 1 || a.x_lo == a.x_lo_out) && a.x_lo && a.x && a.ctx && a.x1_lo && a.st1 && a.hid && a.x_lo_out && a.st_out && a.flags && a.err && a.plan, "sanm_block8: null buffer");
   // opt bit 2: deeper W fragment queues; opt bits 4..7: a timing-only ablation of the GEMM loops (chunk_gemm's ABL)
   typedef void (*Kern)(const SanmBlockArgs);
   static const Kern kerns[] = {sanm_block8_kernel<3, 4, 3, 4, 0>, sanm_block8_kernel<6, 8, 4, 8, 0>, sanm_block8_kernel<3, 4, 3, 4, 1>, sanm_block8_kernel<3, 4, 3, 4, 2>,

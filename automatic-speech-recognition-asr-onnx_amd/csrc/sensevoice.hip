@@ -88,6 +88,8 @@ struct SvSession : asr_session {
   bool use_fbank_split = true;  // ASR_FBANK_SPLIT=0: exact-f32 MFMA DFT in bf16 sessions too
   DeviceBuffer d_dft_split;
   int block8_opt = 0;           // ASR_SANM_BLOCK8_OPT: tuning switches of the 8-wave kernel (SanmBlockArgs::opt)
+  bool block_persist = true;    // ASR_SANM_BLOCK_PERSIST=0: the 8-wave kernel is launched once per block instead of once per run of blocks
+  DeviceBuffer d_layer_tab;     // SanmBlockLayer[n_blocks]: the per-block constants a launch of the 8-wave kernel walks
   int block_v = 8;              // ASR_SANM_BLOCK_V=1: the round-2 form of the block kernel (12 waves, csrc/sanm_block.hip); default: the 8-wave form (csrc/sanm_block8.hip)
   DeviceBuffer d_wpack;         // 8-wave form: fragment-major copy of every 512 -> 512 block's weights, made once per session (ensure_block_pack)
   bool wpack_ready = false;
@@ -103,6 +105,7 @@ struct SvSession : asr_session {
     if (const char* e = getenv("ASR_FBANK_SPLIT")) use_fbank_split = !(e[0] == '0');
     if (const char* e = getenv("ASR_SANM_BLOCK_V")) block_v = (e[0] == '1') ? 1 : 8;
     if (const char* e = getenv("ASR_SANM_BLOCK8_OPT")) block8_opt = atoi(e);
+    if (const char* e = getenv("ASR_SANM_BLOCK_PERSIST")) block_persist = !(e[0] == '0');
     if (const char* e = getenv("ASR_SANM_BLOCK_SCATTER")) block_scatter = e[0] == '1';
     if (const char* e = getenv("ASR_SANM_BLOCK_FAULT")) block_fault = e[0] == '1';
     if (const char* e = getenv("ASR_SANM_BLOCK_DBG")) block_dbg = atoi(e);
@@ -246,6 +249,13 @@ void SvSession::ensure_block_pack() {
     if (b.in_size != cfg.d_model) continue;              // (block 0 maps 560 -> 512: it keeps the separate launches)
     launch_sanm_block8_pack((const bf16_t*)b.wqkv, (const bf16_t*)b.wout, (const bf16_t*)b.w1, (const bf16_t*)b.w2, (unsigned char*)d_wpack.ptr + per * i, stream);
   }
+  std::vector<SanmBlockLayer> tab(cfg.n_blocks);
+  for (int i = 0; i < cfg.n_blocks; ++i) {
+    const SvBlock& b = blocks[i];
+    tab[i] = SanmBlockLayer{b.bqkv, b.cqkv, b.wfsmn, b.bfsmn, b.b1, b.c1, b.b2, (const unsigned char*)d_wpack.ptr + per * i};
+  }
+  d_layer_tab.reserve(tab.size() * sizeof(SanmBlockLayer), stream);
+  HIP_CHECK(hipMemcpyAsync(d_layer_tab.ptr, tab.data(), tab.size() * sizeof(SanmBlockLayer), hipMemcpyHostToDevice, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
   wpack_ready = true;
 }
@@ -312,7 +322,7 @@ void SvSession::enqueue(const SvRunCtx& r) {
           r.batch >= block_min_utts &&          // four workgroups per window: a small batch leaves most CUs idle (one window: 4 of 256), the tiled GEMMs do not
           sanm_block_supported(r.max_T, c.d_head, c.n_heads, d, dff, c.fsmn_kernel);
   const size_t flag_words = (size_t)c.n_blocks * r.batch * 4;
-  HIP_CHECK(hipMemsetAsync(d_flags.ptr, 0, (flag_words + 4) * 4, stream));      // per (block, window, exchange) counters + the error word
+  HIP_CHECK(hipMemsetAsync(d_flags.ptr, 0, (flag_words + 4 + (size_t)c.n_blocks * r.batch) * 4, stream));      // per (block, window, exchange) counters + the error word + per (launch, window) placement words
   const float* x_in = d_x0.as<float>();
   const bf16_t* x_in_lo = x0lo;
   const float2* st_in = nullptr;            // statistics of x_in_lo's rows when its producer wrote them
@@ -338,6 +348,10 @@ void SvSession::enqueue(const SvRunCtx& r) {
           st_in = nullptr;
         }
         const int per = sanm_block_max_utts();
+        // 8-wave kernel: one launch walks every block up to the next stand-alone LayerNorm (blocks 1 .. n_main - 1, then n_main .. n_blocks - 1): a window's
+        // blocks depend on its own cluster only (ASR_SANM_BLOCK_PERSIST=0: one launch per block)
+        const int run_end = (!paraformer && i < c.n_main) ? c.n_main : c.n_blocks;
+        const int n_run = (block_v == 8 && block_persist) ? run_end - i : 1;
         for (int u0 = 0; u0 < r.batch; u0 += per) {
           ProfScope ps(prof, "sanm_block", stream);
           SanmBlockArgs ba{};
@@ -347,16 +361,20 @@ void SvSession::enqueue(const SvRunCtx& r) {
           ba.ctx = (bf16_t*)ctx; ba.x1_lo = xblo; ba.st1 = stb; ba.hid = (bf16_t*)ffn;
           ba.plan = r.dp; ba.utt0 = u0; ba.n_utts = std::min(per, r.batch - u0);
           ba.flags = d_flags.as<unsigned>() + ((size_t)i * r.batch + u0) * 4; ba.err = d_flags.as<unsigned>() + flag_words;
+          ba.flag_stride = r.batch * 4; ba.place = d_flags.as<unsigned>() + flag_words + 4 + (size_t)i * r.batch + u0;
           ba.n_rows_alloc = Mpad; ba.ln_eps = 1e-5f; ba.scatter = block_scatter; ba.fault = (block_fault && i == 1) ? 1 : 0;
-          if (i == block_dbg && u0 == 0) { d_times.reserve(256 * 16 * 8, stream); HIP_CHECK(hipMemsetAsync(d_times.ptr, 0, 256 * 16 * 8, stream)); ba.times = d_times.as<unsigned long long>(); }
+          if (block_dbg >= i && block_dbg < i + n_run && u0 == 0) {
+            d_times.reserve(256 * 16 * 8, stream); HIP_CHECK(hipMemsetAsync(d_times.ptr, 0, 256 * 16 * 8, stream)); ba.times = d_times.as<unsigned long long>();
+            ba.times_layer = block_dbg - i;
+          }
           if (block_v == 8) {
-            ba.wpack = (const unsigned char*)d_wpack.ptr + sanm_block8_pack_bytes() * i; ba.opt = block8_opt;
+            ba.layers = d_layer_tab.as<SanmBlockLayer>() + i; ba.n_layers = n_run; ba.opt = block8_opt;
             ba.st_in_n = st_in_block8 ? 4 : 16;
-            if (i + 1 < c.n_blocks) ba.wpack_next = (const unsigned char*)d_wpack.ptr + sanm_block8_pack_bytes() * (i + 1);
             launch_sanm_block8(ba, stream);
           }
           else launch_sanm_block(ba, stream);
         }
+        i += n_run - 1;                                        // (the loop header steps over the last block of the run)
         st_in = sta;
         st_in_block8 = block_v == 8;
         if (i == c.n_main - 1 && !paraformer) {
@@ -694,7 +712,7 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   grow(d_amax_v, (size_t)Mpad * n_slabs * 4);
   grow(d_amax_i, (size_t)Mpad * n_slabs * 4);
   grow(d_ids, (size_t)Mpad * 4);
-  grow(d_flags, ((size_t)c.n_blocks * batch * 4 + 4) * 4);
+  grow(d_flags, ((size_t)c.n_blocks * batch * 5 + 4) * 4);          // [block][window][4] exchange counters + error word (4) + [block][window] placement words
   grow(d_tok, (size_t)batch * max_tokens * 4);
   grow(d_num, (size_t)batch * 4);
   if (taps_enabled) grow(d_logits, (size_t)Mpad * vpad * 4);

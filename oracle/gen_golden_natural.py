@@ -1,0 +1,147 @@
+"""Goldens on NON-NOISE audio from the REAL reference classes (build container only):
+
+    python -m oracle.gen_golden_natural            # writes tests/golden/audio_natural.npz + tests/golden/*_natural.npz
+
+Clips: oracle/natural_audio.py (digital silence, DC + clipped square, an 80 dB chirp, three clips of the reference's own example speech). Every family's
+reference front-end + model (compiled in place from /root/reference by oracle/reference_harness.py, seeded synthetic checkpoints as in the other
+generators) runs on every clip, batch 1 like the reference; inputs' names + outputs are committed as data.
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "automatic-speech-recognition-asr-onnx_amd"
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _clips():
+    from oracle import natural_audio as na
+    clips = na.synthetic_clips()
+    speech = na.read_reference_wavs()
+    np.savez_compressed(na.CLIPS_NPZ, **speech)
+    clips.update(speech)
+    return {k: clips[k] for k in na.ORDER}
+
+
+def gen_sensevoice(clips):
+    from oracle import kaldi_mel, natural_audio as na, reference_harness as rh
+    cfgm, ckm = importlib.import_module(PKG + ".config"), importlib.import_module(PKG + ".checkpoints")
+    for fixture, cfg_name in (("sensevoice_tiny_natural", "sensevoice_tiny"), ("sensevoice_small_natural", "sensevoice_small")):
+        cfg = getattr(cfgm, cfg_name)()
+        ck = ckm.synth_sensevoice_checkpoint(cfg, 0)
+        ref = rh.build_reference_sensevoice(cfg, ck, kaldi_mel.get_mel_banks)
+        full = cfg.vocab <= 2000
+        out = {"ckpt_seed": np.int64(0), "cfg_name": np.str_(cfg_name), "clips": np.asarray(list(clips), dtype=np.str_)}
+        for i, (name, pcm) in enumerate(clips.items()):
+            lang = i % 7
+            st = rh.reference_sensevoice_stages(ref, na.kaldi_input(pcm), lang)
+            p = name + "_"
+            lg = st["logits"]
+            srt = np.sort(lg, axis=1)
+            out[p + "lang"], out[p + "token_ids"], out[p + "num_id"] = np.int64(lang), st["token_ids"].astype(np.int32), st["num_id"].astype(np.int32)
+            out[p + "frame_ids"], out[p + "margin"], out[p + "top1"] = lg.argmax(1).astype(np.int32), (srt[:, -1] - srt[:, -2]).astype(np.float32), srt[:, -1].astype(np.float32)
+            if full:
+                out[p + "mel"], out[p + "enc_in"], out[p + "logits"] = st["mel"].astype(np.float32), st["enc_in"].astype(np.float32), lg.astype(np.float32)
+            else:
+                out[p + "mel"], out[p + "enc_in"], out[p + "logits_cols"] = st["mel"][::4].astype(np.float32), st["enc_in"][::8].astype(np.float32), lg[:, ::97].astype(np.float32)
+            print(fixture, name, "mel range", float(st["mel"].min()), float(st["mel"].max()), "tokens", st["num_id"], "min margin", float(out[p + "margin"].min()))
+        np.savez_compressed(os.path.join(GOLDEN, fixture + ".npz"), **out)
+
+
+def gen_paraformer(clips):
+    from oracle import kaldi_mel, natural_audio as na, reference_harness as rh
+    cfgm, ckm = importlib.import_module(PKG + ".config"), importlib.import_module(PKG + ".checkpoints")
+    for fixture, cfg_name in (("paraformer_tiny_natural", "paraformer_tiny"), ("paraformer_large_natural", "paraformer_large")):
+        cfg = getattr(cfgm, cfg_name)()
+        ck = ckm.synth_paraformer_checkpoint(cfg, 0)
+        ref = rh.build_reference_paraformer(cfg, ck, kaldi_mel.get_mel_banks)
+        full = cfg.vocab <= 2000
+        out = {"ckpt_seed": np.int64(0), "cfg_name": np.str_(cfg_name), "clips": np.asarray(list(clips), dtype=np.str_)}
+        for name, pcm in clips.items():
+            r = rh.reference_paraformer_stages(ref, na.kaldi_input(pcm))
+            p = name + "_"
+            nid = int(r["num_id"][0])
+            lg = r["logits"]
+            srt = np.sort(lg, axis=1)
+            cs = np.cumsum(np.concatenate([r["alphas"].astype(np.float64), [cfg.tail_threshold]]))
+            out[p + "token_ids"], out[p + "num_id"], out[p + "alphas"] = r["token_ids"], r["num_id"], r["alphas"].astype(np.float32)
+            out[p + "margin"] = (srt[:, -1] - srt[:, -2]).astype(np.float32)[:nid]
+            out[p + "cif_slack"] = np.float32(np.min(np.abs(cs - np.round(cs))))
+            out[p + "mel"] = (r["mel"] if full else r["mel"][::4]).astype(np.float32)
+            if full:
+                out[p + "enc_out"], out[p + "logits"] = r["enc_out"].astype(np.float32), lg.astype(np.float32)
+            else:
+                out[p + "enc_out"], out[p + "logits_cols"], out[p + "top1"] = r["enc_out"][::8].astype(np.float32), lg[:, ::37].astype(np.float32), srt[:, -1].astype(np.float32)
+            print(fixture, name, "num_id", r["num_id"], "cif slack", float(out[p + "cif_slack"]))
+        np.savez_compressed(os.path.join(GOLDEN, fixture + ".npz"), **out)
+
+
+def gen_whisper(clips):
+    import torch
+    from oracle import natural_audio as na, reference_harness as rh
+    from oracle.gen_golden_whisper import reference_greedy
+    cfgm, ckm = importlib.import_module(PKG + ".config"), importlib.import_module(PKG + ".checkpoints")
+    for fixture, cfg_name, n_new in (("whisper_tiny_natural", "whisper_tiny_test", 6), ("whisper_mid_natural", "whisper_mid_test", 4)):
+        cfg = getattr(cfgm, cfg_name)()
+        ck = ckm.synth_whisper_checkpoint(cfg, 0)
+        suppress, begin = ckm.whisper_suppress_tokens(cfg), ckm.whisper_begin_suppress_tokens(cfg)
+        ref = rh.build_reference_whisper(cfg, ck, suppress_tokens=suppress)
+        small = cfg.d_model <= 128
+        prompt = [cfg.sot_id, cfg.first_language_id, cfg.transcribe_id, cfg.no_timestamps_id]
+        out = {"ckpt_seed": np.int64(0), "cfg_name": np.str_(cfg_name), "n_new": np.int64(n_new), "clips": np.asarray(list(clips), dtype=np.str_),
+               "prompt": np.asarray(prompt, np.int32)}
+        L = cfg.n_dec_layers
+        for name, pcm in clips.items():
+            r = reference_greedy(ref, cfg, na.unit_input(pcm), prompt, n_new, suppress, begin)
+            keys = torch.stack([k.permute(0, 2, 1) for k in r["cross"][:L]]).numpy()     # (L, H, T, hd)
+            vals = torch.stack(list(r["cross"][L:])).numpy()
+            p = name + "_"
+            srt = np.sort(r["logits"], axis=1)
+            out[p + "token_ids"], out[p + "margin"] = r["token_ids"], (srt[:, -1] - srt[:, -2]).astype(np.float32)
+            if small:
+                out[p + "cross_k"], out[p + "cross_v"], out[p + "logits"] = keys, vals, r["logits"]
+            else:
+                out[p + "cross_k"], out[p + "cross_v"] = keys[:, ::3, ::8].copy(), vals[:, ::3, ::8].copy()
+                out[p + "logits"], out[p + "top1"] = r["logits"][:, ::17].copy(), srt[:, -1].astype(np.float32)
+            print(fixture, name, "tokens", r["token_ids"], "min margin", float(out[p + "margin"].min()))
+        np.savez_compressed(os.path.join(GOLDEN, fixture + ".npz"), **out)
+
+
+def gen_qwen(clips):
+    from oracle import natural_audio as na, reference_harness as rh
+    from oracle.gen_golden_qwen_asr import HEAD_IDS, SUFFIX_IDS, TAIL_IDS, reference_greedy
+    cfgm, ckm = importlib.import_module(PKG + ".config"), importlib.import_module(PKG + ".checkpoints")
+    fixture, cfg_name, n_new = "qwen_asr_tiny_natural", "qwen_asr_tiny", 5
+    cfg = getattr(cfgm, cfg_name)()
+    ck = ckm.synth_qwen_asr_checkpoint(cfg, 0)
+    ref = rh.build_reference_qwen_asr(cfg, ck, HEAD_IDS, TAIL_IDS, SUFFIX_IDS, max_seq_len=cfg.max_seq_len)
+    out = {"ckpt_seed": np.int64(0), "cfg_name": np.str_(cfg_name), "n_new": np.int64(n_new), "clips": np.asarray(list(clips), dtype=np.str_),
+           "head_ids": np.asarray(HEAD_IDS, np.int32), "tail_ids": np.asarray(TAIL_IDS, np.int32), "suffix_ids": np.asarray(SUFFIX_IDS, np.int32)}
+    for name, pcm in clips.items():
+        r = reference_greedy(ref, cfg, na.unit_input(pcm), n_new, [], [77, 540])
+        p = name + "_"
+        srt = np.sort(r["logits"], axis=1)
+        out[p + "audio_hidden"], out[p + "ids_len"], out[p + "logits"], out[p + "token_ids"] = r["audio_hidden"], np.int64(r["ids_len"]), r["logits"], r["token_ids"]
+        out[p + "margin"] = (srt[:, -1] - srt[:, -2]).astype(np.float32)
+        print(fixture, name, "audio tokens", r["audio_hidden"].shape[0], "tokens", r["token_ids"], "min margin", float(out[p + "margin"].min()))
+    np.savez_compressed(os.path.join(GOLDEN, fixture + ".npz"), **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLDEN, exist_ok=True)
+    which = sys.argv[1:] or ["sensevoice", "paraformer", "whisper", "qwen"]
+    clips = _clips()
+    if "sensevoice" in which:
+        gen_sensevoice(clips)
+    if "paraformer" in which:
+        gen_paraformer(clips)
+    if "whisper" in which:
+        gen_whisper(clips)
+    if "qwen" in which:
+        gen_qwen(clips)

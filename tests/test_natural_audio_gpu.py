@@ -1,0 +1,172 @@
+"""GPU parity on NON-NOISE audio (oracle/natural_audio.py): digital silence, a DC offset under a clipped full-scale square, an 80 dB chirp and three
+clips of the reference's own example speech, through every family, against goldens minted from the reference's classes on exactly these clips
+(oracle/gen_golden_natural.py). Every other fixture of the suite is white noise, whose flat spectrum never takes the branches the front-ends' traps
+exist for: the clamp(FLT_EPS) in front of the Kaldi log (SenseVoice/Export_SenseVoice.py:275-278), Whisper's clamp(1e-10) -> log10 ->
+max(x, global_max - 8) (Whisper/Export_Whisper.py:424-427) and the per-utterance global maximum when silence and speech share a batch.
+
+All six clips of a family go through ONE ragged batch (silence next to speech), f32 mode against the goldens (front-end <= 2e-4, logits <= 1e-3,
+tokens equal where the reference's own margin allows), and the bf16 sessions' front-ends (the split-operand DFT) against the same golden mel."""
+import numpy as np
+import pytest
+
+from conftest import sub
+from helpers import load_golden, sensevoice_setup
+from oracle import natural_audio as na
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = 0, 1
+TOL = 1e-3
+
+
+def _clips():
+    return na.load_clips()
+
+
+@pytest.mark.parametrize("fixture,cfg_name", [("sensevoice_tiny_natural", "sensevoice_tiny"), ("sensevoice_small_natural", "sensevoice_small")])
+def test_sensevoice_f32_and_bf16_front_end(fixture, cfg_name):
+    g = load_golden(fixture)
+    clips = _clips()
+    names = [str(n) for n in g["clips"]]
+    audios = [na.kaldi_input(clips[n]) for n in names]
+    langs = [int(g[n + "_lang"]) for n in names]
+    cfg, ck = sensevoice_setup(cfg_name)
+    full = cfg.vocab <= 2000
+    import torch
+    from oracle.sensevoice_oracle import SenseVoiceOracle
+    tcfg, tck = sensevoice_setup("sensevoice_tiny")                     # (the front-end is the same in both geometries)
+    o64 = SenseVoiceOracle(tcfg, tck, dtype=torch.float64)                # CHECKER ONLY: the float64 log-mel of every clip
+    truth = {n: o64.stages(a, 0)["mel"] for n, a in zip(names, audios)}
+    for prec in (F32, BF16):
+        sess = sub("engine").SenseVoiceSession.from_checkpoint(cfg, ck, precision=prec)
+        sess.taps(True)
+        toks = sess.run(audios, langs)
+        rows = sess.utterance_rows([a.size for a in audios])
+        mel, enc_in, logits = sess.tap("mel"), sess.tap("enc_in"), sess.tap("logits")
+        ids = sess.tap("frame_ids", dtype=np.int32)[:, 0]
+        f_off = 0
+        for n, a, tok, (r0, T) in zip(names, audios, toks, rows):
+            nf = cfg.n_frames(a.size)
+            m = mel[f_off:f_off + nf]
+            f_off += nf
+            assert np.isfinite(m).all(), n
+            ref_mel = g[n + "_mel"]
+            if prec == BF16:
+                # bf16 sessions run the DFT with split operands on the bf16 pipe. On 60-80 dB of in-frame range NO f32 form reaches the exact value: the
+                # reference's own f32 log-mel is 2e-4 .. 5e-4 off the float64 result on these clips (tests/probes/natural_mel_errors.py), and the exact-f32 MFMA
+                # path of the f32 sessions reproduces that rounding (the branch above holds it to 2e-4 of the REFERENCE). The split DFT rounds differently --
+                # measured CLOSER to the float64 truth than the reference on the speech clips (1.0e-4 against 5.2e-4 on shanghai8) -- so its bar is the truth:
+                # no further from it than the usual 2e-4, or than 1.5 x the reference's own distance where that is larger.
+                t64 = truth[n]
+                sel = slice(None) if full else slice(None, None, 4)                              # (the full-size fixture keeps every fourth frame)
+                err, ref_err = np.abs(m[sel] - t64[sel]).max(), np.abs(t64[sel] - ref_mel).max()
+                assert err < max(2e-4, 1.5 * ref_err), (n, err, ref_err)                        # measured: 2.5e-4 against the reference's 2.2e-4 on the chirp
+                continue                                                                          # (bf16 mode: the front-end is the claim; the stack has its own tests)
+            assert np.abs((m if full else m[::4]) - ref_mel).max() < 2e-4, (n, prec)            # the log floor, 80 dB of range, clipped input: same bar as noise
+            e = enc_in[r0:r0 + T]
+            assert np.abs((e if full else e[::8]) - g[n + "_enc_in"]).max() < 2e-4, n
+            lg = logits[r0:r0 + T]
+            if full:
+                assert np.abs(lg - g[n + "_logits"]).max() < TOL, n
+            else:
+                assert np.abs(lg[:, ::97] - g[n + "_logits_cols"]).max() < TOL, n
+            assert np.abs(np.sort(lg, axis=1)[:, -1] - g[n + "_top1"]).max() < TOL, n
+            safe = g[n + "_margin"] > 2 * TOL
+            assert np.array_equal(ids[r0:r0 + T][safe], g[n + "_frame_ids"][safe]), n
+            if safe.all():
+                assert np.array_equal(tok, g[n + "_token_ids"][0][:int(g[n + "_num_id"][0])] if g[n + "_token_ids"].ndim == 2 else g[n + "_token_ids"]), n
+        del sess
+
+
+@pytest.mark.parametrize("fixture", ["paraformer_tiny_natural", "paraformer_large_natural"])
+def test_paraformer_f32(fixture):
+    from test_oracle_paraformer import paraformer_setup
+    g = load_golden(fixture)
+    clips = _clips()
+    names = [str(n) for n in g["clips"]]
+    audios = [na.kaldi_input(clips[n]) for n in names]
+    cfg, ck = paraformer_setup(str(g["cfg_name"]))
+    full = cfg.vocab <= 2000
+    sess = sub("engine").ParaformerSession.from_checkpoint(cfg, ck, precision=F32)
+    sess.taps(True)
+    toks = sess.run(audios)
+    rows = sess.utterance_rows([a.size for a in audios])
+    enc, alphas, logits = sess.tap("enc_out"), sess.tap("alphas")[:, 0], sess.tap("logits")
+    trow = sess.token_rows([t.size for t in toks])
+    for n, tok, (r0, T), t0 in zip(names, toks, rows, trow):
+        nid = int(g[n + "_num_id"][0])
+        assert np.abs(alphas[r0:r0 + T] - g[n + "_alphas"]).max() < TOL, n
+        e = enc[r0:r0 + T]
+        assert np.abs((e if full else e[::8]) - g[n + "_enc_out"]).max() < TOL, n
+        if g[n + "_cif_slack"] > 2e-4:
+            assert tok.size == nid, (n, tok.size, nid)
+            lg = logits[t0:t0 + max(nid, 1)]
+            if full:
+                assert np.abs(lg - g[n + "_logits"]).max() < TOL, n
+            else:
+                assert np.abs(lg[:, ::37] - g[n + "_logits_cols"]).max() < TOL, n
+            if nid and (g[n + "_margin"] > 2 * TOL).all():
+                assert np.array_equal(tok, g[n + "_token_ids"][:nid]), n
+
+
+@pytest.mark.parametrize("fixture", ["whisper_tiny_natural", "whisper_mid_natural"])
+def test_whisper_f32(fixture):
+    from test_oracle_whisper import whisper_setup
+    g = load_golden(fixture)
+    clips = _clips()
+    names = [str(n) for n in g["clips"]]
+    audios = [na.unit_input(clips[n]) for n in names]
+    cfg, ck, sup, beg = whisper_setup(str(g["cfg_name"]))
+    sess = sub("engine").WhisperSession.from_checkpoint(cfg, ck, precision=F32, suppress_tokens=sup, begin_suppress_tokens=beg)
+    sess.taps(True)
+    npos = sess.encode(audios)                       # one ragged batch: the clip-wise global maximum must not leak between silence and speech
+    sub_sampled = (str(names[0]) + "_top1") in g
+    for (k, v), n in zip(sess.cross_kv(npos), names):
+        if sub_sampled:
+            k, v = k[:, ::3, ::8], v[:, ::3, ::8]
+        assert np.isfinite(k).all() and np.isfinite(v).all(), n
+        assert np.abs(k - g[n + "_cross_k"]).max() < TOL and np.abs(v - g[n + "_cross_v"]).max() < TOL, n
+    prompts = np.stack([g["prompt"]] * len(names))
+    nxt, logits = sess.prefill(prompts)
+    steps_logits, steps_ids = [logits], [nxt]
+    for _ in range(int(g["n_new"]) - 1):
+        nxt, logits = sess.decode(None, want_logits=True)
+        steps_logits.append(logits)
+        steps_ids.append(nxt)
+    got_logits, got_ids = np.stack(steps_logits, 1), np.stack(steps_ids, 1)
+    for b, n in enumerate(names):
+        lg = got_logits[b][:, ::17] if sub_sampled else got_logits[b]
+        assert np.abs(lg - g[n + "_logits"]).max() < TOL, n
+        if sub_sampled:
+            assert np.abs(np.sort(got_logits[b], axis=1)[:, -1] - g[n + "_top1"]).max() < TOL, n
+        if (g[n + "_margin"] > 2 * TOL).all():
+            assert np.array_equal(got_ids[b], g[n + "_token_ids"]), n
+
+
+def test_qwen_asr_f32():
+    from test_oracle_qwen_asr import qwen_setup
+    g = load_golden("qwen_asr_tiny_natural")
+    clips = _clips()
+    names = [str(n) for n in g["clips"]]
+    audios = [na.unit_input(clips[n]) for n in names]
+    cfg, ck = qwen_setup(g)
+    sess = sub("engine").QwenAsrSession.from_checkpoint(cfg, ck, precision=F32)
+    head, tail, suffix = g["head_ids"].tolist(), g["tail_ids"].tolist(), g["suffix_ids"].tolist()
+    pre, post = [head + suffix] * len(names), [tail + [77, 540]] * len(names)
+    sess.taps(True)
+    nxt, logits, ids_len = sess.prefill(audios, pre, post)
+    assert ids_len.tolist() == [int(g[n + "_ids_len"]) for n in names]
+    steps_logits, steps_ids = [logits], [nxt]
+    for _ in range(int(g["n_new"]) - 1):
+        nxt, logits = sess.decode(None, want_logits=True)
+        steps_logits.append(logits)
+        steps_ids.append(nxt)
+    got_logits, got_ids = np.stack(steps_logits, 1), np.stack(steps_ids, 1)
+    sess.taps(True)
+    sess.prefill(audios, pre, post)
+    for b, (h, n) in enumerate(zip(sess.audio_hidden([a.size for a in audios]), names)):
+        assert h.shape == g[n + "_audio_hidden"].shape, n
+        assert np.abs(h - g[n + "_audio_hidden"]).max() < TOL, n
+        assert np.abs(got_logits[b] - g[n + "_logits"]).max() < TOL, n
+        if (g[n + "_margin"] > 2 * TOL).all():
+            assert np.array_equal(got_ids[b], g[n + "_token_ids"]), n

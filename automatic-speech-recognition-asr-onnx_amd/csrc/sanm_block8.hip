@@ -652,7 +652,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     // ---- context rows of this head -> memory (whole 16-byte chunks, write-through) and count the workgroup in on exchange 0; alignment rows past the
     //      window become zeros in memory AND in the image (the own chunk of phase B must equal what the other heads read back)
     {
-      const bool plain = false;
+      const bool plain = (a->opt & 256) && cluster_shares_l2(place, a->opt);      // tuning switch: payload left in the shared L2 (ordinary stores)
       if (a->times && tid == 0) a->times[(size_t)blockIdx.x * 16 + 15] = plain ? 1ull : 0ull;
       const int T16 = n_act * 16;
       for (int c = T * 16 + tid; c < T16 * 16; c += NT) *reinterpret_cast<uint4*>(smem + QS + c * 16) = make_uint4(0, 0, 0, 0);
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     khalf_exchange(smem + RED, kh, cg, lane, accb);
     // x1 rows: f32 -> memory (this workgroup's own slab: phase D reads it back), bf16 -> exchange 1 + the own chunk of phase C (slot 0), row statistics
     {
-      const bool plain = false;
+      const bool plain = (a->opt & 256) && cluster_shares_l2(place, a->opt);      // tuning switch: payload left in the shared L2 (ordinary stores)
       const int n = cg * 32 + fgrp * 8;
       float* xo = a->x + (size_t)row0 * D + h * HD + n;
       const bool direct = (a->opt & 8) == 0;                  // payload rows go out of the registers (measured 1.5 % faster than image pieces out of LDS: the stores are bound by the write path, not by their issue); opt 8: through the LDS image
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     if (tid < R) row_stats_finish(smem, a->ln_eps, tid);
     __syncthreads();
     STAMP(9);
-    const bool plain = false;
+    const bool plain = (a->opt & 256) && cluster_shares_l2(place, a->opt);      // tuning switch: payload left in the shared L2 (ordinary stores)
     const bool direct = (a->opt & 8) == 0;
     unsigned char* himg = reinterpret_cast<unsigned char*>(a->hid + (size_t)row0 * DFF) + (size_t)(4 * h) * n_act * 4096;
     {
@@ -847,6 +847,18 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     chunk_gemm<2, 16, 2, PFD, 4, 0, ABL>(smem, wp, wf, 2 * kh, lane, acc,
                                   [&](int q) __attribute__((always_inline)) { issue_chunk_img(hsrc + (size_t)((4 * h + q) & 15) * n_act * 4096, n_act * 4, smem + (q & 3) * CH, wave, lane, nofence); },
                                   [&]() __attribute__((always_inline)) { consume(flags + 2, NH, a->err, !nofence); STAMP(12); });
+    // the x1 rows this wave finishes (fragments 0..4 of K-half 0, 5..8 of K-half 1; written by this very lane in phase B): requested now, they arrive under
+    // the K-half exchange (in front of the loop they would have to live across it: measured, the compiler spills them)
+    float4 x1r[5][2];
+    {
+      const float* xr0 = a->x + (size_t)row0 * D + h * HD + cg * 32 + fgrp * 8;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int i = kh == 0 ? k : min(5 + k, RF - 1);
+        const float* xr = xr0 + (size_t)min(i * 16 + frow, rows_left - 1) * D;
+        x1r[k][0] = *reinterpret_cast<const float4*>(xr); x1r[k][1] = *reinterpret_cast<const float4*>(xr + 4);
+      }
+    }
     __syncthreads();
     STAMP(13);
     khalf_exchange(smem + RED, kh, cg, lane, acc);
@@ -855,12 +867,13 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     const float b8[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
     float* xo = a->x + (size_t)row0 * D + h * HD + n;
     bf16_t* xl = a->x_lo_out + (size_t)row0 * D + h * HD + n;
+    const bool plain_d = (a->opt & 256) && cluster_shares_l2(place, a->opt);
     unsigned char* ximg = reinterpret_cast<unsigned char*>(a->x_lo_out + (size_t)row0 * D) + (size_t)h * n_act * 4096;        // (x_lo == x_lo_out inside a multi-block launch)
 #pragma unroll
     for (int i = 0; i < RF; ++i) {
       if ((kh == 0) == (i < 5) && i < n_act) {
         const int row = i * 16 + frow;
-        const float4 r0 = *reinterpret_cast<const float4*>(xo + (size_t)row * D), r1 = *reinterpret_cast<const float4*>(xo + (size_t)row * D + 4);
+        const float4 r0 = x1r[i < 5 ? i : i - 5][0], r1 = x1r[i < 5 ? i : i - 5][1];
         const float x1[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
         float v[8];
 #pragma unroll
@@ -874,13 +887,13 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
         else {                                                                                 // for the next block of this launch: the own chunk (slot 0) + the image, exchange 3
           const int pos = (((n >> 3)) ^ (row & 15)) << 4;
           *reinterpret_cast<uint4*>(smem + row * 256 + pos) = pk;
-          store16_wt(ximg + row * 256 + pos, pk);
+          store16_wt(ximg + row * 256 + pos, pk, plain_d);
         }
         row_stats_group(pk, smem, cg, row, fgrp);
       }
     }
     __syncthreads();
-    row_stats_publish(smem, a->st_out + (size_t)row0 * (D / 32) + h, n_act * 16, !last, false, tid);
+    row_stats_publish(smem, a->st_out + (size_t)row0 * (D / 32) + h, n_act * 16, !last, plain_d, tid);
     if (!last) publish(flags + 3);
     else if (a->times) wait_vm<0>();
     STAMP(14);

@@ -113,7 +113,7 @@ struct SvSession : asr_session {
     if (const char* e = getenv("ASR_LN_FUSED")) use_ln_alg = !(e[0] == '0');
   }
   int block_scatter = 0;        // ASR_SANM_BLOCK_SCATTER=1: test placement, every cluster spread over four XCDs
-  int block_min_utts = 48;      // ASR_SANM_BLOCK_MIN=<windows>: smallest batch that takes the block kernel
+  int block_min_utts = 12;      // ASR_SANM_BLOCK_MIN=<windows>: smallest batch that takes the block kernel (8-wave form: faster from ~10 windows on; tools/probes/block_min_sweep.sh)
   DeviceBuffer d_times; int block_dbg = -1;   // ASR_SANM_BLOCK_DBG=<block index>: phase clock of that block's launch on stderr
   DeviceBuffer d_flags;         // exchange counters of the block kernel: [n_blocks][batch][4] + the error word at the end
   hipGraphExec_t graph_exec = nullptr;

@@ -363,7 +363,9 @@ def main():
                 k["tflops"] = round(flops[name] / (ms * 1e-3) / 1e12, 1)
             kernels[name] = k
         if "sanm_block" in kernels:
-            dom, dom_desc, dom_match = ["sanm_block"], "sanm_block_kernel (persistent: q|k|v + attention + FSMN + out-proj + FFN of one SANM block per launch)", ("sanm_block_kernel",)
+            dom, dom_match = ["sanm_block"], ("sanm_block8_kernel", "sanm_block_kernel")
+            dom_desc = ("sanm_block8_kernel (q|k|v + attention + FSMN + out-proj + FFN of a SANM block, clusters of four workgroups per window; one launch walks a "
+                        "whole run of blocks: 49 + 20 per step; csrc/sanm_block8.hip)")
         else:
             dom = [n for n in kernels if n.startswith("gemm_") and n != "gemm_ctc"]
             dom_desc = ("gemm_bf16_t144 / gemm_bf16_t288w (SANM out-proj / ffn2: 144 x 128 tiles, ffn1: 288 x 256 tiles; the q|k|v projection "
@@ -373,7 +375,11 @@ def main():
         gemm_flops = sum(flops[n] for n in dom)
         gemm_launches = sum(kernels[n]["launches_per_step"] for n in dom)
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        pmc_key = "sanm_block_kernel" if "sanm_block" in kernels else "gemm_bf16_t144"
+        pmc_key = "sanm_block8_kernel" if "sanm_block" in kernels else "gemm_bf16_t144"
+        n_blocks_in_dom = cfg.n_blocks - cfg.n_enc0 if "sanm_block" in kernels else None        # blocks the block-kernel launches walk per step
+        traffic = hbm_traffic(pmc_key)
+        if traffic and n_blocks_in_dom:                       # a launch walks a run of blocks: the per-block figure is the comparable one
+            traffic["bytes_per_block"] = int(traffic["bytes_per_launch"] * gemm_launches / n_blocks_in_dom)
         out = {
             "metric": "audio-sec/s, SenseVoiceSmall, 8 s @ 16 kHz chunks, batch 64 per GPU (RTF = 1/value per GPU-stream)",
             "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -393,8 +399,9 @@ def main():
             "model_tflops_per_gpu": round(total_flops / (ms_per_step * 1e-3) / 1e12, 1),
             "roofline": {"bound": "mfma", "kernel": dom_desc,
                          "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": hbm_traffic(pmc_key), "pmc": mfma_util(pmc_key),
+                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "pmc": mfma_util(pmc_key),
                          "launches_per_step": gemm_launches, "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),
+                         "blocks_per_step": n_blocks_in_dom, "avg_block_us": None if not n_blocks_in_dom else round(gemm_ms * 1e3 / n_blocks_in_dom, 2),
                          "rocprof": rocprof_avg_us(dom_match),
                          "algorithmic_gflop_per_step": round(gemm_flops / 1e9, 1),
                          "whole_step_frac": round(total_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},

@@ -91,17 +91,16 @@ def test_bf16_full_size_batch_vs_oracle():
     r0a, Ta = rows[0]
     r0c, _ = rows[2]
     assert np.array_equal(t["logits"][r0a:r0a + Ta], t["logits"][r0c:r0c + Ta])
-    agree = total = 0
+    # measured bf16 logit error of this model against the f32 oracle: 0.05 of a +-4.3 range (the batch-64 test below pins 0.052 on 8768 frames); the bound
+    # is twice that, and the arg-max must equal the oracle's wherever its own top-1 / top-2 margin clears twice the bound -- no agreement quota
+    BOUND = 0.1
     for a, lang, (r0, T) in zip(audios, [0, 1, 0, 3, 6], rows):
         st = orc.stages(a, lang)
         err = np.abs(t["logits"][r0:r0 + T] - st["logits"]).max()
-        assert err < 0.25, err
+        assert err < BOUND, err
         srt = np.sort(st["logits"], axis=1)
-        safe = (srt[:, -1] - srt[:, -2]) > 0.5
+        safe = (srt[:, -1] - srt[:, -2]) > 2 * BOUND
         assert np.array_equal(ids[r0:r0 + T][safe], st["frame_ids"][safe])
-        agree += int((ids[r0:r0 + T] == st["frame_ids"]).sum())
-        total += T
-    assert agree / total > 0.85
 
 
 def test_run_is_deterministic_and_rejects_bad_input():

@@ -153,9 +153,23 @@ def cpu_baseline(cfg, ck, audio_np, budget_s=15.0):
         if (el >= budget_s and n_done >= 4) or n_done >= 64:
             break
     secs = audio_np.shape[2] / cfg.sample_rate
-    return {"value": round(n_done * secs / el, 2), "unit": "audio-s/s", "cores": int(torch.get_num_threads()), "host_cores": int(os.cpu_count() or 0), "kind": "port",
-            "sample": f"{n_done} x {secs:.0f} s utterances, batch 1, torch-CPU f32 oracle (oracle/sensevoice_oracle.py), "
-                      f"{el:.1f} s wall; RTF {el / (n_done * secs):.4f}"}
+    out = {"value": round(n_done * secs / el, 2), "unit": "audio-s/s", "cores": int(torch.get_num_threads()), "host_cores": int(os.cpu_count() or 0), "kind": "port",
+           "sample": f"{n_done} x {secs:.0f} s utterances, batch 1, torch-CPU f32 oracle (oracle/sensevoice_oracle.py), "
+                     f"{el:.1f} s wall; RTF {el / (n_done * secs):.4f}; `cores` = the fastest of 8 / 16 / 32 threads"}
+    # the two settings SURVEY section 8(d) names, each on its own bounded sample: every core of the host, and one thread
+    for key, n_thr, budget in (("all_host_cores", int(os.cpu_count() or 1), 5.0), ("single_thread", 1, 8.0)):
+        torch.set_num_threads(n_thr)
+        orc(audio_np[0, 0], 0)
+        k, t0 = 0, time.perf_counter()
+        while True:
+            orc(audio_np[k % audio_np.shape[0], 0], 0)
+            k += 1
+            e2 = time.perf_counter() - t0
+            if e2 >= budget or k >= 32:
+                break
+        out[key] = {"value": round(k * secs / e2, 2), "cores": n_thr, "sample": f"{k} x {secs:.0f} s utterances, {e2:.1f} s wall"}
+    torch.set_num_threads(best_n)
+    return out
 
 
 def self_launch_command(n_gpus, argv, port=None):
@@ -435,14 +449,14 @@ def main():
             del lg_all
             out["parity_spotcheck"] = {"what": f"CTC logits tapped from the timed batch of {B}, bf16 engine vs f32 oracle", "utterances": checks}
             if not args.no_extras:
-                out["secondary"] = secondary_lines(cfg, ck, audio_np, local_rank, device)
+                out["secondary"] = secondary_lines(cfg, ck, audio_np, local_rank, device, cpu_leg=True)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def secondary_lines(cfg, ck, audio_np, local_rank, device):
+def secondary_lines(cfg, ck, audio_np, local_rank, device, cpu_leg=False):
     """The other two figures BASELINE.json's metric names, measured in the same driver-run process (secondary keys, never `value`):
     configs[0] SenseVoiceSmall f32 mode, one 8 s chunk (the mode whose tokens equal the reference's) and Whisper-large-v3 bf16 on 8 s
     chunks at batch 1, 32 and 64 (encoder + prefill + 31 greedy decode steps; random weights never emit EOS)."""
@@ -494,7 +508,6 @@ def secondary_lines(cfg, ck, audio_np, local_rank, device):
         wcfg = cfgm.whisper_large_v3()
         wck = ckm.synth_whisper_checkpoint(wcfg, seed=0)
         blob = arena.build_whisper_arena(wcfg, wck, arena.PRECISION_BF16, ckm.whisper_suppress_tokens(wcfg), ckm.whisper_begin_suppress_tokens(wcfg))
-        del wck
         a_dev = torch.from_numpy(blob).to(device)
         del blob
         ws = eng.WhisperSession(wcfg, a_dev, arena.PRECISION_BF16, local_rank, arena_device_ptr=a_dev.data_ptr(), arena_bytes=a_dev.numel())
@@ -536,6 +549,25 @@ def secondary_lines(cfg, ck, audio_np, local_rank, device):
                 out[f"whisper_large_v3_bf16_b{Bw}x{secs}s"]["config"] = "BASELINE.json configs[2]"
             del wav
         del ws, a_dev
+        if cpu_leg:
+            # the metric's second model on this host's cores: the CPU restatement (CHECKER ONLY), batch 1 like the reference, on a bounded sample
+            # (one warm-up + two timed 8 s utterances: encoder + prefill(4) + 31 decode steps each)
+            from oracle.whisper_oracle import WhisperOracle
+            orc = WhisperOracle(wcfg, wck, ckm.whisper_suppress_tokens(wcfg), ckm.whisper_begin_suppress_tokens(wcfg))
+            n_thr = min(32, os.cpu_count() or 8)
+            torch.set_num_threads(n_thr)
+            ns = 8 * wcfg.sample_rate
+            clips = ckm.synth_audio("unit", 3, ns, seed=4321)
+            prm = [wcfg.sot_id, wcfg.first_language_id, wcfg.transcribe_id, wcfg.no_timestamps_id]
+            orc.greedy([clips[0, 0]], [prm], 8)
+            t0 = time.perf_counter()
+            for k in (1, 2):
+                orc.greedy([clips[k, 0]], [prm], 32)
+            el = time.perf_counter() - t0
+            out["whisper_large_v3_cpu_baseline"] = {"value": round(2 * 8.0 / el, 3), "unit": "audio-s/s", "cores": n_thr, "host_cores": int(os.cpu_count() or 0), "kind": "port",
+                                                    "sample": f"2 x 8 s utterances, batch 1, encoder + prefill(4) + 31 decode steps, torch-CPU f32 oracle "
+                                                              f"(oracle/whisper_oracle.py), {el:.1f} s wall"}
+        del wck
     except Exception as e:                                   # a secondary must never take the headline line down
         out["whisper_large_v3_bf16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out

@@ -283,9 +283,8 @@ bool decode_gemm_supported(const DecGemmArgs& g) {
 //   bytes per workgroup / RATE + (splits > 1 ? HAND + splits * PER_SPLIT : 0)
 // over NT in {1, 2} and the split counts that keep granules x splits within one round; constants from tools/probes/decode_split_sweep.sh.
 void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits) {
-  const int cus = 256;
-  static const int force_nt = getenv("ASR_DECODE_NT") ? atoi(getenv("ASR_DECODE_NT")) : 0;          // tuning hooks
-  static const int force_ks = getenv("ASR_DECODE_KS") ? atoi(getenv("ASR_DECODE_KS")) : 0;
+  const int cus = gemm_env_cus();
+  const int force_nt = gemm_env_decode_nt(), force_ks = gemm_env_decode_ks();          // tuning hooks, re-read at session creation like every other switch
   const int ws_rows = g.M <= 16 ? 16 : g.M <= 32 ? 32 : 64;      // rows per split slab as the kernel addresses them: [ks][MT * 16][N]
   const int mt = ws_rows / 16;
   const bool can_split = g.ws && g.cnt;

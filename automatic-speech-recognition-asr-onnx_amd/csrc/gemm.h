@@ -74,7 +74,11 @@ bool gemm_pp_supported(const GemmArgs& g);
 bool launch_gemm_pp(const GemmArgs& g, hipStream_t s, int var = 0);
 bool gemm_ln_fusable(const GemmArgs& g);   // true when launch_gemm_bf16 would accept g with ln_colsum set
 void gemm_set_variant(int v);   // tuning hook: -1 = built-in heuristic
-void gemm_reload_env();         // re-read the ASR_GEMM_* / ASR_SKINNY_* switches (called at session creation)
+void gemm_reload_env();         // re-read the ASR_GEMM_* / ASR_SKINNY_* / ASR_DECODE_* switches and the device's CU count (called at session creation)
+int gemm_env_decode_nt();       // ASR_DECODE_NT, ASR_DECODE_KS (0 = the cost model), ASR_DECODE_ATTN_WAVE, CUs of the device: as of the last reload
+int gemm_env_decode_ks();
+bool gemm_env_decode_attn_wave();
+int gemm_env_cus();
 const char* gemm_last_kernel(); // kernel family of this thread's last launch_gemm_bf16 ("t288w", "t144", "pipe", "skinny", ...): test hook
 bool gemm_skinny144_enabled();
 void gemm_kernel_counts_reset();

@@ -25,6 +25,9 @@
 struct GemmEnv {
   bool t144 = true, t144w = true, t288w = true, big = true, pp = true, splitk = true, deep = true, skinny144 = false;
   int skinny_splitk = -1, tall_min = 16, skinny_max_plain = 32;
+  int decode_nt = 0, decode_ks = 0;      // ASR_DECODE_NT / ASR_DECODE_KS: force the decode GEMM's column granule / split count (0 = the cost model)
+  bool decode_attn_wave = true;          // ASR_DECODE_ATTN_WAVE=0: single-token self-attention on the general kernel
+  int n_cus = 0;                         // CUs of the current device (the decode GEMM's one-round grid bound)
   bool loaded = false;
 };
 static GemmEnv g_env;
@@ -56,12 +59,19 @@ void gemm_reload_env() {
   e.skinny144 = getenv("ASR_SKINNY_M144") && getenv("ASR_SKINNY_M144")[0] == '1';
   e.skinny_splitk = env_int("ASR_SKINNY_SPLITK", -1); e.tall_min = env_int("ASR_GEMM_TALL_MIN", 16);
   e.skinny_max_plain = env_int("ASR_SKINNY_MAX_M", 32);
+  e.decode_nt = env_int("ASR_DECODE_NT", 0); e.decode_ks = env_int("ASR_DECODE_KS", 0); e.decode_attn_wave = env_flag("ASR_DECODE_ATTN_WAVE", true);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&e.n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || e.n_cus <= 0) e.n_cus = 256;
   e.loaded = true;
   g_env = e;
 }
 static const GemmEnv& genv() { if (!g_env.loaded) gemm_reload_env(); return g_env; }
 const char* gemm_last_kernel() { return g_last_kernel; }
 bool gemm_skinny144_enabled() { return genv().skinny144; }
+int gemm_env_decode_nt() { return genv().decode_nt; }
+int gemm_env_decode_ks() { return genv().decode_ks; }
+bool gemm_env_decode_attn_wave() { return genv().decode_attn_wave; }
+int gemm_env_cus() { return genv().n_cus; }
 
 namespace {
 

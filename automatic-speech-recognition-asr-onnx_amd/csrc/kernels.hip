@@ -1,5 +1,6 @@
 // Non-GEMM kernels of the ASR hot path for gfx950 (wave64, MFMA, LDS-staged tiles).
 #include "kernels.h"
+#include "gemm.h"
 
 #include <algorithm>
 #include <type_traits>
@@ -1572,7 +1573,7 @@ void launch_decode_attention(const DecAttnArgs& a, int batch, hipStream_t s) {
   ASR_REQUIRE(a.n >= 1 && a.n <= DA_MAXN, "decode attention: %d new positions per call (max %d)", a.n, DA_MAXN);
   ASR_REQUIRE(a.plan || a.hist_dev || a.hist + a.n <= DA_MAXKEYS, "decode attention: %d keys exceed %d", a.hist + a.n, DA_MAXKEYS);
   if constexpr (std::is_same<T, bf16_t>::value) {
-    static const bool wave_on = !(getenv("ASR_DECODE_ATTN_WAVE") && getenv("ASR_DECODE_ATTN_WAVE")[0] == '0');
+    const bool wave_on = gemm_env_decode_attn_wave();
     if (wave_on && a.n == 1 && !a.plan && a.kv_new && !a.k_scale && !a.v_scale && (a.ld_q % 8) == 0 && (a.ld_new % 8) == 0 && (a.q_col0 % 8) == 0 &&
         (a.k_col0 % 8) == 0 && (a.v_col0 % 8) == 0 && (a.ld_out % 8) == 0) {                 // single-token self-attention: one wave per (sequence, head)
       hipLaunchKernelGGL(decode_self_attn_wave_kernel, dim3(batch, (a.n_heads + 3) / 4), dim3(256), 0, s, a);

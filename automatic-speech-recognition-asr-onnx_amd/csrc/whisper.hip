@@ -640,8 +640,13 @@ void WhSession::ensure_kv_pages(int B, int positions, size_t elem_bytes) {
   if (bytes > d_kvpool.cap) {
     DeviceBuffer fresh;
     fresh.reserve(bytes, stream);
-    if (hist > 0 && old_bytes) HIP_CHECK(hipMemcpyAsync(fresh.ptr, d_kvpool.ptr, old_bytes, hipMemcpyDeviceToDevice, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
+    try {
+      if (hist > 0 && old_bytes) HIP_CHECK(hipMemcpyAsync(fresh.ptr, d_kvpool.ptr, old_bytes, hipMemcpyDeviceToDevice, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+    } catch (...) {
+      fresh.release();                   // (DeviceBuffer has no destructor: a failed copy must not leak the new pool)
+      throw;
+    }
     d_kvpool.release();
     d_kvpool = fresh;
   }

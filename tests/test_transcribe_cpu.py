@@ -73,3 +73,20 @@ def test_dump_comparator_reports_first_difference(tmp_path):
     m = rep["files"][0]["mismatches"][0]
     assert m["window"] == 0 and m["first_difference_at"] == 2 and m["ours"][0] == 3 and m["reference"][0] == 99
     assert rep["files"][1]["status"] == "missing in reference"
+
+
+def test_the_parity_harness_rejects_wav_widths_whose_samples_differ_from_the_references(tmp_path):
+    """A 24-bit wav is rescaled by the ingest (audioop.lin2lin) where the reference's dump truncates: tools/transcribe.py `run` takes 16-bit wav only unless
+    --any-wav-width is given, so a dump that `compare` will judge cannot be made from samples the reference never saw."""
+    import pytest
+    aio = sub("audio_io")
+    p24 = str(tmp_path / "mono24.wav")
+    _write(p24, np.zeros(3 * 1600, np.uint8).tobytes(), 1, 3, 16000)
+    assert aio.read_wav_int16(p24, 16000).shape == (1600,)                          # the library call converts ...
+    with pytest.raises(ValueError, match="24-bit"):
+        aio.read_wav_int16(p24, 16000, exact_width=True)                            # ... the strict form refuses
+    src = open(os.path.join(ROOT, "tools", "transcribe.py")).read()
+    assert src.count("exact_width=a.strict_wav") == 3 and "read_wav_int16(p, cfg.sample_rate)" not in src     # every ingest of `run` honours the switch
+    t = _tool()
+    ap_defaults = [a for a in ("--any-wav-width",) if a in src]
+    assert ap_defaults and hasattr(t, "main")

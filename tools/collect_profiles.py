@@ -18,7 +18,7 @@ for d, out in (("stats", "sensevoice_b64"), ("stats_whisper", "whisper_b32"), ("
     fs = glob.glob(os.path.join(src, d, "*", "*kernel_stats.csv"))
     if fs:
         shutil.copy(sorted(fs, key=os.path.getmtime)[-1], f"profiles/{rnd}_{out}_kernel_stats.csv")
-for t in ("sensevoice_bf16_b1_trace_summary.txt", "sanm_block_phase_clock.txt", "sensevoice_f32_b1_profile.txt", "fp8_gemm_probe.txt", "gelu_epilogue_cost.txt", "sanm_block_ablations.txt"):
+for t in ("sensevoice_bf16_b1_trace_summary.txt", "sanm_block_phase_clock.txt", "sensevoice_f32_b1_profile.txt", "fp8_gemm_probe.txt", "gelu_epilogue_cost.txt", "sanm_block_ablations.txt", "sanm_block_batch_sweep.txt", "sanm_block_variants.txt", "sanm_block_min_sweep.txt"):
     p = os.path.join(src, t)
     if os.path.isfile(p):
         shutil.copy(p, f"profiles/{rnd}_{t}")

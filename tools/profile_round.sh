@@ -21,8 +21,15 @@ python bench.py --workload whisper --fp8mm --batch 64 --steps 5 --warmup 3 --inf
 python bench.py --workload whisper --fp8mm --seconds 30 --steps 3 --warmup 2 --no-cpu-baseline > $OUT/bench_whisper30_fp8mm.json 2> $OUT/bench_whisper30_fp8mm.err
 python tools/fp8_gemm_probe.py > $OUT/fp8_gemm_probe.txt 2>&1
 python tools/probes/gelu_cost.py > $OUT/gelu_epilogue_cost.txt 2>&1
-for a in 0 1 2 3 16; do echo "=== ASR_SANM_BLOCK_ABL=$a (1 no refills after the prologue, 2 no MFMA, 16 no payload / output stores)"; ASR_SANM_BLOCK_ABL=$a ASR_SANM_BLOCK_DBG=10 python tools/probes/sanm_block_clock.py 2>&1 | grep -v amdgpu.ids | tail -15; done > $OUT/sanm_block_ablations.txt 2>&1
+# the 8-wave block kernel: timing-only ablations of its GEMM loops (ASR_SANM_BLOCK8_OPT bits 4..7), the phase clock of one block of the long launch, and the same
+# box's figures for one launch per block and for the 12-wave kernel of rounds 2-3
+for a in 0 16 32 64 128 192 224; do echo "=== ASR_SANM_BLOCK8_OPT=$a (x16: 1 no MFMA, 2 no A fragment reads, 4 no W refills, 8 no chunk DMA; results are garbage by design)"; ASR_SANM_BLOCK8_OPT=$a ASR_SANM_BLOCK_DBG=10 python tools/probes/sanm_block_clock.py 2>&1 | grep -v amdgpu.ids | tail -17; done > $OUT/sanm_block_ablations.txt 2>&1
 ASR_SANM_BLOCK_DBG=10 python tools/probes/sanm_block_clock.py > $OUT/sanm_block_phase_clock.txt 2>&1
+for b in 1 16; do echo "=== batch $b (ASR_SANM_BLOCK_MIN=1): the per-cluster critical path with the chip idle"; CLOCK_B=$b ASR_SANM_BLOCK_MIN=1 ASR_SANM_BLOCK_DBG=10 python tools/probes/sanm_block_clock.py 2>&1 | grep -v amdgpu.ids | tail -17; done > $OUT/sanm_block_batch_sweep.txt 2>&1
+for v in "ASR_SANM_BLOCK_V=8" "ASR_SANM_BLOCK_PERSIST=0" "ASR_SANM_BLOCK_V=1" "ASR_SANM_BLOCK8_OPT=4" "ASR_SANM_BLOCK8_OPT=8" "ASR_SANM_BLOCK8_OPT=256" "ASR_SANM_BLOCK_V=8"; do
+  echo "$v: $(env $v python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms per step,', d['value'], 'audio-s/s')")"
+done > $OUT/sanm_block_variants.txt 2>&1
+bash tools/probes/block_min_sweep.sh > $OUT/sanm_block_min_sweep.txt 2>&1
 python tools/probes/f32_b1_profile.py > $OUT/sensevoice_f32_b1_profile.txt 2>&1
 python bench.py --workload paraformer-streaming --steps 16 --warmup 8 > $OUT/bench_paraformer_streaming.json 2> $OUT/bench_paraformer_streaming.err
 python bench.py --workload qwen --steps 6 --warmup 2 --inflight 3 > $OUT/bench_qwen.json 2> $OUT/bench_qwen.err

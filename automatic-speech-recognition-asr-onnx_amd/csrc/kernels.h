@@ -316,6 +316,30 @@ void launch_stream_dec_fsmn(const float* x, const float* res, const float* w, in
 void launch_stream_advance(const UttPlan* plan, const UttPlan* token_plan, int n_active, int en_add, int en_cap, int de_add, int de_cap,
                            int32_t* en_len, int32_t* de_len, hipStream_t s);
 
+// ---- Paraformer online encoder layers of one chunk step as ONE launch (stream_layers.hip): clusters of four workgroups per stream, weights streamed
+// from a fragment-major copy of every layer. bf16 sessions, d = 512 / 4 heads / d_ffn = 2048 / history + 16 <= 64 keys.
+struct StreamLayer {
+  const unsigned char* wpack;                               // launch_stream_layers_pack of this layer's q|k|v, out, w1, w2
+  const float *bqkv, *wfsmn, *bfsmn, *b1, *b2;
+  bf16_t* cache_k; bf16_t* cache_v;                        // this layer's histories [stream][head][cap][128]
+};
+struct StreamLayersArgs {
+  const UttPlan* plan;                                      // per active stream: row_off (its 16-row slot), lang = stream id
+  int n_streams, n_layers, n_cur, cap, roll_rows, ktaps;
+  float ln_eps;
+  const int32_t* cache_len;                                 // [stream] history rows (the same for every layer)
+  const StreamLayer* layers;                                // device table
+  float* x;                                                 // [rows][512] residual stream: in = rows entering the first layer of the table, out = rows leaving the last
+  float* xb; bf16_t* ctx; bf16_t* hid;                      // the clusters' exchange buffers [rows][512] f32, [rows][512], [rows][2048]
+  unsigned* flags;                                          // [n_layers][n_streams][4] counters, zero at launch
+  unsigned* err;                                            // raised by a cluster that gave up waiting (the launch's results are void)
+  unsigned long long* times = nullptr; int times_layer = 0; // tuning: thread 0 of every workgroup stamps wall_clock64() at 13 points of layer `times_layer` ([wg][16])
+};
+size_t stream_layers_pack_bytes();
+void launch_stream_layers_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, hipStream_t s);
+bool stream_layers_supported(int d, int d_ffn, int n_heads, int cap, int n_cur, int ktaps);
+void launch_stream_layers(const StreamLayersArgs& a, hipStream_t s);
+
 // ---- Qwen3-ASR decode step as one persistent kernel (qwen_mega.hip): token embedding + every decoder layer, phases separated by a
 // chip-wide barrier; bf16 mode, <= 64 sequences. The final norm / lm_head / head kernels follow as ordinary launches.
 struct QwMegaLayer { const bf16_t *wqkv, *wo, *gate_up, *down; const float *qn, *kn; };

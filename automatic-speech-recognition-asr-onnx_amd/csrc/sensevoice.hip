@@ -2,6 +2,7 @@
 // CTC arg-max + collapse. Follows SENSE_VOICE.forward (SenseVoice/Export_SenseVoice.py:271-296).
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/asr_mi355x.h"
 #include "engine.h"
@@ -58,7 +59,7 @@ struct SvSession : asr_session {
   size_t h_out_cap = 0;
 
   ~SvSession() override {
-    for (DeviceBuffer* b : {&d_dft_split, &d_times, &d_flags, &d_ctplan, &d_mdev, &d_trow, &d_skws, &d_skcnt, &d_sta, &d_stb, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
+    for (DeviceBuffer* b : {&d_dft_split, &d_times, &d_flags, &d_ctplan, &d_mdev, &d_trow, &d_skws, &d_skcnt, &d_sta, &d_stb, &st_wpack, &st_layer_tab, &st_flags, &st_times, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
                             &d_x0lo, &d_xalo, &d_xblo, &d_plan, &d_audio, &d_mel, &d_x0, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx, &d_mem, &d_ffn,
                             &d_amax_v, &d_amax_i, &d_ids, &d_tok, &d_num, &d_logits, &d_enc_lo, &d_ck, &d_cifa, &d_alpha, &d_dec, &d_x2,
                             &d_sa, &d_ffn32, &d_tplan})
@@ -77,6 +78,11 @@ struct SvSession : asr_session {
   // ---- streaming Paraformer (kind 4): per-stream recurrent state in HBM, every step advances n streams by one chunk
   int st_chunk = 0, st_B = 0, st_C = 0, st_en_cap = 0, st_de_cap = 0, st_max = 0, st_frames = 0;
   DeviceBuffer st_enk, st_env, st_dek, st_dev, st_defsmn, st_prev, st_cifh, st_cifa, st_enlen, st_delen, st_start, d_sqkv, d_skv;
+  // streaming encoder layers 1 .. as one launch (stream_layers.hip): fragment-major weight copies, the device layer table, exchange counters (+ err)
+  DeviceBuffer st_wpack, st_layer_tab, st_flags, st_times;
+  int st_times_layer = -1;              // ASR_STREAM_TIMES=<layer>: phase clocks of that fused layer, printed to stderr after every step (tuning)
+  bool st_fused = false;
+  int st_fused_env = 1;                 // ASR_STREAM_FUSED=0: every layer on the per-launch path
   void stream_init(int chunk, int look_back_encoder, int look_back_decoder, int max_streams);
   void stream_reset(int sid);
   template <typename T> void stream_step(const float* audio, int audio_mem, const int32_t* stream_ids, int n, int32_t* tok_out, int max_tokens,
@@ -874,6 +880,29 @@ void SvSession::stream_init(int chunk, int look_back_encoder, int look_back_deco
   st_enlen.reserve((size_t)max_streams * 4, stream);
   st_delen.reserve((size_t)max_streams * 4, stream);
   st_start.reserve((size_t)max_streams * 4, stream);
+  // bf16 sessions of the standard geometry: layers 1 .. n - 1 of a chunk step run as one launch (layer 0 has the 560-wide input and no residual)
+  if (const char* e = getenv("ASR_STREAM_FUSED")) st_fused_env = atoi(e);
+  if (const char* e = getenv("ASR_STREAM_TIMES")) st_times_layer = atoi(e);
+  st_fused = st_fused_env != 0 && precision == ASR_PRECISION_BF16 && c.n_blocks > 1 &&
+             stream_layers_supported(c.d_model, c.d_ffn, c.n_heads, st_en_cap, st_B + st_C, c.fsmn_kernel) && blocks[1].kpad == c.d_model;
+  if (st_fused) {
+    const int nl = c.n_blocks - 1;
+    const size_t pk = stream_layers_pack_bytes(), en_layer = (size_t)st_max * c.n_heads * st_en_cap * 128;
+    st_wpack.reserve(pk * nl, stream);
+    st_layer_tab.reserve(sizeof(StreamLayer) * nl, stream);
+    st_flags.reserve(((size_t)nl * st_max * 4 + 4) * 4, stream);
+    std::vector<StreamLayer> tab(nl);
+    for (int i = 0; i < nl; ++i) {
+      const SvBlock& b = blocks[i + 1];
+      unsigned char* dst = (unsigned char*)st_wpack.ptr + pk * i;
+      launch_stream_layers_pack((const bf16_t*)b.wqkv, (const bf16_t*)b.wout, (const bf16_t*)b.w1, (const bf16_t*)b.w2, dst, stream);
+      tab[i].wpack = dst; tab[i].bqkv = b.bqkv; tab[i].wfsmn = b.wfsmn; tab[i].bfsmn = b.bfsmn; tab[i].b1 = b.b1; tab[i].b2 = b.b2;
+      tab[i].cache_k = st_enk.as<bf16_t>() + (size_t)(i + 1) * en_layer;
+      tab[i].cache_v = st_env.as<bf16_t>() + (size_t)(i + 1) * en_layer;
+    }
+    HIP_CHECK(hipMemcpyAsync(st_layer_tab.ptr, tab.data(), sizeof(StreamLayer) * nl, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
   stream_reset(-1);
 }
 
@@ -956,10 +985,10 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
   grow(d_ffn32, (size_t)Mpad * dd * 4);
   grow(d_tplan, sizeof(UttPlan) * n);
   const size_t out_bytes = (size_t)n * max_tokens * 4 + (size_t)n * 4;
-  if (out_bytes > h_out_cap) {
+  if (out_bytes + 16 > h_out_cap) {
     if (h_out) HIP_CHECK(hipHostFree(h_out));
-    HIP_CHECK(hipHostMalloc(&h_out, out_bytes * 2, hipHostMallocDefault));
-    h_out_cap = out_bytes * 2;
+    HIP_CHECK(hipHostMalloc(&h_out, out_bytes * 2 + 16, hipHostMallocDefault));
+    h_out_cap = out_bytes * 2 + 16;
   }
   HIP_CHECK(hipMemcpyAsync(d_plan.ptr, h_plan, plan_bytes, hipMemcpyHostToDevice, stream));
   const float* d_aud = audio;
@@ -1007,8 +1036,26 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
   float* mem = d_mem.as<float>();
   T* ffn = d_ffn.as<T>();
   const size_t en_layer = (size_t)st_max * H * st_en_cap * 128;
+  const bool fused = st_fused && std::is_same<T, bf16_t>::value;
   for (int i = 0; i < c.n_blocks; ++i) {
     const SvBlock& b = blocks[i];
+    if (fused && i == 1) {               // layers 1 .. n - 1: one launch, the stream's rows stay in xa
+      ProfScope ps(prof, "stream_layers", stream);
+      const int nl = c.n_blocks - 1;
+      HIP_CHECK(hipMemsetAsync(st_flags.ptr, 0, ((size_t)nl * n * 4 + 4) * 4, stream));
+      StreamLayersArgs la;
+      la.plan = dp; la.n_streams = n; la.n_layers = nl; la.n_cur = n_cur; la.cap = st_en_cap; la.roll_rows = st_B; la.ktaps = c.fsmn_kernel;
+      la.ln_eps = 1e-5f; la.cache_len = st_enlen.as<int32_t>(); la.layers = st_layer_tab.as<StreamLayer>();
+      la.x = xa; la.xb = xb; la.ctx = (bf16_t*)ctx; la.hid = (bf16_t*)ffn;
+      la.flags = st_flags.as<unsigned>(); la.err = st_flags.as<unsigned>() + (size_t)nl * n * 4;
+      if (st_times_layer >= 0) {
+        st_times.reserve((size_t)((n + 7) / 8) * 32 * 16 * 8, stream);
+        HIP_CHECK(hipMemsetAsync(st_times.ptr, 0, (size_t)((n + 7) / 8) * 32 * 16 * 8, stream));
+        la.times = st_times.as<unsigned long long>(); la.times_layer = st_times_layer;
+      }
+      launch_stream_layers(la, stream);
+      break;
+    }
     { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(x_in, ld_in, rows, b.in_size, b.ln1_g, b.ln1_b, 1e-5f, h, b.kpad, b.kpad, stream); }
     {
       ProfScope ps(prof, "gemm_qkv", stream);
@@ -1181,8 +1228,29 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
   if (taps_enabled) save_tap("logits", d_logits.ptr, rows, c.vocab, vpad, 4);
   HIP_CHECK(hipMemcpyAsync(h_out, d_tok.ptr, (size_t)n * max_tokens * 4, hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipMemcpyAsync((unsigned char*)h_out + (size_t)n * max_tokens * 4, d_num.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+  const bool fused_ran = st_fused && std::is_same<T, bf16_t>::value;
+  unsigned* h_err = (unsigned*)((unsigned char*)h_out + out_bytes);
+  *h_err = 0;
+  if (fused_ran)
+    HIP_CHECK(hipMemcpyAsync(h_err, st_flags.as<unsigned>() + (size_t)(c.n_blocks - 1) * n * 4, 4, hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
   if (prof.enabled) prof.collect();
+  // (histories of the layers in front of the one that gave up are rolled already: the step cannot be redone, the streams have to be reset)
+  if (fused_ran && st_times_layer >= 0) {               // tuning: mean phase intervals over the workgroups (100 MHz clock -> us)
+    const int nwg = (n + 7) / 8 * 32;
+    std::vector<unsigned long long> t((size_t)nwg * 16);
+    HIP_CHECK(hipMemcpy(t.data(), st_times.ptr, t.size() * 8, hipMemcpyDeviceToHost));
+    double sum[13] = {}; int cnt = 0;
+    for (int w = 0; w < nwg; ++w) {
+      if (!t[(size_t)w * 16]) continue;
+      ++cnt;
+      for (int k = 1; k <= 12; ++k) sum[k] += (double)(t[(size_t)w * 16 + k] - t[(size_t)w * 16 + k - 1]) * 0.01;
+    }
+    fprintf(stderr, "stream_layers layer %d (us, mean of %d workgroups):", st_times_layer, cnt);
+    for (int k = 1; k <= 12; ++k) fprintf(stderr, " %.2f", sum[k] / std::max(cnt, 1));
+    fprintf(stderr, "\n");
+  }
+  ASR_REQUIRE(*h_err == 0, "streaming: a workgroup of the fused encoder launch gave up waiting for its cluster; the step's results are invalid, reset its streams");
   memcpy(num_out, (unsigned char*)h_out + (size_t)n * max_tokens * 4, (size_t)n * 4);
   const int32_t* ht = (const int32_t*)h_out;
   for (int i = 0; i < n; ++i) memcpy(tok_out + (size_t)i * max_tokens, ht + (size_t)i * max_tokens, (size_t)std::min(num_out[i], max_tokens) * 4);

@@ -82,6 +82,7 @@ struct SvSession : asr_session {
   DeviceBuffer st_wpack, st_layer_tab, st_flags, st_times;
   int st_times_layer = -1;              // ASR_STREAM_TIMES=<layer>: phase clocks of that fused layer, printed to stderr after every step (tuning)
   bool st_fused = false;
+  int st_opt = 0;                       // ASR_STREAM_OPT: tuning switches of the fused launch (kernels.h: StreamLayersArgs::opt)
   int st_fused_env = 1;                 // ASR_STREAM_FUSED=0: every layer on the per-launch path
   void stream_init(int chunk, int look_back_encoder, int look_back_decoder, int max_streams);
   void stream_reset(int sid);
@@ -883,6 +884,7 @@ void SvSession::stream_init(int chunk, int look_back_encoder, int look_back_deco
   // bf16 sessions of the standard geometry: layers 1 .. n - 1 of a chunk step run as one launch (layer 0 has the 560-wide input and no residual)
   if (const char* e = getenv("ASR_STREAM_FUSED")) st_fused_env = atoi(e);
   if (const char* e = getenv("ASR_STREAM_TIMES")) st_times_layer = atoi(e);
+  if (const char* e = getenv("ASR_STREAM_OPT")) st_opt = atoi(e);
   st_fused = st_fused_env != 0 && precision == ASR_PRECISION_BF16 && c.n_blocks > 1 &&
              stream_layers_supported(c.d_model, c.d_ffn, c.n_heads, st_en_cap, st_B + st_C, c.fsmn_kernel) && blocks[1].kpad == c.d_model;
   if (st_fused) {
@@ -1048,6 +1050,7 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
       la.ln_eps = 1e-5f; la.cache_len = st_enlen.as<int32_t>(); la.layers = st_layer_tab.as<StreamLayer>();
       la.x = xa; la.xb = xb; la.ctx = (bf16_t*)ctx; la.hid = (bf16_t*)ffn;
       la.flags = st_flags.as<unsigned>(); la.err = st_flags.as<unsigned>() + (size_t)nl * n * 4;
+      la.opt = st_opt;
       if (st_times_layer >= 0) {
         st_times.reserve((size_t)((n + 7) / 8) * 32 * 16 * 8, stream);
         HIP_CHECK(hipMemsetAsync(st_times.ptr, 0, (size_t)((n + 7) / 8) * 32 * 16 * 8, stream));

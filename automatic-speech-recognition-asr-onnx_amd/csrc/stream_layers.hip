@@ -19,6 +19,7 @@
 //
 // Give-up: a cluster that waits 0.2 s on a counter raises `err` and the launch runs out (results void); the host reports it as an error of the
 // step -- histories may be half-rolled, the streams of the step must be reset (never seen: clusters are dispatched in order, per XCD).
+#include <type_traits>
 #include "kernels.h"
 
 namespace {
@@ -44,6 +45,10 @@ constexpr int XB = XRES + SLOT * HD * 4, MEM = XB + SLOT * HD * 4, LDS_BYTES = M
 static_assert(LDS_BYTES <= 160 * 1024 && XRES % 16 == 0 && UNI % 16 == 0, "LDS map");
 
 typedef unsigned long long u64;
+// Every barrier of this kernel orders LDS traffic only (what crosses workgroups goes through publish / consume, which drain the vector queue themselves):
+// a bare s_barrier behind an LDS wait. __syncthreads() would also wait for every outstanding global load -- the weight batches and the L2 warm-up
+// requested ahead are meant to stay in flight across barriers.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;      // (a plain vector: HIP's uint4 class cannot be read through an address-space pointer)
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 // pointers read from the layer table arrive as generic ones: say that they are global (a flat load counts on both wait counters and orders against LDS)
@@ -51,13 +56,16 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); retur
 template <typename T> __device__ __forceinline__ const GAS T* glob(const T* p) { return (const GAS T*)p; }
 template <typename T> __device__ __forceinline__ GAS T* glob(T* p) { return (GAS T*)p; }
 
-// payload of an exchange: agent-scope relaxed accesses (sc1: stores write through this XCD's L2, loads do not trust a stale line of it)
+// Payload and counters of an exchange: agent-scope relaxed accesses (sc1: stores write through this XCD's L2, loads do not trust a stale line of it,
+// the counter lives at the memory side). Tried and dropped: "workgroup"-scope accesses (sc0 stores and loads around an L1 invalidate, L2 atomics) for clusters
+// that sit on one XCD, to shorten every hop to an L2 round trip -- on gfx950 a waiting workgroup then sees its siblings' counts 3-5 us LATER than through the
+// memory side (7 us per exchange instead of 2.5), and under graph replay clusters timed out.
 __device__ __forceinline__ void put8(void* p, u64 v) { __hip_atomic_store(reinterpret_cast<u64*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 get8(const void* p) { return __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ void publish(unsigned* flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every wave's stores are out
-  __syncthreads();
+  lds_barrier();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void consume(unsigned* flag, unsigned* err) {
@@ -72,7 +80,23 @@ __device__ __forceinline__ void consume(unsigned* flag, unsigned* err) {
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
+}
+
+// L2 warm-up: the 6.3 MB of a layer are read by all the (<= 32) workgroups of an XCD at about the same time, so every weight request is an L2 MISS that the
+// first asker waits out (2.5 us) with the others queued behind it. Each workgroup therefore touches 1 / n of the NEXT phase's region -- one lane per 128-byte
+// line, a wave instruction covers 8 KB -- while it waits for its cluster; the fills run under the wait and the phase's own requests hit the L2.
+// The value is consumed only behind the next publish (whose vmcnt(0) has drained it anyway).
+__device__ __forceinline__ unsigned warm(const unsigned char* base, int n_lines, int wg, int n_wg, int tid) {
+  const int per = (n_lines + n_wg - 1) / n_wg;
+  unsigned t = 0;
+  for (int i = tid - 64; i < per; i += NT - 64) {           // (wave 0 polls the counter: nothing of its own queues in front of the poll)
+    if (i < 0) break;
+    const int line = wg * per + i;
+    if (line < n_lines) t = *glob(reinterpret_cast<const unsigned*>(base + (size_t)line * 128));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
 }
 
 // fragments [first, first + N) of this wave's stream -> registers
@@ -93,28 +117,30 @@ __device__ __forceinline__ void wmul(const u32x4 (&w)[KB * NJ], const unsigned c
       acc[j * NACC + (kk % NACC)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8_t, w[kk * NJ + j]), acc[j * NACC + (kk % NACC)], 0, 0, 0);
   }
 }
-// one GEMM phase of a wave: KS k-steps in batches of KB, batch 0 already requested into w0, batch b + 1 requested before batch b is multiplied
-template <int NJ, int KS, int KB, int NACC>
-__device__ __forceinline__ void gemm_phase(u32x4 (&w0)[KB * NJ], const unsigned char* wp, const unsigned char* ap, f32x4_t (&acc)[NJ * NACC]) {
+// one GEMM phase of a wave: KS k-steps in batches of KB; batch 0 is already requested into w0 (and batch 1 into w1 when PF2), batch b + 2 is requested
+// as soon as batch b is multiplied
+template <int NJ, int KS, int KB, int NACC, bool PF2>
+__device__ __forceinline__ void gemm_phase(u32x4 (&w0)[KB * NJ], u32x4 (&w1)[KB * NJ], const unsigned char* wp, const unsigned char* ap, f32x4_t (&acc)[NJ * NACC]) {
   constexpr int NB = KS / KB;
   static_assert(NB == 1 || NB % 2 == 0, "batches come in pairs");
   if constexpr (NB == 1) {
     wmul<NJ, KB, NACC>(w0, ap, 0, acc);
   } else {
-    u32x4 w1[KB * NJ];
+    if constexpr (!PF2) wload<KB * NJ>(w1, wp, KB * NJ);
 #pragma unroll
     for (int b = 0; b < NB; b += 2) {
-      wload<KB * NJ>(w1, wp, (b + 1) * KB * NJ);
       wmul<NJ, KB, NACC>(w0, ap, b * KB, acc);
       if (b + 2 < NB) wload<KB * NJ>(w0, wp, (b + 2) * KB * NJ);
       wmul<NJ, KB, NACC>(w1, ap, (b + 1) * KB, acc);
+      if (b + 3 < NB) wload<KB * NJ>(w1, wp, (b + 3) * KB * NJ);
     }
   }
 }
 
 // full rows of the cluster's f32 stream (16 x 512, exchanged) -> plain normalisation (the affine is folded into the next weights) -> bf16 operand rows;
 // thread = (row, 16 columns); the own 128 columns are kept in f32 at `keep` (the residual of the next epilogue) when asked
-__device__ __forceinline__ void norm_rows(const float* src, unsigned char* smem, int tid, int h, bool keep_own, float eps) {
+template <typename F>
+__device__ __forceinline__ void norm_rows(const float* src, unsigned char* smem, int tid, int h, bool keep_own, float eps, F&& behind_loads) {
   const int row = tid >> 5, c0 = (tid & 31) * 16;
   const float* p = src + (size_t)row * D + c0;
   float v[16];
@@ -124,6 +150,8 @@ __device__ __forceinline__ void norm_rows(const float* src, unsigned char* smem,
     v[2 * e] = __uint_as_float((unsigned)t);
     v[2 * e + 1] = __uint_as_float((unsigned)(t >> 32));
   }
+  __builtin_amdgcn_sched_barrier(0);
+  behind_loads();                                          // (more requests for the queue: they line up behind the rows, the arithmetic below waits for the rows only)
   float s = 0.0f;
 #pragma unroll
   for (int e = 0; e < 16; e += 4) s += (v[e] + v[e + 1]) + (v[e + 2] + v[e + 3]);
@@ -164,6 +192,7 @@ __device__ __forceinline__ void put_slab_f32(float* dst_rows, const unsigned cha
 
 #define STAMP(k) do { if (a.times && li == a.times_layer && threadIdx.x == 0) a.times[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 
+template <int PFM>          // phases whose second weight batch is requested right behind the phase's exchanged rows (under their arithmetic): bit 0 = A, 1 = C, 2 = D
 __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid_0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid_0 >> 6);
@@ -184,6 +213,9 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
   const size_t wave_frag = (size_t)(h * NW + wave);
   u32x4 wa[12];                                                            // batch 0 of phase A: requested a layer ahead
   wload<12>(wa, a.layers[0].wpack + PK_A + wave_frag * PW_A + (tid_0 & 63) * 16, 0);
+  // this workgroup's place among the workgroups of its XCD (workgroup b runs on XCD b % 8): its share of every L2 warm-up
+  const int xcd = blockIdx.x & 7, n_wg_xcd = ((a.n_streams - xcd + 7) >> 3) * NH, wg_xcd = (cl >> 3) * NH + h;
+  unsigned sink = 0, tw = 0;
 
 #pragma unroll 1
   for (int li = 0; li < a.n_layers; ++li) {
@@ -210,10 +242,26 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
         rv[it] = *glob(reinterpret_cast<const u32x4*>(cv + (size_t)p * HD + c0));
       }
     }
+    // epilogue constants of the first half: requested here, a layer's worth of latency ahead of their use (in the epilogue each would cost a round trip)
+    float bA[3], wc[TAPS], bc;
+    {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int lc = wave * 48 + j * 16;
+        bA[j] = glob(L.bqkv)[(lc >> 7) * D + h * HD + (lc & 127) + frow];
+      }
+      const int hc = h * HD + (tid & 127);
+#pragma unroll
+      for (int j = 0; j < TAPS; ++j) wc[j] = glob(L.wfsmn)[hc * TAPS + j];
+      bc = glob(L.bfsmn)[hc];
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- phase A: LayerNorm of the stream's rows (the previous layer's exchange 3, or the rows the launch was given), q|k|v of head h
     if (li > 0) consume(flags - (size_t)a.n_streams * 4 + 3, a.err);
     STAMP(1);
-    norm_rows(x_rows, smem, tid, h, true, a.ln_eps);
+    u32x4 wa1[12];
+    norm_rows(x_rows, smem, tid, h, true, a.ln_eps,
+              [&]() __attribute__((always_inline)) { if constexpr ((PFM & 1) != 0) wload<12>(wa1, wpA, 12); });     // batch 1 of phase A under the LayerNorm
 #pragma unroll
     for (int it = 0; it < 2; ++it) {        // history rows -> the K / V images (row-major bf16, as they are cached); rows past the chunk's slot are zero for P V
       const int s = tid + it * NT, p = s >> 4, c0 = (s & 15) * 8;
@@ -224,15 +272,15 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
         *reinterpret_cast<u32x4*>(smem + VB + p * KS + c0 * 2) = u32x4{0, 0, 0, 0};
       }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(2);
     {
       f32x4_t acc[3] = {};
-      gemm_phase<3, 16, 4, 1>(wa, wpA, a_lane + XN, acc);
+      gemm_phase<3, 16, 4, 1, (PFM & 1) != 0>(wa, wa1, wpA, a_lane + XN, acc);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int lc = wave * 48 + j * 16, part = lc >> 7, within = (lc & 127) + frow;          // (a 16-column tile never straddles q | k | v)
-        const float bias = glob(L.bqkv)[part * D + h * HD + within];
+        const float bias = bA[j];
         const int base = part == 0 ? QB : part == 1 ? KB : VB, r0 = part == 0 ? 0 : len;           // (wave-uniform selects)
 #pragma unroll
         for (int i = 0; i < 4; ++i)                                                                // q|k|v are bf16 tensors on the per-launch path too
@@ -241,8 +289,17 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
     }
     u32x4 wb[16];
     wload<16>(wb, wpB, 0);                                                  // the whole of phase B, under the attention
-    __syncthreads();
+    lds_barrier();
     STAMP(3);
+    float bC[4], bD;                                          // epilogue constants of the second half, in front of the warm-up
+    {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bC[j] = glob(L.b1)[h * 512 + wave * 64 + j * 16 + frow];
+      bD = glob(L.b2)[h * HD + wave * 16 + frow];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    unsigned tw2 = 0;
+    if (!(a.opt & 3)) tw2 = warm(L.wpack + PK_C, (int)((PK_BYTES - PK_C) / 128), wg_xcd, n_wg_xcd, tid);     // both FFN matrices, under the attention (nothing in it waits on the vector queue)
     // ---- attention of the slot's 16 rows over [history | chunk rows]: scores on the matrix pipe (wave = one 16-key tile), soft-max in f32 (wave = two rows),
     //      P (bf16) V on the matrix pipe (wave = 16 channels; the V fragment is gathered down the key axis of the row-major image)
     if (wave * 16 < nk) {
@@ -254,7 +311,7 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
 #pragma unroll
       for (int i = 0; i < 4; ++i) Sf[(fgrp * 4 + i) * (MAXK + 1) + wave * 16 + frow] = sc[i];
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int q = wave + 8 * e;
@@ -264,7 +321,7 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
       const float sum = wave_sum(ex);
       *reinterpret_cast<bf16_t*>(smem + PB + q * PS + lane * 2) = (bf16_t)(pack_bf16x2(ex / sum, 0.0f) & 0xffffu);
     }
-    __syncthreads();
+    lds_barrier();
     {
       f32x4_t o = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -285,11 +342,6 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
     {   // FSMN memory term of the slot (taps outside the chunk rows are zero, rows past the chunk are zero), the head's 128 channels; thread = (channel, 4 rows)
       const int c = tid & 127, t0 = (tid >> 7) * 4;
       constexpr int PAD = (TAPS - 1) / 2, NV = 4 + TAPS - 1;
-      const int hc = h * HD + c;
-      float wc[TAPS];
-#pragma unroll
-      for (int j = 0; j < TAPS; ++j) wc[j] = glob(L.wfsmn)[hc * TAPS + j];
-      const float bc = glob(L.bfsmn)[hc];
       float vr[NV];                                        // rows t0 - PAD .. t0 + 3 + PAD of the chunk's V (zero outside the chunk)
 #pragma unroll
       for (int r = 0; r < NV; ++r) {
@@ -327,7 +379,7 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(4);
     {   // exchange 0: own 128 ctx columns out, the other three heads' in
       const int row = tid >> 5, off = (tid & 31) * 8;
@@ -340,12 +392,12 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
         *reinterpret_cast<u64*>(smem + CTX + row * AS + hq * 256 + off) = get8(reinterpret_cast<const unsigned char*>(ctx_rows + (size_t)row * D + hq * HD) + off);
       }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(5);
     // ---- phase B: out-projection columns 128 h + 16 wave .., + FSMN term + residual -> x1 slab
     {
       f32x4_t acc[2] = {};
-      gemm_phase<1, 16, 16, 2>(wb, wpB, a_lane + CTX, acc);
+      gemm_phase<1, 16, 16, 2, false>(wb, wb, wpB, a_lane + CTX, acc);
       const int col = wave * 16 + frow;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -353,33 +405,35 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
         xbs[row * HD + col] = (acc[0][i] + acc[1][i]) + mem[row * HD + col] + xres[row * HD + col];
       }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(6);
     put_slab_f32(xb_rows, smem + XB, tid, h);
     publish(flags + 1);
-    u32x4 wc0[16];
+    sink ^= tw ^ tw2;                                               // (drained by the publish)
+    u32x4 wc0[16], wc1[16];
     wload<16>(wc0, wpC, 0);
+    if ((a.opt & 3) == 2) tw = warm(L.wpack + PK_C, (int)((PK_D - PK_C) / 128), wg_xcd, n_wg_xcd, tid);
     consume(flags + 1, a.err);
     STAMP(7);
     // ---- phase C: LayerNorm of x1, FFN-1 columns 512 h + 64 wave ..
-    norm_rows(xb_rows, smem, tid, h, false, a.ln_eps);
-    __syncthreads();
+    norm_rows(xb_rows, smem, tid, h, false, a.ln_eps, [&]() __attribute__((always_inline)) { if constexpr ((PFM & 2) != 0) wload<16>(wc1, wpC, 16); });
+    lds_barrier();
     STAMP(8);
     {
       f32x4_t acc[4] = {};
-      gemm_phase<4, 16, 4, 1>(wc0, wpC, a_lane + XN, acc);
+      gemm_phase<4, 16, 4, 1, (PFM & 2) != 0>(wc0, wc1, wpC, a_lane + XN, acc);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int col = h * 512 + wave * 64 + j * 16 + frow;
-        const float bias = glob(L.b1)[col];
+        const float bias = bC[j];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           *reinterpret_cast<bf16_t*>(smem + HID + (fgrp * 4 + i) * HS + col * 2) = (bf16_t)(pack_bf16x2(fmaxf(acc[j][i] + bias, 0.0f), 0.0f) & 0xffffu);
       }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(9);
-    u32x4 wd[16];
+    u32x4 wd[16], wd1[16];
     {   // exchange 2: own 512 hid columns out, the other three quarters in
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -387,7 +441,9 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
         put8(reinterpret_cast<unsigned char*>(hid_rows + (size_t)row * DFF + h * 512) + off, *reinterpret_cast<const u64*>(smem + HID + row * HS + h * 1024 + off));
       }
       publish(flags + 2);
+      sink ^= tw;
       wload<16>(wd, wpD, 0);
+      if ((a.opt & 3) == 2) tw = warm(L.wpack + PK_D, (int)((PK_BYTES - PK_D) / 128), wg_xcd, n_wg_xcd, tid);
       consume(flags + 2, a.err);
 #pragma unroll
       for (int q = 1; q < NH; ++q) {
@@ -398,6 +454,7 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
           const int s = tid + NT * e, row = s >> 7, off = (s & 127) * 8;
           t[e] = get8(reinterpret_cast<const unsigned char*>(hid_rows + (size_t)row * DFF + hq * 512) + off);
         }
+        if constexpr ((PFM & 4) != 0) { if (q == NH - 1) { __builtin_amdgcn_sched_barrier(0); wload<16>(wd1, wpD, 16); } }      // batch 1 of phase D behind the last quarter
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int s = tid + NT * e, row = s >> 7, off = (s & 127) * 8;
@@ -405,27 +462,32 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(10);
     // ---- phase D: FFN-2 columns 128 h + 16 wave .. + b2 + x1 -> the stream's rows of the next layer
     {
       f32x4_t acc[2] = {};
-      gemm_phase<1, 64, 16, 2>(wd, wpD, hid_lane, acc);
+      gemm_phase<1, 64, 16, 2, (PFM & 4) != 0>(wd, wd1, wpD, hid_lane, acc);
       const int col = wave * 16 + frow;
-      const float bias = glob(L.b2)[h * HD + col];
+      const float bias = bD;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = fgrp * 4 + i;
         xres[row * HD + col] = (acc[0][i] + acc[1][i]) + bias + xbs[row * HD + col];
       }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(11);
     put_slab_f32(x_rows, smem + XRES, tid, h);
     publish(flags + 3);
+    sink ^= tw;
     STAMP(12);
-    if (li + 1 < a.n_layers) wload<12>(wa, a.layers[li + 1].wpack + PK_A + wave_frag * PW_A + lane * 16, 0);
+    if (li + 1 < a.n_layers) {
+      wload<12>(wa, a.layers[li + 1].wpack + PK_A + wave_frag * PW_A + lane * 16, 0);
+      if (!(a.opt & 1)) tw = warm(a.layers[li + 1].wpack + PK_A, (int)((PK_C - PK_A) / 128), wg_xcd, n_wg_xcd, tid);      // q|k|v and out-projection of the next layer
+    }
   }
+  if (sink == 0x9e3779b9u && a.n_layers < 0) a.err[1] = sink;            // (keeps the warm-up loads; never true)
 }
 
 // one thread per 16-byte slot of the packed copy: where in the arena's row-major matrices its eight elements live
@@ -458,6 +520,11 @@ __global__ __launch_bounds__(256) void stream_layers_pack_kernel(const bf16_t* _
 
 }  // namespace
 
+template <int M> static void static_for_attr() {          // every instance may use the large dynamic LDS size (set once per device)
+  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_layers_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  if constexpr (M < 7) static_for_attr<M + 1>();
+}
+
 size_t stream_layers_pack_bytes() { return PK_BYTES; }
 
 void launch_stream_layers_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, hipStream_t s) {
@@ -472,9 +539,25 @@ bool stream_layers_supported(int d, int d_ffn, int n_heads, int cap, int n_cur, 
 void launch_stream_layers(const StreamLayersArgs& a, hipStream_t s) {
   ASR_REQUIRE(a.n_streams >= 1 && a.n_layers >= 1 && a.cap + SLOT <= MAXK && a.n_cur <= SLOT && a.ktaps == TAPS, "stream_layers: bad geometry");
   static PerDeviceOnce attr_once;
-  if (attr_once.first())
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_layers_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  const bool first = attr_once.first();
   const int groups = (a.n_streams + 7) / 8;
-  hipLaunchKernelGGL(stream_layers_kernel, dim3(groups * 32), dim3(NT), LDS_BYTES, s, a);
+  const int pfm = 7 & (a.opt >> 4);
+  auto go = [&](auto tag) {
+    constexpr int PFM = decltype(tag)::value;
+    if (first) {
+      static_for_attr<0>();
+    }
+    hipLaunchKernelGGL(stream_layers_kernel<PFM>, dim3(groups * 32), dim3(NT), LDS_BYTES, s, a);
+  };
+  switch (pfm) {
+    case 0: go(std::integral_constant<int, 0>{}); break;
+    case 1: go(std::integral_constant<int, 1>{}); break;
+    case 2: go(std::integral_constant<int, 2>{}); break;
+    case 3: go(std::integral_constant<int, 3>{}); break;
+    case 4: go(std::integral_constant<int, 4>{}); break;
+    case 5: go(std::integral_constant<int, 5>{}); break;
+    case 6: go(std::integral_constant<int, 6>{}); break;
+    default: go(std::integral_constant<int, 7>{}); break;
+  }
   HIP_CHECK(hipGetLastError());
 }

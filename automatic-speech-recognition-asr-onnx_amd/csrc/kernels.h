@@ -341,6 +341,33 @@ void launch_stream_layers_pack(const bf16_t* wqkv, const bf16_t* wout, const bf1
 bool stream_layers_supported(int d, int d_ffn, int n_heads, int cap, int n_cur, int ktaps);
 void launch_stream_layers(const StreamLayersArgs& a, hipStream_t s);
 
+// ---- Paraformer online decoder layers of one chunk step as ONE launch (stream_dec.hip): the same clusters; a stream without a fired token leaves at once
+struct StreamDecLayer {
+  const unsigned char* wpack;                               // launch_stream_dec_pack of this layer's w1, w2, wq, wkv, wo
+  const float *b1, *b2, *n2_g, *n2_b, *wfsmn, *bq, *bkv, *bo;
+  float* fsmn_hist;                                         // [stream][10][512] f32
+  bf16_t* cache_k; bf16_t* cache_v;                        // [stream][head][cap][128]
+  int full;                                                 // 0: FFN-only block (the last one)
+};
+struct StreamDecArgs {
+  const UttPlan* token_plan;                                // per active stream: T = fired tokens, row_off (its 16-row slot), lang = stream id
+  int n_streams, n_layers, n_cur, cap;
+  float ln_eps;
+  const int32_t* cache_len;                                 // [stream] K/V history rows
+  const StreamDecLayer* layers;                             // device table
+  const bf16_t* enc;                                        // [rows][512] the chunk's encoder rows (after_norm, bf16)
+  float* dec;                                               // [rows][512] fired frames in, decoder output rows out
+  float* x1; float* x2; float* hid; bf16_t* ctx;            // exchange buffers [rows][512] f32 x 2, [rows][2048] f32, [rows][512] bf16
+  unsigned* flags;                                          // [n_layers][n_streams][8] counters, zero at launch
+  unsigned* err;
+  int opt = 0;                                              // tuning: 1 = no L2 warm-up
+  unsigned long long* times = nullptr; int times_layer = 0;
+};
+size_t stream_dec_pack_bytes();
+void launch_stream_dec_pack(const bf16_t* w1, const bf16_t* w2, const bf16_t* wq, const bf16_t* wkv, const bf16_t* wo, bool full, void* dst, hipStream_t s);
+bool stream_dec_supported(int d, int d_ffn, int n_heads, int cap, int n_cur, int ktaps);
+void launch_stream_dec(const StreamDecArgs& a, hipStream_t s);
+
 // ---- Qwen3-ASR decode step as one persistent kernel (qwen_mega.hip): token embedding + every decoder layer, phases separated by a
 // chip-wide barrier; bf16 mode, <= 64 sequences. The final norm / lm_head / head kernels follow as ordinary launches.
 struct QwMegaLayer { const bf16_t *wqkv, *wo, *gate_up, *down; const float *qn, *kn; };

@@ -59,7 +59,7 @@ struct SvSession : asr_session {
   size_t h_out_cap = 0;
 
   ~SvSession() override {
-    for (DeviceBuffer* b : {&d_dft_split, &d_times, &d_flags, &d_ctplan, &d_mdev, &d_trow, &d_skws, &d_skcnt, &d_sta, &d_stb, &st_wpack, &st_layer_tab, &st_flags, &st_times, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
+    for (DeviceBuffer* b : {&d_dft_split, &d_times, &d_flags, &d_ctplan, &d_mdev, &d_trow, &d_skws, &d_skcnt, &d_sta, &d_stb, &st_wpack, &st_layer_tab, &st_flags, &st_times, &st_dpack, &st_dlayer_tab, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
                             &d_x0lo, &d_xalo, &d_xblo, &d_plan, &d_audio, &d_mel, &d_x0, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx, &d_mem, &d_ffn,
                             &d_amax_v, &d_amax_i, &d_ids, &d_tok, &d_num, &d_logits, &d_enc_lo, &d_ck, &d_cifa, &d_alpha, &d_dec, &d_x2,
                             &d_sa, &d_ffn32, &d_tplan})
@@ -79,11 +79,12 @@ struct SvSession : asr_session {
   int st_chunk = 0, st_B = 0, st_C = 0, st_en_cap = 0, st_de_cap = 0, st_max = 0, st_frames = 0;
   DeviceBuffer st_enk, st_env, st_dek, st_dev, st_defsmn, st_prev, st_cifh, st_cifa, st_enlen, st_delen, st_start, d_sqkv, d_skv;
   // streaming encoder layers 1 .. as one launch (stream_layers.hip): fragment-major weight copies, the device layer table, exchange counters (+ err)
-  DeviceBuffer st_wpack, st_layer_tab, st_flags, st_times;
+  DeviceBuffer st_wpack, st_layer_tab, st_flags, st_times, st_dpack, st_dlayer_tab;     // (st_d*: the decoder launch, stream_dec.hip)
+  bool st_dec_fused = false;
   int st_times_layer = -1;              // ASR_STREAM_TIMES=<layer>: phase clocks of that fused layer, printed to stderr after every step (tuning)
   bool st_fused = false;
   int st_opt = 0;                       // ASR_STREAM_OPT: tuning switches of the fused launch (kernels.h: StreamLayersArgs::opt)
-  int st_fused_env = 1;                 // ASR_STREAM_FUSED=0: every layer on the per-launch path
+  int st_fused_env = 2;                 // ASR_STREAM_FUSED: 0 = every layer on the per-launch path, 1 = encoder launch only, 2 = encoder and decoder launches
   void stream_init(int chunk, int look_back_encoder, int look_back_decoder, int max_streams);
   void stream_reset(int sid);
   template <typename T> void stream_step(const float* audio, int audio_mem, const int32_t* stream_ids, int n, int32_t* tok_out, int max_tokens,
@@ -892,7 +893,7 @@ void SvSession::stream_init(int chunk, int look_back_encoder, int look_back_deco
     const size_t pk = stream_layers_pack_bytes(), en_layer = (size_t)st_max * c.n_heads * st_en_cap * 128;
     st_wpack.reserve(pk * nl, stream);
     st_layer_tab.reserve(sizeof(StreamLayer) * nl, stream);
-    st_flags.reserve(((size_t)nl * st_max * 4 + 4) * 4, stream);
+    st_flags.reserve(((size_t)nl * st_max * 4 + 4 + (size_t)pdec.size() * st_max * 8) * 4, stream);       // encoder counters, err, decoder counters
     std::vector<StreamLayer> tab(nl);
     for (int i = 0; i < nl; ++i) {
       const SvBlock& b = blocks[i + 1];
@@ -903,6 +904,34 @@ void SvSession::stream_init(int chunk, int look_back_encoder, int look_back_deco
       tab[i].cache_v = st_env.as<bf16_t>() + (size_t)(i + 1) * en_layer;
     }
     HIP_CHECK(hipMemcpyAsync(st_layer_tab.ptr, tab.data(), sizeof(StreamLayer) * nl, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  // ... and so does the decoder (every block of it)
+  st_dec_fused = st_fused && st_fused_env >= 2 && !pdec.empty() &&
+                 stream_dec_supported(c.d_model, pcfg.d_dec_ffn, c.n_heads, st_de_cap, st_B + st_C, c.fsmn_kernel);
+  if (st_dec_fused) {
+    const int ndl = (int)pdec.size();
+    const size_t pk = stream_dec_pack_bytes(), de_layer = (size_t)st_max * c.n_heads * st_de_cap * 128, fs_layer = (size_t)st_max * (c.fsmn_kernel - 1) * c.d_model;
+    st_dpack.reserve(pk * ndl, stream);
+    st_dlayer_tab.reserve(sizeof(StreamDecLayer) * ndl, stream);
+    std::vector<StreamDecLayer> tab(ndl);
+    int li = 0;
+    for (int j = 0; j < ndl; ++j) {
+      const PfDecLayer& L = pdec[j];
+      unsigned char* dst = (unsigned char*)st_dpack.ptr + pk * j;
+      launch_stream_dec_pack((const bf16_t*)L.w1, (const bf16_t*)L.w2, (const bf16_t*)L.wq, (const bf16_t*)L.wkv, (const bf16_t*)L.wo, L.full, dst, stream);
+      StreamDecLayer& t = tab[j];
+      t = StreamDecLayer{};
+      t.wpack = dst; t.b1 = L.b1; t.b2 = L.b2; t.full = L.full ? 1 : 0;
+      if (L.full) {
+        t.n2_g = L.n2_g; t.n2_b = L.n2_b; t.wfsmn = L.wfsmn; t.bq = L.bq; t.bkv = L.bkv; t.bo = L.bo;
+        t.fsmn_hist = st_defsmn.as<float>() + (size_t)li * fs_layer;
+        t.cache_k = st_dek.as<bf16_t>() + (size_t)li * de_layer;
+        t.cache_v = st_dev.as<bf16_t>() + (size_t)li * de_layer;
+        ++li;
+      }
+    }
+    HIP_CHECK(hipMemcpyAsync(st_dlayer_tab.ptr, tab.data(), sizeof(StreamDecLayer) * ndl, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
   }
   stream_reset(-1);
@@ -1044,7 +1073,7 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
     if (fused && i == 1) {               // layers 1 .. n - 1: one launch, the stream's rows stay in xa
       ProfScope ps(prof, "stream_layers", stream);
       const int nl = c.n_blocks - 1;
-      HIP_CHECK(hipMemsetAsync(st_flags.ptr, 0, ((size_t)nl * n * 4 + 4) * 4, stream));
+      HIP_CHECK(hipMemsetAsync(st_flags.ptr, 0, ((size_t)nl * n * 4 + 4 + (size_t)pdec.size() * n * 8) * 4, stream));
       StreamLayersArgs la;
       la.plan = dp; la.n_streams = n; la.n_layers = nl; la.n_cur = n_cur; la.cap = st_en_cap; la.roll_rows = st_B; la.ktaps = c.fsmn_kernel;
       la.ln_eps = 1e-5f; la.cache_len = st_enlen.as<int32_t>(); la.layers = st_layer_tab.as<StreamLayer>();
@@ -1147,6 +1176,21 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
     gemm(g2);
   };
   int li = 0;
+  if (st_dec_fused && std::is_same<T, bf16_t>::value) {      // every decoder block in one launch (stream_dec.hip); streams without a fired frame skip it
+    ProfScope ps(prof, "stream_dec", stream);
+    StreamDecArgs da;
+    da.token_plan = tplan; da.n_streams = n; da.n_layers = (int)pdec.size(); da.n_cur = n_cur; da.cap = st_de_cap; da.ln_eps = 1e-5f;
+    da.cache_len = st_delen.as<int32_t>(); da.layers = st_dlayer_tab.as<StreamDecLayer>(); da.enc = (const bf16_t*)enc_lo;
+    da.dec = dec; da.x1 = x1; da.x2 = x2; da.hid = ffn32; da.ctx = (bf16_t*)ctx;
+    unsigned* fb = st_flags.as<unsigned>() + (size_t)(c.n_blocks - 1) * n * 4;
+    da.err = fb; da.flags = fb + 4; da.opt = st_opt >> 8;
+    if (st_times_layer <= -2) {
+      st_times.reserve((size_t)((n + 7) / 8) * 32 * 16 * 8, stream);
+      HIP_CHECK(hipMemsetAsync(st_times.ptr, 0, (size_t)((n + 7) / 8) * 32 * 16 * 8, stream));
+      da.times = st_times.as<unsigned long long>(); da.times_layer = -2 - st_times_layer;
+    }
+    launch_stream_dec(da, stream);
+  } else
   for (const PfDecLayer& L : pdec) {
     if (!L.full) { ffn_block(L, dec); continue; }
     ffn_block(L, x1);
@@ -1239,18 +1283,19 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
   HIP_CHECK(hipStreamSynchronize(stream));
   if (prof.enabled) prof.collect();
   // (histories of the layers in front of the one that gave up are rolled already: the step cannot be redone, the streams have to be reset)
-  if (fused_ran && st_times_layer >= 0) {               // tuning: mean phase intervals over the workgroups (100 MHz clock -> us)
+  if (fused_ran && (st_times_layer >= 0 || st_times_layer <= -2)) {               // tuning: mean phase intervals over the workgroups (100 MHz clock -> us)
     const int nwg = (n + 7) / 8 * 32;
     std::vector<unsigned long long> t((size_t)nwg * 16);
     HIP_CHECK(hipMemcpy(t.data(), st_times.ptr, t.size() * 8, hipMemcpyDeviceToHost));
-    double sum[13] = {}; int cnt = 0;
+    double sum[14] = {}; int cnt = 0;
+    const int last = st_times_layer >= 0 ? 12 : 13;
     for (int w = 0; w < nwg; ++w) {
       if (!t[(size_t)w * 16]) continue;
       ++cnt;
-      for (int k = 1; k <= 12; ++k) sum[k] += (double)(t[(size_t)w * 16 + k] - t[(size_t)w * 16 + k - 1]) * 0.01;
+      for (int k = 1; k <= last; ++k) sum[k] += (double)(t[(size_t)w * 16 + k] - t[(size_t)w * 16 + k - 1]) * 0.01;
     }
-    fprintf(stderr, "stream_layers layer %d (us, mean of %d workgroups):", st_times_layer, cnt);
-    for (int k = 1; k <= 12; ++k) fprintf(stderr, " %.2f", sum[k] / std::max(cnt, 1));
+    fprintf(stderr, "%s layer %d (us, mean of %d workgroups):", st_times_layer >= 0 ? "stream_layers" : "stream_dec", st_times_layer >= 0 ? st_times_layer : -2 - st_times_layer, cnt);
+    for (int k = 1; k <= last; ++k) fprintf(stderr, " %.2f", sum[k] / std::max(cnt, 1));
     fprintf(stderr, "\n");
   }
   ASR_REQUIRE(*h_err == 0, "streaming: a workgroup of the fused encoder launch gave up waiting for its cluster; the step's results are invalid, reset its streams");

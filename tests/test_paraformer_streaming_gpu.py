@@ -102,3 +102,50 @@ def test_stream_transcriber_follows_the_reference_host_loop():
     padded = ps.pad_to_chunks(np.ones((1, 1, chunk + 10), np.float32), chunk, np.random.default_rng(0))
     assert padded.shape[-1] == 2 * chunk and np.all(padded[0, 0, :chunk + 10] == 1) and padded[0, 0, chunk + 10:].std() > 0.5
     assert ps.pad_to_chunks(np.ones((1, 1, 2 * chunk), np.float32), chunk).shape[-1] == 2 * chunk
+
+
+def test_fused_launches_vs_per_launch_path(monkeypatch):
+    """bf16 sessions run encoder layers 1.. and every decoder block of a chunk step as ONE launch each (csrc/stream_layers.hip, stream_dec.hip: clusters of four
+    workgroups per stream). Same rounding points as the per-launch path (ASR_STREAM_FUSED=0), different accumulation order and bf16 attention weights: 11 streams
+    (not a multiple of the 8 clusters a group holds) over 6 chunks, a subset step, a reset in between -- encoder rows, fired counts, logits of the fired rows and
+    tokens of the two paths side by side, and the launch names of the fused session."""
+    g = load_golden("paraformer_streaming_large")
+    cfg, ck = streaming_setup(g)
+    chunk, S, n_chunks = int(g["chunk"]), 11, 6
+    audio = [kaldi_audio(5100 + i, n_chunks * chunk) for i in range(S)]
+    monkeypatch.setenv("ASR_STREAM_FUSED", "0")
+    plain = sub("engine").ParaformerStreamSession(cfg, ck, precision=BF16, chunk=chunk, max_streams=S)
+    monkeypatch.delenv("ASR_STREAM_FUSED")
+    fused = sub("engine").ParaformerStreamSession(cfg, ck, precision=BF16, chunk=chunk, max_streams=S)
+    plain.taps(True)
+    fused.taps(True)
+    same = total = 0
+    worst_enc = worst_logit = 0.0
+    for k in range(n_chunks):
+        sids = list(range(S)) if k != 3 else [9, 2, 4, 0, 7]                 # one step advances a subset only (slots != stream ids)
+        if k == 4:
+            plain.reset(2)
+            fused.reset(2)
+        chunks = np.stack([audio[s][k * chunk:(k + 1) * chunk] for s in sids])
+        a, b = plain.step(chunks, sids), fused.step(chunks, sids)
+        ea, eb = plain.tap("enc_out"), fused.tap("enc_out")
+        la, lb = plain.tap("logits"), fused.tap("logits")
+        for slot in range(len(sids)):
+            worst_enc = max(worst_enc, float(np.abs(ea[16 * slot:16 * slot + 13] - eb[16 * slot:16 * slot + 13]).max()))
+            total += 1
+            if a[slot].size == b[slot].size:
+                n = a[slot].size
+                if n:
+                    worst_logit = max(worst_logit, float(np.abs(la[16 * slot:16 * slot + n] - lb[16 * slot:16 * slot + n]).max()))
+                same += int(np.array_equal(a[slot], b[slot]))
+    print("fused vs per-launch: enc_out", worst_enc, "logits", worst_logit, "equal token lists", same, "/", total)
+    assert worst_enc < 0.05 and worst_logit < 0.1                             # (measured 0.024 / 0.040)
+    assert same / total >= 0.9                                                # bf16 noise may move a fire across a chunk boundary or flip a near-tie
+    fused.taps(False)
+    fused.profile(True)
+    fused.profile_reset()
+    fused.step(np.stack([audio[s][:chunk] for s in range(S)]), list(range(S)))
+    names = fused.profile_read()
+    fused.profile(False)
+    assert names["stream_layers"]["launches"] == 1 and names["stream_dec"]["launches"] == 1
+    assert sum(v["launches"] for v in names.values()) <= 24                   # (520 launches per step on the per-launch path)

@@ -51,7 +51,7 @@ __device__ __forceinline__ void consume(unsigned* flag, unsigned* err) {
 // line, a wave instruction covers 8 KB -- while it waits for its cluster; the fills run under the wait and the phase's own requests hit the L2.
 // The value is consumed only behind the next publish (whose vmcnt(0) has drained it anyway).
 __device__ __forceinline__ unsigned warm(const unsigned char* base, int n_lines, int wg, int n_wg, int tid) {
-  const int per = (n_lines + n_wg - 1) / n_wg;
+  const int per = min((n_lines + n_wg - 1) / n_wg, 2 * (NT - 64));      // (few streams: two touches per thread at most -- the head of the region -- rather than a long detour)
   unsigned t = 0;
   for (int i = tid - 64; i < per; i += NT - 64) {           // (wave 0 polls the counter: nothing of its own queues in front of the poll)
     if (i < 0) break;

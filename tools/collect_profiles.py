@@ -39,3 +39,15 @@ p = os.path.join(src, "pp_gemm_probe.txt")
 if os.path.isfile(p):
     shutil.copy(p, f"profiles/{rnd}_pp_gemm_probe.txt")
 print(sorted(f for f in os.listdir("profiles") if f.startswith(rnd)))
+
+# round-4 streaming evidence (tools/profile_stream.sh -> gpurun_out/stream)
+ssrc = "gpurun_out/stream"
+if os.path.isdir(ssrc):
+    for name, out in (("bench_fused.json", "bench_paraformer_streaming_n1.json"), ("bench_perlaunch.json", "bench_paraformer_streaming_perlaunch_n1.json"),
+                      ("bench_encoder_only.json", "bench_paraformer_streaming_encoder_only_n1.json"), ("stream_phase_clock.txt", "stream_phase_clock.txt")):
+        p = os.path.join(ssrc, name)
+        if os.path.isfile(p) and os.path.getsize(p) > 0:
+            shutil.copy(p, f"profiles/{rnd}_{out}")
+    fs = glob.glob(os.path.join(ssrc, "stats", "*", "*kernel_stats.csv"))
+    if fs:
+        shutil.copy(sorted(fs, key=os.path.getmtime)[-1], f"profiles/{rnd}_paraformer_streaming_kernel_stats.csv")

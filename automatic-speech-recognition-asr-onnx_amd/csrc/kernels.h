@@ -341,6 +341,26 @@ void launch_stream_layers_pack(const bf16_t* wqkv, const bf16_t* wout, const bf1
 bool stream_layers_supported(int d, int d_ffn, int n_heads, int cap, int n_cur, int ktaps);
 void launch_stream_layers(const StreamLayersArgs& a, hipStream_t s);
 
+// ---- SANM blocks of a SMALL batch of <= 144-row windows, a run of blocks as one launch (sanm_tiles.hip): a workgroup per (16-row tile, head), the streaming
+// encoder's weight images (launch_stream_layers_pack) and layer table entries (cache pointers unused)
+struct SanmTilesArgs {
+  const UttPlan* plan;                                      // per window: T, row_off
+  const int32_t* tile_win; const int32_t* tile_idx;         // per tile cluster: its window, its tile inside the window
+  int n_tiles, n_windows, n_layers;
+  float ln_eps;
+  const StreamLayer* layers;                                // device table
+  float* x;                                                 // [rows][512] residual stream, in place
+  float* xb; bf16_t* ctx; bf16_t* hid;                      // exchange buffers of a tile's four heads: [rows][512] f32, [rows][512], [rows][2048]
+  bf16_t* kv;                                               // exchange buffer of a head's tiles: [rows][k | v][512]
+  unsigned* flags; int flag_stride;                         // per layer: [n_tiles][4] + [n_windows][4] counters, zero at launch; flag_stride = words per layer
+  unsigned* err;
+  int opt = 0;                                              // tuning: 1 = no L2 warm-up
+  unsigned long long* times = nullptr; int times_layer = 0;
+};
+bool sanm_tiles_supported(int max_T, int d, int d_ffn, int n_heads, int d_head, int ktaps);
+int sanm_tiles_max_tiles();
+void launch_sanm_tiles(const SanmTilesArgs& a, hipStream_t s);
+
 // ---- Paraformer online decoder layers of one chunk step as ONE launch (stream_dec.hip): the same clusters; a stream without a fired token leaves at once
 struct StreamDecLayer {
   const unsigned char* wpack;                               // launch_stream_dec_pack of this layer's w1, w2, wq, wkv, wo

@@ -59,7 +59,7 @@ struct SvSession : asr_session {
   size_t h_out_cap = 0;
 
   ~SvSession() override {
-    for (DeviceBuffer* b : {&d_dft_split, &d_times, &d_flags, &d_ctplan, &d_mdev, &d_trow, &d_skws, &d_skcnt, &d_sta, &d_stb, &st_wpack, &st_layer_tab, &st_flags, &st_times, &st_dpack, &st_dlayer_tab, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
+    for (DeviceBuffer* b : {&d_dft_split, &d_times, &d_flags, &d_tpack, &d_tlayer_tab, &d_tkv, &d_ctplan, &d_mdev, &d_trow, &d_skws, &d_skcnt, &d_sta, &d_stb, &st_wpack, &st_layer_tab, &st_flags, &st_times, &st_dpack, &st_dlayer_tab, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
                             &d_x0lo, &d_xalo, &d_xblo, &d_plan, &d_audio, &d_mel, &d_x0, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx, &d_mem, &d_ffn,
                             &d_amax_v, &d_amax_i, &d_ids, &d_tok, &d_num, &d_logits, &d_enc_lo, &d_ck, &d_cifa, &d_alpha, &d_dec, &d_x2,
                             &d_sa, &d_ffn32, &d_tplan})
@@ -99,6 +99,11 @@ struct SvSession : asr_session {
   bool block_persist = true;    // ASR_SANM_BLOCK_PERSIST=0: the 8-wave kernel is launched once per block instead of once per run of blocks
   DeviceBuffer d_layer_tab;     // SanmBlockLayer[n_blocks]: the per-block constants a launch of the 8-wave kernel walks
   int block_v = 8;              // ASR_SANM_BLOCK_V=1: the round-2 form of the block kernel (12 waves, csrc/sanm_block.hip); default: the 8-wave form (csrc/sanm_block8.hip)
+  // small batches: a workgroup per (16-row tile, head), csrc/sanm_tiles.hip (ASR_SANM_TILES=0: four launches per block as before)
+  bool use_tiles = true, tpack_ready = false;
+  int tiles_opt = 0, tiles_dbg = -1;       // ASR_SANM_TILES_OPT (SanmTilesArgs::opt), ASR_SANM_TILES_DBG=<block>: phase clock of that block on stderr
+  DeviceBuffer d_tpack, d_tlayer_tab, d_tkv;
+  void ensure_tiles_pack();
   DeviceBuffer d_wpack;         // 8-wave form: fragment-major copy of every 512 -> 512 block's weights, made once per session (ensure_block_pack)
   bool wpack_ready = false;
   void ensure_block_pack();
@@ -113,6 +118,9 @@ struct SvSession : asr_session {
     if (const char* e = getenv("ASR_FBANK_SPLIT")) use_fbank_split = !(e[0] == '0');
     if (const char* e = getenv("ASR_SANM_BLOCK_V")) block_v = (e[0] == '1') ? 1 : 8;
     if (const char* e = getenv("ASR_SANM_BLOCK8_OPT")) block8_opt = atoi(e);
+    if (const char* e = getenv("ASR_SANM_TILES")) use_tiles = !(e[0] == '0');
+    if (const char* e = getenv("ASR_SANM_TILES_OPT")) tiles_opt = atoi(e);
+    if (const char* e = getenv("ASR_SANM_TILES_DBG")) tiles_dbg = atoi(e);
     if (const char* e = getenv("ASR_SANM_BLOCK_PERSIST")) block_persist = !(e[0] == '0');
     if (const char* e = getenv("ASR_SANM_BLOCK_SCATTER")) block_scatter = e[0] == '1';
     if (const char* e = getenv("ASR_SANM_BLOCK_FAULT")) block_fault = e[0] == '1';
@@ -245,6 +253,9 @@ struct SvRunCtx {
   const float* d_aud;
   const UttPlan* dp;
   const int32_t *d_blk_utt, *d_blk_f0, *d_qb_utt, *d_qb_q0, *d_row_utt;
+  const int32_t *d_tile_win = nullptr, *d_tile_idx = nullptr;    // small batches (sanm_tiles.hip): per 16-row tile its window / its index inside the window
+  int n_tiles = 0;
+  bool tiles = false;
 };
 
 // fragment-major weight copies for the 8-wave block kernel: one pass over the arena's bf16 matrices per session, outside any graph capture
@@ -272,6 +283,26 @@ void SvSession::copy_block_status(const SvRunCtx& r) {
   const size_t flag_words = (size_t)cfg.n_blocks * r.batch * 4;
   HIP_CHECK(hipMemcpyAsync((unsigned char*)h_out + (size_t)r.batch * r.max_tokens * 4 + (size_t)r.batch * 4, d_flags.as<unsigned>() + flag_words, 4,
                            hipMemcpyDeviceToHost, stream));
+}
+
+// the same for the tile kernel of small batches: the streaming encoder's image format and table entries
+void SvSession::ensure_tiles_pack() {
+  if (tpack_ready) return;
+  const size_t per = stream_layers_pack_bytes();
+  d_tpack.reserve(per * cfg.n_blocks, stream);
+  std::vector<StreamLayer> tab(cfg.n_blocks);
+  for (int i = 0; i < cfg.n_blocks; ++i) {
+    const SvBlock& b = blocks[i];
+    tab[i] = StreamLayer{};
+    if (b.in_size != cfg.d_model) continue;
+    unsigned char* dst = (unsigned char*)d_tpack.ptr + per * i;
+    launch_stream_layers_pack((const bf16_t*)b.wqkv, (const bf16_t*)b.wout, (const bf16_t*)b.w1, (const bf16_t*)b.w2, dst, stream);
+    tab[i].wpack = dst; tab[i].bqkv = b.bqkv; tab[i].wfsmn = b.wfsmn; tab[i].bfsmn = b.bfsmn; tab[i].b1 = b.b1; tab[i].b2 = b.b2;
+  }
+  d_tlayer_tab.reserve(tab.size() * sizeof(StreamLayer), stream);
+  HIP_CHECK(hipMemcpyAsync(d_tlayer_tab.ptr, tab.data(), tab.size() * sizeof(StreamLayer), hipMemcpyHostToDevice, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  tpack_ready = true;
 }
 
 template <typename T>
@@ -330,7 +361,9 @@ void SvSession::enqueue(const SvRunCtx& r) {
           r.batch >= block_min_utts &&          // four workgroups per window: a small batch leaves most CUs idle (one window: 4 of 256), the tiled GEMMs do not
           sanm_block_supported(r.max_T, c.d_head, c.n_heads, d, dff, c.fsmn_kernel);
   const size_t flag_words = (size_t)c.n_blocks * r.batch * 4;
-  HIP_CHECK(hipMemsetAsync(d_flags.ptr, 0, (flag_words + 4 + (size_t)c.n_blocks * r.batch) * 4, stream));      // per (block, window, exchange) counters + the error word + per (launch, window) placement words
+  const size_t tile_flag0 = flag_words + 4 + (size_t)c.n_blocks * r.batch, tile_flag_stride = ((size_t)r.n_tiles + r.batch) * 4;       // the tile kernel's counters: per block [tile][4] + [window][4]
+  const bool tiles = r.tiles && block_cooldown == 0;
+  HIP_CHECK(hipMemsetAsync(d_flags.ptr, 0, (tile_flag0 + (tiles ? (size_t)c.n_blocks * tile_flag_stride : 0)) * 4, stream));      // per (block, window, exchange) counters + the error word + per (launch, window) placement words
   const float* x_in = d_x0.as<float>();
   const bf16_t* x_in_lo = x0lo;
   const float2* st_in = nullptr;            // statistics of x_in_lo's rows when its producer wrote them
@@ -388,6 +421,32 @@ void SvSession::enqueue(const SvRunCtx& r) {
         if (i == c.n_main - 1 && !paraformer) {
           ProfScope ps2(prof, "layernorm", stream);
           launch_layernorm<bf16_t>(xa, d, rows, d, after_g, after_b, 1e-5f, xalo, d, d, stream); st_in = nullptr;
+          launch_layernorm<float>(xa, d, rows, d, after_g, after_b, 1e-5f, xa, d, d, stream);
+        }
+        continue;
+      }
+    }
+    if constexpr (sizeof(T) == 2) {
+      if (tiles && !blk && b.in_size == d && x_in == xa) {   // small batch: every block up to the next stand-alone LayerNorm in one launch of (tile, head) workgroups
+        const int run_end = (!paraformer && i < c.n_main) ? c.n_main : c.n_blocks;
+        {
+          ProfScope ps(prof, "sanm_tiles", stream);
+          SanmTilesArgs ta;
+          ta.plan = r.dp; ta.tile_win = r.d_tile_win; ta.tile_idx = r.d_tile_idx; ta.n_tiles = r.n_tiles; ta.n_windows = r.batch; ta.n_layers = run_end - i;
+          ta.ln_eps = 1e-5f; ta.layers = d_tlayer_tab.as<StreamLayer>() + i;
+          ta.x = xa; ta.xb = xb; ta.ctx = (bf16_t*)ctx; ta.hid = (bf16_t*)ffn; ta.kv = d_tkv.as<bf16_t>();
+          ta.flags = d_flags.as<unsigned>() + tile_flag0 + (size_t)i * tile_flag_stride; ta.flag_stride = (int)tile_flag_stride;
+          ta.err = d_flags.as<unsigned>() + flag_words; ta.opt = tiles_opt;
+          if (tiles_dbg >= i && tiles_dbg < run_end) {
+            d_times.reserve(256 * 16 * 8, stream); HIP_CHECK(hipMemsetAsync(d_times.ptr, 0, 256 * 16 * 8, stream)); ta.times = d_times.as<unsigned long long>();
+            ta.times_layer = tiles_dbg - i;
+          }
+          launch_sanm_tiles(ta, stream);
+        }
+        i = run_end - 1;
+        st_in = nullptr;
+        if (i == c.n_main - 1 && !paraformer) {
+          ProfScope ps2(prof, "layernorm", stream);
           launch_layernorm<float>(xa, d, rows, d, after_g, after_b, 1e-5f, xa, d, d, stream);
         }
         continue;
@@ -670,7 +729,8 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   const int64_t total_samples = offs[batch] - base0;
 
   // plan blob: [UttPlan x B][blk_utt n_fb][blk_f0 n_fb][qb_utt n_qb][qb_q0 n_qb][row_utt Mpad]
-  const size_t plan_bytes = sizeof(UttPlan) * batch + sizeof(int32_t) * (2 * (size_t)n_fb + 2 * (size_t)n_qb + Mpad);
+  const int n_tiles = rows / 16;
+  const size_t plan_bytes = sizeof(UttPlan) * batch + sizeof(int32_t) * (2 * (size_t)n_fb + 2 * (size_t)n_qb + Mpad + 2 * (size_t)n_tiles);
   if (plan_bytes > h_plan_cap) {
     if (h_plan) HIP_CHECK(hipHostFree(h_plan));
     HIP_CHECK(hipHostMalloc(&h_plan, plan_bytes * 2, hipHostMallocDefault));
@@ -693,7 +753,17 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
       for (int t = 0; t < r16; ++t) row_utt[plan[b].row_off + t] = b;
     }
     for (int t = rows; t < Mpad; ++t) row_utt[t] = -1;
+    int32_t* tile_win = row_utt + Mpad;
+    int32_t* tile_idx = tile_win + n_tiles;
+    int ti = 0;
+    for (int b = 0; b < batch; ++b)
+      for (int t = 0; t < round_up(plan[b].T, 16) / 16; ++t) { tile_win[ti] = b; tile_idx[ti++] = t; }
   }
+  // small batches take the tile kernel (bf16, LayerNorm-folded arenas of the standard geometry, every workgroup resident at once)
+  const bool tiles = sizeof(T) == 2 && use_tiles && c.n_blocks > 1 && blocks[c.n_blocks - 1].cqkv && blocks[c.n_blocks - 1].c1 &&
+                     !(use_block && batch >= block_min_utts) && n_tiles <= sanm_tiles_max_tiles() &&
+                     sanm_tiles_supported(max_T, d, dff, c.n_heads, c.d_head, c.fsmn_kernel);
+  mix((uint64_t)tiles);
   // ---- workspace (grow-only; any re-allocation invalidates the captured graph) -----------------
   const size_t eT = sizeof(T);
   auto grow = [&](DeviceBuffer& buf, size_t bytes) { void* before = buf.ptr; buf.reserve(bytes, stream); if (buf.ptr != before) ++ws_epoch; };
@@ -720,7 +790,8 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   grow(d_amax_v, (size_t)Mpad * n_slabs * 4);
   grow(d_amax_i, (size_t)Mpad * n_slabs * 4);
   grow(d_ids, (size_t)Mpad * 4);
-  grow(d_flags, ((size_t)c.n_blocks * batch * 5 + 4) * 4);          // [block][window][4] exchange counters + error word (4) + [block][window] placement words
+  grow(d_flags, ((size_t)c.n_blocks * batch * 5 + 4 + (tiles ? (size_t)c.n_blocks * (n_tiles + batch) * 4 : 0)) * 4);
+  if (tiles) grow(d_tkv, (size_t)Mpad * 2 * d * 2);          // [block][window][4] exchange counters + error word (4) + [block][window] placement words
   grow(d_tok, (size_t)batch * max_tokens * 4);
   grow(d_num, (size_t)batch * 4);
   if (taps_enabled) grow(d_logits, (size_t)Mpad * vpad * 4);
@@ -758,17 +829,21 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   r.batch = batch; r.rows = rows; r.Mpad = Mpad; r.frames = frames; r.n_fb = n_fb; r.n_qb = n_qb; r.max_T = max_T;
   r.max_tokens = max_tokens; r.att_qt = att_qt; r.att_nw = att_nw;
   r.dp = d_plan.as<UttPlan>();
+  r.n_tiles = n_tiles; r.tiles = tiles;
   r.d_blk_utt = (const int32_t*)((unsigned char*)d_plan.ptr + sizeof(UttPlan) * batch);
   r.d_blk_f0 = r.d_blk_utt + n_fb;
   r.d_qb_utt = r.d_blk_f0 + n_fb;
   r.d_qb_q0 = r.d_qb_utt + n_qb;
   r.d_row_utt = r.d_qb_q0 + n_qb;
+  r.d_tile_win = r.d_row_utt + Mpad;
+  r.d_tile_idx = r.d_tile_win + n_tiles;
   mix((uint64_t)batch); mix((uint64_t)max_tokens); mix((uint64_t)(uintptr_t)r.d_aud); mix(ws_epoch); mix((uint64_t)(uintptr_t)stream);
   mix((uint64_t)(block_cooldown > 0));        // a session cooling down after a cluster give-up replays the four-launch capture, not the block one
 
   if (sizeof(T) == 2 && use_block && block_v == 8 && cfg.n_blocks > 1 && blocks[cfg.n_blocks - 1].cqkv && blocks[cfg.n_blocks - 1].c1 && batch >= block_min_utts &&
       sanm_block_supported(max_T, cfg.d_head, cfg.n_heads, cfg.d_model, cfg.d_ffn, cfg.fsmn_kernel))
     ensure_block_pack();
+  if (tiles) ensure_tiles_pack();
   // ---- launch: eager the first time a geometry is seen (allocations settle), then capture once and replay ----
   // 570 launches per forward are host-launch-bound when issued eagerly (~13 us each); replay costs ~1 us per node.
   const bool graphable = use_graph && !taps_enabled && !prof.enabled;
@@ -796,6 +871,19 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   }
   HIP_CHECK(hipStreamSynchronize(stream));
   if (prof.enabled) prof.collect();
+  if (tiles_dbg >= 0 && tiles && d_times.ptr) {          // tuning: mean phase intervals of one block of the tile kernel over its workgroups (100 MHz clock -> us)
+    std::vector<unsigned long long> t(256 * 16);
+    HIP_CHECK(hipMemcpy(t.data(), d_times.ptr, t.size() * 8, hipMemcpyDeviceToHost));
+    double sum[14] = {}; int cnt = 0;
+    for (int w = 0; w < 256; ++w) {
+      if (!t[(size_t)w * 16]) continue;
+      ++cnt;
+      for (int k = 1; k <= 13; ++k) sum[k] += (double)(t[(size_t)w * 16 + k] - t[(size_t)w * 16 + k - 1]) * 0.01;
+    }
+    fprintf(stderr, "sanm_tiles block %d (us, mean of %d workgroups):", tiles_dbg, cnt);
+    for (int k = 1; k <= 13; ++k) fprintf(stderr, " %.2f", sum[k] / std::max(cnt, 1));
+    fprintf(stderr, "\n");
+  }
   if (block_dbg >= 0 && d_times.ptr) {
     std::vector<unsigned long long> t(256 * 16);
     HIP_CHECK(hipMemcpy(t.data(), d_times.ptr, t.size() * 8, hipMemcpyDeviceToHost));
@@ -836,7 +924,7 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
     // path (no cross-workgroup waits), still on the GPU; the error is raised only if that fails too.
     unsigned blk_err = 0;
     memcpy(&blk_err, (unsigned char*)h_out + (size_t)batch * max_tokens * 4 + (size_t)batch * 4, 4);
-    if (blk_err != 0 && use_block) {
+    if (blk_err != 0 && (use_block || use_tiles)) {
       if (block_giveups++ == 0)
         fprintf(stderr, "[asr_mi355x] sanm_block: a workgroup gave up waiting for its cluster; the batch is redone on the four-launch path\n");
       block_cooldown = 16;                       // this batch and the next ones stay on the four-launch path

@@ -31,11 +31,11 @@ __device__ __forceinline__ void publish(unsigned* flag) {
   lds_barrier();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void consume(unsigned* flag, unsigned* err) {
+__device__ __forceinline__ void consume(unsigned* flag, unsigned* err, unsigned need = (unsigned)NH) {
   if (threadIdx.x == 0) {
     unsigned spins = 0;
     const u64 t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)NH) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 63u) == 0u) {
         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;                  // somebody gave up: the launch is void

@@ -327,6 +327,54 @@ def test_block_kernel_equals_separate_launches_ragged(monkeypatch, scatter):
     assert np.array_equal(out["1"][2][ra:ra + Ta], out["1"][2][rb:rb + Ta])
 
 
+def test_tile_kernel_of_small_batches_equals_separate_launches(monkeypatch):
+    """Batches below the block kernel's threshold run every block behind block 0 as (16-row tile, head) workgroups, a run of blocks per launch
+    (csrc/sanm_tiles.hip): a ragged batch of six windows (9, 3, 1, 1, 9 and 5 tiles -- 137-row windows next to a 5-row one, odd and even tile counts) and
+    a single window, against the four-launch path (ASR_SANM_TILES=0) and, for the single window, the f32 oracle's tokens' frames."""
+    cfg, ck = sensevoice_setup("sensevoice_small")
+    eng = sub("engine")
+    lens = [128000, 38880, 7777, 400, 128000, 64000]
+    audios = [kaldi_audio(700 + i, n) for i, n in enumerate(lens)]
+    audios[4] = audios[0].copy()
+    langs = [i % 7 for i in range(len(lens))]
+    langs[4] = langs[0]
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ASR_SANM_TILES", flag)
+        sess = eng.SenseVoiceSession.from_checkpoint(cfg, ck, precision=BF16)
+        sess.taps(True)
+        toks = sess.run(audios, langs)
+        b0, lg = sess.tap("block0"), sess.tap("logits")
+        one = sess.run(audios[:1], langs[:1])
+        lg1 = sess.tap("logits")
+        sess.taps(False)
+        t2 = sess.run(audios, langs)                      # eager again, then the captured graph
+        t3 = sess.run(audios, langs)
+        for x, y, z in zip(toks, t2, t3):
+            assert np.array_equal(x, y) and np.array_equal(y, z)
+        sess.profile(True)
+        sess.profile_reset()
+        sess.run(audios, langs)
+        out[flag] = (toks, b0, lg, set(sess.profile_read()), one, lg1)
+    assert "sanm_tiles" in out["1"][3] and "sanm_tiles" not in out["0"][3] and "sanm_block" not in out["1"][3]
+    rows = sess.utterance_rows(lens)
+    same = total = 0
+    worst = 0.0
+    for (r0, T) in rows:
+        assert np.array_equal(out["1"][1][r0:r0 + T], out["0"][1][r0:r0 + T])                # block 0 takes the separate launches either way
+        worst = max(worst, float(np.abs(out["1"][2][r0:r0 + T] - out["0"][2][r0:r0 + T]).max()))
+        same += int((out["1"][2][r0:r0 + T].argmax(1) == out["0"][2][r0:r0 + T].argmax(1)).sum())
+        total += T
+    T0 = rows[0][1]
+    worst1 = float(np.abs(out["1"][5][:T0] - out["0"][5][:T0]).max())
+    print("tiles vs four launches: logits", worst, "single window", worst1, "frame arg-max agreement", same / total)
+    assert worst < 0.12 and worst1 < 0.12                                                      # logits after 69 blocks, both bf16
+    assert same / total > 0.97
+    (ra, Ta), (rb, _) = rows[0], rows[4]
+    assert np.array_equal(out["1"][2][ra:ra + Ta], out["1"][2][rb:rb + Ta])                  # a window's result does not depend on its neighbours
+    assert np.abs(out["1"][5][:T0] - out["1"][2][ra:ra + Ta]).max() < 0.05                     # ... nor, beyond the other kernels' batch-size dispatch (block 0, CTC), on the batch it came in
+
+
 def test_split_operand_dft_of_bf16_sessions_matches_the_golden_mel(monkeypatch):
     """bf16 sessions run the front-end's DFT on the bf16 matrix pipe with split operands (audio = hi + lo, basis = hi + mid + lo,
     csrc/kernels.hip: fbank_split_kernel). Its log-mel must meet the SAME 2e-4 bar against the reference-minted golden as the exact-f32

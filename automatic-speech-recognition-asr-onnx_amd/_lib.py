@@ -79,6 +79,7 @@ SIGNATURES = {
     "asr_qwen_prefill": (_i, [_vp, _vp, _i, _lp, _i, _ip, _ip, _ip, _ip, _ip, _fp, _ip]),
     "asr_qwen_decode": (_i, [_vp, _ip, _ip, _fp]),
     "asr_qwen_generate": (_i, [_vp, _i, _ip, _i, _ip, _ip]),
+    "asr_qwen_kv_stats": (_i, [_vp, _ip]),
     "asr_qwen_beam_search": (_i, [_vp, _i, _i, _ip, _i, _ip, _ip, _fp]),
     "asr_qwen_set_penalty": (_i, [_vp, C.c_float, _i]),
     "asr_qwen_track_history": (_i, [_vp, _i]),

@@ -351,7 +351,7 @@ struct SanmTilesArgs {
   const StreamLayer* layers;                                // device table
   float* x;                                                 // [rows][512] residual stream, in place
   float* xb; bf16_t* ctx; bf16_t* hid;                      // exchange buffers of a tile's four heads: [rows][512] f32, [rows][512], [rows][2048]
-  bf16_t* kv;                                               // exchange buffer of a head's tiles: [rows][k | v][512]
+  bf16_t* kv; size_t kv_parity_stride;                      // exchange buffer of a head's tiles: [block parity][rows][k | v][512], elements between the two
   unsigned* flags; int flag_stride;                         // per layer: [n_tiles][4] + [n_windows][4] counters, zero at launch; flag_stride = words per layer
   unsigned* err;
   int opt = 0;                                              // tuning: 1 = no L2 warm-up

@@ -145,6 +145,18 @@ __global__ __launch_bounds__(256) void qw_rmsnorm_kernel(const float* __restrict
   }
 }
 
+// Where position s of (sequence b, kv head) lives. Two layouts of a layer's cache:
+//   extents (table == nullptr): [seq][kv head][S_max][128] -- beam-search hypothesis rows, the persistent decode kernel, ASR_QWEN_KV_PAGED=0;
+//   pages (the default): 16 positions per page behind a block table [seq][pps] of page ids, one pool for all layers laid out page-major
+//   [page][layer][kv head][16][128] (`base` carries the layer's offset, page_stride the elements between consecutive pages), so a sequence holds
+//   pages for the positions it has, not for max_seq_len, and a finished sequence's pages go back to the free list (host: QwSession::kv_*).
+struct KvAddr { const int32_t* table; int pps; size_t page_stride; int S_max; };
+template <typename T>
+__device__ __forceinline__ T* kv_row(T* base, const KvAddr& a, int b, int kvh, int n_kv, int s) {
+  if (a.table) return base + (size_t)a.table[(size_t)b * a.pps + (s >> 4)] * a.page_stride + ((size_t)kvh * 16 + (s & 15)) * 128;
+  return base + (((size_t)b * n_kv + kvh) * a.S_max + s) * 128;
+}
+
 // per-head RMSNorm of q and k (weight * d^-1/4 folded), RoPE (half-split convention, position = hist + t), then q -> operand
 // buffer, k / v -> the KV cache [layer-local base][seq][kv head][S][128] at that position (:1283-1309). One wave per (row, head).
 template <typename T>
@@ -152,7 +164,7 @@ __global__ __launch_bounds__(256) void qw_qk_rope_kernel(const float* __restrict
                                                          const float* __restrict__ kn, const float* __restrict__ rope, float eps,
                                                          const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_t,
                                                          const int32_t* __restrict__ hist, int rows, T* __restrict__ q_out, T* __restrict__ kc,
-                                                         T* __restrict__ vc, int S_max, T* __restrict__ k_rows) {
+                                                         T* __restrict__ vc, KvAddr ka, T* __restrict__ k_rows) {
   constexpr int HD = 128;
   const int heads = n_heads + 2 * n_kv;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -164,7 +176,7 @@ __global__ __launch_bounds__(256) void qw_qk_rope_kernel(const float* __restrict
   const float* src = qkv + (size_t)row * heads * HD + hh * HD;
   const float x0 = src[lane], x1 = src[lane + 64];              // the two rotary halves of this lane's pair
   if (hh >= n_heads + n_kv) {                                  // v: cached as is
-    T* dst = vc + (((size_t)b * n_kv + (hh - n_heads - n_kv)) * S_max + pos) * HD;
+    T* dst = kv_row(vc, ka, b, hh - n_heads - n_kv, n_kv, pos);
     Elem<T>::store(dst + lane, x0);
     Elem<T>::store(dst + lane + 64, x1);
     return;
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(256) void qw_qk_rope_kernel(const float* __restrict
   const float cs = rope[(size_t)pos * HD + lane], sn = rope[(size_t)pos * HD + 64 + lane];
   const float y0 = a0 * cs - a1 * sn, y1 = a1 * cs + a0 * sn;
   T* dst = hh < n_heads ? q_out + (size_t)row * n_heads * HD + hh * HD
-                        : kc + (((size_t)b * n_kv + (hh - n_heads)) * S_max + pos) * HD;
+                        : kv_row(kc, ka, b, hh - n_heads, n_kv, pos);
   Elem<T>::store(dst + lane, y0);
   Elem<T>::store(dst + lane + 64, y1);
   if (k_rows && hh >= n_heads) {                         // row-major copy of the new keys for the prefill attention kernel
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(256) void qw_qk_rope_kernel(const float* __restrict
 // causal GQA attention over the cache: workgroup = (sequence, q head), 128 threads; query t of the sequence sees keys [0, hist + t]
 template <typename T>
 __global__ __launch_bounds__(128) void qw_attn_kernel(const T* __restrict__ q, int n_heads, int n_kv, const T* __restrict__ kc,
-                                                      const T* __restrict__ vc, int S_max, const UttPlan* __restrict__ plan,
+                                                      const T* __restrict__ vc, KvAddr ka, const UttPlan* __restrict__ plan,
                                                       const int32_t* __restrict__ hist, T* __restrict__ ctx) {
   constexpr int HD = 128;
   extern __shared__ float qw_sc[];                       // [S_max] scores / probabilities
@@ -197,8 +209,6 @@ __global__ __launch_bounds__(128) void qw_attn_kernel(const T* __restrict__ q, i
   const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, kvh = h / (n_heads / n_kv);
   const UttPlan p = plan[b];
   const int nq = p.T, row0 = p.row_off, h0 = hist[b];
-  const T* K = kc + ((size_t)b * n_kv + kvh) * S_max * HD;
-  const T* V = vc + ((size_t)b * n_kv + kvh) * S_max * HD;
   for (int t = 0; t < nq; ++t) {
     const int nk = h0 + t + 1;
     __syncthreads();
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(128) void qw_attn_kernel(const T* __restrict__ q, i
     __syncthreads();
     float mx = -INFINITY;
     for (int s = tid; s < nk; s += 128) {
-      const T* kr = K + (size_t)s * HD;
+      const T* kr = kv_row(kc, ka, b, kvh, n_kv, s);
       float acc = 0.0f;
       for (int e = 0; e < HD; e += 8) {
         float kv8[8];
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(128) void qw_attn_kernel(const T* __restrict__ q, i
     __syncthreads();
     const float inv = 1.0f / (red[0] + red[1]);
     float acc = 0.0f;
-    for (int s = 0; s < nk; ++s) acc = fmaf(qw_sc[s], Elem<T>::load(V + (size_t)s * HD + tid), acc);
+    for (int s = 0; s < nk; ++s) acc = fmaf(qw_sc[s], Elem<T>::load(kv_row(vc, ka, b, kvh, n_kv, s) + tid), acc);
     Elem<T>::store(ctx + (size_t)(row0 + t) * n_heads * HD + h * HD + tid, acc * inv);
   }
 }
@@ -273,10 +283,10 @@ template <> struct Raw8<float> {
 template <typename T, int G, bool BEAM = false>
 __global__ __launch_bounds__(256) void qw_decode_attn_kernel(const float* __restrict__ qkv, int n_heads, int n_kv, const float* __restrict__ qn,
                                                              const float* __restrict__ kn, const float* __restrict__ rope, float eps,
-                                                             const int32_t* __restrict__ hist, T* __restrict__ kc, T* __restrict__ vc, int S_max,
+                                                             const int32_t* __restrict__ hist, T* __restrict__ kc, T* __restrict__ vc, KvAddr ka,
                                                              T* __restrict__ ctx, const int32_t* __restrict__ src = nullptr, int ld_src = 0,
                                                              const int32_t* __restrict__ p0 = nullptr, const T* __restrict__ kc_p = nullptr,
-                                                             const T* __restrict__ vc_p = nullptr, int S_p = 0, int beam = 1) {
+                                                             const T* __restrict__ vc_p = nullptr, KvAddr kap = KvAddr{nullptr, 0, 0, 0}, int beam = 1) {
   constexpr int HD = 128, KPI = BEAM ? 2 : 4, NTASK = (2 + G + 3) / 4;     // (beam search: 5 x the workgroups -- fewer rows in flight per wave, 128 registers, four workgroups per CU instead of three)
   __shared__ float qsh[G][HD];
   __shared__ float knew[HD], vnew[HD];
@@ -296,21 +306,23 @@ __global__ __launch_bounds__(256) void qw_decode_attn_kernel(const float* __rest
   const int pos = hist[b];                               // keys [0, pos) are in the cache; key pos is made here
   const int heads = n_heads + 2 * n_kv;
   const int base = BEAM ? p0[b] : 0;
-  T* K = kc + ((size_t)b * n_kv + kvh) * S_max * HD - (size_t)base * HD;   // BEAM: indexed by position, slot = position - base
-  T* V = vc + ((size_t)b * n_kv + kvh) * S_max * HD - (size_t)base * HD;
-  const T* Kp = BEAM ? kc_p + ((size_t)(b / beam) * n_kv + kvh) * S_p * HD : nullptr;
-  const T* Vp = BEAM ? vc_p + ((size_t)(b / beam) * n_kv + kvh) * S_p * HD : nullptr;
+  const int S_max = ka.S_max;
+  // BEAM: the hypothesis rows' caches are extents indexed by position, slot = position - base; the prompt is the utterance's prefill cache (extents or pages)
+  T* K = BEAM ? kc + ((size_t)b * n_kv + kvh) * S_max * HD - (size_t)base * HD : nullptr;
+  T* V = BEAM ? vc + ((size_t)b * n_kv + kvh) * S_max * HD - (size_t)base * HD : nullptr;
   const float* row = qkv + (size_t)b * heads * HD;
   const int lg = lane >> 4, li = lane & 15, gid = wave * 4 + lg;
   auto row_ptrs = [&](int s, const T*& kp, const T*& vp) {   // where position s of this sequence lives
     if constexpr (BEAM) {
-      if (s < base) { kp = Kp + (size_t)s * HD; vp = Vp + (size_t)s * HD; return; }
+      if (s < base) { kp = kv_row(kc_p, kap, b / beam, kvh, n_kv, s); vp = kv_row(vc_p, kap, b / beam, kvh, n_kv, s); return; }
       const ptrdiff_t o = (ptrdiff_t)(src[(size_t)b * ld_src + (s - base)] - b) * n_kv * S_max * HD + (ptrdiff_t)s * HD;
       kp = K + o; vp = V + o;
       return;
     }
-    kp = K + (size_t)s * HD; vp = V + (size_t)s * HD;
+    kp = kv_row(kc, ka, b, kvh, n_kv, s); vp = kv_row(vc, ka, b, kvh, n_kv, s);
   };
+  T* k_new = BEAM ? K + (size_t)pos * HD : kv_row(kc, ka, b, kvh, n_kv, pos);      // where this step's key / value go
+  T* v_new = BEAM ? V + (size_t)pos * HD : kv_row(vc, ka, b, kvh, n_kv, pos);
   // ---- requests: the new position's inputs first (L2), then the first block of cache rows (HBM)
   float x0[NTASK], x1[NTASK];
 #pragma unroll
@@ -335,8 +347,8 @@ __global__ __launch_bounds__(256) void qw_decode_attn_kernel(const float* __rest
     if (task == 1) {
       Elem<T>::store(&t0, x0[t]);
       Elem<T>::store(&t1, x1[t]);
-      V[(size_t)pos * HD + lane] = t0;
-      V[(size_t)pos * HD + lane + 64] = t1;
+      v_new[lane] = t0;
+      v_new[lane + 64] = t1;
       vnew[lane] = Elem<T>::load(&t0);
       vnew[lane + 64] = Elem<T>::load(&t1);
       continue;
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(256) void qw_decode_attn_kernel(const float* __rest
     float* dst = task == 0 ? knew : qsh[task - 2];
     dst[lane] = Elem<T>::load(&t0);
     dst[lane + 64] = Elem<T>::load(&t1);
-    if (task == 0) { K[(size_t)pos * HD + lane] = t0; K[(size_t)pos * HD + lane + 64] = t1; }
+    if (task == 0) { k_new[lane] = t0; k_new[lane + 64] = t1; }
   }
   __syncthreads();
   float qr[G][8], m[G], l[G], acc[G][8];
@@ -637,6 +649,26 @@ struct QwSession : asr_session {
   std::vector<char> frozen;      // generate(): finished sequences, allowed to sit at max_seq_len while the others go on
   DeviceBuffer d_dplan, d_x, d_x2, d_dh, d_qkv, d_q, d_dctx, d_act, d_last, d_logits, d_next, d_kc, d_vc, d_hist, d_stepplan, d_skws, d_skcnt, d_vt2, d_krows, d_xlo, d_x2lo;
   bool no_fuse = false, use_graph = true;
+  // ---- paged KV cache (the default; ASR_QWEN_KV_PAGED=0 and the persistent decode kernel keep extents). Pool [page][layer][kv head][16][128] for K and for V,
+  // one block table [sequence][pps] for all layers, a free list on the host: a sequence holds pages for the positions it has, gets one more when it crosses a
+  // page boundary, and gives all of them back the step after it finishes (its table row then points at page 0, a scratch page nobody reads meaningfully).
+  bool kv_paged = true, kv_shuffle = false;
+  int kv_pps = 0, kv_pool_pages = 0, kv_high_water = 0;
+  std::vector<int32_t> kv_free, kv_table;                 // free page ids (LIFO); host mirror of the block table
+  std::vector<std::vector<int32_t>> kv_owned;             // pages of every sequence, in position order
+  std::vector<char> kv_released;
+  DeviceBuffer d_kvtab;
+  void* h_kvtab = nullptr; size_t h_kvtab_cap = 0;
+  bool kv_table_dirty = false;
+  size_t kv_page_elems() const { return (size_t)cfg.n_layers * cfg.n_kv_heads * 16 * cfg.d_head; }
+  void kv_begin(int B, const std::vector<int>& lens, size_t eT);
+  void kv_prepare_step(size_t eT);
+  int kv_take(size_t eT);
+  void kv_upload();
+  KvAddr kv_addr() const {
+    if (kv_paged) return KvAddr{d_kvtab.as<int32_t>(), kv_pps, kv_page_elems(), cfg.max_seq_len};
+    return KvAddr{nullptr, 0, 0, cfg.max_seq_len};
+  }
   // decode head (Inference_Qwen_ASR_ONNX.py:369-376): arg-max, penalty-greedy (APPLY_PENALTY + GREEDY_SEARCH) or top-k / top-p sampling
   float penalty_value = 1.0f; int penalty_range = 10;
   bool track_history = false;          // GREEDY_SEARCH graphs append every pick to save_id whatever the penalty value is
@@ -655,13 +687,14 @@ struct QwSession : asr_session {
   ~QwSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_feat, &d_col, &d_c1, &d_c2, &d_c3, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx,
                             &d_ffn, &d_aud_out, &d_dplan, &d_x, &d_x2, &d_dh, &d_qkv, &d_q, &d_dctx, &d_act, &d_last, &d_logits, &d_next,
-                            &d_kc, &d_vc, &d_hist, &d_stepplan, &d_skws, &d_skcnt, &d_vt2, &d_krows, &d_xlo, &d_x2lo, &d_save, &d_nsaved, &d_noise, &d_bkc, &d_bvc, &d_bhist, &d_bp0, &d_bplan, &d_bsrc[0], &d_bsrc[1], &d_btok[0], &d_btok[1], &d_bcum, &d_bfin, &d_blen, &d_bdone, &d_btopv, &d_btopi, &d_bstop, &d_bnext, &d_megabar, &d_megalayers, &d_megadbg, &d_mlo, &d_mctx, &d_mact})
+                            &d_kc, &d_vc, &d_kvtab, &d_hist, &d_stepplan, &d_skws, &d_skcnt, &d_vt2, &d_krows, &d_xlo, &d_x2lo, &d_save, &d_nsaved, &d_noise, &d_bkc, &d_bvc, &d_bhist, &d_bp0, &d_bplan, &d_bsrc[0], &d_bsrc[1], &d_btok[0], &d_btok[1], &d_bcum, &d_bfin, &d_blen, &d_bdone, &d_btopv, &d_btopi, &d_bstop, &d_bnext, &d_megabar, &d_megalayers, &d_megadbg, &d_mlo, &d_mctx, &d_mact})
       b->release();
     for (auto& kv : taps) kv.second.buf.release();
     if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
     if (h_plan) (void)hipHostFree(h_plan);
     if (h_io) (void)hipHostFree(h_io);
     if (h_ids) (void)hipHostFree(h_ids);
+    if (h_kvtab) (void)hipHostFree(h_kvtab);
     prof.release();
     arena.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -738,6 +771,102 @@ void QwSession::init() {
   }
 }
 
+// ---- paged KV cache: host side
+void QwSession::kv_upload() {
+  if (!kv_table_dirty) return;
+  const size_t bytes = kv_table.size() * 4;
+  int32_t* st = (int32_t*)pinned(h_kvtab, h_kvtab_cap, bytes);
+  memcpy(st, kv_table.data(), bytes);
+  HIP_CHECK(hipMemcpyAsync(d_kvtab.ptr, st, bytes, hipMemcpyHostToDevice, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));               // (the staging buffer is reused by the next change)
+  kv_table_dirty = false;
+}
+// one free page; the pool doubles when the list is empty (page-major layout: the old pool is a prefix of the new one)
+int QwSession::kv_take(size_t eT) {
+  if (kv_free.empty()) {
+    const int old_pages = kv_pool_pages, new_pages = std::max(2 * old_pages, old_pages + 64);
+    DeviceBuffer nk, nv;
+    nk.reserve((size_t)new_pages * kv_page_elems() * eT, stream);
+    nv.reserve((size_t)new_pages * kv_page_elems() * eT, stream);
+    HIP_CHECK(hipMemcpyAsync(nk.ptr, d_kc.ptr, (size_t)old_pages * kv_page_elems() * eT, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(nv.ptr, d_vc.ptr, (size_t)old_pages * kv_page_elems() * eT, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    d_kc.release(); d_vc.release();
+    d_kc = nk; d_vc = nv;                                 // (the decode graph is keyed on these pointers: it is captured again)
+    nk.ptr = nullptr; nk.cap = 0; nv.ptr = nullptr; nv.cap = 0;
+    for (int p = new_pages - 1; p >= old_pages; --p) kv_free.push_back(p);
+    kv_pool_pages = new_pages;
+  }
+  const int p = kv_free.back();
+  kv_free.pop_back();
+  kv_high_water = std::max(kv_high_water, kv_pool_pages - (int)kv_free.size());
+  return p;
+}
+// a new batch: every page back to the list, then pages for the prompts (+ the first generated position)
+void QwSession::kv_begin(int B, const std::vector<int>& lens, size_t eT) {
+  const auto& c = cfg;
+  kv_pps = (c.max_seq_len + 15) / 16;
+  int need = 1;
+  for (int b = 0; b < B; ++b) need += (lens[b] + 1 + 15) / 16;
+  if (need > kv_pool_pages) {                             // nothing to keep across batches: a fresh pool
+    d_kc.release(); d_vc.release();
+    d_kc.reserve((size_t)need * kv_page_elems() * eT, stream);
+    d_vc.reserve((size_t)need * kv_page_elems() * eT, stream);
+    kv_pool_pages = need;
+  }
+  kv_free.clear();
+  for (int p = kv_pool_pages - 1; p >= 1; --p) kv_free.push_back(p);          // page 0: the scratch page of finished sequences
+  if (kv_shuffle) {                                       // tests: hand the pages out in a scrambled order
+    uint64_t x = 0x9e3779b97f4a7c15ull;
+    for (size_t i = kv_free.size(); i > 1; --i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; std::swap(kv_free[i - 1], kv_free[x % i]); }
+  }
+  kv_table.assign((size_t)B * kv_pps, 0);
+  kv_owned.assign(B, {});
+  kv_released.assign(B, 0);
+  kv_high_water = 0;
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < (lens[b] + 1 + 15) / 16; ++j) { const int p = kv_take(eT); kv_owned[b].push_back(p); kv_table[(size_t)b * kv_pps + j] = p; }
+  d_kvtab.reserve(kv_table.size() * 4, stream);
+  kv_table_dirty = true;
+  kv_upload();
+}
+// before a decode step: finished sequences give their pages back (their row points at the scratch page from now on), the others get a page when the position
+// this step writes opens a new one
+void QwSession::kv_prepare_step(size_t eT) {
+  if (!kv_paged) return;
+  for (int b = 0; b < batch; ++b) {
+    const bool fz = b < (int)frozen.size() && frozen[b];
+    if (fz) {
+      if (!kv_released[b]) {
+        for (int p : kv_owned[b]) kv_free.push_back(p);
+        kv_owned[b].clear();
+        for (int j = 0; j < kv_pps; ++j) kv_table[(size_t)b * kv_pps + j] = 0;
+        kv_released[b] = 1;
+        kv_table_dirty = true;
+      }
+      continue;
+    }
+  }
+  // a sequence whose next position opens a page it does not own triggers a refill for EVERY running sequence up to two pages past its position: the table
+  // changes (and is uploaded) about every 16 steps, not every time one of 64 sequences crosses a boundary
+  bool need = false;
+  for (int b = 0; b < batch; ++b)
+    need = need || (!kv_released[b] && (seq_len[b] >> 4) >= (int)kv_owned[b].size());
+  if (need) {
+    for (int b = 0; b < batch; ++b) {
+      if (kv_released[b]) continue;
+      const int upto = std::min((seq_len[b] + 32) >> 4, kv_pps - 1);
+      while ((int)kv_owned[b].size() <= upto) {
+        const int p = kv_take(eT);
+        kv_table[(size_t)b * kv_pps + kv_owned[b].size()] = p;
+        kv_owned[b].push_back(p);
+      }
+    }
+    kv_table_dirty = true;
+  }
+  kv_upload();
+}
+
 // one pass of the decoder stack over `rows` packed rows described by `plan` (T new positions per sequence, appended at hist[b])
 template <typename T>
 void QwSession::decoder_pass(const DecPass& P) {
@@ -752,7 +881,10 @@ void QwSession::decoder_pass(const DecPass& P) {
   T* q = d_q.as<T>();
   T* ctx = d_dctx.as<T>();
   T* act = d_act.as<T>();
-  const size_t layer_kv = (size_t)B * KV * S * hd;
+  // the session's own cache is paged (per-layer offset inside a page) or extents; beam hypothesis caches (P.kc) are always extents of S slots
+  const bool own_paged = kv_paged && !P.kc;
+  const size_t layer_kv = own_paged ? (size_t)KV * 16 * hd : (size_t)B * KV * S * hd;
+  const KvAddr ka = own_paged ? kv_addr() : KvAddr{nullptr, 0, 0, S};
   const int32_t* hist = P.hist ? P.hist : d_hist.as<int32_t>();
   const int G = H / KV;
   // single-position steps of small batches (bf16): RMSNorm(x) W^T = rstd(x) (x W^T) -- the weight-streaming GEMM reads the raw residual
@@ -792,16 +924,17 @@ void QwSession::decoder_pass(const DecPass& P) {
       const size_t lds = 0;
       if (P.beam_src) {
         ASR_REQUIRE(fused_attn, "qwen beam search needs the fused decode attention kernel");
-        const size_t prompt_kv = (size_t)(B / P.beam) * KV * c.max_seq_len * hd;    // the utterances' prefill cache, one layer
+        const size_t prompt_kv = kv_paged ? (size_t)KV * 16 * hd : (size_t)(B / P.beam) * KV * c.max_seq_len * hd;    // the utterances' prefill cache, one layer
         const T* kc_p = d_kc.as<T>() + (size_t)i * prompt_kv;
         const T* vc_p = d_vc.as<T>() + (size_t)i * prompt_kv;
-        if (G == 1) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 1, true>), dim3(B * KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx, P.beam_src, P.ld_src, P.beam_p0, kc_p, vc_p, c.max_seq_len, P.beam);
-        else if (G == 2) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 2, true>), dim3(B * KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx, P.beam_src, P.ld_src, P.beam_p0, kc_p, vc_p, c.max_seq_len, P.beam);
-        else hipLaunchKernelGGL((qw_decode_attn_kernel<T, 4, true>), dim3(B * KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx, P.beam_src, P.ld_src, P.beam_p0, kc_p, vc_p, c.max_seq_len, P.beam);
+        const KvAddr kap = kv_addr();
+        if (G == 1) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 1, true>), dim3(B * KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, ka, ctx, P.beam_src, P.ld_src, P.beam_p0, kc_p, vc_p, kap, P.beam);
+        else if (G == 2) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 2, true>), dim3(B * KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, ka, ctx, P.beam_src, P.ld_src, P.beam_p0, kc_p, vc_p, kap, P.beam);
+        else hipLaunchKernelGGL((qw_decode_attn_kernel<T, 4, true>), dim3(B * KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, ka, ctx, P.beam_src, P.ld_src, P.beam_p0, kc_p, vc_p, kap, P.beam);
       } else
-      if (G == 1) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 1, false>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx, (const int32_t*)nullptr, 0, (const int32_t*)nullptr, (const T*)nullptr, (const T*)nullptr, 0, 1);
-      else if (G == 2) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 2, false>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx, (const int32_t*)nullptr, 0, (const int32_t*)nullptr, (const T*)nullptr, (const T*)nullptr, 0, 1);
-      else hipLaunchKernelGGL((qw_decode_attn_kernel<T, 4, false>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, S, ctx, (const int32_t*)nullptr, 0, (const int32_t*)nullptr, (const T*)nullptr, (const T*)nullptr, 0, 1);
+      if (G == 1) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 1, false>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, ka, ctx, (const int32_t*)nullptr, 0, (const int32_t*)nullptr, (const T*)nullptr, (const T*)nullptr, KvAddr{nullptr, 0, 0, 0}, 1);
+      else if (G == 2) hipLaunchKernelGGL((qw_decode_attn_kernel<T, 2, false>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, ka, ctx, (const int32_t*)nullptr, 0, (const int32_t*)nullptr, (const T*)nullptr, (const T*)nullptr, KvAddr{nullptr, 0, 0, 0}, 1);
+      else hipLaunchKernelGGL((qw_decode_attn_kernel<T, 4, false>), dim3(B, KV), dim3(256), lds, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, hist, kc, vc, ka, ctx, (const int32_t*)nullptr, 0, (const int32_t*)nullptr, (const T*)nullptr, (const T*)nullptr, KvAddr{nullptr, 0, 0, 0}, 1);
     } else {
       const bool mfma_attn = bf && !P.step && P.n_qb > 0;
       if (mfma_attn) {                                   // V^T for the MFMA attention kernel (the cache gets V from the q|k|v GEMM)
@@ -812,7 +945,7 @@ void QwSession::decoder_pass(const DecPass& P) {
       { ProfScope ps(prof, "dec_rope", stream);
         const int waves = rows * (H + 2 * KV);
         hipLaunchKernelGGL(qw_qk_rope_kernel<T>, dim3((waves + 3) / 4), dim3(256), 0, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, P.row_seq, P.row_t,
-                           hist, rows, q, kc, vc, S, mfma_attn ? d_krows.as<T>() : (T*)nullptr); }
+                           hist, rows, q, kc, vc, ka, mfma_attn ? d_krows.as<T>() : (T*)nullptr); }
       ProfScope ps(prof, "dec_attn", stream);
       if (mfma_attn) {
         AttnArgs aa; aa.q = q; aa.ld_q = H * hd; aa.k = d_krows.ptr; aa.ld_qk = KV * hd; aa.vt = d_vt2.ptr; aa.ld_vt = P.ld_vt; aa.ctx = ctx; aa.ld_ctx = H * hd;
@@ -820,7 +953,7 @@ void QwSession::decoder_pass(const DecPass& P) {
         aa.causal = 1; aa.kv_group = G;
         launch_attention_bf16_hd128(aa, stream);
       } else {
-        hipLaunchKernelGGL(qw_attn_kernel<T>, dim3(B, H), dim3(128), (size_t)S * 4, stream, q, H, KV, kc, vc, S, P.plan, hist, ctx);
+        hipLaunchKernelGGL(qw_attn_kernel<T>, dim3(B, H), dim3(128), (size_t)S * 4, stream, q, H, KV, kc, vc, ka, P.plan, hist, ctx);
       }
     }
     { ProfScope ps(prof, "dec_gemm", stream);
@@ -1137,8 +1270,12 @@ void QwSession::prefill(const float* audio, int audio_mem, const int64_t* offs, 
   const int KV = c.n_kv_heads, hd = c.d_head, Hq = c.n_heads, I = c.d_ffn, qkvn = (Hq + 2 * KV) * hd, S = c.max_seq_len;
   batch = B;
   seq_len.assign(ids_len.begin(), ids_len.end());
-  d_kc.reserve((size_t)c.n_layers * B * KV * S * hd * eT, stream);
-  d_vc.reserve((size_t)c.n_layers * B * KV * S * hd * eT, stream);
+  kv_paged = kv_paged && !use_mega;                      // (the persistent decode kernel addresses extents)
+  if (kv_paged) kv_begin(B, ids_len, eT);
+  else {
+    d_kc.reserve((size_t)c.n_layers * B * KV * S * hd * eT, stream);
+    d_vc.reserve((size_t)c.n_layers * B * KV * S * hd * eT, stream);
+  }
   d_hist.reserve((size_t)std::max(B, 64) * 4, stream);
   HIP_CHECK(hipMemsetAsync(d_hist.ptr, 0, (size_t)B * 4, stream));
   const int Mmax = std::max(Md, (int)pad_rows(B));
@@ -1257,6 +1394,7 @@ void QwSession::step(const int32_t* ids_host, int32_t* next_out, float* logits_o
     }
     HIP_CHECK(hipMemcpyAsync(d_next.ptr, st, (size_t)B * 4, hipMemcpyHostToDevice, stream));
   }
+  kv_prepare_step(sizeof(T));
   // the step plan (one row per sequence) was uploaded by prefill
   const UttPlan* dsp = d_stepplan.as<UttPlan>();
   const int32_t* d_row_seq = (const int32_t*)(dsp + B);
@@ -1282,7 +1420,7 @@ void QwSession::step(const int32_t* ids_host, int32_t* next_out, float* logits_o
   const bool graphable = use_graph && !taps_enabled && !prof.enabled && !noise_armed;
   uint64_t key = 1469598103934665603ull;
   for (const void* q : {d_x.ptr, d_x2.ptr, d_dh.ptr, d_qkv.ptr, d_q.ptr, d_dctx.ptr, d_xlo.ptr, d_x2lo.ptr, d_act.ptr, d_last.ptr, d_logits.ptr, d_next.ptr, d_kc.ptr,
-                        d_vc.ptr, d_hist.ptr, d_stepplan.ptr, d_skws.ptr, d_save.ptr, (void*)stream, (void*)(uintptr_t)B, (void*)(uintptr_t)head_epoch})
+                        d_vc.ptr, d_kvtab.ptr, d_hist.ptr, d_stepplan.ptr, d_skws.ptr, d_save.ptr, (void*)stream, (void*)(uintptr_t)B, (void*)(uintptr_t)head_epoch})
     key = (key ^ (uint64_t)(uintptr_t)q) * 1099511628211ull;
   if (graphable && dec_graph && key == dec_key) {
     HIP_CHECK(hipGraphLaunch(dec_graph, stream));
@@ -1433,6 +1571,8 @@ extern "C" int asr_qwen_create(const asr_qwen_config* cfg, const void* arena, si
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       if (const char* e = getenv("ASR_QWEN_NO_FUSE")) s->no_fuse = e[0] == '1';
       if (const char* e = getenv("ASR_QWEN_MEGA")) s->use_mega = e[0] == '1';
+      if (const char* e = getenv("ASR_QWEN_KV_PAGED")) s->kv_paged = !(e[0] == '0');
+      if (const char* e = getenv("ASR_KV_PAGE_SHUFFLE")) s->kv_shuffle = e[0] == '1';
       s->arena.load(arena, arena_bytes, arena_mem, s->stream);
       s->init();
     } catch (...) {
@@ -1524,6 +1664,16 @@ extern "C" int asr_qwen_beam_search(asr_session* s, int beam, int max_new, const
     QwSession* q = static_cast<QwSession*>(s);
     if (q->precision == ASR_PRECISION_BF16) q->beam_search<bf16_t>(beam, max_new, stop_ids, n_stop, tokens_out, n_out, scores_out);
     else q->beam_search<float>(beam, max_new, stop_ids, n_stop, tokens_out, n_out, scores_out);
+  });
+}
+
+extern "C" int asr_qwen_kv_stats(asr_session* s, int32_t* out4) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 5 && out4, "qwen_kv_stats: bad argument");
+    QwSession* q = static_cast<QwSession*>(s);
+    int held = 0;
+    for (const auto& v : q->kv_owned) held += (int)v.size();
+    out4[0] = q->kv_paged ? 1 : 0; out4[1] = q->kv_pool_pages; out4[2] = q->kv_paged ? held : 0; out4[3] = q->kv_high_water;
   });
 }
 

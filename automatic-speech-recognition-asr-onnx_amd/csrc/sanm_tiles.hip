@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NT) void sanm_tiles_kernel(const SanmTilesArgs a) {
   float* xb_rows = a.xb + (size_t)row0 * D;
   bf16_t* ctx_rows = a.ctx + (size_t)row0 * D;
   bf16_t* hid_rows = a.hid + (size_t)row0 * DFF;
-  bf16_t* kv_win = a.kv + (size_t)wrow0 * 2 * D;                           // [window row][k | v][512]
+  bf16_t* kv_win0 = a.kv + (size_t)wrow0 * 2 * D;                          // [block parity][window row][k | v][512]
   const size_t wave_frag = (size_t)(h * NW + wave);
   u32x4 wa[12];
   wload<12>(wa, a.layers[0].wpack + PK_A + wave_frag * PW_A + (tid_0 & 63) * 16, 0);
@@ -120,6 +120,9 @@ __global__ __launch_bounds__(NT) void sanm_tiles_kernel(const SanmTilesArgs a) {
     unsigned* lflags = a.flags + (size_t)li * a.flag_stride;
     unsigned* flags = lflags + cl * 4;
     unsigned* kvflag = lflags + a.n_tiles * 4 + win * NH + h;
+    // two k/v buffers, by block parity: a tile that is through block li must not write block li + 1's rows over what a slower tile of its head still reads
+    // (it cannot be two blocks ahead: the next meeting needs the slow tile's count)
+    bf16_t* kv_win = kv_win0 + (size_t)(li & 1) * a.kv_parity_stride;
     const unsigned char* wpA = L.wpack + PK_A + wave_frag * PW_A + lane * 16;
     const unsigned char* wpB = L.wpack + PK_B + wave_frag * PW_B + lane * 16;
     const unsigned char* wpC = L.wpack + PK_C + wave_frag * PW_C + lane * 16;
@@ -244,8 +247,9 @@ __global__ __launch_bounds__(NT) void sanm_tiles_kernel(const SanmTilesArgs a) {
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<bf16_t*>(smem + CTX + (fgrp * 4 + i) * AS + (h * HD + wave * 16 + frow) * 2) = (bf16_t)(pack_bf16x2(o[i], 0.0f) & 0xffffu);
+      for (int i = 0; i < 4; ++i)       // rows past the window stay zero in the ctx buffer (block 0's out-projection of the NEXT run reads its pad rows)
+        *reinterpret_cast<bf16_t*>(smem + CTX + (fgrp * 4 + i) * AS + (h * HD + wave * 16 + frow) * 2) =
+            tile * SLOT + fgrp * 4 + i < T ? (bf16_t)(pack_bf16x2(o[i], 0.0f) & 0xffffu) : (bf16_t)0;
     }
     {   // FSMN memory term of the tile's rows: taps reach 5 rows into the neighbouring tiles, rows outside [0, T) are zero; thread = (channel, 4 rows)
       const int c = tid & 127, t0 = tile * SLOT + (tid >> 7) * 4;

@@ -434,7 +434,7 @@ void SvSession::enqueue(const SvRunCtx& r) {
           SanmTilesArgs ta;
           ta.plan = r.dp; ta.tile_win = r.d_tile_win; ta.tile_idx = r.d_tile_idx; ta.n_tiles = r.n_tiles; ta.n_windows = r.batch; ta.n_layers = run_end - i;
           ta.ln_eps = 1e-5f; ta.layers = d_tlayer_tab.as<StreamLayer>() + i;
-          ta.x = xa; ta.xb = xb; ta.ctx = (bf16_t*)ctx; ta.hid = (bf16_t*)ffn; ta.kv = d_tkv.as<bf16_t>();
+          ta.x = xa; ta.xb = xb; ta.ctx = (bf16_t*)ctx; ta.hid = (bf16_t*)ffn; ta.kv = d_tkv.as<bf16_t>(); ta.kv_parity_stride = (size_t)Mpad * 2 * d;
           ta.flags = d_flags.as<unsigned>() + tile_flag0 + (size_t)i * tile_flag_stride; ta.flag_stride = (int)tile_flag_stride;
           ta.err = d_flags.as<unsigned>() + flag_words; ta.opt = tiles_opt;
           if (tiles_dbg >= i && tiles_dbg < run_end) {
@@ -791,7 +791,7 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   grow(d_amax_i, (size_t)Mpad * n_slabs * 4);
   grow(d_ids, (size_t)Mpad * 4);
   grow(d_flags, ((size_t)c.n_blocks * batch * 5 + 4 + (tiles ? (size_t)c.n_blocks * (n_tiles + batch) * 4 : 0)) * 4);
-  if (tiles) grow(d_tkv, (size_t)Mpad * 2 * d * 2);          // [block][window][4] exchange counters + error word (4) + [block][window] placement words
+  if (tiles) grow(d_tkv, (size_t)Mpad * 2 * d * 2 * 2);          // [block][window][4] exchange counters + error word (4) + [block][window] placement words
   grow(d_tok, (size_t)batch * max_tokens * 4);
   grow(d_num, (size_t)batch * 4);
   if (taps_enabled) grow(d_logits, (size_t)Mpad * vpad * 4);

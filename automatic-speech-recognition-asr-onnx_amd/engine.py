@@ -573,6 +573,12 @@ class QwenAsrSession(_Session):
         _lib.check(_lib.load().asr_qwen_generate(self._h, max_new, _ip(stop) if stop.size else None, stop.size, _ip(tok), _ip(n)))
         return [tok[b, :n[b]].copy() for b in range(self.batch)]
 
+    def kv_stats(self) -> dict:
+        """The KV cache's page accounting (asr_qwen_kv_stats): paged?, pages in the pool, pages held now, high-water mark since the prefill."""
+        out = np.zeros(4, dtype=np.int32)
+        _lib.check(_lib.load().asr_qwen_kv_stats(self._h, _ip(out)))
+        return {"paged": bool(out[0]), "pool_pages": int(out[1]), "held": int(out[2]), "high_water": int(out[3])}
+
     def beam_search(self, beam: int, max_new: int, stop_ids=()):
         """Width-`beam` search after a prefill -> per utterance a best-first list of (token ids, summed log-probability)."""
         tok = np.zeros((self.batch, beam, max_new), dtype=np.int32)

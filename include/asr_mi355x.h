@@ -235,6 +235,11 @@ int asr_qwen_set_sampling_noise(asr_session* s, const float* uniforms, int count
 /* continuation after a prefill with the selected head (:687-745): tokens_out host [B][max_new], n_out host [B]; a sequence ends at
  * the first id in stop_ids (not emitted) or when the cache is full. */
 int asr_qwen_generate(asr_session* s, int max_new, const int32_t* stop_ids, int n_stop, int32_t* tokens_out, int32_t* n_out);
+/* The session's KV cache (Qwen_ASR/Export_Qwen_ASR.py:1265-1336 keeps `in_key_i / in_value_i` tensors of the whole history per sequence; the north-star's paged
+ * cache): 16-position pages behind one block table for all layers, a free list on the host -- a sequence holds pages for the positions it has, and a sequence that
+ * asr_qwen_generate finished gives its pages back while its neighbours go on. out4 = {1 if paged (0: extents of max_seq_len positions, ASR_QWEN_KV_PAGED=0),
+ * pages in the pool, pages held by sequences now, high-water mark of pages in use since the last prefill}. */
+int asr_qwen_kv_stats(asr_session* s, int32_t* out4);
 /* beam search after a prefill (the README's "greedy / beam search" for Qwen3-ASR, README.md:38; the reference ships no code for it, the
  * semantics are written down in oracle/qwen_asr_oracle.py:beam_search_core): width-`beam` (1..8) search over summed log-soft-max scores,
  * no length normalisation. A hypothesis ends at the first id in stop_ids (not emitted) and then stands with its score; an utterance is

@@ -109,6 +109,59 @@ def test_generate_equals_stepwise_and_oracle_bf16(fixture, no_fuse, mega, monkey
         assert np.array_equal(nxt, ids[:, t])
 
 
+@pytest.mark.parametrize("prec", [BF16, F32])
+def test_paged_kv_cache_equals_extents_and_returns_pages_out_of_order(prec, monkeypatch):
+    """The KV cache is paged (16-position pages behind one block table for all layers, a free list on the host): logits bit for bit those of the extent layout
+    (ASR_QWEN_KV_PAGED=0) over a prefill and 40 steps -- every sequence crosses page boundaries, the pool grows on the way --, the same with the free list
+    scrambled (ASR_KV_PAGE_SHUFFLE=1: a table that is not monotone); sequences that finish EARLY in generate() give their pages back while the others go on
+    (out-of-order completion: the third finishes first), the running ones take them over, tokens unchanged; beam search reads a paged prompt."""
+    g = load_golden("qwen_asr_mid")
+    cfg, ck = qwen_setup(g)
+    cases = [c for _, c in golden_cases(g)]
+    audios = [unit_audio(c["audio_seed"], c["n_samples"]) for c in cases]
+    pre, post = _prompts(g, cases)
+    n_new = 41
+    eng = sub("engine")
+    runs = {}
+    for name, env in (("extents", {"ASR_QWEN_KV_PAGED": "0"}), ("paged", {}), ("shuffled", {"ASR_KV_PAGE_SHUFFLE": "1"})):
+        for k in ("ASR_QWEN_KV_PAGED", "ASR_KV_PAGE_SHUFFLE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sess = eng.QwenAsrSession.from_checkpoint(cfg, ck, precision=prec)
+        logits, ids, ids_len = _stepwise(sess, audios, pre, post, n_new)
+        st = sess.kv_stats()
+        # generate with per-sequence stop ids chosen from the stepwise run so that the sequences end at different steps, the LAST one of the batch first
+        B = len(cases)
+        ends = [30, 18, 6][:B] + [12] * max(0, B - 3)
+        stops = [int(ids[b, ends[b]]) for b in range(B)]
+        sess.prefill(audios, pre, post, want_logits=False)
+        held0 = sess.kv_stats()["held"]
+        gen = sess.generate(n_new, stop_ids=tuple(stops))
+        st2 = sess.kv_stats()
+        beam = None
+        if name != "shuffled":
+            sess.prefill(audios, pre, post, want_logits=False)
+            beam = sess.beam_search(3, 6, stop_ids=())
+        runs[name] = (logits, ids, st, gen, held0, st2, beam, [int(x) for x in ids_len])
+        del sess
+    ext, pag, shf = runs["extents"], runs["paged"], runs["shuffled"]
+    assert not ext[2]["paged"] and pag[2]["paged"] and shf[2]["paged"]
+    for other in (pag, shf):
+        assert np.array_equal(other[0], ext[0]) and np.array_equal(other[1], ext[1])       # logits and ids, every step, bit for bit
+        for a, b in zip(other[3], ext[3]):
+            assert np.array_equal(a, b)                                                     # generate() with early finishers
+    for ua, ub in zip(pag[6], ext[6]):                                                     # beam search over a paged prompt: the same n-best lists
+        for (ta, sa), (tb, sb) in zip(ua, ub):
+            assert np.array_equal(ta, tb) and sa == sb
+    # accounting: a sequence holds pages for its positions (+ at most two ahead), nothing like max_seq_len; finished sequences hold none
+    pps, lens = (cfg.max_seq_len + 15) // 16, pag[7]
+    assert pag[2]["held"] <= sum((n + n_new + 15) // 16 + 2 for n in lens) < len(lens) * pps
+    assert pag[4] == sum((n + 1 + 15) // 16 for n in lens)        # after a prefill: the prompt's pages (+ the first generated position's)
+    assert pag[5]["held"] < pag[5]["high_water"]                  # pages came back before the batch ended ...
+    assert pag[5]["high_water"] <= pag[2]["high_water"]           # ... and the peak was no higher than when nobody finished early
+
+
 def test_bad_arguments_fail_loudly():
     g = load_golden("qwen_asr_tiny")
     cfg, ck = qwen_setup(g)

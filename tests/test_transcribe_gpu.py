@@ -32,7 +32,7 @@ def test_sensevoice_wavs_to_dump_and_compare(tmp_path):
         p = str(tmp_path / f"clip{i}.wav")
         aio.write_wav_int16(p, kaldi_audio(70 + i, n).astype(np.int16), 16000)
         wavs.append(p)
-    args = types.SimpleNamespace(family="sensevoice", model=folder, wav=wavs, language="en", tokenizer=None, precision="f32", sliding_window=0,
+    args = types.SimpleNamespace(family="sensevoice", model=folder, wav=wavs, language="en", tokenizer=None, precision="f32", sliding_window=0, strict_wav=True,
                                  repeat_penalty=1.0, beam=1)
     dump = t.run(args)
     sess = sub("engine").SenseVoiceSession.from_checkpoint(cfg, ck, precision=1)
@@ -53,7 +53,7 @@ def test_whisper_wavs_to_dump(tmp_path):
     pcm = np.clip(np.round(unit_audio(41, 24000) * 32768.0), -32768, 32767).astype(np.int16)
     p = str(tmp_path / "clip.wav")
     aio.write_wav_int16(p, pcm, 16000)
-    args = types.SimpleNamespace(family="whisper", model=folder, wav=[p], language="auto", tokenizer=None, precision="f32", sliding_window=0,
+    args = types.SimpleNamespace(family="whisper", model=folder, wav=[p], language="auto", tokenizer=None, precision="f32", sliding_window=0, strict_wav=True,
                                  repeat_penalty=1.0, beam=1)
     dump = t.run(args)
     f = dump["files"][0]
@@ -76,7 +76,7 @@ def test_sensevoice_run_with_sentencepiece_model(tmp_path):
     spm_path = sentencepiece_model(str(tmp_path / "tiny.model"), cfg.vocab)
     p = str(tmp_path / "clip.wav")
     aio.write_wav_int16(p, kaldi_audio(81, 40000).astype(np.int16), 16000)
-    args = types.SimpleNamespace(family="sensevoice", model=folder, wav=[p], language="en", tokenizer=spm_path, precision="f32", sliding_window=0,
+    args = types.SimpleNamespace(family="sensevoice", model=folder, wav=[p], language="en", tokenizer=spm_path, precision="f32", sliding_window=0, strict_wav=True,
                                  repeat_penalty=1.0, beam=1)
     f = t.run(args)["files"][0]
     sp = SentencePieceProcessor(); sp.Load(spm_path)
@@ -96,7 +96,7 @@ def test_whisper_run_with_tokenizer_directory(tmp_path):
     pcm = np.clip(np.round(unit_audio(43, 24000) * 32768.0), -32768, 32767).astype(np.int16)
     p = str(tmp_path / "clip.wav")
     aio.write_wav_int16(p, pcm, 16000)
-    args = types.SimpleNamespace(family="whisper", model=folder, wav=[p], language="en", tokenizer=tok_dir, precision="f32", sliding_window=0,
+    args = types.SimpleNamespace(family="whisper", model=folder, wav=[p], language="en", tokenizer=tok_dir, precision="f32", sliding_window=0, strict_wav=True,
                                  repeat_penalty=1.0, beam=1)
     f = t.run(args)["files"][0]
     tok = AutoTokenizer.from_pretrained(tok_dir)
@@ -121,7 +121,7 @@ def test_qwen_run_with_tokenizer_directory(tmp_path):
     p = str(tmp_path / "clip.wav")
     aio.write_wav_int16(p, pcm, 16000)
     for lang in ("auto", "English"):
-        args = types.SimpleNamespace(family="qwen_asr", model=folder, wav=[p], language=lang, tokenizer=tok_dir, precision="f32", sliding_window=0,
+        args = types.SimpleNamespace(family="qwen_asr", model=folder, wav=[p], language=lang, tokenizer=tok_dir, precision="f32", sliding_window=0, strict_wav=True,
                                      repeat_penalty=1.0, beam=1)
         f = t.run(args)["files"][0]
         ids = f["windows"][0]

@@ -59,7 +59,7 @@ def run(a) -> dict:
         else:
             tr = mod.ParaformerTranscriber(a.model, vocab_path=a.tokenizer, device_type="cuda")
         for p in a.wav:
-            pcm = audio_io.read_wav_int16(p, tr.sample_rate, exact_width=getattr(a, "strict_wav", True))
+            pcm = audio_io.read_wav_int16(p, tr.sample_rate, exact_width=a.strict_wav)
             r = tr.transcribe(pcm, sliding_window=a.sliding_window)
             files.append({"path": p, "n_samples": int(pcm.size), "language": r.get("language", a.language),
                           "windows": [np.asarray(w).reshape(-1).astype(int).tolist() for w in r["token_ids"]], "text": r.get("text"), "rtf": r["rtf"]})
@@ -86,7 +86,7 @@ def run(a) -> dict:
             lang_id = tok.convert_tokens_to_ids(f"<|{a.language}|>")
         window = cfg.max_audio_len
         for p in a.wav:
-            pcm = audio_io.read_wav_int16(p, cfg.sample_rate, exact_width=getattr(a, "strict_wav", True))
+            pcm = audio_io.read_wav_int16(p, cfg.sample_rate, exact_width=a.strict_wav)
             clips = [pcm[s:s + window] for s in range(0, max(pcm.size, 1), window)]
             out, stat = tr.transcribe(clips, language_ids=None if lang_id is None else [lang_id] * len(clips))
             ids = [o["tokens"].astype(int).tolist() for o in out]
@@ -103,7 +103,7 @@ def run(a) -> dict:
             tok = AutoTokenizer.from_pretrained(a.tokenizer)
         tr = _m("qwen_asr").QwenAsrTranscriber(cfg, sess, info["metadata"], tokenizer=tok, repeat_penalty=a.repeat_penalty, beam_size=a.beam)
         for p in a.wav:
-            pcm = audio_io.read_wav_int16(p, cfg.sample_rate, exact_width=getattr(a, "strict_wav", True))
+            pcm = audio_io.read_wav_int16(p, cfg.sample_rate, exact_width=a.strict_wav)
             out, stat = tr.transcribe([pcm], language_prompts=("" if a.language == "auto" else a.language,))
             r = out[0]
             files.append({"path": p, "n_samples": int(pcm.size), "language": r.get("language") or a.language,

@@ -18,6 +18,12 @@ ASR_STREAM_FUSED=1 python bench.py --workload paraformer-streaming --no-cpu-base
   echo "# tuning switches (ASR_STREAM_OPT, kernels.h: StreamLayersArgs::opt): 0 default, 1 no L2 warm-up, 2 FFN warm-up while waiting, 112 second weight batch behind the exchanged rows"
   bash tools/probes/stream_opt_ab.sh 2>&1 | grep -v "^  File\|^    \|Traceback\|json"
 } > $OUT/stream_phase_clock.txt
+# small batches: the tile kernel against the four-launch path, and its phase clock
+bash tools/probes/tiles_b1.sh 2>&1 | grep -v amdgpu.ids > $OUT/sanm_tiles_small_batches.txt
+{ echo "# intervals: wait x | LN1 | q|k|v GEMM | k/v meeting of the head's tiles | attention + FSMN | ctx exchange | out-proj | x1 exchange | LN2 | FFN-1 | hid exchange | FFN-2 | store x + publish (B = 1, then B = 7)"; bash tools/probes/tiles_clock.sh; } >> $OUT/sanm_tiles_small_batches.txt 2>&1
+# Qwen3-ASR: paged KV cache against extents
+for p in 1 0; do ASR_QWEN_KV_PAGED=$p python bench.py --workload qwen --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_qwen_paged$p.json 2> $OUT/bench_qwen_paged$p.err; done
+ASR_QWEN_KV_PAGED=1 python bench.py --workload qwen --beam 5 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_qwen_beam5_paged1.json 2> $OUT/bench_qwen_beam5_paged1.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/stats -- python $GRAFT_REPO_ROOT/bench.py --workload paraformer-streaming --steps 20 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/stats.log 2>&1
 cd $GRAFT_REPO_ROOT

@@ -36,12 +36,14 @@ static_assert(LDS_BYTES <= 160 * 1024 && XRES % 16 == 0 && UNI % 16 == 0, "LDS m
 
 // full rows of the tile's f32 stream (16 x 512, exchanged) -> plain normalisation (the affine is folded into the next weights) -> bf16 operand rows
 __device__ __forceinline__ void norm_rows(const float* src, unsigned char* smem, int tid, int h, bool keep_own, float eps) {
-  const int row = tid >> 5, c0 = (tid & 31) * 16;
-  const float* p = src + (size_t)row * D + c0;
+  // thread = (row, column pairs 64 e + 2 j, e < 8): a wave instruction reads 256 contiguous bytes of each of its two rows (16 columns per thread in a row would be
+  // 64 lanes 64 bytes apart, one 64-byte segment each: 2 us of address processing per LayerNorm)
+  const int row = tid >> 5, j = tid & 31;
+  const float* p = src + (size_t)row * D + 2 * j;
   float v[16];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const u64 t = get8(p + 2 * e);
+    const u64 t = get8(p + 64 * e);
     v[2 * e] = __uint_as_float((unsigned)t);
     v[2 * e + 1] = __uint_as_float((unsigned)(t >> 32));
   }
@@ -60,17 +62,10 @@ __device__ __forceinline__ void norm_rows(const float* src, unsigned char* smem,
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   const float rstd = 1.0f / sqrtf(q * (1.0f / D) + eps);
-  uint4 lo, hi;
-  lo.x = pack_bf16x2((v[0] - mean) * rstd, (v[1] - mean) * rstd); lo.y = pack_bf16x2((v[2] - mean) * rstd, (v[3] - mean) * rstd);
-  lo.z = pack_bf16x2((v[4] - mean) * rstd, (v[5] - mean) * rstd); lo.w = pack_bf16x2((v[6] - mean) * rstd, (v[7] - mean) * rstd);
-  hi.x = pack_bf16x2((v[8] - mean) * rstd, (v[9] - mean) * rstd); hi.y = pack_bf16x2((v[10] - mean) * rstd, (v[11] - mean) * rstd);
-  hi.z = pack_bf16x2((v[12] - mean) * rstd, (v[13] - mean) * rstd); hi.w = pack_bf16x2((v[14] - mean) * rstd, (v[15] - mean) * rstd);
-  *reinterpret_cast<uint4*>(smem + XN + row * AS + c0 * 2) = lo;
-  *reinterpret_cast<uint4*>(smem + XN + row * AS + c0 * 2 + 16) = hi;
-  if (keep_own && (c0 >> 7) == h) {
-    float* k = reinterpret_cast<float*>(smem + XRES) + row * HD + (c0 & 127);
 #pragma unroll
-    for (int e = 0; e < 16; e += 4) *reinterpret_cast<float4*>(k + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
+  for (int e = 0; e < 8; ++e) {
+    *reinterpret_cast<unsigned*>(smem + XN + row * AS + (64 * e + 2 * j) * 2) = pack_bf16x2((v[2 * e] - mean) * rstd, (v[2 * e + 1] - mean) * rstd);
+    if (keep_own && (e >> 1) == h) *reinterpret_cast<float2*>(smem + XRES + (row * HD + 64 * (e & 1) + 2 * j) * 4) = make_float2(v[2 * e], v[2 * e + 1]);
   }
 }
 

@@ -45,12 +45,13 @@ static_assert(SLOT * 512 * 4 <= ENC && VB + MAXK * KS <= UNI_END && LDS_BYTES <=
 //   MODE 1: own 128 columns only: normalised * g + b in f32 -> `keep`
 template <int MODE>
 __device__ __forceinline__ void norm_rows(const float* src, unsigned char* smem, int tid, int h, float eps, float* keep, const float* g, const float* b) {
-  const int row = tid >> 5, c0 = (tid & 31) * 16;
-  const float* p = src + (size_t)row * D + c0;
+  // thread = (row, column pairs 64 e + 2 j, e < 8): lane-contiguous 8-byte loads (256 contiguous bytes per row and instruction)
+  const int row = tid >> 5, j = tid & 31;
+  const float* p = src + (size_t)row * D + 2 * j;
   float v[16];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const u64 t = get8(p + 2 * e);
+    const u64 t = get8(p + 64 * e);
     v[2 * e] = __uint_as_float((unsigned)t);
     v[2 * e + 1] = __uint_as_float((unsigned)(t >> 32));
   }
@@ -69,26 +70,17 @@ __device__ __forceinline__ void norm_rows(const float* src, unsigned char* smem,
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   const float rstd = 1.0f / sqrtf(q * (1.0f / D) + eps);
-  const bool own = (c0 >> 7) == h;
-  if constexpr (MODE == 0) {
-    uint4 lo, hi;
-    lo.x = pack_bf16x2((v[0] - mean) * rstd, (v[1] - mean) * rstd); lo.y = pack_bf16x2((v[2] - mean) * rstd, (v[3] - mean) * rstd);
-    lo.z = pack_bf16x2((v[4] - mean) * rstd, (v[5] - mean) * rstd); lo.w = pack_bf16x2((v[6] - mean) * rstd, (v[7] - mean) * rstd);
-    hi.x = pack_bf16x2((v[8] - mean) * rstd, (v[9] - mean) * rstd); hi.y = pack_bf16x2((v[10] - mean) * rstd, (v[11] - mean) * rstd);
-    hi.z = pack_bf16x2((v[12] - mean) * rstd, (v[13] - mean) * rstd); hi.w = pack_bf16x2((v[14] - mean) * rstd, (v[15] - mean) * rstd);
-    *reinterpret_cast<uint4*>(smem + XN + row * AS + c0 * 2) = lo;
-    *reinterpret_cast<uint4*>(smem + XN + row * AS + c0 * 2 + 16) = hi;
-    if (keep && own) {
 #pragma unroll
-      for (int e = 0; e < 16; e += 4) *reinterpret_cast<float4*>(keep + row * HD + (c0 & 127) + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
-    }
-  } else {
-    if (own) {
-#pragma unroll
-      for (int e = 0; e < 16; e += 4) {
-        const f32x4_t gg = *glob(reinterpret_cast<const f32x4_t*>(g + c0 + e)), bb = *glob(reinterpret_cast<const f32x4_t*>(b + c0 + e));
-        *reinterpret_cast<float4*>(keep + row * HD + (c0 & 127) + e) =
-            make_float4((v[e] - mean) * rstd * gg[0] + bb[0], (v[e + 1] - mean) * rstd * gg[1] + bb[1], (v[e + 2] - mean) * rstd * gg[2] + bb[2], (v[e + 3] - mean) * rstd * gg[3] + bb[3]);
+  for (int e = 0; e < 8; ++e) {
+    const bool own = (e >> 1) == h;
+    const int c = 64 * e + 2 * j;
+    if constexpr (MODE == 0) {
+      *reinterpret_cast<unsigned*>(smem + XN + row * AS + c * 2) = pack_bf16x2((v[2 * e] - mean) * rstd, (v[2 * e + 1] - mean) * rstd);
+      if (keep && own) *reinterpret_cast<float2*>(keep + row * HD + (c & 127)) = make_float2(v[2 * e], v[2 * e + 1]);
+    } else {
+      if (own) {
+        const f32x2_t gg = *glob(reinterpret_cast<const f32x2_t*>(g + c)), bb = *glob(reinterpret_cast<const f32x2_t*>(b + c));
+        *reinterpret_cast<float2*>(keep + row * HD + (c & 127)) = make_float2((v[2 * e] - mean) * rstd * gg[0] + bb[0], (v[2 * e + 1] - mean) * rstd * gg[1] + bb[1]);
       }
     }
   }
@@ -191,16 +183,13 @@ __global__ __launch_bounds__(NT) void stream_dec_kernel(const StreamDecArgs a) {
       sink ^= tw;
       consume(flags + 0, a.err);
       STAMP(4);
-      const int row = tid >> 5, j0 = (tid & 31) * 16;
+      const int row = tid >> 5, j = tid & 31;              // thread = (row, column pairs 64 e + 2 j of every slab): lane-contiguous 8-byte loads
       float v[64];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const u64 t = get8(hid_rows + (size_t)row * DFF + q * 512 + j0 + 2 * e);
-          v[q * 16 + 2 * e] = __uint_as_float((unsigned)t);
-          v[q * 16 + 2 * e + 1] = __uint_as_float((unsigned)(t >> 32));
-        }
+      for (int e = 0; e < 32; ++e) {
+        const u64 t = get8(hid_rows + (size_t)row * DFF + 64 * e + 2 * j);
+        v[2 * e] = __uint_as_float((unsigned)t);
+        v[2 * e + 1] = __uint_as_float((unsigned)(t >> 32));
       }
       float s = 0.0f;
 #pragma unroll
@@ -218,16 +207,8 @@ __global__ __launch_bounds__(NT) void stream_dec_kernel(const StreamDecArgs a) {
       for (int o = 16; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 64);
       const float rstd = 1.0f / sqrtf(qq * (1.0f / DFF) + a.ln_eps);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        uint4 lo, hi;
-        const float* u = v + q * 16;
-        lo.x = pack_bf16x2((u[0] - mean) * rstd, (u[1] - mean) * rstd); lo.y = pack_bf16x2((u[2] - mean) * rstd, (u[3] - mean) * rstd);
-        lo.z = pack_bf16x2((u[4] - mean) * rstd, (u[5] - mean) * rstd); lo.w = pack_bf16x2((u[6] - mean) * rstd, (u[7] - mean) * rstd);
-        hi.x = pack_bf16x2((u[8] - mean) * rstd, (u[9] - mean) * rstd); hi.y = pack_bf16x2((u[10] - mean) * rstd, (u[11] - mean) * rstd);
-        hi.z = pack_bf16x2((u[12] - mean) * rstd, (u[13] - mean) * rstd); hi.w = pack_bf16x2((u[14] - mean) * rstd, (u[15] - mean) * rstd);
-        *reinterpret_cast<uint4*>(smem + HID + row * HS + (q * 512 + j0) * 2) = lo;
-        *reinterpret_cast<uint4*>(smem + HID + row * HS + (q * 512 + j0) * 2 + 16) = hi;
-      }
+      for (int e = 0; e < 32; ++e)
+        *reinterpret_cast<unsigned*>(smem + HID + row * HS + (64 * e + 2 * j) * 2) = pack_bf16x2((v[2 * e] - mean) * rstd, (v[2 * e + 1] - mean) * rstd);
       wload<16>(w2a, wp2, 0);                                 // (64 f32 of the row are live above: no room to request this across the wait)
     }
     lds_barrier();

@@ -806,9 +806,14 @@ int QwSession::kv_take(size_t eT) {
     DeviceBuffer nk, nv;
     nk.reserve((size_t)new_pages * kv_page_elems() * eT, stream);
     nv.reserve((size_t)new_pages * kv_page_elems() * eT, stream);
-    HIP_CHECK(hipMemcpyAsync(nk.ptr, d_kc.ptr, (size_t)old_pages * kv_page_elems() * eT, hipMemcpyDeviceToDevice, stream));
-    HIP_CHECK(hipMemcpyAsync(nv.ptr, d_vc.ptr, (size_t)old_pages * kv_page_elems() * eT, hipMemcpyDeviceToDevice, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
+    try {
+      HIP_CHECK(hipMemcpyAsync(nk.ptr, d_kc.ptr, (size_t)old_pages * kv_page_elems() * eT, hipMemcpyDeviceToDevice, stream));
+      HIP_CHECK(hipMemcpyAsync(nv.ptr, d_vc.ptr, (size_t)old_pages * kv_page_elems() * eT, hipMemcpyDeviceToDevice, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+    } catch (...) {                                       // (DeviceBuffer has no destructor: a failed copy must not leak the new pools)
+      nk.release(); nv.release();
+      throw;
+    }
     d_kc.release(); d_vc.release();
     d_kc = nk; d_vc = nv;                                 // (the decode graph is keyed on these pointers: it is captured again)
     nk.ptr = nullptr; nk.cap = 0; nv.ptr = nullptr; nv.cap = 0;

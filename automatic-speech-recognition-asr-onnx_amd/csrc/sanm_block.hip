@@ -78,7 +78,7 @@ __device__ __forceinline__ void consume(unsigned* flag, unsigned need, unsigned*
     unsigned spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
       __builtin_amdgcn_s_sleep(2);
-      // a cluster in step waits 0.4 .. 2.5 us here; 2^13 polls (a few tens of ms with the sleep and the L2 round trip) means the cluster is not
+      // a cluster in step waits 0.4 .. 2.5 us here; 2^13 polls (about 8 ms: a poll is a sleep + an L2 round trip, about 1 us) means the cluster is not
       // co-resident: give up, never hang -- the host redoes the pass on the four-launch path and keeps the session there for a while
       if (++spins > (1u << 13)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       if ((spins & 255u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;           // somebody already gave up: the launch is void anyway

@@ -609,6 +609,33 @@ def secondary_lines(cfg, ck, audio_np, local_rank, device, cpu_leg=False):
         del wck
     except Exception as e:                                   # a secondary must never take the headline line down
         out["whisper_large_v3_bf16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # ---- BASELINE configs[4]'s streaming leg: Paraformer-large online, 64 concurrent streams, one 0.5 s chunk per step (the own line: --workload paraformer-streaming)
+    try:
+        pcfg = cfgm.paraformer_large()
+        pck = ckm.synth_paraformer_checkpoint(pcfg, seed=0)
+        S, chunk, n_chunks = 64, 8000, 8
+        ps = eng.ParaformerStreamSession(pcfg, pck, precision=0, device_id=local_rank, chunk=chunk, max_streams=S)
+        pa = torch.from_numpy(np.ascontiguousarray(ckm.synth_audio("kaldi", S, n_chunks * chunk, seed=1234)[:, 0].reshape(S, n_chunks, chunk).transpose(1, 0, 2))).to(device)
+        sids = list(range(S))
+
+        def pstep(i):
+            if i % n_chunks == 0:
+                ps.reset(-1)
+            ps.step(None, sids, audio_device_ptr=pa[i % n_chunks].data_ptr())
+        for i in range(n_chunks):
+            pstep(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(3 * n_chunks):
+            pstep(i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / (3 * n_chunks)
+        out["paraformer_large_streaming_bf16_64streams"] = {"ms_per_chunk_step": round(dt * 1e3, 3), "audio_s_per_s": round(S * chunk / pcfg.sample_rate / dt, 1),
+                                                            "what": "64 streams x one 8000-sample chunk per step, audio resident in HBM, token ids returned to host; encoder layers 1..49 and "
+                                                                    "the decoder blocks as one cluster launch each (csrc/stream_layers.hip, stream_dec.hip)"}
+        del ps, pa, pck
+    except Exception as e:
+        out["paraformer_large_streaming_bf16_64streams"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
 
 

@@ -47,7 +47,7 @@ if os.path.isdir(ssrc):
                       ("bench_encoder_only.json", "bench_paraformer_streaming_encoder_only_n1.json"), ("stream_phase_clock.txt", "stream_phase_clock.txt"),
                       ("sanm_tiles_small_batches.txt", "sanm_tiles_small_batches.txt"), ("bench_qwen_paged1.json", "bench_qwen_n1.json"),
                       ("bench_qwen_paged0.json", "bench_qwen_extents_n1.json"), ("bench_qwen_beam5_paged1.json", "bench_qwen_beam5_n1.json"),
-                      ("bench_sensevoice.json", "bench_n1.json")):
+                      ("bench_sensevoice.json", "bench_n1.json"), ("bench_mixed_beam5.json", "bench_mixed_beam5_n1.json")):
         p = os.path.join(ssrc, name)
         if os.path.isfile(p) and os.path.getsize(p) > 0:
             shutil.copy(p, f"profiles/{rnd}_{out}")

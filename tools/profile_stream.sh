@@ -24,6 +24,7 @@ bash tools/probes/tiles_b1.sh 2>&1 | grep -v amdgpu.ids > $OUT/sanm_tiles_small_
 # Qwen3-ASR: paged KV cache against extents
 for p in 1 0; do ASR_QWEN_KV_PAGED=$p python bench.py --workload qwen --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_qwen_paged$p.json 2> $OUT/bench_qwen_paged$p.err; done
 ASR_QWEN_KV_PAGED=1 python bench.py --workload qwen --beam 5 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_qwen_beam5_paged1.json 2> $OUT/bench_qwen_beam5_paged1.err
+python bench.py --workload mixed --beam 5 --steps 6 --warmup 1 > $OUT/bench_mixed_beam5.json 2> $OUT/bench_mixed_beam5.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/stats -- python $GRAFT_REPO_ROOT/bench.py --workload paraformer-streaming --steps 20 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/stats.log 2>&1
 cd $GRAFT_REPO_ROOT

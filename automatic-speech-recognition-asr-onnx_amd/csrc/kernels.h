@@ -354,7 +354,7 @@ struct SanmTilesArgs {
   bf16_t* kv; size_t kv_parity_stride;                      // exchange buffer of a head's tiles: [block parity][rows][k | v][512], elements between the two
   unsigned* flags; int flag_stride;                         // per layer: [n_tiles][4] + [n_windows][4] counters, zero at launch; flag_stride = words per layer
   unsigned* err;
-  int opt = 0;                                              // tuning: 1 = no L2 warm-up
+  int opt = 0;                                              // tuning: 1 = no L2 warm-up, 2 = a tile's four heads on one XCD instead of placement by head
   unsigned long long* times = nullptr; int times_layer = 0;
 };
 bool sanm_tiles_supported(int max_T, int d, int d_ffn, int n_heads, int d_head, int ktaps);

@@ -82,8 +82,12 @@ __device__ __forceinline__ void put_slab_f32(float* dst_rows, const unsigned cha
 __global__ __launch_bounds__(NT) void sanm_tiles_kernel(const SanmTilesArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid_0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid_0 >> 6);
-  // the four heads of a tile get workgroup ids 8 apart (one XCD, as every cluster kernel of the engine)
-  const int idx = blockIdx.x >> 3, cl = ((idx >> 2) << 3) + (blockIdx.x & 7), h = idx & 3;
+  // Placement BY HEAD (workgroup b runs on XCD b % 8): XCDs 2 h and 2 h + 1 host the workgroups of head h, so an XCD's L2 streams a QUARTER of every matrix
+  // (1.57 MB per block instead of 6.3 MB) -- the meetings go through the memory side anyway, they do not care where a tile's four heads sit. The four
+  // workgroups of a tile are within one group of eight consecutive ids: dispatched together. (a.opt & 2: the older placement, a tile's heads on one XCD.)
+  int cl, h;
+  if (a.opt & 2) { const int idx = blockIdx.x >> 3; cl = ((idx >> 2) << 3) + (blockIdx.x & 7); h = idx & 3; }
+  else { const int x = blockIdx.x & 7; h = x >> 1; cl = (blockIdx.x >> 3) * 2 + (x & 1); }
   if (cl >= a.n_tiles) return;
   const int win = a.tile_win[cl], tile = a.tile_idx[cl];
   const UttPlan up = a.plan[win];
@@ -100,8 +104,11 @@ __global__ __launch_bounds__(NT) void sanm_tiles_kernel(const SanmTilesArgs a) {
   const size_t wave_frag = (size_t)(h * NW + wave);
   u32x4 wa[12];
   wload<12>(wa, a.layers[0].wpack + PK_A + wave_frag * PW_A + (tid_0 & 63) * 16, 0);
-  const int xcd = blockIdx.x & 7, n_wg_xcd = ((a.n_tiles - xcd + 7) >> 3) * NH, wg_xcd = (cl >> 3) * NH + h;
-  unsigned sink = 0, tw = 0;
+  // this workgroup's share of an L2 warm-up: by-head placement -> the XCD needs head h's slice of a phase only, shared by the tiles of its parity
+  const bool by_head = !(a.opt & 2);
+  const int xcd = blockIdx.x & 7;
+  const int n_wg_xcd = by_head ? (a.n_tiles - (xcd & 1) + 1) >> 1 : ((a.n_tiles - xcd + 7) >> 3) * NH, wg_xcd = by_head ? cl >> 1 : (cl >> 3) * NH + h;
+  unsigned sink = 0, tw = 0, twb = 0;          // (warm-up values: consumed only behind a drain of the vector queue)
   for (int e = tid_0; e < (VROWS - MAXT) * (KS / 16); e += NT)              // v rows past the last tile: zero once (P is zero there, the product must be too)
     *reinterpret_cast<u32x4*>(smem + VB + MAXT * KS + e * 16) = u32x4{0, 0, 0, 0};
 
@@ -193,8 +200,13 @@ __global__ __launch_bounds__(NT) void sanm_tiles_kernel(const SanmTilesArgs a) {
         }
       }
     }
-    unsigned tw2 = 0;
-    if (!(a.opt & 1)) tw2 = warm(L.wpack + PK_C, (int)((PK_BYTES - PK_C) / 128), wg_xcd, n_wg_xcd, tid);     // both FFN matrices, under the attention (nothing in it waits on the vector queue)
+    unsigned tw2 = 0, tw2b = 0;
+    if (!(a.opt & 1)) {
+      if (by_head) {                                         // head h's slices of FFN-1 and FFN-2
+        tw2 = warm(L.wpack + PK_C + (size_t)h * NW * PW_C, (int)(NW * PW_C / 128), wg_xcd, n_wg_xcd, tid);
+        tw2b = warm(L.wpack + PK_D + (size_t)h * NW * PW_D, (int)(NW * PW_D / 128), wg_xcd, n_wg_xcd, tid);
+      } else tw2 = warm(L.wpack + PK_C, (int)((PK_BYTES - PK_C) / 128), wg_xcd, n_wg_xcd, tid);
+    }     // both FFN matrices, under the attention (nothing in it waits on the vector queue)
     lds_barrier();
     STAMP(4);
     // ---- attention of the tile's 16 rows over the window: scores on the matrix pipe (wave = key tiles w, w + 8), soft-max in f32, P V on the matrix pipe
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(NT) void sanm_tiles_kernel(const SanmTilesArgs a) {
       const int row = tid >> 5, off = (tid & 31) * 8;
       put8(reinterpret_cast<unsigned char*>(ctx_rows + (size_t)row * D + h * HD) + off, *reinterpret_cast<const u64*>(smem + CTX + row * AS + h * 256 + off));
       publish(flags + 0);
-      sink ^= tw2;                                           // (drained by the publish)
+      sink ^= tw2 ^ tw2b;                                    // (drained by the publish)
       consume(flags + 0, a.err);
 #pragma unroll
       for (int q = 1; q < NH; ++q) {
@@ -358,11 +370,17 @@ __global__ __launch_bounds__(NT) void sanm_tiles_kernel(const SanmTilesArgs a) {
     STAMP(12);
     put_slab_f32(x_rows, smem + XRES, tid, h);
     publish(flags + 3);
-    sink ^= tw;
+    sink ^= tw ^ twb;
     STAMP(13);
     if (li + 1 < a.n_layers) {
       wload<12>(wa, a.layers[li + 1].wpack + PK_A + wave_frag * PW_A + lane * 16, 0);
-      if (!(a.opt & 1)) tw = warm(a.layers[li + 1].wpack + PK_A, (int)((PK_C - PK_A) / 128), wg_xcd, n_wg_xcd, tid);
+      if (!(a.opt & 1)) {
+        const unsigned char* nw = a.layers[li + 1].wpack;
+        if (by_head) {
+          tw = warm(nw + PK_A + (size_t)h * NW * PW_A, (int)(NW * PW_A / 128), wg_xcd, n_wg_xcd, tid);
+          twb = warm(nw + PK_B + (size_t)h * NW * PW_B, (int)(NW * PW_B / 128), wg_xcd, n_wg_xcd, tid);
+        } else tw = warm(nw + PK_A, (int)((PK_C - PK_A) / 128), wg_xcd, n_wg_xcd, tid);
+      }
     }
   }
   if (sink == 0x9e3779b9u && a.n_layers < 0) a.err[1] = sink;
@@ -380,7 +398,7 @@ void launch_sanm_tiles(const SanmTilesArgs& a, hipStream_t s) {
   static PerDeviceOnce attr_once;
   if (attr_once.first())
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sanm_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  const int groups = (a.n_tiles + 7) / 8;
-  hipLaunchKernelGGL(sanm_tiles_kernel, dim3(groups * 32), dim3(NT), LDS_BYTES, s, a);
+  const int n_wgs = (a.opt & 2) ? (a.n_tiles + 7) / 8 * 32 : (a.n_tiles + 1) / 2 * 8;
+  hipLaunchKernelGGL(sanm_tiles_kernel, dim3(n_wgs), dim3(NT), LDS_BYTES, s, a);
   HIP_CHECK(hipGetLastError());
 }

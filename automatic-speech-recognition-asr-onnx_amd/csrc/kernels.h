@@ -332,7 +332,7 @@ struct StreamLayersArgs {
   float* x;                                                 // [rows][512] residual stream: in = rows entering the first layer of the table, out = rows leaving the last
   float* xb; bf16_t* ctx; bf16_t* hid;                      // the clusters' exchange buffers [rows][512] f32, [rows][512], [rows][2048]
   unsigned* flags;                                          // [n_layers][n_streams][4] counters, zero at launch
-  int opt = 0;                                              // tuning: 1 = no L2 warm-up of the next phase's weights, 2 = FFN weights warmed while waiting for exchanges 1 / 2 instead of under the attention; bits 4..6 = phases (A, C, D) whose second weight batch is requested right behind the exchanged rows
+  int opt = 0;                                              // tuning: 1 = no L2 warm-up of the next phase's weights, 2 = FFN weights warmed while waiting for exchanges 1 / 2 instead of under the attention, 8 = a stream's four heads on one XCD instead of placement by head; bits 4..6 = phases (A, C, D) whose second weight batch is requested right behind the exchanged rows
   unsigned* err;                                            // raised by a cluster that gave up waiting (the launch's results are void)
   unsigned long long* times = nullptr; int times_layer = 0; // tuning: thread 0 of every workgroup stamps wall_clock64() at 13 points of layer `times_layer` ([wg][16])
 };
@@ -380,7 +380,7 @@ struct StreamDecArgs {
   float* x1; float* x2; float* hid; bf16_t* ctx;            // exchange buffers [rows][512] f32 x 2, [rows][2048] f32, [rows][512] bf16
   unsigned* flags;                                          // [n_layers][n_streams][8] counters, zero at launch
   unsigned* err;
-  int opt = 0;                                              // tuning: 1 = no L2 warm-up
+  int opt = 0;                                              // tuning: 1 = no L2 warm-up, 8 = placement by head (the encoder launch's default; slower here)
   unsigned long long* times = nullptr; int times_layer = 0;
 };
 size_t stream_dec_pack_bytes();

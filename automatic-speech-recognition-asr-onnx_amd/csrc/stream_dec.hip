@@ -100,7 +100,11 @@ __device__ __forceinline__ void put_slab_f32(float* dst_rows, const unsigned cha
 __global__ __launch_bounds__(NT) void stream_dec_kernel(const StreamDecArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid_0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid_0 >> 6);
-  const int idx = blockIdx.x >> 3, cl = ((idx >> 2) << 3) + (blockIdx.x & 7), h = idx & 3;       // cluster members: workgroup ids 8 apart (one XCD)
+  // cluster members: workgroup ids 8 apart (one XCD). a.opt & 8: placement by head as in the encoder launch (XCDs 2 h, 2 h + 1 host head h) -- measured SLOWER here
+  // (0.73 against 0.69 ms: the 128 KB f32 hid meeting is read by four workgroups that then sit on four XCDs)
+  int cl, h;
+  if (!(a.opt & 8)) { const int idx = blockIdx.x >> 3; cl = ((idx >> 2) << 3) + (blockIdx.x & 7); h = idx & 3; }
+  else { const int x = blockIdx.x & 7; h = x >> 1; cl = (blockIdx.x >> 3) * 2 + (x & 1); }
   if (cl >= a.n_streams) return;
   const UttPlan tp = a.token_plan[cl];
   const int T = __builtin_amdgcn_readfirstlane(tp.T), sid = tp.lang, row0 = tp.row_off, n_cur = a.n_cur;
@@ -117,7 +121,9 @@ __global__ __launch_bounds__(NT) void stream_dec_kernel(const StreamDecArgs a) {
   float* hid_rows = a.hid + (size_t)row0 * DFF;
   bf16_t* ctx_rows = a.ctx + (size_t)row0 * D;
   const size_t wave_frag = (size_t)(h * NW + wave);
-  const int xcd = blockIdx.x & 7, n_wg_xcd = ((a.n_streams - xcd + 7) >> 3) * NH, wg_xcd = (cl >> 3) * NH + h;
+  const bool by_head = (a.opt & 8) != 0;
+  const int xcd = blockIdx.x & 7;
+  const int n_wg_xcd = by_head ? (a.n_streams - (xcd & 1) + 1) >> 1 : ((a.n_streams - xcd + 7) >> 3) * NH, wg_xcd = by_head ? cl >> 1 : (cl >> 3) * NH + h;
   unsigned sink = 0, tw = 0;
   {   // the chunk's encoder rows (bf16, after_norm), once
     const bf16_t* er = a.enc + (size_t)row0 * D;
@@ -417,7 +423,10 @@ __global__ __launch_bounds__(NT) void stream_dec_kernel(const StreamDecArgs a) {
     STAMP(13);
     if (li + 1 < a.n_layers) {
       wload<16>(w1a, a.layers[li + 1].wpack + PK_1 + wave_frag * PW_1 + lane * 16, 0);
-      if (!(a.opt & 1)) tw = warm(a.layers[li + 1].wpack + PK_1, (int)((PK_2 - PK_1) / 128), wg_xcd, n_wg_xcd, tid);
+      if (!(a.opt & 1)) {
+        if (by_head) tw = warm(a.layers[li + 1].wpack + PK_1 + (size_t)h * NW * PW_1, (int)(NW * PW_1 / 128), wg_xcd, n_wg_xcd, tid);
+        else tw = warm(a.layers[li + 1].wpack + PK_1, (int)((PK_2 - PK_1) / 128), wg_xcd, n_wg_xcd, tid);
+      }
     }
   }
   if (sink == 0x9e3779b9u && a.n_layers < 0) a.err[1] = sink;            // (keeps the warm-up loads; never true)
@@ -474,7 +483,7 @@ void launch_stream_dec(const StreamDecArgs& a, hipStream_t s) {
   static PerDeviceOnce attr_once;
   if (attr_once.first())
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_dec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  const int groups = (a.n_streams + 7) / 8;
-  hipLaunchKernelGGL(stream_dec_kernel, dim3(groups * 32), dim3(NT), LDS_BYTES, s, a);
+  const int n_wgs = !(a.opt & 8) ? (a.n_streams + 7) / 8 * 32 : (a.n_streams + 1) / 2 * 8;
+  hipLaunchKernelGGL(stream_dec_kernel, dim3(n_wgs), dim3(NT), LDS_BYTES, s, a);
   HIP_CHECK(hipGetLastError());
 }

@@ -99,7 +99,12 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid_0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid_0 >> 6);
   // cluster placement: workgroup b runs on XCD b % 8 (observed, not relied upon): the four workgroups of a stream get ids 8 apart
-  const int idx = blockIdx.x >> 3, cl = ((idx >> 2) << 3) + (blockIdx.x & 7), h = idx & 3;
+  // (round 4, late: placement BY HEAD instead -- XCDs 2 h and 2 h + 1 host the workgroups of head h, so an XCD's L2 streams a quarter of every matrix; the
+  //  meetings go through the memory side and do not care where a stream's four heads sit; a stream's workgroups stay within one group of eight ids.
+  //  a.opt & 8: the old placement, a stream's heads on one XCD)
+  int cl, h;
+  if (a.opt & 8) { const int idx = blockIdx.x >> 3; cl = ((idx >> 2) << 3) + (blockIdx.x & 7); h = idx & 3; }
+  else { const int x = blockIdx.x & 7; h = x >> 1; cl = (blockIdx.x >> 3) * 2 + (x & 1); }
   if (cl >= a.n_streams) return;
   const UttPlan up = a.plan[cl];
   const int sid = up.lang, row0 = up.row_off, n_cur = a.n_cur;
@@ -116,8 +121,10 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
   u32x4 wa[12];                                                            // batch 0 of phase A: requested a layer ahead
   wload<12>(wa, a.layers[0].wpack + PK_A + wave_frag * PW_A + (tid_0 & 63) * 16, 0);
   // this workgroup's place among the workgroups of its XCD (workgroup b runs on XCD b % 8): its share of every L2 warm-up
-  const int xcd = blockIdx.x & 7, n_wg_xcd = ((a.n_streams - xcd + 7) >> 3) * NH, wg_xcd = (cl >> 3) * NH + h;
-  unsigned sink = 0, tw = 0;
+  const bool by_head = !(a.opt & 8);
+  const int xcd = blockIdx.x & 7;
+  const int n_wg_xcd = by_head ? (a.n_streams - (xcd & 1) + 1) >> 1 : ((a.n_streams - xcd + 7) >> 3) * NH, wg_xcd = by_head ? cl >> 1 : (cl >> 3) * NH + h;
+  unsigned sink = 0, tw = 0, twb = 0;
 
 #pragma unroll 1
   for (int li = 0; li < a.n_layers; ++li) {
@@ -201,7 +208,13 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
       __builtin_amdgcn_sched_barrier(0);
     }
     unsigned tw2 = 0;
-    if (!(a.opt & 3)) tw2 = warm(L.wpack + PK_C, (int)((PK_BYTES - PK_C) / 128), wg_xcd, n_wg_xcd, tid);     // both FFN matrices, under the attention (nothing in it waits on the vector queue)
+    unsigned tw2b = 0;
+    if (!(a.opt & 3)) {                                      // both FFN matrices (by-head placement: head h's slices), under the attention (nothing in it waits on the vector queue)
+      if (by_head) {
+        tw2 = warm(L.wpack + PK_C + (size_t)h * NW * PW_C, (int)(NW * PW_C / 128), wg_xcd, n_wg_xcd, tid);
+        tw2b = warm(L.wpack + PK_D + (size_t)h * NW * PW_D, (int)(NW * PW_D / 128), wg_xcd, n_wg_xcd, tid);
+      } else tw2 = warm(L.wpack + PK_C, (int)((PK_BYTES - PK_C) / 128), wg_xcd, n_wg_xcd, tid);
+    }
     // ---- attention of the slot's 16 rows over [history | chunk rows]: scores on the matrix pipe (wave = one 16-key tile), soft-max in f32 (wave = two rows),
     //      P (bf16) V on the matrix pipe (wave = 16 channels; the V fragment is gathered down the key axis of the row-major image)
     if (wave * 16 < nk) {
@@ -311,7 +324,7 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
     STAMP(6);
     put_slab_f32(xb_rows, smem + XB, tid, h);
     publish(flags + 1);
-    sink ^= tw ^ tw2;                                               // (drained by the publish)
+    sink ^= tw ^ twb ^ tw2 ^ tw2b;                                               // (drained by the publish)
     u32x4 wc0[16], wc1[16];
     wload<16>(wc0, wpC, 0);
     if ((a.opt & 3) == 2) tw = warm(L.wpack + PK_C, (int)((PK_D - PK_C) / 128), wg_xcd, n_wg_xcd, tid);
@@ -386,7 +399,13 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
     STAMP(12);
     if (li + 1 < a.n_layers) {
       wload<12>(wa, a.layers[li + 1].wpack + PK_A + wave_frag * PW_A + lane * 16, 0);
-      if (!(a.opt & 1)) tw = warm(a.layers[li + 1].wpack + PK_A, (int)((PK_C - PK_A) / 128), wg_xcd, n_wg_xcd, tid);      // q|k|v and out-projection of the next layer
+      if (!(a.opt & 1)) {                                    // q|k|v and out-projection of the next layer
+        const unsigned char* nw = a.layers[li + 1].wpack;
+        if (by_head) {
+          tw = warm(nw + PK_A + (size_t)h * NW * PW_A, (int)(NW * PW_A / 128), wg_xcd, n_wg_xcd, tid);
+          twb = warm(nw + PK_B + (size_t)h * NW * PW_B, (int)(NW * PW_B / 128), wg_xcd, n_wg_xcd, tid);
+        } else tw = warm(nw + PK_A, (int)((PK_C - PK_A) / 128), wg_xcd, n_wg_xcd, tid);
+      }
     }
   }
   if (sink == 0x9e3779b9u && a.n_layers < 0) a.err[1] = sink;            // (keeps the warm-up loads; never true)
@@ -442,14 +461,14 @@ void launch_stream_layers(const StreamLayersArgs& a, hipStream_t s) {
   ASR_REQUIRE(a.n_streams >= 1 && a.n_layers >= 1 && a.cap + SLOT <= MAXK && a.n_cur <= SLOT && a.ktaps == TAPS, "stream_layers: bad geometry");
   static PerDeviceOnce attr_once;
   const bool first = attr_once.first();
-  const int groups = (a.n_streams + 7) / 8;
+  const int n_wgs = (a.opt & 8) ? (a.n_streams + 7) / 8 * 32 : (a.n_streams + 1) / 2 * 8;
   const int pfm = 7 & (a.opt >> 4);
   auto go = [&](auto tag) {
     constexpr int PFM = decltype(tag)::value;
     if (first) {
       static_for_attr<0>();
     }
-    hipLaunchKernelGGL(stream_layers_kernel<PFM>, dim3(groups * 32), dim3(NT), LDS_BYTES, s, a);
+    hipLaunchKernelGGL(stream_layers_kernel<PFM>, dim3(n_wgs), dim3(NT), LDS_BYTES, s, a);
   };
   switch (pfm) {
     case 0: go(std::integral_constant<int, 0>{}); break;

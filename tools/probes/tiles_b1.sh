@@ -1,6 +1,6 @@
 #!/bin/bash
 # SenseVoiceSmall bf16, small batches of 8 s windows: the tile kernel (with warmer workgroups / self-warming) against the four-launch path, ms per batch.
-for t in "1 0" "1 1" "0 0"; do
+for t in "1 0" "1 1" "1 2" "0 0"; do
   set -- $t
   echo "== ASR_SANM_TILES=$1 ASR_SANM_TILES_OPT=$2"
   ASR_SANM_TILES=$1 ASR_SANM_TILES_OPT=$2 python - <<'PY'

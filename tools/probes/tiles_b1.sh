@@ -1,5 +1,5 @@
 #!/bin/bash
-# SenseVoiceSmall bf16, small batches of 8 s windows: the tile kernel (with warmer workgroups / self-warming) against the four-launch path, ms per batch.
+# SenseVoiceSmall bf16, small batches of 8 s windows, ms per batch: the tile kernel (ASR_SANM_TILES_OPT 0 default, 1 no L2 warm-up, 2 a tile's four heads on one XCD) against the four-launch path (ASR_SANM_TILES=0).
 for t in "1 0" "1 1" "1 2" "0 0"; do
   set -- $t
   echo "== ASR_SANM_TILES=$1 ASR_SANM_TILES_OPT=$2"

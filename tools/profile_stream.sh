@@ -15,7 +15,7 @@ ASR_STREAM_FUSED=1 python bench.py --workload paraformer-streaming --no-cpu-base
   ASR_STREAM_TIMES=-5 ASR_NO_GRAPH=1 python bench.py --workload paraformer-streaming --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | grep "stream_dec layer" | tail -3
   echo "# 8 streams (one cluster per XCD: no sharing of the L2 / fabric)"
   ASR_STREAM_TIMES=20 ASR_NO_GRAPH=1 python bench.py --workload paraformer-streaming --batch 8 --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | grep "stream_layers layer" | tail -1
-  echo "# tuning switches (ASR_STREAM_OPT, kernels.h: StreamLayersArgs::opt): 0 default, 1 no L2 warm-up, 2 FFN warm-up while waiting, 112 second weight batch behind the exchanged rows"
+  echo "# tuning switches (ASR_STREAM_OPT, kernels.h: StreamLayersArgs::opt): 0 default, 1 no L2 warm-up, 2 FFN warm-up while waiting, 8 a stream's four heads on one XCD (placement of the first version)"
   bash tools/probes/stream_opt_ab.sh 2>&1 | grep -v "^  File\|^    \|Traceback\|json"
 } > $OUT/stream_phase_clock.txt
 # small batches: the tile kernel against the four-launch path, and its phase clock

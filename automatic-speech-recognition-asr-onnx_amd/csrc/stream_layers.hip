@@ -6,10 +6,10 @@
 // 6.3 MB of weights -- weight-streaming work, and seven launches of it per layer spend their time filling and draining the chip (round 3:
 // 520 launches, 5.2 ms per step). Here the step's layer loop is one launch of (streams x 4) workgroups:
 //
-//   * the four workgroups (s, h) of stream s form a CLUSTER on one XCD (workgroup ids 8 apart); workgroup h owns head h of the attention and
-//     column slab h of every GEMM; the cluster meets four times per layer (ctx, x1, hid, x) through memory: agent-scope write-through stores
-//     and agent-scope loads of the payload, one relaxed counter per exchange -- no fence, no L2 invalidate, the weights stay in the XCD's L2
-//     for the eight clusters that share it;
+//   * the four workgroups (s, h) of stream s form a CLUSTER; workgroup h owns head h of the attention and column slab h of every GEMM; the
+//     cluster meets four times per layer (ctx, x1, hid, x) through memory: agent-scope write-through stores and agent-scope loads of the
+//     payload, one relaxed counter per exchange -- no fence, no L2 invalidate. Placement is by HEAD (XCDs 2 h and 2 h + 1 host head h's
+//     workgroups): the meetings do not care where a stream's heads sit, and an XCD's L2 then streams a quarter of every matrix;
 //   * a slot is ONE 16-row MFMA tile: wave w of 8 multiplies the slot by its own 48 / 16 / 64 / 16 output columns with the whole K in its
 //     own registers' stream: weights come straight from a fragment-major copy of the layer (`launch_stream_layers_pack`: one contiguous KB
 //     per wave instruction, in consumption order), 12-16 KB per wave in flight, and the first batch of the NEXT phase is requested before the
@@ -98,7 +98,7 @@ template <int PFM>          // phases whose second weight batch is requested rig
 __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid_0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid_0 >> 6);
-  // cluster placement: workgroup b runs on XCD b % 8 (observed, not relied upon): the four workgroups of a stream get ids 8 apart
+  // cluster placement: workgroup b runs on XCD b % 8 (observed; nothing but speed depends on it)
   // (round 4, late: placement BY HEAD instead -- XCDs 2 h and 2 h + 1 host the workgroups of head h, so an XCD's L2 streams a quarter of every matrix; the
   //  meetings go through the memory side and do not care where a stream's four heads sit; a stream's workgroups stay within one group of eight ids.
   //  a.opt & 8: the old placement, a stream's heads on one XCD)

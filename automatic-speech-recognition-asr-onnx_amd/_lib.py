@@ -65,6 +65,7 @@ SIGNATURES = {
     "asr_paraformer_stream_create": (_i, [C.POINTER(ParaformerConfigC), _vp, _sz, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "asr_paraformer_stream_reset": (_i, [_vp, _i]),
     "asr_paraformer_stream_step": (_i, [_vp, _vp, _i, _ip, _i, _ip, _i, _ip]),
+    "asr_paraformer_stream_stats": (_i, [_vp, _ip]),
     "asr_whisper_create": (_i, [C.POINTER(WhisperConfigC), _vp, _sz, _i, _i, _i, C.POINTER(_vp)]),
     "asr_whisper_encode": (_i, [_vp, _vp, _i, _lp, _i, _ip]),
     "asr_whisper_prefill": (_i, [_vp, _ip, _i, _ip, _fp]),

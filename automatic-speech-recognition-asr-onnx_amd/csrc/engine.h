@@ -80,6 +80,7 @@ struct Tap {
 struct asr_session {
   int kind = 0;               // 1 = sensevoice, 2 = whisper
   int device = 0;
+  int tenant_slot = -1;       // this session's entry in the process-wide tenancy table (asr_tenant_attach; released by the destructor)
   int precision = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -87,7 +88,7 @@ struct asr_session {
   Profiler prof;
   bool taps_enabled = false;
   std::map<std::string, Tap> taps;
-  virtual ~asr_session() {}
+  virtual ~asr_session();
   void save_tap(const char* name, const void* src, int64_t rows, int64_t cols, int64_t ld_src, int elt);
 };
 
@@ -106,3 +107,11 @@ int asr_guard(F&& f) {
 }
 
 void asr_require_device(int device_id);
+
+// ---- who else uses this GPU (process-wide). The cluster kernels of the streaming path (and the block kernel) hold every CU for a whole launch and wait on
+// sibling workgroups; next to another session's kernels that costs the other tenant its CUs (Qwen3-ASR 3 415 -> 319 audio-s/s beside 1 024 cluster
+// workgroups) and can void the launch. Every session registers at creation; every compute entry point holds a TenantScope while it runs.
+void asr_tenant_attach(asr_session* s);                                         // after s->device is set
+struct TenantScope { asr_session* s; explicit TenantScope(asr_session* s_); ~TenantScope(); };
+int asr_tenant_live_others(const asr_session* s);                              // other sessions that exist on s->device
+int asr_tenant_busy_others(const asr_session* s, double window_ms);            // ... that are inside a compute call now, or left one less than window_ms ago

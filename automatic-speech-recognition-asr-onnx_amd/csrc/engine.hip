@@ -189,3 +189,50 @@ void asr_session::save_tap(const char* name, const void* src, int64_t rows, int6
   HIP_CHECK(hipMemcpy2DAsync(t.buf.ptr, (size_t)cols * elt, src, (size_t)ld_src * elt, (size_t)cols * elt, (size_t)rows,
                              hipMemcpyDeviceToDevice, stream));
 }
+
+// ---- tenancy table (engine.h)
+#include <atomic>
+#include <chrono>
+namespace {
+constexpr int TENANT_SLOTS = 512;
+struct TenantSlot { std::atomic<int> used{0}, device{-1}, busy{0}; std::atomic<int64_t> last_ns{0}; };
+TenantSlot g_tenants[TENANT_SLOTS];
+int64_t tenant_now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+void asr_tenant_attach(asr_session* s) {
+  if (!s || s->tenant_slot >= 0) return;
+  for (int i = 0; i < TENANT_SLOTS; ++i) {
+    int expect = 0;
+    if (g_tenants[i].used.compare_exchange_strong(expect, 1)) {
+      g_tenants[i].device.store(s->device); g_tenants[i].busy.store(0); g_tenants[i].last_ns.store(0);
+      s->tenant_slot = i;
+      return;
+    }
+  }          // (table full: the session stays anonymous -- it is then never counted, which only ever errs towards the faster path)
+}
+asr_session::~asr_session() {
+  if (tenant_slot >= 0) { g_tenants[tenant_slot].device.store(-1); g_tenants[tenant_slot].used.store(0); tenant_slot = -1; }
+}
+TenantScope::TenantScope(asr_session* s_) : s(s_) {
+  if (s && s->tenant_slot >= 0) { g_tenants[s->tenant_slot].device.store(s->device); g_tenants[s->tenant_slot].busy.fetch_add(1); }
+}
+TenantScope::~TenantScope() {
+  if (s && s->tenant_slot >= 0) { g_tenants[s->tenant_slot].last_ns.store(tenant_now_ns()); g_tenants[s->tenant_slot].busy.fetch_sub(1); }
+}
+int asr_tenant_live_others(const asr_session* s) {
+  int n = 0;
+  for (int i = 0; i < TENANT_SLOTS; ++i)
+    if (i != s->tenant_slot && g_tenants[i].used.load() && g_tenants[i].device.load() == s->device) ++n;
+  return n;
+}
+int asr_tenant_busy_others(const asr_session* s, double window_ms) {
+  const int64_t now = tenant_now_ns(), win = (int64_t)(window_ms * 1e6);
+  int n = 0;
+  for (int i = 0; i < TENANT_SLOTS; ++i) {
+    if (i == s->tenant_slot || !g_tenants[i].used.load() || g_tenants[i].device.load() != s->device) continue;
+    const int64_t last = g_tenants[i].last_ns.load();
+    if (g_tenants[i].busy.load() > 0 || (last != 0 && now - last < win)) ++n;
+  }
+  return n;
+}

@@ -138,9 +138,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp(const GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < 2; ++jj) {
           if constexpr (SWAP) acc[ha * 4 + i][hb * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][jj], af[kk][i], acc[ha * 4 + i][hb * 2 + jj], 0, 0, 0);
           else acc[ha * 4 + i][hb * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], wf[kk][jj], acc[ha * 4 + i][hb * 2 + jj], 0, 0, 0);
+        }
     if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     stamp(3);
@@ -324,9 +325,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_ppp(const GemmArgs g, const 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < 2; ++jj) {
           if constexpr (SWAP) acc[ha * 4 + i][hb * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][jj], af[kk][i], acc[ha * 4 + i][hb * 2 + jj], 0, 0, 0);
           else acc[ha * 4 + i][hb * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], wf[kk][jj], acc[ha * 4 + i][hb * 2 + jj], 0, 0, 0);
+        }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
   };

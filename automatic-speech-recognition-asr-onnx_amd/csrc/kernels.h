@@ -315,6 +315,12 @@ void launch_stream_dec_fsmn(const float* x, const float* res, const float* w, in
                             float* hist, float* out, hipStream_t s);
 void launch_stream_advance(const UttPlan* plan, const UttPlan* token_plan, int n_active, int en_add, int en_cap, int de_add, int de_cap,
                            int32_t* en_len, int32_t* de_len, hipStream_t s);
+// Snapshot / restore of the recurrent state of the ACTIVE streams of a chunk step (K/V histories of every layer, decoder FSMN histories, carried rows, CIF
+// state, history lengths): a fused chunk step whose cluster launch gave up has rolled the histories of the layers in front of the one that stalled, so the step
+// can only be redone (on the per-launch path) from a copy taken in front of it. A segment = one state buffer laid out [outer][stream][per_stream bytes];
+// the shadow has the same layout. restore = false: live -> shadow, true: shadow -> live.
+struct StreamStateSeg { unsigned char* live; unsigned char* shadow; unsigned long long per_stream, outer_stride; int n_outer, first_item; };
+void launch_stream_state_copy(const StreamStateSeg* segs, int n_segs, int n_items, const UttPlan* plan, int n_active, bool restore, hipStream_t s);
 
 // ---- Paraformer online encoder layers of one chunk step as ONE launch (stream_layers.hip): clusters of four workgroups per stream, weights streamed
 // from a fragment-major copy of every layer. bf16 sessions, d = 512 / 4 heads / d_ffn = 2048 / history + 16 <= 64 keys.
@@ -335,6 +341,7 @@ struct StreamLayersArgs {
   int opt = 0;                                              // tuning: 1 = no L2 warm-up of the next phase's weights, 2 = FFN weights warmed while waiting for exchanges 1 / 2 instead of under the attention, 8 = a stream's four heads on one XCD instead of placement by head; bits 4..6 = phases (A, C, D) whose second weight batch is requested right behind the exchanged rows
   unsigned* err;                                            // raised by a cluster that gave up waiting (the launch's results are void)
   unsigned long long* times = nullptr; int times_layer = 0; // tuning: thread 0 of every workgroup stamps wall_clock64() at 13 points of layer `times_layer` ([wg][16])
+  int fault = 0;                                            // tests: workgroup 5 withholds its count on the first exchange of the first layer (its cluster gives up)
 };
 size_t stream_layers_pack_bytes();
 void launch_stream_layers_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, hipStream_t s);

@@ -2120,3 +2120,25 @@ void launch_stream_advance(const UttPlan* plan, const UttPlan* token_plan, int n
                      de_cap, en_len, de_len);
   HIP_CHECK(hipGetLastError());
 }
+
+
+// ---- snapshot / restore of the active streams' recurrent state (kernels.h: StreamStateSeg). blockIdx.x = active stream, blockIdx.y = (segment, outer index)
+__global__ __launch_bounds__(256) void stream_state_copy_kernel(const StreamStateSeg* segs, int n_segs, const UttPlan* plan, int restore) {
+  const int item = blockIdx.y;
+  int sg = 0;
+  while (sg + 1 < n_segs && segs[sg + 1].first_item <= item) ++sg;
+  const StreamStateSeg g = segs[sg];
+  const int sid = plan[blockIdx.x].lang;
+  const size_t off = (size_t)(item - g.first_item) * g.outer_stride + (size_t)sid * g.per_stream;
+  const unsigned char* src = (restore ? g.shadow : g.live) + off;
+  unsigned char* dst = (restore ? g.live : g.shadow) + off;
+  if ((g.per_stream & 15) == 0) {
+    for (size_t i = threadIdx.x; i < g.per_stream / 16; i += 256) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+  } else {
+    for (size_t i = threadIdx.x; i < g.per_stream / 4; i += 256) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(src)[i];
+  }
+}
+void launch_stream_state_copy(const StreamStateSeg* segs, int n_segs, int n_items, const UttPlan* plan, int n_active, bool restore, hipStream_t s) {
+  hipLaunchKernelGGL(stream_state_copy_kernel, dim3(n_active, n_items), dim3(256), 0, s, segs, n_segs, plan, restore ? 1 : 0);
+  HIP_CHECK(hipGetLastError());
+}

@@ -829,8 +829,11 @@ int QwSession::kv_take(size_t eT) {
 void QwSession::kv_begin(int B, const std::vector<int>& lens, size_t eT) {
   const auto& c = cfg;
   kv_pps = (c.max_seq_len + 15) / 16;
+  // pages of a prompt + the first generated position, never more than a sequence can hold: a prompt of exactly max_seq_len positions (prefill accepts it)
+  // has no next position to reserve -- (S + 16) / 16 would be kv_pps + 1 and the fill loop would write one entry past the sequence's table row
+  auto prompt_pages = [&](int len) { return std::min((len + 1 + 15) / 16, kv_pps); };
   int need = 1;
-  for (int b = 0; b < B; ++b) need += (lens[b] + 1 + 15) / 16;
+  for (int b = 0; b < B; ++b) need += prompt_pages(lens[b]);
   if (need > kv_pool_pages) {                             // nothing to keep across batches: a fresh pool
     d_kc.release(); d_vc.release();
     d_kc.reserve((size_t)need * kv_page_elems() * eT, stream);
@@ -848,7 +851,7 @@ void QwSession::kv_begin(int B, const std::vector<int>& lens, size_t eT) {
   kv_released.assign(B, 0);
   kv_high_water = 0;
   for (int b = 0; b < B; ++b)
-    for (int j = 0; j < (lens[b] + 1 + 15) / 16; ++j) { const int p = kv_take(eT); kv_owned[b].push_back(p); kv_table[(size_t)b * kv_pps + j] = p; }
+    for (int j = 0; j < prompt_pages(lens[b]); ++j) { const int p = kv_take(eT); kv_owned[b].push_back(p); kv_table[(size_t)b * kv_pps + j] = p; }
   d_kvtab.reserve(kv_table.size() * 4, stream);
   kv_table_dirty = true;
   kv_upload();
@@ -1407,8 +1410,13 @@ void QwSession::step(const int32_t* ids_host, int32_t* next_out, float* logits_o
   ASR_REQUIRE(batch > 0, "qwen_decode: prefill first");
   HIP_CHECK(hipSetDevice(device));
   const int B = batch, d = c.d_model, Mb = round_up(B, 128);
-  for (int b = 0; b < B; ++b)
+  for (int b = 0; b < B; ++b) {
     ASR_REQUIRE(seq_len[b] + 1 <= c.max_seq_len || (b < (int)frozen.size() && frozen[b]), "qwen_decode: sequence %d is at max_seq_len %d", b, c.max_seq_len);
+    // a sequence that generate() finished has given its cache pages back (its table row points at the scratch page): it cannot be stepped again outside that
+    // generate() call -- fail loudly instead of decoding against page 0
+    ASR_REQUIRE(!(kv_paged && b < (int)kv_released.size() && kv_released[b]) || (b < (int)frozen.size() && frozen[b]),
+                "qwen_decode: sequence %d was finished by generate() and its cache pages were returned; prefill again", b);
+  }
   if (ids_host) {
     int32_t* st = (int32_t*)pinned(h_ids, h_ids_cap, (size_t)B * 4);
     for (int b = 0; b < B; ++b) {
@@ -1586,6 +1594,7 @@ extern "C" int asr_qwen_create(const asr_qwen_config* cfg, const void* arena, si
     try {
       s->kind = 5;
       s->device = device_id;
+      asr_tenant_attach(s);
       s->precision = precision;
       s->cfg = *cfg;
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -1611,6 +1620,7 @@ extern "C" int asr_qwen_prefill(asr_session* s, const float* audio, int audio_me
                                 float* logits_out, int32_t* ids_len_out) {
   return asr_guard([&] {
     ASR_REQUIRE(s && s->kind == 5, "qwen_prefill: not a Qwen3-ASR session");
+    TenantScope tenant(s);
     QwSession* q = static_cast<QwSession*>(s);
     if (q->precision == ASR_PRECISION_BF16)
       q->prefill<bf16_t>(audio, audio_mem, audio_offsets, batch, pre_ids, pre_offsets, post_ids, post_offsets, next_ids_out, logits_out, ids_len_out);
@@ -1622,6 +1632,7 @@ extern "C" int asr_qwen_prefill(asr_session* s, const float* audio, int audio_me
 extern "C" int asr_qwen_decode(asr_session* s, const int32_t* ids, int32_t* next_ids_out, float* logits_out) {
   return asr_guard([&] {
     ASR_REQUIRE(s && s->kind == 5, "qwen_decode: not a Qwen3-ASR session");
+    TenantScope tenant(s);
     QwSession* q = static_cast<QwSession*>(s);
     if (q->precision == ASR_PRECISION_BF16) q->step<bf16_t>(ids, next_ids_out, logits_out);
     else q->step<float>(ids, next_ids_out, logits_out);
@@ -1684,6 +1695,7 @@ extern "C" int asr_qwen_beam_search(asr_session* s, int beam, int max_new, const
                                     float* scores_out) {
   return asr_guard([&] {
     ASR_REQUIRE(s && s->kind == 5 && tokens_out && n_out && max_new >= 1 && n_stop >= 0 && (n_stop == 0 || stop_ids), "qwen_beam_search: bad argument");
+    TenantScope tenant(s);
     QwSession* q = static_cast<QwSession*>(s);
     if (q->precision == ASR_PRECISION_BF16) q->beam_search<bf16_t>(beam, max_new, stop_ids, n_stop, tokens_out, n_out, scores_out);
     else q->beam_search<float>(beam, max_new, stop_ids, n_stop, tokens_out, n_out, scores_out);
@@ -1703,6 +1715,7 @@ extern "C" int asr_qwen_kv_stats(asr_session* s, int32_t* out4) {
 extern "C" int asr_qwen_generate(asr_session* s, int max_new, const int32_t* stop_ids, int n_stop, int32_t* tokens_out, int32_t* n_out) {
   return asr_guard([&] {
     ASR_REQUIRE(s && s->kind == 5 && tokens_out && n_out && max_new >= 1 && (n_stop == 0 || stop_ids), "qwen_generate: bad argument");
+    TenantScope tenant(s);
     QwSession* q = static_cast<QwSession*>(s);
     ASR_REQUIRE(q->batch > 0, "qwen_generate: prefill first");
     const int B = q->batch;
@@ -1712,6 +1725,7 @@ extern "C" int asr_qwen_generate(asr_session* s, int max_new, const int32_t* sto
     HIP_CHECK(hipStreamSynchronize(q->stream));
     std::vector<char> done(B, 0);
     for (int b = 0; b < B; ++b) n_out[b] = 0;
+    struct ClearFrozen { QwSession* q; ~ClearFrozen() { q->frozen.clear(); } } clear_frozen{q};      // also when a step throws: a stale list would release live sequences' pages
     auto is_stop = [&](int32_t t) { for (int i = 0; i < n_stop; ++i) if (stop_ids[i] == t) return true; return false; };
     for (int t = 0; t < max_new; ++t) {
       bool all_done = true, room = true;
@@ -1730,6 +1744,5 @@ extern "C" int asr_qwen_generate(asr_session* s, int max_new, const int32_t* sto
       if (q->precision == ASR_PRECISION_BF16) q->step<bf16_t>(nullptr, cur.data(), nullptr);
       else q->step<float>(nullptr, cur.data(), nullptr);
     }
-    q->frozen.clear();
   });
 }

@@ -42,7 +42,7 @@ constexpr int QS = 0, KS = QS + R * 256, KEYS = 160, VS = KS + KEYS * 256, IMG_E
 constexpr int LDS_BYTES = 160 * 1024;                                      // the whole CU: one workgroup per CU
 constexpr int ST_F = LDS_BYTES - R * 8;                                    // (mean, rstd) [144] float2, at the very end
 constexpr int ST_P = ST_F - 4 * R * 8;                                     // statistics partials [4][144] float2
-constexpr int MEM_BYTES = R * HD * 4;                                      // FSMN term, f32 [144][128] at offset 0 (over the dead q / k images)
+static_assert(R * HD * 4 <= ST_P, "the FSMN term (f32 [144][128] at offset 0, over the dead q / k images) overlaps the statistics");
 static_assert(A_NS * A_STAGE <= ST_P && IMG_END <= ST_P, "phase A overlaps the statistics");
 static_assert(6 * (R + 256) * 64 <= ST_P && 9 * (R + 128) * 64 <= ST_P, "phase B / C / D rings overlap the statistics");
 

@@ -405,7 +405,6 @@ constexpr int GETREG_XCC_ID = 20 | (0 << 6) | ((4 - 1) << 11);          // s_get
 // all four workgroups of the cluster on this XCD? (wave-uniform: one relaxed load per wave)
 __device__ __forceinline__ bool cluster_shares_l2(const unsigned* place, int opt) {
   if (opt & 4) return false;                            // tuning switch: always fence
-  if (opt & 512) return true;                           // placement by head (below): the payload is read with sc1 loads, which are coherent across XCDs as well -- no acquire
   const unsigned w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(place, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   const unsigned b = w & 0xffu;
   return b != 0u && w == b * 0x01010101u;
@@ -422,7 +421,6 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
   // cluster placement: workgroup b runs on XCD b % 8 (observed, not guaranteed): the four workgroups of a window get ids 8 apart
   int cl_0, h_0;
   if (a->scatter) { cl_0 = blockIdx.x >> 2; h_0 = blockIdx.x & 3; }            // test mode: a cluster spread over four XCDs
-  else if (a->opt & 512) { const int x = blockIdx.x & 7; h_0 = x >> 1; cl_0 = (blockIdx.x >> 3) * 2 + (x & 1); }   // tuning: placement by head (XCDs 2 h, 2 h + 1 host head h: an XCD streams a quarter of the weights), as the streaming launches
   else { const int idx = blockIdx.x >> 3; cl_0 = ((idx >> 2) << 3) + (blockIdx.x & 7); h_0 = idx & 3; }
   if (cl_0 >= a->n_utts) return;
   const UttPlan up = a->plan[a->utt0 + cl_0];
@@ -963,7 +961,7 @@ void launch_sanm_block8(const SanmBlockArgs& a, hipStream_t s) {
   static PerDeviceOnce attr_once;
   if (attr_once.first())
     for (Kern k : kerns) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  const int grid = a.scatter ? a.n_utts * 4 : (a.opt & 512) ? (a.n_utts + 1) / 2 * 8 : ((a.n_utts + 7) / 8) * 32;
+  const int grid = a.scatter ? a.n_utts * 4 : ((a.n_utts + 7) / 8) * 32;
   const int abl = (a.opt >> 4) & 15;
   const Kern k = abl == 1 ? kerns[2] : abl == 2 ? kerns[3] : abl == 4 ? kerns[4] : abl == 8 ? kerns[5] : abl == 12 ? kerns[6] : abl == 14 ? kerns[7] : (a.opt & 2) ? kerns[1] : kerns[0];
   hipLaunchKernelGGL(k, dim3(grid), dim3(NT), LDS_BYTES, s, a);

@@ -59,14 +59,14 @@ struct SvSession : asr_session {
   size_t h_out_cap = 0;
 
   ~SvSession() override {
-    for (DeviceBuffer* b : {&d_dft_split, &d_times, &d_flags, &d_tpack, &d_tlayer_tab, &d_tkv, &d_ctplan, &d_mdev, &d_trow, &d_skws, &d_skcnt, &d_sta, &d_stb, &st_wpack, &st_layer_tab, &st_flags, &st_times, &st_dpack, &st_dlayer_tab, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
+    for (DeviceBuffer* b : {&d_dft_split, &d_times, &d_flags, &d_tpack, &d_tlayer_tab, &d_tkv, &d_ctplan, &d_mdev, &d_trow, &d_skws, &d_skcnt, &d_sta, &d_stb, &st_segs, &st_shadow, &st_wpack, &st_layer_tab, &st_flags, &st_times, &st_dpack, &st_dlayer_tab, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
                             &d_x0lo, &d_xalo, &d_xblo, &d_plan, &d_audio, &d_mel, &d_x0, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx, &d_mem, &d_ffn,
                             &d_amax_v, &d_amax_i, &d_ids, &d_tok, &d_num, &d_logits, &d_enc_lo, &d_ck, &d_cifa, &d_alpha, &d_dec, &d_x2,
                             &d_sa, &d_ffn32, &d_tplan})
       b->release();
     for (auto& kv : taps) kv.second.buf.release();
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-    if (st_graph) (void)hipGraphExecDestroy(st_graph);
+    for (hipGraphExec_t g : st_graph) if (g) (void)hipGraphExecDestroy(g);
     if (h_plan) (void)hipHostFree(h_plan);
     if (h_out) (void)hipHostFree(h_out);
     prof.release();
@@ -85,6 +85,20 @@ struct SvSession : asr_session {
   bool st_fused = false;
   int st_opt = 0;                       // ASR_STREAM_OPT: tuning switches of the fused launch (kernels.h: StreamLayersArgs::opt)
   int st_fused_env = 2;                 // ASR_STREAM_FUSED: 0 = every layer on the per-launch path, 1 = encoder launch only, 2 = encoder and decoder launches
+  // Which steps take the cluster launches (round 5). (i) Above st_fused_max active streams the per-launch GEMMs amortise a layer's weights over all the rows
+  // while a cluster launch streams them once per CU-load of clusters: 256 streams ran 10.4 ms fused against 9.0 per launch -- default from the
+  // CU count, ASR_STREAM_FUSED_MAX overrides. (ii) While ANOTHER session of this process is computing on this GPU (asr_tenant_busy_others) the step takes the
+  // per-launch path: (streams x 4) 150-KB workgroups hold every CU for a whole launch and starved a co-tenant's chain of small kernels 10x, and a cluster that is
+  // split across dispatch waves by someone else's kernels can give up. ASR_STREAM_SHARE=0 disables the rule. (iii) A fused step is RECOVERABLE when a snapshot of
+  // the active streams' recurrent state was taken in front of it (launch_stream_state_copy): on a give-up the state is restored, the step is redone on the per-launch
+  // path and the session stays there for st_cooldown_steps steps. Snapshots are taken when other sessions exist on this GPU (they may start computing at any time)
+  // or always with ASR_STREAM_SNAPSHOT=1 (=0: never; a give-up then fails the step and the caller has to reset its streams, as in round 4).
+  int st_fused_max = 0, st_share_rule = 1, st_snapshot_env = -1, st_fault = 0, st_cooldown = 0;
+  int st_giveups = 0, st_shared_steps = 0, st_snapshots = 0;      // counters (asr_paraformer_stream_stats)
+  static constexpr int st_cooldown_steps = 64;
+  DeviceBuffer st_segs, st_shadow;      // StreamStateSeg table + the shadow copies
+  int st_n_segs = 0, st_n_items = 0;
+  void ensure_stream_shadow();
   void stream_init(int chunk, int look_back_encoder, int look_back_decoder, int max_streams);
   void stream_reset(int sid);
   template <typename T> void stream_step(const float* audio, int audio_mem, const int32_t* stream_ids, int n, int32_t* tok_out, int max_tokens,
@@ -134,7 +148,7 @@ struct SvSession : asr_session {
   DeviceBuffer d_flags;         // exchange counters of the block kernel: [n_blocks][batch][4] + the error word at the end
   hipGraphExec_t graph_exec = nullptr;
   uint64_t graph_key = 0, eager_key = 0, ws_epoch = 1;
-  hipGraphExec_t st_graph = nullptr; uint64_t st_graph_key = 0, st_eager_key = 0;     // streaming chunk step
+  hipGraphExec_t st_graph[3] = {nullptr, nullptr, nullptr}; uint64_t st_graph_key[3] = {0, 0, 0}, st_eager_key[3] = {0, 0, 0};     // streaming chunk step: per-launch / fused / fused + snapshot
 
   void init();
   void copy_block_status(const struct SvRunCtx& r);   // the block kernel's error word rides home behind the token counts
@@ -974,6 +988,11 @@ void SvSession::stream_init(int chunk, int look_back_encoder, int look_back_deco
   if (const char* e = getenv("ASR_STREAM_FUSED")) st_fused_env = atoi(e);
   if (const char* e = getenv("ASR_STREAM_TIMES")) st_times_layer = atoi(e);
   if (const char* e = getenv("ASR_STREAM_OPT")) st_opt = atoi(e);
+  st_fused_max = gemm_env_cus() * 5 / 8;               // 160 streams on 256 CUs (tools/probes/stream_fused_sweep.sh: the cross-over against the per-launch path)
+  if (const char* e = getenv("ASR_STREAM_FUSED_MAX")) st_fused_max = atoi(e);
+  if (const char* e = getenv("ASR_STREAM_SHARE")) st_share_rule = atoi(e);
+  if (const char* e = getenv("ASR_STREAM_SNAPSHOT")) st_snapshot_env = atoi(e);
+  if (const char* e = getenv("ASR_STREAM_FAULT")) st_fault = atoi(e);
   st_fused = st_fused_env != 0 && precision == ASR_PRECISION_BF16 && c.n_blocks > 1 &&
              stream_layers_supported(c.d_model, c.d_ffn, c.n_heads, st_en_cap, st_B + st_C, c.fsmn_kernel) && blocks[1].kpad == c.d_model;
   if (st_fused) {
@@ -1023,6 +1042,37 @@ void SvSession::stream_init(int chunk, int look_back_encoder, int look_back_deco
     HIP_CHECK(hipStreamSynchronize(stream));
   }
   stream_reset(-1);
+}
+
+void SvSession::ensure_stream_shadow() {
+  if (st_n_segs) return;
+  const auto& c = cfg;
+  const size_t T = precision == ASR_PRECISION_BF16 ? 2 : 4, head_row = (size_t)c.n_heads * 128;
+  struct Spec { DeviceBuffer* buf; size_t per_stream; int n_outer; };
+  const Spec specs[] = {
+      {&st_enk, st_en_cap * head_row * T, c.n_blocks}, {&st_env, st_en_cap * head_row * T, c.n_blocks},
+      {&st_dek, st_de_cap * head_row * T, pcfg.n_dec}, {&st_dev, st_de_cap * head_row * T, pcfg.n_dec},
+      {&st_defsmn, (size_t)(c.fsmn_kernel - 1) * c.d_model * 4, pcfg.n_dec}, {&st_prev, (size_t)st_C * kpad0 * 4, 1},
+      {&st_cifh, (size_t)c.d_model * 4, 1}, {&st_cifa, 4, 1}, {&st_enlen, 4, 1}, {&st_delen, 4, 1}, {&st_start, 4, 1}};
+  size_t total = 0;
+  for (const Spec& sp : specs) total += (sp.per_stream * st_max * sp.n_outer + 255) / 256 * 256;
+  st_shadow.reserve(total, stream);
+  std::vector<StreamStateSeg> segs;
+  size_t off = 0;
+  int item = 0;
+  for (const Spec& sp : specs) {
+    if (sp.per_stream == 0 || sp.n_outer == 0) continue;
+    StreamStateSeg g;
+    g.live = (unsigned char*)sp.buf->ptr; g.shadow = (unsigned char*)st_shadow.ptr + off;
+    g.per_stream = sp.per_stream; g.outer_stride = sp.per_stream * st_max; g.n_outer = sp.n_outer; g.first_item = item;
+    segs.push_back(g);
+    item += sp.n_outer;
+    off += (sp.per_stream * st_max * sp.n_outer + 255) / 256 * 256;
+  }
+  st_segs.reserve(sizeof(StreamStateSeg) * segs.size(), stream);
+  HIP_CHECK(hipMemcpyAsync(st_segs.ptr, segs.data(), sizeof(StreamStateSeg) * segs.size(), hipMemcpyHostToDevice, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  st_n_segs = (int)segs.size(); st_n_items = item;
 }
 
 void SvSession::stream_reset(int sid) {
@@ -1115,6 +1165,15 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
     HIP_CHECK(hipMemcpyAsync(d_audio.ptr, audio, (size_t)n * st_chunk * 4, hipMemcpyHostToDevice, stream));
     d_aud = d_audio.as<float>();
   }
+  // ---- which path this step takes (see the comment at st_fused_max)
+  bool step_fused = st_fused && std::is_same<T, bf16_t>::value && n <= st_fused_max && st_cooldown == 0;
+  bool snapshot = false;
+  if (st_cooldown > 0) --st_cooldown;
+  if (step_fused && st_share_rule && asr_tenant_busy_others(this, 20.0) > 0) { step_fused = false; ++st_shared_steps; }
+  if (step_fused) snapshot = st_snapshot_env == 1 || (st_snapshot_env < 0 && asr_tenant_live_others(this) > 0);
+  if (snapshot) { ensure_stream_shadow(); ++st_snapshots; }
+  const bool inject_fault = step_fused && st_fault == 1;
+  if (inject_fault) st_fault = 2;                        // once per session
   const UttPlan* dp = d_plan.as<UttPlan>();
   const int32_t* d_blk_utt = (const int32_t*)((unsigned char*)d_plan.ptr + sizeof(UttPlan) * n);
   const int32_t* d_blk_f0 = d_blk_utt + n;
@@ -1123,6 +1182,8 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
   // Everything below reads its geometry from the uploaded plan and the device-side state (history lengths, fired-token counts), so
   // the launch sequence depends on n only: one captured hipGraph replays every chunk step of a given set size.
   auto enqueue = [&]() {
+  if (snapshot && step_fused)
+    launch_stream_state_copy(st_segs.as<StreamStateSeg>(), st_n_segs, st_n_items, dp, n, false, stream);
   // ---- front-end: fbank of the chunk, LFR rows, carried rows in front (:386-399)
   {
     ProfScope ps(prof, "fbank", stream);
@@ -1155,7 +1216,7 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
   float* mem = d_mem.as<float>();
   T* ffn = d_ffn.as<T>();
   const size_t en_layer = (size_t)st_max * H * st_en_cap * 128;
-  const bool fused = st_fused && std::is_same<T, bf16_t>::value;
+  const bool fused = step_fused;
   for (int i = 0; i < c.n_blocks; ++i) {
     const SvBlock& b = blocks[i];
     if (fused && i == 1) {               // layers 1 .. n - 1: one launch, the stream's rows stay in xa
@@ -1167,7 +1228,7 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
       la.ln_eps = 1e-5f; la.cache_len = st_enlen.as<int32_t>(); la.layers = st_layer_tab.as<StreamLayer>();
       la.x = xa; la.xb = xb; la.ctx = (bf16_t*)ctx; la.hid = (bf16_t*)ffn;
       la.flags = st_flags.as<unsigned>(); la.err = st_flags.as<unsigned>() + (size_t)nl * n * 4;
-      la.opt = st_opt;
+      la.opt = st_opt; la.fault = inject_fault ? 1 : 0;
       if (st_times_layer >= 0) {
         st_times.reserve((size_t)((n + 7) / 8) * 32 * 16 * 8, stream);
         HIP_CHECK(hipMemsetAsync(st_times.ptr, 0, (size_t)((n + 7) / 8) * 32 * 16 * 8, stream));
@@ -1264,7 +1325,7 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
     gemm(g2);
   };
   int li = 0;
-  if (st_dec_fused && std::is_same<T, bf16_t>::value) {      // every decoder block in one launch (stream_dec.hip); streams without a fired frame skip it
+  if (st_dec_fused && step_fused) {      // every decoder block in one launch (stream_dec.hip); streams without a fired frame skip it
     ProfScope ps(prof, "stream_dec", stream);
     StreamDecArgs da;
     da.token_plan = tplan; da.n_streams = n; da.n_layers = (int)pdec.size(); da.n_cur = n_cur; da.cap = st_de_cap; da.ln_eps = 1e-5f;
@@ -1335,11 +1396,15 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
                           (const void*)d_ffn.ptr, (const void*)d_amax_v.ptr, (const void*)d_amax_i.ptr, (const void*)d_ids.ptr, (const void*)d_tok.ptr, (const void*)d_num.ptr,
                           (const void*)d_logits.ptr, (const void*)d_enc_lo.ptr, (const void*)d_cifa.ptr, (const void*)d_alpha.ptr, (const void*)d_dec.ptr, (const void*)d_x2.ptr,
                           (const void*)d_sa.ptr, (const void*)d_ffn32.ptr, (const void*)d_tplan.ptr, (const void*)stream, (const void*)(uintptr_t)n,
-                          (const void*)(uintptr_t)max_tokens})
+                          (const void*)(uintptr_t)max_tokens, (const void*)st_shadow.ptr})
       key = (key ^ (uint64_t)(uintptr_t)q) * 1099511628211ull;
-    if (graphable && st_graph && key == st_graph_key) {
+    const int gi = step_fused ? (snapshot ? 2 : 1) : 0;            // one cached graph per path: a session that alternates (a co-tenant comes and goes) does not re-capture
+    hipGraphExec_t& st_graph = this->st_graph[gi];
+    uint64_t& st_graph_key = this->st_graph_key[gi];
+    uint64_t& st_eager_key = this->st_eager_key[gi];
+    if (graphable && !inject_fault && st_graph && key == st_graph_key) {
       HIP_CHECK(hipGraphLaunch(st_graph, stream));
-    } else if (graphable && key == st_eager_key) {
+    } else if (graphable && !inject_fault && key == st_eager_key) {
       if (st_graph) { (void)hipGraphExecDestroy(st_graph); st_graph = nullptr; }
       hipGraph_t graph = nullptr;
       HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
@@ -1357,13 +1422,13 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
       HIP_CHECK(hipGraphLaunch(st_graph, stream));
     } else {
       enqueue();                                         // first step of a geometry runs eagerly (lazy kernel attributes, workspaces)
-      if (graphable) st_eager_key = key;
+      if (graphable && !inject_fault) st_eager_key = key;
     }
   }
   if (taps_enabled) save_tap("logits", d_logits.ptr, rows, c.vocab, vpad, 4);
   HIP_CHECK(hipMemcpyAsync(h_out, d_tok.ptr, (size_t)n * max_tokens * 4, hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipMemcpyAsync((unsigned char*)h_out + (size_t)n * max_tokens * 4, d_num.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
-  const bool fused_ran = st_fused && std::is_same<T, bf16_t>::value;
+  const bool fused_ran = step_fused;
   unsigned* h_err = (unsigned*)((unsigned char*)h_out + out_bytes);
   *h_err = 0;
   if (fused_ran)
@@ -1386,7 +1451,24 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
     for (int k = 1; k <= last; ++k) fprintf(stderr, " %.2f", sum[k] / std::max(cnt, 1));
     fprintf(stderr, "\n");
   }
-  ASR_REQUIRE(*h_err == 0, "streaming: a workgroup of the fused encoder launch gave up waiting for its cluster; the step's results are invalid, reset its streams");
+  if (fused_ran && *h_err != 0 && snapshot) {
+    // A cluster gave up (its workgroups were not co-resident: somebody else's kernels hold CUs). The histories of the layers in front of the stall are rolled,
+    // everything behind the launch ran on garbage: put the active streams' state back as it was in front of the step, redo the step on the per-launch path
+    // (no cross-workgroup waits) and stay there for a while.
+    ++st_giveups;
+    st_cooldown = st_cooldown_steps;
+    fprintf(stderr, "asr_mi355x: streaming step: a cluster of the fused launch gave up; state restored, step redone on the per-launch path (give-up %d of this session)\n", st_giveups);
+    launch_stream_state_copy(st_segs.as<StreamStateSeg>(), st_n_segs, st_n_items, dp, n, true, stream);
+    step_fused = false; snapshot = false;
+    enqueue();
+    HIP_CHECK(hipMemcpyAsync(h_out, d_tok.ptr, (size_t)n * max_tokens * 4, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync((unsigned char*)h_out + (size_t)n * max_tokens * 4, d_num.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (prof.enabled) prof.collect();
+    *h_err = 0;
+  }
+  ASR_REQUIRE(*h_err == 0, "streaming: a workgroup of the fused encoder launch gave up waiting for its cluster and no snapshot was taken (ASR_STREAM_SNAPSHOT=0, or no other "
+              "session existed on this GPU when the step started); the step's results are invalid, reset its streams");
   memcpy(num_out, (unsigned char*)h_out + (size_t)n * max_tokens * 4, (size_t)n * 4);
   const int32_t* ht = (const int32_t*)h_out;
   for (int i = 0; i < n; ++i) memcpy(tok_out + (size_t)i * max_tokens, ht + (size_t)i * max_tokens, (size_t)std::min(num_out[i], max_tokens) * 4);
@@ -1404,6 +1486,7 @@ extern "C" int asr_sensevoice_create(const asr_sensevoice_config* cfg, const voi
     try {
       s->kind = 1;
       s->device = device_id;
+      asr_tenant_attach(s);
       s->precision = precision;
       s->cfg = *cfg;
       s->load_env();
@@ -1423,6 +1506,7 @@ extern "C" int asr_sensevoice_run(asr_session* s, const float* audio, int audio_
                                   const int32_t* language_idx, int32_t* token_ids_out, int max_tokens, int32_t* num_id_out) {
   return asr_guard([&] {
     ASR_REQUIRE(s && s->kind == 1, "sensevoice_run: not a SenseVoice session");
+    TenantScope tenant(s);
     SvSession* sv = static_cast<SvSession*>(s);
     if (sv->precision == ASR_PRECISION_BF16)
       sv->run<bf16_t>(audio, audio_mem, audio_offsets, batch, language_idx, token_ids_out, max_tokens, num_id_out);
@@ -1450,6 +1534,7 @@ extern "C" int asr_paraformer_create(const asr_paraformer_config* cfg, const voi
     try {
       s->kind = 3;
       s->device = device_id;
+      asr_tenant_attach(s);
       s->precision = precision;
       s->paraformer = true;
       s->pcfg = *cfg;
@@ -1499,9 +1584,19 @@ extern "C" int asr_paraformer_stream_step(asr_session* s, const float* audio, in
                                           int32_t* token_ids_out, int max_tokens, int32_t* num_id_out) {
   return asr_guard([&] {
     ASR_REQUIRE(s && s->kind == 4, "paraformer_stream_step: not a streaming Paraformer session");
+    TenantScope tenant(s);
     SvSession* sv = static_cast<SvSession*>(s);
     if (sv->precision == ASR_PRECISION_BF16) sv->stream_step<bf16_t>(audio, audio_mem, stream_ids, n_streams, token_ids_out, max_tokens, num_id_out);
     else sv->stream_step<float>(audio, audio_mem, stream_ids, n_streams, token_ids_out, max_tokens, num_id_out);
+  });
+}
+
+extern "C" int asr_paraformer_stream_stats(asr_session* s, int32_t* out8) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 4 && out8, "paraformer_stream_stats: not a streaming Paraformer session");
+    SvSession* sv = static_cast<SvSession*>(s);
+    out8[0] = sv->st_giveups; out8[1] = sv->st_shared_steps; out8[2] = sv->st_snapshots; out8[3] = sv->st_fused_max; out8[4] = sv->st_cooldown;
+    out8[5] = sv->st_fused ? 1 : 0; out8[6] = 0; out8[7] = 0;
   });
 }
 
@@ -1509,6 +1604,7 @@ extern "C" int asr_paraformer_run(asr_session* s, const float* audio, int audio_
                                   int32_t* token_ids_out, int max_tokens, int32_t* num_id_out) {
   return asr_guard([&] {
     ASR_REQUIRE(s && s->kind == 3, "paraformer_run: not a Paraformer session");
+    TenantScope tenant(s);
     SvSession* sv = static_cast<SvSession*>(s);
     if (sv->precision == ASR_PRECISION_BF16)
       sv->run<bf16_t>(audio, audio_mem, audio_offsets, batch, nullptr, token_ids_out, max_tokens, num_id_out);

@@ -26,10 +26,10 @@ template <typename T> __device__ __forceinline__ GAS T* glob(T* p) { return (GAS
 __device__ __forceinline__ void put8(void* p, u64 v) { __hip_atomic_store(reinterpret_cast<u64*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 get8(const void* p) { return __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __forceinline__ void publish(unsigned* flag) {
+__device__ __forceinline__ void publish(unsigned* flag, bool withhold = false) {      // withhold: fault injection (tests), the count never arrives
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every wave's stores are out
   lds_barrier();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0 && !withhold) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void consume(unsigned* flag, unsigned* err, unsigned need = (unsigned)NH) {
   if (threadIdx.x == 0) {

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
     {   // exchange 0: own 128 ctx columns out, the other three heads' in
       const int row = tid >> 5, off = (tid & 31) * 8;
       put8(reinterpret_cast<unsigned char*>(ctx_rows + (size_t)row * D + h * HD) + off, *reinterpret_cast<const u64*>(smem + CTX + row * AS + h * 256 + off));
-      publish(flags + 0);
+      publish(flags + 0, a.fault != 0 && li == 0 && blockIdx.x == 5);
       consume(flags + 0, a.err);
 #pragma unroll
       for (int q = 1; q < NH; ++q) {

@@ -754,6 +754,7 @@ extern "C" int asr_whisper_create(const asr_whisper_config* cfg, const void* are
     try {
       s->kind = 2;
       s->device = device_id;
+      asr_tenant_attach(s);
       s->fp8 = precision == ASR_PRECISION_FP8W || precision == ASR_PRECISION_FP8MM;
       s->fp8_mm = precision == ASR_PRECISION_FP8MM;
       s->precision = s->fp8 ? ASR_PRECISION_BF16 : precision;        // FP8 mode = bf16 mode with byte-wide decoder weights and cross-K/V
@@ -782,6 +783,7 @@ extern "C" int asr_whisper_encode(asr_session* s, const float* audio, int audio_
                                   int32_t* n_positions_out) {
   return asr_guard([&] {
     ASR_REQUIRE(s && s->kind == 2, "whisper_encode: not a Whisper session");
+    TenantScope tenant(s);
     WhSession* w = static_cast<WhSession*>(s);
     if (w->precision == ASR_PRECISION_BF16) w->encode<bf16_t>(audio, audio_mem, audio_offsets, batch, n_positions_out);
     else w->encode<float>(audio, audio_mem, audio_offsets, batch, n_positions_out);
@@ -791,6 +793,7 @@ extern "C" int asr_whisper_encode(asr_session* s, const float* audio, int audio_
 extern "C" int asr_whisper_prefill(asr_session* s, const int32_t* ids, int n, int32_t* next_ids_out, float* logits_out) {
   return asr_guard([&] {
     ASR_REQUIRE(s && s->kind == 2 && ids, "whisper_prefill: bad argument");
+    TenantScope tenant(s);
     WhSession* w = static_cast<WhSession*>(s);
     if (w->precision == ASR_PRECISION_BF16) w->step<bf16_t>(ids, n, true, next_ids_out, logits_out);
     else w->step<float>(ids, n, true, next_ids_out, logits_out);
@@ -800,6 +803,7 @@ extern "C" int asr_whisper_prefill(asr_session* s, const int32_t* ids, int n, in
 extern "C" int asr_whisper_decode(asr_session* s, const int32_t* ids, int32_t* next_ids_out, float* logits_out) {
   return asr_guard([&] {
     ASR_REQUIRE(s && s->kind == 2, "whisper_decode: not a Whisper session");
+    TenantScope tenant(s);
     WhSession* w = static_cast<WhSession*>(s);
     if (w->precision == ASR_PRECISION_BF16) w->step<bf16_t>(ids, 1, false, next_ids_out, logits_out);
     else w->step<float>(ids, 1, false, next_ids_out, logits_out);
@@ -877,6 +881,7 @@ extern "C" int asr_whisper_set_sampling_noise(asr_session* s, const float* unifo
 extern "C" int asr_whisper_generate(asr_session* s, int max_new, int eos_id, int32_t* tokens_out, int32_t* n_out) {
   return asr_guard([&] {
     ASR_REQUIRE(s && s->kind == 2 && tokens_out && n_out && max_new >= 1, "whisper_generate: bad argument");
+    TenantScope tenant(s);
     WhSession* w = static_cast<WhSession*>(s);
     ASR_REQUIRE(w->hist > 0, "whisper_generate: prefill first");
     const int B = w->batch;

@@ -450,6 +450,14 @@ class ParaformerStreamSession(_Session):
         _lib.check(_lib.load().asr_paraformer_stream_step(self._h, ap, mem, _ip(sid), sid.size, _ip(tok), cap, _ip(num)))
         return [tok[i, :num[i]].copy() for i in range(sid.size)]
 
+    def stream_stats(self) -> dict:
+        """Which path the chunk steps took (asr_paraformer_stream_stats): give-ups recovered, steps moved to the per-launch path because the GPU was shared,
+        snapshots taken, the stream count above which steps stay on the per-launch path, cool-down steps left, whether the session fuses at all."""
+        out = np.zeros(8, dtype=np.int32)
+        _lib.check(_lib.load().asr_paraformer_stream_stats(self._h, _ip(out)))
+        return {"giveups": int(out[0]), "shared_steps": int(out[1]), "snapshots": int(out[2]), "fused_max": int(out[3]), "cooldown": int(out[4]),
+                "can_fuse": bool(out[5])}
+
 
 # =============================================================================== Qwen3-ASR
 class QwenAsrSession(_Session):

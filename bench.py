@@ -32,23 +32,28 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md:42
 HBM_PEAK_GBS = 8000.0               # HBM3E spec, MI355X_MICROARCH.md:35
 
 
-def sensevoice_algorithmic_flops(cfg, lengths):
+def sensevoice_algorithmic_flops(cfg, lengths, blocks=None):
     """Algorithmic FLOPs per kernel class for one batch (GEMM = 2MNK on un-padded rows, attention = 4 T^2 d
-    per layer, no recompute, no padding) -- SURVEY.md section 8(d)."""
+    per layer, no recompute, no padding) -- SURVEY.md section 8(d). `blocks` = (first, end): only the SANM blocks of that range
+    (the block kernel's launches walk blocks n_enc0 .. n_blocks - 1; block 0, whose input is 560 wide, runs as three other launches),
+    head and front-end left out."""
     d, dff, feat = cfg.d_model, cfg.d_ffn, cfg.feat_dim
     nfreq = cfg.nfft // 2 + 1
     out = dict.fromkeys(("gemm_qkv", "gemm_out", "gemm_ffn1", "gemm_ffn2", "gemm_ctc", "attention", "fsmn", "fbank"), 0.0)
+    b0, b1 = blocks if blocks else (0, cfg.n_blocks)
+    n0 = max(0, min(b1, cfg.n_enc0) - b0)                 # blocks of the range whose input is feat_dim wide
     for n in lengths:
         T, frames = cfg.seq_len(n), cfg.n_frames(n)
-        nb = cfg.n_blocks
-        out["gemm_qkv"] += 2.0 * T * 3 * d * (feat * cfg.n_enc0 + d * (nb - cfg.n_enc0))
+        nb = b1 - b0
+        out["gemm_qkv"] += 2.0 * T * 3 * d * (feat * n0 + d * (nb - n0))
         out["gemm_out"] += 2.0 * T * d * d * nb
         out["gemm_ffn1"] += 2.0 * T * d * dff * nb
         out["gemm_ffn2"] += 2.0 * T * d * dff * nb
-        out["gemm_ctc"] += 2.0 * T * d * cfg.vocab
         out["attention"] += 4.0 * T * T * d * nb
         out["fsmn"] += 2.0 * T * d * cfg.fsmn_kernel * nb
-        out["fbank"] += frames * (2.0 * cfg.win_length * 2 * nfreq + 2.0 * nfreq * cfg.n_mels)
+        if not blocks:
+            out["gemm_ctc"] += 2.0 * T * d * cfg.vocab
+            out["fbank"] += frames * (2.0 * cfg.win_length * 2 * nfreq + 2.0 * nfreq * cfg.n_mels)
     return out
 
 
@@ -405,7 +410,8 @@ def main():
         if "sanm_fused" in prof:      # q|k|v projection + attention + FSMN run as one kernel per (utterance, head)
             flops["sanm_fused"] = flops["gemm_qkv"] + flops["attention"] + flops["fsmn"]
         if "sanm_block" in prof:      # one persistent launch per SANM block: every GEMM, the attention and the FSMN of the block
-            flops["sanm_block"] = sum(flops[k] for k in ("gemm_qkv", "gemm_out", "gemm_ffn1", "gemm_ffn2", "attention", "fsmn"))
+            # ... of the blocks the block kernel walks: n_enc0 .. n_blocks - 1 (the scope "sanm_block" times exactly those launches; block 0 is not in it)
+            flops["sanm_block"] = sum(sensevoice_algorithmic_flops(cfg, lengths, blocks=(cfg.n_enc0, cfg.n_blocks)).values())
         kernels = {}
         for name, p in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"]):
             ms = p["total_ms"] / args.profile_steps
@@ -821,7 +827,10 @@ def main_paraformer_streaming(args):
                "config": {"workload": "Paraformer-large streaming bf16: %d streams x one 0.5 s chunk per step (13 encoder rows per stream, K/V histories "
                                       "36 / 9 rows), decoder on fired frames, audio resident in HBM, token ids returned to host" % S,
                           "global_batch": world * S, "audio_seconds_per_step": audio_s, "tokens_per_step": round(tokens / max(args.steps, 1), 1),
-                          "parallelism": f"dp{world} (streams pinned to their GPU)"},
+                          "parallelism": f"dp{world} (streams pinned to their GPU)",
+                          "path": "two cluster launches per step (stream_layers / stream_dec)" if "stream_layers" in kernels else
+                                  "per-launch path (more active streams than the session's fused_max: the per-launch GEMMs amortise the weights over all rows)",
+                          "dispatch": sess.stream_stats()},
                "rtf": round(elapsed / (audio_s * args.steps), 8), "chunk_latency_ms": round(ms, 3),
                "roofline": {"bound": "hbm", "kernel": "whole chunk step (weights streamed once per step; 13 x %d rows keep every GEMM weight-bound). Encoder layers 1..49 "
                                                        "and the decoder blocks are one launch each (stream_layers_kernel / stream_dec_kernel: clusters of four "
@@ -1315,6 +1324,11 @@ def main_mixed(args):
                               "streaming_chunk_steps": int(total_chunks), "streaming_ms_per_chunk_step": round(elapsed / max(total_chunks / world, 1) * 1e3, 2)},
                "solo_per_gpu": {"qwen_audio_s_per_s": round(solo_q, 1), "qwen_ms_per_step": round(q_solo * 1e3, 2), "streaming_audio_s_per_s": round(solo_p, 1),
                                 "streaming_ms_per_chunk_step": round(p_solo * 1e3, 2)},
+               # `value` is a SUM and rewards a tenant that starves the other (1 024 cluster workgroups took Qwen3-ASR from 3 415 to 319 audio-s/s with
+               # the sum unchanged): each tenant's concurrent rate over its solo rate on this GPU, the smaller one first
+               "tenant_slowdown": {"qwen": round(q_audio_s / world / elapsed / solo_q, 3), "streaming": round(p_audio_s / world / elapsed / solo_p, 3),
+                                   "slower_tenant": round(min(q_audio_s / world / elapsed / solo_q, p_audio_s / world / elapsed / solo_p), 3)},
+               "streaming_dispatch": psess.stream_stats(),
                "roofline": {"bound": "hbm", "kernel": "both launch chains are latency-bound; see the qwen and paraformer-streaming workloads", "achieved": None,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}}
         print(json.dumps(out))

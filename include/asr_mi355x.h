@@ -135,6 +135,13 @@ int asr_paraformer_stream_create(const asr_paraformer_config* cfg, const void* a
 int asr_paraformer_stream_reset(asr_session* s, int stream_id);      /* -1 = every stream: empty histories, zero CIF state */
 int asr_paraformer_stream_step(asr_session* s, const float* audio, int audio_mem, const int32_t* stream_ids, int n_streams,
                                int32_t* token_ids_out, int max_tokens, int32_t* num_id_out);
+/* Which path the chunk steps of a streaming session took (no reference counterpart: the reference runs one stream per InferenceSession and has no
+ * co-tenancy to manage). A bf16 step runs the encoder / decoder layer loops as two cluster launches when (i) no more than fused_max streams are active,
+ * (ii) no other session of this process is computing on the same GPU (otherwise the per-launch path, which leaves CUs to the other tenant and waits on nobody);
+ * when other sessions merely exist on the GPU the step first snapshots the active streams' recurrent state, so that a cluster launch that gave up is restored and
+ * redone on the per-launch path instead of costing the streams their history. out8 = {give-ups recovered, steps that took the per-launch path because the GPU
+ * was shared, snapshots taken, fused_max, steps left of the per-launch cool-down after a give-up, 1 if the session can fuse at all, 0, 0}. */
+int asr_paraformer_stream_stats(asr_session* s, int32_t* out8);
 
 /* ------------------------------------------------------------------ Whisper (encoder + KV-cache decoder)
  * Replaces the merged graphs Whisper_ProbePrefillGreedy / Whisper_PrefillGreedy / Whisper_DecodeGreedy

@@ -82,6 +82,40 @@ def gen_paraformer(clips):
         np.savez_compressed(os.path.join(GOLDEN, fixture + ".npz"), **out)
 
 
+def gen_paraformer_streaming(clips):
+    """The streaming graphs (Paraformer/Streaming/Export_Paraformer_Streaming.py:386-463,508-553) on composite clips with silence between speech:
+    the same record layout as oracle/gen_golden_paraformer_streaming.py, the audio named instead of seeded."""
+    from oracle import kaldi_mel, natural_audio as na, reference_harness as rh
+    cfgm, ckm = importlib.import_module(PKG + ".config"), importlib.import_module(PKG + ".checkpoints")
+    sclips = na.streaming_clips(clips)
+    for fixture, cfg_name in (("paraformer_streaming_tiny_natural", "paraformer_tiny"), ("paraformer_streaming_large_natural", "paraformer_large")):
+        cfg = getattr(cfgm, cfg_name)()
+        ck = ckm.synth_paraformer_checkpoint(cfg, 0)
+        ref = rh.build_reference_paraformer_streaming(cfg, ck, kaldi_mel.get_mel_banks)
+        assert int(ref["chunk"]) == na.STREAM_CHUNK
+        small = cfg.d_model <= 128
+        out = {"ckpt_seed": np.int64(0), "n_cases": np.int64(len(sclips)), "cfg_name": np.str_(cfg_name), "chunk": np.int64(ref["chunk"]),
+               "cif_bias": np.float32(np.nan), "clips": np.asarray(list(sclips), dtype=np.str_)}
+        for i, (name, pcm) in enumerate(sclips.items()):
+            recs = rh.reference_paraformer_streaming_run(ref, cfg, na.kaldi_input(pcm))
+            p = f"c{i}_"
+            out[p + "n_chunks"] = np.int64(pcm.size // na.STREAM_CHUNK)
+            out[p + "n_fired"] = np.asarray([r["n"] for r in recs], np.int32)
+            out[p + "cif_alphas"] = np.asarray([r["cif_alphas"] for r in recs], np.float32)
+            out[p + "token_ids"] = np.concatenate([r["token_ids"] for r in recs]).astype(np.int32)
+            margins = []
+            for j, r in enumerate(recs):
+                q = f"{p}k{j}_"
+                out[q + "enc_out"] = r["enc_out"] if small else r["enc_out"][:, ::8].copy()
+                if r["n"]:
+                    srt = np.sort(r["logits"], axis=1)
+                    margins.append(srt[:, -1] - srt[:, -2])
+                    out[q + "logits"] = r["logits"] if small else r["logits"][:, ::37].copy()
+            out[p + "margin"] = np.concatenate(margins).astype(np.float32) if margins else np.zeros(0, np.float32)
+            print(fixture, name, "fired per chunk", out[p + "n_fired"], "min margin", float(out[p + "margin"].min()) if margins else None)
+        np.savez_compressed(os.path.join(GOLDEN, fixture + ".npz"), **out)
+
+
 def gen_whisper(clips):
     import torch
     from oracle import natural_audio as na, reference_harness as rh
@@ -135,12 +169,14 @@ def gen_qwen(clips):
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
-    which = sys.argv[1:] or ["sensevoice", "paraformer", "whisper", "qwen"]
+    which = sys.argv[1:] or ["sensevoice", "paraformer", "paraformer_streaming", "whisper", "qwen"]
     clips = _clips()
     if "sensevoice" in which:
         gen_sensevoice(clips)
     if "paraformer" in which:
         gen_paraformer(clips)
+    if "paraformer_streaming" in which:
+        gen_paraformer_streaming(clips)
     if "whisper" in which:
         gen_whisper(clips)
     if "qwen" in which:

@@ -72,3 +72,24 @@ def kaldi_input(pcm: np.ndarray) -> np.ndarray:
 def unit_input(pcm: np.ndarray) -> np.ndarray:
     """[-1, 1) float32, the Whisper / Qwen3-ASR front-ends' input."""
     return (pcm.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+
+
+STREAM_CHUNK = 8000
+
+
+def streaming_clips(clips: dict | None = None) -> dict:
+    """Composite clips for the STREAMING graphs (whole 0.5 s chunks; the carried CIF / K-V / FSMN state has to survive stretches of digital silence in which
+    nothing fires, then fire again): name -> int16.
+      sil_speech_sil   1 s of silence, zh_1 (2.43 s, zero-padded to whole chunks), 1.5 s of silence                      = 10 chunks
+      talk_gap_talk    multitalk8[0 : 2 s], 1 s of silence, shanghai8[2 s : 4 s], chirp80[0 : 0.5 s]                     = 11 chunks"""
+    c = clips or load_clips()
+    z = lambda n: np.zeros(n, np.int16)
+    zh = c["zh_1"]
+    pad = (-zh.size) % STREAM_CHUNK
+    out = {
+        "sil_speech_sil": np.concatenate([z(16000), zh, z(pad), z(24000)]),
+        "talk_gap_talk": np.concatenate([c["multitalk8"][:32000], z(16000), c["shanghai8"][32000:64000], c["chirp80"][:8000]]),
+    }
+    for k, v in out.items():
+        assert v.size % STREAM_CHUNK == 0 and v.dtype == np.int16, k
+    return out

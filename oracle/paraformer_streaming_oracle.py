@@ -133,7 +133,8 @@ class ParaformerStreamingOracle(ParaformerOracle):
             dec = y + ctx @ L["wo"].t() + L["bo"]
         for L in self.dec3:
             dec = F.layer_norm(torch.relu(F.layer_norm(dec, (d,)) @ L["w1"].t() + L["b1"]), (c.d_dec_ffn,)) @ L["w2"].t() + L["b2"]
-        return F.layer_norm(dec, (d,)) @ self.w_out.t() + self.b_out
+        self.last_dec_hidden = F.layer_norm(dec, (d,))                 # (n, d): what the output layer multiplies (tests build heads with trained margins on these rows)
+        return self.last_dec_hidden @ self.w_out.t() + self.b_out
 
     def run(self, audio_1d, state=None):
         """Whole clip (length a multiple of the chunk) -> list of per-chunk dicts; the decoder runs only for chunks that fired."""
@@ -148,6 +149,7 @@ class ParaformerStreamingOracle(ParaformerOracle):
                 if frames.shape[0]:
                     logits = self.decoder_step(st, enc_out, frames)
                     rec["logits"] = logits.numpy()
+                    rec["dec_hidden"] = self.last_dec_hidden.numpy().copy()
                     rec["token_ids"] = logits.argmax(-1).int().numpy()
                 else:
                     rec["token_ids"] = np.zeros(0, np.int32)

@@ -37,3 +37,22 @@ def test_committed_bench_lines_keep_the_contract():
     for f in files:      # no line prices a kernel above the machine
         frac = json.load(open(f))["roofline"]["frac"]
         assert frac is None or 0.0 < frac < 1.0, f
+
+
+def test_block_kernel_numerator_is_a_known_answer():
+    """roofline.achieved of the headline line = algorithmic work of the 69 blocks the block-kernel launches walk (block 0 runs as three other
+    launches outside the "sanm_block" scope) / their measured time: 901.9 MFLOP x 64 windows x 69 blocks = 3 982.8 GFLOP per 64 x 8 s step."""
+    import importlib
+    cfgmod = importlib.import_module("automatic-speech-recognition-asr-onnx_amd.config")
+    cfg = cfgmod.SenseVoiceConfig()
+    lengths = [128000] * 64
+    walked = bench.sensevoice_algorithmic_flops(cfg, lengths, blocks=(cfg.n_enc0, cfg.n_blocks))
+    assert cfg.n_blocks - cfg.n_enc0 == 69
+    assert abs(sum(walked.values()) / 1e9 - 3982.8) < 0.5
+    assert walked["gemm_ctc"] == 0.0 and walked["fbank"] == 0.0
+    whole = bench.sensevoice_algorithmic_flops(cfg, lengths)
+    assert abs(sum(whole.values()) / 1e12 - 4.29) < 0.01                  # SURVEY 8(d): 67.03 GFLOP per window
+    per_class = ("gemm_qkv", "gemm_out", "gemm_ffn1", "gemm_ffn2", "attention", "fsmn")
+    block0 = bench.sensevoice_algorithmic_flops(cfg, lengths, blocks=(0, cfg.n_enc0))
+    for k in per_class:
+        assert abs(walked[k] + block0[k] - whole[k]) < 1e-3 * whole[k]

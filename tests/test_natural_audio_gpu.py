@@ -170,3 +170,59 @@ def test_qwen_asr_f32():
         assert np.abs(got_logits[b] - g[n + "_logits"]).max() < TOL, n
         if (g[n + "_margin"] > 2 * TOL).all():
             assert np.array_equal(got_ids[b], g[n + "_token_ids"]), n
+
+
+@pytest.mark.parametrize("fixture,prec", [("paraformer_streaming_tiny_natural", F32), ("paraformer_streaming_large_natural", F32),
+                                          ("paraformer_streaming_large_natural", 0)])
+def test_paraformer_streaming_silence_speech_silence(fixture, prec):
+    """The streaming graphs on the composite clips (digital silence -> speech -> silence across chunk boundaries, oracle/natural_audio.py: streaming_clips;
+    goldens from the reference's PARAFORMER_ENCODER / PARAFORMER_DECODER, oracle/gen_golden_natural.py): both clips advance as concurrent streams of one
+    session, the shorter one drops out. Chunks in which nothing fires (the large geometry: 0 0 1 1 0 1 1 1 0 0) carry the CIF state to the next fire.
+    f32 mode: encoder rows, fired counts, logits <= 1e-3, tokens equal. bf16 (the fused cluster launches, the default path): the encoder rows within the
+    bf16 budget of the f32 goldens, the fired COUNT of a chunk equal wherever the golden's carried CIF weight stays 0.02 away from a fire on either side
+    of the chunk (the reference's own f16 exports move such a fire too), tokens equal on those chunks where the golden's margin clears the logit error."""
+    from test_oracle_paraformer_streaming import streaming_cases, streaming_setup
+    g = load_golden(fixture)
+    cfg, ck = streaming_setup(g)
+    chunk = int(g["chunk"])
+    cases = [c for _, c in streaming_cases(g)]
+    clips = na.streaming_clips()
+    audios = [na.kaldi_input(clips[str(n)]) for n in g["clips"]]
+    sess = sub("engine").ParaformerStreamSession(cfg, ck, precision=prec, chunk=chunk, max_streams=4)
+    sess.taps(True)
+    small = cfg.d_model <= 128
+    bf16 = prec == 0
+    tol_enc, tol_logit = (0.12, 0.25) if bf16 else (TOL, TOL)
+    toks = [[] for _ in cases]
+    aligned = [True] * len(cases)
+    worst_enc = worst_logit = 0.0
+    for k in range(max(int(c["n_chunks"]) for c in cases)):
+        live = [i for i, c in enumerate(cases) if k < int(c["n_chunks"])]
+        out = sess.step(np.stack([audios[i][k * chunk:(k + 1) * chunk] for i in live]), [3 - i for i in live])
+        enc, logits = sess.tap("enc_out"), sess.tap("logits")
+        for slot, i in enumerate(live):
+            ref = cases[i]["chunks"][k]
+            e = enc[16 * slot:16 * slot + 13]
+            worst_enc = max(worst_enc, float(np.abs((e if small else e[:, ::8]) - ref["enc_out"]).max()))
+            n = int(cases[i]["n_fired"][k])
+            if bf16:
+                ca = float(cases[i]["cif_alphas"][k])                      # carried CIF weight behind this chunk, in [0, 1)
+                if not aligned[i]:
+                    continue
+                if not (0.02 < ca < 0.98) and out[slot].size != n:
+                    aligned[i] = False                                      # a fire within the bf16 error of the chunk boundary moved across it: the stream's later
+                    continue                                                # chunks are no longer comparable one to one
+            assert out[slot].size == n, (i, k, out[slot].size, n)
+            if n:
+                lg = logits[16 * slot:16 * slot + n]
+                worst_logit = max(worst_logit, float(np.abs((lg if small else lg[:, ::37]) - ref["logits"]).max()))
+            toks[i].append(out[slot])
+    print(fixture, "bf16" if bf16 else "f32", "enc_out error", worst_enc, "logit error", worst_logit)
+    assert worst_enc < tol_enc and worst_logit < tol_logit
+    if not bf16:
+        for i, c in enumerate(cases):
+            got = np.concatenate(toks[i]) if toks[i] else np.zeros(0, np.int32)
+            if (c["margin"] > 2 * TOL).all():
+                assert np.array_equal(got, c["token_ids"]), i
+    else:
+        assert sess.stream_stats()["can_fuse"]

@@ -89,3 +89,27 @@ def test_qwen_asr_oracle_on_natural_clips():
         assert np.abs(r["logits"] - g[n + "_logits"]).max() < 5 * F32_TOL, n
         if (g[n + "_margin"] > 1e-3).all():
             assert np.array_equal(r["token_ids"], g[n + "_token_ids"]), n
+
+
+def test_paraformer_streaming_oracle_on_natural_clips():
+    """The streaming graphs on composite clips with digital silence between speech (oracle/natural_audio.py: streaming_clips): carried rows, K/V / FSMN
+    histories and the CIF state across chunks in which the front-end sits at its log floor."""
+    from oracle.paraformer_streaming_oracle import ParaformerStreamingOracle
+    from test_oracle_paraformer_streaming import streaming_cases, streaming_setup
+    g = load_golden("paraformer_streaming_tiny_natural")
+    cfg, ck = streaming_setup(g)
+    orc = ParaformerStreamingOracle(cfg, ck, chunk=int(g["chunk"]))
+    clips = na.streaming_clips()
+    assert list(clips) == [str(x) for x in g["clips"]]
+    for (i, c), (name, pcm) in zip(streaming_cases(g), clips.items()):
+        assert pcm.size == int(c["n_chunks"]) * na.STREAM_CHUNK
+        recs = orc.run(na.kaldi_input(pcm))
+        assert [r["n"] for r in recs] == c["n_fired"].tolist(), name
+        assert np.abs(np.asarray([r["cif_alphas"] for r in recs]) - c["cif_alphas"]).max() < 2e-4, name
+        small = cfg.d_model <= 128                       # (the generator keeps every 8th column of the rows / every 37th logit of larger geometries)
+        for r, k in zip(recs, c["chunks"]):
+            assert np.abs((r["enc_out"] if small else r["enc_out"][:, ::8]) - k["enc_out"]).max() < 2e-4, name
+            if r["n"]:
+                assert np.abs((r["logits"] if small else r["logits"][:, ::37]) - k["logits"]).max() < 2e-4, name
+        if (c["margin"] > 1e-3).all():
+            assert np.array_equal(np.concatenate([r["token_ids"] for r in recs]), c["token_ids"]), name

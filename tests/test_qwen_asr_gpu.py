@@ -162,6 +162,41 @@ def test_paged_kv_cache_equals_extents_and_returns_pages_out_of_order(prec, monk
     assert pag[5]["high_water"] <= pag[2]["high_water"]           # ... and the peak was no higher than when nobody finished early
 
 
+@pytest.mark.parametrize("prec", [F32, BF16])
+def test_paged_prompt_of_exactly_max_seq_len(prec, monkeypatch):
+    """A prompt of exactly max_seq_len positions (prefill accepts it; max_seq_len is a multiple of the 16-position page) needs max_seq_len / 16 pages, not one
+    more for a next position that does not exist (the fill loop wrote one table entry past the row -- into the NEXT sequence's row, or past the
+    vector). First AND last sequence of the batch at the limit, a short one between them: logits bit for bit those of the extent layout, the page count exact,
+    and a decode step fails loudly for want of room."""
+    g = load_golden("qwen_asr_tiny")
+    cfg, ck = qwen_setup(g)
+    assert cfg.max_seq_len % 16 == 0
+    eng = sub("engine")
+    a = unit_audio(77, 16000)
+    runs = {}
+    for name, env in (("extents", {"ASR_QWEN_KV_PAGED": "0"}), ("paged", {}), ("shuffled", {"ASR_KV_PAGE_SHUFFLE": "1"})):
+        for k in ("ASR_QWEN_KV_PAGED", "ASR_KV_PAGE_SHUFFLE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sess = eng.QwenAsrSession.from_checkpoint(cfg, ck, precision=prec)
+        n_audio = sess.audio_tokens(len(a))
+        full = [3 + (i % 7) for i in range(cfg.max_seq_len - n_audio - 2)]
+        pre, post = [full, [1, 2, 3], full], [[4, 5], [4, 5], [4, 5]]
+        nxt, logits, ids_len = sess.prefill([a, a, a], pre, post)
+        assert [int(x) for x in ids_len] == [cfg.max_seq_len, n_audio + 5, cfg.max_seq_len]
+        short_len = n_audio + 5
+        runs[name] = (nxt, logits, sess.kv_stats())
+        with pytest.raises(Exception, match="max_seq_len"):
+            sess.decode(None)
+        del sess
+    pps = cfg.max_seq_len // 16
+    for name in ("paged", "shuffled"):
+        assert np.array_equal(runs[name][1], runs["extents"][1]) and np.array_equal(runs[name][0], runs["extents"][0])
+        assert runs[name][2]["held"] == 2 * pps + (short_len + 1 + 15) // 16                # full rows: exactly a row of pages each
+    assert np.array_equal(runs["paged"][1][0], runs["paged"][1][2])       # the two full-length rows are the same prompt: the same logits
+
+
 def test_bad_arguments_fail_loudly():
     g = load_golden("qwen_asr_tiny")
     cfg, ck = qwen_setup(g)

@@ -299,7 +299,7 @@ def test_block_kernel_equals_separate_launches_ragged(monkeypatch, scatter):
     out = {}
     for flag in ("1", "0"):
         monkeypatch.setenv("ASR_SANM_BLOCK", flag)
-        monkeypatch.setenv("ASR_SANM_BLOCK_MIN", "1")               # (by default only batches of >= 48 windows take the block kernel)
+        monkeypatch.setenv("ASR_SANM_BLOCK_MIN", "1")               # (by default only batches of >= 12 windows take the block kernel)
         monkeypatch.setenv("ASR_SANM_BLOCK_SCATTER", scatter)
         sess = eng.SenseVoiceSession.from_checkpoint(cfg, ck, precision=BF16)
         sess.taps(True)

@@ -226,13 +226,14 @@ struct SanmBlockArgs {
   int n_rows_alloc; float ln_eps; int scatter;                     // scatter != 0: test placement (a cluster spread over four XCDs)
   unsigned long long* times;                                       // tuning: [workgroups][16] wall-clock stamps (100 MHz) at the phase boundaries, or null
   int fault = 0;                                                   // tests: workgroup 5 withholds its first exchange count (its cluster then gives up after the bounded spin)
+  int ffn22 = 0;                                                   // 8-wave kernel, round 5: the FFN pair as 2 x 2 (row half x hidden half; `hid` then holds the f32 partials) -- needs the matching wpack order
 };
 bool sanm_block_supported(int max_T, int d_head, int n_heads, int d, int d_ffn, int fsmn_taps);
 int sanm_block_max_utts();                                         // windows one launch can take (all workgroups co-resident)
 void launch_sanm_block(const SanmBlockArgs& a, hipStream_t s);        // round-2 form: 12 waves, operands staged through LDS rings (ASR_SANM_BLOCK_V=1)
 void launch_sanm_block8(const SanmBlockArgs& a, hipStream_t s);       // round-4 form: 8 waves, chunked A operand, register-streamed packed weights (needs a.wpack)
 size_t sanm_block8_pack_bytes();                                      // bytes of one block's packed weights
-void launch_sanm_block8_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, hipStream_t s);
+void launch_sanm_block8_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, bool ffn22, hipStream_t s);
 void launch_rows_to_bf16(const float* x, bf16_t* y, size_t n, hipStream_t s);     // f32 -> bf16 (RNE) copy, n a multiple of 8
 void launch_sanm_qkv_attn(const SanmFusedArgs& a, hipStream_t s);
 

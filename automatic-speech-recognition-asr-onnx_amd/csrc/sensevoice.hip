@@ -112,6 +112,8 @@ struct SvSession : asr_session {
   int block8_opt = 0;           // ASR_SANM_BLOCK8_OPT: tuning switches of the 8-wave kernel (SanmBlockArgs::opt)
   bool block_persist = true;    // ASR_SANM_BLOCK_PERSIST=0: the 8-wave kernel is launched once per block instead of once per run of blocks
   DeviceBuffer d_layer_tab;     // SanmBlockLayer[n_blocks]: the per-block constants a launch of the 8-wave kernel walks
+  bool block_ffn22 = false;     // ASR_SANM_BLOCK_FFN22=1: the block kernel's FFN pair as 2 x 2 (row half x hidden half, f32 partials exchanged instead of hid; round 5, VERDICT r04's candidate (a)) --
+                                // built, parity-tested, measured SLOWER than the round-4 form (98 vs 92 us per block: profiles/r05_sanm_block_ffn22.txt), so opt-in
   int block_v = 8;              // ASR_SANM_BLOCK_V=1: the round-2 form of the block kernel (12 waves, csrc/sanm_block.hip); default: the 8-wave form (csrc/sanm_block8.hip)
   // small batches: a workgroup per (16-row tile, head), csrc/sanm_tiles.hip (ASR_SANM_TILES=0: four launches per block as before)
   bool use_tiles = true, tpack_ready = false;
@@ -132,6 +134,8 @@ struct SvSession : asr_session {
     if (const char* e = getenv("ASR_FBANK_SPLIT")) use_fbank_split = !(e[0] == '0');
     if (const char* e = getenv("ASR_SANM_BLOCK_V")) block_v = (e[0] == '1') ? 1 : 8;
     if (const char* e = getenv("ASR_SANM_BLOCK8_OPT")) block8_opt = atoi(e);
+    if (const char* e = getenv("ASR_SANM_BLOCK_FFN22")) block_ffn22 = e[0] == '1';
+    if ((block8_opt >> 4) & 15) block_ffn22 = false;          // the timing-only ablations exist for the round-4 loops
     if (const char* e = getenv("ASR_SANM_TILES")) use_tiles = !(e[0] == '0');
     if (const char* e = getenv("ASR_SANM_TILES_OPT")) tiles_opt = atoi(e);
     if (const char* e = getenv("ASR_SANM_TILES_DBG")) tiles_dbg = atoi(e);
@@ -280,7 +284,7 @@ void SvSession::ensure_block_pack() {
   for (int i = 0; i < cfg.n_blocks; ++i) {
     const SvBlock& b = blocks[i];
     if (b.in_size != cfg.d_model) continue;              // (block 0 maps 560 -> 512: it keeps the separate launches)
-    launch_sanm_block8_pack((const bf16_t*)b.wqkv, (const bf16_t*)b.wout, (const bf16_t*)b.w1, (const bf16_t*)b.w2, (unsigned char*)d_wpack.ptr + per * i, stream);
+    launch_sanm_block8_pack((const bf16_t*)b.wqkv, (const bf16_t*)b.wout, (const bf16_t*)b.w1, (const bf16_t*)b.w2, (unsigned char*)d_wpack.ptr + per * i, block_ffn22, stream);
   }
   std::vector<SanmBlockLayer> tab(cfg.n_blocks);
   for (int i = 0; i < cfg.n_blocks; ++i) {
@@ -423,7 +427,7 @@ void SvSession::enqueue(const SvRunCtx& r) {
             ba.times_layer = block_dbg - i;
           }
           if (block_v == 8) {
-            ba.layers = d_layer_tab.as<SanmBlockLayer>() + i; ba.n_layers = n_run; ba.opt = block8_opt;
+            ba.layers = d_layer_tab.as<SanmBlockLayer>() + i; ba.n_layers = n_run; ba.opt = block8_opt; ba.ffn22 = block_ffn22 ? 1 : 0;
             ba.st_in_n = st_in_block8 ? 4 : 16;
             launch_sanm_block8(ba, stream);
           }
@@ -905,8 +909,10 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
                                       "wait 2", "D loop", "D epilogue"};
     static const char* names8[14] = {"A loop (4 chunks)", "stats+images+attention", "ctx store+publish", "fsmn", "B prologue+wait 0", "B loop", "B epilogue+publish", "C wait 1+stats",
                                      "C loop", "C epilogue (hid)", "publish 2", "D own chunk+wait 2", "D loop (rest)", "D epilogue"};
+    static const char* names8_r5[14] = {"A loop (4 chunks)", "stats+images+attention", "ctx store+publish", "fsmn", "B prologue+wait 0", "B loop", "B epilogue+publish", "FFN wait 1 (W prefetch)",
+                                        "FFN x1 DMA+statistics", "FFN 4 passes+partial out", "publish 2", "final: x1 rows+wait 2", "final: partial loads", "final epilogue"};
     const int nk = block_v == 8 ? 14 : 13;
-    const char* const* names = block_v == 8 ? names8 : names12;
+    const char* const* names = block_v == 8 ? (block_ffn22 ? names8_r5 : names8) : names12;
     unsigned long long t_first = ~0ull, t_last = 0;
     int n = 0;
     double sum[14] = {0}, mx[14] = {0};
@@ -919,6 +925,15 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
     if (n) {
       fprintf(stderr, "[sanm_block %d] %d workgroups, first start -> last end %.1f us\n", block_dbg, n, (double)(t_last - t_first) * 0.01);
       for (int k = 0; k < nk; ++k) fprintf(stderr, "  %-22s avg %6.2f us  max %6.2f us\n", names[k], sum[k] / n, mx[k]);
+      if (block_v == 8 && (block8_opt & 2048)) {            // stamps 4..7 were taken inside phase A (the rows "B prologue .. B epilogue" above are then meaningless)
+        static const char* inside[5] = {"A: statistics", "A: q/k/v images", "A: own attention tile", "A: shared 9th tile", "A: closing barrier"};
+        const int from[5] = {1, 4, 5, 6, 7}, to[5] = {4, 5, 6, 7, 2};
+        for (int q = 0; q < 5; ++q) {
+          double sm = 0.0, m2 = 0.0;
+          for (int w = 0; w < 256; ++w) if (t[w * 16]) { const double us = (double)(t[w * 16 + to[q]] - t[w * 16 + from[q]]) * 0.01; sm += us; m2 = std::max(m2, us); }
+          fprintf(stderr, "  %-22s avg %6.2f us  max %6.2f us\n", inside[q], sm / n, m2);
+        }
+      }
       if (block_v == 8) {
         int n_plain = 0;
         for (int w = 0; w < 256; ++w) if (t[w * 16]) n_plain += (int)t[w * 16 + 15];
@@ -988,7 +1003,8 @@ void SvSession::stream_init(int chunk, int look_back_encoder, int look_back_deco
   if (const char* e = getenv("ASR_STREAM_FUSED")) st_fused_env = atoi(e);
   if (const char* e = getenv("ASR_STREAM_TIMES")) st_times_layer = atoi(e);
   if (const char* e = getenv("ASR_STREAM_OPT")) st_opt = atoi(e);
-  st_fused_max = gemm_env_cus() * 5 / 8;               // 160 streams on 256 CUs (tools/probes/stream_fused_sweep.sh: the cross-over against the per-launch path)
+  st_fused_max = gemm_env_cus() * 3 / 4;               // 192 streams on 256 CUs: tools/probes/stream_fused_sweep.sh (profiles/r05_stream_fused_sweep.txt) -- the cluster launches step by CU-loads of 64 streams
+                                                       // (2.5 / 5.2 / 7.8 / 10.4 ms), the per-launch path grows smoothly (5.3 ms at 64, 8.1 at 192, 8.9 at 256) and is ahead from 193 on
   if (const char* e = getenv("ASR_STREAM_FUSED_MAX")) st_fused_max = atoi(e);
   if (const char* e = getenv("ASR_STREAM_SHARE")) st_share_rule = atoi(e);
   if (const char* e = getenv("ASR_STREAM_SNAPSHOT")) st_snapshot_env = atoi(e);
@@ -1169,7 +1185,7 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
   bool step_fused = st_fused && std::is_same<T, bf16_t>::value && n <= st_fused_max && st_cooldown == 0;
   bool snapshot = false;
   if (st_cooldown > 0) --st_cooldown;
-  if (step_fused && st_share_rule && asr_tenant_busy_others(this, 20.0) > 0) { step_fused = false; ++st_shared_steps; }
+  if (step_fused && st_share_rule && asr_tenant_busy_others(this, 5.0) > 0) { step_fused = false; ++st_shared_steps; }
   if (step_fused) snapshot = st_snapshot_env == 1 || (st_snapshot_env < 0 && asr_tenant_live_others(this) > 0);
   if (snapshot) { ensure_stream_shadow(); ++st_snapshots; }
   const bool inject_fault = step_fused && st_fault == 1;

@@ -174,8 +174,33 @@ def cpu_baseline(cfg, ck, audio_np, budget_s=15.0):
             break
     out["single_thread"] = {"value": round(k * secs / e2, 2), "cores": 1, "sample": f"{k} x {secs:.0f} s utterances, {e2:.1f} s wall"}
     out["all_host_cores"] = cpu_leg_all_cores(int(os.cpu_count() or 1), secs, limit_s=45.0)
+    # ... and every core the way a CPU deployment of the reference would use them for a batch of independent utterances: nproc / best_n worker PROCESSES of
+    # best_n threads each, one utterance at a time per worker (the reference is batch 1 per InferenceSession; utterances are independent -- SURVEY 8e)
+    out["all_host_cores_multiproc"] = cpu_leg_multiproc(int(os.cpu_count() or 1), best_n, secs, limit_s=75.0)
     torch.set_num_threads(best_n)
     return out
+
+
+def cpu_leg_multiproc(n_cores, n_thr, secs, limit_s):
+    """nproc-wide CPU figure that does not depend on one intra-op pool spanning the host: n_cores / n_thr children of `bench.py --cpu-leg n_thr`, started
+    together, each running utterances for 5 s; value = the sum of their rates (they overlap for all but process start-up). CHECKER ONLY."""
+    import subprocess
+    n_proc = max(1, n_cores // max(n_thr, 1))
+    env = dict(os.environ, OMP_NUM_THREADS=str(n_thr), MKL_NUM_THREADS=str(n_thr))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-leg", str(n_thr)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
+             for _ in range(n_proc)]
+    t0, total, done = time.perf_counter(), 0.0, 0
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=max(1.0, limit_s - (time.perf_counter() - t0)))
+            total += float(json.loads(o.strip().splitlines()[-1])["value"])
+            done += 1
+        except (subprocess.TimeoutExpired, ValueError, IndexError, KeyError):
+            pr.kill()
+    if done == 0:
+        return {"value": None, "cores": n_proc * n_thr, "sample": f"none of {n_proc} worker processes finished inside {limit_s:.0f} s"}
+    return {"value": round(total, 2), "cores": done * n_thr,
+            "sample": f"{done} of {n_proc} worker processes x {n_thr} threads, each running {secs:.0f} s utterances one at a time for 5 s (first pass included); sum of their rates"}
 
 
 def cpu_leg_all_cores(n_thr, secs, limit_s):

@@ -132,7 +132,15 @@ def gen_whisper(clips):
                "prompt": np.asarray(prompt, np.int32)}
         L = cfg.n_dec_layers
         for name, pcm in clips.items():
-            r = reference_greedy(ref, cfg, na.unit_input(pcm), prompt, n_new, suppress, begin)
+            # the front-end alone (Export_Whisper.py:424-427: mel -> clamp -> log10 -> max(x, global max - 8) -> (x + 4) / 4) = what conv1 is handed
+            mel_in = {}
+            hook = ref["encoder"].encoder.conv1.register_forward_pre_hook(lambda m, inp: mel_in.__setitem__("mel", inp[0].detach().clone()))
+            try:
+                r = reference_greedy(ref, cfg, na.unit_input(pcm), prompt, n_new, suppress, begin)
+            finally:
+                hook.remove()
+            mel = mel_in["mel"][0].t().contiguous().numpy()                              # (frames, n_mels)
+            out[name + "_mel"] = mel if small else mel[::4].copy()
             keys = torch.stack([k.permute(0, 2, 1) for k in r["cross"][:L]]).numpy()     # (L, H, T, hd)
             vals = torch.stack(list(r["cross"][L:])).numpy()
             p = name + "_"

@@ -64,6 +64,10 @@ def test_whisper_oracle_on_natural_clips():
     orc = WhisperOracle(cfg, ck, sup, beg)
     clips = na.load_clips()
     for n, pcm in clips.items():
+        # the front-end alone (Export_Whisper.py:424-427), not only through 2 layers of encoder: log-mel with the 1e-10 clamp and the clip-wise max - 8 floor
+        import torch
+        mel = orc.log_mel(torch.as_tensor(na.unit_input(pcm))).t().numpy()
+        assert mel.shape == g[n + "_mel"].shape and np.abs(mel - g[n + "_mel"]).max() < F32_TOL, n
         r = orc.greedy([na.unit_input(pcm)], [g["prompt"].tolist()], int(g["n_new"]))
         k, v = r["cross"][0]
         assert np.abs(k - g[n + "_cross_k"]).max() < F32_TOL and np.abs(v - g[n + "_cross_v"]).max() < F32_TOL, n

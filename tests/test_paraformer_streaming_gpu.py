@@ -116,6 +116,7 @@ def test_fused_launches_vs_per_launch_path(monkeypatch):
     monkeypatch.setenv("ASR_STREAM_FUSED", "0")
     plain = sub("engine").ParaformerStreamSession(cfg, ck, precision=BF16, chunk=chunk, max_streams=S)
     monkeypatch.delenv("ASR_STREAM_FUSED")
+    monkeypatch.setenv("ASR_STREAM_SHARE", "0")          # (the two sessions alternate on this GPU: the co-tenancy rule would move the second one to the per-launch path as well)
     fused = sub("engine").ParaformerStreamSession(cfg, ck, precision=BF16, chunk=chunk, max_streams=S)
     plain.taps(True)
     fused.taps(True)
@@ -177,6 +178,7 @@ def test_fused_step_that_gives_up_is_restored_and_redone(monkeypatch):
     want = _run_streams(plain, audio, chunk, n_chunks)
     monkeypatch.setenv("ASR_STREAM_SNAPSHOT", "1")
     monkeypatch.setenv("ASR_STREAM_FAULT", "1")
+    monkeypatch.setenv("ASR_STREAM_SHARE", "0")          # (`plain` left its last call a moment ago: without this the first step would not fuse at all)
     faulty = eng.ParaformerStreamSession(cfg, ck, precision=BF16, chunk=chunk, max_streams=S)
     # two clean fused steps on OTHER stream ids would be possible too; here the very first step of the session is the one that fails
     got = _run_streams(faulty, audio, chunk, n_chunks)
@@ -202,8 +204,9 @@ def test_snapshot_does_not_change_a_clean_step_and_dispatch_follows_the_stream_c
     eng = sub("engine")
     base = eng.ParaformerStreamSession(cfg, ck, precision=BF16, chunk=chunk, max_streams=S)
     want = _run_streams(base, audio, chunk, n_chunks)
-    assert base.stream_stats()["snapshots"] == 0 and base.stream_stats()["fused_max"] >= 64        # alone on the GPU: nothing to guard against (the other sessions of this test are created later)
+    assert base.stream_stats()["giveups"] == 0 and base.stream_stats()["fused_max"] >= 64
     monkeypatch.setenv("ASR_STREAM_SNAPSHOT", "1")
+    monkeypatch.setenv("ASR_STREAM_SHARE", "0")
     snap = eng.ParaformerStreamSession(cfg, ck, precision=BF16, chunk=chunk, max_streams=S)
     got = _run_streams(snap, audio, chunk, n_chunks)
     assert snap.stream_stats()["snapshots"] == n_chunks and snap.stream_stats()["giveups"] == 0
@@ -249,7 +252,8 @@ def test_bf16_64_streams_tokens_equal_the_oracle_on_a_head_with_trained_margins(
     Demanded: the oracle's fired counts and token ids for every chunk of all 64 streams."""
     g = load_golden("paraformer_streaming_large")
     cfg, ck = streaming_setup(g)
-    chunk, S, n_chunks, slack, window = int(g["chunk"]), 64, 5, 0.04, 2.0
+    chunk, S, n_chunks, window = int(g["chunk"]), 64, 3, 2.0
+    slack = lambda k: 0.008 + 0.0013 * k                      # distance from equality demanded of the k-th comparison of a stream: the bf16 error of ONE weight + the drift of the running sum
     orc = ParaformerStreamingOracle(cfg, ck, chunk=chunk)
     A, B = orc.A, orc.B
     audio, recs_all, tried = [], [], 0
@@ -257,14 +261,15 @@ def test_bf16_64_streams_tokens_equal_the_oracle_on_a_head_with_trained_margins(
         a = kaldi_audio(8800 + tried, n_chunks * chunk)
         recs = orc.run(a)
         tried += 1
-        ca, ok = 0.0, True
+        ca, ok, kk = 0.0, True, 0
         for r in recs:                                           # replay the integrate-and-fire on the oracle's weights: distance of every comparison from equality
-            ok = ok and abs(ca - 1.0) > slack
+            ok = ok and abs(ca - 1.0) > slack(kk)
             if ca >= 1.0:
                 ca -= 1.0
             for t in range(A, A + B):
                 al = float(r["alphas"][t])
-                ok = ok and abs(ca + al - 1.0) > slack
+                ok = ok and abs(ca + al - 1.0) > slack(kk)
+                kk += 1
                 ca += al
                 if ca >= 1.0:
                     ca -= 1.0
@@ -285,13 +290,18 @@ def test_bf16_64_streams_tokens_equal_the_oracle_on_a_head_with_trained_margins(
         for k, r in enumerate(recs):
             want[(s, k)] = cls[k0:k0 + r["n"]]
             k0 += r["n"]
-    margins, wrong, e_near, e_all, e_alpha = [], [], 0.0, 0.0, 0.0
+    margins, wrong, e_near, e_all, e_alpha, e_run = [], [], 0.0, 0.0, 0.0, 0.0
+    drift = np.zeros(S)                                          # running sum of (bf16 weight - oracle weight) per stream
     for k in range(n_chunks):
         out = sess.step(np.stack([a[k * chunk:(k + 1) * chunk] for a in audio]), list(range(S)))
         logits, alphas = sess.tap("logits"), sess.tap("alphas")[:, 0]
         for s in range(S):
             r = recs_all[s][k]
-            e_alpha = max(e_alpha, float(np.abs(alphas[16 * s:16 * s + A + B] - r["alphas"][:A + B]).max()))
+            da = alphas[16 * s + A:16 * s + A + B].astype(np.float64) - r["alphas"][A:A + B].astype(np.float64)
+            e_alpha = max(e_alpha, float(np.abs(da).max()))
+            run = drift[s] + np.cumsum(da)
+            e_run = max(e_run, float((np.abs(run) / np.asarray([slack(k * B + t) for t in range(B)])).max()))      # as a fraction of what the selection allowed for
+            drift[s] = run[-1]
             if out[s].size != r["n"] or not np.array_equal(out[s], want[(s, k)]):
                 wrong.append((s, k, out[s].tolist(), want[(s, k)].tolist()))
                 continue
@@ -305,10 +315,10 @@ def test_bf16_64_streams_tokens_equal_the_oracle_on_a_head_with_trained_margins(
                 margins.append(np.partition(d_orc, 1, axis=1)[:, 1])
                 e_all, e_near = max(e_all, float(err.max())), max(e_near, float(err[d_orc <= window].max()))
     margins = np.concatenate(margins)
-    print(f"streaming, 64 streams x {n_chunks} chunks ({tried} candidate seeds): {k0} tokens; CIF weights off by <= {e_alpha:.4f} (slack {slack}); oracle margin min "
+    print(f"streaming, 64 streams x {n_chunks} chunks ({tried} candidate seeds): {k0} tokens; CIF weights off by <= {e_alpha:.4f} each, their running sum <= {e_run:.2f} of the allowance; oracle margin min "
           f"{margins.min():.3f} median {np.median(margins):.3f}; bf16 error of logit differences {e_near:.3f} within {window} of the winner, {e_all:.3f} over all classes")
     assert not wrong, (len(wrong), wrong[:3])
-    assert e_alpha < slack / 2
+    assert e_run < 1.0
     assert margins.min() > 2 * e_near, (margins.min(), e_near)
     st = sess.stream_stats()
     assert st["giveups"] == 0 and st["shared_steps"] == 0

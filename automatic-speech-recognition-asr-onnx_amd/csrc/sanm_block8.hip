@@ -574,11 +574,21 @@ __device__ __forceinline__ int opaque_s(int v) { asm volatile("" : "+s"(v)); ret
 
 constexpr int GETREG_XCC_ID = 20 | (0 << 6) | ((4 - 1) << 11);          // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4)
 // all four workgroups of the cluster on this XCD? (wave-uniform: one relaxed load per wave)
-__device__ __forceinline__ bool cluster_shares_l2(const unsigned* place, int opt) {
-  if (opt & 4) return false;                            // tuning switch: always fence
+__device__ __forceinline__ bool cluster_on_one_xcd(const unsigned* place) {
   const unsigned w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(place, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   const unsigned b = w & 0xffu;
   return b != 0u && w == b * 0x01010101u;
+}
+// "no fence" form of an exchange (write-through stores, sc1 loads, no acquire): only inside one XCD. opt 4: always fence; opt 1024 (round 5): inside one XCD the payload
+// STAYS in the shared L2 -- ordinary stores, ONE agent-scope acquire per consumer (drops its L1), ordinary loads, which then hit the (dirty) L2 lines the three
+// siblings share instead of fetching every chunk three times from the memory side
+__device__ __forceinline__ bool cluster_shares_l2(const unsigned* place, int opt) {
+  if (opt & (4 | 1024)) return false;
+  return cluster_on_one_xcd(place);
+}
+__device__ __forceinline__ bool cluster_plain_stores(const unsigned* place, int opt) {
+  if (opt & 1024) return cluster_on_one_xcd(place);
+  return (opt & 256) && cluster_shares_l2(place, opt);
 }
 
 // opt & 2048: the phase clock looks INSIDE phase A -- stamps 4..7 are taken behind the statistics, the images, the waves' own attention tiles and the shared tile
@@ -830,7 +840,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     // ---- context rows of this head -> memory (whole 16-byte chunks, write-through) and count the workgroup in on exchange 0; alignment rows past the
     //      window become zeros in memory AND in the image (the own chunk of phase B must equal what the other heads read back)
     {
-      const bool plain = (a->opt & 256) && cluster_shares_l2(place, a->opt);      // tuning switch: payload left in the shared L2 (ordinary stores)
+      const bool plain = cluster_plain_stores(place, a->opt);      // tuning switch: payload left in the shared L2 (ordinary stores)
       if (a->times && tid == 0) a->times[(size_t)blockIdx.x * 16 + 15] = plain ? 1ull : 0ull;
       const int T16 = n_act * 16;
       for (int c = T * 16 + tid; c < T16 * 16; c += NT) *reinterpret_cast<uint4*>(smem + QS + c * 16) = make_uint4(0, 0, 0, 0);
@@ -917,7 +927,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     khalf_exchange(smem + RED, kh, cg, lane, accb);
     // x1 rows: f32 -> memory (this workgroup's own slab: phase D reads it back), bf16 -> exchange 1 + the own chunk of phase C (slot 0), row statistics
     {
-      const bool plain = (a->opt & 256) && cluster_shares_l2(place, a->opt);      // tuning switch: payload left in the shared L2 (ordinary stores)
+      const bool plain = cluster_plain_stores(place, a->opt);      // tuning switch: payload left in the shared L2 (ordinary stores)
       const int n = cg * 32 + fgrp * 8;
       float* xo = a->x + (size_t)row0 * D + h * HD + n;
       const bool direct = (a->opt & 8) == 0;                  // payload rows go out of the registers (measured 1.5 % faster than image pieces out of LDS: the stores are bound by the write path, not by their issue); opt 8: through the LDS image
@@ -958,7 +968,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     bf16x8_t wr[PWR][2];
     w_prefetch<2, PWR>(wr, wp);
     const bool nofence = cluster_shares_l2(place, a->opt);
-    const bool plain = (a->opt & 256) && nofence;
+    const bool plain = cluster_plain_stores(place, a->opt);
     consume(flags + 1, NH, a->err, !nofence);
     STAMP(8);
     {
@@ -1037,7 +1047,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     const float b8[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
     float* xo = a->x + (size_t)row0 * D + h * HD + n;
     bf16_t* xl = a->x_lo_out + (size_t)row0 * D + h * HD + n;
-    const bool plain_d = (a->opt & 256) && cluster_shares_l2(place, a->opt);
+    const bool plain_d = cluster_plain_stores(place, a->opt);
     unsigned char* ximg = reinterpret_cast<unsigned char*>(a->x_lo_out + (size_t)row0 * D) + (size_t)h * n_act * 4096;
 #pragma unroll
     for (int i = 0; i < RF; ++i) {
@@ -1096,7 +1106,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     if (tid < R) row_stats_finish(smem, a->ln_eps, tid);
     __syncthreads();
     STAMP(9);
-    const bool plain = (a->opt & 256) && cluster_shares_l2(place, a->opt);      // tuning switch: payload left in the shared L2 (ordinary stores)
+    const bool plain = cluster_plain_stores(place, a->opt);      // tuning switch: payload left in the shared L2 (ordinary stores)
     const bool direct = (a->opt & 8) == 0;
     unsigned char* himg = reinterpret_cast<unsigned char*>(a->hid + (size_t)row0 * DFF) + (size_t)(4 * h) * n_act * 4096;
     {
@@ -1169,7 +1179,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     const float b8[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
     float* xo = a->x + (size_t)row0 * D + h * HD + n;
     bf16_t* xl = a->x_lo_out + (size_t)row0 * D + h * HD + n;
-    const bool plain_d = (a->opt & 256) && cluster_shares_l2(place, a->opt);
+    const bool plain_d = cluster_plain_stores(place, a->opt);
     unsigned char* ximg = reinterpret_cast<unsigned char*>(a->x_lo_out + (size_t)row0 * D) + (size_t)h * n_act * 4096;        // (x_lo == x_lo_out inside a multi-block launch)
 #pragma unroll
     for (int i = 0; i < RF; ++i) {

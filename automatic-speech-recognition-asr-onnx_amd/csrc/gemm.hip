@@ -24,6 +24,7 @@
 // ---- tuning / ablation switches (environment), re-read by gemm_reload_env() at every session creation so that a test can flip them in-process
 struct GemmEnv {
   bool t144 = true, t144w = true, t288w = true, big = true, pp = true, splitk = true, deep = true, skinny144 = false;
+  bool amax_pp = false;                  // ASR_GEMM_AMAX_PP=1: the arg-max head on the persistent ping-pong kernel instead of the 288 x 256 tiles
   int skinny_splitk = -1, tall_min = 16, skinny_max_plain = 32;
   int decode_nt = 0, decode_ks = 0;      // ASR_DECODE_NT / ASR_DECODE_KS: force the decode GEMM's column granule / split count (0 = the cost model)
   bool decode_attn_wave = true;          // ASR_DECODE_ATTN_WAVE=0: single-token self-attention on the general kernel
@@ -55,6 +56,7 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 void gemm_reload_env() {
   GemmEnv e;
   e.t144 = env_flag("ASR_GEMM_T144", true); e.t144w = env_flag("ASR_GEMM_T144W", true); e.t288w = env_flag("ASR_GEMM_T288W", true);
+  e.amax_pp = env_flag("ASR_GEMM_AMAX_PP", false);
   e.big = env_flag("ASR_GEMM_BIG", true); e.pp = env_flag("ASR_GEMM_PP", true); e.splitk = env_flag("ASR_GEMM_SPLITK", true); e.deep = env_flag("ASR_GEMM_DEEP", true);
   e.skinny144 = getenv("ASR_SKINNY_M144") && getenv("ASR_SKINNY_M144")[0] == '1';
   e.skinny_splitk = env_int("ASR_SKINNY_SPLITK", -1); e.tall_min = env_int("ASR_GEMM_TALL_MIN", 16);
@@ -1426,8 +1428,9 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
       ASR_REQUIRE(t144_stages(g) == 4 ? launch_t144<4>(g, s) : launch_t144<2>(g, s), "gemm: no LayerNorm-fused instance for this epilogue");
       return;
     }
+    if (g.amax_val && genv().amax_pp && pp_fits(g) && launch_gemm_pp(g, s)) { note_kernel("pp_amax"); return; }
     if (launch_t288w_amax(g, s)) return;
-    if (pp_fits(g) && launch_gemm_pp(g, s)) { note_kernel("pp"); return; }
+    if (!g.amax_val && pp_fits(g) && launch_gemm_pp(g, s)) { note_kernel("pp"); return; }
     if (big_fits(g) && launch_big(g, s)) return;
     if (t144_enabled() && t144_fits(g, &st) && (st == 4 ? launch_t144<4>(g, s) : launch_t144<2>(g, s))) return;
     if (const int sp = tiled_splits(g); sp > 1) {

@@ -113,7 +113,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4_t (&acc)[
         const int n0 = n_wave + frag_col(j, fgrp * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = acc[i][j][r] + (has_bias ? g.bias[n0 + r] : 0.0f);
+          float v = acc[i][j][r] + (has_bias ? (bias_at ? bias_at : g.bias)[n0 + r] : 0.0f);
           if (n0 + r >= g.n_valid) v = -INFINITY;
           if (v > best) { best = v; bidx = n0 + r; }          // first max wins
         }

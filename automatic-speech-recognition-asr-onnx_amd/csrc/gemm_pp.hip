@@ -609,7 +609,8 @@ void launch_pp32_inst(const GemmArgs& g, hipStream_t s) {
 bool gemm_pp_supported(const GemmArgs& g) {
   if (g.out_t && (g.add || g.add2 || g.out_f32 || g.out_lo || g.act != ACT_NONE)) return false;
   if ((size_t)g.M * g.lda * 2 >= ((size_t)1 << 32) || (size_t)g.N * g.ldw * 2 >= ((size_t)1 << 32)) return false;
-  return !g.amax_val && !g.ln_colsum && !g.st_out && !g.m_dev && !g.rms_out && g.k_splits <= 1 && g.N % PP_T == 0 && g.K % 128 == 0 &&
+  if (g.amax_val && (g.out_f32 || g.out_lo || g.out_t || g.add || g.add2 || g.act != ACT_NONE || !g.bias || !g.amax_idx)) return false;      // the arg-max head: partial (max, index) per 64-column slab only
+  return !g.ln_colsum && !g.st_out && !g.m_dev && !g.rms_out && g.k_splits <= 1 && g.N % PP_T == 0 && g.K % 128 == 0 &&
          g.K >= 128 && g.M >= 1;
 }
 
@@ -635,7 +636,7 @@ bool launch_gemm_pp(const GemmArgs& g, hipStream_t s, int var) {
     }
   }
   if (g.out_t) { launch_ppp_inst<ACT_NONE, 0, false>(g, s); return true; }          // V^T (bias handled at run time by the transposed epilogue)
-  const int epi = (g.add ? E_ADD : 0) | (g.add2 ? E_ADD2 : 0) | (g.out_f32 ? E_F32 : 0) | (g.out_lo ? E_LO : 0) | (g.bias ? E_BIAS : 0);
+  const int epi = (g.add ? E_ADD : 0) | (g.add2 ? E_ADD2 : 0) | (g.out_f32 ? E_F32 : 0) | (g.out_lo ? E_LO : 0) | (g.bias ? E_BIAS : 0) | (g.amax_val ? E_AMAX : 0);
 #define ASR_PP_CASE(ACT_, EPI_) \
   if (g.act == (ACT_) && epi == (EPI_)) { if (var < 0) launch_pp_inst<ACT_, EPI_>(g, s); else launch_ppp_inst<ACT_, EPI_>(g, s); return true; }
   ASR_PP_CASE(ACT_NONE, E_BIAS | E_LO)                      // q|k projections, cross-K/V slabs (lo_group)
@@ -646,6 +647,7 @@ bool launch_gemm_pp(const GemmArgs& g, hipStream_t s, int var) {
   ASR_PP_CASE(ACT_SWIGLU, E_LO)                             // Qwen3 decoder gate|up
   ASR_PP_CASE(ACT_NONE, E_ADD | E_F32)                      // Qwen3 decoder o_proj / down_proj
   ASR_PP_CASE(ACT_NONE, E_BIAS | E_F32)                     // logits
+  ASR_PP_CASE(ACT_NONE, E_BIAS | E_AMAX)                    // CTC / vocabulary head with the fused row arg-max (round 5: K = 512 tiles streamed through the tile boundary)
   ASR_PP_CASE(ACT_RELU, E_BIAS | E_LO)
   ASR_PP_CASE(ACT_GELU_ERF, E_BIAS | E_ADD2 | E_F32)        // Whisper conv2: gelu(conv) + positions
   ASR_PP_CASE(ACT_GELU_TANH, E_BIAS | E_ADD2 | E_F32)

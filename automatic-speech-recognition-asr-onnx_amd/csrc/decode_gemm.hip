@@ -285,7 +285,8 @@ bool decode_gemm_supported(const DecGemmArgs& g) {
 void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits) {
   const int cus = gemm_env_cus();
   const int force_nt = gemm_env_decode_nt(), force_ks = gemm_env_decode_ks();          // tuning hooks, re-read at session creation like every other switch
-  const int ws_rows = g.M <= 16 ? 16 : g.M <= 32 ? 32 : 64;      // rows per split slab as the kernel addresses them: [ks][MT * 16][N]
+  const int pm = g.plan_M > g.M ? g.plan_M : g.M;
+  const int ws_rows = pm <= 16 ? 16 : pm <= 32 ? 32 : 64;        // rows per split slab as the kernel addresses them: [ks][MT * 16][N]
   const int mt = ws_rows / 16;
   const bool can_split = g.ws && g.cnt;
   double best_cost = 1e30;

@@ -35,6 +35,10 @@ struct GemmArgs {
   // every workgroup accumulates sum(x^2) from the A fragments it streams anyway and scales its output rows by rsqrt(mean + a_rms_eps)
   // before bias / residual terms. a_rms_eps > 0 enables it (the norm weight must be folded into W).
   float a_rms_eps = 0.0f;
+  // Skinny path, byte weights (precision mode ASR_PRECISION_FP8W of Qwen3-ASR): W8 holds OCP e4m3 bytes [N][K] (row pitch ldw8 bytes) with one power-of-two f32 scale
+  // per output column; a lane loads 8 bytes per fragment, widens them to bf16 in registers (exact) and the finished sum is multiplied by the scale -- bit for bit the
+  // product over the dequantised bf16 copy (which W keeps for every other path). With W8 set a launch of <= 64 rows always streams weights (skinny kernel).
+  const unsigned char* W8 = nullptr; int ldw8 = 0; const float* w_scale = nullptr;
   // LayerNorm evaluated inside the GEMM (144-row-tile kernel only; K must span the whole normalised row): A holds the RAW rows
   // x in bf16, row statistics over the first ln_dim columns are accumulated from the LDS tiles during the MFMA loop and
   // C = rstd (x W^T - mean ln_colsum) + bias. Needs the LayerNorm affine folded into W / bias; ln_colsum[n] = sum_k W[n][k].
@@ -91,6 +95,8 @@ struct DecGemmArgs {
   const bf16_t* W = nullptr; int ldw = 0;            // [N][K]
   const unsigned char* W8 = nullptr; const float* w_scale = nullptr;    // FP8 mode instead of W: e4m3 bytes [N][K] (pitch ldw) + one power-of-two scale per output column
   int M = 0, N = 0, K = 0;
+  int plan_M = 0;                                    // rows the grid shape (column granule, K splits: the summation order) is planned for; 0 = M. The decode chains of whisper.hip plan every
+                                                     // chain for the largest one, so a sequence's result does not depend on the chain it rides in
   const float* bias = nullptr;
   const float* colsum = nullptr; float ln_eps = 1e-5f;      // c[n] = sum_k W[n][k]: out = rstd (A W^T - mean c) + bias
   const float* add = nullptr; int ld_add = 0;        // + f32 residual rows

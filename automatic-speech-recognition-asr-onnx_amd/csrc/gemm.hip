@@ -17,6 +17,7 @@
 //
 // f32 kernel: same tile on v_mfma_f32_16x16x4_f32 (exact f32 FMA chains) for verification mode.
 #include <cstring>
+#include <type_traits>
 #include <string>
 #include "gemm.h"
 #include "gemm_dev.h"
@@ -24,7 +25,7 @@
 // ---- tuning / ablation switches (environment), re-read by gemm_reload_env() at every session creation so that a test can flip them in-process
 struct GemmEnv {
   bool t144 = true, t144w = true, t288w = true, big = true, pp = true, splitk = true, deep = true, skinny144 = false;
-  bool amax_pp = false;                  // ASR_GEMM_AMAX_PP=1: the arg-max head on the persistent ping-pong kernel instead of the 288 x 256 tiles
+  bool amax_pp = true;                   // ASR_GEMM_AMAX_PP=0: the arg-max head on the 288 x 256 tiles instead of the persistent ping-pong kernel (CTC head at 64 x 8 s: 288 -> 217 us)
   int skinny_splitk = -1, tall_min = 16, skinny_max_plain = 32;
   int decode_nt = 0, decode_ks = 0;      // ASR_DECODE_NT / ASR_DECODE_KS: force the decode GEMM's column granule / split count (0 = the cost model)
   bool decode_attn_wave = true;          // ASR_DECODE_ATTN_WAVE=0: single-token self-attention on the general kernel
@@ -56,7 +57,7 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 void gemm_reload_env() {
   GemmEnv e;
   e.t144 = env_flag("ASR_GEMM_T144", true); e.t144w = env_flag("ASR_GEMM_T144W", true); e.t288w = env_flag("ASR_GEMM_T288W", true);
-  e.amax_pp = env_flag("ASR_GEMM_AMAX_PP", false);
+  e.amax_pp = env_flag("ASR_GEMM_AMAX_PP", true);
   e.big = env_flag("ASR_GEMM_BIG", true); e.pp = env_flag("ASR_GEMM_PP", true); e.splitk = env_flag("ASR_GEMM_SPLITK", true); e.deep = env_flag("ASR_GEMM_DEEP", true);
   e.skinny144 = getenv("ASR_SKINNY_M144") && getenv("ASR_SKINNY_M144")[0] == '1';
   e.skinny_splitk = env_int("ASR_SKINNY_SPLITK", -1); e.tall_min = env_int("ASR_GEMM_TALL_MIN", 16);
@@ -703,7 +704,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t288w(const GemmArgs g0) {
 // for the bias / residual / store epilogue. With g.ln_x the A rows are LayerNorm(ln_x) computed in the prologue.
 constexpr int SK_WAVES = 8;
 
-template <int MT, bool LN>     // LN: the LayerNorm prologue (own instance: its registers / LDS allow one workgroup per CU only)
+typedef __attribute__((ext_vector_type(2))) unsigned int sk_u32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 sk_bf16x2_hw_t;
+// 8 e4m3 bytes -> one bf16x8 MFMA fragment (v_cvt_scalef32_pk_bf16_fp8, scale 1: exact)
+__device__ __forceinline__ bf16x8_t sk_fp8x8_to_bf16x8(sk_u32x2_t r) {
+  union { bf16x8_t v; sk_bf16x2_hw_t p[4]; } u;
+  u.p[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[0], 1.0f, false); u.p[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[0], 1.0f, true);
+  u.p[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[1], 1.0f, false); u.p[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[1], 1.0f, true);
+  return u.v;
+}
+
+template <int MT, bool LN, bool W8 = false>     // LN: the LayerNorm prologue (own instance: its registers / LDS allow one workgroup per CU only); W8: e4m3 weight bytes (GemmArgs::W8)
 __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_bf16_skinny(const GemmArgs g) {   // <= 128 VGPRs: two workgroups share a CU
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -716,14 +727,20 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
   // the simultaneous requests over the slices (the cross-wave sum below is order-stable per workgroup, so results stay reproducible).
   const int kw = (wave + (int)blockIdx.x) & (SK_WAVES - 1);
   const int k_begin = (ks * SK_WAVES + kw) * kslice;
+  using wfrag_t = typename std::conditional<W8, sk_u32x2_t, bf16x8_t>::type;       // a lane's 8 weights of one K-step: 8 bytes or 16
   const bf16_t* wp = reinterpret_cast<const bf16_t*>(g.W) + (size_t)(n0 + frow) * g.ldw + k_begin + fgrp * 8;
+  const unsigned char* wp8 = g.W8 + (size_t)(n0 + frow) * g.ldw8 + k_begin + fgrp * 8;
+  auto w_load = [&](int k) -> wfrag_t {
+    if constexpr (W8) return __builtin_nontemporal_load(reinterpret_cast<const sk_u32x2_t*>(wp8 + k));
+    else return __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + k));
+  };
 
   constexpr int U = MT >= 4 ? 4 : 8;                    // K-steps per trip: U x 16-byte weight loads in flight per lane (4 row tiles: fewer, to stay under 128 VGPRs => two workgroups per CU)
   // the weight stream does not depend on the activations: start it before the LayerNorm prologue
-  bf16x8_t wf0[U];
+  wfrag_t wf0[U];
 #pragma unroll
   for (int u = 0; u < U; ++u)
-    if (u * 32 < kslice) wf0[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + u * 32));
+    if (u * 32 < kslice) wf0[u] = w_load(u * 32);
 
   // the residual term of the epilogue (wave w finishes row tiles w, w + 8) is requested now: its L2 round trip hides behind the stream
   float4 addv[(MT + SK_WAVES - 1) / SK_WAVES];
@@ -805,25 +822,27 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
   const bool a_rms = g.a_rms_eps > 0.0f;
   // Two register sets of U weight fragments: the loads of trip t + 1 are issued BEFORE the MFMAs of trip t, so a long K slice (fc2:
   // K = 5120 -> 20 K-steps per wave = 3 trips) pays one HBM round trip, not one per trip (19.2 -> ~10 us per launch at 32 rows).
-  auto load_set = [&](bf16x8_t (&wf)[U], int k) {
+  auto load_set = [&](wfrag_t (&wf)[U], int k) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (k + u * 32 < kslice) wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + k + u * 32));
+      if (k + u * 32 < kslice) wf[u] = w_load(k + u * 32);
   };
-  auto mma_set = [&](const bf16x8_t (&wf)[U], int k) {
+  auto mma_set = [&](const wfrag_t (&wf)[U], int k) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (k + u * 32 < kslice) {
+        bf16x8_t wv;
+        if constexpr (W8) wv = sk_fp8x8_to_bf16x8(wf[u]); else wv = wf[u];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(ap + (size_t)i * 16 * lda + k + u * 32);
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], af, acc[i], 0, 0, 0);   // D[n = 4 fgrp + r][m = frow]
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, af, acc[i], 0, 0, 0);   // D[n = 4 fgrp + r][m = frow]
           if (a_rms) gram[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, af, gram[i], 0, 0, 0);
         }
       }
     }
   };
-  bf16x8_t wf1[U];
+  wfrag_t wf1[U];
   for (int k = 0; k < kslice; k += 64 * U) {
     if (k + 32 * U < kslice) load_set(wf1, k + 32 * U);
     mma_set(wf0, k);
@@ -910,6 +929,7 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
     float4 sum = sums[t];
     const int m = i * 16 + frow, n = n0 + fgrp * 4;
     if (m >= g.M) continue;
+    if constexpr (W8) { const float4 sc = *reinterpret_cast<const float4*>(g.w_scale + n); sum.x *= sc.x; sum.y *= sc.y; sum.z *= sc.z; sum.w *= sc.w; }   // (powers of two: exact)
     if (a_rms) {                                          // fixed summation order over the waves
       float t = ss_red[0][m];
 #pragma unroll
@@ -974,6 +994,15 @@ void launch_skinny(const GemmArgs& g, hipStream_t s) {
     if (g.ln_x) {
       note_kernel("skinny_ln");
       hipLaunchKernelGGL((gemm_bf16_skinny<MT, true>), dim3(g.N / 16, gg.sk_splits), dim3(64 * SK_WAVES), lds, s, gg);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
+  }
+  if constexpr (MT <= 4) {
+    if (g.W8) {
+      ASR_REQUIRE(g.w_scale && !g.ln_x && g.ldw8 % 8 == 0, "gemm(skinny): byte weights need their scales, 8-byte aligned rows and no LayerNorm prologue");
+      note_kernel("skinny_w8");
+      hipLaunchKernelGGL((gemm_bf16_skinny<MT, false, true>), dim3(g.N / 16, gg.sk_splits), dim3(64 * SK_WAVES), lds, s, gg);
       HIP_CHECK(hipGetLastError());
       return;
     }
@@ -1383,7 +1412,7 @@ bool gemm_ln_fusable(const GemmArgs& g) {
 // mirrors the routing of launch_gemm_bf16 (conservatively: "false" only costs the caller a stand-alone RMSNorm launch)
 bool gemm_reduce_can_norm(const GemmArgs& g) {
   if (g.N != 1024 || g_gemm_variant >= 0 || g.ln_x || g.a_rms_eps != 0.0f || g.ln_colsum || g.amax_val || g.out_t || g.lo_group) return false;
-  const bool needs_skinny = !g.sk_ws;
+  const bool needs_skinny = !g.sk_ws || g.W8 != nullptr;
   if (g.M <= 64 && (needs_skinny || g.M <= genv().skinny_max_plain) && g.K % (32 * SK_WAVES) == 0) return false;
   if (genv().skinny144 && g.M <= 144 && g.sk_ws && !g.st_out && g.K % (32 * SK_WAVES) == 0 && (g.lda * 2) % 16 == 0) return false;
   int st = 0;
@@ -1399,7 +1428,7 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
   const int tall_min = genv().tall_min;
   const bool tall = g.M > tall_min && g.N >= 16384 && !g.ln_x && g.a_rms_eps == 0.0f && g.act != ACT_SWIGLU;
   const int skinny_max_plain = genv().skinny_max_plain;   // rows up to which PLAIN GEMMs (no prologue) stream weights; above, the tiled split-K pass shares the activation rows across 64 columns (Whisper B = 64: 4.62 -> 3.89 ms per token)
-  const bool needs_skinny = g.ln_x || g.a_rms_eps != 0.0f || !g.sk_ws;
+  const bool needs_skinny = g.ln_x || g.a_rms_eps != 0.0f || !g.sk_ws || g.W8 != nullptr;
   if (g.M <= 64 && (needs_skinny || g.M <= skinny_max_plain || g.N % 128 != 0) && !tall && !g.out_t && !g.amax_val && g.lo_group == 0 && g.K % (32 * SK_WAVES) == 0 && g_gemm_variant < 0) {
     ASR_REQUIRE((g.A || g.ln_x) && g.W && g.N % 16 == 0, "gemm(skinny): bad operands");
     ASR_REQUIRE(g.ln_x || (g.lda * 2) % 16 == 0, "gemm(skinny): lda must be a 16-byte multiple");

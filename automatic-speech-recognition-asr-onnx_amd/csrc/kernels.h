@@ -85,6 +85,9 @@ struct DecAttnArgs {
   // paged self-KV cache (block table; stride_b / stride_h unused): position s of (sequence b, head h) lives at
   //   k_base + page_table[b * pages_per_seq + (s >> 4)] * page_stride + h * 1024 + (s & 15) * 64       (pages of 16 positions x 64 dims per head)
   const int32_t* page_table = nullptr; int pages_per_seq = 0; int64_t page_stride = 0;
+  // a launch over the sub-batch [b0, b0 + grid.x) of the session's batch (the decode chains of whisper.hip): every per-sequence index is b0 + blockIdx.x;
+  // scale_ld = sequences per head row of k_scale / v_scale (0: the launch's own grid.x)
+  int b0 = 0, scale_ld = 0;
 };
 // FP8 (OCP e4m3, power-of-two scales) quantisers of precision mode ASR_PRECISION_FP8W
 void launch_quantize_rows_fp8(const bf16_t* W, int ld, int N, int K, unsigned char* W8, float* scale, bf16_t* Wdq, hipStream_t s);

@@ -30,22 +30,25 @@ __global__ __launch_bounds__(256) void fbank_kernel(const FbankArgs a) {
   const UttPlan up = a.plan[u];
   const float* src = a.audio + up.audio_off;
   const int s0 = f0 * HOP;
-  if (!a.whisper) {
-    for (int i = tid; i < FB_SPAN; i += 256) {
-      const int s = s0 + i;
-      aud[i + i / HOP] = (s < up.n_samples) ? src[s] : 0.0f;
+  // every thread requests all of its samples before it stores the first (a load / store loop runs as one memory round trip per iteration: see fbank_split_kernel)
+  constexpr int NL = (FB_SPAN + 255) / 256;
+  float av[NL];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    // Kaldi reads x[s]; Whisper the padded signal [x[200..1] | x | x[L-2 .. L-41]]  (reflect, right pad shortened by one hop)
+    const int i = tid + j * 256, L = up.n_samples, half = WIN / 2, p = s0 + i;
+    int idx = p;
+    bool ok = i < FB_SPAN && p < L;
+    if (a.whisper) {
+      idx = p < half ? half - p : p < half + L ? p - half : 2 * L + half - 2 - p;
+      ok = i < FB_SPAN && p < L + WIN - HOP;
     }
-  } else {
-    // padded signal = [x[200..1] | x | x[L-2 .. L-41]]  (reflect, right pad shortened by one hop)
-    const int L = up.n_samples, half = WIN / 2;
-    for (int i = tid; i < FB_SPAN; i += 256) {
-      const int p = s0 + i;
-      float v = 0.0f;
-      if (p < half) v = src[half - p];
-      else if (p < half + L) v = src[p - half];
-      else if (p < L + WIN - HOP) v = src[2 * L + half - 2 - p];
-      aud[i + i / HOP] = v;
-    }
+    av[j] = ok ? src[idx] : 0.0f;
+  }
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int i = tid + j * 256;
+    if (i < FB_SPAN) aud[i + i / HOP] = av[j];
   }
   __syncthreads();
 
@@ -143,71 +146,103 @@ __global__ __launch_bounds__(256) void fbank_split_kernel(const FbankArgs a) {
   const UttPlan up = a.plan[u];
   const float* src = a.audio + up.audio_off;
   const int s0 = f0 * HOP;
-  for (int i = tid; i < FB_SPAN + 32; i += 256) {
-    float v = 0.0f;
-    if (!a.whisper) {
-      const int s = s0 + i;
-      if (s < up.n_samples) v = src[s];
-    } else {                     // padded signal = [x[200..1] | x | x[L-2 .. L-41]]  (reflect, right pad shortened by one hop)
-      const int L = up.n_samples, half = WIN / 2, p = s0 + i;
-      if (p < half) v = src[half - p];
-      else if (p < half + L) v = src[p - half];
-      else if (p < L + WIN - HOP) v = src[2 * L + half - 2 - p];
+  // the workgroup's audio span: every thread requests ALL of its samples before it uses the first (written as one loop of load / split / store the compiler kept the
+  // loads in program order behind a wait each -- 42 dependent memory round trips, ~60 of the workgroup's ~78 us, with nothing else on the CU to cover them)
+  constexpr int FB_NL = (FB_SPAN + 32 + 255) / 256;
+  float av[FB_NL];
+#pragma unroll
+  for (int j = 0; j < FB_NL; ++j) {
+    const int i = tid + j * 256;
+    // one predicated load per sample: Kaldi reads x[s]; Whisper the padded signal [x[200..1] | x | x[L-2 .. L-41]]  (reflect, right pad shortened by one hop)
+    const int L = up.n_samples, half = WIN / 2, p = s0 + i;
+    int idx = p;
+    bool ok = i < FB_SPAN + 32 && p < L;
+    if (a.whisper) {
+      idx = p < half ? half - p : p < half + L ? p - half : 2 * L + half - 2 - p;
+      ok = i < FB_SPAN + 32 && p < L + WIN - HOP;
     }
-    const uint32_t hb = pack_bf16x2(v, 0.0f) & 0xffffu;
-    const float hi = __uint_as_float(hb << 16);
-    const int pos = i + (i / HOP) * 8;
-    audh[pos] = (bf16_t)hb;
-    audl[pos] = (bf16_t)(pack_bf16x2(v - hi, 0.0f) & 0xffffu);
+    av[j] = ok ? src[idx] : 0.0f;
+  }
+#pragma unroll
+  for (int j = 0; j < FB_NL; ++j) {
+    const int i = tid + j * 256;
+    if (i < FB_SPAN + 32) {
+      const float v = av[j];
+      const uint32_t hb = pack_bf16x2(v, 0.0f) & 0xffffu;
+      const float hi = __uint_as_float(hb << 16);
+      const int pos = i + (i / HOP) * 8;
+      audh[pos] = (bf16_t)hb;
+      audl[pos] = (bf16_t)(pack_bf16x2(v - hi, 0.0f) & 0xffffu);
+    }
   }
   __syncthreads();
 
   const int frow = lane & 15, fgrp = lane >> 4;
   const uint4* tab = reinterpret_cast<const uint4*>(a.dft_split);
-  for (int t = wave; t < a.n_bin_tiles; t += 4) {
-    f32x4_t re[4], im[4];
+  // A wave's (bin tile, chunk) steps form ONE stream of basis fragments (6 KB per step: re | im x three bf16 terms) with FB_PF steps in flight, across tile
+  // boundaries. With one step in flight (rounds 2-4) the loop ran at one L2 round trip per step -- 13 x 5 trips per workgroup next to 17 us of MFMA work, and the
+  // workgroup's 115 KB of LDS leave no second workgroup on the CU to cover them: 286 us per 64 x 8 s batch. The flat step loop is unrolled by FB_PF so that the ring slots
+  // are static registers that are never moved while their load is in flight; the scheduling barriers keep the refills where they are written (left alone, the
+  // scheduler sinks every refill to just in front of its use -- one step in flight again).
+  constexpr int FB_PF = 4;
+  union BF { uint4 q; bf16x8_t v; };
+  BF ring[FB_PF][6];
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int n_steps = wv < a.n_bin_tiles ? (a.n_bin_tiles - wv + 3) / 4 * FB_K32 : 0;
+  constexpr size_t FB_IM = (size_t)FB_K32 * 3 * 64;                       // im fragments of a tile follow its re fragments
+  auto frag_ptr = [&](int t, int kc) { return tab + (((size_t)(t * 2) * FB_K32 + kc) * 3) * 64 + lane; };
+  int pt = wv, pkc = 0, ps = 0;                                           // the step the next refill fetches (it stops at the wave's last step: harmless re-reads)
+  auto refill = [&](BF (&slot)[6]) {
+    const uint4* src = frag_ptr(pt, pkc);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) { re[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; im[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-    const uint4* tre = tab + ((size_t)(t * 2 + 0) * FB_K32) * 3 * 64 + lane;
-    const uint4* tim = tab + ((size_t)(t * 2 + 1) * FB_K32) * 3 * 64 + lane;
-    union BF { uint4 q; bf16x8_t v; };
-    BF br[3], bi[3];
+    for (int z = 0; z < 3; ++z) { slot[z].q = src[z * 64]; slot[3 + z].q = src[FB_IM + z * 64]; }
+    if (ps + 1 < n_steps) { ++ps; if (++pkc == FB_K32) { pkc = 0; pt += 4; } }
+  };
+  f32x4_t re[4], im[4];
 #pragma unroll
-    for (int z = 0; z < 3; ++z) { br[z].q = tre[z * 64]; bi[z].q = tim[z * 64]; }
-    for (int kc = 0; kc < FB_K32; ++kc) {
-      BF brn[3], bin[3];                           // the next chunk's basis fragments are requested before this chunk's MFMAs
+  for (int mt = 0; mt < 4; ++mt) { re[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; im[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  if (n_steps > 0) {
 #pragma unroll
-      for (int z = 0; z < 3; ++z) { brn[z] = br[z]; bin[z] = bi[z]; }
-      if (kc + 1 < FB_K32) {
+    for (int u = 0; u < FB_PF; ++u) refill(ring[u]);
+  }
+  int t = wv, kc = 0;
+  for (int s0 = 0; s0 < n_steps; s0 += FB_PF) {
 #pragma unroll
-        for (int z = 0; z < 3; ++z) { brn[z].q = tre[((kc + 1) * 3 + z) * 64]; bin[z].q = tim[((kc + 1) * 3 + z) * 64]; }
+    for (int u = 0; u < FB_PF; ++u) {
+      if (s0 + u < n_steps) {                                               // (wave-uniform)
+        const int k = kc * 32 + fgrp * 8;
+        const int koff = k + ((k >= HOP) + (k >= 2 * HOP)) * 8;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int pos = (mt * 16 + frow) * FB_HP + koff;
+          const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(audh + pos), al = *reinterpret_cast<const bf16x8_t*>(audl + pos);
+          // smallest terms first: the f32 accumulator then rounds the dominant product last
+          re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ring[u][1].v, re[mt], 0, 0, 0);
+          im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ring[u][4].v, im[mt], 0, 0, 0);
+          re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ring[u][2].v, re[mt], 0, 0, 0);
+          im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ring[u][5].v, im[mt], 0, 0, 0);
+          re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ring[u][0].v, re[mt], 0, 0, 0);
+          im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ring[u][3].v, im[mt], 0, 0, 0);
+          re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ring[u][1].v, re[mt], 0, 0, 0);
+          im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ring[u][4].v, im[mt], 0, 0, 0);
+          re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ring[u][0].v, re[mt], 0, 0, 0);
+          im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ring[u][3].v, im[mt], 0, 0, 0);
+        }
+        if (++kc == FB_K32) {                                               // the tile is complete: power spectrum to LDS, next tile
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              pw[(mt * 16 + fgrp * 4 + r) * FB_PLD + t * 16 + frow] = re[mt][r] * re[mt][r] + im[mt][r] * im[mt][r];
+            re[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; im[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          }
+          kc = 0; t += 4;
+        }
       }
-      const int k = kc * 32 + fgrp * 8;
-      const int koff = k + (k / HOP) * 8;
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const int pos = (mt * 16 + frow) * FB_HP + koff;
-        const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(audh + pos), al = *reinterpret_cast<const bf16x8_t*>(audl + pos);
-        // smallest terms first: the f32 accumulator then rounds the dominant product last
-        re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, br[1].v, re[mt], 0, 0, 0);
-        im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bi[1].v, im[mt], 0, 0, 0);
-        re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, br[2].v, re[mt], 0, 0, 0);
-        im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bi[2].v, im[mt], 0, 0, 0);
-        re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, br[0].v, re[mt], 0, 0, 0);
-        im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bi[0].v, im[mt], 0, 0, 0);
-        re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, br[1].v, re[mt], 0, 0, 0);
-        im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bi[1].v, im[mt], 0, 0, 0);
-        re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, br[0].v, re[mt], 0, 0, 0);
-        im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bi[0].v, im[mt], 0, 0, 0);
-      }
-#pragma unroll
-      for (int z = 0; z < 3; ++z) { br[z] = brn[z]; bi[z] = bin[z]; }
+      __builtin_amdgcn_sched_barrier(0);
+      refill(ring[u]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        pw[(mt * 16 + fgrp * 4 + r) * FB_PLD + t * 16 + frow] = re[mt][r] * re[mt][r] + im[mt][r] * im[mt][r];
   }
   __syncthreads();
 
@@ -850,7 +885,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
   __shared__ float qs[NQ][64];
   __shared__ float red[4][NQ][64];
   __shared__ float stat[2][NQ];
-  const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x + a.b0, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane & 7;                     // which 8 dims of the row
   const int n = a.n;
   const int hist = a.hist_dev ? *a.hist_dev : a.hist;
@@ -865,7 +900,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttnArgs a) {
   auto crow = [&](int s) -> size_t { return pt ? (size_t)pt[s >> 4] * (size_t)a.page_stride + (size_t)(s & 15) * 64 : (size_t)s * 64; };
   const T* Q = reinterpret_cast<const T*>(a.q);
   const T* NEW = KV8 ? nullptr : reinterpret_cast<const T*>(a.kv_new);
-  const float k_scale = KV8 ? a.k_scale[(size_t)h * gridDim.x + b] : 1.0f, v_scale = KV8 ? a.v_scale[(size_t)h * gridDim.x + b] : 1.0f;
+  const int s_ld = a.scale_ld ? a.scale_ld : (int)gridDim.x;
+  const float k_scale = KV8 ? a.k_scale[(size_t)h * s_ld + b] : 1.0f, v_scale = KV8 ? a.v_scale[(size_t)h * s_ld + b] : 1.0f;
 
   for (int i = tid; i < n * 64; i += 256) qs[i >> 6][i & 63] = Elem<T>::load(Q + (size_t)(b * n + (i >> 6)) * a.ld_q + a.q_col0 + h * 64 + (i & 63));
   if constexpr (!KV8) if (NEW) {               // append the new rows to the cache (read back only by later steps)
@@ -1467,7 +1503,7 @@ namespace {
 // (its query, the new K / V row, up to 64 cached K and V rows) is requested at once, 8 lanes per 128-byte row (16 B each, coalesced), the dot
 // products are reduced inside the 8-lane groups by DPP, the soft-max runs online over blocks of 64 keys with wave shuffles, and nothing goes through LDS.
 __global__ __launch_bounds__(256) void decode_self_attn_wave_kernel(const DecAttnArgs a) {
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x + a.b0, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = blockIdx.y * 4 + wave;
   if (h >= a.n_heads) return;
   const int hist = a.hist_dev ? *a.hist_dev : a.hist;          // keys 0 .. hist - 1 are cached, key `hist` is the new row

@@ -78,7 +78,14 @@ struct WhSession : asr_session {
   bool fp8 = false, fp8_fake = false, fp8_weights = true, fp8_kv = true;     // ASR_FP8_WEIGHTS=0 / ASR_FP8_KV=0: leave that half in bf16 (to price the halves separately)
   std::vector<Dec8Layer> dec8;
   DeviceBuffer d_w8, d_wscale, d_wdq, d_cross8, d_cscale;
-  hipGraphExec_t dec_graph = nullptr;
+  hipGraphExec_t dec_graph = nullptr;      // the whole single-token step (one chain), or -- several chains -- its tail: logits + heads
+  hipGraphExec_t chain_graph[4] = {nullptr, nullptr, nullptr, nullptr};     // several chains: chain ci's embedding + layer loop, replayed on its own stream
+  int dec_graph_chains = 0;
+  void drop_graphs() {
+    if (dec_graph) { (void)hipGraphExecDestroy(dec_graph); dec_graph = nullptr; }
+    for (auto& g : chain_graph) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    dec_graph_chains = 0;
+  }
   uint64_t dec_key = 0, dec_eager_key = 0, ws_epoch = 1;
   void* h_plan = nullptr; size_t h_plan_cap = 0;
   void* h_io = nullptr; size_t h_io_cap = 0;
@@ -87,7 +94,11 @@ struct WhSession : asr_session {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_x0, &d_h1, &d_xa, &d_xb, &d_xc, &d_h, &d_qk, &d_vt, &d_ctx,
                             &d_ffn, &d_cross, &d_kc, &d_vc, &d_kvpool, &d_ptable, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise, &d_nsp, &d_skws, &d_skcnt, &d_colsum, &d_dlo, &d_w8, &d_wscale, &d_wdq, &d_cross8, &d_cscale, &d_ew8, &d_ewscale, &d_h8, &d_ffn8})
       b->release();
-    if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
+    drop_graphs();
+    for (int i = 0; i < MAX_CHAINS; ++i) {
+      if (chain_stream[i]) (void)hipStreamDestroy(chain_stream[i]);
+      if (chain_ev[i]) (void)hipEventDestroy(chain_ev[i]);
+    }
     for (auto& kv : taps) kv.second.buf.release();
     if (h_plan) (void)hipHostFree(h_plan);
     if (h_io) (void)hipHostFree(h_io);
@@ -96,12 +107,23 @@ struct WhSession : asr_session {
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
   void init();
-  DeviceBuffer d_skws, d_skcnt;        // split-K workspace + tickets of the skinny GEMM (per session: sessions may run concurrently)
+  DeviceBuffer d_skws, d_skcnt;        // split-K workspace + tickets of the skinny GEMM (per session: sessions may run concurrently), one slice per decode chain
+  static constexpr int MAX_CHAINS = 4, SK_CNT = 4096;
+  static constexpr size_t SK_WS_BYTES = (size_t)16 << 20;
+  int dec_chains = 0;                  // ASR_DECODE_CHAINS (enqueue_step): 0 = by batch size
+  hipStream_t chain_stream[MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t chain_ev[MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
+  void ensure_chain_streams(int nc) {
+    for (int i = 0; i < nc; ++i) {
+      if (i > 0 && !chain_stream[i]) HIP_CHECK(hipStreamCreateWithFlags(&chain_stream[i], hipStreamNonBlocking));
+      if (!chain_ev[i]) HIP_CHECK(hipEventCreateWithFlags(&chain_ev[i], hipEventDisableTiming));
+    }
+  }
   void gemm(const GemmArgs& g0) {
     if (precision != ASR_PRECISION_BF16) { launch_gemm_f32(g0, stream); return; }
-    if (!d_skws.ptr) { d_skws.reserve((size_t)16 << 20, stream); d_skcnt.reserve(4096 * 4, stream); }
+    if (!d_skws.ptr) { d_skws.reserve((size_t)MAX_CHAINS * SK_WS_BYTES, stream); d_skcnt.reserve((size_t)MAX_CHAINS * SK_CNT * 4, stream); }
     GemmArgs g = g0;
-    g.sk_ws = d_skws.as<float>(); g.sk_ws_bytes = d_skws.cap; g.sk_cnt = d_skcnt.as<int32_t>();
+    g.sk_ws = d_skws.as<float>(); g.sk_ws_bytes = SK_WS_BYTES; g.sk_cnt = d_skcnt.as<int32_t>();
     launch_gemm_bf16(g, stream);
   }
   void* pinned(size_t bytes) {
@@ -113,7 +135,23 @@ struct WhSession : asr_session {
     return h_io;
   }
   template <typename T> void encode(const float* audio, int audio_mem, const int64_t* offs, int B, int32_t* n_pos_out);
-  template <typename T> void enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, bool use_hist_dev);
+  static constexpr int PART_ALL = -1, PART_HEAD = -2;      // enqueue_step's `part`: everything / logits + heads only / >= 0: the embedding + layer loop of that chain only
+  template <typename T> void enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, bool use_hist_dev, int part = PART_ALL);
+  // decode chains of a step over B sequences x n positions (see enqueue_step): the number of chains, sequences per chain in *per
+  int chain_plan(int B, int n, size_t elem, int* per) const {
+    *per = B;
+    const bool dgm = elem == 2 && use_decode_gemm && B * n <= 64 && d_colsum.ptr != nullptr && cfg.d_model % 256 == 0 && cfg.d_ffn % 256 == 0;
+    if (!dgm || n != 1 || prof.enabled || taps_enabled) return 1;
+    int nc = dec_chains > 0 ? dec_chains : 1;      // measured (profiles/r05_whisper_decode_chains.txt): two chains 3.29 vs 3.31 ms per token at 64 sequences, slower at 32 -> opt-in
+    nc = std::max(1, std::min({nc, MAX_CHAINS, (B + 15) / 16}));
+    if (nc == 1) return 1;
+    // sub-batches of whole 16-row tiles; a chain of more than 32 rows would send fc2 through the session-wide generic GEMM, so chains stay <= 32 rows
+    const int p = std::min(32, round_up((B + nc - 1) / nc, 16));
+    nc = (B + p - 1) / p;
+    if (nc > MAX_CHAINS || nc == 1) return 1;
+    *per = p;
+    return nc;
+  }
   template <typename T> void step(const int32_t* ids_host, int n, bool is_prefill, int32_t* next_out, float* logits_out);
 };
 
@@ -455,7 +493,7 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
 // All launches of one step. `hist_dev` (device-resident history length) is what the kernels read, so the single-token
 // step is position independent and ONE captured hipGraph replays for every decode position.
 template <typename T>
-void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, bool use_hist_dev) {
+void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, bool use_hist_dev, int part) {
   const auto& c = cfg;
   const int B = batch, d = c.d_model, dff = c.d_ffn, Ld = c.n_dec_layers, H = c.n_heads;
   const int R = B * n, Rp = round_up(R, 128);
@@ -470,7 +508,6 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
   T* cq = ffn + (size_t)Rp * dff;
   T* hl = cq + (size_t)Rp * d;
   const UttPlan* dp = d_plan.as<UttPlan>();
-  { ProfScope ps(prof, "dec_embed", stream); launch_embed_pos<T>(ids_dev, R, n, hist, hd, (const T*)embed, dec_pos, d, xa, stream); }
   const size_t cache_l = (size_t)B * H * c.max_target_positions * 64;
   // bf16 mode, M <= 64 rows: the (affine-less) LayerNorm runs inside the skinny GEMM's prologue
   const bool fuse_ln = precision == ASR_PRECISION_BF16 && R <= 32 && d % 256 == 0;   // above 32 rows a separate LayerNorm launch is cheaper
@@ -492,100 +529,135 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
     xa_lo = d_dlo.as<bf16_t>(); xb_lo = xa_lo + (size_t)Rp * d; xc_lo = xb_lo + (size_t)Rp * d;
   }
   const bool w8 = fp8 && fp8_weights && !fp8_fake;
-  int cur_layer = 0;
-  auto dg = [&](const void* A, int lda, const void* Wt, int wi, int N, int K, const float* bias, const float* colsum, const float* add, int act_, float* of32,
-                void* olo, int ld_lo) {
-    ProfScope ps(prof, "dec_gemm", stream);
-    if (!d_skws.ptr) { d_skws.reserve((size_t)16 << 20, stream); d_skcnt.reserve(4096 * 4, stream); }
+  // ---- decode chains. A single-token step is a chain of 8 dependent launches per layer, each a latency chain of its own (first weight bytes, fragment loop, cross-wave
+  // reduction, hand-over) that leaves the chip mostly idle: the six GEMMs of a layer move their 46 MB at ~1 TB/s. The sequences of a batch never meet before the
+  // logits, so the batch is cut into `NC` sub-batches (chain_plan) whose embedding + layer loops run on one HIP stream each -- replayed as one captured graph per chain
+  // (step()) -- and cover each other's latencies; the weights are streamed once per chain (the later reader mostly finds them in the memory-side cache). The logits +
+  // heads behind the join run on the whole batch. ASR_DECODE_CHAINS: 0 / unset / 1 = one chain (the default: see chain_plan), N = N chains.
+  int per = B;
+  const int NC = chain_plan(B, n, sizeof(T), &per);
+  ASR_REQUIRE(NC == 1 || dgm, "whisper: decode chains without the decode GEMM");
+  ASR_REQUIRE(part < NC, "whisper: chain %d of %d", part, NC);
+  if (!d_skws.ptr) { d_skws.reserve((size_t)MAX_CHAINS * SK_WS_BYTES, stream); d_skcnt.reserve((size_t)MAX_CHAINS * SK_CNT * 4, stream); }
+  int plan_rows = 0;                     // several chains: every chain's GEMMs take the grid shape of the largest chain (same summation order for every sequence)
+  auto dg = [&](hipStream_t st, int ci, int r0, int Rc, int layer, const void* A, int lda, const void* Wt, int wi, int N, int K, const float* bias, const float* colsum,
+                const float* add, int act_, float* of32, void* olo, int ld_lo) {
+    ProfScope ps(prof, "dec_gemm", st);
     DecGemmArgs g;
-    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)Wt; g.ldw = K; g.M = R; g.N = N; g.K = K; g.bias = bias; g.colsum = colsum;
-    if (w8) { g.W = nullptr; g.W8 = dec8[cur_layer].w[wi]; g.w_scale = dec8[cur_layer].s[wi]; }
-    g.add = add; g.ld_add = d; g.act = act_; g.out_f32 = of32; g.ld_out_f32 = d; g.out_lo = (bf16_t*)olo; g.ld_out_lo = ld_lo;
-    g.ws = d_skws.as<float>(); g.ws_bytes = d_skws.cap; g.cnt = d_skcnt.as<int32_t>();
-    launch_decode_gemm(g, stream);
+    g.A = (const bf16_t*)A + (size_t)r0 * lda; g.lda = lda; g.W = (const bf16_t*)Wt; g.ldw = K; g.M = Rc; g.plan_M = plan_rows; g.N = N; g.K = K; g.bias = bias; g.colsum = colsum;
+    if (w8) { g.W = nullptr; g.W8 = dec8[layer].w[wi]; g.w_scale = dec8[layer].s[wi]; }
+    g.add = add ? add + (size_t)r0 * d : nullptr; g.ld_add = d; g.act = act_; g.out_f32 = of32 ? of32 + (size_t)r0 * d : nullptr; g.ld_out_f32 = d;
+    g.out_lo = olo ? (bf16_t*)olo + (size_t)r0 * ld_lo : nullptr; g.ld_out_lo = ld_lo;
+    g.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(d_skws.ptr) + (size_t)ci * SK_WS_BYTES); g.ws_bytes = SK_WS_BYTES;
+    g.cnt = d_skcnt.as<int32_t>() + (size_t)ci * SK_CNT;
+    launch_decode_gemm(g, st);
   };
-  if (dgm) { ProfScope ps(prof, "dec_embed", stream); launch_rows_to_bf16(xa, xa_lo, (size_t)Rp * d, stream); }
-  for (int l = 0; l < Ld; ++l) {
-    const DecLayer& L = dec[l];
-    cur_layer = l;
-    if (dgm) dg(xa_lo, d, L.wqkv, 0, 3 * d, d, L.bqkv, csum + l * cs_l, nullptr, ACT_NONE, nullptr, qkv, 3 * d);
-    else {
-      GemmArgs g;
-      g.W = L.wqkv; g.ldw = d; g.M = R; g.N = 3 * d; g.K = d; g.bias = L.bqkv; g.out_lo = qkv; g.ld_out_lo = 3 * d;
-      ln_gemm(xa, g);
-    }
-    {
-      ProfScope ps(prof, "dec_self_attn", stream);
-      DecAttnArgs a;
-      a.q = qkv; a.ld_q = 3 * d; a.q_col0 = 0; a.kv_new = qkv; a.ld_new = 3 * d; a.k_col0 = d; a.v_col0 = 2 * d;
-      if (kv_paged) {
-        a.k_base = d_kvpool.as<T>() + (size_t)(l * 2) * H * KV_PAGE * 64; a.v_base = d_kvpool.as<T>() + (size_t)(l * 2 + 1) * H * KV_PAGE * 64;
-        a.page_table = d_ptable.as<int32_t>(); a.pages_per_seq = (c.max_target_positions + KV_PAGE - 1) / KV_PAGE;
-        a.page_stride = (int64_t)Ld * 2 * H * KV_PAGE * 64;
-      } else {
-        a.k_base = d_kc.as<T>() + l * cache_l; a.v_base = d_vc.as<T>() + l * cache_l;
-        a.stride_b = (int64_t)H * c.max_target_positions * 64; a.stride_h = (int64_t)c.max_target_positions * 64;
-      }
-      a.plan = nullptr; a.hist = hist; a.hist_dev = hd; a.n = n; a.n_heads = H; a.causal = 1; a.out = ctx; a.ld_out = d;
-      a.max_keys = c.max_target_positions;
-      launch_decode_attention<T>(a, B, stream);
-    }
-    if (dgm) {
-      dg(ctx, d, L.wo, 1, d, d, L.bo, nullptr, xa, ACT_NONE, xb, xb_lo, d);
-      dg(xb_lo, d, L.wcq, 2, d, d, L.bcq, csum + l * cs_l + 3 * d, nullptr, ACT_NONE, nullptr, cq, d);
-    } else {
-      {
-        ProfScope ps(prof, "dec_gemm", stream);
+  // embedding + layer loop of sequences [b0, b0 + nb) on stream `st` (chain ci)
+  auto run_chain = [&](hipStream_t st, int ci, int b0, int nb) {
+    const int r0 = b0 * n, Rc = nb * n;
+    { ProfScope ps(prof, "dec_embed", st);
+      launch_embed_pos<T>(ids_dev + r0, Rc, n, hist, hd, (const T*)embed, dec_pos, d, xa + (size_t)r0 * d, st);
+      if (dgm) launch_rows_to_bf16(xa + (size_t)r0 * d, xa_lo + (size_t)r0 * d, (size_t)(NC == 1 ? Rp : Rc) * d, st); }
+    for (int l = 0; l < Ld; ++l) {
+      const DecLayer& L = dec[l];
+      if (dgm) dg(st, ci, r0, Rc, l, xa_lo, d, L.wqkv, 0, 3 * d, d, L.bqkv, csum + l * cs_l, nullptr, ACT_NONE, nullptr, qkv, 3 * d);
+      else {
         GemmArgs g;
-        g.A = ctx; g.lda = d; g.W = L.wo; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bo; g.add = xa; g.ld_add = d; g.out_f32 = xb; g.ld_out_f32 = d;
-        gemm(g);
+        g.W = L.wqkv; g.ldw = d; g.M = R; g.N = 3 * d; g.K = d; g.bias = L.bqkv; g.out_lo = qkv; g.ld_out_lo = 3 * d;
+        ln_gemm(xa, g);
       }
-      GemmArgs g;
-      g.W = L.wcq; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bcq; g.out_lo = cq; g.ld_out_lo = d;
-      ln_gemm(xb, g);
-    }
-    {
-      ProfScope ps(prof, "dec_cross_attn", stream);
-      DecAttnArgs a;
-      a.q = cq; a.ld_q = d; a.q_col0 = 0; a.kv_new = nullptr; a.ld_new = 0; a.k_col0 = a.v_col0 = 0;
-      a.k_base = d_cross.as<T>() + (size_t)(0 * Ld + l) * H * Mpad * 64;
-      a.v_base = d_cross.as<T>() + (size_t)(1 * Ld + l) * H * Mpad * 64;
-      a.stride_b = 0; a.stride_h = (int64_t)Mpad * 64; a.plan = dp; a.hist = 0; a.hist_dev = nullptr; a.n = n; a.n_heads = H; a.causal = 0;
-      a.max_keys = max_T_enc;
-      a.out = ctx; a.ld_out = d;
-      if (fp8 && fp8_kv && !fp8_fake) {
-        a.k_base = d_cross8.as<unsigned char>() + (size_t)(0 * Ld + l) * H * Mpad * 64;
-        a.v_base = d_cross8.as<unsigned char>() + (size_t)(1 * Ld + l) * H * Mpad * 64;
-        a.k_scale = d_cscale.as<float>() + (size_t)(0 * Ld + l) * H * B; a.v_scale = d_cscale.as<float>() + (size_t)(1 * Ld + l) * H * B;
+      {
+        ProfScope ps(prof, "dec_self_attn", st);
+        DecAttnArgs a;
+        a.q = qkv; a.ld_q = 3 * d; a.q_col0 = 0; a.kv_new = qkv; a.ld_new = 3 * d; a.k_col0 = d; a.v_col0 = 2 * d;
+        if (kv_paged) {
+          a.k_base = d_kvpool.as<T>() + (size_t)(l * 2) * H * KV_PAGE * 64; a.v_base = d_kvpool.as<T>() + (size_t)(l * 2 + 1) * H * KV_PAGE * 64;
+          a.page_table = d_ptable.as<int32_t>(); a.pages_per_seq = (c.max_target_positions + KV_PAGE - 1) / KV_PAGE;
+          a.page_stride = (int64_t)Ld * 2 * H * KV_PAGE * 64;
+        } else {
+          a.k_base = d_kc.as<T>() + l * cache_l; a.v_base = d_vc.as<T>() + l * cache_l;
+          a.stride_b = (int64_t)H * c.max_target_positions * 64; a.stride_h = (int64_t)c.max_target_positions * 64;
+        }
+        a.plan = nullptr; a.hist = hist; a.hist_dev = hd; a.n = n; a.n_heads = H; a.causal = 1; a.out = ctx; a.ld_out = d;
+        a.max_keys = c.max_target_positions;
+        a.b0 = b0;
+        launch_decode_attention<T>(a, nb, st);
       }
-      launch_decode_attention<T>(a, B, stream);
-    }
-    if (dgm) {
-      dg(ctx, d, L.wco, 3, d, d, L.bco, nullptr, xb, ACT_NONE, xc, xc_lo, d);
-      dg(xc_lo, d, L.w1, 4, dff, d, L.b1, csum + l * cs_l + 4 * d, nullptr, act, nullptr, ffn, dff);
-      if (R <= 32 || w8) dg(ffn, dff, L.w2, 5, d, dff, L.b2, nullptr, xc, ACT_NONE, xa, xa_lo, d);
-      else {               // 33..64 rows: the tiled split-K pass shares the activation rows across 64 columns (13.8 vs 17.9 us); it writes the bf16 copy too
+      if (dgm) {
+        dg(st, ci, r0, Rc, l, ctx, d, L.wo, 1, d, d, L.bo, nullptr, xa, ACT_NONE, xb, xb_lo, d);
+        dg(st, ci, r0, Rc, l, xb_lo, d, L.wcq, 2, d, d, L.bcq, csum + l * cs_l + 3 * d, nullptr, ACT_NONE, nullptr, cq, d);
+      } else {
+        {
+          ProfScope ps(prof, "dec_gemm", stream);
+          GemmArgs g;
+          g.A = ctx; g.lda = d; g.W = L.wo; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bo; g.add = xa; g.ld_add = d; g.out_f32 = xb; g.ld_out_f32 = d;
+          gemm(g);
+        }
+        GemmArgs g;
+        g.W = L.wcq; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bcq; g.out_lo = cq; g.ld_out_lo = d;
+        ln_gemm(xb, g);
+      }
+      {
+        ProfScope ps(prof, "dec_cross_attn", st);
+        DecAttnArgs a;
+        a.q = cq; a.ld_q = d; a.q_col0 = 0; a.kv_new = nullptr; a.ld_new = 0; a.k_col0 = a.v_col0 = 0;
+        a.k_base = d_cross.as<T>() + (size_t)(0 * Ld + l) * H * Mpad * 64;
+        a.v_base = d_cross.as<T>() + (size_t)(1 * Ld + l) * H * Mpad * 64;
+        a.stride_b = 0; a.stride_h = (int64_t)Mpad * 64; a.plan = dp; a.hist = 0; a.hist_dev = nullptr; a.n = n; a.n_heads = H; a.causal = 0;
+        a.max_keys = max_T_enc;
+        a.out = ctx; a.ld_out = d;
+        if (fp8 && fp8_kv && !fp8_fake) {
+          a.k_base = d_cross8.as<unsigned char>() + (size_t)(0 * Ld + l) * H * Mpad * 64;
+          a.v_base = d_cross8.as<unsigned char>() + (size_t)(1 * Ld + l) * H * Mpad * 64;
+          a.k_scale = d_cscale.as<float>() + (size_t)(0 * Ld + l) * H * B; a.v_scale = d_cscale.as<float>() + (size_t)(1 * Ld + l) * H * B;
+        }
+        a.b0 = b0; a.scale_ld = B;
+        launch_decode_attention<T>(a, nb, st);
+      }
+      if (dgm) {
+        dg(st, ci, r0, Rc, l, ctx, d, L.wco, 3, d, d, L.bco, nullptr, xb, ACT_NONE, xc, xc_lo, d);
+        dg(st, ci, r0, Rc, l, xc_lo, d, L.w1, 4, dff, d, L.b1, csum + l * cs_l + 4 * d, nullptr, act, nullptr, ffn, dff);
+        if (Rc <= 32 || w8) dg(st, ci, r0, Rc, l, ffn, dff, L.w2, 5, d, dff, L.b2, nullptr, xc, ACT_NONE, xa, xa_lo, d);
+        else {               // 33..64 rows: the tiled split-K pass shares the activation rows across 64 columns (13.8 vs 17.9 us); it writes the bf16 copy too (one chain only: Rc = R)
+          ProfScope ps(prof, "dec_gemm", stream);
+          GemmArgs g2;
+          g2.A = ffn; g2.lda = dff; g2.W = L.w2; g2.ldw = dff; g2.M = R; g2.N = d; g2.K = dff; g2.bias = L.b2; g2.add = xc; g2.ld_add = d;
+          g2.out_f32 = xa; g2.ld_out_f32 = d; g2.out_lo = xa_lo; g2.ld_out_lo = d;
+          gemm(g2);
+        }
+      } else {
+        {
+          ProfScope ps(prof, "dec_gemm", stream);
+          GemmArgs g;
+          g.A = ctx; g.lda = d; g.W = L.wco; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bco; g.add = xb; g.ld_add = d; g.out_f32 = xc; g.ld_out_f32 = d;
+          gemm(g);
+        }
+        GemmArgs g;
+        g.W = L.w1; g.ldw = d; g.M = R; g.N = dff; g.K = d; g.bias = L.b1; g.act = act; g.out_lo = ffn; g.ld_out_lo = dff;
+        ln_gemm(xc, g);
         ProfScope ps(prof, "dec_gemm", stream);
         GemmArgs g2;
         g2.A = ffn; g2.lda = dff; g2.W = L.w2; g2.ldw = dff; g2.M = R; g2.N = d; g2.K = dff; g2.bias = L.b2; g2.add = xc; g2.ld_add = d;
-        g2.out_f32 = xa; g2.ld_out_f32 = d; g2.out_lo = xa_lo; g2.ld_out_lo = d;
+        g2.out_f32 = xa; g2.ld_out_f32 = d;
         gemm(g2);
       }
-    } else {
-      {
-        ProfScope ps(prof, "dec_gemm", stream);
-        GemmArgs g;
-        g.A = ctx; g.lda = d; g.W = L.wco; g.ldw = d; g.M = R; g.N = d; g.K = d; g.bias = L.bco; g.add = xb; g.ld_add = d; g.out_f32 = xc; g.ld_out_f32 = d;
-        gemm(g);
+    }
+  };
+  if (NC > 1) { ensure_chain_streams(NC); plan_rows = per * n; }
+  if (part >= 0) {                       // (capture of one chain's graph, on that chain's stream)
+    run_chain(part == 0 ? stream : chain_stream[part], part, part * per, std::min(per, B - part * per));
+    return;
+  }
+  if (part == PART_ALL) {
+    if (NC == 1) run_chain(stream, 0, 0, B);
+    else {                               // eager form of the chained step: fork / join by events
+      HIP_CHECK(hipEventRecord(chain_ev[0], stream));
+      for (int ci = 1; ci < NC; ++ci) HIP_CHECK(hipStreamWaitEvent(chain_stream[ci], chain_ev[0], 0));
+      for (int ci = 0; ci < NC; ++ci) run_chain(ci == 0 ? stream : chain_stream[ci], ci, ci * per, std::min(per, B - ci * per));
+      for (int ci = 1; ci < NC; ++ci) {
+        HIP_CHECK(hipEventRecord(chain_ev[ci], chain_stream[ci]));
+        HIP_CHECK(hipStreamWaitEvent(stream, chain_ev[ci], 0));
       }
-      GemmArgs g;
-      g.W = L.w1; g.ldw = d; g.M = R; g.N = dff; g.K = d; g.bias = L.b1; g.act = act; g.out_lo = ffn; g.ld_out_lo = dff;
-      ln_gemm(xc, g);
-      ProfScope ps(prof, "dec_gemm", stream);
-      GemmArgs g2;
-      g2.A = ffn; g2.lda = dff; g2.W = L.w2; g2.ldw = dff; g2.M = R; g2.N = d; g2.K = dff; g2.bias = L.b2; g2.add = xc; g2.ld_add = d;
-      g2.out_f32 = xa; g2.ld_out_f32 = d;
-      gemm(g2);
     }
   }
   // final LayerNorm of the LAST position of every sequence, tied proj_out, -128 suppress penalty (:663-666)
@@ -704,24 +776,51 @@ void WhSession::step(const int32_t* ids_host, int n, bool is_prefill, int32_t* n
   // single-token steps fed from the device are position independent => one graph for all of them
   const bool graphable = use_graph && !ids_host && n == 1 && !taps_enabled && !prof.enabled && !noise_armed;
   const uint64_t key = ((uint64_t)B << 32) ^ (uint64_t)Mpad ^ (ws_epoch << 48) ^ (uint64_t)(uintptr_t)stream;
-  if (graphable && dec_graph && key == dec_key) {
-    HIP_CHECK(hipGraphLaunch(dec_graph, stream));
-  } else if (graphable && key == dec_eager_key) {
-    if (dec_graph) { (void)hipGraphExecDestroy(dec_graph); dec_graph = nullptr; }
+  int per = B;
+  const int NC = graphable ? chain_plan(B, 1, sizeof(T), &per) : 1;
+  auto capture = [&](hipStream_t cs, int part) {
     hipGraph_t graph = nullptr;
-    HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    hipGraphExec_t exec = nullptr;
+    HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
     try {
-      enqueue_step<T>(ids_dev, 1, false, true);
+      enqueue_step<T>(ids_dev, 1, false, true, part);
     } catch (...) {
-      (void)hipStreamEndCapture(stream, &graph);
+      (void)hipStreamEndCapture(cs, &graph);
       if (graph) (void)hipGraphDestroy(graph);
       throw;
     }
-    HIP_CHECK(hipStreamEndCapture(stream, &graph));
-    HIP_CHECK(hipGraphInstantiate(&dec_graph, graph, nullptr, nullptr, 0));
+    HIP_CHECK(hipStreamEndCapture(cs, &graph));
+    HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     (void)hipGraphDestroy(graph);
-    dec_key = key;
+    return exec;
+  };
+  // several chains: one graph per chain, replayed on the chain's own stream between a fork and a join event, then the tail's graph. (Parallel branches inside ONE
+  // captured graph were measured first: the runtime serialises most of them and every node gets dearer -- 3.28 -> 3.81 ms per token at 64 sequences, 5.14 with four chains.)
+  auto replay = [&]() {
+    if (NC == 1) { HIP_CHECK(hipGraphLaunch(dec_graph, stream)); return; }
+    HIP_CHECK(hipEventRecord(chain_ev[0], stream));
+    for (int ci = 1; ci < NC; ++ci) {
+      HIP_CHECK(hipStreamWaitEvent(chain_stream[ci], chain_ev[0], 0));
+      HIP_CHECK(hipGraphLaunch(chain_graph[ci], chain_stream[ci]));
+      HIP_CHECK(hipEventRecord(chain_ev[ci], chain_stream[ci]));
+    }
+    HIP_CHECK(hipGraphLaunch(chain_graph[0], stream));
+    for (int ci = 1; ci < NC; ++ci) HIP_CHECK(hipStreamWaitEvent(stream, chain_ev[ci], 0));
     HIP_CHECK(hipGraphLaunch(dec_graph, stream));
+  };
+  if (graphable && dec_graph && key == dec_key && dec_graph_chains == NC) {
+    replay();
+  } else if (graphable && key == dec_eager_key) {
+    drop_graphs();
+    if (NC == 1) dec_graph = capture(stream, PART_ALL);
+    else {
+      ensure_chain_streams(NC);
+      for (int ci = 0; ci < NC; ++ci) chain_graph[ci] = capture(ci == 0 ? stream : chain_stream[ci], ci);
+      dec_graph = capture(stream, PART_HEAD);
+    }
+    dec_key = key;
+    dec_graph_chains = NC;
+    replay();
   } else {
     enqueue_step<T>(ids_dev, n, is_prefill, true);
     if (graphable) dec_eager_key = key;
@@ -767,6 +866,7 @@ extern "C" int asr_whisper_create(const asr_whisper_config* cfg, const void* are
       if (const char* e = getenv("ASR_KV_PAGED")) s->kv_paged = !(e[0] == '0');
       if (const char* e = getenv("ASR_KV_PAGE_SHUFFLE")) s->kv_shuffle = e[0] == '1';
       if (const char* e = getenv("ASR_DECODE_GEMM")) s->use_decode_gemm = !(e[0] == '0');
+      if (const char* e = getenv("ASR_DECODE_CHAINS")) s->dec_chains = atoi(e);
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;
       s->arena.load(arena, arena_bytes, arena_mem, s->stream);

@@ -284,17 +284,20 @@ def test_gemm_layernorm_folded_wide_tiles(M, want):
 
 
 @pytest.mark.parametrize("M", [9216, 9353])
-def test_gemm_argmax_wide_tiles(M):
-    """CTC head at batch 64: 288 x 256 tiles with the per-slab arg-max epilogue + reduce; ids must equal the arg-max of the f32
-    product wherever the top-2 margin exceeds the accumulation-order noise, and equal the 128 x 128-tile path's ids there."""
+@pytest.mark.parametrize("pp", [1, 0])
+def test_gemm_argmax_wide_tiles(M, pp, monkeypatch):
+    """CTC head at batch 64: the persistent ping-pong kernel (the default since round 5) or -- ASR_GEMM_AMAX_PP=0 -- the 288 x 256 tiles, with the per-slab
+    arg-max epilogue + reduce; ids must equal the arg-max of the f32 product wherever the top-2 margin exceeds the accumulation-order noise, and equal the
+    128 x 128-tile path's ids there."""
     probe = sub("_probe")
+    monkeypatch.setenv("ASR_GEMM_AMAX_PP", str(pp))
     N, K, V = 25088, 512, 25055
     rng = np.random.default_rng(M)
     a = rng.standard_normal((M, K)).astype(np.float32)
     w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
     bias = (rng.standard_normal(N) * 0.5).astype(np.float32)
     out, kern = probe.gemm(a, w, bias, argmax=True, n_valid=V)
-    assert kern == "t288w_amax", kern
+    assert kern == ("pp_amax" if pp else "t288w_amax"), kern
     z = torch.from_numpy(_bf16_round(a)) @ torch.from_numpy(_bf16_round(w)).t() + torch.from_numpy(bias)
     z[:, V:] = -np.inf
     top2 = torch.topk(z, 2, dim=1)

@@ -34,6 +34,7 @@ struct FbankArgs {
   // Whisper variant (Whisper/STFT_Process.py:224-246): reflect pad nfft/2 left, nfft/2 - hop right (last frame dropped),
   // log10 instead of ln, and the per-workgroup maximum written to blk_max for the per-utterance clamp
   int whisper;
+  int dbg = 0;                 // ASR_FBANK_DBG (fbank_split_kernel, timing-only ablations; results are garbage by design): 1 no DFT steps, 2 no mel projection, 4 no audio loads, 8 no basis refills
   float* blk_max;
   // bf16 sessions: the DFT on the bf16 matrix pipe with split operands (launch_fbank_split_table): null = exact-f32 MFMA
   const void* dft_split = nullptr;

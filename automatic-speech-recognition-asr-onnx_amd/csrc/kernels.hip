@@ -136,7 +136,11 @@ constexpr int FB_HP = HOP + 8;                                   // bf16 audio r
 constexpr int FB_K32 = (WIN + 31) / 32;                          // 13 chunks of 32 samples (the last one half empty: basis rows >= 400 are zero)
 constexpr int FB_A16 = ((FB_SPAN + 32 + HOP - 1) / HOP) * FB_HP; // bf16 elements per split array (span + the tail the last chunk reads)
 
-__global__ __launch_bounds__(256) void fbank_split_kernel(const FbankArgs a) {
+// Eight waves (round 5; four before): the workgroup's 115 KB of LDS allow one workgroup per CU, so with four waves every SIMD held ONE wave and nothing covered its
+// fragment reads, its waits or its accumulator hand-offs (ablations, profiles/r05_fbank_ablations.txt: DFT 42 us and mel 26 us per workgroup against 19 + 5 us of MFMA
+// issue). Two waves per SIMD split the bin tiles (DFT) and the mel tiles (mel) of the same 64 frames; every accumulator still sums in the same order.
+constexpr int FB_WAVES = 8;
+__global__ __launch_bounds__(64 * FB_WAVES) void fbank_split_kernel(const FbankArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* audh = reinterpret_cast<bf16_t*>(smem);
   bf16_t* audl = audh + FB_A16;
@@ -148,11 +152,11 @@ __global__ __launch_bounds__(256) void fbank_split_kernel(const FbankArgs a) {
   const int s0 = f0 * HOP;
   // the workgroup's audio span: every thread requests ALL of its samples before it uses the first (written as one loop of load / split / store the compiler kept the
   // loads in program order behind a wait each -- 42 dependent memory round trips, ~60 of the workgroup's ~78 us, with nothing else on the CU to cover them)
-  constexpr int FB_NL = (FB_SPAN + 32 + 255) / 256;
+  constexpr int FB_NL = (FB_SPAN + 32 + 64 * FB_WAVES - 1) / (64 * FB_WAVES);
   float av[FB_NL];
 #pragma unroll
   for (int j = 0; j < FB_NL; ++j) {
-    const int i = tid + j * 256;
+    const int i = tid + j * 64 * FB_WAVES;
     // one predicated load per sample: Kaldi reads x[s]; Whisper the padded signal [x[200..1] | x | x[L-2 .. L-41]]  (reflect, right pad shortened by one hop)
     const int L = up.n_samples, half = WIN / 2, p = s0 + i;
     int idx = p;
@@ -161,11 +165,11 @@ __global__ __launch_bounds__(256) void fbank_split_kernel(const FbankArgs a) {
       idx = p < half ? half - p : p < half + L ? p - half : 2 * L + half - 2 - p;
       ok = i < FB_SPAN + 32 && p < L + WIN - HOP;
     }
-    av[j] = ok ? src[idx] : 0.0f;
+    av[j] = (ok && !(a.dbg & 4)) ? src[idx] : 0.0f;
   }
 #pragma unroll
   for (int j = 0; j < FB_NL; ++j) {
-    const int i = tid + j * 256;
+    const int i = tid + j * 64 * FB_WAVES;
     if (i < FB_SPAN + 32) {
       const float v = av[j];
       const uint32_t hb = pack_bf16x2(v, 0.0f) & 0xffffu;
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void fbank_split_kernel(const FbankArgs a) {
   union BF { uint4 q; bf16x8_t v; };
   BF ring[FB_PF][6];
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const int n_steps = wv < a.n_bin_tiles ? (a.n_bin_tiles - wv + 3) / 4 * FB_K32 : 0;
+  const int n_steps = (wv < a.n_bin_tiles && !(a.dbg & 1)) ? (a.n_bin_tiles - wv + FB_WAVES - 1) / FB_WAVES * FB_K32 : 0;
   constexpr size_t FB_IM = (size_t)FB_K32 * 3 * 64;                       // im fragments of a tile follow its re fragments
   auto frag_ptr = [&](int t, int kc) { return tab + (((size_t)(t * 2) * FB_K32 + kc) * 3) * 64 + lane; };
   int pt = wv, pkc = 0, ps = 0;                                           // the step the next refill fetches (it stops at the wave's last step: harmless re-reads)
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void fbank_split_kernel(const FbankArgs a) {
     const uint4* src = frag_ptr(pt, pkc);
 #pragma unroll
     for (int z = 0; z < 3; ++z) { slot[z].q = src[z * 64]; slot[3 + z].q = src[FB_IM + z * 64]; }
-    if (ps + 1 < n_steps) { ++ps; if (++pkc == FB_K32) { pkc = 0; pt += 4; } }
+    if (ps + 1 < n_steps) { ++ps; if (++pkc == FB_K32) { pkc = 0; pt += FB_WAVES; } }
   };
   f32x4_t re[4], im[4];
 #pragma unroll
@@ -212,22 +216,25 @@ __global__ __launch_bounds__(256) void fbank_split_kernel(const FbankArgs a) {
       if (s0 + u < n_steps) {                                               // (wave-uniform)
         const int k = kc * 32 + fgrp * 8;
         const int koff = k + ((k >= HOP) + (k >= 2 * HOP)) * 8;
+        bf16x8_t ah[4], al[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const int pos = (mt * 16 + frow) * FB_HP + koff;
-          const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(audh + pos), al = *reinterpret_cast<const bf16x8_t*>(audl + pos);
-          // smallest terms first: the f32 accumulator then rounds the dominant product last
-          re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ring[u][1].v, re[mt], 0, 0, 0);
-          im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ring[u][4].v, im[mt], 0, 0, 0);
-          re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ring[u][2].v, re[mt], 0, 0, 0);
-          im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ring[u][5].v, im[mt], 0, 0, 0);
-          re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ring[u][0].v, re[mt], 0, 0, 0);
-          im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ring[u][3].v, im[mt], 0, 0, 0);
-          re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ring[u][1].v, re[mt], 0, 0, 0);
-          im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ring[u][4].v, im[mt], 0, 0, 0);
-          re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ring[u][0].v, re[mt], 0, 0, 0);
-          im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ring[u][3].v, im[mt], 0, 0, 0);
+          ah[mt] = *reinterpret_cast<const bf16x8_t*>(audh + pos); al[mt] = *reinterpret_cast<const bf16x8_t*>(audl + pos);
         }
+        // Per accumulator the five terms arrive smallest first (the f32 accumulator then rounds the dominant product last), as before; across accumulators the
+        // order is term-major, so that two MFMAs on the SAME accumulator are eight issues apart (mt-major they were two apart: a dependent-accumulator stall per MFMA)
+#define ASR_FB_TERM(X, ZR, ZI)                                                                          \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                               \
+          re[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[mt], ring[u][ZR].v, re[mt], 0, 0, 0);       \
+          im[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[mt], ring[u][ZI].v, im[mt], 0, 0, 0);       \
+        }
+        ASR_FB_TERM(al, 1, 4)
+        ASR_FB_TERM(ah, 2, 5)
+        ASR_FB_TERM(al, 0, 3)
+        ASR_FB_TERM(ah, 1, 4)
+        ASR_FB_TERM(ah, 0, 3)
+#undef ASR_FB_TERM
         if (++kc == FB_K32) {                                               // the tile is complete: power spectrum to LDS, next tile
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {
@@ -236,50 +243,73 @@ __global__ __launch_bounds__(256) void fbank_split_kernel(const FbankArgs a) {
               pw[(mt * 16 + fgrp * 4 + r) * FB_PLD + t * 16 + frow] = re[mt][r] * re[mt][r] + im[mt][r] * im[mt][r];
             re[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; im[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
           }
-          kc = 0; t += 4;
+          kc = 0; t += FB_WAVES;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      refill(ring[u]);
+      if (!(a.dbg & 8)) refill(ring[u]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   __syncthreads();
 
-  // mel: wave w owns frames [16w, 16w+16); all mel tiles (exact f32, as in fbank_kernel)
+  // mel: wave w owns frames [16w, 16w+16) (exact f32, as in fbank_kernel). The mel tiles advance together: one power fragment read feeds every tile's MFMA, and
+  // consecutive MFMAs hit different accumulators (tile by tile, every MFMA waited for its predecessor on the same accumulator -- 40 cycles -- and re-read the fragment);
+  // every accumulator still sums its bins in the same order
   float wmax = -INFINITY;
   const float4* melp = reinterpret_cast<const float4*>(a.mel_packed);
-  for (int nt = 0; nt < a.n_mel_tiles; ++nt) {
-    f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float4 b4 = melp[(size_t)(nt * a.n_bin_tiles) * 64 + lane];
+  constexpr int FB_MT = 4;                               // mel tiles in flight per wave (80 mels = 5 tiles, 128 mels = 8: split over the two waves of a frame tile)
+  const int fw = wave & 3, mg = wave >> 2;               // frames [16 fw, 16 fw + 16), mel tiles mg, mg + 2, ...
+  for (int nt0 = mg; nt0 < ((a.dbg & 2) ? 0 : a.n_mel_tiles); nt0 += 2 * FB_MT) {
+    f32x4_t acc[FB_MT];
+#pragma unroll
+    for (int q = 0; q < FB_MT; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto mel_frags = [&](float4 (&b)[FB_MT], int kc) {
+#pragma unroll
+      for (int q = 0; q < FB_MT; ++q) b[q] = nt0 + 2 * q < a.n_mel_tiles ? melp[(size_t)((nt0 + 2 * q) * a.n_bin_tiles + kc) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float4 b4[FB_MT], b4n[FB_MT];
+    mel_frags(b4, 0);
     for (int kc = 0; kc < a.n_bin_tiles; ++kc) {
-      float4 b4n = b4;
-      if (kc + 1 < a.n_bin_tiles) b4n = melp[(size_t)(nt * a.n_bin_tiles + kc + 1) * 64 + lane];
-      const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+      mel_frags(b4n, kc + 1 < a.n_bin_tiles ? kc + 1 : kc);         // the next bin tile's weights are requested before this one's MFMAs
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float av = pw[(wave * 16 + frow) * FB_PLD + kc * 16 + j * 4 + fgrp];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc, 0, 0, 0);
+        const float av = pw[(fw * 16 + frow) * FB_PLD + kc * 16 + j * 4 + fgrp];
+#pragma unroll
+        for (int q = 0; q < FB_MT; ++q) {
+          const float bv = j == 0 ? b4[q].x : j == 1 ? b4[q].y : j == 2 ? b4[q].z : b4[q].w;
+          if (nt0 + 2 * q < a.n_mel_tiles) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[q], 0, 0, 0);
+        }
       }
-      b4 = b4n;
+#pragma unroll
+      for (int q = 0; q < FB_MT; ++q) b4[q] = b4n[q];
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = f0 + wave * 16 + fgrp * 4 + r;
-      if (f < up.n_frames) {
-        const float c = fmaxf(acc[r], a.log_floor);
-        const float v = a.whisper ? log10f(c) : logf(c);
-        a.mel_out[(size_t)(up.frame_off + f) * a.n_mels + nt * 16 + frow] = v;
-        wmax = fmaxf(wmax, v);
+    for (int q = 0; q < FB_MT; ++q) {
+      if (nt0 + 2 * q >= a.n_mel_tiles) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = f0 + fw * 16 + fgrp * 4 + r;
+        if (f < up.n_frames) {
+          const float c = fmaxf(acc[q][r], a.log_floor);
+          const float v = a.whisper ? log10f(c) : logf(c);
+          a.mel_out[(size_t)(up.frame_off + f) * a.n_mels + (nt0 + 2 * q) * 16 + frow] = v;
+          wmax = fmaxf(wmax, v);
+        }
       }
     }
   }
   if (a.whisper) {
-    __shared__ float red[4];
+    __shared__ float red[FB_WAVES];
     wmax = wave_max(wmax);
     if (lane == 0) red[wave] = wmax;
     __syncthreads();
-    if (tid == 0) a.blk_max[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (tid == 0) {
+      float m = red[0];
+#pragma unroll
+      for (int w = 1; w < FB_WAVES; ++w) m = fmaxf(m, red[w]);
+      a.blk_max[blockIdx.x] = m;
+    }
   }
 }
 
@@ -1338,12 +1368,14 @@ void launch_fbank(const FbankArgs& a, int n_blocks, hipStream_t s) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fbank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   if (a.dft_split) {
+    FbankArgs b = a;
+    if (const char* e = getenv("ASR_FBANK_DBG")) b.dbg = atoi(e);
     const size_t lds2 = (size_t)FB_A16 * 2 * 2 + (size_t)FB_FRAMES * FB_PLD * sizeof(float);
     static PerDeviceOnce attr2_once;
     if (attr2_once.first()) {
       HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fbank_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     }
-    hipLaunchKernelGGL(fbank_split_kernel, dim3(n_blocks), dim3(256), lds2, s, a);
+    hipLaunchKernelGGL(fbank_split_kernel, dim3(n_blocks), dim3(64 * FB_WAVES), lds2, s, b);
     HIP_CHECK(hipGetLastError());
     return;
   }

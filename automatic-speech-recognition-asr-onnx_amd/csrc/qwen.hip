@@ -642,6 +642,7 @@ __global__ void qw_beam_init_kernel(const int32_t* __restrict__ hist_in, int B, 
 // ------------------------------------------------------------------------------------ session
 struct QwEncLayer { const void *wqkv, *wo, *w1, *w2; const float *bqkv, *bo, *b1, *b2; };
 struct QwDecLayer { const void *wqkv, *wo, *gate_up, *down; const float *qn, *kn; };
+struct QwDec8Layer { const unsigned char* w[4]; const float* s[4]; };      // FP8W mode: e4m3 bytes + per-row power-of-two scales of wqkv, wo, gate_up, down
 
 // one decoder pass: the packed rows (T new positions per sequence) and, for the bf16 prefill, the MFMA attention geometry
 struct DecPass {
@@ -667,6 +668,13 @@ struct QwSession : asr_session {
   std::vector<char> frozen;      // generate(): finished sequences, allowed to sit at max_seq_len while the others go on
   DeviceBuffer d_dplan, d_x, d_x2, d_dh, d_qkv, d_q, d_dctx, d_act, d_last, d_logits, d_next, d_kc, d_vc, d_hist, d_stepplan, d_skws, d_skcnt, d_vt2, d_krows, d_xlo, d_x2lo;
   bool no_fuse = false, use_graph = true;
+  // precision mode ASR_PRECISION_FP8W (opt-in; everything else as in bf16 mode; the MI355X counterpart of the reference's q4f32 / q8f32 decoders, README.md:70,
+  // Optimize_ONNX_Common.py:27,55-60): the four projections of every decoder layer as e4m3 bytes with one power-of-two scale per output row, streamed by the
+  // weight-streaming GEMM of the decode step (<= 64 rows; gemm.hip: gemm_bf16_skinny<.., W8>); their exact bf16 dequantisation serves every other path (prefill, beam
+  // search above 64 rows), so all steps of a session see the same effective weights. ASR_FP8_FAKE=1: same quantisation, bf16 kernels throughout (the tests' exact twin).
+  bool fp8 = false, fp8_fake = false;
+  std::vector<QwDec8Layer> dec8;
+  DeviceBuffer d_w8, d_wscale, d_wdq;
   // ---- paged KV cache (the default; ASR_QWEN_KV_PAGED=0 and the persistent decode kernel keep extents). Pool [page][layer][kv head][16][128] for K and for V,
   // one block table [sequence][pps] for all layers, a free list on the host: a sequence holds pages for the positions it has, gets one more when it crosses a
   // page boundary, and gives all of them back the step after it finishes (its table row then points at page 0, a scratch page nobody reads meaningfully).
@@ -705,7 +713,7 @@ struct QwSession : asr_session {
   ~QwSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_feat, &d_col, &d_c1, &d_c2, &d_c3, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx,
                             &d_ffn, &d_aud_out, &d_dplan, &d_x, &d_x2, &d_dh, &d_qkv, &d_q, &d_dctx, &d_act, &d_last, &d_logits, &d_next,
-                            &d_kc, &d_vc, &d_kvtab, &d_hist, &d_stepplan, &d_skws, &d_skcnt, &d_vt2, &d_krows, &d_xlo, &d_x2lo, &d_save, &d_nsaved, &d_noise, &d_bkc, &d_bvc, &d_bhist, &d_bp0, &d_bplan, &d_bsrc[0], &d_bsrc[1], &d_btok[0], &d_btok[1], &d_bcum, &d_bfin, &d_blen, &d_bdone, &d_btopv, &d_btopi, &d_bstop, &d_bnext, &d_megabar, &d_megalayers, &d_megadbg, &d_mlo, &d_mctx, &d_mact})
+                            &d_kc, &d_vc, &d_kvtab, &d_hist, &d_stepplan, &d_skws, &d_skcnt, &d_vt2, &d_krows, &d_xlo, &d_x2lo, &d_save, &d_nsaved, &d_noise, &d_bkc, &d_bvc, &d_bhist, &d_bp0, &d_bplan, &d_bsrc[0], &d_bsrc[1], &d_btok[0], &d_btok[1], &d_bcum, &d_bfin, &d_blen, &d_bdone, &d_btopv, &d_btopi, &d_bstop, &d_bnext, &d_megabar, &d_megalayers, &d_megadbg, &d_mlo, &d_mctx, &d_mact, &d_w8, &d_wscale, &d_wdq})
       b->release();
     for (auto& kv : taps) kv.second.buf.release();
     if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
@@ -786,6 +794,29 @@ void QwSession::init() {
     const std::string q = "dec" + std::to_string(i) + ".";
     dec[i] = {W(q + "wqkv", {qkvn, d}), W(q + "wo", {d, c.n_heads * c.d_head}), W(q + "gate_up", {2 * c.d_ffn, d}), W(q + "down", {d, c.d_ffn}),
               F(q + "qn", {c.d_head}), F(q + "kn", {c.d_head})};
+  }
+  if (fp8) {
+    const int I = c.d_ffn, od = c.n_heads * c.d_head;
+    ASR_REQUIRE(d % 256 == 0 && I % 256 == 0 && od % 256 == 0, "qwen: FP8 mode needs d_model, d_ffn and heads x head_dim to be multiples of 256");
+    const int Ns[4] = {qkvn, d, 2 * I, d}, Ks[4] = {d, od, d, I};
+    size_t w_elems = 0, n_scales = 0;
+    for (int j = 0; j < 4; ++j) { w_elems += (size_t)Ns[j] * Ks[j]; n_scales += Ns[j]; }
+    d_w8.reserve(c.n_layers * w_elems, stream); d_wscale.reserve(c.n_layers * n_scales * 4, stream); d_wdq.reserve(c.n_layers * w_elems * 2, stream);
+    dec8.resize(c.n_layers);
+    for (int i = 0; i < c.n_layers; ++i) {
+      QwDecLayer& L = dec[i];
+      const void** slot[4] = {&L.wqkv, &L.wo, &L.gate_up, &L.down};
+      unsigned char* w8 = d_w8.as<unsigned char>() + i * w_elems;
+      bf16_t* dq = d_wdq.as<bf16_t>() + i * w_elems;
+      float* sc = d_wscale.as<float>() + i * n_scales;
+      for (int j = 0; j < 4; ++j) {
+        launch_quantize_rows_fp8((const bf16_t*)*slot[j], Ks[j], Ns[j], Ks[j], w8, sc, dq, stream);
+        dec8[i].w[j] = w8; dec8[i].s[j] = sc;
+        *slot[j] = dq;                                     // from here on "the weights" are the dequantised copies
+        w8 += (size_t)Ns[j] * Ks[j]; dq += (size_t)Ns[j] * Ks[j]; sc += Ns[j];
+      }
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
   }
 }
 
@@ -918,6 +949,8 @@ void QwSession::decoder_pass(const DecPass& P) {
   const bool rms_in_gemm = P.step && bf && rows <= 64 && d % 256 == 0 && !no_fuse;
   const bool fused_attn = P.step && (G == 1 || G == 2 || G == 4) && !no_fuse;
   const bool norm_in_reduce = bf && !rms_in_gemm && !no_fuse && d == 1024;
+  const bool w8 = fp8 && !fp8_fake && rms_in_gemm;           // byte weights: the weight-streaming launches of a decode step
+  auto bytes_of = [&](GemmArgs& g, int layer, int wi) { if (w8) { g.W8 = dec8[layer].w[wi]; g.ldw8 = g.K; g.w_scale = dec8[layer].s[wi]; } };
   auto can_norm = [&](const GemmArgs& g0) {           // (the session's gemm() adds the split-K workspace: ask with it in place)
     if (!d_skws.ptr) { d_skws.reserve((size_t)16 << 20, stream); d_skcnt.reserve(4096 * 4, stream); }
     GemmArgs g = g0;
@@ -944,7 +977,7 @@ void QwSession::decoder_pass(const DecPass& P) {
     const QwDecLayer& L = dec[i];
     T* kc = (P.kc ? (T*)P.kc : d_kc.as<T>()) + (size_t)i * layer_kv;
     T* vc = (P.vc ? (T*)P.vc : d_vc.as<T>()) + (size_t)i * layer_kv;
-    { GemmArgs g; g.W = L.wqkv; g.ldw = d; g.M = rows; g.N = qkvn; g.K = d; g.out_f32 = qkv; g.ld_out_f32 = qkvn; normed_gemm(x, xlo, g); }
+    { GemmArgs g; g.W = L.wqkv; g.ldw = d; g.M = rows; g.N = qkvn; g.K = d; g.out_f32 = qkv; g.ld_out_f32 = qkvn; bytes_of(g, i, 0); normed_gemm(x, xlo, g); }
     if (fused_attn) {
       ProfScope ps(prof, "dec_attn", stream);
       const size_t lds = 0;
@@ -987,14 +1020,16 @@ void QwSession::decoder_pass(const DecPass& P) {
       g.out_f32 = x2; g.ld_out_f32 = d;
       if (rms_in_gemm) { g.out_lo = x2lo; g.ld_out_lo = d; }
       else if (norm_in_reduce && can_norm(g)) { g.rms_out = h; g.ld_rms_out = d; g.rms_eps = c.rms_eps; h_is_norm = true; }
+      bytes_of(g, i, 1);
       gemm(g); }
     // gate|up rows are interleaved in the arena: the epilogue stores silu(gate) * up directly (:1322-1325)
-    { GemmArgs g; g.W = L.gate_up; g.ldw = d; g.M = rows; g.N = 2 * I; g.K = d; g.act = ACT_SWIGLU; g.out_lo = act; g.ld_out_lo = I; normed_gemm(x2, x2lo, g); }
+    { GemmArgs g; g.W = L.gate_up; g.ldw = d; g.M = rows; g.N = 2 * I; g.K = d; g.act = ACT_SWIGLU; g.out_lo = act; g.ld_out_lo = I; bytes_of(g, i, 2); normed_gemm(x2, x2lo, g); }
     { ProfScope ps(prof, "dec_gemm", stream);
       GemmArgs g2; g2.A = act; g2.lda = I; g2.W = L.down; g2.ldw = I; g2.M = rows; g2.N = d; g2.K = I; g2.add = x2; g2.ld_add = d;
       g2.out_f32 = x; g2.ld_out_f32 = d;
       if (rms_in_gemm) { g2.out_lo = xlo; g2.ld_out_lo = d; }
       else if (norm_in_reduce && i + 1 < c.n_layers && can_norm(g2)) { g2.rms_out = h; g2.ld_rms_out = d; g2.rms_eps = c.rms_eps; h_is_norm = true; }
+      bytes_of(g2, i, 3);
       gemm(g2); }
   }
   logits_head<T>(P);
@@ -1588,21 +1623,23 @@ extern "C" int asr_qwen_create(const asr_qwen_config* cfg, const void* arena, si
                                asr_session** out) {
   return asr_guard([&] {
     ASR_REQUIRE(cfg && arena && out, "qwen_create: null argument");
-    ASR_REQUIRE(precision == ASR_PRECISION_BF16 || precision == ASR_PRECISION_F32, "qwen_create: bad precision %d", precision);
+    ASR_REQUIRE(precision == ASR_PRECISION_BF16 || precision == ASR_PRECISION_F32 || precision == ASR_PRECISION_FP8W, "qwen_create: bad precision %d", precision);
     asr_require_device(device_id);
     QwSession* s = new QwSession();
     try {
       s->kind = 5;
       s->device = device_id;
       asr_tenant_attach(s);
-      s->precision = precision;
+      s->fp8 = precision == ASR_PRECISION_FP8W;
+      s->precision = s->fp8 ? ASR_PRECISION_BF16 : precision;        // FP8 mode = bf16 mode with byte-wide decoder projections
       s->cfg = *cfg;
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;
       gemm_reload_env();
+      if (const char* e = getenv("ASR_FP8_FAKE")) s->fp8_fake = e[0] == '1';
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       if (const char* e = getenv("ASR_QWEN_NO_FUSE")) s->no_fuse = e[0] == '1';
-      if (const char* e = getenv("ASR_QWEN_MEGA")) s->use_mega = e[0] == '1';
+      if (const char* e = getenv("ASR_QWEN_MEGA")) s->use_mega = e[0] == '1' && !s->fp8;          // (the persistent decode kernel streams bf16 weights only)
       if (const char* e = getenv("ASR_QWEN_KV_PAGED")) s->kv_paged = !(e[0] == '0');
       if (const char* e = getenv("ASR_KV_PAGE_SHUFFLE")) s->kv_shuffle = e[0] == '1';
       s->arena.load(arena, arena_bytes, arena_mem, s->stream);

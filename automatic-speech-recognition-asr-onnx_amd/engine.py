@@ -487,7 +487,8 @@ class QwenAsrSession(_Session):
     @classmethod
     def from_checkpoint(cls, cfg, ck, precision=PRECISION_BF16, device_id=0):
         from .arena import build_qwen_asr_arena
-        return cls(cfg, build_qwen_asr_arena(cfg, ck, precision), precision, device_id)
+        arena_precision = PRECISION_BF16 if precision == PRECISION_FP8W else precision
+        return cls(cfg, build_qwen_asr_arena(cfg, ck, arena_precision), precision, device_id)
 
     @staticmethod
     def _ragged(seqs, B):

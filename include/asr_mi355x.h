@@ -47,10 +47,12 @@ enum asr_status {
  * soft-max / front-end. F32: exact-f32 MFMA everywhere (verification mode for the
  * "logits within 1e-3" parity bar). The weight arena must be built for the same mode.
  *
- * FP8W (opt-in, Whisper sessions only; the low-bit counterpart of the reference's quantised decoders, Whisper/Optimize_ONNX.py:81-96,
- * Optimize_ONNX_Common.py:55-60): bf16 mode whose decoder projection weights and cross-K/V cache are stored as OCP e4m3 bytes with
- * power-of-two scales (per output column / per (sequence, head) slab) and widened to bf16 in registers -- activations, accumulation,
- * self-KV cache, encoder and vocabulary projection are unchanged. Takes a bf16 arena; quantisation happens at session creation.
+ * FP8W (opt-in, Whisper and Qwen3-ASR sessions; the low-bit counterpart of the reference's quantised decoders, Whisper/Optimize_ONNX.py:81-96,
+ * Optimize_ONNX_Common.py:27,55-60, README.md:70 q4f32): bf16 mode whose decoder projection weights (Whisper: and the cross-K/V cache) are stored as
+ * OCP e4m3 bytes with power-of-two scales (per output column / per (sequence, head) slab) and widened to bf16 in registers -- activations, accumulation,
+ * self-KV cache, encoder and vocabulary projection are unchanged. Takes a bf16 arena; quantisation happens at session creation. Qwen3-ASR: the four
+ * projections of every decoder layer (q|k|v, o, gate|up, down); decode steps of <= 64 rows stream the bytes, every other pass (prefill, wider beam steps)
+ * reads their exact bf16 dequantisation, so all passes of a session see the same effective weights. Needs d_model, d_ffn and heads x head_dim multiples of 256.
  *
  * FP8MM (opt-in, Whisper sessions only): FP8W plus the encoder's feed-forward pair on the FP8 MATRIX pipe -- fc1 / fc2 weights as e4m3 bytes with one
  * power-of-two scale per output column, their activation operands (the second LayerNorm's output, the GELU output) as e4m3 bytes at unit scale

@@ -222,7 +222,7 @@ def test_long_and_maximum_windows_mixed_with_short_ones(prec):
 
 def test_batch64_headline_dispatch_vs_small_tile_paths_and_oracle(monkeypatch):
     """BASELINE.json configs[1] exactly: SenseVoiceSmall bf16, 64 x 8 s windows in one batch, three ways:
-      block  the default: one launch per SANM block (clusters of four workgroups per window, csrc/sanm_block.hip) + 288 x 256 CTC tiles
+      block  the default: one launch per SANM block (clusters of four workgroups per window, csrc/sanm_block.hip) + the CTC head on the persistent ping-pong GEMM
       wide   ASR_SANM_BLOCK=0: four launches per block, FFN-1 on the 288 x 256 tiles (round 1's headline path)
       small  ... and the wide tilings off too (144 x 128 / 128 x 128 tiles)
     -- kernels no smaller batch dispatches. All 64 utterances are compared across the three (same function, other summation
@@ -254,8 +254,8 @@ def test_batch64_headline_dispatch_vs_small_tile_paths_and_oracle(monkeypatch):
         rows = sess.utterance_rows([a.size for a in audios])
         del sess
     # the 8-wave block kernel walks a whole run of blocks per launch: blocks 1 .. n_main - 1, then (behind the stand-alone LayerNorm) n_main .. n_blocks - 1
-    assert out["block"][4]["sanm_block"]["launches"] == (2 if cfg.n_tp > 0 else 1) and out["block"][3].get("t288w_amax", 0) == 1, (out["block"][3], list(out["block"][4]))
-    assert "sanm_block" not in out["wide"][4] and out["wide"][3].get("t288w", 0) == cfg.n_blocks and out["wide"][3].get("t288w_amax", 0) == 1, out["wide"][3]
+    assert out["block"][4]["sanm_block"]["launches"] == (2 if cfg.n_tp > 0 else 1) and out["block"][3].get("pp_amax", 0) == 1, (out["block"][3], list(out["block"][4]))
+    assert "sanm_block" not in out["wide"][4] and out["wide"][3].get("t288w", 0) == cfg.n_blocks and out["wide"][3].get("pp_amax", 0) == 1, out["wide"][3]
     k0 = out["small"][3]
     assert "t288w" not in k0 and "t288w_amax" not in k0 and "t144w" not in k0, k0
     for other in ("wide", "small"):

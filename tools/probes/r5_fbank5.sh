@@ -1,0 +1,11 @@
+set -x
+mkdir -p gpurun_out/r5h
+python -m pytest tests/test_qwen_fp8_gpu.py -q -s > gpurun_out/r5h/pytest_qfp8.txt 2>&1
+tail -6 gpurun_out/r5h/pytest_qfp8.txt
+python -m pytest tests/test_sensevoice_gpu.py tests/test_natural_audio_gpu.py tests/test_paraformer_gpu.py -q -x > gpurun_out/r5h/pytest.txt 2>&1
+tail -3 gpurun_out/r5h/pytest.txt
+line() { python -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); k = d.get('kernels', {}); print(d['ms_per_step'], 'ms per step; fbank', k['fbank']['ms_per_step'])"; }
+for v in 0 1 2 3 0; do
+  echo "ASR_FBANK_DBG=$v: $(ASR_FBANK_DBG=$v python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | line)"
+done > gpurun_out/r5h/fbank_ablations.txt 2>&1
+cat gpurun_out/r5h/fbank_ablations.txt

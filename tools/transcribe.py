@@ -49,8 +49,8 @@ def whisper_text(tokenizer, ids, remove_repeats=True):
 def run(a) -> dict:
     shim, eng, audio_io, cfgm = _m("ort_shim"), _m("engine"), _m("audio_io"), _m("config")
     prec = 1 if a.precision == "f32" else 0
-    if a.precision in ("fp8w", "fp8mm") and a.family != "whisper":
-        raise SystemExit("--precision %s exists for --family whisper only" % a.precision)
+    if (a.precision == "fp8mm" and a.family != "whisper") or (a.precision == "fp8w" and a.family not in ("whisper", "qwen_asr")):
+        raise SystemExit("--precision %s exists for --family whisper%s only" % (a.precision, " / qwen_asr" if a.precision == "fp8w" else ""))
     files = []
     if a.family in ("sensevoice", "paraformer"):
         mod = _m(a.family)
@@ -96,7 +96,12 @@ def run(a) -> dict:
     elif a.family == "qwen_asr":
         info, blob = shim.load_model(os.path.join(a.model, "Qwen_ASR.asrmodel"))
         cfg = cfgm.QwenAsrConfig(**info["config"])
-        sess = eng.QwenAsrSession(cfg, blob, int(info.get("precision", prec)))
+        bundle_prec = int(info.get("precision", prec))
+        if a.precision == "fp8w":                   # opt-in: the decoder's projections as e4m3 bytes over a bf16 bundle (include/asr_mi355x.h)
+            if bundle_prec != 0:
+                raise SystemExit("--precision fp8w needs a bf16 bundle (convert the checkpoint with --precision bf16)")
+            bundle_prec = 2
+        sess = eng.QwenAsrSession(cfg, blob, bundle_prec)
         tok = None
         if a.tokenizer:
             from transformers import AutoTokenizer
@@ -161,7 +166,7 @@ def main():
     r.add_argument("--language", default="auto")
     r.add_argument("--tokenizer", help="SentencePiece model (SenseVoice), vocabulary file (Paraformer) or HF tokenizer directory (Whisper / Qwen3-ASR)")
     r.add_argument("--precision", default="f32", choices=("bf16", "f32", "fp8w", "fp8mm"),
-                   help="f32 = verification mode (the mode whose tokens equal the reference's); fp8w = Whisper only, opt-in e4m3 decoder weights / cross-K/V; fp8mm = fp8w + encoder FFN on the FP8 matrix pipe")
+                   help="f32 = verification mode (the mode whose tokens equal the reference's); fp8w = Whisper / Qwen3-ASR, opt-in e4m3 decoder weights (Whisper: and cross-K/V); fp8mm = fp8w + encoder FFN on the FP8 matrix pipe")
     r.add_argument("--sliding-window", type=int, default=0)
     r.add_argument("--repeat-penalty", type=float, default=1.0, help="1.0 = plain greedy (the comparison default); the reference scripts default to 0.8")
     r.add_argument("--beam", type=int, default=1)

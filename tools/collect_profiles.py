@@ -10,7 +10,7 @@ names = {"bench_sensevoice": "bench_n1", "bench_sensevoice_4launch": "bench_4lau
          "bench_whisper30_fp8": "bench_whisper30_fp8_n1", "bench_whisper_fp8": "bench_whisper_fp8_n1",
          "bench_whisper_b64_fp8mm": "bench_whisper_b64_fp8mm_n1", "bench_whisper30_fp8mm": "bench_whisper30_fp8mm_n1",
          "bench_qwen": "bench_qwen_n1", "bench_qwen_beam5": "bench_qwen_beam5_n1", "bench_mixed_beam5": "bench_mixed_beam5_n1",
-         "bench_paraformer_streaming_256": "bench_paraformer_streaming_256_n1"}
+         "bench_paraformer_streaming_256": "bench_paraformer_streaming_256_n1", "bench_qwen_fp8": "bench_qwen_fp8_n1"}
 for a, b in names.items():
     p = os.path.join(src, a + ".json")
     if os.path.isfile(p) and os.path.getsize(p) > 10:
@@ -19,7 +19,7 @@ for d, out in (("stats", "sensevoice_b64"), ("stats_whisper", "whisper_b32"), ("
     fs = glob.glob(os.path.join(src, d, "*", "*kernel_stats.csv"))
     if fs:
         shutil.copy(sorted(fs, key=os.path.getmtime)[-1], f"profiles/{rnd}_{out}_kernel_stats.csv")
-for t in ("sensevoice_bf16_b1_trace_summary.txt", "sanm_block_phase_clock.txt", "sensevoice_f32_b1_profile.txt", "fp8_gemm_probe.txt", "gelu_epilogue_cost.txt", "sanm_block_ablations.txt", "sanm_block_batch_sweep.txt", "sanm_block_variants.txt", "sanm_block_min_sweep.txt", "sanm_block_clock_inside_A.txt"):
+for t in ("sensevoice_bf16_b1_trace_summary.txt", "sanm_block_phase_clock.txt", "sensevoice_f32_b1_profile.txt", "fp8_gemm_probe.txt", "gelu_epilogue_cost.txt", "sanm_block_ablations.txt", "sanm_block_batch_sweep.txt", "sanm_block_variants.txt", "sanm_block_min_sweep.txt", "sanm_block_clock_inside_A.txt", "fbank_ablations_final.txt"):
     p = os.path.join(src, t)
     if os.path.isfile(p):
         shutil.copy(p, f"profiles/{rnd}_{t}")

@@ -26,7 +26,7 @@ python tools/probes/gelu_cost.py > $OUT/gelu_epilogue_cost.txt 2>&1
 for a in 0 16 32 64 128 192 224; do echo "=== ASR_SANM_BLOCK8_OPT=$a (x16: 1 no MFMA, 2 no A fragment reads, 4 no W refills, 8 no chunk DMA; results are garbage by design)"; ASR_SANM_BLOCK8_OPT=$a ASR_SANM_BLOCK_DBG=10 python tools/probes/sanm_block_clock.py 2>&1 | grep -v amdgpu.ids | tail -17; done > $OUT/sanm_block_ablations.txt 2>&1
 ASR_SANM_BLOCK_DBG=10 python tools/probes/sanm_block_clock.py > $OUT/sanm_block_phase_clock.txt 2>&1
 for b in 1 16; do echo "=== batch $b (ASR_SANM_BLOCK_MIN=1): the per-cluster critical path with the chip idle"; CLOCK_B=$b ASR_SANM_BLOCK_MIN=1 ASR_SANM_BLOCK_DBG=10 python tools/probes/sanm_block_clock.py 2>&1 | grep -v amdgpu.ids | tail -17; done > $OUT/sanm_block_batch_sweep.txt 2>&1
-for v in "ASR_SANM_BLOCK_V=8" "ASR_SANM_BLOCK_FFN22=1" "ASR_SANM_BLOCK8_OPT=1024" "ASR_GEMM_AMAX_PP=1" "ASR_SANM_BLOCK_PERSIST=0" "ASR_SANM_BLOCK_V=1" "ASR_SANM_BLOCK8_OPT=4" "ASR_SANM_BLOCK8_OPT=256" "ASR_SANM_BLOCK_V=8"; do
+for v in "ASR_SANM_BLOCK_V=8" "ASR_SANM_BLOCK_FFN22=1" "ASR_SANM_BLOCK8_OPT=1024" "ASR_GEMM_AMAX_PP=0" "ASR_SANM_BLOCK_PERSIST=0" "ASR_SANM_BLOCK_V=1" "ASR_SANM_BLOCK8_OPT=4" "ASR_SANM_BLOCK8_OPT=256" "ASR_SANM_BLOCK_V=8"; do
   echo "$v: $(env $v python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms per step,', d['value'], 'audio-s/s')")"
 done > $OUT/sanm_block_variants.txt 2>&1
 bash tools/probes/block_min_sweep.sh > $OUT/sanm_block_min_sweep.txt 2>&1
@@ -36,6 +36,8 @@ python bench.py --workload paraformer-streaming --batch 256 --steps 16 --warmup 
 ASR_SANM_BLOCK8_OPT=2048 ASR_SANM_BLOCK_DBG=10 python tools/probes/sanm_block_clock.py 2>&1 | grep -v amdgpu.ids | tail -23 > $OUT/sanm_block_clock_inside_A.txt
 python bench.py --workload qwen --steps 6 --warmup 2 --inflight 3 > $OUT/bench_qwen.json 2> $OUT/bench_qwen.err
 python bench.py --workload qwen --beam 5 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_qwen_beam5.json 2> $OUT/bench_qwen_beam5.err
+python bench.py --workload qwen --fp8 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_qwen_fp8.json 2> $OUT/bench_qwen_fp8.err
+for v in 0 1 2 3 4 8; do echo "ASR_FBANK_DBG=$v: $(ASR_FBANK_DBG=$v python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms per step; fbank', d['kernels']['fbank']['ms_per_step'])")"; done > $OUT/fbank_ablations_final.txt 2>&1
 python bench.py --workload mixed --beam 5 --steps 6 --warmup 1 > $OUT/bench_mixed_beam5.json 2> $OUT/bench_mixed_beam5.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --profile-steps 1 > $OUT/stats.log 2>&1

@@ -15,6 +15,7 @@
 // Tried and dropped: 16 extra workgroups (two per XCD) that do nothing but touch the next phase's weights one phase ahead of tile cluster 0 -- with 220 idle CUs
 // at one window it looked free, but the GEMM phases got 15 % SLOWER (5.4 / 5.5 / 6.2 us against 4.6 / 4.8 / 5.7 with every workgroup touching its 1 / n).
 #include "stream_cluster.h"
+#include "gemm.h"
 
 namespace {
 
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(NT) void sanm_tiles_kernel(const SanmTilesArgs a) {
 bool sanm_tiles_supported(int max_T, int d, int d_ffn, int n_heads, int d_head, int ktaps) {
   return max_T <= MAXT && d == D && d_ffn == DFF && n_heads == NH && d_head == HD && ktaps == TAPS;
 }
-int sanm_tiles_max_tiles() { return 64; }             // one workgroup per CU: 64 tiles x 4 heads
+int sanm_tiles_max_tiles() { return gemm_env_cus() / 8 * 2; }   // one workgroup per CU, tiles in pairs: 64 tiles x 4 heads on 256 CUs (the device's count as of the last gemm_reload_env(); a larger batch takes the other paths)
 
 void launch_sanm_tiles(const SanmTilesArgs& a, hipStream_t s) {
   ASR_REQUIRE(a.n_tiles >= 1 && a.n_tiles <= sanm_tiles_max_tiles() && a.n_layers >= 1, "sanm_tiles: %d tiles", a.n_tiles);

@@ -40,12 +40,19 @@ __device__ __forceinline__ bf16x8_t fp8x8_to_bf16x8(u32x2_t r) {
 }
 
 template <int MT, int NT, bool FOLD, bool W8>
-__global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g) {
+__global__ __launch_bounds__(512) void decode_gemm_kernel(const DecGemmArgs g) {       // (grids are shaped to <= one workgroup per CU: the activation batches may take the registers of two)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fgrp = lane >> 4;
   const int n0 = blockIdx.x * 16 * NT;
   const int KS = gridDim.y, ks = blockIdx.y;
+  // phase clock (probe only): workgroup (0, 0) -> slots 0..4, the last workgroup -> slots 5..9
+  unsigned long long* clk = nullptr;
+  if (g.dbg_clk && tid == 0) {
+    if (blockIdx.x == 0 && blockIdx.y == 0) clk = g.dbg_clk;
+    else if (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) clk = g.dbg_clk + 5;
+  }
+  if (clk) clk[0] = wall_clock64();
   const int kw = (wave + (int)blockIdx.x) & (DW - 1);    // rotate the wave -> slice map per workgroup: the shared activation rows are not hit in lock-step
   // K in steps of 32: this workgroup's share of the steps, then this wave's share of those (shares differ by at most one step, so any split
   // count divides any K)
@@ -56,7 +63,7 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
   const bf16_t* wp = g.W + (size_t)(n0 + frow) * g.ldw + k_begin + fgrp * 8;
   const unsigned char* wp8 = g.W8 + (size_t)(n0 + frow) * g.ldw + k_begin + fgrp * 8;     // (W8: ldw counts bytes = elements)
   const bf16_t* ap = g.A + (size_t)frow * g.lda + k_begin + fgrp * 8;
-  constexpr int U = (W8 ? 16 : 8) / NT;                // K-steps per trip: U x NT weight fragments in flight per wave (16 B per lane each; byte weights: 8 B, twice as many)
+  constexpr int U = 8 / NT;                            // K-steps per trip: U x NT weight fragments in flight per wave (16 B per lane each; byte weights: 8 B)
 
   f32x4_t acc[MT][NT], sx[MT], sxx[MT];
 #pragma unroll
@@ -65,22 +72,17 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
-  // the residual term of the epilogue does not depend on the product: requested first, it arrives under the weight stream
-  constexpr int TILES = MT * NT;                       // output tiles of 16 x 16; wave t finishes tile t (TILES <= 8)
-  static_assert(TILES <= DW, "one finishing wave per output tile");
-  const int ti = wave / NT, tj = wave % NT;            // tile of this wave in the epilogue
-  float4 addv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (wave < TILES && g.add && ti * 16 + frow < g.M) addv = *reinterpret_cast<const float4*>(g.add + (size_t)(ti * 16 + frow) * g.ld_add + n0 + tj * 16 + fgrp * 4);
-  // ... and so do the bias and the column sums of the fold: a global load issued in the epilogue would sit on the launch's critical path
-  float4 biasv = make_float4(0.f, 0.f, 0.f, 0.f), csumv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (wave < TILES) {
-    if (g.bias) biasv = *reinterpret_cast<const float4*>(g.bias + n0 + tj * 16 + fgrp * 4);
-    if constexpr (FOLD) csumv = *reinterpret_cast<const float4*>(g.colsum + n0 + tj * 16 + fgrp * 4);
-  }
-  const bf16x8_t ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
-  for (int k = 0; k < kslice; k += 32 * U) {
-    using raw_t = typename std::conditional<W8, u32x2_t, bf16x8_t>::type;
-    raw_t wf[U][NT];
+  // ---- operand requests (round 5, second form). The phase clock (tools/probes/decode_gemm_clock.py, profiles/r05_decode_gemm_clock.txt) puts 4.3 of a 6.7 us launch at
+  // 32 rows (6.6 of 9.4 at 64, 3.2 of 5.3 at one row) between the first weight request and the last MFMA of a wave -- not the ~2.5 us the weights take to arrive, but that
+  // plus one L2 round trip per activation fragment: written as "load a fragment, multiply" the loop compiled to load -> s_waitcnt vmcnt(0) -> MFMA, MT x K-steps times per wave.
+  // All requests of a trip are therefore issued in front of its MFMAs, weights first, activation fragments in batches of <= 16, and NOTHING older is pending when the first
+  // trip's requests go out (the epilogue's residual / bias / column-sum loads come after them: in the first form of this change they came first, their registers were
+  // reused by the batch and the compiler parked the batch behind an s_waitcnt for them -- two memory round trips in sequence, slower than the one-at-a-time loop).
+  using raw_t = typename std::conditional<W8, u32x2_t, bf16x8_t>::type;
+  constexpr int UA = MT * U > 16 ? (16 / MT < 1 ? 1 : 16 / MT) : U;        // K-steps per activation batch
+  raw_t wf[U][NT];
+  bf16x8_t af[UA][MT];
+  auto issue_w = [&](int k) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (k + u * 32 < kslice) {
@@ -90,25 +92,63 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
           else wf[u][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)j * 16 * g.ldw + k + u * 32));
         }
       }
+  };
+  auto issue_a = [&](int k, int u0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (k + u * 32 < kslice) {
+    for (int uu = 0; uu < UA; ++uu)
+      if (k + (u0 + uu) * 32 < kslice) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(ap + (size_t)i * 16 * g.lda + k + u * 32);
+          // rows past M are never stored: their lanes request nothing (at one row the 16-row tile would pull 16 x the bytes through this CU's 64 B / clk path)
+          af[uu][i] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+          if (i * 16 + frow < g.M) af[uu][i] = *reinterpret_cast<const bf16x8_t*>(ap + (size_t)i * 16 * g.lda + k + (u0 + uu) * 32);
+        }
+      }
+  };
+  issue_w(0);
+  issue_a(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  // the residual term, the bias and the column sums of the fold do not depend on the product: requested here, they arrive under the weight stream
+  constexpr int TILES = MT * NT;                       // output tiles of 16 x 16; wave t finishes tile t (TILES <= 8)
+  static_assert(TILES <= DW, "one finishing wave per output tile");
+  const int ti = wave / NT, tj = wave % NT;            // tile of this wave in the epilogue
+  float4 addv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (wave < TILES && g.add && ti * 16 + frow < g.M) addv = *reinterpret_cast<const float4*>(g.add + (size_t)(ti * 16 + frow) * g.ld_add + n0 + tj * 16 + fgrp * 4);
+  float4 biasv = make_float4(0.f, 0.f, 0.f, 0.f), csumv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (wave < TILES) {
+    if (g.bias) biasv = *reinterpret_cast<const float4*>(g.bias + n0 + tj * 16 + fgrp * 4);
+    if constexpr (FOLD) csumv = *reinterpret_cast<const float4*>(g.colsum + n0 + tj * 16 + fgrp * 4);
+  }
+  const bf16x8_t ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  if (clk) clk[1] = wall_clock64();
+  for (int k = 0; k < kslice; k += 32 * U) {
+    if (k > 0) { issue_w(k); issue_a(k, 0); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            bf16x8_t wv;
-            if constexpr (W8) wv = fp8x8_to_bf16x8(wf[u][j]); else wv = wf[u][j];
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, af, acc[i][j], 0, 0, 0);   // D[n = 4 fgrp + r][m = frow]
-          }
-          if constexpr (FOLD) {
-            sx[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af, sx[i], 0, 0, 0);       // D[*][m = frow] = sum_k x[m][k]
-            sxx[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, af, sxx[i], 0, 0, 0);       // D[a][b] = x[a] . x[b]: the diagonal is sum(x^2)
+    for (int u0 = 0; u0 < U; u0 += UA) {
+      if (k + u0 * 32 >= kslice) break;                  // (wave-uniform)
+      if (u0 > 0) { issue_a(k, u0); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+      for (int uu = 0; uu < UA; ++uu) {
+        const int u = u0 + uu;
+        if (k + u * 32 < kslice) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              bf16x8_t wv;
+              if constexpr (W8) wv = fp8x8_to_bf16x8(wf[u][j]); else wv = wf[u][j];
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, af[uu][i], acc[i][j], 0, 0, 0);   // D[n = 4 fgrp + r][m = frow]
+            }
+            if constexpr (FOLD) {
+              sx[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[uu][i], sx[i], 0, 0, 0);       // D[*][m = frow] = sum_k x[m][k]
+              sxx[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[uu][i], af[uu][i], sxx[i], 0, 0, 0);       // D[a][b] = x[a] . x[b]: the diagonal is sum(x^2)
+            }
           }
         }
       }
+    }
   }
+  if (clk) { asm volatile("s_nop 0" :: "v"(acc[0][0])); clk[2] = wall_clock64(); }       // (the product of this wave's slice is in its registers)
   // ---- cross-wave reduction through LDS: red[wave][tile][lane] (float4), statistics st[wave][row] (float2)
   float4* red = reinterpret_cast<float4*>(smem);
   float2* st = reinterpret_cast<float2*>(smem + DW * TILES * 1024);
@@ -129,6 +169,7 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
 #pragma unroll
     for (int w = 1; w < DW; ++w) { const float4 q = red[(w * TILES + tile) * 64 + lane]; sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w; }
   }
+  if (clk) { asm volatile("s_nop 0" :: "v"(sum.x)); clk[3] = wall_clock64(); }
   const int rows16 = MT * 16;
   float fold_s1 = 0.0f, fold_s2 = 0.0f;              // FOLD with K split across workgroups: the statistics summed over the splits
   if (KS > 1) {            // hand the partial tiles over (write-through, 16 bytes per lane); the last workgroup of this column granule finishes
@@ -225,6 +266,7 @@ __global__ __launch_bounds__(512, 2) void decode_gemm_kernel(const DecGemmArgs g
     w.x = pack_bf16x2(sum.x, sum.y); w.y = pack_bf16x2(sum.z, sum.w);
     *reinterpret_cast<uint2*>(g.out_lo + (size_t)m * g.ld_out_lo + n) = w;
   }
+  if (clk) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); clk[4] = wall_clock64(); }       // (this thread's output stores are acknowledged)
 }
 
 // c[n] = sum_k W[n][k] of the bf16 weights, accumulated in double (one wave per row)

@@ -104,6 +104,7 @@ struct DecGemmArgs {
   float* out_f32 = nullptr; int ld_out_f32 = 0;      // either or both outputs
   bf16_t* out_lo = nullptr; int ld_out_lo = 0;
   float* ws = nullptr; size_t ws_bytes = 0; int32_t* cnt = nullptr;     // split-K partials [splits][rows16][N] + self-resetting tickets [N / 16] (per session)
+  unsigned long long* dbg_clk = nullptr;             // tuning (tools/probes/decode_gemm_clock.py): thread 0 of the first and of the last workgroup stamp wall_clock64() at five points ([2][5])
 };
 bool decode_gemm_supported(const DecGemmArgs& g);
 void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits);

@@ -173,6 +173,10 @@ extern "C" int asr_probe_gemm_chain(int M, int N, int K, int epilogue, int cold_
       evs.resize(chain + 1);
       for (auto& e : evs) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    // ASR_PROBE_CLK=1: every launch of the chain stamps its phase clock (decode_gemm_kernel: DecGemmArgs::dbg_clk); the breakdown of the last replay goes to stderr
+    const bool clocked = use_dg && getenv("ASR_PROBE_CLK") && getenv("ASR_PROBE_CLK")[0] == '1';
+    unsigned long long* dclk = clocked ? (unsigned long long*)t.alloc((size_t)chain * 10 * 8) : nullptr;
+    if (dclk) HIP_CHECK(hipMemset(dclk, 0, (size_t)chain * 10 * 8));
     auto enqueue = [&] {
       for (int i = 0; i < chain; ++i) {
         if (prefetch) {
@@ -181,7 +185,7 @@ extern "C" int asr_probe_gemm_chain(int M, int N, int K, int epilogue, int cold_
           HIP_CHECK(hipStreamWaitEvent(s2, evs[i], 0));
           launch_decode_gemm_prefetch(gn, s2);
         }
-        if (use_dg) { DecGemmArgs gi = dg; gi.W = (const bf16_t*)((char*)dw + wbytes * (i % copies)); launch_decode_gemm(gi, s); }
+        if (use_dg) { DecGemmArgs gi = dg; gi.W = (const bf16_t*)((char*)dw + wbytes * (i % copies)); gi.dbg_clk = dclk ? dclk + (size_t)i * 10 : nullptr; launch_decode_gemm(gi, s); }
         else { GemmArgs gi = g; gi.W = (char*)dw + wbytes * (i % copies); launch_gemm_bf16(gi, s); }
       }
       if (prefetch) { HIP_CHECK(hipEventRecord(evs[chain], s2)); HIP_CHECK(hipStreamWaitEvent(s, evs[chain], 0)); }
@@ -204,6 +208,25 @@ extern "C" int asr_probe_gemm_chain(int M, int N, int K, int epilogue, int cold_
     float ms = 0.f;
     HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     *us_per_launch = ms * 1e3f / ((float)replays * chain);
+    if (dclk) {
+      std::vector<unsigned long long> h((size_t)chain * 10);
+      HIP_CHECK(hipMemcpy(h.data(), dclk, h.size() * 8, hipMemcpyDeviceToHost));
+      double seg[4] = {0, 0, 0, 0}, body = 0, gap = 0, skew = 0, tail = 0;
+      int n = 0;
+      for (int i = 1; i + 1 < chain; ++i) {            // 100 MHz clock: 0.01 us per tick
+        const unsigned long long* a = &h[(size_t)i * 10];
+        const unsigned long long* b = &h[(size_t)(i + 1) * 10];
+        if (!a[0] || !a[4] || !b[0] || !a[5] || !a[9]) continue;
+        for (int q = 0; q < 4; ++q) seg[q] += (double)(a[q + 1] - a[q]) * 0.01;
+        body += (double)(a[4] - a[0]) * 0.01;
+        skew += (double)((long long)a[5] - (long long)a[0]) * 0.01;                    // the last workgroup starts this much after the first
+        tail += (double)((long long)std::max(a[9], a[4]) - (long long)a[4]) * 0.01;    // ... and ends this much after the first one's end
+        gap += (double)((long long)std::min(b[0], b[5]) - (long long)std::max(a[4], a[9])) * 0.01;   // last store acknowledged -> first instruction of the next launch
+        ++n;
+      }
+      if (n) fprintf(stderr, "  [clock M=%d N=%d K=%d %s] launch %.2f us = body of workgroup 0 %.2f (setup %.2f, weights + MFMA %.2f, reduce %.2f, hand-over + epilogue + store ack %.2f) + last workgroup start skew %.2f / end tail %.2f; boundary to the next launch %.2f\n",
+                     M, N, K, g_chain_kernel, *us_per_launch, body / n, seg[0] / n, seg[1] / n, seg[2] / n, seg[3] / n, skew / n, tail / n, gap / n);
+    }
     if (!use_dg) snprintf(g_chain_kernel, sizeof(g_chain_kernel), "%s", gemm_last_kernel());
     (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
     if (s2) (void)hipStreamDestroy(s2);

@@ -126,7 +126,10 @@ extern "C" int asr_session_tap_read(asr_session* s, const char* name, void* host
     const size_t need = (size_t)t.rows * t.cols * t.elt;
     ASR_REQUIRE(bytes == need, "tap_read: '%s' is %zu bytes, buffer is %zu", name, need, bytes);
     HIP_CHECK(hipSetDevice(s->device));
-    HIP_CHECK(hipMemcpy(host_out, t.buf.ptr, need, hipMemcpyDeviceToHost));
+    // on the session's own stream, not the legacy null stream: a synchronous null-stream copy next to captured graphs is what tools/probes/stream_taps_toggle.py
+    // trips over on this runtime (taps read between steps, then the cached step graph replayed: a cluster of the fused launch never saw its siblings)
+    HIP_CHECK(hipMemcpyAsync(host_out, t.buf.ptr, need, hipMemcpyDeviceToHost, s->stream));
+    HIP_CHECK(hipStreamSynchronize(s->stream));
   });
 }
 

@@ -1878,8 +1878,14 @@ constexpr int SA_MAXQ = 16;
 
 template <typename T>
 __global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a) {
-  __shared__ float Ks[SA_MAXK][SA_HD + 1];
-  __shared__ float Vs[SA_MAXK][SA_HD + 1];
+  // The K / V images hold the session's element type (round 5): as f32 the kernel's static LDS was 78 KB -- more than 64 KB, yet small enough to share a CU with other
+  // workgroups -- and next to ANOTHER session's kernels its results moved by a percent on some query rows, silently and only then (tools/probes/stream_determinism.py,
+  // profiles/r05_stream_determinism.txt: identical q|k|v, history and lengths in, different context out; gone when the workgroup owns the CU's LDS, not gone with the LDS
+  // cleared, an acquire at kernel start or one workgroup of this kernel per CU). bf16 sessions now use 46 KB; the f32 instance is launched with the CU's LDS to itself.
+  // Row pitch: an odd number of dwords, so that 64 keys at one column are 64 banks.
+  constexpr int SA_KP = SA_HD + (sizeof(T) == 2 ? 2 : 1);
+  __shared__ T Ks[SA_MAXK][SA_KP];
+  __shared__ T Vs[SA_MAXK][SA_KP];
   __shared__ float Qs[SA_MAXQ][SA_HD + 1];
   __shared__ float Ps[SA_MAXQ][SA_MAXK + 1];
   const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1916,7 +1922,7 @@ __global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a
         rk[it].get(k8);
         rv[it].get(v8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { Ks[p][c0 + e] = k8[e]; Vs[p][c0 + e] = v8[e]; }
+        for (int e = 0; e < 8; ++e) { Elem<T>::store(&Ks[p][c0 + e], k8[e]); Elem<T>::store(&Vs[p][c0 + e], v8[e]); }      // (exact: the values came from T)
       }
     }
   }
@@ -1935,7 +1941,7 @@ __global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a
         float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 8
         for (int c = 0; c < SA_HD; ++c) {
-          const float kv = Ks[k][c];
+          const float kv = Elem<T>::load(&Ks[k][c]);
 #pragma unroll
           for (int j = 0; j < 4; ++j) s4[j] = fmaf(Qs[qg + 4 * j][c], kv, s4[j]);
         }
@@ -1958,7 +1964,7 @@ __global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a
       float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 4
       for (int p = 0; p < nk; ++p) {
-        const float v = Vs[p][c];
+        const float v = Elem<T>::load(&Vs[p][c]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = fmaf(Ps[qh + 2 * j][p], v, acc[j]);
       }
@@ -1985,7 +1991,7 @@ __global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const int tt = t + j - pad;
-          if (j < a.ktaps && tt >= 0 && tt < a.n_cur) acc = fmaf(wc[j], Vs[len + tt][c], acc);
+          if (j < a.ktaps && tt >= 0 && tt < a.n_cur) acc = fmaf(wc[j], Elem<T>::load(&Vs[len + tt][c]), acc);
         }
       }
       a.mem[(size_t)(row0 + t) * a.d + hc] = acc;
@@ -1999,8 +2005,8 @@ __global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a
       for (int e = tid; e < new_len * SA_HD; e += 256) {
         const int p = e >> 7, c = e & 127, src = p + drop;
         if (src >= len || drop > 0) {                    // rows that move or are new (values round-trip exactly: they came from T)
-          Elem<T>::store(wk + (size_t)p * SA_HD + c, Ks[src][c]);
-          Elem<T>::store(wv + (size_t)p * SA_HD + c, Vs[src][c]);
+          wk[(size_t)p * SA_HD + c] = Ks[src][c];
+          wv[(size_t)p * SA_HD + c] = Vs[src][c];
         }
       }
     }
@@ -2139,7 +2145,14 @@ void launch_stream_carry(const float* x, int ld, const UttPlan* plan, int n_acti
 template <typename T>
 void launch_stream_attn(const StreamAttnArgs& a, int n_active, hipStream_t s) {
   ASR_REQUIRE(a.cap + a.n_cur <= SA_MAXK, "stream_attn: %d + %d keys exceed %d", a.cap, a.n_cur, SA_MAXK);
-  hipLaunchKernelGGL(stream_attn_kernel<T>, dim3(n_active, a.n_heads), dim3(256), 0, s, a);
+  // f32 sessions: 78 KB of static LDS per workgroup; with 80 KB of (unused) dynamic LDS on top nothing else shares the CU's LDS with it (see the kernel)
+  size_t pad = 0;
+  if (sizeof(T) == 4) {
+    pad = 80 * 1024;
+    static PerDeviceOnce once;
+    if (once.first()) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_attn_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+  }
+  hipLaunchKernelGGL(stream_attn_kernel<T>, dim3(n_active, a.n_heads), dim3(256), pad, s, a);
   HIP_CHECK(hipGetLastError());
 }
 template void launch_stream_attn<float>(const StreamAttnArgs&, int, hipStream_t);

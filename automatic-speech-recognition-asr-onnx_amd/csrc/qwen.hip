@@ -673,6 +673,7 @@ struct QwSession : asr_session {
   // weight-streaming GEMM of the decode step (<= 64 rows; gemm.hip: gemm_bf16_skinny<.., W8>); their exact bf16 dequantisation serves every other path (prefill, beam
   // search above 64 rows), so all steps of a session see the same effective weights. ASR_FP8_FAKE=1: same quantisation, bf16 kernels throughout (the tests' exact twin).
   bool fp8 = false, fp8_fake = false;
+  bool use_decode_gemm = true;         // ASR_QWEN_DECODE_GEMM=0: o_proj / down_proj of a decode step through the tiled split-K pass + reduce launch (rounds 1-4) instead of csrc/decode_gemm.hip
   std::vector<QwDec8Layer> dec8;
   DeviceBuffer d_w8, d_wscale, d_wdq;
   // ---- paged KV cache (the default; ASR_QWEN_KV_PAGED=0 and the persistent decode kernel keep extents). Pool [page][layer][kv head][16][128] for K and for V,
@@ -951,6 +952,19 @@ void QwSession::decoder_pass(const DecPass& P) {
   const bool norm_in_reduce = bf && !rms_in_gemm && !no_fuse && d == 1024;
   const bool w8 = fp8 && !fp8_fake && rms_in_gemm;           // byte weights: the weight-streaming launches of a decode step
   auto bytes_of = [&](GemmArgs& g, int layer, int wi) { if (w8) { g.W8 = dec8[layer].w[wi]; g.ldw8 = g.K; g.w_scale = dec8[layer].s[wi]; } };
+  // o_proj / down_proj of a decode step (<= 64 rows, + residual, f32 and bf16 copies of the stream): the decode GEMM of csrc/decode_gemm.hip -- K split across workgroups
+  // with the hand-over inside the launch -- instead of the tiled split-K pass and its reduce launch (6.3 + 4.8 us per projection at 64 rows)
+  const bool dgm = rms_in_gemm && use_decode_gemm;
+  auto dg = [&](const T* A, int lda, const void* Wt, int layer, int wi, int N, int K, const float* add, float* of32, T* olo) {
+    ProfScope ps(prof, "dec_gemm", stream);
+    if (!d_skws.ptr) { d_skws.reserve((size_t)16 << 20, stream); d_skcnt.reserve(4096 * 4, stream); }
+    DecGemmArgs a;
+    a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)Wt; a.ldw = K; a.M = rows; a.N = N; a.K = K;
+    if (w8) { a.W = nullptr; a.W8 = dec8[layer].w[wi]; a.w_scale = dec8[layer].s[wi]; }
+    a.add = add; a.ld_add = d; a.out_f32 = of32; a.ld_out_f32 = d; a.out_lo = (bf16_t*)olo; a.ld_out_lo = d;
+    a.ws = d_skws.as<float>(); a.ws_bytes = d_skws.cap; a.cnt = d_skcnt.as<int32_t>();
+    launch_decode_gemm(a, stream);
+  };
   auto can_norm = [&](const GemmArgs& g0) {           // (the session's gemm() adds the split-K workspace: ask with it in place)
     if (!d_skws.ptr) { d_skws.reserve((size_t)16 << 20, stream); d_skcnt.reserve(4096 * 4, stream); }
     GemmArgs g = g0;
@@ -1015,6 +1029,8 @@ void QwSession::decoder_pass(const DecPass& P) {
         hipLaunchKernelGGL(qw_attn_kernel<T>, dim3(B, H), dim3(128), (size_t)S * 4, stream, q, H, KV, kc, vc, ka, P.plan, hist, ctx);
       }
     }
+    if constexpr (sizeof(T) == 2) { if (dgm) dg(ctx, H * hd, L.wo, i, 1, d, H * hd, x, x2, x2lo); }
+    if (!(sizeof(T) == 2 && dgm))
     { ProfScope ps(prof, "dec_gemm", stream);
       GemmArgs g; g.A = ctx; g.lda = H * hd; g.W = L.wo; g.ldw = H * hd; g.M = rows; g.N = d; g.K = H * hd; g.add = x; g.ld_add = d;
       g.out_f32 = x2; g.ld_out_f32 = d;
@@ -1024,6 +1040,8 @@ void QwSession::decoder_pass(const DecPass& P) {
       gemm(g); }
     // gate|up rows are interleaved in the arena: the epilogue stores silu(gate) * up directly (:1322-1325)
     { GemmArgs g; g.W = L.gate_up; g.ldw = d; g.M = rows; g.N = 2 * I; g.K = d; g.act = ACT_SWIGLU; g.out_lo = act; g.ld_out_lo = I; bytes_of(g, i, 2); normed_gemm(x2, x2lo, g); }
+    if constexpr (sizeof(T) == 2) { if (dgm) dg(act, I, L.down, i, 3, d, I, x2, x, xlo); }
+    if (!(sizeof(T) == 2 && dgm))
     { ProfScope ps(prof, "dec_gemm", stream);
       GemmArgs g2; g2.A = act; g2.lda = I; g2.W = L.down; g2.ldw = I; g2.M = rows; g2.N = d; g2.K = I; g2.add = x2; g2.ld_add = d;
       g2.out_f32 = x; g2.ld_out_f32 = d;
@@ -1637,6 +1655,7 @@ extern "C" int asr_qwen_create(const asr_qwen_config* cfg, const void* arena, si
       s->own_stream = true;
       gemm_reload_env();
       if (const char* e = getenv("ASR_FP8_FAKE")) s->fp8_fake = e[0] == '1';
+      if (const char* e = getenv("ASR_QWEN_DECODE_GEMM")) s->use_decode_gemm = !(e[0] == '0');
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       if (const char* e = getenv("ASR_QWEN_NO_FUSE")) s->no_fuse = e[0] == '1';
       if (const char* e = getenv("ASR_QWEN_MEGA")) s->use_mega = e[0] == '1' && !s->fp8;          // (the persistent decode kernel streams bf16 weights only)

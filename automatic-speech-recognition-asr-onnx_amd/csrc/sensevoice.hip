@@ -1272,7 +1272,19 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
       // and computes the FSMN memory term of the chunk rows
       sa.roll_rows = st_B;
       sa.fsmn_w = b.wfsmn; sa.fsmn_b = b.bfsmn; sa.ktaps = c.fsmn_kernel; sa.mem = mem; sa.d = d;
+      if (taps_enabled && i == 0) {                        // (bisect taps, tools/probes/stream_determinism.py: the layer's history as the attention launch finds it)
+        save_tap("s0_ck", ck, (int64_t)st_max * H * st_en_cap, 128, 128, sizeof(T));
+        save_tap("s0_cv", cv, (int64_t)st_max * H * st_en_cap, 128, 128, sizeof(T));
+        save_tap("s0_len", st_enlen.ptr, st_max, 1, 1, 4);
+      }
       launch_stream_attn<T>(sa, n, stream);
+    }
+    if (taps_enabled && (i == 0 || i == 3)) {
+      const std::string pre = "s" + std::to_string(i) + "_";
+      save_tap((pre + "h").c_str(), h, rows, b.kpad, b.kpad, sizeof(T));
+      save_tap((pre + "qkv").c_str(), qkv, rows, 3 * d, 3 * d, sizeof(T));
+      save_tap((pre + "ctx").c_str(), ctx, rows, d, d, sizeof(T));
+      save_tap((pre + "mem").c_str(), mem, rows, d, d, 4);
     }
     {
       ProfScope ps(prof, "gemm_out", stream);
@@ -1294,6 +1306,12 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
       GemmArgs g;
       g.A = ffn; g.lda = dff; g.W = b.w2; g.ldw = dff; g.M = rows; g.N = d; g.K = dff; g.bias = b.b2; g.add = xb; g.ld_add = d; g.out_f32 = xa; g.ld_out_f32 = d;
       gemm(g);
+    }
+    if (taps_enabled && (i == 0 || i == 3)) {
+      const std::string pre = "s" + std::to_string(i) + "_";
+      save_tap((pre + "xb").c_str(), xb, rows, d, d, 4);
+      save_tap((pre + "ffn").c_str(), ffn, rows, dff, dff, sizeof(T));
+      save_tap((pre + "xa").c_str(), xa, rows, d, d, 4);
     }
     x_in = xa;
     ld_in = d;

@@ -15,10 +15,12 @@
 //     per wave instruction, in consumption order), 12-16 KB per wave in flight, and the first batch of the NEXT phase is requested before the
 //     workgroup waits for its cluster -- the exchange latency hides the weight latency and the other way round;
 //   * rounding points are those of the per-launch path (bf16 operand of every GEMM, bf16 q|k|v and ctx, f32 residual stream, f32 soft-max
-//     and FSMN in LDS), so the fixtures of that path hold for this one.
+//     and FSMN in LDS) with ONE addition: the soft-max weights enter P V as bf16 MFMA operands here, where stream_attn_kernel multiplies them in f32. The
+//     fixtures of the per-launch path hold for this one within the bars of tests/test_paraformer_streaming_gpu.py::test_fused_launches_vs_per_launch_path.
 //
-// Give-up: a cluster that waits 0.2 s on a counter raises `err` and the launch runs out (results void); the host reports it as an error of the
-// step -- histories may be half-rolled, the streams of the step must be reset (never seen: clusters are dispatched in order, per XCD).
+// Give-up: a cluster that waits 0.2 s on a counter raises `err` and the launch runs out (results void, histories half-rolled). Round 5: when other sessions exist on the
+// GPU the host snapshots the active streams' state in front of the step, restores it and redoes the step on the per-launch path (SvSession::stream_step); without a
+// snapshot the step fails and its streams must be reset.
 #include <type_traits>
 #include "stream_cluster.h"
 

@@ -1882,12 +1882,23 @@ __global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a
   // workgroups -- and next to ANOTHER session's kernels its results moved by a percent on some query rows, silently and only then (tools/probes/stream_determinism.py,
   // profiles/r05_stream_determinism.txt: identical q|k|v, history and lengths in, different context out; gone when the workgroup owns the CU's LDS, not gone with the LDS
   // cleared, an acquire at kernel start or one workgroup of this kernel per CU). bf16 sessions now use 46 KB; the f32 instance is launched with the CU's LDS to itself.
-  // Row pitch: an odd number of dwords, so that 64 keys at one column are 64 banks.
-  constexpr int SA_KP = SA_HD + (sizeof(T) == 2 ? 2 : 1);
-  __shared__ T Ks[SA_MAXK][SA_KP];
-  __shared__ T Vs[SA_MAXK][SA_KP];
-  __shared__ float Qs[SA_MAXQ][SA_HD + 1];
-  __shared__ float Ps[SA_MAXQ][SA_MAXK + 1];
+  // LDS reads come FOUR values at a time (round 5: at 256 streams this launch was 31 % of the per-launch chunk step -- 37.6 us for 1 024 workgroups, five scalar LDS
+  // reads per four FMAs in the score phase, nine per eight in the context phase): a key row's four dims are one 8- / 16-byte read, a query row's and a score row's four values
+  // one 16-byte broadcast read. Every FMA chain still runs in the original order, so the results are unchanged bit for bit. Row pitches: K / V 4 elements over 128 (rows stay
+  // 8- / 16-byte aligned; 64 keys at one column pair hit every bank once per half / quarter wave), Q and P rows 16-byte aligned.
+  constexpr int SA_KP = SA_HD + 4, SA_QP = SA_HD + 4, SA_PP = SA_MAXK + 4;
+  __shared__ __attribute__((aligned(16))) T Ks[SA_MAXK][SA_KP];
+  __shared__ __attribute__((aligned(16))) T Vs[SA_MAXK][SA_KP];
+  __shared__ __attribute__((aligned(16))) float Qs[SA_MAXQ][SA_QP];
+  __shared__ __attribute__((aligned(16))) float Ps[SA_MAXQ][SA_PP];
+  auto lds4 = [](const T* p) -> float4 {                    // four consecutive elements of a K / V row
+    if constexpr (sizeof(T) == 2) {
+      const uint2 w = *reinterpret_cast<const uint2*>(p);
+      return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u));
+    } else {
+      return *reinterpret_cast<const float4*>(p);
+    }
+  };
   const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const UttPlan qp = a.q_plan[i];
   const int nq_all = qp.T, sid = qp.lang, row0 = qp.row_off;
@@ -1918,11 +1929,13 @@ __global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a
     for (int it = 0; it < NIT; ++it) {
       const int idx = tid + it * 256, p = idx >> 4, c0 = (idx & 15) * 8;
       if (p < nk) {
-        float k8[8], v8[8];
-        rk[it].get(k8);
-        rv[it].get(v8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { Elem<T>::store(&Ks[p][c0 + e], k8[e]); Elem<T>::store(&Vs[p][c0 + e], v8[e]); }      // (exact: the values came from T)
+        if constexpr (sizeof(T) == 2) {                   // the 16 bytes as they came, in two 8-byte stores (rows are 8-byte aligned)
+          *reinterpret_cast<uint2*>(&Ks[p][c0]) = make_uint2(rk[it].v.x, rk[it].v.y); *reinterpret_cast<uint2*>(&Ks[p][c0 + 4]) = make_uint2(rk[it].v.z, rk[it].v.w);
+          *reinterpret_cast<uint2*>(&Vs[p][c0]) = make_uint2(rv[it].v.x, rv[it].v.y); *reinterpret_cast<uint2*>(&Vs[p][c0 + 4]) = make_uint2(rv[it].v.z, rv[it].v.w);
+        } else {
+          *reinterpret_cast<float4*>(&Ks[p][c0]) = rk[it].a; *reinterpret_cast<float4*>(&Ks[p][c0 + 4]) = rk[it].b;
+          *reinterpret_cast<float4*>(&Vs[p][c0]) = rv[it].a; *reinterpret_cast<float4*>(&Vs[p][c0 + 4]) = rv[it].b;
+        }
       }
     }
   }
@@ -1939,11 +1952,14 @@ __global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a
       const int k = tid & 63, qg = tid >> 6;
       if (k < nk) {
         float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 8
-        for (int c = 0; c < SA_HD; ++c) {
-          const float kv = Elem<T>::load(&Ks[k][c]);
+#pragma unroll 4
+        for (int c = 0; c < SA_HD; c += 4) {
+          const float4 kv = lds4(&Ks[k][c]);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) s4[j] = fmaf(Qs[qg + 4 * j][c], kv, s4[j]);
+          for (int j = 0; j < 4; ++j) {
+            const float4 q4 = *reinterpret_cast<const float4*>(&Qs[qg + 4 * j][c]);
+            s4[j] = fmaf(q4.x, kv.x, s4[j]); s4[j] = fmaf(q4.y, kv.y, s4[j]); s4[j] = fmaf(q4.z, kv.z, s4[j]); s4[j] = fmaf(q4.w, kv.w, s4[j]);
+          }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -1962,8 +1978,16 @@ __global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a
     {   // context: thread = (channel, query parity); one V read serves eight queries
       const int c = tid & 127, qh = tid >> 7;
       float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
-      for (int p = 0; p < nk; ++p) {
+      int p = 0;
+      for (; p + 4 <= nk; p += 4) {                        // four keys per trip: four V reads, one 16-byte (broadcast) read of each score row
+        const float v0 = Elem<T>::load(&Vs[p][c]), v1 = Elem<T>::load(&Vs[p + 1][c]), v2 = Elem<T>::load(&Vs[p + 2][c]), v3 = Elem<T>::load(&Vs[p + 3][c]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float4 p4 = *reinterpret_cast<const float4*>(&Ps[qh + 2 * j][p]);
+          acc[j] = fmaf(p4.x, v0, acc[j]); acc[j] = fmaf(p4.y, v1, acc[j]); acc[j] = fmaf(p4.z, v2, acc[j]); acc[j] = fmaf(p4.w, v3, acc[j]);
+        }
+      }
+      for (; p < nk; ++p) {
         const float v = Elem<T>::load(&Vs[p][c]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = fmaf(Ps[qh + 2 * j][p], v, acc[j]);

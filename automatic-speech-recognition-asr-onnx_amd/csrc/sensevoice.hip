@@ -1169,6 +1169,10 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
   grow(d_sa, (size_t)Mpad * d * 4);
   grow(d_ffn32, (size_t)Mpad * dd * 4);
   grow(d_tplan, sizeof(UttPlan) * n);
+  if (precision == ASR_PRECISION_BF16) {                // LayerNorm inside the per-launch layers' projections (see the layer loop): bf16 copies of the residual stream + their row statistics
+    grow(d_xblo, (size_t)Mpad * d * 2);
+    grow(d_stb, (size_t)Mpad * (d / 32) * 8);
+  }
   const size_t out_bytes = (size_t)n * max_tokens * 4 + (size_t)n * 4;
   if (out_bytes + 16 > h_out_cap) {
     if (h_out) HIP_CHECK(hipHostFree(h_out));
@@ -1233,6 +1237,21 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
   T* ffn = d_ffn.as<T>();
   const size_t en_layer = (size_t)st_max * H * st_en_cap * 128;
   const bool fused = step_fused;
+  // Round 5: the per-launch layers evaluate their SECOND LayerNorm inside FFN-1, as the offline four-launch path does (rstd (x W^T - mean colsum(W)) + b over the bf16 copy of
+  // the out-projection's result, row statistics handed over by that GEMM's epilogue) -- at 256 streams the ~100 stand-alone LayerNorm launches of a chunk step were 10 % of it at
+  // their 5.4 us launch floor; this removes half of them. The first LayerNorm stays a launch: the LayerNorm-folded GEMM has no instance for the q|k|v epilogue (the offline path
+  // folds it inside sanm_qkv_attn_kernel). ASR_LN_FUSED=0 restores the launches.
+  bool st_alg = false;
+  bf16_t* xblo = nullptr;
+  float2* stb = nullptr;
+  if constexpr (sizeof(T) == 2) {
+    const SvBlock& bl = blocks[c.n_blocks - 1];
+    GemmArgs probe;
+    probe.M = rows; probe.N = dff; probe.K = d; probe.ln_dim = d; probe.ln_colsum = bl.c1; probe.act = ACT_RELU; probe.bias = bl.b1;
+    probe.out_lo = d_ffn.ptr; probe.A = d_xblo.ptr; probe.W = bl.w1;
+    st_alg = use_ln_alg && bl.c1 && d_xblo.ptr && gemm_ln_fusable(probe);
+    xblo = d_xblo.as<bf16_t>(); stb = d_stb.as<float2>();
+  }
   for (int i = 0; i < c.n_blocks; ++i) {
     const SvBlock& b = blocks[i];
     if (fused && i == 1) {               // layers 1 .. n - 1: one launch, the stream's rows stay in xa
@@ -1292,13 +1311,15 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
       g.A = ctx; g.lda = d; g.W = b.wout; g.ldw = d; g.M = rows; g.N = d; g.K = d; g.add = mem; g.ld_add = d;
       if (i > 0) { g.add2 = x_in; g.ld_add2 = ld_in; }             // residual from the second layer on (:402-403,431-432)
       g.out_f32 = xb; g.ld_out_f32 = d;
+      if (st_alg) { g.out_lo = xblo; g.ld_out_lo = d; g.st_out = stb; }
       gemm(g);
     }
-    { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(xb, d, rows, d, b.ln2_g, b.ln2_b, 1e-5f, h, d, d, stream); }
+    if (!st_alg) { ProfScope ps(prof, "layernorm", stream); launch_layernorm<T>(xb, d, rows, d, b.ln2_g, b.ln2_b, 1e-5f, h, d, d, stream); }
     {
       ProfScope ps(prof, "gemm_ffn1", stream);
       GemmArgs g;
       g.A = h; g.lda = d; g.W = b.w1; g.ldw = d; g.M = rows; g.N = dff; g.K = d; g.bias = b.b1; g.act = ACT_RELU; g.out_lo = ffn; g.ld_out_lo = dff;
+      if (st_alg) { g.A = xblo; g.ln_colsum = b.c1; g.ln_dim = d; g.ln_stats_in = stb; g.ln_slots = d / 32; }
       gemm(g);
     }
     {
@@ -1430,7 +1451,7 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
                           (const void*)d_ffn.ptr, (const void*)d_amax_v.ptr, (const void*)d_amax_i.ptr, (const void*)d_ids.ptr, (const void*)d_tok.ptr, (const void*)d_num.ptr,
                           (const void*)d_logits.ptr, (const void*)d_enc_lo.ptr, (const void*)d_cifa.ptr, (const void*)d_alpha.ptr, (const void*)d_dec.ptr, (const void*)d_x2.ptr,
                           (const void*)d_sa.ptr, (const void*)d_ffn32.ptr, (const void*)d_tplan.ptr, (const void*)stream, (const void*)(uintptr_t)n,
-                          (const void*)(uintptr_t)max_tokens, (const void*)st_shadow.ptr})
+                          (const void*)(uintptr_t)max_tokens, (const void*)st_shadow.ptr, (const void*)d_xblo.ptr, (const void*)d_stb.ptr})
       key = (key ^ (uint64_t)(uintptr_t)q) * 1099511628211ull;
     const int gi = step_fused ? (snapshot ? 2 : 1) : 0;            // one cached graph per path: a session that alternates (a co-tenant comes and goes) does not re-capture
     hipGraphExec_t& st_graph = this->st_graph[gi];

@@ -835,7 +835,10 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
         if constexpr (W8) wv = sk_fp8x8_to_bf16x8(wf[u]); else wv = wf[u];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(ap + (size_t)i * 16 * lda + k + u * 32);
+          // rows past M are never stored: their lanes request nothing from memory (at one row the 16-row tile pulled 16 x the bytes through this CU's 64 B / clk path;
+          // csrc/decode_gemm.hip, profiles/r05_decode_gemm_clock.txt). The LayerNorm instance reads its rows from LDS, where rows past M are zero already.
+          bf16x8_t af = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (LN || i * 16 + frow < g.M) af = *reinterpret_cast<const bf16x8_t*>(ap + (size_t)i * 16 * lda + k + u * 32);
           acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, af, acc[i], 0, 0, 0);   // D[n = 4 fgrp + r][m = frow]
           if (a_rms) gram[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, af, gram[i], 0, 0, 0);
         }

@@ -1298,7 +1298,7 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
       }
       launch_stream_attn<T>(sa, n, stream);
     }
-    if (taps_enabled && (i == 0 || i == 3)) {
+    if (taps_enabled && (i == 0 || i == 3)) {             // (bisect taps of layers 0 and 3: what tools/probes/stream_determinism.py compares between a solo pass and a pass beside a co-tenant)
       const std::string pre = "s" + std::to_string(i) + "_";
       save_tap((pre + "h").c_str(), h, rows, b.kpad, b.kpad, sizeof(T));
       save_tap((pre + "qkv").c_str(), qkv, rows, 3 * d, 3 * d, sizeof(T));

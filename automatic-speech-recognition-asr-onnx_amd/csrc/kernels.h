@@ -230,14 +230,12 @@ struct SanmBlockArgs {
   int n_rows_alloc; float ln_eps; int scatter;                     // scatter != 0: test placement (a cluster spread over four XCDs)
   unsigned long long* times;                                       // tuning: [workgroups][16] wall-clock stamps (100 MHz) at the phase boundaries, or null
   int fault = 0;                                                   // tests: workgroup 5 withholds its first exchange count (its cluster then gives up after the bounded spin)
-  int ffn22 = 0;                                                   // 8-wave kernel, round 5: the FFN pair as 2 x 2 (row half x hidden half; `hid` then holds the f32 partials) -- needs the matching wpack order
 };
 bool sanm_block_supported(int max_T, int d_head, int n_heads, int d, int d_ffn, int fsmn_taps);
 int sanm_block_max_utts();                                         // windows one launch can take (all workgroups co-resident)
-void launch_sanm_block(const SanmBlockArgs& a, hipStream_t s);        // round-2 form: 12 waves, operands staged through LDS rings (ASR_SANM_BLOCK_V=1)
 void launch_sanm_block8(const SanmBlockArgs& a, hipStream_t s);       // round-4 form: 8 waves, chunked A operand, register-streamed packed weights (needs a.wpack)
 size_t sanm_block8_pack_bytes();                                      // bytes of one block's packed weights
-void launch_sanm_block8_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, bool ffn22, hipStream_t s);
+void launch_sanm_block8_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, hipStream_t s);
 void launch_rows_to_bf16(const float* x, bf16_t* y, size_t n, hipStream_t s);     // f32 -> bf16 (RNE) copy, n a multiple of 8
 void launch_sanm_qkv_attn(const SanmFusedArgs& a, hipStream_t s);
 
@@ -400,24 +398,3 @@ void launch_stream_dec_pack(const bf16_t* w1, const bf16_t* w2, const bf16_t* wq
 bool stream_dec_supported(int d, int d_ffn, int n_heads, int cap, int n_cur, int ktaps);
 void launch_stream_dec(const StreamDecArgs& a, hipStream_t s);
 
-// ---- Qwen3-ASR decode step as one persistent kernel (qwen_mega.hip): token embedding + every decoder layer, phases separated by a
-// chip-wide barrier; bf16 mode, <= 64 sequences. The final norm / lm_head / head kernels follow as ordinary launches.
-struct QwMegaLayer { const bf16_t *wqkv, *wo, *gate_up, *down; const float *qn, *kn; };
-struct QwMegaArgs {
-  int B, n_layers, d, d_ffn, n_heads, n_kv, S_max; float eps;
-  const QwMegaLayer* layers;                 // device array [n_layers]
-  const bf16_t* embed; const int32_t* ids;   // token embedding table, this step's ids [B]
-  const float* rope;                         // [S_max][cos(64) | sin(64)]
-  const int32_t* hist; int32_t* hist_rw;     // positions already in the cache per sequence (advanced by the kernel)
-  float *x, *x2, *qkv;                       // inter-phase activations read once per element: sc1 traffic
-  // broadcast operands (every workgroup reads all of them): ONE buffer PER LAYER, each written exactly once per launch (sc1 store) before
-  // anyone reads it, so consumers may use ordinary cached loads -- no XCD L2 can hold a stale line of an address nobody has read yet
-  bf16_t *xlo, *x2lo, *ctx, *act; size_t xlo_stride, ctx_stride, act_stride;     // element strides between layers
-  bf16_t *kc, *vc; size_t layer_kv;          // KV cache [layer][b][kv head][S_max][128]
-  unsigned int *bar_xcd, *bar_chip, *bar_flag; unsigned int gen_base;     // barrier state (zeroed once) and this launch's first generation - 1
-  int* failed;                               // set to 1 when a workgroup gave up waiting at a barrier
-  unsigned long long* dbg_clock;             // tuning: workgroup 0 stamps wall_clock64() after every barrier (nullable)
-};
-bool qw_decode_mega_supported(const QwMegaArgs& a);
-int qw_decode_mega_barriers(const QwMegaArgs& a);          // generations one launch consumes
-void launch_qw_decode_mega(const QwMegaArgs& a, hipStream_t s);

@@ -701,9 +701,6 @@ struct QwSession : asr_session {
   bool track_history = false;          // GREEDY_SEARCH graphs append every pick to save_id whatever the penalty value is
   bool sampling = false, noise_armed = false; float temperature = 0.8f, top_p = 0.95f, samp_rep_penalty = 1.0f; int top_k = 10; uint64_t samp_seed = 0;
   uint64_t head_epoch = 0;
-  // persistent decode-step kernel (qwen_mega.hip): barrier state, per-layer pointer table, generation counter
-  // opt-in (ASR_QWEN_MEGA=1): measured 2.0 ms / token vs 1.72 for per-phase launches
-  bool use_mega = false, mega_used = false; unsigned int mega_gen = 0; DeviceBuffer d_megabar, d_megalayers, d_megadbg, d_mlo, d_mctx, d_mact;
   DeviceBuffer d_save, d_nsaved, d_noise;
   DeviceBuffer d_bkc, d_bvc, d_bhist, d_bp0, d_bplan, d_bsrc[2], d_btok[2], d_bcum, d_bfin, d_blen, d_bdone, d_btopv, d_btopi, d_bstop, d_bnext;   // beam search state
   hipGraphExec_t dec_graph = nullptr; uint64_t dec_key = 0, dec_eager_key = 0;
@@ -714,7 +711,7 @@ struct QwSession : asr_session {
   ~QwSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_feat, &d_col, &d_c1, &d_c2, &d_c3, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx,
                             &d_ffn, &d_aud_out, &d_dplan, &d_x, &d_x2, &d_dh, &d_qkv, &d_q, &d_dctx, &d_act, &d_last, &d_logits, &d_next,
-                            &d_kc, &d_vc, &d_kvtab, &d_hist, &d_stepplan, &d_skws, &d_skcnt, &d_vt2, &d_krows, &d_xlo, &d_x2lo, &d_save, &d_nsaved, &d_noise, &d_bkc, &d_bvc, &d_bhist, &d_bp0, &d_bplan, &d_bsrc[0], &d_bsrc[1], &d_btok[0], &d_btok[1], &d_bcum, &d_bfin, &d_blen, &d_bdone, &d_btopv, &d_btopi, &d_bstop, &d_bnext, &d_megabar, &d_megalayers, &d_megadbg, &d_mlo, &d_mctx, &d_mact, &d_w8, &d_wscale, &d_wdq})
+                            &d_kc, &d_vc, &d_kvtab, &d_hist, &d_stepplan, &d_skws, &d_skcnt, &d_vt2, &d_krows, &d_xlo, &d_x2lo, &d_save, &d_nsaved, &d_noise, &d_bkc, &d_bvc, &d_bhist, &d_bp0, &d_bplan, &d_bsrc[0], &d_bsrc[1], &d_btok[0], &d_btok[1], &d_bcum, &d_bfin, &d_blen, &d_bdone, &d_btopv, &d_btopi, &d_bstop, &d_bnext, &d_w8, &d_wscale, &d_wdq})
       b->release();
     for (auto& kv : taps) kv.second.buf.release();
     if (dec_graph) (void)hipGraphExecDestroy(dec_graph);
@@ -746,7 +743,6 @@ struct QwSession : asr_session {
                                      const int32_t* post_ids, const int32_t* post_off, int32_t* next_out, float* logits_out, int32_t* ids_len_out);
   template <typename T> void decoder_pass(const DecPass& P);
   template <typename T> void logits_head(const DecPass& P);
-  bool mega_step(int B);
   template <typename T> void step(const int32_t* ids_host, int32_t* next_out, float* logits_out);
   template <typename T> void finish(int B, int32_t* next_out, float* logits_out, bool sync);
   template <typename T> void beam_search(int beam, int max_new, const int32_t* stop_ids, int n_stop, int32_t* tokens_out, int32_t* n_out, float* scores_out);
@@ -954,7 +950,14 @@ void QwSession::decoder_pass(const DecPass& P) {
   auto bytes_of = [&](GemmArgs& g, int layer, int wi) { if (w8) { g.W8 = dec8[layer].w[wi]; g.ldw8 = g.K; g.w_scale = dec8[layer].s[wi]; } };
   // o_proj / down_proj of a decode step (<= 64 rows, + residual, f32 and bf16 copies of the stream): the decode GEMM of csrc/decode_gemm.hip -- K split across workgroups
   // with the hand-over inside the launch -- instead of the tiled split-K pass and its reduce launch (6.3 + 4.8 us per projection at 64 rows)
-  const bool dgm = rms_in_gemm && use_decode_gemm;
+  // (the decode GEMM has its own shape limits -- K % 32, K >= 256, 16-byte rows: a geometry outside them keeps the tiled pass)
+  auto dgm_shape_ok = [&](int K, int lda) {
+    DecGemmArgs a;
+    a.A = (const bf16_t*)ctx; a.lda = lda; a.W = (const bf16_t*)ctx; a.ldw = K; a.M = rows; a.N = d; a.K = K;
+    if (w8) { a.W = nullptr; a.W8 = (const unsigned char*)ctx; a.w_scale = (const float*)ctx; }
+    return decode_gemm_supported(a);
+  };
+  const bool dgm = rms_in_gemm && use_decode_gemm && dgm_shape_ok(H * hd, H * hd) && dgm_shape_ok(I, I);
   auto dg = [&](const T* A, int lda, const void* Wt, int layer, int wi, int N, int K, const float* add, float* of32, T* olo) {
     ProfScope ps(prof, "dec_gemm", stream);
     if (!d_skws.ptr) { d_skws.reserve((size_t)16 << 20, stream); d_skcnt.reserve(4096 * 4, stream); }
@@ -1095,14 +1098,9 @@ void QwSession::finish(int B, int32_t* next_out, float* logits_out, bool sync) {
   const auto& c = cfg;
   if (taps_enabled) save_tap("logits", d_logits.ptr, B, c.vocab, vpad, 4);
   const bool wait = next_out || logits_out || sync || prof.enabled;
-  int32_t* fail_flag = nullptr;
   if (wait) {
     unsigned char* st = (unsigned char*)pinned(h_io, h_io_cap, (size_t)B * 4 + 64 + (logits_out ? (size_t)B * c.vocab * 4 : 0));
     if (next_out) HIP_CHECK(hipMemcpyAsync(st, d_next.ptr, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
-    if (mega_used) {                                     // did a workgroup of the persistent kernel give up at a barrier?
-      fail_flag = (int32_t*)(st + (size_t)B * 4);
-      HIP_CHECK(hipMemcpyAsync(fail_flag, d_megabar.as<unsigned int>() + 17 * 32, 4, hipMemcpyDeviceToHost, stream));
-    }
     if (logits_out)
       HIP_CHECK(hipMemcpy2DAsync(st + (size_t)B * 4 + 64, (size_t)c.vocab * 4, d_logits.ptr, (size_t)vpad * 4, (size_t)c.vocab * 4, B, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -1110,15 +1108,6 @@ void QwSession::finish(int B, int32_t* next_out, float* logits_out, bool sync) {
     if (logits_out) memcpy(logits_out, st + (size_t)B * 4 + 64, (size_t)B * c.vocab * 4);
   }
   if (prof.enabled) prof.collect();
-  if (fail_flag) {
-    mega_used = false;
-    if (*fail_flag) {
-      HIP_CHECK(hipMemset(d_megabar.ptr, 0, 4096));
-      mega_gen = 0;
-      use_mega = false;
-      ASR_THROW(ASR_ERR_HIP, "qwen decode kernel: a workgroup timed out at a chip-wide barrier (grid not co-resident?); later steps use per-phase launches");
-    }
-  }
 }
 
 template <typename T>
@@ -1349,7 +1338,6 @@ void QwSession::prefill(const float* audio, int audio_mem, const int64_t* offs, 
   const int KV = c.n_kv_heads, hd = c.d_head, Hq = c.n_heads, I = c.d_ffn, qkvn = (Hq + 2 * KV) * hd, S = c.max_seq_len;
   batch = B;
   seq_len.assign(ids_len.begin(), ids_len.end());
-  kv_paged = kv_paged && !use_mega;                      // (the persistent decode kernel addresses extents)
   if (kv_paged) kv_begin(B, ids_len, eT);
   else {
     d_kc.reserve((size_t)c.n_layers * B * KV * S * hd * eT, stream);
@@ -1402,61 +1390,6 @@ void QwSession::prefill(const float* audio, int audio_mem, const int64_t* offs, 
   finish<T>(B, next_out, logits_out, true);
 }
 
-// the whole decoder stack of one step as one persistent kernel; false when the geometry / mode is not covered
-bool QwSession::mega_step(int B) {
-  const auto& c = cfg;
-  if (!use_mega || no_fuse || precision != ASR_PRECISION_BF16 || taps_enabled) return false;
-  QwMegaArgs a{};
-  a.B = B; a.n_layers = c.n_layers; a.d = c.d_model; a.d_ffn = c.d_ffn; a.n_heads = c.n_heads; a.n_kv = c.n_kv_heads; a.S_max = c.max_seq_len; a.eps = c.rms_eps;
-  if (!qw_decode_mega_supported(a)) return false;
-  if (!d_megabar.ptr) {
-    d_megabar.reserve(4096, stream);                     // zero-filled: [8][32] XCD counters, [32] chip counter, [8][32] flags, failed
-    std::vector<QwMegaLayer> hl(c.n_layers);
-    for (int i = 0; i < c.n_layers; ++i)
-      hl[i] = {(const bf16_t*)dec[i].wqkv, (const bf16_t*)dec[i].wo, (const bf16_t*)dec[i].gate_up, (const bf16_t*)dec[i].down, dec[i].qn, dec[i].kn};
-    d_megalayers.reserve(sizeof(QwMegaLayer) * c.n_layers, stream);
-    HIP_CHECK(hipMemcpyAsync(d_megalayers.ptr, hl.data(), sizeof(QwMegaLayer) * c.n_layers, hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));             // `hl` is a stack object
-    mega_gen = 0;
-  }
-  if (mega_gen > 0x03000000u) {                          // far from the 2^32 / 32 wrap of the per-XCD counters: start over
-    HIP_CHECK(hipMemsetAsync(d_megabar.ptr, 0, 4096, stream));
-    mega_gen = 0;
-  }
-  unsigned int* bar = d_megabar.as<unsigned int>();
-  a.layers = d_megalayers.as<QwMegaLayer>();
-  a.embed = (const bf16_t*)embed; a.ids = d_next.as<int32_t>(); a.rope = rope; a.hist = d_hist.as<int32_t>(); a.hist_rw = d_hist.as<int32_t>();
-  a.x = d_x.as<float>(); a.x2 = d_x2.as<float>(); a.qkv = d_qkv.as<float>();
-  {                                                      // per-layer write-once operand buffers (rows padded like every GEMM operand)
-    const size_t rows = pad_rows(B), L1 = (size_t)c.n_layers + 1;
-    a.xlo_stride = rows * c.d_model; a.ctx_stride = rows * c.n_heads * c.d_head; a.act_stride = rows * c.d_ffn;
-    d_mlo.reserve(2 * L1 * a.xlo_stride * 2, stream);
-    d_mctx.reserve(L1 * a.ctx_stride * 2, stream);
-    d_mact.reserve(L1 * a.act_stride * 2, stream);
-    a.xlo = d_mlo.as<bf16_t>(); a.x2lo = a.xlo + L1 * a.xlo_stride; a.ctx = d_mctx.as<bf16_t>(); a.act = d_mact.as<bf16_t>();
-  }
-  a.kc = d_kc.as<bf16_t>(); a.vc = d_vc.as<bf16_t>(); a.layer_kv = (size_t)B * c.n_kv_heads * c.max_seq_len * c.d_head;
-  a.bar_xcd = bar; a.bar_chip = bar + 8 * 32; a.bar_flag = bar + 9 * 32; a.failed = (int*)(bar + 17 * 32);
-  a.gen_base = mega_gen;
-  static const bool dbg = getenv("ASR_QWEN_MEGA_DBG") != nullptr;
-  if (dbg) { d_megadbg.reserve(8 * 1024, stream); a.dbg_clock = d_megadbg.as<unsigned long long>(); }
-  { ProfScope ps(prof, "dec_mega", stream); launch_qw_decode_mega(a, stream); }
-  if (dbg) {                                             // phase times of layers 0..1 (100 MHz wall clock)
-    std::vector<unsigned long long> h(1024);
-    HIP_CHECK(hipStreamSynchronize(stream));
-    HIP_CHECK(hipMemcpy(h.data(), d_megadbg.ptr, 8 * 1024, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[qwen mega] embed %.1f us;", (h[1] - h[0]) * 0.01);
-    for (int l = 0; l < 2 && l < c.n_layers; ++l)
-      fprintf(stderr, " L%d: qkv %.1f attn %.1f wo %.1f gate_up %.1f down %.1f;", l, (h[2 + 5 * l] - h[1 + 5 * l]) * 0.01, (h[3 + 5 * l] - h[2 + 5 * l]) * 0.01,
-              (h[4 + 5 * l] - h[3 + 5 * l]) * 0.01, (h[5 + 5 * l] - h[4 + 5 * l]) * 0.01, (h[6 + 5 * l] - h[5 + 5 * l]) * 0.01);
-    fprintf(stderr, " total %.1f us; L1 qkv inside workgroup 0: operands+mfma %.1f reduce %.1f stores acked %.1f barrier %.1f\n", (h[5 * c.n_layers] - h[0]) * 0.01,
-            (h[512] - h[516]) * 0.01, (h[513] - h[512]) * 0.01, (h[514] - h[513]) * 0.01, (h[7] - h[514]) * 0.01);
-  }
-  mega_gen += (unsigned int)qw_decode_mega_barriers(a);
-  mega_used = true;
-  return true;
-}
-
 template <typename T>
 void QwSession::step(const int32_t* ids_host, int32_t* next_out, float* logits_out) {
   const auto& c = cfg;
@@ -1492,14 +1425,6 @@ void QwSession::step(const int32_t* ids_host, int32_t* next_out, float* logits_o
                          INT32_MIN, d_x.as<float>(), precision == ASR_PRECISION_BF16 ? d_xlo.as<T>() : (T*)nullptr); }
     decoder_pass<T>(P);
   };
-  if (mega_step(B)) {                                    // embedding + all layers in one persistent kernel, then the head
-    P.hist_done = true;
-    logits_head<T>(P);
-    noise_armed = false;
-    for (int b = 0; b < B; ++b) seq_len[b] = std::min(seq_len[b] + 1, c.max_seq_len);
-    finish<T>(B, next_out, logits_out, ids_host != nullptr);
-    return;
-  }
   // every step reads its position from the device-side history counters => one captured graph replays for all of them
   const bool graphable = use_graph && !taps_enabled && !prof.enabled && !noise_armed;
   uint64_t key = 1469598103934665603ull;
@@ -1658,7 +1583,6 @@ extern "C" int asr_qwen_create(const asr_qwen_config* cfg, const void* arena, si
       if (const char* e = getenv("ASR_QWEN_DECODE_GEMM")) s->use_decode_gemm = !(e[0] == '0');
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
       if (const char* e = getenv("ASR_QWEN_NO_FUSE")) s->no_fuse = e[0] == '1';
-      if (const char* e = getenv("ASR_QWEN_MEGA")) s->use_mega = e[0] == '1' && !s->fp8;          // (the persistent decode kernel streams bf16 weights only)
       if (const char* e = getenv("ASR_QWEN_KV_PAGED")) s->kv_paged = !(e[0] == '0');
       if (const char* e = getenv("ASR_KV_PAGE_SHUFFLE")) s->kv_shuffle = e[0] == '1';
       s->arena.load(arena, arena_bytes, arena_mem, s->stream);

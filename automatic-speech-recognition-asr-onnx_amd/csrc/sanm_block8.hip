@@ -24,7 +24,7 @@
 //   C  FFN-1 slab: relu(LN(x1) W1[512 h ..]^T + b1) -> hid[:, 512 h ..] (bf16)                                              -- exchange 2 -->
 //   D  FFN-2 slab (wave = K-half x 32 columns) + b2 + x1 -> x (f32), bf16 copy + row statistics of the next block
 //
-// Exchange protocol, give-up bound, placement and launch limits are those of round 2 (csrc/sanm_block.hip, which stays as `ASR_SANM_BLOCK_V=1`).
+// Exchange protocol, give-up bound, placement and launch limits are those of round 2 (the 12-wave kernel of rounds 2-3 was deleted in round 6; DESIGN.md history table).
 #include <algorithm>
 #include <type_traits>
 #include <utility>
@@ -389,177 +389,6 @@ __device__ __forceinline__ void row_stats_publish(unsigned char* smem, float2* r
   }
 }
 
-// ================================================================ round 5: the FFN pair as 2 x 2 (row half x hidden half)
-// Rounds 2-4 gave workgroup h all 144 rows of hidden slab h: `hid` (590 KB per window) crossed the fabric -- 147 KB out and 442 KB in per workgroup and block, read
-// at the memory-side rate by three siblings each (188 of the 242 MB a block fetched) -- and phase D ran at the fabric's limit chip-wide.
-// Here workgroup h = (r, c) = (h >> 1, h & 1) takes ROW HALF r (fragments 0..4 = 80 rows / 5..8 = 64 rows) and HIDDEN HALF c (1024 columns), in four quarter
-// passes of 256 hidden columns:  hid_q = relu(LN(x1[rows r]) W1[q]^T + b1[q])  stays in LDS (40 KB), and  acc2 += hid_q W2[:, q]^T  accumulates the workgroup's
-// [rows r][512] partial of FFN-2 in registers over all four passes. What crosses the fabric instead of hid:
-//   in   x1 rows r of the three foreign column chunks (60 KB, a subset of what phase C pulled) and the f32 partials of the workgroup's own 128 output columns
-//        (80 rows from the sibling of its row half + 2 x 64 rows of the other half: 106 KB);
-//   out  its partial's three foreign 128-column pieces (f32, 120 KB, write-through).
-// 386 KB inbound per workgroup and block instead of 772, and the weights of the pair are streamed twice as often (2 MB per workgroup: both row halves read the
-// same W1 / W2 half -- L2 hits behind the first reader). Ownership of the block output (all rows x 128 columns of head h), phases A / B and exchanges 0, 1, 3 are
-// unchanged; exchange 2 carries the partials. The K order of both GEMMs differs from rounds 2-4 (natural chunk order, quarters), so results equal the
-// four-launch path within bf16 accumulation noise, not bit for bit.
-constexpr int RH0 = 5;                               // row fragments of row half 0 (half 1: RF - RH0 = 4)
-constexpr int SUB = RH0 * 16 * 256;                  // a sub-chunk: 80 rows x 256 B = 20480
-constexpr int X1F = CH;                              // the three foreign x1 chunks' rows of this half, sub-chunk s at X1F + s * SUB (the own chunk sits in slot 0, absolute rows)
-constexpr int HBUF = X1F + 3 * SUB;                  // hid quarter [80 rows][256 columns] bf16 = two sub-chunks (chunk-image format)
-constexpr int B1C1 = HBUF + 2 * SUB;                 // b1 | c1 of the workgroup's 1024 hidden columns, f32
-constexpr int OWNP = X1F;                            // after the passes: the own 128-column piece of the partial, f32 [80][128], 32-byte granules XOR-swizzled by the row
-static_assert(B1C1 + 2 * 1024 * 4 == ST_F && OWNP + RH0 * 16 * HD * 4 <= HBUF, "LDS map of the 2 x 2 FFN");
-// packed weights of the pair: [c][wave][quarter][32 units][2 fragments][64 lanes][16 B]; units 0..15 of a quarter = the 16 K-steps of FFN-1 (hidden columns
-// 1024 c + 256 q + 32 wave ..), units 16..31 = the 8 K-steps of FFN-2 over those 256 hidden columns x two fragment pairs (output columns 64 wave ..)
-constexpr size_t PK_FFN = PK_W1, PK_FFN_Q = 32 * 2048, PK_FFN_WAVE = 4 * PK_FFN_Q;
-static_assert(PK_FFN + 2 * NW * PK_FFN_WAVE == PK_BYTES, "the 2 x 2 order holds W1 and W2 once");
-constexpr int PWR = 5;                               // W units in flight per wave (16 KB)
-
-__device__ __forceinline__ u32x4_t load16_sc1(const void* p) {
-  u32x4_t w;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w) : "v"(p) : "memory");
-  return w;
-}
-// rows [20 r ..) of one foreign chunk image -> a sub-chunk; three DMA instructions per wave (pieces of four rows)
-__device__ __forceinline__ void issue_half_chunk_img(const unsigned char* img, int piece0, int np, unsigned char* dst, int wave, int lane, bool sc1) {
-  if (np <= 0) return;
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int pl = min(wave + NW * t, np - 1);
-    const unsigned char* src = img + (size_t)(piece0 + pl) * 1024 + lane * 16;
-    if (sc1) GLDS_SC1(src, dst + pl * 1024); else GLDS(src, dst + pl * 1024);
-  }
-}
-
-// one quarter pass. wq = this lane's position in the wave's stream at the quarter's first unit; ring slot of unit U of the stream = U % PWR;
-// unit u + PWR is requested right behind the MFMAs of unit u. LAST: the block's stream ends with this quarter (no requests past it).
-template <int RFL, int JQ>
-__device__ __forceinline__ void ffn22_quarter(unsigned char* smem, const unsigned char* wq, bf16x8_t (&wr)[PWR][2], const unsigned char* (&xk)[4], const int (&lane_off)[4],
-                                              int wave, int r, int frow, int fgrp, f32x4_t (&acc2)[RFL][4]) {
-  f32x4_t acc1[RFL][2];
-#pragma unroll
-  for (int i = 0; i < RFL; ++i) { acc1[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-  // ---- FFN-1: 16 K-steps over the x1 rows (natural chunk order), 32 hidden columns per wave
-  static_for<16>([&](auto kt) __attribute__((always_inline)) {
-    constexpr int ks = decltype(kt)::value, U = JQ * 32 + ks, slot = U % PWR;                 // U = unit of the block's stream (4 x 32)
-    constexpr int younger = 127 - U < PWR - 1 ? 127 - U : PWR - 1;
-    const unsigned char* ap = xk[ks >> 2] + lane_off[ks & 3];
-    bf16x8_t af[RFL];
-#pragma unroll
-    for (int i = 0; i < RFL; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(ap + i * 4096);
-    wait_set<2 * younger>(wr[slot]);
-#pragma unroll
-    for (int i = 0; i < RFL; ++i) {
-      acc1[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[slot][0], af[i], acc1[i][0], 0, 0, 0);
-      acc1[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[slot][1], af[i], acc1[i][1], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (U + PWR < 128) wload_set<2>(wr[slot], wq + (size_t)(ks + PWR) * 2048);
-  });
-  // ---- hid quarter -> LDS (LayerNorm fold + bias + ReLU). The barrier in front: every wave is done reading the previous quarter's image (FFN-2 of pass jq - 1)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  {
-    const float* b1s = reinterpret_cast<const float*>(smem + B1C1) + JQ * 256 + wave * 32 + fgrp * 8;
-    const float4 b0 = *reinterpret_cast<const float4*>(b1s), b1v = *reinterpret_cast<const float4*>(b1s + 4);
-    const float4 c0 = *reinterpret_cast<const float4*>(b1s + 1024), c1v = *reinterpret_cast<const float4*>(b1s + 1024 + 4);
-    const float b8[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
-    const float c8[8] = {c0.x, c0.y, c0.z, c0.w, c1v.x, c1v.y, c1v.z, c1v.w};
-    const float2* st_fin = reinterpret_cast<const float2*>(smem + ST_F) + r * (RH0 * 16);
-    unsigned char* hdst = smem + HBUF + (wave >> 2) * SUB + frow * 256 + ((((wave & 3) * 4 + fgrp) ^ frow) << 4);
-#pragma unroll
-    for (int i = 0; i < RFL; ++i) {
-      const float2 mr = st_fin[i * 16 + frow];
-      float v[8];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { v[q] = acc1[i][0][q]; v[4 + q] = acc1[i][1][q]; }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf((v[e] - mr.x * c8[e]) * mr.y + b8[e], 0.0f);
-      *reinterpret_cast<uint4*>(hdst + i * 4096) = pack8(v);
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  // ---- FFN-2: 8 K-steps over the quarter's 256 hidden columns, 64 output columns per wave in two units of two fragments
-  static_for<8>([&](auto tt) __attribute__((always_inline)) {
-    constexpr int t = decltype(tt)::value;
-    const unsigned char* ap = smem + HBUF + (t >> 2) * SUB + frow * 256 + lane_off[t & 3];
-    bf16x8_t af[RFL];
-#pragma unroll
-    for (int i = 0; i < RFL; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(ap + i * 4096);
-    static_for<2>([&](auto et) __attribute__((always_inline)) {
-      constexpr int e = decltype(et)::value, u = 16 + 2 * t + e, U = JQ * 32 + u, slot = U % PWR;
-      constexpr int younger = 127 - U < PWR - 1 ? 127 - U : PWR - 1;
-      wait_set<2 * younger>(wr[slot]);
-#pragma unroll
-      for (int i = 0; i < RFL; ++i) {
-        acc2[i][2 * e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[slot][0], af[i], acc2[i][2 * e], 0, 0, 0);
-        acc2[i][2 * e + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[slot][1], af[i], acc2[i][2 * e + 1], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (U + PWR < 128) wload_set<2>(wr[slot], wq + (size_t)(u + PWR) * 2048);
-    });
-  });
-}
-
-// the four passes of row half r (RFL fragments) + the hand-over of the partial: the own 128-column piece to LDS (OWNP), the three others to the cluster's
-// partial buffer `pbuf` (the window's rows of the old hid buffer: [dest head][source hidden half][T16 rows][128] f32), write-through
-template <int RFL>
-__device__ __forceinline__ void ffn22_passes(unsigned char* smem, const unsigned char* wp, bf16x8_t (&wr)[PWR][2], int h, int wave, int lane, int n_act, unsigned char* pbuf, bool plain) {
-  const int r = h >> 1, c = h & 1, frow = lane & 15, fgrp = lane >> 4;
-  asm volatile("" : "+v"(wp));            // (the two row halves walk the same stream: without this the 31 request addresses are computed once in front of the branch -- 62 registers held across the passes, spilled)
-  // x1 chunk k (columns 128 k ..): the own one in slot 0 at its absolute rows, the others in the sub-chunks in the order (h + 1 + s) & 3
-  const unsigned char* xk[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) xk[k] = smem + (k == h ? r * SUB : X1F + ((k - h - 1) & 3) * SUB) + frow * 256;
-  int lane_off[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) lane_off[t] = ((t * 4 + fgrp) ^ frow) << 4;
-  f32x4_t acc2[RFL][4];
-#pragma unroll
-  for (int i = 0; i < RFL; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc2[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  // (fully unrolled: the ring registers are filled by asynchronous loads the compiler does not know of -- a loop-carried copy of one of them would read it before
-  //  its data arrived)
-  static_for<4>([&](auto qt) __attribute__((always_inline)) {
-    constexpr int jq = decltype(qt)::value;
-    ffn22_quarter<RFL, jq>(smem, wp + (size_t)jq * PK_FFN_Q, wr, xk, lane_off, wave, r, frow, fgrp, acc2);
-  });
-  // ---- partial out: this wave holds output columns 64 wave .. = head wave / 2, columns 64 (wave & 1) + 32 p + 8 fgrp .. + 7 of it, rows 16 i + frow of the half
-  const int hd = wave >> 1, n_loc = RFL == RH0 ? min(n_act, RH0) : max(n_act - RH0, 0);          // active fragments of this half
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                               // every wave is past FFN-1 of the last pass: the x1 sub-chunks are dead (OWNP lives there)
-  if (hd == h) {
-#pragma unroll
-    for (int i = 0; i < RFL; ++i) {
-      const int row = i * 16 + frow;
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int col = (wave & 1) * 64 + p * 32 + fgrp * 8;
-        unsigned char* d = smem + OWNP + row * 512 + (((col >> 3) ^ frow) << 5);
-        *reinterpret_cast<f32x4_t*>(d) = acc2[i][2 * p];
-        *reinterpret_cast<f32x4_t*>(d + 16) = acc2[i][2 * p + 1];
-      }
-    }
-  } else {
-    unsigned char* piece = pbuf + (size_t)(hd * 2 + c) * n_act * 16 * 512 + (size_t)(r * RH0 * 16) * 512;
-#pragma unroll
-    for (int i = 0; i < RFL; ++i) {
-      if (i < n_loc) {
-        const int row = i * 16 + frow;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          unsigned char* d = piece + (size_t)row * 512 + ((wave & 1) * 64 + p * 32 + fgrp * 8) * 4;
-          const f32x4_t v0 = acc2[i][2 * p], v1 = acc2[i][2 * p + 1];
-          store16_wt(d, make_uint4(__float_as_uint(v0[0]), __float_as_uint(v0[1]), __float_as_uint(v0[2]), __float_as_uint(v0[3])), plain);
-          store16_wt(d + 16, make_uint4(__float_as_uint(v1[0]), __float_as_uint(v1[1]), __float_as_uint(v1[2]), __float_as_uint(v1[3])), plain);
-        }
-      }
-    }
-  }
-}
-
 // Per-phase views: the kernel arguments are re-read from the kernarg segment and the lane id is made opaque at every phase start, so the compiler cannot
 // hoist a later phase's pointers / per-lane offsets above an earlier loop (they would be spilled around it, and a scratch reload next to hand-counted
 // vmcnt waits costs a full drain -- or, worse, falsifies the count)
@@ -579,15 +408,13 @@ __device__ __forceinline__ bool cluster_on_one_xcd(const unsigned* place) {
   const unsigned b = w & 0xffu;
   return b != 0u && w == b * 0x01010101u;
 }
-// "no fence" form of an exchange (write-through stores, sc1 loads, no acquire): only inside one XCD. opt 4: always fence; opt 1024 (round 5): inside one XCD the payload
-// STAYS in the shared L2 -- ordinary stores, ONE agent-scope acquire per consumer (drops its L1), ordinary loads, which then hit the (dirty) L2 lines the three
-// siblings share instead of fetching every chunk three times from the memory side
+// "no fence" form of an exchange (write-through stores, sc1 loads, no acquire): only inside one XCD. opt 4: always fence. (Round 5 also measured the payload
+// left dirty in the shared L2 -- ordinary stores, one acquire per consumer: 101.7 vs 96.1 us per block, profiles/r05_sanm_block_l2_exchange.txt; removed.)
 __device__ __forceinline__ bool cluster_shares_l2(const unsigned* place, int opt) {
-  if (opt & (4 | 1024)) return false;
+  if (opt & 4) return false;
   return cluster_on_one_xcd(place);
 }
 __device__ __forceinline__ bool cluster_plain_stores(const unsigned* place, int opt) {
-  if (opt & 1024) return cluster_on_one_xcd(place);
   return (opt & 256) && cluster_shares_l2(place, opt);
 }
 
@@ -596,7 +423,7 @@ __device__ __forceinline__ bool cluster_plain_stores(const unsigned* place, int 
 #define STAMP(k) do { if (a->times && li == a->times_layer && threadIdx.x == 0 && !((a->opt & 2048) && (k) >= 4 && (k) <= 7)) a->times[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 #define STAMP_A(k) do { if (a->times && li == a->times_layer && threadIdx.x == 0 && (a->opt & 2048)) a->times[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 
-template <int PFA, int PFB, int PFC, int PFD, int ABL, int FFN>
+template <int PFA, int PFB, int PFC, int PFD, int ABL>
 __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_byval) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid_0 = threadIdx.x, wave_0 = __builtin_amdgcn_readfirstlane(tid_0 >> 6);
@@ -955,130 +782,6 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     STAMP(7);
   }
 
-  if constexpr (FFN == 1) {
-  // ================================================================ phases C + D, round-5 form: the FFN pair as 2 x 2 (see ffn22_passes)
-  {
-    a = phase_args();
-    L = a->layers + li;
-    lane = opaque(tid & 63); frow = lane & 15; fgrp = lane >> 4;
-    const int r = h >> 1, c = h & 1;
-    // b1 | c1 of this workgroup's 1024 hidden columns -> registers now, LDS behind the exchange wait (256 threads each)
-    const float4 bc = *reinterpret_cast<const float4*>((tid < 256 ? L->b1 : L->c1) + c * 1024 + (tid & 255) * 4);
-    const unsigned char* wp = reinterpret_cast<const unsigned char*>(L->wpack) + PK_FFN + (size_t)(c * NW + wave) * PK_FFN_WAVE + lane * 16;
-    bf16x8_t wr[PWR][2];
-    w_prefetch<2, PWR>(wr, wp);
-    const bool nofence = cluster_shares_l2(place, a->opt);
-    const bool plain = cluster_plain_stores(place, a->opt);
-    consume(flags + 1, NH, a->err, !nofence);
-    STAMP(8);
-    {
-      const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(a->x1_lo + (size_t)row0 * D);
-      const int np = r == 0 ? min(n_act * 4, RH0 * 4) : max(n_act * 4 - RH0 * 4, 0);
-#pragma unroll
-      for (int sidx = 0; sidx < 3; ++sidx)
-        issue_half_chunk_img(xsrc + (size_t)((h + 1 + sidx) & 3) * n_act * 4096, r * RH0 * 4, np, smem + X1F + sidx * SUB, wave, lane, nofence);
-      row_stats_request(a->st1 + (size_t)row0 * (D / 32), rows_left, smem, wave, lane, nofence);
-      *reinterpret_cast<float4*>(smem + B1C1 + tid * 16) = bc;
-    }
-    wait_vm<0>();
-    __syncthreads();
-    if (tid < R) row_stats_finish(smem, a->ln_eps, tid);
-    __syncthreads();
-    STAMP(9);
-    unsigned char* pbuf = reinterpret_cast<unsigned char*>(a->hid + (size_t)row0 * DFF);
-    if (r == 0) ffn22_passes<RH0>(smem, wp, wr, h, wave, lane, n_act, pbuf, plain);
-    else ffn22_passes<RF - RH0>(smem, wp, wr, h, wave, lane, n_act, pbuf, plain);
-    STAMP(10);
-    publish(flags + 2);
-    STAMP(11);
-  }
-  {
-    a = phase_args();
-    L = a->layers + li;
-    lane = opaque(tid & 63); frow = lane & 15; fgrp = lane >> 4;
-    const int r = h >> 1;
-    const bool nofence = cluster_shares_l2(place, a->opt);
-    // the x1 rows this wave finishes (written by this very lane in phase B): requested in front of the exchange wait
-    float4 x1r[5][2];
-    {
-      const float* xr0 = a->x + (size_t)row0 * D + h * HD + cg * 32 + fgrp * 8;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const int i = kh == 0 ? k : min(5 + k, RF - 1);
-        const float* xr = xr0 + (size_t)min(i * 16 + frow, rows_left - 1) * D;
-        x1r[k][0] = *reinterpret_cast<const float4*>(xr); x1r[k][1] = *reinterpret_cast<const float4*>(xr + 4);
-      }
-    }
-    consume(flags + 2, NH, a->err, !nofence);
-    STAMP(12);
-    // the two partials of every row: source hidden halves 0 and 1 of the row's half kh (this wave's rows all lie in one half); the own one sits in LDS
-    const unsigned char* pbuf = reinterpret_cast<const unsigned char*>(a->hid + (size_t)row0 * DFF);
-    const int n = cg * 32 + fgrp * 8;
-    u32x4_t pa[5][2], pb[5][2];
-    const bool own_half = kh == r;
-    const int c_own = h & 1;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int i = kh == 0 ? k : min(5 + k, RF - 1);
-      const int row = min(i, max(n_act - 1, 0)) * 16 + frow;
-      const unsigned char* q0 = pbuf + (size_t)(h * 2 + 0) * n_act * 16 * 512 + (size_t)row * 512 + n * 4;
-      const unsigned char* q1 = pbuf + (size_t)(h * 2 + 1) * n_act * 16 * 512 + (size_t)row * 512 + n * 4;
-      // (unconditional: the own piece's slot of the buffer is never written, its bytes are replaced from LDS below -- a conditional request would leave the
-      //  registers undefined on one path, and the compiler keeps such values "live" across the whole block loop, in scratch memory)
-      pa[k][0] = load16_sc1(q0); pa[k][1] = load16_sc1(q0 + 16);
-      pb[k][0] = load16_sc1(q1); pb[k][1] = load16_sc1(q1 + 16);
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k)
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[k][0]), "+v"(pa[k][1]), "+v"(pb[k][0]), "+v"(pb[k][1]) :: "memory");
-    if (own_half) {
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const int il = kh == 0 ? k : min(k, RF - RH0 - 1);                 // fragment inside the half
-        const unsigned char* d = smem + OWNP + (il * 16 + frow) * 512 + (((n >> 3) ^ frow) << 5);
-        const u32x4_t v0 = *reinterpret_cast<const u32x4_t*>(d), v1 = *reinterpret_cast<const u32x4_t*>(d + 16);
-        pa[k][0] = c_own == 0 ? v0 : pa[k][0]; pa[k][1] = c_own == 0 ? v1 : pa[k][1];
-        pb[k][0] = c_own == 1 ? v0 : pb[k][0]; pb[k][1] = c_own == 1 ? v1 : pb[k][1];
-      }
-    }
-    __syncthreads();                                          // every wave has read its piece of OWNP: slot 0 may take the block's output chunk
-    STAMP(13);
-    const float4 b0 = *reinterpret_cast<const float4*>(L->b2 + h * HD + n), b1v = *reinterpret_cast<const float4*>(L->b2 + h * HD + n + 4);
-    const float b8[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
-    float* xo = a->x + (size_t)row0 * D + h * HD + n;
-    bf16_t* xl = a->x_lo_out + (size_t)row0 * D + h * HD + n;
-    const bool plain_d = cluster_plain_stores(place, a->opt);
-    unsigned char* ximg = reinterpret_cast<unsigned char*>(a->x_lo_out + (size_t)row0 * D) + (size_t)h * n_act * 4096;
-#pragma unroll
-    for (int i = 0; i < RF; ++i) {
-      if ((kh == 0) == (i < 5) && i < n_act) {
-        const int row = i * 16 + frow, k = i < 5 ? i : i - 5;
-        const float4 r0 = x1r[k][0], r1 = x1r[k][1];
-        const float x1[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-        const uint32_t wa[8] = {pa[k][0][0], pa[k][0][1], pa[k][0][2], pa[k][0][3], pa[k][1][0], pa[k][1][1], pa[k][1][2], pa[k][1][3]};
-        const uint32_t wb[8] = {pb[k][0][0], pb[k][0][1], pb[k][0][2], pb[k][0][3], pb[k][1][0], pb[k][1][1], pb[k][1][2], pb[k][1][3]};
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (__uint_as_float(wa[e]) + __uint_as_float(wb[e])) + (b8[e] + x1[e]);
-        *reinterpret_cast<float4*>(xo + (size_t)row * D) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(xo + (size_t)row * D + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        const uint4 pk = pack8(v);
-        if (last) *reinterpret_cast<uint4*>(xl + (size_t)row * D) = pk;
-        else {
-          const int pos = (((n >> 3)) ^ (row & 15)) << 4;
-          *reinterpret_cast<uint4*>(smem + row * 256 + pos) = pk;
-          store16_wt(ximg + row * 256 + pos, pk, plain_d);
-        }
-        row_stats_group(pk, smem, cg, row, fgrp);
-      }
-    }
-    __syncthreads();
-    row_stats_publish(smem, a->st_out + (size_t)row0 * (D / 32) + h, n_act * 16, !last, plain_d, tid);
-    if (!last) publish(flags + 3);
-    else if (a->times) wait_vm<0>();
-    STAMP(14);
-  }
-  } else {
   // ================================================================ phase C: FFN-1 slab, LayerNorm folded in -> hid slab (exchange 2 + the four own chunks of phase D)
   {
     a = phase_args();
@@ -1210,7 +913,6 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     else if (a->times) wait_vm<0>();
     STAMP(14);
   }
-  }        // FFN == 0: the round-4 form of phases C / D
   }        // blocks of this launch
 }
 
@@ -1218,7 +920,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
 // A swapped-order fragment of 16 columns: lane (fr = lane & 15, g = lane >> 4) holds W[n0 + perm(fr)][k0 + 8 g .. + 7]; perm pairs two fragments so that a
 // lane ends with 8 consecutive output columns (frag_col); the un-swapped V fragment holds W[n0 + fr][...].
 struct PackSrc { const bf16_t* wqkv; const bf16_t* wout; const bf16_t* w1; const bf16_t* w2; };
-__global__ void sanm_block8_pack_kernel(PackSrc src, unsigned char* dst, int ffn22) {
+__global__ void sanm_block8_pack_kernel(PackSrc src, unsigned char* dst) {
   const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // 16-byte slot of the packed copy
   if (slot * 16 >= PK_BYTES) return;
   const size_t byte = slot * 16;
@@ -1237,11 +939,6 @@ __global__ void sanm_block8_pack_kernel(PackSrc src, unsigned char* dst, int ffn
     const int kh = wave >> 2, cg = wave & 3, q = s >> 1, t = s & 1;
     w = src.wout; ld = D; k0 = 128 * ((h + q) & 3) + 32 * (2 * kh + t) + 8 * g;
     row = h * HD + cg * 32 + frag_col(j, fr);
-  } else if (ffn22) {                                   // the FFN pair in the 2 x 2 order: [c][wave][quarter][32 units][2 frags] (see PK_FFN)
-    const size_t e = (byte - PK_FFN) / 1024;
-    const int jj = (int)(e % 2), u = (int)((e / 2) % 32), jq = (int)((e / 64) % 4), wave = (int)((e / 256) % NW), c = (int)(e / (256 * NW));
-    if (u < 16) { w = src.w1; ld = D; k0 = 32 * u + 8 * g; row = c * 1024 + jq * 256 + wave * 32 + frag_col(jj, fr); }
-    else { const int t = (u - 16) >> 1, eh = (u - 16) & 1; w = src.w2; ld = DFF; k0 = c * 1024 + jq * 256 + 32 * t + 8 * g; row = wave * 64 + frag_col(2 * eh + jj, fr); }
   } else if (byte < PK_W2) {                            // [h][wave][16 steps = chunk order (h + q) & 3, K-steps t][4 frags]: hidden columns 512 h + 64 wave ..
     const size_t e = (byte - PK_W1) / 1024;
     const int j = (int)(e % 4), s = (int)((e / 4) % 16), wave = (int)((e / 64) % NW), h = (int)(e / (64 * NW));
@@ -1258,14 +955,45 @@ __global__ void sanm_block8_pack_kernel(PackSrc src, unsigned char* dst, int ffn
   *reinterpret_cast<uint4*>(dst + byte) = *reinterpret_cast<const uint4*>(w + (size_t)row * ld + k0);
 }
 
+__global__ void rows_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    uint4 w;
+    w.x = pack_bf16x2(a.x, a.y); w.y = pack_bf16x2(a.z, a.w); w.z = pack_bf16x2(b.x, b.y); w.w = pack_bf16x2(b.z, b.w);
+    reinterpret_cast<uint4*>(y)[i] = w;
+  }
+}
+
 }  // namespace
+
+void launch_rows_to_bf16(const float* x, bf16_t* y, size_t n, hipStream_t s) {
+  ASR_REQUIRE(n % 8 == 0, "rows_to_bf16: element count must be a multiple of 8");
+  const size_t n8 = n / 8;
+  hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((unsigned)std::min<size_t>((n8 + 255) / 256, 2048)), dim3(256), 0, s, x, y, n8);
+  HIP_CHECK(hipGetLastError());
+}
 
 size_t sanm_block8_pack_bytes() { return PK_BYTES; }
 
-void launch_sanm_block8_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, bool ffn22, hipStream_t s) {
+bool sanm_block_supported(int max_T, int d_head, int n_heads, int d, int d_ffn, int fsmn_taps) {
+  return max_T <= R && d_head == HD && n_heads == NH && d == D && d_ffn == DFF && fsmn_taps == TAPS;
+}
+
+int sanm_block_max_utts() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return (cus / 32) * 8;          // whole groups of 8 windows (one per XCD), four workgroups each, one workgroup per CU
+}
+
+void launch_sanm_block8_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, hipStream_t s) {
   const PackSrc src{wqkv, wout, w1, w2};
   const unsigned n = (unsigned)(PK_BYTES / 16);
-  hipLaunchKernelGGL(sanm_block8_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, reinterpret_cast<unsigned char*>(dst), ffn22 ? 1 : 0);
+  hipLaunchKernelGGL(sanm_block8_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, reinterpret_cast<unsigned char*>(dst));
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1274,15 +1002,14 @@ void launch_sanm_block8(const SanmBlockArgs& a, hipStream_t s) {
   ASR_REQUIRE(a.layers && a.place && a.n_layers >= 1 && (a.n_layers == 1 || a.x_lo == a.x_lo_out) && a.x_lo && a.x && a.ctx && a.x1_lo && a.st1 && a.hid && a.x_lo_out && a.st_out && a.flags && a.err && a.plan, "sanm_block8: null buffer");
   // opt bit 2: deeper W fragment queues; opt bits 4..7: a timing-only ablation of the GEMM loops (chunk_gemm's ABL)
   typedef void (*Kern)(const SanmBlockArgs);
-  static const Kern kerns[] = {sanm_block8_kernel<3, 4, 3, 4, 0, 0>, sanm_block8_kernel<6, 8, 4, 8, 0, 0>, sanm_block8_kernel<3, 4, 3, 4, 1, 0>, sanm_block8_kernel<3, 4, 3, 4, 2, 0>,
-                               sanm_block8_kernel<3, 4, 3, 4, 4, 0>, sanm_block8_kernel<3, 4, 3, 4, 8, 0>, sanm_block8_kernel<3, 4, 3, 4, 12, 0>, sanm_block8_kernel<3, 4, 3, 4, 14, 0>,
-                               sanm_block8_kernel<3, 4, 3, 4, 0, 1>};
+  static const Kern kerns[] = {sanm_block8_kernel<3, 4, 3, 4, 0>, sanm_block8_kernel<6, 8, 4, 8, 0>, sanm_block8_kernel<3, 4, 3, 4, 1>, sanm_block8_kernel<3, 4, 3, 4, 2>,
+                               sanm_block8_kernel<3, 4, 3, 4, 4>, sanm_block8_kernel<3, 4, 3, 4, 8>, sanm_block8_kernel<3, 4, 3, 4, 12>, sanm_block8_kernel<3, 4, 3, 4, 14>};
   static PerDeviceOnce attr_once;
   if (attr_once.first())
     for (Kern k : kerns) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   const int grid = a.scatter ? a.n_utts * 4 : ((a.n_utts + 7) / 8) * 32;
   const int abl = (a.opt >> 4) & 15;
-  const Kern k = a.ffn22 ? kerns[8] : abl == 1 ? kerns[2] : abl == 2 ? kerns[3] : abl == 4 ? kerns[4] : abl == 8 ? kerns[5] : abl == 12 ? kerns[6] : abl == 14 ? kerns[7] : (a.opt & 2) ? kerns[1] : kerns[0];
+  const Kern k = abl == 1 ? kerns[2] : abl == 2 ? kerns[3] : abl == 4 ? kerns[4] : abl == 8 ? kerns[5] : abl == 12 ? kerns[6] : abl == 14 ? kerns[7] : (a.opt & 2) ? kerns[1] : kerns[0];
   hipLaunchKernelGGL(k, dim3(grid), dim3(NT), LDS_BYTES, s, a);
   HIP_CHECK(hipGetLastError());
 }

@@ -112,9 +112,6 @@ struct SvSession : asr_session {
   int block8_opt = 0;           // ASR_SANM_BLOCK8_OPT: tuning switches of the 8-wave kernel (SanmBlockArgs::opt)
   bool block_persist = true;    // ASR_SANM_BLOCK_PERSIST=0: the 8-wave kernel is launched once per block instead of once per run of blocks
   DeviceBuffer d_layer_tab;     // SanmBlockLayer[n_blocks]: the per-block constants a launch of the 8-wave kernel walks
-  bool block_ffn22 = false;     // ASR_SANM_BLOCK_FFN22=1: the block kernel's FFN pair as 2 x 2 (row half x hidden half, f32 partials exchanged instead of hid; round 5, VERDICT r04's candidate (a)) --
-                                // built, parity-tested, measured SLOWER than the round-4 form (98 vs 92 us per block: profiles/r05_sanm_block_ffn22.txt), so opt-in
-  int block_v = 8;              // ASR_SANM_BLOCK_V=1: the round-2 form of the block kernel (12 waves, csrc/sanm_block.hip); default: the 8-wave form (csrc/sanm_block8.hip)
   // small batches: a workgroup per (16-row tile, head), csrc/sanm_tiles.hip (ASR_SANM_TILES=0: four launches per block as before)
   bool use_tiles = true, tpack_ready = false;
   int tiles_opt = 0, tiles_dbg = -1;       // ASR_SANM_TILES_OPT (SanmTilesArgs::opt), ASR_SANM_TILES_DBG=<block>: phase clock of that block on stderr
@@ -132,10 +129,7 @@ struct SvSession : asr_session {
     if (const char* e = getenv("ASR_SANM_FUSED")) use_fused = !(e[0] == '0');
     if (const char* e = getenv("ASR_SANM_BLOCK")) use_block = !(e[0] == '0');
     if (const char* e = getenv("ASR_FBANK_SPLIT")) use_fbank_split = !(e[0] == '0');
-    if (const char* e = getenv("ASR_SANM_BLOCK_V")) block_v = (e[0] == '1') ? 1 : 8;
     if (const char* e = getenv("ASR_SANM_BLOCK8_OPT")) block8_opt = atoi(e);
-    if (const char* e = getenv("ASR_SANM_BLOCK_FFN22")) block_ffn22 = e[0] == '1';
-    if ((block8_opt >> 4) & 15) block_ffn22 = false;          // the timing-only ablations exist for the round-4 loops
     if (const char* e = getenv("ASR_SANM_TILES")) use_tiles = !(e[0] == '0');
     if (const char* e = getenv("ASR_SANM_TILES_OPT")) tiles_opt = atoi(e);
     if (const char* e = getenv("ASR_SANM_TILES_DBG")) tiles_dbg = atoi(e);
@@ -284,7 +278,7 @@ void SvSession::ensure_block_pack() {
   for (int i = 0; i < cfg.n_blocks; ++i) {
     const SvBlock& b = blocks[i];
     if (b.in_size != cfg.d_model) continue;              // (block 0 maps 560 -> 512: it keeps the separate launches)
-    launch_sanm_block8_pack((const bf16_t*)b.wqkv, (const bf16_t*)b.wout, (const bf16_t*)b.w1, (const bf16_t*)b.w2, (unsigned char*)d_wpack.ptr + per * i, block_ffn22, stream);
+    launch_sanm_block8_pack((const bf16_t*)b.wqkv, (const bf16_t*)b.wout, (const bf16_t*)b.w1, (const bf16_t*)b.w2, (unsigned char*)d_wpack.ptr + per * i, stream);
   }
   std::vector<SanmBlockLayer> tab(cfg.n_blocks);
   for (int i = 0; i < cfg.n_blocks; ++i) {
@@ -410,7 +404,7 @@ void SvSession::enqueue(const SvRunCtx& r) {
         // 8-wave kernel: one launch walks every block up to the next stand-alone LayerNorm (blocks 1 .. n_main - 1, then n_main .. n_blocks - 1): a window's
         // blocks depend on its own cluster only (ASR_SANM_BLOCK_PERSIST=0: one launch per block)
         const int run_end = (!paraformer && i < c.n_main) ? c.n_main : c.n_blocks;
-        const int n_run = (block_v == 8 && block_persist) ? run_end - i : 1;
+        const int n_run = block_persist ? run_end - i : 1;
         for (int u0 = 0; u0 < r.batch; u0 += per) {
           ProfScope ps(prof, "sanm_block", stream);
           SanmBlockArgs ba{};
@@ -426,16 +420,13 @@ void SvSession::enqueue(const SvRunCtx& r) {
             d_times.reserve(256 * 16 * 8, stream); HIP_CHECK(hipMemsetAsync(d_times.ptr, 0, 256 * 16 * 8, stream)); ba.times = d_times.as<unsigned long long>();
             ba.times_layer = block_dbg - i;
           }
-          if (block_v == 8) {
-            ba.layers = d_layer_tab.as<SanmBlockLayer>() + i; ba.n_layers = n_run; ba.opt = block8_opt; ba.ffn22 = block_ffn22 ? 1 : 0;
-            ba.st_in_n = st_in_block8 ? 4 : 16;
-            launch_sanm_block8(ba, stream);
-          }
-          else launch_sanm_block(ba, stream);
+          ba.layers = d_layer_tab.as<SanmBlockLayer>() + i; ba.n_layers = n_run; ba.opt = block8_opt;
+          ba.st_in_n = st_in_block8 ? 4 : 16;
+          launch_sanm_block8(ba, stream);
         }
         i += n_run - 1;                                        // (the loop header steps over the last block of the run)
         st_in = sta;
-        st_in_block8 = block_v == 8;
+        st_in_block8 = true;
         if (i == c.n_main - 1 && !paraformer) {
           ProfScope ps2(prof, "layernorm", stream);
           launch_layernorm<bf16_t>(xa, d, rows, d, after_g, after_b, 1e-5f, xalo, d, d, stream); st_in = nullptr;
@@ -858,7 +849,7 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   mix((uint64_t)batch); mix((uint64_t)max_tokens); mix((uint64_t)(uintptr_t)r.d_aud); mix(ws_epoch); mix((uint64_t)(uintptr_t)stream);
   mix((uint64_t)(block_cooldown > 0));        // a session cooling down after a cluster give-up replays the four-launch capture, not the block one
 
-  if (sizeof(T) == 2 && use_block && block_v == 8 && cfg.n_blocks > 1 && blocks[cfg.n_blocks - 1].cqkv && blocks[cfg.n_blocks - 1].c1 && batch >= block_min_utts &&
+  if (sizeof(T) == 2 && use_block && cfg.n_blocks > 1 && blocks[cfg.n_blocks - 1].cqkv && blocks[cfg.n_blocks - 1].c1 && batch >= block_min_utts &&
       sanm_block_supported(max_T, cfg.d_head, cfg.n_heads, cfg.d_model, cfg.d_ffn, cfg.fsmn_kernel))
     ensure_block_pack();
   if (tiles) ensure_tiles_pack();
@@ -905,14 +896,10 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   if (block_dbg >= 0 && d_times.ptr) {
     std::vector<unsigned long long> t(256 * 16);
     HIP_CHECK(hipMemcpy(t.data(), d_times.ptr, t.size() * 8, hipMemcpyDeviceToHost));
-    static const char* names12[13] = {"A loop", "images+attention", "ctx store+publish", "fsmn", "wait 0", "B loop", "B epilogue+publish", "wait 1", "C (both halves)", "publish 2",
-                                      "wait 2", "D loop", "D epilogue"};
     static const char* names8[14] = {"A loop (4 chunks)", "stats+images+attention", "ctx store+publish", "fsmn", "B prologue+wait 0", "B loop", "B epilogue+publish", "C wait 1+stats",
                                      "C loop", "C epilogue (hid)", "publish 2", "D own chunk+wait 2", "D loop (rest)", "D epilogue"};
-    static const char* names8_r5[14] = {"A loop (4 chunks)", "stats+images+attention", "ctx store+publish", "fsmn", "B prologue+wait 0", "B loop", "B epilogue+publish", "FFN wait 1 (W prefetch)",
-                                        "FFN x1 DMA+statistics", "FFN 4 passes+partial out", "publish 2", "final: x1 rows+wait 2", "final: partial loads", "final epilogue"};
-    const int nk = block_v == 8 ? 14 : 13;
-    const char* const* names = block_v == 8 ? (block_ffn22 ? names8_r5 : names8) : names12;
+    const int nk = 14;
+    const char* const* names = names8;
     unsigned long long t_first = ~0ull, t_last = 0;
     int n = 0;
     double sum[14] = {0}, mx[14] = {0};
@@ -925,7 +912,7 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
     if (n) {
       fprintf(stderr, "[sanm_block %d] %d workgroups, first start -> last end %.1f us\n", block_dbg, n, (double)(t_last - t_first) * 0.01);
       for (int k = 0; k < nk; ++k) fprintf(stderr, "  %-22s avg %6.2f us  max %6.2f us\n", names[k], sum[k] / n, mx[k]);
-      if (block_v == 8 && (block8_opt & 2048)) {            // stamps 4..7 were taken inside phase A (the rows "B prologue .. B epilogue" above are then meaningless)
+      if (block8_opt & 2048) {            // stamps 4..7 were taken inside phase A (the rows "B prologue .. B epilogue" above are then meaningless)
         static const char* inside[5] = {"A: statistics", "A: q/k/v images", "A: own attention tile", "A: shared 9th tile", "A: closing barrier"};
         const int from[5] = {1, 4, 5, 6, 7}, to[5] = {4, 5, 6, 7, 2};
         for (int q = 0; q < 5; ++q) {
@@ -934,16 +921,9 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
           fprintf(stderr, "  %-22s avg %6.2f us  max %6.2f us\n", inside[q], sm / n, m2);
         }
       }
-      if (block_v == 8) {
-        int n_plain = 0;
-        for (int w = 0; w < 256; ++w) if (t[w * 16]) n_plain += (int)t[w * 16 + 15];
-        fprintf(stderr, "  (debug word 15: %d of %d workgroups)\n", n_plain, n);
-      }
-      if (block_v != 8) {
-        double c_loops = 0.0;
-        for (int w = 0; w < 256; ++w) if (t[w * 16]) c_loops += (double)t[w * 16 + 14] * 0.01;
-        fprintf(stderr, "  %-22s avg %6.2f us  (inside C: the two GEMM loops without their epilogues)\n", "C loops", c_loops / n);
-      }
+      int n_plain = 0;
+      for (int w = 0; w < 256; ++w) if (t[w * 16]) n_plain += (int)t[w * 16 + 15];
+      fprintf(stderr, "  (debug word 15: %d of %d workgroups)\n", n_plain, n);
     }
   }
   {

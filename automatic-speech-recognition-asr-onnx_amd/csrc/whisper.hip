@@ -78,13 +78,9 @@ struct WhSession : asr_session {
   bool fp8 = false, fp8_fake = false, fp8_weights = true, fp8_kv = true;     // ASR_FP8_WEIGHTS=0 / ASR_FP8_KV=0: leave that half in bf16 (to price the halves separately)
   std::vector<Dec8Layer> dec8;
   DeviceBuffer d_w8, d_wscale, d_wdq, d_cross8, d_cscale;
-  hipGraphExec_t dec_graph = nullptr;      // the whole single-token step (one chain), or -- several chains -- its tail: logits + heads
-  hipGraphExec_t chain_graph[4] = {nullptr, nullptr, nullptr, nullptr};     // several chains: chain ci's embedding + layer loop, replayed on its own stream
-  int dec_graph_chains = 0;
+  hipGraphExec_t dec_graph = nullptr;      // the whole single-token step
   void drop_graphs() {
     if (dec_graph) { (void)hipGraphExecDestroy(dec_graph); dec_graph = nullptr; }
-    for (auto& g : chain_graph) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
-    dec_graph_chains = 0;
   }
   uint64_t dec_key = 0, dec_eager_key = 0, ws_epoch = 1;
   void* h_plan = nullptr; size_t h_plan_cap = 0;
@@ -95,10 +91,6 @@ struct WhSession : asr_session {
                             &d_ffn, &d_cross, &d_kc, &d_vc, &d_kvpool, &d_ptable, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise, &d_nsp, &d_skws, &d_skcnt, &d_colsum, &d_dlo, &d_w8, &d_wscale, &d_wdq, &d_cross8, &d_cscale, &d_ew8, &d_ewscale, &d_h8, &d_ffn8})
       b->release();
     drop_graphs();
-    for (int i = 0; i < MAX_CHAINS; ++i) {
-      if (chain_stream[i]) (void)hipStreamDestroy(chain_stream[i]);
-      if (chain_ev[i]) (void)hipEventDestroy(chain_ev[i]);
-    }
     for (auto& kv : taps) kv.second.buf.release();
     if (h_plan) (void)hipHostFree(h_plan);
     if (h_io) (void)hipHostFree(h_io);
@@ -107,21 +99,12 @@ struct WhSession : asr_session {
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
   void init();
-  DeviceBuffer d_skws, d_skcnt;        // split-K workspace + tickets of the skinny GEMM (per session: sessions may run concurrently), one slice per decode chain
-  static constexpr int MAX_CHAINS = 4, SK_CNT = 4096;
+  DeviceBuffer d_skws, d_skcnt;        // split-K workspace + tickets of the skinny / decode GEMM (per session: sessions may run concurrently)
+  static constexpr int SK_CNT = 4096;
   static constexpr size_t SK_WS_BYTES = (size_t)16 << 20;
-  int dec_chains = 0;                  // ASR_DECODE_CHAINS (enqueue_step): 0 = by batch size
-  hipStream_t chain_stream[MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t chain_ev[MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
-  void ensure_chain_streams(int nc) {
-    for (int i = 0; i < nc; ++i) {
-      if (i > 0 && !chain_stream[i]) HIP_CHECK(hipStreamCreateWithFlags(&chain_stream[i], hipStreamNonBlocking));
-      if (!chain_ev[i]) HIP_CHECK(hipEventCreateWithFlags(&chain_ev[i], hipEventDisableTiming));
-    }
-  }
   void gemm(const GemmArgs& g0) {
     if (precision != ASR_PRECISION_BF16) { launch_gemm_f32(g0, stream); return; }
-    if (!d_skws.ptr) { d_skws.reserve((size_t)MAX_CHAINS * SK_WS_BYTES, stream); d_skcnt.reserve((size_t)MAX_CHAINS * SK_CNT * 4, stream); }
+    if (!d_skws.ptr) { d_skws.reserve(SK_WS_BYTES, stream); d_skcnt.reserve((size_t)SK_CNT * 4, stream); }
     GemmArgs g = g0;
     g.sk_ws = d_skws.as<float>(); g.sk_ws_bytes = SK_WS_BYTES; g.sk_cnt = d_skcnt.as<int32_t>();
     launch_gemm_bf16(g, stream);
@@ -135,23 +118,7 @@ struct WhSession : asr_session {
     return h_io;
   }
   template <typename T> void encode(const float* audio, int audio_mem, const int64_t* offs, int B, int32_t* n_pos_out);
-  static constexpr int PART_ALL = -1, PART_HEAD = -2;      // enqueue_step's `part`: everything / logits + heads only / >= 0: the embedding + layer loop of that chain only
-  template <typename T> void enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, bool use_hist_dev, int part = PART_ALL);
-  // decode chains of a step over B sequences x n positions (see enqueue_step): the number of chains, sequences per chain in *per
-  int chain_plan(int B, int n, size_t elem, int* per) const {
-    *per = B;
-    const bool dgm = elem == 2 && use_decode_gemm && B * n <= 64 && d_colsum.ptr != nullptr && cfg.d_model % 256 == 0 && cfg.d_ffn % 256 == 0;
-    if (!dgm || n != 1 || prof.enabled || taps_enabled) return 1;
-    int nc = dec_chains > 0 ? dec_chains : 1;      // measured (profiles/r05_whisper_decode_chains.txt): two chains 3.29 vs 3.31 ms per token at 64 sequences, slower at 32 -> opt-in
-    nc = std::max(1, std::min({nc, MAX_CHAINS, (B + 15) / 16}));
-    if (nc == 1) return 1;
-    // sub-batches of whole 16-row tiles; a chain of more than 32 rows would send fc2 through the session-wide generic GEMM, so chains stay <= 32 rows
-    const int p = std::min(32, round_up((B + nc - 1) / nc, 16));
-    nc = (B + p - 1) / p;
-    if (nc > MAX_CHAINS || nc == 1) return 1;
-    *per = p;
-    return nc;
-  }
+  template <typename T> void enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, bool use_hist_dev);
   template <typename T> void step(const int32_t* ids_host, int n, bool is_prefill, int32_t* next_out, float* logits_out);
 };
 
@@ -493,7 +460,7 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
 // All launches of one step. `hist_dev` (device-resident history length) is what the kernels read, so the single-token
 // step is position independent and ONE captured hipGraph replays for every decode position.
 template <typename T>
-void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, bool use_hist_dev, int part) {
+void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, bool use_hist_dev) {
   const auto& c = cfg;
   const int B = batch, d = c.d_model, dff = c.d_ffn, Ld = c.n_dec_layers, H = c.n_heads;
   const int R = B * n, Rp = round_up(R, 128);
@@ -529,17 +496,10 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
     xa_lo = d_dlo.as<bf16_t>(); xb_lo = xa_lo + (size_t)Rp * d; xc_lo = xb_lo + (size_t)Rp * d;
   }
   const bool w8 = fp8 && fp8_weights && !fp8_fake;
-  // ---- decode chains. A single-token step is a chain of 8 dependent launches per layer, each a latency chain of its own (first weight bytes, fragment loop, cross-wave
-  // reduction, hand-over) that leaves the chip mostly idle: the six GEMMs of a layer move their 46 MB at ~1 TB/s. The sequences of a batch never meet before the
-  // logits, so the batch is cut into `NC` sub-batches (chain_plan) whose embedding + layer loops run on one HIP stream each -- replayed as one captured graph per chain
-  // (step()) -- and cover each other's latencies; the weights are streamed once per chain (the later reader mostly finds them in the memory-side cache). The logits +
-  // heads behind the join run on the whole batch. ASR_DECODE_CHAINS: 0 / unset / 1 = one chain (the default: see chain_plan), N = N chains.
-  int per = B;
-  const int NC = chain_plan(B, n, sizeof(T), &per);
-  ASR_REQUIRE(NC == 1 || dgm, "whisper: decode chains without the decode GEMM");
-  ASR_REQUIRE(part < NC, "whisper: chain %d of %d", part, NC);
-  if (!d_skws.ptr) { d_skws.reserve((size_t)MAX_CHAINS * SK_WS_BYTES, stream); d_skcnt.reserve((size_t)MAX_CHAINS * SK_CNT * 4, stream); }
-  int plan_rows = 0;                     // several chains: every chain's GEMMs take the grid shape of the largest chain (same summation order for every sequence)
+  // (Round 5 also cut the batch into sub-batches whose layer loops ran on one stream each ("decode chains"): 3.29 vs 3.31 ms per token at 64 sequences,
+  //  slower at 32 -- profiles/r05_whisper_decode_chains.txt; removed in round 6.)
+  if (!d_skws.ptr) { d_skws.reserve(SK_WS_BYTES, stream); d_skcnt.reserve((size_t)SK_CNT * 4, stream); }
+  const int plan_rows = 0, NC = 1;
   auto dg = [&](hipStream_t st, int ci, int r0, int Rc, int layer, const void* A, int lda, const void* Wt, int wi, int N, int K, const float* bias, const float* colsum,
                 const float* add, int act_, float* of32, void* olo, int ld_lo) {
     ProfScope ps(prof, "dec_gemm", st);
@@ -643,23 +603,7 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
       }
     }
   };
-  if (NC > 1) { ensure_chain_streams(NC); plan_rows = per * n; }
-  if (part >= 0) {                       // (capture of one chain's graph, on that chain's stream)
-    run_chain(part == 0 ? stream : chain_stream[part], part, part * per, std::min(per, B - part * per));
-    return;
-  }
-  if (part == PART_ALL) {
-    if (NC == 1) run_chain(stream, 0, 0, B);
-    else {                               // eager form of the chained step: fork / join by events
-      HIP_CHECK(hipEventRecord(chain_ev[0], stream));
-      for (int ci = 1; ci < NC; ++ci) HIP_CHECK(hipStreamWaitEvent(chain_stream[ci], chain_ev[0], 0));
-      for (int ci = 0; ci < NC; ++ci) run_chain(ci == 0 ? stream : chain_stream[ci], ci, ci * per, std::min(per, B - ci * per));
-      for (int ci = 1; ci < NC; ++ci) {
-        HIP_CHECK(hipEventRecord(chain_ev[ci], chain_stream[ci]));
-        HIP_CHECK(hipStreamWaitEvent(stream, chain_ev[ci], 0));
-      }
-    }
-  }
+  run_chain(stream, 0, 0, B);
   // final LayerNorm of the LAST position of every sequence, tied proj_out, -128 suppress penalty (:663-666)
   {
     ProfScope ps(prof, "dec_logits", stream);
@@ -776,14 +720,12 @@ void WhSession::step(const int32_t* ids_host, int n, bool is_prefill, int32_t* n
   // single-token steps fed from the device are position independent => one graph for all of them
   const bool graphable = use_graph && !ids_host && n == 1 && !taps_enabled && !prof.enabled && !noise_armed;
   const uint64_t key = ((uint64_t)B << 32) ^ (uint64_t)Mpad ^ (ws_epoch << 48) ^ (uint64_t)(uintptr_t)stream;
-  int per = B;
-  const int NC = graphable ? chain_plan(B, 1, sizeof(T), &per) : 1;
-  auto capture = [&](hipStream_t cs, int part) {
+  auto capture = [&](hipStream_t cs) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
     try {
-      enqueue_step<T>(ids_dev, 1, false, true, part);
+      enqueue_step<T>(ids_dev, 1, false, true);
     } catch (...) {
       (void)hipStreamEndCapture(cs, &graph);
       if (graph) (void)hipGraphDestroy(graph);
@@ -794,33 +736,13 @@ void WhSession::step(const int32_t* ids_host, int n, bool is_prefill, int32_t* n
     (void)hipGraphDestroy(graph);
     return exec;
   };
-  // several chains: one graph per chain, replayed on the chain's own stream between a fork and a join event, then the tail's graph. (Parallel branches inside ONE
-  // captured graph were measured first: the runtime serialises most of them and every node gets dearer -- 3.28 -> 3.81 ms per token at 64 sequences, 5.14 with four chains.)
-  auto replay = [&]() {
-    if (NC == 1) { HIP_CHECK(hipGraphLaunch(dec_graph, stream)); return; }
-    HIP_CHECK(hipEventRecord(chain_ev[0], stream));
-    for (int ci = 1; ci < NC; ++ci) {
-      HIP_CHECK(hipStreamWaitEvent(chain_stream[ci], chain_ev[0], 0));
-      HIP_CHECK(hipGraphLaunch(chain_graph[ci], chain_stream[ci]));
-      HIP_CHECK(hipEventRecord(chain_ev[ci], chain_stream[ci]));
-    }
-    HIP_CHECK(hipGraphLaunch(chain_graph[0], stream));
-    for (int ci = 1; ci < NC; ++ci) HIP_CHECK(hipStreamWaitEvent(stream, chain_ev[ci], 0));
+  if (graphable && dec_graph && key == dec_key) {
     HIP_CHECK(hipGraphLaunch(dec_graph, stream));
-  };
-  if (graphable && dec_graph && key == dec_key && dec_graph_chains == NC) {
-    replay();
   } else if (graphable && key == dec_eager_key) {
     drop_graphs();
-    if (NC == 1) dec_graph = capture(stream, PART_ALL);
-    else {
-      ensure_chain_streams(NC);
-      for (int ci = 0; ci < NC; ++ci) chain_graph[ci] = capture(ci == 0 ? stream : chain_stream[ci], ci);
-      dec_graph = capture(stream, PART_HEAD);
-    }
+    dec_graph = capture(stream);
     dec_key = key;
-    dec_graph_chains = NC;
-    replay();
+    HIP_CHECK(hipGraphLaunch(dec_graph, stream));
   } else {
     enqueue_step<T>(ids_dev, n, is_prefill, true);
     if (graphable) dec_eager_key = key;
@@ -866,7 +788,6 @@ extern "C" int asr_whisper_create(const asr_whisper_config* cfg, const void* are
       if (const char* e = getenv("ASR_KV_PAGED")) s->kv_paged = !(e[0] == '0');
       if (const char* e = getenv("ASR_KV_PAGE_SHUFFLE")) s->kv_shuffle = e[0] == '1';
       if (const char* e = getenv("ASR_DECODE_GEMM")) s->use_decode_gemm = !(e[0] == '0');
-      if (const char* e = getenv("ASR_DECODE_CHAINS")) s->dec_chains = atoi(e);
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
       s->own_stream = true;
       s->arena.load(arena, arena_bytes, arena_mem, s->stream);

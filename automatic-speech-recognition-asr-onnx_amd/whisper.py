@@ -9,7 +9,12 @@
   prefill                 = _prefill (:437-490) with [SOT, language, task, <|notimestamps|>] (:807)
   decode                  = _decode_tokens (:584-663): greedy (REPEAT_PENALTY = 1.0) or penalty-greedy (any other value; the
                             multiplier applies once PENALTY_RANGE ids were generated, :630-632), limit MAX_SEQ_LEN - 4 (:821)
-Batch extension: a list of clips is one batch; language detection / no-speech are per clip.
+  windows of one file    = :745-806: stride SLIDING_WINDOW (or the window length), `ceil((len - window) / stride) + 1` windows, the
+                            tail window zero-padded to the aligned length; the [SOT] probe (language, no-speech) runs on window 0
+                            ONLY, a no-speech verdict aborts the whole file, later windows reuse window 0's language id; the
+                            windows' ids are concatenated and the repeat guard sees the concatenation (:705-708)
+Batch extension: `transcribe` takes a list of independent clips as one batch (language detection / no-speech per clip);
+`transcribe_file` is the reference's per-file behaviour (the windows of one file form the batch).
 """
 from __future__ import annotations
 
@@ -51,6 +56,18 @@ def remove_repeated_parts(ids: Sequence[int], repeat_words_threshold: int, ids_l
             if all(ids[j + k] == ids[i + k] for k in range(-left, right)):
                 return ids[:j - left]
     return ids
+
+
+def plan_windows(audio_len: int, input_audio_length: int | None, sliding_window: int = 0):
+    """(windows, stride, window_length, aligned_length) of one file, Inference_Whisper_ONNX.py:741-757.
+    `input_audio_length=None` is the dynamic-axis export: the window is the whole file."""
+    window = int(audio_len) if input_audio_length is None else int(input_audio_length)
+    stride = window if sliding_window <= 0 else int(sliding_window)
+    if audio_len <= window:
+        windows = 1
+    else:
+        windows = int(np.ceil((audio_len - window) / stride)) + 1
+    return windows, stride, window, (windows - 1) * stride + window
 
 
 def no_speech_probability(logits: np.ndarray, suppress_tokens: Sequence[int], no_speech_id: int) -> np.ndarray:
@@ -117,3 +134,52 @@ class WhisperTranscriber:
                         "skipped": bool(skipped[b])})
         total_s = sum(a.size for a in audios) / cfg.sample_rate
         return out, {"rtf": wall / total_s, "wall_s": wall}
+
+    def transcribe_file(self, pcm_int16: np.ndarray, language_id: int | None = None, sliding_window: int = 0,
+                        input_audio_length: int | None = -1, max_new: int | None = None):
+        """One file the way the reference's loop walks it (Inference_Whisper_ONNX.py:741-829).
+        -> dict(tokens = the windows' ids concatenated (repeat guard applied when enabled), windows = per-window ids,
+                language_id, no_speech_prob, no_speech), stats.
+        The windows are independent once window 0's probe has fixed the language, so they run as ONE batch; the probe's [SOT]
+        prefill is evaluated for the batch but only window 0's row is read (the reference never probes a later window)."""
+        cfg = self.cfg
+        if input_audio_length == -1:
+            input_audio_length = cfg.max_audio_len
+        raw = np.asarray(pcm_int16, dtype=np.int16).reshape(-1)
+        audio_len = int(raw.size)
+        audio = prepare_audio_input(raw)
+        n_win, stride, window, aligned = plan_windows(audio_len, input_audio_length, sliding_window)
+        if audio.size < aligned:                                         # zero-padded tail (:751-757)
+            audio = np.concatenate([audio, np.zeros(aligned - audio.size, dtype=audio.dtype)])
+        clips = [np.ascontiguousarray(audio[w * stride:w * stride + window]) for w in range(n_win)]
+        lang = cfg.first_language_id if language_id is None else int(language_id)
+        t0 = time.time()
+        self.sess.encode(clips)
+        prob, no_speech = 0.0, False
+        if self.detect_language or self.no_speech_detection:            # needs_probe: window 0 only (:768)
+            self.sess.set_sampling(False)
+            self.sess.set_penalty(1.0, self.penalty_range)
+            _, logits = self.sess.prefill(np.full((n_win, 1), cfg.sot_id, dtype=np.int32))
+            if self.detect_language:
+                lang = int(self.language_token_ids[np.argmax(logits[0, self.language_token_ids])])
+            if self.no_speech_detection:
+                prob = float(self.sess.no_speech_prob(cfg.no_speech_id)[0])
+                no_speech = prob >= self.no_speech_threshold             # aborts the file (:801-805)
+        windows: list[list[int]] = []
+        if not no_speech:
+            prompt = np.tile(np.asarray([[cfg.sot_id, lang, self.task_token, cfg.no_timestamps_id]], dtype=np.int32), (n_win, 1))
+            limit = max(0, cfg.max_target_positions - prompt.shape[1])
+            if max_new is not None:
+                limit = min(limit, max_new)
+            self.sess.set_penalty(self.repeat_penalty, self.penalty_range)
+            self.sess.set_sampling(*self.sampling)
+            self.sess.prefill(prompt, want_logits=False)
+            toks = self.sess.generate(limit, eos_id=cfg.eot_id) if limit > 0 else [np.zeros(0, np.int32)] * n_win
+            windows = [t.astype(int).tolist() for t in toks]
+        wall = time.time() - t0
+        ids = [t for w in windows for t in w]
+        if self.remove_repeats:
+            ids = list(remove_repeated_parts(ids, 3, len(ids)))
+        res = {"tokens": np.asarray(ids, dtype=np.int32), "windows": windows, "language_id": lang, "no_speech_prob": prob,
+               "no_speech": bool(no_speech), "n_windows": n_win, "stride": stride, "window": window}
+        return res, {"rtf": wall / max(audio_len / cfg.sample_rate, 1e-9), "wall_s": wall}

@@ -447,7 +447,7 @@ def main():
                 k["tflops"] = round(flops[name] / (ms * 1e-3) / 1e12, 1)
             kernels[name] = k
         if "sanm_block" in kernels:
-            dom, dom_match = ["sanm_block"], ("sanm_block8_kernel", "sanm_block_kernel")
+            dom, dom_match = ["sanm_block"], ("sanm_block8_kernel",)
             dom_desc = ("sanm_block8_kernel (q|k|v + attention + FSMN + out-proj + FFN of a SANM block, clusters of four workgroups per window; one launch walks a "
                         "whole run of blocks: 49 + 20 per step; csrc/sanm_block8.hip)")
         else:
@@ -747,7 +747,7 @@ def main_paraformer(args):
         if "sanm_block" in kernels:        # one launch per encoder block: its GEMMs + attention + FSMN (block 0 keeps the separate launches)
             enc_gemm += B * (4.0 * T * T * d + 2.0 * T * d * cfg.fsmn_kernel) * nb
             enc_ms = kernels["sanm_block"]["ms_per_step"] + sum(kernels[k]["ms_per_step"] for k in ("sanm_fused", "gemm_qkv", "gemm_ffn1", "gemm_ffn2") if k in kernels)
-            dom_desc = "sanm_block_kernel (one launch per SANM encoder block: q|k|v + attention + FSMN + out-proj + FFN; csrc/sanm_block.hip)"
+            dom_desc = "sanm_block8_kernel (one launch walks the SANM encoder blocks: q|k|v + attention + FSMN + out-proj + FFN; csrc/sanm_block8.hip)"
         else:
             enc_ms = sum(kernels[k]["ms_per_step"] for k in ("gemm_qkv", "gemm_ffn1", "gemm_ffn2") if k in kernels)
             enc_ms += kernels.get("gemm_out", {"ms_per_step": 0})["ms_per_step"]

@@ -217,6 +217,7 @@ class WhisperOracle:
             hn = F.layer_norm(h, (d,))
             h = h + _gelu(hn @ self._c(L["w1"]).t() + self._c(L["b1"]), self.gelu) @ self._c(L["w2"]).t() + self._c(L["b2"])
         last = F.layer_norm(h[:, -1], (d,), self._c(ck["model.decoder.layer_norm.weight"]), self._c(ck["model.decoder.layer_norm.bias"]))
+        self.last_hidden = last                                    # test tap: the rows the tied projection sees (B, d)
         logits = last @ self._c(ck["model.decoder.embed_tokens.weight"]).t() + self._c(self.suppress_penalty)
         return logits, nk, nv
 

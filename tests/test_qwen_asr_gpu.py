@@ -65,14 +65,12 @@ def test_f32_mode_matches_reference_goldens(fixture, order):
             assert np.array_equal(got_ids[b], c["token_ids"]), b
 
 
-@pytest.mark.parametrize("fixture,no_fuse,mega", [("qwen_asr_tiny", "0", "0"), ("qwen_asr_mid", "0", "0"), ("qwen_asr_mid", "1", "0"),
-                                                  ("qwen_asr_mid", "0", "1")])
-def test_generate_equals_stepwise_and_oracle_bf16(fixture, no_fuse, mega, monkeypatch):
+@pytest.mark.parametrize("fixture,no_fuse", [("qwen_asr_tiny", "0"), ("qwen_asr_mid", "0"), ("qwen_asr_mid", "1")])
+def test_generate_equals_stepwise_and_oracle_bf16(fixture, no_fuse, monkeypatch):
     """bf16 mode: generate() == explicit prefill / decode; logits stay within the bf16 budget of the reference; host-fed ids == device-fed.
     no_fuse = 1 runs the unfused kernels (separate RMSNorm / RoPE / per-head attention) instead of the fused decode step and the MFMA
-    prefill attention; mega = 1 runs every decode step as the one persistent kernel with chip-wide barriers (qwen_mega.hip)."""
+    prefill attention."""
     monkeypatch.setenv("ASR_QWEN_NO_FUSE", no_fuse)
-    monkeypatch.setenv("ASR_QWEN_MEGA", mega)
     g = load_golden(fixture)
     cfg, ck = qwen_setup(g)
     sess = sub("engine").QwenAsrSession.from_checkpoint(cfg, ck, precision=BF16)

@@ -247,6 +247,127 @@ def test_batch64_32_steps_every_disagreement_with_the_oracle_is_an_oracle_near_t
           f"differ (all inside 2 e); {int(clear.sum())} pairs clear 2 e")
 
 
+def _teacher_forced_oracle(orc, cfg, audios, prompt, forced, hidden=None):
+    """f32 oracle, every utterance teacher-forced along its row of `forced`: logits (B, S, V); optionally the rows the tied projection saw."""
+    B, S = forced.shape[0], forced.shape[1] + 1
+    want = np.zeros((B, S, cfg.vocab), np.float32)
+    with torch.inference_mode():
+        for b in range(B):
+            ck_, cv_ = (z.unsqueeze(0) for z in orc.encode(audios[b]))
+            logits, sk, sv = orc.decoder(torch.tensor([prompt], dtype=torch.long), 0, None, None, ck_, cv_)
+            want[b, 0] = logits[0].float().numpy()
+            if hidden is not None:
+                hidden[b, 0] = orc.last_hidden[0].double().numpy()
+            for s in range(S - 1):
+                logits, sk, sv = orc.decoder(torch.tensor([[int(forced[b, s])]]), len(prompt) + s, sk, sv, ck_, cv_)
+                want[b, s + 1] = logits[0].float().numpy()
+                if hidden is not None:
+                    hidden[b, s + 1] = orc.last_hidden[0].double().numpy()
+    return want
+
+
+def _prototype_rows(X, alpha, target):
+    """Nearest-prototype rows for a projection WITHOUT bias. The final LayerNorm gives every row x nearly the same length R, so
+    x . (R m_c / |m_c| - mu) = R |x| cos(x, m_c) - x . mu ranks the classes c of a row x by the cosine to their mean direction m_c (the
+    mu term is the same for every class). Rows start as classes of their own; a row whose f32 margin is below `target` has its class
+    merged with its best competitor's (similar decoder states share a token, as they do under a trained head) until every margin clears
+    `target`. Returns (rows (K, d), class of every row of X)."""
+    N, d = X.shape
+    U = X / np.linalg.norm(X, axis=1, keepdims=True)
+    R, mu = float(np.linalg.norm(X, axis=1).mean()), X.mean(0)
+    cls = np.arange(N)
+    for _ in range(200):
+        _, cls = np.unique(cls, return_inverse=True)
+        K = int(cls.max()) + 1
+        M = np.zeros((K, d))
+        np.add.at(M, cls, U)
+        M /= np.linalg.norm(M, axis=1, keepdims=True)
+        P = alpha * (R * M - mu)
+        lo = X @ P.T
+        own = lo[np.arange(N), cls].copy()
+        lo[np.arange(N), cls] = -np.inf
+        rival = lo.argmax(1)
+        weak = np.flatnonzero(own - lo[np.arange(N), rival] < target)
+        if weak.size == 0:
+            return P, cls
+        for i in weak:                                                        # merge the weak row's class into its rival's
+            a, b = cls[i], rival[i]
+            cls[cls == max(a, b)] = min(a, b)
+    raise AssertionError("prototype classes did not settle")
+
+
+@pytest.mark.parametrize("prec", [BF16, FP8W])
+def test_batch64_32_steps_token_for_token_on_a_prototype_head(prec):
+    """bf16 parity of the Whisper decoder that does not lean on near-tie exclusions.
+
+    The output projection is tied to the token embedding, but under teacher forcing only the embedding rows of the ids that are FED matter
+    to the hidden states. So: feed ids from a small set F (distinct across the utterances of a step), and plant prototype rows in vocabulary
+    ids OUTSIDE F (never fed, not suppressed) -- one class per (utterance, step) pair, pairs whose decoder states are too similar for any head
+    to tell apart sharing a class (_prototype_rows: all 64 first picks follow the same prompt and do) -- built on x = the f32 oracle's final
+    LayerNorm rows: a head with the margins a trained model has, on the hidden states this decoder really produces. Planting does not change
+    the hidden states (asserted), the logits become peaky, and the demand is the user's: the SAME pick as the f32 oracle on all 64 x 32 = 2048
+    (utterance, step) pairs, every one of them clearing twice the measured error of the logit differences that decide it."""
+    cfg, ck, sup, beg = whisper_setup("whisper_d256_test")
+    B, S, alpha, target = 64, 32, 2.0, 1.0
+    rng = np.random.default_rng(64033)
+    audios = [unit_audio(8900 + b, int(rng.integers(16000, 128001))) for b in range(B)]
+    prompt = [cfg.sot_id, cfg.first_language_id, cfg.transcribe_id, cfg.no_timestamps_id]
+    banned = set(sup) | set(beg)
+    text = [i for i in range(cfg.eot_id) if i not in banned]
+    fed, pool = np.asarray(text[:400]), np.asarray(text[400:])
+    assert pool.size >= B * S
+    forced = np.stack([fed[rng.permutation(fed.size)[:B]] for _ in range(S - 1)], 1).astype(np.int32)
+    X = np.zeros((B, S, cfg.d_model))
+    _teacher_forced_oracle(WhisperOracle(cfg, ck, sup, beg), cfg, audios, prompt, forced, hidden=X)
+    P, cls = _prototype_rows(X.reshape(B * S, -1), alpha, target)
+    K = P.shape[0]
+    ids_of_class = pool[rng.permutation(pool.size)[:K]]
+    planted = ids_of_class[cls].reshape(B, S)
+    E = ck["model.decoder.embed_tokens.weight"].copy()
+    E[ids_of_class] = P.astype(np.float32)
+    ck2 = dict(ck)
+    ck2["model.decoder.embed_tokens.weight"] = E
+    orc2 = WhisperOracle(cfg, ck2, sup, beg)
+    X2 = np.zeros_like(X)
+    want = _teacher_forced_oracle(orc2, cfg, audios, prompt, forced, hidden=X2)
+    assert np.array_equal(X, X2)                                               # planting did not touch what the decoder computes
+    head = want.copy()
+    head[:, 0] += orc2.begin_bias.float().numpy()
+    top = head.argmax(2)
+    assert np.array_equal(top, planted)                                        # the head does what it was built to do (in f32)
+    part = np.partition(head, -2, axis=2)
+    margin = part[..., -1] - part[..., -2]
+    assert K > 0.9 * B * (S - 1), K                                            # nearly every later step is a class of its own
+
+    sess = sub("engine").WhisperSession.from_checkpoint(cfg, ck2, precision=prec, suppress_tokens=sup, begin_suppress_tokens=beg)
+    sess.encode(audios)
+    nxt, logits = sess.prefill(np.array([prompt] * B, np.int32))
+    got, picks = [logits], [nxt.copy()]
+    for s in range(S - 1):
+        nxt, logits = sess.decode(np.ascontiguousarray(forced[:, s:s + 1]), want_logits=True)
+        got.append(logits); picks.append(nxt.copy())
+    got, picks = np.stack(got, 1)[..., :cfg.vocab], np.stack(picks, 1).reshape(B, S)
+    got[:, 0] += orc2.begin_bias.float().numpy()
+    # the error of what decides a pick: logit differences to the oracle's winner
+    d_orc = np.take_along_axis(head, top[..., None], 2) - head
+    d_gpu = np.take_along_axis(got, top[..., None], 2) - got
+    err, window = np.abs(d_gpu - d_orc), 4.0
+    e, e_all = float(err[d_orc <= window].max()), float(err.max())            # classes within `window` of the winner are the only ones that can compete
+    print(f"whisper_d256 prototype head ({K} classes), B = {B} x {S} steps, precision {prec}: oracle margin min {margin.min():.3f} median {np.median(margin):.3f}; "
+          f"error of logit differences {e:.4f} within {window} of the winner, {e_all:.4f} over all classes; {int((picks != top).sum())} of {B * S} picks differ")
+    assert margin.min() > 2 * e, (float(margin.min()), e)                      # every pair clears twice the measured error ...
+    assert e_all < window                                                      # ... no class from outside the window can get in ...
+    assert np.array_equal(picks, top)                                          # ... and every pick is the oracle's, token for token
+    # the production path (no logits download): prefill + decode without taps picks the same ids
+    sess.encode(audios)
+    nxt, _ = sess.prefill(np.array([prompt] * B, np.int32), want_logits=False)
+    p2 = [nxt.copy()]
+    for s in range(S - 1):
+        nxt, _ = sess.decode(np.ascontiguousarray(forced[:, s:s + 1]), want_logits=False)
+        p2.append(nxt.copy())
+    assert np.array_equal(np.stack(p2, 1).reshape(B, S), top)
+
+
 def test_large_v3_fp8mm_30s_vs_golden_budget():
     """FP8MM at full dimensions (d_model 1280, d_ffn 5120, 32 + 32 layers): the 30 s clip of the reference-minted golden in a ragged batch of 4 (30 s, 8 s, 30 s,
     2.5 s -- compacted encoder rows of different counts go through the FP8 GEMM's row tiles), prefill + decode steps teacher-forced on the golden's ids; the

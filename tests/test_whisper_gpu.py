@@ -363,13 +363,10 @@ def test_paged_self_kv_cache_equals_the_contiguous_extents_bit_for_bit(prec, mon
 
 
 @pytest.mark.parametrize("prec", [BF16, 2])
-def test_decode_chains_give_the_single_chain_logits(prec, monkeypatch):
-    """Single-token decode steps of >= 32 sequences run the layer loop as parallel sub-batch chains (csrc/whisper.hip: enqueue_step, `NC`; two HIP streams that
-    become parallel branches of the captured step). A sequence's logits may depend on the chain cut only through the decode GEMM's split plan (a chain of 16
-    or 32 rows splits K differently from one of 40: other summation order, bf16-level differences), never on which chain it rode in: 40 sequences (cut 32 + 8,
-    and 16 + 16 + 8 with three chains forced) of which 0 / 35 and 7 / 33 are the same audio must give, over a prefill and 20 graph-replayed steps with the penalty
-    head on, identical logits for the twins inside every mode, and across modes logits within the bf16 budget with every confident pick equal. prec 2 = FP8W:
-    the cross-K/V scale rows are addressed per head over the WHOLE batch (DecAttnArgs::scale_ld)."""
+def test_twin_sequences_in_one_batch_get_identical_logits(prec):
+    """A sequence's logits must not depend on its position in the batch: 40 sequences of which 0 / 35 and 7 / 33 are the same audio, over a prefill and 20
+    graph-replayed steps with the penalty head on, give identical logits and picks for the twins. prec 2 = FP8W: the cross-K/V scale rows are addressed per
+    head over the WHOLE batch (DecAttnArgs::scale_ld). (Round 5's decode chains, which this test was written for, were removed in round 6.)"""
     name = "whisper_d256_test"
     cfg, ck, sup, beg = whisper_setup(name)
     eng = sub("engine")
@@ -379,36 +376,18 @@ def test_decode_chains_give_the_single_chain_logits(prec, monkeypatch):
     audios[33] = audios[7].copy()
     prompt = [cfg.sot_id, cfg.first_language_id, cfg.transcribe_id, cfg.no_timestamps_id]
     prompts = np.array([prompt] * B, np.int32)
-    out = {}
-    for chains in ("1", "2", "3"):
-        monkeypatch.setenv("ASR_DECODE_CHAINS", chains)
-        sess = eng.WhisperSession.from_checkpoint(cfg, ck, precision=prec, suppress_tokens=sup, begin_suppress_tokens=beg)
-        sess.set_penalty(0.9, 4)
-        sess.encode(audios)
-        nxt, logits = sess.prefill(prompts)
-        ids, steps = [nxt], [logits]
-        for _ in range(20):
-            nxt, logits = sess.decode(None, want_logits=True)
-            ids.append(nxt)
-            steps.append(logits)
-        out[chains] = (np.stack(ids, 1), np.stack(steps, 1)[..., :cfg.vocab])
-        del sess
-    monkeypatch.delenv("ASR_DECODE_CHAINS")
-    ids1, lg1 = out["1"]
-    scale = float(np.abs(lg1).max())
-    srt = np.sort(lg1, axis=-1)
-    margin = srt[..., -1] - srt[..., -2]
-    for chains in ("1", "2", "3"):
-        ids, lg = out[chains]
-        assert np.isfinite(lg).all()
-        assert np.array_equal(lg[0], lg[35]) and np.array_equal(lg[7], lg[33]), chains
-        assert np.array_equal(ids[0], ids[35]) and np.array_equal(ids[7], ids[33]), chains
-    for chains in ("2", "3"):
-        ids, lg = out[chains]
-        # teacher forcing is not available on the graph-replayed path (ids stay on the device): compare up to each sequence's first disagreement, which must be a near-tie
-        for b in range(B):
-            diff = np.nonzero(ids[b] != ids1[b])[0]
-            upto = int(diff[0]) if diff.size else ids.shape[1] - 1
-            assert np.abs(lg[b, :upto + 1] - lg1[b, :upto + 1]).max() < 4e-3 * scale, (chains, b)
-            if diff.size:
-                assert margin[b, upto] < 8e-3 * scale, (chains, b, upto)
+    sess = eng.WhisperSession.from_checkpoint(cfg, ck, precision=prec, suppress_tokens=sup, begin_suppress_tokens=beg)
+    sess.set_penalty(0.9, 4)
+    sess.encode(audios)
+    nxt, logits = sess.prefill(prompts)
+    ids, steps = [nxt], [logits]
+    for _ in range(20):
+        nxt, logits = sess.decode(None, want_logits=True)
+        ids.append(nxt)
+        steps.append(logits)
+    ids, lg = np.stack(ids, 1), np.stack(steps, 1)[..., :cfg.vocab]
+    assert np.isfinite(lg).all()
+    assert np.array_equal(lg[0], lg[35]) and np.array_equal(lg[7], lg[33])
+    assert np.array_equal(ids[0], ids[35]) and np.array_equal(ids[7], ids[33])
+
+

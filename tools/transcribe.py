@@ -84,15 +84,18 @@ def run(a) -> dict:
             if tok is None:
                 raise SystemExit("--language other than 'auto' needs --tokenizer (language token ids come from its vocabulary)")
             lang_id = tok.convert_tokens_to_ids(f"<|{a.language}|>")
-        window = cfg.max_audio_len
         for p in a.wav:
             pcm = audio_io.read_wav_int16(p, cfg.sample_rate, exact_width=a.strict_wav)
-            clips = [pcm[s:s + window] for s in range(0, max(pcm.size, 1), window)]
-            out, stat = tr.transcribe(clips, language_ids=None if lang_id is None else [lang_id] * len(clips))
-            ids = [o["tokens"].astype(int).tolist() for o in out]
-            text = "".join(whisper_text(tok, i) for i in ids if i) if tok is not None else None
+            # the reference's per-file loop (Inference_Whisper_ONNX.py:741-829): SLIDING_WINDOW stride, zero-padded tail, probe on window 0 only,
+            # a no-speech verdict aborts the file, later windows reuse window 0's language
+            r, stat = tr.transcribe_file(pcm, language_id=lang_id, sliding_window=a.sliding_window)
+            ids = r["windows"]
+            flat = [t for w in ids for t in w]
+            text = None
+            if tok is not None:
+                text = "[no speech detected]" if r["no_speech"] else (whisper_text(tok, flat) if flat else "")
             files.append({"path": p, "n_samples": int(pcm.size), "language": a.language, "windows": ids, "text": text, "rtf": stat["rtf"],
-                          "language_ids": [o["language_id"] for o in out], "no_speech_prob": [o["no_speech_prob"] for o in out]})
+                          "language_ids": [r["language_id"]] * len(ids), "no_speech_prob": [r["no_speech_prob"]], "no_speech": r["no_speech"]})
     elif a.family == "qwen_asr":
         info, blob = shim.load_model(os.path.join(a.model, "Qwen_ASR.asrmodel"))
         cfg = cfgm.QwenAsrConfig(**info["config"])

@@ -57,8 +57,12 @@ SIGNATURES = {
     "asr_abi_version": (_i, []),
     "asr_last_error": (C.c_char_p, []),
     "asr_device_count": (_i, [C.POINTER(C.c_int)]),
+    "asr_device_foreign_begin": (_i, [_i]),
+    "asr_device_foreign_end": (_i, [_i]),
+    "asr_device_foreign_stats": (_i, [_i, _lp]),
     "asr_sensevoice_create": (_i, [C.POINTER(SenseVoiceConfigC), _vp, _sz, _i, _i, _i, C.POINTER(_vp)]),
     "asr_sensevoice_run": (_i, [_vp, _vp, _i, _lp, _i, _ip, _ip, _i, _ip]),
+    "asr_sanm_stats": (_i, [_vp, _ip]),
     "asr_sensevoice_seq_len": (_i, [C.POINTER(SenseVoiceConfigC), _i, C.POINTER(C.c_int)]),
     "asr_paraformer_create": (_i, [C.POINTER(ParaformerConfigC), _vp, _sz, _i, _i, _i, C.POINTER(_vp)]),
     "asr_paraformer_run": (_i, [_vp, _vp, _i, _lp, _i, _ip, _i, _ip]),

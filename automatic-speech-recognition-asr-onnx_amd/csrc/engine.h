@@ -115,3 +115,16 @@ void asr_tenant_attach(asr_session* s);                                         
 struct TenantScope { asr_session* s; explicit TenantScope(asr_session* s_); ~TenantScope(); };
 int asr_tenant_live_others(const asr_session* s);                              // other sessions that exist on s->device
 int asr_tenant_busy_others(const asr_session* s, double window_ms);            // ... that are inside a compute call now, or left one less than window_ms ago
+
+// ---- foreign kernels on this GPU: RCCL collectives (or anything else the host program launches outside this library) must never share the chip with a
+// cluster kernel (sanm_block8 / sanm_tiles / stream_layers / stream_dec: every workgroup of the grid must be resident and they spin on each other's counters --
+// an RCCL kernel parked on a few CUs is exactly the co-tenant that splits a cluster). The rule, process-wide and per device:
+//   * asr_device_foreign_begin(dev) (C ABI) opens a foreign section and BLOCKS until no cluster pass is in flight on `dev`; asr_device_foreign_end(dev) closes it
+//     (the caller makes sure its kernels have finished by then);
+//   * a compute call that would launch cluster kernels asks ClusterScope first: while a foreign section is open it takes its cluster-free path instead
+//     (four launches per SANM block, per-layer launches of the streaming step -- same results), it never waits, so the two sides cannot deadlock.
+struct ClusterScope {
+  int dev; bool ok;                 // ok: cluster kernels may be launched until this scope ends (the call returns with its stream drained)
+  explicit ClusterScope(int device);
+  ~ClusterScope();
+};

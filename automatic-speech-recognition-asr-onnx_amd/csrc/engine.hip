@@ -236,3 +236,52 @@ int asr_tenant_busy_others(const asr_session* s, double window_ms) {
   }
   return n;
 }
+
+// ---- foreign-kernel gate (engine.h)
+#include <condition_variable>
+#include <mutex>
+namespace {
+constexpr int GATE_DEVS = 64;
+std::mutex g_gate_mu;
+std::condition_variable g_gate_cv;
+int g_foreign[GATE_DEVS], g_cluster[GATE_DEVS];
+int64_t g_gate_stats[GATE_DEVS][4];              // foreign sections opened, cluster passes diverted, sections that had to wait, cluster passes admitted
+inline int gate_slot(int device) { return device >= 0 && device < GATE_DEVS ? device : GATE_DEVS - 1; }
+}  // namespace
+
+ClusterScope::ClusterScope(int device) : dev(gate_slot(device)), ok(false) {
+  std::lock_guard<std::mutex> lk(g_gate_mu);
+  if (g_foreign[dev] > 0) { ++g_gate_stats[dev][1]; return; }
+  ++g_cluster[dev]; ++g_gate_stats[dev][3];
+  ok = true;
+}
+ClusterScope::~ClusterScope() {
+  if (!ok) return;
+  { std::lock_guard<std::mutex> lk(g_gate_mu); --g_cluster[dev]; }
+  g_gate_cv.notify_all();
+}
+
+extern "C" int asr_device_foreign_begin(int device_id) {
+  return asr_guard([&] {
+    ASR_REQUIRE(device_id >= 0 && device_id < GATE_DEVS, "device_foreign_begin: device %d", device_id);
+    std::unique_lock<std::mutex> lk(g_gate_mu);
+    ++g_foreign[device_id]; ++g_gate_stats[device_id][0];
+    if (g_cluster[device_id] > 0) ++g_gate_stats[device_id][2];
+    g_gate_cv.wait(lk, [&] { return g_cluster[device_id] == 0; });
+  });
+}
+extern "C" int asr_device_foreign_end(int device_id) {
+  return asr_guard([&] {
+    ASR_REQUIRE(device_id >= 0 && device_id < GATE_DEVS, "device_foreign_end: device %d", device_id);
+    std::lock_guard<std::mutex> lk(g_gate_mu);
+    ASR_REQUIRE(g_foreign[device_id] > 0, "device_foreign_end: no foreign section is open on device %d", device_id);
+    --g_foreign[device_id];
+  });
+}
+extern "C" int asr_device_foreign_stats(int device_id, int64_t* out4) {
+  return asr_guard([&] {
+    ASR_REQUIRE(device_id >= 0 && device_id < GATE_DEVS && out4, "device_foreign_stats: bad argument");
+    std::lock_guard<std::mutex> lk(g_gate_mu);
+    for (int i = 0; i < 4; ++i) out4[i] = g_gate_stats[device_id][i];
+  });
+}

@@ -122,6 +122,8 @@ struct SvSession : asr_session {
   void ensure_block_pack();
   int block_fault = 0;          // ASR_SANM_BLOCK_FAULT=1 (tests): one workgroup of the first block launch withholds an exchange count
   int block_giveups = 0;        // forward passes redone on the four-launch path because a cluster gave up (see run())
+  bool foreign_now = false;     // a foreign section (RCCL collective, engine.h: ClusterScope) is open on this GPU: this pass launches no cluster kernel
+  int foreign_diverted = 0;     // passes that took the cluster-free path for that reason
   int block_cooldown = 0;       // batches left on the four-launch path after a give-up (other sessions are holding CUs: do not walk into the same wait again)
   void load_env() {             // debug / ablation switches, re-read at every session creation
     gemm_reload_env();
@@ -369,12 +371,12 @@ void SvSession::enqueue(const SvRunCtx& r) {
   // (it has its own tiling, so unlike `alg` it does not need batches of near-full windows: ragged batches qualify too)
   bool blk = false;
   if constexpr (sizeof(T) == 2)
-    blk = use_block && block_cooldown == 0 && use_ln_alg && use_fused && blocks[c.n_blocks - 1].cqkv && blocks[c.n_blocks - 1].c1 && c.n_blocks > 1 &&
+    blk = use_block && block_cooldown == 0 && !foreign_now && use_ln_alg && use_fused && blocks[c.n_blocks - 1].cqkv && blocks[c.n_blocks - 1].c1 && c.n_blocks > 1 &&
           r.batch >= block_min_utts &&          // four workgroups per window: a small batch leaves most CUs idle (one window: 4 of 256), the tiled GEMMs do not
           sanm_block_supported(r.max_T, c.d_head, c.n_heads, d, dff, c.fsmn_kernel);
   const size_t flag_words = (size_t)c.n_blocks * r.batch * 4;
   const size_t tile_flag0 = flag_words + 4 + (size_t)c.n_blocks * r.batch, tile_flag_stride = ((size_t)r.n_tiles + r.batch) * 4;       // the tile kernel's counters: per block [tile][4] + [window][4]
-  const bool tiles = r.tiles && block_cooldown == 0;
+  const bool tiles = r.tiles && block_cooldown == 0 && !foreign_now;
   HIP_CHECK(hipMemsetAsync(d_flags.ptr, 0, (tile_flag0 + (tiles ? (size_t)c.n_blocks * tile_flag_stride : 0)) * 4, stream));      // per (block, window, exchange) counters + the error word + per (launch, window) placement words
   const float* x_in = d_x0.as<float>();
   const bf16_t* x_in_lo = x0lo;
@@ -700,6 +702,10 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   ASR_REQUIRE(batch > 0, "sensevoice: empty batch");
   ASR_REQUIRE(audio && offs && (lang || paraformer) && tok_out && num_out, "sensevoice: null argument");
   HIP_CHECK(hipSetDevice(device));
+  // no cluster kernel beside a foreign (RCCL) section: this whole call -- it returns with the stream drained -- is one cluster pass, or takes the four-launch path
+  ClusterScope cluster(device);
+  foreign_now = !cluster.ok;
+  if (foreign_now) ++foreign_diverted;
   const int d = c.d_model, dff = c.d_ffn;
 
   // ---- host plan -------------------------------------------------------------------------
@@ -847,7 +853,7 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   r.d_tile_win = r.d_row_utt + Mpad;
   r.d_tile_idx = r.d_tile_win + n_tiles;
   mix((uint64_t)batch); mix((uint64_t)max_tokens); mix((uint64_t)(uintptr_t)r.d_aud); mix(ws_epoch); mix((uint64_t)(uintptr_t)stream);
-  mix((uint64_t)(block_cooldown > 0));        // a session cooling down after a cluster give-up replays the four-launch capture, not the block one
+  mix((uint64_t)(block_cooldown > 0 || foreign_now));        // a session cooling down after a cluster give-up replays the four-launch capture, not the block one
 
   if (sizeof(T) == 2 && use_block && cfg.n_blocks > 1 && blocks[cfg.n_blocks - 1].cqkv && blocks[cfg.n_blocks - 1].c1 && batch >= block_min_utts &&
       sanm_block_supported(max_T, cfg.d_head, cfg.n_heads, cfg.d_model, cfg.d_ffn, cfg.fsmn_kernel))
@@ -1096,6 +1102,9 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
   ASR_REQUIRE(st_max > 0, "streaming: session was not created with asr_paraformer_stream_create");
   ASR_REQUIRE(audio && stream_ids && tok_out && num_out && n >= 1 && n <= st_max && max_tokens >= st_B + 1, "streaming: bad argument (n = %d)", n);
   HIP_CHECK(hipSetDevice(device));
+  ClusterScope cluster(device);                          // (as in run(): fused = cluster kernels; a foreign section open on this GPU sends the step down the per-launch path)
+  foreign_now = !cluster.ok;
+  if (foreign_now) ++foreign_diverted;
   const int d = c.d_model, dff = c.d_ffn, dd = pcfg.d_dec_ffn, H = c.n_heads, n_cur = st_B + st_C;
   const int rows = n * 16, Mpad = round_up(rows, 128), frames = n * st_frames, n_slabs = vpad / 64;
   std::vector<char> seen(st_max, 0);
@@ -1166,7 +1175,7 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
     d_aud = d_audio.as<float>();
   }
   // ---- which path this step takes (see the comment at st_fused_max)
-  bool step_fused = st_fused && std::is_same<T, bf16_t>::value && n <= st_fused_max && st_cooldown == 0;
+  bool step_fused = st_fused && std::is_same<T, bf16_t>::value && n <= st_fused_max && st_cooldown == 0 && !foreign_now;
   bool snapshot = false;
   if (st_cooldown > 0) --st_cooldown;
   if (step_fused && st_share_rule && asr_tenant_busy_others(this, 5.0) > 0) { step_fused = false; ++st_shared_steps; }
@@ -1631,7 +1640,16 @@ extern "C" int asr_paraformer_stream_stats(asr_session* s, int32_t* out8) {
     ASR_REQUIRE(s && s->kind == 4 && out8, "paraformer_stream_stats: not a streaming Paraformer session");
     SvSession* sv = static_cast<SvSession*>(s);
     out8[0] = sv->st_giveups; out8[1] = sv->st_shared_steps; out8[2] = sv->st_snapshots; out8[3] = sv->st_fused_max; out8[4] = sv->st_cooldown;
-    out8[5] = sv->st_fused ? 1 : 0; out8[6] = 0; out8[7] = 0;
+    out8[5] = sv->st_fused ? 1 : 0; out8[6] = sv->foreign_diverted; out8[7] = 0;
+  });
+}
+
+extern "C" int asr_sanm_stats(asr_session* s, int32_t* out8) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && (s->kind == 1 || s->kind == 3 || s->kind == 4) && out8, "sanm_stats: not a SenseVoice / Paraformer session");
+    SvSession* sv = static_cast<SvSession*>(s);
+    out8[0] = sv->block_giveups; out8[1] = sv->block_cooldown; out8[2] = sv->foreign_diverted; out8[3] = sv->use_block ? 1 : 0;
+    out8[4] = out8[5] = out8[6] = out8[7] = 0;
   });
 }
 

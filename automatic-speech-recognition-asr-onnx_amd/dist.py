@@ -6,6 +6,13 @@ streaming session -- so the path shards with no data-path collective. Two collec
 "gloo" in the CPU tests):
   * start-up: broadcast of the weight arena built by rank 0 (0.47 GB SenseVoice / 3.1 GB Whisper),
   * end of batch: gather of fixed-width hypothesis slabs (B_local, 1 + max_tokens) int32 to rank 0.
+
+Collectives and cluster kernels never share a GPU: every collective issued here on a CUDA device runs inside a FOREIGN SECTION of the native library
+(`foreign_section`: asr_device_foreign_begin / _end, include/asr_mi355x.h) -- opening it waits for any SANM block / tile / fused streaming pass in flight on
+that GPU, and while it is open every compute call takes its cluster-free path; the section closes only after the collective's kernels have finished
+(`torch.cuda.synchronize`). A serving loop that overlaps `gather_hypotheses` of batch k with `run` of batch k + 1 (pool.SessionPool, several threads)
+is therefore safe by construction, at the price of that batch's block kernel. Code that issues its own torch.distributed / RCCL calls next to this library
+must wrap them the same way.
 """
 from __future__ import annotations
 
@@ -15,6 +22,41 @@ from typing import Sequence
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def foreign_section(device):
+    """Bracket kernels this library did not launch (RCCL collectives) on `device`: no cluster kernel of the native library runs beside them.
+    CPU devices (the gloo tests) pass straight through and never load the native library."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        yield
+        return
+    from . import _lib
+    lib = _lib.load()
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    _lib.check(lib.asr_device_foreign_begin(idx))
+    try:
+        yield
+    finally:
+        try:
+            torch.cuda.synchronize(idx)                  # the collective's kernels (c10d's own stream included) have left the GPU
+        finally:
+            _lib.check(lib.asr_device_foreign_end(idx))
+
+
+def foreign_stats(device) -> dict:
+    """Counters of the foreign-kernel gate of `device` (process-wide)."""
+    import ctypes as C
+    from . import _lib
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    out = (C.c_int64 * 4)()
+    _lib.check(_lib.load().asr_device_foreign_stats(idx, out))
+    return {"sections": int(out[0]), "cluster_passes_diverted": int(out[1]), "sections_that_waited": int(out[2]), "cluster_passes_admitted": int(out[3])}
 
 
 _GATHER_OK = None        # gather vs send / recv: decided ONCE per process group, by every rank together (a per-call try / except could split the ranks)
@@ -63,15 +105,16 @@ def broadcast_arena(blob: np.ndarray | None, device: torch.device, src: int = 0)
     if world == 1:
         return torch.from_numpy(blob).to(device)
     rank = dist.get_rank()
-    n = torch.zeros(1, dtype=torch.int64, device=device)
-    if rank == src:
-        n[0] = blob.nbytes
-    dist.broadcast(n, src)
-    if rank == src:
-        t = torch.from_numpy(blob).to(device)
-    else:
-        t = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
-    dist.broadcast(t, src)
+    with foreign_section(device):
+        n = torch.zeros(1, dtype=torch.int64, device=device)
+        if rank == src:
+            n[0] = blob.nbytes
+        dist.broadcast(n, src)
+        if rank == src:
+            t = torch.from_numpy(blob).to(device)
+        else:
+            t = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
+        dist.broadcast(t, src)
     return t
 
 
@@ -94,15 +137,16 @@ def _backend_has_gather(device: torch.device) -> bool:
     global _GATHER_OK
     if _GATHER_OK is None:
         ok = 1
-        try:
-            t = torch.zeros(1, dtype=torch.int32, device=device)
-            bucket = [torch.empty_like(t) for _ in range(dist.get_world_size())] if dist.get_rank() == 0 else None
-            dist.gather(t, bucket, dst=0)
-        except (RuntimeError, NotImplementedError):
-            ok = 0
-        v = torch.tensor([ok], dtype=torch.int32, device=device)
-        dist.all_reduce(v, op=dist.ReduceOp.MIN)
-        _GATHER_OK = bool(int(v.item()))
+        with foreign_section(device):
+            try:
+                t = torch.zeros(1, dtype=torch.int32, device=device)
+                bucket = [torch.empty_like(t) for _ in range(dist.get_world_size())] if dist.get_rank() == 0 else None
+                dist.gather(t, bucket, dst=0)
+            except (RuntimeError, NotImplementedError):
+                ok = 0
+            v = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN)
+            _GATHER_OK = bool(int(v.item()))
     return _GATHER_OK
 
 
@@ -114,25 +158,35 @@ def gather_hypotheses(slab: np.ndarray, device: torch.device, dst: int = 0):
     if world == 1:
         return [slab]
     rank = dist.get_rank()
-    t = torch.from_numpy(np.ascontiguousarray(slab)).to(device)
-    bucket = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-    if _backend_has_gather(device):
-        dist.gather(t, bucket, dst=dst)
-    else:
-        if rank == dst:
-            bucket[dst].copy_(t)
-            for src in range(world):
-                if src != dst:
-                    dist.recv(bucket[src], src=src)
+    has_gather = _backend_has_gather(device)
+    with foreign_section(device):
+        t = torch.from_numpy(np.ascontiguousarray(slab)).to(device)
+        bucket = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
+        if has_gather:
+            dist.gather(t, bucket, dst=dst)
         else:
-            dist.send(t, dst=dst)
-    return [b.cpu().numpy() for b in bucket] if rank == dst else None
+            if rank == dst:
+                bucket[dst].copy_(t)
+                for src in range(world):
+                    if src != dst:
+                        dist.recv(bucket[src], src=src)
+            else:
+                dist.send(t, dst=dst)
+        return [b.cpu().numpy() for b in bucket] if rank == dst else None
 
 
 def max_over_ranks(value: float, device: torch.device) -> float:
     """The slowest rank's figure (bench.py: elapsed time of the timed region, bracketed by barriers on both sides)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    with foreign_section(device):
+        t = torch.tensor([value], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def barrier(device) -> None:
+    """dist.barrier() inside a foreign section (on RCCL a barrier is an all-reduce kernel)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        with foreign_section(device):
+            dist.barrier()

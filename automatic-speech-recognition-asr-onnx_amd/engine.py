@@ -77,6 +77,12 @@ class _Session:
             out[nm] = {"total_ms": ms[i], "launches": int(cnt[i])}
         return out
 
+    def sanm_stats(self) -> dict:
+        """SenseVoice / Paraformer sessions: counters of the cluster kernels (asr_sanm_stats)."""
+        out = np.zeros(8, dtype=np.int32)
+        _lib.check(_lib.load().asr_sanm_stats(self._h, _ip(out)))
+        return {"giveups": int(out[0]), "cooldown": int(out[1]), "foreign_diverted": int(out[2]), "block_kernel": bool(out[3])}
+
     def taps(self, enable: bool):
         _lib.check(_lib.load().asr_session_taps_enable(self._h, int(enable)))
 

@@ -137,16 +137,19 @@ class WhisperTranscriber:
 
     def transcribe_file(self, pcm_int16: np.ndarray, language_id: int | None = None, sliding_window: int = 0,
                         input_audio_length: int | None = -1, max_new: int | None = None):
-        """One file the way the reference's loop walks it (Inference_Whisper_ONNX.py:741-829).
+        """One file the way the reference's loop walks it (Inference_Whisper_ONNX.py:741-829). input_audio_length: the encoder's static audio
+        dimension, None = dynamic axis (one unpadded window), -1 = dynamic when the file fits the encoder, else windows of cfg.max_audio_len.
         -> dict(tokens = the windows' ids concatenated (repeat guard applied when enabled), windows = per-window ids,
                 language_id, no_speech_prob, no_speech), stats.
         The windows are independent once window 0's probe has fixed the language, so they run as ONE batch; the probe's [SOT]
         prefill is evaluated for the batch but only window 0's row is read (the reference never probes a later window)."""
         cfg = self.cfg
-        if input_audio_length == -1:
-            input_audio_length = cfg.max_audio_len
         raw = np.asarray(pcm_int16, dtype=np.int16).reshape(-1)
         audio_len = int(raw.size)
+        if input_audio_length == -1:
+            # the reference's default export keeps the audio axis dynamic (Export_Whisper.py:743): the window is the file, unpadded. A file longer than
+            # the encoder's position table can only run through the static-axis export: windows of max_audio_len, the tail zero-padded.
+            input_audio_length = None if audio_len <= cfg.max_audio_len else cfg.max_audio_len
         audio = prepare_audio_input(raw)
         n_win, stride, window, aligned = plan_windows(audio_len, input_audio_length, sliding_window)
         if audio.size < aligned:                                         # zero-padded tail (:751-757)

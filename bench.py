@@ -251,20 +251,43 @@ def self_launch_command(n_gpus, argv, port=None):
 
 
 def dry_run(args):
-    """ASR_BENCH_DRYRUN=1: the launch / rendezvous / clock path of a step loop without a GPU (gloo on CPU) -- what tests/test_dist_cpu.py
-    drives to prove that `python bench.py --gpus N` starts N ranks, synchronises them and prints one line on rank 0."""
+    """ASR_BENCH_DRYRUN=1: the launch / rendezvous / data-parallel plumbing of a workload's step loop without a GPU (gloo on CPU) -- what
+    tests/test_dist_cpu.py drives to prove that `python bench.py --workload W --gpus N` starts N ranks, broadcasts an arena from rank 0, shards the
+    utterances, gathers every step's hypothesis slabs on rank 0, takes the slowest rank's clock and prints ONE line on rank 0 (BASELINE.json configs[3] /
+    [4] are this path at N = 8 with the RCCL backend; no 8-GPU node was available to any round)."""
+    import torch
     import torch.distributed as dist
     dp = importlib.import_module(PKG + ".dist")
     rank, local_rank, world = dp.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    cpu = torch.device("cpu")
+    B = args.batch or (32 if args.workload == "whisper" else 64)
+    width = {"whisper": int(args.decode_tokens or 4 * args.seconds), "qwen": 64, "mixed": 64}.get(args.workload, 137)
+    blob = (np.arange(1 << 16, dtype=np.uint32).view(np.uint8) if rank == 0 else None)          # stands in for the weight arena rank 0 builds
+    arena = dp.broadcast_arena(blob, cpu)
+    assert int(arena.to(torch.int64).sum()) == int(np.arange(1 << 16, dtype=np.uint32).view(np.uint8).astype(np.int64).sum())
+    dp.barrier(cpu)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
+    gathered = 0
+    for k in range(args.warmup + args.steps):
+        num = np.full(B, 1 + (rank + k) % width, dtype=np.int32)
+        tok = np.tile(np.arange(width, dtype=np.int32)[None] + 1000 * rank, (B, 1))
+        slabs = dp.gather_hypotheses(dp.pack_hypotheses(tok, num, width), cpu)
+        if rank == 0:
+            assert len(slabs) == world
+            for r_, sl in enumerate(slabs):
+                hyp = dp.unpack_hypotheses(sl)
+                assert len(hyp) == B and all(h.size == 1 + (r_ + k) % width and (h.size == 0 or h[0] == 1000 * r_) for h in hyp)
+            if k >= args.warmup:
+                gathered += world * B
     time.sleep(0.01 * (rank + 1))
-    import torch
-    elapsed = dp.max_over_ranks(time.perf_counter() - t0, torch.device("cpu"))
+    elapsed = dp.max_over_ranks(time.perf_counter() - t0, cpu)
     if rank == 0:
-        print(json.dumps({"metric": "dry run (no GPU work)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "max_rank_seconds": round(elapsed, 4)}))
+        print(json.dumps({"metric": "dry run (no GPU work)", "workload": args.workload, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "global_batch": world * B, "gathered_hypotheses": gathered, "arena_broadcast_bytes": int(arena.numel()),
+                          "max_rank_seconds": round(elapsed, 4)}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -373,7 +396,7 @@ def main():
 
     def fence():
         if world > 1:
-            dist.barrier()
+            dp.barrier(device)
         torch.cuda.synchronize()
 
     def timed(n_steps, upload):
@@ -522,7 +545,7 @@ def main():
                 out["secondary"] = secondary_lines(cfg, ck, audio_np, local_rank, device, cpu_leg=True)
         print(json.dumps(out))
     if world > 1:
-        dist.barrier()
+        dp.barrier(device)
         dist.destroy_process_group()
 
 
@@ -716,7 +739,7 @@ def main_paraformer(args):
 
     def fence():
         if world > 1:
-            dist.barrier()
+            dp.barrier(device)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -784,7 +807,7 @@ def main_paraformer(args):
                                    f"(oracle/paraformer_oracle.py), {el:.1f} s wall"}
         print(json.dumps(out))
     if world > 1:
-        dist.barrier()
+        dp.barrier(device)
         dist.destroy_process_group()
 
 
@@ -820,7 +843,7 @@ def main_paraformer_streaming(args):
 
     def fence():
         if world > 1:
-            dist.barrier()
+            dp.barrier(device)
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -883,7 +906,7 @@ def main_paraformer_streaming(args):
                                    f"(oracle/paraformer_streaming_oracle.py), {el:.1f} s wall"}
         print(json.dumps(out))
     if world > 1:
-        dist.barrier()
+        dp.barrier(device)
         dist.destroy_process_group()
 
 
@@ -957,7 +980,7 @@ def main_whisper(args):
 
     def fence():
         if world > 1:
-            dist.barrier()
+            dp.barrier(device)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -1071,7 +1094,7 @@ def main_whisper(args):
                                        "logit_abs_max": round(float(np.abs(ref0).max()), 3)}
         print(json.dumps(out))
     if world > 1:
-        dist.barrier()
+        dp.barrier(device)
         dist.destroy_process_group()
 
 
@@ -1127,7 +1150,7 @@ def main_qwen(args):
 
     def fence():
         if world > 1:
-            dist.barrier()
+            dp.barrier(device)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -1231,7 +1254,7 @@ def main_qwen(args):
                                              f"(oracle/qwen_asr_oracle.py), {el:.1f} s wall"}
         print(json.dumps(out))
     if world > 1:
-        dist.barrier()
+        dp.barrier(device)
         dist.destroy_process_group()
 
 
@@ -1286,7 +1309,7 @@ def main_mixed(args):
 
     def fence():
         if world > 1:
-            dist.barrier()
+            dp.barrier(device)
         torch.cuda.synchronize()
 
     for i in range(max(args.warmup, 1)):
@@ -1330,8 +1353,9 @@ def main_mixed(args):
     if world > 1:
         elapsed = dp.max_over_ranks(elapsed, device)
         c = torch.tensor([chunks_done[0]], dtype=torch.float64, device=device)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total_chunks = float(c.item())
+        with dp.foreign_section(device):
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            total_chunks = float(c.item())
     else:
         total_chunks = float(chunks_done[0])
     if rank == 0:
@@ -1359,7 +1383,7 @@ def main_mixed(args):
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}}
         print(json.dumps(out))
     if world > 1:
-        dist.barrier()
+        dp.barrier(device)
         dist.destroy_process_group()
 
 

@@ -69,6 +69,19 @@ int asr_abi_version(void);
 const char* asr_last_error(void);
 int asr_device_count(int* count);
 
+/* Foreign kernels on a GPU this library computes on -- the RCCL collectives of the data-parallel path (weight-arena broadcast, hypothesis
+ * gather; the reference has no counterpart, its runtime is one onnxruntime session per process) or any other kernel the host program launches itself.
+ * The SANM block / tile kernels and the fused streaming step need every workgroup of their grid resident at once; a foreign kernel holding a few CUs can
+ * split a cluster (the launch then gives up after a bounded spin and the batch is redone cluster-free). So bracket foreign work:
+ *   asr_device_foreign_begin(dev)  blocks until no cluster pass is in flight on `dev`; until the matching _end every compute call on `dev` takes its
+ *                                  cluster-free path (same results; the call never waits, so the two sides cannot deadlock);
+ *   asr_device_foreign_end(dev)    after the foreign kernels have FINISHED on the device (synchronise their stream first).
+ * Sections nest (a count per device, process-wide). _stats: out4 = {sections opened, cluster passes diverted to the cluster-free path, sections that had
+ * to wait for a cluster pass, cluster passes admitted}. dist.py brackets every torch.distributed collective on a CUDA device with this pair. */
+int asr_device_foreign_begin(int device_id);
+int asr_device_foreign_end(int device_id);
+int asr_device_foreign_stats(int device_id, int64_t* out4);
+
 /* ------------------------------------------------------------------ SenseVoice (non-AR, CTC)
  * Replaces SenseVoiceSmall.onnx == SENSE_VOICE.forward (SenseVoice/Export_SenseVoice.py:271-296).
  * Graph I/O it mirrors (Export_SenseVoice.py:375-379): audio (1,1,audio_len) f32 int16-range,
@@ -103,6 +116,10 @@ int asr_sensevoice_run(asr_session* s, const float* audio, int audio_mem, const 
 
 /* sequence length (prompt + LFR rows) the graph produces for an utterance of n_samples */
 int asr_sensevoice_seq_len(const asr_sensevoice_config* cfg, int n_samples, int* seq_len);
+/* Counters of a SenseVoice / Paraformer session's cluster kernels: out8 = {forward passes redone cluster-free because a cluster gave up, batches left on the
+ * cluster-free path after the last give-up, passes that took the cluster-free path because a foreign section was open (asr_device_foreign_begin),
+ * block kernel enabled, 0, 0, 0, 0}. */
+int asr_sanm_stats(asr_session* s, int32_t* out8);
 
 /* ------------------------------------------------------------------ Paraformer (non-streaming, CIF + NAR decoder)
  * Replaces Paraformer.onnx == PARAFORMER.forward (Paraformer/Non-Streaming/Export_Paraformer.py:474-563).

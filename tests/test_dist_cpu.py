@@ -1,6 +1,8 @@
 """CPU, world_size 2 over gloo: utterance sharding, arena broadcast and hypothesis gather."""
 import os
 
+import pytest
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -73,21 +75,38 @@ def test_broadcast_and_gather_world2(tmp_path):
     assert (tmp_path / "ok").read_text() == "ok"
 
 
-def test_bench_self_launches_under_torchrun():
-    """`python bench.py --gpus 2` with no launcher in the environment re-executes itself under torch.distributed.run (127.0.0.1 rendezvous):
+@pytest.mark.parametrize("workload", ["sensevoice", "whisper", "mixed"])
+def test_bench_self_launches_under_torchrun(workload):
+    """`python bench.py --workload W --gpus 2` with no launcher in the environment re-executes itself under torch.distributed.run (127.0.0.1 rendezvous):
     two ranks start, meet at the barrier, rank 0 prints ONE JSON line with n_gpus = 2 (ASR_BENCH_DRYRUN=1: the step loop's launch / clock path
-    on gloo, no GPU work). The round-2 bench died on `assert world == args.gpus` here."""
+    on gloo, no GPU work: arena broadcast from rank 0, one hypothesis gather per step, slowest rank's clock). whisper = BASELINE.json configs[3]'s
+    launch line, mixed = configs[4]'s. The round-2 bench died on `assert world == args.gpus` here."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["ASR_BENCH_DRYRUN"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env, capture_output=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["workload"] == workload
+    B = 32 if workload == "whisper" else 64
+    assert rec["global_batch"] == 2 * B and rec["gathered_hypotheses"] == 3 * 2 * B and rec["arena_broadcast_bytes"] == 4 << 16
+
+
+def test_foreign_section_is_a_no_op_on_cpu_devices():
+    """dist.foreign_section brackets RCCL collectives on CUDA devices (the native library's cluster kernels must not run beside them); the gloo
+    path of the CPU tests passes straight through without touching the native library."""
+    import torch
+    d = sub("dist")
+    ran = []
+    with d.foreign_section(torch.device("cpu")):
+        ran.append(1)
+    with d.foreign_section("cpu"):
+        ran.append(2)
+    assert ran == [1, 2]
 
 
 def test_bench_self_launch_command_shape():

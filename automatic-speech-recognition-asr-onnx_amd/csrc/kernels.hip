@@ -473,8 +473,14 @@ __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const float* __restr
 // directly the B fragment of O^T = V^T P^T (no LDS round trip for P). O^T's C fragment again has one query per
 // lane column, so the online-softmax rescale is lane-local, and each lane ends with 4 consecutive d values of
 // its query row (one 8-byte store).
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 template <int HD, int CHUNK, int QT>
-__global__ __launch_bounds__(512) void attn_bf16_kernel(const AttnArgs a, int n_rows_alloc) {
+__global__ __launch_bounds__(512, (HD * QT <= 128) ? 4 : (HD * QT <= 256 ? 2 : 1)) void attn_bf16_kernel(const AttnArgs a, int n_rows_alloc) {
   constexpr int SLOTS = HD / 8;               // 16-byte slots per K row
   constexpr int KROWB = HD * 2;               // bytes per K row
   constexpr int K_RPI = 64 / SLOTS;           // K rows per LDS-DMA wave-instruction (1 KiB)
@@ -540,69 +546,84 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(const AttnArgs a, int n_
       }
     }
     __syncthreads();                          // chunk landed (the barrier drains the LDS-DMA queue)
-    for (int s = 0; s * 32 < nkeys; ++s) {
+    // One 32-key sub-tile: S^T MFMAs, soft-max update, O^T MFMAs. The soft-max is what bounds this kernel at head_dim 64 (256 MFMA flops per score against
+    // ~25 VALU cycles + a quarter-rate v_exp per score: round 5's body ran 86 full-rate VALU ops + 9 exps per tile and sub-tile, 488 issue cycles against 128
+    // of MFMA), so: keys are masked only in sub-tiles that need it (the chunk's last one, or any under the causal rule); p = exp2(fma(s, log2 e, -m log2 e))
+    // -- one packed FMA per two scores, no subtract / multiply pair; the running output is rescaled only when some lane's maximum moved (wave-uniform
+    // test: after the first few sub-tiles it almost never does), with packed multiplies, outside the MFMA chain.
+    const int perm16 = (lane ^ 16) << 2, perm32 = (lane ^ 32) << 2;       // ds_bpermute addresses of the two row-maximum exchanges
+    auto subtile = [&](const int s, auto masked_tag) __attribute__((always_inline)) {
+      constexpr bool MASKED = decltype(masked_tag)::value;
+      constexpr float LOG2E = 1.4426950408889634f;
       f32x4_t st0[QT], st1[QT];
 #pragma unroll
       for (int t = 0; t < QT; ++t) { st0[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; st1[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-      const int key0 = s * 32 + fq, key1 = key0 + 16;
+      // score row i of the two S^T tiles of a sub-tile = keys 8 (i / 4) + (i % 4) and + 4: lane group g then holds scores of the 8 CONSECUTIVE keys 8 g .. 8 g + 7
+      // (tile 0: the first four, tile 1: the last four), so its packed probabilities are the B fragment for a V^T fragment that is ONE 16-byte LDS read
+      const int key0 = s * 32 + ((fq >> 2) << 3) + (fq & 3), key1 = key0 + 4;
 #pragma unroll
       for (int ks = 0; ks < HD / 32; ++ks) {
         const int c = ks * 4 + g;
         const bf16x8_t kf0 = *reinterpret_cast<const bf16x8_t*>(Ks + key0 * KROWB + ((c ^ (key0 & (SLOTS - 1))) << 4));
         const bf16x8_t kf1 = *reinterpret_cast<const bf16x8_t*>(Ks + key1 * KROWB + ((c ^ (key1 & (SLOTS - 1))) << 4));
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-          if (act[t]) {
-            st0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[t][ks], st0[t], 0, 0, 0);
-            st1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[t][ks], st1[t], 0, 0, 0);
-          }
+        for (int t = 0; t < QT; ++t) {       // (tiles past the utterance's end run too -- straight-line code; nothing of theirs is ever stored)
+          st0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[t][ks], st0[t], 0, 0, 0);
+          st1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[t][ks], st1[t], 0, 0, 0);
         }
       }
-      const int kb = kv0 + s * 32 + g * 4;
+      const int kb = kv0 + s * 32 + g * 8;       // this lane's keys: kb .. kb + 3 (tile 0), kb + 4 .. kb + 7 (tile 1)
       bf16x8_t pfv[QT];
       float alpha[QT];
+      bool moved = false;
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
-        float sv[8] = {st0[t][0], st0[t][1], st0[t][2], st0[t][3], st1[t][0], st1[t][1], st1[t][2], st1[t][3]};
-        float mx = -INFINITY;
+        f32x4_t s0 = st0[t], s1 = st1[t];
+        if constexpr (MASKED) {
+          const int qi = q_base + (t * NW + wave) * 16 + fq;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int key = kb + (r & 3) + ((r >> 2) << 4);
-          if (key >= T || (a.causal && key > q_base + (t * NW + wave) * 16 + fq)) sv[r] = -INFINITY;
-          mx = fmaxf(mx, sv[r]);
+          for (int r = 0; r < 4; ++r) {
+            if (kb + r >= T || (a.causal && kb + r > qi)) s0[r] = -INFINITY;
+            if (kb + 4 + r >= T || (a.causal && kb + 4 + r > qi)) s1[r] = -INFINITY;
+          }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run[t], mx);
-        alpha[t] = __expf(m_run[t] - m_new);
-        float psum = 0.0f;
-        float p[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { p[r] = __expf(sv[r] - m_new); psum += p[r]; }
-        l_run[t] = l_run[t] * alpha[t] + psum;
+        // (v_max3 by hand: fmaxf() costs a canonicalising v_max x, x per operand under IEEE rules -- 16 of the 28 maximum instructions of a sub-tile)
+        float mx = vmax3(vmax3(s0[0], s0[1], s0[2]), vmax3(s0[3], s1[0], s1[1]), vmax3(s1[2], s1[3], s1[3]));
+        mx = vmax3(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm16, __builtin_bit_cast(int, mx))), mx);
+        const float m_old = m_run[t], m_new = vmax3(m_old, mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm32, __builtin_bit_cast(int, mx))));
         m_run[t] = m_new;
+        moved = moved || (m_new != m_old);
+        alpha[t] = __builtin_amdgcn_exp2f((m_old - m_new) * LOG2E);
+        const f32x2_t mneg = {-m_new * LOG2E, -m_new * LOG2E}, l2 = {LOG2E, LOG2E};
+        const f32x2_t e0 = __builtin_elementwise_fma(f32x2_t{s0[0], s0[1]}, l2, mneg), e1 = __builtin_elementwise_fma(f32x2_t{s0[2], s0[3]}, l2, mneg);
+        const f32x2_t e2 = __builtin_elementwise_fma(f32x2_t{s1[0], s1[1]}, l2, mneg), e3 = __builtin_elementwise_fma(f32x2_t{s1[2], s1[3]}, l2, mneg);
+        const f32x2_t p0 = {__builtin_amdgcn_exp2f(e0[0]), __builtin_amdgcn_exp2f(e0[1])}, p1 = {__builtin_amdgcn_exp2f(e1[0]), __builtin_amdgcn_exp2f(e1[1])};
+        const f32x2_t p2 = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])}, p3 = {__builtin_amdgcn_exp2f(e3[0]), __builtin_amdgcn_exp2f(e3[1])};
+        const f32x2_t ps = (p0 + p1) + (p2 + p3);
+        l_run[t] = fmaf(l_run[t], alpha[t], ps[0] + ps[1]);
         union { bf16x8_t v; uint32_t w[4]; } pf;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pf.w[r] = pack_bf16x2(p[2 * r], p[2 * r + 1]);
+        pf.w[0] = pack_bf16x2(p0[0], p0[1]); pf.w[1] = pack_bf16x2(p1[0], p1[1]); pf.w[2] = pack_bf16x2(p2[0], p2[1]); pf.w[3] = pack_bf16x2(p3[0], p3[1]);
         pfv[t] = pf.v;
+      }
+      if (__builtin_amdgcn_ballot_w64(moved) != 0ull) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+          for (int dt = 0; dt < HD / 16; ++dt) ot[t][dt] *= alpha[t];
       }
 #pragma unroll
       for (int dt = 0; dt < HD / 16; ++dt) {
         const int d = dt * 16 + fq;
-        const unsigned char* vr = Vs + d * VROWB + (g & 1) * 8;
-        union { bf16x8_t v; uint2 h2[2]; } vf;
-        vf.h2[0] = *reinterpret_cast<const uint2*>(vr + (((s * 4 + (g >> 1)) ^ (d & 15)) << 4));
-        vf.h2[1] = *reinterpret_cast<const uint2*>(vr + (((s * 4 + 2 + (g >> 1)) ^ (d & 15)) << 4));
+        const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vs + d * VROWB + (((s * 4 + g) ^ (d & 15)) << 4));
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-          if (act[t]) {
-            f32x4_t o = ot[t][dt];
-            o[0] *= alpha[t]; o[1] *= alpha[t]; o[2] *= alpha[t]; o[3] *= alpha[t];
-            ot[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pfv[t], o, 0, 0, 0);
-          }
-        }
+        for (int t = 0; t < QT; ++t) ot[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfv[t], ot[t][dt], 0, 0, 0);
       }
-    }
+    };
+    // sub-tiles whose 32 keys all exist need no mask unless the causal rule cuts into this chunk
+    const int n_sub = (nkeys + 31) >> 5;
+    const int n_plain = (a.causal && kv0 + nkeys > q_base) ? 0 : min(n_sub, (T - kv0) >> 5);
+    for (int s = 0; s < n_plain; ++s) subtile(s, std::false_type{});
+    for (int s = n_plain; s < n_sub; ++s) subtile(s, std::true_type{});
   }
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
@@ -1446,22 +1467,14 @@ void attention_geometry(int max_T, int head_dim, int* qt, int* nw) {
 }
 
 void launch_attention_bf16_hd128(const AttnArgs& a, hipStream_t s) {
-  ASR_REQUIRE(a.qt >= 1 && a.qt <= 3 && a.n_waves >= 1 && a.n_waves <= 8, "attention: bad geometry qt=%d nw=%d", a.qt, a.n_waves);
+  ASR_REQUIRE(a.qt >= 1 && a.qt <= 2 && a.n_waves >= 1 && a.n_waves <= 8, "attention: bad geometry qt=%d nw=%d", a.qt, a.n_waves);
   const bool big = a.max_T <= 256;             // whole utterance in one 256-key chunk (128 KiB LDS)
-  switch (a.qt) {
-    case 1: big ? launch_attn_inst<128, 256, 1>(a, s) : launch_attn_inst<128, 128, 1>(a, s); break;
-    case 2: big ? launch_attn_inst<128, 256, 2>(a, s) : launch_attn_inst<128, 128, 2>(a, s); break;
-    default: big ? launch_attn_inst<128, 256, 3>(a, s) : launch_attn_inst<128, 128, 3>(a, s); break;
-  }
+  if (a.qt == 1) { big ? launch_attn_inst<128, 256, 1>(a, s) : launch_attn_inst<128, 128, 1>(a, s); }
+  else { big ? launch_attn_inst<128, 256, 2>(a, s) : launch_attn_inst<128, 128, 2>(a, s); }
 }
 void launch_attention_bf16_hd64(const AttnArgs& a, hipStream_t s) {
-  ASR_REQUIRE(a.qt >= 1 && a.qt <= 4 && a.n_waves >= 1 && a.n_waves <= 8, "attention: bad geometry qt=%d nw=%d", a.qt, a.n_waves);
-  switch (a.qt) {
-    case 1: launch_attn_inst<64, 256, 1>(a, s); break;
-    case 2: launch_attn_inst<64, 256, 2>(a, s); break;
-    case 3: launch_attn_inst<64, 256, 3>(a, s); break;
-    default: launch_attn_inst<64, 256, 4>(a, s); break;
-  }
+  ASR_REQUIRE(a.qt >= 1 && a.qt <= 2 && a.n_waves >= 1 && a.n_waves <= 8, "attention: bad geometry qt=%d nw=%d", a.qt, a.n_waves);
+  if (a.qt == 1) launch_attn_inst<64, 256, 1>(a, s); else launch_attn_inst<64, 256, 2>(a, s);
 }
 
 void launch_attention_f32(const AttnArgs& a, int head_dim, hipStream_t s) {

@@ -26,6 +26,8 @@ SIGNATURES = {
     "asr_probe_gemm_chain": (C.c_int, [C.c_int] * 6 + [_fp]),
     "asr_probe_last_kernel": (C.c_char_p, []),
     "asr_probe_quantize_fp8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, _fp, C.c_void_p]),
+    "asr_probe_quantize_mxfp4": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "asr_probe_decode_gemm_mxfp4": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _fp, C.c_int, _fp]),
     "asr_probe_decode_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _fp, _fp, C.c_int, _fp]),
     "asr_probe_gemm_counts": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "asr_probe_gemm_fp8": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, _fp, C.c_float, _fp, _fp, C.c_int, C.c_void_p, _fp, C.c_int, _fp]),
@@ -124,6 +126,29 @@ def quantize_fp8(w):
     q = np.zeros((N, K), np.uint8); sc = np.zeros((N,), np.float32); dq = np.zeros((N, K), np.uint16)
     _lib.check(load().asr_probe_quantize_fp8(wb.ctypes.data, N, K, q.ctypes.data, sc.ctypes.data_as(_fp), dq.ctypes.data))
     return q, sc, _bf16_to_f32(dq)
+
+
+def quantize_mxfp4(w):
+    """Block quantiser of the MXFP4 mode on an f32 array (rounded to bf16 first): (nibbles [N][K / 2] uint8, e8m0 scales [N][K / 32] uint8, dequantised f32 [N][K])."""
+    wb = _bf16_bits(w)
+    N, K = wb.shape
+    q = np.zeros((N, K // 2), np.uint8); sc = np.zeros((N, K // 32), np.uint8); dq = np.zeros((N, K), np.uint16)
+    _lib.check(load().asr_probe_quantize_mxfp4(wb.ctypes.data, N, K, q.ctypes.data, sc.ctypes.data, dq.ctypes.data))
+    return q, sc, _bf16_to_f32(dq)
+
+
+def decode_gemm_mxfp4(a, w4, scale8, w_dq=None, bias=None, fold=False):
+    """Decode GEMM (<= 64 rows) over MXFP4 weights; w_dq (f32, exact in bf16) supplies the column sums of the LayerNorm fold."""
+    ab = _bf16_bits(a)
+    M, K = ab.shape
+    N = w4.shape[0]
+    out = np.zeros((M, N), np.float32)
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    dq = None if w_dq is None else _bf16_bits(w_dq)
+    q, s = np.ascontiguousarray(w4, np.uint8), np.ascontiguousarray(scale8, np.uint8)
+    _lib.check(load().asr_probe_decode_gemm_mxfp4(M, N, K, ab.ctypes.data, q.ctypes.data, s.ctypes.data, None if dq is None else dq.ctypes.data,
+                                                  None if b is None else b.ctypes.data_as(_fp), int(fold), out.ctypes.data_as(_fp)))
+    return out
 
 
 def decode_gemm(a, w=None, w8=None, scale=None, bias=None, fold=False):

@@ -25,6 +25,7 @@ from .config import SenseVoiceConfig
 DT_F32, DT_BF16, DT_I32, DT_F16 = 0, 1, 2, 3
 PRECISION_BF16, PRECISION_F32 = 0, 1
 PRECISION_FP8W = 2          # Whisper sessions only: bf16 arena, decoder weights / cross-K/V quantised to e4m3 at session creation (asr_mi355x.h)
+PRECISION_MXFP4W = 4        # Whisper sessions: FP8W with the decoder projections as OCP MXFP4 (e2m1 + one e8m0 scale per 32 input channels) instead of e4m3
 PRECISION_FP8MM = 3         # FP8W + the encoder's FFN pair on the FP8 matrix pipe (e4m3 weights and activations, v_mfma_scale_f32_16x16x128_f8f6f4)
 
 

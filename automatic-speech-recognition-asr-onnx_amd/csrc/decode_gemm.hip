@@ -39,8 +39,19 @@ __device__ __forceinline__ bf16x8_t fp8x8_to_bf16x8(u32x2_t r) {
   return u.v;
 }
 
-template <int MT, int NT, bool FOLD, bool W8>
-__global__ __launch_bounds__(512) void decode_gemm_kernel(const DecGemmArgs g) {       // (grids are shaped to <= one workgroup per CU: the activation batches may take the registers of two)
+// 8 e2m1 nibbles (one dword) x the block's e8m0 scale -> one bf16x8 fragment (v_cvt_scalef32_pk_bf16_fp4: a byte = two elements, low nibble first; exact)
+__device__ __forceinline__ bf16x8_t fp4x8_to_bf16x8(unsigned r, float scale) {
+  union { bf16x8_t v; bf16x2_hw_t p[4]; } u;
+  u.p[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(r, scale, 0); u.p[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(r, scale, 1);
+  u.p[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(r, scale, 2); u.p[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(r, scale, 3);
+  return u.v;
+}
+
+// WQ: 0 = bf16 weights, 1 = e4m3 bytes + one scale per output column (W8), 2 = MXFP4: e2m1 nibbles + one e8m0 scale per (column, 32 k) -- the K-step of the MFMA is
+// the block of the format, so a fragment needs the one scale byte of (its column, this step), applied by the widening instruction itself
+template <int MT, int NT, bool FOLD, int WQ>
+__global__ __launch_bounds__(512) void decode_gemm_kernel(const DecGemmArgs g) {
+  constexpr bool W8 = WQ == 1, W4 = WQ == 2;       // (grids are shaped to <= one workgroup per CU: the activation batches may take the registers of two)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fgrp = lane >> 4;
@@ -62,6 +73,8 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(const DecGemmArgs g) {
   const int k_begin = w_lo * 32, kslice = (w_hi - w_lo) * 32;
   const bf16_t* wp = g.W + (size_t)(n0 + frow) * g.ldw + k_begin + fgrp * 8;
   const unsigned char* wp8 = g.W8 + (size_t)(n0 + frow) * g.ldw + k_begin + fgrp * 8;     // (W8: ldw counts bytes = elements)
+  const unsigned char* wp4 = g.W4 + (size_t)(n0 + frow) * (g.ldw >> 1) + ((k_begin + fgrp * 8) >> 1);       // (W4: ldw counts elements, two per byte)
+  const unsigned char* sp4 = g.w_scale4 + (size_t)(n0 + frow) * (g.K >> 5) + (k_begin >> 5);
   const bf16_t* ap = g.A + (size_t)frow * g.lda + k_begin + fgrp * 8;
   constexpr int U = 8 / NT;                            // K-steps per trip: U x NT weight fragments in flight per wave (16 B per lane each; byte weights: 8 B)
 
@@ -78,7 +91,8 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(const DecGemmArgs g) {
   // All requests of a trip are therefore issued in front of its MFMAs, weights first, activation fragments in batches of <= 16, and NOTHING older is pending when the first
   // trip's requests go out (the epilogue's residual / bias / column-sum loads come after them: in the first form of this change they came first, their registers were
   // reused by the batch and the compiler parked the batch behind an s_waitcnt for them -- two memory round trips in sequence, slower than the one-at-a-time loop).
-  using raw_t = typename std::conditional<W8, u32x2_t, bf16x8_t>::type;
+  using raw_t = typename std::conditional<W8, u32x2_t, typename std::conditional<W4, unsigned, bf16x8_t>::type>::type;
+  unsigned char wsc[W4 ? U : 1][NT];                   // W4: the block scales of the trip's fragments
   constexpr int UA = MT * U > 16 ? (16 / MT < 1 ? 1 : 16 / MT) : U;        // K-steps per activation batch
   raw_t wf[U][NT];
   bf16x8_t af[UA][MT];
@@ -89,6 +103,10 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(const DecGemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           if constexpr (W8) wf[u][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(wp8 + (size_t)j * 16 * g.ldw + k + u * 32));
+          else if constexpr (W4) {
+            wf[u][j] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(wp4 + (size_t)j * 16 * (g.ldw >> 1) + ((k + u * 32) >> 1)));
+            wsc[u][j] = sp4[(size_t)j * 16 * (g.K >> 5) + ((k + u * 32) >> 5)];
+          }
           else wf[u][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)j * 16 * g.ldw + k + u * 32));
         }
       }
@@ -136,7 +154,9 @@ __global__ __launch_bounds__(512) void decode_gemm_kernel(const DecGemmArgs g) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
               bf16x8_t wv;
-              if constexpr (W8) wv = fp8x8_to_bf16x8(wf[u][j]); else wv = wf[u][j];
+              if constexpr (W8) wv = fp8x8_to_bf16x8(wf[u][j]);
+              else if constexpr (W4) wv = fp4x8_to_bf16x8(wf[u][j], __uint_as_float((unsigned)wsc[u][j] << 23));
+              else wv = wf[u][j];
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, af[uu][i], acc[i][j], 0, 0, 0);   // D[n = 4 fgrp + r][m = frow]
             }
             if constexpr (FOLD) {
@@ -307,16 +327,17 @@ void launch_inst(const DecGemmArgs& g, int splits, hipStream_t s) {
     }
     hipLaunchKernelGGL(kern, grid, dim3(64 * DW), lds, s, g);
   };
-  if (g.W8) { if (g.colsum) go(decode_gemm_kernel<MT, NT, true, true>); else go(decode_gemm_kernel<MT, NT, false, true>); }
-  else { if (g.colsum) go(decode_gemm_kernel<MT, NT, true, false>); else go(decode_gemm_kernel<MT, NT, false, false>); }
+  if (g.W4) { if (g.colsum) go(decode_gemm_kernel<MT, NT, true, 2>); else go(decode_gemm_kernel<MT, NT, false, 2>); }
+  else if (g.W8) { if (g.colsum) go(decode_gemm_kernel<MT, NT, true, 1>); else go(decode_gemm_kernel<MT, NT, false, 1>); }
+  else { if (g.colsum) go(decode_gemm_kernel<MT, NT, true, 0>); else go(decode_gemm_kernel<MT, NT, false, 0>); }
   HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace
 
 bool decode_gemm_supported(const DecGemmArgs& g) {
-  return g.M >= 1 && g.M <= 64 && g.N % 32 == 0 && g.K % 32 == 0 && g.K >= 32 * DW && (g.lda * 2) % 16 == 0 && (g.ldw * (g.W8 ? 1 : 2)) % 16 == 0 && !(g.colsum && !g.A) &&
-         !(g.W8 && !g.w_scale);
+  return g.M >= 1 && g.M <= 64 && g.N % 32 == 0 && g.K % 32 == 0 && g.K >= 32 * DW && (g.lda * 2) % 16 == 0 && (g.W4 ? g.ldw % 32 == 0 : (g.ldw * (g.W8 ? 1 : 2)) % 16 == 0) &&
+         !(g.colsum && !g.A) && !(g.W8 && !g.w_scale) && !(g.W4 && !g.w_scale4) && !(g.W4 && g.W8);
 }
 
 // grid shape: column granules of 16 NT, K split across `splits` workgroups -- at most one even round of the chip's CUs.
@@ -356,7 +377,7 @@ void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits) {
 
 void launch_decode_gemm(const DecGemmArgs& g, hipStream_t s) {
   ASR_REQUIRE(decode_gemm_supported(g), "decode_gemm: unsupported shape (M = %d, N = %d, K = %d)", g.M, g.N, g.K);
-  ASR_REQUIRE(g.A && (g.W || g.W8) && (g.out_f32 || g.out_lo), "decode_gemm: null operand");
+  ASR_REQUIRE(g.A && (g.W || g.W8 || g.W4) && (g.out_f32 || g.out_lo), "decode_gemm: null operand");
   int nt = 1, splits = 1;
   decode_gemm_plan(g, &nt, &splits);
   ASR_REQUIRE(g.N % (16 * nt) == 0, "decode_gemm: N = %d", g.N);

@@ -94,6 +94,7 @@ struct DecGemmArgs {
   const bf16_t* A = nullptr; int lda = 0;            // [M][K] bf16 (colsum set: the RAW residual rows, LayerNorm applied inside)
   const bf16_t* W = nullptr; int ldw = 0;            // [N][K]
   const unsigned char* W8 = nullptr; const float* w_scale = nullptr;    // FP8 mode instead of W: e4m3 bytes [N][K] (pitch ldw) + one power-of-two scale per output column
+  const unsigned char* W4 = nullptr; const unsigned char* w_scale4 = nullptr;   // MXFP4 mode instead of W: e2m1 nibbles [N][K / 2] + e8m0 block scales [N][K / 32] (launch_quantize_rows_mxfp4)
   int M = 0, N = 0, K = 0;
   int plan_M = 0;                                    // rows the grid shape (column granule, K splits: the summation order) is planned for; 0 = M. The decode chains of whisper.hip plan every
                                                      // chain for the largest one, so a sequence's result does not depend on the chain it rides in

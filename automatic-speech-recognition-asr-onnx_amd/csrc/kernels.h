@@ -92,6 +92,8 @@ struct DecAttnArgs {
 };
 // FP8 (OCP e4m3, power-of-two scales) quantisers of precision mode ASR_PRECISION_FP8W
 void launch_quantize_rows_fp8(const bf16_t* W, int ld, int N, int K, unsigned char* W8, float* scale, bf16_t* Wdq, hipStream_t s);
+// MXFP4 (e2m1 + one e8m0 scale per 32 k): W4 [N][K / 2] bytes, S [N][K / 32] bytes, Wdq (nullable) the exact bf16 dequantisation
+void launch_quantize_rows_mxfp4(const bf16_t* W, int ld, int N, int K, unsigned char* W4, unsigned char* S, bf16_t* Wdq, hipStream_t s);
 void launch_quantize_crosskv_fp8(bf16_t* slabs, size_t slab_elems, int n_slabs, const UttPlan* plan, int batch, unsigned char* out8, float* scale,
                                  int dq_in_place, hipStream_t s);
 template <typename T>

@@ -473,11 +473,10 @@ __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const float* __restr
 // directly the B fragment of O^T = V^T P^T (no LDS round trip for P). O^T's C fragment again has one query per
 // lane column, so the online-softmax rescale is lane-local, and each lane ends with 4 consecutive d values of
 // its query row (one 8-byte store).
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+// (a hand-written v_max3_f32 in inline asm would save the canonicalising v_max x, x that fmaxf() costs per MFMA output under IEEE rules, but the hazard recogniser
+//  does not see inline asm: it placed the v_max3 directly behind the MFMA that writes its operands and results depended on timing -- round 6, measured as 21 failing
+//  determinism tests. Plain fmaxf: the compiler still fuses pairs into v_max3.)
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 template <int HD, int CHUNK, int QT>
 __global__ __launch_bounds__(512, (HD * QT <= 128) ? 4 : (HD * QT <= 256 ? 2 : 1)) void attn_bf16_kernel(const AttnArgs a, int n_rows_alloc) {
@@ -587,7 +586,6 @@ __global__ __launch_bounds__(512, (HD * QT <= 128) ? 4 : (HD * QT <= 256 ? 2 : 1
             if (kb + 4 + r >= T || (a.causal && kb + 4 + r > qi)) s1[r] = -INFINITY;
           }
         }
-        // (v_max3 by hand: fmaxf() costs a canonicalising v_max x, x per operand under IEEE rules -- 16 of the 28 maximum instructions of a sub-tile)
         float mx = vmax3(vmax3(s0[0], s0[1], s0[2]), vmax3(s0[3], s1[0], s1[1]), vmax3(s1[2], s1[3], s1[3]));
         mx = vmax3(mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm16, __builtin_bit_cast(int, mx))), mx);
         const float m_old = m_run[t], m_new = vmax3(m_old, mx, __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm32, __builtin_bit_cast(int, mx))));
@@ -1734,6 +1732,52 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __
     if (Wdq) *reinterpret_cast<uint4*>(Wdq + (size_t)n * K + k) = dq;
   }
 }
+// ---- MXFP4 (OCP Microscaling v1.0: e2m1 elements, one e8m0 scale per 32 consecutive k): W [N][K] bf16 -> W4 [N][K / 2] bytes (element 2 i in the low nibble of
+// byte i), S [N][K / 32] e8m0 bytes (+ Wdq [N][K] bf16, the exact dequantisation: 2 significant bits times a power of two). Shared exponent of a block =
+// floor(log2(amax)) - 2 (e2m1's largest exponent), so amax / scale lies in [4, 8) and everything above 6 saturates at 6 (the specification's clamp); elements are
+// rounded to nearest, ties to the even code. A block of zeros takes scale 1. The reference's counterpart: its MatMulNBits Q4 graphs (Optimize_ONNX_Common.py:55-60,
+// README.md:70: Qwen3-ASR is published as q4f32).
+__device__ __forceinline__ unsigned e2m1_code(float v) {        // v >= 0, already divided by the block scale
+  return (unsigned)(v > 0.25f) + (unsigned)(v >= 0.75f) + (unsigned)(v > 1.25f) + (unsigned)(v >= 1.75f) + (unsigned)(v > 2.5f) + (unsigned)(v >= 3.5f) + (unsigned)(v > 5.0f);
+}
+__global__ __launch_bounds__(256) void quantize_rows_mxfp4_kernel(const bf16_t* __restrict__ W, int ld, int K, unsigned char* __restrict__ W4, unsigned char* __restrict__ S,
+                                                                  bf16_t* __restrict__ Wdq) {
+  const int n = blockIdx.x;
+  const bf16_t* row = W + (size_t)n * ld;
+  for (int blk = threadIdx.x; blk * 32 < K; blk += 256) {
+    uint4 raw[4];
+    float m = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { raw[i] = *reinterpret_cast<const uint4*>(row + blk * 32 + i * 8); m = fmaxf(m, amax8(raw[i])); }
+    int eb = (int)((__float_as_uint(m) >> 23) & 0xffu) - 2;            // biased exponent of the scale
+    if (m == 0.0f) eb = 127;
+    eb = max(eb, 1);                                                   // (a block whose amax is below 2^-124 keeps the smallest normal scale)
+    const float inv_s = __uint_as_float((unsigned)(254 - eb) << 23);   // 2^-(eb - 127)
+    const float sc = __uint_as_float((unsigned)eb << 23);
+    S[(size_t)n * (K >> 5) + blk] = (unsigned char)eb;
+    uint4 packed;
+    unsigned pw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned wd[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+      unsigned nib = 0, dqw[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = __uint_as_float(wd[e] << 16), hi = __uint_as_float(wd[e] & 0xffff0000u);
+        const unsigned cl = e2m1_code(fabsf(lo) * inv_s) | ((wd[e] >> 12) & 8u), ch = e2m1_code(fabsf(hi) * inv_s) | ((wd[e] >> 28) & 8u);
+        nib |= (cl | (ch << 4)) << (8 * e);
+        // dequantised value = level * scale, exact in f32 and in bf16 (the widening instruction of the GEMM computes the same product)
+        const float lv[8] = {0.0f, 0.5f, 1.0f, 1.5f, 2.0f, 3.0f, 4.0f, 6.0f};
+        const float dl = lv[cl & 7u] * sc, dh = lv[ch & 7u] * sc;
+        dqw[e] = ((__float_as_uint(dl) >> 16) | ((cl & 8u) << 12)) | ((__float_as_uint(dh) & 0xffff0000u) | ((ch & 8u) << 28));
+      }
+      pw[i] = nib;
+      if (Wdq) *reinterpret_cast<uint4*>(Wdq + (size_t)n * K + blk * 32 + i * 8) = make_uint4(dqw[0], dqw[1], dqw[2], dqw[3]);
+    }
+    packed = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+    *reinterpret_cast<uint4*>(W4 + (size_t)n * (K >> 1) + blk * 16) = packed;
+  }
+}
 // one workgroup per (sequence, slab): the T rows x 64 dims of sequence b inside slab (kv, layer, head) -> bytes + scale[slab][b];
 // dq_in_place: additionally overwrite the bf16 rows with their dequantisation (the bf16 reference of the FP8 path)
 __global__ __launch_bounds__(256) void quantize_crosskv_fp8_kernel(bf16_t* __restrict__ slabs, size_t slab_elems, const UttPlan* __restrict__ plan,
@@ -1760,6 +1804,11 @@ __global__ __launch_bounds__(256) void quantize_crosskv_fp8_kernel(bf16_t* __res
 void launch_quantize_rows_fp8(const bf16_t* W, int ld, int N, int K, unsigned char* W8, float* scale, bf16_t* Wdq, hipStream_t s) {
   ASR_REQUIRE(K % 8 == 0 && ld % 8 == 0, "quantize_rows_fp8: K and the row pitch must be multiples of 8");
   hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(N), dim3(256), 0, s, W, ld, K, W8, scale, Wdq);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_quantize_rows_mxfp4(const bf16_t* W, int ld, int N, int K, unsigned char* W4, unsigned char* S, bf16_t* Wdq, hipStream_t s) {
+  ASR_REQUIRE(K % 32 == 0 && ld % 8 == 0, "quantize_rows_mxfp4: K must be a multiple of the 32-element block (and the row pitch of 8)");
+  hipLaunchKernelGGL(quantize_rows_mxfp4_kernel, dim3(N), dim3(256), 0, s, W, ld, K, W4, S, Wdq);
   HIP_CHECK(hipGetLastError());
 }
 void launch_quantize_crosskv_fp8(bf16_t* slabs, size_t slab_elems, int n_slabs, const UttPlan* plan, int batch, unsigned char* out8, float* scale,

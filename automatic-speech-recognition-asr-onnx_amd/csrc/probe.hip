@@ -280,6 +280,52 @@ extern "C" int asr_probe_decode_gemm(int M, int N, int K, const uint16_t* a, con
   });
 }
 
+// ---- MXFP4 mode (ASR_PRECISION_MXFP4W): the block quantiser and the decode GEMM over nibble weights, on host arrays
+extern "C" int asr_probe_quantize_mxfp4(const uint16_t* w_bf16, int N, int K, uint8_t* out4, uint8_t* scale8, uint16_t* dq_bf16) {
+  return asr_guard([&] {
+    ASR_REQUIRE(w_bf16 && out4 && scale8 && N > 0 && K > 0 && K % 32 == 0, "probe_quantize_mxfp4: bad argument");
+    asr_require_device(0);
+    DeviceBuffer w, q, sc, dq;
+    w.reserve((size_t)N * K * 2, nullptr); q.reserve((size_t)N * K / 2, nullptr); sc.reserve((size_t)N * K / 32, nullptr); dq.reserve((size_t)N * K * 2, nullptr);
+    HIP_CHECK(hipMemcpy(w.ptr, w_bf16, (size_t)N * K * 2, hipMemcpyHostToDevice));
+    launch_quantize_rows_mxfp4(w.as<bf16_t>(), K, N, K, q.as<unsigned char>(), sc.as<unsigned char>(), dq.as<bf16_t>(), nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out4, q.ptr, (size_t)N * K / 2, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(scale8, sc.ptr, (size_t)N * K / 32, hipMemcpyDeviceToHost));
+    if (dq_bf16) HIP_CHECK(hipMemcpy(dq_bf16, dq.ptr, (size_t)N * K * 2, hipMemcpyDeviceToHost));
+    w.release(); q.release(); sc.release(); dq.release();
+  });
+}
+
+// out[M][N] (f32) = decode GEMM of a[M][K] (bf16) with the MXFP4 weights (w4 [N][K / 2], scale8 [N][K / 32]); fold != 0: LayerNorm folded in, column sums
+// taken from w_dq (the dequantised bf16 copy, as the session does)
+extern "C" int asr_probe_decode_gemm_mxfp4(int M, int N, int K, const uint16_t* a, const uint8_t* w4, const uint8_t* scale8, const uint16_t* w_dq,
+                                           const float* bias, int fold, float* out) {
+  return asr_guard([&] {
+    ASR_REQUIRE(a && out && w4 && scale8 && !(fold && !w_dq), "probe_decode_gemm_mxfp4: bad argument");
+    asr_require_device(0);
+    DeviceBuffer da, dw, dw4, dsc, db, dcs, dout, ws, cnt;
+    da.reserve((size_t)64 * K * 2, nullptr); dout.reserve((size_t)64 * N * 4, nullptr); ws.reserve((size_t)16 << 20, nullptr); cnt.reserve(4096 * 4, nullptr);
+    HIP_CHECK(hipMemset(da.ptr, 0, (size_t)64 * K * 2)); HIP_CHECK(hipMemset(cnt.ptr, 0, 4096 * 4));
+    HIP_CHECK(hipMemcpy(da.ptr, a, (size_t)M * K * 2, hipMemcpyHostToDevice));
+    DecGemmArgs g;
+    g.A = da.as<bf16_t>(); g.lda = K; g.ldw = K; g.M = M; g.N = N; g.K = K; g.out_f32 = dout.as<float>(); g.ld_out_f32 = N;
+    g.ws = ws.as<float>(); g.ws_bytes = ws.cap; g.cnt = cnt.as<int32_t>();
+    dw4.reserve((size_t)N * K / 2, nullptr); dsc.reserve((size_t)N * K / 32, nullptr);
+    HIP_CHECK(hipMemcpy(dw4.ptr, w4, (size_t)N * K / 2, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(dsc.ptr, scale8, (size_t)N * K / 32, hipMemcpyHostToDevice));
+    g.W4 = dw4.as<unsigned char>(); g.w_scale4 = dsc.as<unsigned char>();
+    if (bias) { db.reserve((size_t)N * 4, nullptr); HIP_CHECK(hipMemcpy(db.ptr, bias, (size_t)N * 4, hipMemcpyHostToDevice)); g.bias = db.as<float>(); }
+    if (fold) {
+      dw.reserve((size_t)N * K * 2, nullptr); HIP_CHECK(hipMemcpy(dw.ptr, w_dq, (size_t)N * K * 2, hipMemcpyHostToDevice));
+      dcs.reserve((size_t)N * 4, nullptr); launch_colsum_bf16(dw.as<bf16_t>(), K, N, K, dcs.as<float>(), nullptr); g.colsum = dcs.as<float>();
+    }
+    launch_decode_gemm(g, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out, dout.ptr, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    for (DeviceBuffer* b : {&da, &dw, &dw4, &dsc, &db, &dcs, &dout, &ws, &cnt}) b->release();
+  });
+}
+
 // FP8 matrix-pipe GEMM on host arrays (csrc/gemm_fp8.hip): a8 [M][K], w8 [N][K] e4m3 bytes, w_scale [N], bias [N]; either out8 [M][N] (act, bytes) or
 // out_f32 [M][N] (+ add [M][N]). iters > 0: also times that many launches (microseconds per launch in *us).
 extern "C" int asr_probe_gemm_fp8(int M, int N, int K, const uint8_t* a8, const uint8_t* w8, const float* w_scale, float a_scale, const float* bias,

@@ -22,7 +22,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct EncLayer { const void *wqkv, *wo, *w1, *w2; const float *bqkv, *bo, *b1, *b2; };
 struct DecLayer { const void *wqkv, *wo, *wcq, *wco, *w1, *w2; const float *bqkv, *bo, *bcq, *bco, *b1, *b2; };
-struct Dec8Layer { const unsigned char* w[6]; const float* s[6]; };
+struct Dec8Layer { const unsigned char* w[6]; const float* s[6]; const unsigned char* s4[6]; };      // FP8W: bytes + per-column scales; MXFP4W: nibbles (w) + e8m0 block scales (s4)
 struct Enc8Layer { const unsigned char *w1, *w2; const float *s1, *s2; };     // FP8MM mode: the encoder FFN pair as e4m3 bytes + per-row scales        // FP8 mode: e4m3 bytes + per-column scales of wqkv, wo, wcq, wco, w1, w2
 
 struct WhSession : asr_session {
@@ -75,6 +75,7 @@ struct WhSession : asr_session {
   bool fp8_mm = false;
   std::vector<Enc8Layer> enc8;
   DeviceBuffer d_ew8, d_ewscale, d_h8, d_ffn8;
+  bool fp4 = false;                    // precision mode ASR_PRECISION_MXFP4W (opt-in): FP8W with the decoder projections as MXFP4 (e2m1 + e8m0 per 32 k) instead of e4m3
   bool fp8 = false, fp8_fake = false, fp8_weights = true, fp8_kv = true;     // ASR_FP8_WEIGHTS=0 / ASR_FP8_KV=0: leave that half in bf16 (to price the halves separately)
   std::vector<Dec8Layer> dec8;
   DeviceBuffer d_w8, d_wscale, d_wdq, d_cross8, d_cscale;
@@ -181,22 +182,26 @@ void WhSession::init() {
     }
   }
   if (fp8 && fp8_weights) {
-    ASR_REQUIRE(d % 256 == 0 && dff % 256 == 0, "whisper: FP8 mode needs d_model and d_ffn to be multiples of 256");
+    ASR_REQUIRE(d % 256 == 0 && dff % 256 == 0, "whisper: FP8 / MXFP4 mode needs d_model and d_ffn to be multiples of 256");
     const size_t w_elems = (size_t)6 * d * d + (size_t)2 * d * dff, n_scales = (size_t)7 * d + dff;      // per layer
-    d_w8.reserve(Ld * w_elems, stream); d_wscale.reserve(Ld * n_scales * 4, stream); d_wdq.reserve(Ld * w_elems * 2, stream);
+    // MXFP4W: d_w8 holds the nibbles (half a byte per element), d_wscale the e8m0 block scales (one byte per 32 elements)
+    d_w8.reserve(fp4 ? Ld * w_elems / 2 : Ld * w_elems, stream); d_wscale.reserve(fp4 ? Ld * w_elems / 32 : Ld * n_scales * 4, stream); d_wdq.reserve(Ld * w_elems * 2, stream);
     dec8.resize(Ld);
     for (int i = 0; i < Ld; ++i) {
       DecLayer& L = dec[i];
       const void** slot[6] = {&L.wqkv, &L.wo, &L.wcq, &L.wco, &L.w1, &L.w2};
       const int Ns[6] = {3 * d, d, d, d, dff, d}, Ks[6] = {d, d, d, d, d, dff};
-      unsigned char* w8 = d_w8.as<unsigned char>() + i * w_elems;
+      unsigned char* w8 = d_w8.as<unsigned char>() + (fp4 ? i * w_elems / 2 : i * w_elems);
       bf16_t* dq = d_wdq.as<bf16_t>() + i * w_elems;
       float* sc = d_wscale.as<float>() + i * n_scales;
+      unsigned char* sc4 = d_wscale.as<unsigned char>() + i * w_elems / 32;
       for (int j = 0; j < 6; ++j) {
-        launch_quantize_rows_fp8((const bf16_t*)*slot[j], Ks[j], Ns[j], Ks[j], w8, sc, dq, stream);
-        dec8[i].w[j] = w8; dec8[i].s[j] = sc;
+        const size_t ne = (size_t)Ns[j] * Ks[j];
+        if (fp4) launch_quantize_rows_mxfp4((const bf16_t*)*slot[j], Ks[j], Ns[j], Ks[j], w8, sc4, dq, stream);
+        else launch_quantize_rows_fp8((const bf16_t*)*slot[j], Ks[j], Ns[j], Ks[j], w8, sc, dq, stream);
+        dec8[i].w[j] = w8; dec8[i].s[j] = sc; dec8[i].s4[j] = sc4;
         *slot[j] = dq;                                     // from here on "the weights" are the dequantised copies
-        w8 += (size_t)Ns[j] * Ks[j]; dq += (size_t)Ns[j] * Ks[j]; sc += Ns[j];
+        w8 += fp4 ? ne / 2 : ne; dq += ne; sc += Ns[j]; sc4 += ne / 32;
       }
     }
   }
@@ -505,7 +510,8 @@ void WhSession::enqueue_step(const int32_t* ids_dev, int n, bool is_prefill, boo
     ProfScope ps(prof, "dec_gemm", st);
     DecGemmArgs g;
     g.A = (const bf16_t*)A + (size_t)r0 * lda; g.lda = lda; g.W = (const bf16_t*)Wt; g.ldw = K; g.M = Rc; g.plan_M = plan_rows; g.N = N; g.K = K; g.bias = bias; g.colsum = colsum;
-    if (w8) { g.W = nullptr; g.W8 = dec8[layer].w[wi]; g.w_scale = dec8[layer].s[wi]; }
+    if (w8 && fp4) { g.W = nullptr; g.W4 = dec8[layer].w[wi]; g.w_scale4 = dec8[layer].s4[wi]; }
+    else if (w8) { g.W = nullptr; g.W8 = dec8[layer].w[wi]; g.w_scale = dec8[layer].s[wi]; }
     g.add = add ? add + (size_t)r0 * d : nullptr; g.ld_add = d; g.act = act_; g.out_f32 = of32 ? of32 + (size_t)r0 * d : nullptr; g.ld_out_f32 = d;
     g.out_lo = olo ? (bf16_t*)olo + (size_t)r0 * ld_lo : nullptr; g.ld_out_lo = ld_lo;
     g.ws = reinterpret_cast<float*>(static_cast<unsigned char*>(d_skws.ptr) + (size_t)ci * SK_WS_BYTES); g.ws_bytes = SK_WS_BYTES;
@@ -769,14 +775,16 @@ extern "C" int asr_whisper_create(const asr_whisper_config* cfg, const void* are
                                   int device_id, int precision, asr_session** out) {
   return asr_guard([&] {
     ASR_REQUIRE(cfg && arena && out, "whisper_create: null argument");
-    ASR_REQUIRE(precision == ASR_PRECISION_BF16 || precision == ASR_PRECISION_F32 || precision == ASR_PRECISION_FP8W || precision == ASR_PRECISION_FP8MM, "whisper_create: bad precision %d", precision);
+    ASR_REQUIRE(precision == ASR_PRECISION_BF16 || precision == ASR_PRECISION_F32 || precision == ASR_PRECISION_FP8W || precision == ASR_PRECISION_FP8MM ||
+                precision == ASR_PRECISION_MXFP4W, "whisper_create: bad precision %d", precision);
     asr_require_device(device_id);
     WhSession* s = new WhSession();
     try {
       s->kind = 2;
       s->device = device_id;
       asr_tenant_attach(s);
-      s->fp8 = precision == ASR_PRECISION_FP8W || precision == ASR_PRECISION_FP8MM;
+      s->fp4 = precision == ASR_PRECISION_MXFP4W;
+      s->fp8 = precision == ASR_PRECISION_FP8W || precision == ASR_PRECISION_FP8MM || s->fp4;
       s->fp8_mm = precision == ASR_PRECISION_FP8MM;
       s->precision = s->fp8 ? ASR_PRECISION_BF16 : precision;        // FP8 mode = bf16 mode with byte-wide decoder weights and cross-K/V
       s->cfg = *cfg;

@@ -7,7 +7,7 @@ from typing import Sequence
 import numpy as np
 
 from . import _lib
-from .arena import PRECISION_BF16, PRECISION_F32, PRECISION_FP8MM, PRECISION_FP8W, build_sensevoice_arena
+from .arena import PRECISION_BF16, PRECISION_F32, PRECISION_FP8MM, PRECISION_FP8W, PRECISION_MXFP4W, build_sensevoice_arena
 from .config import SenseVoiceConfig
 
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -258,7 +258,7 @@ class WhisperSession(_Session):
     def from_checkpoint(cls, cfg, ck, precision=PRECISION_BF16, device_id=0, suppress_tokens=None, begin_suppress_tokens=(),
                         gelu_tanh=False):
         from .arena import build_whisper_arena
-        arena_precision = PRECISION_BF16 if precision in (PRECISION_FP8W, PRECISION_FP8MM) else precision
+        arena_precision = PRECISION_BF16 if precision in (PRECISION_FP8W, PRECISION_FP8MM, PRECISION_MXFP4W) else precision
         return cls(cfg, build_whisper_arena(cfg, ck, arena_precision, suppress_tokens, begin_suppress_tokens), precision, device_id, gelu_tanh)
 
     def encode_packed(self, audio, offsets, audio_device_ptr: int | None = None) -> np.ndarray:

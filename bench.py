@@ -310,6 +310,7 @@ def main():
     ap.add_argument("--streams", type=int, default=256, help="mixed: concurrent Paraformer streams per GPU")
     ap.add_argument("--beam", type=int, default=1, help="qwen / mixed: beam width (1 = greedy; BASELINE.json configs[4] names beam 5)")
     ap.add_argument("--fp8mm", action="store_true", help="whisper: opt-in precision mode ASR_PRECISION_FP8MM (FP8W + the encoder's FFN pair on the FP8 matrix pipe); a secondary figure, never the headline")
+    ap.add_argument("--mxfp4", action="store_true", help="whisper: opt-in precision mode ASR_PRECISION_MXFP4W (decoder projections as OCP MXFP4, cross-K/V as e4m3); a secondary figure, never the headline")
     ap.add_argument("--fp8", action="store_true", help="whisper / qwen: opt-in precision mode ASR_PRECISION_FP8W (decoder projections -- Whisper: and cross-K/V -- as e4m3 bytes); a secondary figure, never the headline")
     ap.add_argument("--decode-tokens", type=int, default=0, help="whisper: generated tokens per utterance (default 4 per audio second)")
     ap.add_argument("--cpu-leg", type=int, default=0, help=argparse.SUPPRESS)        # child process of the CPU baseline's every-core leg
@@ -910,7 +911,7 @@ def main_paraformer_streaming(args):
         dist.destroy_process_group()
 
 
-def whisper_algorithmic(cfg, n_samples, B, n_tokens, prompt_len, fp8=False):
+def whisper_algorithmic(cfg, n_samples, B, n_tokens, prompt_len, fp8=False, weight_bits=None):
     """Algorithmic FLOPs / bytes: encoder GEMM 2MNK + attention 4 T^2 d per layer + conv stem + cross-KV
     projection; decode: weights read once per step for the batch + cross-KV + self-KV streamed per utterance."""
     d, dff, Le, Ld, T = cfg.d_model, cfg.d_ffn, cfg.n_enc_layers, cfg.n_dec_layers, cfg.n_enc_pos(n_samples)
@@ -921,7 +922,7 @@ def whisper_algorithmic(cfg, n_samples, B, n_tokens, prompt_len, fp8=False):
     dec_tok = 2.0 * dec_w_params + Ld * 4.0 * T * d
     step_bytes = 2.0 * dec_w_params + B * Ld * 2 * T * d * 2.0          # bf16 weights once per step + bf16 cross-KV per utterance
     if fp8:                                                              # FP8W mode: the decoder layers' projections and the cross-K/V are bytes (proj_out stays bf16)
-        step_bytes = 1.0 * (dec_w_params - cfg.vocab * d) + 2.0 * cfg.vocab * d + B * Ld * 2 * T * d * 1.0
+        step_bytes = (weight_bits / 8.0 if weight_bits else 1.0) * (dec_w_params - cfg.vocab * d) + 2.0 * cfg.vocab * d + B * Ld * 2 * T * d * 1.0      # (MXFP4W: 4.25 bits per weight)
     return {"encoder_flops": B * enc, "decode_flops_per_step": B * dec_tok, "decode_bytes_per_step": step_bytes}
 
 
@@ -954,8 +955,8 @@ def main_whisper(args):
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t0
     blob = None
-    if args.fp8mm: args.fp8 = True
-    prec = arena.PRECISION_FP8MM if args.fp8mm else arena.PRECISION_FP8W if args.fp8 else arena.PRECISION_BF16
+    if args.fp8mm or args.mxfp4: args.fp8 = True
+    prec = arena.PRECISION_FP8MM if args.fp8mm else arena.PRECISION_MXFP4W if args.mxfp4 else arena.PRECISION_FP8W if args.fp8 else arena.PRECISION_BF16
     sess = eng.WhisperSession(cfg, arena_dev, prec, local_rank, arena_device_ptr=arena_dev.data_ptr(), arena_bytes=arena_dev.numel())
     audio_np = ckm.synth_audio("unit", B, n_samples, seed=1234 + rank)
     audio_dev = torch.from_numpy(audio_np).to(device)
@@ -1030,7 +1031,7 @@ def main_whisper(args):
     prof = sess.profile_read()
     sess.profile(False)
     if rank == 0:
-        alg = whisper_algorithmic(cfg, n_samples, B, n_tok, 4, fp8=args.fp8)
+        alg = whisper_algorithmic(cfg, n_samples, B, n_tok, 4, fp8=args.fp8, weight_bits=4.25 if args.mxfp4 else None)
         audio_s = world * B * args.seconds
         kernels = {k: {"ms_per_step": round(v["total_ms"], 3), "launches_per_step": v["launches"]}
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
@@ -1046,12 +1047,13 @@ def main_whisper(args):
         t_dec = t_parts["decode"] / args.steps
         out = {
             "metric": "audio-sec/s, Whisper-large-v3, %g s @ 16 kHz chunks, batch %d per GPU, greedy, %d tokens/utterance" % (args.seconds, B, n_tok)
-                      + (" [opt-in FP8W mode: decoder projections + cross-K/V stored as e4m3, NOT the reference's precision]" if args.fp8 else "")
+                      + (" [opt-in MXFP4W mode: decoder projections stored as OCP MXFP4 (e2m1 + e8m0 per 32), cross-K/V as e4m3, NOT the reference's precision]" if args.mxfp4 else
+                         " [opt-in FP8W mode: decoder projections + cross-K/V stored as e4m3, NOT the reference's precision]" if args.fp8 else "")
                       + (" [+ FP8MM: encoder fc1 / fc2 on the FP8 matrix pipe, e4m3 activations]" if args.fp8mm else ""),
             "value": round(audio_s * args.steps / elapsed, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 (e4m3 storage of decoder weights and cross-K/V)" if args.fp8 else "bf16", "data": "synthetic",
-            "config": {"workload": "Whisper-large-v3 %s (1.54 B params), batch=%d x %g s per GPU, encoder + cross-KV + prefill(4) + %d greedy decode steps, audio resident in HBM" % ("bf16 + FP8MM" if args.fp8mm else "bf16 + FP8W" if args.fp8 else "bf16", B, args.seconds, n_tok - 1),
+            "dtype": "bf16 (MXFP4 storage of decoder weights, e4m3 cross-K/V)" if args.mxfp4 else "bf16 (e4m3 storage of decoder weights and cross-K/V)" if args.fp8 else "bf16", "data": "synthetic",
+            "config": {"workload": "Whisper-large-v3 %s (1.54 B params), batch=%d x %g s per GPU, encoder + cross-KV + prefill(4) + %d greedy decode steps, audio resident in HBM" % ("bf16 + FP8MM" if args.fp8mm else "bf16 + MXFP4W" if args.mxfp4 else "bf16 + FP8W" if args.fp8 else "bf16", B, args.seconds, n_tok - 1),
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "kv_cache": "self-KV paged (16-position pages, block table shared by the layers); cross-K/V ragged extents" if os.environ.get("ASR_KV_PAGED", "1") != "0" else "contiguous extents (ASR_KV_PAGED=0)"},
             "rtf": round(elapsed / (audio_s * args.steps), 7),
@@ -1090,7 +1092,7 @@ def main_whisper(args):
             sess.encode_packed(None, offsets, audio_device_ptr=audio_dev.data_ptr())
             _, lg = sess.prefill(prompt)
             ref0 = first["logits"][0][0]
-            out["parity_spotcheck"] = {"what": "prefill logits of utterance 0, %s engine vs f32 oracle" % ("FP8MM" if args.fp8mm else "FP8W" if args.fp8 else "bf16"), "max_abs_diff": round(float(np.abs(lg[0] - ref0).max()), 4),
+            out["parity_spotcheck"] = {"what": "prefill logits of utterance 0, %s engine vs f32 oracle" % ("FP8MM" if args.fp8mm else "MXFP4W" if args.mxfp4 else "FP8W" if args.fp8 else "bf16"), "max_abs_diff": round(float(np.abs(lg[0] - ref0).max()), 4),
                                        "logit_abs_max": round(float(np.abs(ref0).max()), 3)}
         print(json.dumps(out))
     if world > 1:

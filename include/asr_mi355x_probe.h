@@ -43,6 +43,10 @@ const char* asr_probe_last_kernel(void);      /* kernel family of the last asr_p
  * dequantisation dq_bf16[N][K]. Decode GEMM on host arrays: out[M][N] f32 = a[M][K] (bf16, M <= 64) x either w_bf16 or (w8, scale);
  * fold != 0 applies the folded LayerNorm (column sums from w_bf16: pass the dequantised copy next to byte weights). */
 int asr_probe_quantize_fp8(const uint16_t* w_bf16, int N, int K, uint8_t* out8, float* scale, uint16_t* dq_bf16);
+/* MXFP4 mode: block quantiser (out4 [N][K / 2] nibbles, scale8 [N][K / 32] e8m0 bytes, dq the exact bf16 dequantisation) and the decode GEMM over them */
+int asr_probe_quantize_mxfp4(const uint16_t* w_bf16, int N, int K, uint8_t* out4, uint8_t* scale8, uint16_t* dq_bf16);
+int asr_probe_decode_gemm_mxfp4(int M, int N, int K, const uint16_t* a, const uint8_t* w4, const uint8_t* scale8, const uint16_t* w_dq, const float* bias,
+                                int fold, float* out);
 int asr_probe_decode_gemm(int M, int N, int K, const uint16_t* a, const uint16_t* w_bf16, const uint8_t* w8, const float* scale,
                           const float* bias, int fold, float* out);
 

@@ -34,7 +34,7 @@ def test_precision_modes_agree_between_header_and_host():
     vals = dict((k.strip(), int(v)) for k, v in (item.split("=") for item in m.group(1).split(",")))
     arena = sub("arena")
     assert vals == {"ASR_PRECISION_BF16": arena.PRECISION_BF16, "ASR_PRECISION_F32": arena.PRECISION_F32, "ASR_PRECISION_FP8W": arena.PRECISION_FP8W,
-                    "ASR_PRECISION_FP8MM": arena.PRECISION_FP8MM}
+                    "ASR_PRECISION_FP8MM": arena.PRECISION_FP8MM, "ASR_PRECISION_MXFP4W": arena.PRECISION_MXFP4W}
 
 
 def test_probe_library_is_separate_from_the_product_abi():

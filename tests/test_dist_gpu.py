@@ -46,19 +46,30 @@ def test_collectives_in_flight_never_meet_a_cluster_kernel(rccl_world1, capfd):
     ref = sess.run(audios, langs)
     sess.run(audios, langs)                                                    # second pass: the captured graph of the block path
     assert sess.sanm_stats() == {"giveups": 0, "cooldown": 0, "foreign_diverted": 0, "block_kernel": True}
-    # the cluster-free path a diverted pass takes gives the same tokens (bf16 accumulation order differs: compare through the quiet four-launch run)
+    # a diverted pass takes the four-launch path: exactly the tokens of a session that never uses the block kernel (other K order than the block path:
+    # on this random head near-tie frames differ between the two paths, so each path is compared with its own quiet run)
+    os.environ["ASR_SANM_BLOCK"] = os.environ["ASR_SANM_TILES"] = "0"
+    try:
+        quiet4 = eng.SenseVoiceSession.from_checkpoint(cfg, ck, precision=BF16)
+    finally:
+        del os.environ["ASR_SANM_BLOCK"], os.environ["ASR_SANM_TILES"]
+    ref4 = quiet4.run(audios, langs)
+    del quiet4
     with dp.foreign_section(dev):
         inside = sess.run(audios, langs)
     st = sess.sanm_stats()
     assert st["foreign_diverted"] == 1 and st["giveups"] == 0
-    agree = sum(int(np.array_equal(a, b)) for a, b in zip(inside, ref))
-    assert agree >= B - 2, agree                                               # (other K order on the four-launch path: a near-tie frame may flip)
+    assert all(np.array_equal(a, b) for a, b in zip(inside, ref4))
     capfd.readouterr()
-    g0 = dp.foreign_stats(dev)
     stop = threading.Event()
     n_coll = [0]
     payload = torch.arange(1 << 20, dtype=torch.float32, device=dev)           # 4 MB: a collective that lives for a while
     side = torch.cuda.Stream(device=dev)
+    with dp.foreign_section(dev):                                              # (the first collective builds the communicator: seconds, not part of what is tested)
+        with torch.cuda.stream(side):
+            dist.all_reduce(payload)
+            dist.broadcast(payload, 0)
+    g0 = dp.foreign_stats(dev)
 
     def collectives():
         torch.cuda.set_device(0)
@@ -78,7 +89,9 @@ def test_collectives_in_flight_never_meet_a_cluster_kernel(rccl_world1, capfd):
     t = threading.Thread(target=collectives)
     t.start()
     try:
-        for it in range(iters):
+        it = -1
+        while it + 1 < iters or (n_coll[0] < 10 and it < 20 * iters):           # at least `iters` passes, and until ten collective rounds ran beside them
+            it += 1
             t0 = time.perf_counter()
             got = sess.run(audios, langs)
             lat.append(time.perf_counter() - t0)
@@ -99,8 +112,8 @@ def test_collectives_in_flight_never_meet_a_cluster_kernel(rccl_world1, capfd):
     assert n_coll[0] >= 5, n_coll                                               # the collectives really ran beside the passes
     d = {k: g1[k] - g0[k] for k in g0}
     assert d["sections"] >= n_coll[0]                                          # one section per bracketed group (+ those dist.py opens itself)
-    assert d["cluster_passes_admitted"] + d["cluster_passes_diverted"] == iters
-    print(f"{iters} block-kernel passes beside {n_coll[0]} collective rounds: {d['cluster_passes_diverted']} passes diverted to the cluster-free path, "
+    assert d["cluster_passes_admitted"] + d["cluster_passes_diverted"] == it + 1
+    print(f"{it + 1} block-kernel passes beside {n_coll[0]} collective rounds: {d['cluster_passes_diverted']} passes diverted to the cluster-free path, "
           f"{d['sections_that_waited']} sections waited for a pass; median pass {np.median(lat) * 1e3:.2f} ms, max {max(lat) * 1e3:.2f} ms")
 
 

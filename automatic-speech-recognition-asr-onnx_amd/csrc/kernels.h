@@ -221,6 +221,7 @@ struct SanmBlockArgs {
   int times_layer = 0;                                             // ... which block of the launch `times` stamps
   int st_in_n = 16;                                                // partials per row in st_in: 16 (a GEMM epilogue's 32-column groups) or 4 (the 8-wave kernel's own records, one per workgroup, slots 0..3)
   int opt = 0;                                                     // tuning switches of the 8-wave kernel (ASR_SANM_BLOCK8_OPT): 1 = no L2 warm-up loads, 2 = deeper W fragment queues, 4 = always acquire-fence at an exchange (default: clusters that share an XCD read the payload with sc1 loads instead)
+  int ffnk = 0;                                                    // round 6: FFN-2 K-split over the workgroup's own hidden columns, f16 partials exchanged instead of hid (needs the matching wpack order; `hid` then holds the partial images)
   const void* wpack = nullptr;                                     // round-4 kernel (sanm_block8.hip): fragment-major copy of the four matrices (launch_sanm_block8_pack)
   const bf16_t* x_lo; const float2* st_in;                         // block input rows (bf16) + their row statistics [rows][16] (null: derived in the kernel)
   float* x;                                                        // residual stream f32 [rows][512]: read (phase B) and overwritten (phase D) in place
@@ -237,7 +238,7 @@ bool sanm_block_supported(int max_T, int d_head, int n_heads, int d, int d_ffn, 
 int sanm_block_max_utts();                                         // windows one launch can take (all workgroups co-resident)
 void launch_sanm_block8(const SanmBlockArgs& a, hipStream_t s);       // round-4 form: 8 waves, chunked A operand, register-streamed packed weights (needs a.wpack)
 size_t sanm_block8_pack_bytes();                                      // bytes of one block's packed weights
-void launch_sanm_block8_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, hipStream_t s);
+void launch_sanm_block8_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, bool ffnk, hipStream_t s);
 void launch_rows_to_bf16(const float* x, bf16_t* y, size_t n, hipStream_t s);     // f32 -> bf16 (RNE) copy, n a multiple of 8
 void launch_sanm_qkv_attn(const SanmFusedArgs& a, hipStream_t s);
 

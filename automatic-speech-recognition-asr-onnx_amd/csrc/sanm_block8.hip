@@ -114,6 +114,22 @@ __device__ __forceinline__ void stats8(const uint4& w, float& s1, float& s2) {
   }
 }
 
+// f16 images of the FFN-2 partials (FFNK form): 8 f32 -> 16 bytes (round to nearest even) and back
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ uint4 pack8_f16(const float (&v)[8]) {
+  uint4 w;
+  w.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{v[0], v[1]}, f16x2_t)); w.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{v[2], v[3]}, f16x2_t));
+  w.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{v[4], v[5]}, f16x2_t)); w.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{v[6], v[7]}, f16x2_t));
+  return w;
+}
+__device__ __forceinline__ void add8_f16(float (&v)[8], const u32x4_t w) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const f32x2_t f = __builtin_convertvector(__builtin_bit_cast(f16x2_t, (uint32_t)w[e]), f32x2_t);
+    v[2 * e] += f[0]; v[2 * e + 1] += f[1];
+  }
+}
+
 template <int... I, typename F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
@@ -423,7 +439,7 @@ __device__ __forceinline__ bool cluster_plain_stores(const unsigned* place, int 
 #define STAMP(k) do { if (a->times && li == a->times_layer && threadIdx.x == 0 && !((a->opt & 2048) && (k) >= 4 && (k) <= 7)) a->times[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 #define STAMP_A(k) do { if (a->times && li == a->times_layer && threadIdx.x == 0 && (a->opt & 2048)) a->times[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 
-template <int PFA, int PFB, int PFC, int PFD, int ABL>
+template <int PFA, int PFB, int PFC, int PFD, int ABL, int FFNK>
 __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_byval) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid_0 = threadIdx.x, wave_0 = __builtin_amdgcn_readfirstlane(tid_0 >> 6);
@@ -832,20 +848,152 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
           for (int e = 0; e < 8; ++e) v[e] = fmaxf((v[e] - mr.x * c8[e]) * mr.y + b8[e], 0.0f);
           const uint4 pk = pack8(v);
           *reinterpret_cast<uint4*>(slot + row * 256 + (((8 * (wave & 1) + 4 * p + fgrp) ^ (row & 15)) << 4)) = pk;
-          if (direct && i < n_act) store16_wt(himg + (size_t)(wave >> 1) * n_act * 4096 + row * 256 + (((8 * (wave & 1) + 4 * p + fgrp) ^ (row & 15)) << 4), pk, plain);
+          if constexpr (!FFNK) { if (direct && i < n_act) store16_wt(himg + (size_t)(wave >> 1) * n_act * 4096 + row * 256 + (((8 * (wave & 1) + 4 * p + fgrp) ^ (row & 15)) << 4), pk, plain); }
         }
       }
     }
-    if (!direct) {
-      __syncthreads();
+    if constexpr (!FFNK) {
+      if (!direct) {
+        __syncthreads();
 #pragma unroll
-      for (int c = 0; c < 4; ++c) store_chunk_img(himg + (size_t)c * n_act * 4096, smem + c * CH, n_act * 4, wave, lane, plain);
+        for (int c = 0; c < 4; ++c) store_chunk_img(himg + (size_t)c * n_act * 4096, smem + c * CH, n_act * 4, wave, lane, plain);
+      }
+      STAMP(10);
+      publish(flags + 2);
+    } else {
+      STAMP(10);
+      __syncthreads();                                         // FFNK: hid never leaves the CU -- the four own chunks are phase D's whole A operand
     }
-    STAMP(10);
-    publish(flags + 2);
     STAMP(11);
   }
 
+  if constexpr (FFNK) {
+  // ================================================================ phase D, K-split form (round 6): FFN-2 over the workgroup's OWN 512 hidden columns for ALL 512 output
+  // columns -- hid (590 KB per window) never crosses the fabric; what does is the [144][512] partial: the three foreign 128-column slabs go out as f16 chunk images
+  // (110 KB per workgroup out and in, against 147 KB out + 442 KB in for hid), the sum of the four partials + bias + x1 is this workgroup's slab of the block output.
+  // f16, not bf16: three more mantissa bits keep the hand-over below the bf16 rounding the path already has (a partial is |x| ~ 1..100, far inside f16's range).
+  // r04's probe of this split exchanged f32 partials (221 KB out per workgroup: write-path-bound, slower than hid); r05's 2 x 2 form added a row split that doubled
+  // the W stream. This form keeps phase C's tiles (144 x 64 per wave) and phase C's W rate.
+  {
+    a = phase_args();
+    L = a->layers + li;
+    lane = opaque(tid & 63); frow = lane & 15; fgrp = lane >> 4;
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(L->wpack) + PK_W2 + (size_t)(h * NW + wave) * PK_W2_WAVE + lane * 16;
+    bf16x8_t wf[PFC][4];
+    w_prefetch<4, PFC>(wf, wp);
+    f32x4_t acc[RF][4];
+#pragma unroll
+    for (int i = 0; i < RF; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    chunk_gemm<4, 4, 4, PFC, 4, 0, ABL>(smem, wp, wf, 0, lane, acc, [&](int) __attribute__((always_inline)) {}, [&]() __attribute__((always_inline)) {});
+    STAMP(12);
+    __syncthreads();                                          // every wave is done reading the hid chunks: slots 2, 3 take the own slab, slot 0 the block output
+    // ---- partial out: this wave holds output columns 64 wave .. + 63 = slab (wave >> 1); the own slab -> LDS (f32, 32-byte granules swizzled by the row), the others ->
+    //      image (destination slab, source h) of the exchange buffer, f16, write-through
+    const int dst_h = wave >> 1;
+    const bool plain = cluster_plain_stores(place, a->opt);
+    unsigned char* pimg = reinterpret_cast<unsigned char*>(a->hid + (size_t)row0 * DFF) + (size_t)(4 * dst_h + h) * n_act * 4096;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int i = 0; i < RF; ++i) {
+        const int row = i * 16 + frow;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * p][r]; v[4 + r] = acc[i][2 * p + 1][r]; }
+        const int gi = 8 * (wave & 1) + 4 * p + fgrp;          // 8-column group inside the 128-column slab
+        if (dst_h == h) {
+          float* o = reinterpret_cast<float*>(smem + RED + row * 512 + ((gi ^ (row & 15)) << 5));
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else if (i < n_act) {
+          store16_wt(pimg + row * 256 + ((gi ^ (row & 15)) << 4), pack8_f16(v), plain);
+        }
+      }
+    }
+    // the x1 rows this wave finishes (fragments 0..4 of K-half 0, 5..8 of K-half 1; written by this very lane in phase B): they arrive under the publish
+    float4 x1r[5][2];
+    {
+      const float* xr0 = a->x + (size_t)row0 * D + h * HD + cg * 32 + fgrp * 8;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int i = kh == 0 ? k : min(5 + k, RF - 1);
+        const float* xr = xr0 + (size_t)min(i * 16 + frow, rows_left - 1) * D;
+        x1r[k][0] = *reinterpret_cast<const float4*>(xr); x1r[k][1] = *reinterpret_cast<const float4*>(xr + 4);
+      }
+    }
+    publish(flags + 2);                                       // (its barrier also closes the own slab in LDS)
+    STAMP(13);
+    const bool nofence = cluster_shares_l2(place, a->opt);
+    consume(flags + 2, NH, a->err, !nofence);
+    // ---- the three foreign partials of the own slab: 16 bytes per (image, row fragment), sc1 loads (they bypass this CU's L1), one wait for all of them
+    const int n = cg * 32 + fgrp * 8, gi = cg * 4 + fgrp;
+    u32x4_t fp[3][5];
+    {
+      const unsigned char* own = reinterpret_cast<const unsigned char*>(a->hid + (size_t)row0 * DFF) + (size_t)(4 * h) * n_act * 4096;
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        const unsigned char* img = own + (size_t)((h + 1 + s3) & 3) * n_act * 4096;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const int i = kh == 0 ? k : min(5 + k, RF - 1);
+          const int row = min(i * 16 + frow, n_act * 16 - 1);
+          const unsigned char* src = img + row * 256 + ((gi ^ (row & 15)) << 4);
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(fp[s3][k]) : "v"(src) : "memory");
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(fp[0][0]), "+v"(fp[0][1]), "+v"(fp[0][2]), "+v"(fp[0][3]), "+v"(fp[0][4]), "+v"(fp[1][0]), "+v"(fp[1][1]), "+v"(fp[1][2]), "+v"(fp[1][3]),
+                   "+v"(fp[1][4]), "+v"(fp[2][0]), "+v"(fp[2][1]), "+v"(fp[2][2]), "+v"(fp[2][3]), "+v"(fp[2][4]) :: "memory");
+    }
+    const float4 b0 = *reinterpret_cast<const float4*>(L->b2 + h * HD + n), b1v = *reinterpret_cast<const float4*>(L->b2 + h * HD + n + 4);
+    const float b8[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
+    float* xo = a->x + (size_t)row0 * D + h * HD + n;
+    bf16_t* xl = a->x_lo_out + (size_t)row0 * D + h * HD + n;
+    unsigned char* ximg = reinterpret_cast<unsigned char*>(a->x_lo_out + (size_t)row0 * D) + (size_t)h * n_act * 4096;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int i = kh == 0 ? k : 5 + k;
+      if (i < n_act && i < RF) {
+        const int row = i * 16 + frow;
+        const float* o = reinterpret_cast<const float*>(smem + RED + row * 512 + ((gi ^ (row & 15)) << 5));
+        const float4 o0 = *reinterpret_cast<const float4*>(o), o1 = *reinterpret_cast<const float4*>(o + 4);
+        const float4 r0 = x1r[k][0], r1 = x1r[k][1];
+        float v[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+        // partials are added in SOURCE-head order (the own one where its head comes), so the four workgroups of a cluster sum in one order whatever h is
+        float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int src_h = 0; src_h < NH; ++src_h) {
+          if (src_h == h) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc8[e] += v[e];
+          } else {
+            const int s3 = (src_h - h - 1) & 3;
+            add8_f16(acc8, s3 == 0 ? fp[0][k] : s3 == 1 ? fp[1][k] : fp[2][k]);
+          }
+        }
+        const float x1[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc8[e] + (b8[e] + x1[e]);
+        *reinterpret_cast<float4*>(xo + (size_t)row * D) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(xo + (size_t)row * D + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        const uint4 pk = pack8(v);
+        if (last) *reinterpret_cast<uint4*>(xl + (size_t)row * D) = pk;
+        else {
+          const int pos = (((n >> 3)) ^ (row & 15)) << 4;
+          *reinterpret_cast<uint4*>(smem + row * 256 + pos) = pk;
+          store16_wt(ximg + row * 256 + pos, pk, plain);
+        }
+        row_stats_group(pk, smem, cg, row, fgrp);
+      }
+    }
+    __syncthreads();
+    row_stats_publish(smem, a->st_out + (size_t)row0 * (D / 32) + h, n_act * 16, !last, plain, tid);
+    if (!last) publish(flags + 3);
+    else if (a->times) wait_vm<0>();
+    STAMP(14);
+  }
+  } else {
   // ================================================================ phase D: FFN-2 slab + bias + x1 -> x (f32), bf16 copy + row statistics
   {
     a = phase_args();
@@ -913,6 +1061,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     else if (a->times) wait_vm<0>();
     STAMP(14);
   }
+  }        // FFNK == 0: hid exchanged (round-4 form)
   }        // blocks of this launch
 }
 
@@ -920,7 +1069,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
 // A swapped-order fragment of 16 columns: lane (fr = lane & 15, g = lane >> 4) holds W[n0 + perm(fr)][k0 + 8 g .. + 7]; perm pairs two fragments so that a
 // lane ends with 8 consecutive output columns (frag_col); the un-swapped V fragment holds W[n0 + fr][...].
 struct PackSrc { const bf16_t* wqkv; const bf16_t* wout; const bf16_t* w1; const bf16_t* w2; };
-__global__ void sanm_block8_pack_kernel(PackSrc src, unsigned char* dst) {
+__global__ void sanm_block8_pack_kernel(PackSrc src, unsigned char* dst, int ffnk) {
   const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // 16-byte slot of the packed copy
   if (slot * 16 >= PK_BYTES) return;
   const size_t byte = slot * 16;
@@ -945,6 +1094,12 @@ __global__ void sanm_block8_pack_kernel(PackSrc src, unsigned char* dst) {
     const int q = s >> 2, t = s & 3;
     w = src.w1; ld = D; k0 = 128 * ((h + q) & 3) + 32 * t + 8 * g;
     row = h * 512 + wave * 64 + frag_col(j, fr);
+  } else if (ffnk) {                                    // K-split FFN-2: [h][wave][16 steps = own hid chunk q, K-step t][4 frags]: K = hidden 512 h + 128 q + 32 t .., output columns 64 wave ..
+    const size_t e = (byte - PK_W2) / 1024;
+    const int j = (int)(e % 4), s = (int)((e / 4) % 16), wave = (int)((e / 64) % NW), h = (int)(e / (64 * NW));
+    const int q = s >> 2, t = s & 3;
+    w = src.w2; ld = DFF; k0 = 512 * h + 128 * q + 32 * t + 8 * g;
+    row = wave * 64 + frag_col(j, fr);
   } else {                                              // [h][wave = (kh, cg)][32 steps = chunk order (4 h + q) & 15, K-steps 2 kh + t][2 frags]
     const size_t e = (byte - PK_W2) / 1024;
     const int j = (int)(e % 2), s = (int)((e / 2) % 32), wave = (int)((e / 64) % NW), h = (int)(e / (64 * NW));
@@ -990,10 +1145,10 @@ int sanm_block_max_utts() {
   return (cus / 32) * 8;          // whole groups of 8 windows (one per XCD), four workgroups each, one workgroup per CU
 }
 
-void launch_sanm_block8_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, hipStream_t s) {
+void launch_sanm_block8_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, bool ffnk, hipStream_t s) {
   const PackSrc src{wqkv, wout, w1, w2};
   const unsigned n = (unsigned)(PK_BYTES / 16);
-  hipLaunchKernelGGL(sanm_block8_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, reinterpret_cast<unsigned char*>(dst));
+  hipLaunchKernelGGL(sanm_block8_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, reinterpret_cast<unsigned char*>(dst), ffnk ? 1 : 0);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1002,14 +1157,15 @@ void launch_sanm_block8(const SanmBlockArgs& a, hipStream_t s) {
   ASR_REQUIRE(a.layers && a.place && a.n_layers >= 1 && (a.n_layers == 1 || a.x_lo == a.x_lo_out) && a.x_lo && a.x && a.ctx && a.x1_lo && a.st1 && a.hid && a.x_lo_out && a.st_out && a.flags && a.err && a.plan, "sanm_block8: null buffer");
   // opt bit 2: deeper W fragment queues; opt bits 4..7: a timing-only ablation of the GEMM loops (chunk_gemm's ABL)
   typedef void (*Kern)(const SanmBlockArgs);
-  static const Kern kerns[] = {sanm_block8_kernel<3, 4, 3, 4, 0>, sanm_block8_kernel<6, 8, 4, 8, 0>, sanm_block8_kernel<3, 4, 3, 4, 1>, sanm_block8_kernel<3, 4, 3, 4, 2>,
-                               sanm_block8_kernel<3, 4, 3, 4, 4>, sanm_block8_kernel<3, 4, 3, 4, 8>, sanm_block8_kernel<3, 4, 3, 4, 12>, sanm_block8_kernel<3, 4, 3, 4, 14>};
+  static const Kern kerns[] = {sanm_block8_kernel<3, 4, 3, 4, 0, 0>, sanm_block8_kernel<6, 8, 4, 8, 0, 0>, sanm_block8_kernel<3, 4, 3, 4, 1, 0>, sanm_block8_kernel<3, 4, 3, 4, 2, 0>,
+                               sanm_block8_kernel<3, 4, 3, 4, 4, 0>, sanm_block8_kernel<3, 4, 3, 4, 8, 0>, sanm_block8_kernel<3, 4, 3, 4, 12, 0>, sanm_block8_kernel<3, 4, 3, 4, 14, 0>,
+                               sanm_block8_kernel<3, 4, 3, 4, 0, 1>};
   static PerDeviceOnce attr_once;
   if (attr_once.first())
     for (Kern k : kerns) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   const int grid = a.scatter ? a.n_utts * 4 : ((a.n_utts + 7) / 8) * 32;
   const int abl = (a.opt >> 4) & 15;
-  const Kern k = abl == 1 ? kerns[2] : abl == 2 ? kerns[3] : abl == 4 ? kerns[4] : abl == 8 ? kerns[5] : abl == 12 ? kerns[6] : abl == 14 ? kerns[7] : (a.opt & 2) ? kerns[1] : kerns[0];
+  const Kern k = a.ffnk ? kerns[8] : abl == 1 ? kerns[2] : abl == 2 ? kerns[3] : abl == 4 ? kerns[4] : abl == 8 ? kerns[5] : abl == 12 ? kerns[6] : abl == 14 ? kerns[7] : (a.opt & 2) ? kerns[1] : kerns[0];
   hipLaunchKernelGGL(k, dim3(grid), dim3(NT), LDS_BYTES, s, a);
   HIP_CHECK(hipGetLastError());
 }

@@ -122,6 +122,7 @@ struct SvSession : asr_session {
   void ensure_block_pack();
   int block_fault = 0;          // ASR_SANM_BLOCK_FAULT=1 (tests): one workgroup of the first block launch withholds an exchange count
   int block_giveups = 0;        // forward passes redone on the four-launch path because a cluster gave up (see run())
+  bool block_ffnk = true;       // ASR_SANM_BLOCK_FFNK=0: the round-4 form of the block kernel's FFN pair (hid exchanged); default: FFN-2 split over K, f16 partials exchanged (round 6)
   bool foreign_now = false;     // a foreign section (RCCL collective, engine.h: ClusterScope) is open on this GPU: this pass launches no cluster kernel
   int foreign_diverted = 0;     // passes that took the cluster-free path for that reason
   int block_cooldown = 0;       // batches left on the four-launch path after a give-up (other sessions are holding CUs: do not walk into the same wait again)
@@ -132,6 +133,8 @@ struct SvSession : asr_session {
     if (const char* e = getenv("ASR_SANM_BLOCK")) use_block = !(e[0] == '0');
     if (const char* e = getenv("ASR_FBANK_SPLIT")) use_fbank_split = !(e[0] == '0');
     if (const char* e = getenv("ASR_SANM_BLOCK8_OPT")) block8_opt = atoi(e);
+    if (const char* e = getenv("ASR_SANM_BLOCK_FFNK")) block_ffnk = !(e[0] == '0');
+    if ((block8_opt >> 4) & 15) block_ffnk = false;          // the timing-only ablations exist for the round-4 loops
     if (const char* e = getenv("ASR_SANM_TILES")) use_tiles = !(e[0] == '0');
     if (const char* e = getenv("ASR_SANM_TILES_OPT")) tiles_opt = atoi(e);
     if (const char* e = getenv("ASR_SANM_TILES_DBG")) tiles_dbg = atoi(e);
@@ -280,7 +283,7 @@ void SvSession::ensure_block_pack() {
   for (int i = 0; i < cfg.n_blocks; ++i) {
     const SvBlock& b = blocks[i];
     if (b.in_size != cfg.d_model) continue;              // (block 0 maps 560 -> 512: it keeps the separate launches)
-    launch_sanm_block8_pack((const bf16_t*)b.wqkv, (const bf16_t*)b.wout, (const bf16_t*)b.w1, (const bf16_t*)b.w2, (unsigned char*)d_wpack.ptr + per * i, stream);
+    launch_sanm_block8_pack((const bf16_t*)b.wqkv, (const bf16_t*)b.wout, (const bf16_t*)b.w1, (const bf16_t*)b.w2, (unsigned char*)d_wpack.ptr + per * i, block_ffnk, stream);
   }
   std::vector<SanmBlockLayer> tab(cfg.n_blocks);
   for (int i = 0; i < cfg.n_blocks; ++i) {
@@ -422,7 +425,7 @@ void SvSession::enqueue(const SvRunCtx& r) {
             d_times.reserve(256 * 16 * 8, stream); HIP_CHECK(hipMemsetAsync(d_times.ptr, 0, 256 * 16 * 8, stream)); ba.times = d_times.as<unsigned long long>();
             ba.times_layer = block_dbg - i;
           }
-          ba.layers = d_layer_tab.as<SanmBlockLayer>() + i; ba.n_layers = n_run; ba.opt = block8_opt;
+          ba.layers = d_layer_tab.as<SanmBlockLayer>() + i; ba.n_layers = n_run; ba.opt = block8_opt; ba.ffnk = block_ffnk ? 1 : 0;
           ba.st_in_n = st_in_block8 ? 4 : 16;
           launch_sanm_block8(ba, stream);
         }

@@ -9,8 +9,8 @@ only the class/function *definitions* are compiled from the reference file where
 it lies (nothing is copied into this repo) and run eagerly on CPU against a
 stand-in module tree carrying our seeded synthetic checkpoint.
 
-Used by `oracle/gen_golden.py` (writes tests/golden/*.npz) and by
-`tests/test_oracle_vs_reference.py` (skipped when /root/reference is absent).
+Used by `oracle/gen_golden*.py` (write tests/golden/*.npz) and by the live-reference tests in
+`tests/test_oracle_*.py` (skipped when /root/reference is absent).
 """
 from __future__ import annotations
 

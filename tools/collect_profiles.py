@@ -8,6 +8,7 @@ os.makedirs("profiles", exist_ok=True)
 names = {"bench_sensevoice": "bench_n1", "bench_sensevoice_4launch": "bench_4launch_n1", "bench_paraformer": "bench_paraformer_n1", "bench_whisper": "bench_whisper_n1",
          "bench_whisper_b64": "bench_whisper_b64_n1", "bench_whisper30": "bench_whisper30_n1", "bench_paraformer_streaming": "bench_paraformer_streaming_n1",
          "bench_whisper30_fp8": "bench_whisper30_fp8_n1", "bench_whisper_fp8": "bench_whisper_fp8_n1",
+         "bench_whisper30_mxfp4": "bench_whisper30_mxfp4_n1", "bench_whisper_mxfp4": "bench_whisper_mxfp4_n1",
          "bench_whisper_b64_fp8mm": "bench_whisper_b64_fp8mm_n1", "bench_whisper30_fp8mm": "bench_whisper30_fp8mm_n1",
          "bench_qwen": "bench_qwen_n1", "bench_qwen_beam5": "bench_qwen_beam5_n1", "bench_mixed_beam5": "bench_mixed_beam5_n1",
          "bench_paraformer_streaming_256": "bench_paraformer_streaming_256_n1", "bench_qwen_fp8": "bench_qwen_fp8_n1"}

@@ -17,16 +17,18 @@ python bench.py --workload whisper --batch 64 --steps 5 --warmup 3 --inflight 2 
 python bench.py --workload whisper --seconds 30 --steps 3 --warmup 2 --inflight 3 --no-cpu-baseline > $OUT/bench_whisper30.json 2> $OUT/bench_whisper30.err
 python bench.py --workload whisper --fp8 --seconds 30 --steps 3 --warmup 2 --no-cpu-baseline > $OUT/bench_whisper30_fp8.json 2> $OUT/bench_whisper30_fp8.err
 python bench.py --workload whisper --fp8 --steps 6 --warmup 3 --no-cpu-baseline > $OUT/bench_whisper_fp8.json 2> $OUT/bench_whisper_fp8.err
+python bench.py --workload whisper --mxfp4 --seconds 30 --steps 3 --warmup 2 --no-cpu-baseline > $OUT/bench_whisper30_mxfp4.json 2> $OUT/bench_whisper30_mxfp4.err
+python bench.py --workload whisper --mxfp4 --steps 6 --warmup 3 --no-cpu-baseline > $OUT/bench_whisper_mxfp4.json 2> $OUT/bench_whisper_mxfp4.err
 python bench.py --workload whisper --fp8mm --batch 64 --steps 5 --warmup 3 --inflight 2 --no-cpu-baseline > $OUT/bench_whisper_b64_fp8mm.json 2> $OUT/bench_whisper_b64_fp8mm.err
 python bench.py --workload whisper --fp8mm --seconds 30 --steps 3 --warmup 2 --no-cpu-baseline > $OUT/bench_whisper30_fp8mm.json 2> $OUT/bench_whisper30_fp8mm.err
 python tools/fp8_gemm_probe.py > $OUT/fp8_gemm_probe.txt 2>&1
 python tools/probes/gelu_cost.py > $OUT/gelu_epilogue_cost.txt 2>&1
-# the 8-wave block kernel: timing-only ablations of its GEMM loops (ASR_SANM_BLOCK8_OPT bits 4..7), the phase clock of one block of the long launch, and the same
-# box's figures for one launch per block and for the 12-wave kernel of rounds 2-3
+# the 8-wave block kernel: timing-only ablations of its GEMM loops (ASR_SANM_BLOCK8_OPT bits 4..7; they exist for the round-4 form of the FFN pair and switch the K-split
+# form off), the phase clock of one block of the long launch in both forms, and the same box's step times for the switches that are left
 for a in 0 16 32 64 128 192 224; do echo "=== ASR_SANM_BLOCK8_OPT=$a (x16: 1 no MFMA, 2 no A fragment reads, 4 no W refills, 8 no chunk DMA; results are garbage by design)"; ASR_SANM_BLOCK8_OPT=$a ASR_SANM_BLOCK_DBG=10 python tools/probes/sanm_block_clock.py 2>&1 | grep -v amdgpu.ids | tail -17; done > $OUT/sanm_block_ablations.txt 2>&1
-ASR_SANM_BLOCK_DBG=10 python tools/probes/sanm_block_clock.py > $OUT/sanm_block_phase_clock.txt 2>&1
+for k in 1 0; do echo "=== ASR_SANM_BLOCK_FFNK=$k (1 = FFN-2 split over K, f16 partials exchanged: stamps 11->12 = the FFN-2 loop, 12->13 = partial out + publish, 13->14 = wait + foreign partials + epilogue)"; ASR_SANM_BLOCK_FFNK=$k ASR_SANM_BLOCK_DBG=10 python tools/probes/sanm_block_clock.py 2>&1 | grep -v amdgpu.ids | tail -51; done > $OUT/sanm_block_phase_clock.txt 2>&1
 for b in 1 16; do echo "=== batch $b (ASR_SANM_BLOCK_MIN=1): the per-cluster critical path with the chip idle"; CLOCK_B=$b ASR_SANM_BLOCK_MIN=1 ASR_SANM_BLOCK_DBG=10 python tools/probes/sanm_block_clock.py 2>&1 | grep -v amdgpu.ids | tail -17; done > $OUT/sanm_block_batch_sweep.txt 2>&1
-for v in "ASR_SANM_BLOCK_V=8" "ASR_SANM_BLOCK_FFN22=1" "ASR_SANM_BLOCK8_OPT=1024" "ASR_GEMM_AMAX_PP=0" "ASR_SANM_BLOCK_PERSIST=0" "ASR_SANM_BLOCK_V=1" "ASR_SANM_BLOCK8_OPT=4" "ASR_SANM_BLOCK8_OPT=256" "ASR_SANM_BLOCK_V=8"; do
+for v in "ASR_SANM_BLOCK_FFNK=1" "ASR_SANM_BLOCK_FFNK=0" "ASR_GEMM_AMAX_PP=0" "ASR_SANM_BLOCK_PERSIST=0" "ASR_SANM_BLOCK8_OPT=4" "ASR_SANM_BLOCK8_OPT=256" "ASR_SANM_BLOCK_FFNK=0" "ASR_SANM_BLOCK_FFNK=1"; do
   echo "$v: $(env $v python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms per step,', d['value'], 'audio-s/s')")"
 done > $OUT/sanm_block_variants.txt 2>&1
 bash tools/probes/block_min_sweep.sh > $OUT/sanm_block_min_sweep.txt 2>&1

@@ -350,7 +350,7 @@ struct StreamLayersArgs {
   int fault = 0;                                            // tests: workgroup 5 withholds its count on the first exchange of the first layer (its cluster gives up)
 };
 size_t stream_layers_pack_bytes();
-void launch_stream_layers_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, hipStream_t s, bool ksplit = false);      // ksplit: out-projection and FFN-2 in the K-split order of sanm_tiles.hip
+void launch_stream_layers_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, hipStream_t s);
 bool stream_layers_supported(int d, int d_ffn, int n_heads, int cap, int n_cur, int ktaps);
 void launch_stream_layers(const StreamLayersArgs& a, hipStream_t s);
 
@@ -365,8 +365,6 @@ struct SanmTilesArgs {
   float* x;                                                 // [rows][512] residual stream, in place
   float* xb; bf16_t* ctx; bf16_t* hid;                      // exchange buffers of a tile's four heads: [rows][512] f32, [rows][512], [rows][2048]
   bf16_t* kv; size_t kv_parity_stride;                      // exchange buffer of a head's tiles: [block parity][rows][k | v][512], elements between the two
-  float* part = nullptr;                                    // K-split form: [2][rows][4 heads][512] f32 partials of the out-projection (0) and of FFN-2 (1); null = the round-4 form
-  size_t part_stride = 0;                                   // floats between the two
   unsigned* flags; int flag_stride;                         // per layer: [n_tiles][4] + [n_windows][4] counters, zero at launch; flag_stride = words per layer
   unsigned* err;
   int opt = 0;                                              // tuning: 1 = no L2 warm-up, 2 = a tile's four heads on one XCD instead of placement by head

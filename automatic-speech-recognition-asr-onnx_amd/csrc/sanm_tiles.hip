@@ -36,30 +36,17 @@ constexpr int XB = XRES + SLOT * HD * 4, MEM = XB + SLOT * HD * 4, LDS_BYTES = M
 static_assert(LDS_BYTES <= 160 * 1024 && XRES % 16 == 0 && UNI % 16 == 0, "LDS map");
 
 // full rows of the tile's f32 stream (16 x 512, exchanged) -> plain normalisation (the affine is folded into the next weights) -> bf16 operand rows
-// n_src > 1 (K-split form): a row of `src` is n_src partial rows of 512 floats back to back ([row][head][512]); they are summed in head order, so the four workgroups
-// of a tile -- each normalising the whole row for itself -- get the same bits. keep: where the own 128 columns of the summed row go (f32 [16][128]), or -1.
-__device__ __forceinline__ void norm_rows(const float* src, unsigned char* smem, int tid, int h, int keep, float eps, int n_src = 1) {
+__device__ __forceinline__ void norm_rows(const float* src, unsigned char* smem, int tid, int h, bool keep_own, float eps) {
   // thread = (row, column pairs 64 e + 2 j, e < 8): a wave instruction reads 256 contiguous bytes of each of its two rows (16 columns per thread in a row would be
   // 64 lanes 64 bytes apart, one 64-byte segment each: 2 us of address processing per LayerNorm)
   const int row = tid >> 5, j = tid & 31;
-  const float* p = src + (size_t)row * D * n_src + 2 * j;
+  const float* p = src + (size_t)row * D + 2 * j;
   float v[16];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const u64 t = get8(p + 64 * e);
     v[2 * e] = __uint_as_float((unsigned)t);
     v[2 * e + 1] = __uint_as_float((unsigned)(t >> 32));
-  }
-  if (n_src > 1) {
-    u64 t[3][8];
-#pragma unroll
-    for (int sidx = 0; sidx < 3; ++sidx)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) t[sidx][e] = get8(p + (sidx + 1) * D + 64 * e);
-#pragma unroll
-    for (int sidx = 0; sidx < 3; ++sidx)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { v[2 * e] += __uint_as_float((unsigned)t[sidx][e]); v[2 * e + 1] += __uint_as_float((unsigned)(t[sidx][e] >> 32)); }
   }
   float s = 0.0f;
 #pragma unroll
@@ -79,7 +66,7 @@ __device__ __forceinline__ void norm_rows(const float* src, unsigned char* smem,
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     *reinterpret_cast<unsigned*>(smem + XN + row * AS + (64 * e + 2 * j) * 2) = pack_bf16x2((v[2 * e] - mean) * rstd, (v[2 * e + 1] - mean) * rstd);
-    if (keep >= 0 && (e >> 1) == h) *reinterpret_cast<float2*>(smem + keep + (row * HD + 64 * (e & 1) + 2 * j) * 4) = make_float2(v[2 * e], v[2 * e + 1]);
+    if (keep_own && (e >> 1) == h) *reinterpret_cast<float2*>(smem + XRES + (row * HD + 64 * (e & 1) + 2 * j) * 4) = make_float2(v[2 * e], v[2 * e + 1]);
   }
 }
 
@@ -91,20 +78,8 @@ __device__ __forceinline__ void put_slab_f32(float* dst_rows, const unsigned cha
   }
 }
 
-// K-split form: a wave's [16][64] f32 piece of the tile's partial -> the staging rows in LDS (pitch 516 floats), then the whole [16][512] partial -> memory, 8 bytes per
-// thread and request (write-through: put8)
-constexpr int PSTR = 516;
-__device__ __forceinline__ void put_partial_f32(float* dst_rows, const unsigned char* stage, int tid, int h) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int idx = tid + NT * e, row = idx >> 8, c2 = (idx & 255) * 2;
-    put8(dst_rows + ((size_t)row * NH + h) * D + c2, *reinterpret_cast<const u64*>(stage + (row * PSTR + c2) * 4));
-  }
-}
-
 #define STAMP(k) do { if (a.times && li == a.times_layer && threadIdx.x == 0) a.times[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 
-template <bool KSP>
 __global__ __launch_bounds__(NT) void sanm_tiles_kernel(const SanmTilesArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid_0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid_0 >> 6);
@@ -126,8 +101,6 @@ __global__ __launch_bounds__(NT) void sanm_tiles_kernel(const SanmTilesArgs a) {
   float* xb_rows = a.xb + (size_t)row0 * D;
   bf16_t* ctx_rows = a.ctx + (size_t)row0 * D;
   bf16_t* hid_rows = a.hid + (size_t)row0 * DFF;
-  float* pb_rows = a.part + (size_t)row0 * NH * D;                         // K-split form: the tile's out-projection partials [16][4 heads][512] ...
-  float* pd_rows = a.part + a.part_stride + (size_t)row0 * NH * D;         // ... and its FFN-2 partials
   bf16_t* kv_win0 = a.kv + (size_t)wrow0 * 2 * D;                          // [block parity][window row][k | v][512]
   const size_t wave_frag = (size_t)(h * NW + wave);
   u32x4 wa[12];
@@ -171,10 +144,9 @@ __global__ __launch_bounds__(NT) void sanm_tiles_kernel(const SanmTilesArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- phase A: LayerNorm of the tile's rows, q|k|v of head h
-    if (li > 0) consume(flags - a.flag_stride + (KSP ? 2 : 3), a.err);
+    if (li > 0) consume(flags - a.flag_stride + 3, a.err);
     STAMP(1);
-    if (KSP && li > 0) norm_rows(pd_rows, smem, tid, h, XRES, a.ln_eps, NH);       // the block input = the sum of the previous block's four FFN-2 partials
-    else norm_rows(x_rows, smem, tid, h, XRES, a.ln_eps);
+    norm_rows(x_rows, smem, tid, h, true, a.ln_eps);
     lds_barrier();
     STAMP(2);
     {
@@ -306,37 +278,6 @@ __global__ __launch_bounds__(NT) void sanm_tiles_kernel(const SanmTilesArgs a) {
     }
     lds_barrier();
     STAMP(5);
-    u32x4 wc0[16], wc1[16];
-    if constexpr (KSP) {
-      // ---- phase B, K-split: the out-projection of head h's OWN 128 ctx columns for ALL 512 output columns; the own slab also takes the FSMN term and the residual, so the
-      //      four partials of a tile add up to x1. One meeting (partials out, every head reads all four) replaces the ctx exchange AND the x1 exchange.
-      STAMP(6);
-      {
-        f32x4_t acc[4] = {};
-        gemm_phase<4, 4, 4, 1, false>(wb, wb, wpB, a_lane + CTX + h * 256, acc);
-        float* stage = reinterpret_cast<float*>(smem + UNI);       // (the k / v images are dead: the barrier above closed attention and FSMN)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int col = wave * 64 + j * 16 + frow;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int row = fgrp * 4 + i;
-            float v = acc[j][i];
-            if ((col >> 7) == h) v += mem[row * HD + (col & 127)] + xres[row * HD + (col & 127)];
-            stage[row * PSTR + col] = v;
-          }
-        }
-      }
-      lds_barrier();
-      STAMP(7);
-      put_partial_f32(pb_rows, smem + UNI, tid, h);
-      publish(flags + 0);
-      sink ^= tw2 ^ tw2b;                                    // (drained by the publish)
-      wload<16>(wc0, wpC, 0);
-      consume(flags + 0, a.err);
-      STAMP(8);
-      norm_rows(pb_rows, smem, tid, h, XB, a.ln_eps, NH);    // x1 = the sum of the four partials: LayerNorm rows -> XN, the own slab (f32) -> XB for phase D's residual
-    } else {
     {   // exchange 0: own 128 ctx columns out, the other three heads' in
       const int row = tid >> 5, off = (tid & 31) * 8;
       put8(reinterpret_cast<unsigned char*>(ctx_rows + (size_t)row * D + h * HD) + off, *reinterpret_cast<const u64*>(smem + CTX + row * AS + h * 256 + off));
@@ -366,12 +307,12 @@ __global__ __launch_bounds__(NT) void sanm_tiles_kernel(const SanmTilesArgs a) {
     STAMP(7);
     put_slab_f32(xb_rows, smem + XB, tid, h);
     publish(flags + 1);
+    u32x4 wc0[16], wc1[16];
     wload<16>(wc0, wpC, 0);
     consume(flags + 1, a.err);
     STAMP(8);
     // ---- phase C: LayerNorm of x1, FFN-1 columns 512 h + 64 wave ..
-    norm_rows(xb_rows, smem, tid, h, -1, a.ln_eps);
-    }
+    norm_rows(xb_rows, smem, tid, h, false, a.ln_eps);
     lds_barrier();
     STAMP(9);
     {
@@ -388,51 +329,6 @@ __global__ __launch_bounds__(NT) void sanm_tiles_kernel(const SanmTilesArgs a) {
     lds_barrier();
     STAMP(10);
     u32x4 wd[16], wd1[16];
-    if constexpr (KSP) {
-      // ---- phase D, K-split: FFN-2 over the workgroup's OWN 512 hidden columns for all 512 output columns (hid never leaves the CU); the own slab also takes b2 and x1.
-      //      The partials are the next block's input: its phase A sums them -- the hid exchange and the x exchange are one meeting.
-      wload<16>(wd, wpD, 0);
-      STAMP(11);
-      f32x4_t acc[4] = {};
-      gemm_phase<4, 16, 4, 1, false>(wd, wd1, wpD, hid_lane + h * 1024, acc);
-      lds_barrier();                                         // every wave is done reading hid: its place takes the staging rows
-      {
-        float* stage = reinterpret_cast<float*>(smem + UNI);
-        const float bown = glob(L.b2)[h * HD + (wave & 1) * 64 + frow];       // (read for every wave; used by the two that hold the own slab)
-        const float b4[4] = {bown, glob(L.b2)[h * HD + (wave & 1) * 64 + 16 + frow], glob(L.b2)[h * HD + (wave & 1) * 64 + 32 + frow], glob(L.b2)[h * HD + (wave & 1) * 64 + 48 + frow]};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int col = wave * 64 + j * 16 + frow;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int row = fgrp * 4 + i;
-            float v = acc[j][i];
-            if ((col >> 7) == h) v += b4[j] + xbs[row * HD + (col & 127)];
-            stage[row * PSTR + col] = v;
-          }
-        }
-      }
-      lds_barrier();
-      STAMP(12);
-      put_partial_f32(pd_rows, smem + UNI, tid, h);
-      publish(flags + 2);
-      sink ^= tw ^ twb;
-      if (li + 1 == a.n_layers) {                            // the launch's last block: the sum itself is the output -- own slab of x, from the four partials in head order
-        consume(flags + 2, a.err);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int idx = tid + NT * e, row = idx >> 6, c2 = (idx & 63) * 2;
-          const float* src = pd_rows + (size_t)row * NH * D + h * HD + c2;
-          u64 t[4];
-#pragma unroll
-          for (int q = 0; q < NH; ++q) t[q] = get8(src + q * D);
-          float lo = 0.0f, hi = 0.0f;
-#pragma unroll
-          for (int q = 0; q < NH; ++q) { lo += __uint_as_float((unsigned)t[q]); hi += __uint_as_float((unsigned)(t[q] >> 32)); }
-          put8(x_rows + (size_t)row * D + h * HD + c2, (u64)__float_as_uint(lo) | ((u64)__float_as_uint(hi) << 32));
-        }
-      }
-    } else {
     {   // exchange 2: own 512 hid columns out, the other three quarters in
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -476,7 +372,6 @@ __global__ __launch_bounds__(NT) void sanm_tiles_kernel(const SanmTilesArgs a) {
     put_slab_f32(x_rows, smem + XRES, tid, h);
     publish(flags + 3);
     sink ^= tw ^ twb;
-    }
     STAMP(13);
     if (li + 1 < a.n_layers) {
       wload<12>(wa, a.layers[li + 1].wpack + PK_A + wave_frag * PW_A + lane * 16, 0);
@@ -503,12 +398,8 @@ void launch_sanm_tiles(const SanmTilesArgs& a, hipStream_t s) {
   ASR_REQUIRE(a.n_tiles >= 1 && a.n_tiles <= sanm_tiles_max_tiles() && a.n_layers >= 1, "sanm_tiles: %d tiles", a.n_tiles);
   static PerDeviceOnce attr_once;
   if (attr_once.first())
-  {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sanm_tiles_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sanm_tiles_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  }
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sanm_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   const int n_wgs = (a.opt & 2) ? (a.n_tiles + 7) / 8 * 32 : (a.n_tiles + 1) / 2 * 8;
-  if (a.part) hipLaunchKernelGGL(sanm_tiles_kernel<true>, dim3(n_wgs), dim3(NT), LDS_BYTES, s, a);
-  else hipLaunchKernelGGL(sanm_tiles_kernel<false>, dim3(n_wgs), dim3(NT), LDS_BYTES, s, a);
+  hipLaunchKernelGGL(sanm_tiles_kernel, dim3(n_wgs), dim3(NT), LDS_BYTES, s, a);
   HIP_CHECK(hipGetLastError());
 }

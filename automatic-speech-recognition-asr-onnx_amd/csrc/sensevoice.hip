@@ -59,7 +59,7 @@ struct SvSession : asr_session {
   size_t h_out_cap = 0;
 
   ~SvSession() override {
-    for (DeviceBuffer* b : {&d_dft_split, &d_times, &d_flags, &d_tpack, &d_tlayer_tab, &d_tkv, &d_tpart, &d_ctplan, &d_mdev, &d_trow, &d_skws, &d_skcnt, &d_sta, &d_stb, &st_segs, &st_shadow, &st_wpack, &st_layer_tab, &st_flags, &st_times, &st_dpack, &st_dlayer_tab, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
+    for (DeviceBuffer* b : {&d_dft_split, &d_times, &d_flags, &d_tpack, &d_tlayer_tab, &d_tkv, &d_ctplan, &d_mdev, &d_trow, &d_skws, &d_skcnt, &d_sta, &d_stb, &st_segs, &st_shadow, &st_wpack, &st_layer_tab, &st_flags, &st_times, &st_dpack, &st_dlayer_tab, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
                             &d_x0lo, &d_xalo, &d_xblo, &d_plan, &d_audio, &d_mel, &d_x0, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx, &d_mem, &d_ffn,
                             &d_amax_v, &d_amax_i, &d_ids, &d_tok, &d_num, &d_logits, &d_enc_lo, &d_ck, &d_cifa, &d_alpha, &d_dec, &d_x2,
                             &d_sa, &d_ffn32, &d_tplan})
@@ -115,8 +115,7 @@ struct SvSession : asr_session {
   // small batches: a workgroup per (16-row tile, head), csrc/sanm_tiles.hip (ASR_SANM_TILES=0: four launches per block as before)
   bool use_tiles = true, tpack_ready = false;
   int tiles_opt = 0, tiles_dbg = -1;       // ASR_SANM_TILES_OPT (SanmTilesArgs::opt), ASR_SANM_TILES_DBG=<block>: phase clock of that block on stderr
-  DeviceBuffer d_tpack, d_tlayer_tab, d_tkv, d_tpart;
-  bool tiles_ksplit = true;     // ASR_SANM_TILES_KSPLIT=0: the round-4 form of the tile kernel (ctx / x1 / hid / x exchanged: five meetings per block); default: out-projection and FFN-2 split over K, f32 partials, three meetings
+  DeviceBuffer d_tpack, d_tlayer_tab, d_tkv;
   void ensure_tiles_pack();
   DeviceBuffer d_wpack;         // 8-wave form: fragment-major copy of every 512 -> 512 block's weights, made once per session (ensure_block_pack)
   bool wpack_ready = false;
@@ -138,7 +137,6 @@ struct SvSession : asr_session {
     if ((block8_opt >> 4) & 15) block_ffnk = false;          // the timing-only ablations exist for the round-4 loops
     if (const char* e = getenv("ASR_SANM_TILES")) use_tiles = !(e[0] == '0');
     if (const char* e = getenv("ASR_SANM_TILES_OPT")) tiles_opt = atoi(e);
-    if (const char* e = getenv("ASR_SANM_TILES_KSPLIT")) tiles_ksplit = !(e[0] == '0');
     if (const char* e = getenv("ASR_SANM_TILES_DBG")) tiles_dbg = atoi(e);
     if (const char* e = getenv("ASR_SANM_BLOCK_PERSIST")) block_persist = !(e[0] == '0');
     if (const char* e = getenv("ASR_SANM_BLOCK_SCATTER")) block_scatter = e[0] == '1';
@@ -315,7 +313,7 @@ void SvSession::ensure_tiles_pack() {
     tab[i] = StreamLayer{};
     if (b.in_size != cfg.d_model) continue;
     unsigned char* dst = (unsigned char*)d_tpack.ptr + per * i;
-    launch_stream_layers_pack((const bf16_t*)b.wqkv, (const bf16_t*)b.wout, (const bf16_t*)b.w1, (const bf16_t*)b.w2, dst, stream, tiles_ksplit);
+    launch_stream_layers_pack((const bf16_t*)b.wqkv, (const bf16_t*)b.wout, (const bf16_t*)b.w1, (const bf16_t*)b.w2, dst, stream);
     tab[i].wpack = dst; tab[i].bqkv = b.bqkv; tab[i].wfsmn = b.wfsmn; tab[i].bfsmn = b.bfsmn; tab[i].b1 = b.b1; tab[i].b2 = b.b2;
   }
   d_tlayer_tab.reserve(tab.size() * sizeof(StreamLayer), stream);
@@ -453,7 +451,6 @@ void SvSession::enqueue(const SvRunCtx& r) {
           ta.x = xa; ta.xb = xb; ta.ctx = (bf16_t*)ctx; ta.hid = (bf16_t*)ffn; ta.kv = d_tkv.as<bf16_t>(); ta.kv_parity_stride = (size_t)Mpad * 2 * d;
           ta.flags = d_flags.as<unsigned>() + tile_flag0 + (size_t)i * tile_flag_stride; ta.flag_stride = (int)tile_flag_stride;
           ta.err = d_flags.as<unsigned>() + flag_words; ta.opt = tiles_opt;
-          if (tiles_ksplit) { ta.part = d_tpart.as<float>(); ta.part_stride = (size_t)Mpad * 4 * d; }
           if (tiles_dbg >= i && tiles_dbg < run_end) {
             d_times.reserve(256 * 16 * 8, stream); HIP_CHECK(hipMemsetAsync(d_times.ptr, 0, 256 * 16 * 8, stream)); ta.times = d_times.as<unsigned long long>();
             ta.times_layer = tiles_dbg - i;
@@ -812,8 +809,7 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   grow(d_amax_i, (size_t)Mpad * n_slabs * 4);
   grow(d_ids, (size_t)Mpad * 4);
   grow(d_flags, ((size_t)c.n_blocks * batch * 5 + 4 + (tiles ? (size_t)c.n_blocks * (n_tiles + batch) * 4 : 0)) * 4);
-  if (tiles) grow(d_tkv, (size_t)Mpad * 2 * d * 2 * 2);
-  if (tiles && tiles_ksplit) grow(d_tpart, (size_t)2 * Mpad * 4 * d * 4);          // [out-projection | FFN-2][row][head][512] f32 partials of the K-split tile kernel          // [block][window][4] exchange counters + error word (4) + [block][window] placement words
+  if (tiles) grow(d_tkv, (size_t)Mpad * 2 * d * 2 * 2);          // [block][window][4] exchange counters + error word (4) + [block][window] placement words
   grow(d_tok, (size_t)batch * max_tokens * 4);
   grow(d_num, (size_t)batch * 4);
   if (taps_enabled) grow(d_logits, (size_t)Mpad * vpad * 4);

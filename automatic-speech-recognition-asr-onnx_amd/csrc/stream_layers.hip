@@ -415,7 +415,7 @@ __global__ __launch_bounds__(NT) void stream_layers_kernel(const StreamLayersArg
 
 // one thread per 16-byte slot of the packed copy: where in the arena's row-major matrices its eight elements live
 __global__ __launch_bounds__(256) void stream_layers_pack_kernel(const bf16_t* __restrict__ wqkv, const bf16_t* __restrict__ wout, const bf16_t* __restrict__ w1,
-                                                                 const bf16_t* __restrict__ w2, unsigned char* __restrict__ dst, int ksplit) {
+                                                                 const bf16_t* __restrict__ w2, unsigned char* __restrict__ dst) {
   const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x, o = slot * 16;
   if (o >= PK_BYTES) return;
   const int lane = (int)((o >> 4) & 63), frow = lane & 15, kq = (lane >> 4) * 8;
@@ -428,8 +428,6 @@ __global__ __launch_bounds__(256) void stream_layers_pack_kernel(const bf16_t* _
   } else if (o < PK_C) {
     const size_t r = o - PK_B;
     const int hw = (int)(r / PW_B), ks = (int)((r % PW_B) >> 10), h = hw >> 3, w = hw & 7;
-    if (ksplit) src = wout + (size_t)(w * 64 + (ks & 3) * 16 + frow) * D + h * HD + (ks >> 2) * 32 + kq;      // K-split form (sanm_tiles.hip): [4 k-steps of head h's 128 ctx columns][4 column tiles of 64 w ..]
-    else
     src = wout + (size_t)(h * HD + w * 16 + frow) * D + ks * 32 + kq;
   } else if (o < PK_D) {
     const size_t r = o - PK_C;
@@ -438,8 +436,6 @@ __global__ __launch_bounds__(256) void stream_layers_pack_kernel(const bf16_t* _
   } else {
     const size_t r = o - PK_D;
     const int hw = (int)(r / PW_D), ks = (int)((r % PW_D) >> 10), h = hw >> 3, w = hw & 7;
-    if (ksplit) src = w2 + (size_t)(w * 64 + (ks & 3) * 16 + frow) * DFF + h * 512 + (ks >> 2) * 32 + kq;      // K-split form: [16 k-steps of head h's 512 hidden columns][4 column tiles of 64 w ..]
-    else
     src = w2 + (size_t)(h * HD + w * 16 + frow) * DFF + ks * 32 + kq;
   }
   *reinterpret_cast<uint4*>(dst + o) = *reinterpret_cast<const uint4*>(src);
@@ -454,8 +450,8 @@ template <int M> static void static_for_attr() {          // every instance may 
 
 size_t stream_layers_pack_bytes() { return PK_BYTES; }
 
-void launch_stream_layers_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, hipStream_t s, bool ksplit) {
-  hipLaunchKernelGGL(stream_layers_pack_kernel, dim3((unsigned)((PK_BYTES / 16 + 255) / 256)), dim3(256), 0, s, wqkv, wout, w1, w2, (unsigned char*)dst, ksplit ? 1 : 0);
+void launch_stream_layers_pack(const bf16_t* wqkv, const bf16_t* wout, const bf16_t* w1, const bf16_t* w2, void* dst, hipStream_t s) {
+  hipLaunchKernelGGL(stream_layers_pack_kernel, dim3((unsigned)((PK_BYTES / 16 + 255) / 256)), dim3(256), 0, s, wqkv, wout, w1, w2, (unsigned char*)dst);
   HIP_CHECK(hipGetLastError());
 }
 

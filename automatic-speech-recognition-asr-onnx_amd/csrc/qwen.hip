@@ -1705,6 +1705,9 @@ extern "C" int asr_qwen_generate(asr_session* s, int max_new, const int32_t* sto
     HIP_CHECK(hipStreamSynchronize(q->stream));
     std::vector<char> done(B, 0);
     for (int b = 0; b < B; ++b) n_out[b] = 0;
+    // a sequence that an EARLIER generate() call of this batch finished has given its pages back: it stays finished (no tokens) while the others go on -- chunked generation
+    // after hitting max_new must not abort the batch
+    if (q->kv_paged) for (int b = 0; b < B && b < (int)q->kv_released.size(); ++b) if (q->kv_released[b]) done[b] = 1;
     struct ClearFrozen { QwSession* q; ~ClearFrozen() { q->frozen.clear(); } } clear_frozen{q};      // also when a step throws: a stale list would release live sequences' pages
     auto is_stop = [&](int32_t t) { for (int i = 0; i < n_stop; ++i) if (stop_ids[i] == t) return true; return false; };
     for (int t = 0; t < max_new; ++t) {

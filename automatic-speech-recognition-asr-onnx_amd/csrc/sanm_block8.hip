@@ -579,14 +579,17 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
       const int fq = frow, g = fgrp;
       const int n_sub = (T + 31) >> 5;
       const bool shared_tile = T > 128;
+      // (round 6: the soft-max body of kernels.hip's attention kernel -- score row i of a sub-tile's two S^T tiles is key 8 (i / 4) + (i % 4) (+ 4), so a lane group holds 8
+      //  CONSECUTIVE keys and the V^T fragment is one 16-byte read; keys are masked only in the sub-tile that holds the window's end; p = exp2(fma(s, log2 e, -m log2 e)))
       auto scores = [&](const bf16x8_t (&qf)[HD / 32], bf16x8_t (&pf)[5], float& inv) {
+        constexpr float LOG2E = 1.4426950408889634f;
         f32x4_t st[5][2];
 #pragma unroll
         for (int s = 0; s < 5; ++s) { st[s][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; st[s][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
           if (s < n_sub) {
-            const int key0 = s * 32 + fq, key1 = key0 + 16;
+            const int key0 = s * 32 + ((fq >> 2) << 3) + (fq & 3), key1 = key0 + 4;
 #pragma unroll
             for (int ks = 0; ks < HD / 32; ++ks) {
               const int c = ks * 4 + g;
@@ -599,28 +602,35 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
         }
         float mx = -INFINITY;
 #pragma unroll
-        for (int s = 0; s < 5; ++s)
+        for (int s = 0; s < 5; ++s) {
+          if (s * 32 + 32 > T) {                               // (wave-uniform: only the sub-tiles at or past the window's end mask; sub-tiles past n_sub are all -inf)
 #pragma unroll
-          for (int hlf = 0; hlf < 2; ++hlf)
+            for (int hlf = 0; hlf < 2; ++hlf)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int key = s * 32 + hlf * 16 + g * 4 + r;
-              if (key >= T) st[s][hlf][r] = -INFINITY;
-              mx = fmaxf(mx, st[s][hlf][r]);
-            }
+              for (int r = 0; r < 4; ++r)
+                if (s * 32 + g * 8 + hlf * 4 + r >= T) st[s][hlf][r] = -INFINITY;
+          }
+          mx = fmaxf(fmaxf(fmaxf(mx, fmaxf(st[s][0][0], st[s][0][1])), fmaxf(st[s][0][2], st[s][0][3])), fmaxf(fmaxf(st[s][1][0], st[s][1][1]), fmaxf(st[s][1][2], st[s][1][3])));
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float l = 0.0f;
+        const f32x2_t mneg = {-mx * LOG2E, -mx * LOG2E}, l2 = {LOG2E, LOG2E};
+        f32x2_t lsum = {0.0f, 0.0f};
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
-          float p[8];
+          f32x2_t p[4];
 #pragma unroll
-          for (int r = 0; r < 8; ++r) { p[r] = __expf(st[s][r >> 2][r & 3] - mx); l += p[r]; }
+          for (int q = 0; q < 4; ++q) {
+            const f32x2_t e = __builtin_elementwise_fma(f32x2_t{st[s][q >> 1][2 * (q & 1)], st[s][q >> 1][2 * (q & 1) + 1]}, l2, mneg);
+            p[q] = f32x2_t{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+          }
+          lsum += (p[0] + p[1]) + (p[2] + p[3]);
           union { bf16x8_t v; uint32_t w[4]; } u8;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) u8.w[r] = pack_bf16x2(p[2 * r], p[2 * r + 1]);
+          for (int q = 0; q < 4; ++q) u8.w[q] = pack_bf16x2(p[q][0], p[q][1]);
           pf[s] = u8.v;
         }
+        float l = lsum[0] + lsum[1];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         inv = 1.0f / l;
@@ -638,11 +648,8 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
 #pragma unroll
             for (int e = 0; e < ND; ++e) {
               const int d = (dt0 + e) * 16 + fq;
-              const unsigned char* vr = Vs + d * 512 + (g & 1) * 8;
-              union { bf16x8_t v; uint2 h2[2]; } vf;
-              vf.h2[0] = *reinterpret_cast<const uint2*>(vr + (((s * 4 + (g >> 1)) ^ (d & 15)) << 4));
-              vf.h2[1] = *reinterpret_cast<const uint2*>(vr + (((s * 4 + 2 + (g >> 1)) ^ (d & 15)) << 4));
-              ot[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[s], ot[e], 0, 0, 0);
+              const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vs + d * 512 + (((s * 4 + g) ^ (d & 15)) << 4));
+              ot[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[s], ot[e], 0, 0, 0);
             }
           }
         }

@@ -137,6 +137,14 @@ def test_paged_kv_cache_equals_extents_and_returns_pages_out_of_order(prec, monk
         held0 = sess.kv_stats()["held"]
         gen = sess.generate(n_new, stop_ids=tuple(stops))
         st2 = sess.kv_stats()
+        # generation in two calls: a sequence the first call finished (its pages are back in the pool) stays finished, the others go on (this used to abort the batch)
+        sess.prefill(audios, pre, post, want_logits=False)
+        g1 = sess.generate(10, stop_ids=tuple(stops))
+        g2 = sess.generate(5, stop_ids=tuple(stops))
+        if len(gen[0]) >= 14:
+            assert np.array_equal(np.concatenate([g1[0], g2[0][1:]]), gen[0][:14]) and g2[0][0] == g1[0][-1]      # (a call starts by emitting the pick the last one ended on)
+        if B >= 3:
+            assert len(g1[2]) == len(gen[2]) < 10 and len(g2[2]) == 0
         beam = None
         if name != "shuffled":
             sess.prefill(audios, pre, post, want_logits=False)

@@ -49,7 +49,7 @@ def whisper_text(tokenizer, ids, remove_repeats=True):
 def run(a) -> dict:
     shim, eng, audio_io, cfgm = _m("ort_shim"), _m("engine"), _m("audio_io"), _m("config")
     prec = 1 if a.precision == "f32" else 0
-    if (a.precision == "fp8mm" and a.family != "whisper") or (a.precision == "fp8w" and a.family not in ("whisper", "qwen_asr")):
+    if (a.precision in ("fp8mm", "mxfp4w") and a.family != "whisper") or (a.precision == "fp8w" and a.family not in ("whisper", "qwen_asr")):
         raise SystemExit("--precision %s exists for --family whisper%s only" % (a.precision, " / qwen_asr" if a.precision == "fp8w" else ""))
     files = []
     if a.family in ("sensevoice", "paraformer"):
@@ -68,10 +68,10 @@ def run(a) -> dict:
         cfg = cfgm.WhisperConfig(**info["config"])
         ckm = _m("checkpoints")
         bundle_prec = int(info.get("precision", prec))
-        if a.precision in ("fp8w", "fp8mm"):       # opt-in: decoder projections + cross-K/V as e4m3 bytes over a bf16 bundle; fp8mm also runs the encoder FFN pair on the FP8 matrix pipe (include/asr_mi355x.h)
+        if a.precision in ("fp8w", "fp8mm", "mxfp4w"):       # opt-in: decoder projections + cross-K/V as e4m3 bytes over a bf16 bundle; fp8mm also runs the encoder FFN pair on the FP8 matrix pipe (include/asr_mi355x.h)
             if bundle_prec != 0:
                 raise SystemExit("--precision %s needs a bf16 bundle (convert the checkpoint with --precision bf16)" % a.precision)
-            bundle_prec = 2 if a.precision == "fp8w" else 3
+            bundle_prec = {"fp8w": 2, "fp8mm": 3, "mxfp4w": 4}[a.precision]
         sess = eng.WhisperSession(cfg, blob, bundle_prec)
         tok = None
         if a.tokenizer:
@@ -168,8 +168,8 @@ def main():
     r.add_argument("--wav", nargs="+", required=True)
     r.add_argument("--language", default="auto")
     r.add_argument("--tokenizer", help="SentencePiece model (SenseVoice), vocabulary file (Paraformer) or HF tokenizer directory (Whisper / Qwen3-ASR)")
-    r.add_argument("--precision", default="f32", choices=("bf16", "f32", "fp8w", "fp8mm"),
-                   help="f32 = verification mode (the mode whose tokens equal the reference's); fp8w = Whisper / Qwen3-ASR, opt-in e4m3 decoder weights (Whisper: and cross-K/V); fp8mm = fp8w + encoder FFN on the FP8 matrix pipe")
+    r.add_argument("--precision", default="f32", choices=("bf16", "f32", "fp8w", "fp8mm", "mxfp4w"),
+                   help="f32 = verification mode (the mode whose tokens equal the reference's); fp8w = Whisper / Qwen3-ASR, opt-in e4m3 decoder weights (Whisper: and cross-K/V); fp8mm = fp8w + encoder FFN on the FP8 matrix pipe; mxfp4w = fp8w with the Whisper decoder weights as OCP MXFP4")
     r.add_argument("--sliding-window", type=int, default=0)
     r.add_argument("--repeat-penalty", type=float, default=1.0, help="1.0 = plain greedy (the comparison default); the reference scripts default to 0.8")
     r.add_argument("--beam", type=int, default=1)

@@ -1937,6 +1937,7 @@ constexpr int SA_MAXK = 64, SA_HD = 128;
 // query rows are staged in LDS, the nq x nk scores are spread over the threads (one 128-long dot product each), a wave per
 // query row does the soft-max, and the nq x 128 outputs are spread over the threads again.
 constexpr int SA_MAXQ = 16;
+constexpr int SA_F32_DYN = 144 * 1024;          // dynamic LDS of the f32 instance: its K / V images (67.6 KB) + the rest of the CU, so that nothing shares the CU's LDS with it
 
 template <typename T>
 __global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a) {
@@ -1948,9 +1949,17 @@ __global__ __launch_bounds__(256) void stream_attn_kernel(const StreamAttnArgs a
   // reads per four FMAs in the score phase, nine per eight in the context phase): a key row's four dims are one 8- / 16-byte read, a query row's and a score row's four values
   // one 16-byte broadcast read. Every FMA chain still runs in the original order, so the results are unchanged bit for bit. Row pitches: K / V 4 elements over 128 (rows stay
   // 8- / 16-byte aligned; 64 keys at one column pair hit every bank once per half / quarter wave), Q and P rows 16-byte aligned.
+  // (round 6, ADVICE r05: the f32 instance's K / V images live in DYNAMIC LDS -- launch_stream_attn asks for SA_F32_DYN bytes, which with the static Q / P tiles is the
+  //  whole CU -- so its static footprint is 13 KB like any other kernel's and growth of SA_MAXK / the pitches fails at compile time, not at launch)
   constexpr int SA_KP = SA_HD + 4, SA_QP = SA_HD + 4, SA_PP = SA_MAXK + 4;
-  __shared__ __attribute__((aligned(16))) T Ks[SA_MAXK][SA_KP];
-  __shared__ __attribute__((aligned(16))) T Vs[SA_MAXK][SA_KP];
+  constexpr bool DYN = sizeof(T) == 4;
+  static_assert(!DYN || 2 * SA_MAXK * SA_KP * (int)sizeof(T) <= SA_F32_DYN, "stream_attn<float>: K / V images exceed the dynamic LDS the launcher asks for");
+  static_assert(SA_F32_DYN + SA_MAXQ * (SA_QP + SA_PP) * 4 + 2 * SA_KP * 4 <= 160 * 1024, "stream_attn<float>: static + dynamic LDS exceed a CU");
+  __shared__ __attribute__((aligned(16))) T KsS[DYN ? 1 : SA_MAXK][SA_KP];
+  __shared__ __attribute__((aligned(16))) T VsS[DYN ? 1 : SA_MAXK][SA_KP];
+  extern __shared__ __attribute__((aligned(16))) unsigned char sa_dyn[];
+  T (*Ks)[SA_KP] = DYN ? reinterpret_cast<T (*)[SA_KP]>(sa_dyn) : KsS;
+  T (*Vs)[SA_KP] = DYN ? reinterpret_cast<T (*)[SA_KP]>(sa_dyn + (size_t)SA_MAXK * SA_KP * sizeof(T)) : VsS;
   __shared__ __attribute__((aligned(16))) float Qs[SA_MAXQ][SA_QP];
   __shared__ __attribute__((aligned(16))) float Ps[SA_MAXQ][SA_PP];
   auto lds4 = [](const T* p) -> float4 {                    // four consecutive elements of a K / V row
@@ -2231,10 +2240,10 @@ void launch_stream_carry(const float* x, int ld, const UttPlan* plan, int n_acti
 template <typename T>
 void launch_stream_attn(const StreamAttnArgs& a, int n_active, hipStream_t s) {
   ASR_REQUIRE(a.cap + a.n_cur <= SA_MAXK, "stream_attn: %d + %d keys exceed %d", a.cap, a.n_cur, SA_MAXK);
-  // f32 sessions: 78 KB of static LDS per workgroup; with 80 KB of (unused) dynamic LDS on top nothing else shares the CU's LDS with it (see the kernel)
+  // f32 sessions: the K / V images are dynamic LDS, and the request covers the rest of the CU: nothing else shares the CU's LDS with this workgroup (see the kernel)
   size_t pad = 0;
   if (sizeof(T) == 4) {
-    pad = 80 * 1024;
+    pad = SA_F32_DYN;
     static PerDeviceOnce once;
     if (once.first()) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_attn_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
   }

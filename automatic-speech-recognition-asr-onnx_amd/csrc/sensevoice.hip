@@ -1482,7 +1482,8 @@ void SvSession::stream_step(const float* audio, int audio_mem, const int32_t* st
     HIP_CHECK(hipMemcpyAsync(h_err, st_flags.as<unsigned>() + (size_t)(c.n_blocks - 1) * n * 4, 4, hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
   if (prof.enabled) prof.collect();
-  // (histories of the layers in front of the one that gave up are rolled already: the step cannot be redone, the streams have to be reset)
+  // (a cluster that gave up has rolled the histories of the layers in front of it: with a snapshot the state is restored and the step redone on the per-launch path
+  //  below; without one -- no other session existed when the step started -- the step fails loudly and the streams have to be reset)
   if (fused_ran && (st_times_layer >= 0 || st_times_layer <= -2)) {               // tuning: mean phase intervals over the workgroups (100 MHz clock -> us)
     const int nwg = (n + 7) / 8 * 32;
     std::vector<unsigned long long> t((size_t)nwg * 16);

@@ -39,6 +39,9 @@ struct GemmArgs {
   // per output column; a lane loads 8 bytes per fragment, widens them to bf16 in registers (exact) and the finished sum is multiplied by the scale -- bit for bit the
   // product over the dequantised bf16 copy (which W keeps for every other path). With W8 set a launch of <= 64 rows always streams weights (skinny kernel).
   const unsigned char* W8 = nullptr; int ldw8 = 0; const float* w_scale = nullptr;
+  // Skinny path, MXFP4 weights (precision mode ASR_PRECISION_MXFP4W of Qwen3-ASR): e2m1 nibbles [N][K / 2] + one e8m0 scale byte per (row, 32 k) [N][K / 32]
+  // (launch_quantize_rows_mxfp4); the K-step of the MFMA is the block of the format, the widening instruction applies the scale. W keeps the dequantised bf16 copy.
+  const unsigned char* W4 = nullptr; const unsigned char* w_scale4 = nullptr;
   // LayerNorm evaluated inside the GEMM (144-row-tile kernel only; K must span the whole normalised row): A holds the RAW rows
   // x in bf16, row statistics over the first ln_dim columns are accumulated from the LDS tiles during the MFMA loop and
   // C = rstd (x W^T - mean ln_colsum) + bias. Needs the LayerNorm affine folded into W / bias; ln_colsum[n] = sum_k W[n][k].

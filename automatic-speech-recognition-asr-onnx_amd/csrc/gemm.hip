@@ -714,8 +714,18 @@ __device__ __forceinline__ bf16x8_t sk_fp8x8_to_bf16x8(sk_u32x2_t r) {
   return u.v;
 }
 
-template <int MT, bool LN, bool W8 = false>     // LN: the LayerNorm prologue (own instance: its registers / LDS allow one workgroup per CU only); W8: e4m3 weight bytes (GemmArgs::W8)
+struct sk_w4_t { unsigned r; unsigned e; };       // MXFP4: a lane's 8 nibbles of one K-step + the block's e8m0 scale byte
+__device__ __forceinline__ bf16x8_t sk_fp4x8_to_bf16x8(sk_w4_t w) {
+  const float sc = __uint_as_float(w.e << 23);
+  union { bf16x8_t v; sk_bf16x2_hw_t p[4]; } u;
+  u.p[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w.r, sc, 0); u.p[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w.r, sc, 1);
+  u.p[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w.r, sc, 2); u.p[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w.r, sc, 3);
+  return u.v;
+}
+
+template <int MT, bool LN, int WQ = 0>     // LN: the LayerNorm prologue (own instance: its registers / LDS allow one workgroup per CU only); WQ: 1 = e4m3 weight bytes (GemmArgs::W8), 2 = MXFP4 (GemmArgs::W4)
 __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_bf16_skinny(const GemmArgs g) {   // <= 128 VGPRs: two workgroups share a CU
+  constexpr bool W8 = WQ == 1, W4 = WQ == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fgrp = lane >> 4;
@@ -727,10 +737,14 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
   // the simultaneous requests over the slices (the cross-wave sum below is order-stable per workgroup, so results stay reproducible).
   const int kw = (wave + (int)blockIdx.x) & (SK_WAVES - 1);
   const int k_begin = (ks * SK_WAVES + kw) * kslice;
-  using wfrag_t = typename std::conditional<W8, sk_u32x2_t, bf16x8_t>::type;       // a lane's 8 weights of one K-step: 8 bytes or 16
+  using wfrag_t = typename std::conditional<W8, sk_u32x2_t, typename std::conditional<W4, sk_w4_t, bf16x8_t>::type>::type;       // a lane's 8 weights of one K-step: 8 bytes, 4 bytes + a scale, or 16
   const bf16_t* wp = reinterpret_cast<const bf16_t*>(g.W) + (size_t)(n0 + frow) * g.ldw + k_begin + fgrp * 8;
   const unsigned char* wp8 = g.W8 + (size_t)(n0 + frow) * g.ldw8 + k_begin + fgrp * 8;
+  const unsigned char* wp4 = g.W4 + (size_t)(n0 + frow) * (g.K >> 1) + ((k_begin + fgrp * 8) >> 1);
+  const unsigned char* sp4 = g.w_scale4 + (size_t)(n0 + frow) * (g.K >> 5) + (k_begin >> 5);
   auto w_load = [&](int k) -> wfrag_t {
+    if constexpr (W4) return sk_w4_t{__builtin_nontemporal_load(reinterpret_cast<const unsigned*>(wp4 + (k >> 1))), (unsigned)sp4[k >> 5]};
+    else
     if constexpr (W8) return __builtin_nontemporal_load(reinterpret_cast<const sk_u32x2_t*>(wp8 + k));
     else return __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + k));
   };
@@ -832,7 +846,7 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
     for (int u = 0; u < U; ++u) {
       if (k + u * 32 < kslice) {
         bf16x8_t wv;
-        if constexpr (W8) wv = sk_fp8x8_to_bf16x8(wf[u]); else wv = wf[u];
+        if constexpr (W8) wv = sk_fp8x8_to_bf16x8(wf[u]); else if constexpr (W4) wv = sk_fp4x8_to_bf16x8(wf[u]); else wv = wf[u];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           // rows past M are never stored: their lanes request nothing from memory (at one row the 16-row tile pulled 16 x the bytes through this CU's 64 B / clk path;
@@ -1002,10 +1016,17 @@ void launch_skinny(const GemmArgs& g, hipStream_t s) {
     }
   }
   if constexpr (MT <= 4) {
+    if (g.W4) {
+      ASR_REQUIRE(g.w_scale4 && !g.ln_x && g.K % 32 == 0, "gemm(skinny): MXFP4 weights need their block scales, K a multiple of 32 and no LayerNorm prologue");
+      note_kernel("skinny_w4");
+      hipLaunchKernelGGL((gemm_bf16_skinny<MT, false, 2>), dim3(g.N / 16, gg.sk_splits), dim3(64 * SK_WAVES), lds, s, gg);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     if (g.W8) {
       ASR_REQUIRE(g.w_scale && !g.ln_x && g.ldw8 % 8 == 0, "gemm(skinny): byte weights need their scales, 8-byte aligned rows and no LayerNorm prologue");
       note_kernel("skinny_w8");
-      hipLaunchKernelGGL((gemm_bf16_skinny<MT, false, true>), dim3(g.N / 16, gg.sk_splits), dim3(64 * SK_WAVES), lds, s, gg);
+      hipLaunchKernelGGL((gemm_bf16_skinny<MT, false, 1>), dim3(g.N / 16, gg.sk_splits), dim3(64 * SK_WAVES), lds, s, gg);
       HIP_CHECK(hipGetLastError());
       return;
     }
@@ -1415,7 +1436,7 @@ bool gemm_ln_fusable(const GemmArgs& g) {
 // mirrors the routing of launch_gemm_bf16 (conservatively: "false" only costs the caller a stand-alone RMSNorm launch)
 bool gemm_reduce_can_norm(const GemmArgs& g) {
   if (g.N != 1024 || g_gemm_variant >= 0 || g.ln_x || g.a_rms_eps != 0.0f || g.ln_colsum || g.amax_val || g.out_t || g.lo_group) return false;
-  const bool needs_skinny = !g.sk_ws || g.W8 != nullptr;
+  const bool needs_skinny = !g.sk_ws || g.W8 != nullptr || g.W4 != nullptr;
   if (g.M <= 64 && (needs_skinny || g.M <= genv().skinny_max_plain) && g.K % (32 * SK_WAVES) == 0) return false;
   if (genv().skinny144 && g.M <= 144 && g.sk_ws && !g.st_out && g.K % (32 * SK_WAVES) == 0 && (g.lda * 2) % 16 == 0) return false;
   int st = 0;
@@ -1431,7 +1452,7 @@ void launch_gemm_bf16(const GemmArgs& g, hipStream_t s) {
   const int tall_min = genv().tall_min;
   const bool tall = g.M > tall_min && g.N >= 16384 && !g.ln_x && g.a_rms_eps == 0.0f && g.act != ACT_SWIGLU;
   const int skinny_max_plain = genv().skinny_max_plain;   // rows up to which PLAIN GEMMs (no prologue) stream weights; above, the tiled split-K pass shares the activation rows across 64 columns (Whisper B = 64: 4.62 -> 3.89 ms per token)
-  const bool needs_skinny = g.ln_x || g.a_rms_eps != 0.0f || !g.sk_ws || g.W8 != nullptr;
+  const bool needs_skinny = g.ln_x || g.a_rms_eps != 0.0f || !g.sk_ws || g.W8 != nullptr || g.W4 != nullptr;
   if (g.M <= 64 && (needs_skinny || g.M <= skinny_max_plain || g.N % 128 != 0) && !tall && !g.out_t && !g.amax_val && g.lo_group == 0 && g.K % (32 * SK_WAVES) == 0 && g_gemm_variant < 0) {
     ASR_REQUIRE((g.A || g.ln_x) && g.W && g.N % 16 == 0, "gemm(skinny): bad operands");
     ASR_REQUIRE(g.ln_x || (g.lda * 2) % 16 == 0, "gemm(skinny): lda must be a 16-byte multiple");

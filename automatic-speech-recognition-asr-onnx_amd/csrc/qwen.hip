@@ -642,7 +642,7 @@ __global__ void qw_beam_init_kernel(const int32_t* __restrict__ hist_in, int B, 
 // ------------------------------------------------------------------------------------ session
 struct QwEncLayer { const void *wqkv, *wo, *w1, *w2; const float *bqkv, *bo, *b1, *b2; };
 struct QwDecLayer { const void *wqkv, *wo, *gate_up, *down; const float *qn, *kn; };
-struct QwDec8Layer { const unsigned char* w[4]; const float* s[4]; };      // FP8W mode: e4m3 bytes + per-row power-of-two scales of wqkv, wo, gate_up, down
+struct QwDec8Layer { const unsigned char* w[4]; const float* s[4]; const unsigned char* s4[4]; };      // FP8W mode: e4m3 bytes + per-row power-of-two scales of wqkv, wo, gate_up, down
 
 // one decoder pass: the packed rows (T new positions per sequence) and, for the bf16 prefill, the MFMA attention geometry
 struct DecPass {
@@ -672,6 +672,7 @@ struct QwSession : asr_session {
   // Optimize_ONNX_Common.py:27,55-60): the four projections of every decoder layer as e4m3 bytes with one power-of-two scale per output row, streamed by the
   // weight-streaming GEMM of the decode step (<= 64 rows; gemm.hip: gemm_bf16_skinny<.., W8>); their exact bf16 dequantisation serves every other path (prefill, beam
   // search above 64 rows), so all steps of a session see the same effective weights. ASR_FP8_FAKE=1: same quantisation, bf16 kernels throughout (the tests' exact twin).
+  bool fp4 = false;                    // precision mode ASR_PRECISION_MXFP4W: the four projections as OCP MXFP4 (nibbles in d_w8, e8m0 block scales in d_wscale) instead of e4m3
   bool fp8 = false, fp8_fake = false;
   bool use_decode_gemm = true;         // ASR_QWEN_DECODE_GEMM=0: o_proj / down_proj of a decode step through the tiled split-K pass + reduce launch (rounds 1-4) instead of csrc/decode_gemm.hip
   std::vector<QwDec8Layer> dec8;
@@ -798,19 +799,23 @@ void QwSession::init() {
     const int Ns[4] = {qkvn, d, 2 * I, d}, Ks[4] = {d, od, d, I};
     size_t w_elems = 0, n_scales = 0;
     for (int j = 0; j < 4; ++j) { w_elems += (size_t)Ns[j] * Ks[j]; n_scales += Ns[j]; }
-    d_w8.reserve(c.n_layers * w_elems, stream); d_wscale.reserve(c.n_layers * n_scales * 4, stream); d_wdq.reserve(c.n_layers * w_elems * 2, stream);
+    d_w8.reserve(fp4 ? c.n_layers * w_elems / 2 : c.n_layers * w_elems, stream); d_wscale.reserve(fp4 ? c.n_layers * w_elems / 32 : c.n_layers * n_scales * 4, stream);
+    d_wdq.reserve(c.n_layers * w_elems * 2, stream);
     dec8.resize(c.n_layers);
     for (int i = 0; i < c.n_layers; ++i) {
       QwDecLayer& L = dec[i];
       const void** slot[4] = {&L.wqkv, &L.wo, &L.gate_up, &L.down};
-      unsigned char* w8 = d_w8.as<unsigned char>() + i * w_elems;
+      unsigned char* w8 = d_w8.as<unsigned char>() + (fp4 ? i * w_elems / 2 : i * w_elems);
       bf16_t* dq = d_wdq.as<bf16_t>() + i * w_elems;
       float* sc = d_wscale.as<float>() + i * n_scales;
+      unsigned char* sc4 = d_wscale.as<unsigned char>() + i * w_elems / 32;
       for (int j = 0; j < 4; ++j) {
-        launch_quantize_rows_fp8((const bf16_t*)*slot[j], Ks[j], Ns[j], Ks[j], w8, sc, dq, stream);
-        dec8[i].w[j] = w8; dec8[i].s[j] = sc;
+        const size_t ne = (size_t)Ns[j] * Ks[j];
+        if (fp4) launch_quantize_rows_mxfp4((const bf16_t*)*slot[j], Ks[j], Ns[j], Ks[j], w8, sc4, dq, stream);
+        else launch_quantize_rows_fp8((const bf16_t*)*slot[j], Ks[j], Ns[j], Ks[j], w8, sc, dq, stream);
+        dec8[i].w[j] = w8; dec8[i].s[j] = sc; dec8[i].s4[j] = sc4;
         *slot[j] = dq;                                     // from here on "the weights" are the dequantised copies
-        w8 += (size_t)Ns[j] * Ks[j]; dq += (size_t)Ns[j] * Ks[j]; sc += Ns[j];
+        w8 += fp4 ? ne / 2 : ne; dq += ne; sc += Ns[j]; sc4 += ne / 32;
       }
     }
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -947,14 +952,18 @@ void QwSession::decoder_pass(const DecPass& P) {
   const bool fused_attn = P.step && (G == 1 || G == 2 || G == 4) && !no_fuse;
   const bool norm_in_reduce = bf && !rms_in_gemm && !no_fuse && d == 1024;
   const bool w8 = fp8 && !fp8_fake && rms_in_gemm;           // byte weights: the weight-streaming launches of a decode step
-  auto bytes_of = [&](GemmArgs& g, int layer, int wi) { if (w8) { g.W8 = dec8[layer].w[wi]; g.ldw8 = g.K; g.w_scale = dec8[layer].s[wi]; } };
+  auto bytes_of = [&](GemmArgs& g, int layer, int wi) {
+    if (w8 && fp4) { g.W4 = dec8[layer].w[wi]; g.w_scale4 = dec8[layer].s4[wi]; }
+    else if (w8) { g.W8 = dec8[layer].w[wi]; g.ldw8 = g.K; g.w_scale = dec8[layer].s[wi]; }
+  };
   // o_proj / down_proj of a decode step (<= 64 rows, + residual, f32 and bf16 copies of the stream): the decode GEMM of csrc/decode_gemm.hip -- K split across workgroups
   // with the hand-over inside the launch -- instead of the tiled split-K pass and its reduce launch (6.3 + 4.8 us per projection at 64 rows)
   // (the decode GEMM has its own shape limits -- K % 32, K >= 256, 16-byte rows: a geometry outside them keeps the tiled pass)
   auto dgm_shape_ok = [&](int K, int lda) {
     DecGemmArgs a;
     a.A = (const bf16_t*)ctx; a.lda = lda; a.W = (const bf16_t*)ctx; a.ldw = K; a.M = rows; a.N = d; a.K = K;
-    if (w8) { a.W = nullptr; a.W8 = (const unsigned char*)ctx; a.w_scale = (const float*)ctx; }
+    if (w8 && fp4) { a.W = nullptr; a.W4 = (const unsigned char*)ctx; a.w_scale4 = (const unsigned char*)ctx; }
+    else if (w8) { a.W = nullptr; a.W8 = (const unsigned char*)ctx; a.w_scale = (const float*)ctx; }
     return decode_gemm_supported(a);
   };
   const bool dgm = rms_in_gemm && use_decode_gemm && dgm_shape_ok(H * hd, H * hd) && dgm_shape_ok(I, I);
@@ -963,7 +972,8 @@ void QwSession::decoder_pass(const DecPass& P) {
     if (!d_skws.ptr) { d_skws.reserve((size_t)16 << 20, stream); d_skcnt.reserve(4096 * 4, stream); }
     DecGemmArgs a;
     a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)Wt; a.ldw = K; a.M = rows; a.N = N; a.K = K;
-    if (w8) { a.W = nullptr; a.W8 = dec8[layer].w[wi]; a.w_scale = dec8[layer].s[wi]; }
+    if (w8 && fp4) { a.W = nullptr; a.W4 = dec8[layer].w[wi]; a.w_scale4 = dec8[layer].s4[wi]; }
+    else if (w8) { a.W = nullptr; a.W8 = dec8[layer].w[wi]; a.w_scale = dec8[layer].s[wi]; }
     a.add = add; a.ld_add = d; a.out_f32 = of32; a.ld_out_f32 = d; a.out_lo = (bf16_t*)olo; a.ld_out_lo = d;
     a.ws = d_skws.as<float>(); a.ws_bytes = d_skws.cap; a.cnt = d_skcnt.as<int32_t>();
     launch_decode_gemm(a, stream);
@@ -1566,14 +1576,15 @@ extern "C" int asr_qwen_create(const asr_qwen_config* cfg, const void* arena, si
                                asr_session** out) {
   return asr_guard([&] {
     ASR_REQUIRE(cfg && arena && out, "qwen_create: null argument");
-    ASR_REQUIRE(precision == ASR_PRECISION_BF16 || precision == ASR_PRECISION_F32 || precision == ASR_PRECISION_FP8W, "qwen_create: bad precision %d", precision);
+    ASR_REQUIRE(precision == ASR_PRECISION_BF16 || precision == ASR_PRECISION_F32 || precision == ASR_PRECISION_FP8W || precision == ASR_PRECISION_MXFP4W, "qwen_create: bad precision %d", precision);
     asr_require_device(device_id);
     QwSession* s = new QwSession();
     try {
       s->kind = 5;
       s->device = device_id;
       asr_tenant_attach(s);
-      s->fp8 = precision == ASR_PRECISION_FP8W;
+      s->fp4 = precision == ASR_PRECISION_MXFP4W;
+      s->fp8 = precision == ASR_PRECISION_FP8W || s->fp4;
       s->precision = s->fp8 ? ASR_PRECISION_BF16 : precision;        // FP8 mode = bf16 mode with byte-wide decoder projections
       s->cfg = *cfg;
       HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));

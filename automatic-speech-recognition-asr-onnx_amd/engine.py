@@ -493,7 +493,7 @@ class QwenAsrSession(_Session):
     @classmethod
     def from_checkpoint(cls, cfg, ck, precision=PRECISION_BF16, device_id=0):
         from .arena import build_qwen_asr_arena
-        arena_precision = PRECISION_BF16 if precision == PRECISION_FP8W else precision
+        arena_precision = PRECISION_BF16 if precision in (PRECISION_FP8W, PRECISION_MXFP4W) else precision
         return cls(cfg, build_qwen_asr_arena(cfg, ck, arena_precision), precision, device_id)
 
     @staticmethod

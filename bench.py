@@ -310,7 +310,7 @@ def main():
     ap.add_argument("--streams", type=int, default=256, help="mixed: concurrent Paraformer streams per GPU")
     ap.add_argument("--beam", type=int, default=1, help="qwen / mixed: beam width (1 = greedy; BASELINE.json configs[4] names beam 5)")
     ap.add_argument("--fp8mm", action="store_true", help="whisper: opt-in precision mode ASR_PRECISION_FP8MM (FP8W + the encoder's FFN pair on the FP8 matrix pipe); a secondary figure, never the headline")
-    ap.add_argument("--mxfp4", action="store_true", help="whisper: opt-in precision mode ASR_PRECISION_MXFP4W (decoder projections as OCP MXFP4, cross-K/V as e4m3); a secondary figure, never the headline")
+    ap.add_argument("--mxfp4", action="store_true", help="whisper / qwen: opt-in precision mode ASR_PRECISION_MXFP4W (decoder projections as OCP MXFP4; Whisper: cross-K/V as e4m3); a secondary figure, never the headline")
     ap.add_argument("--fp8", action="store_true", help="whisper / qwen: opt-in precision mode ASR_PRECISION_FP8W (decoder projections -- Whisper: and cross-K/V -- as e4m3 bytes); a secondary figure, never the headline")
     ap.add_argument("--decode-tokens", type=int, default=0, help="whisper: generated tokens per utterance (default 4 per audio second)")
     ap.add_argument("--cpu-leg", type=int, default=0, help=argparse.SUPPRESS)        # child process of the CPU baseline's every-core leg
@@ -1129,7 +1129,7 @@ def main_qwen(args):
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t0
     blob = None
-    qprec = arena.PRECISION_FP8W if args.fp8 else arena.PRECISION_BF16         # --fp8: the decoder's projections as e4m3 bytes (opt-in, a secondary figure)
+    qprec = arena.PRECISION_MXFP4W if args.mxfp4 else arena.PRECISION_FP8W if args.fp8 else arena.PRECISION_BF16         # --fp8: the decoder's projections as e4m3 bytes (opt-in, a secondary figure)
     sess = eng.QwenAsrSession(cfg, arena_dev, qprec, local_rank, arena_device_ptr=arena_dev.data_ptr(), arena_bytes=arena_dev.numel())
     audio_np = ckm.synth_audio("unit", B, n_samples, seed=1234 + rank)
     audio_dev = torch.from_numpy(audio_np).to(device)
@@ -1211,7 +1211,7 @@ def main_qwen(args):
         kernels = {k: {"ms_per_step": round(v["total_ms"], 3), "launches_per_step": v["launches"]}
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
         t_pre, t_dec = t_parts["prefill"] / args.steps, t_parts["decode"] / args.steps
-        step_bytes = (1.0 if args.fp8 and B * max(args.beam, 1) <= 64 else 2.0) * dec_params + 2.0 * cfg.vocab * d + B * max(args.beam, 1) * cfg.n_layers * 2 * cfg.n_kv_heads * cfg.d_head * 2.0 * (L + n_tok / 2)
+        step_bytes = ((4.25 / 8 if args.mxfp4 else 1.0) if (args.fp8 or args.mxfp4) and B * max(args.beam, 1) <= 64 else 2.0) * dec_params + 2.0 * cfg.vocab * d + B * max(args.beam, 1) * cfg.n_layers * 2 * cfg.n_kv_heads * cfg.d_head * 2.0 * (L + n_tok / 2)
         per_tok = t_dec / max(n_tok - 1, 1)
         mode = "greedy" if args.beam <= 1 else "beam %d (%d hypothesis rows per step)" % (args.beam, B * args.beam)
         flops = B * (stem + enc + pre_dec)
@@ -1219,7 +1219,7 @@ def main_qwen(args):
             "metric": "audio-sec/s, Qwen3-ASR-0.6B, %g s @ 16 kHz chunks, batch %d per GPU, %s, %d tokens/utterance" % (args.seconds, B, mode, n_tok),
             "value": round(audio_s * args.steps / elapsed, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 (e4m3 storage of the decoder projections)" if args.fp8 else "bf16", "data": "synthetic",
+            "dtype": "bf16 (MXFP4 storage of the decoder projections)" if args.mxfp4 else "bf16 (e4m3 storage of the decoder projections)" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": "Qwen3-ASR-0.6B bf16 (18-layer windowed audio encoder + 28-layer Qwen3 decoder), batch=%d x %g s per GPU, prefill of "
                                    "%d positions (%d audio tokens) + %d %s decode steps, audio resident in HBM" % (B, args.seconds, L, n_audio, n_tok - 1, mode),
                        "global_batch": world * B, "parallelism": f"dp{world}"},

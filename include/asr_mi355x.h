@@ -60,10 +60,11 @@ enum asr_status {
  * the residual stream and the decoder are FP8W's. Needs d_model and d_ffn multiples of 256. The reference's counterpart: its MatMulNBits /
  * dynamic-int8 graphs (Optimize_ONNX_Common.py:55-60).
  *
- * MXFP4W (opt-in, Whisper sessions; round 6): FP8W with the decoder projection weights stored as OCP MXFP4 instead of e4m3 -- e2m1 elements, two per byte,
+ * MXFP4W (opt-in, Whisper and Qwen3-ASR sessions; round 6): FP8W with the decoder projection weights stored as OCP MXFP4 instead of e4m3 -- e2m1 elements, two per byte,
  * one e8m0 scale per 32 consecutive input channels (4.25 bits per weight; the 4-bit counterpart of the reference's MatMulNBits Q4 graphs, README.md:70 q4f32).
  * The block of the format is the K-step of the bf16 MFMA, so a decode-step fragment is widened -- exactly: 2 significant bits x a power of two -- by
- * v_cvt_scalef32_pk_bf16_fp4 with its block's scale; every other pass reads the exact bf16 dequantisation. The cross-K/V cache is FP8W's. */
+ * v_cvt_scalef32_pk_bf16_fp4 with its block's scale; every other pass reads the exact bf16 dequantisation. Whisper's cross-K/V cache is FP8W's; Qwen3-ASR: the four
+ * projections of every decoder layer (the reference's own headline for this family is a 4-bit decoder, README.md:70 q4f32). */
 enum asr_precision { ASR_PRECISION_BF16 = 0, ASR_PRECISION_F32 = 1, ASR_PRECISION_FP8W = 2, ASR_PRECISION_FP8MM = 3, ASR_PRECISION_MXFP4W = 4 };
 
 enum asr_mem { ASR_MEM_HOST = 0, ASR_MEM_DEVICE = 1 };

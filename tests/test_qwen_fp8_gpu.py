@@ -11,7 +11,7 @@ from test_oracle_qwen_asr import qwen_setup, unit_audio
 
 pytestmark = pytest.mark.gpu
 
-BF16, F32, FP8W = 0, 1, 2
+BF16, F32, FP8W, MXFP4W = 0, 1, 2, 4
 
 
 def _forced(sess, audios, pre, post, forced):
@@ -122,3 +122,39 @@ def test_0p6b_fp8_batch64_equals_its_bf16_twin_and_budget_vs_bf16(monkeypatch):
             assert margin[b, upto] < 0.5 * scale, (b, upto, float(margin[b, upto]))
     print(f"qwen_asr_0p6b B=64 logits |max| {scale:.2f}: fp8w vs bf16 {worst:.4f}")
     assert worst < 0.25 * scale
+
+
+def test_mxfp4_session_equals_fake_quantised_bf16_session_and_budget(monkeypatch):
+    """ASR_PRECISION_MXFP4W for Qwen3-ASR (round 6; the reference publishes this family as q4f32, README.md:70): the four projections of every decoder layer as OCP MXFP4
+    (e2m1 + one e8m0 scale per 32 input channels; the quantiser itself is pinned in tests/test_whisper_mxfp4_gpu.py). (1) The nibble kernels add no error of their own:
+    e2m1 x 2^e is exact in bf16, so a bf16 session over the dequantised weights (ASR_FP8_FAKE=1) returns identical logits over a prefill and six teacher-forced steps.
+    (2) The decode launches really stream nibbles (`skinny_w4`). (3) Error against the f32 oracle next to FP8W's, with the budget written down."""
+    g, cfg, ck, cases, head, tail, suffix = _setup("qwen_asr_mid")
+    eng, probe = sub("engine"), sub("_probe")
+    cases = cases[:3]
+    audios = [unit_audio(c["audio_seed"], c["n_samples"]) for c in cases]
+    pre = [head + c["query_ids"].tolist() + suffix for c in cases]
+    post = [tail + c["language_tail_ids"].tolist() for c in cases]
+    orc = QwenAsrOracle(cfg, ck, head, tail, suffix)
+    refs = [orc.greedy(a, 7, c["query_ids"].tolist(), c["language_tail_ids"].tolist()) for a, c in zip(audios, cases)]
+    forced = np.stack([r["token_ids"][:6] for r in refs]).astype(np.int32)
+    want = np.stack([r["logits"][:7] for r in refs])
+    s4 = eng.QwenAsrSession.from_checkpoint(cfg, ck, precision=MXFP4W)
+    probe.gemm_counts(reset=True)
+    l4 = _forced(s4, audios, pre, post, forced)
+    counts = probe.gemm_counts()
+    assert counts.get("skinny_w4", 0) >= 2 * 2 * cfg.n_layers and counts.get("skinny_w8", 0) == 0, counts
+    monkeypatch.setenv("ASR_FP8_FAKE", "1")
+    sf = eng.QwenAsrSession.from_checkpoint(cfg, ck, precision=MXFP4W)
+    monkeypatch.delenv("ASR_FP8_FAKE")
+    lf = _forced(sf, audios, pre, post, forced)
+    s8 = eng.QwenAsrSession.from_checkpoint(cfg, ck, precision=FP8W)
+    l8 = _forced(s8, audios, pre, post, forced)
+    V = cfg.vocab
+    assert np.array_equal(l4[..., :V], lf[..., :V])
+    scale = float(np.abs(want).max())
+    e_4, e_8 = float(np.abs(l4[..., :V] - want).max()), float(np.abs(l8[..., :V] - want).max())
+    print(f"qwen_asr_mid logits |max| {scale:.2f}: fp8w error {e_8:.4f}, mxfp4w error {e_4:.4f}")
+    assert e_4 > e_8                                           # (sanity: 4 bits cost more than 8)
+    assert e_4 < 0.5 * scale + 0.2                             # e2m1 keeps 2 significant bits: ~10 x e4m3's error per weight; a lossy mode on random weights
+    assert np.array_equal(_forced(s4, audios, pre, post, forced), l4)

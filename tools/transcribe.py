@@ -49,7 +49,7 @@ def whisper_text(tokenizer, ids, remove_repeats=True):
 def run(a) -> dict:
     shim, eng, audio_io, cfgm = _m("ort_shim"), _m("engine"), _m("audio_io"), _m("config")
     prec = 1 if a.precision == "f32" else 0
-    if (a.precision in ("fp8mm", "mxfp4w") and a.family != "whisper") or (a.precision == "fp8w" and a.family not in ("whisper", "qwen_asr")):
+    if (a.precision == "fp8mm" and a.family != "whisper") or (a.precision in ("fp8w", "mxfp4w") and a.family not in ("whisper", "qwen_asr")):
         raise SystemExit("--precision %s exists for --family whisper%s only" % (a.precision, " / qwen_asr" if a.precision == "fp8w" else ""))
     files = []
     if a.family in ("sensevoice", "paraformer"):
@@ -100,10 +100,10 @@ def run(a) -> dict:
         info, blob = shim.load_model(os.path.join(a.model, "Qwen_ASR.asrmodel"))
         cfg = cfgm.QwenAsrConfig(**info["config"])
         bundle_prec = int(info.get("precision", prec))
-        if a.precision == "fp8w":                   # opt-in: the decoder's projections as e4m3 bytes over a bf16 bundle (include/asr_mi355x.h)
+        if a.precision in ("fp8w", "mxfp4w"):      # opt-in: the decoder's projections as e4m3 bytes / MXFP4 nibbles over a bf16 bundle (include/asr_mi355x.h)
             if bundle_prec != 0:
-                raise SystemExit("--precision fp8w needs a bf16 bundle (convert the checkpoint with --precision bf16)")
-            bundle_prec = 2
+                raise SystemExit("--precision %s needs a bf16 bundle (convert the checkpoint with --precision bf16)" % a.precision)
+            bundle_prec = 2 if a.precision == "fp8w" else 4
         sess = eng.QwenAsrSession(cfg, blob, bundle_prec)
         tok = None
         if a.tokenizer:

@@ -594,8 +594,13 @@ def secondary_lines(cfg, ck, audio_np, local_rank, device, cpu_leg=False):
     for _ in range(20):
         s16.run(one, [0])
     dt = (time.perf_counter() - t0) / 20
-    out["sensevoice_bf16_b1"] = {"ms_per_chunk": round(dt * 1e3, 3), "audio_s_per_s": round(n_samples / cfg.sample_rate / dt, 1),
-                                 "rtf": round(dt / (n_samples / cfg.sample_rate), 6)}
+    w_bytes = 2.0 * 234.0e6                                  # SenseVoiceSmall, 234.0 M parameters in bf16, read once per batch: the algorithmic bytes of a batch-1 pass
+    out["sensevoice_bf16_b1"] = {"what": "SenseVoiceSmall bf16, ONE 8 s chunk per call (the metric's batch-1 point), host audio in / ids out; SANM blocks on sanm_tiles_kernel (36 workgroups per window)",
+                                 "ms_per_chunk": round(dt * 1e3, 3), "audio_s_per_s": round(n_samples / cfg.sample_rate / dt, 1),
+                                 "rtf": round(dt / (n_samples / cfg.sample_rate), 6),
+                                 "roofline": {"bound": "hbm", "achieved": round(w_bytes / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(w_bytes / dt / 1e9 / HBM_PEAK_GBS, 4),
+                                              "traffic": None, "floor_us": round(w_bytes / 6.29e12 * 1e6, 1),
+                                              "note": "a latency chain (five meetings per block at memory-side latency), not a bandwidth-bound stream: DESIGN.md 4.13"}}
     del s32, s16
     # ---- Whisper-large-v3 bf16, 8 s chunks (the other model the metric names)
     try:

@@ -900,6 +900,8 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
     //      image (destination slab, source h) of the exchange buffer, f16, write-through
     const int dst_h = wave >> 1;
     const bool plain = cluster_plain_stores(place, a->opt);
+    // opt 512 (tuning): the partial images by ORDINARY stores when the cluster shares an XCD -- unlike the all-gathered payloads an image has exactly one reader, so a dirty line is read once
+    const bool plain_p = plain || ((a->opt & 512) && cluster_shares_l2(place, a->opt));
     unsigned char* pimg = reinterpret_cast<unsigned char*>(a->hid + (size_t)row0 * DFF) + (size_t)(4 * dst_h + h) * n_act * 4096;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -915,7 +917,7 @@ __global__ __launch_bounds__(NT) void sanm_block8_kernel(const SanmBlockArgs a_b
           *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
           *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else if (i < n_act) {
-          store16_wt(pimg + row * 256 + ((gi ^ (row & 15)) << 4), pack8_f16(v), plain);
+          store16_wt(pimg + row * 256 + ((gi ^ (row & 15)) << 4), pack8_f16(v), plain_p);
         }
       }
     }

@@ -352,7 +352,8 @@ def test_batch64_32_steps_token_for_token_on_a_prototype_head(prec):
     d_orc = np.take_along_axis(head, top[..., None], 2) - head
     d_gpu = np.take_along_axis(got, top[..., None], 2) - got
     window, live = 4.0, np.isfinite(d_orc)                                     # (begin-suppressed classes sit at -inf in both: no difference to measure)
-    err = np.where(live, np.abs(np.where(live, d_gpu - d_orc, 0.0)), 0.0)
+    with np.errstate(invalid="ignore"):                                        # (inf - inf at the suppressed classes, masked out by `live`)
+        err = np.where(live, np.abs(d_gpu - d_orc), 0.0)
     assert np.array_equal(np.isfinite(d_gpu), live)
     e, e_all = float(err[live & (d_orc <= window)].max()), float(err.max())            # classes within `window` of the winner are the only ones that can compete
     print(f"whisper_d256 prototype head ({K} classes), B = {B} x {S} steps, precision {prec}: oracle margin min {margin.min():.3f} median {np.median(margin):.3f}; "

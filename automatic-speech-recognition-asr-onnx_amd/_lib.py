@@ -77,6 +77,8 @@ SIGNATURES = {
     "asr_whisper_generate": (_i, [_vp, _i, _i, _ip, _ip]),
     "asr_whisper_set_penalty": (_i, [_vp, C.c_float, _i]),
     "asr_whisper_track_history": (_i, [_vp, _i]),
+    "asr_whisper_set_fp8_act_shift": (_i, [_vp, _i]),
+    "asr_whisper_fp8_stats": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "asr_whisper_no_speech_prob": (_i, [_vp, _i, _fp]),
     "asr_whisper_set_sampling": (_i, [_vp, _i, C.c_float, _i, C.c_float, C.c_float, C.c_uint64]),
     "asr_whisper_set_sampling_noise": (_i, [_vp, _fp, _i]),

@@ -128,6 +128,7 @@ struct Fp8GemmArgs {
   int act = ACT_NONE;                                 // byte output only
   unsigned char* out8 = nullptr; int ld_out8 = 0; float out_inv_scale = 1.0f;    // e4m3 bytes of act(...) * out_inv_scale, saturating at +-448
   float* out_f32 = nullptr; int ld_out_f32 = 0;
+  unsigned long long* sat_count = nullptr;            // byte output: += the number of elements whose scaled value left +-448 (or was NaN) before the clamp
   int group_m = 0;                                    // (set by the launcher)
 };
 void launch_gemm_fp8(const Fp8GemmArgs& g, hipStream_t s);

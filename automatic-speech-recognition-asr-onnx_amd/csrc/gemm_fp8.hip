@@ -27,6 +27,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_ppp(const Fp8GemmArgs g, cons
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  int n_sat = 0;                                         // byte output: elements of this lane that met the e4m3 clamp
   const int tiles_n = g.N / PP_T, tiles_m = total_tiles / tiles_n;
   auto tile_of = [&](int vb, int& tm, int& tn) {
     const int tile = xcd_remap(vb, total_tiles);
@@ -199,8 +200,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_ppp(const Fp8GemmArgs g, cons
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
               if constexpr (ACT == ACT_GELU_ERF) gelu_erf_fast2(v[e], v[e + 1]); else { v[e] = apply_act_ct<ACT>(v[e]); v[e + 1] = apply_act_ct<ACT>(v[e + 1]); }
-              v[e] = fminf(fmaxf(v[e] * g.out_inv_scale, -448.0f), 448.0f);
-              v[e + 1] = fminf(fmaxf(v[e + 1] * g.out_inv_scale, -448.0f), 448.0f);
+              const float t0 = v[e] * g.out_inv_scale, t1 = v[e + 1] * g.out_inv_scale;
+              v[e] = fminf(fmaxf(t0, -448.0f), 448.0f);
+              v[e + 1] = fminf(fmaxf(t1, -448.0f), 448.0f);
+              if (m < g.M) n_sat += (v[e] != t0) + (v[e + 1] != t1);          // (a NaN compares unequal too)
             }
             int w0 = 0, w1 = 0;
             w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w0, true);
@@ -212,6 +215,9 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_ppp(const Fp8GemmArgs g, cons
     }
     if (!has_next) break;
     vb = nvb; tm = ntm; tn = ntn; tpar ^= 1;
+  }
+  if constexpr (OUT == 0) {
+    if (g.sat_count && n_sat) atomicAdd(g.sat_count, (unsigned long long)n_sat);          // (rare: a saturating operand is a mis-scaled one)
   }
   wait_vmcnt<0>();                                       // the units nobody reads must land before the LDS is handed to another workgroup
 }

@@ -72,9 +72,13 @@ struct WhSession : asr_session {
   // scale per (sequence, head) and streamed as bytes by the decode attention. ASR_FP8_FAKE=1: same quantisation, bf16 kernels throughout.
   // precision mode ASR_PRECISION_FP8MM (opt-in): FP8W plus the encoder's FFN pair on the FP8 matrix pipe (csrc/gemm_fp8.hip): fc1 / fc2 weights as e4m3 bytes with
   // per-row power-of-two scales, their activation operands (the second LayerNorm's output, the GELU output) as e4m3 bytes at unit scale
+  // (saturating at 448: the LayerNorm output cannot get there -- its affine pair is folded into fc1, |row| <= sqrt(d_model) --; the GELU output can on a real
+  // checkpoint: it is stored as value * 2^-act_shift (ASR_FP8MM_ACT_SHIFT / asr_whisper_set_fp8_act_shift, default 0), fc2 multiplies the shift back, and every
+  // element that still meets the clamp is counted -- asr_whisper_fp8_stats; the Python session warns when the count moves)
   bool fp8_mm = false;
+  int fp8_act_shift = 0;
   std::vector<Enc8Layer> enc8;
-  DeviceBuffer d_ew8, d_ewscale, d_h8, d_ffn8;
+  DeviceBuffer d_ew8, d_ewscale, d_h8, d_ffn8, d_sat;
   bool fp4 = false;                    // precision mode ASR_PRECISION_MXFP4W (opt-in): FP8W with the decoder projections as MXFP4 (e2m1 + e8m0 per 32 k) instead of e4m3
   bool fp8 = false, fp8_fake = false, fp8_weights = true, fp8_kv = true;     // ASR_FP8_WEIGHTS=0 / ASR_FP8_KV=0: leave that half in bf16 (to price the halves separately)
   std::vector<Dec8Layer> dec8;
@@ -89,7 +93,7 @@ struct WhSession : asr_session {
 
   ~WhSession() override {
     for (DeviceBuffer* b : {&d_plan, &d_audio, &d_mel, &d_blkmax, &d_x0, &d_h1, &d_xa, &d_xb, &d_xc, &d_h, &d_qk, &d_vt, &d_ctx,
-                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_kvpool, &d_ptable, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise, &d_nsp, &d_skws, &d_skcnt, &d_colsum, &d_dlo, &d_w8, &d_wscale, &d_wdq, &d_cross8, &d_cscale, &d_ew8, &d_ewscale, &d_h8, &d_ffn8})
+                            &d_ffn, &d_cross, &d_kc, &d_vc, &d_kvpool, &d_ptable, &d_ids, &d_next, &d_logits, &d_dx, &d_dqkv, &d_dtok, &d_hist, &d_save, &d_nsaved, &d_noise, &d_nsp, &d_skws, &d_skcnt, &d_colsum, &d_dlo, &d_w8, &d_wscale, &d_wdq, &d_cross8, &d_cscale, &d_ew8, &d_ewscale, &d_h8, &d_ffn8, &d_sat})
       b->release();
     drop_graphs();
     for (auto& kv : taps) kv.second.buf.release();
@@ -172,6 +176,7 @@ void WhSession::init() {
     ASR_REQUIRE(d % 256 == 0 && dff % 256 == 0, "whisper: FP8MM mode needs d_model and d_ffn to be multiples of 256");
     const size_t per = (size_t)2 * d * dff;
     d_ew8.reserve((size_t)c.n_enc_layers * per, stream); d_ewscale.reserve((size_t)c.n_enc_layers * (d + dff) * 4, stream);
+    d_sat.reserve(8, stream); HIP_CHECK(hipMemsetAsync(d_sat.ptr, 0, 8, stream));
     enc8.resize(c.n_enc_layers);
     for (int i = 0; i < c.n_enc_layers; ++i) {
       unsigned char* w8 = d_ew8.as<unsigned char>() + i * per;
@@ -407,12 +412,14 @@ void WhSession::encode(const float* audio, int audio_mem, const int64_t* offs, i
         Fp8GemmArgs g;
         g.A = d_h8.as<unsigned char>(); g.lda = d; g.W = enc8[i].w1; g.ldw = d; g.M = rows; g.N = dff; g.K = d; g.w_scale = enc8[i].s1; g.bias = L.b1;
         g.act = act; g.out8 = d_ffn8.as<unsigned char>(); g.ld_out8 = dff;
+        g.out_inv_scale = ldexpf(1.0f, -fp8_act_shift); g.sat_count = d_sat.as<unsigned long long>();
         launch_gemm_fp8(g, stream);
       }
       {
         ProfScope ps(prof, "gemm_ffn2", stream);
         Fp8GemmArgs g;
         g.A = d_ffn8.as<unsigned char>(); g.lda = dff; g.W = enc8[i].w2; g.ldw = dff; g.M = rows; g.N = d; g.K = dff; g.w_scale = enc8[i].s2; g.bias = L.b2;
+        g.a_scale = ldexpf(1.0f, fp8_act_shift);
         g.add = xb; g.ld_add = d; g.out_f32 = xa; g.ld_out_f32 = d;
         launch_gemm_fp8(g, stream);
       }
@@ -790,6 +797,7 @@ extern "C" int asr_whisper_create(const asr_whisper_config* cfg, const void* are
       s->cfg = *cfg;
       gemm_reload_env();
       if (const char* e = getenv("ASR_FP8_FAKE")) s->fp8_fake = e[0] == '1';
+      if (const char* e = getenv("ASR_FP8MM_ACT_SHIFT")) s->fp8_act_shift = std::min(std::max(atoi(e), 0), 16);
       if (const char* e = getenv("ASR_FP8_WEIGHTS")) s->fp8_weights = !(e[0] == '0');
       if (const char* e = getenv("ASR_FP8_KV")) s->fp8_kv = !(e[0] == '0');
       if (const char* e = getenv("ASR_NO_GRAPH")) s->use_graph = !(e[0] == '1');
@@ -863,6 +871,29 @@ extern "C" int asr_whisper_no_speech_prob(asr_session* s, int no_speech_id, floa
     launch_no_speech_prob(w->d_logits.as<float>(), w->vpad, B, w->cfg.vocab, w->suppress, no_speech_id, w->d_nsp.as<float>(), w->stream);
     HIP_CHECK(hipMemcpyAsync(prob_out, w->d_nsp.ptr, (size_t)B * 4, hipMemcpyDeviceToHost, w->stream));
     HIP_CHECK(hipStreamSynchronize(w->stream));
+  });
+}
+
+extern "C" int asr_whisper_set_fp8_act_shift(asr_session* s, int shift) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 2, "whisper_set_fp8_act_shift: not a Whisper session");
+    ASR_REQUIRE(shift >= 0 && shift <= 16, "whisper_set_fp8_act_shift: shift %d outside 0 .. 16", shift);
+    static_cast<WhSession*>(s)->fp8_act_shift = shift;          // (the encoder is not graph-captured: the next encode uses it)
+  });
+}
+
+extern "C" int asr_whisper_fp8_stats(asr_session* s, uint64_t stats[2]) {
+  return asr_guard([&] {
+    ASR_REQUIRE(s && s->kind == 2 && stats, "whisper_fp8_stats: not a Whisper session");
+    WhSession* w = static_cast<WhSession*>(s);
+    HIP_CHECK(hipSetDevice(w->device));
+    stats[0] = 0; stats[1] = (uint64_t)w->fp8_act_shift;
+    if (w->fp8_mm && w->d_sat.ptr) {
+      unsigned long long n = 0;
+      HIP_CHECK(hipStreamSynchronize(w->stream));
+      HIP_CHECK(hipMemcpy(&n, w->d_sat.ptr, 8, hipMemcpyDeviceToHost));
+      stats[0] = n;
+    }
   });
 }
 

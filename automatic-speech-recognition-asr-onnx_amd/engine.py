@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 from typing import Sequence
 
 import numpy as np
@@ -272,7 +273,23 @@ class WhisperSession(_Session):
             ap, mem = audio.ctypes.data_as(C.c_void_p), MEM_HOST
         _lib.check(_lib.load().asr_whisper_encode(self._h, ap, mem, offsets.ctypes.data_as(C.POINTER(C.c_int64)), B, _ip(npos)))
         self.batch = B
+        if self.precision == PRECISION_FP8MM:                     # a GELU operand that met the e4m3 clamp: loud, not silent (the scale is static)
+            n, shift = self.fp8_stats()
+            if n > getattr(self, "_fp8_saturated", 0):
+                warnings.warn(f"Whisper FP8MM: {n - getattr(self, '_fp8_saturated', 0)} activation elements saturated at 448 * 2^{shift} in this encode; "
+                              f"raise the shift (set_fp8_act_shift / ASR_FP8MM_ACT_SHIFT)", RuntimeWarning, stacklevel=2)
+            self._fp8_saturated = n
         return npos
+
+    def fp8_stats(self) -> tuple[int, int]:
+        """(activation elements that met the e4m3 clamp since creation, activation shift in use) -- asr_whisper_fp8_stats; zeros outside FP8MM."""
+        st = (C.c_uint64 * 2)()
+        _lib.check(_lib.load().asr_whisper_fp8_stats(self._h, st))
+        return int(st[0]), int(st[1])
+
+    def set_fp8_act_shift(self, shift: int):
+        """FP8MM: store fc2's GELU operand as value * 2^-shift (asr_whisper_set_fp8_act_shift)."""
+        _lib.check(_lib.load().asr_whisper_set_fp8_act_shift(self._h, int(shift)))
 
     def encode(self, audios: Sequence[np.ndarray]) -> np.ndarray:
         flat = [_f32(a).reshape(-1) for a in audios]

@@ -55,8 +55,9 @@ enum asr_status {
  * reads their exact bf16 dequantisation, so all passes of a session see the same effective weights. Needs d_model, d_ffn and heads x head_dim multiples of 256.
  *
  * FP8MM (opt-in, Whisper sessions only): FP8W plus the encoder's feed-forward pair on the FP8 MATRIX pipe -- fc1 / fc2 weights as e4m3 bytes with one
- * power-of-two scale per output column, their activation operands (the second LayerNorm's output, the GELU output) as e4m3 bytes at unit scale
- * (saturating at 448), products on v_mfma_scale_f32_16x16x128_f8f6f4 at unit block scales with f32 accumulation; attention, the other projections,
+ * power-of-two scale per output column, their activation operands as e4m3 bytes: the second LayerNorm's output at unit scale (its affine pair is folded
+ * into fc1, so |value| <= sqrt(d_model) < 448), the GELU output as value * 2^-shift (asr_whisper_set_fp8_act_shift, default 0) saturating at 448 -- every
+ * element that meets the clamp is counted (asr_whisper_fp8_stats): a count that moves says the shift is too small for this checkpoint --, products on v_mfma_scale_f32_16x16x128_f8f6f4 at unit block scales with f32 accumulation; attention, the other projections,
  * the residual stream and the decoder are FP8W's. Needs d_model and d_ffn multiples of 256. The reference's counterpart: its MatMulNBits /
  * dynamic-int8 graphs (Optimize_ONNX_Common.py:55-60).
  *
@@ -209,6 +210,13 @@ int asr_whisper_generate(asr_session* s, int max_new, int eos_id, int32_t* token
  * on the device and restarts at every prefill. Applies to prefill / decode / generate; logits_out then holds the
  * penalised logits. */
 int asr_whisper_set_penalty(asr_session* s, float repeat_penalty, int penalty_range);
+/* FP8MM sessions: the GELU operand of fc2 is stored as value * 2^-shift (0 .. 16; also ASR_FP8MM_ACT_SHIFT at creation); takes effect at the next encode.
+ * asr_whisper_fp8_stats: stats[0] = activation elements that met the e4m3 clamp (|value * 2^-shift| > 448, or NaN) since the session was created,
+ * stats[1] = the shift in use. Zero / the shift on sessions of other precisions. No reference counterpart (its low-bit graphs quantise activations
+ * dynamically per tensor, Optimize_ONNX_Common.py:55-60); here the scale is static and the counter is what makes a wrong one loud. */
+int asr_whisper_set_fp8_act_shift(asr_session* s, int shift);
+int asr_whisper_fp8_stats(asr_session* s, uint64_t stats[2]);
+
 /* The *PenaltyGreedy graphs run GREEDY_SEARCH (:243-251) on every step, so save_id grows even while the host still feeds
  * penalty_penalty_value = 1.0 (before PENALTY_RANGE ids exist, Inference_Whisper_ONNX.py:630-632): enable = 1 keeps appending the
  * picks to the device-side history whatever the penalty value is (the onnxruntime shim drives the value per step). */

@@ -201,6 +201,43 @@ def test_fp8mm_session_stays_within_budget_of_the_oracle_and_rejects_what_it_can
         _session("whisper_mid_test", FP8MM)                   # d_model 384 is not a multiple of 256
 
 
+def test_fp8mm_saturating_gelu_operand_is_counted_and_an_activation_shift_cures_it():
+    """The GELU operand of fc2 is e4m3 at a STATIC scale (2^shift, default 1): on a checkpoint whose fc1 outputs leave +-448 the bytes clamp. The clamp is
+    counted (asr_whisper_fp8_stats), the Python session warns, and asr_whisper_set_fp8_act_shift moves the operand back into range. Checkpoint: the test
+    model with encoder layer 0's fc1 scaled by 256 and its fc2 by 1 / 256 (GELU is positively homogeneous away from zero, so the network barely changes)."""
+    name = "whisper_d256_test"
+    cfg, ck, sup, beg = whisper_setup(name)
+    ck = dict(ck)
+    p = "model.encoder.layers.0."
+    ck[p + "fc1.weight"] = ck[p + "fc1.weight"] * np.float32(256.0); ck[p + "fc1.bias"] = ck[p + "fc1.bias"] * np.float32(256.0)
+    ck[p + "fc2.weight"] = ck[p + "fc2.weight"] * np.float32(1.0 / 256.0)
+    smm = sub("engine").WhisperSession.from_checkpoint(cfg, ck, precision=FP8MM, suppress_tokens=sup, begin_suppress_tokens=beg)
+    audios = [unit_audio(81, 64000), unit_audio(82, 25600)]
+    prompt = [cfg.sot_id, cfg.first_language_id, cfg.transcribe_id, cfg.no_timestamps_id]
+    prompts = np.array([prompt] * 2, np.int32)
+    orc = WhisperOracle(cfg, ck, sup, beg)
+    ref = orc.greedy(audios, [prompt] * 2, 3)
+    forced = np.stack([np.asarray(ref["token_ids"][b][:2], np.int32) for b in range(2)])
+    want = np.stack([np.stack(ref["logits"][b][:3]) for b in range(2)])
+    V, scale = cfg.vocab, float(np.abs(want).max())
+    assert smm.fp8_stats() == (0, 0)
+    with pytest.warns(RuntimeWarning, match="saturated"):
+        l_sat = _run(smm, audios, prompts, forced)
+    n_sat, _ = smm.fp8_stats()
+    assert n_sat > 0
+    smm.set_fp8_act_shift(4)                                   # |GELU| here stays below 448 * 16
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        l_ok = _run(smm, audios, prompts, forced)
+    assert smm.fp8_stats() == (n_sat, 4)
+    e_sat, e_ok = float(np.abs(l_sat[..., :V] - want).max()), float(np.abs(l_ok[..., :V] - want).max())
+    print(f"fp8mm on a checkpoint with |GELU| > 448: {n_sat} clamped elements, logits error {e_sat:.4f} clamped vs {e_ok:.4f} with shift 4 (|logits| max {scale:.2f})")
+    assert e_ok < 3e-2 * scale and e_ok < e_sat
+    with pytest.raises(RuntimeError):
+        smm.set_fp8_act_shift(17)
+
+
 @pytest.mark.parametrize("prec,budget", [(BF16, 1e-3), (FP8W, 6e-3)])
 def test_batch64_32_steps_every_disagreement_with_the_oracle_is_an_oracle_near_tie(prec, budget):
     """64 utterances x 32 decoder steps, teacher-forced along RANDOM token histories (left to itself the random-weight decoder settles on

@@ -157,8 +157,12 @@ __device__ __forceinline__ T* kv_row(T* base, const KvAddr& a, int b, int kvh, i
   return base + (((size_t)b * n_kv + kvh) * a.S_max + s) * 128;
 }
 
+__device__ __forceinline__ void qw_store4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void qw_store4(bf16_t* p, const float (&v)[4]) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
+
 // per-head RMSNorm of q and k (weight * d^-1/4 folded), RoPE (half-split convention, position = hist + t), then q -> operand
-// buffer, k / v -> the KV cache [layer-local base][seq][kv head][S][128] at that position (:1283-1309). One wave per (row, head).
+// buffer, k / v -> the KV cache [layer-local base][seq][kv head][S][128] at that position (:1283-1309). Sixteen lanes per (row, head) -- four heads per wave --,
+// a lane holds four consecutive elements of each rotary half (16-byte loads; the one-element-per-lane form of rounds 3-5 moved 280 MB per prefill layer at 2 TB/s).
 template <typename T>
 __global__ __launch_bounds__(256) void qw_qk_rope_kernel(const float* __restrict__ qkv, int n_heads, int n_kv, const float* __restrict__ qn,
                                                          const float* __restrict__ kn, const float* __restrict__ rope, float eps,
@@ -167,33 +171,40 @@ __global__ __launch_bounds__(256) void qw_qk_rope_kernel(const float* __restrict
                                                          T* __restrict__ vc, KvAddr ka, T* __restrict__ k_rows) {
   constexpr int HD = 128;
   const int heads = n_heads + 2 * n_kv;
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int row = wid / heads, hh = wid - row * heads;
-  if (row >= rows) return;
-  const int b = row_seq[row];
-  if (b < 0) return;
-  const int pos = hist[b] + row_t[row];
-  const float* src = qkv + (size_t)row * heads * HD + hh * HD;
-  const float x0 = src[lane], x1 = src[lane + 64];              // the two rotary halves of this lane's pair
+  const int gid = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;          // (row, head) unit; a row's heads are consecutive units
+  const int row = gid / heads, hh = gid - row * heads;
+  const bool live = row < rows && row_seq[min(row, rows - 1)] >= 0;
+  const int b = live ? row_seq[row] : 0;
+  const int pos = live ? hist[b] + row_t[row] : 0;
+  const float* src = qkv + (size_t)(live ? row : 0) * heads * HD + hh * HD + 4 * l;
+  const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 64);
+  const float x0[4] = {lo.x, lo.y, lo.z, lo.w}, x1[4] = {hi.x, hi.y, hi.z, hi.w};              // the two rotary halves of this lane's four pairs
+  float ss = (x0[0] * x0[0] + x1[0] * x1[0]) + (x0[1] * x0[1] + x1[1] * x1[1]) + ((x0[2] * x0[2] + x1[2] * x1[2]) + (x0[3] * x0[3] + x1[3] * x1[3]));
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);                                  // (every lane of the wave takes part: no early exit above)
+  if (!live) return;
   if (hh >= n_heads + n_kv) {                                  // v: cached as is
-    T* dst = kv_row(vc, ka, b, hh - n_heads - n_kv, n_kv, pos);
-    Elem<T>::store(dst + lane, x0);
-    Elem<T>::store(dst + lane + 64, x1);
+    T* dst = kv_row(vc, ka, b, hh - n_heads - n_kv, n_kv, pos) + 4 * l;
+    qw_store4(dst, x0); qw_store4(dst + 64, x1);
     return;
   }
-  const float r = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / (float)HD + eps);
-  const float* w = hh < n_heads ? qn : kn;
-  const float a0 = x0 * r * w[lane], a1 = x1 * r * w[lane + 64];
-  const float cs = rope[(size_t)pos * HD + lane], sn = rope[(size_t)pos * HD + 64 + lane];
-  const float y0 = a0 * cs - a1 * sn, y1 = a1 * cs + a0 * sn;
-  T* dst = hh < n_heads ? q_out + (size_t)row * n_heads * HD + hh * HD
-                        : kv_row(kc, ka, b, hh - n_heads, n_kv, pos);
-  Elem<T>::store(dst + lane, y0);
-  Elem<T>::store(dst + lane + 64, y1);
+  const float r = rsqrtf(ss / (float)HD + eps);
+  const float* w = (hh < n_heads ? qn : kn) + 4 * l;
+  const float4 w0 = *reinterpret_cast<const float4*>(w), w1 = *reinterpret_cast<const float4*>(w + 64);
+  const float* rp = rope + (size_t)pos * HD + 4 * l;
+  const float4 c4 = *reinterpret_cast<const float4*>(rp), s4 = *reinterpret_cast<const float4*>(rp + 64);
+  const float wa[4] = {w0.x, w0.y, w0.z, w0.w}, wb[4] = {w1.x, w1.y, w1.z, w1.w}, cs[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
+  float y0[4], y1[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float a0 = x0[e] * r * wa[e], a1 = x1[e] * r * wb[e];
+    y0[e] = a0 * cs[e] - a1 * sn[e]; y1[e] = a1 * cs[e] + a0 * sn[e];
+  }
+  T* dst = (hh < n_heads ? q_out + (size_t)row * n_heads * HD + hh * HD : kv_row(kc, ka, b, hh - n_heads, n_kv, pos)) + 4 * l;
+  qw_store4(dst, y0); qw_store4(dst + 64, y1);
   if (k_rows && hh >= n_heads) {                         // row-major copy of the new keys for the prefill attention kernel
-    T* kr = k_rows + (size_t)row * n_kv * HD + (hh - n_heads) * HD;
-    Elem<T>::store(kr + lane, y0);
-    Elem<T>::store(kr + lane + 64, y1);
+    T* kr = k_rows + (size_t)row * n_kv * HD + (hh - n_heads) * HD + 4 * l;
+    qw_store4(kr, y0); qw_store4(kr + 64, y1);
   }
 }
 
@@ -1029,8 +1040,8 @@ void QwSession::decoder_pass(const DecPass& P) {
         gv.out_t = d_vt2.ptr; gv.ld_out_t = P.ld_vt; gemm(gv);
       }
       { ProfScope ps(prof, "dec_rope", stream);
-        const int waves = rows * (H + 2 * KV);
-        hipLaunchKernelGGL(qw_qk_rope_kernel<T>, dim3((waves + 3) / 4), dim3(256), 0, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, P.row_seq, P.row_t,
+        const int units = rows * (H + 2 * KV);           // sixteen lanes each
+        hipLaunchKernelGGL(qw_qk_rope_kernel<T>, dim3((units + 15) / 16), dim3(256), 0, stream, qkv, H, KV, L.qn, L.kn, rope, c.rms_eps, P.row_seq, P.row_t,
                            hist, rows, q, kc, vc, ka, mfma_attn ? d_krows.as<T>() : (T*)nullptr); }
       ProfScope ps(prof, "dec_attn", stream);
       if (mfma_attn) {

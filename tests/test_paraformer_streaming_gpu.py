@@ -242,6 +242,15 @@ def _prototype_head(cfg, ck, hidden):
     return ck2, 10 + np.arange(K)
 
 
+# The first 88 seeds >= 8800 whose oracle run keeps every integrate-and-fire comparison `slack` away from equality (425 seeds scanned, 72 s of oracle time: the scan
+# was this test's slowest part). Every listed seed is still CHECKED below on the machine that runs the test; one that fails there is skipped and the scan goes on
+# behind the list. To regenerate: set the list to [8799] and print the seeds the loop accepts.
+_MARGIN_SEEDS = [8800, 8802, 8814, 8820, 8822, 8823, 8827, 8829, 8831, 8840, 8841, 8842, 8848, 8849, 8851, 8855, 8861, 8862, 8871, 8872, 8880, 8885, 8891, 8896, 8902, 8909,
+                 8918, 8921, 8923, 8924, 8928, 8932, 8934, 8936, 8942, 8945, 8946, 8955, 8960, 8965, 8968, 8973, 8979, 8985, 8986, 8999, 9005, 9009, 9010, 9027, 9032, 9037,
+                 9039, 9045, 9047, 9054, 9056, 9057, 9058, 9061, 9070, 9084, 9089, 9092, 9095, 9099, 9101, 9106, 9109, 9124, 9128, 9142, 9147, 9151, 9153, 9160, 9163, 9164,
+                 9176, 9180, 9194, 9196, 9198, 9210, 9214, 9221, 9223, 9224]
+
+
 def test_bf16_64_streams_tokens_equal_the_oracle_on_a_head_with_trained_margins():
     """The default bf16 path (the two cluster launches) at the stream count the bench times: 64 streams x 5 chunks of Paraformer-large against the f32 oracle,
     without near-tie exclusions (the streaming twin of tests/test_paraformer_gpu.py's batch-64 test). Two decisions are discrete:
@@ -258,8 +267,9 @@ def test_bf16_64_streams_tokens_equal_the_oracle_on_a_head_with_trained_margins(
     A, B = orc.A, orc.B
     audio, recs_all, tried = [], [], 0
     S_cand = S + 24                                             # a few more than needed: the streams whose tokens sit closest to another token's row are dropped below
+    seeds = iter(list(_MARGIN_SEEDS) + list(range(_MARGIN_SEEDS[-1] + 1, 8800 + 8 * S)))
     while len(audio) < S_cand:
-        a = kaldi_audio(8800 + tried, n_chunks * chunk)
+        a = kaldi_audio(next(seeds), n_chunks * chunk)
         recs = orc.run(a)
         tried += 1
         ca, ok, kk = 0.0, True, 0

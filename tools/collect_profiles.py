@@ -11,7 +11,7 @@ names = {"bench_sensevoice": "bench_n1", "bench_sensevoice_4launch": "bench_4lau
          "bench_whisper30_mxfp4": "bench_whisper30_mxfp4_n1", "bench_whisper_mxfp4": "bench_whisper_mxfp4_n1",
          "bench_whisper_b64_fp8mm": "bench_whisper_b64_fp8mm_n1", "bench_whisper30_fp8mm": "bench_whisper30_fp8mm_n1",
          "bench_qwen": "bench_qwen_n1", "bench_qwen_beam5": "bench_qwen_beam5_n1", "bench_mixed_beam5": "bench_mixed_beam5_n1",
-         "bench_paraformer_streaming_256": "bench_paraformer_streaming_256_n1", "bench_qwen_fp8": "bench_qwen_fp8_n1"}
+         "bench_paraformer_streaming_256": "bench_paraformer_streaming_256_n1", "bench_qwen_fp8": "bench_qwen_fp8_n1", "bench_qwen_mxfp4": "bench_qwen_mxfp4_n1"}
 for a, b in names.items():
     p = os.path.join(src, a + ".json")
     if os.path.isfile(p) and os.path.getsize(p) > 10:

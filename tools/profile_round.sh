@@ -39,6 +39,7 @@ ASR_SANM_BLOCK8_OPT=2048 ASR_SANM_BLOCK_DBG=10 python tools/probes/sanm_block_cl
 python bench.py --workload qwen --steps 6 --warmup 2 --inflight 3 > $OUT/bench_qwen.json 2> $OUT/bench_qwen.err
 python bench.py --workload qwen --beam 5 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_qwen_beam5.json 2> $OUT/bench_qwen_beam5.err
 python bench.py --workload qwen --fp8 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_qwen_fp8.json 2> $OUT/bench_qwen_fp8.err
+python bench.py --workload qwen --mxfp4 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_qwen_mxfp4.json 2> $OUT/bench_qwen_mxfp4.err
 for v in 0 1 2 3 4 8; do echo "ASR_FBANK_DBG=$v: $(ASR_FBANK_DBG=$v python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms per step; fbank', d['kernels']['fbank']['ms_per_step'])")"; done > $OUT/fbank_ablations_final.txt 2>&1
 python bench.py --workload mixed --beam 5 --steps 6 --warmup 1 > $OUT/bench_mixed_beam5.json 2> $OUT/bench_mixed_beam5.err
 cd /tmp

@@ -36,6 +36,9 @@ struct SvSession : asr_session {
   const void *cif_conv_w = nullptr, *pf_out_w = nullptr;
   const float *cif_conv_b = nullptr, *cif_out_w = nullptr, *cif_out_b = nullptr, *pf_out_b = nullptr;
   DeviceBuffer d_enc_lo, d_ck, d_cifa, d_alpha, d_dec, d_x2, d_sa, d_ffn32, d_tplan;
+  // the cross-attention K / V projections of ALL decoder layers as two GEMMs over the encoder output (they depend on nothing the decoder computes): the layers' wkv halves
+  // gathered once into [n_full d][d] images (ASR_PF_KV_BATCH=0: one pair of launches per layer, the round-2..5 form)
+  DeviceBuffer d_wk_all, d_wv_all, d_bk_all, d_bv_all; int pf_n_full = 0; bool pf_kv_batch = true;
   template <typename T> void enqueue_paraformer_tail(const struct SvRunCtx& r);
 
   asr_sensevoice_config cfg;
@@ -61,7 +64,7 @@ struct SvSession : asr_session {
   ~SvSession() override {
     for (DeviceBuffer* b : {&d_dft_split, &d_times, &d_flags, &d_tpack, &d_tlayer_tab, &d_tkv, &d_ctplan, &d_mdev, &d_trow, &d_skws, &d_skcnt, &d_sta, &d_stb, &st_segs, &st_shadow, &st_wpack, &st_layer_tab, &st_flags, &st_times, &st_dpack, &st_dlayer_tab, &st_enk, &st_env, &st_dek, &st_dev, &st_defsmn, &st_prev, &st_cifh, &st_cifa, &st_enlen, &st_delen, &st_start, &d_sqkv, &d_skv,
                             &d_x0lo, &d_xalo, &d_xblo, &d_plan, &d_audio, &d_mel, &d_x0, &d_xa, &d_xb, &d_h, &d_qk, &d_vt, &d_ctx, &d_mem, &d_ffn,
-                            &d_amax_v, &d_amax_i, &d_ids, &d_tok, &d_num, &d_logits, &d_enc_lo, &d_ck, &d_cifa, &d_alpha, &d_dec, &d_x2,
+                            &d_amax_v, &d_amax_i, &d_ids, &d_tok, &d_num, &d_logits, &d_enc_lo, &d_ck, &d_wk_all, &d_wv_all, &d_bk_all, &d_bv_all, &d_cifa, &d_alpha, &d_dec, &d_x2,
                             &d_sa, &d_ffn32, &d_tplan})
       b->release();
     for (auto& kv : taps) kv.second.buf.release();
@@ -236,6 +239,23 @@ void SvSession::init() {
         L.bkv = (const float*)arena.get(q + "bkv", ARENA_F32, {2 * d}).ptr;
         L.wo = arena.get(q + "wo", wt, {d, d}).ptr;
         L.bo = (const float*)arena.get(q + "bo", ARENA_F32, {d}).ptr;
+      }
+    }
+    if (const char* e = getenv("ASR_PF_KV_BATCH")) pf_kv_batch = !(e[0] == '0');
+    pf_n_full = 0;
+    for (const PfDecLayer& L : pdec) pf_n_full += L.full ? 1 : 0;
+    if (pf_kv_batch && pf_n_full > 0) {
+      const size_t ew = wt == ARENA_BF16 ? 2 : 4, wbytes = (size_t)d * d * ew;
+      d_wk_all.reserve(pf_n_full * wbytes, stream); d_wv_all.reserve(pf_n_full * wbytes, stream);
+      d_bk_all.reserve((size_t)pf_n_full * d * 4, stream); d_bv_all.reserve((size_t)pf_n_full * d * 4, stream);
+      int li = 0;
+      for (const PfDecLayer& L : pdec) {
+        if (!L.full) continue;
+        HIP_CHECK(hipMemcpyAsync((unsigned char*)d_wk_all.ptr + li * wbytes, L.wkv, wbytes, hipMemcpyDeviceToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync((unsigned char*)d_wv_all.ptr + li * wbytes, (const unsigned char*)L.wkv + wbytes, wbytes, hipMemcpyDeviceToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_bk_all.as<float>() + (size_t)li * d, L.bkv, (size_t)d * 4, hipMemcpyDeviceToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(d_bv_all.as<float>() + (size_t)li * d, L.bkv + d, (size_t)d * 4, hipMemcpyDeviceToDevice, stream));
+        ++li;
       }
     }
   }
@@ -640,9 +660,25 @@ void SvSession::enqueue_paraformer_tail(const SvRunCtx& r) {
     if (res) { g2.add = res; g2.ld_add = d; }
     gemm(g2);
   };
+  const bool kv_all = pf_kv_batch && pf_n_full > 0;
+  const int ld_k = kv_all ? pf_n_full * d : d;
+  if (kv_all) {                                                       // every layer's cross K (row-major, layer l at columns l d ..) and V (transposed, layer l at rows l d ..) from the memory
+    ProfScope ps(prof, "gemm_dec", stream);
+    GemmArgs gk;
+    gk.A = enc_lo; gk.lda = d; gk.W = d_wk_all.ptr; gk.ldw = d; gk.M = rows; gk.N = pf_n_full * d; gk.K = d; gk.bias = d_bk_all.as<float>(); gk.out_lo = ck; gk.ld_out_lo = ld_k;
+    gemm(gk);
+    GemmArgs gv;
+    gv.A = enc_lo; gv.lda = d; gv.W = d_wv_all.ptr; gv.ldw = d; gv.M = rows; gv.N = pf_n_full * d; gv.K = d; gv.bias = d_bv_all.as<float>();
+    gv.out_t = cvt; gv.ld_out_t = Mpad;
+    gemm(gv);
+  }
+  int full_i = 0;
   for (const PfDecLayer& L : pdec) {
     if (!L.full) { ffn_block(L, dec, nullptr); continue; }           // decoders3: dec = FFN(dec), no residual (:553-555)
-    {
+    T* ck_l = kv_all ? ck + (size_t)full_i * d : ck;
+    T* cvt_l = kv_all ? cvt + (size_t)full_i * d * Mpad : cvt;
+    ++full_i;
+    if (!kv_all) {
       ProfScope ps(prof, "gemm_dec", stream);                        // this layer's cross K (row-major) and V (transposed) from the memory
       GemmArgs gk;
       gk.A = enc_lo; gk.lda = d; gk.W = L.wkv; gk.ldw = d; gk.M = rows; gk.N = d; gk.K = d; gk.bias = L.bkv; gk.out_lo = ck; gk.ld_out_lo = d;
@@ -668,7 +704,7 @@ void SvSession::enqueue_paraformer_tail(const SvRunCtx& r) {
     {
       ProfScope ps(prof, "attention", stream);
       AttnArgs aa;
-      aa.q = q; aa.ld_q = d; aa.k = ck; aa.ld_qk = d; aa.vt = cvt; aa.ld_vt = Mpad; aa.ctx = ctx; aa.ld_ctx = d;
+      aa.q = q; aa.ld_q = d; aa.k = ck_l; aa.ld_qk = ld_k; aa.vt = cvt_l; aa.ld_vt = Mpad; aa.ctx = ctx; aa.ld_ctx = d;
       aa.plan = r.dp; aa.q_plan = tplan; aa.qb_utt = r.d_qb_utt; aa.qb_q0 = r.d_qb_q0; aa.n_qblocks = r.n_qb; aa.n_heads = c.n_heads;
       aa.qt = r.att_qt; aa.n_waves = r.att_nw; aa.max_T = r.max_T;
       if (precision == ASR_PRECISION_BF16) launch_attention_bf16_hd128(aa, stream);
@@ -816,7 +852,8 @@ void SvSession::run(const float* audio, int audio_mem, const int64_t* offs, int 
   if (paraformer) {
     const int dd = pcfg.d_dec_ffn;
     grow(d_enc_lo, (size_t)Mpad * d * eT);
-    grow(d_ck, (size_t)Mpad * d * eT);
+    grow(d_ck, (size_t)Mpad * d * eT * (pf_kv_batch ? std::max(pf_n_full, 1) : 1));
+    if (pf_kv_batch) grow(d_vt, (size_t)Mpad * d * eT * std::max(pf_n_full, 1));
     grow(d_cifa, (size_t)Mpad * 3 * d * eT);
     grow(d_alpha, (size_t)Mpad * 4);
     grow(d_dec, (size_t)Mpad * d * 4);

@@ -164,6 +164,29 @@ def test_block_kernel_equals_separate_launches(monkeypatch):
         assert np.abs(out["1"][2][r0:r0 + T] - out["0"][2][r0:r0 + T]).max() < 0.02
 
 
+@pytest.mark.parametrize("prec", [BF16, F32])
+def test_batched_cross_kv_projections_equal_the_per_layer_launches(monkeypatch, prec):
+    """The cross-attention K / V projections of all decoder layers as two GEMMs over the encoder output (round 6, the default) against one pair of launches per layer
+    (ASR_PF_KV_BATCH=0) on a ragged batch: the same products in another launch shape. Demanded: identical token ids, logits within a bf16 key's last bit."""
+    cfg, ck = paraformer_setup("paraformer_large")
+    eng = sub("engine")
+    lens = [128000, 38880, 16000, 127000, 64000, 99840]
+    audios = [kaldi_audio(7700 + i, n) for i, n in enumerate(lens)]
+    out = {}
+    for batch in ("1", "0"):
+        monkeypatch.setenv("ASR_PF_KV_BATCH", batch)
+        sess = eng.ParaformerSession.from_checkpoint(cfg, ck, precision=prec)
+        sess.taps(True)
+        toks = sess.run(audios)
+        out[batch] = (toks, sess.tap("logits").copy())
+        del sess
+    for a, b in zip(out["1"][0], out["0"][0]):
+        assert np.array_equal(a, b)
+    diff = float(np.abs(out["1"][1] - out["0"][1]).max())
+    print(f"paraformer decoder, precision {prec}: batched vs per-layer cross K / V projections, logits differ by at most {diff:.3g}")
+    assert diff < (2e-2 if prec == BF16 else 1e-4)
+
+
 def _prototype_output_layer(cfg, ck, hidden):
     """An output projection with the decision structure of a trained one, built on the ORACLE's decoder rows (list of (n_b, d) arrays, the
     after_norm output without its affine): every token of every utterance is a class of its own (ids from 10 up) whose row is the

@@ -1,5 +1,5 @@
 // One SANM encoder block (Export_SenseVoice.py:227-258: LayerNorm -> q|k|v -> soft-max attention + FSMN -> out-projection + residual
-// -> LayerNorm -> FFN + residual) as ONE launch for batches of <= 144-row windows (8 s chunks): the bf16 headline path, round-4 form.
+// -> LayerNorm -> FFN + residual) as ONE launch for batches of <= 144-row windows (8 s chunks): the bf16 headline path (multiplication scheme of round 4, FFN pair of round 6).
 //
 // Decomposition (as in round 2): 64 windows x 4 heads = 256 = one workgroup per CU; the four workgroups (w, h) of window w form a CLUSTER,
 // workgroup h owns head h of the attention half and column slab h of every GEMM, and the A operand of each GEMM phase is what the cluster
@@ -13,7 +13,7 @@
 //   * The A operand lives in LDS as four 36 KB CHUNKS of 128 columns ([144 rows][256 B], 16-byte slots XOR-swizzled by the row). An exchanged
 //     operand arrives by LDS-DMA, one chunk per `s_barrier`; the workgroup's OWN quarter of every exchange is written into its chunk slot by
 //     the producing epilogue and never comes back from memory: a phase starts multiplying its own chunk while the three foreign ones are in
-//     flight. FFN-2 walks the 16 chunks of `hid` starting with its own four (already in LDS), the ring refilling behind it.
+//     flight. (Round-4 form of FFN-2: the 16 chunks of `hid` starting with the own four, the ring refilling behind; round-6 form: only the own four.)
 //   * No barrier inside a chunk, hand-counted `s_waitcnt vmcnt(N)` for both streams (see `Sched`): the compiler's own bookkeeping gives up
 //     (vmcnt(0) / lgkmcnt(0)) while an LDS-DMA is pending, so the W loads are inline asm and their waits are tied to the registers they fill.
 //
@@ -21,8 +21,11 @@
 //      shared by all waves: scores redundantly, context split over the head dimension), FSMN        ctx[:, 128 h ..] (bf16)  -- exchange 0 -->
 //   B  out-projection slab (wave = K-half x 32 columns; accumulators start from FSMN term + residual)
 //        -> x1 slab: f32 to memory (own rows, read back in D), bf16 copy + row statistics                                   -- exchange 1 -->
-//   C  FFN-1 slab: relu(LN(x1) W1[512 h ..]^T + b1) -> hid[:, 512 h ..] (bf16)                                              -- exchange 2 -->
-//   D  FFN-2 slab (wave = K-half x 32 columns) + b2 + x1 -> x (f32), bf16 copy + row statistics of the next block
+//   C  FFN-1 slab: relu(LN(x1) W1[512 h ..]^T + b1) -> hid[:, 512 h ..] (bf16), the four own chunks of phase D, in LDS
+//   D  (FFNK = 1, the default since round 6) FFN-2 over the workgroup's OWN 512 hidden columns for ALL 512 output columns: hid never leaves the CU; the own 128-column slab
+//      of the partial stays in LDS (f32), the three foreign slabs go out as f16 chunk images                                  -- exchange 2 -->
+//      sum of the four partials (source-head order) + b2 + x1 -> x (f32), bf16 copy + row statistics of the next block        -- exchange 3 -->
+//      (FFNK = 0, ASR_SANM_BLOCK_FFNK=0: the round-4 form -- hid is exchanged, FFN-2 is a column slab over the 16 chunks of hid, wave = K-half x 32 columns)
 //
 // Exchange protocol, give-up bound, placement and launch limits are those of round 2 (the 12-wave kernel of rounds 2-3 was deleted in round 6; DESIGN.md history table).
 #include <algorithm>

@@ -153,10 +153,11 @@ __device__ __forceinline__ void issue_chunk(const unsigned char* src, int ld_byt
   }
 }
 
-// The cluster's exchange buffers (ctx, x1, hid) hold CHUNK IMAGES: inside the window's own rows of the buffer, chunk c is the T16 x 256-byte LDS image of
-// its 128 columns, swizzled slots and all, at c * T16 * 256 bytes. Producers write the image into an LDS slot first (it is the own chunk of the next phase
-// anyway) and store it piece by piece -- one wave instruction = four rows = one contiguous KB, against sixteen 64-byte segments per instruction when the
-// rows went out of registers (the epilogues were store-ISSUE-bound: 147 KB of hid took 5 us per workgroup); consumers read it back the same way.
+// The cluster's exchange buffers (ctx, x1, the FFN-2 partials / hid, x) hold CHUNK IMAGES: inside the window's own rows of the buffer, chunk c is the T16 x 256-byte LDS
+// image of its 128 columns, swizzled slots and all, at c * T16 * 256 bytes: a consumer's LDS-DMA of one wave instruction lands four rows = one contiguous KB. Producers
+// write the image into their LDS slot (it is the own chunk of the next phase anyway) and, by default, store the same 16-byte granules to memory straight from the
+// registers (write-through); `store_chunk_img` -- pieces out of the LDS image, one contiguous KB per instruction -- is the ctx image's path and opt bit 8's for the rest
+// (measured 1.5 % slower there: the exchange stores are bound by the write path, not by their issue).
 __device__ __forceinline__ void issue_chunk_img(const unsigned char* img, int n_pieces, unsigned char* slot, int wave, int lane, bool sc1 = false) {
 #pragma unroll
   for (int t = 0; t < DMA_PER_CHUNK; ++t) {

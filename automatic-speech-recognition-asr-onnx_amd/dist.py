@@ -17,6 +17,8 @@ must wrap them the same way.
 from __future__ import annotations
 
 import os
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: set before the HIP runtime starts in a multi-process job
 from typing import Sequence
 
 import numpy as np

@@ -22,6 +22,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (what the host driver supports): RCCL across processes needs it before the HIP runtime starts
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

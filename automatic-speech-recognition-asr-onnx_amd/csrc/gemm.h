@@ -85,6 +85,7 @@ void gemm_reload_env();         // re-read the ASR_GEMM_* / ASR_SKINNY_* / ASR_D
 int gemm_env_decode_nt();       // ASR_DECODE_NT, ASR_DECODE_KS (0 = the cost model), ASR_DECODE_ATTN_WAVE, CUs of the device: as of the last reload
 int gemm_env_decode_ks();
 bool gemm_env_decode_attn_wave();
+bool gemm_env_decode_attn_online();
 int gemm_env_cus();
 const char* gemm_last_kernel(); // kernel family of this thread's last launch_gemm_bf16 ("t288w", "t144", "pipe", "skinny", ...): test hook
 bool gemm_skinny144_enabled();

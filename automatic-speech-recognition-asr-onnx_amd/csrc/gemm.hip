@@ -29,6 +29,7 @@ struct GemmEnv {
   int skinny_splitk = -1, tall_min = 16, skinny_max_plain = 32;
   int decode_nt = 0, decode_ks = 0;      // ASR_DECODE_NT / ASR_DECODE_KS: force the decode GEMM's column granule / split count (0 = the cost model)
   bool decode_attn_wave = true;          // ASR_DECODE_ATTN_WAVE=0: single-token self-attention on the general kernel
+  bool decode_attn_online = true;        // ASR_DECODE_ATTN_ONLINE=0: single-token cross-attention on the general (two-pass) kernel
   int n_cus = 0;                         // CUs of the current device (the decode GEMM's one-round grid bound)
   bool loaded = false;
 };
@@ -62,7 +63,7 @@ void gemm_reload_env() {
   e.skinny144 = getenv("ASR_SKINNY_M144") && getenv("ASR_SKINNY_M144")[0] == '1';
   e.skinny_splitk = env_int("ASR_SKINNY_SPLITK", -1); e.tall_min = env_int("ASR_GEMM_TALL_MIN", 16);
   e.skinny_max_plain = env_int("ASR_SKINNY_MAX_M", 32);
-  e.decode_nt = env_int("ASR_DECODE_NT", 0); e.decode_ks = env_int("ASR_DECODE_KS", 0); e.decode_attn_wave = env_flag("ASR_DECODE_ATTN_WAVE", true);
+  e.decode_nt = env_int("ASR_DECODE_NT", 0); e.decode_ks = env_int("ASR_DECODE_KS", 0); e.decode_attn_wave = env_flag("ASR_DECODE_ATTN_WAVE", true); e.decode_attn_online = env_flag("ASR_DECODE_ATTN_ONLINE", true);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&e.n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || e.n_cus <= 0) e.n_cus = 256;
   e.loaded = true;
@@ -74,6 +75,7 @@ bool gemm_skinny144_enabled() { return genv().skinny144; }
 int gemm_env_decode_nt() { return genv().decode_nt; }
 int gemm_env_decode_ks() { return genv().decode_ks; }
 bool gemm_env_decode_attn_wave() { return genv().decode_attn_wave; }
+bool gemm_env_decode_attn_online() { return genv().decode_attn_online; }
 int gemm_env_cus() { return genv().n_cus; }
 
 namespace {

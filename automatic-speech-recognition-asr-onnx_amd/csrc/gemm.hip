@@ -29,6 +29,7 @@ struct GemmEnv {
   int skinny_splitk = -1, tall_min = 16, skinny_max_plain = 32;
   int decode_nt = 0, decode_ks = 0;      // ASR_DECODE_NT / ASR_DECODE_KS: force the decode GEMM's column granule / split count (0 = the cost model)
   bool decode_attn_wave = true;          // ASR_DECODE_ATTN_WAVE=0: single-token self-attention on the general kernel
+  int skinny_nt = 2;                     // ASR_SKINNY_NT=1: one 16-column granule per workgroup of the skinny GEMM even where the output is wider than the chip
   bool decode_attn_online = true;        // ASR_DECODE_ATTN_ONLINE=0: single-token cross-attention on the general (two-pass) kernel
   int n_cus = 0;                         // CUs of the current device (the decode GEMM's one-round grid bound)
   bool loaded = false;
@@ -62,7 +63,7 @@ void gemm_reload_env() {
   e.big = env_flag("ASR_GEMM_BIG", true); e.pp = env_flag("ASR_GEMM_PP", true); e.splitk = env_flag("ASR_GEMM_SPLITK", true); e.deep = env_flag("ASR_GEMM_DEEP", true);
   e.skinny144 = getenv("ASR_SKINNY_M144") && getenv("ASR_SKINNY_M144")[0] == '1';
   e.skinny_splitk = env_int("ASR_SKINNY_SPLITK", -1); e.tall_min = env_int("ASR_GEMM_TALL_MIN", 16);
-  e.skinny_max_plain = env_int("ASR_SKINNY_MAX_M", 32);
+  e.skinny_max_plain = env_int("ASR_SKINNY_MAX_M", 32); e.skinny_nt = env_int("ASR_SKINNY_NT", 2);
   e.decode_nt = env_int("ASR_DECODE_NT", 0); e.decode_ks = env_int("ASR_DECODE_KS", 0); e.decode_attn_wave = env_flag("ASR_DECODE_ATTN_WAVE", true); e.decode_attn_online = env_flag("ASR_DECODE_ATTN_ONLINE", true);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&e.n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || e.n_cus <= 0) e.n_cus = 256;
@@ -725,13 +726,14 @@ __device__ __forceinline__ bf16x8_t sk_fp4x8_to_bf16x8(sk_w4_t w) {
   return u.v;
 }
 
-template <int MT, bool LN, int WQ = 0>     // LN: the LayerNorm prologue (own instance: its registers / LDS allow one workgroup per CU only); WQ: 1 = e4m3 weight bytes (GemmArgs::W8), 2 = MXFP4 (GemmArgs::W4)
-__global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_bf16_skinny(const GemmArgs g) {   // <= 128 VGPRs: two workgroups share a CU
+template <int MT, bool LN, int WQ = 0, int NT = 1>     // NT: 16-column granules per workgroup (2: an activation fragment read from L2 feeds two weight granules -- outputs wider than the chip, see launch_skinny); LN: the LayerNorm prologue (own instance: its registers / LDS allow one workgroup per CU only); WQ: 1 = e4m3 weight bytes (GemmArgs::W8), 2 = MXFP4 (GemmArgs::W4)
+__global__ __launch_bounds__(512, !LN && NT == 1 && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_bf16_skinny(const GemmArgs g) {   // <= 128 VGPRs: two workgroups share a CU
   constexpr bool W8 = WQ == 1, W4 = WQ == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fgrp = lane >> 4;
-  const int n0 = blockIdx.x * 16;
+  static_assert(NT == 1 || !LN, "the LayerNorm instance keeps one granule per workgroup");
+  const int n0 = blockIdx.x * 16 * NT;
   const int KS = g.sk_splits > 1 ? g.sk_splits : 1, ks = blockIdx.y;
   const int kslice = g.K / (SK_WAVES * KS);               // multiple of 32 (host-checked)
   // Every workgroup reads the SAME activation rows: if all of them walked K in the same order, each L2 channel would be hit by all
@@ -744,35 +746,39 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
   const unsigned char* wp8 = g.W8 + (size_t)(n0 + frow) * g.ldw8 + k_begin + fgrp * 8;
   const unsigned char* wp4 = g.W4 + (size_t)(n0 + frow) * (g.K >> 1) + ((k_begin + fgrp * 8) >> 1);
   const unsigned char* sp4 = g.w_scale4 + (size_t)(n0 + frow) * (g.K >> 5) + (k_begin >> 5);
-  auto w_load = [&](int k) -> wfrag_t {
-    if constexpr (W4) return sk_w4_t{__builtin_nontemporal_load(reinterpret_cast<const unsigned*>(wp4 + (k >> 1))), (unsigned)sp4[k >> 5]};
+  auto w_load = [&](int k, int j) -> wfrag_t {          // granule j of this workgroup: weight rows n0 + 16 j ..
+    if constexpr (W4) return sk_w4_t{__builtin_nontemporal_load(reinterpret_cast<const unsigned*>(wp4 + (size_t)j * 16 * (g.K >> 1) + (k >> 1))), (unsigned)sp4[(size_t)j * 16 * (g.K >> 5) + (k >> 5)]};
     else
-    if constexpr (W8) return __builtin_nontemporal_load(reinterpret_cast<const sk_u32x2_t*>(wp8 + k));
-    else return __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + k));
+    if constexpr (W8) return __builtin_nontemporal_load(reinterpret_cast<const sk_u32x2_t*>(wp8 + (size_t)j * 16 * g.ldw8 + k));
+    else return __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + (size_t)j * 16 * g.ldw + k));
   };
 
   constexpr int U = MT >= 4 ? 4 : 8;                    // K-steps per trip: U x 16-byte weight loads in flight per lane (4 row tiles: fewer, to stay under 128 VGPRs => two workgroups per CU)
   // the weight stream does not depend on the activations: start it before the LayerNorm prologue
-  wfrag_t wf0[U];
+  wfrag_t wf0[NT][U];
 #pragma unroll
-  for (int u = 0; u < U; ++u)
-    if (u * 32 < kslice) wf0[u] = w_load(u * 32);
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u * 32 < kslice) wf0[j][u] = w_load(u * 32, j);
 
   // the residual term of the epilogue (wave w finishes row tiles w, w + 8) is requested now: its L2 round trip hides behind the stream
-  float4 addv[(MT + SK_WAVES - 1) / SK_WAVES];
+  float4 addv[NT][(MT + SK_WAVES - 1) / SK_WAVES];
 #pragma unroll
-  for (int t = 0; t < (MT + SK_WAVES - 1) / SK_WAVES; ++t) {
-    const int m = (wave + t * SK_WAVES) * 16 + frow;
-    addv[t] = (g.add && wave + t * SK_WAVES < MT && m < g.M) ? *reinterpret_cast<const float4*>(g.add + (size_t)m * g.ld_add + n0 + fgrp * 4)
-                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int t = 0; t < (MT + SK_WAVES - 1) / SK_WAVES; ++t) {
+      const int m = (wave + t * SK_WAVES) * 16 + frow;
+      addv[j][t] = (g.add && wave + t * SK_WAVES < MT && m < g.M) ? *reinterpret_cast<const float4*>(g.add + (size_t)m * g.ld_add + n0 + j * 16 + fgrp * 4)
+                                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
   // ---- A source: bf16 rows, or LayerNorm(ln_x) built here into LDS as bf16 [MT*16][K]
   const bf16_t* A;
   int lda;
   if constexpr (LN) {                                    // (<= 32 rows: beyond that every workgroup redoing all rows costs more than a launch)
     {
-      bf16_t* An = reinterpret_cast<bf16_t*>(smem + SK_WAVES * MT * 1024);
+      bf16_t* An = reinterpret_cast<bf16_t*>(smem + SK_WAVES * MT * NT * 1024);
       // wave w normalises rows w, w+8, ...: ALL of its rows are fetched in one batch of float4 loads (one L2 round trip),
       // then mean / variance / output come from registers.
       constexpr int RPW = MT * 16 / SK_WAVES;        // rows per wave
@@ -831,37 +837,47 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
   }
   const bf16_t* ap = A + (size_t)frow * lda + k_begin + fgrp * 8;
 
-  f32x4_t acc[MT];
+  f32x4_t acc[NT][MT];
   f32x4_t gram[MT];                                      // a_rms: A A^T of the row tile on the (idle) MFMA pipe; its diagonal is sum(x^2)
 #pragma unroll
-  for (int i = 0; i < MT; ++i) { acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; gram[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < MT; ++i) {
+    gram[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
   const bool a_rms = g.a_rms_eps > 0.0f;
   // Two register sets of U weight fragments: the loads of trip t + 1 are issued BEFORE the MFMAs of trip t, so a long K slice (fc2:
   // K = 5120 -> 20 K-steps per wave = 3 trips) pays one HBM round trip, not one per trip (19.2 -> ~10 us per launch at 32 rows).
-  auto load_set = [&](wfrag_t (&wf)[U], int k) {
+  auto load_set = [&](wfrag_t (&wf)[NT][U], int k) {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (k + u * 32 < kslice) wf[u] = w_load(k + u * 32);
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (k + u * 32 < kslice) wf[j][u] = w_load(k + u * 32, j);
   };
-  auto mma_set = [&](const wfrag_t (&wf)[U], int k) {
+  auto mma_set = [&](const wfrag_t (&wf)[NT][U], int k) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (k + u * 32 < kslice) {
-        bf16x8_t wv;
-        if constexpr (W8) wv = sk_fp8x8_to_bf16x8(wf[u]); else if constexpr (W4) wv = sk_fp4x8_to_bf16x8(wf[u]); else wv = wf[u];
+        bf16x8_t wv[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if constexpr (W8) wv[j] = sk_fp8x8_to_bf16x8(wf[j][u]); else if constexpr (W4) wv[j] = sk_fp4x8_to_bf16x8(wf[j][u]); else wv[j] = wf[j][u];
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           // rows past M are never stored: their lanes request nothing from memory (at one row the 16-row tile pulled 16 x the bytes through this CU's 64 B / clk path;
           // csrc/decode_gemm.hip, profiles/r05_decode_gemm_clock.txt). The LayerNorm instance reads its rows from LDS, where rows past M are zero already.
           bf16x8_t af = {0, 0, 0, 0, 0, 0, 0, 0};
           if (LN || i * 16 + frow < g.M) af = *reinterpret_cast<const bf16x8_t*>(ap + (size_t)i * 16 * lda + k + u * 32);
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, af, acc[i], 0, 0, 0);   // D[n = 4 fgrp + r][m = frow]
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[j], af, acc[j][i], 0, 0, 0);   // D[n = 4 fgrp + r][m = frow]
           if (a_rms) gram[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, af, gram[i], 0, 0, 0);
         }
       }
     }
   };
-  wfrag_t wf1[U];
+  wfrag_t wf1[NT][U];
   for (int k = 0; k < kslice; k += 64 * U) {
     if (k + 32 * U < kslice) load_set(wf1, k + 32 * U);
     mma_set(wf0, k);
@@ -869,10 +885,12 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
     if (k + 32 * U < kslice) mma_set(wf1, k + 32 * U);
   }
   // ---- cross-wave reduction
-  float4* red = reinterpret_cast<float4*>(smem);                                     // [wave][MT][64]
-  float (*ss_red)[MT * 16] = reinterpret_cast<float (*)[MT * 16]>(smem + SK_WAVES * MT * 1024);    // a_rms only (excludes ln_x)
+  float4* red = reinterpret_cast<float4*>(smem);                                     // [granule][wave][MT][64]
+  float (*ss_red)[MT * 16] = reinterpret_cast<float (*)[MT * 16]>(smem + SK_WAVES * MT * NT * 1024);    // a_rms only (excludes ln_x)
 #pragma unroll
-  for (int i = 0; i < MT; ++i) red[(wave * MT + i) * 64 + lane] = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) red[((j * SK_WAVES + wave) * MT + i) * 64 + lane] = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
   if (a_rms) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)                          // D[4 fgrp + r][frow]: the diagonal entry of row frow sits in lane group frow / 4
@@ -880,22 +898,24 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
   }
   __syncthreads();
   const int rows16 = MT * 16;
-  float4 sums[(MT + SK_WAVES - 1) / SK_WAVES];
+  float4 sums[NT][(MT + SK_WAVES - 1) / SK_WAVES];
 #pragma unroll
-  for (int t = 0; t < (MT + SK_WAVES - 1) / SK_WAVES; ++t) {                          // wave w finishes row tiles w, w + 8
-    const int i = wave + t * SK_WAVES;
-    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < MT) {
-      sum = red[i * 64 + lane];
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int w = 1; w < SK_WAVES; ++w) {
-        const float4 q = red[(w * MT + i) * 64 + lane];
-        sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
+    for (int t = 0; t < (MT + SK_WAVES - 1) / SK_WAVES; ++t) {                        // wave w finishes row tiles w, w + 8
+      const int i = wave + t * SK_WAVES;
+      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < MT) {
+        sum = red[(j * SK_WAVES * MT + i) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < SK_WAVES; ++w) {
+          const float4 q = red[((j * SK_WAVES + w) * MT + i) * 64 + lane];
+          sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
+        }
       }
+      sums[j][t] = sum;
     }
-    sums[t] = sum;
-  }
-  if (KS > 1) {                      // hand the partial sums over; the last workgroup of this column granule finishes.
+  if constexpr (NT == 1) if (KS > 1) {                      // hand the partial sums over; the last workgroup of this column granule finishes.
     // Cross-XCD visibility without a release fence (on this part __threadfence() writes back / invalidates a whole L2): the
     // partials and the ticket are relaxed AGENT-scope atomics (sc1: written through to / read from the memory side), and every
     // thread waits for its own stores to complete before the workgroup takes its ticket.
@@ -904,7 +924,7 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
       const int i = wave + t * SK_WAVES;
       if (i < MT) {        // one 16-byte write-through store per lane (four 4-byte sc1 stores are four fabric writes: ~6x the time per byte)
         float* dst = g.sk_ws + ((size_t)ks * rows16 + i * 16 + frow) * g.N + n0 + fgrp * 4;
-        const f32x4_t v = {sums[t].x, sums[t].y, sums[t].z, sums[t].w};
+        const f32x4_t v = {sums[0][t].x, sums[0][t].y, sums[0][t].z, sums[0][t].w};
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
       }
     }
@@ -937,16 +957,18 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
           for (int j = 0; j < 8; ++j)
             if (s0 + j < KS) { sum.x += q[j][0]; sum.y += q[j][1]; sum.z += q[j][2]; sum.w += q[j][3]; }
         }
-        sums[t] = sum;
+        sums[0][t] = sum;
       }
     }
   }
 #pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
   for (int t = 0; t < (MT + SK_WAVES - 1) / SK_WAVES; ++t) {
     const int i = wave + t * SK_WAVES;
     if (i >= MT) continue;
-    float4 sum = sums[t];
-    const int m = i * 16 + frow, n = n0 + fgrp * 4;
+    float4 sum = sums[j][t];
+    const int m = i * 16 + frow, n = n0 + j * 16 + fgrp * 4;
     if (m >= g.M) continue;
     if constexpr (W8) { const float4 sc = *reinterpret_cast<const float4*>(g.w_scale + n); sum.x *= sc.x; sum.y *= sc.y; sum.z *= sc.z; sum.w *= sc.w; }   // (powers of two: exact)
     if (a_rms) {                                          // fixed summation order over the waves
@@ -962,7 +984,7 @@ __global__ __launch_bounds__(512, !LN && MT >= 2 && MT <= 4 ? 4 : 2) void gemm_b
       continue;
     }
     if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + n); sum.x += b.x; sum.y += b.y; sum.z += b.z; sum.w += b.w; }
-    if (g.add) { const float4 q = addv[t]; sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w; }
+    if (g.add) { const float4 q = addv[j][t]; sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w; }
     if (g.act != ACT_NONE) { sum.x = apply_act_rt(sum.x, g.act); sum.y = apply_act_rt(sum.y, g.act); sum.z = apply_act_rt(sum.z, g.act); sum.w = apply_act_rt(sum.w, g.act); }
     if (g.add2) {
       const float4 q = *reinterpret_cast<const float4*>(g.add2 + (size_t)(g.add2_rows ? g.add2_rows[m] : m) * g.ld_add2 + n);
@@ -1009,6 +1031,35 @@ void launch_skinny(const GemmArgs& g, hipStream_t s) {
   }
   GemmArgs gg = g;
   gg.sk_splits = skinny_splits(g, MT * 16);
+  // outputs wider than the chip at three or four row tiles (Qwen3-ASR gate|up at 64 sequences: 384 granules, 128 KB of activation rows per granule from L2): a CU that
+  // holds two workgroups pulls 2 x (rows + weights) through its fill path; two granules per workgroup read the rows once -- 12.8 -> ~9 us per launch (ASR_SKINNY_NT=1: off)
+  if constexpr (MT >= 3 && MT <= 4) {
+    const bool nt2 = genv().skinny_nt >= 2;
+    if (nt2 && !g.ln_x && gg.sk_splits == 1 && g.N % 32 == 0 && g.N / 16 > 256) {
+      const size_t lds2 = (size_t)SK_WAVES * MT * 2 * 1024 + (g.a_rms_eps > 0.0f ? (size_t)SK_WAVES * MT * 64 : 0);
+      static PerDeviceOnce once2;
+      if (once2.first()) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny<MT, false, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny<MT, false, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_skinny<MT, false, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+      }
+      const dim3 grid2(g.N / 32, 1);
+      if (g.W4) {
+        ASR_REQUIRE(g.w_scale4 && g.K % 32 == 0, "gemm(skinny): MXFP4 weights need their block scales and K a multiple of 32");
+        note_kernel("skinny_w4");
+        hipLaunchKernelGGL((gemm_bf16_skinny<MT, false, 2, 2>), grid2, dim3(64 * SK_WAVES), lds2, s, gg);
+      } else if (g.W8) {
+        ASR_REQUIRE(g.w_scale && g.ldw8 % 8 == 0, "gemm(skinny): byte weights need their scales and 8-byte aligned rows");
+        note_kernel("skinny_w8");
+        hipLaunchKernelGGL((gemm_bf16_skinny<MT, false, 1, 2>), grid2, dim3(64 * SK_WAVES), lds2, s, gg);
+      } else {
+        note_kernel("skinny");
+        hipLaunchKernelGGL((gemm_bf16_skinny<MT, false, 0, 2>), grid2, dim3(64 * SK_WAVES), lds2, s, gg);
+      }
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
+  }
   if constexpr (MT <= 2) {
     if (g.ln_x) {
       note_kernel("skinny_ln");

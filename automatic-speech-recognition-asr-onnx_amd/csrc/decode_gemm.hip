@@ -50,8 +50,19 @@ __device__ __forceinline__ bf16x8_t fp4x8_to_bf16x8(unsigned r, float scale) {
 // WQ: 0 = bf16 weights, 1 = e4m3 bytes + one scale per output column (W8), 2 = MXFP4: e2m1 nibbles + one e8m0 scale per (column, 32 k) -- the K-step of the MFMA is
 // the block of the format, so a fragment needs the one scale byte of (its column, this step), applied by the widening instruction itself
 template <int MT, int NT, bool FOLD, int WQ>
-__global__ __launch_bounds__(512) void decode_gemm_kernel(const DecGemmArgs g) {
+__global__ __launch_bounds__(512) void decode_gemm_kernel(const DecGemmArgs g_in) {
   constexpr bool W8 = WQ == 1, W4 = WQ == 2;       // (grids are shaped to <= one workgroup per CU: the activation batches may take the registers of two)
+  // row blocks (gridDim.z > 1, no K split): block z multiplies rows 16 MT z .. of the batch -- a narrow output at 64 rows then spreads over twice the CUs, each pulling
+  // half the activation rows through its fill path (decode_gemm_plan)
+  DecGemmArgs g = g_in;
+  if (gridDim.z > 1) {
+    const int r0 = (int)blockIdx.z * MT * 16;
+    g.A += (size_t)r0 * g.lda;
+    if (g.add) g.add += (size_t)r0 * g.ld_add;
+    if (g.out_f32) g.out_f32 += (size_t)r0 * g.ld_out_f32;
+    if (g.out_lo) g.out_lo += (size_t)r0 * g.ld_out_lo;
+    g.M = min(MT * 16, g.M - r0);
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fgrp = lane >> 4;
@@ -317,9 +328,9 @@ __global__ __launch_bounds__(256) void decode_gemm_prefetch_kernel(const unsigne
 }
 
 template <int MT, int NT>
-void launch_inst(const DecGemmArgs& g, int splits, hipStream_t s) {
+void launch_inst(const DecGemmArgs& g, int splits, hipStream_t s, int row_blocks = 1) {
   const size_t lds = (size_t)DW * MT * NT * 1024 + (size_t)DW * MT * 16 * 8;
-  const dim3 grid(g.N / (16 * NT), splits);
+  const dim3 grid(g.N / (16 * NT), splits, row_blocks);
   auto go = [&](auto kern) {
     if (lds > 48 * 1024) {
       static PerDeviceOnce once;        // (per instantiation of this lambda: one kernel each)
@@ -345,7 +356,7 @@ bool decode_gemm_supported(const DecGemmArgs& g) {
 // split costs a hand-over (partial tiles written through, a ticket, the last arriver re-reading `splits` tiles): the plan minimises
 //   bytes per workgroup / RATE + (splits > 1 ? HAND + splits * PER_SPLIT : 0)
 // over NT in {1, 2} and the split counts that keep granules x splits within one round; constants from tools/probes/decode_split_sweep.sh.
-void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits) {
+void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits, int* row_blocks) {
   const int cus = gemm_env_cus();
   const int force_nt = gemm_env_decode_nt(), force_ks = gemm_env_decode_ks();          // tuning hooks, re-read at session creation like every other switch
   const int pm = g.plan_M > g.M ? g.plan_M : g.M;
@@ -372,15 +383,30 @@ void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits) {
       if (cost < best_cost) { best_cost = cost; best_nt = NT; best_ks = sp; }
     }
   }
+  int best_rb = 1;
+  if (mt == 4 && gemm_env_decode_rb() != 1) {                       // 33 .. 64 rows: two blocks of 32 rows, no K split -- (16 NT + 32) K bytes per workgroup and no hand-over
+    for (int NT = 1; NT <= 2; ++NT) {
+      if (g.N % (16 * NT) != 0 || (force_nt && NT != force_nt) || (force_ks && force_ks != 1)) continue;
+      const int granules = g.N / (16 * NT);
+      if (granules * 2 > cus) continue;
+      const double cost = (double)(16 * NT + 32) * g.K * 2 / 45e3;
+      if (cost < best_cost || gemm_env_decode_rb() == 2) { best_cost = cost; best_nt = NT; best_ks = 1; best_rb = 2; }
+    }
+  }
   *nt = best_nt; *splits = best_ks;
+  if (row_blocks) *row_blocks = best_rb;
 }
 
 void launch_decode_gemm(const DecGemmArgs& g, hipStream_t s) {
   ASR_REQUIRE(decode_gemm_supported(g), "decode_gemm: unsupported shape (M = %d, N = %d, K = %d)", g.M, g.N, g.K);
   ASR_REQUIRE(g.A && (g.W || g.W8 || g.W4) && (g.out_f32 || g.out_lo), "decode_gemm: null operand");
-  int nt = 1, splits = 1;
-  decode_gemm_plan(g, &nt, &splits);
+  int nt = 1, splits = 1, rb = 1;
+  decode_gemm_plan(g, &nt, &splits, &rb);
   ASR_REQUIRE(g.N % (16 * nt) == 0, "decode_gemm: N = %d", g.N);
+  if (rb == 2 && g.M > 32) {                                        // two 32-row blocks side by side (splits == 1)
+    if (nt == 2) launch_inst<2, 2>(g, 1, s, 2); else launch_inst<2, 1>(g, 1, s, 2);
+    return;
+  }
   const int mt = g.M <= 16 ? 1 : g.M <= 32 ? 2 : 4;
   if (nt == 2) { if (mt == 1) launch_inst<1, 2>(g, splits, s); else if (mt == 2) launch_inst<2, 2>(g, splits, s); else launch_inst<4, 2>(g, splits, s); }
   else if (mt == 1) launch_inst<1, 1>(g, splits, s);
@@ -395,7 +421,7 @@ void launch_colsum_bf16(const bf16_t* W, int ldw, int N, int K, float* c, hipStr
 
 void launch_decode_gemm_prefetch(const DecGemmArgs& g, hipStream_t s) {
   int nt = 1, splits = 1;
-  decode_gemm_plan(g, &nt, &splits);
+  decode_gemm_plan(g, &nt, &splits, nullptr);
   const unsigned char* w = g.W8 ? g.W8 : reinterpret_cast<const unsigned char*>(g.W);
   const int elem = g.W8 ? 1 : 2;
   hipLaunchKernelGGL(decode_gemm_prefetch_kernel, dim3(g.N / (16 * nt), splits), dim3(256), 0, s, w, g.ldw * elem, elem, 16 * nt, g.K >> 5, (unsigned*)nullptr);

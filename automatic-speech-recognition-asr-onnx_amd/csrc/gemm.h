@@ -86,6 +86,7 @@ int gemm_env_decode_nt();       // ASR_DECODE_NT, ASR_DECODE_KS (0 = the cost mo
 int gemm_env_decode_ks();
 bool gemm_env_decode_attn_wave();
 bool gemm_env_decode_attn_online();
+int gemm_env_decode_rb();
 int gemm_env_cus();
 const char* gemm_last_kernel(); // kernel family of this thread's last launch_gemm_bf16 ("t288w", "t144", "pipe", "skinny", ...): test hook
 bool gemm_skinny144_enabled();
@@ -112,7 +113,7 @@ struct DecGemmArgs {
   unsigned long long* dbg_clk = nullptr;             // tuning (tools/probes/decode_gemm_clock.py): thread 0 of the first and of the last workgroup stamp wall_clock64() at five points ([2][5])
 };
 bool decode_gemm_supported(const DecGemmArgs& g);
-void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits);
+void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits, int* row_blocks = nullptr);
 void launch_decode_gemm(const DecGemmArgs& g, hipStream_t s);
 // touch the weight bytes of a coming launch_decode_gemm(g) from the workgroups (hence XCDs) that will stream them; for a side branch of the decode graph
 void launch_decode_gemm_prefetch(const DecGemmArgs& g, hipStream_t s);

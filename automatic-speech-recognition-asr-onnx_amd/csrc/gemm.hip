@@ -29,6 +29,7 @@ struct GemmEnv {
   int skinny_splitk = -1, tall_min = 16, skinny_max_plain = 32;
   int decode_nt = 0, decode_ks = 0;      // ASR_DECODE_NT / ASR_DECODE_KS: force the decode GEMM's column granule / split count (0 = the cost model)
   bool decode_attn_wave = true;          // ASR_DECODE_ATTN_WAVE=0: single-token self-attention on the general kernel
+  int decode_rb = 0;                     // ASR_DECODE_RB: 0 = the plan decides, 1 = never split 33 .. 64 rows into two row blocks, 2 = always where it fits
   int skinny_nt = 2;                     // ASR_SKINNY_NT=1: one 16-column granule per workgroup of the skinny GEMM even where the output is wider than the chip
   bool decode_attn_online = true;        // ASR_DECODE_ATTN_ONLINE=0: single-token cross-attention on the general (two-pass) kernel
   int n_cus = 0;                         // CUs of the current device (the decode GEMM's one-round grid bound)
@@ -63,7 +64,7 @@ void gemm_reload_env() {
   e.big = env_flag("ASR_GEMM_BIG", true); e.pp = env_flag("ASR_GEMM_PP", true); e.splitk = env_flag("ASR_GEMM_SPLITK", true); e.deep = env_flag("ASR_GEMM_DEEP", true);
   e.skinny144 = getenv("ASR_SKINNY_M144") && getenv("ASR_SKINNY_M144")[0] == '1';
   e.skinny_splitk = env_int("ASR_SKINNY_SPLITK", -1); e.tall_min = env_int("ASR_GEMM_TALL_MIN", 16);
-  e.skinny_max_plain = env_int("ASR_SKINNY_MAX_M", 32); e.skinny_nt = env_int("ASR_SKINNY_NT", 2);
+  e.skinny_max_plain = env_int("ASR_SKINNY_MAX_M", 32); e.skinny_nt = env_int("ASR_SKINNY_NT", 2); e.decode_rb = env_int("ASR_DECODE_RB", 0);
   e.decode_nt = env_int("ASR_DECODE_NT", 0); e.decode_ks = env_int("ASR_DECODE_KS", 0); e.decode_attn_wave = env_flag("ASR_DECODE_ATTN_WAVE", true); e.decode_attn_online = env_flag("ASR_DECODE_ATTN_ONLINE", true);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&e.n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || e.n_cus <= 0) e.n_cus = 256;
@@ -77,6 +78,7 @@ int gemm_env_decode_nt() { return genv().decode_nt; }
 int gemm_env_decode_ks() { return genv().decode_ks; }
 bool gemm_env_decode_attn_wave() { return genv().decode_attn_wave; }
 bool gemm_env_decode_attn_online() { return genv().decode_attn_online; }
+int gemm_env_decode_rb() { return genv().decode_rb; }
 int gemm_env_cus() { return genv().n_cus; }
 
 namespace {

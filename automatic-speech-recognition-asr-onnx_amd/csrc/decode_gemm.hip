@@ -384,12 +384,13 @@ void decode_gemm_plan(const DecGemmArgs& g, int* nt, int* splits, int* row_block
     }
   }
   int best_rb = 1;
-  if (mt == 4 && gemm_env_decode_rb() != 1) {                       // 33 .. 64 rows: two blocks of 32 rows, no K split -- (16 NT + 32) K bytes per workgroup and no hand-over
+  if (mt >= 2 && gemm_env_decode_rb() != 1) {                       // 17 .. 64 rows: two blocks of 16 / 32 rows, no K split -- (16 NT + rows / 2) K bytes per workgroup and no hand-over
+    const int half = ws_rows / 2;                                   // (measured, Whisper-large-v3 decode: 64 sequences 146.4 -> 139.6 ms per 64 x 8 s batch, profiles/r06_decode_gemm_row_blocks.txt)
     for (int NT = 1; NT <= 2; ++NT) {
       if (g.N % (16 * NT) != 0 || (force_nt && NT != force_nt) || (force_ks && force_ks != 1)) continue;
       const int granules = g.N / (16 * NT);
       if (granules * 2 > cus) continue;
-      const double cost = (double)(16 * NT + 32) * g.K * 2 / 45e3;
+      const double cost = (double)(16 * NT + half) * g.K * 2 / 45e3;
       if (cost < best_cost || gemm_env_decode_rb() == 2) { best_cost = cost; best_nt = NT; best_ks = 1; best_rb = 2; }
     }
   }
@@ -405,6 +406,10 @@ void launch_decode_gemm(const DecGemmArgs& g, hipStream_t s) {
   ASR_REQUIRE(g.N % (16 * nt) == 0, "decode_gemm: N = %d", g.N);
   if (rb == 2 && g.M > 32) {                                        // two 32-row blocks side by side (splits == 1)
     if (nt == 2) launch_inst<2, 2>(g, 1, s, 2); else launch_inst<2, 1>(g, 1, s, 2);
+    return;
+  }
+  if (rb == 2 && g.M > 16) {                                        // two 16-row blocks
+    if (nt == 2) launch_inst<1, 2>(g, 1, s, 2); else launch_inst<1, 1>(g, 1, s, 2);
     return;
   }
   const int mt = g.M <= 16 ? 1 : g.M <= 32 ? 2 : 4;

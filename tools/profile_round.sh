@@ -9,6 +9,11 @@ OUT=$R/gpurun_out/prof
 rm -rf $OUT
 mkdir -p $OUT
 cd $R
+# the headline's kernel table FIRST, copied over the committed one on this box: the bench line below cites profiles/<round>_sensevoice_b64_kernel_stats.csv and
+# compares its own HIP-event launch time with that table's average -- both are then this box's
+ROUND=${ROUND:-r06}
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --profile-steps 1 > $OUT/stats.log 2>&1
+for f in $(find $OUT/stats -name "*kernel_stats.csv" | head -1); do cp $f profiles/${ROUND}_sensevoice_b64_kernel_stats.csv; done
 python bench.py --steps 20 --warmup 5 > $OUT/bench_sensevoice.json 2> $OUT/bench_sensevoice.err
 ASR_SANM_BLOCK=0 python bench.py --steps 100 --warmup 5 --no-extras --no-cpu-baseline > $OUT/bench_sensevoice_4launch.json 2> $OUT/bench_sensevoice_4launch.err
 python bench.py --workload paraformer --steps 10 > $OUT/bench_paraformer.json 2> $OUT/bench_paraformer.err
@@ -43,7 +48,6 @@ python bench.py --workload qwen --mxfp4 --steps 6 --warmup 2 --no-cpu-baseline >
 for v in 0 1 2 3 4 8; do echo "ASR_FBANK_DBG=$v: $(ASR_FBANK_DBG=$v python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms per step; fbank', d['kernels']['fbank']['ms_per_step'])")"; done > $OUT/fbank_ablations_final.txt 2>&1
 python bench.py --workload mixed --beam 5 --steps 6 --warmup 1 > $OUT/bench_mixed_beam5.json 2> $OUT/bench_mixed_beam5.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --profile-steps 1 > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extras > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- python $R/bench.py --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extras > $OUT/pmc_sq.log 2>&1

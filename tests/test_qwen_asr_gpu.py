@@ -570,6 +570,30 @@ def test_0p6b_bf16_batch64_vs_golden_and_oracle():
         assert np.abs(got[1][t] - r["logits"][t]).max() < 0.03 * scale + 0.1
 
 
+def test_0p6b_two_granule_gate_up_gemm_agrees_with_one_granule(monkeypatch):
+    """Round 6: at 64 sequences the gate|up GEMM (6144 columns = 384 granules, wider than the chip) takes TWO 16-column granules per workgroup (the default, what the
+    test above runs); ASR_SKINNY_NT=1 is the one-granule form it replaced. Same batch, the prefill (identical: it does not take that kernel) + ONE decode step fed with the prefill's picks: its logits differ by summation order only."""
+    g = load_golden("qwen_asr_0p6b")
+    cfg, ck = qwen_setup(g)
+    c0 = [c for _, c in golden_cases(g)][0]
+    head, tail, suffix = g["head_ids"].tolist(), g["tail_ids"].tolist(), g["suffix_ids"].tolist()
+    B = 64
+    audios = [unit_audio(8300 + i, 128000) for i in range(B)]
+    pre = [head + c0["query_ids"].tolist() + suffix] * B
+    post = [tail + c0["language_tail_ids"].tolist()] * B
+    out = {}
+    for nt in ("2", "1"):
+        monkeypatch.setenv("ASR_SKINNY_NT", nt)
+        sess = sub("engine").QwenAsrSession.from_checkpoint(cfg, ck, precision=BF16)
+        out[nt] = _stepwise(sess, audios, pre, post, 2)[0]
+        del sess
+    assert np.array_equal(out["2"][:, 0], out["1"][:, 0])
+    scale = max(float(np.abs(out["1"]).max()), 1.0)
+    diff = float(np.abs(out["2"] - out["1"]).max())
+    print(f"qwen 0.6b, 64 sequences: two-granule vs one-granule gate|up GEMM, logits differ by {diff:.4f} (|max| {scale:.1f})")
+    assert diff < 0.02 * scale + 0.05
+
+
 def test_0p6b_bf16_beam5_batch64_vs_oracle_rule():
     """The Qwen3-ASR half of BASELINE.json configs[4] as written: 0.6B dimensions, bf16, beam = 5, 64 x 8 s in one batch = 320 hypothesis
     rows per step (tiled decode GEMMs at 320 rows, the ancestry-table attention over 8 kv heads, device-side top-k over 151936 columns).

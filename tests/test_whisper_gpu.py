@@ -391,3 +391,41 @@ def test_twin_sequences_in_one_batch_get_identical_logits(prec):
     assert np.array_equal(ids[0], ids[35]) and np.array_equal(ids[7], ids[33])
 
 
+
+
+@pytest.mark.parametrize("B", [20, 40])
+def test_decode_step_forms_of_round_6_agree_with_the_forms_they_replaced(monkeypatch, B):
+    """Round 6 changed HOW three pieces of a decode step run, not what they compute: the decode GEMM multiplies a narrow output as two row blocks side by side instead
+    of one block or a K split (ASR_DECODE_RB=1: off; 20 sequences = 16 + 4 rows, 40 = 32 + 8), the single-token cross-attention runs in one pass with a running
+    soft-max (ASR_DECODE_ATTN_ONLINE=0: two passes). Both sessions see the same ragged batch over a prefill and 6 teacher-forced steps: the logits may differ by
+    summation order only (a few bf16 ulps of an O(100) logit), and the new forms are what every other test of this file runs on."""
+    name = "whisper_d256_test"
+    cfg, ck, sup, beg = whisper_setup(name)
+    eng = sub("engine")
+    audios = [unit_audio(1500 + i, (25600, 64000, 128000)[i % 3]) for i in range(B)]
+    prompt = [cfg.sot_id, cfg.first_language_id, cfg.transcribe_id, cfg.no_timestamps_id]
+    prompts = np.array([prompt] * B, np.int32)
+    out = {}
+    for key, env in (("new", {}), ("old", {"ASR_DECODE_RB": "1", "ASR_DECODE_ATTN_ONLINE": "0"})):
+        for k in ("ASR_DECODE_RB", "ASR_DECODE_ATTN_ONLINE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sess = eng.WhisperSession.from_checkpoint(cfg, ck, precision=BF16, suppress_tokens=sup, begin_suppress_tokens=beg)
+        sess.encode(audios)
+        nxt, logits = sess.prefill(prompts)
+        steps, forced = [logits], out["new"][1] if key == "old" else []
+        for s in range(6):
+            ids = np.ascontiguousarray(forced[s]) if key == "old" else nxt
+            if key == "new":
+                forced.append(nxt.copy())
+            nxt, logits = sess.decode(ids.reshape(B, 1), want_logits=True)
+            steps.append(logits)
+        out[key] = (np.stack(steps, 1)[..., :cfg.vocab], forced)
+        del sess
+    a, b = out["new"][0], out["old"][0]
+    scale = float(np.abs(b).max())
+    diff = float(np.abs(a - b).max())
+    print(f"whisper_d256, {B} sequences: new vs old decode-step forms differ by {diff:.4f} on logits of |max| {scale:.1f}")
+    assert np.isfinite(a).all() and diff < 1e-2 * scale
+    assert (a.argmax(-1) == b.argmax(-1)).mean() > 0.97
